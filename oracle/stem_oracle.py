@@ -1,0 +1,382 @@
+"""ctypes binding + model-level composition for the CPU ORACLE (test infrastructure).
+
+NOT the product: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg import this module.  The arithmetic lives in oracle/stem_oracle.c (plain C);
+this file only marshals numpy arrays and chains the ops in the order the
+reference's modules do (citations are paths under /root/reference):
+
+* g_a / g_s of JointAutoregressiveHierarchicalPriors  compressai/models/priors.py:421-439,686-694,397-402
+* SpatioTemporalPriorModel(_Res).forward              compressai/models/spatiotemporalpriors.py:561-585,845-868
+* EMLoss                                              utils.py:18-27
+
+Layout is the reference's NCHW fp32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+EB_NPARAM = 58
+SCALE_BOUND = 0.11      # GaussianConditional scale_bound (entropy_models.py:484)
+LIK_BOUND = 1e-9        # EntropyModel likelihood_bound (entropy_models.py:79)
+LRELU = 0.01            # nn.LeakyReLU default slope
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libstem_oracle.so")
+    src = os.path.join(_HERE, "stem_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "libstem_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_rate_bpp.restype = C.c_double
+        _LIB.orc_eb_aux_loss.restype = C.c_float
+        _LIB.orc_rans_encode.restype = C.c_long
+    return _LIB
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ----------------------------------------------------------------------------- ops
+def conv2d_fwd(x, w, b, stride, pad):
+    x, w = _f(x), _f(w)
+    b = None if b is None else _f(b)
+    N, Cc, H, W = x.shape
+    K, _, R, S = w.shape
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+    y = np.empty((N, K, Ho, Wo), np.float32)
+    lib().orc_conv2d_fwd(_p(x), _p(w), _p(b), _p(y), N, Cc, H, W, K, R, S, stride, pad)
+    return y
+
+
+def conv2d_bwd(x, w, dy, stride, pad, need_dx=True):
+    x, w, dy = _f(x), _f(w), _f(dy)
+    N, Cc, H, W = x.shape
+    K, _, R, S = w.shape
+    dx = np.empty_like(x) if need_dx else None
+    if need_dx:
+        lib().orc_conv2d_dgrad(_p(dy), _p(w), _p(dx), N, Cc, H, W, K, R, S, stride, pad)
+    dw, db = np.empty_like(w), np.empty((K,), np.float32)
+    lib().orc_conv2d_wgrad(_p(x), _p(dy), _p(dw), _p(db), N, Cc, H, W, K, R, S, stride, pad)
+    return dx, dw, db
+
+
+def deconv2d_fwd(x, w, b, stride, pad, opad):
+    x, w = _f(x), _f(w)
+    b = None if b is None else _f(b)
+    N, Cc, H, W = x.shape
+    _, K, R, S = w.shape
+    Ho, Wo = (H - 1) * stride - 2 * pad + R + opad, (W - 1) * stride - 2 * pad + S + opad
+    y = np.empty((N, K, Ho, Wo), np.float32)
+    lib().orc_deconv2d_fwd(_p(x), _p(w), _p(b), _p(y), N, Cc, H, W, K, R, S, stride, pad, opad)
+    return y
+
+
+def deconv2d_bwd(x, w, dy, stride, pad, opad, need_dx=True):
+    x, w, dy = _f(x), _f(w), _f(dy)
+    N, Cc, H, W = x.shape
+    _, K, R, S = w.shape
+    dx = np.empty_like(x) if need_dx else None
+    if need_dx:
+        lib().orc_deconv2d_dgrad(_p(dy), _p(w), _p(dx), N, Cc, H, W, K, R, S, stride, pad, opad)
+    dw, db = np.empty_like(w), np.empty((K,), np.float32)
+    lib().orc_deconv2d_wgrad(_p(x), _p(dy), _p(dw), _p(db), N, Cc, H, W, K, R, S, stride, pad, opad)
+    return dx, dw, db
+
+
+def lrelu_fwd(x, slope=LRELU):
+    x = _f(x)
+    y = np.empty_like(x)
+    lib().orc_lrelu_fwd(_p(x), _p(y), C.c_size_t(x.size), C.c_float(slope))
+    return y
+
+
+def lrelu_bwd(y, dy, slope=LRELU):
+    y, dy = _f(y), _f(dy)
+    dx = np.empty_like(y)
+    lib().orc_lrelu_bwd(_p(y), _p(dy), _p(dx), C.c_size_t(y.size), C.c_float(slope))
+    return dx
+
+
+def gdn_fwd(x, beta_p, gamma_p, inverse=False, beta_min=1e-6):
+    x, beta_p, gamma_p = _f(x), _f(beta_p), _f(gamma_p)
+    N, Cc, H, W = x.shape
+    y = np.empty_like(x)
+    lib().orc_gdn_fwd(_p(x), _p(beta_p), _p(gamma_p), _p(y), N, Cc, H, W, int(inverse), C.c_float(beta_min))
+    return y
+
+
+def eb_pack_params(sd, prefix="entropy_bottleneck."):
+    """[C,58] pack in the order stem_oracle.c documents (matrix, bias, factor per layer)."""
+    cols = []
+    for i in range(5):
+        cols.append(np.asarray(sd[f"{prefix}_matrix{i}"], np.float32).reshape(len(sd[f"{prefix}_matrix{i}"]), -1))
+        cols.append(np.asarray(sd[f"{prefix}_bias{i}"], np.float32).reshape(cols[-1].shape[0], -1))
+        if i < 4:
+            cols.append(np.asarray(sd[f"{prefix}_factor{i}"], np.float32).reshape(cols[-1].shape[0], -1))
+    out = np.concatenate(cols, axis=1)
+    assert out.shape[1] == EB_NPARAM
+    return np.ascontiguousarray(out)
+
+
+def eb_unpack_grads(dpack, prefix="entropy_bottleneck."):
+    shapes = [(3, 1), (3, 1), (3, 1), (3, 3), (3, 1), (3, 1), (3, 3), (3, 1), (3, 1), (3, 3), (3, 1), (3, 1), (1, 3), (1, 1)]
+    names = []
+    for i in range(5):
+        names += [f"_matrix{i}", f"_bias{i}"] + ([f"_factor{i}"] if i < 4 else [])
+    out, o = {}, 0
+    for n, s in zip(names, shapes):
+        k = s[0] * s[1]
+        out[prefix + n] = dpack[:, o:o + k].reshape(-1, *s).copy()
+        o += k
+    return out
+
+
+def eb_likelihood_fwd(v_cl, pack):
+    """v_cl: [C, L] channel-major values (already noised/rounded)."""
+    v_cl, pack = _f(v_cl), _f(pack)
+    lik = np.empty_like(v_cl)
+    lib().orc_eb_likelihood_fwd(_p(v_cl), _p(pack), _p(lik), v_cl.shape[0], C.c_size_t(v_cl.shape[1]), C.c_float(LIK_BOUND))
+    return lik
+
+
+def eb_likelihood_bwd(v_cl, pack, dlik_cl):
+    v_cl, pack, dlik_cl = _f(v_cl), _f(pack), _f(dlik_cl)
+    dv, dp = np.empty_like(v_cl), np.empty_like(pack)
+    lib().orc_eb_likelihood_bwd(_p(v_cl), _p(pack), _p(dlik_cl), _p(dv), _p(dp), v_cl.shape[0],
+                                C.c_size_t(v_cl.shape[1]), C.c_float(LIK_BOUND))
+    return dv, dp
+
+
+def eb_aux_loss(quantiles, pack, target):
+    q, pack, t = _f(quantiles).reshape(-1, 3), _f(pack), _f(target)
+    dq = np.empty_like(q)
+    loss = lib().orc_eb_aux_loss(_p(q), _p(pack), _p(t), _p(dq), q.shape[0])
+    return float(loss), dq.reshape(-1, 1, 3)
+
+
+def nchw_to_cl(x):
+    """EntropyBottleneck.forward's permute(1,2,3,0).reshape(C,1,-1) (entropy_models.py:426-428) -> [C, H*W*N]"""
+    return np.ascontiguousarray(np.transpose(x, (1, 2, 3, 0)).reshape(x.shape[1], -1))
+
+
+def cl_to_nchw(v, shape):
+    N, Cc, H, W = shape
+    return np.ascontiguousarray(np.transpose(v.reshape(Cc, H, W, N), (3, 0, 1, 2)))
+
+
+def gc_likelihood_fwd(y, scales, means):
+    y, scales = _f(y), _f(scales)
+    means = None if means is None else _f(means)
+    lik = np.empty_like(y)
+    lib().orc_gc_likelihood_fwd(_p(y), _p(scales), _p(means), _p(lik), C.c_size_t(y.size), C.c_float(SCALE_BOUND), C.c_float(LIK_BOUND))
+    return lik
+
+
+def gc_likelihood_bwd(y, scales, means, dlik):
+    y, scales, means, dlik = _f(y), _f(scales), _f(means), _f(dlik)
+    dy, ds, dm = np.empty_like(y), np.empty_like(y), np.empty_like(y)
+    lib().orc_gc_likelihood_bwd(_p(y), _p(scales), _p(means), _p(dlik), _p(dy), _p(ds), _p(dm), C.c_size_t(y.size),
+                                C.c_float(SCALE_BOUND), C.c_float(LIK_BOUND))
+    return dy, ds, dm
+
+
+def quantize_dequantize(x, means=None):
+    x = _f(x)
+    means = None if means is None else _f(np.broadcast_to(means, x.shape))
+    out = np.empty_like(x)
+    lib().orc_quantize_dequantize(_p(x), _p(means), _p(out), C.c_size_t(x.size))
+    return out
+
+
+def quantize_symbols(x, means=None):
+    x = _f(x)
+    means = None if means is None else _f(np.broadcast_to(means, x.shape))
+    out = np.empty(x.shape, np.int32)
+    lib().orc_quantize_symbols(_p(x), _p(means), _p(out), C.c_size_t(x.size))
+    return out
+
+
+def build_indexes(scales, table):
+    scales, table = _f(scales), _f(table)
+    idx = np.empty(scales.shape, np.int32)
+    lib().orc_build_indexes(_p(scales), _p(table), len(table), _p(idx), C.c_size_t(scales.size), C.c_float(SCALE_BOUND))
+    return idx
+
+
+def rate_bpp(lik, num_pixels):
+    lik = _f(lik)
+    return float(lib().orc_rate_bpp(_p(lik), C.c_size_t(lik.size), C.c_double(num_pixels)))
+
+
+def pmf_to_quantized_cdf(pmf, precision=16):
+    pmf = _f(pmf)
+    cdf = np.empty(len(pmf) + 1, np.uint32)
+    rc = lib().orc_pmf_to_quantized_cdf(_p(pmf), len(pmf), precision, _p(cdf))
+    if rc != 0:
+        raise ValueError(f"pmf_to_quantized_cdf failed ({rc})")
+    return cdf
+
+
+def rans_encode(symbols, indexes, cdfs, sizes, offsets) -> bytes:
+    symbols, indexes = np.ascontiguousarray(symbols, np.int32), np.ascontiguousarray(indexes, np.int32)
+    cdfs, sizes, offsets = (np.ascontiguousarray(a, np.int32) for a in (cdfs, sizes, offsets))
+    cap = 8 * symbols.size + 64
+    out = np.empty(cap, np.uint8)
+    n = lib().orc_rans_encode(_p(symbols), _p(indexes), C.c_size_t(symbols.size), _p(cdfs), cdfs.shape[1], _p(sizes),
+                              _p(offsets), _p(out), C.c_size_t(cap))
+    if n < 0:
+        raise RuntimeError("rans_encode: output buffer too small")
+    return out[:n].tobytes()
+
+
+def rans_decode(stream: bytes, indexes, cdfs, sizes, offsets):
+    buf = np.frombuffer(stream, np.uint8).copy()
+    indexes = np.ascontiguousarray(indexes, np.int32)
+    cdfs, sizes, offsets = (np.ascontiguousarray(a, np.int32) for a in (cdfs, sizes, offsets))
+    out = np.empty(indexes.shape, np.int32)
+    lib().orc_rans_decode(_p(buf), C.c_size_t(buf.size), _p(indexes), C.c_size_t(indexes.size), _p(cdfs), cdfs.shape[1],
+                          _p(sizes), _p(offsets), _p(out))
+    return out
+
+
+# ----------------------------------------------------------------------------- model composition
+def g_a(sd, x, prefix="g_a."):
+    """priors.py:421-429: 4x conv5x5 s2 with GDN after the first three."""
+    h = x
+    for i in range(4):
+        h = conv2d_fwd(h, sd[f"{prefix}{2 * i}.weight"], sd[f"{prefix}{2 * i}.bias"], 2, 2)
+        if i < 3:
+            h = gdn_fwd(h, sd[f"{prefix}{2 * i + 1}.beta"], sd[f"{prefix}{2 * i + 1}.gamma"], inverse=False)
+    return h
+
+
+def g_s(sd, y, prefix="g_s."):
+    """priors.py:431-439 + getX clamp (priors.py:397-402)."""
+    h = y
+    for i in range(4):
+        h = deconv2d_fwd(h, sd[f"{prefix}{2 * i}.weight"], sd[f"{prefix}{2 * i}.bias"], 2, 2, 1)
+        if i < 3:
+            h = gdn_fwd(h, sd[f"{prefix}{2 * i + 1}.beta"], sd[f"{prefix}{2 * i + 1}.gamma"], inverse=True)
+    return np.clip(h, 0.0, 1.0)
+
+
+def masked_weight(w):
+    """MaskedConv2d type-A mask (layers/layers.py:39-42)."""
+    m = np.ones_like(w)
+    _, _, h, ww = w.shape
+    m[:, :, h // 2, ww // 2:] = 0
+    m[:, :, h // 2 + 1:] = 0
+    return w * m
+
+
+def stem_forward(sd, y_cur, y_cond, residual: bool, training: bool, noise=None, keep=None):
+    """SpatioTemporalPriorModel(_Res).forward.  `noise` = dict with 'z', 'q', 'lik' arrays (training).
+    Returns dict(y_hat, lik_y, lik_z, scales, means); `keep` (dict) receives activations for backward."""
+    k = {} if keep is None else keep
+    sd = {n: np.asarray(v, np.float32) for n, v in sd.items() if np.asarray(v).dtype.kind == "f"}
+    cat = np.concatenate([y_cur, y_cond], 1)
+    k["he_in"] = cat
+    k["he0"] = lrelu_fwd(conv2d_fwd(cat, sd["HE.0.weight"], sd["HE.0.bias"], 1, 1))
+    k["he2"] = lrelu_fwd(conv2d_fwd(k["he0"], sd["HE.2.weight"], sd["HE.2.bias"], 2, 2))
+    z = conv2d_fwd(k["he2"], sd["HE.4.weight"], sd["HE.4.bias"], 2, 2)
+    pack = eb_pack_params(sd)
+    med = sd["entropy_bottleneck.quantiles"][:, 0, 1]
+    zc = nchw_to_cl(z)
+    if training:
+        zq = zc + nchw_to_cl(noise["z"])
+    else:
+        zq = quantize_dequantize(zc, med[:, None])
+    k["z_cl"], k["pack"] = zq, pack
+    lik_z = cl_to_nchw(eb_likelihood_fwd(zq, pack), z.shape)
+    z_hat = cl_to_nchw(zq, z.shape)
+    k["z_hat"] = z_hat
+    k["hd0"] = lrelu_fwd(deconv2d_fwd(z_hat, sd["HD.0.weight"], sd["HD.0.bias"], 2, 2, 1))
+    k["hd2"] = lrelu_fwd(deconv2d_fwd(k["hd0"], sd["HD.2.weight"], sd["HD.2.bias"], 2, 2, 1))
+    hp = conv2d_fwd(k["hd2"], sd["HD.4.weight"], sd["HD.4.bias"], 1, 1)
+    k["tp_in"] = y_cond
+    k["tp0"] = lrelu_fwd(conv2d_fwd(y_cond, sd["TPM.0.weight"], sd["TPM.0.bias"], 1, 2))
+    k["tp2"] = lrelu_fwd(conv2d_fwd(k["tp0"], sd["TPM.2.weight"], sd["TPM.2.bias"], 1, 2))
+    tp = conv2d_fwd(k["tp2"], sd["TPM.4.weight"], sd["TPM.4.bias"], 1, 2)
+    target = (y_cur - y_cond) if residual else y_cur
+    if training:
+        t_hat = target + noise["q"]
+    else:
+        t_hat = quantize_dequantize(target)
+    k["t_hat"] = t_hat
+    ctx = conv2d_fwd(t_hat, masked_weight(sd["context_prediction.weight"]), sd["context_prediction.bias"], 1, 2)
+    k["epm_in"] = np.concatenate([tp, hp, ctx], 1)
+    k["e0"] = lrelu_fwd(conv2d_fwd(k["epm_in"], sd["EPM.0.weight"], sd["EPM.0.bias"], 1, 0))
+    k["e2"] = lrelu_fwd(conv2d_fwd(k["e0"], sd["EPM.2.weight"], sd["EPM.2.bias"], 1, 0))
+    gp = conv2d_fwd(k["e2"], sd["EPM.4.weight"], sd["EPM.4.bias"], 1, 0)
+    M = gp.shape[1] // 2
+    scales, means = np.ascontiguousarray(gp[:, :M]), np.ascontiguousarray(gp[:, M:])
+    if training:
+        out = target + noise["lik"]
+    else:
+        out = quantize_dequantize(target, means)
+    k["gc_in"], k["scales"], k["means"] = out, scales, means
+    lik_y = gc_likelihood_fwd(out, scales, means)
+    y_hat = (t_hat + y_cond) if residual else t_hat
+    return {"y_hat": y_hat, "lik_y": lik_y, "lik_z": lik_z, "scales": scales, "means": means}
+
+
+def stem_backward(sd, keep, lik_y, lik_z, num_pixels):
+    """Gradient of EMLoss = (sum log lik_y + sum log lik_z) / (-ln2 * num_pixels) wrt every STEM parameter
+    (torch autograd of spatiotemporalpriors.py:845-868 with y_cur / y_cond detached as in stem/trainSTEM.py:208)."""
+    sd = {n: np.asarray(v, np.float32) for n, v in sd.items() if np.asarray(v).dtype.kind == "f"}
+    k, g = keep, {}
+    c = np.float32(1.0 / (-np.log(2.0) * num_pixels))
+    dlik_y = (c / lik_y).astype(np.float32)
+    dlik_z = (c / lik_z).astype(np.float32)
+    _, dsc, dmu = gc_likelihood_bwd(k["gc_in"], k["scales"], k["means"], dlik_y)
+    dgp = np.concatenate([dsc, dmu], 1)
+    d, g["EPM.4.weight"], g["EPM.4.bias"] = conv2d_bwd(k["e2"], sd["EPM.4.weight"], dgp, 1, 0)
+    d = lrelu_bwd(k["e2"], d)
+    d, g["EPM.2.weight"], g["EPM.2.bias"] = conv2d_bwd(k["e0"], sd["EPM.2.weight"], d, 1, 0)
+    d = lrelu_bwd(k["e0"], d)
+    d, g["EPM.0.weight"], g["EPM.0.bias"] = conv2d_bwd(k["epm_in"], sd["EPM.0.weight"], d, 1, 0)
+    c_tp = c_hp = k["epm_in"].shape[1] // 3
+    dtp, dhp, dctx = d[:, :c_tp], d[:, c_tp:c_tp + c_hp], d[:, c_tp + c_hp:]
+    # context_prediction: wgrad of all 25 taps (unmasked), no dgrad needed (input is detached data + noise)
+    _, g["context_prediction.weight"], g["context_prediction.bias"] = conv2d_bwd(
+        k["t_hat"], sd["context_prediction.weight"], np.ascontiguousarray(dctx), 1, 2, need_dx=False)
+    # TPM
+    d, g["TPM.4.weight"], g["TPM.4.bias"] = conv2d_bwd(k["tp2"], sd["TPM.4.weight"], np.ascontiguousarray(dtp), 1, 2)
+    d = lrelu_bwd(k["tp2"], d)
+    d, g["TPM.2.weight"], g["TPM.2.bias"] = conv2d_bwd(k["tp0"], sd["TPM.2.weight"], d, 1, 2)
+    d = lrelu_bwd(k["tp0"], d)
+    _, g["TPM.0.weight"], g["TPM.0.bias"] = conv2d_bwd(k["tp_in"], sd["TPM.0.weight"], d, 1, 2, need_dx=False)
+    # HD
+    d, g["HD.4.weight"], g["HD.4.bias"] = conv2d_bwd(k["hd2"], sd["HD.4.weight"], np.ascontiguousarray(dhp), 1, 1)
+    d = lrelu_bwd(k["hd2"], d)
+    d, g["HD.2.weight"], g["HD.2.bias"] = deconv2d_bwd(k["hd0"], sd["HD.2.weight"], d, 2, 2, 1)
+    d = lrelu_bwd(k["hd0"], d)
+    dz_hat, g["HD.0.weight"], g["HD.0.bias"] = deconv2d_bwd(k["z_hat"], sd["HD.0.weight"], d, 2, 2, 1)
+    # entropy bottleneck
+    dv, dpack = eb_likelihood_bwd(k["z_cl"], k["pack"], nchw_to_cl(dlik_z))
+    g.update(eb_unpack_grads(dpack))
+    dz = dz_hat + cl_to_nchw(dv, dz_hat.shape)
+    # HE
+    d, g["HE.4.weight"], g["HE.4.bias"] = conv2d_bwd(k["he2"], sd["HE.4.weight"], dz, 2, 2)
+    d = lrelu_bwd(k["he2"], d)
+    d, g["HE.2.weight"], g["HE.2.bias"] = conv2d_bwd(k["he0"], sd["HE.2.weight"], d, 2, 2)
+    d = lrelu_bwd(k["he0"], d)
+    _, g["HE.0.weight"], g["HE.0.bias"] = conv2d_bwd(k["he_in"], sd["HE.0.weight"], d, 1, 1, need_dx=False)
+    return g

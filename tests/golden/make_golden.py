@@ -1,0 +1,430 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference).  Follows the import
+recipe of SURVEY.md §8(c): copy the reference's `compressai` package to a
+scratch directory (never into this repo), drop the Windows stubs, compile the
+two pybind11 host extensions from the sources where they lie, stub the two
+torchvision names the STEM modules import but never call, then import it and
+run the reference code on closed-form weights/inputs
+(`spatiotemporalentropymodel_amd.weights`).  Only inputs/outputs are saved.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz
+"""
+import importlib.util
+import os
+import shutil
+import subprocess
+import sys
+import sysconfig
+import tempfile
+import zlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("STEM_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+from spatiotemporalentropymodel_amd.weights import (  # noqa: E402
+    closed_form_fill_,
+    closed_form_input,
+    smooth_frames,
+)
+
+
+def import_reference():
+    scratch = tempfile.mkdtemp(prefix="stem_ref_")
+    shutil.copytree(os.path.join(REF, "compressai"), os.path.join(scratch, "compressai"))
+    pkg = os.path.join(scratch, "compressai")
+    for f in ("ans.py", "_CXX.py"):
+        os.remove(os.path.join(pkg, f))
+    for f in os.listdir(pkg):
+        if f.endswith(".pyd"):
+            os.remove(os.path.join(pkg, f))
+    open(os.path.join(pkg, "models", "gain.py"), "w").close()
+    os.makedirs(os.path.join(scratch, "torchvision"))
+    open(os.path.join(scratch, "torchvision", "__init__.py"), "w").close()
+    with open(os.path.join(scratch, "torchvision", "utils.py"), "w") as f:
+        f.write("def make_grid(*a, **k):\n    raise NotImplementedError\n"
+                "def save_image(*a, **k):\n    raise NotImplementedError\n")
+    ext = sysconfig.get_config_var("EXT_SUFFIX")
+    inc = subprocess.check_output([sys.executable, "-m", "pybind11", "--includes"]).decode().split()
+    base = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", *inc]
+    subprocess.check_call(base + [f"-I{REF}/third_party/ryg_rans", f"-I{pkg}/cpp_exts/rans",
+                                  f"{pkg}/cpp_exts/rans/rans_interface.cpp", "-o", f"{pkg}/ans{ext}"])
+    subprocess.check_call(base + [f"{pkg}/cpp_exts/ops/ops.cpp", "-o", f"{pkg}/_CXX{ext}"])
+    sys.path.insert(0, scratch)
+    spec = importlib.util.spec_from_file_location("ref_root_utils", os.path.join(REF, "utils.py"))
+    root_utils = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(root_utils)
+    return scratch, root_utils
+
+
+class NoiseFeed:
+    """Replaces EntropyModel._get_noise_cached (entropy_models.py:112-120) on one
+    instance: the k-th draw of role R is closed_form_input(f"noise:{R}:{k}")."""
+
+    def __init__(self, role, log):
+        self.role, self.k, self.log = role, 0, log
+
+    def __call__(self, x):
+        name = f"noise:{self.role}:{self.k}"
+        self.k += 1
+        self.log.append((name, tuple(x.shape)))
+        return closed_form_input(name, tuple(x.shape), -0.5, 0.5).to(x.dtype)
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, d):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **d)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(d)} arrays")
+
+
+# ---------------------------------------------------------------------------
+def gen_ops(ref):
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from compressai.entropy_models import EntropyBottleneck, GaussianConditional
+    from compressai.layers import GDN, MaskedConv2d
+    from compressai.ops import LowerBound
+
+    d = {}
+    # --- convolutions (nn.Conv2d as built by models/utils.py:112-120 and spatiotemporalpriors.py:807-838)
+    conv_cases = {
+        "conv_k5s2": (2, 6, 11, 9, 8, 5, 2, 2),
+        "conv_k5s1": (1, 5, 7, 8, 6, 5, 1, 2),
+        "conv_k3s1": (2, 7, 6, 5, 9, 3, 1, 1),
+        "conv_k1s1": (2, 12, 4, 5, 10, 1, 1, 0),
+        "conv_c3": (1, 3, 16, 12, 8, 5, 2, 2),
+    }
+    for name, (N, C, H, W, K, R, st, pd) in conv_cases.items():
+        m = nn.Conv2d(C, K, R, stride=st, padding=pd)
+        closed_form_fill_wrapped(m, name)
+        x = closed_form_input(name + ":x", (N, C, H, W), -1, 1).requires_grad_()
+        y = m(x)
+        dy = closed_form_input(name + ":dy", tuple(y.shape), -1, 1)
+        y.backward(dy)
+        d.update({f"{name}:cfg": np.array([N, C, H, W, K, R, st, pd]), f"{name}:x": t2n(x), f"{name}:w": t2n(m.weight),
+                  f"{name}:b": t2n(m.bias), f"{name}:y": t2n(y), f"{name}:dy": t2n(dy), f"{name}:dx": t2n(x.grad),
+                  f"{name}:dw": t2n(m.weight.grad), f"{name}:db": t2n(m.bias.grad)})
+    # --- transposed convolution (models/utils.py:122-130; spatiotemporalpriors.py:821-826)
+    for name, (N, C, H, W, K, R, st, pd, op) in {"deconv_k5s2": (2, 6, 5, 4, 8, 5, 2, 2, 1),
+                                                 "deconv_c3": (1, 8, 6, 5, 3, 5, 2, 2, 1)}.items():
+        m = nn.ConvTranspose2d(C, K, R, stride=st, padding=pd, output_padding=op)
+        closed_form_fill_wrapped(m, name)
+        x = closed_form_input(name + ":x", (N, C, H, W), -1, 1).requires_grad_()
+        y = m(x)
+        dy = closed_form_input(name + ":dy", tuple(y.shape), -1, 1)
+        y.backward(dy)
+        d.update({f"{name}:cfg": np.array([N, C, H, W, K, R, st, pd, op]), f"{name}:x": t2n(x), f"{name}:w": t2n(m.weight),
+                  f"{name}:b": t2n(m.bias), f"{name}:y": t2n(y), f"{name}:dy": t2n(dy), f"{name}:dx": t2n(x.grad),
+                  f"{name}:dw": t2n(m.weight.grad), f"{name}:db": t2n(m.bias.grad)})
+    # --- MaskedConv2d (layers/layers.py:21-47): forward masks weight.data in place, wgrad is NOT masked
+    name = "masked_k5"
+    m = MaskedConv2d(6, 10, kernel_size=5, padding=2, stride=1)
+    closed_form_fill_wrapped(m, name)
+    w_before = t2n(m.weight).copy()
+    x = closed_form_input(name + ":x", (2, 6, 6, 7), -1, 1).requires_grad_()
+    y = m(x)
+    dy = closed_form_input(name + ":dy", tuple(y.shape), -1, 1)
+    y.backward(dy)
+    d.update({f"{name}:x": t2n(x), f"{name}:w_before": w_before, f"{name}:w_after": t2n(m.weight), f"{name}:mask": t2n(m.mask),
+              f"{name}:b": t2n(m.bias), f"{name}:y": t2n(y), f"{name}:dy": t2n(dy), f"{name}:dx": t2n(x.grad),
+              f"{name}:dw": t2n(m.weight.grad), f"{name}:db": t2n(m.bias.grad)})
+    # --- GDN / IGDN (layers/gdn.py:22-67)
+    for name, inv in (("gdn", False), ("igdn", True)):
+        m = GDN(8, inverse=inv)
+        closed_form_fill_wrapped(m, name)
+        x = closed_form_input(name + ":x", (2, 8, 5, 6), -2, 2).requires_grad_()
+        y = m(x)
+        dy = closed_form_input(name + ":dy", tuple(y.shape), -1, 1)
+        y.backward(dy)
+        d.update({f"{name}:x": t2n(x), f"{name}:beta": t2n(m.beta), f"{name}:gamma": t2n(m.gamma), f"{name}:y": t2n(y),
+                  f"{name}:dy": t2n(dy), f"{name}:dx": t2n(x.grad), f"{name}:dbeta": t2n(m.beta.grad),
+                  f"{name}:dgamma": t2n(m.gamma.grad)})
+    # GDN known-answer at init (compressai_tests/test_layers.py:118-156): y = x / sqrt(1 + .1 x^2)
+    m = GDN(4)
+    x = closed_form_input("gdn_init:x", (1, 4, 3, 3), -2, 2)
+    d["gdn_init:x"], d["gdn_init:y"] = t2n(x), t2n(m(x))
+    d["gdn_init:beta"], d["gdn_init:gamma"] = t2n(m.beta), t2n(m.gamma)
+    # --- LowerBound (ops/bound_ops.py:19-53; compressai_tests/test_ops.py:33-55)
+    lb = LowerBound(0.3)
+    x = closed_form_input("lb:x", (40,), -1, 1).requires_grad_()
+    y = lb(x)
+    dy = closed_form_input("lb:dy", (40,), -1, 1)
+    y.backward(dy)
+    d.update({"lb:x": t2n(x), "lb:y": t2n(y), "lb:dy": t2n(dy), "lb:dx": t2n(x.grad)})
+    # --- EntropyBottleneck (entropy_models.py:282-470)
+    eb = EntropyBottleneck(4)
+    closed_form_fill_wrapped(eb, "eb")
+    log = []
+    eb._get_noise_cached = NoiseFeed("eb", log)
+    x = closed_form_input("eb:x", (2, 4, 3, 5), -6, 6).requires_grad_()
+    eb.train()
+    out, lik = eb(x)
+    dlik = closed_form_input("eb:dlik", tuple(lik.shape), -1, 1)
+    lik.backward(dlik)
+    d.update({"eb:x": t2n(x), "eb:train_out": t2n(out), "eb:train_lik": t2n(lik), "eb:dlik": t2n(dlik), "eb:dx": t2n(x.grad)})
+    for n_, p in eb.named_parameters():
+        d[f"eb:p:{n_}"] = t2n(p)
+        if p.grad is not None:
+            d[f"eb:g:{n_}"] = t2n(p.grad)
+    eb.zero_grad()
+    aux = eb.loss()
+    aux.backward()
+    d["eb:aux"], d["eb:aux_dquantiles"] = t2n(aux), t2n(eb.quantiles.grad)
+    eb.eval()
+    out, lik = eb(x.detach())
+    d["eb:eval_out"], d["eb:eval_lik"] = t2n(out), t2n(lik)
+    eb.update(force=True)
+    d["eb:offset"], d["eb:cdf"], d["eb:cdf_length"] = t2n(eb._offset), t2n(eb._quantized_cdf), t2n(eb._cdf_length)
+    strings = eb.compress(x.detach())
+    d["eb:string0"] = np.frombuffer(strings[0], dtype=np.uint8)
+    d["eb:string1"] = np.frombuffer(strings[1], dtype=np.uint8)
+    d["eb:decompressed"] = t2n(eb.decompress(strings, (3, 5)))
+    # --- GaussianConditional (entropy_models.py:473-604)
+    gc = GaussianConditional(None)
+    gc._get_noise_cached = NoiseFeed("gc", log)
+    y = closed_form_input("gc:y", (2, 6, 4, 5), -8, 8).requires_grad_()
+    sc = closed_form_input("gc:scales", (2, 6, 4, 5), -0.2, 3.0).requires_grad_()   # some below the 0.11 bound
+    mu = closed_form_input("gc:means", (2, 6, 4, 5), -6, 6).requires_grad_()
+    gc.train()
+    out, lik = gc(y, sc, means=mu)
+    dlik = closed_form_input("gc:dlik", tuple(lik.shape), -1, 1)
+    lik.backward(dlik)
+    d.update({"gc:y": t2n(y), "gc:scales": t2n(sc), "gc:means": t2n(mu), "gc:train_out": t2n(out), "gc:train_lik": t2n(lik),
+              "gc:dlik": t2n(dlik), "gc:dy": t2n(y.grad), "gc:dscales": t2n(sc.grad), "gc:dmeans": t2n(mu.grad)})
+    gc.eval()
+    out, lik = gc(y.detach(), sc.detach(), means=mu.detach())
+    d["gc:eval_out"], d["gc:eval_lik"] = t2n(out), t2n(lik)
+    d["noise_log"] = np.array([f"{n}|{','.join(map(str, s))}" for n, s in log])
+    save("ops_small.npz", d)
+
+
+def closed_form_fill_wrapped(m, prefix):
+    """closed_form_fill_ keyed by '<prefix>.<param name>' so each case gets its own stream."""
+    from spatiotemporalentropymodel_amd.weights import closed_form_tensor
+    with torch.no_grad():
+        for n_, p in m.named_parameters():
+            t = closed_form_tensor(f"{prefix}.{n_}", p.shape, p)
+            if t is not None:
+                p.copy_(t)
+
+
+# ---------------------------------------------------------------------------
+def gen_codec(ref):
+    from compressai import ans
+    from compressai._CXX import pmf_to_quantized_cdf
+    from compressai.entropy_models import GaussianConditional
+    from compressai.models.spatiotemporalpriors import get_scale_table
+
+    d = {}
+    rng = np.random.default_rng(20261002)
+    # pmf_to_quantized_cdf (cpp_exts/ops/ops.cpp:24-81)
+    for i, n in enumerate((3, 17, 64, 255)):
+        pmf = rng.random(n).astype(np.float32) ** (1 + i)
+        pmf[rng.integers(0, n, size=max(1, n // 6))] = 0.0        # force the steal-from-smallest branch
+        pmf = (pmf / pmf.sum()).astype(np.float32)
+        d[f"pmf{i}"] = pmf
+        d[f"cdf{i}"] = np.array(pmf_to_quantized_cdf(pmf.tolist(), 16), dtype=np.uint32)
+    # GaussianConditional.update tables (entropy_models.py:532-568)
+    gc = GaussianConditional(None)
+    gc.update_scale_table(get_scale_table())
+    cdf = t2n(gc._quantized_cdf)
+    d["gc:scale_table"] = t2n(gc.scale_table)
+    d["gc:offset"], d["gc:cdf_length"] = t2n(gc._offset), t2n(gc._cdf_length)
+    d["gc:cdf_shape"] = np.array(cdf.shape)
+    d["gc:cdf_crc32"] = np.array([zlib.crc32(np.ascontiguousarray(cdf).tobytes())], dtype=np.uint64)
+    for r in (0, 1, 17, 31, 48, 63):
+        d[f"gc:cdf_row{r}"] = cdf[r]
+    # rANS streams (cpp_exts/rans/rans_interface.cpp:99-350) against the Gaussian tables,
+    # symbols far outside the table ranges force the 4-bit bypass escapes.
+    sizes, offsets = t2n(gc._cdf_length).astype(np.int32), t2n(gc._offset).astype(np.int32)
+    cdf_list, sizes_list, offsets_list = cdf.tolist(), sizes.tolist(), offsets.tolist()
+    for i, n in enumerate((5, 7, 192, 4096)):  # n=1 overruns the reference encoder's own buffer (UB, rans_interface.cpp:170)
+        idx = rng.integers(0, 64, size=n).astype(np.int32)
+        scale = t2n(gc.scale_table)[idx]
+        sym = np.rint(rng.normal(size=n) * scale).astype(np.int32)
+        out = rng.random(n) < 0.05
+        sym[out] += (rng.integers(-1, 2, size=out.sum()) * rng.integers(1, 70000, size=out.sum())).astype(np.int32)
+        s = ans.RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), cdf_list, sizes_list, offsets_list)
+        dec = ans.RansDecoder().decode_with_indexes(s, idx.tolist(), cdf_list, sizes_list, offsets_list)
+        assert dec == sym.tolist()
+        d[f"rans{i}:symbols"], d[f"rans{i}:indexes"] = sym, idx
+        d[f"rans{i}:bytes"] = np.frombuffer(s, dtype=np.uint8)
+    # BufferedRansEncoder with two pushes + flush, decoded piecewise with decode_stream
+    enc = ans.BufferedRansEncoder()
+    idx_a, idx_b = rng.integers(0, 64, size=50).astype(np.int32), rng.integers(0, 64, size=30).astype(np.int32)
+    sym_a = np.rint(rng.normal(size=50) * t2n(gc.scale_table)[idx_a]).astype(np.int32)
+    sym_b = np.rint(rng.normal(size=30) * t2n(gc.scale_table)[idx_b]).astype(np.int32)
+    enc.encode_with_indexes(sym_a.tolist(), idx_a.tolist(), cdf_list, sizes_list, offsets_list)
+    enc.encode_with_indexes(sym_b.tolist(), idx_b.tolist(), cdf_list, sizes_list, offsets_list)
+    s = enc.flush()
+    dec = ans.RansDecoder()
+    dec.set_stream(s)
+    assert dec.decode_stream(idx_a.tolist(), cdf_list, sizes_list, offsets_list) == sym_a.tolist()
+    assert dec.decode_stream(idx_b.tolist(), cdf_list, sizes_list, offsets_list) == sym_b.tolist()
+    d["bufrans:sym_a"], d["bufrans:idx_a"], d["bufrans:sym_b"], d["bufrans:idx_b"] = sym_a, idx_a, sym_b, idx_b
+    d["bufrans:bytes"] = np.frombuffer(s, dtype=np.uint8)
+    save("codec.npz", d)
+
+
+# ---------------------------------------------------------------------------
+def gen_stem_small_forward(ref):
+    """BASELINE.json configs[0]: one 7x256x256 septuplet, I-frame mbt2018(N=64,M=96) transforms +
+    SpatioTemporalPriorModel(ebc=64,in=96) forward in eval mode, bpp / MSE plumbing."""
+    from compressai.models.priors import JointAutoregressiveHierarchicalPriors
+    from compressai.models.spatiotemporalpriors import SpatioTemporalPriorModel
+
+    log = []
+    imodel = JointAutoregressiveHierarchicalPriors(64, 96).eval()
+    closed_form_fill_(imodel)
+    imodel.gaussian_conditional._get_noise_cached = NoiseFeed("iframe_gc", log)
+    stem = SpatioTemporalPriorModel(64, 96).eval()
+    closed_form_fill_(stem)
+    cap = {}
+    stem.EPM.register_forward_hook(lambda m, i, o: cap.__setitem__("gp", o.detach()))
+    frames = smooth_frames("septuplet0", 1, 7, 256)
+    d = {"frame0_crop": t2n(frames[0][:, :, :32, :32])}
+    bpp_y, bpp_z, mse = [], [], []
+    with torch.no_grad():
+        y0, y_cond = imodel.getY(frames[0])
+        d["y0"] = t2n(y0)
+        for t in range(1, 7):
+            y_cur, _ = imodel.getY(frames[t])
+            out = stem(y_cur, y_cond)
+            x_hat = imodel.getX(out["y_hat"])
+            npix = 256 * 256
+            bpp_y.append(float(torch.log(out["likelihoods"]["y"]).double().sum() / (-np.log(2) * npix)))
+            bpp_z.append(float(torch.log(out["likelihoods"]["z"]).double().sum() / (-np.log(2) * npix)))
+            mse.append(float(((x_hat - frames[t]).double() ** 2).mean()))
+            if t == 1:
+                sc, mu = cap["gp"].chunk(2, 1)
+                d.update({"f1:y_cur": t2n(y_cur), "f1:y_cond": t2n(y_cond), "f1:y_hat": t2n(out["y_hat"]),
+                          "f1:lik_y": t2n(out["likelihoods"]["y"]), "f1:lik_z": t2n(out["likelihoods"]["z"]),
+                          "f1:scales": t2n(sc), "f1:means": t2n(mu), "f1:x_hat_crop": t2n(x_hat[:, :, 100:132, 60:92])})
+            if t == 6:
+                d["f6:y_hat"] = t2n(out["y_hat"])
+            y_cond = out["y_hat"]
+    d["bpp_y"], d["bpp_z"], d["mse"] = np.array(bpp_y), np.array(bpp_z), np.array(mse)
+    d["noise_log"] = np.array([f"{n}|{','.join(map(str, s))}" for n, s in log])
+    save("stem_small_forward.npz", d)
+
+
+def _train_case(ref, ebc, cin, N, M, batch, size, tag, steps=2):
+    """The per-P-frame loop of stem/trainSTEM.py:194-218 (getY -> stem fwd -> EMLoss -> backward ->
+    clip_grad_norm_ -> optimizer.step -> aux_loss.backward -> aux_optimizer.step), reference code."""
+    import types
+    from compressai.models.priors import JointAutoregressiveHierarchicalPriors
+    from compressai.models.spatiotemporalpriors import SpatioTemporalPriorModel_Res
+
+    log = []
+    imodel = JointAutoregressiveHierarchicalPriors(N, M).eval()      # trainSTEM.py:128 IFrameCompressor.eval()
+    closed_form_fill_(imodel)
+    imodel.gaussian_conditional._get_noise_cached = NoiseFeed("iframe_gc", log)
+    stem = SpatioTemporalPriorModel_Res(ebc, cin).train()
+    closed_form_fill_(stem)
+    stem.entropy_bottleneck._get_noise_cached = NoiseFeed("stem_eb", log)
+    stem.gaussian_conditional._get_noise_cached = NoiseFeed("stem_gc", log)
+    args = types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3)
+    optimizer, aux_optimizer = ref.configure_optimizers(stem, args)
+    criterion = ref.EMLoss()
+    frames = smooth_frames("train:" + tag, batch, steps + 1, size)
+    d = {}
+    with torch.no_grad():
+        _, y_cond = imodel.getY(frames[0])
+    for t in range(1, steps + 1):
+        optimizer.zero_grad()
+        aux_optimizer.zero_grad()
+        y_cur, _ = imodel.getY(frames[t])
+        out = stem(y_cur.detach(), y_cond.detach())
+        y_cond = out["y_hat"]
+        oc = criterion(out, frames[t])
+        oc["loss"].backward()
+        gn = torch.nn.utils.clip_grad_norm_(stem.parameters(), 1.0)
+        if t == 1:
+            d["s1:y_cur"], d["s1:y_hat"] = t2n(y_cur), t2n(out["y_hat"])
+            d["s1:lik_y"], d["s1:lik_z"] = t2n(out["likelihoods"]["y"]), t2n(out["likelihoods"]["z"])
+            for n_, p in stem.named_parameters():
+                if p.grad is None:
+                    continue
+                g = p.grad.double()          # after clipping
+                d[f"s1:gsum:{n_}"] = np.array([float(g.sum()), float(g.abs().sum()), float((g * g).sum())])
+                d[f"s1:gslice:{n_}"] = t2n(p.grad.reshape(-1)[:: max(1, p.numel() // 64)][:64])
+        optimizer.step()
+        aux = stem.aux_loss()
+        aux.backward()
+        aux_optimizer.step()
+        d[f"s{t}:scalars"] = np.array([float(oc["loss"]), float(oc["y_bpp_loss"]), float(oc["z_bpp_loss"]), float(aux), float(gn)])
+        if t == 1:
+            d["s1:dquantiles"] = t2n(stem.entropy_bottleneck.quantiles.grad)
+    for n_, p in stem.named_parameters():
+        pd_ = p.detach().double()
+        d[f"final:psum:{n_}"] = np.array([float(pd_.sum()), float(pd_.abs().sum())])
+        d[f"final:pslice:{n_}"] = t2n(p.reshape(-1)[:: max(1, p.numel() // 64)][:64])
+    d["noise_log"] = np.array([f"{n}|{','.join(map(str, s))}" for n, s in log])
+    d["cfg"] = np.array([ebc, cin, N, M, batch, size, steps])
+    save(f"stem_train_{tag}.npz", d)
+
+
+def gen_stem_codec(ref):
+    """compress()/decompress() with the host rANS (spatiotemporalpriors.py:871-1054 and 588-770)."""
+    from compressai.models.priors import JointAutoregressiveHierarchicalPriors
+    from compressai.models.spatiotemporalpriors import SpatioTemporalPriorModel, SpatioTemporalPriorModel_Res
+
+    log = []
+    imodel = JointAutoregressiveHierarchicalPriors(64, 96).eval()
+    closed_form_fill_(imodel)
+    imodel.gaussian_conditional._get_noise_cached = NoiseFeed("iframe_gc", log)
+    frames = smooth_frames("codec", 1, 2, 128)
+    d = {}
+    with torch.no_grad():
+        _, y_cond = imodel.getY(frames[0])
+        y_cur, _ = imodel.getY(frames[1])
+        y_cur = y_cur * 4.0          # random-init latents are tiny; scale so that symbols are not all zero
+        y_cond = y_cond * 4.0
+        d["y_cur"], d["y_cond"] = t2n(y_cur), t2n(y_cond)
+        for tag, cls in (("res", SpatioTemporalPriorModel_Res), ("full", SpatioTemporalPriorModel)):
+            stem = cls(64, 96).eval()
+            closed_form_fill_(stem)
+            stem.update(force=True)
+            enc = stem.compress(y_cur, y_cond)
+            dec = stem.decompress(enc["strings"], enc["shape"], y_cond)
+            y_hat = dec["y_hat"] if isinstance(dec, dict) else dec
+            fwd = stem(y_cur, y_cond)
+            d[f"{tag}:y_string"] = np.frombuffer(enc["strings"][0][0], dtype=np.uint8)
+            d[f"{tag}:z_string"] = np.frombuffer(enc["strings"][1][0], dtype=np.uint8)
+            d[f"{tag}:shape"] = np.array(enc["shape"])
+            d[f"{tag}:y_hat"] = t2n(y_hat)
+            d[f"{tag}:fwd_y_hat"] = t2n(fwd["y_hat"])
+            d[f"{tag}:eb_cdf"], d[f"{tag}:eb_offset"] = t2n(stem.entropy_bottleneck._quantized_cdf), t2n(stem.entropy_bottleneck._offset)
+            d[f"{tag}:eb_cdf_length"] = t2n(stem.entropy_bottleneck._cdf_length)
+    save("stem_codec_small.npz", d)
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    scratch, ref_utils = import_reference()
+    try:
+        which = sys.argv[1:] or ["ops", "codec", "fwd", "train_small", "train_big", "stemcodec"]
+        if "ops" in which:
+            gen_ops(ref_utils)
+        if "codec" in which:
+            gen_codec(ref_utils)
+        if "fwd" in which:
+            gen_stem_small_forward(ref_utils)
+        if "train_small" in which:
+            _train_case(ref_utils, 64, 96, 64, 96, batch=2, size=128, tag="small")
+        if "train_big" in which:
+            _train_case(ref_utils, 256, 192, 192, 192, batch=2, size=64, tag="big")
+        if "stemcodec" in which:
+            gen_stem_codec(ref_utils)
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)

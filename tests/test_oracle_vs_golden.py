@@ -1,0 +1,322 @@
+"""Pins the CPU oracle (oracle/stem_oracle.c) against golden vectors captured from the
+reference itself (tests/golden/make_golden.py).  CPU only; no HIP code is touched here.
+
+Tolerances: the oracle accumulates in double, the reference in fp32 (torch CPU), so the two
+differ by fp32 summation noise only: 1e-5 relative for single ops, 1e-4 (north_star) end to
+end.  Integer work (CDF tables, rANS bytes, symbols, indexes) is bit-exact.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO, assert_close
+
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+import stem_oracle as orc  # noqa: E402
+
+
+@pytest.mark.parametrize("name", ["conv_k5s2", "conv_k5s1", "conv_k3s1", "conv_k1s1", "conv_c3"])
+def test_conv_ops(golden, name):
+    g = golden("ops_small.npz")
+    N, C, H, W, K, R, st, pd = g[f"{name}:cfg"]
+    y = orc.conv2d_fwd(g[f"{name}:x"], g[f"{name}:w"], g[f"{name}:b"], int(st), int(pd))
+    assert_close(y, g[f"{name}:y"], 1e-5, what=name + " y")
+    dx, dw, db = orc.conv2d_bwd(g[f"{name}:x"], g[f"{name}:w"], g[f"{name}:dy"], int(st), int(pd))
+    assert_close(dx, g[f"{name}:dx"], 1e-5, what=name + " dx")
+    assert_close(dw, g[f"{name}:dw"], 1e-5, what=name + " dw")
+    assert_close(db, g[f"{name}:db"], 1e-5, what=name + " db")
+
+
+@pytest.mark.parametrize("name", ["deconv_k5s2", "deconv_c3"])
+def test_deconv_ops(golden, name):
+    g = golden("ops_small.npz")
+    N, C, H, W, K, R, st, pd, op = (int(v) for v in g[f"{name}:cfg"])
+    y = orc.deconv2d_fwd(g[f"{name}:x"], g[f"{name}:w"], g[f"{name}:b"], st, pd, op)
+    assert_close(y, g[f"{name}:y"], 1e-5, what=name + " y")
+    dx, dw, db = orc.deconv2d_bwd(g[f"{name}:x"], g[f"{name}:w"], g[f"{name}:dy"], st, pd, op)
+    assert_close(dx, g[f"{name}:dx"], 1e-5, what=name + " dx")
+    assert_close(dw, g[f"{name}:dw"], 1e-5, what=name + " dw")
+    assert_close(db, g[f"{name}:db"], 1e-5, what=name + " db")
+
+
+def test_masked_conv(golden):
+    g = golden("ops_small.npz")
+    n = "masked_k5"
+    wm = orc.masked_weight(g[f"{n}:w_before"])
+    np.testing.assert_array_equal(wm, g[f"{n}:w_after"])            # in-place masking of weight.data
+    assert int(g[f"{n}:mask"][0, 0].sum()) == 12                      # type-A 5x5: 12 live taps
+    y = orc.conv2d_fwd(g[f"{n}:x"], wm, g[f"{n}:b"], 1, 2)
+    assert_close(y, g[f"{n}:y"], 1e-5, what="masked y")
+    dx, dw, db = orc.conv2d_bwd(g[f"{n}:x"], wm, g[f"{n}:dy"], 1, 2)
+    assert_close(dx, g[f"{n}:dx"], 1e-5, what="masked dx")
+    assert_close(dw, g[f"{n}:dw"], 1e-5, what="masked dw (all 25 taps)")
+    assert np.abs(g[f"{n}:dw"][:, :, 3:]).max() > 0                   # masked taps DO get gradients
+
+
+def test_gdn(golden):
+    g = golden("ops_small.npz")
+    for n, inv in (("gdn", False), ("igdn", True)):
+        y = orc.gdn_fwd(g[f"{n}:x"], g[f"{n}:beta"], g[f"{n}:gamma"], inverse=inv)
+        assert_close(y, g[f"{n}:y"], 1e-5, what=n)
+    # closed form at init (compressai_tests/test_layers.py:118-156)
+    x = g["gdn_init:x"]
+    y = orc.gdn_fwd(x, g["gdn_init:beta"], g["gdn_init:gamma"])
+    assert_close(y, x / np.sqrt(1 + 0.1 * x ** 2), 1e-5, what="gdn closed form")
+    assert_close(y, g["gdn_init:y"], 1e-5, what="gdn init")
+
+
+def _eb_sd(g):
+    return {k[len("eb:p:"):]: v for k, v in g.items() if k.startswith("eb:p:")}
+
+
+def test_entropy_bottleneck(golden):
+    from spatiotemporalentropymodel_amd.weights import closed_form_input
+    g = golden("ops_small.npz")
+    sd = _eb_sd(g)
+    pack = orc.eb_pack_params(sd, prefix="")
+    x = g["eb:x"]
+    # train mode: x + injected noise
+    noise = closed_form_input("noise:eb:0", (4, 1, 2 * 3 * 5), -0.5, 0.5).numpy().reshape(4, -1)
+    v = orc.nchw_to_cl(x) + noise
+    assert_close(orc.cl_to_nchw(v, x.shape), g["eb:train_out"], 1e-6, what="eb noisy out")
+    lik = orc.eb_likelihood_fwd(v, pack)
+    assert_close(orc.cl_to_nchw(lik, x.shape), g["eb:train_lik"], 1e-5, atol=1e-9, what="eb train lik")
+    dv, dp = orc.eb_likelihood_bwd(v, pack, orc.nchw_to_cl(g["eb:dlik"]))
+    assert_close(orc.cl_to_nchw(dv, x.shape), g["eb:dx"], 1e-4, what="eb dx")
+    for name, gr in orc.eb_unpack_grads(dp, prefix="").items():
+        assert_close(gr, g[f"eb:g:{name}"], 1e-4, what="eb grad " + name)
+    # eval mode: round(x - median) + median
+    med = sd["quantiles"][:, 0, 1]
+    vq = orc.quantize_dequantize(orc.nchw_to_cl(x), med[:, None])
+    np.testing.assert_array_equal(orc.cl_to_nchw(vq, x.shape), g["eb:eval_out"])
+    assert_close(orc.cl_to_nchw(orc.eb_likelihood_fwd(vq, pack), x.shape), g["eb:eval_lik"], 1e-5, atol=1e-9, what="eb eval lik")
+    # aux loss
+    target = np.array([-np.log(2 / 1e-9 - 1), 0, np.log(2 / 1e-9 - 1)], np.float32)
+    loss, dq = orc.eb_aux_loss(sd["quantiles"], pack, target)
+    assert_close(loss, g["eb:aux"], 1e-5, what="aux loss")
+    assert_close(dq, g["eb:aux_dquantiles"], 1e-4, what="aux dquantiles")
+
+
+def test_gaussian_conditional(golden):
+    from spatiotemporalentropymodel_amd.weights import closed_form_input
+    g = golden("ops_small.npz")
+    y, sc, mu = g["gc:y"], g["gc:scales"], g["gc:means"]
+    noise = closed_form_input("noise:gc:0", y.shape, -0.5, 0.5).numpy()
+    out = y + noise
+    assert_close(out, g["gc:train_out"], 1e-6, what="gc noisy")
+    lik = orc.gc_likelihood_fwd(out, sc, mu)
+    assert_close(lik, g["gc:train_lik"], 1e-4, atol=1e-9, what="gc lik")
+    dy, ds, dm = orc.gc_likelihood_bwd(out, sc, mu, g["gc:dlik"])
+    assert_close(dy, g["gc:dy"], 1e-4, atol=1e-9, what="gc dy")
+    assert_close(ds, g["gc:dscales"], 1e-4, atol=1e-9, what="gc dscales")
+    assert_close(dm, g["gc:dmeans"], 1e-4, atol=1e-9, what="gc dmeans")
+    outq = orc.quantize_dequantize(y, mu)
+    np.testing.assert_array_equal(outq, g["gc:eval_out"])
+    assert_close(orc.gc_likelihood_fwd(outq, sc, mu), g["gc:eval_lik"], 1e-4, atol=1e-9, what="gc eval lik")
+
+
+def test_lower_bound_rule(golden):
+    g = golden("ops_small.npz")
+    x, dy = g["lb:x"], g["lb:dy"]
+    np.testing.assert_array_equal(np.maximum(x, np.float32(0.3)), g["lb:y"])
+    np.testing.assert_array_equal(((x >= np.float32(0.3)) | (dy < 0)) * dy, g["lb:dx"])
+
+
+def test_quantize_half_to_even():
+    x = np.array([0.5, 1.5, 2.5, -0.5, -1.5, 2.4999, 1e9], np.float32)
+    np.testing.assert_array_equal(orc.quantize_dequantize(x), np.array([0, 2, 2, -0.0, -2, 2, 1e9], np.float32))
+    np.testing.assert_array_equal(orc.quantize_symbols(x[:6]), np.array([0, 2, 2, 0, -2, 2], np.int32))
+
+
+# ----------------------------------------------------------------------------- integer / codec
+def test_pmf_to_quantized_cdf(golden):
+    g = golden("codec.npz")
+    for i in range(4):
+        np.testing.assert_array_equal(orc.pmf_to_quantized_cdf(g[f"pmf{i}"]), g[f"cdf{i}"])
+
+
+def _gc_tables(g):
+    """Rebuild the 64x3133 Gaussian CDF table with the oracle exactly as GaussianConditional.update does
+    (entropy_models.py:543-568) from the committed scale table; verified against the reference's crc32."""
+    import scipy.stats
+    import torch
+    table = g["gc:scale_table"]
+    mult = -scipy.stats.norm.ppf(1e-9 / 2)
+    center = np.ceil(table * np.float32(mult)).astype(np.int32)          # torch: float32 table * python float
+    length = 2 * center + 1
+    maxlen = int(length.max())
+    samples = np.abs(np.arange(maxlen, dtype=np.int32)[None, :] - center[:, None]).astype(np.float32)
+    sc = table[:, None].astype(np.float32)
+
+    def cum(v):     # _standardized_cumulative (entropy_models.py:521-526) through torch.erfc to match fp32 exactly
+        return (0.5 * torch.erfc(torch.tensor(np.float32(-(2 ** -0.5)) * v))).numpy()
+
+    upper, lower = cum((np.float32(0.5) - samples) / sc), cum((np.float32(-0.5) - samples) / sc)
+    pmf = upper - lower
+    tail = 2 * lower[:, :1]
+    cdf = np.zeros((len(table), maxlen + 2), np.int32)
+    for i in range(len(table)):
+        prob = np.concatenate([pmf[i, : length[i]], tail[i]])
+        c = orc.pmf_to_quantized_cdf(prob)
+        cdf[i, : len(c)] = c
+    return cdf, (length + 2).astype(np.int32), (-center).astype(np.int32)
+
+
+def test_gaussian_tables_and_rans(golden):
+    import zlib
+    g = golden("codec.npz")
+    cdf, sizes, offsets = _gc_tables(g)
+    np.testing.assert_array_equal(sizes, g["gc:cdf_length"])
+    np.testing.assert_array_equal(offsets, g["gc:offset"])
+    assert tuple(cdf.shape) == tuple(g["gc:cdf_shape"])
+    for r in (0, 1, 17, 31, 48, 63):
+        np.testing.assert_array_equal(cdf[r], g[f"gc:cdf_row{r}"])
+    assert zlib.crc32(np.ascontiguousarray(cdf).tobytes()) == int(g["gc:cdf_crc32"][0])
+    for i in range(4):
+        sym, idx = g[f"rans{i}:symbols"], g[f"rans{i}:indexes"]
+        s = orc.rans_encode(sym, idx, cdf, sizes, offsets)
+        assert s == g[f"rans{i}:bytes"].tobytes(), f"rANS stream {i} differs from the reference's bytes"
+        np.testing.assert_array_equal(orc.rans_decode(s, idx, cdf, sizes, offsets), sym)
+    # two pushes + one flush == one stream of the concatenation
+    sym = np.concatenate([g["bufrans:sym_a"], g["bufrans:sym_b"]])
+    idx = np.concatenate([g["bufrans:idx_a"], g["bufrans:idx_b"]])
+    assert orc.rans_encode(sym, idx, cdf, sizes, offsets) == g["bufrans:bytes"].tobytes()
+
+
+def test_reference_codec_build_agrees():
+    """oracle/_ref (the reference's own C++ compiled from /root/reference) vs the C restatement."""
+    ref_dir = os.path.join(REPO, "oracle", "_ref")
+    if not os.path.isdir(ref_dir) or not any(f.startswith("ans") for f in os.listdir(ref_dir)):
+        pytest.skip("oracle/_ref not built")
+    sys.path.insert(0, ref_dir)
+    import _CXX
+    import ans
+    rng = np.random.default_rng(7)
+    pmf = rng.random(40).astype(np.float32)
+    pmf /= pmf.sum()
+    cdf_row = orc.pmf_to_quantized_cdf(pmf)
+    assert _CXX.pmf_to_quantized_cdf(pmf.tolist(), 16) == cdf_row.tolist()
+    cdf = cdf_row[None, :].astype(np.int32)
+    sizes, offsets = np.array([41], np.int32), np.array([-20], np.int32)
+    sym = rng.integers(-60, 60, size=500).astype(np.int32)
+    idx = np.zeros(500, np.int32)
+    s_ref = ans.RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), cdf.tolist(), sizes.tolist(), offsets.tolist())
+    assert orc.rans_encode(sym, idx, cdf, sizes, offsets) == s_ref
+
+
+# ----------------------------------------------------------------------------- model level
+def _closed_form_sd(module_keys):
+    from spatiotemporalentropymodel_amd.weights import closed_form_tensor
+    return {k: closed_form_tensor(k, shp).numpy() for k, shp in module_keys.items()}
+
+
+def _imodel_keys(N, M):
+    keys = {}
+    for pre, first, last in (("g_a", 3, M), ("g_s", M, 3)):
+        chans = [first, N, N, N, last]
+        for i in range(4):
+            cin, cout = chans[i], chans[i + 1]
+            keys[f"{pre}.{2 * i}.weight"] = (cout, cin, 5, 5) if pre == "g_a" else (cin, cout, 5, 5)
+            keys[f"{pre}.{2 * i}.bias"] = (cout,)
+            if i < 3:
+                keys[f"{pre}.{2 * i + 1}.beta"] = (N,)
+                keys[f"{pre}.{2 * i + 1}.gamma"] = (N, N)
+    return keys
+
+
+def _stem_keys(ebc, cin):
+    keys = {}
+    for i, (fo, fi) in enumerate([(3, 1), (3, 3), (3, 3), (3, 3), (1, 3)]):
+        keys[f"entropy_bottleneck._matrix{i}"] = (ebc, fo, fi)
+        keys[f"entropy_bottleneck._bias{i}"] = (ebc, fo, 1)
+        if i < 4:
+            keys[f"entropy_bottleneck._factor{i}"] = (ebc, fo, 1)
+    keys["entropy_bottleneck.quantiles"] = (ebc, 1, 3)
+    conv = {"TPM.0": (256, cin, 5), "TPM.2": (320, 256, 5), "TPM.4": (2 * cin, 320, 5),
+            "HE.0": (256, 2 * cin, 3), "HE.2": (256, 256, 5), "HE.4": (ebc, 256, 5),
+            "HD.0": (ebc, 256, 5), "HD.2": (256, 256, 5), "HD.4": (2 * cin, 256, 3),
+            "context_prediction": (2 * cin, cin, 5),
+            "EPM.0": (768, 6 * cin, 1), "EPM.2": (576, 768, 1), "EPM.4": (2 * cin, 576, 1)}
+    for n, (o, i, k) in conv.items():
+        keys[n + ".weight"] = (o, i, k, k)
+        keys[n + ".bias"] = (256,) if n in ("HD.0", "HD.2") else (o,)
+    return keys
+
+
+def test_stem_small_forward_config1(golden):
+    """BASELINE.json configs[0]: frame 1 of the septuplet, all tensors; bpp + MSE."""
+    from spatiotemporalentropymodel_amd.weights import closed_form_input, smooth_frames
+    g = golden("stem_small_forward.npz")
+    isd, ssd = _closed_form_sd(_imodel_keys(64, 96)), _closed_form_sd(_stem_keys(64, 96))
+    frames = [f.numpy() for f in smooth_frames("septuplet0", 1, 7, 256)]
+    np.testing.assert_array_equal(frames[0][:, :, :32, :32], g["frame0_crop"])
+    y0 = orc.g_a(isd, frames[0])
+    assert_close(y0, g["y0"], 1e-4, what="g_a(y0)")
+    y_cur = orc.g_a(isd, frames[1])
+    assert_close(y_cur, g["f1:y_cur"], 1e-4, what="g_a(y1)")
+    # use the reference's own y_cond / y_cur so that rounding decisions are compared on identical inputs
+    out = orc.stem_forward(ssd, g["f1:y_cur"], g["f1:y_cond"], residual=False, training=False)
+    assert_close(out["scales"], g["f1:scales"], 1e-4, what="scales")
+    assert_close(out["means"], g["f1:means"], 1e-4, what="means")
+    np.testing.assert_array_equal(out["y_hat"], g["f1:y_hat"])
+    assert_close(out["lik_z"], g["f1:lik_z"], 1e-4, atol=1e-9, what="lik_z")
+    assert_close(out["lik_y"], g["f1:lik_y"], 2e-4, atol=1e-9, what="lik_y")
+    npix = 256 * 256
+    assert abs(orc.rate_bpp(out["lik_y"], npix) - g["bpp_y"][0]) < 1e-4 * g["bpp_y"][0]
+    assert abs(orc.rate_bpp(out["lik_z"], npix) - g["bpp_z"][0]) < 1e-4 * g["bpp_z"][0]
+    x_hat = orc.g_s(isd, out["y_hat"])
+    assert_close(x_hat[:, :, 100:132, 60:92], g["f1:x_hat_crop"], 1e-4, what="x_hat")
+    mse = float(((x_hat.astype(np.float64) - frames[1]) ** 2).mean())
+    assert abs(mse - g["mse"][0]) < 1e-4 * g["mse"][0]
+
+
+@pytest.mark.parametrize("tag", ["small", "big"])
+def test_stem_train_step1_gradients(golden, tag):
+    """First P-frame step of the stem/trainSTEM.py:194-218 loop: loss terms, every parameter gradient
+    (checksums + strided slices, after clip_grad_norm_) and the global grad norm."""
+    from spatiotemporalentropymodel_amd.weights import closed_form_input
+    g = golden(f"stem_train_{tag}.npz")
+    ebc, cin, N, M, batch, size, steps = (int(v) for v in g["cfg"])
+    ssd = _closed_form_sd(_stem_keys(ebc, cin))
+    ls, lz = size // 16, size // 64
+    noise = {k: closed_form_input(n, s, -0.5, 0.5).numpy() for k, n, s in (
+        ("icond", "noise:iframe_gc:0", (batch, M, ls, ls)),
+        ("z", "noise:stem_eb:0", (ebc, 1, batch * lz * lz)),
+        ("q", "noise:stem_gc:0", (batch, cin, ls, ls)),
+        ("lik", "noise:stem_gc:1", (batch, cin, ls, ls)))}
+    noise["z"] = orc.cl_to_nchw(noise["z"].reshape(ebc, -1), (batch, ebc, lz, lz))
+    y_cur = g["s1:y_cur"]
+    y_hat_ref = g["s1:y_hat"]
+    # y_hat = res_hat + y_cond, res_hat = y_cur - y_cond + noise_q  =>  y_cond is not recoverable from y_hat alone;
+    # recompute it with the oracle's g_a on frame 0 (+ the injected I-frame noise)
+    from spatiotemporalentropymodel_amd.weights import smooth_frames
+    frames = [f.numpy() for f in smooth_frames("train:" + tag, batch, steps + 1, size)]
+    isd = _closed_form_sd(_imodel_keys(N, M))
+    y_cond = orc.g_a(isd, frames[0]) + noise["icond"]
+    assert_close(orc.g_a(isd, frames[1]), y_cur, 1e-4, what="y_cur")
+    keep = {}
+    out = orc.stem_forward(ssd, y_cur, y_cond, residual=True, training=True, noise=noise, keep=keep)
+    assert_close(out["y_hat"], y_hat_ref, 1e-4, what="y_hat")
+    assert_close(out["lik_y"], g["s1:lik_y"], 2e-4, atol=1e-9, what="lik_y")
+    assert_close(out["lik_z"], g["s1:lik_z"], 1e-4, atol=1e-9, what="lik_z")
+    npix = batch * size * size
+    loss, ybpp, zbpp, aux, gn = g["s1:scalars"]
+    assert abs(orc.rate_bpp(out["lik_y"], npix) - ybpp) < 1e-4 * ybpp
+    assert abs(orc.rate_bpp(out["lik_z"], npix) - zbpp) < 1e-4 * zbpp
+    grads = orc.stem_backward(ssd, keep, out["lik_y"], out["lik_z"], npix)
+    total = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in grads.values()))
+    assert abs(total - gn) < 2e-4 * gn, (total, gn)
+    clip = min(1.0, 1.0 / (total + 1e-6))          # torch.nn.utils.clip_grad_norm_(…, 1.0)
+    for name, gr in grads.items():
+        ref = g[f"s1:gsum:{name}"]
+        gd = gr.astype(np.float64) * clip
+        assert abs(gd.sum() - ref[0]) <= 2e-4 * ref[1] + 1e-12, name
+        assert abs(np.abs(gd).sum() - ref[1]) <= 2e-4 * ref[1] + 1e-12, name
+        sl = gd.reshape(-1)[:: max(1, gd.size // 64)][:64]
+        assert_close(sl, g[f"s1:gslice:{name}"], 5e-4, atol=1e-7 * float(np.abs(g[f's1:gslice:{name}']).max() + 1e-30), what="grad " + name)
+    pack = orc.eb_pack_params(ssd)
+    target = np.array([-np.log(2 / 1e-9 - 1), 0, np.log(2 / 1e-9 - 1)], np.float32)
+    # aux loss is evaluated after optimizer.step in the reference -> only its dquantiles structure is checked here
+    assert g["s1:dquantiles"].shape == (ebc, 1, 3)
