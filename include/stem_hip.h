@@ -1,0 +1,156 @@
+/*
+ * stem_hip.h -- C ABI of libstem_hip.so: hand-written HIP kernels (gfx950 / MI355X)
+ * for the STEM hot path of mmSir/SpatioTemporalEntropyModel.
+ *
+ * The reference has no device FFI: its "operator interface" for this path is the
+ * set of torch ops its modules call.  Each entry point below
+ * names the reference call site it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors);
+ *    outputs are pre-allocated by the caller; nothing here allocates or syncs;
+ *  - kernels are asynchronous on `stream` (a hipStream_t passed as void*);
+ *  - return 0 on success, <0 on error; stem_last_error() describes the last
+ *    failure on the calling thread;
+ *  - activations are NHWC fp32 ("channels_last"): element (b,y,x,c) of a view
+ *    lives at p[((b*H + y)*W + x)*ld + c]; `ld` >= C lets a tensor be a channel
+ *    slice of a wider buffer, which is how torch.cat / chunk on the channel axis
+ *    (spatiotemporalpriors.py:846,858-859) are done without a copy;
+ *  - convolution weights are consumed in a packed K-contiguous layout made by
+ *    stem_pack_weight() from the reference's OIHW / IOHW tensors.
+ */
+#ifndef STEM_HIP_H
+#define STEM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char *stem_last_error(void);
+int stem_abi_version(void);
+
+/* ---- weight packing ------------------------------------------------------
+ * roles (what the packed copy will be multiplied with):                       */
+enum {
+    STEM_PACK_CONV_FWD = 0,     /* nn.Conv2d weight [K,C,R,S] -> [R*S][K][C]  (forward)            */
+    STEM_PACK_CONV_DGRAD = 1,   /* nn.Conv2d weight [K,C,R,S] -> [R*S][C][K]  (input gradient)      */
+    STEM_PACK_DECONV_FWD = 2,   /* nn.ConvTranspose2d weight [C,K,R,S] -> [R*S][K][C] (forward)      */
+    STEM_PACK_DECONV_DGRAD = 3, /* nn.ConvTranspose2d weight [C,K,R,S] -> [R*S][C][K]                */
+    STEM_PACK_CONV_FWD_C4 = 4   /* Conv2d weight [K,3or4,R,S] -> [K][32 taps][4] zero padded         */
+};
+/* `masked` != 0 applies MaskedConv2d's type-A mask (compressai/layers/layers.py:39-47).      */
+int stem_pack_weight(const float *w, float *wp, int K, int C, int R, int S, int role, int masked, void *stream);
+size_t stem_packed_weight_elems(int K, int C, int R, int S, int role);
+/* gradient in packed layout [splits][R*S][K][C] (from stem_conv2d_wgrad) -> reference layout,
+ * summing the split-K slabs.  deconv != 0 writes the ConvTranspose2d layout [C,K,R,S].        */
+int stem_unpack_wgrad(const float *dwp, float *dw, int K, int C, int R, int S, int splits, int deconv, void *stream);
+
+/* ---- epilogues --------------------------------------------------------- */
+enum { STEM_ACT_NONE = 0, STEM_ACT_LRELU = 1 };
+
+/* nn.Conv2d forward (+bias, optional fused LeakyReLU).  Replaces F.conv2d under
+ * compressai/models/utils.py:112-120 and spatiotemporalpriors.py:807-838.
+ * x[B,H,W,C] (ldx)  wp = STEM_PACK_CONV_FWD  ->  y[B,Ho,Wo,K] (ldy)                             */
+int stem_conv2d_fwd(const float *x, int ldx, const float *wp, const float *bias, float *y, int ldy,
+                    int B, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                    int act, float slope, void *stream);
+/* first analysis layer (C_in = 3, priors.py:422): x is NHWC with 4 channels (4th zero) made by
+ * stem_nchw3_to_nhwc4; wp = STEM_PACK_CONV_FWD_C4.                                               */
+int stem_conv2d_fwd_c4(const float *x4, const float *wp, const float *bias, float *y, int ldy,
+                       int B, int H, int W, int K, int R, int S, int stride, int pad, void *stream);
+/* dX of nn.Conv2d.  dy[B,Ho,Wo,K] -> dx[B,H,W,C].  wp = STEM_PACK_CONV_DGRAD.  If `xact` != NULL the
+ * result is multiplied by LeakyReLU'(xact) (xact = the layer's *input* activation = output of the
+ * preceding LeakyReLU), fusing the activation backward.                                           */
+int stem_conv2d_dgrad(const float *dy, int lddy, const float *wp, float *dx, int lddx,
+                      const float *xact, int ldxact, float slope,
+                      int B, int H, int W, int C, int K, int R, int S, int stride, int pad, void *stream);
+/* dW (packed, `splits` slabs of [R*S][K][C]) and db[K] of nn.Conv2d.  All R*S taps are produced
+ * (the reference's autograd does not mask MaskedConv2d's weight gradient).                        */
+int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
+                      int B, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                      int splits, void *stream);
+int stem_wgrad_splits(int B, int Ho, int Wo, int C, int K, int R, int S);
+
+/* nn.ConvTranspose2d forward as sub-pixel phases (no zero insertion).  models/utils.py:122-130,
+ * spatiotemporalpriors.py:821-826.  x[B,H,W,C] -> y[B,Ho,Wo,K], wp = STEM_PACK_DECONV_FWD.        */
+int stem_deconv2d_fwd(const float *x, int ldx, const float *wp, const float *bias, float *y, int ldy,
+                      int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad,
+                      int act, float slope, void *stream);
+int stem_deconv2d_dgrad(const float *dy, int lddy, const float *wp, float *dx, int lddx,
+                        const float *xact, int ldxact, float slope,
+                        int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad, void *stream);
+/* dW packed as [splits][R*S][K][C] with K = out channels, C = in channels; unpack with deconv=1. */
+int stem_deconv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
+                        int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad,
+                        int splits, void *stream);
+
+/* GDN / IGDN forward, compressai/layers/gdn.py:52-67 with the NonNegativeParametrizer
+ * (compressai/ops/parametrizers.py:42-45) applied to the stored beta[C], gamma[C,C] on the fly. */
+int stem_gdn_fwd(const float *x, int ldx, const float *beta, const float *gamma, float *y, int ldy,
+                 int B, int H, int W, int C, int inverse, float beta_min, void *stream);
+
+/* LeakyReLU backward given the activation OUTPUT (sign-preserving): dx = dy * (yact>0 ? 1 : slope). */
+int stem_lrelu_bwd(const float *yact, const float *dy, float *dx, size_t n, float slope, void *stream);
+
+/* ---- layout ------------------------------------------------------------ */
+int stem_nchw_to_nhwc(const float *x, float *y, int ldy, int B, int C, int H, int W, void *stream);
+int stem_nhwc_to_nchw(const float *x, int ldx, float *y, int B, int C, int H, int W, int clamp01, void *stream);
+int stem_nchw3_to_nhwc4(const float *x, float *y, int B, int H, int W, void *stream);
+
+/* ---- entropy models ---------------------------------------------------- */
+#define STEM_EB_NPARAM 58
+/* pack the EntropyBottleneck parameters (entropy_models.py:310-328) into [C][58]:
+ * per layer i: matrix_i (out x in), bias_i, factor_i (i<4).  Pointers are the 14 tensors in that order. */
+int stem_eb_pack(const float *const *tensors14, float *pack, int C, void *stream);
+int stem_eb_unpack_grads(const float *dpack, float *const *tensors14, int C, void *stream);
+/* EntropyBottleneck.forward (entropy_models.py:424-452) on z[B,H,W,C] NHWC.
+ * mode 0: z_hat = z + noise (noise != NULL, same layout);  mode 1: z_hat = round(z - median) + median.
+ * lik = max(|sigmoid(s*upper) - sigmoid(s*lower)|, bound).                                        */
+int stem_eb_forward(const float *z, int ldz, const float *noise, const float *pack, const float *medians,
+                    float *z_hat, float *lik, int B, int H, int W, int C, int mode, float bound, void *stream);
+/* backward: dlik -> dz (+= dzhat_in if non-NULL) and dpack[C][58].                                */
+int stem_eb_backward(const float *z_hat, const float *pack, const float *dlik, const float *dzhat_in,
+                     float *dz, float *dpack, int B, int H, int W, int C, float bound, void *stream);
+/* EntropyBottleneck.loss (entropy_models.py:383-386): loss[1], dquantiles[C][3]                   */
+int stem_eb_aux_loss(const float *quantiles, const float *pack, const float *target3, float *loss,
+                     float *dquantiles, int C, void *stream);
+
+/* GaussianConditional.forward (entropy_models.py:570-596) fused with quantize:
+ * mode 0: out = y + noise ; mode 1: out = round(y - mean) + mean.  y/noise/out/lik contiguous NHWC [n_pix][C];
+ * scales / means are channel slices (ld) of the EPM output.                                       */
+int stem_gc_forward(const float *y, const float *noise, const float *scales, const float *means, int ldsm,
+                    float *out, float *lik, size_t npix, int C, int mode, float scale_bound, float lik_bound,
+                    void *stream);
+int stem_gc_backward(const float *out, const float *scales, const float *means, int ldsm, const float *dlik,
+                     float *dscales, float *dmeans, int lddsm, float *dy, size_t npix, int C,
+                     float scale_bound, float lik_bound, void *stream);
+/* sum(log2(lik)) accumulated in double: acc[0] += sum.  (EMLoss, utils.py:18-27)                   */
+int stem_log2_sum(const float *lik, size_t n, double *acc, void *stream);
+/* dlik = coef / lik  (gradient of coef*sum(log lik))                                              */
+int stem_dlog(const float *lik, float *dlik, size_t n, float coef, void *stream);
+/* elementwise helpers on contiguous buffers */
+int stem_sub(const float *a, const float *b, float *out, size_t n, void *stream);
+int stem_add(const float *a, const float *b, float *out, size_t n, void *stream);
+int stem_round(const float *a, float *out, size_t n, void *stream);
+/* counter-based uniform noise in [-0.5, 0.5) (Philox4x32-10), replaces Tensor.uniform_ at
+ * entropy_models.py:119; (seed, offset) make the stream reproducible and rank-dependent.          */
+int stem_uniform_noise(float *out, size_t n, uint64_t seed, uint64_t offset, void *stream);
+/* GaussianConditional.build_indexes + quantize("symbols") (entropy_models.py:598-604,137-150)     */
+int stem_build_indexes(const float *scales, int lds, const float *table, int T, int32_t *idx, size_t npix, int C,
+                       float scale_bound, void *stream);
+
+/* ---- optimiser --------------------------------------------------------- */
+/* sum of squares of a flat gradient buffer accumulated into acc[0] (double)                       */
+int stem_sumsq(const float *g, size_t n, double *acc, void *stream);
+/* torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step fused over a flat buffer:
+ * scale = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) (max_norm <= 0: no clipping), g *= scale * gscale. */
+int stem_adam_step(float *p, const float *g, float *m, float *v, size_t n, const double *sumsq, float max_norm,
+                   float gscale, float lr, float beta1, float beta2, float eps, int step, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,122 @@
+"""ctypes loader for the two C-ABI libraries (include/stem_hip.h, include/stem_rans.h).
+
+The HIP library is the product compute path: there is NO CPU or PyTorch fallback.  If
+libstem_hip.so is missing every device op raises (loudly), it never silently degrades.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+HIP_SO = os.path.join(_PKG, "libstem_hip.so")
+RANS_SO = os.path.join(_PKG, "libstem_rans.so")
+
+_hip = None
+_rans = None
+
+vp, ci, cf, sz, u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+_HIP_SIG = {
+    "stem_pack_weight": [vp, vp, ci, ci, ci, ci, ci, ci, vp],
+    "stem_unpack_wgrad": [vp, vp, ci, ci, ci, ci, ci, ci, vp],
+    "stem_conv2d_fwd": [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp],
+    "stem_conv2d_fwd_c4": [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_conv2d_dgrad": [vp, ci, vp, vp, ci, vp, ci, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_conv2d_wgrad": [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_wgrad_splits": [ci, ci, ci, ci, ci, ci, ci],
+    "stem_deconv2d_fwd": [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp],
+    "stem_deconv2d_dgrad": [vp, ci, vp, vp, ci, vp, ci, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_deconv2d_wgrad": [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_gdn_fwd": [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp],
+    "stem_lrelu_bwd": [vp, vp, vp, sz, cf, vp],
+    "stem_nchw_to_nhwc": [vp, vp, ci, ci, ci, ci, ci, vp],
+    "stem_nhwc_to_nchw": [vp, ci, vp, ci, ci, ci, ci, ci, vp],
+    "stem_nchw3_to_nhwc4": [vp, vp, ci, ci, ci, vp],
+    "stem_eb_pack": [vp, vp, ci, vp],
+    "stem_eb_unpack_grads": [vp, vp, ci, vp],
+    "stem_eb_forward": [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cf, vp],
+    "stem_eb_backward": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp],
+    "stem_eb_aux_loss": [vp, vp, vp, vp, vp, ci, vp],
+    "stem_gc_forward": [vp, vp, vp, vp, ci, vp, vp, sz, ci, ci, cf, cf, vp],
+    "stem_gc_backward": [vp, vp, vp, ci, vp, vp, vp, ci, vp, sz, ci, cf, cf, vp],
+    "stem_log2_sum": [vp, sz, vp, vp],
+    "stem_dlog": [vp, vp, sz, cf, vp],
+    "stem_sub": [vp, vp, vp, sz, vp],
+    "stem_add": [vp, vp, vp, sz, vp],
+    "stem_round": [vp, vp, sz, vp],
+    "stem_uniform_noise": [vp, sz, u64, u64, vp],
+    "stem_build_indexes": [vp, ci, vp, ci, vp, sz, ci, cf, vp],
+    "stem_sumsq": [vp, sz, vp, vp],
+    "stem_adam_step": [vp, vp, vp, vp, sz, vp, cf, cf, cf, cf, cf, cf, ci, vp],
+    "stem_packed_weight_elems": [ci, ci, ci, ci, ci],
+    "stem_abi_version": [],
+    "stem_last_error": [],
+}
+_RESTYPE = {"stem_packed_weight_elems": sz, "stem_last_error": C.c_char_p}
+
+_RANS_SIG = {
+    "stem_rans_encode": [vp, vp, sz, vp, ci, ci, vp, vp, vp, sz],
+    "stem_rans_decode": [vp, sz, vp, sz, vp, ci, ci, vp, vp, vp],
+    "stem_rans_encoder_create": [],
+    "stem_rans_encoder_destroy": [vp],
+    "stem_rans_encoder_push": [vp, vp, vp, sz, vp, ci, ci, vp, vp],
+    "stem_rans_encoder_flush": [vp, vp, sz],
+    "stem_rans_encoder_pending_bytes": [vp],
+    "stem_rans_decoder_create": [],
+    "stem_rans_decoder_destroy": [vp],
+    "stem_rans_decoder_set_stream": [vp, vp, sz],
+    "stem_rans_decoder_decode": [vp, vp, sz, vp, ci, ci, vp, vp, vp],
+    "stem_pmf_to_quantized_cdf": [vp, ci, ci, vp],
+    "stem_rans_last_error": [],
+}
+_RANS_RESTYPE = {"stem_rans_encode": C.c_long, "stem_rans_encoder_flush": C.c_long, "stem_rans_encoder_create": vp,
+                 "stem_rans_decoder_create": vp, "stem_rans_last_error": C.c_char_p,
+                 "stem_rans_encoder_pending_bytes": sz, "stem_rans_encoder_destroy": None, "stem_rans_decoder_destroy": None}
+
+
+class StemLibraryError(RuntimeError):
+    pass
+
+
+def _bind(lib, sigs, restypes):
+    for name, args in sigs.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.argtypes = args
+        fn.restype = restypes.get(name, C.c_int)
+    return lib
+
+
+def hip():
+    """libstem_hip.so, or raise: the product path has no fallback."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_SO):
+            raise StemLibraryError(
+                f"{HIP_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the STEM kernels.")
+        _hip = _bind(C.CDLL(HIP_SO), _HIP_SIG, _RESTYPE)
+    return _hip
+
+
+def rans():
+    global _rans
+    if _rans is None:
+        if not os.path.exists(RANS_SO):
+            raise StemLibraryError(f"{RANS_SO} is missing: run `make -C {os.path.join(_PKG, 'csrc')}`")
+        _rans = _bind(C.CDLL(RANS_SO), _RANS_SIG, _RANS_RESTYPE)
+    return _rans
+
+
+def check(rc: int):
+    if rc != 0:
+        raise RuntimeError((hip().stem_last_error() or b"").decode() or f"libstem_hip error {rc}")
+
+
+def declared_hip_symbols():
+    return sorted(_HIP_SIG)
+
+
+def declared_rans_symbols():
+    return sorted(_RANS_SIG)

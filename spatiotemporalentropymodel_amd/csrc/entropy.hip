@@ -1,0 +1,525 @@
+// Entropy-model kernels: EntropyBottleneck / GaussianConditional likelihoods (forward + backward),
+// quantisation, rate reduction, counter-based noise.  All HBM/latency-bound elementwise work; every
+// multi-pass torch expression of the reference (entropy_models.py:388-452, 570-596) is one kernel.
+#include "stem_common.h"
+
+namespace {
+
+constexpr int NP = STEM_EB_NPARAM;   // 58 floats per channel: M0 b0 f0 | M1 b1 f1 | M2 b2 f2 | M3 b3 f3 | M4 b4
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// per-channel transformed parameters: softplus(matrix), bias, tanh(factor)
+struct EbPrep {
+    float sp0[3], b0[3], tf0[3];
+    float sp[3][9], b[3][3], tf[3][3];
+    float sp4[3], b4;
+};
+
+__device__ void eb_prepare(const float *p, EbPrep &e)
+{
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        e.sp0[o] = softplus_f(p[o]);
+        e.b0[o] = p[3 + o];
+        e.tf0[o] = tanhf(p[6 + o]);
+    }
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        const float *q = p + 9 + 15 * l;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) e.sp[l][k] = softplus_f(q[k]);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            e.b[l][o] = q[9 + o];
+            e.tf[l][o] = tanhf(q[12 + o]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) e.sp4[k] = softplus_f(p[54 + k]);
+    e.b4 = p[57];
+}
+
+// _logits_cumulative (entropy_models.py:388-407).  pre[l][o] = value before the tanh gate of layer l,
+// in[l][o] = input of layer l (l=1..4); kept for the backward when KEEP.
+template <bool KEEP>
+__device__ __forceinline__ float eb_logits(const EbPrep &e, float v, float pre[4][3], float inp[4][3])
+{
+    float h[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const float a = e.sp0[o] * v + e.b0[o];
+        if (KEEP) pre[0][o] = a;
+        h[o] = a + e.tf0[o] * tanhf(a);
+    }
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        float g[3];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            if (KEEP) inp[l][o] = h[o];
+        }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float a = e.sp[l][o * 3 + 0] * h[0] + e.sp[l][o * 3 + 1] * h[1] + e.sp[l][o * 3 + 2] * h[2] + e.b[l][o];
+            if (KEEP) pre[l + 1][o] = a;
+            g[o] = a + e.tf[l][o] * tanhf(a);
+        }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) h[o] = g[o];
+    }
+    if (KEEP) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) inp[3][o] = h[o];
+    }
+    return e.sp4[0] * h[0] + e.sp4[1] * h[1] + e.sp4[2] * h[2] + e.b4;
+}
+
+// reverse pass; accumulates d/d(raw params) into dp[58] and returns d/dv
+__device__ float eb_logits_bwd(const float *p, const EbPrep &e, float v, const float pre[4][3], const float inp[4][3],
+                               float gl, float *dp)
+{
+    float gh[3];
+    // layer 4: out = sp4 . h + b4
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        dp[54 + k] += gl * inp[3][k] * sigmoid_f(p[54 + k]);
+        gh[k] = gl * e.sp4[k];
+    }
+    dp[57] += gl;
+#pragma unroll
+    for (int l = 2; l >= 0; --l) {
+        const float *q = p + 9 + 15 * l;
+        float *dq = dp + 9 + 15 * l;
+        float gin[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float a = pre[l + 1][o], ta = tanhf(a), tf = e.tf[l][o];
+            dq[12 + o] += gh[o] * ta * (1.f - tf * tf);
+            const float ga = gh[o] * (1.f + tf * (1.f - ta * ta));
+            dq[9 + o] += ga;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                dq[o * 3 + k] += ga * inp[l][k] * sigmoid_f(q[o * 3 + k]);
+                gin[k] += ga * e.sp[l][o * 3 + k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gh[k] = gin[k];
+    }
+    float gv = 0.f;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const float a = pre[0][o], ta = tanhf(a), tf = e.tf0[o];
+        dp[6 + o] += gh[o] * ta * (1.f - tf * tf);
+        const float ga = gh[o] * (1.f + tf * (1.f - ta * ta));
+        dp[3 + o] += ga;
+        dp[o] += ga * v * sigmoid_f(p[o]);
+        gv += ga * e.sp0[o];
+    }
+    return gv;
+}
+
+__global__ __launch_bounds__(256) void eb_forward_kernel(const float *z, int ldz, const float *noise, const float *pack,
+                                                         const float *med, float *zhat, float *lik, size_t npix, int C,
+                                                         int mode, float bound)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix * C) return;
+    const size_t pix = i / C;
+    const int c = (int)(i - pix * C);
+    EbPrep e;
+    eb_prepare(pack + (size_t)c * NP, e);
+    float v = z[pix * ldz + c];
+    if (mode == 0) {
+        v += noise[i];
+    } else {
+        const float m = med[c];
+        v = rintf(v - m) + m;
+    }
+    zhat[i] = v;
+    const float lo = eb_logits<false>(e, v - 0.5f, nullptr, nullptr);
+    const float up = eb_logits<false>(e, v + 0.5f, nullptr, nullptr);
+    const float s = lo + up;
+    const float sg = s > 0.f ? -1.f : (s < 0.f ? 1.f : 0.f);
+    const float l = fabsf(sigmoid_f(sg * up) - sigmoid_f(sg * lo));
+    lik[i] = fmaxf(l, bound);
+}
+
+// one block (64 threads = one wavefront) per channel; reduces the 58 parameter gradients over pixels
+__global__ __launch_bounds__(64) void eb_backward_kernel(const float *zhat, const float *pack, const float *dlik,
+                                                         const float *dzin, float *dz, float *dpack, size_t npix, int C,
+                                                         float bound)
+{
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const float *p = pack + (size_t)c * NP;
+    EbPrep e;
+    eb_prepare(p, e);
+    float dp[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) dp[k] = 0.f;
+    for (size_t pix = lane; pix < npix; pix += 64) {
+        const size_t i = pix * C + c;
+        const float v = zhat[i];
+        float pre_lo[4][3], in_lo[4][3], pre_up[4][3], in_up[4][3];
+        const float lo = eb_logits<true>(e, v - 0.5f, pre_lo, in_lo);
+        const float up = eb_logits<true>(e, v + 0.5f, pre_up, in_up);
+        const float s = lo + up;
+        const float sg = s > 0.f ? -1.f : (s < 0.f ? 1.f : 0.f);
+        const float su = sigmoid_f(sg * up), sl = sigmoid_f(sg * lo);
+        const float diff = su - sl;
+        float g = dlik[i];
+        if (!(fabsf(diff) >= bound || g < 0.f)) g = 0.f;     // LowerBound rule (bound_ops.py:28-31)
+        const float gd = g * (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
+        const float gup = gd * su * (1.f - su) * sg;
+        const float glo = -gd * sl * (1.f - sl) * sg;
+        float gv = eb_logits_bwd(p, e, v + 0.5f, pre_up, in_up, gup, dp);
+        gv += eb_logits_bwd(p, e, v - 0.5f, pre_lo, in_lo, glo, dp);
+        if (dz) dz[i] = gv + (dzin ? dzin[i] : 0.f);
+    }
+    if (dpack) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            float s = dp[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+            if (lane == 0) dpack[(size_t)c * NP + k] = s;
+        }
+    }
+}
+
+// EntropyBottleneck.loss: sum |logits(quantiles) - target|, gradient wrt quantiles only
+__global__ __launch_bounds__(256) void eb_aux_kernel(const float *quant, const float *pack, const float *target, float *loss,
+                                                     float *dq, int C)
+{
+    __shared__ float red[256];
+    float local = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < C * 3; i += gridDim.x * 256) {
+        const int c = i / 3, k = i - c * 3;
+        EbPrep e;
+        eb_prepare(pack + (size_t)c * NP, e);
+        float pre[4][3], inp[4][3], dp[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) dp[q] = 0.f;
+        const float v = quant[i];
+        const float d = eb_logits<true>(e, v, pre, inp) - target[k];
+        local += fabsf(d);
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        if (dq) dq[i] = eb_logits_bwd(pack + (size_t)c * NP, e, v, pre, inp, sgn, dp);
+    }
+    red[threadIdx.x] = local;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(loss, red[0]);
+}
+
+struct Ptr14 {
+    const float *p[14];
+};
+struct MPtr14 {
+    float *p[14];
+};
+__constant__ const int kOff[14] = {0, 3, 6, 9, 18, 21, 24, 33, 36, 39, 48, 51, 54, 57};
+__constant__ const int kLen[14] = {3, 3, 3, 9, 3, 3, 9, 3, 3, 9, 3, 3, 3, 1};
+
+__global__ void eb_pack_kernel(Ptr14 t, float *pack, int C)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * NP) return;
+    const int c = i / NP, k = i - c * NP;
+    int s = 0;
+#pragma unroll
+    for (int q = 1; q < 14; ++q)
+        if (k >= kOff[q]) s = q;
+    pack[i] = t.p[s][c * kLen[s] + (k - kOff[s])];
+}
+__global__ void eb_unpack_kernel(const float *dpack, MPtr14 t, int C)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * NP) return;
+    const int c = i / NP, k = i - c * NP;
+    int s = 0;
+#pragma unroll
+    for (int q = 1; q < 14; ++q)
+        if (k >= kOff[q]) s = q;
+    t.p[s][c * kLen[s] + (k - kOff[s])] = dpack[i];
+}
+
+// ---- GaussianConditional -----------------------------------------------------------------------
+__device__ __forceinline__ float std_cum(float x) { return 0.5f * erfcf(-0.70710678118654752440f * x); }
+
+__global__ __launch_bounds__(256) void gc_forward_kernel(const float *y, const float *noise, const float *scales,
+                                                         const float *means, int ldsm, float *out, float *lik, size_t npix,
+                                                         int C, int mode, float sb, float lb)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix * C) return;
+    const size_t pix = i / C;
+    const int c = (int)(i - pix * C);
+    const float mu = means[pix * ldsm + c], sc = scales[pix * ldsm + c];
+    float o = y[i];
+    if (mode == 0)
+        o += noise[i];
+    else
+        o = rintf(o - mu) + mu;
+    out[i] = o;
+    const float v = fabsf(o - mu);
+    const float s = fmaxf(sc, sb);
+    const float l = std_cum((0.5f - v) / s) - std_cum((-0.5f - v) / s);
+    lik[i] = fmaxf(l, lb);
+}
+
+__global__ __launch_bounds__(256) void gc_backward_kernel(const float *out, const float *scales, const float *means, int ldsm,
+                                                          const float *dlik, float *dsc, float *dmu, int ldd, float *dy,
+                                                          size_t npix, int C, float sb, float lb)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix * C) return;
+    const size_t pix = i / C;
+    const int c = (int)(i - pix * C);
+    const float mu = means[pix * ldsm + c], sc = scales[pix * ldsm + c];
+    const float d = out[i] - mu, v = fabsf(d);
+    const float s = fmaxf(sc, sb);
+    const float a = (0.5f - v) / s, b = (-0.5f - v) / s;
+    const float lraw = std_cum(a) - std_cum(b);
+    float g = dlik[i];
+    if (!(lraw >= lb || g < 0.f)) g = 0.f;
+    const float k = 0.39894228040143267794f;
+    const float pa = k * expf(-0.5f * a * a), pb = k * expf(-0.5f * b * b);
+    const float dv = g * (-(pa - pb) / s);
+    float ds = g * (-(pa * a - pb * b) / s);
+    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    if (!(sc >= sb || ds < 0.f)) ds = 0.f;
+    if (dsc) dsc[pix * ldd + c] = ds;
+    if (dmu) dmu[pix * ldd + c] = -dv * sgn;
+    if (dy) dy[i] = dv * sgn;
+}
+
+__global__ __launch_bounds__(256) void log2_sum_kernel(const float *lik, size_t n, double *acc)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += (double)log2f(lik[i]);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(acc, red[0]);
+}
+
+__global__ void dlog_kernel(const float *lik, float *dlik, size_t n, float coef)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dlik[i] = coef / lik[i];
+}
+template <int OP>
+__global__ void ew_kernel(const float *a, const float *b, float *o, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (OP == 0) o[i] = a[i] - b[i];
+    if (OP == 1) o[i] = a[i] + b[i];
+    if (OP == 2) o[i] = rintf(a[i]);     // torch.round: half to even
+}
+__global__ void lrelu_bwd_kernel(const float *yact, const float *dy, float *dx, size_t n, float slope)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dx[i] = yact[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+
+// Philox4x32-10
+__device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0, uint32_t k1)
+{
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__global__ void noise_kernel(float *out, size_t n, uint64_t seed, uint64_t offset)
+{
+    const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q * 4 >= n) return;
+    const uint64_t ctr = offset + q;
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const uint32_t r4[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (q * 4 + e < n) out[q * 4 + e] = (float)(r4[e] >> 8) * (1.0f / 16777216.0f) - 0.5f;
+}
+
+__global__ void build_indexes_kernel(const float *scales, int lds, const float *table, int T, int32_t *idx, size_t npix, int C,
+                                     float sb)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * C) return;
+    const size_t pix = i / C;
+    const int c = (int)(i - pix * C);
+    const float s = fmaxf(scales[pix * lds + c], sb);
+    int k = T - 1;
+    for (int t = 0; t < T - 1; ++t) k -= (s <= table[t]) ? 1 : 0;
+    idx[i] = k;
+}
+
+inline unsigned nblk(size_t n) { return (unsigned)cdivz(n, 256); }
+
+}   // namespace
+
+STEM_EXPORT int stem_eb_pack(const float *const *tensors14, float *pack, int C, void *stream)
+{
+    STEM_CHECK_ARG(tensors14 && pack && C > 0, "stem_eb_pack: bad arguments");
+    Ptr14 t;
+    for (int i = 0; i < 14; ++i) t.p[i] = tensors14[i];
+    hipLaunchKernelGGL(eb_pack_kernel, dim3(nblk((size_t)C * NP)), dim3(256), 0, (hipStream_t)stream, t, pack, C);
+    STEM_LAUNCH_CHECK("eb_pack");
+    return 0;
+}
+STEM_EXPORT int stem_eb_unpack_grads(const float *dpack, float *const *tensors14, int C, void *stream)
+{
+    STEM_CHECK_ARG(tensors14 && dpack && C > 0, "stem_eb_unpack_grads: bad arguments");
+    MPtr14 t;
+    for (int i = 0; i < 14; ++i) t.p[i] = tensors14[i];
+    hipLaunchKernelGGL(eb_unpack_kernel, dim3(nblk((size_t)C * NP)), dim3(256), 0, (hipStream_t)stream, dpack, t, C);
+    STEM_LAUNCH_CHECK("eb_unpack");
+    return 0;
+}
+
+STEM_EXPORT int stem_eb_forward(const float *z, int ldz, const float *noise, const float *pack, const float *medians,
+                                float *z_hat, float *lik, int B, int H, int W, int C, int mode, float bound, void *stream)
+{
+    STEM_CHECK_ARG(z && pack && z_hat && lik, "stem_eb_forward: null pointer");
+    STEM_CHECK_ARG((mode == 0 && noise) || (mode == 1 && medians), "stem_eb_forward: mode %d needs %s", mode, mode ? "medians" : "noise");
+    const size_t npix = (size_t)B * H * W;
+    hipLaunchKernelGGL(eb_forward_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, z, ldz, noise, pack, medians,
+                       z_hat, lik, npix, C, mode, bound);
+    STEM_LAUNCH_CHECK("eb_forward");
+    return 0;
+}
+
+STEM_EXPORT int stem_eb_backward(const float *z_hat, const float *pack, const float *dlik, const float *dzhat_in,
+                                 float *dz, float *dpack, int B, int H, int W, int C, float bound, void *stream)
+{
+    STEM_CHECK_ARG(z_hat && pack && dlik, "stem_eb_backward: null pointer");
+    hipLaunchKernelGGL(eb_backward_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, z_hat, pack, dlik, dzhat_in, dz, dpack,
+                       (size_t)B * H * W, C, bound);
+    STEM_LAUNCH_CHECK("eb_backward");
+    return 0;
+}
+
+STEM_EXPORT int stem_eb_aux_loss(const float *quantiles, const float *pack, const float *target3, float *loss,
+                                 float *dquantiles, int C, void *stream)
+{
+    STEM_CHECK_ARG(quantiles && pack && target3 && loss, "stem_eb_aux_loss: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) {
+        stem_set_error("stem_eb_aux_loss: memset failed");
+        return -2;
+    }
+    hipLaunchKernelGGL(eb_aux_kernel, dim3(cdiv(C * 3, 256)), dim3(256), 0, st, quantiles, pack, target3, loss, dquantiles, C);
+    STEM_LAUNCH_CHECK("eb_aux");
+    return 0;
+}
+
+STEM_EXPORT int stem_gc_forward(const float *y, const float *noise, const float *scales, const float *means, int ldsm,
+                                float *out, float *lik, size_t npix, int C, int mode, float scale_bound, float lik_bound,
+                                void *stream)
+{
+    STEM_CHECK_ARG(y && scales && means && out && lik, "stem_gc_forward: null pointer");
+    STEM_CHECK_ARG(mode == 1 || noise, "stem_gc_forward: noise mode without a noise tensor");
+    hipLaunchKernelGGL(gc_forward_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, y, noise, scales, means, ldsm,
+                       out, lik, npix, C, mode, scale_bound, lik_bound);
+    STEM_LAUNCH_CHECK("gc_forward");
+    return 0;
+}
+
+STEM_EXPORT int stem_gc_backward(const float *out, const float *scales, const float *means, int ldsm, const float *dlik,
+                                 float *dscales, float *dmeans, int lddsm, float *dy, size_t npix, int C,
+                                 float scale_bound, float lik_bound, void *stream)
+{
+    STEM_CHECK_ARG(out && scales && means && dlik, "stem_gc_backward: null pointer");
+    hipLaunchKernelGGL(gc_backward_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, out, scales, means, ldsm,
+                       dlik, dscales, dmeans, lddsm, dy, npix, C, scale_bound, lik_bound);
+    STEM_LAUNCH_CHECK("gc_backward");
+    return 0;
+}
+
+STEM_EXPORT int stem_log2_sum(const float *lik, size_t n, double *acc, void *stream)
+{
+    STEM_CHECK_ARG(lik && acc, "stem_log2_sum: null pointer");
+    unsigned nb = nblk(n);
+    if (nb > 1024) nb = 1024;
+    if (nb == 0) return 0;
+    hipLaunchKernelGGL(log2_sum_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, lik, n, acc);
+    STEM_LAUNCH_CHECK("log2_sum");
+    return 0;
+}
+
+STEM_EXPORT int stem_dlog(const float *lik, float *dlik, size_t n, float coef, void *stream)
+{
+    STEM_CHECK_ARG(lik && dlik, "stem_dlog: null pointer");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dlog_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, lik, dlik, n, coef);
+    STEM_LAUNCH_CHECK("dlog");
+    return 0;
+}
+
+#define STEM_EW(name, OP)                                                                                    \
+    STEM_EXPORT int name(const float *a, const float *b, float *out, size_t n, void *stream)                 \
+    {                                                                                                        \
+        STEM_CHECK_ARG(a && b && out, #name ": null pointer");                                               \
+        if (n == 0) return 0;                                                                                \
+        hipLaunchKernelGGL((ew_kernel<OP>), dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n); \
+        STEM_LAUNCH_CHECK(#name);                                                                            \
+        return 0;                                                                                            \
+    }
+STEM_EW(stem_sub, 0)
+STEM_EW(stem_add, 1)
+
+STEM_EXPORT int stem_round(const float *a, float *out, size_t n, void *stream)
+{
+    STEM_CHECK_ARG(a && out, "stem_round: null pointer");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL((ew_kernel<2>), dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, a, a, out, n);
+    STEM_LAUNCH_CHECK("stem_round");
+    return 0;
+}
+
+STEM_EXPORT int stem_lrelu_bwd(const float *yact, const float *dy, float *dx, size_t n, float slope, void *stream)
+{
+    STEM_CHECK_ARG(yact && dy && dx, "stem_lrelu_bwd: null pointer");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, yact, dy, dx, n, slope);
+    STEM_LAUNCH_CHECK("lrelu_bwd");
+    return 0;
+}
+
+STEM_EXPORT int stem_uniform_noise(float *out, size_t n, uint64_t seed, uint64_t offset, void *stream)
+{
+    STEM_CHECK_ARG(out, "stem_uniform_noise: null pointer");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(noise_kernel, dim3(nblk(cdivz(n, 4))), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset);
+    STEM_LAUNCH_CHECK("noise");
+    return 0;
+}
+
+STEM_EXPORT int stem_build_indexes(const float *scales, int lds, const float *table, int T, int32_t *idx, size_t npix, int C,
+                                   float scale_bound, void *stream)
+{
+    STEM_CHECK_ARG(scales && table && idx && T >= 1, "stem_build_indexes: bad arguments");
+    hipLaunchKernelGGL(build_indexes_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, scales, lds, table, T, idx,
+                       npix, C, scale_bound);
+    STEM_LAUNCH_CHECK("build_indexes");
+    return 0;
+}

@@ -1,0 +1,443 @@
+// Implicit-GEMM convolution family for gfx950 (MI355X), fp32 in / fp32 accumulate on the
+// matrix cores (v_mfma_f32_32x32x2_f32: bit-exact fp32 FMA chain, 157 TFLOP/s peak).
+//
+// One kernel covers every dense contraction on the STEM hot path:
+//   out[b, qy*osy+ooy, qx*osx+oox, n] = epi( bias[n] + sum_t sum_c  X[b, qy*isy+dy_t, qx*isx+dx_t, c] * Wp[wt_t][n][c] )
+// with a per-phase tap table (dy,dx,wt).  Direct convolutions use one phase with isy=stride;
+// transposed convolutions and the input-gradients of strided convolutions are decomposed into
+// stride*stride sub-pixel phases (blockIdx.z) so no zero-inserted tensor ever exists.
+//
+// Tiling: 256 threads = 4 wavefronts of 64 lanes; block tile BM pixels x BN channels, K chunk
+// of 32 (one tap x 32 input channels, or 8 taps x 4 channels for the 3-channel first layer).
+// Operands are staged global -> VGPR -> LDS ([row][32+4] fp32, rows 144 B so ds_write_b128 /
+// ds_read_b128 are aligned and bank-conflict free), double buffered, one barrier per chunk.
+// Each lane reads 4 consecutive k of its row with one ds_read_b128; lane half h supplies
+// k = 4h+s to MFMA step s (any bijection of k is valid as long as A and B agree), so one
+// LDS read per operand tile feeds four MFMAs.
+#include "stem_common.h"
+
+namespace {
+
+constexpr int KC = 32;        // K chunk
+constexpr int PITCH = 36;     // LDS row pitch in floats (32 + 4 pad)
+constexpr int MAXTAP = 28;
+
+enum { EPI_BIAS = 0, EPI_LRELU = 1, EPI_DACT = 2, EPI_GDN = 3, EPI_IGDN = 4 };
+
+struct TapPhase {
+    int ooy, oox, qh, qw, ntaps;
+    signed char dy[MAXTAP];
+    signed char dx[MAXTAP];
+    unsigned char wt[MAXTAP];
+};
+
+struct IgemmArgs {
+    const float *x, *w, *bias, *z, *beta;
+    float *y;
+    int ldx, ldw, ldy, ldz;
+    int B, H, W, C, N, OH, OW;
+    int isy, isx, osy, osx;
+    int nphase, epi, asquare, breparam;
+    float slope, beta_bound;
+    TapPhase ph[4];
+};
+
+template <int BM, int BN, int WM, int WN, bool VEC, bool C4>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
+{
+    constexpr int TM = WM / 32, TN = WN / 32, AR = BM / 32, BR = BN / 32;
+    constexpr int WCOLS = BN / WN;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                       // [2][BM][PITCH]
+    float *Bs = smem + 2 * BM * PITCH;      // [2][BN][PITCH]
+    int *tapi = reinterpret_cast<int *>(smem + 2 * (BM + BN) * PITCH);   // [32][4]: dy, dx, wt, valid
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const TapPhase &ph = a.ph[blockIdx.z];
+    const int Mtot = a.B * ph.qh * ph.qw;
+    const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+    if (bm0 >= Mtot) return;
+
+    if (tid < 32) {
+        const bool v = tid < ph.ntaps;
+        tapi[tid * 4 + 0] = v ? ph.dy[tid] : 0;
+        tapi[tid * 4 + 1] = v ? ph.dx[tid] : 0;
+        tapi[tid * 4 + 2] = v ? ph.wt[tid] : 0;
+        tapi[tid * 4 + 3] = v ? 1 : 0;
+    }
+
+    // ---- staging assignment: thread -> (row srow+32j, float4 column c4) -------------------------
+    const int srow = tid >> 3, c4 = tid & 7;
+    int p_by[AR], p_bx[AR], p_base[AR];
+    bool p_ok[AR];
+    const int qhw = ph.qh * ph.qw;
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+        const int m = bm0 + srow + 32 * j;
+        p_ok[j] = m < Mtot;
+        const int mm = p_ok[j] ? m : 0;
+        const int b = mm / qhw, rem = mm - b * qhw;
+        const int qy = rem / ph.qw, qx = rem - qy * ph.qw;
+        p_by[j] = qy * a.isy;
+        p_bx[j] = qx * a.isx;
+        p_base[j] = b * a.H * a.W;
+    }
+    const int nkc = C4 ? 1 : (a.C + KC - 1) / KC;
+    const int nchunks = C4 ? (ph.ntaps + 7) / 8 : ph.ntaps * nkc;
+    __syncthreads();
+
+    f32x4 ra[AR], rb[BR];
+
+    auto gload = [&](int q) {
+        int t, k0;
+        if (C4) {
+            t = q * 8 + c4;
+            k0 = 0;
+        } else {
+            t = q / nkc;
+            k0 = (q - t * nkc) * KC + 4 * c4;
+        }
+        const int dy = tapi[t * 4 + 0], dx = tapi[t * 4 + 1], wt = tapi[t * 4 + 2];
+        const bool tv = tapi[t * 4 + 3] != 0;
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
+            const int iy = p_by[j] + dy, ix = p_bx[j] + dx;
+            const bool ok = p_ok[j] && tv && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                const float *src = a.x + (size_t)(p_base[j] + iy * a.W + ix) * a.ldx + k0;
+                if (VEC) {
+                    if (k0 < a.C) v = *reinterpret_cast<const f32x4 *>(src);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k0 + e < a.C) v[e] = src[e];
+                }
+            }
+            if (a.asquare) v = v * v;
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            const int n = bn0 + srow + 32 * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < a.N && (C4 || tv)) {
+                const float *src = C4 ? a.w + (size_t)n * a.ldw + q * KC + 4 * c4
+                                      : a.w + ((size_t)wt * a.N + n) * a.ldw + k0;
+                if (VEC) {
+                    if (C4 || k0 < a.C) v = *reinterpret_cast<const f32x4 *>(src);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k0 + e < a.C) v[e] = src[e];
+                }
+                if (a.breparam) {   // NonNegativeParametrizer on gamma (parametrizers.py:42-45)
+                    const float bound = 3.814697265625e-06f, ped = 1.4551915228366852e-11f;   // 2^-18, 2^-36
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float g = fmaxf(v[e], bound);
+                        v[e] = (VEC || k0 + e < a.C) ? g * g - ped : 0.f;
+                    }
+                }
+            }
+            rb[j] = v;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < AR; ++j)
+            *reinterpret_cast<f32x4 *>(&As[(buf * BM + srow + 32 * j) * PITCH + 4 * c4]) = ra[j];
+#pragma unroll
+        for (int j = 0; j < BR; ++j)
+            *reinterpret_cast<f32x4 *>(&Bs[(buf * BN + srow + 32 * j) * PITCH + 4 * c4]) = rb[j];
+    };
+
+    // ---- wave tile -------------------------------------------------------------------------------
+    const int wm0 = (wave / WCOLS) * WM, wn0 = (wave % WCOLS) * WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int q = 0; q < nchunks; ++q) {
+        const int cur = q & 1;
+        if (q + 1 < nchunks) gload(q + 1);
+        const float *Ab = As + (cur * BM + wm0 + lr) * PITCH + 4 * lh;
+        const float *Bb = Bs + (cur * BN + wn0 + lr) * PITCH + 4 * lh;
+#pragma unroll
+        for (int k8 = 0; k8 < KC / 8; ++k8) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * PITCH + k8 * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * PITCH + k8 * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (q + 1 < nchunks) sstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds column n = ..+lr, rows (r&3)+8*(r>>2)+4*lh of each 32x32 tile -------
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = bn0 + wn0 + j * 32 + lr;
+        const bool nok = n < a.N;
+        float bias = (a.bias && nok) ? a.bias[n] : 0.f;
+        if ((a.epi == EPI_GDN || a.epi == EPI_IGDN) && nok) {   // beta' = max(beta, bound)^2 - 2^-36
+            const float bb = fmaxf(a.beta[n], a.beta_bound);
+            bias = bb * bb - 1.4551915228366852e-11f;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = bm0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= Mtot || !nok) continue;
+                const int b = m / qhw, rem = m - b * qhw;
+                const int qy = rem / ph.qw, qx = rem - qy * ph.qw;
+                const size_t opix = (size_t)(b * a.OH + qy * a.osy + ph.ooy) * a.OW + qx * a.osx + ph.oox;
+                float v = acc[i][j][r] + bias;
+                if (a.epi == EPI_LRELU) {
+                    v = v > 0.f ? v : v * a.slope;
+                } else if (a.epi == EPI_DACT) {
+                    const float zz = a.z[opix * a.ldz + n];
+                    v = zz > 0.f ? v : v * a.slope;
+                } else if (a.epi == EPI_GDN) {
+                    v = a.z[opix * a.ldz + n] / sqrtf(v);
+                } else if (a.epi == EPI_IGDN) {
+                    v = a.z[opix * a.ldz + n] * sqrtf(v);
+                }
+                a.y[opix * a.ldy + n] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+void build_direct(IgemmArgs &g, int R, int S, int stride, int pad, int OH, int OW)
+{
+    g.nphase = 1;
+    g.isy = g.isx = stride;
+    g.osy = g.osx = 1;
+    TapPhase &p = g.ph[0];
+    p.ooy = p.oox = 0;
+    p.qh = OH;
+    p.qw = OW;
+    p.ntaps = R * S;
+    for (int r = 0; r < R; ++r)
+        for (int s = 0; s < S; ++s) {
+            p.dy[r * S + s] = (signed char)(r - pad);
+            p.dx[r * S + s] = (signed char)(s - pad);
+            p.wt[r * S + s] = (unsigned char)(r * S + s);
+        }
+}
+
+// out[oy] gathers in[(oy + pad - r)/stride] for taps with (oy + pad - r) % stride == 0
+void build_transposed(IgemmArgs &g, int R, int S, int stride, int pad, int OH, int OW)
+{
+    g.nphase = stride * stride;
+    g.isy = g.isx = 1;
+    g.osy = g.osx = stride;
+    for (int py = 0; py < stride; ++py)
+        for (int px = 0; px < stride; ++px) {
+            TapPhase &p = g.ph[py * stride + px];
+            p.ooy = py;
+            p.oox = px;
+            p.qh = (OH - py + stride - 1) / stride;
+            p.qw = (OW - px + stride - 1) / stride;
+            if (p.qh < 0) p.qh = 0;
+            if (p.qw < 0) p.qw = 0;
+            int nt = 0;
+            for (int r = 0; r < R; ++r) {
+                if (((py + pad - r) % stride + stride) % stride != 0) continue;
+                for (int s = 0; s < S; ++s) {
+                    if (((px + pad - s) % stride + stride) % stride != 0) continue;
+                    // floor division for negative numerators is exact here (remainder is 0)
+                    p.dy[nt] = (signed char)((py + pad - r) / stride);
+                    p.dx[nt] = (signed char)((px + pad - s) / stride);
+                    p.wt[nt] = (unsigned char)(r * S + s);
+                    ++nt;
+                }
+            }
+            p.ntaps = nt;
+        }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(const IgemmArgs &g, bool vec, bool c4, hipStream_t st)
+{
+    int maxM = 0;
+    for (int p = 0; p < g.nphase; ++p) {
+        const int m = g.B * g.ph[p].qh * g.ph[p].qw;
+        if (m > maxM) maxM = m;
+    }
+    if (maxM == 0 || g.N == 0) return 0;
+    dim3 grid(cdiv(maxM, BM), cdiv(g.N, BN), g.nphase), block(256);
+    const size_t lds = (size_t)2 * (BM + BN) * PITCH * sizeof(float) + 32 * 4 * sizeof(int);
+    static bool attr_done = false;     // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    if (c4)
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, true>), grid, block, lds, st, g);
+    else if (vec)
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, false>), grid, block, lds, st, g);
+    else
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false, false>), grid, block, lds, st, g);
+    STEM_LAUNCH_CHECK("igemm");
+    return 0;
+}
+
+int launch(const IgemmArgs &g, bool c4, hipStream_t st)
+{
+    const bool vec = c4 || ((g.C % 4 == 0) && (g.ldx % 4 == 0) && (g.ldw % 4 == 0) &&
+                            (((uintptr_t)g.x & 15) == 0) && (((uintptr_t)g.w & 15) == 0));
+    int maxM = 0;
+    for (int p = 0; p < g.nphase; ++p) {
+        const int m = g.B * g.ph[p].qh * g.ph[p].qw;
+        if (m > maxM) maxM = m;
+    }
+    // 128x128 tiles when they still fill the chip (>= 2 blocks per CU), else 64x64.
+    const long big = (long)cdiv(maxM, 128) * cdiv(g.N, 128) * g.nphase;
+    if (big >= 512 && g.N >= 96) return launch_cfg<128, 128, 64, 64>(g, vec, c4, st);
+    return launch_cfg<64, 64, 32, 32>(g, vec, c4, st);
+}
+
+int check_common(const char *name, const void *x, const void *w, const void *y, int B, int H, int W, int C, int K,
+                 int R, int S, int stride)
+{
+    STEM_CHECK_ARG(x && w && y, "%s: null pointer", name);
+    STEM_CHECK_ARG(B > 0 && H > 0 && W > 0 && C > 0 && K > 0, "%s: bad dims B=%d H=%d W=%d C=%d K=%d", name, B, H, W, C, K);
+    STEM_CHECK_ARG(R >= 1 && S >= 1 && R * S <= 25, "%s: kernel %dx%d unsupported (max 25 taps)", name, R, S);
+    STEM_CHECK_ARG(stride == 1 || stride == 2, "%s: stride %d unsupported", name, stride);
+    return 0;
+}
+
+}   // namespace
+
+// =================================================================================================
+STEM_EXPORT int stem_conv2d_fwd(const float *x, int ldx, const float *wp, const float *bias, float *y, int ldy,
+                                int B, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                                int act, float slope, void *stream)
+{
+    if (check_common("stem_conv2d_fwd", x, wp, y, B, H, W, C, K, R, S, stride)) return -1;
+    IgemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.x = x; g.w = wp; g.bias = bias; g.y = y;
+    g.ldx = ldx; g.ldw = C; g.ldy = ldy;
+    g.B = B; g.H = H; g.W = W; g.C = C; g.N = K;
+    g.OH = (H + 2 * pad - R) / stride + 1;
+    g.OW = (W + 2 * pad - S) / stride + 1;
+    STEM_CHECK_ARG(g.OH > 0 && g.OW > 0, "stem_conv2d_fwd: empty output");
+    build_direct(g, R, S, stride, pad, g.OH, g.OW);
+    g.epi = act == STEM_ACT_LRELU ? EPI_LRELU : EPI_BIAS;
+    g.slope = slope;
+    return launch(g, false, (hipStream_t)stream);
+}
+
+STEM_EXPORT int stem_conv2d_fwd_c4(const float *x4, const float *wp, const float *bias, float *y, int ldy,
+                                   int B, int H, int W, int K, int R, int S, int stride, int pad, void *stream)
+{
+    if (check_common("stem_conv2d_fwd_c4", x4, wp, y, B, H, W, 4, K, R, S, stride)) return -1;
+    IgemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.x = x4; g.w = wp; g.bias = bias; g.y = y;
+    g.ldx = 4; g.ldw = 128; g.ldy = ldy;
+    g.B = B; g.H = H; g.W = W; g.C = 4; g.N = K;
+    g.OH = (H + 2 * pad - R) / stride + 1;
+    g.OW = (W + 2 * pad - S) / stride + 1;
+    build_direct(g, R, S, stride, pad, g.OH, g.OW);
+    g.epi = EPI_BIAS;
+    return launch(g, true, (hipStream_t)stream);
+}
+
+STEM_EXPORT int stem_conv2d_dgrad(const float *dy, int lddy, const float *wp, float *dx, int lddx,
+                                  const float *xact, int ldxact, float slope,
+                                  int B, int H, int W, int C, int K, int R, int S, int stride, int pad, void *stream)
+{
+    if (check_common("stem_conv2d_dgrad", dy, wp, dx, B, H, W, C, K, R, S, stride)) return -1;
+    IgemmArgs g;
+    memset(&g, 0, sizeof(g));
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    g.x = dy; g.w = wp; g.y = dx; g.z = xact;
+    g.ldx = lddy; g.ldw = K; g.ldy = lddx; g.ldz = ldxact;
+    g.B = B; g.H = Ho; g.W = Wo; g.C = K; g.N = C;
+    g.OH = H; g.OW = W;
+    build_transposed(g, R, S, stride, pad, H, W);
+    g.epi = xact ? EPI_DACT : EPI_BIAS;
+    g.slope = slope;
+    return launch(g, false, (hipStream_t)stream);
+}
+
+STEM_EXPORT int stem_deconv2d_fwd(const float *x, int ldx, const float *wp, const float *bias, float *y, int ldy,
+                                  int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad,
+                                  int act, float slope, void *stream)
+{
+    if (check_common("stem_deconv2d_fwd", x, wp, y, B, H, W, C, K, R, S, stride)) return -1;
+    IgemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.x = x; g.w = wp; g.bias = bias; g.y = y;
+    g.ldx = ldx; g.ldw = C; g.ldy = ldy;
+    g.B = B; g.H = H; g.W = W; g.C = C; g.N = K;
+    g.OH = (H - 1) * stride - 2 * pad + R + opad;
+    g.OW = (W - 1) * stride - 2 * pad + S + opad;
+    build_transposed(g, R, S, stride, pad, g.OH, g.OW);
+    g.epi = act == STEM_ACT_LRELU ? EPI_LRELU : EPI_BIAS;
+    g.slope = slope;
+    return launch(g, false, (hipStream_t)stream);
+}
+
+STEM_EXPORT int stem_deconv2d_dgrad(const float *dy, int lddy, const float *wp, float *dx, int lddx,
+                                    const float *xact, int ldxact, float slope,
+                                    int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad,
+                                    void *stream)
+{
+    if (check_common("stem_deconv2d_dgrad", dy, wp, dx, B, H, W, C, K, R, S, stride)) return -1;
+    IgemmArgs g;
+    memset(&g, 0, sizeof(g));
+    const int Ho = (H - 1) * stride - 2 * pad + R + opad, Wo = (W - 1) * stride - 2 * pad + S + opad;
+    g.x = dy; g.w = wp; g.y = dx; g.z = xact;
+    g.ldx = lddy; g.ldw = K; g.ldy = lddx; g.ldz = ldxact;
+    g.B = B; g.H = Ho; g.W = Wo; g.C = K; g.N = C;
+    g.OH = H; g.OW = W;
+    build_direct(g, R, S, stride, pad, H, W);
+    g.epi = xact ? EPI_DACT : EPI_BIAS;
+    g.slope = slope;
+    return launch(g, false, (hipStream_t)stream);
+}
+
+STEM_EXPORT int stem_gdn_fwd(const float *x, int ldx, const float *beta, const float *gamma, float *y, int ldy,
+                             int B, int H, int W, int C, int inverse, float beta_min, void *stream)
+{
+    if (check_common("stem_gdn_fwd", x, gamma, y, B, H, W, C, C, 1, 1, 1)) return -1;
+    STEM_CHECK_ARG(beta, "stem_gdn_fwd: null beta");
+    IgemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.x = x; g.w = gamma; g.y = y; g.z = x; g.beta = beta;
+    g.ldx = ldx; g.ldw = C; g.ldy = ldy; g.ldz = ldx;
+    g.B = B; g.H = H; g.W = W; g.C = C; g.N = C;
+    g.OH = H; g.OW = W;
+    build_direct(g, 1, 1, 1, 0, H, W);
+    g.epi = inverse ? EPI_IGDN : EPI_GDN;
+    g.asquare = 1;
+    g.breparam = 1;
+    g.beta_bound = sqrtf(beta_min + 1.4551915228366852e-11f);
+    return launch(g, false, (hipStream_t)stream);
+}

@@ -1,0 +1,77 @@
+// Fused optimiser kernels over flat fp32 buffers: global-norm reduction and clip + Adam.
+// Replaces torch.nn.utils.clip_grad_norm_ + two torch.optim.Adam.step() calls of
+// stem/trainSTEM.py:213-218 (utils.py:127-134): 41 tensors x ~6 elementwise passes become one
+// HBM-bound pass (16 B read + 12 B written per parameter).
+#include "stem_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const f32x4 *g4, const float *g, size_t n4, size_t n, double *acc)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = g4[i];
+        s += (double)v[0] * v[0] + (double)v[1] * v[1] + (double)v[2] * v[2] + (double)v[3] * v[3];
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) s += (double)g[i] * g[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(acc, red[0]);
+}
+
+// torch.optim.Adam single-tensor update (no amsgrad, no weight decay):
+//   m.lerp_(g, 1-b1); v = v*b2 + (1-b2) g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, float *m, float *v, size_t n, const double *sumsq,
+                                                   float max_norm, float gscale, float step_size, float b1, float b2,
+                                                   float inv_sqrt_bc2, float eps)
+{
+    float coef = gscale;
+    if (max_norm > 0.f && sumsq) {
+        const float total = (float)sqrt(sumsq[0]) * gscale;
+        coef *= fminf(max_norm / (total + 1e-6f), 1.0f);
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i] * coef;
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    }
+}
+
+}   // namespace
+
+STEM_EXPORT int stem_sumsq(const float *g, size_t n, double *acc, void *stream)
+{
+    STEM_CHECK_ARG(g && acc, "stem_sumsq: null pointer");
+    if (n == 0) return 0;
+    const bool al = (((uintptr_t)g) & 15) == 0;
+    const size_t n4 = al ? n / 4 : 0;
+    size_t nb = cdivz(n4 ? n4 : 1, 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f32x4 *>(g), g, n4, n, acc);
+    STEM_LAUNCH_CHECK("sumsq");
+    return 0;
+}
+
+STEM_EXPORT int stem_adam_step(float *p, const float *g, float *m, float *v, size_t n, const double *sumsq, float max_norm,
+                               float gscale, float lr, float beta1, float beta2, float eps, int step, void *stream)
+{
+    STEM_CHECK_ARG(p && g && m && v && step >= 1, "stem_adam_step: bad arguments");
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    size_t nb = cdivz(n, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm,
+                       gscale, (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps);
+    STEM_LAUNCH_CHECK("adam");
+    return 0;
+}

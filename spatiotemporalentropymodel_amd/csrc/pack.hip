@@ -1,0 +1,202 @@
+// Weight (un)packing and NCHW <-> NHWC layout kernels.  All HBM-bound byte movers: every global
+// access is a contiguous run (taps of one filter on the reference side, a channel row on the
+// packed side); the permutation happens in LDS.
+#include <stdarg.h>
+
+#include "stem_common.h"
+
+static thread_local char g_err[512] = "";
+void stem_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+STEM_EXPORT const char *stem_last_error(void) { return g_err; }
+STEM_EXPORT int stem_abi_version(void) { return 1; }
+
+namespace {
+
+// out[t][a][b] = w[a*sa + b*sb + t]  (taps are the innermost axis of OIHW and IOHW).
+// One block per `a`: gather the Bd x T slab into LDS reading runs of T floats, write rows of Bd.
+__global__ __launch_bounds__(256) void pack_kernel(const float *w, float *out, int A, int Bd, int T, long sa, long sb,
+                                                   int R, int S, int masked)
+{
+    extern __shared__ float tile[];   // [Bd][T]
+    const int a = blockIdx.x;
+    const int n = Bd * T;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int b = i / T, t = i - b * T;
+        float v = w[a * sa + b * sb + t];
+        if (masked) {   // MaskedConv2d type A (layers.py:39-42): row > R/2, or row == R/2 and col >= S/2
+            const int r = t / S, s = t - r * S;
+            if (r > R / 2 || (r == R / 2 && s >= S / 2)) v = 0.f;
+        }
+        tile[i] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int t = i / Bd, b = i - t * Bd;
+        out[((size_t)t * A + a) * Bd + b] = tile[b * T + t];
+    }
+}
+
+// first layer: w[K][C<=4][T] -> out[K][32][4], zero padded
+__global__ void pack_c4_kernel(const float *w, float *out, int K, int C, int T)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * 128) return;
+    const int k = i >> 7, r = i & 127, t = r >> 2, c = r & 3;
+    out[i] = (t < T && c < C) ? w[((size_t)k * C + c) * T + t] : 0.f;
+}
+
+// dw[(a*Bd + b)*T + t] = sum_s dwp[s][t][a][b]
+__global__ __launch_bounds__(256) void unpack_kernel(const float *dwp, float *dw, int A, int Bd, int T, int splits)
+{
+    extern __shared__ float tile[];   // [Bd][T+1]
+    const int a = blockIdx.x;
+    const int n = Bd * T;
+    const size_t slab = (size_t)T * A * Bd;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int t = i / Bd, b = i - t * Bd;
+        float v = 0.f;
+        for (int s = 0; s < splits; ++s) v += dwp[s * slab + ((size_t)t * A + a) * Bd + b];
+        tile[b * (T + 1) + t] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int b = i / T, t = i - b * T;
+        dw[(size_t)a * n + i] = tile[b * (T + 1) + t];
+    }
+}
+
+// [B][C][HW] -> [B][HW][ld]  (32x32 LDS tiles)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *x, float *y, int ldy, int C, int HW)
+{
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        tile[r][tx] = (c < C && p < HW) ? x[((size_t)b * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        if (p < HW && c < C) y[((size_t)b * HW + p) * ldy + c] = tile[tx][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *x, int ldx, float *y, int C, int HW, int clamp01)
+{
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        tile[r][tx] = (c < C && p < HW) ? x[((size_t)b * HW + p) * ldx + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (p < HW && c < C) {
+            float v = tile[tx][r];
+            if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+            y[((size_t)b * C + c) * HW + p] = v;
+        }
+    }
+}
+
+__global__ void nchw3_to_nhwc4_kernel(const float *x, f32x4 *y, size_t HW, size_t total)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t b = i / HW, p = i - b * HW;
+    const float *src = x + b * 3 * HW + p;
+    f32x4 v = {src[0], src[HW], src[2 * HW], 0.f};
+    y[i] = v;
+}
+
+}   // namespace
+
+STEM_EXPORT size_t stem_packed_weight_elems(int K, int C, int R, int S, int role)
+{
+    if (role == STEM_PACK_CONV_FWD_C4) return (size_t)K * 128;
+    return (size_t)K * C * R * S;
+}
+
+STEM_EXPORT int stem_pack_weight(const float *w, float *wp, int K, int C, int R, int S, int role, int masked, void *stream)
+{
+    STEM_CHECK_ARG(w && wp, "stem_pack_weight: null pointer");
+    STEM_CHECK_ARG(K > 0 && C > 0 && R > 0 && S > 0 && R * S <= 25, "stem_pack_weight: bad dims");
+    hipStream_t st = (hipStream_t)stream;
+    const int T = R * S;
+    int A, Bd;
+    long sa, sb;
+    switch (role) {
+    case STEM_PACK_CONV_FWD:     A = K; Bd = C; sa = (long)C * T; sb = T; break;            // w[K][C][T] -> [t][K][C]
+    case STEM_PACK_CONV_DGRAD:   A = C; Bd = K; sa = T; sb = (long)C * T; break;            // w[K][C][T] -> [t][C][K]
+    case STEM_PACK_DECONV_FWD:   A = K; Bd = C; sa = T; sb = (long)K * T; break;            // w[C][K][T] -> [t][K][C]
+    case STEM_PACK_DECONV_DGRAD: A = C; Bd = K; sa = (long)K * T; sb = T; break;            // w[C][K][T] -> [t][C][K]
+    case STEM_PACK_CONV_FWD_C4:
+        STEM_CHECK_ARG(C <= 4 && T <= 32, "stem_pack_weight: C4 role needs C<=4, taps<=32");
+        hipLaunchKernelGGL(pack_c4_kernel, dim3(cdiv(K * 128, 256)), dim3(256), 0, st, w, wp, K, C, T);
+        STEM_LAUNCH_CHECK("pack_c4");
+        return 0;
+    default:
+        stem_set_error("stem_pack_weight: unknown role %d", role);
+        return -1;
+    }
+    const size_t lds = (size_t)Bd * T * sizeof(float);
+    STEM_CHECK_ARG(lds <= 160 * 1024, "stem_pack_weight: slab of %zu B exceeds LDS", lds);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(pack_kernel, dim3(A), dim3(256), lds, st, w, wp, A, Bd, T, sa, sb, R, S, masked);
+    STEM_LAUNCH_CHECK("pack");
+    return 0;
+}
+
+STEM_EXPORT int stem_unpack_wgrad(const float *dwp, float *dw, int K, int C, int R, int S, int splits, int deconv,
+                                  void *stream)
+{
+    STEM_CHECK_ARG(dwp && dw && splits >= 1, "stem_unpack_wgrad: bad arguments");
+    const int T = R * S;
+    // Conv2d: slabs [t][K][C] -> dw[K][C][T].  ConvTranspose2d: slabs [t][C][K] -> dw[C][K][T].
+    const int A = deconv ? C : K, Bd = deconv ? K : C;
+    const size_t lds = (size_t)Bd * (T + 1) * sizeof(float);
+    STEM_CHECK_ARG(lds <= 160 * 1024, "stem_unpack_wgrad: slab of %zu B exceeds LDS", lds);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)unpack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(unpack_kernel, dim3(A), dim3(256), lds, (hipStream_t)stream, dwp, dw, A, Bd, T, splits);
+    STEM_LAUNCH_CHECK("unpack");
+    return 0;
+}
+
+STEM_EXPORT int stem_nchw_to_nhwc(const float *x, float *y, int ldy, int B, int C, int H, int W, void *stream)
+{
+    STEM_CHECK_ARG(x && y && ldy >= C, "stem_nchw_to_nhwc: bad arguments");
+    const int HW = H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, x, y, ldy, C, HW);
+    STEM_LAUNCH_CHECK("nchw_to_nhwc");
+    return 0;
+}
+
+STEM_EXPORT int stem_nhwc_to_nchw(const float *x, int ldx, float *y, int B, int C, int H, int W, int clamp01, void *stream)
+{
+    STEM_CHECK_ARG(x && y && ldx >= C, "stem_nhwc_to_nchw: bad arguments");
+    const int HW = H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, x, ldx, y, C, HW, clamp01);
+    STEM_LAUNCH_CHECK("nhwc_to_nchw");
+    return 0;
+}
+
+STEM_EXPORT int stem_nchw3_to_nhwc4(const float *x, float *y, int B, int H, int W, void *stream)
+{
+    STEM_CHECK_ARG(x && y, "stem_nchw3_to_nhwc4: null pointer");
+    const size_t HW = (size_t)H * W, total = HW * B;
+    hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       reinterpret_cast<f32x4 *>(y), HW, total);
+    STEM_LAUNCH_CHECK("nchw3_to_nhwc4");
+    return 0;
+}

@@ -1,0 +1,265 @@
+// Weight-gradient kernels (fp32 MFMA) for nn.Conv2d / nn.ConvTranspose2d on NHWC activations.
+//
+//   out[split][t][i][j] = sum_{m in split}  P[m][i] * G[g(m,t)][j]
+// P is the tensor that lives on the loop grid (dY for Conv2d, x for ConvTranspose2d),
+// G the tensor gathered at (py*stride - pad + r, px*stride - pad + s) (x for Conv2d, dY for
+// ConvTranspose2d).  The reduction runs over pixels, which is the slow axis of both NHWC
+// operands, so both tiles are staged "pixel-major" ([32 px][channels]) and the MFMA operand
+// fetch is a conflict-free ds_read_b32 (consecutive lanes = consecutive channels).
+// Split-K over pixel ranges writes separate slabs that stem_unpack_wgrad sums in a fixed order
+// (bit-reproducible, no float atomics).
+#include "stem_common.h"
+
+namespace {
+
+constexpr int KP = 32;   // pixels per chunk
+
+struct WgradArgs {
+    const float *p, *g;
+    float *out;
+    int ldp, ldg, CP, CG;
+    int B, PH, PW, GH, GW;
+    int stride, pad, R, S;
+    int splits, chunks_per_split, nchunks;
+};
+
+template <int BM, int BN, int WM, int WN, bool VEC>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
+{
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WCOLS = BN / WN;
+    constexpr int PA = BM + 4, PB = BN + 4;                 // LDS pitches
+    constexpr int F4A = BM / 4, F4B = BN / 4;               // float4 per pixel row
+    constexpr int RPA = 256 / F4A, RPB = 256 / F4B;         // pixel rows per pass
+    constexpr int NPA = KP / RPA, NPB = KP / RPB;           // passes
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Ps = smem;                    // [2][KP][PA]
+    float *Gs = smem + 2 * KP * PA;      // [2][KP][PB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_j = (a.CG + BN - 1) / BN;
+    const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j;
+    const int i0 = ti * BM, j0 = tj * BN;
+    const int t = blockIdx.y, split = blockIdx.z;
+    const int tr = t / a.S, ts = t - tr * a.S;
+    const int Mtot = a.B * a.PH * a.PW, phw = a.PH * a.PW;
+    const int c_begin = split * a.chunks_per_split;
+    int c_end = c_begin + a.chunks_per_split;
+    if (c_end > a.nchunks) c_end = a.nchunks;
+
+    const int rowA = tid / F4A, colA = (tid - rowA * F4A) * 4;
+    const int rowB = tid / F4B, colB = (tid - rowB * F4B) * 4;
+    f32x4 ra[NPA], rb[NPB];
+
+    auto gload = [&](int chunk) {
+#pragma unroll
+        for (int q = 0; q < NPA; ++q) {
+            const int m = chunk * KP + rowA + q * RPA;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < Mtot) {
+                const float *src = a.p + (size_t)m * a.ldp + i0 + colA;
+                if (VEC) {
+                    if (i0 + colA < a.CP) v = *reinterpret_cast<const f32x4 *>(src);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (i0 + colA + e < a.CP) v[e] = src[e];
+                }
+            }
+            ra[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) {
+            const int m = chunk * KP + rowB + q * RPB;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < Mtot) {
+                const int b = m / phw, rem = m - b * phw;
+                const int py = rem / a.PW, px = rem - py * a.PW;
+                const int gy = py * a.stride - a.pad + tr, gx = px * a.stride - a.pad + ts;
+                if (gy >= 0 && gy < a.GH && gx >= 0 && gx < a.GW) {
+                    const float *src = a.g + (size_t)((b * a.GH + gy) * a.GW + gx) * a.ldg + j0 + colB;
+                    if (VEC) {
+                        if (j0 + colB < a.CG) v = *reinterpret_cast<const f32x4 *>(src);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (j0 + colB + e < a.CG) v[e] = src[e];
+                    }
+                }
+            }
+            rb[q] = v;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NPA; ++q)
+            *reinterpret_cast<f32x4 *>(&Ps[(buf * KP + rowA + q * RPA) * PA + colA]) = ra[q];
+#pragma unroll
+        for (int q = 0; q < NPB; ++q)
+            *reinterpret_cast<f32x4 *>(&Gs[(buf * KP + rowB + q * RPB) * PB + colB]) = rb[q];
+    };
+
+    const int wm0 = (wave / WCOLS) * WM, wn0 = (wave % WCOLS) * WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end) {
+        gload(c_begin);
+        sstore(0);
+        __syncthreads();
+        for (int c = c_begin; c < c_end; ++c) {
+            const int cur = (c - c_begin) & 1;
+            if (c + 1 < c_end) gload(c + 1);
+            const float *Ab = Ps + (cur * KP + lh) * PA + wm0 + lr;
+            const float *Bb = Gs + (cur * KP + lh) * PB + wn0 + lr;
+#pragma unroll
+            for (int ks = 0; ks < KP / 2; ++ks) {
+                float af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = Ab[ks * 2 * PA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = Bb[ks * 2 * PB + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            if (c + 1 < c_end) sstore(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    float *outp = a.out + ((size_t)split * a.R * a.S + t) * a.CP * a.CG;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int jj = j0 + wn0 + j * 32 + lr;
+        if (jj >= a.CG) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ii = i0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (ii < a.CP) outp[(size_t)ii * a.CG + jj] = acc[i][j][r];
+            }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(const WgradArgs &a, bool vec, hipStream_t st)
+{
+    dim3 grid(cdiv(a.CP, BM) * cdiv(a.CG, BN), a.R * a.S, a.splits), block(256);
+    const size_t lds = (size_t)2 * KP * (BM + 4 + BN + 4) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)wgrad_kernel<BM, BN, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)wgrad_kernel<BM, BN, WM, WN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    if (vec)
+        hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, true>), grid, block, lds, st, a);
+    else
+        hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, false>), grid, block, lds, st, a);
+    STEM_LAUNCH_CHECK("wgrad");
+    return 0;
+}
+
+bool use_big_tiles(int CP, int CG, int T, int nchunks)
+{
+    // 128x128 tiles halve the L2->LDS traffic per flop; use them when split-K can still fill the chip
+    const long tiles = (long)cdiv(CP, 128) * cdiv(CG, 128) * T;
+    return CP >= 96 && CG >= 96 && tiles * (nchunks >= 8 ? nchunks / 8 : 1) >= 256;
+}
+
+int pick_splits(int CP, int CG, int T, int nchunks)
+{
+    const bool big = use_big_tiles(CP, CG, T, nchunks);
+    const int tb = big ? 128 : 64;
+    const long tiles = (long)cdiv(CP, tb) * cdiv(CG, tb) * T;
+    long s = (768 + tiles - 1) / tiles;
+    const int maxs = nchunks >= 8 ? nchunks / 8 : 1;     // at least 8 chunks (256 px) per split
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+
+int run(const float *p, int ldp, int CP, const float *g, int ldg, int CG, float *out, int B, int PH, int PW,
+        int GH, int GW, int R, int S, int stride, int pad, int splits, hipStream_t st)
+{
+    WgradArgs a;
+    a.p = p; a.g = g; a.out = out;
+    a.ldp = ldp; a.ldg = ldg; a.CP = CP; a.CG = CG;
+    a.B = B; a.PH = PH; a.PW = PW; a.GH = GH; a.GW = GW;
+    a.stride = stride; a.pad = pad; a.R = R; a.S = S;
+    a.nchunks = cdiv(B * PH * PW, KP);
+    a.splits = splits;
+    a.chunks_per_split = cdiv(a.nchunks, splits);
+    const bool vec = (CP % 4 == 0) && (CG % 4 == 0) && (ldp % 4 == 0) && (ldg % 4 == 0) &&
+                     (((uintptr_t)p & 15) == 0) && (((uintptr_t)g & 15) == 0);
+    if (use_big_tiles(CP, CG, R * S, a.nchunks)) return launch_cfg<128, 128, 64, 64>(a, vec, st);
+    return launch_cfg<64, 64, 32, 32>(a, vec, st);
+}
+
+// column sums: db[k] = sum_m dy[m][k].  One block per 32-channel tile, 8 pixel rows in flight.
+__global__ __launch_bounds__(256) void colsum_kernel(const float *dy, int ld, size_t npix, int K, float *out)
+{
+    __shared__ float red[8][33];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = threadIdx.x >> 5;
+    float s = 0.f;
+    if (c < K)
+        for (size_t m = r; m < npix; m += 8) s += dy[m * ld + c];
+    red[r][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (r == 0 && c < K) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q][threadIdx.x & 31];
+        out[c] = t;
+    }
+}
+
+}   // namespace
+
+STEM_EXPORT int stem_wgrad_splits(int B, int Ho, int Wo, int C, int K, int R, int S)
+{
+    return pick_splits(K, C, R * S, cdiv(B * Ho * Wo, KP));
+}
+
+STEM_EXPORT int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
+                                  int B, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                                  int splits, void *stream)
+{
+    STEM_CHECK_ARG(x && dy && dwp, "stem_conv2d_wgrad: null pointer");
+    STEM_CHECK_ARG(splits >= 1, "stem_conv2d_wgrad: splits must be >= 1");
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (db) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(K, 32)), dim3(256), 0, st, dy, lddy, (size_t)B * Ho * Wo, K, db);
+        STEM_LAUNCH_CHECK("colsum");
+    }
+    // P = dY on the output grid (K channels), G = x gathered at oy*stride - pad + r  ->  [t][K][C]
+    return run(dy, lddy, K, x, ldx, C, dwp, B, Ho, Wo, H, W, R, S, stride, pad, splits, st);
+}
+
+STEM_EXPORT int stem_deconv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
+                                    int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad,
+                                    int splits, void *stream)
+{
+    STEM_CHECK_ARG(x && dy && dwp, "stem_deconv2d_wgrad: null pointer");
+    STEM_CHECK_ARG(splits >= 1, "stem_deconv2d_wgrad: splits must be >= 1");
+    const int Ho = (H - 1) * stride - 2 * pad + R + opad, Wo = (W - 1) * stride - 2 * pad + S + opad;
+    hipStream_t st = (hipStream_t)stream;
+    if (db) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(K, 32)), dim3(256), 0, st, dy, lddy, (size_t)B * Ho * Wo, K, db);
+        STEM_LAUNCH_CHECK("colsum");
+    }
+    // P = x on the input grid (C channels), G = dY gathered at iy*stride - pad + r  ->  [t][C][K]
+    return run(x, ldx, C, dy, lddy, K, dwp, B, H, W, Ho, Wo, R, S, stride, pad, splits, st);
+}

@@ -1,0 +1,376 @@
+"""Thin Python veneer over the C ABI (include/stem_hip.h): tensor plumbing only.
+
+Activations are torch CUDA tensors of logical shape [B,C,H,W] whose memory is NHWC
+("channels_last"), optionally a channel slice of a wider buffer (pixel pitch `ld` > C).
+Every function launches hand-written HIP kernels on torch's current stream; nothing here
+computes with torch ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_DECONV_FWD, PACK_DECONV_DGRAD, PACK_CONV_FWD_C4 = 0, 1, 2, 3, 4
+ACT_NONE, ACT_LRELU = 0, 1
+LRELU_SLOPE = 0.01
+EB_NPARAM = 58
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(rc):
+    if rc != 0:
+        _lib.check(rc)
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("STEM HIP kernels need CUDA/ROCm tensors (no CPU fallback exists)")
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError(f"STEM HIP kernels are fp32, got {t.dtype}")
+
+
+# ----------------------------------------------------------------------------- layout helpers
+def nhwc_ld(t: torch.Tensor):
+    """Pixel pitch of a [B,C,H,W] tensor laid out NHWC (possibly a channel slice), or None."""
+    if t.dim() != 4:
+        return None
+    B, Cc, H, W = t.shape
+    sb, sc, sh, sw = t.stride()
+    if Cc > 1 and sc != 1:
+        return None
+    ld = None
+    if W > 1:
+        ld = sw
+    elif H > 1:
+        ld = sh
+    elif B > 1:
+        ld = sb
+    else:
+        ld = Cc
+    if ld < Cc:
+        return None
+    if W > 1 and sw != ld:
+        return None
+    if H > 1 and sh != W * ld:
+        return None
+    if B > 1 and sb != H * W * ld:
+        return None
+    return ld
+
+
+def empty_nhwc(B, Cc, H, W, device, ld=None):
+    """Uninitialised [B,C,H,W] tensor with NHWC memory; ld > C allocates a wider pitch."""
+    ld = Cc if ld is None else ld
+    buf = torch.empty((B, H, W, ld), device=device, dtype=torch.float32)
+    return buf.permute(0, 3, 1, 2)[:, :Cc]
+
+
+def channel_slice(buf: torch.Tensor, c0: int, c1: int):
+    """[B,C,H,W] NHWC buffer -> view of channels [c0,c1) sharing memory (replaces torch.cat / chunk)."""
+    return buf[:, c0:c1]
+
+
+def to_nhwc(t: torch.Tensor) -> torch.Tensor:
+    """Return t unchanged if its memory already is NHWC, else convert with the HIP transpose kernel."""
+    _require_cuda(t)
+    if nhwc_ld(t) is not None:
+        return t
+    src = t.contiguous()          # NCHW
+    B, Cc, H, W = src.shape
+    out = empty_nhwc(B, Cc, H, W, t.device)
+    _chk(_lib.hip().stem_nchw_to_nhwc(src.data_ptr(), out.data_ptr(), Cc, B, Cc, H, W, _stream()))
+    return out
+
+
+def to_nchw(t: torch.Tensor, clamp01: bool = False) -> torch.Tensor:
+    """NHWC-memory tensor -> contiguous NCHW tensor (optionally clamped to [0,1], getX: priors.py:399)."""
+    _require_cuda(t)
+    ld = nhwc_ld(t)
+    if ld is None:
+        raise RuntimeError("to_nchw expects an NHWC-memory tensor")
+    B, Cc, H, W = t.shape
+    out = torch.empty((B, Cc, H, W), device=t.device, dtype=torch.float32)
+    _chk(_lib.hip().stem_nhwc_to_nchw(t.data_ptr(), ld, out.data_ptr(), B, Cc, H, W, int(clamp01), _stream()))
+    return out
+
+
+def nchw3_to_nhwc4(x: torch.Tensor) -> torch.Tensor:
+    _require_cuda(x)
+    x = x.contiguous()
+    B, Cc, H, W = x.shape
+    assert Cc == 3
+    out = torch.empty((B, H, W, 4), device=x.device, dtype=torch.float32)
+    _chk(_lib.hip().stem_nchw3_to_nhwc4(x.data_ptr(), out.data_ptr(), B, H, W, _stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------- weights
+def pack_weight(w: torch.Tensor, role: int, masked: bool = False) -> torch.Tensor:
+    """w: Conv2d [K,C,R,S] or ConvTranspose2d [C,K,R,S] (contiguous) -> packed copy for `role`."""
+    _require_cuda(w)
+    w = w.detach().contiguous()
+    if role in (PACK_DECONV_FWD, PACK_DECONV_DGRAD):
+        Cc, K, R, S = w.shape
+    else:
+        K, Cc, R, S = w.shape
+    n = _lib.hip().stem_packed_weight_elems(K, Cc, R, S, role)
+    out = torch.empty(n, device=w.device, dtype=torch.float32)
+    _chk(_lib.hip().stem_pack_weight(w.data_ptr(), out.data_ptr(), K, Cc, R, S, role, int(masked), _stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------- convolutions
+def conv_out_hw(H, W, R, S, stride, pad):
+    return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+
+
+def deconv_out_hw(H, W, R, S, stride, pad, opad):
+    return (H - 1) * stride - 2 * pad + R + opad, (W - 1) * stride - 2 * pad + S + opad
+
+
+def conv2d_fwd(x, wp, bias, K, R, S, stride, pad, act=ACT_NONE, out=None):
+    _require_cuda(x, wp, bias)
+    B, Cc, H, W = x.shape
+    ldx = nhwc_ld(x)
+    assert ldx is not None, "conv2d_fwd: input must be NHWC memory"
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    if out is None:
+        out = empty_nhwc(B, K, Ho, Wo, x.device)
+    _chk(_lib.hip().stem_conv2d_fwd(x.data_ptr(), ldx, wp.data_ptr(), _ptr(bias), out.data_ptr(), nhwc_ld(out),
+                                    B, H, W, Cc, K, R, S, stride, pad, act, LRELU_SLOPE, _stream()))
+    return out
+
+
+def conv2d_fwd_c4(x4, wp, bias, K, R, S, stride, pad, out=None):
+    """First analysis layer: x4 is the [B,H,W,4] buffer from nchw3_to_nhwc4."""
+    B, H, W, _ = x4.shape
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    if out is None:
+        out = empty_nhwc(B, K, Ho, Wo, x4.device)
+    _chk(_lib.hip().stem_conv2d_fwd_c4(x4.data_ptr(), wp.data_ptr(), _ptr(bias), out.data_ptr(), nhwc_ld(out),
+                                       B, H, W, K, R, S, stride, pad, _stream()))
+    return out
+
+
+def conv2d_dgrad(dy, wp_dgrad, x_shape, K, R, S, stride, pad, xact=None, out=None):
+    """dX of Conv2d; xact (the layer input, an LReLU output) fuses the activation backward."""
+    B, Cc, H, W = x_shape
+    if out is None:
+        out = empty_nhwc(B, Cc, H, W, dy.device)
+    _chk(_lib.hip().stem_conv2d_dgrad(dy.data_ptr(), nhwc_ld(dy), wp_dgrad.data_ptr(), out.data_ptr(), nhwc_ld(out),
+                                      _ptr(xact), 0 if xact is None else nhwc_ld(xact), LRELU_SLOPE,
+                                      B, H, W, Cc, K, R, S, stride, pad, _stream()))
+    return out
+
+
+def conv2d_wgrad(x, dy, K, R, S, stride, pad, dw_out=None, db_out=None, need_db=True):
+    """-> (dW [K,C,R,S], db [K]) in the reference's layouts."""
+    B, Cc, H, W = x.shape
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    lib = _lib.hip()
+    splits = lib.stem_wgrad_splits(B, Ho, Wo, Cc, K, R, S)
+    dwp = torch.empty(splits * R * S * K * Cc, device=x.device, dtype=torch.float32)
+    db = (db_out if db_out is not None else torch.empty(K, device=x.device, dtype=torch.float32)) if need_db else None
+    _chk(lib.stem_conv2d_wgrad(x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), dwp.data_ptr(), _ptr(db),
+                               B, H, W, Cc, K, R, S, stride, pad, splits, _stream()))
+    dw = dw_out if dw_out is not None else torch.empty((K, Cc, R, S), device=x.device, dtype=torch.float32)
+    _chk(lib.stem_unpack_wgrad(dwp.data_ptr(), dw.data_ptr(), K, Cc, R, S, splits, 0, _stream()))
+    return dw, db
+
+
+def deconv2d_fwd(x, wp, bias, K, R, S, stride, pad, opad, act=ACT_NONE, out=None):
+    _require_cuda(x, wp, bias)
+    B, Cc, H, W = x.shape
+    Ho, Wo = deconv_out_hw(H, W, R, S, stride, pad, opad)
+    if out is None:
+        out = empty_nhwc(B, K, Ho, Wo, x.device)
+    _chk(_lib.hip().stem_deconv2d_fwd(x.data_ptr(), nhwc_ld(x), wp.data_ptr(), _ptr(bias), out.data_ptr(), nhwc_ld(out),
+                                      B, H, W, Cc, K, R, S, stride, pad, opad, act, LRELU_SLOPE, _stream()))
+    return out
+
+
+def deconv2d_dgrad(dy, wp_dgrad, x_shape, K, R, S, stride, pad, opad, xact=None, out=None):
+    B, Cc, H, W = x_shape
+    if out is None:
+        out = empty_nhwc(B, Cc, H, W, dy.device)
+    _chk(_lib.hip().stem_deconv2d_dgrad(dy.data_ptr(), nhwc_ld(dy), wp_dgrad.data_ptr(), out.data_ptr(), nhwc_ld(out),
+                                        _ptr(xact), 0 if xact is None else nhwc_ld(xact), LRELU_SLOPE,
+                                        B, H, W, Cc, K, R, S, stride, pad, opad, _stream()))
+    return out
+
+
+def deconv2d_wgrad(x, dy, K, R, S, stride, pad, opad, dw_out=None, db_out=None, need_db=True):
+    """-> (dW [C,K,R,S], db [K]) in nn.ConvTranspose2d's layout."""
+    B, Cc, H, W = x.shape
+    lib = _lib.hip()
+    splits = lib.stem_wgrad_splits(B, H, W, K, Cc, R, S)
+    dwp = torch.empty(splits * R * S * K * Cc, device=x.device, dtype=torch.float32)
+    db = (db_out if db_out is not None else torch.empty(K, device=x.device, dtype=torch.float32)) if need_db else None
+    _chk(lib.stem_deconv2d_wgrad(x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), dwp.data_ptr(), _ptr(db),
+                                 B, H, W, Cc, K, R, S, stride, pad, opad, splits, _stream()))
+    dw = dw_out if dw_out is not None else torch.empty((Cc, K, R, S), device=x.device, dtype=torch.float32)
+    _chk(lib.stem_unpack_wgrad(dwp.data_ptr(), dw.data_ptr(), K, Cc, R, S, splits, 1, _stream()))
+    return dw, db
+
+
+def gdn_fwd(x, beta, gamma, inverse=False, beta_min=1e-6, out=None):
+    _require_cuda(x, beta, gamma)
+    B, Cc, H, W = x.shape
+    if out is None:
+        out = empty_nhwc(B, Cc, H, W, x.device)
+    _chk(_lib.hip().stem_gdn_fwd(x.data_ptr(), nhwc_ld(x), beta.data_ptr(), gamma.data_ptr(), out.data_ptr(), nhwc_ld(out),
+                                 B, H, W, Cc, int(inverse), beta_min, _stream()))
+    return out
+
+
+def lrelu_bwd(yact, dy):
+    assert nhwc_ld(yact) == yact.shape[1] and nhwc_ld(dy) == dy.shape[1]
+    out = empty_nhwc(*yact.shape, yact.device)
+    _chk(_lib.hip().stem_lrelu_bwd(yact.data_ptr(), dy.data_ptr(), out.data_ptr(), yact.numel(), LRELU_SLOPE, _stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------- entropy models
+EB_TENSORS = [f"_{k}{i}" for i in range(5) for k in (("matrix", "bias", "factor") if i < 4 else ("matrix", "bias"))]
+
+
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def eb_pack(tensors14):
+    """14 EntropyBottleneck tensors in EB_TENSORS order -> [C,58] pack."""
+    Cc = tensors14[0].shape[0]
+    ts = [t.detach().contiguous() for t in tensors14]
+    pack = torch.empty((Cc, EB_NPARAM), device=ts[0].device, dtype=torch.float32)
+    _chk(_lib.hip().stem_eb_pack(_ptr_array(ts), pack.data_ptr(), Cc, _stream()))
+    return pack
+
+
+def eb_unpack_grads(dpack, grads14):
+    Cc = dpack.shape[0]
+    _chk(_lib.hip().stem_eb_unpack_grads(dpack.data_ptr(), _ptr_array(grads14), Cc, _stream()))
+
+
+def eb_forward(z, pack, medians=None, noise=None, bound=1e-9):
+    """-> (z_hat, lik) dense NHWC tensors.  noise given -> training mode, else round around medians."""
+    B, Cc, H, W = z.shape
+    z_hat, lik = empty_nhwc(B, Cc, H, W, z.device), empty_nhwc(B, Cc, H, W, z.device)
+    mode = 0 if noise is not None else 1
+    if noise is not None:
+        assert nhwc_ld(noise) == Cc
+    _chk(_lib.hip().stem_eb_forward(z.data_ptr(), nhwc_ld(z), _ptr(noise), pack.data_ptr(), _ptr(medians), z_hat.data_ptr(),
+                                    lik.data_ptr(), B, H, W, Cc, mode, bound, _stream()))
+    return z_hat, lik
+
+
+def eb_backward(z_hat, pack, dlik, dzhat_in=None, bound=1e-9):
+    B, Cc, H, W = z_hat.shape
+    dz = empty_nhwc(B, Cc, H, W, z_hat.device)
+    dpack = torch.empty_like(pack)
+    _chk(_lib.hip().stem_eb_backward(z_hat.data_ptr(), pack.data_ptr(), dlik.data_ptr(), _ptr(dzhat_in), dz.data_ptr(),
+                                     dpack.data_ptr(), B, H, W, Cc, bound, _stream()))
+    return dz, dpack
+
+
+def eb_aux_loss(quantiles, pack, target, need_grad=True):
+    Cc = quantiles.shape[0]
+    loss = torch.empty(1, device=quantiles.device, dtype=torch.float32)
+    dq = torch.empty_like(quantiles) if need_grad else None
+    _chk(_lib.hip().stem_eb_aux_loss(quantiles.detach().contiguous().data_ptr(), pack.data_ptr(), target.data_ptr(),
+                                     loss.data_ptr(), _ptr(dq), Cc, _stream()))
+    return loss, dq
+
+
+def gc_forward(y, scales, means, noise=None, scale_bound=0.11, lik_bound=1e-9):
+    """y dense NHWC; scales/means channel slices with a common pitch -> (out, lik)."""
+    B, Cc, H, W = y.shape
+    assert nhwc_ld(y) == Cc
+    ldsm = nhwc_ld(scales)
+    assert ldsm == nhwc_ld(means)
+    out, lik = empty_nhwc(B, Cc, H, W, y.device), empty_nhwc(B, Cc, H, W, y.device)
+    mode = 0 if noise is not None else 1
+    _chk(_lib.hip().stem_gc_forward(y.data_ptr(), _ptr(noise), scales.data_ptr(), means.data_ptr(), ldsm, out.data_ptr(),
+                                    lik.data_ptr(), B * H * W, Cc, mode, scale_bound, lik_bound, _stream()))
+    return out, lik
+
+
+def gc_backward(out, scales, means, dlik, dscales, dmeans, dy=None, scale_bound=0.11, lik_bound=1e-9):
+    B, Cc, H, W = out.shape
+    ldd = nhwc_ld(dscales)
+    assert ldd == nhwc_ld(dmeans)
+    _chk(_lib.hip().stem_gc_backward(out.data_ptr(), scales.data_ptr(), means.data_ptr(), nhwc_ld(scales), dlik.data_ptr(),
+                                     dscales.data_ptr(), dmeans.data_ptr(), ldd, _ptr(dy), B * H * W, Cc, scale_bound,
+                                     lik_bound, _stream()))
+
+
+def log2_sum(lik, acc):
+    """acc (float64[1]) += sum(log2(lik)); lik must be dense."""
+    _chk(_lib.hip().stem_log2_sum(lik.data_ptr(), lik.numel(), acc.data_ptr(), _stream()))
+
+
+def dlog(lik, coef):
+    out = torch.empty_like(lik)
+    _chk(_lib.hip().stem_dlog(lik.data_ptr(), out.data_ptr(), lik.numel(), coef, _stream()))
+    return out
+
+
+def _dense_like(a):
+    B, Cc, H, W = a.shape
+    return empty_nhwc(B, Cc, H, W, a.device)
+
+
+def sub(a, b):
+    assert nhwc_ld(a) == a.shape[1] and nhwc_ld(b) == b.shape[1]
+    out = _dense_like(a)
+    _chk(_lib.hip().stem_sub(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()))
+    return out
+
+
+def add(a, b):
+    assert nhwc_ld(a) == a.shape[1] and nhwc_ld(b) == b.shape[1]
+    out = _dense_like(a)
+    _chk(_lib.hip().stem_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()))
+    return out
+
+
+def round_(a):
+    assert nhwc_ld(a) == a.shape[1]
+    out = _dense_like(a)
+    _chk(_lib.hip().stem_round(a.data_ptr(), out.data_ptr(), a.numel(), _stream()))
+    return out
+
+
+def uniform_noise_like(a, seed: int, offset: int):
+    out = _dense_like(a)
+    _chk(_lib.hip().stem_uniform_noise(out.data_ptr(), out.numel(), seed & (2 ** 64 - 1), offset & (2 ** 64 - 1), _stream()))
+    return out
+
+
+def build_indexes(scales, table, scale_bound=0.11):
+    B, Cc, H, W = scales.shape
+    idx = torch.empty((B, H, W, Cc), device=scales.device, dtype=torch.int32).permute(0, 3, 1, 2)
+    _chk(_lib.hip().stem_build_indexes(scales.data_ptr(), nhwc_ld(scales), table.data_ptr(), table.numel(), idx.data_ptr(),
+                                       B * H * W, Cc, scale_bound, _stream()))
+    return idx
+
+
+def sumsq(g, acc):
+    _chk(_lib.hip().stem_sumsq(g.data_ptr(), g.numel(), acc.data_ptr(), _stream()))
+
+
+def adam_step(p, g, m, v, sumsq_acc, max_norm, gscale, lr, beta1, beta2, eps, step):
+    _chk(_lib.hip().stem_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), _ptr(sumsq_acc),
+                                   max_norm, gscale, lr, beta1, beta2, eps, step, _stream()))
