@@ -41,7 +41,9 @@ enum {
     STEM_PACK_DECONV_DGRAD = 3, /* nn.ConvTranspose2d weight [C,K,R,S] -> [R*S][C][K]                */
     STEM_PACK_CONV_FWD_C4 = 4   /* Conv2d weight [K,3or4,R,S] -> [K][32 taps][4] zero padded         */
 };
-/* `masked` != 0 applies MaskedConv2d's type-A mask (compressai/layers/layers.py:39-47).      */
+/* `masked` != 0 applies MaskedConv2d's type-A mask (compressai/layers/layers.py:39-47);
+ * masked == 2 additionally zeroes the masked taps of `w` itself, which is what the reference's
+ * forward does (`self.weight.data *= self.mask`, layers.py:46).                                */
 int stem_pack_weight(const float *w, float *wp, int K, int C, int R, int S, int role, int masked, void *stream);
 size_t stem_packed_weight_elems(int K, int C, int R, int S, int role);
 /* gradient in packed layout [splits][R*S][K][C] (from stem_conv2d_wgrad) -> reference layout,
@@ -99,6 +101,9 @@ int stem_lrelu_bwd(const float *yact, const float *dy, float *dx, size_t n, floa
 int stem_nchw_to_nhwc(const float *x, float *y, int ldy, int B, int C, int H, int W, void *stream);
 int stem_nhwc_to_nchw(const float *x, int ldx, float *y, int B, int C, int H, int W, int clamp01, void *stream);
 int stem_nchw3_to_nhwc4(const float *x, float *y, int B, int H, int W, void *stream);
+/* dst[p][c] = src[p][c] for c < C with independent pixel pitches: writes a tensor into a channel slice
+ * of a wider buffer (what is left of torch.cat, spatiotemporalpriors.py:846).                         */
+int stem_copy_channels(const float *src, int lds, float *dst, int ldd, size_t npix, int C, void *stream);
 
 /* ---- entropy models ---------------------------------------------------- */
 #define STEM_EB_NPARAM 58

@@ -34,6 +34,7 @@ _HIP_SIG = {
     "stem_nchw_to_nhwc": [vp, vp, ci, ci, ci, ci, ci, vp],
     "stem_nhwc_to_nchw": [vp, ci, vp, ci, ci, ci, ci, ci, vp],
     "stem_nchw3_to_nhwc4": [vp, vp, ci, ci, ci, vp],
+    "stem_copy_channels": [vp, ci, vp, ci, sz, ci, vp],
     "stem_eb_pack": [vp, vp, ci, vp],
     "stem_eb_unpack_grads": [vp, vp, ci, vp],
     "stem_eb_forward": [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cf, vp],

@@ -20,7 +20,7 @@ namespace {
 
 // out[t][a][b] = w[a*sa + b*sb + t]  (taps are the innermost axis of OIHW and IOHW).
 // One block per `a`: gather the Bd x T slab into LDS reading runs of T floats, write rows of Bd.
-__global__ __launch_bounds__(256) void pack_kernel(const float *w, float *out, int A, int Bd, int T, long sa, long sb,
+__global__ __launch_bounds__(256) void pack_kernel(float *w, float *out, int A, int Bd, int T, long sa, long sb,
                                                    int R, int S, int masked)
 {
     extern __shared__ float tile[];   // [Bd][T]
@@ -31,7 +31,10 @@ __global__ __launch_bounds__(256) void pack_kernel(const float *w, float *out, i
         float v = w[a * sa + b * sb + t];
         if (masked) {   // MaskedConv2d type A (layers.py:39-42): row > R/2, or row == R/2 and col >= S/2
             const int r = t / S, s = t - r * S;
-            if (r > R / 2 || (r == R / 2 && s >= S / 2)) v = 0.f;
+            if (r > R / 2 || (r == R / 2 && s >= S / 2)) {
+                v = 0.f;
+                if (masked == 2) w[a * sa + b * sb + t] = 0.f;   // `self.weight.data *= self.mask`, in place
+            }
         }
         tile[i] = v;
     }
@@ -108,6 +111,16 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *x, int l
     }
 }
 
+// dst[p*ldd + c] = src[p*lds + c]   (channel-slice copy: the only thing left of torch.cat)
+__global__ void copy2d_kernel(const float *src, int lds, float *dst, int ldd, size_t npix, int C)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix * C) return;
+    const size_t p = i / C;
+    const int c = (int)(i - p * C);
+    dst[p * ldd + c] = src[p * lds + c];
+}
+
 __global__ void nchw3_to_nhwc4_kernel(const float *x, f32x4 *y, size_t HW, size_t total)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -152,7 +165,7 @@ STEM_EXPORT int stem_pack_weight(const float *w, float *wp, int K, int C, int R,
     STEM_CHECK_ARG(lds <= 160 * 1024, "stem_pack_weight: slab of %zu B exceeds LDS", lds);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(pack_kernel, dim3(A), dim3(256), lds, st, w, wp, A, Bd, T, sa, sb, R, S, masked);
+    hipLaunchKernelGGL(pack_kernel, dim3(A), dim3(256), lds, st, const_cast<float *>(w), wp, A, Bd, T, sa, sb, R, S, masked);
     STEM_LAUNCH_CHECK("pack");
     return 0;
 }
@@ -198,5 +211,14 @@ STEM_EXPORT int stem_nchw3_to_nhwc4(const float *x, float *y, int B, int H, int 
     hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
                        reinterpret_cast<f32x4 *>(y), HW, total);
     STEM_LAUNCH_CHECK("nchw3_to_nhwc4");
+    return 0;
+}
+
+STEM_EXPORT int stem_copy_channels(const float *src, int lds, float *dst, int ldd, size_t npix, int C, void *stream)
+{
+    STEM_CHECK_ARG(src && dst && lds >= C && ldd >= C, "stem_copy_channels: bad arguments");
+    if (npix == 0) return 0;
+    hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)cdivz(npix * C, 256)), dim3(256), 0, (hipStream_t)stream, src, lds, dst, ldd, npix, C);
+    STEM_LAUNCH_CHECK("copy_channels");
     return 0;
 }

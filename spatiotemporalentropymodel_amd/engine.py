@@ -1,0 +1,212 @@
+"""StemEngine: the whole-model forward / backward schedule of a STEM entropy model as a flat sequence
+of C-ABI kernel launches (no per-layer autograd nodes, no concatenations, no activation passes).
+
+Mirrors, for all five model variants, the dataflow of
+  compressai/models/spatiotemporalpriors.py:70-83, 176-194, 292-311, 561-585, 845-868 (forward)
+and what torch autograd derives from it for `EMLoss` (utils.py:18-27) with y_cur / y_conditioned
+detached (stem/trainSTEM.py:208).
+
+Memory plan (NHWC fp32): `he_in` = [y_cur | y_cond] and `epm_in` = [tp | hp | ctx]
+are single buffers whose channel slices are written in place by their producers; the EPM output
+`gp` is read as (scales | means) slices by the Gaussian kernel.  LeakyReLU is fused into the
+producing convolution (forward) and into the consuming dgrad's epilogue (backward).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import functional as F
+
+
+class _Layer:
+    """One convolution of the schedule with its parameter tensors and packed-weight cache."""
+
+    def __init__(self, mod, kind):
+        self.mod, self.kind = mod, kind           # kind: "conv" | "deconv"
+        self.R = mod.kernel_size
+        self.stride, self.pad = mod.stride, mod.padding
+        self.opad = getattr(mod, "output_padding", 0)
+        self.K, self.C = mod.out_channels, mod.in_channels
+        self.masked = getattr(mod, "_masked", 0)
+
+    def fwd(self, x, act=F.ACT_NONE, out=None):
+        m = self.mod
+        if self.kind == "conv":
+            wp = m._packs.get(m.weight, F.PACK_CONV_FWD, self.masked)
+            return F.conv2d_fwd(x, wp, m.bias, self.K, self.R, self.R, self.stride, self.pad, act, out=out)
+        wp = m._packs.get(m.weight, F.PACK_DECONV_FWD)
+        return F.deconv2d_fwd(x, wp, m.bias, self.K, self.R, self.R, self.stride, self.pad, self.opad, act, out=out)
+
+    def dgrad(self, dy, x_shape, xact=None):
+        m = self.mod
+        if self.kind == "conv":
+            wp = m._packs.get(m.weight, F.PACK_CONV_DGRAD, 1 if self.masked else 0)
+            return F.conv2d_dgrad(dy, wp, x_shape, self.K, self.R, self.R, self.stride, self.pad, xact=xact)
+        wp = m._packs.get(m.weight, F.PACK_DECONV_DGRAD)
+        return F.deconv2d_dgrad(dy, wp, x_shape, self.K, self.R, self.R, self.stride, self.pad, self.opad, xact=xact)
+
+    def wgrad(self, x, dy):
+        """writes straight into .grad of weight and bias (allocated once; flat-buffer views if a
+        FlatParameters owner installed them)."""
+        m = self.mod
+        gw, gb = _grad_of(m.weight), _grad_of(m.bias)
+        if self.kind == "conv":
+            F.conv2d_wgrad(x, dy, self.K, self.R, self.R, self.stride, self.pad, dw_out=gw, db_out=gb)
+        else:
+            F.deconv2d_wgrad(x, dy, self.K, self.R, self.R, self.stride, self.pad, self.opad, dw_out=gw, db_out=gb)
+
+
+def _grad_of(p):
+    if p.grad is None:
+        owner = getattr(p, "_flat_grad_view", None)
+        p.grad = owner if owner is not None else torch.empty_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+class StemEngine:
+    def __init__(self, model, has_tpm: bool, has_spm: bool, residual: bool):
+        self.m = model
+        self.has_tpm, self.has_spm, self.residual = has_tpm, has_spm, residual
+        L = lambda mod: _Layer(mod, "conv")
+        D = lambda mod: _Layer(mod, "deconv")
+        self.HE = [L(model.HE[0]), L(model.HE[2]), L(model.HE[4])]
+        self.HD = [D(model.HD[0]), D(model.HD[2]), L(model.HD[4])]
+        self.TPM = [L(model.TPM[0]), L(model.TPM[2]), L(model.TPM[4])] if has_tpm else None
+        self.CTX = L(model.context_prediction) if has_spm else None
+        self.EPM = [L(model.EPM[0]), L(model.EPM[2]), L(model.EPM[4])]
+        self.nprior = 1 + int(has_tpm) + int(has_spm)
+
+    # -------------------------------------------------------------------------------------------
+    def forward(self, y_cur, y_cond, training: bool):
+        m = self.m
+        yc, yd = F.to_nhwc(y_cur.detach()), F.to_nhwc(y_cond.detach())
+        B, Cin, H, W = yc.shape
+        dev = yc.device
+        eb, gc = m.entropy_bottleneck, m.gaussian_conditional
+        k = {}
+        # hyper encoder on cat(y_cur, y_cond): the two halves are written into one buffer
+        he_in = F.empty_nhwc(B, 2 * Cin, H, W, dev)
+        F.copy_channels(yc, he_in[:, :Cin])
+        F.copy_channels(yd, he_in[:, Cin:])
+        he0 = self.HE[0].fwd(he_in, F.ACT_LRELU)
+        he2 = self.HE[1].fwd(he0, F.ACT_LRELU)
+        z = self.HE[2].fwd(he2)
+        pack = F.eb_pack(eb._tensors14())
+        if training:
+            z_hat, lik_z = F.eb_forward(z, pack, noise=eb._noise_like(z))
+        else:
+            z_hat, lik_z = F.eb_forward(z, pack, medians=eb._medians_vec())
+        # hyper decoder; its last conv writes the `hp` slice of the EPM input
+        hd0 = self.HD[0].fwd(z_hat, F.ACT_LRELU)
+        hd2 = self.HD[1].fwd(hd0, F.ACT_LRELU)
+        P = 2 * Cin
+        epm_in = F.empty_nhwc(B, self.nprior * P, H, W, dev)
+        o_tp, o_hp = (0, P) if self.has_tpm else (None, 0)
+        o_ctx = o_hp + P
+        self.HD[2].fwd(hd2, out=epm_in[:, o_hp:o_hp + P])
+        tp0 = tp2 = None
+        if self.has_tpm:
+            tp0 = self.TPM[0].fwd(yd, F.ACT_LRELU)
+            tp2 = self.TPM[1].fwd(tp0, F.ACT_LRELU)
+            self.TPM[2].fwd(tp2, out=epm_in[:, o_tp:o_tp + P])
+        target = F.sub(yc, yd) if self.residual else (yc if F.nhwc_ld(yc) == Cin else F.copy_channels(yc, F.empty_nhwc(B, Cin, H, W, dev)))
+        t_hat = None
+        if self.has_spm:
+            # gaussian_conditional.quantize(target, "noise" | "dequantize") with no means (:570-572, :853-855)
+            t_hat = F.add(target, gc._noise_like(target)) if training else F.round_(target)
+            self.CTX.fwd(t_hat, out=epm_in[:, o_ctx:o_ctx + P])
+        e0 = self.EPM[0].fwd(epm_in, F.ACT_LRELU)
+        e2 = self.EPM[1].fwd(e0, F.ACT_LRELU)
+        gp = self.EPM[2].fwd(e2)                                   # [B, 2*Cin, H, W] = scales | means
+        scales, means = gp[:, :Cin], gp[:, Cin:]
+        noise = gc._noise_like(target) if training else None
+        gc_out, lik_y = F.gc_forward(target, scales, means, noise=noise, scale_bound=gc._scale_bound, lik_bound=gc._lik_bound)
+        if self.has_spm:
+            y_hat = F.add(t_hat, yd if F.nhwc_ld(yd) == Cin else F.copy_channels(yd, F.empty_nhwc(B, Cin, H, W, dev))) if self.residual else t_hat
+        else:
+            y_hat = gc_out
+        k.update(he_in=he_in, he0=he0, he2=he2, z_hat=z_hat, pack=pack, hd0=hd0, hd2=hd2, epm_in=epm_in, tp0=tp0, tp2=tp2,
+                 yd=yd, t_hat=t_hat, e0=e0, e2=e2, gp=gp, gc_out=gc_out, offs=(o_tp, o_hp, o_ctx), P=P, Cin=Cin)
+        return y_hat, lik_y, lik_z, k
+
+    # -------------------------------------------------------------------------------------------
+    def backward(self, k, dlik_y, dlik_z):
+        """Parameter gradients of a scalar that depends on (lik_y, lik_z); written into .grad (overwritten,
+        not accumulated: the reference zeroes gradients before every backward, stem/trainSTEM.py:203)."""
+        m = self.m
+        gc = m.gaussian_conditional
+        Cin, P = k["Cin"], k["P"]
+        o_tp, o_hp, o_ctx = k["offs"]
+        gp = k["gp"]
+        B, _, H, W = gp.shape
+        dgp = F.empty_nhwc(B, 2 * Cin, H, W, gp.device)
+        F.gc_backward(k["gc_out"], gp[:, :Cin], gp[:, Cin:], dlik_y, dgp[:, :Cin], dgp[:, Cin:], dy=None,
+                      scale_bound=gc._scale_bound, lik_bound=gc._lik_bound)
+        # EPM (1x1 chain)
+        self.EPM[2].wgrad(k["e2"], dgp)
+        de2 = self.EPM[2].dgrad(dgp, k["e2"].shape, xact=k["e2"])
+        self.EPM[1].wgrad(k["e0"], de2)
+        de0 = self.EPM[1].dgrad(de2, k["e0"].shape, xact=k["e0"])
+        self.EPM[0].wgrad(k["epm_in"], de0)
+        dpri = self.EPM[0].dgrad(de0, k["epm_in"].shape)
+        # spatial prior: weight gradient of all 25 taps, no input gradient (its input is data + noise)
+        if self.has_spm:
+            self.CTX.wgrad(k["t_hat"], dpri[:, o_ctx:o_ctx + P])
+        if self.has_tpm:
+            dtp = dpri[:, o_tp:o_tp + P]
+            self.TPM[2].wgrad(k["tp2"], dtp)
+            d = self.TPM[2].dgrad(dtp, k["tp2"].shape, xact=k["tp2"])
+            self.TPM[1].wgrad(k["tp0"], d)
+            d = self.TPM[1].dgrad(d, k["tp0"].shape, xact=k["tp0"])
+            self.TPM[0].wgrad(k["yd"], d)
+        # hyper decoder
+        dhp = dpri[:, o_hp:o_hp + P]
+        self.HD[2].wgrad(k["hd2"], dhp)
+        d = self.HD[2].dgrad(dhp, k["hd2"].shape, xact=k["hd2"])
+        self.HD[1].wgrad(k["hd0"], d)
+        d = self.HD[1].dgrad(d, k["hd0"].shape, xact=k["hd0"])
+        self.HD[0].wgrad(k["z_hat"], d)
+        dz_hat = self.HD[0].dgrad(d, k["z_hat"].shape)
+        # entropy bottleneck: d/dz = dz_hat + likelihood path; 58 parameter gradients per channel
+        eb = m.entropy_bottleneck
+        dz, dpack = F.eb_backward(k["z_hat"], k["pack"], dlik_z, dzhat_in=dz_hat, bound=eb._lik_bound)
+        F.eb_unpack_grads(dpack, [_grad_of(p) for p in eb._tensors14()])
+        # hyper encoder
+        self.HE[2].wgrad(k["he2"], dz)
+        d = self.HE[2].dgrad(dz, k["he2"].shape, xact=k["he2"])
+        self.HE[1].wgrad(k["he0"], d)
+        d = self.HE[1].dgrad(d, k["he0"].shape, xact=k["he0"])
+        self.HE[0].wgrad(k["he_in"], d)
+
+
+class StemFunction(torch.autograd.Function):
+    """Autograd node wrapping a whole STEM forward: inputs are the model parameters (so that
+    `loss.backward()` reaches us), outputs (y_hat, lik_y, lik_z).  Parameter gradients are written
+    directly into `.grad` by the engine and `None` is returned to autograd."""
+
+    @staticmethod
+    def forward(ctx, engine, training, y_cur, y_cond, *params):
+        y_hat, lik_y, lik_z, k = engine.forward(y_cur, y_cond, training)
+        ctx.engine, ctx.keep = engine, k
+        ctx.mark_non_differentiable(y_hat)
+        return y_hat, lik_y, lik_z
+
+    @staticmethod
+    def backward(ctx, _dy_hat, dlik_y, dlik_z):
+        eng, k = ctx.engine, ctx.keep
+        ctx.keep = None
+        gp = k["gp"]
+        B, _, H, W = gp.shape
+        if dlik_y is None:
+            dlik_y = torch.zeros_like(k["gc_out"])
+        if dlik_z is None:
+            dlik_z = torch.zeros_like(k["z_hat"])
+        eng.backward(k, _dense(dlik_y), _dense(dlik_z))
+        return (None,) * (4 + len(eng.m._engine_params))
+
+
+def _dense(t):
+    t = F.to_nhwc(t)
+    if F.nhwc_ld(t) != t.shape[1]:
+        t = F.copy_channels(t, F.empty_nhwc(*t.shape, t.device))
+    return t

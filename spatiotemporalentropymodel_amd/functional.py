@@ -105,6 +105,14 @@ def to_nchw(t: torch.Tensor, clamp01: bool = False) -> torch.Tensor:
     return out
 
 
+def copy_channels(src: torch.Tensor, dst: torch.Tensor):
+    """dst (a channel slice of a wider NHWC buffer) <- src (any NHWC view), same [B,C,H,W]."""
+    assert src.shape == dst.shape
+    B, Cc, H, W = src.shape
+    _chk(_lib.hip().stem_copy_channels(src.data_ptr(), nhwc_ld(src), dst.data_ptr(), nhwc_ld(dst), B * H * W, Cc, _stream()))
+    return dst
+
+
 def nchw3_to_nhwc4(x: torch.Tensor) -> torch.Tensor:
     _require_cuda(x)
     x = x.contiguous()
@@ -116,7 +124,7 @@ def nchw3_to_nhwc4(x: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- weights
-def pack_weight(w: torch.Tensor, role: int, masked: bool = False) -> torch.Tensor:
+def pack_weight(w: torch.Tensor, role: int, masked: int = 0) -> torch.Tensor:
     """w: Conv2d [K,C,R,S] or ConvTranspose2d [C,K,R,S] (contiguous) -> packed copy for `role`."""
     _require_cuda(w)
     w = w.detach().contiguous()

@@ -1,0 +1,237 @@
+"""Layer modules with the reference's names, constructor arguments and state-dict keys, whose
+forward/backward run the HIP kernels through the C ABI.
+
+  Conv2d / ConvTranspose2d   torch.nn.Conv2d / ConvTranspose2d as built by compressai/models/utils.py:112-130
+  MaskedConv2d               compressai/layers/layers.py:21-47
+  GDN                        compressai/layers/gdn.py:22-67
+  FusedSequential            nn.Sequential that fuses Conv -> LeakyReLU pairs into the conv epilogue
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import functional as F
+from .ops import NonNegativeParametrizer
+
+_WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    """Called by the fused optimiser: parameters changed behind torch's version counters."""
+    _WEIGHT_EPOCH[0] += 1
+
+
+class _PackCache:
+    """Packed weight copies, rebuilt only when the parameter changed."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, w: torch.Tensor, role: int, masked: int = 0):
+        key = (w._version, w.data_ptr(), _WEIGHT_EPOCH[0], tuple(w.shape))
+        hit = self._c.get(role)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        wp = F.pack_weight(w, role, masked)
+        if masked == 2:                          # the kernel zeroed taps of w in place
+            key = (w._version, w.data_ptr(), _WEIGHT_EPOCH[0], tuple(w.shape))
+        self._c[role] = (key, wp)
+        return wp
+
+
+# ----------------------------------------------------------------------------- autograd functions
+class Conv2dFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, act, masked, cache):
+        K, Cc, R, S = weight.shape
+        first = Cc == 3 and F.nhwc_ld(x) is None       # image input, NCHW: fused layout change (g_a.0)
+        if first:
+            xin = F.nchw3_to_nhwc4(x)
+            y = F.conv2d_fwd_c4(xin, cache.get(weight, F.PACK_CONV_FWD_C4), bias, K, R, S, stride, pad)
+            xin = xin.permute(0, 3, 1, 2)               # [B,4,H,W] NHWC view for the weight gradient
+        else:
+            xin = F.to_nhwc(x)
+            y = F.conv2d_fwd(xin, cache.get(weight, F.PACK_CONV_FWD, masked), bias, K, R, S, stride, pad, act)
+        ctx.cfg = (stride, pad, act, masked, cache, first, tuple(x.shape))
+        ctx.save_for_backward(xin, weight, y if act else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, pad, act, masked, cache, first, xshape = ctx.cfg
+        xin, weight, y = ctx.saved_tensors
+        K, Cc, R, S = weight.shape
+        dy = F.to_nhwc(dy)
+        if F.nhwc_ld(dy) != K:
+            dy = F.copy_channels(dy, F.empty_nhwc(*dy.shape, dy.device))
+        if act:
+            dy = F.lrelu_bwd(y, dy)
+        dx = None
+        if ctx.needs_input_grad[0] and not first:
+            dx = F.conv2d_dgrad(dy, cache.get(weight, F.PACK_CONV_DGRAD, 1 if masked else 0), xshape, K, R, S, stride, pad)
+        dw = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw, db = F.conv2d_wgrad(xin, dy, K, R, S, stride, pad, need_db=ctx.needs_input_grad[2])
+            if first:
+                dw = dw[:, :3].contiguous()
+        return dx, dw, db, None, None, None, None, None
+
+
+class ConvTranspose2dFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, opad, act, cache):
+        Cc, K, R, S = weight.shape
+        xin = F.to_nhwc(x)
+        y = F.deconv2d_fwd(xin, cache.get(weight, F.PACK_DECONV_FWD), bias, K, R, S, stride, pad, opad, act)
+        ctx.cfg = (stride, pad, opad, act, cache, tuple(x.shape))
+        ctx.save_for_backward(xin, weight, y if act else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        stride, pad, opad, act, cache, xshape = ctx.cfg
+        xin, weight, y = ctx.saved_tensors
+        Cc, K, R, S = weight.shape
+        dy = F.to_nhwc(dy)
+        if F.nhwc_ld(dy) != K:
+            dy = F.copy_channels(dy, F.empty_nhwc(*dy.shape, dy.device))
+        if act:
+            dy = F.lrelu_bwd(y, dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = F.deconv2d_dgrad(dy, cache.get(weight, F.PACK_DECONV_DGRAD), xshape, K, R, S, stride, pad, opad)
+        dw = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw, db = F.deconv2d_wgrad(xin, dy, K, R, S, stride, pad, opad, need_db=ctx.needs_input_grad[2])
+        return dx, dw, db, None, None, None, None, None
+
+
+class GDNFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, beta, gamma, inverse, beta_min):
+        return F.gdn_fwd(F.to_nhwc(x), beta, gamma, inverse, beta_min)
+
+    @staticmethod
+    def backward(ctx, dy):
+        raise NotImplementedError(
+            "GDN backward is not on the round-1 hot path: stem/trainSTEM.py trains only the STEM "
+            "entropy model and the I-frame transforms are used forward-only (DESIGN.md, scope).")
+
+
+# ----------------------------------------------------------------------------- modules
+def _pair(v):
+    return v if isinstance(v, int) else v[0]
+
+
+class Conv2d(nn.Module):
+    """nn.Conv2d(in, out, kernel_size, stride, padding) with square kernels, bias, dilation 1."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = int(in_channels), int(out_channels)
+        self.kernel_size, self.stride, self.padding = _pair(kernel_size), _pair(stride), _pair(padding)
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, self.kernel_size, self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self._packs = _PackCache()
+        self._masked = 0
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))      # nn.Conv2d default; models re-init (priors.py:67-72)
+        if self.bias is not None:
+            bound = 1 / math.sqrt(self.weight[0].numel())
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, act=F.ACT_NONE):
+        return Conv2dFunction.apply(x, self.weight, self.bias, self.stride, self.padding, act, self._masked, self._packs)
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}"
+
+
+class ConvTranspose2d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, output_padding=0, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = int(in_channels), int(out_channels)
+        self.kernel_size, self.stride, self.padding = _pair(kernel_size), _pair(stride), _pair(padding)
+        self.output_padding = _pair(output_padding)
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels, self.kernel_size, self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self._packs = _PackCache()
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1 / math.sqrt(self.weight.shape[0] * self.kernel_size ** 2)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, act=F.ACT_NONE):
+        return ConvTranspose2dFunction.apply(x, self.weight, self.bias, self.stride, self.padding, self.output_padding,
+                                             act, self._packs)
+
+
+class MaskedConv2d(Conv2d):
+    """PixelCNN-style masked convolution; like the reference the masked taps of `weight` are zeroed
+    *in place* at every forward (the pack kernel does it) while their gradients stay unmasked."""
+
+    def __init__(self, *args, mask_type="A", **kwargs):
+        super().__init__(*args, **kwargs)
+        if mask_type not in ("A", "B"):
+            raise ValueError(f'Invalid "mask_type" value "{mask_type}"')
+        if mask_type != "A":
+            raise NotImplementedError("only mask_type='A' is on the STEM path (spatiotemporalpriors.py:546,830)")
+        self.register_buffer("mask", torch.ones_like(self.weight.data))
+        _, _, h, w = self.mask.size()
+        self.mask[:, :, h // 2, w // 2:] = 0
+        self.mask[:, :, h // 2 + 1:] = 0
+        self._masked = 2
+
+
+class GDN(nn.Module):
+    def __init__(self, in_channels, inverse=False, beta_min=1e-6, gamma_init=0.1):
+        super().__init__()
+        self.inverse = bool(inverse)
+        self.beta_min = float(beta_min)
+        self.beta_reparam = NonNegativeParametrizer(minimum=beta_min)
+        self.beta = nn.Parameter(self.beta_reparam.init(torch.ones(in_channels)))
+        self.gamma_reparam = NonNegativeParametrizer()
+        self.gamma = nn.Parameter(self.gamma_reparam.init(float(gamma_init) * torch.eye(in_channels)))
+
+    def forward(self, x):
+        return GDNFunction.apply(x, self.beta, self.gamma, self.inverse, self.beta_min)
+
+
+class LeakyReLU(nn.LeakyReLU):
+    """Placeholder that keeps nn.Sequential indices (`HE.0`, `HE.2`, …) identical to the reference;
+    FusedSequential folds it into the preceding convolution's epilogue."""
+
+
+class FusedSequential(nn.Sequential):
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, (Conv2d, ConvTranspose2d)) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
+                assert abs(mods[i + 1].negative_slope - F.LRELU_SLOPE) < 1e-12
+                x = m(x, act=F.ACT_LRELU)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
+def conv(in_channels, out_channels, kernel_size=5, stride=2):
+    """compressai/models/utils.py:112-120"""
+    return Conv2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=kernel_size // 2)
+
+
+def deconv(in_channels, out_channels, kernel_size=5, stride=2):
+    """compressai/models/utils.py:122-130"""
+    return ConvTranspose2d(in_channels, out_channels, kernel_size=kernel_size, stride=stride,
+                           output_padding=stride - 1, padding=kernel_size // 2)

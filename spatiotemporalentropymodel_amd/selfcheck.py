@@ -1,0 +1,110 @@
+"""Shared harness pieces for smoke(), the GPU tests and bench.py: noise injection, the restated
+per-P-frame training step of stem/trainSTEM.py:194-218, and smoke_check()."""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+from .weights import closed_form_fill_, closed_form_input, smooth_frames
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class NoiseFeed:
+    """noise_source hook: the k-th draw of role R is closed_form_input("noise:R:k") -- the same numbers
+    tests/golden/make_golden.py fed to the reference through EntropyModel._get_noise_cached."""
+
+    def __init__(self, role):
+        self.role, self.k = role, 0
+
+    def __call__(self, shape, device):
+        name = f"noise:{self.role}:{self.k}"
+        self.k += 1
+        return closed_form_input(name, tuple(shape), -0.5, 0.5).to(device)
+
+
+def build_models(ebc, cin, N, M, device, cls=None, closed_form=True, inject_noise=True):
+    from .models import JointAutoregressiveHierarchicalPriors, SpatioTemporalPriorModel_Res
+    cls = cls or SpatioTemporalPriorModel_Res
+    imodel = JointAutoregressiveHierarchicalPriors(N, M)
+    stem = cls(ebc, cin)
+    if closed_form:
+        closed_form_fill_(imodel)
+        closed_form_fill_(stem)
+    imodel, stem = imodel.to(device).eval(), stem.to(device)
+    if inject_noise:
+        imodel.gaussian_conditional.noise_source = NoiseFeed("iframe_gc")
+        stem.entropy_bottleneck.noise_source = NoiseFeed("stem_eb")
+        stem.gaussian_conditional.noise_source = NoiseFeed("stem_gc")
+    return imodel, stem
+
+
+def p_frame_step(imodel, stem, criterion, optimizer, aux_optimizer, x, y_cond, grad_scale=1.0, reducer=None):
+    """One P-frame optimisation step, the body of stem/trainSTEM.py:203-218 with the fused optimiser:
+    zero_grad -> getY -> stem forward -> EMLoss -> backward -> [all-reduce] -> clip+Adam -> aux loss/step."""
+    optimizer.zero_grad()
+    aux_optimizer.zero_grad()
+    with torch.no_grad():
+        y_cur, _ = imodel.getY(x)
+    out = stem(y_cur, y_cond)
+    oc = criterion(out, x)
+    oc["loss"].backward()
+    if reducer is not None:
+        reducer.all_reduce()
+    gn = optimizer.grad_norm() * grad_scale if hasattr(optimizer, "grad_norm") else None
+    optimizer.step(grad_scale) if hasattr(optimizer, "grad_norm") else optimizer.step()
+    aux = stem.aux_loss()
+    aux.backward()
+    aux_optimizer.step()
+    return out, oc, aux, gn
+
+
+def smoke_check(verbose=False):
+    """One small training step on cuda:0 checked against (a) the golden vectors of the reference and
+    (b) the CPU oracle evaluated on the very same inputs."""
+    assert torch.cuda.is_available(), "smoke() needs cuda:0"
+    from . import _lib
+    _lib.hip()                                    # fail loudly if the HIP extension is missing
+    from .losses import EMLoss
+    from .optim import configure_optimizers
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import stem_oracle as orc
+
+    dev = torch.device("cuda:0")
+    g = dict(np.load(os.path.join(REPO, "tests", "golden", "stem_train_small.npz")))
+    ebc, cin, N, M, batch, size, steps = (int(v) for v in g["cfg"])
+    imodel, stem = build_models(ebc, cin, N, M, dev)
+    stem.train()
+    args = types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3)
+    opt, aux_opt = configure_optimizers(stem, args)
+    frames = [f.to(dev) for f in smooth_frames("train:small", batch, steps + 1, size)]
+    with torch.no_grad():
+        _, y_cond = imodel.getY(frames[0])
+    out, oc, aux, gn = p_frame_step(imodel, stem, EMLoss(), opt, aux_opt, frames[1], y_cond)
+    torch.cuda.synchronize()
+    loss, ybpp, zbpp, aux_ref, gn_ref = g["s1:scalars"]
+
+    def rel(a, b):
+        return abs(float(a) - float(b)) / max(abs(float(b)), 1e-30)
+
+    checks = {"loss": rel(oc["loss"], loss), "y_bpp": rel(oc["y_bpp_loss"], ybpp), "z_bpp": rel(oc["z_bpp_loss"], zbpp),
+              "grad_norm": rel(gn, gn_ref), "aux_loss": rel(aux, aux_ref)}
+    lik_y = out["likelihoods"]["y"].detach().cpu().contiguous().numpy()
+    checks["lik_y_vs_golden"] = float(np.max(np.abs(lik_y - g["s1:lik_y"]) / (np.abs(g["s1:lik_y"]) + 1e-3)))
+    # oracle on the same y_cur / y_cond (g_a through the oracle as well)
+    isd = {k: v.detach().cpu().numpy() for k, v in imodel.state_dict().items() if v.dtype == torch.float32}
+    y_ref = orc.g_a(isd, frames[1].cpu().numpy())
+    with torch.no_grad():
+        y_hip, _ = imodel.getY(frames[1])
+    checks["g_a_vs_oracle"] = float(np.max(np.abs(y_hip.cpu().contiguous().numpy() - y_ref)) / np.abs(y_ref).max())
+    if verbose:
+        for k, v in checks.items():
+            print(f"smoke: {k:18s} rel err {v:.3e}")
+    bad = {k: v for k, v in checks.items() if not v < 2e-4}
+    if bad:
+        raise AssertionError(f"smoke(): HIP path disagrees with the reference/oracle: {bad}")
+    return checks

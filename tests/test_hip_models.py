@@ -1,0 +1,183 @@
+"""GPU parity tests, model level: the nn.Module surface (getY / STEM forward / EMLoss / backward /
+fused clip+Adam / aux step) on the HIP path vs golden vectors captured from the reference, with
+identical closed-form weights, inputs and injected noise.  1e-4 relative (north_star)."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def host(t):
+    return t.detach().cpu().contiguous().numpy()
+
+
+@pytest.fixture(scope="module")
+def S():
+    from spatiotemporalentropymodel_amd import selfcheck
+    assert torch.cuda.is_available()
+    return selfcheck
+
+
+def test_config1_small_forward_septuplet(S, golden):
+    """BASELINE.json configs[0]: one 7x256x256 septuplet, mbt2018(64,96) transforms + SpatioTemporalPriorModel(64,96)
+    eval forward, bpp and MSE per frame."""
+    from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel
+    from spatiotemporalentropymodel_amd.weights import smooth_frames
+    from spatiotemporalentropymodel_amd.losses import log2_sum
+    g = golden("stem_small_forward.npz")
+    dev = torch.device("cuda:0")
+    imodel, stem = S.build_models(64, 96, 64, 96, dev, cls=SpatioTemporalPriorModel)
+    stem.eval()
+    frames = [f.to(dev) for f in smooth_frames("septuplet0", 1, 7, 256)]
+    with torch.no_grad():
+        y0, y_cond = imodel.getY(frames[0])
+        assert_close(host(y0), g["y0"], what="g_a(frame 0)")
+        y_cur, _ = imodel.getY(frames[1])
+        assert_close(host(y_cur), g["f1:y_cur"], what="g_a(frame 1)")
+        assert_close(host(y_cond), g["f1:y_cond"], what="y_cond = y0 + injected noise")
+        # frame 1 on the reference's own latents: every tensor
+        yc, yd = torch.from_numpy(g["f1:y_cur"]).to(dev), torch.from_numpy(g["f1:y_cond"]).to(dev)
+        out = stem(yc, yd)
+        gp = stem.engine().forward(yc, yd, False)[3]["gp"]
+        assert_close(host(gp[:, :96]), g["f1:scales"], what="scales")
+        assert_close(host(gp[:, 96:]), g["f1:means"], what="means")
+        np.testing.assert_array_equal(host(out["y_hat"]), g["f1:y_hat"])
+        assert_close(host(out["likelihoods"]["z"]), g["f1:lik_z"], atol=1e-9, what="lik_z")
+        assert_close(host(out["likelihoods"]["y"]), g["f1:lik_y"], 2e-4, atol=1e-9, what="lik_y")
+        npix = 256 * 256
+        assert abs(float(log2_sum(out["likelihoods"]["y"])) / -npix - g["bpp_y"][0]) < 1e-4 * g["bpp_y"][0]
+        assert abs(float(log2_sum(out["likelihoods"]["z"])) / -npix - g["bpp_z"][0]) < 1e-4 * g["bpp_z"][0]
+        x_hat = imodel.getX(out["y_hat"])
+        assert x_hat.is_contiguous() and tuple(x_hat.shape) == (1, 3, 256, 256)
+        assert_close(host(x_hat)[:, :, 100:132, 60:92], g["f1:x_hat_crop"], what="g_s + clamp")
+        mse = float(((x_hat.double() - frames[1].double()) ** 2).mean())
+        assert abs(mse - g["mse"][0]) < 1e-4 * g["mse"][0]
+        # the whole chain (y_cond <- y_hat): a rounding decision within fp32 noise of .5 may flip, so the
+        # chained frames are compared on their rate / distortion at 1e-3
+        y_cond_chain = y_cond
+        for t in range(1, 7):
+            y_cur, _ = imodel.getY(frames[t])
+            o = stem(y_cur, y_cond_chain)
+            by = float(log2_sum(o["likelihoods"]["y"])) / -npix
+            bz = float(log2_sum(o["likelihoods"]["z"])) / -npix
+            ms = float(((imodel.getX(o["y_hat"]).double() - frames[t].double()) ** 2).mean())
+            assert abs(by - g["bpp_y"][t - 1]) < 1e-3 * g["bpp_y"][t - 1], (t, by, g["bpp_y"][t - 1])
+            assert abs(bz - g["bpp_z"][t - 1]) < 1e-3 * g["bpp_z"][t - 1], (t, bz)
+            assert abs(ms - g["mse"][t - 1]) < 1e-3 * g["mse"][t - 1], (t, ms)
+            y_cond_chain = o["y_hat"]
+        mism = float((host(y_cond_chain) != g["f6:y_hat"]).mean())
+        assert mism < 1e-3, f"{mism:.2e} of the frame-6 latents differ after a 6-frame chain"
+
+
+@pytest.mark.parametrize("tag", ["small", "big"])
+def test_train_steps_match_reference(S, golden, tag):
+    """Two consecutive P-frame steps of the stem/trainSTEM.py loop: losses, grad norm, every parameter
+    gradient of step 1, auxiliary loss + dquantiles, and every parameter after step 2."""
+    from spatiotemporalentropymodel_amd.losses import EMLoss
+    from spatiotemporalentropymodel_amd.optim import configure_optimizers
+    from spatiotemporalentropymodel_amd.weights import smooth_frames
+    g = golden(f"stem_train_{tag}.npz")
+    ebc, cin, N, M, batch, size, steps = (int(v) for v in g["cfg"])
+    dev = torch.device("cuda:0")
+    imodel, stem = S.build_models(ebc, cin, N, M, dev)
+    stem.train()
+    args = types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3)
+    opt, aux_opt = configure_optimizers(stem, args)
+    crit = EMLoss()
+    frames = [f.to(dev) for f in smooth_frames("train:" + tag, batch, steps + 1, size)]
+    with torch.no_grad():
+        _, y_cond = imodel.getY(frames[0])
+    for t in range(1, steps + 1):
+        if t == 1:
+            # run step 1 by hand to look at gradients before the fused optimiser consumes them
+            opt.zero_grad(), aux_opt.zero_grad()
+            with torch.no_grad():
+                y_cur, _ = imodel.getY(frames[t])
+            out = stem(y_cur, y_cond)
+            oc = crit(out, frames[t])
+            oc["loss"].backward()
+            gn = float(opt.grad_norm())
+            loss, ybpp, zbpp, aux_ref, gn_ref = g["s1:scalars"]
+            assert_close(host(y_cur), g["s1:y_cur"], what="y_cur")
+            assert_close(host(out["y_hat"]), g["s1:y_hat"], what="y_hat")
+            assert_close(host(out["likelihoods"]["y"]), g["s1:lik_y"], 2e-4, atol=1e-9, what="lik_y")
+            assert_close(host(out["likelihoods"]["z"]), g["s1:lik_z"], atol=1e-9, what="lik_z")
+            assert abs(float(oc["loss"]) - loss) < 1e-4 * loss
+            assert abs(float(oc["y_bpp_loss"]) - ybpp) < 1e-4 * ybpp and abs(float(oc["z_bpp_loss"]) - zbpp) < 1e-4 * zbpp
+            assert abs(gn - gn_ref) < 2e-4 * gn_ref, (gn, gn_ref)
+            clip = min(1.0, 1.0 / (gn + 1e-6))
+            for name, p in stem.named_parameters():
+                if name.endswith(".quantiles"):
+                    continue
+                ref = g[f"s1:gsum:{name}"]
+                gd = p.grad.double() * clip
+                assert abs(float(gd.sum()) - ref[0]) <= 2e-4 * ref[1] + 1e-12, name
+                assert abs(float(gd.abs().sum()) - ref[1]) <= 2e-4 * ref[1] + 1e-12, name
+                sl = host(gd.reshape(-1)[:: max(1, gd.numel() // 64)][:64])
+                rs = g[f"s1:gslice:{name}"]
+                assert_close(sl, rs, 5e-4, atol=1e-7 * float(np.abs(rs).max() + 1e-30), what="grad " + name)
+            opt.step()
+            aux = stem.aux_loss()
+            aux.backward()
+            assert abs(float(aux) - aux_ref) < 1e-4 * aux_ref
+            assert_close(host(stem.entropy_bottleneck.quantiles.grad), g["s1:dquantiles"], what="dquantiles")
+            aux_opt.step()
+            y_cond = out["y_hat"]
+        else:
+            out, oc, aux, gn = S.p_frame_step(imodel, stem, crit, opt, aux_opt, frames[t], y_cond)
+            loss, ybpp, zbpp, aux_ref, gn_ref = g[f"s{t}:scalars"]
+            assert abs(float(oc["loss"]) - loss) < 2e-4 * loss, (float(oc["loss"]), loss)
+            assert abs(float(gn) - gn_ref) < 5e-4 * gn_ref, (float(gn), gn_ref)
+            assert abs(float(aux) - aux_ref) < 2e-4 * aux_ref
+            y_cond = out["y_hat"]
+    for name, p in stem.named_parameters():
+        ref = g[f"final:psum:{name}"]
+        pd_ = p.detach().double()
+        assert abs(float(pd_.sum()) - ref[0]) <= 1e-5 * ref[1] + 1e-12, name
+        sl = host(p.detach().reshape(-1)[:: max(1, p.numel() // 64)][:64])
+        assert_close(sl, g[f"final:pslice:{name}"], 1e-5, what="param " + name)
+
+
+def test_masked_weights_zeroed_in_place_like_reference(S):
+    """MaskedConv2d.forward mutates weight.data (layers.py:46); the pack kernel reproduces that side effect."""
+    dev = torch.device("cuda:0")
+    _, stem = S.build_models(64, 96, 64, 96, dev)
+    stem.eval()
+    w = stem.context_prediction.weight
+    assert float(w[:, :, 2, 2:].abs().sum()) > 0
+    with torch.no_grad():
+        stem(torch.zeros(1, 96, 4, 4, device=dev), torch.zeros(1, 96, 4, 4, device=dev))
+    assert float(w[:, :, 2, 2:].abs().sum()) == 0 and float(w[:, :, 3:].abs().sum()) == 0
+    assert float(w[:, :, :2].abs().sum()) > 0
+
+
+def test_layer_modules_autograd(S):
+    """op-level modules (used outside the fused engine): Conv2d / ConvTranspose2d backward through torch autograd."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import stem_oracle as orc
+    from spatiotemporalentropymodel_amd.layers import Conv2d, ConvTranspose2d, FusedSequential, LeakyReLU
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = FusedSequential(Conv2d(32, 64, 3, padding=1), LeakyReLU(), ConvTranspose2d(64, 32, 5, stride=2, padding=2, output_padding=1)).to(dev)
+    x = torch.randn(2, 32, 6, 5, device=dev, requires_grad=True)
+    y = net(x)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    xn, dyn = host(x), host(dy)
+    w0, b0, w1, b1 = (host(t) for t in (net[0].weight, net[0].bias, net[2].weight, net[2].bias))
+    h = orc.lrelu_fwd(orc.conv2d_fwd(xn, w0, b0, 1, 1))
+    assert_close(host(y), orc.deconv2d_fwd(h, w1, b1, 2, 2, 1), what="y")
+    dh, dw1, db1 = orc.deconv2d_bwd(h, w1, dyn, 2, 2, 1)
+    dx, dw0, db0 = orc.conv2d_bwd(xn, w0, orc.lrelu_bwd(h, dh), 1, 1)
+    assert_close(host(x.grad), dx, what="dx")
+    assert_close(host(net[0].weight.grad), dw0, what="dw0")
+    assert_close(host(net[2].weight.grad), dw1, what="dw1")
+    assert_close(host(net[0].bias.grad), db0, what="db0")
+    assert_close(host(net[2].bias.grad), db1, what="db1")

@@ -1,0 +1,205 @@
+"""CPU tests of the host-side product code: module surface / state-dict compatibility, the host rANS
+library (bit-exact vs the reference's bytes), CDF tables from update(), flat parameter buffers."""
+import types
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+import spatiotemporalentropymodel_amd as pkg
+from spatiotemporalentropymodel_amd import entropy_models as em
+from spatiotemporalentropymodel_amd.models import (JointAutoregressiveHierarchicalPriors, SpatioTemporalPriorModel,
+                                                   SpatioTemporalPriorModel_Res, SpatioTemporalPriorModelWithoutSPM,
+                                                   SpatioTemporalPriorModelWithoutSPMTPM, SpatioTemporalPriorModelWithoutTPM,
+                                                   get_scale_table)
+
+
+def test_parameter_counts_match_survey():
+    """SURVEY.md §2a / BASELINE.md: 18,083,712 (big), 10,642,944 (small), mbt2018(192,192) 14,130,467."""
+    assert sum(p.numel() for p in SpatioTemporalPriorModel_Res().parameters()) == 18_083_712
+    assert len(list(SpatioTemporalPriorModel_Res().parameters())) == 41
+    assert sum(p.numel() for p in SpatioTemporalPriorModel_Res(64, 96).parameters()) == 10_642_944
+    assert sum(p.numel() for p in JointAutoregressiveHierarchicalPriors(192, 192).parameters()) == 14_130_467
+
+
+def test_state_dict_keys_match_reference(golden):
+    g = golden("stem_train_small.npz")
+    ref_params = [k[len("final:psum:"):] for k in g if k.startswith("final:psum:")]
+    m = SpatioTemporalPriorModel_Res(64, 96)
+    ours = [n for n, _ in m.named_parameters()]
+    assert ours == ref_params                      # same names, same ORDER (optimizer state interchange)
+    sd = m.state_dict()
+    for extra in ("entropy_bottleneck._offset", "entropy_bottleneck._quantized_cdf", "entropy_bottleneck._cdf_length",
+                  "entropy_bottleneck.target", "entropy_bottleneck.likelihood_lower_bound.bound", "context_prediction.mask",
+                  "gaussian_conditional._offset", "gaussian_conditional._quantized_cdf", "gaussian_conditional._cdf_length",
+                  "gaussian_conditional.scale_table", "gaussian_conditional.scale_bound",
+                  "gaussian_conditional.likelihood_lower_bound.bound", "gaussian_conditional.lower_bound_scale.bound"):
+        assert extra in sd, extra
+    assert len(sd) == 54
+    assert tuple(sd["HD.0.weight"].shape) == (64, 256, 5, 5) and tuple(sd["EPM.0.weight"].shape) == (768, 576, 1, 1)
+    isd = JointAutoregressiveHierarchicalPriors(64, 96).state_dict()
+    for k in ("g_a.0.weight", "g_a.1.beta", "g_a.1.gamma", "g_a.1.beta_reparam.pedestal", "g_a.1.beta_reparam.lower_bound.bound",
+              "g_a.1.gamma_reparam.pedestal", "g_a.1.gamma_reparam.lower_bound.bound", "g_s.6.bias", "h_a.0.weight", "h_s.4.weight",
+              "entropy_parameters.4.bias", "context_prediction.mask"):
+        assert k in isd, k
+
+
+def test_ablation_variants_structure():
+    assert not hasattr(SpatioTemporalPriorModelWithoutSPMTPM(), "TPM")
+    m = SpatioTemporalPriorModelWithoutSPM(64, 96)
+    assert m.HE[4].out_channels == 256            # hard-coded width in the two SPM-less ablations (:44-58,150-164)
+    assert m.EPM[0].in_channels == 96 * 4 and not hasattr(m, "context_prediction")
+    m = SpatioTemporalPriorModelWithoutTPM(64, 96)
+    assert m.HE[4].out_channels == 64 and m.EPM[0].in_channels == 96 * 4 and not hasattr(m, "TPM")
+    assert SpatioTemporalPriorModel(64, 96).EPM[0].in_channels == 96 * 6
+
+
+def test_state_dict_roundtrip_with_cdf_buffers():
+    a = SpatioTemporalPriorModel_Res(64, 96)
+    a.update(force=True)
+    b = SpatioTemporalPriorModel_Res(64, 96)
+    b.load_state_dict(a.state_dict())               # resizes the empty CDF buffers first (spatiotemporalpriors.py:1058-1066)
+    assert tuple(b.gaussian_conditional._quantized_cdf.shape) == (64, 3133)
+    assert torch.equal(b.entropy_bottleneck._quantized_cdf, a.entropy_bottleneck._quantized_cdf)
+
+
+def test_compressai_alias_imports():
+    pkg.install_compressai_alias()
+    import compressai
+    from compressai.ans import BufferedRansEncoder, RansDecoder  # noqa: F401
+    from compressai.models.spatiotemporalpriors import SpatioTemporalPriorModel_Res as R
+    from compressai.zoo import models
+    assert R is SpatioTemporalPriorModel_Res
+    assert isinstance(models["mbt2018"](quality=4), JointAutoregressiveHierarchicalPriors)
+    assert compressai.available_entropy_coders() == ["ans"]
+    compressai.set_entropy_coder("ans")
+    with pytest.raises(ValueError):
+        compressai.set_entropy_coder("nope")
+
+
+# ----------------------------------------------------------------------------- error behaviour (test_entropy_models.py:96-144)
+def test_entropy_model_error_paths():
+    gc = em.GaussianConditional(None)
+    with pytest.raises(ValueError):
+        gc.quantize(torch.zeros(1, 1, 1, 1), "bogus")
+    with pytest.raises(ValueError):
+        gc._check_cdf_size()
+    with pytest.raises(ValueError):
+        em.GaussianConditional(1)
+    with pytest.raises(ValueError):
+        em.GaussianConditional([])
+    with pytest.raises(ValueError):
+        em.GaussianConditional([2.0, 1.0])
+    with pytest.raises(ValueError):
+        em.GaussianConditional(None, scale_bound=-0.1)
+    with pytest.raises(ValueError):
+        em._EntropyCoder("rangecoder42")
+    with pytest.raises(NotImplementedError):
+        em.EntropyModel().forward()
+
+
+# ----------------------------------------------------------------------------- host codec, bit exact
+def test_gaussian_update_tables_match_reference(golden):
+    g = golden("codec.npz")
+    gc = em.GaussianConditional(None)
+    assert gc.update_scale_table(get_scale_table()) is True
+    assert gc.update_scale_table(get_scale_table()) is False
+    np.testing.assert_array_equal(gc.scale_table.numpy(), g["gc:scale_table"])
+    np.testing.assert_array_equal(gc._offset.numpy(), g["gc:offset"])
+    np.testing.assert_array_equal(gc._cdf_length.numpy(), g["gc:cdf_length"])
+    cdf = gc._quantized_cdf.numpy()
+    assert tuple(cdf.shape) == tuple(g["gc:cdf_shape"])
+    assert zlib.crc32(np.ascontiguousarray(cdf).tobytes()) == int(g["gc:cdf_crc32"][0])
+
+
+def test_pmf_to_quantized_cdf_matches_reference(golden):
+    g = golden("codec.npz")
+    for i in range(4):
+        np.testing.assert_array_equal(em.pmf_to_quantized_cdf(torch.from_numpy(g[f"pmf{i}"]), 16).numpy().astype(np.uint32), g[f"cdf{i}"])
+    with pytest.raises(ValueError):
+        em.pmf_to_quantized_cdf(torch.zeros(4), 16)
+
+
+def _tables():
+    gc = em.GaussianConditional(None)
+    gc.update_scale_table(get_scale_table())
+    return gc.host_tables(), gc
+
+
+def test_rans_streams_are_byte_identical_to_reference(golden):
+    g = golden("codec.npz")
+    t, gc = _tables()
+    for i in range(4):
+        sym, idx = g[f"rans{i}:symbols"], g[f"rans{i}:indexes"]
+        s = em.RansEncoder().encode_with_indexes(sym, idx, t)
+        assert s == g[f"rans{i}:bytes"].tobytes()
+        np.testing.assert_array_equal(em.RansDecoder().decode_with_indexes_np(s, idx, t), sym)
+        # the reference's list-of-lists calling convention works too
+        s2 = em.RansEncoder().encode_with_indexes(sym.tolist(), idx.tolist(), gc.quantized_cdf.tolist(),
+                                                  gc.cdf_length.tolist(), gc.offset.tolist())
+        assert s2 == s
+    enc = em.BufferedRansEncoder()
+    enc.encode_with_indexes(g["bufrans:sym_a"], g["bufrans:idx_a"], t)
+    enc.encode_with_indexes(g["bufrans:sym_b"], g["bufrans:idx_b"], t)
+    s = enc.flush()
+    assert s == g["bufrans:bytes"].tobytes()
+    dec = em.RansDecoder()
+    dec.set_stream(s)
+    assert dec.decode_stream(g["bufrans:idx_a"], t) == g["bufrans:sym_a"].tolist()
+    assert dec.decode_stream(g["bufrans:idx_b"], t) == g["bufrans:sym_b"].tolist()
+
+
+def test_rans_edge_cases():
+    t, _ = _tables()
+    # empty and 1-symbol streams (the reference's encoder overruns its own buffer here, rans_interface.cpp:170)
+    s = em.RansEncoder().encode_with_indexes(np.zeros(0, np.int32), np.zeros(0, np.int32), t)
+    assert len(s) == 8
+    for v in (0, 5, -100000, 2 ** 20):
+        s = em.RansEncoder().encode_with_indexes(np.array([v], np.int32), np.array([3], np.int32), t)
+        assert em.RansDecoder().decode_with_indexes(s, np.array([3], np.int32), t) == [v]
+    # long ragged stream with many escapes, maximum / minimum index
+    rng = np.random.default_rng(3)
+    idx = rng.choice([0, 63], size=20001).astype(np.int32)
+    sym = rng.integers(-3000, 3000, size=20001).astype(np.int32)
+    s = em.RansEncoder().encode_with_indexes(sym, idx, t)
+    np.testing.assert_array_equal(em.RansDecoder().decode_with_indexes_np(s, idx, t), sym)
+    # invalid input is an error, not UB
+    with pytest.raises(RuntimeError):
+        em.RansEncoder().encode_with_indexes(np.array([1], np.int32), np.array([64], np.int32), t)
+    with pytest.raises(RuntimeError):
+        em.RansDecoder().decode_with_indexes(b"\x00" * 5, np.array([0], np.int32), t)
+    with pytest.raises(RuntimeError):
+        em.RansDecoder().decode_stream(np.array([0], np.int32), t)          # set_stream not called
+    with pytest.raises(RuntimeError):
+        em.RansDecoder().decode_with_indexes(s[: len(s) // 2], idx, t)      # truncated stream
+
+
+def test_entropy_bottleneck_update_tables_match_reference(golden):
+    g = golden("ops_small.npz")
+    eb = em.EntropyBottleneck(4)
+    with torch.no_grad():
+        for n, p in eb.named_parameters():
+            p.copy_(torch.from_numpy(g[f"eb:p:{n}"]))
+    assert eb.update(force=True)
+    np.testing.assert_array_equal(eb._offset.numpy(), g["eb:offset"])
+    np.testing.assert_array_equal(eb._cdf_length.numpy(), g["eb:cdf_length"])
+    np.testing.assert_array_equal(eb._quantized_cdf.numpy(), g["eb:cdf"])
+    assert eb.update() is False
+
+
+# ----------------------------------------------------------------------------- flat buffers
+def test_flat_parameters_views_and_order():
+    from spatiotemporalentropymodel_amd.optim import FlatParameters
+    m = SpatioTemporalPriorModel_Res(64, 96)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    main = sorted([(n, p) for n, p in m.named_parameters() if not n.endswith(".quantiles")], key=lambda t: t[0])
+    flat = FlatParameters(main)
+    assert flat.numel >= sum(p.numel() for _, p in main) and flat.numel % 4 == 0
+    for (n, p), o in zip(main, flat.offsets):
+        assert torch.equal(p, before[n]) and o % 4 == 0
+        assert p.data_ptr() == flat.data.data_ptr() + 4 * o          # a view, not a copy
+        assert p.grad.data_ptr() == flat.grad.data_ptr() + 4 * o
+    flat.data.mul_(2.0)
+    n0, p0 = main[0]
+    assert torch.equal(p0, before[n0] * 2)
