@@ -94,7 +94,8 @@ def smoke_check(verbose=False):
     checks = {"loss": rel(oc["loss"], loss), "y_bpp": rel(oc["y_bpp_loss"], ybpp), "z_bpp": rel(oc["z_bpp_loss"], zbpp),
               "grad_norm": rel(gn, gn_ref), "aux_loss": rel(aux, aux_ref)}
     lik_y = out["likelihoods"]["y"].detach().cpu().contiguous().numpy()
-    checks["lik_y_vs_golden"] = float(np.max(np.abs(lik_y - g["s1:lik_y"]) / (np.abs(g["s1:lik_y"]) + 1e-3)))
+    ref_l = g["s1:lik_y"]        # same metric as tests/conftest.py:assert_close (floor = 0.1 x max)
+    checks["lik_y_vs_golden"] = float(np.max(np.abs(lik_y - ref_l) / np.maximum(np.abs(ref_l), 0.1 * ref_l.max())))
     # oracle on the same y_cur / y_cond (g_a through the oracle as well)
     isd = {k: v.detach().cpu().numpy() for k, v in imodel.state_dict().items() if v.dtype == torch.float32}
     y_ref = orc.g_a(isd, frames[1].cpu().numpy())
