@@ -53,12 +53,20 @@ int stem_unpack_wgrad(const float *dwp, float *dw, int K, int C, int R, int S, i
 /* ---- epilogues --------------------------------------------------------- */
 enum { STEM_ACT_NONE = 0, STEM_ACT_LRELU = 1 };
 
+/* Split-K workspace.  Layers whose output is too small to fill 256 CUs (the 16x16 / 8x8 / 4x4 STEM latents)
+ * split their reduction over taps x channels across workgroups; the fp32 partial tiles go to `ws` and a second
+ * kernel sums them in a fixed order and applies bias / activation (bit-reproducible, no float atomics).
+ * kind: 0 conv fwd, 1 conv dgrad, 2 deconv fwd, 3 deconv dgrad; dims are the LAYER's (B,H,W,C in / K out).
+ * Passing ws = NULL (or too few bytes) is legal and runs the unsplit schedule.                              */
+enum { STEM_KIND_CONV_FWD = 0, STEM_KIND_CONV_DGRAD = 1, STEM_KIND_DECONV_FWD = 2, STEM_KIND_DECONV_DGRAD = 3 };
+size_t stem_conv_workspace_bytes(int kind, int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad);
+
 /* nn.Conv2d forward (+bias, optional fused LeakyReLU).  Replaces F.conv2d under
  * compressai/models/utils.py:112-120 and spatiotemporalpriors.py:807-838.
  * x[B,H,W,C] (ldx)  wp = STEM_PACK_CONV_FWD  ->  y[B,Ho,Wo,K] (ldy)                             */
 int stem_conv2d_fwd(const float *x, int ldx, const float *wp, const float *bias, float *y, int ldy,
                     int B, int H, int W, int C, int K, int R, int S, int stride, int pad,
-                    int act, float slope, void *stream);
+                    int act, float slope, void *ws, size_t ws_bytes, void *stream);
 /* first analysis layer (C_in = 3, priors.py:422): x is NHWC with 4 channels (4th zero) made by
  * stem_nchw3_to_nhwc4; wp = STEM_PACK_CONV_FWD_C4.                                               */
 int stem_conv2d_fwd_c4(const float *x4, const float *wp, const float *bias, float *y, int ldy,
@@ -68,22 +76,26 @@ int stem_conv2d_fwd_c4(const float *x4, const float *wp, const float *bias, floa
  * preceding LeakyReLU), fusing the activation backward.                                           */
 int stem_conv2d_dgrad(const float *dy, int lddy, const float *wp, float *dx, int lddx,
                       const float *xact, int ldxact, float slope,
-                      int B, int H, int W, int C, int K, int R, int S, int stride, int pad, void *stream);
+                      int B, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                      void *ws, size_t ws_bytes, void *stream);
 /* dW (packed, `splits` slabs of [R*S][K][C]) and db[K] of nn.Conv2d.  All R*S taps are produced
- * (the reference's autograd does not mask MaskedConv2d's weight gradient).                        */
+ * (the reference's autograd does not mask MaskedConv2d's weight gradient).  dwp must hold
+ * stem_wgrad_workspace_elems() floats: the slabs plus scratch for the two-stage bias-gradient sum.  */
 int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
                       int B, int H, int W, int C, int K, int R, int S, int stride, int pad,
                       int splits, void *stream);
-int stem_wgrad_splits(int B, int Ho, int Wo, int C, int K, int R, int S);
+int stem_wgrad_splits(int B, int Ho, int Wo, int C, int K, int R, int S);      /* Ho,Wo = the loop grid (Conv2d: output) */
+size_t stem_wgrad_workspace_elems(int splits, int C, int K, int R, int S);
 
 /* nn.ConvTranspose2d forward as sub-pixel phases (no zero insertion).  models/utils.py:122-130,
  * spatiotemporalpriors.py:821-826.  x[B,H,W,C] -> y[B,Ho,Wo,K], wp = STEM_PACK_DECONV_FWD.        */
 int stem_deconv2d_fwd(const float *x, int ldx, const float *wp, const float *bias, float *y, int ldy,
                       int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad,
-                      int act, float slope, void *stream);
+                      int act, float slope, void *ws, size_t ws_bytes, void *stream);
 int stem_deconv2d_dgrad(const float *dy, int lddy, const float *wp, float *dx, int lddx,
                         const float *xact, int ldxact, float slope,
-                        int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad, void *stream);
+                        int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad,
+                        void *ws, size_t ws_bytes, void *stream);
 /* dW packed as [splits][R*S][K][C] with K = out channels, C = in channels; unpack with deconv=1. */
 int stem_deconv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
                         int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad,

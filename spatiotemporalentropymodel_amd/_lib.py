@@ -21,13 +21,15 @@ vp, ci, cf, sz, u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 _HIP_SIG = {
     "stem_pack_weight": [vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "stem_unpack_wgrad": [vp, vp, ci, ci, ci, ci, ci, ci, vp],
-    "stem_conv2d_fwd": [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp],
+    "stem_conv2d_fwd": [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, sz, vp],
     "stem_conv2d_fwd_c4": [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
-    "stem_conv2d_dgrad": [vp, ci, vp, vp, ci, vp, ci, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_conv2d_dgrad": [vp, ci, vp, vp, ci, vp, ci, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],
     "stem_conv2d_wgrad": [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_wgrad_splits": [ci, ci, ci, ci, ci, ci, ci],
-    "stem_deconv2d_fwd": [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp],
-    "stem_deconv2d_dgrad": [vp, ci, vp, vp, ci, vp, ci, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_wgrad_workspace_elems": [ci, ci, ci, ci, ci],
+    "stem_conv_workspace_bytes": [ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci],
+    "stem_deconv2d_fwd": [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, sz, vp],
+    "stem_deconv2d_dgrad": [vp, ci, vp, vp, ci, vp, ci, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],
     "stem_deconv2d_wgrad": [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_gdn_fwd": [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp],
     "stem_lrelu_bwd": [vp, vp, vp, sz, cf, vp],
@@ -55,7 +57,7 @@ _HIP_SIG = {
     "stem_abi_version": [],
     "stem_last_error": [],
 }
-_RESTYPE = {"stem_packed_weight_elems": sz, "stem_last_error": C.c_char_p}
+_RESTYPE = {"stem_packed_weight_elems": sz, "stem_wgrad_workspace_elems": sz, "stem_conv_workspace_bytes": sz, "stem_last_error": C.c_char_p}
 
 _RANS_SIG = {
     "stem_rans_encode": [vp, vp, sz, vp, ci, ci, vp, vp, vp, sz],

@@ -39,6 +39,11 @@ struct IgemmArgs {
     int isy, isx, osy, osx;
     int nphase, epi, asquare, breparam;
     float slope, beta_bound;
+    // split-K: blockIdx.z = phase * nsplit + split; each split reduces chunks [split*cps, (split+1)*cps) and
+    // writes its raw fp32 partial tile to ws[split][out pixel][n]; splitk_reduce_kernel applies the epilogue.
+    float *ws;
+    int nsplit, cps;
+    long slab;
     TapPhase ph[4];
 };
 
@@ -54,7 +59,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
     int *tapi = reinterpret_cast<int *>(smem + 2 * (BM + BN) * PITCH);   // [32][4]: dy, dx, wt, valid
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const TapPhase &ph = a.ph[blockIdx.z];
+    const int zphase = blockIdx.z / a.nsplit, zsplit = blockIdx.z - zphase * a.nsplit;
+    const TapPhase &ph = a.ph[zphase];
     const int Mtot = a.B * ph.qh * ph.qw;
     const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
     if (bm0 >= Mtot) return;
@@ -84,7 +90,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
         p_base[j] = b * a.H * a.W;
     }
     const int nkc = C4 ? 1 : (a.C + KC - 1) / KC;
-    const int nchunks = C4 ? (ph.ntaps + 7) / 8 : ph.ntaps * nkc;
+    const int nchunks_all = C4 ? (ph.ntaps + 7) / 8 : ph.ntaps * nkc;
+    const int q_begin = zsplit * a.cps;
+    const int q_end = a.nsplit > 1 ? (q_begin + a.cps < nchunks_all ? q_begin + a.cps : nchunks_all) : nchunks_all;
     __syncthreads();
 
     f32x4 ra[AR], rb[BR];
@@ -164,12 +172,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    gload(0);
-    sstore(0);
+    if (q_begin < q_end) {
+        gload(q_begin);
+        sstore(0);
+    }
     __syncthreads();
-    for (int q = 0; q < nchunks; ++q) {
-        const int cur = q & 1;
-        if (q + 1 < nchunks) gload(q + 1);
+    for (int q = q_begin; q < q_end; ++q) {
+        const int cur = (q - q_begin) & 1;
+        if (q + 1 < q_end) gload(q + 1);
         const float *Ab = As + (cur * BM + wm0 + lr) * PITCH + 4 * lh;
         const float *Bb = Bs + (cur * BN + wn0 + lr) * PITCH + 4 * lh;
 #pragma unroll
@@ -187,8 +197,29 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (q + 1 < nchunks) sstore(cur ^ 1);
+        if (q + 1 < q_end) sstore(cur ^ 1);
         __syncthreads();
+    }
+
+    if (a.nsplit > 1) {   // raw partial sums; bias / activation happen in splitk_reduce_kernel
+        float *wsp = a.ws + (size_t)zsplit * a.slab;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = bn0 + wn0 + j * 32 + lr;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = bm0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m >= Mtot) continue;
+                    const int b = m / qhw, rem = m - b * qhw;
+                    const int qy = rem / ph.qw, qx = rem - qy * ph.qw;
+                    const size_t opix = (size_t)(b * a.OH + qy * a.osy + ph.ooy) * a.OW + qx * a.osx + ph.oox;
+                    wsp[opix * a.N + n] = acc[i][j][r];
+                }
+        }
+        return;
     }
 
     // ---- epilogue: lane holds column n = ..+lr, rows (r&3)+8*(r>>2)+4*lh of each 32x32 tile -------
@@ -224,6 +255,42 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
                 a.y[opix * a.ldy + n] = v;
             }
         }
+    }
+}
+
+// y[pix][n] = epi(bias[n] + sum_s ws[s][pix][n]); one thread per 4 channels when VEC4
+template <bool VEC4>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *ws, long slab, int nsplit, const float *bias,
+                                                            const float *z, int ldz, float *y, int ldy, size_t npix, int N,
+                                                            int epi, float slope)
+{
+    constexpr int V = VEC4 ? 4 : 1;
+    const int nv = N / V;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix * nv) return;
+    const size_t pix = i / nv;
+    const int n = (int)(i - pix * nv) * V;
+    float v[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = bias ? bias[n + e] : 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float *p = ws + (size_t)s * slab + pix * N + n;
+        if (VEC4) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(p);
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] += t[e];
+        } else {
+            v[0] += p[0];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        if (epi == EPI_LRELU) {
+            v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+        } else if (epi == EPI_DACT) {
+            v[e] = z[pix * ldz + n + e] > 0.f ? v[e] : v[e] * slope;
+        }
+        y[pix * ldy + n + e] = v[e];
     }
 }
 
@@ -277,6 +344,55 @@ void build_transposed(IgemmArgs &g, int R, int S, int stride, int pad, int OH, i
         }
 }
 
+struct Plan {
+    bool big;
+    int nsplit, cps;
+    size_t ws_bytes;
+};
+
+// Tile / split-K choice.  128x128 tiles have twice the flop per staged byte of 64x64; when the output is
+// too small to fill 256 CUs with them the reduction (taps x channels) is split over blockIdx.z instead.
+Plan make_plan(const IgemmArgs &g, bool c4)
+{
+    int maxM = 0, maxchunks = 0;
+    const int nkc = c4 ? 1 : cdiv(g.C, KC);
+    for (int p = 0; p < g.nphase; ++p) {
+        const int m = g.B * g.ph[p].qh * g.ph[p].qw;
+        if (m > maxM) maxM = m;
+        const int nc = c4 ? cdiv(g.ph[p].ntaps, 8) : g.ph[p].ntaps * nkc;
+        if (nc > maxchunks) maxchunks = nc;
+    }
+    Plan pl{true, 1, maxchunks, 0};
+    if (maxM == 0) return pl;
+    const long t128 = (long)cdiv(maxM, 128) * cdiv(g.N, 128) * g.nphase;
+    const long t64 = (long)cdiv(maxM, 64) * cdiv(g.N, 64) * g.nphase;
+    const bool can_split = g.epi != EPI_GDN && g.epi != EPI_IGDN && !c4;
+    if (t128 >= 512 && g.N >= 96) return pl;
+    if (!can_split) {
+        pl.big = t128 >= 256 && g.N >= 96;
+        return pl;
+    }
+    long s128 = cdiv(512, (int)t128);
+    if (s128 > maxchunks / 8) s128 = maxchunks / 8;
+    if (s128 > 32) s128 = 32;
+    if (s128 < 1) s128 = 1;
+    if (g.N >= 96 && t128 * s128 >= 256) {
+        pl.big = true;
+        pl.nsplit = (int)s128;
+    } else {
+        long s64 = cdiv(768, (int)t64);
+        if (s64 > maxchunks / 4) s64 = maxchunks / 4;
+        if (s64 > 64) s64 = 64;
+        if (s64 < 1) s64 = 1;
+        pl.big = false;
+        pl.nsplit = (int)s64;
+    }
+    pl.cps = cdiv(maxchunks, pl.nsplit);
+    pl.nsplit = cdiv(maxchunks, pl.cps);           // drop empty trailing splits
+    if (pl.nsplit > 1) pl.ws_bytes = (size_t)pl.nsplit * g.B * g.OH * g.OW * g.N * sizeof(float);
+    return pl;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const IgemmArgs &g, bool vec, bool c4, hipStream_t st)
 {
@@ -286,7 +402,7 @@ int launch_cfg(const IgemmArgs &g, bool vec, bool c4, hipStream_t st)
         if (m > maxM) maxM = m;
     }
     if (maxM == 0 || g.N == 0) return 0;
-    dim3 grid(cdiv(maxM, BM), cdiv(g.N, BN), g.nphase), block(256);
+    dim3 grid(cdiv(maxM, BM), cdiv(g.N, BN), g.nphase * g.nsplit), block(256);
     const size_t lds = (size_t)2 * (BM + BN) * PITCH * sizeof(float) + 32 * 4 * sizeof(int);
     static bool attr_done = false;     // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
     if (!attr_done) {
@@ -305,19 +421,33 @@ int launch_cfg(const IgemmArgs &g, bool vec, bool c4, hipStream_t st)
     return 0;
 }
 
-int launch(const IgemmArgs &g, bool c4, hipStream_t st)
+int launch(IgemmArgs &g, bool c4, void *ws, size_t ws_bytes, hipStream_t st)
 {
     const bool vec = c4 || ((g.C % 4 == 0) && (g.ldx % 4 == 0) && (g.ldw % 4 == 0) &&
                             (((uintptr_t)g.x & 15) == 0) && (((uintptr_t)g.w & 15) == 0));
-    int maxM = 0;
-    for (int p = 0; p < g.nphase; ++p) {
-        const int m = g.B * g.ph[p].qh * g.ph[p].qw;
-        if (m > maxM) maxM = m;
+    Plan pl = make_plan(g, c4);
+    if (pl.nsplit > 1 && (ws == nullptr || ws_bytes < pl.ws_bytes)) {      // no workspace: run unsplit (slower, same result)
+        pl.nsplit = 1;
+        pl.ws_bytes = 0;
     }
-    // 128x128 tiles when they still fill the chip (>= 2 blocks per CU), else 64x64.
-    const long big = (long)cdiv(maxM, 128) * cdiv(g.N, 128) * g.nphase;
-    if (big >= 512 && g.N >= 96) return launch_cfg<128, 128, 64, 64>(g, vec, c4, st);
-    return launch_cfg<64, 64, 32, 32>(g, vec, c4, st);
+    g.nsplit = pl.nsplit;
+    g.cps = pl.cps;
+    g.ws = (float *)ws;
+    g.slab = (long)g.B * g.OH * g.OW * g.N;
+    const int rc = pl.big ? launch_cfg<128, 128, 64, 64>(g, vec, c4, st) : launch_cfg<64, 64, 32, 32>(g, vec, c4, st);
+    if (rc || pl.nsplit == 1) return rc;
+    const size_t npix = (size_t)g.B * g.OH * g.OW;
+    const bool v4 = (g.N % 4 == 0) && (g.ldy % 4 == 0) && (((uintptr_t)g.y & 15) == 0) &&
+                    (g.epi != EPI_DACT || (g.ldz % 4 == 0));
+    const size_t nthreads = npix * (v4 ? g.N / 4 : g.N);
+    if (v4)
+        hipLaunchKernelGGL((splitk_reduce_kernel<true>), dim3((unsigned)cdivz(nthreads, 256)), dim3(256), 0, st, g.ws, g.slab,
+                           g.nsplit, g.bias, g.z, g.ldz, g.y, g.ldy, npix, g.N, g.epi, g.slope);
+    else
+        hipLaunchKernelGGL((splitk_reduce_kernel<false>), dim3((unsigned)cdivz(nthreads, 256)), dim3(256), 0, st, g.ws, g.slab,
+                           g.nsplit, g.bias, g.z, g.ldz, g.y, g.ldy, npix, g.N, g.epi, g.slope);
+    STEM_LAUNCH_CHECK("splitk_reduce");
+    return 0;
 }
 
 int check_common(const char *name, const void *x, const void *w, const void *y, int B, int H, int W, int C, int K,
@@ -333,23 +463,61 @@ int check_common(const char *name, const void *x, const void *w, const void *y, 
 }   // namespace
 
 // =================================================================================================
+namespace {
+
+enum { KIND_CONV_FWD = 0, KIND_CONV_DGRAD = 1, KIND_DECONV_FWD = 2, KIND_DECONV_DGRAD = 3 };
+
+// geometry of the four convolution-shaped ops in terms of the generic kernel (B,H,W,C,K = the LAYER's dims)
+void fill_geometry(IgemmArgs &g, int kind, int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad)
+{
+    memset(&g, 0, sizeof(g));
+    g.B = B;
+    const int Hc = (H + 2 * pad - R) / stride + 1, Wc = (W + 2 * pad - S) / stride + 1;              // Conv2d output
+    const int Hd = (H - 1) * stride - 2 * pad + R + opad, Wd = (W - 1) * stride - 2 * pad + S + opad;  // ConvTranspose2d output
+    switch (kind) {
+    case KIND_CONV_FWD:        // x[B,H,W,C] -> y[B,Hc,Wc,K]
+        g.H = H; g.W = W; g.C = C; g.N = K; g.OH = Hc; g.OW = Wc; g.ldw = C;
+        build_direct(g, R, S, stride, pad, Hc, Wc);
+        break;
+    case KIND_CONV_DGRAD:      // dy[B,Hc,Wc,K] -> dx[B,H,W,C]
+        g.H = Hc; g.W = Wc; g.C = K; g.N = C; g.OH = H; g.OW = W; g.ldw = K;
+        build_transposed(g, R, S, stride, pad, H, W);
+        break;
+    case KIND_DECONV_FWD:      // x[B,H,W,C] -> y[B,Hd,Wd,K]
+        g.H = H; g.W = W; g.C = C; g.N = K; g.OH = Hd; g.OW = Wd; g.ldw = C;
+        build_transposed(g, R, S, stride, pad, Hd, Wd);
+        break;
+    default:                   // dy[B,Hd,Wd,K] -> dx[B,H,W,C]
+        g.H = Hd; g.W = Wd; g.C = K; g.N = C; g.OH = H; g.OW = W; g.ldw = K;
+        build_direct(g, R, S, stride, pad, H, W);
+        break;
+    }
+}
+
+}   // namespace
+
+STEM_EXPORT size_t stem_conv_workspace_bytes(int kind, int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad)
+{
+    if (kind < 0 || kind > 3 || B <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R * S > 25 || R < 1 || S < 1) return 0;
+    IgemmArgs g;
+    fill_geometry(g, kind, B, H, W, C, K, R, S, stride, pad, opad);
+    if (g.OH <= 0 || g.OW <= 0) return 0;
+    return make_plan(g, false).ws_bytes;
+}
+
 STEM_EXPORT int stem_conv2d_fwd(const float *x, int ldx, const float *wp, const float *bias, float *y, int ldy,
                                 int B, int H, int W, int C, int K, int R, int S, int stride, int pad,
-                                int act, float slope, void *stream)
+                                int act, float slope, void *ws, size_t ws_bytes, void *stream)
 {
     if (check_common("stem_conv2d_fwd", x, wp, y, B, H, W, C, K, R, S, stride)) return -1;
     IgemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.x = x; g.w = wp; g.bias = bias; g.y = y;
-    g.ldx = ldx; g.ldw = C; g.ldy = ldy;
-    g.B = B; g.H = H; g.W = W; g.C = C; g.N = K;
-    g.OH = (H + 2 * pad - R) / stride + 1;
-    g.OW = (W + 2 * pad - S) / stride + 1;
+    fill_geometry(g, KIND_CONV_FWD, B, H, W, C, K, R, S, stride, pad, 0);
     STEM_CHECK_ARG(g.OH > 0 && g.OW > 0, "stem_conv2d_fwd: empty output");
-    build_direct(g, R, S, stride, pad, g.OH, g.OW);
+    g.x = x; g.w = wp; g.bias = bias; g.y = y;
+    g.ldx = ldx; g.ldy = ldy;
     g.epi = act == STEM_ACT_LRELU ? EPI_LRELU : EPI_BIAS;
     g.slope = slope;
-    return launch(g, false, (hipStream_t)stream);
+    return launch(g, false, ws, ws_bytes, (hipStream_t)stream);
 }
 
 STEM_EXPORT int stem_conv2d_fwd_c4(const float *x4, const float *wp, const float *bias, float *y, int ldy,
@@ -357,70 +525,55 @@ STEM_EXPORT int stem_conv2d_fwd_c4(const float *x4, const float *wp, const float
 {
     if (check_common("stem_conv2d_fwd_c4", x4, wp, y, B, H, W, 4, K, R, S, stride)) return -1;
     IgemmArgs g;
-    memset(&g, 0, sizeof(g));
+    fill_geometry(g, KIND_CONV_FWD, B, H, W, 4, K, R, S, stride, pad, 0);
     g.x = x4; g.w = wp; g.bias = bias; g.y = y;
     g.ldx = 4; g.ldw = 128; g.ldy = ldy;
-    g.B = B; g.H = H; g.W = W; g.C = 4; g.N = K;
-    g.OH = (H + 2 * pad - R) / stride + 1;
-    g.OW = (W + 2 * pad - S) / stride + 1;
-    build_direct(g, R, S, stride, pad, g.OH, g.OW);
     g.epi = EPI_BIAS;
-    return launch(g, true, (hipStream_t)stream);
+    return launch(g, true, nullptr, 0, (hipStream_t)stream);
 }
 
 STEM_EXPORT int stem_conv2d_dgrad(const float *dy, int lddy, const float *wp, float *dx, int lddx,
                                   const float *xact, int ldxact, float slope,
-                                  int B, int H, int W, int C, int K, int R, int S, int stride, int pad, void *stream)
+                                  int B, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                                  void *ws, size_t ws_bytes, void *stream)
 {
     if (check_common("stem_conv2d_dgrad", dy, wp, dx, B, H, W, C, K, R, S, stride)) return -1;
     IgemmArgs g;
-    memset(&g, 0, sizeof(g));
-    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    fill_geometry(g, KIND_CONV_DGRAD, B, H, W, C, K, R, S, stride, pad, 0);
     g.x = dy; g.w = wp; g.y = dx; g.z = xact;
-    g.ldx = lddy; g.ldw = K; g.ldy = lddx; g.ldz = ldxact;
-    g.B = B; g.H = Ho; g.W = Wo; g.C = K; g.N = C;
-    g.OH = H; g.OW = W;
-    build_transposed(g, R, S, stride, pad, H, W);
+    g.ldx = lddy; g.ldy = lddx; g.ldz = ldxact;
     g.epi = xact ? EPI_DACT : EPI_BIAS;
     g.slope = slope;
-    return launch(g, false, (hipStream_t)stream);
+    return launch(g, false, ws, ws_bytes, (hipStream_t)stream);
 }
 
 STEM_EXPORT int stem_deconv2d_fwd(const float *x, int ldx, const float *wp, const float *bias, float *y, int ldy,
                                   int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad,
-                                  int act, float slope, void *stream)
+                                  int act, float slope, void *ws, size_t ws_bytes, void *stream)
 {
     if (check_common("stem_deconv2d_fwd", x, wp, y, B, H, W, C, K, R, S, stride)) return -1;
     IgemmArgs g;
-    memset(&g, 0, sizeof(g));
+    fill_geometry(g, KIND_DECONV_FWD, B, H, W, C, K, R, S, stride, pad, opad);
     g.x = x; g.w = wp; g.bias = bias; g.y = y;
-    g.ldx = ldx; g.ldw = C; g.ldy = ldy;
-    g.B = B; g.H = H; g.W = W; g.C = C; g.N = K;
-    g.OH = (H - 1) * stride - 2 * pad + R + opad;
-    g.OW = (W - 1) * stride - 2 * pad + S + opad;
-    build_transposed(g, R, S, stride, pad, g.OH, g.OW);
+    g.ldx = ldx; g.ldy = ldy;
     g.epi = act == STEM_ACT_LRELU ? EPI_LRELU : EPI_BIAS;
     g.slope = slope;
-    return launch(g, false, (hipStream_t)stream);
+    return launch(g, false, ws, ws_bytes, (hipStream_t)stream);
 }
 
 STEM_EXPORT int stem_deconv2d_dgrad(const float *dy, int lddy, const float *wp, float *dx, int lddx,
                                     const float *xact, int ldxact, float slope,
                                     int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad,
-                                    void *stream)
+                                    void *ws, size_t ws_bytes, void *stream)
 {
     if (check_common("stem_deconv2d_dgrad", dy, wp, dx, B, H, W, C, K, R, S, stride)) return -1;
     IgemmArgs g;
-    memset(&g, 0, sizeof(g));
-    const int Ho = (H - 1) * stride - 2 * pad + R + opad, Wo = (W - 1) * stride - 2 * pad + S + opad;
+    fill_geometry(g, KIND_DECONV_DGRAD, B, H, W, C, K, R, S, stride, pad, opad);
     g.x = dy; g.w = wp; g.y = dx; g.z = xact;
-    g.ldx = lddy; g.ldw = K; g.ldy = lddx; g.ldz = ldxact;
-    g.B = B; g.H = Ho; g.W = Wo; g.C = K; g.N = C;
-    g.OH = H; g.OW = W;
-    build_direct(g, R, S, stride, pad, H, W);
+    g.ldx = lddy; g.ldy = lddx; g.ldz = ldxact;
     g.epi = xact ? EPI_DACT : EPI_BIAS;
     g.slope = slope;
-    return launch(g, false, (hipStream_t)stream);
+    return launch(g, false, ws, ws_bytes, (hipStream_t)stream);
 }
 
 STEM_EXPORT int stem_gdn_fwd(const float *x, int ldx, const float *beta, const float *gamma, float *y, int ldy,
@@ -429,15 +582,12 @@ STEM_EXPORT int stem_gdn_fwd(const float *x, int ldx, const float *beta, const f
     if (check_common("stem_gdn_fwd", x, gamma, y, B, H, W, C, C, 1, 1, 1)) return -1;
     STEM_CHECK_ARG(beta, "stem_gdn_fwd: null beta");
     IgemmArgs g;
-    memset(&g, 0, sizeof(g));
+    fill_geometry(g, KIND_CONV_FWD, B, H, W, C, C, 1, 1, 1, 0, 0);
     g.x = x; g.w = gamma; g.y = y; g.z = x; g.beta = beta;
-    g.ldx = ldx; g.ldw = C; g.ldy = ldy; g.ldz = ldx;
-    g.B = B; g.H = H; g.W = W; g.C = C; g.N = C;
-    g.OH = H; g.OW = W;
-    build_direct(g, 1, 1, 1, 0, H, W);
+    g.ldx = ldx; g.ldy = ldy; g.ldz = ldx;
     g.epi = inverse ? EPI_IGDN : EPI_GDN;
     g.asquare = 1;
     g.breparam = 1;
-    g.beta_bound = sqrtf(beta_min + 1.4551915228366852e-11f);
-    return launch(g, false, (hipStream_t)stream);
+    g.beta_bound = (float)sqrt((double)beta_min + 1.4551915228366852e-11);
+    return launch(g, false, nullptr, 0, (hipStream_t)stream);
 }

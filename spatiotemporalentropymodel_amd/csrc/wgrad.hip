@@ -207,25 +207,48 @@ int run(const float *p, int ldp, int CP, const float *g, int ldg, int CG, float 
     return launch_cfg<64, 64, 32, 32>(a, vec, st);
 }
 
-// column sums: db[k] = sum_m dy[m][k].  One block per 32-channel tile, 8 pixel rows in flight.
-__global__ __launch_bounds__(256) void colsum_kernel(const float *dy, int ld, size_t npix, int K, float *out)
+// Bias gradient db[k] = sum_m dy[m][k] in two deterministic stages: CS_PARTS pixel ranges x 64-channel tiles
+// write partial column sums (coalesced 256-B rows), then one thread per channel adds the partials in order.
+constexpr int CS_PARTS = 64;
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *dy, int ld, size_t npix, int K, float *part)
 {
-    __shared__ float red[8][33];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = threadIdx.x >> 5;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const size_t per = (npix + CS_PARTS - 1) / CS_PARTS;
+    const size_t m0 = blockIdx.y * per, m1 = m0 + per < npix ? m0 + per : npix;
     float s = 0.f;
     if (c < K)
-        for (size_t m = r; m < npix; m += 8) s += dy[m * ld + c];
-    red[r][threadIdx.x & 31] = s;
+        for (size_t m = m0 + r; m < m1; m += 4) s += dy[m * ld + c];
+    red[r][lane] = s;
     __syncthreads();
-    if (r == 0 && c < K) {
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) t += red[q][threadIdx.x & 31];
-        out[c] = t;
-    }
+    if (r == 0 && c < K) part[(size_t)blockIdx.y * K + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+__global__ void colsum_final_kernel(const float *part, int K, float *out)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= K) return;
+    float s = 0.f;
+    for (int p = 0; p < CS_PARTS; ++p) s += part[(size_t)p * K + c];
+    out[c] = s;
+}
+
+int colsum(const float *dy, int ld, size_t npix, int K, float *scratch, float *db, hipStream_t st)
+{
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(K, 64), CS_PARTS), dim3(256), 0, st, dy, ld, npix, K, scratch);
+    STEM_LAUNCH_CHECK("colsum_partial");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, scratch, K, db);
+    STEM_LAUNCH_CHECK("colsum_final");
+    return 0;
 }
 
 }   // namespace
+
+STEM_EXPORT size_t stem_wgrad_workspace_elems(int splits, int C, int K, int R, int S)
+{
+    return (size_t)splits * R * S * K * C + (size_t)CS_PARTS * K;
+}
 
 STEM_EXPORT int stem_wgrad_splits(int B, int Ho, int Wo, int C, int K, int R, int S)
 {
@@ -240,10 +263,7 @@ STEM_EXPORT int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int 
     STEM_CHECK_ARG(splits >= 1, "stem_conv2d_wgrad: splits must be >= 1");
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     hipStream_t st = (hipStream_t)stream;
-    if (db) {
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(K, 32)), dim3(256), 0, st, dy, lddy, (size_t)B * Ho * Wo, K, db);
-        STEM_LAUNCH_CHECK("colsum");
-    }
+    if (db && colsum(dy, lddy, (size_t)B * Ho * Wo, K, dwp + (size_t)splits * R * S * K * C, db, st)) return -2;
     // P = dY on the output grid (K channels), G = x gathered at oy*stride - pad + r  ->  [t][K][C]
     return run(dy, lddy, K, x, ldx, C, dwp, B, Ho, Wo, H, W, R, S, stride, pad, splits, st);
 }
@@ -256,10 +276,7 @@ STEM_EXPORT int stem_deconv2d_wgrad(const float *x, int ldx, const float *dy, in
     STEM_CHECK_ARG(splits >= 1, "stem_deconv2d_wgrad: splits must be >= 1");
     const int Ho = (H - 1) * stride - 2 * pad + R + opad, Wo = (W - 1) * stride - 2 * pad + S + opad;
     hipStream_t st = (hipStream_t)stream;
-    if (db) {
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(K, 32)), dim3(256), 0, st, dy, lddy, (size_t)B * Ho * Wo, K, db);
-        STEM_LAUNCH_CHECK("colsum");
-    }
+    if (db && colsum(dy, lddy, (size_t)B * Ho * Wo, K, dwp + (size_t)splits * R * S * K * C, db, st)) return -2;
     // P = x on the input grid (C channels), G = dY gathered at iy*stride - pad + r  ->  [t][C][K]
     return run(x, ldx, C, dy, lddy, K, dwp, B, H, W, Ho, Wo, R, S, stride, pad, splits, st);
 }

@@ -139,6 +139,25 @@ def pack_weight(w: torch.Tensor, role: int, masked: int = 0) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- convolutions
+_WS = {}
+_WS_BYTES = {}
+
+
+def _workspace(kind, dims, device):
+    """(ptr, nbytes) of the split-K scratch for this layer shape.  One growing buffer per device: kernels on a
+    stream are ordered, so consecutive layers can share it."""
+    key = (kind, dims)
+    need = _WS_BYTES.get(key)
+    if need is None:
+        need = _WS_BYTES[key] = int(_lib.hip().stem_conv_workspace_bytes(kind, *dims))
+    if need == 0:
+        return 0, 0
+    buf = _WS.get(device)
+    if buf is None or buf.numel() * 4 < need:
+        buf = _WS[device] = torch.empty((need + 3) // 4, device=device, dtype=torch.float32)
+    return buf.data_ptr(), need
+
+
 def conv_out_hw(H, W, R, S, stride, pad):
     return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
 
@@ -155,8 +174,9 @@ def conv2d_fwd(x, wp, bias, K, R, S, stride, pad, act=ACT_NONE, out=None):
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
     if out is None:
         out = empty_nhwc(B, K, Ho, Wo, x.device)
+    ws, wsb = _workspace(0, (B, H, W, Cc, K, R, S, stride, pad, 0), x.device)
     _chk(_lib.hip().stem_conv2d_fwd(x.data_ptr(), ldx, wp.data_ptr(), _ptr(bias), out.data_ptr(), nhwc_ld(out),
-                                    B, H, W, Cc, K, R, S, stride, pad, act, LRELU_SLOPE, _stream()))
+                                    B, H, W, Cc, K, R, S, stride, pad, act, LRELU_SLOPE, ws, wsb, _stream()))
     return out
 
 
@@ -176,9 +196,10 @@ def conv2d_dgrad(dy, wp_dgrad, x_shape, K, R, S, stride, pad, xact=None, out=Non
     B, Cc, H, W = x_shape
     if out is None:
         out = empty_nhwc(B, Cc, H, W, dy.device)
+    ws, wsb = _workspace(1, (B, H, W, Cc, K, R, S, stride, pad, 0), dy.device)
     _chk(_lib.hip().stem_conv2d_dgrad(dy.data_ptr(), nhwc_ld(dy), wp_dgrad.data_ptr(), out.data_ptr(), nhwc_ld(out),
                                       _ptr(xact), 0 if xact is None else nhwc_ld(xact), LRELU_SLOPE,
-                                      B, H, W, Cc, K, R, S, stride, pad, _stream()))
+                                      B, H, W, Cc, K, R, S, stride, pad, ws, wsb, _stream()))
     return out
 
 
@@ -188,7 +209,7 @@ def conv2d_wgrad(x, dy, K, R, S, stride, pad, dw_out=None, db_out=None, need_db=
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
     lib = _lib.hip()
     splits = lib.stem_wgrad_splits(B, Ho, Wo, Cc, K, R, S)
-    dwp = torch.empty(splits * R * S * K * Cc, device=x.device, dtype=torch.float32)
+    dwp = torch.empty(lib.stem_wgrad_workspace_elems(splits, Cc, K, R, S), device=x.device, dtype=torch.float32)
     db = (db_out if db_out is not None else torch.empty(K, device=x.device, dtype=torch.float32)) if need_db else None
     _chk(lib.stem_conv2d_wgrad(x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), dwp.data_ptr(), _ptr(db),
                                B, H, W, Cc, K, R, S, stride, pad, splits, _stream()))
@@ -203,8 +224,9 @@ def deconv2d_fwd(x, wp, bias, K, R, S, stride, pad, opad, act=ACT_NONE, out=None
     Ho, Wo = deconv_out_hw(H, W, R, S, stride, pad, opad)
     if out is None:
         out = empty_nhwc(B, K, Ho, Wo, x.device)
+    ws, wsb = _workspace(2, (B, H, W, Cc, K, R, S, stride, pad, opad), x.device)
     _chk(_lib.hip().stem_deconv2d_fwd(x.data_ptr(), nhwc_ld(x), wp.data_ptr(), _ptr(bias), out.data_ptr(), nhwc_ld(out),
-                                      B, H, W, Cc, K, R, S, stride, pad, opad, act, LRELU_SLOPE, _stream()))
+                                      B, H, W, Cc, K, R, S, stride, pad, opad, act, LRELU_SLOPE, ws, wsb, _stream()))
     return out
 
 
@@ -212,9 +234,10 @@ def deconv2d_dgrad(dy, wp_dgrad, x_shape, K, R, S, stride, pad, opad, xact=None,
     B, Cc, H, W = x_shape
     if out is None:
         out = empty_nhwc(B, Cc, H, W, dy.device)
+    ws, wsb = _workspace(3, (B, H, W, Cc, K, R, S, stride, pad, opad), dy.device)
     _chk(_lib.hip().stem_deconv2d_dgrad(dy.data_ptr(), nhwc_ld(dy), wp_dgrad.data_ptr(), out.data_ptr(), nhwc_ld(out),
                                         _ptr(xact), 0 if xact is None else nhwc_ld(xact), LRELU_SLOPE,
-                                        B, H, W, Cc, K, R, S, stride, pad, opad, _stream()))
+                                        B, H, W, Cc, K, R, S, stride, pad, opad, ws, wsb, _stream()))
     return out
 
 
@@ -223,7 +246,7 @@ def deconv2d_wgrad(x, dy, K, R, S, stride, pad, opad, dw_out=None, db_out=None, 
     B, Cc, H, W = x.shape
     lib = _lib.hip()
     splits = lib.stem_wgrad_splits(B, H, W, K, Cc, R, S)
-    dwp = torch.empty(splits * R * S * K * Cc, device=x.device, dtype=torch.float32)
+    dwp = torch.empty(lib.stem_wgrad_workspace_elems(splits, Cc, K, R, S), device=x.device, dtype=torch.float32)
     db = (db_out if db_out is not None else torch.empty(K, device=x.device, dtype=torch.float32)) if need_db else None
     _chk(lib.stem_deconv2d_wgrad(x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), dwp.data_ptr(), _ptr(db),
                                  B, H, W, Cc, K, R, S, stride, pad, opad, splits, _stream()))
