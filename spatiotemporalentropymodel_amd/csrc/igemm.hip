@@ -47,7 +47,7 @@ struct IgemmArgs {
     TapPhase ph[4];
 };
 
-template <int BM, int BN, int WM, int WN, bool VEC, bool C4>
+template <int BM, int BN, int WM, int WN, bool VEC, bool C4, bool GDNOP>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
 {
     constexpr int TM = WM / 32, TN = WN / 32, AR = BM / 32, BR = BN / 32;
@@ -123,7 +123,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
                         if (k0 + e < a.C) v[e] = src[e];
                 }
             }
-            if (a.asquare) v = v * v;
             ra[j] = v;
         }
 #pragma unroll
@@ -140,25 +139,32 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
                     for (int e = 0; e < 4; ++e)
                         if (k0 + e < a.C) v[e] = src[e];
                 }
-                if (a.breparam) {   // NonNegativeParametrizer on gamma (parametrizers.py:42-45)
-                    const float bound = 3.814697265625e-06f, ped = 1.4551915228366852e-11f;   // 2^-18, 2^-36
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float g = fmaxf(v[e], bound);
-                        v[e] = (VEC || k0 + e < a.C) ? g * g - ped : 0.f;
-                    }
-                }
             }
             rb[j] = v;
         }
     };
+    // Loaded values are first touched here, AFTER the MFMA block of the current chunk, so the global loads of
+    // chunk q+1 stay in flight under the matrix work of chunk q (a use inside gload would force vmcnt(0) there).
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < AR; ++j)
-            *reinterpret_cast<f32x4 *>(&As[(buf * BM + srow + 32 * j) * PITCH + 4 * c4]) = ra[j];
+        for (int j = 0; j < AR; ++j) {
+            f32x4 v = ra[j];
+            if (GDNOP) v = v * v;                                   // GDN: x^2 (gdn.py:58)
+            *reinterpret_cast<f32x4 *>(&As[(buf * BM + srow + 32 * j) * PITCH + 4 * c4]) = v;
+        }
 #pragma unroll
-        for (int j = 0; j < BR; ++j)
-            *reinterpret_cast<f32x4 *>(&Bs[(buf * BN + srow + 32 * j) * PITCH + 4 * c4]) = rb[j];
+        for (int j = 0; j < BR; ++j) {
+            f32x4 v = rb[j];
+            if (GDNOP) {   // NonNegativeParametrizer on gamma (parametrizers.py:42-45); padded lanes (0) map to 0
+                const float bound = 3.814697265625e-06f, ped = 1.4551915228366852e-11f;   // 2^-18, 2^-36
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = fmaxf(v[e], bound);
+                    v[e] = g * g - ped;
+                }
+            }
+            *reinterpret_cast<f32x4 *>(&Bs[(buf * BN + srow + 32 * j) * PITCH + 4 * c4]) = v;
+        }
     };
 
     // ---- wave tile -------------------------------------------------------------------------------
@@ -344,14 +350,23 @@ void build_transposed(IgemmArgs &g, int R, int S, int stride, int pad, int OH, i
         }
 }
 
+// Tile configurations (all 4 wavefronts / 256 threads): {BM, BN, WM, WN, relative efficiency}.
+// 128x128 has the most flop per staged byte; 64x192 and 128x64 exist so that N = 192 / 320 / 576 do not
+// pad to a multiple of 128 (25 % / 20 % / 11 % of the MFMAs would multiply zeros).
+struct TileCfg {
+    int bm, bn;
+    float eff;
+};
+constexpr TileCfg kCfg[4] = {{128, 128, 1.00f}, {64, 192, 0.95f}, {128, 64, 0.90f}, {64, 64, 0.70f}};
+
 struct Plan {
-    bool big;
+    int cfg;
     int nsplit, cps;
     size_t ws_bytes;
 };
 
-// Tile / split-K choice.  128x128 tiles have twice the flop per staged byte of 64x64; when the output is
-// too small to fill 256 CUs with them the reduction (taps x channels) is split over blockIdx.z instead.
+// Tile / split-K choice: minimise padded MFMA work / efficiency, then split the reduction (taps x channels)
+// over blockIdx.z when the output is too small to fill 256 CUs.
 Plan make_plan(const IgemmArgs &g, bool c4)
 {
     int maxM = 0, maxchunks = 0;
@@ -362,30 +377,31 @@ Plan make_plan(const IgemmArgs &g, bool c4)
         const int nc = c4 ? cdiv(g.ph[p].ntaps, 8) : g.ph[p].ntaps * nkc;
         if (nc > maxchunks) maxchunks = nc;
     }
-    Plan pl{true, 1, maxchunks, 0};
+    Plan pl{0, 1, maxchunks, 0};
     if (maxM == 0) return pl;
-    const long t128 = (long)cdiv(maxM, 128) * cdiv(g.N, 128) * g.nphase;
-    const long t64 = (long)cdiv(maxM, 64) * cdiv(g.N, 64) * g.nphase;
     const bool can_split = g.epi != EPI_GDN && g.epi != EPI_IGDN && !c4;
-    if (t128 >= 512 && g.N >= 96) return pl;
-    if (!can_split) {
-        pl.big = t128 >= 256 && g.N >= 96;
-        return pl;
-    }
-    long s128 = cdiv(512, (int)t128);
-    if (s128 > maxchunks / 8) s128 = maxchunks / 8;
-    if (s128 > 32) s128 = 32;
-    if (s128 < 1) s128 = 1;
-    if (g.N >= 96 && t128 * s128 >= 256) {
-        pl.big = true;
-        pl.nsplit = (int)s128;
-    } else {
-        long s64 = cdiv(768, (int)t64);
-        if (s64 > maxchunks / 4) s64 = maxchunks / 4;
-        if (s64 > 64) s64 = 64;
-        if (s64 < 1) s64 = 1;
-        pl.big = false;
-        pl.nsplit = (int)s64;
+    double best = 1e300;
+    for (int c = 0; c < 4; ++c) {
+        const long tm = cdiv(maxM, kCfg[c].bm), tn = cdiv(g.N, kCfg[c].bn);
+        const long tiles = tm * tn * g.nphase;
+        long split = 1;
+        if (can_split && tiles < 512) {
+            split = cdiv(512, (int)tiles);
+            const long cap = maxchunks / (kCfg[c].bm * kCfg[c].bn >= 128 * 96 ? 8 : 4);
+            if (split > cap) split = cap;
+            if (split > 64) split = 64;
+            if (split < 1) split = 1;
+        }
+        // time ~ padded work / efficiency, stretched when fewer than 2 workgroups per CU exist
+        double cost = (double)tm * kCfg[c].bm * tn * kCfg[c].bn / kCfg[c].eff;
+        const double blocks = (double)tiles * split;
+        if (blocks < 512.0) cost *= 512.0 / blocks;
+        if (split > 1) cost *= 1.0 + 0.02 * split;      // slab traffic + reduce kernel
+        if (cost < best) {
+            best = cost;
+            pl.cfg = c;
+            pl.nsplit = (int)split;
+        }
     }
     pl.cps = cdiv(maxchunks, pl.nsplit);
     pl.nsplit = cdiv(maxchunks, pl.cps);           // drop empty trailing splits
@@ -406,17 +422,24 @@ int launch_cfg(const IgemmArgs &g, bool vec, bool c4, hipStream_t st)
     const size_t lds = (size_t)2 * (BM + BN) * PITCH * sizeof(float) + 32 * 4 * sizeof(int);
     static bool attr_done = false;     // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
+    const bool gdn = g.epi == EPI_GDN || g.epi == EPI_IGDN;
     if (c4)
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, true>), grid, block, lds, st, g);
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, true, false>), grid, block, lds, st, g);
+    else if (gdn && vec)
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, false, true>), grid, block, lds, st, g);
+    else if (gdn)
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false, false, true>), grid, block, lds, st, g);
     else if (vec)
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, false>), grid, block, lds, st, g);
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, false, false>), grid, block, lds, st, g);
     else
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false, false>), grid, block, lds, st, g);
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false, false, false>), grid, block, lds, st, g);
     STEM_LAUNCH_CHECK("igemm");
     return 0;
 }
@@ -434,7 +457,13 @@ int launch(IgemmArgs &g, bool c4, void *ws, size_t ws_bytes, hipStream_t st)
     g.cps = pl.cps;
     g.ws = (float *)ws;
     g.slab = (long)g.B * g.OH * g.OW * g.N;
-    const int rc = pl.big ? launch_cfg<128, 128, 64, 64>(g, vec, c4, st) : launch_cfg<64, 64, 32, 32>(g, vec, c4, st);
+    int rc;
+    switch (pl.cfg) {
+    case 0: rc = launch_cfg<128, 128, 64, 64>(g, vec, c4, st); break;
+    case 1: rc = launch_cfg<64, 192, 32, 96>(g, vec, c4, st); break;
+    case 2: rc = launch_cfg<128, 64, 64, 32>(g, vec, c4, st); break;
+    default: rc = launch_cfg<64, 64, 32, 32>(g, vec, c4, st); break;
+    }
     if (rc || pl.nsplit == 1) return rc;
     const size_t npix = (size_t)g.B * g.OH * g.OW;
     const bool v4 = (g.N % 4 == 0) && (g.ldy % 4 == 0) && (((uintptr_t)g.y & 15) == 0) &&
