@@ -159,6 +159,22 @@ int stem_uniform_noise(float *out, size_t n, uint64_t seed, uint64_t offset, voi
 int stem_build_indexes(const float *scales, int lds, const float *table, int T, int32_t *idx, size_t npix, int C,
                        float scale_bound, void *stream);
 
+/* ---- autoregressive coding loop (spatiotemporalpriors.py:916-961, 1015-1054) ----------------------
+ * y[n] = act(bias[n] + sum over up to three contiguous input segments of W[n][woff_i + k] * x_i[k]);
+ * one wavefront per output row, shuffle reduction.  Segments let the 5x5 context window and
+ * cat(tp, hp, ctx) be consumed in place.  Lengths / offsets are multiples of 4 floats, 16-byte aligned. */
+int stem_gemv3(const float *W, int ldw, const float *bias, const float *x0, int len0, int woff0,
+               const float *x1, int len1, int woff1, const float *x2, int len2, int woff2, float *y, int N,
+               int act, float slope, void *stream);
+/* MaskedConv2d weight [K][C][5][5] -> [K][12 live taps][C] for stem_gemv3 */
+int stem_pack_ctx_gemv(const float *w, float *out, int K, int C, void *stream);
+/* gp = scales[M] | means[M] of one pixel.  encode: idx = build_indexes(scale), sym = round(pix - mean),
+ * pix <- sym + mean (spatiotemporalpriors.py:945-952).  decode: pix <- sym + mean (:1050-1054).        */
+int stem_ar_finish_encode(const float *gp, const float *table, int T, float scale_bound, float *pix,
+                          int32_t *sym, int32_t *idx, int M, void *stream);
+int stem_ar_index(const float *gp, const float *table, int T, float scale_bound, int32_t *idx, int M, void *stream);
+int stem_ar_finish_decode(const float *gp, const int32_t *sym, float *pix, int M, void *stream);
+
 /* ---- optimiser --------------------------------------------------------- */
 /* sum of squares of a flat gradient buffer accumulated into acc[0] (double)                       */
 int stem_sumsq(const float *g, size_t n, double *acc, void *stream);

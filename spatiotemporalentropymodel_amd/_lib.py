@@ -51,6 +51,11 @@ _HIP_SIG = {
     "stem_round": [vp, vp, sz, vp],
     "stem_uniform_noise": [vp, sz, u64, u64, vp],
     "stem_build_indexes": [vp, ci, vp, ci, vp, sz, ci, cf, vp],
+    "stem_gemv3": [vp, ci, vp, vp, ci, ci, vp, ci, ci, vp, ci, ci, vp, ci, ci, cf, vp],
+    "stem_pack_ctx_gemv": [vp, vp, ci, ci, vp],
+    "stem_ar_finish_encode": [vp, vp, ci, cf, vp, vp, vp, ci, vp],
+    "stem_ar_index": [vp, vp, ci, cf, vp, ci, vp],
+    "stem_ar_finish_decode": [vp, vp, vp, ci, vp],
     "stem_sumsq": [vp, sz, vp, vp],
     "stem_adam_step": [vp, vp, vp, vp, sz, vp, cf, cf, cf, cf, cf, cf, ci, vp],
     "stem_packed_weight_elems": [ci, ci, ci, ci, ci],

@@ -1,0 +1,194 @@
+"""compress() / decompress() of the STEM models: transforms and per-position probability model on the GPU,
+rANS on the host (north_star), bitstreams interchangeable with the reference's
+(compressai/models/spatiotemporalpriors.py:86-111, 197-225, 871-1054).
+
+Models without a spatial prior are coded in one shot.  Models with the masked-convolution prior are coded
+in raster order: position (h, w) needs the *decoded* values to its left and above, so each position is a
+chain of four matrix-vector kernels (csrc/ar.hip) on one pixel; the encoder queues the whole frame
+asynchronously and calls the host coder once, the decoder synchronises once per position to pull 2M
+indexes and push M symbols.  (Round-1 structure; a persistent device loop is the "next" row, DESIGN.md.)
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import functional as F
+from .entropy_models import BufferedRansEncoder, RansDecoder
+
+_K = 5      # context kernel size
+_P = 2      # its padding
+
+
+def _hyper(model, y_cur, y_cond, strings_z=None, shape=None):
+    """z path shared by compress / decompress: returns (z_strings, hp, tp) with hp/tp dense NHWC tensors."""
+    eng = model.engine()
+    eb = model.entropy_bottleneck
+    yd = F.to_nhwc(y_cond.detach())
+    if strings_z is None:
+        yc = F.to_nhwc(y_cur.detach())
+        B, Cin, H, W = yc.shape
+        he_in = F.empty_nhwc(B, 2 * Cin, H, W, yc.device)
+        F.copy_channels(yc, he_in[:, :Cin])
+        F.copy_channels(yd, he_in[:, Cin:])
+        z = eng.HE[2].fwd(eng.HE[1].fwd(eng.HE[0].fwd(he_in, F.ACT_LRELU), F.ACT_LRELU))
+        strings_z = eb.compress(z)
+        shape = z.shape[-2:]
+    z_hat = eb.decompress(strings_z, shape).to(yd.device).float()
+    hp = eng.HD[2].fwd(eng.HD[1].fwd(eng.HD[0].fwd(F.to_nhwc(z_hat), F.ACT_LRELU), F.ACT_LRELU))
+    tp = None
+    if eng.has_tpm:
+        tp = eng.TPM[2].fwd(eng.TPM[1].fwd(eng.TPM[0].fwd(yd, F.ACT_LRELU), F.ACT_LRELU))
+    return strings_z, shape, hp, tp
+
+
+def _gaussian_params(model, priors):
+    """EPM on the concatenated priors (all dense NHWC) -> gp = scales | means."""
+    eng = model.engine()
+    B, P, H, W = priors[0].shape
+    epm_in = F.empty_nhwc(B, P * len(priors), H, W, priors[0].device)
+    for i, p in enumerate(priors):
+        F.copy_channels(p, epm_in[:, i * P:(i + 1) * P])
+    return eng.EPM[2].fwd(eng.EPM[1].fwd(eng.EPM[0].fwd(epm_in, F.ACT_LRELU), F.ACT_LRELU))
+
+
+class _ARContext:
+    """Per-model device state of the raster-order loop: GEMV-layout weights and scratch vectors."""
+
+    def __init__(self, model, device):
+        m = model
+        M = m.in_channels
+        self.M = M
+        w = m.context_prediction.weight.detach().contiguous()
+        self.w_ctx = torch.empty((2 * M, 12 * M), device=device, dtype=torch.float32)
+        F._chk(_lib.hip().stem_pack_ctx_gemv(w.data_ptr(), self.w_ctx.data_ptr(), 2 * M, M, F._stream()))
+        self.b_ctx = m.context_prediction.bias.detach()
+        self.w0 = m.EPM[0].weight.detach().reshape(m.EPM[0].out_channels, -1).contiguous()
+        self.w1 = m.EPM[2].weight.detach().reshape(m.EPM[2].out_channels, -1).contiguous()
+        self.w2 = m.EPM[4].weight.detach().reshape(m.EPM[4].out_channels, -1).contiguous()
+        self.b0, self.b1, self.b2 = m.EPM[0].bias.detach(), m.EPM[2].bias.detach(), m.EPM[4].bias.detach()
+        self.ctx = torch.empty(2 * M, device=device)
+        self.h1 = torch.empty(self.w0.shape[0], device=device)
+        self.h2 = torch.empty(self.w1.shape[0], device=device)
+        self.gp = torch.empty(2 * M, device=device)
+        self.table = m.gaussian_conditional.scale_table.to(device).float().contiguous()
+        self.bound = m.gaussian_conditional._scale_bound
+        self.has_tpm = m.HAS_TPM
+
+    def position(self, buf, Wp, h, w, tp_pix, hp_pix):
+        """gp <- EPM(tp, hp, ctx(window at h,w)); buf is the padded [Hp, Wp, M] latent of ONE image."""
+        lib, M, st = _lib.hip(), self.M, F._stream()
+        base = buf.data_ptr()
+        r0 = base + 4 * ((h * Wp + w) * M)
+        r1 = base + 4 * (((h + 1) * Wp + w) * M)
+        r2 = base + 4 * (((h + 2) * Wp + w) * M)
+        F._chk(lib.stem_gemv3(self.w_ctx.data_ptr(), 12 * M, self.b_ctx.data_ptr(), r0, 5 * M, 0, r1, 5 * M, 5 * M,
+                              r2, 2 * M, 10 * M, self.ctx.data_ptr(), 2 * M, 0, 0.0, st))
+        P = 2 * M
+        if self.has_tpm:
+            segs = (tp_pix, P, 0, hp_pix, P, P, self.ctx.data_ptr(), P, 2 * P)
+        else:
+            segs = (hp_pix, P, 0, self.ctx.data_ptr(), P, P, 0, 0, 0)
+        F._chk(lib.stem_gemv3(self.w0.data_ptr(), self.w0.shape[1], self.b0.data_ptr(), *segs, self.h1.data_ptr(),
+                              self.w0.shape[0], F.ACT_LRELU, F.LRELU_SLOPE, st))
+        F._chk(lib.stem_gemv3(self.w1.data_ptr(), self.w1.shape[1], self.b1.data_ptr(), self.h1.data_ptr(), self.w1.shape[1], 0,
+                              0, 0, 0, 0, 0, 0, self.h2.data_ptr(), self.w1.shape[0], F.ACT_LRELU, F.LRELU_SLOPE, st))
+        F._chk(lib.stem_gemv3(self.w2.data_ptr(), self.w2.shape[1], self.b2.data_ptr(), self.h2.data_ptr(), self.w2.shape[1], 0,
+                              0, 0, 0, 0, 0, 0, self.gp.data_ptr(), self.w2.shape[0], 0, 0.0, st))
+
+
+def _padded(target_img, H, W, M, device):
+    """[Hp, Wp, M] zero-padded NHWC copy of one image's latent (F.pad(..., (2,2,2,2)), :898)."""
+    buf = torch.zeros((H + 2 * _P, W + 2 * _P, M), device=device, dtype=torch.float32)
+    if target_img is not None:
+        inner = buf[_P:_P + H, _P:_P + W].permute(2, 0, 1).unsqueeze(0)          # [1,M,H,W] view, pitch-strided rows
+        inner.copy_(target_img)                                                   # one small strided copy per image
+    return buf
+
+
+def stem_compress(model, y_cur, y_cond):
+    gc = model.gaussian_conditional
+    z_strings, zshape, hp, tp = _hyper(model, y_cur, y_cond)
+    yc, yd = F.to_nhwc(y_cur.detach()), F.to_nhwc(y_cond.detach())
+    B, M, H, W = yc.shape
+    target = F.sub(_dense(yc), _dense(yd)) if model.RESIDUAL else _dense(yc)
+    if not model.HAS_SPM:
+        gp = _gaussian_params(model, [p for p in (tp, hp) if p is not None])
+        scales, means = gp[:, :M], gp[:, M:]
+        indexes = gc.build_indexes(scales)
+        y_strings = gc.compress(target, indexes, means=means)
+        return {"strings": [y_strings, z_strings], "shape": zshape}
+    ar = _ARContext(model, yc.device)
+    tables = gc.host_tables()
+    lib, st = _lib.hip(), None
+    y_strings = []
+    Wp = W + 2 * _P
+    for b in range(B):
+        buf = _padded(target[b:b + 1], H, W, M, yc.device)
+        sym = torch.empty((H * W, M), device=yc.device, dtype=torch.int32)
+        idx = torch.empty((H * W, M), device=yc.device, dtype=torch.int32)
+        hp_b, tp_b = hp[b], (tp[b] if tp is not None else None)      # [2M,H,W] NHWC views: pixel (h,w) is contiguous
+        for h in range(H):
+            for w in range(W):
+                pos = h * W + w
+                hp_pix = hp.data_ptr() + 4 * ((b * H * W + pos) * 2 * M)
+                tp_pix = tp.data_ptr() + 4 * ((b * H * W + pos) * 2 * M) if tp is not None else 0
+                ar.position(buf, Wp, h, w, tp_pix, hp_pix)
+                pix = buf.data_ptr() + 4 * (((h + _P) * Wp + (w + _P)) * M)
+                F._chk(lib.stem_ar_finish_encode(ar.gp.data_ptr(), ar.table.data_ptr(), ar.table.numel(), ar.bound, pix,
+                                                 sym.data_ptr() + 4 * pos * M, idx.data_ptr() + 4 * pos * M, M, F._stream()))
+        enc = BufferedRansEncoder()
+        enc.encode_with_indexes(sym.cpu().numpy(), idx.cpu().numpy(), tables)      # one host call per image (:955-959)
+        y_strings.append(enc.flush())
+    return {"strings": [y_strings, z_strings], "shape": zshape}
+
+
+def stem_decompress(model, strings, shape, y_cond):
+    gc = model.gaussian_conditional
+    _, _, hp, tp = _hyper(model, None, y_cond, strings_z=strings[1], shape=shape)
+    yd = F.to_nhwc(y_cond.detach())
+    B, P, H, W = hp.shape
+    M = P // 2
+    dev = hp.device
+    if not model.HAS_SPM:
+        gp = _gaussian_params(model, [p for p in (tp, hp) if p is not None])
+        scales, means = gp[:, :M], gp[:, M:]
+        indexes = gc.build_indexes(scales)
+        return gc.decompress(strings[0], indexes, means=means)
+    ar = _ARContext(model, dev)
+    tables = gc.host_tables()
+    lib = _lib.hip()
+    Wp = W + 2 * _P
+    out = F.empty_nhwc(B, M, H, W, dev)
+    idx_dev = torch.empty(M, device=dev, dtype=torch.int32)
+    sym_dev = torch.empty(M, device=dev, dtype=torch.int32)
+    idx_host = torch.empty(M, dtype=torch.int32).pin_memory()
+    sym_host = torch.empty(M, dtype=torch.int32).pin_memory()
+    for b, s in enumerate(strings[0]):
+        buf = _padded(None, H, W, M, dev)
+        dec = RansDecoder()
+        dec.set_stream(s)
+        for h in range(H):
+            for w in range(W):
+                pos = h * W + w
+                hp_pix = hp.data_ptr() + 4 * ((b * H * W + pos) * 2 * M)
+                tp_pix = tp.data_ptr() + 4 * ((b * H * W + pos) * 2 * M) if tp is not None else 0
+                ar.position(buf, Wp, h, w, tp_pix, hp_pix)
+                F._chk(lib.stem_ar_index(ar.gp.data_ptr(), ar.table.data_ptr(), ar.table.numel(), ar.bound, idx_dev.data_ptr(), M, F._stream()))
+                idx_host.copy_(idx_dev, non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                sym_host.copy_(torch.from_numpy(dec.decode_stream_np(idx_host.numpy(), tables)))
+                sym_dev.copy_(sym_host, non_blocking=True)
+                pix = buf.data_ptr() + 4 * (((h + _P) * Wp + (w + _P)) * M)
+                F._chk(lib.stem_ar_finish_decode(ar.gp.data_ptr(), sym_dev.data_ptr(), pix, M, F._stream()))
+        out[b:b + 1].copy_(buf[_P:_P + H, _P:_P + W].permute(2, 0, 1).unsqueeze(0))
+    if model.RESIDUAL:
+        out = F.add(out, _dense(yd))
+    return out
+
+
+def _dense(t):
+    if F.nhwc_ld(t) != t.shape[1]:
+        t = F.copy_channels(t, F.empty_nhwc(*t.shape, t.device))
+    return t

@@ -405,6 +405,12 @@ def gen_stem_codec(ref):
             d[f"{tag}:fwd_y_hat"] = t2n(fwd["y_hat"])
             d[f"{tag}:eb_cdf"], d[f"{tag}:eb_offset"] = t2n(stem.entropy_bottleneck._quantized_cdf), t2n(stem.entropy_bottleneck._offset)
             d[f"{tag}:eb_cdf_length"] = t2n(stem.entropy_bottleneck._cdf_length)
+            # the Gaussian tables travel with a checkpoint's state_dict; committed so that the bitstream test does not
+            # depend on the libm of the machine that runs update() (torch CPU erfc/tanh differ by an ulp across CPUs)
+            d["gc_cdf"] = t2n(stem.gaussian_conditional._quantized_cdf).astype(np.int32)
+            d["gc_offset"] = t2n(stem.gaussian_conditional._offset)
+            d["gc_cdf_length"] = t2n(stem.gaussian_conditional._cdf_length)
+            d["gc_scale_table"] = t2n(stem.gaussian_conditional.scale_table)
     save("stem_codec_small.npz", d)
 
 
