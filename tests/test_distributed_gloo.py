@@ -1,0 +1,100 @@
+"""CPU, world_size 2, gloo: the data-parallel plumbing of bench.py / distributed.py.
+
+Checks (a) bucketed sum all-reduce of the flat gradient buffer + grad_scale, (b) parameter broadcast,
+(c) max-over-ranks timing aggregation, and (d) the claim DP relies on: because EMLoss normalises by the LOCAL
+pixel count, the mean of per-rank gradients equals the gradient of the global batch (verified with the CPU
+oracle's STEM forward/backward on a 2-sample batch split over 2 ranks)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    torch.set_num_threads(2)
+    from spatiotemporalentropymodel_amd import distributed as D
+    r, w, _ = D.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    out = {}
+    # (a) bucketed all-reduce
+    n = 1_000_003
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    red = D.FlatGradReducer(g, n_buckets=4, min_bucket_elems=1000)
+    assert len(red.ranges) == 4 and red.ranges[0][0] == 0 and red.ranges[-1][1] == n
+    assert all(a[1] == b[0] for a, b in zip(red.ranges, red.ranges[1:]))
+    red.all_reduce()
+    out["allreduce_ok"] = bool(torch.equal(g, torch.arange(n, dtype=torch.float32) * 3)) and red.grad_scale == 0.5
+    # (b) broadcast
+    lin = torch.nn.Linear(4, 4)
+    with torch.no_grad():
+        lin.weight.fill_(float(rank + 1))
+    D.broadcast_parameters(lin)
+    out["bcast_ok"] = bool((lin.weight == 1.0).all())
+    # (c) timing aggregation and per-rank seeds
+    out["max"] = D.max_over_ranks(1.0 + rank, "cpu")
+    out["seed"] = D.shard_seed(1234, rank)
+    # (d) mean of per-rank gradients == global-batch gradient (oracle)
+    import stem_oracle as orc
+    from spatiotemporalentropymodel_amd.weights import closed_form_input, closed_form_tensor
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_oracle_vs_golden import _stem_keys
+    ssd = {k: closed_form_tensor(k, s).numpy() for k, s in _stem_keys(64, 96).items()}
+    B, ls = 2, 4
+    y_cur = closed_form_input("dp:y", (B, 96, ls, ls), -4, 4).numpy()
+    y_cond = closed_form_input("dp:c", (B, 96, ls, ls), -4, 4).numpy()
+    noise = {"z": closed_form_input("dp:nz", (B, 64, 1, 1), -.5, .5).numpy(), "q": closed_form_input("dp:nq", (B, 96, ls, ls), -.5, .5).numpy(),
+             "lik": closed_form_input("dp:nl", (B, 96, ls, ls), -.5, .5).numpy()}
+
+    def grads(sl):
+        keep = {}
+        o = orc.stem_forward(ssd, y_cur[sl], y_cond[sl], residual=True, training=True, noise={k: v[sl] for k, v in noise.items()}, keep=keep)
+        npix = y_cur[sl].shape[0] * 64 * 64
+        return orc.stem_backward(ssd, keep, o["lik_y"], o["lik_z"], npix)
+
+    mine = grads(slice(rank, rank + 1))
+    names = sorted(mine)
+    flat = torch.from_numpy(np.concatenate([mine[k].ravel() for k in names]))
+    D.FlatGradReducer(flat, n_buckets=3, min_bucket_elems=1000).all_reduce()
+    flat *= 0.5
+    if rank == 0:
+        full = grads(slice(0, 2))
+        ref = np.concatenate([full[k].ravel() for k in names])
+        err = np.abs(flat.numpy() - ref).max() / np.abs(ref).max()
+        out["dp_grad_rel_err"] = float(err)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+@pytest.mark.timeout(600)
+def test_dp_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=500) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert res[r]["allreduce_ok"] and res[r]["bcast_ok"]
+        assert res[r]["max"] == 2.0 and res[r]["seed"] == 1234 + r
+    assert res[0]["dp_grad_rel_err"] < 1e-5, res[0]
