@@ -50,6 +50,20 @@ size_t stem_packed_weight_elems(int K, int C, int R, int S, int role);
  * summing the split-K slabs.  deconv != 0 writes the ConvTranspose2d layout [C,K,R,S].        */
 int stem_unpack_wgrad(const float *dwp, float *dw, int K, int C, int R, int S, int splits, int deconv, void *stream);
 
+/* Multi-tensor forms: every layer of a model in one launch (host arrays of descriptors, device pointers inside). */
+typedef struct {
+    const float *w;   /* reference-layout weight (masked == 2 also writes it, see above) */
+    float *wp;        /* packed output */
+    int K, C, R, S, role, masked;
+} stem_pack_desc;
+typedef struct {
+    const float *dwp; /* [splits][R*S][..][..] slabs from stem_conv2d_wgrad / stem_deconv2d_wgrad */
+    float *dw;        /* gradient in the reference layout */
+    int K, C, R, S, splits, deconv;
+} stem_unpack_desc;
+int stem_pack_weights_multi(const stem_pack_desc *descs, int n, void *stream);
+int stem_unpack_wgrads_multi(const stem_unpack_desc *descs, int n, void *stream);
+
 /* ---- epilogues --------------------------------------------------------- */
 enum { STEM_ACT_NONE = 0, STEM_ACT_LRELU = 1 };
 

@@ -21,6 +21,8 @@ vp, ci, cf, sz, u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 _HIP_SIG = {
     "stem_pack_weight": [vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "stem_unpack_wgrad": [vp, vp, ci, ci, ci, ci, ci, ci, vp],
+    "stem_pack_weights_multi": [vp, ci, vp],
+    "stem_unpack_wgrads_multi": [vp, ci, vp],
     "stem_conv2d_fwd": [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, sz, vp],
     "stem_conv2d_fwd_c4": [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_conv2d_dgrad": [vp, ci, vp, vp, ci, vp, ci, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],
@@ -82,6 +84,14 @@ _RANS_SIG = {
 _RANS_RESTYPE = {"stem_rans_encode": C.c_long, "stem_rans_encoder_flush": C.c_long, "stem_rans_encoder_create": vp,
                  "stem_rans_decoder_create": vp, "stem_rans_last_error": C.c_char_p,
                  "stem_rans_encoder_pending_bytes": sz, "stem_rans_encoder_destroy": None, "stem_rans_decoder_destroy": None}
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("w", vp), ("wp", vp), ("K", ci), ("C", ci), ("R", ci), ("S", ci), ("role", ci), ("masked", ci)]
+
+
+class UnpackDesc(C.Structure):
+    _fields_ = [("dwp", vp), ("dw", vp), ("K", ci), ("C", ci), ("R", ci), ("S", ci), ("splits", ci), ("deconv", ci)]
 
 
 class StemLibraryError(RuntimeError):

@@ -45,6 +45,77 @@ __global__ __launch_bounds__(256) void pack_kernel(float *w, float *out, int A, 
     }
 }
 
+// ---- multi-tensor variants: all layers of a model in ONE launch (26 packs / 13 unpacks per optimiser step
+// would otherwise be 39 latency-bound launches of 10-30 us each) ------------------------------------------
+constexpr int MAXD = 32;
+struct PackD {
+    float *w;
+    float *out;
+    int A, Bd, T, R, S, masked, block0;
+    long sa, sb;
+};
+struct PackTable {
+    PackD d[MAXD];
+    int n;
+};
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackTable tb)
+{
+    extern __shared__ float tile[];
+    int i = 0;
+    while (i + 1 < tb.n && (int)blockIdx.x >= tb.d[i + 1].block0) ++i;
+    const PackD d = tb.d[i];
+    const int a = blockIdx.x - d.block0;
+    const int n = d.Bd * d.T;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const int b = k / d.T, t = k - b * d.T;
+        float v = d.w[a * d.sa + b * d.sb + t];
+        if (d.masked) {
+            const int r = t / d.S, s = t - r * d.S;
+            if (r > d.R / 2 || (r == d.R / 2 && s >= d.S / 2)) {
+                v = 0.f;
+                if (d.masked == 2) d.w[a * d.sa + b * d.sb + t] = 0.f;
+            }
+        }
+        tile[k] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const int t = k / d.Bd, b = k - t * d.Bd;
+        d.out[((size_t)t * d.A + a) * d.Bd + b] = tile[b * d.T + t];
+    }
+}
+
+struct UnpackD {
+    const float *dwp;
+    float *dw;
+    int A, Bd, T, splits, block0;
+};
+struct UnpackTable {
+    UnpackD d[MAXD];
+    int n;
+};
+__global__ __launch_bounds__(256) void unpack_multi_kernel(const UnpackTable tb)
+{
+    extern __shared__ float tile[];
+    int i = 0;
+    while (i + 1 < tb.n && (int)blockIdx.x >= tb.d[i + 1].block0) ++i;
+    const UnpackD d = tb.d[i];
+    const int a = blockIdx.x - d.block0;
+    const int n = d.Bd * d.T;
+    const size_t slab = (size_t)d.T * d.A * d.Bd;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const int t = k / d.Bd, b = k - t * d.Bd;
+        float v = 0.f;
+        for (int s = 0; s < d.splits; ++s) v += d.dwp[s * slab + ((size_t)t * d.A + a) * d.Bd + b];
+        tile[b * (d.T + 1) + t] = v;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const int b = k / d.T, t = k - b * d.T;
+        d.dw[(size_t)a * n + k] = tile[b * (d.T + 1) + t];
+    }
+}
+
 // first layer: w[K][C<=4][T] -> out[K][32][4], zero padded
 __global__ void pack_c4_kernel(const float *w, float *out, int K, int C, int T)
 {
@@ -167,6 +238,82 @@ STEM_EXPORT int stem_pack_weight(const float *w, float *wp, int K, int C, int R,
         (void)hipFuncSetAttribute((const void *)pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(pack_kernel, dim3(A), dim3(256), lds, st, const_cast<float *>(w), wp, A, Bd, T, sa, sb, R, S, masked);
     STEM_LAUNCH_CHECK("pack");
+    return 0;
+}
+
+static int role_geometry(int role, int K, int C, int T, int *A, int *Bd, long *sa, long *sb)
+{
+    switch (role) {
+    case STEM_PACK_CONV_FWD:     *A = K; *Bd = C; *sa = (long)C * T; *sb = T; return 0;
+    case STEM_PACK_CONV_DGRAD:   *A = C; *Bd = K; *sa = T; *sb = (long)C * T; return 0;
+    case STEM_PACK_DECONV_FWD:   *A = K; *Bd = C; *sa = T; *sb = (long)K * T; return 0;
+    case STEM_PACK_DECONV_DGRAD: *A = C; *Bd = K; *sa = (long)K * T; *sb = T; return 0;
+    default: return -1;
+    }
+}
+
+STEM_EXPORT int stem_pack_weights_multi(const stem_pack_desc *descs, int n, void *stream)
+{
+    STEM_CHECK_ARG(descs && n >= 0, "stem_pack_weights_multi: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += MAXD) {
+        PackTable tb;
+        tb.n = n - base < MAXD ? n - base : MAXD;
+        int blocks = 0;
+        size_t lds = 0;
+        for (int i = 0; i < tb.n; ++i) {
+            const stem_pack_desc &q = descs[base + i];
+            PackD &d = tb.d[i];
+            const int T = q.R * q.S;
+            STEM_CHECK_ARG(q.w && q.wp && T >= 1 && T <= 25, "stem_pack_weights_multi: bad descriptor %d", base + i);
+            STEM_CHECK_ARG(role_geometry(q.role, q.K, q.C, T, &d.A, &d.Bd, &d.sa, &d.sb) == 0,
+                           "stem_pack_weights_multi: role %d not supported in the multi-tensor path", q.role);
+            d.w = const_cast<float *>(q.w);
+            d.out = q.wp;
+            d.T = T; d.R = q.R; d.S = q.S; d.masked = q.masked;
+            d.block0 = blocks;
+            blocks += d.A;
+            const size_t need = (size_t)d.Bd * T * sizeof(float);
+            if (need > lds) lds = need;
+        }
+        STEM_CHECK_ARG(lds <= 160 * 1024, "stem_pack_weights_multi: slab of %zu B exceeds LDS", lds);
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)pack_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (blocks) hipLaunchKernelGGL(pack_multi_kernel, dim3(blocks), dim3(256), lds, st, tb);
+        STEM_LAUNCH_CHECK("pack_multi");
+    }
+    return 0;
+}
+
+STEM_EXPORT int stem_unpack_wgrads_multi(const stem_unpack_desc *descs, int n, void *stream)
+{
+    STEM_CHECK_ARG(descs && n >= 0, "stem_unpack_wgrads_multi: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += MAXD) {
+        UnpackTable tb;
+        tb.n = n - base < MAXD ? n - base : MAXD;
+        int blocks = 0;
+        size_t lds = 0;
+        for (int i = 0; i < tb.n; ++i) {
+            const stem_unpack_desc &q = descs[base + i];
+            UnpackD &d = tb.d[i];
+            STEM_CHECK_ARG(q.dwp && q.dw && q.splits >= 1, "stem_unpack_wgrads_multi: bad descriptor %d", base + i);
+            d.dwp = q.dwp; d.dw = q.dw;
+            d.T = q.R * q.S;
+            d.A = q.deconv ? q.C : q.K;
+            d.Bd = q.deconv ? q.K : q.C;
+            d.splits = q.splits;
+            d.block0 = blocks;
+            blocks += d.A;
+            const size_t need = (size_t)d.Bd * (d.T + 1) * sizeof(float);
+            if (need > lds) lds = need;
+        }
+        STEM_CHECK_ARG(lds <= 160 * 1024, "stem_unpack_wgrads_multi: slab of %zu B exceeds LDS", lds);
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void *)unpack_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (blocks) hipLaunchKernelGGL(unpack_multi_kernel, dim3(blocks), dim3(256), lds, st, tb);
+        STEM_LAUNCH_CHECK("unpack_multi");
+    }
     return 0;
 }
 

@@ -15,45 +15,75 @@ from __future__ import annotations
 
 import torch
 
+from . import _lib
 from . import functional as F
+from . import layers as _layers
 
 
 class _Layer:
-    """One convolution of the schedule with its parameter tensors and packed-weight cache."""
+    """One convolution of the schedule: parameters, persistent packed-weight buffers and wgrad slabs."""
 
-    def __init__(self, mod, kind):
-        self.mod, self.kind = mod, kind           # kind: "conv" | "deconv"
+    def __init__(self, mod, kind, eng):
+        self.mod, self.kind, self.eng = mod, kind, eng      # kind: "conv" | "deconv"
         self.R = mod.kernel_size
         self.stride, self.pad = mod.stride, mod.padding
         self.opad = getattr(mod, "output_padding", 0)
         self.K, self.C = mod.out_channels, mod.in_channels
         self.masked = getattr(mod, "_masked", 0)
+        self.wp_fwd = self.wp_dgrad = None
+        self.need_dgrad = True
+        self._slabs = {}
+        self.pending = None       # (dwp, splits) of the last wgrad, consumed by StemEngine.unpack_all
+
+    def alloc_packs(self, device):
+        n = self.K * self.C * self.R * self.R
+        self.wp_fwd = torch.empty(n, device=device, dtype=torch.float32)
+        self.wp_dgrad = torch.empty(n, device=device, dtype=torch.float32) if self.need_dgrad else None
+
+    def pack_descs(self):
+        w = self.mod.weight
+        conv = self.kind == "conv"
+        out = [_lib.PackDesc(w.data_ptr(), self.wp_fwd.data_ptr(), self.K, self.C, self.R, self.R,
+                             F.PACK_CONV_FWD if conv else F.PACK_DECONV_FWD, self.masked)]
+        if self.need_dgrad:
+            out.append(_lib.PackDesc(w.data_ptr(), self.wp_dgrad.data_ptr(), self.K, self.C, self.R, self.R,
+                                     F.PACK_CONV_DGRAD if conv else F.PACK_DECONV_DGRAD, 1 if self.masked else 0))
+        return out
 
     def fwd(self, x, act=F.ACT_NONE, out=None):
+        self.eng.ensure_packed()
         m = self.mod
         if self.kind == "conv":
-            wp = m._packs.get(m.weight, F.PACK_CONV_FWD, self.masked)
-            return F.conv2d_fwd(x, wp, m.bias, self.K, self.R, self.R, self.stride, self.pad, act, out=out)
-        wp = m._packs.get(m.weight, F.PACK_DECONV_FWD)
-        return F.deconv2d_fwd(x, wp, m.bias, self.K, self.R, self.R, self.stride, self.pad, self.opad, act, out=out)
+            return F.conv2d_fwd(x, self.wp_fwd, m.bias, self.K, self.R, self.R, self.stride, self.pad, act, out=out)
+        return F.deconv2d_fwd(x, self.wp_fwd, m.bias, self.K, self.R, self.R, self.stride, self.pad, self.opad, act, out=out)
 
     def dgrad(self, dy, x_shape, xact=None):
-        m = self.mod
         if self.kind == "conv":
-            wp = m._packs.get(m.weight, F.PACK_CONV_DGRAD, 1 if self.masked else 0)
-            return F.conv2d_dgrad(dy, wp, x_shape, self.K, self.R, self.R, self.stride, self.pad, xact=xact)
-        wp = m._packs.get(m.weight, F.PACK_DECONV_DGRAD)
-        return F.deconv2d_dgrad(dy, wp, x_shape, self.K, self.R, self.R, self.stride, self.pad, self.opad, xact=xact)
+            return F.conv2d_dgrad(dy, self.wp_dgrad, x_shape, self.K, self.R, self.R, self.stride, self.pad, xact=xact)
+        return F.deconv2d_dgrad(dy, self.wp_dgrad, x_shape, self.K, self.R, self.R, self.stride, self.pad, self.opad, xact=xact)
 
     def wgrad(self, x, dy):
-        """writes straight into .grad of weight and bias (allocated once; flat-buffer views if a
-        FlatParameters owner installed them)."""
+        """packed slabs now, bias gradient straight into .grad; StemEngine.unpack_all() turns every layer's
+        slabs into .grad tensors with one launch."""
         m = self.mod
-        gw, gb = _grad_of(m.weight), _grad_of(m.bias)
-        if self.kind == "conv":
-            F.conv2d_wgrad(x, dy, self.K, self.R, self.R, self.stride, self.pad, dw_out=gw, db_out=gb)
+        gb = _grad_of(m.bias)
+        deconv = self.kind == "deconv"
+        key = tuple(x.shape)
+        if key not in self._slabs:
+            splits, elems = F.wgrad_plan(x.shape, self.K, self.R, self.R, self.stride, self.pad, deconv=deconv)
+            self._slabs[key] = (torch.empty(elems, device=x.device, dtype=torch.float32), splits)
+        dwp, splits = self._slabs[key]
+        if deconv:
+            F.deconv2d_wgrad(x, dy, self.K, self.R, self.R, self.stride, self.pad, self.opad, db_out=gb, dwp=dwp, unpack=False)
         else:
-            F.deconv2d_wgrad(x, dy, self.K, self.R, self.R, self.stride, self.pad, self.opad, dw_out=gw, db_out=gb)
+            F.conv2d_wgrad(x, dy, self.K, self.R, self.R, self.stride, self.pad, db_out=gb, dwp=dwp, unpack=False)
+        self.pending = (dwp, splits)
+
+    def unpack_desc(self):
+        dwp, splits = self.pending
+        self.pending = None
+        return _lib.UnpackDesc(dwp.data_ptr(), _grad_of(self.mod.weight).data_ptr(), self.K, self.C, self.R, self.R, splits,
+                               1 if self.kind == "deconv" else 0)
 
 
 def _grad_of(p):
@@ -67,14 +97,41 @@ class StemEngine:
     def __init__(self, model, has_tpm: bool, has_spm: bool, residual: bool):
         self.m = model
         self.has_tpm, self.has_spm, self.residual = has_tpm, has_spm, residual
-        L = lambda mod: _Layer(mod, "conv")
-        D = lambda mod: _Layer(mod, "deconv")
+        L = lambda mod: _Layer(mod, "conv", self)
+        D = lambda mod: _Layer(mod, "deconv", self)
         self.HE = [L(model.HE[0]), L(model.HE[2]), L(model.HE[4])]
         self.HD = [D(model.HD[0]), D(model.HD[2]), L(model.HD[4])]
         self.TPM = [L(model.TPM[0]), L(model.TPM[2]), L(model.TPM[4])] if has_tpm else None
         self.CTX = L(model.context_prediction) if has_spm else None
         self.EPM = [L(model.EPM[0]), L(model.EPM[2]), L(model.EPM[4])]
         self.nprior = 1 + int(has_tpm) + int(has_spm)
+        self.layers = self.HE + self.HD + (self.TPM or []) + ([self.CTX] if has_spm else []) + self.EPM
+        # no input gradient is ever needed for the first layer of a chain fed by (detached) data
+        for first in [self.HE[0]] + ([self.TPM[0]] if has_tpm else []) + ([self.CTX] if has_spm else []):
+            first.need_dgrad = False
+        self._pack_key = None
+        self._pack_descs = None
+
+    def ensure_packed(self):
+        """(Re)build every layer's packed weight copies with ONE kernel launch when any weight changed."""
+        key = (_layers._WEIGHT_EPOCH[0],) + tuple((l.mod.weight._version, l.mod.weight.data_ptr()) for l in self.layers)
+        if key == self._pack_key:
+            return
+        if self.layers[0].wp_fwd is None or self.layers[0].wp_fwd.device != self.layers[0].mod.weight.device:
+            for l in self.layers:
+                l.alloc_packs(l.mod.weight.device)
+            self._pack_descs = None
+        descs = [d for l in self.layers for d in l.pack_descs()]
+        arr = (_lib.PackDesc * len(descs))(*descs)
+        F.pack_weights_multi(arr)
+        # masked == 2 zeroed taps of the context weight in place: refresh its version in the key
+        self._pack_key = (_layers._WEIGHT_EPOCH[0],) + tuple((l.mod.weight._version, l.mod.weight.data_ptr()) for l in self.layers)
+
+    def unpack_all(self):
+        descs = [l.unpack_desc() for l in self.layers if l.pending is not None]
+        if descs:
+            arr = (_lib.UnpackDesc * len(descs))(*descs)
+            F.unpack_wgrads_multi(arr)
 
     # -------------------------------------------------------------------------------------------
     def forward(self, y_cur, y_cond, training: bool):
@@ -177,6 +234,7 @@ class StemEngine:
         self.HE[1].wgrad(k["he0"], d)
         d = self.HE[1].dgrad(d, k["he0"].shape, xact=k["he0"])
         self.HE[0].wgrad(k["he_in"], d)
+        self.unpack_all()
 
 
 class StemFunction(torch.autograd.Function):

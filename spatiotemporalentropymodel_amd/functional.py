@@ -203,16 +203,31 @@ def conv2d_dgrad(dy, wp_dgrad, x_shape, K, R, S, stride, pad, xact=None, out=Non
     return out
 
 
-def conv2d_wgrad(x, dy, K, R, S, stride, pad, dw_out=None, db_out=None, need_db=True):
-    """-> (dW [K,C,R,S], db [K]) in the reference's layouts."""
-    B, Cc, H, W = x.shape
-    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+def wgrad_plan(x_shape, K, R, S, stride, pad, deconv=False):
+    """(splits, slab-buffer elements) for a weight-gradient launch on this input shape."""
+    B, Cc, H, W = x_shape
     lib = _lib.hip()
-    splits = lib.stem_wgrad_splits(B, Ho, Wo, Cc, K, R, S)
-    dwp = torch.empty(lib.stem_wgrad_workspace_elems(splits, Cc, K, R, S), device=x.device, dtype=torch.float32)
+    if deconv:
+        splits = lib.stem_wgrad_splits(B, H, W, K, Cc, R, S)
+    else:
+        Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+        splits = lib.stem_wgrad_splits(B, Ho, Wo, Cc, K, R, S)
+    return splits, int(lib.stem_wgrad_workspace_elems(splits, Cc, K, R, S))
+
+
+def conv2d_wgrad(x, dy, K, R, S, stride, pad, dw_out=None, db_out=None, need_db=True, dwp=None, unpack=True):
+    """-> (dW [K,C,R,S], db [K]) in the reference's layouts.  With unpack=False only the packed slabs in `dwp`
+    are produced (the caller sums/transposes all layers at once with unpack_wgrads_multi)."""
+    B, Cc, H, W = x.shape
+    lib = _lib.hip()
+    splits, elems = wgrad_plan(x.shape, K, R, S, stride, pad)
+    if dwp is None:
+        dwp = torch.empty(elems, device=x.device, dtype=torch.float32)
     db = (db_out if db_out is not None else torch.empty(K, device=x.device, dtype=torch.float32)) if need_db else None
     _chk(lib.stem_conv2d_wgrad(x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), dwp.data_ptr(), _ptr(db),
                                B, H, W, Cc, K, R, S, stride, pad, splits, _stream()))
+    if not unpack:
+        return None, db
     dw = dw_out if dw_out is not None else torch.empty((K, Cc, R, S), device=x.device, dtype=torch.float32)
     _chk(lib.stem_unpack_wgrad(dwp.data_ptr(), dw.data_ptr(), K, Cc, R, S, splits, 0, _stream()))
     return dw, db
@@ -241,18 +256,30 @@ def deconv2d_dgrad(dy, wp_dgrad, x_shape, K, R, S, stride, pad, opad, xact=None,
     return out
 
 
-def deconv2d_wgrad(x, dy, K, R, S, stride, pad, opad, dw_out=None, db_out=None, need_db=True):
+def deconv2d_wgrad(x, dy, K, R, S, stride, pad, opad, dw_out=None, db_out=None, need_db=True, dwp=None, unpack=True):
     """-> (dW [C,K,R,S], db [K]) in nn.ConvTranspose2d's layout."""
     B, Cc, H, W = x.shape
     lib = _lib.hip()
-    splits = lib.stem_wgrad_splits(B, H, W, K, Cc, R, S)
-    dwp = torch.empty(lib.stem_wgrad_workspace_elems(splits, Cc, K, R, S), device=x.device, dtype=torch.float32)
+    splits, elems = wgrad_plan(x.shape, K, R, S, stride, pad, deconv=True)
+    if dwp is None:
+        dwp = torch.empty(elems, device=x.device, dtype=torch.float32)
     db = (db_out if db_out is not None else torch.empty(K, device=x.device, dtype=torch.float32)) if need_db else None
     _chk(lib.stem_deconv2d_wgrad(x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), dwp.data_ptr(), _ptr(db),
                                  B, H, W, Cc, K, R, S, stride, pad, opad, splits, _stream()))
+    if not unpack:
+        return None, db
     dw = dw_out if dw_out is not None else torch.empty((Cc, K, R, S), device=x.device, dtype=torch.float32)
     _chk(lib.stem_unpack_wgrad(dwp.data_ptr(), dw.data_ptr(), K, Cc, R, S, splits, 1, _stream()))
     return dw, db
+
+
+def pack_weights_multi(descs):
+    """descs: ctypes array of _lib.PackDesc"""
+    _chk(_lib.hip().stem_pack_weights_multi(C.addressof(descs), len(descs), _stream()))
+
+
+def unpack_wgrads_multi(descs):
+    _chk(_lib.hip().stem_unpack_wgrads_multi(C.addressof(descs), len(descs), _stream()))
 
 
 def gdn_fwd(x, beta, gamma, inverse=False, beta_min=1e-6, out=None):
