@@ -170,24 +170,35 @@ int launch_cfg(const WgradArgs &a, bool vec, hipStream_t st)
     return 0;
 }
 
-bool use_big_tiles(int CP, int CG, int T, int nchunks)
-{
-    // 128x128 tiles halve the L2->LDS traffic per flop; use them when split-K can still fill the chip
-    const long tiles = (long)cdiv(CP, 128) * cdiv(CG, 128) * T;
-    return CP >= 96 && CG >= 96 && tiles * (nchunks >= 8 ? nchunks / 8 : 1) >= 256;
-}
+struct WTile {
+    int bm, bn;
+    float eff;
+};
+constexpr WTile kWT[4] = {{128, 128, 1.00f}, {128, 64, 0.90f}, {64, 128, 0.90f}, {64, 64, 0.75f}};
 
-int pick_splits(int CP, int CG, int T, int nchunks)
+// tile + split choice: minimise padded MFMA work / efficiency, split the pixel reduction to fill the chip
+void plan(int CP, int CG, int T, int nchunks, int *cfg, int *splits)
 {
-    const bool big = use_big_tiles(CP, CG, T, nchunks);
-    const int tb = big ? 128 : 64;
-    const long tiles = (long)cdiv(CP, tb) * cdiv(CG, tb) * T;
-    long s = (768 + tiles - 1) / tiles;
-    const int maxs = nchunks >= 8 ? nchunks / 8 : 1;     // at least 8 chunks (256 px) per split
-    if (s > maxs) s = maxs;
-    if (s < 1) s = 1;
-    if (s > 64) s = 64;
-    return (int)s;
+    double best = 1e300;
+    *cfg = 0;
+    *splits = 1;
+    for (int c = 0; c < 4; ++c) {
+        const long ti = cdiv(CP, kWT[c].bm), tj = cdiv(CG, kWT[c].bn);
+        const long tiles = ti * tj * T;
+        long s = cdiv(768, (int)(tiles > 768 ? 768 : tiles));
+        const long maxs = nchunks >= 8 ? nchunks / 8 : 1;       // at least 8 chunks (256 px) per split
+        if (s > maxs) s = maxs;
+        if (s > 64) s = 64;
+        if (s < 1) s = 1;
+        double cost = (double)ti * kWT[c].bm * tj * kWT[c].bn / kWT[c].eff;
+        const double blocks = (double)tiles * s;
+        if (blocks < 512.0) cost *= 512.0 / blocks;
+        if (cost < best) {
+            best = cost;
+            *cfg = c;
+            *splits = (int)s;
+        }
+    }
 }
 
 int run(const float *p, int ldp, int CP, const float *g, int ldg, int CG, float *out, int B, int PH, int PW,
@@ -203,8 +214,14 @@ int run(const float *p, int ldp, int CP, const float *g, int ldg, int CG, float 
     a.chunks_per_split = cdiv(a.nchunks, splits);
     const bool vec = (CP % 4 == 0) && (CG % 4 == 0) && (ldp % 4 == 0) && (ldg % 4 == 0) &&
                      (((uintptr_t)p & 15) == 0) && (((uintptr_t)g & 15) == 0);
-    if (use_big_tiles(CP, CG, R * S, a.nchunks)) return launch_cfg<128, 128, 64, 64>(a, vec, st);
-    return launch_cfg<64, 64, 32, 32>(a, vec, st);
+    int cfg, s_unused;
+    plan(CP, CG, R * S, a.nchunks, &cfg, &s_unused);
+    switch (cfg) {
+    case 0: return launch_cfg<128, 128, 64, 64>(a, vec, st);
+    case 1: return launch_cfg<128, 64, 64, 32>(a, vec, st);
+    case 2: return launch_cfg<64, 128, 32, 64>(a, vec, st);
+    default: return launch_cfg<64, 64, 32, 32>(a, vec, st);
+    }
 }
 
 // Bias gradient db[k] = sum_m dy[m][k] in two deterministic stages: CS_PARTS pixel ranges x 64-channel tiles
@@ -252,7 +269,9 @@ STEM_EXPORT size_t stem_wgrad_workspace_elems(int splits, int C, int K, int R, i
 
 STEM_EXPORT int stem_wgrad_splits(int B, int Ho, int Wo, int C, int K, int R, int S)
 {
-    return pick_splits(K, C, R * S, cdiv(B * Ho * Wo, KP));
+    int cfg, splits;
+    plan(K, C, R * S, cdiv(B * Ho * Wo, KP), &cfg, &splits);
+    return splits;
 }
 
 STEM_EXPORT int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
