@@ -44,6 +44,7 @@ struct IgemmArgs {
     float *ws;
     int nsplit, cps;
     long slab;
+    int xbytes, wbytes;      // extents of the x / w views for the range-checked buffer loads
     TapPhase ph[4];
 };
 
@@ -65,19 +66,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
     const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
     if (bm0 >= Mtot) return;
 
+    const int qhw = ph.qh * ph.qw;
     if (tid < 32) {
         const bool v = tid < ph.ntaps;
-        tapi[tid * 4 + 0] = v ? ph.dy[tid] : 0;
-        tapi[tid * 4 + 1] = v ? ph.dx[tid] : 0;
-        tapi[tid * 4 + 2] = v ? ph.wt[tid] : 0;
+        const int dy = v ? ph.dy[tid] : 0, dx = v ? ph.dx[tid] : 0, wt = v ? ph.wt[tid] : 0;
+        tapi[tid * 4 + 0] = VEC ? (dy * a.W + dx) * a.ldx * 4 : dy;      // VEC: byte offset of the tap inside x
+        tapi[tid * 4 + 1] = VEC ? wt * a.N * a.ldw * 4 : dx;             // VEC: byte offset of the tap's weight slab
+        tapi[tid * 4 + 2] = wt;
         tapi[tid * 4 + 3] = v ? 1 : 0;
     }
 
     // ---- staging assignment: thread -> (row srow+32j, float4 column c4) -------------------------
     const int srow = tid >> 3, c4 = tid & 7;
     int p_by[AR], p_bx[AR], p_base[AR];
+    unsigned p_mask[AR];          // bit t: tap t of this row reads inside the image (computed once, not per chunk)
     bool p_ok[AR];
-    const int qhw = ph.qh * ph.qw;
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
         const int m = bm0 + srow + 32 * j;
@@ -87,13 +90,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
         const int qy = rem / ph.qw, qx = rem - qy * ph.qw;
         p_by[j] = qy * a.isy;
         p_bx[j] = qx * a.isx;
-        p_base[j] = b * a.H * a.W;
+        p_base[j] = VEC ? ((b * a.H + p_by[j]) * a.W + p_bx[j]) * a.ldx * 4 : b * a.H * a.W;
+        unsigned mk = 0;
+        for (int t = 0; t < ph.ntaps; ++t) {
+            const int iy = p_by[j] + ph.dy[t], ix = p_bx[j] + ph.dx[t];
+            if (p_ok[j] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) mk |= 1u << t;
+        }
+        p_mask[j] = mk;
+    }
+    int n_off[BR];                // VEC: byte offset of weight row n, or an out-of-range offset when n >= N
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        const int n = bn0 + srow + 32 * j;
+        n_off[j] = n < a.N ? n * a.ldw * 4 : 0x7FFFFF00;
     }
     const int nkc = C4 ? 1 : (a.C + KC - 1) / KC;
     const int nchunks_all = C4 ? (ph.ntaps + 7) / 8 : ph.ntaps * nkc;
     const int q_begin = zsplit * a.cps;
     const int q_end = a.nsplit > 1 ? (q_begin + a.cps < nchunks_all ? q_begin + a.cps : nchunks_all) : nchunks_all;
     __syncthreads();
+
+    // Hardware range-checked buffer loads: an offset past the end of the view returns 0, so padding pixels,
+    // tile tails and K tails need no branches; the loop body is one basic block the scheduler can interleave
+    // with the MFMAs.
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, a.wbytes, 0x00020000);
 
     f32x4 ra[AR], rb[BR];
 
@@ -106,8 +127,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
             t = q / nkc;
             k0 = (q - t * nkc) * KC + 4 * c4;
         }
-        const int dy = tapi[t * 4 + 0], dx = tapi[t * 4 + 1], wt = tapi[t * 4 + 2];
+        const int t0 = tapi[t * 4 + 0], t1 = tapi[t * 4 + 1], wt = tapi[t * 4 + 2];
         const bool tv = tapi[t * 4 + 3] != 0;
+        if (VEC) {
+            const bool kok = k0 < a.C;
+#pragma unroll
+            for (int j = 0; j < AR; ++j) {
+                const bool ok = ((p_mask[j] >> t) & 1u) && kok;
+                const int off = ok ? p_base[j] + t0 + k0 * 4 : 0x7FFFFF00;
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+            }
+#pragma unroll
+            for (int j = 0; j < BR; ++j) {
+                const int off = C4 ? n_off[j] + (q * KC + 4 * c4) * 4 : ((tv && kok) ? n_off[j] + t1 + k0 * 4 : 0x7FFFFF00);
+                rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
+            }
+            return;
+        }
+        const int dy = t0, dx = t1;
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             const int iy = p_by[j] + dy, ix = p_bx[j] + dx;
@@ -115,13 +152,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok) {
                 const float *src = a.x + (size_t)(p_base[j] + iy * a.W + ix) * a.ldx + k0;
-                if (VEC) {
-                    if (k0 < a.C) v = *reinterpret_cast<const f32x4 *>(src);
-                } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (k0 + e < a.C) v[e] = src[e];
-                }
+                for (int e = 0; e < 4; ++e)
+                    if (k0 + e < a.C) v[e] = src[e];
             }
             ra[j] = v;
         }
@@ -129,16 +162,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
         for (int j = 0; j < BR; ++j) {
             const int n = bn0 + srow + 32 * j;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < a.N && (C4 || tv)) {
-                const float *src = C4 ? a.w + (size_t)n * a.ldw + q * KC + 4 * c4
-                                      : a.w + ((size_t)wt * a.N + n) * a.ldw + k0;
-                if (VEC) {
-                    if (C4 || k0 < a.C) v = *reinterpret_cast<const f32x4 *>(src);
-                } else {
+            if (n < a.N && tv) {
+                const float *src = a.w + ((size_t)wt * a.N + n) * a.ldw + k0;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (k0 + e < a.C) v[e] = src[e];
-                }
+                for (int e = 0; e < 4; ++e)
+                    if (k0 + e < a.C) v[e] = src[e];
             }
             rb[j] = v;
         }
@@ -452,6 +480,20 @@ int launch(IgemmArgs &g, bool c4, void *ws, size_t ws_bytes, hipStream_t st)
     if (pl.nsplit > 1 && (ws == nullptr || ws_bytes < pl.ws_bytes)) {      // no workspace: run unsplit (slower, same result)
         pl.nsplit = 1;
         pl.ws_bytes = 0;
+    }
+    {
+        const long xb = (((long)g.B * g.H * g.W - 1) * g.ldx + g.C) * 4;
+        int maxwt = 0;
+        for (int p = 0; p < g.nphase; ++p)
+            for (int t = 0; t < g.ph[p].ntaps; ++t)
+                if (g.ph[p].wt[t] > maxwt) maxwt = g.ph[p].wt[t];
+        const long wb = c4 ? (long)g.N * g.ldw * 4 : ((((long)maxwt + 1) * g.N - 1) * g.ldw + g.C) * 4;
+        if (xb >= 0x7FFFFF00L || wb >= 0x7FFFFF00L) {
+            stem_set_error("igemm: tensor view of %ld / %ld bytes exceeds the 2 GiB buffer-descriptor range", xb, wb);
+            return -1;
+        }
+        g.xbytes = (int)xb;
+        g.wbytes = (int)wb;
     }
     g.nsplit = pl.nsplit;
     g.cps = pl.cps;
