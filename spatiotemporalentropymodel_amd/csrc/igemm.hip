@@ -45,6 +45,7 @@ struct IgemmArgs {
     int nsplit, cps;
     long slab;
     int xbytes, wbytes;      // extents of the x / w views for the range-checked buffer loads
+    int ident;               // output pixel index == m (stride-1, single phase): no div/mod in the epilogue
     TapPhase ph[4];
 };
 
@@ -247,9 +248,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
                 for (int r = 0; r < 16; ++r) {
                     const int m = bm0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (m >= Mtot) continue;
-                    const int b = m / qhw, rem = m - b * qhw;
-                    const int qy = rem / ph.qw, qx = rem - qy * ph.qw;
-                    const size_t opix = (size_t)(b * a.OH + qy * a.osy + ph.ooy) * a.OW + qx * a.osx + ph.oox;
+                    size_t opix = m;
+                    if (!a.ident) {
+                        const int b = m / qhw, rem = m - b * qhw;
+                        const int qy = rem / ph.qw, qx = rem - qy * ph.qw;
+                        opix = (size_t)(b * a.OH + qy * a.osy + ph.ooy) * a.OW + qx * a.osx + ph.oox;
+                    }
                     wsp[opix * a.N + n] = acc[i][j][r];
                 }
         }
@@ -272,9 +276,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
             for (int r = 0; r < 16; ++r) {
                 const int m = bm0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= Mtot || !nok) continue;
-                const int b = m / qhw, rem = m - b * qhw;
-                const int qy = rem / ph.qw, qx = rem - qy * ph.qw;
-                const size_t opix = (size_t)(b * a.OH + qy * a.osy + ph.ooy) * a.OW + qx * a.osx + ph.oox;
+                size_t opix = m;
+                if (!a.ident) {
+                    const int b = m / qhw, rem = m - b * qhw;
+                    const int qy = rem / ph.qw, qx = rem - qy * ph.qw;
+                    opix = (size_t)(b * a.OH + qy * a.osy + ph.ooy) * a.OW + qx * a.osx + ph.oox;
+                }
                 float v = acc[i][j][r] + bias;
                 if (a.epi == EPI_LRELU) {
                     v = v > 0.f ? v : v * a.slope;
@@ -282,9 +289,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
                     const float zz = a.z[opix * a.ldz + n];
                     v = zz > 0.f ? v : v * a.slope;
                 } else if (a.epi == EPI_GDN) {
-                    v = a.z[opix * a.ldz + n] / sqrtf(v);
+                    v = a.z[opix * a.ldz + n] * __builtin_amdgcn_rsqf(v);      // v_rsq_f32, 1 ulp (torch.rsqrt, gdn.py:63)
                 } else if (a.epi == EPI_IGDN) {
-                    v = a.z[opix * a.ldz + n] * sqrtf(v);
+                    v = a.z[opix * a.ldz + n] * __builtin_amdgcn_sqrtf(v);     // v_sqrt_f32, 1 ulp (gdn.py:61)
                 }
                 a.y[opix * a.ldy + n] = v;
             }
@@ -408,27 +415,28 @@ Plan make_plan(const IgemmArgs &g, bool c4)
     Plan pl{0, 1, maxchunks, 0};
     if (maxM == 0) return pl;
     const bool can_split = g.epi != EPI_GDN && g.epi != EPI_IGDN && !c4;
+    // co-resident workgroups per chip (LDS-limited): 2 per CU for the 55-74 KB tiles, 4 for 64x64
+    const int slots[4] = {512, 512, 512, 1024};
     double best = 1e300;
     for (int c = 0; c < 4; ++c) {
         const long tm = cdiv(maxM, kCfg[c].bm), tn = cdiv(g.N, kCfg[c].bn);
         const long tiles = tm * tn * g.nphase;
-        long split = 1;
-        if (can_split && tiles < 512) {
-            split = cdiv(512, (int)tiles);
-            const long cap = maxchunks / (kCfg[c].bm * kCfg[c].bn >= 128 * 96 ? 8 : 4);
-            if (split > cap) split = cap;
-            if (split > 64) split = 64;
-            if (split < 1) split = 1;
-        }
-        // time ~ padded work / efficiency, stretched when fewer than 2 workgroups per CU exist
-        double cost = (double)tm * kCfg[c].bm * tn * kCfg[c].bn / kCfg[c].eff;
-        const double blocks = (double)tiles * split;
-        if (blocks < 512.0) cost *= 512.0 / blocks;
-        if (split > 1) cost *= 1.0 + 0.02 * split;      // slab traffic + reduce kernel
-        if (cost < best) {
-            best = cost;
-            pl.cfg = c;
-            pl.nsplit = (int)split;
+        const int min_cps = kCfg[c].bm * kCfg[c].bn >= 128 * 96 ? 8 : 4;
+        const int max_split = can_split ? (maxchunks / min_cps > 64 ? 64 : (maxchunks / min_cps < 1 ? 1 : maxchunks / min_cps)) : 1;
+        for (int split = 1; split <= max_split; ++split) {
+            const int cps = cdiv(maxchunks, split);
+            if (split > 1 && cdiv(maxchunks, cps) != split) continue;          // same schedule as a smaller split
+            const long blocks = tiles * split;
+            const long rounds = cdiv((int)blocks, slots[c]);
+            // time ~ rounds x chunks per block x tile work / efficiency (+ fixed per-block prologue/epilogue ~ 3 chunks)
+            double cost = (double)rounds * (cps + 3) * kCfg[c].bm * kCfg[c].bn / kCfg[c].eff;
+            if (blocks < 256) cost *= 256.0 / blocks * 0.5 + 0.5;              // fewer workgroups than CUs
+            if (split > 1) cost += 0.15 * (double)split * maxM * g.N * 32.0 / 256.0;   // slab write + reduce pass
+            if (cost < best) {
+                best = cost;
+                pl.cfg = c;
+                pl.nsplit = split;
+            }
         }
     }
     pl.cps = cdiv(maxchunks, pl.nsplit);
@@ -495,6 +503,8 @@ int launch(IgemmArgs &g, bool c4, void *ws, size_t ws_bytes, hipStream_t st)
         g.xbytes = (int)xb;
         g.wbytes = (int)wb;
     }
+    g.ident = (g.nphase == 1 && g.osy == 1 && g.osx == 1 && g.ph[0].ooy == 0 && g.ph[0].oox == 0 &&
+               g.ph[0].qh == g.OH && g.ph[0].qw == g.OW) ? 1 : 0;
     g.nsplit = pl.nsplit;
     g.cps = pl.cps;
     g.ws = (float *)ws;

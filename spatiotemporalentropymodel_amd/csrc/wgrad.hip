@@ -182,21 +182,24 @@ void plan(int CP, int CG, int T, int nchunks, int *cfg, int *splits)
     double best = 1e300;
     *cfg = 0;
     *splits = 1;
+    const int slots[4] = {512, 768, 768, 1024};      // co-resident workgroups (LDS: 68 / 51 / 51 / 34 KB)
     for (int c = 0; c < 4; ++c) {
         const long ti = cdiv(CP, kWT[c].bm), tj = cdiv(CG, kWT[c].bn);
         const long tiles = ti * tj * T;
-        long s = cdiv(768, (int)(tiles > 768 ? 768 : tiles));
-        const long maxs = nchunks >= 8 ? nchunks / 8 : 1;       // at least 8 chunks (256 px) per split
-        if (s > maxs) s = maxs;
-        if (s > 64) s = 64;
-        if (s < 1) s = 1;
-        double cost = (double)ti * kWT[c].bm * tj * kWT[c].bn / kWT[c].eff;
-        const double blocks = (double)tiles * s;
-        if (blocks < 512.0) cost *= 512.0 / blocks;
-        if (cost < best) {
-            best = cost;
-            *cfg = c;
-            *splits = (int)s;
+        const int max_s = nchunks >= 8 ? (nchunks / 8 > 64 ? 64 : nchunks / 8) : 1;      // >= 8 chunks (256 px) per split
+        for (int s = 1; s <= max_s; ++s) {
+            const int cps = cdiv(nchunks, s);
+            if (s > 1 && cdiv(nchunks, cps) != s) continue;
+            const long blocks = tiles * s;
+            const long rounds = cdiv((int)blocks, slots[c]);
+            double cost = (double)rounds * (cps + 3) * kWT[c].bm * kWT[c].bn / kWT[c].eff;
+            if (blocks < 256) cost *= 256.0 / blocks * 0.5 + 0.5;
+            cost += 0.1 * (double)s * CP * CG * T * 32.0 / 256.0;                    // slab write + unpack read
+            if (cost < best) {
+                best = cost;
+                *cfg = c;
+                *splits = s;
+            }
         }
     }
 }
