@@ -99,7 +99,7 @@ int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float 
                       int B, int H, int W, int C, int K, int R, int S, int stride, int pad,
                       int splits, void *stream);
 int stem_wgrad_splits(int B, int Ho, int Wo, int C, int K, int R, int S);      /* Ho,Wo = the loop grid (Conv2d: output) */
-size_t stem_wgrad_workspace_elems(int splits, int C, int K, int R, int S);
+size_t stem_wgrad_workspace_elems(int splits, int C, int K, int R, int S, int npix);   /* npix = B*Ho*Wo of the loop grid */
 
 /* nn.ConvTranspose2d forward as sub-pixel phases (no zero insertion).  models/utils.py:122-130,
  * spatiotemporalpriors.py:821-826.  x[B,H,W,C] -> y[B,Ho,Wo,K], wp = STEM_PACK_DECONV_FWD.        */

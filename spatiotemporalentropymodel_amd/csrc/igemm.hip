@@ -14,6 +14,8 @@
 // Each lane reads 4 consecutive k of its row with one ds_read_b128; lane half h supplies
 // k = 4h+s to MFMA step s (any bijection of k is valid as long as A and B agree), so one
 // LDS read per operand tile feeds four MFMAs.
+#include <stdlib.h>
+
 #include "stem_common.h"
 
 namespace {
@@ -392,7 +394,8 @@ struct TileCfg {
     int bm, bn;
     float eff;
 };
-constexpr TileCfg kCfg[4] = {{128, 128, 1.00f}, {64, 192, 0.95f}, {128, 64, 0.90f}, {64, 64, 0.70f}};
+// relative efficiencies measured on MI355X with STEM_IGEMM_CFG sweeps of tools/kernel_bench.py (padding-free shapes)
+constexpr TileCfg kCfg[4] = {{128, 128, 1.00f}, {64, 192, 0.91f}, {128, 64, 0.88f}, {64, 64, 0.83f}};
 
 struct Plan {
     int cfg;
@@ -415,10 +418,11 @@ Plan make_plan(const IgemmArgs &g, bool c4)
     Plan pl{0, 1, maxchunks, 0};
     if (maxM == 0) return pl;
     const bool can_split = g.epi != EPI_GDN && g.epi != EPI_IGDN && !c4;
-    // co-resident workgroups per chip (LDS-limited): 2 per CU for the 55-74 KB tiles, 4 for 64x64
-    const int slots[4] = {512, 512, 512, 1024};
+    // MFMA-bound model: time ~ (workgroups on the most loaded CU) x (chunks + fixed prologue/epilogue) x tile / efficiency
     double best = 1e300;
+    static const int forced = getenv("STEM_IGEMM_CFG") ? atoi(getenv("STEM_IGEMM_CFG")) : -1;     // tuning aid
     for (int c = 0; c < 4; ++c) {
+        if (forced >= 0 && c != forced) continue;
         const long tm = cdiv(maxM, kCfg[c].bm), tn = cdiv(g.N, kCfg[c].bn);
         const long tiles = tm * tn * g.nphase;
         const int min_cps = kCfg[c].bm * kCfg[c].bn >= 128 * 96 ? 8 : 4;
@@ -427,10 +431,8 @@ Plan make_plan(const IgemmArgs &g, bool c4)
             const int cps = cdiv(maxchunks, split);
             if (split > 1 && cdiv(maxchunks, cps) != split) continue;          // same schedule as a smaller split
             const long blocks = tiles * split;
-            const long rounds = cdiv((int)blocks, slots[c]);
-            // time ~ rounds x chunks per block x tile work / efficiency (+ fixed per-block prologue/epilogue ~ 3 chunks)
-            double cost = (double)rounds * (cps + 3) * kCfg[c].bm * kCfg[c].bn / kCfg[c].eff;
-            if (blocks < 256) cost *= 256.0 / blocks * 0.5 + 0.5;              // fewer workgroups than CUs
+            const long per_cu = cdiv((int)blocks, 256);
+            double cost = (double)per_cu * (cps + 3) * kCfg[c].bm * kCfg[c].bn / kCfg[c].eff;
             if (split > 1) cost += 0.15 * (double)split * maxM * g.N * 32.0 / 256.0;   // slab write + reduce pass
             if (cost < best) {
                 best = cost;

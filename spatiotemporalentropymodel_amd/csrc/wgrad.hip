@@ -8,6 +8,8 @@
 // fetch is a conflict-free ds_read_b32 (consecutive lanes = consecutive channels).
 // Split-K over pixel ranges writes separate slabs that stem_unpack_wgrad sums in a fixed order
 // (bit-reproducible, no float atomics).
+#include <stdlib.h>
+
 #include "stem_common.h"
 
 namespace {
@@ -21,7 +23,26 @@ struct WgradArgs {
     int B, PH, PW, GH, GW;
     int stride, pad, R, S;
     int splits, chunks_per_split, nchunks;
+    const int *ptab;     // [M][2]: byte offset of the gathered pixel for tap (0,0), validity mask of the R*S taps
+    int pbytes, gbytes, tbytes;
 };
+
+// one entry per loop-grid pixel; removes the per-chunk div/mod and bounds tests from the gather
+__global__ void wgrad_pixtab_kernel(int *ptab, int Mtot, int PH, int PW, int GH, int GW, int ldg, int stride, int pad, int R, int S)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= Mtot) return;
+    const int phw = PH * PW;
+    const int b = m / phw, rem = m - b * phw;
+    const int py = rem / PW, px = rem - py * PW;
+    const int gy0 = py * stride - pad, gx0 = px * stride - pad;
+    unsigned mask = 0;
+    for (int r = 0; r < R; ++r)
+        for (int s = 0; s < S; ++s)
+            if (gy0 + r >= 0 && gy0 + r < GH && gx0 + s >= 0 && gx0 + s < GW) mask |= 1u << (r * S + s);
+    ptab[2 * m] = ((b * GH + gy0) * GW + gx0) * ldg * 4;
+    ptab[2 * m + 1] = (int)mask;
+}
 
 template <int BM, int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
@@ -51,20 +72,46 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
     const int rowB = tid / F4B, colB = (tid - rowB * F4B) * 4;
     f32x4 ra[NPA], rb[NPB];
 
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.p), 0, a.pbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.g), 0, a.gbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(a.ptab), 0, a.tbytes, 0x00020000);
+    const int tapoff = (tr * a.GW + ts) * a.ldg * 4;          // byte offset of this workgroup's tap
+    const bool colA_ok = i0 + colA < a.CP, colB_ok = j0 + colB < a.CG;
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    i32x2 pt[NPB];                                           // pixel-table entries of the NEXT chunk to load
+
+    auto tload = [&](int chunk) {
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) {
+            const int m = chunk * KP + rowB + q * RPB;
+            pt[q] = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(rt, m * 8, 0, 0));   // past the end -> {0,0}
+        }
+    };
     auto gload = [&](int chunk) {
+        if (VEC) {
+#pragma unroll
+            for (int q = 0; q < NPA; ++q) {
+                const int m = chunk * KP + rowA + q * RPA;
+                const int off = (m < Mtot && colA_ok) ? (m * a.ldp + i0 + colA) * 4 : 0x7FFFFF00;
+                ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 0));
+            }
+#pragma unroll
+            for (int q = 0; q < NPB; ++q) {
+                const bool ok = ((unsigned)pt[q][1] >> t) & 1u;
+                const int off = (ok && colB_ok) ? pt[q][0] + tapoff + (j0 + colB) * 4 : 0x7FFFFF00;
+                rb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < NPA; ++q) {
             const int m = chunk * KP + rowA + q * RPA;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (m < Mtot) {
                 const float *src = a.p + (size_t)m * a.ldp + i0 + colA;
-                if (VEC) {
-                    if (i0 + colA < a.CP) v = *reinterpret_cast<const f32x4 *>(src);
-                } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (i0 + colA + e < a.CP) v[e] = src[e];
-                }
+                for (int e = 0; e < 4; ++e)
+                    if (i0 + colA + e < a.CP) v[e] = src[e];
             }
             ra[q] = v;
         }
@@ -78,13 +125,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
                 const int gy = py * a.stride - a.pad + tr, gx = px * a.stride - a.pad + ts;
                 if (gy >= 0 && gy < a.GH && gx >= 0 && gx < a.GW) {
                     const float *src = a.g + (size_t)((b * a.GH + gy) * a.GW + gx) * a.ldg + j0 + colB;
-                    if (VEC) {
-                        if (j0 + colB < a.CG) v = *reinterpret_cast<const f32x4 *>(src);
-                    } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (j0 + colB + e < a.CG) v[e] = src[e];
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        if (j0 + colB + e < a.CG) v[e] = src[e];
                 }
             }
             rb[q] = v;
@@ -110,12 +153,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (c_begin < c_end) {
+        if (VEC) tload(c_begin);
         gload(c_begin);
+        if (VEC) tload(c_begin + 1);
         sstore(0);
         __syncthreads();
         for (int c = c_begin; c < c_end; ++c) {
             const int cur = (c - c_begin) & 1;
-            if (c + 1 < c_end) gload(c + 1);
+            if (c + 1 < c_end) {
+                gload(c + 1);
+                if (VEC) tload(c + 2);          // table entries one chunk further ahead: no dependent-load stall
+            }
             const float *Ab = Ps + (cur * KP + lh) * PA + wm0 + lr;
             const float *Bb = Gs + (cur * KP + lh) * PB + wn0 + lr;
 #pragma unroll
@@ -183,7 +231,9 @@ void plan(int CP, int CG, int T, int nchunks, int *cfg, int *splits)
     *cfg = 0;
     *splits = 1;
     const int slots[4] = {512, 768, 768, 1024};      // co-resident workgroups (LDS: 68 / 51 / 51 / 34 KB)
+    static const int forced = getenv("STEM_WGRAD_CFG") ? atoi(getenv("STEM_WGRAD_CFG")) : -1;      // tuning aid
     for (int c = 0; c < 4; ++c) {
+        if (forced >= 0 && c != forced) continue;
         const long ti = cdiv(CP, kWT[c].bm), tj = cdiv(CG, kWT[c].bn);
         const long tiles = ti * tj * T;
         const int max_s = nchunks >= 8 ? (nchunks / 8 > 64 ? 64 : nchunks / 8) : 1;      // >= 8 chunks (256 px) per split
@@ -204,7 +254,7 @@ void plan(int CP, int CG, int T, int nchunks, int *cfg, int *splits)
     }
 }
 
-int run(const float *p, int ldp, int CP, const float *g, int ldg, int CG, float *out, int B, int PH, int PW,
+int run(const float *p, int ldp, int CP, const float *g, int ldg, int CG, float *out, int *ptab, int B, int PH, int PW,
         int GH, int GW, int R, int S, int stride, int pad, int splits, hipStream_t st)
 {
     WgradArgs a;
@@ -215,6 +265,18 @@ int run(const float *p, int ldp, int CP, const float *g, int ldg, int CG, float 
     a.nchunks = cdiv(B * PH * PW, KP);
     a.splits = splits;
     a.chunks_per_split = cdiv(a.nchunks, splits);
+    const int Mtot = B * PH * PW;
+    const long pb = (((long)Mtot - 1) * ldp + CP) * 4, gb = (((long)B * GH * GW - 1) * ldg + CG) * 4;
+    if (pb >= 0x7FFFFF00L || gb >= 0x7FFFFF00L) {
+        stem_set_error("wgrad: tensor view of %ld / %ld bytes exceeds the 2 GiB buffer-descriptor range", pb, gb);
+        return -1;
+    }
+    a.pbytes = (int)pb;
+    a.gbytes = (int)gb;
+    a.tbytes = Mtot * 8;
+    a.ptab = ptab;
+    hipLaunchKernelGGL(wgrad_pixtab_kernel, dim3(cdiv(Mtot, 256)), dim3(256), 0, st, ptab, Mtot, PH, PW, GH, GW, ldg, stride, pad, R, S);
+    STEM_LAUNCH_CHECK("wgrad_pixtab");
     const bool vec = (CP % 4 == 0) && (CG % 4 == 0) && (ldp % 4 == 0) && (ldg % 4 == 0) &&
                      (((uintptr_t)p & 15) == 0) && (((uintptr_t)g & 15) == 0);
     int cfg, s_unused;
@@ -265,9 +327,10 @@ int colsum(const float *dy, int ld, size_t npix, int K, float *scratch, float *d
 
 }   // namespace
 
-STEM_EXPORT size_t stem_wgrad_workspace_elems(int splits, int C, int K, int R, int S)
+STEM_EXPORT size_t stem_wgrad_workspace_elems(int splits, int C, int K, int R, int S, int npix)
 {
-    return (size_t)splits * R * S * K * C + (size_t)CS_PARTS * K;
+    // slabs | bias-gradient partial sums | per-pixel gather table (offset, tap mask)
+    return (size_t)splits * R * S * K * C + (size_t)CS_PARTS * K + (size_t)2 * npix + 4;
 }
 
 STEM_EXPORT int stem_wgrad_splits(int B, int Ho, int Wo, int C, int K, int R, int S)
@@ -287,7 +350,8 @@ STEM_EXPORT int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int 
     hipStream_t st = (hipStream_t)stream;
     if (db && colsum(dy, lddy, (size_t)B * Ho * Wo, K, dwp + (size_t)splits * R * S * K * C, db, st)) return -2;
     // P = dY on the output grid (K channels), G = x gathered at oy*stride - pad + r  ->  [t][K][C]
-    return run(dy, lddy, K, x, ldx, C, dwp, B, Ho, Wo, H, W, R, S, stride, pad, splits, st);
+    int *ptab = reinterpret_cast<int *>(dwp + (size_t)splits * R * S * K * C + (size_t)CS_PARTS * K);
+    return run(dy, lddy, K, x, ldx, C, dwp, ptab, B, Ho, Wo, H, W, R, S, stride, pad, splits, st);
 }
 
 STEM_EXPORT int stem_deconv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
@@ -300,5 +364,6 @@ STEM_EXPORT int stem_deconv2d_wgrad(const float *x, int ldx, const float *dy, in
     hipStream_t st = (hipStream_t)stream;
     if (db && colsum(dy, lddy, (size_t)B * Ho * Wo, K, dwp + (size_t)splits * R * S * K * C, db, st)) return -2;
     // P = x on the input grid (C channels), G = dY gathered at iy*stride - pad + r  ->  [t][C][K]
-    return run(x, ldx, C, dy, lddy, K, dwp, B, H, W, Ho, Wo, R, S, stride, pad, splits, st);
+    int *ptab = reinterpret_cast<int *>(dwp + (size_t)splits * R * S * K * C + (size_t)CS_PARTS * K);
+    return run(x, ldx, C, dy, lddy, K, dwp, ptab, B, H, W, Ho, Wo, R, S, stride, pad, splits, st);
 }

@@ -209,10 +209,12 @@ def wgrad_plan(x_shape, K, R, S, stride, pad, deconv=False):
     lib = _lib.hip()
     if deconv:
         splits = lib.stem_wgrad_splits(B, H, W, K, Cc, R, S)
+        npix = B * H * W
     else:
         Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
         splits = lib.stem_wgrad_splits(B, Ho, Wo, Cc, K, R, S)
-    return splits, int(lib.stem_wgrad_workspace_elems(splits, Cc, K, R, S))
+        npix = B * Ho * Wo
+    return splits, int(lib.stem_wgrad_workspace_elems(splits, Cc, K, R, S, npix))
 
 
 def conv2d_wgrad(x, dy, K, R, S, stride, pad, dw_out=None, db_out=None, need_db=True, dwp=None, unpack=True):
