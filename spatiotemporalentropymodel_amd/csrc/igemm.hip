@@ -47,16 +47,20 @@ struct IgemmArgs {
     int nsplit, cps;
     long slab;
     int xbytes, wbytes;      // extents of the x / w views for the range-checked buffer loads
+    int exper;               // tuning experiments (STEM_IGEMM_EXPER), 0 in production
     int ident;               // output pixel index == m (stride-1, single phase): no div/mod in the epilogue
     TapPhase ph[4];
 };
 
 template <int BM, int BN, int WM, int WN, bool VEC, bool C4, bool GDNOP>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const IgemmArgs a)
 {
-    constexpr int TM = WM / 32, TN = WN / 32, AR = BM / 32, BR = BN / 32;
+    constexpr int NT = (BM / WM) * (BN / WN) * 64;       // 256 (4 wavefronts) or 512 (8 wavefronts)
+    constexpr int RPP = NT / 8;                          // tile rows staged per pass (8 float4 per 32-float row)
+    constexpr int TM = WM / 32, TN = WN / 32, AR = BM / RPP, BR = BN / RPP;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the rows staged per pass");
     constexpr int WCOLS = BN / WN;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    static_assert(NT == 256 || NT == 512, "4 or 8 waves per block");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                       // [2][BM][PITCH]
     float *Bs = smem + 2 * BM * PITCH;      // [2][BN][PITCH]
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
     bool p_ok[AR];
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
-        const int m = bm0 + srow + 32 * j;
+        const int m = bm0 + srow + RPP * j;
         p_ok[j] = m < Mtot;
         const int mm = p_ok[j] ? m : 0;
         const int b = mm / qhw, rem = mm - b * qhw;
@@ -104,8 +108,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
     int n_off[BR];                // VEC: byte offset of weight row n, or an out-of-range offset when n >= N
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
-        const int n = bn0 + srow + 32 * j;
-        n_off[j] = n < a.N ? n * a.ldw * 4 : 0x7FFFFF00;
+        const int n = bn0 + srow + RPP * j;
+        n_off[j] = n < a.N ? n * a.ldw * 4 : 0x40000000;      // + tap/k offsets (< 2^30, checked on the host) stays out of range
     }
     const int nkc = C4 ? 1 : (a.C + KC - 1) / KC;
     const int nchunks_all = C4 ? (ph.ntaps + 7) / 8 : ph.ntaps * nkc;
@@ -119,9 +123,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x), 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.w), 0, a.wbytes, 0x00020000);
 
-    f32x4 ra[AR], rb[BR];
+    // two register sets: loads run TWO chunks ahead of the MFMAs that consume them (L2/MALL latency under load
+    // exceeds one chunk of matrix work); named sets + a 2x unrolled loop keep every index static.
+    f32x4 raA[AR], rbA[BR], raB[AR], rbB[BR];
 
-    auto gload = [&](int q) {
+    auto gload = [&](int q, f32x4 (&ra)[AR], f32x4 (&rb)[BR]) {
         int t, k0;
         if (C4) {
             t = q * 8 + c4;
@@ -133,16 +139,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
         const int t0 = tapi[t * 4 + 0], t1 = tapi[t * 4 + 1], wt = tapi[t * 4 + 2];
         const bool tv = tapi[t * 4 + 3] != 0;
         if (VEC) {
-            const bool kok = k0 < a.C;
+            const int kmask = -(int)(k0 < a.C), tvmask = -(int)tv;
 #pragma unroll
             for (int j = 0; j < AR; ++j) {
-                const bool ok = ((p_mask[j] >> t) & 1u) && kok;
-                const int off = ok ? p_base[j] + t0 + k0 * 4 : 0x7FFFFF00;
+                const int mk = -(int)((p_mask[j] >> t) & 1u) & kmask;
+                const int off = ((p_base[j] + t0 + k0 * 4) & mk) | (0x7FFFFF00 & ~mk);
                 ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
             }
 #pragma unroll
             for (int j = 0; j < BR; ++j) {
-                const int off = C4 ? n_off[j] + (q * KC + 4 * c4) * 4 : ((tv && kok) ? n_off[j] + t1 + k0 * 4 : 0x7FFFFF00);
+                const int mk = C4 ? -1 : (tvmask & kmask);
+                const int o = C4 ? n_off[j] + (q * KC + 4 * c4) * 4 : n_off[j] + t1 + k0 * 4;
+                const int off = (o & mk) | (0x7FFFFF00 & ~mk);
                 rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
             }
             return;
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
-            const int n = bn0 + srow + 32 * j;
+            const int n = bn0 + srow + RPP * j;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (n < a.N && tv) {
                 const float *src = a.w + ((size_t)wt * a.N + n) * a.ldw + k0;
@@ -176,12 +184,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
     };
     // Loaded values are first touched here, AFTER the MFMA block of the current chunk, so the global loads of
     // chunk q+1 stay in flight under the matrix work of chunk q (a use inside gload would force vmcnt(0) there).
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, f32x4 (&ra)[AR], f32x4 (&rb)[BR]) {
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             f32x4 v = ra[j];
             if (GDNOP) v = v * v;                                   // GDN: x^2 (gdn.py:58)
-            *reinterpret_cast<f32x4 *>(&As[(buf * BM + srow + 32 * j) * PITCH + 4 * c4]) = v;
+            *reinterpret_cast<f32x4 *>(&As[(buf * BM + srow + RPP * j) * PITCH + 4 * c4]) = v;
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
                     v[e] = g * g - ped;
                 }
             }
-            *reinterpret_cast<f32x4 *>(&Bs[(buf * BN + srow + 32 * j) * PITCH + 4 * c4]) = v;
+            *reinterpret_cast<f32x4 *>(&Bs[(buf * BN + srow + RPP * j) * PITCH + 4 * c4]) = v;
         }
     };
 
@@ -209,14 +217,80 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (q_begin < q_end) {
-        gload(q_begin);
-        sstore(0);
-    }
-    __syncthreads();
-    for (int q = q_begin; q < q_end; ++q) {
-        const int cur = (q - q_begin) & 1;
-        if (q + 1 < q_end) gload(q + 1);
+    // One pipeline step = the MFMAs of the chunk in LDS buffer `cur`, with the staging of later chunks woven into
+    // the same basic block so that the scheduler can slot it between MFMAs (each MFMA occupies the matrix pipe for
+    // 64 cycles but the issue port only briefly): after k-group 0/1 the register set (chunk +1) is written to the
+    // other LDS buffer, after k-group 2/3 the same set is refilled with chunk `qn` (two chunks ahead).
+    auto step = [&](int cur, f32x4 (&ra)[AR], f32x4 (&rb)[BR], int qn) {
+        const float *Ab = As + (cur * BM + wm0 + lr) * PITCH + 4 * lh;
+        const float *Bb = Bs + (cur * BN + wn0 + lr) * PITCH + 4 * lh;
+        int t, k0;
+        if (C4) {
+            t = qn * 8 + c4;
+            k0 = 0;
+        } else {
+            t = qn / nkc;
+            k0 = (qn - t * nkc) * KC + 4 * c4;
+        }
+        const int t0 = tapi[t * 4 + 0], t1 = tapi[t * 4 + 1];
+        const int tvmask = -tapi[t * 4 + 3];                 // 0 / -1
+        const int kmask = -(int)(k0 < a.C);
+#pragma unroll
+        for (int k8 = 0; k8 < KC / 8; ++k8) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * PITCH + k8 * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * PITCH + k8 * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            if (k8 == 0) {
+#pragma unroll
+                for (int j = 0; j < AR; ++j) {
+                    f32x4 v = ra[j];
+                    if (GDNOP) v = v * v;
+                    *reinterpret_cast<f32x4 *>(&As[((cur ^ 1) * BM + srow + RPP * j) * PITCH + 4 * c4]) = v;
+                }
+            } else if (k8 == 1) {
+#pragma unroll
+                for (int j = 0; j < BR; ++j) {
+                    f32x4 v = rb[j];
+                    if (GDNOP) {
+                        const float bound = 3.814697265625e-06f, ped = 1.4551915228366852e-11f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float g = fmaxf(v[e], bound);
+                            v[e] = g * g - ped;
+                        }
+                    }
+                    *reinterpret_cast<f32x4 *>(&Bs[((cur ^ 1) * BN + srow + RPP * j) * PITCH + 4 * c4]) = v;
+                }
+            } else if (k8 == 2) {
+#pragma unroll
+                for (int j = 0; j < AR; ++j) {
+                    // mask arithmetic instead of ?: -- a select feeding the load gets lowered to two loads under
+                    // divergent branches, which also breaks the compiler's vmcnt accounting (it then waits for ALL loads)
+                    const int mk = -(int)((p_mask[j] >> t) & 1u) & kmask;
+                    const int off = ((p_base[j] + t0 + k0 * 4) & mk) | (0x7FFFFF00 & ~mk);
+                    ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < BR; ++j) {
+                    const int mk = C4 ? -1 : (tvmask & kmask);
+                    const int o = C4 ? n_off[j] + (qn * KC + 4 * c4) * 4 : n_off[j] + t1 + k0 * 4;
+                    const int off = (o & mk) | (0x7FFFFF00 & ~mk);
+                    rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, off, 0, 0));
+                }
+            }
+        }
+    };
+    auto compute = [&](int cur) {
         const float *Ab = As + (cur * BM + wm0 + lr) * PITCH + 4 * lh;
         const float *Bb = Bs + (cur * BN + wn0 + lr) * PITCH + 4 * lh;
 #pragma unroll
@@ -234,8 +308,39 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a)
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (q + 1 < q_end) sstore(cur ^ 1);
-        __syncthreads();
+    };
+
+    // chunk q lives in LDS buffer (q - q_begin) & 1; set A holds chunk q+1, set B chunk q+2 (odd/even alternate).
+    // Prefetch targets past the last chunk are clamped to it (loaded, never used): no branches in the loop body.
+    const int q_last = q_end - 1;
+    auto clampq = [&](int q) { return q < q_last ? q : q_last; };
+    if (q_begin < q_end) {
+        gload(q_begin, raA, rbA);
+        sstore(0, raA, rbA);
+        gload(clampq(q_begin + 1), raA, rbA);
+        gload(clampq(q_begin + 2), raB, rbB);
+    }
+    __syncthreads();
+    if (VEC) {
+        for (int q = q_begin; q < q_end; q += 2) {
+            step(0, raA, rbA, clampq(q + 3));                  // chunk q; stage q+1 -> buffer 1; prefetch q+3
+            __syncthreads();
+            if (q + 1 >= q_end) break;
+            step(1, raB, rbB, clampq(q + 4));                  // chunk q+1; stage q+2 -> buffer 0; prefetch q+4
+            __syncthreads();
+        }
+    } else {
+        for (int q = q_begin; q < q_end; q += 2) {
+            compute(0);
+            if (q + 1 < q_end) sstore(1, raA, rbA);
+            if (q + 3 < q_end) gload(q + 3, raA, rbA);
+            __syncthreads();
+            if (q + 1 >= q_end) break;
+            compute(1);
+            if (q + 2 < q_end) sstore(0, raB, rbB);
+            if (q + 4 < q_end) gload(q + 4, raB, rbB);
+            __syncthreads();
+        }
     }
 
     if (a.nsplit > 1) {   // raw partial sums; bias / activation happen in splitk_reduce_kernel
@@ -395,7 +500,9 @@ struct TileCfg {
     float eff;
 };
 // relative efficiencies measured on MI355X with STEM_IGEMM_CFG sweeps of tools/kernel_bench.py (padding-free shapes)
-constexpr TileCfg kCfg[4] = {{128, 128, 1.00f}, {64, 192, 0.91f}, {128, 64, 0.88f}, {64, 64, 0.83f}};
+constexpr int NCFG = 6;
+constexpr TileCfg kCfg[NCFG] = {{128, 128, 0.88f}, {64, 192, 0.95f}, {128, 64, 0.85f}, {64, 64, 0.90f},
+                                {128, 192, 1.00f} /* 8 waves */, {128, 128, 0.97f} /* 8 waves */};
 
 struct Plan {
     int cfg;
@@ -421,7 +528,7 @@ Plan make_plan(const IgemmArgs &g, bool c4)
     // MFMA-bound model: time ~ (workgroups on the most loaded CU) x (chunks + fixed prologue/epilogue) x tile / efficiency
     double best = 1e300;
     static const int forced = getenv("STEM_IGEMM_CFG") ? atoi(getenv("STEM_IGEMM_CFG")) : -1;     // tuning aid
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NCFG; ++c) {
         if (forced >= 0 && c != forced) continue;
         const long tm = cdiv(maxM, kCfg[c].bm), tn = cdiv(g.N, kCfg[c].bn);
         const long tiles = tm * tn * g.nphase;
@@ -456,8 +563,9 @@ int launch_cfg(const IgemmArgs &g, bool vec, bool c4, hipStream_t st)
         if (m > maxM) maxM = m;
     }
     if (maxM == 0 || g.N == 0) return 0;
-    dim3 grid(cdiv(maxM, BM), cdiv(g.N, BN), g.nphase * g.nsplit), block(256);
-    const size_t lds = (size_t)2 * (BM + BN) * PITCH * sizeof(float) + 32 * 4 * sizeof(int);
+    dim3 grid(cdiv(maxM, BM), cdiv(g.N, BN), g.nphase * g.nsplit), block((BM / WM) * (BN / WN) * 64);
+    static const size_t extra_lds = getenv("STEM_IGEMM_EXTRA_LDS") ? atoi(getenv("STEM_IGEMM_EXTRA_LDS")) : 0;   // occupancy experiments
+    const size_t lds = (size_t)2 * (BM + BN) * PITCH * sizeof(float) + 32 * 4 * sizeof(int) + extra_lds;
     static bool attr_done = false;     // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -498,13 +606,15 @@ int launch(IgemmArgs &g, bool c4, void *ws, size_t ws_bytes, hipStream_t st)
             for (int t = 0; t < g.ph[p].ntaps; ++t)
                 if (g.ph[p].wt[t] > maxwt) maxwt = g.ph[p].wt[t];
         const long wb = c4 ? (long)g.N * g.ldw * 4 : ((((long)maxwt + 1) * g.N - 1) * g.ldw + g.C) * 4;
-        if (xb >= 0x7FFFFF00L || wb >= 0x7FFFFF00L) {
+        if (xb >= 0x7FFFFF00L || wb >= 0x40000000L) {
             stem_set_error("igemm: tensor view of %ld / %ld bytes exceeds the 2 GiB buffer-descriptor range", xb, wb);
             return -1;
         }
         g.xbytes = (int)xb;
         g.wbytes = (int)wb;
     }
+    static const int exper = getenv("STEM_IGEMM_EXPER") ? atoi(getenv("STEM_IGEMM_EXPER")) : 0;
+    g.exper = exper;
     g.ident = (g.nphase == 1 && g.osy == 1 && g.osx == 1 && g.ph[0].ooy == 0 && g.ph[0].oox == 0 &&
                g.ph[0].qh == g.OH && g.ph[0].qw == g.OW) ? 1 : 0;
     g.nsplit = pl.nsplit;
@@ -516,6 +626,8 @@ int launch(IgemmArgs &g, bool c4, void *ws, size_t ws_bytes, hipStream_t st)
     case 0: rc = launch_cfg<128, 128, 64, 64>(g, vec, c4, st); break;
     case 1: rc = launch_cfg<64, 192, 32, 96>(g, vec, c4, st); break;
     case 2: rc = launch_cfg<128, 64, 64, 32>(g, vec, c4, st); break;
+    case 4: rc = launch_cfg<128, 192, 32, 96>(g, vec, c4, st); break;
+    case 5: rc = launch_cfg<128, 128, 32, 64>(g, vec, c4, st); break;
     default: rc = launch_cfg<64, 64, 32, 32>(g, vec, c4, st); break;
     }
     if (rc || pl.nsplit == 1) return rc;
