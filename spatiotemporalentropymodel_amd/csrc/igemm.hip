@@ -539,7 +539,14 @@ Plan make_plan(const IgemmArgs &g, bool c4)
             if (split > 1 && cdiv(maxchunks, cps) != split) continue;          // same schedule as a smaller split
             const long blocks = tiles * split;
             const long per_cu = cdiv((int)blocks, 256);
-            double cost = (double)per_cu * (cps + 3) * kCfg[c].bm * kCfg[c].bn / kCfg[c].eff;
+            // resident wavefronts per SIMD decide how well staging / barriers hide under the other waves' MFMAs
+            // (measured with padded LDS: 1 wave 0.75, 2 waves 0.91, 4 waves 1.0 of the same tile's throughput)
+            static const int maxblk[NCFG] = {2, 2, 2, 4, 1, 2}, wpb[NCFG] = {1, 1, 1, 1, 2, 2};
+            static const double occf[5] = {0.0, 0.75, 0.91, 0.96, 1.0};
+            const int res = (int)(per_cu < maxblk[c] ? per_cu : maxblk[c]) * wpb[c];
+            const int resmax = maxblk[c] * wpb[c];
+            const double eff = kCfg[c].eff * occf[res > 4 ? 4 : res] / occf[resmax > 4 ? 4 : resmax];
+            double cost = (double)per_cu * (cps + 3) * kCfg[c].bm * kCfg[c].bn / eff;
             if (split > 1) cost += 0.15 * (double)split * maxM * g.N * 32.0 / 256.0;   // slab write + reduce pass
             if (cost < best) {
                 best = cost;
@@ -550,6 +557,10 @@ Plan make_plan(const IgemmArgs &g, bool c4)
     }
     pl.cps = cdiv(maxchunks, pl.nsplit);
     pl.nsplit = cdiv(maxchunks, pl.cps);           // drop empty trailing splits
+    static const bool verbose = getenv("STEM_IGEMM_VERBOSE") != nullptr;
+    if (verbose)
+        fprintf(stderr, "[igemm plan] M=%d N=%d C=%d phases=%d chunks=%d -> tile %dx%d split %d (cps %d)\n", maxM, g.N, g.C,
+                g.nphase, maxchunks, kCfg[pl.cfg].bm, kCfg[pl.cfg].bn, pl.nsplit, pl.cps);
     if (pl.nsplit > 1) pl.ws_bytes = (size_t)pl.nsplit * g.B * g.OH * g.OW * g.N * sizeof(float);
     return pl;
 }
