@@ -70,7 +70,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
     const int zphase = blockIdx.z / a.nsplit, zsplit = blockIdx.z - zphase * a.nsplit;
     const TapPhase &ph = a.ph[zphase];
     const int Mtot = a.B * ph.qh * ph.qw;
-    const int bm0 = blockIdx.x * BM, bn0 = blockIdx.y * BN;
+    // XCD-aware pixel-tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so
+    // tile t -> (t % 8) gets a contiguous eighth of the pixel tiles: neighbouring tiles share halo rows / the same
+    // weights in ONE L2 instead of fetching them once per XCD.  Pure speed heuristic; any placement is correct.
+    int tile_m = blockIdx.x;
+    {
+        const int nb = gridDim.x, qq = nb >> 3, rr = nb & 7, xcd = tile_m & 7, idx = tile_m >> 3;
+        if (nb >= 16) tile_m = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int bm0 = tile_m * BM, bn0 = blockIdx.y * BN;
     if (bm0 >= Mtot) return;
 
     const int qhw = ph.qh * ph.qw;
@@ -133,8 +141,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
             t = q * 8 + c4;
             k0 = 0;
         } else {
-            t = q / nkc;
-            k0 = (q - t * nkc) * KC + 4 * c4;
+            // channel chunk outer, taps inner: the 25 taps of one 32-channel slab re-touch the same input lines
+            // back to back (L1/L2 hits) instead of once per full sweep of all channels (L2-capacity misses)
+            const int kc = q / ph.ntaps;
+            t = q - kc * ph.ntaps;
+            k0 = kc * KC + 4 * c4;
         }
         const int t0 = tapi[t * 4 + 0], t1 = tapi[t * 4 + 1], wt = tapi[t * 4 + 2];
         const bool tv = tapi[t * 4 + 3] != 0;
@@ -229,8 +240,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
             t = qn * 8 + c4;
             k0 = 0;
         } else {
-            t = qn / nkc;
-            k0 = (qn - t * nkc) * KC + 4 * c4;
+            const int kc = qn / ph.ntaps;
+            t = qn - kc * ph.ntaps;
+            k0 = kc * KC + 4 * c4;
         }
         const int t0 = tapi[t * 4 + 0], t1 = tapi[t * 4 + 1];
         const int tvmask = -tapi[t * 4 + 3];                 // 0 / -1
