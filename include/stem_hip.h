@@ -120,6 +120,19 @@ int stem_deconv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, floa
 int stem_gdn_fwd(const float *x, int ldx, const float *beta, const float *gamma, float *y, int ldy,
                  int B, int H, int W, int C, int inverse, float beta_min, void *stream);
 
+/* Convolution (or transposed convolution) with the following GDN / IGDN fused into its epilogue (inference path
+ * of g_a / g_s, priors.py:421-439): the conv output of a pixel tile stays in registers, its squares are parked in
+ * LDS and the normalisation is a second K = N contraction in the same kernel.  N <= 192, N % 4 == 0.            */
+int stem_conv2d_gdn_fwd(const float *x, int ldx, const float *wp, const float *bias, const float *beta,
+                        const float *gamma, float *y, int ldy, int B, int H, int W, int C, int K, int R, int S,
+                        int stride, int pad, int inverse, float beta_min, void *stream);
+int stem_conv2d_fwd_c4_gdn(const float *x4, const float *wp, const float *bias, const float *beta,
+                           const float *gamma, float *y, int ldy, int B, int H, int W, int K, int R, int S,
+                           int stride, int pad, int inverse, float beta_min, void *stream);
+int stem_deconv2d_gdn_fwd(const float *x, int ldx, const float *wp, const float *bias, const float *beta,
+                          const float *gamma, float *y, int ldy, int B, int H, int W, int C, int K, int R, int S,
+                          int stride, int pad, int opad, int inverse, float beta_min, void *stream);
+
 /* LeakyReLU backward given the activation OUTPUT (sign-preserving): dx = dy * (yact>0 ? 1 : slope). */
 int stem_lrelu_bwd(const float *yact, const float *dy, float *dx, size_t n, float slope, void *stream);
 

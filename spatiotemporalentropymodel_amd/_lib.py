@@ -34,6 +34,9 @@ _HIP_SIG = {
     "stem_deconv2d_dgrad": [vp, ci, vp, vp, ci, vp, ci, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],
     "stem_deconv2d_wgrad": [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_gdn_fwd": [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp],
+    "stem_conv2d_gdn_fwd": [vp, ci, vp, vp, vp, vp, vp, ci] + [ci] * 10 + [cf, vp],
+    "stem_conv2d_fwd_c4_gdn": [vp, vp, vp, vp, vp, vp, ci] + [ci] * 9 + [cf, vp],
+    "stem_deconv2d_gdn_fwd": [vp, ci, vp, vp, vp, vp, vp, ci] + [ci] * 11 + [cf, vp],
     "stem_lrelu_bwd": [vp, vp, vp, sz, cf, vp],
     "stem_nchw_to_nhwc": [vp, vp, ci, ci, ci, ci, ci, vp],
     "stem_nhwc_to_nchw": [vp, ci, vp, ci, ci, ci, ci, ci, vp],

@@ -47,12 +47,14 @@ struct IgemmArgs {
     int nsplit, cps;
     long slab;
     int xbytes, wbytes;      // extents of the x / w views for the range-checked buffer loads
+    const float *gamma;      // fused conv + GDN/IGDN (FUSE kernels): stored gamma [N][N], beta in `beta`
+    int fuse, gmbytes;       // 0 none, 1 GDN, 2 IGDN
     int exper;               // tuning experiments (STEM_IGEMM_EXPER), 0 in production
     int ident;               // output pixel index == m (stride-1, single phase): no div/mod in the epilogue
     TapPhase ph[4];
 };
 
-template <int BM, int BN, int WM, int WN, bool VEC, bool C4, bool GDNOP>
+template <int BM, int BN, int WM, int WN, bool VEC, bool C4, bool GDNOP, bool FUSE = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const IgemmArgs a)
 {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;       // 256 (4 wavefronts) or 512 (8 wavefronts)
@@ -380,6 +382,106 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
     }
 
     // ---- epilogue: lane holds column n = ..+lr, rows (r&3)+8*(r>>2)+4*lh of each 32x32 tile -------
+    // ---- fused GDN / IGDN (gdn.py:52-67) on the tile still held in registers: the workgroup owns ALL N channels
+    // of its pixels (BN >= N), so norm[px][i] = beta'[i] + sum_j gamma'[i][j] * v[px][j]^2 is a second small GEMM
+    // (K = N) whose A operand is the squared conv output parked in LDS and whose B operand (gamma, reparametrised
+    // on the fly) is streamed 32 columns at a time.  The conv output never makes the HBM round trip.
+    if (FUSE) {
+        constexpr int XP = BN + 4;                     // row pitch of the x^2 tile (conflict-free ds_read_b128)
+        float *X2 = smem;                              // [BM][XP]
+        float *Gs = smem + BM * XP;                    // [BN][PITCH]
+        __syncthreads();                               // every wave is done with the main-loop buffers
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = bn0 + wn0 + j * 32 + lr;
+            const float bias = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][j][r] + bias;
+                    acc[i][j][r] = v;                  // keep v for the final multiply
+                    X2[(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * XP + wn0 + j * 32 + lr] = v * v;
+                }
+        }
+        f32x16 nrm[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nrm[i][j][r] = 0.f;
+        const __amdgpu_buffer_rsrc_t rgm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gamma), 0, a.gmbytes, 0x00020000);
+        const int nkg = (a.N + KC - 1) / KC;
+        for (int kc = 0; kc < nkg; ++kc) {
+            const int kcol = kc * KC + 4 * c4;
+            f32x4 g4[BR];
+#pragma unroll
+            for (int j = 0; j < BR; ++j) {
+                const int n = srow + RPP * j;
+                const int mk = -(int)(n < a.N && kcol < a.N);
+                const int off = (((n * a.N + kcol) * 4) & mk) | (0x7FFFFF00 & ~mk);
+                g4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgm, off, 0, 0));
+            }
+            __syncthreads();                           // previous chunk's Gs (and, first time, X2) settled
+#pragma unroll
+            for (int j = 0; j < BR; ++j) {
+                f32x4 v = g4[j];
+                const float bound = 3.814697265625e-06f, ped = 1.4551915228366852e-11f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = fmaxf(v[e], bound);
+                    v[e] = g * g - ped;
+                }
+                *reinterpret_cast<f32x4 *>(&Gs[(srow + RPP * j) * PITCH + 4 * c4]) = v;
+            }
+            __syncthreads();
+            const float *Ab = X2 + (wm0 + lr) * XP + kc * KC + 4 * lh;
+            const float *Bb = Gs + (wn0 + lr) * PITCH + 4 * lh;
+#pragma unroll
+            for (int k8 = 0; k8 < KC / 8; ++k8) {
+                f32x4 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4 *>(Ab + i * 32 * XP + k8 * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * PITCH + k8 * 8);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            nrm[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], nrm[i][j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = bn0 + wn0 + j * 32 + lr;
+            const bool nok = n < a.N;
+            float bt = 0.f;
+            if (nok) {
+                const float bb = fmaxf(a.beta[n], a.beta_bound);
+                bt = bb * bb - 1.4551915228366852e-11f;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = bm0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m >= Mtot || !nok) continue;
+                    size_t opix = m;
+                    if (!a.ident) {
+                        const int b = m / qhw, rem = m - b * qhw;
+                        const int qy = rem / ph.qw, qx = rem - qy * ph.qw;
+                        opix = (size_t)(b * a.OH + qy * a.osy + ph.ooy) * a.OW + qx * a.osx + ph.oox;
+                    }
+                    const float nv = nrm[i][j][r] + bt;
+                    a.y[opix * a.ldy + n] = acc[i][j][r] * (a.fuse == 2 ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv));
+                }
+        }
+        return;
+    }
+
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = bn0 + wn0 + j * 32 + lr;
@@ -536,12 +638,13 @@ Plan make_plan(const IgemmArgs &g, bool c4)
     }
     Plan pl{0, 1, maxchunks, 0};
     if (maxM == 0) return pl;
-    const bool can_split = g.epi != EPI_GDN && g.epi != EPI_IGDN && !c4;
+    const bool can_split = g.epi != EPI_GDN && g.epi != EPI_IGDN && !c4 && !g.fuse;
     // MFMA-bound model: time ~ (workgroups on the most loaded CU) x (chunks + fixed prologue/epilogue) x tile / efficiency
     double best = 1e300;
     static const int forced = getenv("STEM_IGEMM_CFG") ? atoi(getenv("STEM_IGEMM_CFG")) : -1;     // tuning aid
     for (int c = 0; c < NCFG; ++c) {
-        if (forced >= 0 && c != forced) continue;
+        if (forced >= 0 && c != forced && !g.fuse) continue;
+        if (g.fuse && !((c == 1 || c == 4) && kCfg[c].bn >= g.N)) continue;      // fused GDN: all channels in one 192-wide tile
         const long tm = cdiv(maxM, kCfg[c].bm), tn = cdiv(g.N, kCfg[c].bn);
         const long tiles = tm * tn * g.nphase;
         const int min_cps = kCfg[c].bm * kCfg[c].bn >= 128 * 96 ? 8 : 4;
@@ -588,18 +691,40 @@ int launch_cfg(const IgemmArgs &g, bool vec, bool c4, hipStream_t st)
     if (maxM == 0 || g.N == 0) return 0;
     dim3 grid(cdiv(maxM, BM), cdiv(g.N, BN), g.nphase * g.nsplit), block((BM / WM) * (BN / WN) * 64);
     static const size_t extra_lds = getenv("STEM_IGEMM_EXTRA_LDS") ? atoi(getenv("STEM_IGEMM_EXTRA_LDS")) : 0;   // occupancy experiments
-    const size_t lds = (size_t)2 * (BM + BN) * PITCH * sizeof(float) + 32 * 4 * sizeof(int) + extra_lds;
+    size_t lds = (size_t)2 * (BM + BN) * PITCH * sizeof(float) + 32 * 4 * sizeof(int) + extra_lds;
+    constexpr bool can_fuse = BN == 192;
+    const size_t lds_fuse = ((size_t)BM * (BN + 4) + (size_t)BN * PITCH) * sizeof(float);
+    if (g.fuse && lds_fuse > lds) lds = lds_fuse;
     static bool attr_done = false;     // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int mx = (int)(lds_fuse > lds ? lds_fuse : lds) + 1024;
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        if constexpr (can_fuse) {
+            (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, true, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+            (void)hipFuncSetAttribute((const void *)igemm_kernel<BM, BN, WM, WN, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, mx);
+        }
         attr_done = true;
     }
     const bool gdn = g.epi == EPI_GDN || g.epi == EPI_IGDN;
-    if (c4)
+    if (g.fuse) {
+        if constexpr (can_fuse) {
+            if (!vec) {
+                stem_set_error("igemm: fused GDN needs 16-byte aligned channel counts / pitches");
+                return -1;
+            }
+            if (c4)
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, true, false, true>), grid, block, lds, st, g);
+            else
+                hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, false, false, true>), grid, block, lds, st, g);
+        } else {
+            stem_set_error("igemm: fused GDN needs a 192-wide tile");
+            return -1;
+        }
+    } else if (c4)
         hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, true, false>), grid, block, lds, st, g);
     else if (gdn && vec)
         hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, false, true>), grid, block, lds, st, g);
@@ -792,6 +917,60 @@ STEM_EXPORT int stem_deconv2d_dgrad(const float *dy, int lddy, const float *wp, 
     g.epi = xact ? EPI_DACT : EPI_BIAS;
     g.slope = slope;
     return launch(g, false, ws, ws_bytes, (hipStream_t)stream);
+}
+
+namespace {
+int set_fuse(IgemmArgs &g, const float *beta, const float *gamma, int inverse, float beta_min, const char *name)
+{
+    STEM_CHECK_ARG(beta && gamma, "%s: null beta/gamma", name);
+    STEM_CHECK_ARG(g.N <= 192 && g.N % 4 == 0, "%s: fused GDN supports up to 192 channels (multiple of 4), got %d", name, g.N);
+    g.beta = beta;
+    g.gamma = gamma;
+    g.fuse = inverse ? 2 : 1;
+    g.gmbytes = g.N * g.N * 4;
+    g.beta_bound = (float)sqrt((double)beta_min + 1.4551915228366852e-11);
+    g.epi = EPI_BIAS;
+    return 0;
+}
+}   // namespace
+
+STEM_EXPORT int stem_conv2d_gdn_fwd(const float *x, int ldx, const float *wp, const float *bias, const float *beta,
+                                    const float *gamma, float *y, int ldy, int B, int H, int W, int C, int K, int R, int S,
+                                    int stride, int pad, int inverse, float beta_min, void *stream)
+{
+    if (check_common("stem_conv2d_gdn_fwd", x, wp, y, B, H, W, C, K, R, S, stride)) return -1;
+    IgemmArgs g;
+    fill_geometry(g, KIND_CONV_FWD, B, H, W, C, K, R, S, stride, pad, 0);
+    g.x = x; g.w = wp; g.bias = bias; g.y = y;
+    g.ldx = ldx; g.ldy = ldy;
+    if (set_fuse(g, beta, gamma, inverse, beta_min, "stem_conv2d_gdn_fwd")) return -1;
+    return launch(g, false, nullptr, 0, (hipStream_t)stream);
+}
+
+STEM_EXPORT int stem_conv2d_fwd_c4_gdn(const float *x4, const float *wp, const float *bias, const float *beta,
+                                       const float *gamma, float *y, int ldy, int B, int H, int W, int K, int R, int S,
+                                       int stride, int pad, int inverse, float beta_min, void *stream)
+{
+    if (check_common("stem_conv2d_fwd_c4_gdn", x4, wp, y, B, H, W, 4, K, R, S, stride)) return -1;
+    IgemmArgs g;
+    fill_geometry(g, KIND_CONV_FWD, B, H, W, 4, K, R, S, stride, pad, 0);
+    g.x = x4; g.w = wp; g.bias = bias; g.y = y;
+    g.ldx = 4; g.ldw = 128; g.ldy = ldy;
+    if (set_fuse(g, beta, gamma, inverse, beta_min, "stem_conv2d_fwd_c4_gdn")) return -1;
+    return launch(g, true, nullptr, 0, (hipStream_t)stream);
+}
+
+STEM_EXPORT int stem_deconv2d_gdn_fwd(const float *x, int ldx, const float *wp, const float *bias, const float *beta,
+                                      const float *gamma, float *y, int ldy, int B, int H, int W, int C, int K, int R, int S,
+                                      int stride, int pad, int opad, int inverse, float beta_min, void *stream)
+{
+    if (check_common("stem_deconv2d_gdn_fwd", x, wp, y, B, H, W, C, K, R, S, stride)) return -1;
+    IgemmArgs g;
+    fill_geometry(g, KIND_DECONV_FWD, B, H, W, C, K, R, S, stride, pad, opad);
+    g.x = x; g.w = wp; g.bias = bias; g.y = y;
+    g.ldx = ldx; g.ldy = ldy;
+    if (set_fuse(g, beta, gamma, inverse, beta_min, "stem_deconv2d_gdn_fwd")) return -1;
+    return launch(g, false, nullptr, 0, (hipStream_t)stream);
 }
 
 STEM_EXPORT int stem_gdn_fwd(const float *x, int ldx, const float *beta, const float *gamma, float *y, int ldy,

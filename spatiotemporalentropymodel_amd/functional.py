@@ -294,6 +294,38 @@ def gdn_fwd(x, beta, gamma, inverse=False, beta_min=1e-6, out=None):
     return out
 
 
+def conv2d_gdn_fwd(x, wp, bias, beta, gamma, K, R, S, stride, pad, inverse=False, beta_min=1e-6, out=None):
+    """Conv2d with the following GDN/IGDN fused into the epilogue (inference path)."""
+    B, Cc, H, W = x.shape
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    if out is None:
+        out = empty_nhwc(B, K, Ho, Wo, x.device)
+    _chk(_lib.hip().stem_conv2d_gdn_fwd(x.data_ptr(), nhwc_ld(x), wp.data_ptr(), _ptr(bias), beta.data_ptr(), gamma.data_ptr(),
+                                        out.data_ptr(), nhwc_ld(out), B, H, W, Cc, K, R, S, stride, pad, int(inverse), beta_min, _stream()))
+    return out
+
+
+def conv2d_fwd_c4_gdn(x4, wp, bias, beta, gamma, K, R, S, stride, pad, inverse=False, beta_min=1e-6, out=None):
+    B, H, W, _ = x4.shape
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    if out is None:
+        out = empty_nhwc(B, K, Ho, Wo, x4.device)
+    _chk(_lib.hip().stem_conv2d_fwd_c4_gdn(x4.data_ptr(), wp.data_ptr(), _ptr(bias), beta.data_ptr(), gamma.data_ptr(), out.data_ptr(),
+                                           nhwc_ld(out), B, H, W, K, R, S, stride, pad, int(inverse), beta_min, _stream()))
+    return out
+
+
+def deconv2d_gdn_fwd(x, wp, bias, beta, gamma, K, R, S, stride, pad, opad, inverse=True, beta_min=1e-6, out=None):
+    B, Cc, H, W = x.shape
+    Ho, Wo = deconv_out_hw(H, W, R, S, stride, pad, opad)
+    if out is None:
+        out = empty_nhwc(B, K, Ho, Wo, x.device)
+    _chk(_lib.hip().stem_deconv2d_gdn_fwd(x.data_ptr(), nhwc_ld(x), wp.data_ptr(), _ptr(bias), beta.data_ptr(), gamma.data_ptr(),
+                                          out.data_ptr(), nhwc_ld(out), B, H, W, Cc, K, R, S, stride, pad, opad, int(inverse),
+                                          beta_min, _stream()))
+    return out
+
+
 def lrelu_bwd(yact, dy):
     assert nhwc_ld(yact) == yact.shape[1] and nhwc_ld(dy) == dy.shape[1]
     out = empty_nhwc(*yact.shape, yact.device)

@@ -161,6 +161,33 @@ def test_gdn_vs_oracle(F):
         assert_close(host(y), orc.gdn_fwd(x, beta, gamma, inverse=inv), what=f"gdn inverse={inv}")
 
 
+def test_fused_conv_gdn_vs_oracle(F):
+    """conv -> GDN and deconv -> IGDN in one kernel (g_a / g_s inference path) == the two separate oracle ops."""
+    C = 192
+    beta = np.sqrt(1 + 0.2 * rnd((C,), 32) + 2.0 ** -36).astype(np.float32)
+    gamma = np.sqrt(0.1 * np.eye(C) + 0.02 * np.abs(rnd((C, C), 33)) + 2.0 ** -36).astype(np.float32)
+    x, w, b = rnd((2, 192, 20, 12), 34), rnd((C, 192, 5, 5), 35, -0.03, 0.03), rnd((C,), 36)
+    ref = orc.gdn_fwd(orc.conv2d_fwd(x, w, b, 2, 2), beta, gamma, inverse=False)
+    y = F.conv2d_gdn_fwd(dev(x), F.pack_weight(dev(w), F.PACK_CONV_FWD), dev(b), dev(beta), dev(gamma), C, 5, 5, 2, 2)
+    assert_close(host(y), ref, what="conv+GDN")
+    x3, w3 = rnd((2, 3, 40, 24), 37, 0, 1), rnd((C, 3, 5, 5), 38, -0.2, 0.2)
+    ref = orc.gdn_fwd(orc.conv2d_fwd(x3, w3, b, 2, 2), beta, gamma, inverse=False)
+    y = F.conv2d_fwd_c4_gdn(F.nchw3_to_nhwc4(torch.from_numpy(x3).cuda()), F.pack_weight(dev(w3), F.PACK_CONV_FWD_C4), dev(b),
+                            dev(beta), dev(gamma), C, 5, 5, 2, 2)
+    assert_close(host(y), ref, what="first layer conv+GDN")
+    xd, wd = rnd((1, 192, 7, 9), 39), rnd((192, C, 5, 5), 40, -0.03, 0.03)
+    ref = orc.gdn_fwd(orc.deconv2d_fwd(xd, wd, b, 2, 2, 1), beta, gamma, inverse=True)
+    y = F.deconv2d_gdn_fwd(dev(xd), F.pack_weight(dev(wd), F.PACK_DECONV_FWD), dev(b), dev(beta), dev(gamma), C, 5, 5, 2, 2, 1, inverse=True)
+    assert_close(host(y), ref, what="deconv+IGDN")
+    # fewer channels than the 192-wide tile (small model: N = 64)
+    C2 = 64
+    w2, b2 = rnd((C2, 64, 5, 5), 41, -0.05, 0.05), rnd((C2,), 42)
+    x2 = rnd((2, 64, 10, 10), 43)
+    ref = orc.gdn_fwd(orc.conv2d_fwd(x2, w2, b2, 2, 2), beta[:C2], gamma[:C2, :C2].copy(), inverse=False)
+    y = F.conv2d_gdn_fwd(dev(x2), F.pack_weight(dev(w2), F.PACK_CONV_FWD), dev(b2), dev(beta[:C2].copy()), dev(gamma[:C2, :C2].copy()), C2, 5, 5, 2, 2)
+    assert_close(host(y), ref, what="conv+GDN, N=64")
+
+
 def test_channel_slice_views(F):
     """torch.cat / chunk along channels are pitch views: conv reads a slice and writes into a slice."""
     B, H, W = 2, 8, 8
