@@ -95,9 +95,10 @@ int stem_conv2d_dgrad(const float *dy, int lddy, const float *wp, float *dx, int
 /* dW (packed, `splits` slabs of [R*S][K][C]) and db[K] of nn.Conv2d.  All R*S taps are produced
  * (the reference's autograd does not mask MaskedConv2d's weight gradient).  dwp must hold
  * stem_wgrad_workspace_elems() floats: the slabs plus scratch for the two-stage bias-gradient sum.  */
+#define STEM_WGRAD_TABLE_VALID 1   /* flags: `dwp` still holds the gather table of an earlier call with the same geometry */
 int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
                       int B, int H, int W, int C, int K, int R, int S, int stride, int pad,
-                      int splits, void *stream);
+                      int splits, int flags, void *stream);
 int stem_wgrad_splits(int B, int Ho, int Wo, int C, int K, int R, int S);      /* Ho,Wo = the loop grid (Conv2d: output) */
 size_t stem_wgrad_workspace_elems(int splits, int C, int K, int R, int S, int npix);   /* npix = B*Ho*Wo of the loop grid */
 
@@ -113,7 +114,7 @@ int stem_deconv2d_dgrad(const float *dy, int lddy, const float *wp, float *dx, i
 /* dW packed as [splits][R*S][K][C] with K = out channels, C = in channels; unpack with deconv=1. */
 int stem_deconv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
                         int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad,
-                        int splits, void *stream);
+                        int splits, int flags, void *stream);
 
 /* GDN / IGDN forward, compressai/layers/gdn.py:52-67 with the NonNegativeParametrizer
  * (compressai/ops/parametrizers.py:42-45) applied to the stored beta[C], gamma[C,C] on the fly. */

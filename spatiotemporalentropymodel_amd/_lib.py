@@ -26,13 +26,13 @@ _HIP_SIG = {
     "stem_conv2d_fwd": [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, sz, vp],
     "stem_conv2d_fwd_c4": [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_conv2d_dgrad": [vp, ci, vp, vp, ci, vp, ci, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],
-    "stem_conv2d_wgrad": [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_conv2d_wgrad": [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_wgrad_splits": [ci, ci, ci, ci, ci, ci, ci],
     "stem_wgrad_workspace_elems": [ci, ci, ci, ci, ci, ci],
     "stem_conv_workspace_bytes": [ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci],
     "stem_deconv2d_fwd": [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, sz, vp],
     "stem_deconv2d_dgrad": [vp, ci, vp, vp, ci, vp, ci, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],
-    "stem_deconv2d_wgrad": [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_deconv2d_wgrad": [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_gdn_fwd": [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp],
     "stem_conv2d_gdn_fwd": [vp, ci, vp, vp, vp, vp, vp, ci] + [ci] * 10 + [cf, vp],
     "stem_conv2d_fwd_c4_gdn": [vp, vp, vp, vp, vp, vp, ci] + [ci] * 9 + [cf, vp],

@@ -78,31 +78,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
     const int tapoff = (tr * a.GW + ts) * a.ldg * 4;          // byte offset of this workgroup's tap
     const bool colA_ok = i0 + colA < a.CP, colB_ok = j0 + colB < a.CG;
     typedef int i32x2 __attribute__((ext_vector_type(2)));
-    i32x2 pt[NPB];                                           // pixel-table entries of the NEXT chunk to load
-
-    auto tload = [&](int chunk) {
-#pragma unroll
-        for (int q = 0; q < NPB; ++q) {
-            const int m = chunk * KP + rowB + q * RPB;
-            pt[q] = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(rt, m * 8, 0, 0));   // past the end -> {0,0}
-        }
-    };
     auto gload = [&](int chunk) {
-        if (VEC) {
-#pragma unroll
-            for (int q = 0; q < NPA; ++q) {
-                const int m = chunk * KP + rowA + q * RPA;
-                const int off = (m < Mtot && colA_ok) ? (m * a.ldp + i0 + colA) * 4 : 0x7FFFFF00;
-                ra[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 0));
-            }
-#pragma unroll
-            for (int q = 0; q < NPB; ++q) {
-                const bool ok = ((unsigned)pt[q][1] >> t) & 1u;
-                const int off = (ok && colB_ok) ? pt[q][0] + tapoff + (j0 + colB) * 4 : 0x7FFFFF00;
-                rb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
-            }
-            return;
-        }
 #pragma unroll
         for (int q = 0; q < NPA; ++q) {
             const int m = chunk * KP + rowA + q * RPA;
@@ -152,18 +128,94 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (c_begin < c_end) {
-        if (VEC) tload(c_begin);
+    if (VEC) {
+        // Woven pipeline (same scheme as igemm.hip): two register sets run two chunks ahead, their gather-table entries
+        // one step further; LDS writes and global loads are placed between the MFMA groups of the current chunk, all in
+        // one basic block (masks instead of branches), so the scheduler can hide them under the 64-cycle MFMAs.
+        f32x4 raB[NPA], rbB[NPB];
+        i32x2 ptA[NPB], ptB[NPB];
+        auto tl = [&](int chunk, i32x2 (&p)[NPB]) {
+#pragma unroll
+            for (int q = 0; q < NPB; ++q)
+                p[q] = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(rt, (chunk * KP + rowB + q * RPB) * 8, 0, 0));
+        };
+        auto glA = [&](int chunk, f32x4 (&r)[NPA]) {
+#pragma unroll
+            for (int q = 0; q < NPA; ++q) {
+                const int m = chunk * KP + rowA + q * RPA;
+                const int mk = -(int)(m < Mtot && colA_ok);
+                const int off = (((m * a.ldp + i0 + colA) * 4) & mk) | (0x7FFFFF00 & ~mk);
+                r[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, off, 0, 0));
+            }
+        };
+        auto glB = [&](f32x4 (&r)[NPB], const i32x2 (&p)[NPB]) {
+#pragma unroll
+            for (int q = 0; q < NPB; ++q) {
+                const int mk = -(int)(((unsigned)p[q][1] >> t) & 1u) & -(int)colB_ok;
+                const int off = ((p[q][0] + tapoff + (j0 + colB) * 4) & mk) | (0x7FFFFF00 & ~mk);
+                r[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
+            }
+        };
+        auto stA = [&](int buf, const f32x4 (&r)[NPA]) {
+#pragma unroll
+            for (int q = 0; q < NPA; ++q) *reinterpret_cast<f32x4 *>(&Ps[(buf * KP + rowA + q * RPA) * PA + colA]) = r[q];
+        };
+        auto stB = [&](int buf, const f32x4 (&r)[NPB]) {
+#pragma unroll
+            for (int q = 0; q < NPB; ++q) *reinterpret_cast<f32x4 *>(&Gs[(buf * KP + rowB + q * RPB) * PB + colB]) = r[q];
+        };
+        auto step = [&](int cur, f32x4 (&sa)[NPA], f32x4 (&sb)[NPB], i32x2 (&p)[NPB], int cn) {
+            const float *Ab = Ps + (cur * KP + lh) * PA + wm0 + lr;
+            const float *Bb = Gs + (cur * KP + lh) * PB + wn0 + lr;
+#pragma unroll
+            for (int ks = 0; ks < KP / 2; ++ks) {
+                float af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = Ab[ks * 2 * PA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j] = Bb[ks * 2 * PB + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                if (ks == 2) stA(cur ^ 1, sa);
+                if (ks == 5) stB(cur ^ 1, sb);
+                if (ks == 9) glA(cn, sa);
+                if (ks == 12) glB(sb, p);
+                if (ks == 14) tl(cn + 2, p);
+            }
+        };
+        if (c_begin < c_end) {
+            tl(c_begin, ptA);
+            glA(c_begin, ra);
+            glB(rb, ptA);
+            stA(0, ra);
+            stB(0, rb);
+            tl(c_begin + 1, ptA);
+            tl(c_begin + 2, ptB);
+            glA(c_begin + 1, ra);
+            glB(rb, ptA);
+            glA(c_begin + 2, raB);
+            glB(rbB, ptB);
+            tl(c_begin + 3, ptA);
+            tl(c_begin + 4, ptB);
+        }
+        __syncthreads();
+        for (int c = c_begin; c < c_end; c += 2) {
+            step(0, ra, rb, ptA, c + 3);          // chunk c; stage c+1 -> buffer 1; prefetch c+3 (table c+5)
+            __syncthreads();
+            if (c + 1 >= c_end) break;
+            step(1, raB, rbB, ptB, c + 4);        // chunk c+1; stage c+2 -> buffer 0; prefetch c+4 (table c+6)
+            __syncthreads();
+        }
+    } else if (c_begin < c_end) {
         gload(c_begin);
-        if (VEC) tload(c_begin + 1);
         sstore(0);
         __syncthreads();
         for (int c = c_begin; c < c_end; ++c) {
             const int cur = (c - c_begin) & 1;
-            if (c + 1 < c_end) {
-                gload(c + 1);
-                if (VEC) tload(c + 2);          // table entries one chunk further ahead: no dependent-load stall
-            }
+            if (c + 1 < c_end) gload(c + 1);
             const float *Ab = Ps + (cur * KP + lh) * PA + wm0 + lr;
             const float *Bb = Gs + (cur * KP + lh) * PB + wn0 + lr;
 #pragma unroll
@@ -255,7 +307,7 @@ void plan(int CP, int CG, int T, int nchunks, int *cfg, int *splits)
 }
 
 int run(const float *p, int ldp, int CP, const float *g, int ldg, int CG, float *out, int *ptab, int B, int PH, int PW,
-        int GH, int GW, int R, int S, int stride, int pad, int splits, hipStream_t st)
+        int GH, int GW, int R, int S, int stride, int pad, int splits, int flags, hipStream_t st)
 {
     WgradArgs a;
     a.p = p; a.g = g; a.out = out;
@@ -275,8 +327,10 @@ int run(const float *p, int ldp, int CP, const float *g, int ldg, int CG, float 
     a.gbytes = (int)gb;
     a.tbytes = Mtot * 8;
     a.ptab = ptab;
-    hipLaunchKernelGGL(wgrad_pixtab_kernel, dim3(cdiv(Mtot, 256)), dim3(256), 0, st, ptab, Mtot, PH, PW, GH, GW, ldg, stride, pad, R, S);
-    STEM_LAUNCH_CHECK("wgrad_pixtab");
+    if (!(flags & STEM_WGRAD_TABLE_VALID)) {      // the table depends on geometry only: callers that keep `dwp` reuse it
+        hipLaunchKernelGGL(wgrad_pixtab_kernel, dim3(cdiv(Mtot, 256)), dim3(256), 0, st, ptab, Mtot, PH, PW, GH, GW, ldg, stride, pad, R, S);
+        STEM_LAUNCH_CHECK("wgrad_pixtab");
+    }
     const bool vec = (CP % 4 == 0) && (CG % 4 == 0) && (ldp % 4 == 0) && (ldg % 4 == 0) &&
                      (((uintptr_t)p & 15) == 0) && (((uintptr_t)g & 15) == 0);
     int cfg, s_unused;
@@ -342,7 +396,7 @@ STEM_EXPORT int stem_wgrad_splits(int B, int Ho, int Wo, int C, int K, int R, in
 
 STEM_EXPORT int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
                                   int B, int H, int W, int C, int K, int R, int S, int stride, int pad,
-                                  int splits, void *stream)
+                                  int splits, int flags, void *stream)
 {
     STEM_CHECK_ARG(x && dy && dwp, "stem_conv2d_wgrad: null pointer");
     STEM_CHECK_ARG(splits >= 1, "stem_conv2d_wgrad: splits must be >= 1");
@@ -351,12 +405,12 @@ STEM_EXPORT int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int 
     if (db && colsum(dy, lddy, (size_t)B * Ho * Wo, K, dwp + (size_t)splits * R * S * K * C, db, st)) return -2;
     // P = dY on the output grid (K channels), G = x gathered at oy*stride - pad + r  ->  [t][K][C]
     int *ptab = reinterpret_cast<int *>(dwp + (size_t)splits * R * S * K * C + (size_t)CS_PARTS * K);
-    return run(dy, lddy, K, x, ldx, C, dwp, ptab, B, Ho, Wo, H, W, R, S, stride, pad, splits, st);
+    return run(dy, lddy, K, x, ldx, C, dwp, ptab, B, Ho, Wo, H, W, R, S, stride, pad, splits, flags, st);
 }
 
 STEM_EXPORT int stem_deconv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
                                     int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad,
-                                    int splits, void *stream)
+                                    int splits, int flags, void *stream)
 {
     STEM_CHECK_ARG(x && dy && dwp, "stem_deconv2d_wgrad: null pointer");
     STEM_CHECK_ARG(splits >= 1, "stem_deconv2d_wgrad: splits must be >= 1");
@@ -365,5 +419,5 @@ STEM_EXPORT int stem_deconv2d_wgrad(const float *x, int ldx, const float *dy, in
     if (db && colsum(dy, lddy, (size_t)B * Ho * Wo, K, dwp + (size_t)splits * R * S * K * C, db, st)) return -2;
     // P = x on the input grid (C channels), G = dY gathered at iy*stride - pad + r  ->  [t][C][K]
     int *ptab = reinterpret_cast<int *>(dwp + (size_t)splits * R * S * K * C + (size_t)CS_PARTS * K);
-    return run(x, ldx, C, dy, lddy, K, dwp, ptab, B, H, W, Ho, Wo, R, S, stride, pad, splits, st);
+    return run(x, ldx, C, dy, lddy, K, dwp, ptab, B, H, W, Ho, Wo, R, S, stride, pad, splits, flags, st);
 }

@@ -69,14 +69,18 @@ class _Layer:
         gb = _grad_of(m.bias)
         deconv = self.kind == "deconv"
         key = tuple(x.shape)
-        if key not in self._slabs:
+        key = key + (F.nhwc_ld(x), F.nhwc_ld(dy))          # the gather table bakes in the pitch of the gathered tensor
+        fresh = key not in self._slabs
+        if fresh:
             splits, elems = F.wgrad_plan(x.shape, self.K, self.R, self.R, self.stride, self.pad, deconv=deconv)
             self._slabs[key] = (torch.empty(elems, device=x.device, dtype=torch.float32), splits)
         dwp, splits = self._slabs[key]
         if deconv:
-            F.deconv2d_wgrad(x, dy, self.K, self.R, self.R, self.stride, self.pad, self.opad, db_out=gb, dwp=dwp, unpack=False)
+            F.deconv2d_wgrad(x, dy, self.K, self.R, self.R, self.stride, self.pad, self.opad, db_out=gb, dwp=dwp, unpack=False,
+                             table_valid=not fresh)
         else:
-            F.conv2d_wgrad(x, dy, self.K, self.R, self.R, self.stride, self.pad, db_out=gb, dwp=dwp, unpack=False)
+            F.conv2d_wgrad(x, dy, self.K, self.R, self.R, self.stride, self.pad, db_out=gb, dwp=dwp, unpack=False,
+                           table_valid=not fresh)
         self.pending = (dwp, splits)
 
     def unpack_desc(self):

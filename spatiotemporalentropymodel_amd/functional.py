@@ -217,7 +217,7 @@ def wgrad_plan(x_shape, K, R, S, stride, pad, deconv=False):
     return splits, int(lib.stem_wgrad_workspace_elems(splits, Cc, K, R, S, npix))
 
 
-def conv2d_wgrad(x, dy, K, R, S, stride, pad, dw_out=None, db_out=None, need_db=True, dwp=None, unpack=True):
+def conv2d_wgrad(x, dy, K, R, S, stride, pad, dw_out=None, db_out=None, need_db=True, dwp=None, unpack=True, table_valid=False):
     """-> (dW [K,C,R,S], db [K]) in the reference's layouts.  With unpack=False only the packed slabs in `dwp`
     are produced (the caller sums/transposes all layers at once with unpack_wgrads_multi)."""
     B, Cc, H, W = x.shape
@@ -227,7 +227,7 @@ def conv2d_wgrad(x, dy, K, R, S, stride, pad, dw_out=None, db_out=None, need_db=
         dwp = torch.empty(elems, device=x.device, dtype=torch.float32)
     db = (db_out if db_out is not None else torch.empty(K, device=x.device, dtype=torch.float32)) if need_db else None
     _chk(lib.stem_conv2d_wgrad(x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), dwp.data_ptr(), _ptr(db),
-                               B, H, W, Cc, K, R, S, stride, pad, splits, _stream()))
+                               B, H, W, Cc, K, R, S, stride, pad, splits, int(table_valid), _stream()))
     if not unpack:
         return None, db
     dw = dw_out if dw_out is not None else torch.empty((K, Cc, R, S), device=x.device, dtype=torch.float32)
@@ -258,7 +258,7 @@ def deconv2d_dgrad(dy, wp_dgrad, x_shape, K, R, S, stride, pad, opad, xact=None,
     return out
 
 
-def deconv2d_wgrad(x, dy, K, R, S, stride, pad, opad, dw_out=None, db_out=None, need_db=True, dwp=None, unpack=True):
+def deconv2d_wgrad(x, dy, K, R, S, stride, pad, opad, dw_out=None, db_out=None, need_db=True, dwp=None, unpack=True, table_valid=False):
     """-> (dW [C,K,R,S], db [K]) in nn.ConvTranspose2d's layout."""
     B, Cc, H, W = x.shape
     lib = _lib.hip()
@@ -267,7 +267,7 @@ def deconv2d_wgrad(x, dy, K, R, S, stride, pad, opad, dw_out=None, db_out=None, 
         dwp = torch.empty(elems, device=x.device, dtype=torch.float32)
     db = (db_out if db_out is not None else torch.empty(K, device=x.device, dtype=torch.float32)) if need_db else None
     _chk(lib.stem_deconv2d_wgrad(x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), dwp.data_ptr(), _ptr(db),
-                                 B, H, W, Cc, K, R, S, stride, pad, opad, splits, _stream()))
+                                 B, H, W, Cc, K, R, S, stride, pad, opad, splits, int(table_valid), _stream()))
     if not unpack:
         return None, db
     dw = dw_out if dw_out is not None else torch.empty((Cc, K, R, S), device=x.device, dtype=torch.float32)
