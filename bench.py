@@ -166,7 +166,7 @@ def main():
     dt = D.max_over_ranks(time.perf_counter() - t0, dev)
 
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in probe])) if probe else float("nan")
-    loss = float(last["loss"])
+    loss = float(last["loss"].detach())
     if rank != 0:
         return
     flop = GA2_FLOP_PER_FRAME * BATCH
