@@ -1,0 +1,148 @@
+"""GPU tests at BASELINE.json's FULL sizes, through size-independent properties (the oracle cannot run these
+sizes in seconds): linearity, adjoint identities <Ax, y> = <x, A^T y> tying forward / dgrad / wgrad together,
+bit-reproducibility of a whole training step, spot checks of single output pixels against the oracle on crops,
+and an encode -> decode round trip of a 1080p-shaped latent (configs[3])."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, assert_close
+
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+import stem_oracle as orc  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F():
+    from spatiotemporalentropymodel_amd import functional
+    assert torch.cuda.is_available()
+    return functional
+
+
+def cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+def test_analysis_conv_fullsize_linearity_and_spot_checks(F):
+    """g_a.2 at the benchmark size: [16,192,128,128] -> [16,192,64,64], 5x5 stride 2 (120.8 GFLOP)."""
+    torch.manual_seed(0)
+    B, C, H, W, K = 16, 192, 128, 128, 192
+    x1, x2 = cl(torch.randn(B, C, H, W, device="cuda")), cl(torch.randn(B, C, H, W, device="cuda"))
+    w = torch.randn(K, C, 5, 5, device="cuda") * 0.02
+    b = torch.randn(K, device="cuda")
+    wp = F.pack_weight(w, F.PACK_CONV_FWD)
+    y1, y2 = F.conv2d_fwd(x1, wp, b, K, 5, 5, 2, 2), F.conv2d_fwd(x2, wp, b, K, 5, 5, 2, 2)
+    y3 = F.conv2d_fwd(cl(1.5 * x1 - 0.5 * x2), wp, b, K, 5, 5, 2, 2)
+    lin = 1.5 * (y1 - b.view(1, -1, 1, 1)) - 0.5 * (y2 - b.view(1, -1, 1, 1)) + b.view(1, -1, 1, 1)
+    err = float((y3 - lin).abs().max()) / float(lin.abs().max())
+    assert err < 2e-5, err
+    # single output pixels vs the oracle evaluated on the 5x5 input window (incl. image borders and last batch item)
+    wn, bn = w.cpu().numpy(), b.cpu().numpy()
+    for (bi, oy, ox) in [(0, 0, 0), (3, 17, 40), (15, 63, 63), (7, 0, 31), (9, 63, 0)]:
+        win = torch.zeros(1, C, 5, 5)
+        for r in range(5):
+            for s in range(5):
+                iy, ix = 2 * oy - 2 + r, 2 * ox - 2 + s
+                if 0 <= iy < H and 0 <= ix < W:
+                    win[0, :, r, s] = x1[bi, :, iy, ix].cpu()
+        ref = orc.conv2d_fwd(win.numpy(), wn, bn, 1, 0)[0, :, 0, 0]
+        assert_close(y1[bi, :, oy, ox].cpu().numpy(), ref, what=f"pixel {(bi, oy, ox)}")
+
+
+@pytest.mark.parametrize("shape", [(16, 256, 16, 16, 320, 5, 1, 2), (16, 256, 16, 16, 256, 5, 2, 2), (16, 1152, 16, 16, 768, 1, 1, 0)])
+def test_adjoint_identities_fullsize(F, shape):
+    """<conv(x), dy> = <x, dgrad(dy)> = <w, wgrad(x, dy)> (bias-free) at B=16 STEM layer sizes: TPM.2, HE.2, EPM.0."""
+    B, C, H, W, K, R, st, pd = shape
+    torch.manual_seed(1)
+    x = cl(torch.randn(B, C, H, W, device="cuda"))
+    w = torch.randn(K, C, R, R, device="cuda") * 0.05
+    y = F.conv2d_fwd(x, F.pack_weight(w, F.PACK_CONV_FWD), None, K, R, R, st, pd)
+    dy = cl(torch.randn_like(y))
+    dx = F.conv2d_dgrad(dy, F.pack_weight(w, F.PACK_CONV_DGRAD), x.shape, K, R, R, st, pd)
+    dw, db = F.conv2d_wgrad(x, dy, K, R, R, st, pd)
+    s_fwd, s_dgrad, s_wgrad = dot(y, dy), dot(x, dx), dot(w, dw)
+    scale = float(y.double().norm() * dy.double().norm())
+    assert abs(s_fwd - s_dgrad) < 1e-5 * scale and abs(s_fwd - s_wgrad) < 1e-5 * scale, (s_fwd, s_dgrad, s_wgrad)
+    assert_close(db.cpu().numpy(), dy.double().sum((0, 2, 3)).float().cpu().numpy(), what="bias gradient")
+
+
+def test_deconv_adjoint_fullsize(F):
+    B, C, H, W, K = 16, 256, 8, 8, 256                      # HD.2
+    torch.manual_seed(2)
+    x = cl(torch.randn(B, C, H, W, device="cuda"))
+    w = torch.randn(C, K, 5, 5, device="cuda") * 0.05
+    y = F.deconv2d_fwd(x, F.pack_weight(w, F.PACK_DECONV_FWD), None, K, 5, 5, 2, 2, 1)
+    assert tuple(y.shape) == (B, K, 16, 16)
+    dy = cl(torch.randn_like(y))
+    dx = F.deconv2d_dgrad(dy, F.pack_weight(w, F.PACK_DECONV_DGRAD), x.shape, K, 5, 5, 2, 2, 1)
+    dw, _ = F.deconv2d_wgrad(x, dy, K, 5, 5, 2, 2, 1)
+    s = dot(y, dy)
+    scale = float(y.double().norm() * dy.double().norm())
+    assert abs(s - dot(x, dx)) < 1e-5 * scale and abs(s - dot(w, dw)) < 1e-5 * scale
+
+
+def test_config2_training_step_is_bit_reproducible():
+    """configs[1] shapes (B=16, N=M=192, ebc=256): two runs of the same P-frame step from the same state give
+    bit-identical gradients and parameters (no float atomics anywhere on the gradient path)."""
+    from spatiotemporalentropymodel_amd.losses import EMLoss
+    from spatiotemporalentropymodel_amd.optim import configure_optimizers
+    from spatiotemporalentropymodel_amd.selfcheck import p_frame_step
+    from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel_Res
+    from spatiotemporalentropymodel_amd.zoo import models
+    dev = torch.device("cuda:0")
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(7)
+        imodel = models["mbt2018"](quality=4).to(dev).eval()
+        stem = SpatioTemporalPriorModel_Res().to(dev).train()
+        opt, aux = configure_optimizers(stem, types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3))
+        g = torch.Generator(device=dev)
+        g.manual_seed(11)
+        frames = [torch.rand(16, 3, 256, 256, device=dev, generator=g) for _ in range(2)]
+        with torch.no_grad():
+            _, y_cond = imodel.getY(frames[0])
+        out, oc, auxl, gn = p_frame_step(imodel, stem, EMLoss(), opt, aux, frames[1], y_cond)
+        torch.cuda.synchronize()
+        outs.append((opt.flat.grad.clone(), opt.flat.data.clone(), float(oc["loss"].detach()), float(gn), out["y_hat"].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]), "gradients differ between two identical runs"
+    assert torch.equal(outs[0][1], outs[1][1]), "parameters differ between two identical runs"
+    assert torch.equal(outs[0][4], outs[1][4])
+    assert abs(outs[0][2] - outs[1][2]) <= 1e-12 * abs(outs[0][2]) and np.isfinite(outs[0][2]) and outs[0][3] > 0
+    assert tuple(outs[0][4].shape) == (16, 192, 16, 16)
+
+
+def test_1080p_latent_roundtrip_config4():
+    """configs[3]: 1920x1080 frame padded to 1088 -> y [1,192,68,120], z [1,256,17,30]: compress -> decompress."""
+    from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel_Res
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_
+    dev = torch.device("cuda:0")
+    m = SpatioTemporalPriorModel_Res()
+    closed_form_fill_(m)
+    m = m.to(dev).eval()
+    m.update(force=True)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    y_cond = torch.randn(1, 192, 68, 120, device=dev, generator=g) * 3
+    y_cur = y_cond + torch.randn(1, 192, 68, 120, device=dev, generator=g) * 2
+    with torch.no_grad():
+        enc = m.compress(y_cur, y_cond)
+        assert tuple(enc["shape"]) == (17, 30)
+        enc2 = m.compress(y_cur, y_cond)
+        assert enc2["strings"][0][0] == enc["strings"][0][0] and enc2["strings"][1][0] == enc["strings"][1][0]
+        y_hat = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"]
+    assert tuple(y_hat.shape) == (1, 192, 68, 120)
+    # y_hat = round(res - mu) + mu + y_cond  =>  within half a quantisation step of y_cur everywhere
+    err = float((y_hat - y_cur).abs().max())
+    assert err <= 0.5 + 1e-4, err
+    bpp = 8 * (len(enc["strings"][0][0]) + len(enc["strings"][1][0])) / (1088 * 1920)
+    assert 0 < bpp < 24
