@@ -95,6 +95,7 @@ int stem_conv2d_dgrad(const float *dy, int lddy, const float *wp, float *dx, int
 /* dW (packed, `splits` slabs of [R*S][K][C]) and db[K] of nn.Conv2d.  All R*S taps are produced
  * (the reference's autograd does not mask MaskedConv2d's weight gradient).  dwp must hold
  * stem_wgrad_workspace_elems() floats: the slabs plus scratch for the two-stage bias-gradient sum.  */
+#define STEM_WGRAD_SQUARE_G 2     /* flags: use x^2 instead of x (GDN gamma gradient) */
 #define STEM_WGRAD_TABLE_VALID 1   /* flags: `dwp` still holds the gather table of an earlier call with the same geometry */
 int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
                       int B, int H, int W, int C, int K, int R, int S, int stride, int pad,
@@ -133,6 +134,15 @@ int stem_conv2d_fwd_c4_gdn(const float *x4, const float *wp, const float *bias, 
 int stem_deconv2d_gdn_fwd(const float *x, int ldx, const float *wp, const float *bias, const float *beta,
                           const float *gamma, float *y, int ldy, int B, int H, int W, int C, int K, int R, int S,
                           int stride, int pad, int opad, int inverse, float beta_min, void *stream);
+
+/* GDN / IGDN backward (torch autograd of gdn.py:52-67 incl. the NonNegativeParametrizer / LowerBound chain):
+ * x, dy -> dx, dbeta[C], dgamma[C,C] (gradients of the STORED parameters).  The denominator is recomputed
+ * (one K=C contraction), dx needs a second one with gamma'^T, dgamma a pixel reduction of g (x) x^2.
+ * ws: stem_gdn_bwd_workspace_bytes(B,H,W,C) bytes of scratch.                                                    */
+size_t stem_gdn_bwd_workspace_bytes(int B, int H, int W, int C);
+int stem_gdn_bwd(const float *x, int ldx, const float *dy, int lddy, const float *beta, const float *gamma,
+                 float *dx, int lddx, float *dbeta, float *dgamma, int B, int H, int W, int C, int inverse,
+                 float beta_min, void *ws, size_t ws_bytes, void *stream);
 
 /* LeakyReLU backward given the activation OUTPUT (sign-preserving): dx = dy * (yact>0 ? 1 : slope). */
 int stem_lrelu_bwd(const float *yact, const float *dy, float *dx, size_t n, float slope, void *stream);

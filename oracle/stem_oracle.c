@@ -326,6 +326,62 @@ ORC_API void orc_gdn_fwd(const float *x, const float *beta_p, const float *gamma
     free(gamma);
 }
 
+/* GDN / IGDN backward = torch autograd of gdn.py:52-67 including the NonNegativeParametrizer chain
+ * (parametrizers.py:42-45: out = LowerBound(p)^2 - pedestal; LowerBound passes the gradient iff
+ * p >= bound or the incoming gradient is negative, bound_ops.py:28-31).
+ *   n_i = beta'_i + sum_j gamma'_ij x_j^2 ;  GDN: y = x n^-1/2 ;  IGDN: y = x n^1/2
+ *   g_i := dL/dn_i = dy_i x_i * (-1/2 n_i^-3/2 | +1/2 n_i^-1/2)
+ *   dx_k = dy_k n_k^(-1/2|+1/2) + 2 x_k sum_i gamma'_ik g_i ; dbeta'_i = sum_pix g_i ; dgamma'_ij = sum_pix g_i x_j^2 */
+ORC_API void orc_gdn_bwd(const float *x, const float *dy, const float *beta_p, const float *gamma_p, float *dx,
+                         float *dbeta, float *dgamma, int N, int C, int H, int W, int inverse, float beta_min)
+{
+    const double pedestal = ldexp(1.0, -36);
+    const float bbound = (float)sqrt((double)beta_min + pedestal), gbound = (float)sqrt(pedestal);
+    const size_t HW = (size_t)H * W;
+    double *beta = (double *)malloc(sizeof(double) * C), *gamma = (double *)malloc(sizeof(double) * (size_t)C * C);
+    double *db = (double *)calloc(C, sizeof(double)), *dg = (double *)calloc((size_t)C * C, sizeof(double));
+    for (int i = 0; i < C; ++i) {
+        const double v = beta_p[i] > bbound ? beta_p[i] : bbound;
+        beta[i] = v * v - pedestal;
+    }
+    for (size_t i = 0; i < (size_t)C * C; ++i) {
+        const double v = gamma_p[i] > gbound ? gamma_p[i] : gbound;
+        gamma[i] = v * v - pedestal;
+    }
+    double *g = (double *)malloc(sizeof(double) * C), *nn = (double *)malloc(sizeof(double) * C);
+    for (int n = 0; n < N; ++n)
+        for (size_t p = 0; p < HW; ++p) {
+            const float *xp = x + (size_t)n * C * HW + p;
+            const float *dyp = dy + (size_t)n * C * HW + p;
+            for (int i = 0; i < C; ++i) {
+                double a = beta[i];
+                for (int j = 0; j < C; ++j) a += gamma[(size_t)i * C + j] * (double)xp[j * HW] * (double)xp[j * HW];
+                nn[i] = a;
+                const double xi = xp[i * HW], dyi = dyp[i * HW];
+                g[i] = inverse ? 0.5 * dyi * xi / sqrt(a) : -0.5 * dyi * xi / (a * sqrt(a));
+                db[i] += g[i];
+                for (int j = 0; j < C; ++j) dg[(size_t)i * C + j] += g[i] * (double)xp[j * HW] * (double)xp[j * HW];
+            }
+            for (int k = 0; k < C; ++k) {
+                double a = 0.0;
+                for (int i = 0; i < C; ++i) a += gamma[(size_t)i * C + k] * g[i];
+                const double u = inverse ? dyp[k * HW] * sqrt(nn[k]) : dyp[k * HW] / sqrt(nn[k]);
+                dx[(size_t)n * C * HW + k * HW + p] = (float)(u + 2.0 * xp[k * HW] * a);
+            }
+        }
+    for (int i = 0; i < C; ++i) {
+        const double lb = beta_p[i] > bbound ? beta_p[i] : bbound;
+        const double gl = 2.0 * lb * db[i];
+        dbeta[i] = (beta_p[i] >= bbound || gl < 0) ? (float)gl : 0.f;
+    }
+    for (size_t i = 0; i < (size_t)C * C; ++i) {
+        const double lb = gamma_p[i] > gbound ? gamma_p[i] : gbound;
+        const double gl = 2.0 * lb * dg[i];
+        dgamma[i] = (gamma_p[i] >= gbound || gl < 0) ? (float)gl : 0.f;
+    }
+    free(beta); free(gamma); free(db); free(dg); free(g); free(nn);
+}
+
 /* ------------------------------------------------------------------------- */
 /* EntropyBottleneck factorised density.                                      */
 /* compressai/entropy_models/entropy_models.py:388-422.                       */

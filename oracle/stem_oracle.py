@@ -122,6 +122,14 @@ def gdn_fwd(x, beta_p, gamma_p, inverse=False, beta_min=1e-6):
     return y
 
 
+def gdn_bwd(x, dy, beta_p, gamma_p, inverse=False, beta_min=1e-6):
+    x, dy, beta_p, gamma_p = _f(x), _f(dy), _f(beta_p), _f(gamma_p)
+    N, Cc, H, W = x.shape
+    dx, db, dg = np.empty_like(x), np.empty_like(beta_p), np.empty_like(gamma_p)
+    lib().orc_gdn_bwd(_p(x), _p(dy), _p(beta_p), _p(gamma_p), _p(dx), _p(db), _p(dg), N, Cc, H, W, int(inverse), C.c_float(beta_min))
+    return dx, db, dg
+
+
 def eb_pack_params(sd, prefix="entropy_bottleneck."):
     """[C,58] pack in the order stem_oracle.c documents (matrix, bias, factor per layer)."""
     cols = []

@@ -37,6 +37,8 @@ _HIP_SIG = {
     "stem_conv2d_gdn_fwd": [vp, ci, vp, vp, vp, vp, vp, ci] + [ci] * 10 + [cf, vp],
     "stem_conv2d_fwd_c4_gdn": [vp, vp, vp, vp, vp, vp, ci] + [ci] * 9 + [cf, vp],
     "stem_deconv2d_gdn_fwd": [vp, ci, vp, vp, vp, vp, vp, ci] + [ci] * 11 + [cf, vp],
+    "stem_gdn_bwd": [vp, ci, vp, ci, vp, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, cf, vp, sz, vp],
+    "stem_gdn_bwd_workspace_bytes": [ci, ci, ci, ci],
     "stem_lrelu_bwd": [vp, vp, vp, sz, cf, vp],
     "stem_nchw_to_nhwc": [vp, vp, ci, ci, ci, ci, ci, vp],
     "stem_nhwc_to_nchw": [vp, ci, vp, ci, ci, ci, ci, ci, vp],
@@ -67,7 +69,7 @@ _HIP_SIG = {
     "stem_abi_version": [],
     "stem_last_error": [],
 }
-_RESTYPE = {"stem_packed_weight_elems": sz, "stem_wgrad_workspace_elems": sz, "stem_conv_workspace_bytes": sz, "stem_last_error": C.c_char_p}
+_RESTYPE = {"stem_packed_weight_elems": sz, "stem_gdn_bwd_workspace_bytes": sz, "stem_wgrad_workspace_elems": sz, "stem_conv_workspace_bytes": sz, "stem_last_error": C.c_char_p}
 
 _RANS_SIG = {
     "stem_rans_encode": [vp, vp, sz, vp, ci, ci, vp, vp, vp, sz],

@@ -24,7 +24,7 @@ constexpr int KC = 32;        // K chunk
 constexpr int PITCH = 36;     // LDS row pitch in floats (32 + 4 pad)
 constexpr int MAXTAP = 28;
 
-enum { EPI_BIAS = 0, EPI_LRELU = 1, EPI_DACT = 2, EPI_GDN = 3, EPI_IGDN = 4 };
+enum { EPI_BIAS = 0, EPI_LRELU = 1, EPI_DACT = 2, EPI_GDN = 3, EPI_IGDN = 4, EPI_NORM = 5 /* GDN denominator only */ };
 
 struct TapPhase {
     int ooy, oox, qh, qw, ntaps;
@@ -487,7 +487,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
         const int n = bn0 + wn0 + j * 32 + lr;
         const bool nok = n < a.N;
         float bias = (a.bias && nok) ? a.bias[n] : 0.f;
-        if ((a.epi == EPI_GDN || a.epi == EPI_IGDN) && nok) {   // beta' = max(beta, bound)^2 - 2^-36
+        if ((a.epi == EPI_GDN || a.epi == EPI_IGDN || a.epi == EPI_NORM) && nok) {   // beta' = max(beta, bound)^2 - 2^-36
             const float bb = fmaxf(a.beta[n], a.beta_bound);
             bias = bb * bb - 1.4551915228366852e-11f;
         }
@@ -638,7 +638,7 @@ Plan make_plan(const IgemmArgs &g, bool c4)
     }
     Plan pl{0, 1, maxchunks, 0};
     if (maxM == 0) return pl;
-    const bool can_split = g.epi != EPI_GDN && g.epi != EPI_IGDN && !c4 && !g.fuse;
+    const bool can_split = g.epi != EPI_GDN && g.epi != EPI_IGDN && g.epi != EPI_NORM && !c4 && !g.fuse;
     // MFMA-bound model: time ~ (workgroups on the most loaded CU) x (chunks + fixed prologue/epilogue) x tile / efficiency
     double best = 1e300;
     static const int forced = getenv("STEM_IGEMM_CFG") ? atoi(getenv("STEM_IGEMM_CFG")) : -1;     // tuning aid
@@ -709,7 +709,7 @@ int launch_cfg(const IgemmArgs &g, bool vec, bool c4, hipStream_t st)
         }
         attr_done = true;
     }
-    const bool gdn = g.epi == EPI_GDN || g.epi == EPI_IGDN;
+    const bool gdn = g.epi == EPI_GDN || g.epi == EPI_IGDN || g.epi == EPI_NORM;
     if (g.fuse) {
         if constexpr (can_fuse) {
             if (!vec) {
@@ -982,7 +982,7 @@ STEM_EXPORT int stem_gdn_fwd(const float *x, int ldx, const float *beta, const f
     fill_geometry(g, KIND_CONV_FWD, B, H, W, C, C, 1, 1, 1, 0, 0);
     g.x = x; g.w = gamma; g.y = y; g.z = x; g.beta = beta;
     g.ldx = ldx; g.ldy = ldy; g.ldz = ldx;
-    g.epi = inverse ? EPI_IGDN : EPI_GDN;
+    g.epi = inverse == 2 ? EPI_NORM : (inverse ? EPI_IGDN : EPI_GDN);      // inverse == 2: write the denominator n (backward)
     g.asquare = 1;
     g.breparam = 1;
     g.beta_bound = (float)sqrt((double)beta_min + 1.4551915228366852e-11);

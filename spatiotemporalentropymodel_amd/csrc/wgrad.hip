@@ -25,6 +25,7 @@ struct WgradArgs {
     int splits, chunks_per_split, nchunks;
     const int *ptab;     // [M][2]: byte offset of the gathered pixel for tap (0,0), validity mask of the R*S taps
     int pbytes, gbytes, tbytes;
+    int gsq;             // square the gathered operand while staging (GDN: dgamma = sum g (x) x^2)
 };
 
 // one entry per loop-grid pixel; removes the per-chunk div/mod and bounds tests from the gather
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
         };
         auto stB = [&](int buf, const f32x4 (&r)[NPB]) {
 #pragma unroll
-            for (int q = 0; q < NPB; ++q) *reinterpret_cast<f32x4 *>(&Gs[(buf * KP + rowB + q * RPB) * PB + colB]) = r[q];
+            for (int q = 0; q < NPB; ++q) *reinterpret_cast<f32x4 *>(&Gs[(buf * KP + rowB + q * RPB) * PB + colB]) = a.gsq ? r[q] * r[q] : r[q];
         };
         auto step = [&](int cur, f32x4 (&sa)[NPA], f32x4 (&sb)[NPB], i32x2 (&p)[NPB], int cn) {
             const float *Ab = Ps + (cur * KP + lh) * PA + wm0 + lr;
@@ -327,6 +328,11 @@ int run(const float *p, int ldp, int CP, const float *g, int ldg, int CG, float 
     a.gbytes = (int)gb;
     a.tbytes = Mtot * 8;
     a.ptab = ptab;
+    a.gsq = (flags & STEM_WGRAD_SQUARE_G) ? 1 : 0;
+    if (a.gsq && !((CP % 4 == 0) && (CG % 4 == 0) && (ldp % 4 == 0) && (ldg % 4 == 0))) {
+        stem_set_error("wgrad: STEM_WGRAD_SQUARE_G needs 16-byte aligned channel counts");
+        return -1;
+    }
     if (!(flags & STEM_WGRAD_TABLE_VALID)) {      // the table depends on geometry only: callers that keep `dwp` reuse it
         hipLaunchKernelGGL(wgrad_pixtab_kernel, dim3(cdiv(Mtot, 256)), dim3(256), 0, st, ptab, Mtot, PH, PW, GH, GW, ldg, stride, pad, R, S);
         STEM_LAUNCH_CHECK("wgrad_pixtab");

@@ -326,6 +326,20 @@ def deconv2d_gdn_fwd(x, wp, bias, beta, gamma, K, R, S, stride, pad, opad, inver
     return out
 
 
+def gdn_bwd(x, dy, beta, gamma, inverse=False, beta_min=1e-6):
+    """-> (dx, dbeta, dgamma): gradients wrt the input and the STORED (reparametrised) parameters."""
+    B, Cc, H, W = x.shape
+    lib = _lib.hip()
+    nbytes = int(lib.stem_gdn_bwd_workspace_bytes(B, H, W, Cc))
+    ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+    dx = empty_nhwc(B, Cc, H, W, x.device)
+    dbeta, dgamma = torch.empty_like(beta), torch.empty_like(gamma)
+    _chk(lib.stem_gdn_bwd(x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), beta.data_ptr(), gamma.data_ptr(), dx.data_ptr(),
+                          nhwc_ld(dx), dbeta.data_ptr(), dgamma.data_ptr(), B, H, W, Cc, int(inverse), beta_min, ws.data_ptr(),
+                          nbytes, _stream()))
+    return dx, dbeta, dgamma
+
+
 def lrelu_bwd(yact, dy):
     assert nhwc_ld(yact) == yact.shape[1] and nhwc_ld(dy) == dy.shape[1]
     out = empty_nhwc(*yact.shape, yact.device)

@@ -112,13 +112,20 @@ class ConvTranspose2dFunction(torch.autograd.Function):
 class GDNFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, beta, gamma, inverse, beta_min):
-        return F.gdn_fwd(F.to_nhwc(x), beta, gamma, inverse, beta_min)
+        xin = F.to_nhwc(x)
+        ctx.cfg = (inverse, beta_min)
+        ctx.save_for_backward(xin, beta, gamma)
+        return F.gdn_fwd(xin, beta, gamma, inverse, beta_min)
 
     @staticmethod
     def backward(ctx, dy):
-        raise NotImplementedError(
-            "GDN backward is not on the round-1 hot path: stem/trainSTEM.py trains only the STEM "
-            "entropy model and the I-frame transforms are used forward-only (DESIGN.md, scope).")
+        inverse, beta_min = ctx.cfg
+        xin, beta, gamma = ctx.saved_tensors
+        dy = F.to_nhwc(dy)
+        if F.nhwc_ld(dy) % 4 or F.nhwc_ld(xin) % 4:
+            raise NotImplementedError("GDN backward needs channel counts that are multiples of 4")
+        dx, dbeta, dgamma = F.gdn_bwd(xin, dy, beta.detach().contiguous(), gamma.detach().contiguous(), inverse, beta_min)
+        return dx, dbeta, dgamma, None, None
 
 
 # ----------------------------------------------------------------------------- modules

@@ -161,6 +161,28 @@ def test_gdn_vs_oracle(F):
         assert_close(host(y), orc.gdn_fwd(x, beta, gamma, inverse=inv), what=f"gdn inverse={inv}")
 
 
+def test_gdn_backward(F, golden):
+    """dx, dbeta, dgamma (stored parameters, through the reparametrisation and its LowerBound rule)."""
+    g = golden("ops_small.npz")
+    for n, inv in (("gdn", False), ("igdn", True)):
+        dx, db, dg = F.gdn_bwd(dev(g[f"{n}:x"]), dev(g[f"{n}:dy"]), dev(g[f"{n}:beta"]), dev(g[f"{n}:gamma"]), inverse=inv)
+        assert_close(host(dx), g[f"{n}:dx"], what=n + " dx")
+        assert_close(host(db), g[f"{n}:dbeta"], what=n + " dbeta")
+        assert_close(host(dg), g[f"{n}:dgamma"], what=n + " dgamma")
+    B, C, H, W = 2, 192, 12, 10
+    x, dy = rnd((B, C, H, W), 131, -3, 3), rnd((B, C, H, W), 132)
+    beta = np.sqrt(1 + 0.2 * rnd((C,), 32) + 2.0 ** -36).astype(np.float32)
+    gamma = np.sqrt(0.1 * np.eye(C) + 0.02 * np.abs(rnd((C, C), 33)) + 2.0 ** -36).astype(np.float32)
+    gamma[3, :7] = 0.0                       # below the bound: gradient only passes when it pushes the value up
+    beta[5] = 0.0
+    for inv in (False, True):
+        dx, db, dg = F.gdn_bwd(dev(x), dev(dy), dev(beta), dev(gamma), inverse=inv)
+        rx, rb, rg = orc.gdn_bwd(x, dy, beta, gamma, inverse=inv)
+        assert_close(host(dx), rx, what=f"dx inverse={inv}")
+        assert_close(host(db), rb, what=f"dbeta inverse={inv}")
+        assert_close(host(dg), rg, what=f"dgamma inverse={inv}")
+
+
 def test_fused_conv_gdn_vs_oracle(F):
     """conv -> GDN and deconv -> IGDN in one kernel (g_a / g_s inference path) == the two separate oracle ops."""
     C = 192

@@ -60,6 +60,10 @@ def test_gdn(golden):
     for n, inv in (("gdn", False), ("igdn", True)):
         y = orc.gdn_fwd(g[f"{n}:x"], g[f"{n}:beta"], g[f"{n}:gamma"], inverse=inv)
         assert_close(y, g[f"{n}:y"], 1e-5, what=n)
+        dx, db, dg = orc.gdn_bwd(g[f"{n}:x"], g[f"{n}:dy"], g[f"{n}:beta"], g[f"{n}:gamma"], inverse=inv)
+        assert_close(dx, g[f"{n}:dx"], 1e-5, what=n + " dx")
+        assert_close(db, g[f"{n}:dbeta"], 1e-5, what=n + " dbeta")
+        assert_close(dg, g[f"{n}:dgamma"], 1e-5, what=n + " dgamma")
     # closed form at init (compressai_tests/test_layers.py:118-156)
     x = g["gdn_init:x"]
     y = orc.gdn_fwd(x, g["gdn_init:beta"], g["gdn_init:gamma"])
