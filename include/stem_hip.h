@@ -213,6 +213,19 @@ int stem_ar_finish_encode(const float *gp, const float *table, int T, float scal
 int stem_ar_index(const float *gp, const float *table, int T, float scale_bound, int32_t *idx, int M, void *stream);
 int stem_ar_finish_decode(const float *gp, const int32_t *sym, float *pix, int M, void *stream);
 
+/* Wavefront-parallel encoder: all latent positions with the same t = w + 3h are independent under the 5x5
+ * type-A mask, so a H x W frame is coded in W + 3(H-1) batched steps instead of H*W sequential ones.  Input
+ * segment of position p at (h, w): x + sh*h + sw*w + sp*p (element offsets); output y[p*ldy + n].            */
+typedef struct {
+    const float *x;
+    int len, woff;
+    long sh, sw, sp;
+} stem_wave_seg;
+int stem_gemv3_wave(const float *W, int ldw, const float *bias, const stem_wave_seg *segs3, float *y, int ldy, int N,
+                    int act, float slope, int t, int H, int Wd, void *stream);
+int stem_ar_finish_encode_wave(const float *gp, const float *table, int T, float scale_bound, float *buf,
+                               int32_t *sym, int32_t *idx, int M, int t, int H, int Wd, int Wp, int pad, void *stream);
+
 /* ---- optimiser --------------------------------------------------------- */
 /* sum of squares of a flat gradient buffer accumulated into acc[0] (double)                       */
 int stem_sumsq(const float *g, size_t n, double *acc, void *stream);

@@ -63,6 +63,8 @@ _HIP_SIG = {
     "stem_ar_finish_encode": [vp, vp, ci, cf, vp, vp, vp, ci, vp],
     "stem_ar_index": [vp, vp, ci, cf, vp, ci, vp],
     "stem_ar_finish_decode": [vp, vp, vp, ci, vp],
+    "stem_gemv3_wave": [vp, ci, vp, vp, vp, ci, ci, ci, cf, ci, ci, ci, vp],
+    "stem_ar_finish_encode_wave": [vp, vp, ci, cf, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "stem_sumsq": [vp, sz, vp, vp],
     "stem_adam_step": [vp, vp, vp, vp, sz, vp, cf, cf, cf, cf, cf, cf, ci, vp],
     "stem_packed_weight_elems": [ci, ci, ci, ci, ci],
@@ -97,6 +99,10 @@ class PackDesc(C.Structure):
 
 class UnpackDesc(C.Structure):
     _fields_ = [("dwp", vp), ("dw", vp), ("K", ci), ("C", ci), ("R", ci), ("S", ci), ("splits", ci), ("deconv", ci)]
+
+
+class WaveSeg(C.Structure):
+    _fields_ = [("x", vp), ("len", ci), ("woff", ci), ("sh", C.c_long), ("sw", C.c_long), ("sp", C.c_long)]
 
 
 class StemLibraryError(RuntimeError):

@@ -76,6 +76,45 @@ class _ARContext:
         self.bound = m.gaussian_conditional._scale_bound
         self.has_tpm = m.HAS_TPM
 
+    def encode_wavefront(self, buf, H, W, tp_b, hp_b, sym, idx):
+        """All positions with equal t = w + 3h are independent under the 5x5 type-A mask: W + 3(H-1) batched steps
+        (csrc/ar.hip) instead of H*W sequential ones; symbols / indexes are written in raster order."""
+        lib, M, st = _lib.hip(), self.M, F._stream()
+        P, Wp = 2 * M, W + 2 * _P
+        npmax = min(H, (W + 2) // 3)
+        dev = buf.device
+        if getattr(self, "_wave_np", 0) < npmax:
+            self._wctx = torch.empty((npmax, P), device=dev)
+            self._wh1 = torch.empty((npmax, self.w0.shape[0]), device=dev)
+            self._wh2 = torch.empty((npmax, self.w1.shape[0]), device=dev)
+            self._wgp = torch.empty((npmax, P), device=dev)
+            self._wave_np = npmax
+        S = _lib.WaveSeg
+        base = buf.data_ptr()
+        row = Wp * M
+        seg_ctx = (S * 3)(S(base, 5 * M, 0, row, M, 0), S(base + 4 * row, 5 * M, 5 * M, row, M, 0), S(base + 8 * row, 2 * M, 10 * M, row, M, 0))
+        ctx_seg = S(self._wctx.data_ptr(), P, 0, 0, 0, P)
+        if self.has_tpm:
+            ctx_seg.woff = 2 * P
+            seg_e0 = (S * 3)(S(tp_b, P, 0, W * P, P, 0), S(hp_b, P, P, W * P, P, 0), ctx_seg)
+        else:
+            ctx_seg.woff = P
+            seg_e0 = (S * 3)(S(hp_b, P, 0, W * P, P, 0), ctx_seg, S(0, 0, 0, 0, 0, 0))
+        n1, n2 = self.w0.shape[0], self.w1.shape[0]
+        seg_e1 = (S * 3)(S(self._wh1.data_ptr(), n1, 0, 0, 0, n1), S(0, 0, 0, 0, 0, 0), S(0, 0, 0, 0, 0, 0))
+        seg_e2 = (S * 3)(S(self._wh2.data_ptr(), n2, 0, 0, 0, n2), S(0, 0, 0, 0, 0, 0), S(0, 0, 0, 0, 0, 0))
+        import ctypes as C
+        a_ctx, a_e0, a_e1, a_e2 = (C.addressof(x) for x in (seg_ctx, seg_e0, seg_e1, seg_e2))
+        for t in range(W + 3 * (H - 1)):
+            F._chk(lib.stem_gemv3_wave(self.w_ctx.data_ptr(), 12 * M, self.b_ctx.data_ptr(), a_ctx, self._wctx.data_ptr(), P, P, 0, 0.0, t, H, W, st))
+            F._chk(lib.stem_gemv3_wave(self.w0.data_ptr(), self.w0.shape[1], self.b0.data_ptr(), a_e0, self._wh1.data_ptr(), n1, n1,
+                                       F.ACT_LRELU, F.LRELU_SLOPE, t, H, W, st))
+            F._chk(lib.stem_gemv3_wave(self.w1.data_ptr(), self.w1.shape[1], self.b1.data_ptr(), a_e1, self._wh2.data_ptr(), n2, n2,
+                                       F.ACT_LRELU, F.LRELU_SLOPE, t, H, W, st))
+            F._chk(lib.stem_gemv3_wave(self.w2.data_ptr(), self.w2.shape[1], self.b2.data_ptr(), a_e2, self._wgp.data_ptr(), P, P, 0, 0.0, t, H, W, st))
+            F._chk(lib.stem_ar_finish_encode_wave(self._wgp.data_ptr(), self.table.data_ptr(), self.table.numel(), self.bound,
+                                                  buf.data_ptr(), sym.data_ptr(), idx.data_ptr(), M, t, H, W, Wp, _P, st))
+
     def position(self, buf, Wp, h, w, tp_pix, hp_pix):
         """gp <- EPM(tp, hp, ctx(window at h,w)); buf is the padded [Hp, Wp, M] latent of ONE image."""
         lib, M, st = _lib.hip(), self.M, F._stream()
@@ -121,23 +160,14 @@ def stem_compress(model, y_cur, y_cond):
         return {"strings": [y_strings, z_strings], "shape": zshape}
     ar = _ARContext(model, yc.device)
     tables = gc.host_tables()
-    lib, st = _lib.hip(), None
     y_strings = []
-    Wp = W + 2 * _P
     for b in range(B):
         buf = _padded(target[b:b + 1], H, W, M, yc.device)
         sym = torch.empty((H * W, M), device=yc.device, dtype=torch.int32)
         idx = torch.empty((H * W, M), device=yc.device, dtype=torch.int32)
-        hp_b, tp_b = hp[b], (tp[b] if tp is not None else None)      # [2M,H,W] NHWC views: pixel (h,w) is contiguous
-        for h in range(H):
-            for w in range(W):
-                pos = h * W + w
-                hp_pix = hp.data_ptr() + 4 * ((b * H * W + pos) * 2 * M)
-                tp_pix = tp.data_ptr() + 4 * ((b * H * W + pos) * 2 * M) if tp is not None else 0
-                ar.position(buf, Wp, h, w, tp_pix, hp_pix)
-                pix = buf.data_ptr() + 4 * (((h + _P) * Wp + (w + _P)) * M)
-                F._chk(lib.stem_ar_finish_encode(ar.gp.data_ptr(), ar.table.data_ptr(), ar.table.numel(), ar.bound, pix,
-                                                 sym.data_ptr() + 4 * pos * M, idx.data_ptr() + 4 * pos * M, M, F._stream()))
+        hp_b = hp.data_ptr() + 4 * (b * H * W * 2 * M)
+        tp_b = tp.data_ptr() + 4 * (b * H * W * 2 * M) if tp is not None else 0
+        ar.encode_wavefront(buf, H, W, tp_b, hp_b, sym, idx)
         enc = BufferedRansEncoder()
         enc.encode_with_indexes(sym.cpu().numpy(), idx.cpu().numpy(), tables)      # one host call per image (:955-959)
         y_strings.append(enc.flush())

@@ -139,3 +139,116 @@ STEM_EXPORT int stem_ar_finish_decode(const float *gp, const int32_t *sym, float
     STEM_LAUNCH_CHECK("ar_finish_decode");
     return 0;
 }
+
+// ================================================================================================
+// Wavefront-parallel ENCODER.  With a 5x5 type-A mask and raster order, position (h, w) depends on
+// (h, w-1..w-2) and on rows h-1, h-2 at columns w-2..w+2, so all positions with the same t = w + 3h are
+// mutually independent: a frame of H x W latents needs W + 3(H-1) steps (321 for 68 x 120) instead of H*W
+// (8160), each step a *batch* of up to min(H, W/3) pixels.  Symbols and indexes land in raster order, so the
+// host coder produces the same bytes as the sequential loop.  (The decoder cannot do this: the rANS stream
+// itself is sequential in raster order.)
+//
+// Batched matrix-vector product: one wavefront per output row n, looping over the step's positions so the
+// weight row stays in L1; the input of position p is up to three segments at offsets sh*h + sw*w + sp*p.
+namespace {
+
+struct WSeg {
+    const float *x;
+    int len, woff;
+    long sh, sw, sp;
+};
+
+__device__ __forceinline__ void wave_range(int t, int H, int Wd, int &h0, int &np)
+{
+    int lo = t - (Wd - 1);
+    lo = lo > 0 ? (lo + 2) / 3 : 0;
+    int hi = t / 3;
+    if (hi > H - 1) hi = H - 1;
+    h0 = lo;
+    np = hi - lo + 1;
+}
+
+__global__ __launch_bounds__(256) void gemv3_wave_kernel(const float *W, int ldw, const float *bias, WSeg s0, WSeg s1, WSeg s2,
+                                                         float *y, int ldy, int N, int act, float slope, int t, int H, int Wd)
+{
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    int h0, np;
+    wave_range(t, H, Wd, h0, np);
+    const float *wr = W + (size_t)n * ldw;
+    const float b = bias ? bias[n] : 0.f;
+    const WSeg segs[3] = {s0, s1, s2};
+    for (int p = 0; p < np; ++p) {
+        const int h = h0 + p, w = t - 3 * h;
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const WSeg s = segs[q];
+            const float *xp = s.x + s.sh * h + s.sw * w + s.sp * p;
+            for (int k = lane * 4; k < s.len; k += 256) {
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(xp + k);
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(wr + s.woff + k);
+                acc += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) {
+            float v = acc + b;
+            if (act == STEM_ACT_LRELU) v = v > 0.f ? v : v * slope;
+            y[(size_t)p * ldy + n] = v;
+        }
+    }
+}
+
+__global__ void ar_finish_encode_wave_kernel(const float *gp, const float *table, int T, float scale_bound, float *buf,
+                                             int32_t *sym, int32_t *idx, int M, int t, int H, int Wd, int Wp, int pad)
+{
+    int h0, np;
+    wave_range(t, H, Wd, h0, np);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= np * M) return;
+    const int p = i / M, c = i - p * M;
+    const int h = h0 + p, w = t - 3 * h;
+    const float *g = gp + (size_t)p * 2 * M;
+    const float s = fmaxf(g[c], scale_bound), mu = g[M + c];
+    int k = T - 1;
+    for (int q = 0; q < T - 1; ++q) k -= (s <= table[q]) ? 1 : 0;
+    float *pix = buf + ((size_t)(h + pad) * Wp + (w + pad)) * M;
+    const float qv = rintf(pix[c] - mu);
+    pix[c] = qv + mu;
+    const size_t o = ((size_t)h * Wd + w) * M + c;
+    sym[o] = (int32_t)qv;
+    idx[o] = k;
+}
+
+}   // namespace
+
+STEM_EXPORT int stem_gemv3_wave(const float *W, int ldw, const float *bias, const stem_wave_seg *segs, float *y, int ldy, int N,
+                                int act, float slope, int t, int H, int Wd, void *stream)
+{
+    STEM_CHECK_ARG(W && segs && y && N > 0 && ldw % 4 == 0, "stem_gemv3_wave: bad arguments");
+    WSeg s[3];
+    for (int i = 0; i < 3; ++i) {
+        s[i].x = segs[i].x; s[i].len = segs[i].len; s[i].woff = segs[i].woff;
+        s[i].sh = segs[i].sh; s[i].sw = segs[i].sw; s[i].sp = segs[i].sp;
+        STEM_CHECK_ARG(s[i].len == 0 || (s[i].x && s[i].len % 4 == 0 && s[i].woff % 4 == 0 && s[i].sh % 4 == 0 && s[i].sw % 4 == 0 && s[i].sp % 4 == 0),
+                       "stem_gemv3_wave: segment %d is not 16-byte granular", i);
+    }
+    hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, W, ldw, bias, s[0], s[1], s[2], y, ldy, N,
+                       act, slope, t, H, Wd);
+    STEM_LAUNCH_CHECK("gemv3_wave");
+    return 0;
+}
+
+STEM_EXPORT int stem_ar_finish_encode_wave(const float *gp, const float *table, int T, float scale_bound, float *buf,
+                                           int32_t *sym, int32_t *idx, int M, int t, int H, int Wd, int Wp, int pad, void *stream)
+{
+    STEM_CHECK_ARG(gp && table && buf && sym && idx && M > 0 && T >= 1, "stem_ar_finish_encode_wave: bad arguments");
+    const int maxp = H < (Wd + 2) / 3 ? H : (Wd + 2) / 3;
+    hipLaunchKernelGGL(ar_finish_encode_wave_kernel, dim3(cdiv(maxp * M, 256)), dim3(256), 0, (hipStream_t)stream, gp, table, T,
+                       scale_bound, buf, sym, idx, M, t, H, Wd, Wp, pad);
+    STEM_LAUNCH_CHECK("ar_finish_encode_wave");
+    return 0;
+}
