@@ -133,7 +133,8 @@ def main():
     for m in (imodel.gaussian_conditional, stem.entropy_bottleneck, stem.gaussian_conditional):
         m.noise_seed = seed * 7919 + id(m) % 1000
     opt, aux_opt = configure_optimizers(stem, types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3))
-    reducer = D.FlatGradReducer(opt.flat.grad) if world > 1 else None
+    # gradient slices are all-reduced (RCCL, side stream) as backward finishes each module group
+    reducer = D.OverlappedGradReducer(opt.flat).attach(stem.engine()) if world > 1 else None
     crit = EMLoss()
     frames = synthetic_septuplet(BATCH, SIZE, seed, dev)
 

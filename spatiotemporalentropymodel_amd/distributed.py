@@ -82,6 +82,74 @@ class FlatGradReducer:
         cur.wait_stream(self._stream)
 
 
+class OverlappedGradReducer:
+    """Sum all-reduce of a FlatParameters gradient buffer, one contiguous slice per module group, started from
+    StemEngine.grad_ready_hook while the rest of backward is still running (RCCL on a side stream).
+
+        red = OverlappedGradReducer(opt.flat); red.attach(stem.engine())
+        loss.backward()          # slices are exchanged as they become final
+        red.finish()             # compute stream waits for the last slice; then opt.step(red.grad_scale)
+    """
+
+    def __init__(self, flat):
+        self.flat = flat
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self._off = {id(p): (o, p.numel()) for p, o in zip(flat.params, flat.offsets)}
+        self._stream = torch.cuda.Stream() if flat.grad.is_cuda else None
+        self._covered = 0
+        self.calls = 0
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world
+
+    def attach(self, engine):
+        engine.grad_ready_hook = self.reduce_params
+        return self
+
+    def reduce_params(self, params):
+        """Exchange the smallest contiguous slice of the flat buffer that covers `params` (module groups are
+        contiguous because the flat order is sorted by parameter name)."""
+        spans = sorted(self._off[id(p)] for p in params if id(p) in self._off)
+        if not spans:
+            return
+        # merge neighbours (tensors are padded to 4 elements) into maximal runs; never bridge over foreign tensors,
+        # whose gradients may not be final yet
+        runs = []
+        for o, n in spans:
+            e = (o + n + 3) // 4 * 4
+            if runs and o <= runs[-1][1]:
+                runs[-1][1] = max(runs[-1][1], e)
+            else:
+                runs.append([o, e])
+        for lo, hi in runs:
+            hi = min(hi, self.flat.grad.numel())
+            self._covered += hi - lo
+            self.calls += 1
+            if self.world == 1:
+                continue
+            g = self.flat.grad[lo:hi]
+            if self._stream is None:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                continue
+            self._stream.wait_stream(torch.cuda.current_stream())      # the slice is final on the compute stream
+            with torch.cuda.stream(self._stream):
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+
+    def finish(self):
+        covered, self._covered = self._covered, 0
+        if covered < self.flat.numel:   # some group never reported: fall back to one big exchange
+            if self.world > 1:
+                if self._stream is not None:
+                    self._stream.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(self._stream):
+                        dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)
+                else:
+                    dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+
+
 def shard_seed(base_seed: int, rank: int) -> int:
     """Per-rank data / noise seed (seed 1234 + rank)."""
     return base_seed + rank

@@ -132,10 +132,22 @@ class StemEngine:
         self._pack_key = (_layers._WEIGHT_EPOCH[0],) + tuple((l.mod.weight._version, l.mod.weight.data_ptr()) for l in self.layers)
 
     def unpack_all(self):
-        descs = [l.unpack_desc() for l in self.layers if l.pending is not None]
+        self._group_ready(self.layers, [])
+
+    #: optional callable(list_of_parameters): invoked during backward as soon as the gradients of a module group
+    #: (EPM, context_prediction, TPM, HD + entropy_bottleneck, HE -- the order backward produces them) are final,
+    #: so a data-parallel reducer can start exchanging that slice while the rest of backward still runs
+    grad_ready_hook = None
+
+    def _group_ready(self, layers, extra_params):
+        descs = [l.unpack_desc() for l in layers if l.pending is not None]
         if descs:
             arr = (_lib.UnpackDesc * len(descs))(*descs)
             F.unpack_wgrads_multi(arr)
+        if self.grad_ready_hook is not None:
+            params = [p for l in layers for p in (l.mod.weight, l.mod.bias) if p is not None] + list(extra_params)
+            if params:
+                self.grad_ready_hook(params)
 
     # -------------------------------------------------------------------------------------------
     def forward(self, y_cur, y_cond, training: bool):
@@ -210,9 +222,11 @@ class StemEngine:
         de0 = self.EPM[1].dgrad(de2, k["e0"].shape, xact=k["e0"])
         self.EPM[0].wgrad(k["epm_in"], de0)
         dpri = self.EPM[0].dgrad(de0, k["epm_in"].shape)
+        self._group_ready(self.EPM, [])
         # spatial prior: weight gradient of all 25 taps, no input gradient (its input is data + noise)
         if self.has_spm:
             self.CTX.wgrad(k["t_hat"], dpri[:, o_ctx:o_ctx + P])
+            self._group_ready([self.CTX], [])
         if self.has_tpm:
             dtp = dpri[:, o_tp:o_tp + P]
             self.TPM[2].wgrad(k["tp2"], dtp)
@@ -220,6 +234,7 @@ class StemEngine:
             self.TPM[1].wgrad(k["tp0"], d)
             d = self.TPM[1].dgrad(d, k["tp0"].shape, xact=k["tp0"])
             self.TPM[0].wgrad(k["yd"], d)
+            self._group_ready(self.TPM, [])
         # hyper decoder
         dhp = dpri[:, o_hp:o_hp + P]
         self.HD[2].wgrad(k["hd2"], dhp)
@@ -232,13 +247,14 @@ class StemEngine:
         eb = m.entropy_bottleneck
         dz, dpack = F.eb_backward(k["z_hat"], k["pack"], dlik_z, dzhat_in=dz_hat, bound=eb._lik_bound)
         F.eb_unpack_grads(dpack, [_grad_of(p) for p in eb._tensors14()])
+        self._group_ready(self.HD, eb._tensors14())
         # hyper encoder
         self.HE[2].wgrad(k["he2"], dz)
         d = self.HE[2].dgrad(dz, k["he2"].shape, xact=k["he2"])
         self.HE[1].wgrad(k["he0"], d)
         d = self.HE[1].dgrad(d, k["he0"].shape, xact=k["he0"])
         self.HE[0].wgrad(k["he_in"], d)
-        self.unpack_all()
+        self._group_ready(self.HE, [])
 
 
 class StemFunction(torch.autograd.Function):

@@ -52,9 +52,9 @@ def p_frame_step(imodel, stem, criterion, optimizer, aux_optimizer, x, y_cond, g
         y_cur, _ = imodel.getY(x)
     out = stem(y_cur, y_cond)
     oc = criterion(out, x)
-    oc["loss"].backward()
+    oc["loss"].backward()                 # an attached OverlappedGradReducer exchanges slices during this call
     if reducer is not None:
-        reducer.all_reduce()
+        reducer.finish() if hasattr(reducer, "finish") else reducer.all_reduce()
     gn = optimizer.grad_norm() * grad_scale if hasattr(optimizer, "grad_norm") else None
     optimizer.step(grad_scale) if hasattr(optimizer, "grad_norm") else optimizer.step()
     aux = stem.aux_loss()
