@@ -147,6 +147,15 @@ int stem_gdn_bwd(const float *x, int ldx, const float *dy, int lddy, const float
 /* LeakyReLU backward given the activation OUTPUT (sign-preserving): dx = dy * (yact>0 ? 1 : slope). */
 int stem_lrelu_bwd(const float *yact, const float *dy, float *dx, size_t n, float slope, void *stream);
 
+/* ---- variable-rate (ROI) models: SFT modulation and quality-map pooling (compressai/models/stem_utils.py:24-63) ----
+ * out = act(x * (1 + gamma) + beta), act = LeakyReLU(slope) (slope 1: none).  Dense tensors of n floats.           */
+int stem_sft_fwd(const float *x, const float *gamma, const float *beta, float *out, size_t n, float slope, void *stream);
+int stem_sft_bwd(const float *x, const float *gamma, const float *out, const float *dout, float *dx, float *dgamma,
+                 float *dbeta, size_t n, float slope, void *stream);
+int stem_lrelu_fwd(const float *x, float *y, size_t n, float slope, void *stream);
+/* adaptive_avg_pool2d for integer ratios: x[B,H,W,C] -> y[B,Ho,Wo,C] */
+int stem_avgpool_fwd(const float *x, int ldx, float *y, int ldy, int B, int H, int W, int C, int Ho, int Wo, void *stream);
+
 /* ---- layout ------------------------------------------------------------ */
 int stem_nchw_to_nhwc(const float *x, float *y, int ldy, int B, int C, int H, int W, void *stream);
 int stem_nhwc_to_nchw(const float *x, int ldx, float *y, int B, int C, int H, int W, int clamp01, void *stream);

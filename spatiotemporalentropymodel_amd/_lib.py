@@ -40,6 +40,10 @@ _HIP_SIG = {
     "stem_gdn_bwd": [vp, ci, vp, ci, vp, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, cf, vp, sz, vp],
     "stem_gdn_bwd_workspace_bytes": [ci, ci, ci, ci],
     "stem_lrelu_bwd": [vp, vp, vp, sz, cf, vp],
+    "stem_lrelu_fwd": [vp, vp, sz, cf, vp],
+    "stem_sft_fwd": [vp, vp, vp, vp, sz, cf, vp],
+    "stem_sft_bwd": [vp, vp, vp, vp, vp, vp, vp, sz, cf, vp],
+    "stem_avgpool_fwd": [vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_nchw_to_nhwc": [vp, vp, ci, ci, ci, ci, ci, vp],
     "stem_nhwc_to_nchw": [vp, ci, vp, ci, ci, ci, ci, ci, vp],
     "stem_nchw3_to_nhwc4": [vp, vp, ci, ci, ci, vp],

@@ -166,7 +166,7 @@ def deconv_out_hw(H, W, R, S, stride, pad, opad):
     return (H - 1) * stride - 2 * pad + R + opad, (W - 1) * stride - 2 * pad + S + opad
 
 
-def conv2d_fwd(x, wp, bias, K, R, S, stride, pad, act=ACT_NONE, out=None):
+def conv2d_fwd(x, wp, bias, K, R, S, stride, pad, act=ACT_NONE, out=None, slope=LRELU_SLOPE):
     _require_cuda(x, wp, bias)
     B, Cc, H, W = x.shape
     ldx = nhwc_ld(x)
@@ -176,7 +176,7 @@ def conv2d_fwd(x, wp, bias, K, R, S, stride, pad, act=ACT_NONE, out=None):
         out = empty_nhwc(B, K, Ho, Wo, x.device)
     ws, wsb = _workspace(0, (B, H, W, Cc, K, R, S, stride, pad, 0), x.device)
     _chk(_lib.hip().stem_conv2d_fwd(x.data_ptr(), ldx, wp.data_ptr(), _ptr(bias), out.data_ptr(), nhwc_ld(out),
-                                    B, H, W, Cc, K, R, S, stride, pad, act, LRELU_SLOPE, ws, wsb, _stream()))
+                                    B, H, W, Cc, K, R, S, stride, pad, act, slope, ws, wsb, _stream()))
     return out
 
 
@@ -235,7 +235,7 @@ def conv2d_wgrad(x, dy, K, R, S, stride, pad, dw_out=None, db_out=None, need_db=
     return dw, db
 
 
-def deconv2d_fwd(x, wp, bias, K, R, S, stride, pad, opad, act=ACT_NONE, out=None):
+def deconv2d_fwd(x, wp, bias, K, R, S, stride, pad, opad, act=ACT_NONE, out=None, slope=LRELU_SLOPE):
     _require_cuda(x, wp, bias)
     B, Cc, H, W = x.shape
     Ho, Wo = deconv_out_hw(H, W, R, S, stride, pad, opad)
@@ -243,7 +243,7 @@ def deconv2d_fwd(x, wp, bias, K, R, S, stride, pad, opad, act=ACT_NONE, out=None
         out = empty_nhwc(B, K, Ho, Wo, x.device)
     ws, wsb = _workspace(2, (B, H, W, Cc, K, R, S, stride, pad, opad), x.device)
     _chk(_lib.hip().stem_deconv2d_fwd(x.data_ptr(), nhwc_ld(x), wp.data_ptr(), _ptr(bias), out.data_ptr(), nhwc_ld(out),
-                                      B, H, W, Cc, K, R, S, stride, pad, opad, act, LRELU_SLOPE, ws, wsb, _stream()))
+                                      B, H, W, Cc, K, R, S, stride, pad, opad, act, slope, ws, wsb, _stream()))
     return out
 
 
@@ -340,10 +340,42 @@ def gdn_bwd(x, dy, beta, gamma, inverse=False, beta_min=1e-6):
     return dx, dbeta, dgamma
 
 
-def lrelu_bwd(yact, dy):
+def lrelu_bwd(yact, dy, slope=LRELU_SLOPE):
     assert nhwc_ld(yact) == yact.shape[1] and nhwc_ld(dy) == dy.shape[1]
     out = empty_nhwc(*yact.shape, yact.device)
-    _chk(_lib.hip().stem_lrelu_bwd(yact.data_ptr(), dy.data_ptr(), out.data_ptr(), yact.numel(), LRELU_SLOPE, _stream()))
+    _chk(_lib.hip().stem_lrelu_bwd(yact.data_ptr(), dy.data_ptr(), out.data_ptr(), yact.numel(), slope, _stream()))
+    return out
+
+
+def lrelu_fwd(x, slope=LRELU_SLOPE):
+    assert nhwc_ld(x) == x.shape[1]
+    out = empty_nhwc(*x.shape, x.device)
+    _chk(_lib.hip().stem_lrelu_fwd(x.data_ptr(), out.data_ptr(), x.numel(), slope, _stream()))
+    return out
+
+
+def sft_fwd(x, gamma, beta, slope=1.0):
+    """act(x * (1 + gamma) + beta) on dense NHWC tensors (stem_utils.py:41); slope 1.0 = no activation."""
+    assert nhwc_ld(x) == x.shape[1] and nhwc_ld(gamma) == x.shape[1] and nhwc_ld(beta) == x.shape[1]
+    out = empty_nhwc(*x.shape, x.device)
+    _chk(_lib.hip().stem_sft_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), x.numel(), slope, _stream()))
+    return out
+
+
+def sft_bwd(x, gamma, out, dout, slope=1.0):
+    dx, dg, db = (empty_nhwc(*x.shape, x.device) for _ in range(3))
+    _chk(_lib.hip().stem_sft_bwd(x.data_ptr(), gamma.data_ptr(), out.data_ptr(), dout.data_ptr(), dx.data_ptr(), dg.data_ptr(),
+                                 db.data_ptr(), x.numel(), slope, _stream()))
+    return dx, dg, db
+
+
+def avgpool(x, Ho, Wo):
+    """adaptive_avg_pool2d for integer ratios (quality map -> feature resolution)."""
+    B, Cc, H, W = x.shape
+    if (H, W) == (Ho, Wo):
+        return x
+    out = empty_nhwc(B, Cc, Ho, Wo, x.device)
+    _chk(_lib.hip().stem_avgpool_fwd(x.data_ptr(), nhwc_ld(x), out.data_ptr(), Cc, B, H, W, Cc, Ho, Wo, _stream()))
     return out
 
 

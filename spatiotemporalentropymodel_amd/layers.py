@@ -45,7 +45,7 @@ class _PackCache:
 # ----------------------------------------------------------------------------- autograd functions
 class Conv2dFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, masked, cache):
+    def forward(ctx, x, weight, bias, stride, pad, act, masked, cache, slope=F.LRELU_SLOPE):
         K, Cc, R, S = weight.shape
         first = Cc == 3 and F.nhwc_ld(x) is None       # image input, NCHW: fused layout change (g_a.0)
         if first:
@@ -54,21 +54,23 @@ class Conv2dFunction(torch.autograd.Function):
             xin = xin.permute(0, 3, 1, 2)               # [B,4,H,W] NHWC view for the weight gradient
         else:
             xin = F.to_nhwc(x)
-            y = F.conv2d_fwd(xin, cache.get(weight, F.PACK_CONV_FWD, masked), bias, K, R, S, stride, pad, act)
-        ctx.cfg = (stride, pad, act, masked, cache, first, tuple(x.shape))
+            y = F.conv2d_fwd(xin, cache.get(weight, F.PACK_CONV_FWD, masked), bias, K, R, S, stride, pad, act, slope=slope)
+        if first and act:
+            y = F.lrelu_fwd(y, slope)
+        ctx.cfg = (stride, pad, act, masked, cache, first, tuple(x.shape), slope)
         ctx.save_for_backward(xin, weight, y if act else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        stride, pad, act, masked, cache, first, xshape = ctx.cfg
+        stride, pad, act, masked, cache, first, xshape, slope = ctx.cfg
         xin, weight, y = ctx.saved_tensors
         K, Cc, R, S = weight.shape
         dy = F.to_nhwc(dy)
         if F.nhwc_ld(dy) != K:
             dy = F.copy_channels(dy, F.empty_nhwc(*dy.shape, dy.device))
         if act:
-            dy = F.lrelu_bwd(y, dy)
+            dy = F.lrelu_bwd(y, dy, slope)
         dx = None
         if ctx.needs_input_grad[0] and not first:
             dx = F.conv2d_dgrad(dy, cache.get(weight, F.PACK_CONV_DGRAD, 1 if masked else 0), xshape, K, R, S, stride, pad)
@@ -77,36 +79,36 @@ class Conv2dFunction(torch.autograd.Function):
             dw, db = F.conv2d_wgrad(xin, dy, K, R, S, stride, pad, need_db=ctx.needs_input_grad[2])
             if first:
                 dw = dw[:, :3].contiguous()
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class ConvTranspose2dFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, opad, act, cache):
+    def forward(ctx, x, weight, bias, stride, pad, opad, act, cache, slope=F.LRELU_SLOPE):
         Cc, K, R, S = weight.shape
         xin = F.to_nhwc(x)
-        y = F.deconv2d_fwd(xin, cache.get(weight, F.PACK_DECONV_FWD), bias, K, R, S, stride, pad, opad, act)
-        ctx.cfg = (stride, pad, opad, act, cache, tuple(x.shape))
+        y = F.deconv2d_fwd(xin, cache.get(weight, F.PACK_DECONV_FWD), bias, K, R, S, stride, pad, opad, act, slope=slope)
+        ctx.cfg = (stride, pad, opad, act, cache, tuple(x.shape), slope)
         ctx.save_for_backward(xin, weight, y if act else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        stride, pad, opad, act, cache, xshape = ctx.cfg
+        stride, pad, opad, act, cache, xshape, slope = ctx.cfg
         xin, weight, y = ctx.saved_tensors
         Cc, K, R, S = weight.shape
         dy = F.to_nhwc(dy)
         if F.nhwc_ld(dy) != K:
             dy = F.copy_channels(dy, F.empty_nhwc(*dy.shape, dy.device))
         if act:
-            dy = F.lrelu_bwd(y, dy)
+            dy = F.lrelu_bwd(y, dy, slope)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = F.deconv2d_dgrad(dy, cache.get(weight, F.PACK_DECONV_DGRAD), xshape, K, R, S, stride, pad, opad)
         dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw, db = F.deconv2d_wgrad(xin, dy, K, R, S, stride, pad, opad, need_db=ctx.needs_input_grad[2])
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class GDNFunction(torch.autograd.Function):
@@ -152,8 +154,8 @@ class Conv2d(nn.Module):
             bound = 1 / math.sqrt(self.weight[0].numel())
             nn.init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, x, act=F.ACT_NONE):
-        return Conv2dFunction.apply(x, self.weight, self.bias, self.stride, self.padding, act, self._masked, self._packs)
+    def forward(self, x, act=F.ACT_NONE, slope=F.LRELU_SLOPE):
+        return Conv2dFunction.apply(x, self.weight, self.bias, self.stride, self.padding, act, self._masked, self._packs, slope)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}"
@@ -176,9 +178,9 @@ class ConvTranspose2d(nn.Module):
             bound = 1 / math.sqrt(self.weight.shape[0] * self.kernel_size ** 2)
             nn.init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, x, act=F.ACT_NONE):
+    def forward(self, x, act=F.ACT_NONE, slope=F.LRELU_SLOPE):
         return ConvTranspose2dFunction.apply(x, self.weight, self.bias, self.stride, self.padding, self.output_padding,
-                                             act, self._packs)
+                                             act, self._packs, slope)
 
 
 class MaskedConv2d(Conv2d):
@@ -254,9 +256,9 @@ class FusedSequential(nn.Sequential):
                     x = _conv_gdn_fused(m, mods[i + 1], x)
                 i += 2
                 continue
-            if isinstance(m, (Conv2d, ConvTranspose2d)) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
-                assert abs(mods[i + 1].negative_slope - F.LRELU_SLOPE) < 1e-12
-                x = m(x, act=F.ACT_LRELU)
+            if isinstance(m, (Conv2d, ConvTranspose2d)) and i + 1 < len(mods) and isinstance(mods[i + 1], (nn.LeakyReLU, nn.ReLU)):
+                nxt = mods[i + 1]           # LeakyReLU(slope) or ReLU (= slope 0) folded into the conv epilogue
+                x = m(x, act=F.ACT_LRELU, slope=float(nxt.negative_slope) if isinstance(nxt, nn.LeakyReLU) else 0.0)
                 i += 2
             else:
                 x = m(x)
