@@ -155,6 +155,13 @@ int stem_sft_bwd(const float *x, const float *gamma, const float *out, const flo
 int stem_lrelu_fwd(const float *x, float *y, size_t n, float slope, void *stream);
 /* adaptive_avg_pool2d for integer ratios: x[B,H,W,C] -> y[B,Ho,Wo,C] */
 int stem_avgpool_fwd(const float *x, int ldx, float *y, int ldy, int B, int H, int W, int C, int Ho, int Wo, void *stream);
+/* its adjoint: dx[B,H,W,C] = dy[B,Ho,Wo,C] / window, broadcast over each window */
+int stem_avgpool_bwd(const float *dy, int ldy, float *dx, int ldx, int B, int H, int W, int C, int Ho, int Wo, void *stream);
+/* pixel-wise weighted distortion (PixelwiseRateDistortionLoss, reference utils.py:53-74): NCHW images, lambda [B,1,H,W].
+ * *acc (fp64, device) += sum lambda (xhat-x)^2 ;  dxhat = (*g) * coef * 2 lambda (xhat-x) with g a device scalar. */
+int stem_weighted_sqerr_sum(const float *xhat, const float *x, const float *lambda, int B, int C, size_t HW, double *acc, void *stream);
+int stem_weighted_sqerr_bwd(const float *xhat, const float *x, const float *lambda, float *dxhat, int B, int C, size_t HW,
+                            const double *g, float coef, void *stream);
 
 /* ---- layout ------------------------------------------------------------ */
 int stem_nchw_to_nhwc(const float *x, float *y, int ldy, int B, int C, int H, int W, void *stream);

@@ -282,6 +282,57 @@ ORC_API void orc_lrelu_bwd(const float *y, const float *dy, float *dx, size_t n,
 }
 
 /* ------------------------------------------------------------------------- */
+/* Spatial feature transform of the variable-rate models,                    */
+/* compressai/models/stem_utils.py:36-43: out = x * (1 + gamma) + beta, with  */
+/* the leaky-ReLU its callers apply next (stem_utils.py:56-57,62-63;          */
+/* stem_roi.py:566-573) folded in; slope 1 = no activation.                   */
+ORC_API void orc_sft_fwd(const float *x, const float *g, const float *b, float *o, size_t n, float slope)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const float v = x[i] * (1.f + g[i]) + b[i];
+        o[i] = v > 0.f ? v : v * slope;
+    }
+}
+ORC_API void orc_sft_bwd(const float *x, const float *g, const float *o, const float *dout, float *dx, float *dg, float *db,
+                         size_t n, float slope)
+{
+    for (size_t i = 0; i < n; ++i) {
+        const float d = o[i] > 0.f ? dout[i] : dout[i] * slope;
+        dx[i] = d * (1.f + g[i]);
+        dg[i] = d * x[i];
+        db[i] = d;
+    }
+}
+/* F.adaptive_avg_pool2d(x, (Ho, Wo)) (stem_utils.py:37, stem_roi.py:563), general window rule of              */
+/* torch: rows floor(o*H/Ho) .. ceil((o+1)*H/Ho); NCHW.                                                        */
+ORC_API void orc_adaptive_avgpool_fwd(const float *x, float *y, int NC, int H, int W, int Ho, int Wo)
+{
+    for (int p = 0; p < NC; ++p)
+        for (int oy = 0; oy < Ho; ++oy)
+            for (int ox = 0; ox < Wo; ++ox) {
+                const int y0 = (oy * H) / Ho, y1 = ((oy + 1) * H + Ho - 1) / Ho;
+                const int x0 = (ox * W) / Wo, x1 = ((ox + 1) * W + Wo - 1) / Wo;
+                float s = 0.f;
+                for (int iy = y0; iy < y1; ++iy)
+                    for (int ix = x0; ix < x1; ++ix) s += x[((size_t)p * H + iy) * W + ix];
+                y[((size_t)p * Ho + oy) * Wo + ox] = s / (float)((y1 - y0) * (x1 - x0));
+            }
+}
+ORC_API void orc_adaptive_avgpool_bwd(const float *dy, float *dx, int NC, int H, int W, int Ho, int Wo)
+{
+    memset(dx, 0, sizeof(float) * (size_t)NC * H * W);
+    for (int p = 0; p < NC; ++p)
+        for (int oy = 0; oy < Ho; ++oy)
+            for (int ox = 0; ox < Wo; ++ox) {
+                const int y0 = (oy * H) / Ho, y1 = ((oy + 1) * H + Ho - 1) / Ho;
+                const int x0 = (ox * W) / Wo, x1 = ((ox + 1) * W + Wo - 1) / Wo;
+                const float d = dy[((size_t)p * Ho + oy) * Wo + ox] / (float)((y1 - y0) * (x1 - x0));
+                for (int iy = y0; iy < y1; ++iy)
+                    for (int ix = x0; ix < x1; ++ix) dx[((size_t)p * H + iy) * W + ix] += d;
+            }
+}
+
+/* ------------------------------------------------------------------------- */
 /* GDN / IGDN forward.  compressai/layers/gdn.py:52-67 with the               */
 /* NonNegativeParametrizer (compressai/ops/parametrizers.py:27-45):           */
 /*   pedestal = 2^-36 ; bound = sqrt(minimum + pedestal)                      */

@@ -114,6 +114,79 @@ def lrelu_bwd(y, dy, slope=LRELU):
     return dx
 
 
+def sft_fwd(x, gamma, beta, slope=1.0):
+    x, gamma, beta = _f(x), _f(gamma), _f(beta)
+    out = np.empty_like(x)
+    lib().orc_sft_fwd(_p(x), _p(gamma), _p(beta), _p(out), C.c_size_t(x.size), C.c_float(slope))
+    return out
+
+
+def sft_bwd(x, gamma, out, dout, slope=1.0):
+    x, gamma, out, dout = _f(x), _f(gamma), _f(out), _f(dout)
+    dx, dg, db = np.empty_like(x), np.empty_like(x), np.empty_like(x)
+    lib().orc_sft_bwd(_p(x), _p(gamma), _p(out), _p(dout), _p(dx), _p(dg), _p(db), C.c_size_t(x.size), C.c_float(slope))
+    return dx, dg, db
+
+
+def avgpool_fwd(x, Ho, Wo):
+    x = _f(x)
+    N, Cc, H, W = x.shape
+    y = np.empty((N, Cc, Ho, Wo), np.float32)
+    lib().orc_adaptive_avgpool_fwd(_p(x), _p(y), N * Cc, H, W, Ho, Wo)
+    return y
+
+
+def avgpool_bwd(dy, H, W):
+    dy = _f(dy)
+    N, Cc, Ho, Wo = dy.shape
+    dx = np.empty((N, Cc, H, W), np.float32)
+    lib().orc_adaptive_avgpool_bwd(_p(dy), _p(dx), N * Cc, H, W, Ho, Wo)
+    return dx
+
+
+# ---- SFT / SFTResblk modules (compressai/models/stem_utils.py:24-63), forward and backward ----------------------
+def sft_module_fwd(p, prefix, x, q, slope=1.0):
+    """p: {name: ndarray} with the reference's parameter names under `prefix`; ks taken from the weights."""
+    pad = p[prefix + "mlp_shared.0.weight"].shape[-1] // 2
+    qp = avgpool_fwd(q, x.shape[2], x.shape[3])                                       # stem_utils.py:37
+    actv = lrelu_fwd(conv2d_fwd(qp, p[prefix + "mlp_shared.0.weight"], p[prefix + "mlp_shared.0.bias"], 1, pad), 0.0)   # ReLU
+    gamma = conv2d_fwd(actv, p[prefix + "mlp_gamma.weight"], p[prefix + "mlp_gamma.bias"], 1, pad)
+    beta = conv2d_fwd(actv, p[prefix + "mlp_beta.weight"], p[prefix + "mlp_beta.bias"], 1, pad)
+    out = sft_fwd(x, gamma, beta, slope)                                              # stem_utils.py:41
+    return out, (x, q, qp, actv, gamma, out, slope, pad)
+
+
+def sft_module_bwd(p, prefix, cache, dout):
+    x, q, qp, actv, gamma, out, slope, pad = cache
+    dx, dgamma, dbeta = sft_bwd(x, gamma, out, dout, slope)
+    g = {}
+    da1, g[prefix + "mlp_gamma.weight"], g[prefix + "mlp_gamma.bias"] = conv2d_bwd(actv, p[prefix + "mlp_gamma.weight"], dgamma, 1, pad)
+    da2, g[prefix + "mlp_beta.weight"], g[prefix + "mlp_beta.bias"] = conv2d_bwd(actv, p[prefix + "mlp_beta.weight"], dbeta, 1, pad)
+    dact = lrelu_bwd(actv, da1 + da2, 0.0)
+    dqp, g[prefix + "mlp_shared.0.weight"], g[prefix + "mlp_shared.0.bias"] = conv2d_bwd(qp, p[prefix + "mlp_shared.0.weight"], dact, 1, pad)
+    return dx, avgpool_bwd(dqp, q.shape[2], q.shape[3]), g
+
+
+def sft_resblk_fwd(p, prefix, x, q):
+    a0, c0 = sft_module_fwd(p, prefix + "norm_0.", x, q, 0.2)                         # stem_utils.py:56,62-63
+    d0 = conv2d_fwd(a0, p[prefix + "conv_0.weight"], p[prefix + "conv_0.bias"], 1, 1)
+    a1, c1 = sft_module_fwd(p, prefix + "norm_1.", d0, q, 0.2)
+    d1 = conv2d_fwd(a1, p[prefix + "conv_1.weight"], p[prefix + "conv_1.bias"], 1, 1)
+    return x + d1, (c0, a0, c1, a1)
+
+
+def sft_resblk_bwd(p, prefix, cache, dout):
+    c0, a0, c1, a1 = cache
+    g = {}
+    da1, g[prefix + "conv_1.weight"], g[prefix + "conv_1.bias"] = conv2d_bwd(a1, p[prefix + "conv_1.weight"], dout, 1, 1)
+    dd0, dq1, g1 = sft_module_bwd(p, prefix + "norm_1.", c1, da1)
+    da0, g[prefix + "conv_0.weight"], g[prefix + "conv_0.bias"] = conv2d_bwd(a0, p[prefix + "conv_0.weight"], dd0, 1, 1)
+    dx, dq0, g0 = sft_module_bwd(p, prefix + "norm_0.", c0, da0)
+    g.update(g0)
+    g.update(g1)
+    return dout + dx, dq0 + dq1, g
+
+
 def gdn_fwd(x, beta_p, gamma_p, inverse=False, beta_min=1e-6):
     x, beta_p, gamma_p = _f(x), _f(beta_p), _f(gamma_p)
     N, Cc, H, W = x.shape

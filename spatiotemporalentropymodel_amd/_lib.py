@@ -44,6 +44,9 @@ _HIP_SIG = {
     "stem_sft_fwd": [vp, vp, vp, vp, sz, cf, vp],
     "stem_sft_bwd": [vp, vp, vp, vp, vp, vp, vp, sz, cf, vp],
     "stem_avgpool_fwd": [vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_avgpool_bwd": [vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_weighted_sqerr_sum": [vp, vp, vp, ci, ci, sz, vp, vp],
+    "stem_weighted_sqerr_bwd": [vp, vp, vp, vp, ci, ci, sz, vp, cf, vp],
     "stem_nchw_to_nhwc": [vp, vp, ci, ci, ci, ci, ci, vp],
     "stem_nhwc_to_nchw": [vp, ci, vp, ci, ci, ci, ci, ci, vp],
     "stem_nchw3_to_nhwc4": [vp, vp, ci, ci, ci, vp],

@@ -65,6 +65,50 @@ __global__ void avgpool_kernel(const float *x, int ldx, float *y, int ldy, int B
     y[((size_t)(b * Ho + oy) * Wo + ox) * ldy + c] = s / (float)(fy * fx);
 }
 
+// dx[B,H,W,C] = dy[B,H/f,W/f,C] / (fy*fx) broadcast over each window
+__global__ void avgpool_bwd_kernel(const float *dy, int ldy, float *dx, int ldx, int B, int H, int W, int C, int fy, int fx)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * H * W * C;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    size_t p = i / C;
+    const int ix = (int)(p % W);
+    p /= W;
+    const int iy = (int)(p % H), b = (int)(p / H);
+    const int Ho = H / fy, Wo = W / fx;
+    dx[((size_t)(b * H + iy) * W + ix) * ldx + c] = dy[((size_t)(b * Ho + iy / fy) * Wo + ix / fx) * ldy + c] / (float)(fy * fx);
+}
+
+// sum over [B,C,H,W] of lambda[b,h,w] * (xhat - x)^2, NCHW images (root utils.py:69-71), fp64 accumulation
+__global__ __launch_bounds__(256) void wsqerr_sum_kernel(const float *xhat, const float *x, const float *lam, size_t n, int C, size_t HW,
+                                                         double *acc)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / (HW * C), p = i % HW;
+        const float d = xhat[i] - x[i];
+        s += (double)(lam[b * HW + p] * (d * d));
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(acc, red[0]);
+}
+// dxhat = g * coef * 2 lambda (xhat - x); g is the upstream scalar gradient, read from device memory
+__global__ void wsqerr_bwd_kernel(const float *xhat, const float *x, const float *lam, float *dxhat, size_t n, int C, size_t HW,
+                                  const double *g, float coef)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t b = i / (HW * C), p = i % HW;
+    dxhat[i] = (float)(*g) * coef * 2.f * lam[b * HW + p] * (xhat[i] - x[i]);
+}
+
 inline unsigned nb(size_t n) { return (unsigned)cdivz(n, 256); }
 inline bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -110,5 +154,39 @@ STEM_EXPORT int stem_avgpool_fwd(const float *x, int ldx, float *y, int ldy, int
     hipLaunchKernelGGL(avgpool_kernel, dim3(nb((size_t)B * Ho * Wo * C)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, B, Ho, Wo, C,
                        H / Ho, W / Wo);
     STEM_LAUNCH_CHECK("avgpool");
+    return 0;
+}
+
+STEM_EXPORT int stem_avgpool_bwd(const float *dy, int ldy, float *dx, int ldx, int B, int H, int W, int C, int Ho, int Wo, void *stream)
+{
+    STEM_CHECK_ARG(dy && dx && Ho > 0 && Wo > 0, "stem_avgpool_bwd: bad arguments");
+    STEM_CHECK_ARG(H % Ho == 0 && W % Wo == 0, "stem_avgpool_bwd: %dx%d is not an integer multiple of %dx%d", H, W, Ho, Wo);
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(nb((size_t)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, ldy, dx, ldx, B, H, W, C,
+                       H / Ho, W / Wo);
+    STEM_LAUNCH_CHECK("avgpool_bwd");
+    return 0;
+}
+
+STEM_EXPORT int stem_weighted_sqerr_sum(const float *xhat, const float *x, const float *lambda, int B, int C, size_t HW, double *acc,
+                                        void *stream)
+{
+    STEM_CHECK_ARG(xhat && x && lambda && acc, "stem_weighted_sqerr_sum: null pointer");
+    const size_t n = (size_t)B * C * HW;
+    if (n == 0) return 0;
+    unsigned blocks = nb(n);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(wsqerr_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, xhat, x, lambda, n, C, HW, acc);
+    STEM_LAUNCH_CHECK("weighted_sqerr_sum");
+    return 0;
+}
+
+STEM_EXPORT int stem_weighted_sqerr_bwd(const float *xhat, const float *x, const float *lambda, float *dxhat, int B, int C, size_t HW,
+                                        const double *g, float coef, void *stream)
+{
+    STEM_CHECK_ARG(xhat && x && lambda && dxhat && g, "stem_weighted_sqerr_bwd: null pointer");
+    const size_t n = (size_t)B * C * HW;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(wsqerr_bwd_kernel, dim3(nb(n)), dim3(256), 0, (hipStream_t)stream, xhat, x, lambda, dxhat, n, C, HW, g, coef);
+    STEM_LAUNCH_CHECK("weighted_sqerr_bwd");
     return 0;
 }

@@ -113,6 +113,14 @@ def copy_channels(src: torch.Tensor, dst: torch.Tensor):
     return dst
 
 
+def dense_nhwc(t: torch.Tensor) -> torch.Tensor:
+    """NHWC tensor whose pixel pitch equals its channel count (copies channel-slice views)."""
+    t = to_nhwc(t)
+    if nhwc_ld(t) != t.shape[1]:
+        t = copy_channels(t, empty_nhwc(*t.shape, t.device))
+    return t
+
+
 def nchw3_to_nhwc4(x: torch.Tensor) -> torch.Tensor:
     _require_cuda(x)
     x = x.contiguous()
@@ -376,6 +384,33 @@ def avgpool(x, Ho, Wo):
         return x
     out = empty_nhwc(B, Cc, Ho, Wo, x.device)
     _chk(_lib.hip().stem_avgpool_fwd(x.data_ptr(), nhwc_ld(x), out.data_ptr(), Cc, B, H, W, Cc, Ho, Wo, _stream()))
+    return out
+
+
+def avgpool_bwd(dy, H, W):
+    B, Cc, Ho, Wo = dy.shape
+    if (H, W) == (Ho, Wo):
+        return dy
+    dx = empty_nhwc(B, Cc, H, W, dy.device)
+    _chk(_lib.hip().stem_avgpool_bwd(dy.data_ptr(), nhwc_ld(dy), dx.data_ptr(), Cc, B, H, W, Cc, Ho, Wo, _stream()))
+    return dx
+
+
+def weighted_sqerr_sum(xhat, x, lam):
+    """sum(lam * (xhat - x)^2) over contiguous NCHW images, lam [B,1,H,W] -> fp64 0-dim tensor."""
+    B, Cc, H, W = xhat.shape
+    assert xhat.is_contiguous() and x.is_contiguous() and lam.is_contiguous() and lam.shape == (B, 1, H, W) and x.shape == xhat.shape
+    acc = torch.zeros(1, dtype=torch.float64, device=xhat.device)
+    _chk(_lib.hip().stem_weighted_sqerr_sum(xhat.data_ptr(), x.data_ptr(), lam.data_ptr(), B, Cc, H * W, acc.data_ptr(), _stream()))
+    return acc.reshape(())
+
+
+def weighted_sqerr_bwd(xhat, x, lam, g, coef):
+    B, Cc, H, W = xhat.shape
+    g = g.to(torch.float64).contiguous()
+    out = torch.empty_like(xhat)
+    _chk(_lib.hip().stem_weighted_sqerr_bwd(xhat.data_ptr(), x.data_ptr(), lam.data_ptr(), out.data_ptr(), B, Cc, H * W, g.data_ptr(),
+                                            float(coef), _stream()))
     return out
 
 

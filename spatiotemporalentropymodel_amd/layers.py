@@ -47,9 +47,10 @@ class Conv2dFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, act, masked, cache, slope=F.LRELU_SLOPE):
         K, Cc, R, S = weight.shape
-        first = Cc == 3 and F.nhwc_ld(x) is None       # image input, NCHW: fused layout change (g_a.0)
+        # <=4 input channels: the image (NCHW, fused layout change: g_a.0) or image+quality map (stem_roi.py:529)
+        first = (Cc == 3 and F.nhwc_ld(x) is None) or (Cc == 4 and R * S <= 32)
         if first:
-            xin = F.nchw3_to_nhwc4(x)
+            xin = F.nchw3_to_nhwc4(x) if Cc == 3 else F.dense_nhwc(x).permute(0, 2, 3, 1)
             y = F.conv2d_fwd_c4(xin, cache.get(weight, F.PACK_CONV_FWD_C4), bias, K, R, S, stride, pad)
             xin = xin.permute(0, 3, 1, 2)               # [B,4,H,W] NHWC view for the weight gradient
         else:
@@ -72,12 +73,12 @@ class Conv2dFunction(torch.autograd.Function):
         if act:
             dy = F.lrelu_bwd(y, dy, slope)
         dx = None
-        if ctx.needs_input_grad[0] and not first:
+        if ctx.needs_input_grad[0]:
             dx = F.conv2d_dgrad(dy, cache.get(weight, F.PACK_CONV_DGRAD, 1 if masked else 0), xshape, K, R, S, stride, pad)
         dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw, db = F.conv2d_wgrad(xin, dy, K, R, S, stride, pad, need_db=ctx.needs_input_grad[2])
-            if first:
+            if first and Cc == 3:
                 dw = dw[:, :3].contiguous()
         return dx, dw, db, None, None, None, None, None, None
 
@@ -128,6 +129,99 @@ class GDNFunction(torch.autograd.Function):
             raise NotImplementedError("GDN backward needs channel counts that are multiples of 4")
         dx, dbeta, dgamma = F.gdn_bwd(xin, dy, beta.detach().contiguous(), gamma.detach().contiguous(), inverse, beta_min)
         return dx, dbeta, dgamma, None, None
+
+
+class SFTFunction(torch.autograd.Function):
+    """act(x * (1 + gamma) + beta), act = leaky-ReLU(slope) or identity (slope 1): stem_utils.py:41,56-57."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope):
+        x, gamma, beta = (F.dense_nhwc(t) for t in (x, gamma, beta))
+        out = F.sft_fwd(x, gamma, beta, slope)
+        ctx.slope = slope
+        ctx.save_for_backward(x, gamma, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gamma, out = ctx.saved_tensors
+        dx, dg, db = F.sft_bwd(x, gamma, out, F.dense_nhwc(dout), ctx.slope)
+        return dx, dg, db, None
+
+
+class AvgPoolFunction(torch.autograd.Function):
+    """F.adaptive_avg_pool2d(x, (Ho, Wo)) for integer ratios (stem_utils.py:37, stem_roi.py:563)."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        ctx.hw = tuple(x.shape[2:])
+        return F.avgpool(F.to_nhwc(x), Ho, Wo)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return F.avgpool_bwd(F.to_nhwc(dy), *ctx.hw), None, None
+
+
+class CatFunction(torch.autograd.Function):
+    """torch.cat(xs, dim=1) into one NHWC buffer; the gradient hands back channel-slice views."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        B, _, H, W = xs[0].shape
+        ctx.widths = [int(t.shape[1]) for t in xs]
+        buf = F.empty_nhwc(B, sum(ctx.widths), H, W, xs[0].device)
+        c = 0
+        for t, n in zip(xs, ctx.widths):
+            F.copy_channels(F.to_nhwc(t), buf[:, c:c + n])
+            c += n
+        return buf
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = F.to_nhwc(dy)
+        outs, c = [], 0
+        for n in ctx.widths:
+            outs.append(dy[:, c:c + n])
+            c += n
+        return tuple(outs)
+
+
+class AddFunction(torch.autograd.Function):
+    """Residual sum x + dx (stem_utils.py:58) on dense NHWC tensors."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return F.add(F.dense_nhwc(a), F.dense_nhwc(b))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class ToNCHWFunction(torch.autograd.Function):
+    """NHWC feature map -> contiguous NCHW tensor (the image handed back to the caller)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return F.to_nchw(F.to_nhwc(x))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return F.to_nhwc(dy)
+
+
+def cat(xs):
+    return CatFunction.apply(*xs)
+
+
+def to_nchw(x):
+    return ToNCHWFunction.apply(x)
+
+
+def adaptive_avg_pool2d(x, size):
+    if tuple(x.shape[2:]) == tuple(size):
+        return x
+    return AvgPoolFunction.apply(x, int(size[0]), int(size[1]))
 
 
 # ----------------------------------------------------------------------------- modules

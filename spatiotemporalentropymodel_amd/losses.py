@@ -66,6 +66,34 @@ class RateDistortionLoss(nn.Module):
         return out
 
 
+class _WeightedMSEFunction(torch.autograd.Function):
+    """mean(lambda * (x_hat - x)^2) over [B,C,H,W] as one fp64-accumulating kernel; backward in one pass."""
+
+    @staticmethod
+    def forward(ctx, x_hat, target, lmbdamap):
+        x_hat, target, lmbdamap = x_hat.contiguous(), target.contiguous(), lmbdamap.contiguous()
+        ctx.save_for_backward(x_hat, target, lmbdamap)
+        return F.weighted_sqerr_sum(x_hat, target, lmbdamap) / x_hat.numel()
+
+    @staticmethod
+    def backward(ctx, g):
+        x_hat, target, lmbdamap = ctx.saved_tensors
+        return F.weighted_sqerr_bwd(x_hat, target, lmbdamap, g, 1.0 / x_hat.numel()), None, None
+
+
+class PixelwiseRateDistortionLoss(nn.Module):
+    """Rate + spatially weighted distortion of the variable-rate models (utils.py:53-74): lmbdamap is [B,1,H,W]."""
+
+    def forward(self, output, target, lmbdamap):
+        N, _, H, W = target.size()
+        num_pixels = N * H * W
+        out = {}
+        out["bpp_loss"] = sum(log2_sum(l) / (-num_pixels) for l in output["likelihoods"].values())
+        out["mse_loss"] = _WeightedMSEFunction.apply(output["x_hat"], target, lmbdamap)
+        out["loss"] = 255 ** 2 * out["mse_loss"] + out["bpp_loss"]
+        return out
+
+
 def quality2lambda(qmap):
     """utils.py:97-101"""
     return 0.002 * torch.exp(3.4409 * qmap)

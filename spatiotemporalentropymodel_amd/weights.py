@@ -85,6 +85,18 @@ def closed_form_fill_(module: torch.nn.Module) -> torch.nn.Module:
     return module
 
 
+@torch.no_grad()
+def closed_form_fill_scaled_(module: torch.nn.Module, prefix: str, conv_scale: float) -> torch.nn.Module:
+    """closed_form_fill_ keyed by '<prefix>.<name>', with every 4-D (convolution) weight multiplied by `conv_scale`.
+    The variable-rate models stack ~60 convolutions with multiplicative SFT stages: the variance-preserving scale of
+    closed_form_tensor overflows there, 0.7 keeps latents in +-2 and reconstructions in +-2 (tests/golden/make_golden.py)."""
+    for name, p in module.named_parameters():
+        t = closed_form_tensor(f"{prefix}.{name}", p.shape, p)
+        if t is not None:
+            p.copy_(t * conv_scale if t.dim() == 4 else t)
+    return module
+
+
 def closed_form_input(name: str, shape, lo: float = 0.0, hi: float = 1.0) -> torch.Tensor:
     """Deterministic input/noise tensor in [lo, hi)."""
     n = int(np.prod(shape))

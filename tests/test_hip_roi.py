@@ -1,0 +1,221 @@
+"""GPU parity tests for the variable-rate (ROI) pixel-domain models -- SURVEY.md §8(f)-1, BASELINE.json configs[4]:
+stem_roi_i / stem_roi on the HIP path vs golden vectors captured from the reference's own classes, loss and
+quality2lambda (tests/golden/make_golden.py:gen_stem_roi), same closed-form weights, inputs and injected noise."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, assert_close
+
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+import stem_oracle as orc  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+ROI_CONV_SCALE = 0.7
+
+
+def host(t):
+    return t.detach().cpu().contiguous().numpy()
+
+
+@pytest.fixture(scope="module")
+def F():
+    from spatiotemporalentropymodel_amd import functional
+    assert torch.cuda.is_available()
+    return functional
+
+
+def cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+# ----------------------------------------------------------------------------- ops
+@pytest.mark.parametrize("slope", [1.0, 0.2, 0.01, 0.0])
+def test_sft_forward_backward_vs_oracle(F, slope):
+    torch.manual_seed(3)
+    x, g, b, do = (cl(torch.randn(2, 64, 9, 7)) for _ in range(4))
+    out = F.sft_fwd(cl(x.cuda()), cl(g.cuda()), cl(b.cuda()), slope)
+    ref = orc.sft_fwd(x.numpy(), g.numpy(), b.numpy(), slope)
+    assert_close(host(out), ref, 1e-6, what="sft forward")
+    dx, dg, db = F.sft_bwd(cl(x.cuda()), cl(g.cuda()), out, cl(do.cuda()), slope)
+    rx, rg, rb = orc.sft_bwd(x.numpy(), g.numpy(), ref, do.numpy(), slope)
+    assert_close(host(dx), rx, 1e-6, what="sft dx")
+    assert_close(host(dg), rg, 1e-6, what="sft dgamma")
+    assert_close(host(db), rb, 1e-6, what="sft dbeta")
+
+
+@pytest.mark.parametrize("shape,out", [((2, 5, 16, 32), (1, 2)), ((1, 128, 8, 8), (4, 4)), ((2, 1, 64, 64), (4, 4))])
+def test_avgpool_forward_backward_vs_oracle(F, shape, out):
+    torch.manual_seed(4)
+    x = torch.randn(*shape)
+    y = F.avgpool(cl(x.cuda()), *out)
+    assert_close(host(y), orc.avgpool_fwd(x.numpy(), *out), 1e-6, what="avgpool")
+    dy = torch.randn(shape[0], shape[1], *out)
+    dx = F.avgpool_bwd(cl(dy.cuda()), shape[2], shape[3])
+    assert_close(host(dx), orc.avgpool_bwd(dy.numpy(), shape[2], shape[3]), 1e-6, what="avgpool backward")
+    with pytest.raises(RuntimeError):
+        F.avgpool(cl(x.cuda()), 3, 3)
+
+
+@pytest.mark.parametrize("cfg", [
+    # Cin, Cout, k, stride, deconv, H      (layer shapes only the ROI models use)
+    (4, 192, 3, 1, False, 16),            # qmap_feature_ga1.0: image + quality map
+    (385, 128, 3, 1, False, 8),           # qmap_feature_ha1.0: odd channel count
+    (128, 128, 3, 2, False, 16),          # qmap_feature_ga2.0
+    (192, 128, 3, 2, True, 8),            # qmap_feature_gs1.0: 3x3 stride-2 transposed
+    (128, 192, 1, 1, False, 8),           # qmap_feature_ga4.2
+    (3, 128, 5, 2, False, 32),            # ConditionEncoder.0 with a gradient w.r.t. the image
+])
+def test_roi_layer_shapes_vs_oracle(cfg):
+    from spatiotemporalentropymodel_amd.layers import conv, deconv
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_
+    cin, cout, k, st, up, H = cfg
+    m = closed_form_fill_((deconv if up else conv)(cin, cout, k, st)).cuda()
+    torch.manual_seed(5)
+    x = torch.randn(2, cin, H, H)
+    xg = x.cuda().requires_grad_(True)
+    y = m(xg)
+    w, b = host(m.weight), host(m.bias)
+    pad = k // 2
+    if up:
+        ref = orc.deconv2d_fwd(x.numpy(), w, b, st, pad, st - 1)
+    else:
+        ref = orc.conv2d_fwd(x.numpy(), w, b, st, pad)
+    assert_close(host(y), ref, what=f"forward {cfg}")
+    dy = torch.randn(*ref.shape)
+    y.backward(cl(dy.cuda()))
+    if up:
+        rdx, rdw, rdb = orc.deconv2d_bwd(x.numpy(), w, dy.numpy(), st, pad, st - 1)
+    else:
+        rdx, rdw, rdb = orc.conv2d_bwd(x.numpy(), w, dy.numpy(), st, pad)
+    assert_close(host(xg.grad), rdx, what=f"dgrad {cfg}")
+    assert_close(host(m.weight.grad), rdw, what=f"wgrad {cfg}")
+    assert_close(host(m.bias.grad), rdb, what=f"bias grad {cfg}")
+
+
+# ----------------------------------------------------------------------------- models
+def _build(dev):
+    from spatiotemporalentropymodel_amd.models import stem_roi, stem_roi_i
+    from spatiotemporalentropymodel_amd.selfcheck import NoiseFeed
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_scaled_
+    ms = []
+    for tag, cls in (("roi_i", stem_roi_i), ("roi_p", stem_roi)):
+        m = closed_form_fill_scaled_(cls(), tag, ROI_CONV_SCALE).to(dev).train()
+        m.entropy_bottleneck.noise_source = NoiseFeed(tag + "_eb")
+        m.gaussian_conditional.noise_source = NoiseFeed(tag + "_gc")
+        ms.append(m)
+    return ms
+
+
+def _check_grads(g, tag, module, rtol=1e-4):
+    """Raw (unclipped) gradients of every parameter: checksums and 64-element strided slices at 1e-4 of the
+    tensor's own scale (north_star tolerance)."""
+    seen = 0
+    for n, p in module.named_parameters():
+        key = f"{tag}:gsum:{n}"
+        if key not in g:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, f"{n}: gradient where the reference has none"
+            continue
+        assert p.grad is not None, f"{n}: no gradient"
+        gd = p.grad.double()
+        s = np.array([float(gd.sum()), float(gd.abs().sum()), float((gd * gd).sum())])
+        ref = g[key]
+        assert abs(s[1] - ref[1]) <= rtol * ref[1] + 1e-12, (n, s, ref)
+        assert abs(s[2] - ref[2]) <= 2 * rtol * ref[2] + 1e-20, (n, s, ref)
+        assert abs(s[0] - ref[0]) <= rtol * ref[1] + 1e-12, (n, s, ref)
+        sl = host(p.grad.reshape(-1)[:: max(1, p.numel() // 64)][:64])
+        assert_close(sl, g[f"{tag}:gslice:{n}"], rtol, what=f"{tag} grad slice {n}")
+        seen += 1
+    return seen
+
+
+def test_roi_iframe_pframe_training_pass_matches_reference(golden):
+    """stem_roi/train_stem_roi.py:515-566: I(x0, Q) -> loss.backward(retain_graph) -> P(x1, x_hat_I, Q) -> loss.backward."""
+    from spatiotemporalentropymodel_amd.losses import PixelwiseRateDistortionLoss, quality2lambda
+    from spatiotemporalentropymodel_amd.weights import smooth_frames
+    g = golden("stem_roi.npz")
+    dev = torch.device("cuda:0")
+    imodel, pmodel = _build(dev)
+    B, size = (int(v) for v in g["cfg"])
+    frames = [f.to(dev) for f in smooth_frames("roi", B, 2, size)]
+    qmap = torch.from_numpy(g["qmap"]).to(dev)
+    lmbdamap = quality2lambda(qmap)
+    assert_close(host(lmbdamap), g["lmbdamap"], 1e-6, what="quality2lambda")
+    criterion = PixelwiseRateDistortionLoss()
+
+    out_i = imodel(frames[0], qmap)
+    assert out_i["x_hat"].is_contiguous() and tuple(out_i["x_hat"].shape) == (B, 3, size, size)
+    assert_close(host(out_i["y_hat"]), g["i:y_hat"], what="I y_hat")
+    assert_close(host(out_i["likelihoods"]["z"]), g["i:lik_z"], atol=1e-9, what="I lik_z")
+    assert_close(host(out_i["likelihoods"]["y"]), g["i:lik_y"], 2e-4, atol=1e-9, what="I lik_y")
+    assert_close(host(out_i["x_hat"]), g["i:x_hat"], what="I x_hat")
+    oc_i = criterion(out_i, frames[0], lmbdamap)
+    for k, ref in zip(("loss", "mse_loss", "bpp_loss"), g["i:scalars"]):
+        assert abs(float(oc_i[k].detach()) - ref) <= 1e-4 * abs(ref), (k, float(oc_i[k].detach()), ref)
+    oc_i["loss"].backward(retain_graph=True)
+    assert _check_grads(g, "i", imodel) > 250
+
+    caught = []
+    out_i["x_hat"].register_hook(lambda t: caught.append(t.detach().clone()))
+    out_p = pmodel(frames[1], out_i["x_hat"], qmap)
+    assert_close(host(out_p["y_hat"]), g["p:y_hat"], what="P y_hat")
+    assert_close(host(out_p["likelihoods"]["z"]), g["p:lik_z"], atol=1e-9, what="P lik_z")
+    assert_close(host(out_p["likelihoods"]["y"]), g["p:lik_y"], 2e-4, atol=1e-9, what="P lik_y")
+    assert_close(host(out_p["x_hat"]), g["p:x_hat"], what="P x_hat")
+    oc_p = criterion(out_p, frames[1], lmbdamap)
+    for k, ref in zip(("loss", "mse_loss", "bpp_loss"), g["p:scalars"]):
+        assert abs(float(oc_p[k].detach()) - ref) <= 1e-4 * abs(ref), (k, float(oc_p[k].detach()), ref)
+    oc_p["loss"].backward()
+    assert _check_grads(g, "p", pmodel) > 250
+    assert_close(host(caught[0]), g["p:dx_conditioned"], what="dL_p/dx_conditioned")
+    _check_grads(g, "ip", imodel)                 # accumulated through x_conditioned into the I-frame model
+    aux = [float(imodel.aux_loss()), float(pmodel.aux_loss())]
+    assert_close(np.array(aux), g["aux"], what="aux losses")
+
+
+def test_roi_codec_roundtrip_and_rate(golden):
+    """eval_stem_roi.py: compress / decompress of the I and the P model.  Bitstreams depend on rounding decisions of
+    network outputs (fp32 noise can flip a symbol sitting at .5), so sizes are held to 1% of the reference's and the
+    decoder is checked to reproduce the encoder-side reconstruction exactly."""
+    g = golden("stem_roi.npz")
+    dev = torch.device("cuda:0")
+    imodel, pmodel = _build(dev)
+    from spatiotemporalentropymodel_amd.weights import smooth_frames
+    B, size = (int(v) for v in g["cfg"])
+    frames = [f.to(dev) for f in smooth_frames("roi", B, 2, size)]
+    qmap = torch.from_numpy(g["qmap"]).to(dev)
+    for tag, m in (("roi_i", imodel), ("roi_p", pmodel)):
+        m.eval()
+        m.update(force=True)
+        for k in ("_quantized_cdf", "_offset", "_cdf_length"):       # tables as the reference built them (libm-exact)
+            getattr(m.entropy_bottleneck, k).copy_(torch.from_numpy(g[f"{tag}:entropy_bottleneck.{k}"]))
+            ref = g[f"{tag}:gaussian_conditional.{k}"]
+            np.testing.assert_array_equal(host(getattr(m.gaussian_conditional, k)), ref)
+    with torch.no_grad():
+        enc_i = imodel.compress(frames[0], qmap)
+        dec_i = imodel.decompress(enc_i["strings"], enc_i["shape"])
+        assert tuple(enc_i["shape"]) == (size // 64, size // 64)
+        nb = np.array([[len(s) for s in enc_i["strings"][0]], [len(s) for s in enc_i["strings"][1]]])
+        assert np.all(np.abs(nb - g["ci:nbytes"]) <= np.maximum(0.01 * g["ci:nbytes"], 4)), (nb, g["ci:nbytes"])
+        mism = float((np.abs(host(dec_i["y_hat"]) - g["ci:y_hat"]) > 1e-3).mean())      # y_hat = symbol + mean (a float)
+        assert mism < 2e-3, f"{mism:.2e} of the I latents differ from the reference decode"
+        assert float((dec_i["x_hat"] - torch.from_numpy(g["ci:x_hat"]).to(dev)).abs().mean()) < 2e-3
+        assert float(dec_i["x_hat"].min()) >= 0 and float(dec_i["x_hat"].max()) <= 1
+        # P frame on the reference's decoded I frame
+        x_cond = torch.from_numpy(g["ci:x_hat"]).to(dev)
+        enc_p = pmodel.compress(frames[1], x_cond, qmap)
+        dec_p = pmodel.decompress(enc_p["strings"], enc_p["shape"], x_cond)
+        nb = np.array([[len(s) for s in enc_p["strings"][0]], [len(s) for s in enc_p["strings"][1]]])
+        assert np.all(np.abs(nb - g["cp:nbytes"]) <= np.maximum(0.01 * g["cp:nbytes"], 4)), (nb, g["cp:nbytes"])
+        mism = float((np.abs(host(dec_p["y_hat"]) - g["cp:y_hat"]) > 1e-3).mean())
+        assert mism < 2e-3, f"{mism:.2e} of the P latents differ from the reference decode"
+        assert float((dec_p["x_hat"] - torch.from_numpy(g["cp:x_hat"]).to(dev)).abs().mean()) < 2e-3
+        # decoder == encoder-side eval forward (dequantize mode) on the same inputs
+        ev = pmodel(frames[1], x_cond, qmap)
+        np.testing.assert_array_equal(host(ev["y_hat"]), host(dec_p["y_hat"]))
+        assert_close(host(ev["likelihoods"]["y"]), g["evp:lik_y"], 2e-3, atol=1e-6, what="eval lik_y")
+        with pytest.raises(TypeError):
+            pmodel.decompress(enc_p["strings"], enc_p["shape"])

@@ -324,3 +324,29 @@ def test_stem_train_step1_gradients(golden, tag):
     target = np.array([-np.log(2 / 1e-9 - 1), 0, np.log(2 / 1e-9 - 1)], np.float32)
     # aux loss is evaluated after optimizer.step in the reference -> only its dquantiles structure is checked here
     assert g["s1:dquantiles"].shape == (ebc, 1, 3)
+
+
+# ----------------------------------------------------------------------------- variable-rate (ROI) building blocks
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_adaptive_avgpool(golden, i):
+    g = golden("roi_ops.npz")
+    x, y, dy = g[f"pool{i}:x"], g[f"pool{i}:y"], g[f"pool{i}:dy"]
+    assert_close(orc.avgpool_fwd(x, y.shape[2], y.shape[3]), y, 1e-6, what="adaptive_avg_pool2d")
+    assert_close(orc.avgpool_bwd(dy, x.shape[2], x.shape[3]), g[f"pool{i}:dx"], 1e-6, what="adaptive_avg_pool2d backward")
+
+
+@pytest.mark.parametrize("tag", ["sft", "resblk"])
+def test_sft_modules(golden, tag):
+    """SFT / SFTResblk of the reference (stem_utils.py:24-63) vs the oracle's composition of its own ops, incl. every gradient."""
+    g = golden("roi_ops.npz")
+    p = {k[len(tag) + 3:]: v for k, v in g.items() if k.startswith(tag + ":p:")}
+    x, q, dout = g[f"{tag}:x"], g[f"{tag}:q"], g[f"{tag}:dout"]
+    fwd, bwd = (orc.sft_module_fwd, orc.sft_module_bwd) if tag == "sft" else (orc.sft_resblk_fwd, orc.sft_resblk_bwd)
+    out, cache = fwd(p, "", x, q)
+    assert_close(out, g[f"{tag}:out"], what=f"{tag} forward")
+    dx, dq, grads = bwd(p, "", cache, dout)
+    assert_close(dx, g[f"{tag}:dx"], what=f"{tag} dx")
+    assert_close(dq, g[f"{tag}:dq"], what=f"{tag} dqmap")
+    assert len(grads) == len(p)
+    for k, v in grads.items():
+        assert_close(v, g[f"{tag}:g:{k}"], what=f"{tag} grad {k}")
