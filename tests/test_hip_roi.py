@@ -127,7 +127,8 @@ def _check_grads(g, tag, module, rtol=1e-4):
         assert abs(s[2] - ref[2]) <= 2 * rtol * ref[2] + 1e-20, (n, s, ref)
         assert abs(s[0] - ref[0]) <= rtol * ref[1] + 1e-12, (n, s, ref)
         sl = host(p.grad.reshape(-1)[:: max(1, p.numel() // 64)][:64])
-        assert_close(sl, g[f"{tag}:gslice:{n}"], rtol, what=f"{tag} grad slice {n}")
+        rms = float(np.sqrt(ref[2] / p.numel()))              # whole-tensor RMS: the slice's own max underestimates the scale
+        assert_close(sl, g[f"{tag}:gslice:{n}"], rtol, atol=rtol * rms, what=f"{tag} grad slice {n}")
         seen += 1
     return seen
 
