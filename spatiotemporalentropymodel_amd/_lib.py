@@ -73,6 +73,7 @@ _HIP_SIG = {
     "stem_gemv3_wave": [vp, ci, vp, vp, vp, ci, ci, ci, cf, ci, ci, ci, vp],
     "stem_ar_finish_encode_wave": [vp, vp, ci, cf, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "stem_sumsq": [vp, sz, vp, vp],
+    "stem_clip_scale": [vp, sz, vp, cf, vp],
     "stem_adam_step": [vp, vp, vp, vp, sz, vp, cf, cf, cf, cf, cf, cf, ci, vp],
     "stem_packed_weight_elems": [ci, ci, ci, ci, ci],
     "stem_abi_version": [],

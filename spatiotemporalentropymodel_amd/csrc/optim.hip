@@ -46,6 +46,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, flo
     }
 }
 
+// torch.nn.utils.clip_grad_norm_ on its own: g *= min(1, max_norm / (sqrt(sumsq) + 1e-6)), coefficient computed on the device
+__global__ __launch_bounds__(256) void clip_scale_kernel(float *g, size_t n, const double *sumsq, float max_norm)
+{
+    const float coef = fminf(max_norm / ((float)sqrt(sumsq[0]) + 1e-6f), 1.0f);
+    if (coef >= 1.0f) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) g[i] *= coef;
+}
+
 }   // namespace
 
 STEM_EXPORT int stem_sumsq(const float *g, size_t n, double *acc, void *stream)
@@ -73,5 +81,16 @@ STEM_EXPORT int stem_adam_step(float *p, const float *g, float *m, float *v, siz
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm,
                        gscale, (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps);
     STEM_LAUNCH_CHECK("adam");
+    return 0;
+}
+
+STEM_EXPORT int stem_clip_scale(float *g, size_t n, const double *sumsq, float max_norm, void *stream)
+{
+    STEM_CHECK_ARG(g && sumsq && max_norm > 0.f, "stem_clip_scale: bad arguments");
+    if (n == 0) return 0;
+    size_t nb = cdivz(n, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(clip_scale_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g, n, sumsq, max_norm);
+    STEM_LAUNCH_CHECK("clip_scale");
     return 0;
 }

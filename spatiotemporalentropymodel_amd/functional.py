@@ -544,6 +544,10 @@ def sumsq(g, acc):
     _chk(_lib.hip().stem_sumsq(g.data_ptr(), g.numel(), acc.data_ptr(), _stream()))
 
 
+def clip_scale(g, sumsq_acc, max_norm):
+    _chk(_lib.hip().stem_clip_scale(g.data_ptr(), g.numel(), sumsq_acc.data_ptr(), float(max_norm), _stream()))
+
+
 def adam_step(p, g, m, v, sumsq_acc, max_norm, gscale, lr, beta1, beta2, eps, step):
     _chk(_lib.hip().stem_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), _ptr(sumsq_acc),
                                    max_norm, gscale, lr, beta1, beta2, eps, step, _stream()))

@@ -86,6 +86,21 @@ class FusedClipAdam:
         self.param_groups[0]["lr"] = self.lr
 
 
+def clip_grad_norm_(optimizers, max_norm):
+    """torch.nn.utils.clip_grad_norm_ over the union of the optimisers' flat gradient buffers, without a host sync:
+    one reduction per buffer into a shared fp64 accumulator, then one scaling pass per buffer.  Returns the norm
+    before clipping as a 0-dim device tensor.  (The variable-rate training loop clips after every frame while the
+    gradients of a GOP keep accumulating: stem_roi/train_stem_roi.py:536,563.)"""
+    optimizers = [o for o in optimizers if o is not None]
+    acc = optimizers[0]._sumsq
+    acc.zero_()
+    for o in optimizers:
+        F.sumsq(o.flat.grad, acc)
+    for o in optimizers:
+        F.clip_scale(o.flat.grad, acc, max_norm)
+    return acc.sqrt().reshape(())
+
+
 def configure_optimizers(net, args, fused=True, max_norm=1.0):
     """utils.py:104-135: main Adam over everything but `.quantiles`, aux Adam over `.quantiles`.
     fused=True returns FusedClipAdam objects (clip folded into the main step); fused=False returns the

@@ -63,6 +63,49 @@ def p_frame_step(imodel, stem, criterion, optimizer, aux_optimizer, x, y_cond, g
     return out, oc, aux, gn
 
 
+def roi_gop_step(imodel, pmodel, criterion, optimizers, frames, qmap, clip_max_norm=1.0, max_loss=None, grad_scale=1.0,
+                 reducer=None):
+    """One GOP iteration of the variable-rate training loop, stem_roi/train_stem_roi.py:509-631:
+
+        zero all four gradients; lmbdamap = quality2lambda(Qmap)
+        frame 0:  I(x0, Q)          -> loss.backward(retain_graph) -> clip(I grads)  -> I.aux_loss().backward()
+        frame t:  P(xt, x_hat, Q)   -> loss.backward(retain_graph) -> clip(P grads)  -> P.aux_loss().backward()
+        step optimizer_i, aux_optimizer_i, optimizer_p, aux_optimizer_p            (once, no further clipping)
+
+    x_hat is NOT detached between frames, so a P frame's loss back-propagates through every earlier frame into both
+    models; each model's running gradient (its `.quantiles` included, as clip_grad_norm_(model.parameters()) does) is
+    clipped right after its own frame's backward.  `optimizers` = (opt_i, aux_i, opt_p, aux_p) from configure_optimizers
+    (max_norm=None).  `max_loss` reproduces the script's "skip invalid loss" break (NaN/Inf/loss > max_loss; costs a host
+    sync per frame; upstream compares the I frame against the previous GOP's P loss, here each frame checks its own).
+    Returns the per-frame criterion dictionaries, clip norms and aux losses."""
+    from .losses import quality2lambda
+    from .optim import clip_grad_norm_
+    opt_i, aux_i, opt_p, aux_p = optimizers
+    for o in optimizers:
+        o.zero_grad()
+    lmbdamap = quality2lambda(qmap)
+    log, x_cond = [], None
+    for idx, x in enumerate(frames):
+        model, opts = (imodel, (opt_i, aux_i)) if idx == 0 else (pmodel, (opt_p, aux_p))
+        out = model(x, qmap) if idx == 0 else model(x, x_cond, qmap)
+        x_cond = out["x_hat"]
+        oc = criterion(out, x, lmbdamap)
+        if max_loss is not None:
+            lv = float(oc["loss"].detach())
+            if not np.isfinite(lv) or lv > max_loss:
+                break
+        oc["loss"].backward(retain_graph=True)
+        gn = clip_grad_norm_(opts, clip_max_norm) if clip_max_norm and clip_max_norm > 0 else None
+        aux = model.aux_loss()
+        aux.backward()
+        log.append((oc, gn, aux))
+    if reducer is not None:
+        reducer.all_reduce()
+    for o in optimizers:
+        o.step(grad_scale)
+    return log
+
+
 def smoke_check(verbose=False):
     """One small training step on cuda:0 checked against (a) the golden vectors of the reference and
     (b) the CPU oracle evaluated on the very same inputs."""

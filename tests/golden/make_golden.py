@@ -517,12 +517,64 @@ def gen_stem_roi(ref, batch=1, size=128):
     save("stem_roi.npz", d)
 
 
+def gen_stem_roi_gop(ref, batch=1, size=64, nframes=3):
+    """One GOP iteration of stem_roi/train_stem_roi.py:509-631 with the reference's models, criterion, clip_grad_norm_ and
+    torch Adam optimisers: gradients accumulate over the frames (graph retained, x_conditioned NOT detached), the running
+    gradient is clipped after every frame, the four optimisers step once at the end."""
+    import types
+    from compressai.models.stem_roi import stem_roi, stem_roi_i
+
+    log, d = [], {}
+    imodel, pmodel = stem_roi_i().train(), stem_roi().train()
+    for tag, m in (("gop_i", imodel), ("gop_p", pmodel)):
+        closed_form_fill_scaled_(m, tag, ROI_CONV_SCALE)
+        m.entropy_bottleneck._get_noise_cached = NoiseFeed(tag + "_eb", log)
+        m.gaussian_conditional._get_noise_cached = NoiseFeed(tag + "_gc", log)
+    args = types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3, clip_max_norm=1.0)
+    opt_i, aux_i = ref.configure_optimizers(imodel, args)
+    opt_p, aux_p = ref.configure_optimizers(pmodel, args)
+    frames = smooth_frames("roigop", batch, nframes, size)
+    qmap = closed_form_input("roigop:qmap", (batch, 1, size, size), 0.0, 1.0)
+    criterion = ref.PixelwiseRateDistortionLoss()
+    for o in (opt_i, aux_i, opt_p, aux_p):
+        o.zero_grad()
+    lmbdamap = ref.quality2lambda(qmap)
+    scal = []
+    for idx in range(nframes):
+        if idx == 0:
+            out = imodel(frames[0], qmap)
+            model = imodel
+        else:
+            out = pmodel(frames[idx], x_cond, qmap)
+            model = pmodel
+        x_cond = out["x_hat"]
+        oc = criterion(out, frames[idx], lmbdamap)
+        oc["loss"].backward(retain_graph=True)
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip_max_norm)
+        aux = model.aux_loss()
+        aux.backward()
+        scal.append([float(oc["loss"]), float(oc["mse_loss"]), float(oc["bpp_loss"]), float(gn), float(aux)])
+    d["scalars"] = np.array(scal)
+    _grad_digest(d, "i", imodel)
+    _grad_digest(d, "p", pmodel)
+    for o in (opt_i, aux_i, opt_p, aux_p):
+        o.step()
+    for tag, m in (("i", imodel), ("p", pmodel)):
+        for n_, p in m.named_parameters():
+            pd_ = p.detach().double()
+            d[f"{tag}:psum:{n_}"] = np.array([float(pd_.sum()), float(pd_.abs().sum())])
+            d[f"{tag}:pslice:{n_}"] = t2n(p.reshape(-1)[:: max(1, p.numel() // 64)][:64])
+    d["qmap"] = t2n(qmap)
+    d["cfg"] = np.array([batch, size, nframes])
+    save("stem_roi_gop.npz", d)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     scratch, ref_utils = import_reference()
     try:
-        which = sys.argv[1:] or ["ops", "codec", "fwd", "train_small", "train_big", "stemcodec", "roi", "roiops"]
+        which = sys.argv[1:] or ["ops", "codec", "fwd", "train_small", "train_big", "stemcodec", "roi", "roiops", "roigop"]
         if "ops" in which:
             gen_ops(ref_utils)
         if "codec" in which:
@@ -539,5 +591,7 @@ if __name__ == "__main__":
             gen_stem_roi(ref_utils)
         if "roiops" in which:
             gen_roi_ops(ref_utils)
+        if "roigop" in which:
+            gen_stem_roi_gop(ref_utils)
     finally:
         shutil.rmtree(scratch, ignore_errors=True)
