@@ -47,8 +47,11 @@ enum {
 int stem_pack_weight(const float *w, float *wp, int K, int C, int R, int S, int role, int masked, void *stream);
 size_t stem_packed_weight_elems(int K, int C, int R, int S, int role);
 /* gradient in packed layout [splits][R*S][K][C] (from stem_conv2d_wgrad) -> reference layout,
- * summing the split-K slabs.  deconv != 0 writes the ConvTranspose2d layout [C,K,R,S].        */
-int stem_unpack_wgrad(const float *dwp, float *dw, int K, int C, int R, int S, int splits, int deconv, void *stream);
+ * summing the split-K slabs in a fixed order.  flags: STEM_UNPACK_DECONV writes the ConvTranspose2d layout
+ * [C,K,R,S]; STEM_UNPACK_ACCUMULATE adds to `dw` instead of overwriting it (what autograd's `.grad +=` does when
+ * gradients of several backward passes accumulate: stem_roi/train_stem_roi.py:533,560).        */
+enum { STEM_UNPACK_DECONV = 1, STEM_UNPACK_ACCUMULATE = 2 };
+int stem_unpack_wgrad(const float *dwp, float *dw, int K, int C, int R, int S, int splits, int flags, void *stream);
 
 /* Multi-tensor forms: every layer of a model in one launch (host arrays of descriptors, device pointers inside). */
 typedef struct {
@@ -97,6 +100,7 @@ int stem_conv2d_dgrad(const float *dy, int lddy, const float *wp, float *dx, int
  * stem_wgrad_workspace_elems() floats: the slabs plus scratch for the two-stage bias-gradient sum.  */
 #define STEM_WGRAD_SQUARE_G 2     /* flags: use x^2 instead of x (GDN gamma gradient) */
 #define STEM_WGRAD_TABLE_VALID 1   /* flags: `dwp` still holds the gather table of an earlier call with the same geometry */
+#define STEM_WGRAD_ACCUMULATE_DB 4 /* flags: db += column sums instead of db = (gradient accumulation over several backward passes) */
 int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
                       int B, int H, int W, int C, int K, int R, int S, int stride, int pad,
                       int splits, int flags, void *stream);

@@ -125,23 +125,33 @@ __global__ void pack_c4_kernel(const float *w, float *out, int K, int C, int T)
     out[i] = (t < T && c < C) ? w[((size_t)k * C + c) * T + t] : 0.f;
 }
 
-// dw[(a*Bd + b)*T + t] = sum_s dwp[s][t][a][b]
-__global__ __launch_bounds__(256) void unpack_kernel(const float *dwp, float *dw, int A, int Bd, int T, int splits)
+// dw[(a*Bd + b)*T + t] (+)= sum_s dwp[s][t][a][b]; one workgroup per (a, 32-wide range of b): A * Bd/32 workgroups
+constexpr int UNPACK_BT = 32;
+__global__ __launch_bounds__(256) void unpack_kernel(const float *dwp, float *dw, int A, int Bd, int T, int splits, int accumulate)
 {
-    extern __shared__ float tile[];   // [Bd][T+1]
-    const int a = blockIdx.x;
-    const int n = Bd * T;
+    extern __shared__ float tile[];   // [UNPACK_BT][T+1]
+    const int a = blockIdx.x, b0 = blockIdx.y * UNPACK_BT;
+    const int nb = Bd - b0 < UNPACK_BT ? Bd - b0 : UNPACK_BT;
+    const int n = nb * T;
     const size_t slab = (size_t)T * A * Bd;
     for (int i = threadIdx.x; i < n; i += 256) {
-        const int t = i / Bd, b = i - t * Bd;
-        float v = 0.f;
-        for (int s = 0; s < splits; ++s) v += dwp[s * slab + ((size_t)t * A + a) * Bd + b];
-        tile[b * (T + 1) + t] = v;
+        const int t = i / nb, b = i - t * nb;
+        const float *src = dwp + ((size_t)t * A + a) * Bd + b0 + b;
+        float v0 = 0.f, v1 = 0.f;
+        int s = 0;
+        for (; s + 1 < splits; s += 2) {
+            v0 += src[s * slab];
+            v1 += src[(s + 1) * slab];
+        }
+        if (s < splits) v0 += src[s * slab];
+        tile[b * (T + 1) + t] = v0 + v1;
     }
     __syncthreads();
+    float *dst = dw + ((size_t)a * Bd + b0) * T;
     for (int i = threadIdx.x; i < n; i += 256) {
         const int b = i / T, t = i - b * T;
-        dw[(size_t)a * n + i] = tile[b * (T + 1) + t];
+        const float v = tile[b * (T + 1) + t];
+        dst[i] = accumulate ? dst[i] + v : v;
     }
 }
 
@@ -317,18 +327,18 @@ STEM_EXPORT int stem_unpack_wgrads_multi(const stem_unpack_desc *descs, int n, v
     return 0;
 }
 
-STEM_EXPORT int stem_unpack_wgrad(const float *dwp, float *dw, int K, int C, int R, int S, int splits, int deconv,
+STEM_EXPORT int stem_unpack_wgrad(const float *dwp, float *dw, int K, int C, int R, int S, int splits, int flags,
                                   void *stream)
 {
     STEM_CHECK_ARG(dwp && dw && splits >= 1, "stem_unpack_wgrad: bad arguments");
     const int T = R * S;
+    const int deconv = flags & STEM_UNPACK_DECONV;
     // Conv2d: slabs [t][K][C] -> dw[K][C][T].  ConvTranspose2d: slabs [t][C][K] -> dw[C][K][T].
     const int A = deconv ? C : K, Bd = deconv ? K : C;
-    const size_t lds = (size_t)Bd * (T + 1) * sizeof(float);
-    STEM_CHECK_ARG(lds <= 160 * 1024, "stem_unpack_wgrad: slab of %zu B exceeds LDS", lds);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void *)unpack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(unpack_kernel, dim3(A), dim3(256), lds, (hipStream_t)stream, dwp, dw, A, Bd, T, splits);
+    const size_t lds = (size_t)UNPACK_BT * (T + 1) * sizeof(float);
+    STEM_CHECK_ARG(lds <= 64 * 1024, "stem_unpack_wgrad: %d taps exceed the staging tile", T);
+    hipLaunchKernelGGL(unpack_kernel, dim3(A, cdiv(Bd, UNPACK_BT)), dim3(256), lds, (hipStream_t)stream, dwp, dw, A, Bd, T, splits,
+                       (flags & STEM_UNPACK_ACCUMULATE) ? 1 : 0);
     STEM_LAUNCH_CHECK("unpack");
     return 0;
 }

@@ -45,8 +45,10 @@ __global__ void wgrad_pixtab_kernel(int *ptab, int Mtot, int PH, int PW, int GH,
     ptab[2 * m + 1] = (int)mask;
 }
 
+// second launch-bound = waves per SIMD the register allocation must leave room for (the LDS footprint allows 2 / 3 / 3 / 4
+// workgroups per CU for the four tiles; without it the 128x128 tile takes 284 VGPRs = one workgroup per CU)
 template <int BM, int BN, int WM, int WN, bool VEC>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : BM * BN >= 128 * 64 ? 3 : 4)) void wgrad_kernel(const WgradArgs a)
 {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WCOLS = BN / WN;
@@ -60,9 +62,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_j = (a.CG + BN - 1) / BN;
-    const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j;
+    // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (private L2 each).  All tiles x taps of one
+    // pixel range (split) re-read the same dY / x rows, so consecutive *virtual* ids -- split slowest -- are handed to
+    // the same XCD: the rows are fetched from HBM into one L2 instead of eight.  Any placement is correct.
+    int vid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    {
+        const int nb = gridDim.x * gridDim.y * gridDim.z, qq = nb >> 3, rr = nb & 7, xcd = vid & 7, idx = vid >> 3;
+        if (nb >= 16) vid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int tile = vid % (int)gridDim.x, vt = vid / (int)gridDim.x;
+    const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
     const int i0 = ti * BM, j0 = tj * BN;
-    const int t = blockIdx.y, split = blockIdx.z;
+    const int t = vt % (int)gridDim.y, split = vt / (int)gridDim.y;
     const int tr = t / a.S, ts = t - tr * a.S;
     const int Mtot = a.B * a.PH * a.PW, phw = a.PH * a.PW;
     const int c_begin = split * a.chunks_per_split;
@@ -203,13 +214,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a)
             tl(c_begin + 4, ptB);
         }
         __syncthreads();
-        for (int c = c_begin; c < c_end; c += 2) {
+        int c = c_begin;
+        for (; c + 1 < c_end; c += 2) {
             step(0, ra, rb, ptA, c + 3);          // chunk c; stage c+1 -> buffer 1; prefetch c+3 (table c+5)
             __syncthreads();
-            if (c + 1 >= c_end) break;
             step(1, raB, rbB, ptB, c + 4);        // chunk c+1; stage c+2 -> buffer 0; prefetch c+4 (table c+6)
             __syncthreads();
         }
+        if (c < c_end) step(0, ra, rb, ptA, c + 3);      // odd tail (its prefetches are masked out of range)
     } else if (c_begin < c_end) {
         gload(c_begin);
         sstore(0);
@@ -294,9 +306,12 @@ void plan(int CP, int CG, int T, int nchunks, int *cfg, int *splits)
             const int cps = cdiv(nchunks, s);
             if (s > 1 && cdiv(nchunks, cps) != s) continue;
             const long blocks = tiles * s;
-            const long rounds = cdiv((int)blocks, slots[c]);
-            double cost = (double)rounds * (cps + 3) * kWT[c].bm * kWT[c].bn / kWT[c].eff;
-            if (blocks < 256) cost *= 256.0 / blocks * 0.5 + 0.5;
+            // workgroups are dealt round-robin to the 256 CUs and share the CU's MFMA pipes: time ~ (blocks per CU) x
+            // (MFMA work per block); fewer co-resident workgroups hide less latency (measured on the igemm twin kernel)
+            const long per_cu = cdiv((int)blocks, 256);
+            const long resident = per_cu < slots[c] / 256 ? per_cu : slots[c] / 256;
+            const double occf = resident >= 4 ? 1.0 : resident == 3 ? 0.96 : resident == 2 ? 0.91 : 0.75;
+            double cost = (double)per_cu * (cps + 3) * kWT[c].bm * kWT[c].bn / (kWT[c].eff * occf);
             cost += 0.1 * (double)s * CP * CG * T * 32.0 / 256.0;                    // slab write + unpack read
             if (cost < best) {
                 best = cost;
@@ -349,38 +364,85 @@ int run(const float *p, int ldp, int CP, const float *g, int ldg, int CG, float 
     }
 }
 
-// Bias gradient db[k] = sum_m dy[m][k] in two deterministic stages: CS_PARTS pixel ranges x 64-channel tiles
-// write partial column sums (coalesced 256-B rows), then one thread per channel adds the partials in order.
-constexpr int CS_PARTS = 64;
+// Bias gradient db[k] = sum_m dy[m][k] in two deterministic stages (no float atomics): `parts` pixel ranges x 64-channel
+// tiles write partial column sums, then the partials are added in a fixed order.  HBM-bound (dy is read once, 16-byte
+// loads, 4 rows in flight per thread); parts is sized so that the launch has ~2048 workgroups.
+constexpr int CS_MAX_PARTS = 1024;
 
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *dy, int ld, size_t npix, int K, float *part)
+inline int colsum_parts(size_t npix, int K)
+{
+    const int kt = cdiv(K, 64);
+    long parts = 2048 / kt;
+    const long by_rows = (long)((npix + 127) / 128);        // >= 128 rows per part
+    if (parts > by_rows) parts = by_rows;
+    if (parts > CS_MAX_PARTS) parts = CS_MAX_PARTS;
+    return parts < 1 ? 1 : (int)parts;
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *dy, int ld, size_t npix, int K, int parts, float *part)
+{
+    __shared__ float red[16][64 + 4];
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;          // 16 float4 column groups x 16 row groups
+    const int c = blockIdx.x * 64 + cg * 4;
+    const size_t per = (npix + parts - 1) / parts;
+    const size_t m0 = blockIdx.y * per, m1 = m0 + per < npix ? m0 + per : npix;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (VEC4) {
+        if (c < K) {
+            const float *base = dy + c;
+            size_t m = m0 + rg;
+            for (; m + 48 < m1; m += 64) {
+                s0 += *reinterpret_cast<const f32x4 *>(base + m * ld);
+                s1 += *reinterpret_cast<const f32x4 *>(base + (m + 16) * ld);
+                s2 += *reinterpret_cast<const f32x4 *>(base + (m + 32) * ld);
+                s3 += *reinterpret_cast<const f32x4 *>(base + (m + 48) * ld);
+            }
+            for (; m < m1; m += 16) s0 += *reinterpret_cast<const f32x4 *>(base + m * ld);
+        }
+    } else {
+        for (size_t m = m0 + rg; m < m1; m += 16)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < K) s0[e] += dy[m * ld + c + e];
+    }
+    const f32x4 s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rg][cg * 4 + e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < K) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
+        part[(size_t)blockIdx.y * K + blockIdx.x * 64 + threadIdx.x] = t;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *part, int K, int parts, float *out, int accumulate)
 {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    const size_t per = (npix + CS_PARTS - 1) / CS_PARTS;
-    const size_t m0 = blockIdx.y * per, m1 = m0 + per < npix ? m0 + per : npix;
     float s = 0.f;
     if (c < K)
-        for (size_t m = m0 + r; m < m1; m += 4) s += dy[m * ld + c];
+        for (int p = r; p < parts; p += 4) s += part[(size_t)p * K + c];
     red[r][lane] = s;
     __syncthreads();
-    if (r == 0 && c < K) part[(size_t)blockIdx.y * K + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-}
-__global__ void colsum_final_kernel(const float *part, int K, float *out)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= K) return;
-    float s = 0.f;
-    for (int p = 0; p < CS_PARTS; ++p) s += part[(size_t)p * K + c];
-    out[c] = s;
+    if (r == 0 && c < K) {
+        const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        out[c] = accumulate ? out[c] + v : v;
+    }
 }
 
-int colsum(const float *dy, int ld, size_t npix, int K, float *scratch, float *db, hipStream_t st)
+int colsum(const float *dy, int ld, size_t npix, int K, float *scratch, float *db, int accumulate, hipStream_t st)
 {
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(K, 64), CS_PARTS), dim3(256), 0, st, dy, ld, npix, K, scratch);
+    const int parts = colsum_parts(npix, K);
+    const bool vec = (K % 4 == 0) && (ld % 4 == 0) && ((((uintptr_t)dy) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL((colsum_partial_kernel<true>), dim3(cdiv(K, 64), parts), dim3(256), 0, st, dy, ld, npix, K, parts, scratch);
+    else
+        hipLaunchKernelGGL((colsum_partial_kernel<false>), dim3(cdiv(K, 64), parts), dim3(256), 0, st, dy, ld, npix, K, parts, scratch);
     STEM_LAUNCH_CHECK("colsum_partial");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(K, 256)), dim3(256), 0, st, scratch, K, db);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(K, 64)), dim3(256), 0, st, scratch, K, parts, db, accumulate);
     STEM_LAUNCH_CHECK("colsum_final");
     return 0;
 }
@@ -390,7 +452,7 @@ int colsum(const float *dy, int ld, size_t npix, int K, float *scratch, float *d
 STEM_EXPORT size_t stem_wgrad_workspace_elems(int splits, int C, int K, int R, int S, int npix)
 {
     // slabs | bias-gradient partial sums | per-pixel gather table (offset, tap mask)
-    return (size_t)splits * R * S * K * C + (size_t)CS_PARTS * K + (size_t)2 * npix + 4;
+    return (size_t)splits * R * S * K * C + (size_t)CS_MAX_PARTS * K + (size_t)2 * npix + 4;
 }
 
 STEM_EXPORT int stem_wgrad_splits(int B, int Ho, int Wo, int C, int K, int R, int S)
@@ -408,9 +470,10 @@ STEM_EXPORT int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int 
     STEM_CHECK_ARG(splits >= 1, "stem_conv2d_wgrad: splits must be >= 1");
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     hipStream_t st = (hipStream_t)stream;
-    if (db && colsum(dy, lddy, (size_t)B * Ho * Wo, K, dwp + (size_t)splits * R * S * K * C, db, st)) return -2;
+    if (db && colsum(dy, lddy, (size_t)B * Ho * Wo, K, dwp + (size_t)splits * R * S * K * C, db, (flags & STEM_WGRAD_ACCUMULATE_DB) ? 1 : 0, st))
+        return -2;
     // P = dY on the output grid (K channels), G = x gathered at oy*stride - pad + r  ->  [t][K][C]
-    int *ptab = reinterpret_cast<int *>(dwp + (size_t)splits * R * S * K * C + (size_t)CS_PARTS * K);
+    int *ptab = reinterpret_cast<int *>(dwp + (size_t)splits * R * S * K * C + (size_t)CS_MAX_PARTS * K);
     return run(dy, lddy, K, x, ldx, C, dwp, ptab, B, Ho, Wo, H, W, R, S, stride, pad, splits, flags, st);
 }
 
@@ -422,8 +485,9 @@ STEM_EXPORT int stem_deconv2d_wgrad(const float *x, int ldx, const float *dy, in
     STEM_CHECK_ARG(splits >= 1, "stem_deconv2d_wgrad: splits must be >= 1");
     const int Ho = (H - 1) * stride - 2 * pad + R + opad, Wo = (W - 1) * stride - 2 * pad + S + opad;
     hipStream_t st = (hipStream_t)stream;
-    if (db && colsum(dy, lddy, (size_t)B * Ho * Wo, K, dwp + (size_t)splits * R * S * K * C, db, st)) return -2;
+    if (db && colsum(dy, lddy, (size_t)B * Ho * Wo, K, dwp + (size_t)splits * R * S * K * C, db, (flags & STEM_WGRAD_ACCUMULATE_DB) ? 1 : 0, st))
+        return -2;
     // P = x on the input grid (C channels), G = dY gathered at iy*stride - pad + r  ->  [t][C][K]
-    int *ptab = reinterpret_cast<int *>(dwp + (size_t)splits * R * S * K * C + (size_t)CS_PARTS * K);
+    int *ptab = reinterpret_cast<int *>(dwp + (size_t)splits * R * S * K * C + (size_t)CS_MAX_PARTS * K);
     return run(x, ldx, C, dy, lddy, K, dwp, ptab, B, H, W, Ho, Wo, R, S, stride, pad, splits, flags, st);
 }

@@ -225,21 +225,40 @@ def wgrad_plan(x_shape, K, R, S, stride, pad, deconv=False):
     return splits, int(lib.stem_wgrad_workspace_elems(splits, Cc, K, R, S, npix))
 
 
-def conv2d_wgrad(x, dy, K, R, S, stride, pad, dw_out=None, db_out=None, need_db=True, dwp=None, unpack=True, table_valid=False):
+_WGRAD_WS = {}
+WGRAD_TABLE_VALID, WGRAD_ACCUMULATE_DB = 1, 4
+UNPACK_DECONV, UNPACK_ACCUMULATE = 1, 2
+
+
+def _wgrad_workspace(key, elems, device):
+    """Slab / partial-sum / gather-table scratch of one layer geometry.  Kernels of a stream are ordered, so every layer
+    with this geometry shares the buffer, and its gather table (a function of the geometry only) is built once."""
+    hit = _WGRAD_WS.get(key)
+    if hit is not None and hit.numel() >= elems:
+        return hit, True
+    buf = _WGRAD_WS[key] = torch.empty(elems, device=device, dtype=torch.float32)
+    return buf, False
+
+
+def conv2d_wgrad(x, dy, K, R, S, stride, pad, dw_out=None, db_out=None, need_db=True, dwp=None, unpack=True, table_valid=False,
+                 accumulate=False):
     """-> (dW [K,C,R,S], db [K]) in the reference's layouts.  With unpack=False only the packed slabs in `dwp`
-    are produced (the caller sums/transposes all layers at once with unpack_wgrads_multi)."""
+    are produced (the caller sums/transposes all layers at once with unpack_wgrads_multi).  accumulate=True adds into
+    dw_out / db_out (gradient accumulation over several backward passes)."""
     B, Cc, H, W = x.shape
     lib = _lib.hip()
     splits, elems = wgrad_plan(x.shape, K, R, S, stride, pad)
     if dwp is None:
-        dwp = torch.empty(elems, device=x.device, dtype=torch.float32)
+        dwp, table_valid = _wgrad_workspace((x.device, 0, tuple(x.shape), nhwc_ld(x), K, R, S, stride, pad), elems, x.device)
+    assert not accumulate or (dw_out is not None and (db_out is not None or not need_db))
     db = (db_out if db_out is not None else torch.empty(K, device=x.device, dtype=torch.float32)) if need_db else None
+    flags = (WGRAD_TABLE_VALID if table_valid else 0) | (WGRAD_ACCUMULATE_DB if accumulate else 0)
     _chk(lib.stem_conv2d_wgrad(x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), dwp.data_ptr(), _ptr(db),
-                               B, H, W, Cc, K, R, S, stride, pad, splits, int(table_valid), _stream()))
+                               B, H, W, Cc, K, R, S, stride, pad, splits, flags, _stream()))
     if not unpack:
         return None, db
     dw = dw_out if dw_out is not None else torch.empty((K, Cc, R, S), device=x.device, dtype=torch.float32)
-    _chk(lib.stem_unpack_wgrad(dwp.data_ptr(), dw.data_ptr(), K, Cc, R, S, splits, 0, _stream()))
+    _chk(lib.stem_unpack_wgrad(dwp.data_ptr(), dw.data_ptr(), K, Cc, R, S, splits, UNPACK_ACCUMULATE if accumulate else 0, _stream()))
     return dw, db
 
 
@@ -266,20 +285,24 @@ def deconv2d_dgrad(dy, wp_dgrad, x_shape, K, R, S, stride, pad, opad, xact=None,
     return out
 
 
-def deconv2d_wgrad(x, dy, K, R, S, stride, pad, opad, dw_out=None, db_out=None, need_db=True, dwp=None, unpack=True, table_valid=False):
+def deconv2d_wgrad(x, dy, K, R, S, stride, pad, opad, dw_out=None, db_out=None, need_db=True, dwp=None, unpack=True, table_valid=False,
+                   accumulate=False):
     """-> (dW [C,K,R,S], db [K]) in nn.ConvTranspose2d's layout."""
     B, Cc, H, W = x.shape
     lib = _lib.hip()
     splits, elems = wgrad_plan(x.shape, K, R, S, stride, pad, deconv=True)
     if dwp is None:
-        dwp = torch.empty(elems, device=x.device, dtype=torch.float32)
+        dwp, table_valid = _wgrad_workspace((x.device, 1, tuple(x.shape), nhwc_ld(dy), K, R, S, stride, pad, opad), elems, x.device)
+    assert not accumulate or (dw_out is not None and (db_out is not None or not need_db))
     db = (db_out if db_out is not None else torch.empty(K, device=x.device, dtype=torch.float32)) if need_db else None
+    flags = (WGRAD_TABLE_VALID if table_valid else 0) | (WGRAD_ACCUMULATE_DB if accumulate else 0)
     _chk(lib.stem_deconv2d_wgrad(x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), dwp.data_ptr(), _ptr(db),
-                                 B, H, W, Cc, K, R, S, stride, pad, opad, splits, int(table_valid), _stream()))
+                                 B, H, W, Cc, K, R, S, stride, pad, opad, splits, flags, _stream()))
     if not unpack:
         return None, db
     dw = dw_out if dw_out is not None else torch.empty((Cc, K, R, S), device=x.device, dtype=torch.float32)
-    _chk(lib.stem_unpack_wgrad(dwp.data_ptr(), dw.data_ptr(), K, Cc, R, S, splits, 1, _stream()))
+    _chk(lib.stem_unpack_wgrad(dwp.data_ptr(), dw.data_ptr(), K, Cc, R, S, splits,
+                               UNPACK_DECONV | (UNPACK_ACCUMULATE if accumulate else 0), _stream()))
     return dw, db
 
 

@@ -42,6 +42,16 @@ class _PackCache:
         return wp
 
 
+def _flat_grad(p):
+    """The parameter's slot in a FlatParameters gradient buffer when `p.grad` currently IS that slot, else None.
+    Weight / bias gradients are then accumulated straight into the slot by the unpack / column-sum kernels and the
+    autograd Function returns None for them: exactly what AccumulateGrad's `p.grad += g` would do, without the
+    temporary and the extra pass.  (Only `.backward()` accumulation is served this way; torch.autograd.grad() with
+    these parameters as inputs would see None -- use plain parameters, i.e. no FlatParameters, for that.)"""
+    view = getattr(p, "_flat_grad_view", None)
+    return view if view is not None and p.grad is view else None
+
+
 # ----------------------------------------------------------------------------- autograd functions
 class Conv2dFunction(torch.autograd.Function):
     @staticmethod
@@ -59,6 +69,7 @@ class Conv2dFunction(torch.autograd.Function):
         if first and act:
             y = F.lrelu_fwd(y, slope)
         ctx.cfg = (stride, pad, act, masked, cache, first, tuple(x.shape), slope)
+        ctx.params = (weight, bias)
         ctx.save_for_backward(xin, weight, y if act else None)
         return y
 
@@ -77,9 +88,14 @@ class Conv2dFunction(torch.autograd.Function):
             dx = F.conv2d_dgrad(dy, cache.get(weight, F.PACK_CONV_DGRAD, 1 if masked else 0), xshape, K, R, S, stride, pad)
         dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dw, db = F.conv2d_wgrad(xin, dy, K, R, S, stride, pad, need_db=ctx.needs_input_grad[2])
-            if first and Cc == 3:
-                dw = dw[:, :3].contiguous()
+            need_db = bool(ctx.needs_input_grad[2])
+            gw, gb = _flat_grad(ctx.params[0]), (_flat_grad(ctx.params[1]) if need_db else None)
+            if gw is not None and (gb is not None or not need_db) and not (first and Cc == 3):
+                F.conv2d_wgrad(xin, dy, K, R, S, stride, pad, dw_out=gw, db_out=gb, need_db=need_db, accumulate=True)
+            else:
+                dw, db = F.conv2d_wgrad(xin, dy, K, R, S, stride, pad, need_db=need_db)
+                if first and Cc == 3:
+                    dw = dw[:, :3].contiguous()
         return dx, dw, db, None, None, None, None, None, None
 
 
@@ -90,6 +106,7 @@ class ConvTranspose2dFunction(torch.autograd.Function):
         xin = F.to_nhwc(x)
         y = F.deconv2d_fwd(xin, cache.get(weight, F.PACK_DECONV_FWD), bias, K, R, S, stride, pad, opad, act, slope=slope)
         ctx.cfg = (stride, pad, opad, act, cache, tuple(x.shape), slope)
+        ctx.params = (weight, bias)
         ctx.save_for_backward(xin, weight, y if act else None)
         return y
 
@@ -108,7 +125,12 @@ class ConvTranspose2dFunction(torch.autograd.Function):
             dx = F.deconv2d_dgrad(dy, cache.get(weight, F.PACK_DECONV_DGRAD), xshape, K, R, S, stride, pad, opad)
         dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dw, db = F.deconv2d_wgrad(xin, dy, K, R, S, stride, pad, opad, need_db=ctx.needs_input_grad[2])
+            need_db = bool(ctx.needs_input_grad[2])
+            gw, gb = _flat_grad(ctx.params[0]), (_flat_grad(ctx.params[1]) if need_db else None)
+            if gw is not None and (gb is not None or not need_db):
+                F.deconv2d_wgrad(xin, dy, K, R, S, stride, pad, opad, dw_out=gw, db_out=gb, need_db=need_db, accumulate=True)
+            else:
+                dw, db = F.deconv2d_wgrad(xin, dy, K, R, S, stride, pad, opad, need_db=need_db)
         return dx, dw, db, None, None, None, None, None, None
 
 
