@@ -47,9 +47,15 @@ __global__ void wgrad_pixtab_kernel(int *ptab, int Mtot, int PH, int PW, int GH,
 
 // second launch-bound = waves per SIMD the register allocation must leave room for (the LDS footprint allows 2 / 3 / 3 / 4
 // workgroups per CU for the four tiles; without it the 128x128 tile takes 284 VGPRs = one workgroup per CU)
-template <int BM, int BN, int WM, int WN, bool VEC>
+//
+// C4: the gathered operand has 4 channels at pitch 4 (image + quality map, or an image gradient padded to 4): the taps
+// are folded into the tile's N axis -- column j = (t mod BN/4) * 4 + c, BN/4 taps per tile -- instead of one workgroup
+// row per tap with a 4-of-BN filled tile.
+template <int BM, int BN, int WM, int WN, bool VEC, bool C4 = false>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : BM * BN >= 128 * 64 ? 3 : 4)) void wgrad_kernel(const WgradArgs a)
 {
+    static_assert(!C4 || VEC, "the folded-tap mode uses the vector path");
+    constexpr int TPT = BN / 4;                             // taps per tile (C4)
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WCOLS = BN / WN;
     constexpr int PA = BM + 4, PB = BN + 4;                 // LDS pitches
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : BM * BN >= 128 * 6
     float *Gs = smem + 2 * KP * PA;      // [2][KP][PB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_j = (a.CG + BN - 1) / BN;
+    const int tiles_j = C4 ? (a.R * a.S + TPT - 1) / TPT : (a.CG + BN - 1) / BN;
     // XCD-aware placement: workgroups are dealt round-robin over the 8 XCDs (private L2 each).  All tiles x taps of one
     // pixel range (split) re-read the same dY / x rows, so consecutive *virtual* ids -- split slowest -- are handed to
     // the same XCD: the rows are fetched from HBM into one L2 instead of eight.  Any placement is correct.
@@ -73,7 +79,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : BM * BN >= 128 * 6
     const int tile = vid % (int)gridDim.x, vt = vid / (int)gridDim.x;
     const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
     const int i0 = ti * BM, j0 = tj * BN;
-    const int t = vt % (int)gridDim.y, split = vt / (int)gridDim.y;
+    const int split = vt / (int)gridDim.y;
+    const int colB_ = ((int)threadIdx.x % (BN / 4)) * 4;
+    const int t = C4 ? tj * TPT + colB_ / 4 : vt % (int)gridDim.y;      // C4: this thread's own tap
     const int tr = t / a.S, ts = t - tr * a.S;
     const int Mtot = a.B * a.PH * a.PW, phw = a.PH * a.PW;
     const int c_begin = split * a.chunks_per_split;
@@ -88,7 +96,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : BM * BN >= 128 * 6
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.g), 0, a.gbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(a.ptab), 0, a.tbytes, 0x00020000);
     const int tapoff = (tr * a.GW + ts) * a.ldg * 4;          // byte offset of this workgroup's tap
-    const bool colA_ok = i0 + colA < a.CP, colB_ok = j0 + colB < a.CG;
+    const bool colA_ok = i0 + colA < a.CP, colB_ok = C4 ? t < a.R * a.S : j0 + colB < a.CG;
     typedef int i32x2 __attribute__((ext_vector_type(2)));
     auto gload = [&](int chunk) {
 #pragma unroll
@@ -163,8 +171,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : BM * BN >= 128 * 6
         auto glB = [&](f32x4 (&r)[NPB], const i32x2 (&p)[NPB]) {
 #pragma unroll
             for (int q = 0; q < NPB; ++q) {
-                const int mk = -(int)(((unsigned)p[q][1] >> t) & 1u) & -(int)colB_ok;
-                const int off = ((p[q][0] + tapoff + (j0 + colB) * 4) & mk) | (0x7FFFFF00 & ~mk);
+                const int mk = -(int)(((unsigned)p[q][1] >> (t & 31)) & 1u) & -(int)colB_ok;
+                const int off = ((p[q][0] + tapoff + (C4 ? 0 : (j0 + colB) * 4)) & mk) | (0x7FFFFF00 & ~mk);
                 r[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
             }
         };
@@ -249,6 +257,22 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : BM * BN >= 128 * 6
         }
     }
 
+    if (C4) {
+        float *outs = a.out + (size_t)split * a.R * a.S * a.CP * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int jl = wn0 + j * 32 + lr, tt = tj * TPT + (jl >> 2);
+            if (tt >= a.R * a.S) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ii = i0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (ii < a.CP) outs[((size_t)tt * a.CP + ii) * 4 + (jl & 3)] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     float *outp = a.out + ((size_t)split * a.R * a.S + t) * a.CP * a.CG;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -283,6 +307,16 @@ int launch_cfg(const WgradArgs &a, bool vec, hipStream_t st)
     return 0;
 }
 
+int launch_c4(const WgradArgs &a, hipStream_t st)
+{
+    constexpr int BM = 64, BN = 64;
+    dim3 grid(cdiv(a.CP, BM) * cdiv(a.R * a.S, BN / 4), 1, a.splits), block(256);
+    const size_t lds = (size_t)2 * KP * (BM + 4 + BN + 4) * sizeof(float);
+    hipLaunchKernelGGL((wgrad_kernel<BM, BN, 32, 32, true, true>), grid, block, lds, st, a);
+    STEM_LAUNCH_CHECK("wgrad_c4");
+    return 0;
+}
+
 struct WTile {
     int bm, bn;
     float eff;
@@ -295,6 +329,17 @@ void plan(int CP, int CG, int T, int nchunks, int *cfg, int *splits)
     double best = 1e300;
     *cfg = 0;
     *splits = 1;
+    if (CG == 4) {      // folded-tap mode (launch_c4): 64-row tiles x 16-tap tiles; split the pixels to ~1024 workgroups
+        const int tiles = cdiv(CP, 64) * cdiv(T, 16);
+        int s = 1024 / tiles, max_s = nchunks >= 8 ? nchunks / 8 : 1;
+        if (s > max_s) s = max_s;
+        if (s > 64) s = 64;
+        if (s < 1) s = 1;
+        const int cps = cdiv(nchunks, s);
+        *cfg = 3;
+        *splits = cdiv(nchunks, cps);
+        return;
+    }
     const int slots[4] = {512, 768, 768, 1024};      // co-resident workgroups (LDS: 68 / 51 / 51 / 34 KB)
     static const int forced = getenv("STEM_WGRAD_CFG") ? atoi(getenv("STEM_WGRAD_CFG")) : -1;      // tuning aid
     for (int c = 0; c < 4; ++c) {
@@ -356,6 +401,7 @@ int run(const float *p, int ldp, int CP, const float *g, int ldg, int CG, float 
                      (((uintptr_t)p & 15) == 0) && (((uintptr_t)g & 15) == 0);
     int cfg, s_unused;
     plan(CP, CG, R * S, a.nchunks, &cfg, &s_unused);
+    if (vec && CG == 4 && ldg == 4 && !a.gsq && R * S <= 32) return launch_c4(a, st);
     switch (cfg) {
     case 0: return launch_cfg<128, 128, 64, 64>(a, vec, st);
     case 1: return launch_cfg<128, 64, 64, 32>(a, vec, st);
