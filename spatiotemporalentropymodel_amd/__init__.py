@@ -17,7 +17,10 @@ def install_compressai_alias():
     import types
 
     from . import entropy_models, layers, ops, zoo
-    from .models import priors, spatiotemporalpriors, utils
+    import importlib
+
+    from .models import priors, spatiotemporalpriors, stem_utils, utils
+    stem_roi = importlib.import_module(".models.stem_roi", __name__)      # the package attribute of that name is the class
 
     root = types.ModuleType("compressai")
     root.__path__ = []
@@ -30,11 +33,13 @@ def install_compressai_alias():
     cxx.pmf_to_quantized_cdf = lambda pmf, precision: entropy_models.pmf_to_quantized_cdf(pmf, precision).tolist()
     models = types.ModuleType("compressai.models")
     models.__path__ = []
-    for name in priors.__all__ + spatiotemporalpriors.__all__:
-        setattr(models, name, getattr(priors, name, None) or getattr(spatiotemporalpriors, name))
+    for mod in (priors, spatiotemporalpriors, stem_roi, stem_utils):
+        for name in mod.__all__:
+            setattr(models, name, getattr(mod, name))
     table = {"compressai": root, "compressai.ans": ans, "compressai._CXX": cxx, "compressai.zoo": zoo,
              "compressai.models": models, "compressai.models.priors": priors, "compressai.models.utils": utils,
-             "compressai.models.spatiotemporalpriors": spatiotemporalpriors, "compressai.layers": layers,
+             "compressai.models.spatiotemporalpriors": spatiotemporalpriors, "compressai.models.stem_roi": stem_roi,
+             "compressai.models.stem_utils": stem_utils, "compressai.layers": layers,
              "compressai.entropy_models": entropy_models, "compressai.ops": ops}
     for k, v in table.items():
         sys.modules[k] = v

@@ -80,6 +80,10 @@ def test_compressai_alias_imports():
     from compressai.models.spatiotemporalpriors import SpatioTemporalPriorModel_Res as R
     from compressai.zoo import models
     assert R is SpatioTemporalPriorModel_Res
+    from compressai.models.stem_roi import stem_roi, stem_roi_i  # noqa: F401  (stem_roi/train_stem_roi.py:9)
+    from compressai.models.stem_utils import SFT, SFTResblk  # noqa: F401
+    import spatiotemporalentropymodel_amd.models as mine
+    assert stem_roi is mine.stem_roi and SFT is mine.SFT
     assert isinstance(models["mbt2018"](quality=4), JointAutoregressiveHierarchicalPriors)
     assert compressai.available_entropy_coders() == ["ans"]
     compressai.set_entropy_coder("ans")
