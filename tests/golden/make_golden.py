@@ -50,6 +50,8 @@ def import_reference():
     with open(os.path.join(scratch, "torchvision", "utils.py"), "w") as f:
         f.write("def make_grid(*a, **k):\n    raise NotImplementedError\n"
                 "def save_image(*a, **k):\n    raise NotImplementedError\n")
+    with open(os.path.join(scratch, "torchvision", "transforms.py"), "w") as f:      # names compressai_examples/codec.py imports
+        f.write("class ToPILImage:\n    pass\nclass ToTensor:\n    pass\n")
     ext = sysconfig.get_config_var("EXT_SUFFIX")
     inc = subprocess.check_output([sys.executable, "-m", "pybind11", "--includes"]).decode().split()
     base = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", *inc]
@@ -569,12 +571,40 @@ def gen_stem_roi_gop(ref, batch=1, size=64, nframes=3):
     save("stem_roi_gop.npz", d)
 
 
+def gen_container(ref):
+    """Byte layout of compressai_examples/codec.py's container (:63-119,178-187) from the reference's own writers."""
+    import io
+    spec = importlib.util.spec_from_file_location("ref_codec_tool", os.path.join(REF, "compressai_examples", "codec.py"))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    d = {}
+    cases = [("mbt2018", "mse", 4, (1080, 1920), (17, 30), [[bytes(range(37))], [b"\x00\xffabc"]]),
+             ("bmshj2018-factorized", "mse", 1, (64, 64), (4, 4), [[b"x"]]),
+             ("cheng2020-attn", "mse", 8, (768, 512), (12, 8), [[b""], [bytes(1000)], [b"\x01\x02\x03"]])]
+    for i, (model, metric, q, size, shape, strings) in enumerate(cases):
+        f = io.BytesIO()
+        tool.write_uchars(f, tool.get_header(model, metric, q))
+        tool.write_uints(f, size)
+        tool.write_uints(f, (shape[0], shape[1], len(strings)))
+        for s_ in strings:
+            tool.write_uints(f, (len(s_[0]),))
+            tool.write_bytes(f, s_[0])
+        d[f"case{i}:bytes"] = np.frombuffer(f.getvalue(), dtype=np.uint8).copy()
+        d[f"case{i}:meta"] = np.array([f"{model}|{metric}|{q}|{size[0]},{size[1]}|{shape[0]},{shape[1]}"])
+        for j, s_ in enumerate(strings):
+            d[f"case{i}:s{j}"] = np.frombuffer(s_[0], dtype=np.uint8).copy()
+    x = closed_form_input("container:x", (1, 3, 50, 75), 0.0, 1.0)
+    xp = tool.pad(x, 64)
+    d["pad:x"], d["pad:xp"], d["pad:back"] = t2n(x), t2n(xp), t2n(tool.crop(xp, (50, 75)))
+    save("container.npz", d)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     scratch, ref_utils = import_reference()
     try:
-        which = sys.argv[1:] or ["ops", "codec", "fwd", "train_small", "train_big", "stemcodec", "roi", "roiops", "roigop"]
+        which = sys.argv[1:] or ["ops", "codec", "fwd", "train_small", "train_big", "stemcodec", "roi", "roiops", "roigop", "container"]
         if "ops" in which:
             gen_ops(ref_utils)
         if "codec" in which:
@@ -593,5 +623,7 @@ if __name__ == "__main__":
             gen_roi_ops(ref_utils)
         if "roigop" in which:
             gen_stem_roi_gop(ref_utils)
+        if "container" in which:
+            gen_container(ref_utils)
     finally:
         shutil.rmtree(scratch, ignore_errors=True)

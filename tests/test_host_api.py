@@ -216,3 +216,37 @@ def test_flat_parameters_views_and_order():
     flat.data.mul_(2.0)
     n0, p0 = main[0]
     assert torch.equal(p0, before[n0] * 2)
+
+
+# ----------------------------------------------------------------------------- container (compressai_examples/codec.py:63-220)
+def test_bitstream_container_matches_reference_bytes(golden):
+    import io
+    from spatiotemporalentropymodel_amd import bitstream as bs
+    g = golden("container.npz")
+    frames = []
+    for i in range(3):
+        model, metric, q, size, shape = str(g[f"case{i}:meta"][0]).split("|")
+        size, shape = tuple(map(int, size.split(","))), tuple(map(int, shape.split(",")))
+        strings = []
+        j = 0
+        while f"case{i}:s{j}" in g:
+            strings.append([g[f"case{i}:s{j}"].tobytes()])
+            j += 1
+        f = io.BytesIO()
+        bs.write_frame(f, bs.get_header(model, metric, int(q)), size, shape, strings)
+        assert f.getvalue() == g[f"case{i}:bytes"].tobytes()
+        hdr, osz, shp, back = bs.read_frame(io.BytesIO(f.getvalue()))
+        assert hdr == (model, metric, int(q)) and osz == size and shp == shape and back == strings
+        frames.append((bs.get_header(model, metric, int(q)), size, shape, strings))
+    f = io.BytesIO()
+    bs.write_sequence(f, frames)
+    seq = bs.read_sequence(io.BytesIO(f.getvalue()))
+    assert [fr[3] for fr in seq] == [fr[3] for fr in frames] and len(seq) == 3
+    with pytest.raises(ValueError):
+        bs.read_frame(io.BytesIO(f.getvalue()[4:40]))
+    with pytest.raises(ValueError):
+        bs.get_header("nope", "mse", 1)
+    x = torch.from_numpy(g["pad:x"])
+    xp = bs.pad(x, 64)
+    np.testing.assert_array_equal(xp.numpy(), g["pad:xp"])
+    np.testing.assert_array_equal(bs.crop(xp, (50, 75)).numpy(), g["pad:back"])
