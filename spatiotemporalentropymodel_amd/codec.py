@@ -191,10 +191,12 @@ def stem_decompress(model, strings, shape, y_cond):
     lib = _lib.hip()
     Wp = W + 2 * _P
     out = F.empty_nhwc(B, M, H, W, dev)
-    idx_dev = torch.empty(M, device=dev, dtype=torch.int32)
-    sym_dev = torch.empty(M, device=dev, dtype=torch.int32)
+    # host mailbox: pinned (device-visible) memory the index kernel writes and the finish kernel reads directly, so a
+    # position costs kernel launches + ONE stream synchronisation and no memcpy calls
     idx_host = torch.empty(M, dtype=torch.int32).pin_memory()
     sym_host = torch.empty(M, dtype=torch.int32).pin_memory()
+    idx_np, sym_np = idx_host.numpy(), sym_host.numpy()
+    stream = torch.cuda.current_stream()
     for b, s in enumerate(strings[0]):
         buf = _padded(None, H, W, M, dev)
         dec = RansDecoder()
@@ -205,13 +207,11 @@ def stem_decompress(model, strings, shape, y_cond):
                 hp_pix = hp.data_ptr() + 4 * ((b * H * W + pos) * 2 * M)
                 tp_pix = tp.data_ptr() + 4 * ((b * H * W + pos) * 2 * M) if tp is not None else 0
                 ar.position(buf, Wp, h, w, tp_pix, hp_pix)
-                F._chk(lib.stem_ar_index(ar.gp.data_ptr(), ar.table.data_ptr(), ar.table.numel(), ar.bound, idx_dev.data_ptr(), M, F._stream()))
-                idx_host.copy_(idx_dev, non_blocking=True)
-                torch.cuda.current_stream().synchronize()
-                sym_host.copy_(torch.from_numpy(dec.decode_stream_np(idx_host.numpy(), tables)))
-                sym_dev.copy_(sym_host, non_blocking=True)
+                F._chk(lib.stem_ar_index(ar.gp.data_ptr(), ar.table.data_ptr(), ar.table.numel(), ar.bound, idx_host.data_ptr(), M, F._stream()))
+                stream.synchronize()
+                sym_np[:] = dec.decode_stream_np(idx_np, tables)
                 pix = buf.data_ptr() + 4 * (((h + _P) * Wp + (w + _P)) * M)
-                F._chk(lib.stem_ar_finish_decode(ar.gp.data_ptr(), sym_dev.data_ptr(), pix, M, F._stream()))
+                F._chk(lib.stem_ar_finish_decode(ar.gp.data_ptr(), sym_host.data_ptr(), pix, M, F._stream()))
         out[b:b + 1].copy_(buf[_P:_P + H, _P:_P + W].permute(2, 0, 1).unsqueeze(0))
     if model.RESIDUAL:
         out = F.add(out, _dense(yd))
