@@ -166,6 +166,14 @@ int stem_avgpool_bwd(const float *dy, int ldy, float *dx, int ldx, int B, int H,
 int stem_weighted_sqerr_sum(const float *xhat, const float *x, const float *lambda, int B, int C, size_t HW, double *acc, void *stream);
 int stem_weighted_sqerr_bwd(const float *xhat, const float *x, const float *lambda, float *dxhat, int B, int C, size_t HW,
                             const double *g, float coef, void *stream);
+/* ---- training-data pipeline on the device (stem/dataset_vidseq.py, stem_roi/stem_roi_dataset.py) ----
+ * src: decoded frames uint8 [B][T][H][W][3]; params int32 [B][3] = (top, left, flip); dst float [T][B][3][crop][crop]:
+ * frame t of sample b is source frame (flip ? T-1-t : t), cropped, as ToTensor would give it (byte / 255).            */
+int stem_crop_u8_to_f32(const unsigned char *src, float *dst, const int *params, int B, int T, int H, int W, int crop, void *stream);
+/* quality maps: params double [B][stem_qmap_params_per_sample()] = mode (0 uniform, 1 gradation, 2 Gaussians), value|v1|count,
+ * v2|final factor, transpose, then (mu_row, mu_col, var_row, var_col) x 20; out float [B][crop][crop] = map * inv_range. */
+int stem_qmap_params_per_sample(void);
+int stem_qmap_render(const double *params, float *out, int B, int crop, float inv_range, void *stream);
 
 /* ---- layout ------------------------------------------------------------ */
 int stem_nchw_to_nhwc(const float *x, float *y, int ldy, int B, int C, int H, int W, void *stream);

@@ -45,6 +45,9 @@ _HIP_SIG = {
     "stem_sft_bwd": [vp, vp, vp, vp, vp, vp, vp, sz, cf, vp],
     "stem_avgpool_fwd": [vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_avgpool_bwd": [vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_crop_u8_to_f32": [vp, vp, vp, ci, ci, ci, ci, ci, vp],
+    "stem_qmap_params_per_sample": [],
+    "stem_qmap_render": [vp, vp, ci, ci, cf, vp],
     "stem_weighted_sqerr_sum": [vp, vp, vp, ci, ci, sz, vp, vp],
     "stem_weighted_sqerr_bwd": [vp, vp, vp, vp, ci, ci, sz, vp, cf, vp],
     "stem_nchw_to_nhwc": [vp, vp, ci, ci, ci, ci, ci, vp],

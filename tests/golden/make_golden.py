@@ -50,8 +50,15 @@ def import_reference():
     with open(os.path.join(scratch, "torchvision", "utils.py"), "w") as f:
         f.write("def make_grid(*a, **k):\n    raise NotImplementedError\n"
                 "def save_image(*a, **k):\n    raise NotImplementedError\n")
-    with open(os.path.join(scratch, "torchvision", "transforms.py"), "w") as f:      # names compressai_examples/codec.py imports
+    os.makedirs(os.path.join(scratch, "torchvision", "transforms"))
+    with open(os.path.join(scratch, "torchvision", "transforms", "__init__.py"), "w") as f:      # names compressai_examples/codec.py imports
         f.write("class ToPILImage:\n    pass\nclass ToTensor:\n    pass\n")
+    with open(os.path.join(scratch, "torchvision", "transforms", "functional.py"), "w") as f:
+        # stand-in for torchvision's to_tensor (uint8 HWC -> float CHW / 255), used ONLY by gen_roi_dataset, which records
+        # integers decoded from the pixels (crop offsets, frame order) and the quality map -- nothing that depends on it
+        f.write("import numpy as np, torch\n"
+                "def to_tensor(pic):\n"
+                "    return torch.from_numpy(np.asarray(pic, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255)\n")
     ext = sysconfig.get_config_var("EXT_SUFFIX")
     inc = subprocess.check_output([sys.executable, "-m", "pybind11", "--includes"]).decode().split()
     base = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", *inc]
@@ -599,12 +606,81 @@ def gen_container(ref):
     save("container.npz", d)
 
 
+def _write_coordinate_septuplets(root, names, H=256, W=448):
+    """PNG septuplets whose pixels encode (x, y, frame): R = x & 255, G = y & 255, B = (x >> 8) | (y >> 8) << 2 | frame << 4."""
+    from PIL import Image
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    for name in names:
+        d_ = os.path.join(root, "sequences", name)
+        os.makedirs(d_, exist_ok=True)
+        for fr in range(1, 8):
+            img = np.stack([xx & 255, yy & 255, (xx >> 8) | ((yy >> 8) << 2) | (fr << 4)], -1).astype(np.uint8)
+            Image.fromarray(img).save(os.path.join(d_, f"f00{fr}.png"))
+    for lst in ("vimeo_sep_trainlist_all.txt", "sep_trainlist.txt", "sep_testlist.txt"):
+        with open(os.path.join(root, lst), "w") as f:
+            f.write("\n".join(names) + "\n")
+
+
+def gen_roi_dataset(ref, cropsize=64, nseeds=400):
+    """stem_roi/stem_roi_dataset.py: VimeoSepTuplet_QMap.__getitem__ of the reference on coordinate-coded PNGs, one call
+    per `random.seed(s)`: crop offsets and frame order (decoded from the pixels), and the quality map.  Seeds are chosen
+    so that every branch of the map synthesis is present."""
+    import random
+    spec = importlib.util.spec_from_file_location("ref_roi_dataset", os.path.join(REF, "stem_roi", "stem_roi_dataset.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    root = tempfile.mkdtemp(prefix="stem_vimeo_")
+    try:
+        _write_coordinate_septuplets(root, ["00001/0001"])
+        d = {}
+        for training in (True, False):
+            ds = mod.VimeoSepTuplet_QMap(root, is_training=training, cropsize=cropsize, level=37)
+            want = {"zero": 1, "hi": 2, "uni": 2, "grad": 3, "gradT": 3, "gauss": 5} if training else {"test": 2}
+            kept = []
+            for seed in range(nseeds):
+                random.seed(seed)
+                images, qmap = ds[0]
+                q = qmap.numpy()[0]
+                px = (images[0] * 255).round().long()
+                left = int(px[0, 0, 0]) | ((int(px[2, 0, 0]) & 3) << 8)
+                top = int(px[1, 0, 0]) | (((int(px[2, 0, 0]) >> 2) & 3) << 8)
+                order = [int(im[2, 0, 0] * 255 + 0.5) >> 4 for im in images]
+                if not training:
+                    tag = "test"
+                elif q.max() == q.min():
+                    # replay the draws to tell the three uniform branches apart
+                    random.seed(seed)
+                    random.randint(0, 256 - cropsize), random.randint(0, 448 - cropsize), random.random(), random.random()
+                    tmp = random.random()
+                    tag = "zero" if tmp < 0.01 else "hi" if tmp < 0.2 else "uni"
+                elif np.all(q == q[:1]):
+                    tag = "grad"
+                elif np.all(q == q[:, :1]):
+                    tag = "gradT"
+                else:
+                    tag = "gauss"
+                if want.get(tag, 0) > 0:
+                    want[tag] -= 1
+                    kept.append((seed, tag, top, left, order, q))
+            assert not any(want.values()), want
+            key = "train" if training else "test"
+            d[f"{key}:seeds"] = np.array([k[0] for k in kept])
+            d[f"{key}:tags"] = np.array([k[1] for k in kept])
+            d[f"{key}:top_left"] = np.array([[k[2], k[3]] for k in kept])
+            d[f"{key}:order"] = np.array([k[4] for k in kept])
+            d[f"{key}:qmap"] = np.stack([k[5] for k in kept]).astype(np.float32)
+        d["cfg"] = np.array([cropsize, 256, 448, 37])
+        save("roi_dataset.npz", d)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     scratch, ref_utils = import_reference()
     try:
-        which = sys.argv[1:] or ["ops", "codec", "fwd", "train_small", "train_big", "stemcodec", "roi", "roiops", "roigop", "container"]
+        which = sys.argv[1:] or ["ops", "codec", "fwd", "train_small", "train_big", "stemcodec", "roi", "roiops", "roigop", "container", "dataset"]
         if "ops" in which:
             gen_ops(ref_utils)
         if "codec" in which:
@@ -625,5 +701,7 @@ if __name__ == "__main__":
             gen_stem_roi_gop(ref_utils)
         if "container" in which:
             gen_container(ref_utils)
+        if "dataset" in which:
+            gen_roi_dataset(ref_utils)
     finally:
         shutil.rmtree(scratch, ignore_errors=True)
