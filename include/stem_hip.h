@@ -260,6 +260,8 @@ int stem_sumsq(const float *g, size_t n, double *acc, void *stream);
 /* stand-alone torch.nn.utils.clip_grad_norm_ (stem_roi/train_stem_roi.py:536,563 clips once per frame while gradients
  * accumulate over the GOP): g *= min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)); sumsq may span several buffers. */
 int stem_clip_scale(float *g, size_t n, const double *sumsq, float max_norm, void *stream);
+/* y += a * x on flat buffers (running GOP gradient += 1/world * all-reduced frame gradient) */
+int stem_axpy(float *y, const float *x, float a, size_t n, void *stream);
 /* torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step fused over a flat buffer:
  * scale = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) (max_norm <= 0: no clipping), g *= scale * gscale. */
 int stem_adam_step(float *p, const float *g, float *m, float *v, size_t n, const double *sumsq, float max_norm,

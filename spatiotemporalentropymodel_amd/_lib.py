@@ -77,6 +77,7 @@ _HIP_SIG = {
     "stem_ar_finish_encode_wave": [vp, vp, ci, cf, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "stem_sumsq": [vp, sz, vp, vp],
     "stem_clip_scale": [vp, sz, vp, cf, vp],
+    "stem_axpy": [vp, vp, cf, sz, vp],
     "stem_adam_step": [vp, vp, vp, vp, sz, vp, cf, cf, cf, cf, cf, cf, ci, vp],
     "stem_packed_weight_elems": [ci, ci, ci, ci, ci],
     "stem_abi_version": [],

@@ -54,6 +54,12 @@ __global__ __launch_bounds__(256) void clip_scale_kernel(float *g, size_t n, con
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) g[i] *= coef;
 }
 
+// y += a * x (gradient accumulation across the frames of a GOP in the data-parallel variable-rate loop)
+__global__ __launch_bounds__(256) void axpy_kernel(float *y, const float *x, float a, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] += a * x[i];
+}
+
 }   // namespace
 
 STEM_EXPORT int stem_sumsq(const float *g, size_t n, double *acc, void *stream)
@@ -92,5 +98,16 @@ STEM_EXPORT int stem_clip_scale(float *g, size_t n, const double *sumsq, float m
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(clip_scale_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, g, n, sumsq, max_norm);
     STEM_LAUNCH_CHECK("clip_scale");
+    return 0;
+}
+
+STEM_EXPORT int stem_axpy(float *y, const float *x, float a, size_t n, void *stream)
+{
+    STEM_CHECK_ARG(y && x, "stem_axpy: null pointer");
+    if (n == 0) return 0;
+    size_t nb = cdivz(n, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, y, x, a, n);
+    STEM_LAUNCH_CHECK("axpy");
     return 0;
 }

@@ -571,6 +571,11 @@ def clip_scale(g, sumsq_acc, max_norm):
     _chk(_lib.hip().stem_clip_scale(g.data_ptr(), g.numel(), sumsq_acc.data_ptr(), float(max_norm), _stream()))
 
 
+def axpy_(y, x, a):
+    _chk(_lib.hip().stem_axpy(y.data_ptr(), x.data_ptr(), float(a), y.numel(), _stream()))
+    return y
+
+
 def adam_step(p, g, m, v, sumsq_acc, max_norm, gscale, lr, beta1, beta2, eps, step):
     _chk(_lib.hip().stem_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), _ptr(sumsq_acc),
                                    max_norm, gscale, lr, beta1, beta2, eps, step, _stream()))

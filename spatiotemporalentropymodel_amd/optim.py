@@ -86,18 +86,20 @@ class FusedClipAdam:
         self.param_groups[0]["lr"] = self.lr
 
 
-def clip_grad_norm_(optimizers, max_norm):
+def clip_grad_norm_(optimizers, max_norm, tensors=None):
     """torch.nn.utils.clip_grad_norm_ over the union of the optimisers' flat gradient buffers, without a host sync:
     one reduction per buffer into a shared fp64 accumulator, then one scaling pass per buffer.  Returns the norm
     before clipping as a 0-dim device tensor.  (The variable-rate training loop clips after every frame while the
-    gradients of a GOP keep accumulating: stem_roi/train_stem_roi.py:536,563.)"""
+    gradients of a GOP keep accumulating: stem_roi/train_stem_roi.py:536,563.)  `tensors` overrides which flat
+    buffers are clipped (the data-parallel loop clips the running global sums, distributed.GopGradAccumulator)."""
     optimizers = [o for o in optimizers if o is not None]
+    bufs = list(tensors) if tensors is not None else [o.flat.grad for o in optimizers]
     acc = optimizers[0]._sumsq
     acc.zero_()
-    for o in optimizers:
-        F.sumsq(o.flat.grad, acc)
-    for o in optimizers:
-        F.clip_scale(o.flat.grad, acc, max_norm)
+    for g in bufs:
+        F.sumsq(g, acc)
+    for g in bufs:
+        F.clip_scale(g, acc, max_norm)
     return acc.sqrt().reshape(())
 
 

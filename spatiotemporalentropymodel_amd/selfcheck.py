@@ -63,8 +63,7 @@ def p_frame_step(imodel, stem, criterion, optimizer, aux_optimizer, x, y_cond, g
     return out, oc, aux, gn
 
 
-def roi_gop_step(imodel, pmodel, criterion, optimizers, frames, qmap, clip_max_norm=1.0, max_loss=None, grad_scale=1.0,
-                 reducer=None):
+def roi_gop_step(imodel, pmodel, criterion, optimizers, frames, qmap, clip_max_norm=1.0, max_loss=None, accumulator=None):
     """One GOP iteration of the variable-rate training loop, stem_roi/train_stem_roi.py:509-631:
 
         zero all four gradients; lmbdamap = quality2lambda(Qmap)
@@ -77,12 +76,17 @@ def roi_gop_step(imodel, pmodel, criterion, optimizers, frames, qmap, clip_max_n
     clipped right after its own frame's backward.  `optimizers` = (opt_i, aux_i, opt_p, aux_p) from configure_optimizers
     (max_norm=None).  `max_loss` reproduces the script's "skip invalid loss" break (NaN/Inf/loss > max_loss; costs a host
     sync per frame; upstream compares the I frame against the previous GOP's P loss, here each frame checks its own).
+    `accumulator` (distributed.GopGradAccumulator over the four flat buffers) makes the loop data parallel: the frame
+    gradient is all-reduced before it joins the running sum that gets clipped.
     Returns the per-frame criterion dictionaries, clip norms and aux losses."""
     from .losses import quality2lambda
     from .optim import clip_grad_norm_
     opt_i, aux_i, opt_p, aux_p = optimizers
-    for o in optimizers:
-        o.zero_grad()
+    if accumulator is not None:
+        accumulator.begin()
+    else:
+        for o in optimizers:
+            o.zero_grad()
     lmbdamap = quality2lambda(qmap)
     log, x_cond = [], None
     for idx, x in enumerate(frames):
@@ -95,14 +99,21 @@ def roi_gop_step(imodel, pmodel, criterion, optimizers, frames, qmap, clip_max_n
             if not np.isfinite(lv) or lv > max_loss:
                 break
         oc["loss"].backward(retain_graph=True)
-        gn = clip_grad_norm_(opts, clip_max_norm) if clip_max_norm and clip_max_norm > 0 else None
+        gn = None
+        if accumulator is not None:
+            accumulator.end_frame()
+        if clip_max_norm and clip_max_norm > 0:
+            bufs = [accumulator.running(o.flat) for o in opts] if accumulator is not None else None
+            gn = clip_grad_norm_(opts, clip_max_norm, tensors=bufs)
         aux = model.aux_loss()
         aux.backward()
+        if accumulator is not None:
+            accumulator.end_aux()
         log.append((oc, gn, aux))
-    if reducer is not None:
-        reducer.all_reduce()
+    if accumulator is not None:
+        accumulator.finish()
     for o in optimizers:
-        o.step(grad_scale)
+        o.step()
     return log
 
 

@@ -154,3 +154,77 @@ def test_overlapped_group_reducer_world2_gloo():
     for r in (0, 1):
         assert res[r]["ok"], "every element must be summed exactly once"
         assert res[r]["runs"] and res[r]["calls"] == 6 and res[r]["scale"] == 0.5
+
+
+class _Flat:
+    """Minimal stand-in for optim.FlatParameters (grad buffer + zero_grad) so the accumulator logic runs on CPU."""
+
+    def __init__(self, n):
+        self.grad = torch.zeros(n)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+def _clip(bufs, max_norm):
+    total = torch.sqrt(sum((b.double() ** 2).sum() for b in bufs))
+    coef = min(1.0, max_norm / (float(total) + 1e-6))
+    for b in bufs:
+        b.mul_(coef)
+    return float(total)
+
+
+def _gop_reference(frame_grads, aux_grads, max_norm):
+    """Single-process semantics (train_stem_roi.py:533-541): G += g_t; clip(G, Gaux); Gaux += a_t."""
+    G, A = torch.zeros_like(frame_grads[0]), torch.zeros_like(aux_grads[0])
+    norms = []
+    for g, a in zip(frame_grads, aux_grads):
+        G += g
+        norms.append(_clip([G, A], max_norm))
+        A += a
+    return G, A, norms
+
+
+def _worker_gop(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, REPO)
+    torch.set_num_threads(2)
+    from spatiotemporalentropymodel_amd import distributed as D
+    D.init_from_env(backend="gloo")
+    gen = torch.Generator().manual_seed(7)
+    T, n, na = 4, 1003, 48
+    per_rank = [[torch.randn(n, generator=gen) * (3.0 if t == 1 else 0.3) for _ in range(world)] for t in range(T)]
+    aux = [torch.randn(na, generator=gen) * 0.2 for _ in range(T)]
+    main, side = _Flat(n), _Flat(na)
+    acc = D.GopGradAccumulator([main], [side])
+    acc.begin()
+    norms = []
+    for t in range(T):
+        main.grad += per_rank[t][rank]                       # "backward" of frame t on this rank's samples
+        acc.end_frame()
+        norms.append(_clip([acc.running(main), acc.running(side)], 1.0))
+        side.grad += aux[t]                                  # aux loss: parameters only, identical on every rank
+        acc.end_aux()
+    acc.finish()
+    G, A, ref_norms = _gop_reference([sum(per_rank[t]) / world for t in range(T)], aux, 1.0)
+    ok = bool(torch.allclose(main.grad, G, rtol=1e-6, atol=1e-7)) and bool(torch.allclose(side.grad, A, rtol=1e-6, atol=1e-7))
+    q.put((rank, {"ok": ok, "norms": bool(np.allclose(norms, ref_norms, rtol=1e-6)), "clipped": sum(v > 1.0 for v in ref_norms)}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_gop_gradient_accumulator_world2_gloo():
+    """Per-frame exchange + clip of the running sum == the single-process full-batch loop (variable-rate training)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_gop, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=500) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert res[r]["ok"] and res[r]["norms"] and res[r]["clipped"] >= 2, res

@@ -222,9 +222,12 @@ def test_roi_codec_roundtrip_and_rate(golden):
             pmodel.decompress(enc_p["strings"], enc_p["shape"])
 
 
-def test_roi_gop_training_iteration_matches_reference(golden):
+@pytest.mark.parametrize("data_parallel", [False, True])
+def test_roi_gop_training_iteration_matches_reference(golden, data_parallel):
     """A whole GOP iteration (I + 2 P frames) with clipping after every frame and one Adam step of the four optimisers:
-    accumulated gradients, clip norms, aux losses and the stepped parameters vs the reference run."""
+    accumulated gradients, clip norms, aux losses and the stepped parameters vs the reference run.  data_parallel runs
+    the same iteration through distributed.GopGradAccumulator (world 1: the exchange is the identity), i.e. frame
+    gradients are built in zeroed buffers and folded into running sums that get clipped."""
     import types
     from spatiotemporalentropymodel_amd.losses import PixelwiseRateDistortionLoss
     from spatiotemporalentropymodel_amd.models import stem_roi, stem_roi_i
@@ -259,7 +262,12 @@ def test_roi_gop_training_iteration_matches_reference(golden):
         def step(self, *_):
             pass
 
-    log = roi_gop_step(imodel, pmodel, PixelwiseRateDistortionLoss(), tuple(_NoStep(o) for o in opts), frames, qmap, 1.0)
+    acc = None
+    if data_parallel:
+        from spatiotemporalentropymodel_amd.distributed import GopGradAccumulator
+        acc = GopGradAccumulator([opts[0].flat, opts[2].flat], [opts[1].flat, opts[3].flat])
+    log = roi_gop_step(imodel, pmodel, PixelwiseRateDistortionLoss(), tuple(_NoStep(o) for o in opts), frames, qmap, 1.0,
+                       accumulator=acc)
     assert len(log) == nframes
     for (oc, gn, aux), ref in zip(log, g["scalars"]):
         got = [float(oc["loss"].detach()), float(oc["mse_loss"].detach()), float(oc["bpp_loss"].detach()), float(gn), float(aux.detach())]
