@@ -413,12 +413,12 @@ int run(const float *p, int ldp, int CP, const float *g, int ldg, int CG, float 
 // Bias gradient db[k] = sum_m dy[m][k] in two deterministic stages (no float atomics): `parts` pixel ranges x 64-channel
 // tiles write partial column sums, then the partials are added in a fixed order.  HBM-bound (dy is read once, 16-byte
 // loads, 4 rows in flight per thread); parts is sized so that the launch has ~2048 workgroups.
-constexpr int CS_MAX_PARTS = 1024;
+constexpr int CS_MAX_PARTS = 512;
 
 inline int colsum_parts(size_t npix, int K)
 {
     const int kt = cdiv(K, 64);
-    long parts = 2048 / kt;
+    long parts = 1536 / kt;
     const long by_rows = (long)((npix + 127) / 128);        // >= 128 rows per part
     if (parts > by_rows) parts = by_rows;
     if (parts > CS_MAX_PARTS) parts = CS_MAX_PARTS;
@@ -463,18 +463,20 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *dy, in
         part[(size_t)blockIdx.y * K + blockIdx.x * 64 + threadIdx.x] = t;
     }
 }
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float *part, int K, int parts, float *out, int accumulate)
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float *part, int K, int parts, float *out, int accumulate)
 {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;          // 16 row groups x 64 channels
     const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
     if (c < K)
-        for (int p = r; p < parts; p += 4) s += part[(size_t)p * K + c];
+        for (int p = r; p < parts; p += 16) s += part[(size_t)p * K + c];
     red[r][lane] = s;
     __syncthreads();
     if (r == 0 && c < K) {
-        const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += red[q][lane];
         out[c] = accumulate ? out[c] + v : v;
     }
 }
@@ -488,7 +490,7 @@ int colsum(const float *dy, int ld, size_t npix, int K, float *scratch, float *d
     else
         hipLaunchKernelGGL((colsum_partial_kernel<false>), dim3(cdiv(K, 64), parts), dim3(256), 0, st, dy, ld, npix, K, parts, scratch);
     STEM_LAUNCH_CHECK("colsum_partial");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(K, 64)), dim3(256), 0, st, scratch, K, parts, db, accumulate);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(K, 64)), dim3(1024), 0, st, scratch, K, parts, db, accumulate);
     STEM_LAUNCH_CHECK("colsum_final");
     return 0;
 }

@@ -116,6 +116,8 @@ class ConvTranspose2dFunction(torch.autograd.Function):
         xin, weight, y = ctx.saved_tensors
         Cc, K, R, S = weight.shape
         dy = F.to_nhwc(dy)
+        if K == 3 and not act and R * S <= 32:
+            return ConvTranspose2dFunction._backward_rgb(ctx, dy)
         if F.nhwc_ld(dy) != K:
             dy = F.copy_channels(dy, F.empty_nhwc(*dy.shape, dy.device))
         if act:
@@ -131,6 +133,29 @@ class ConvTranspose2dFunction(torch.autograd.Function):
                 F.deconv2d_wgrad(xin, dy, K, R, S, stride, pad, opad, dw_out=gw, db_out=gb, need_db=need_db, accumulate=True)
             else:
                 dw, db = F.deconv2d_wgrad(xin, dy, K, R, S, stride, pad, opad, need_db=need_db)
+        return dx, dw, db, None, None, None, None, None, None
+
+    @staticmethod
+    def _backward_rgb(ctx, dy):
+        """The synthesis transform's last layer (-> 3 image channels): the image gradient is padded to 4 channels so that
+        the input gradient is the 4-channel-input convolution kernel (it IS Conv2d(weight [C,3,R,S], stride, pad) applied
+        to dY) and the weight gradient uses the folded-tap mode, instead of 3-wide operands in 64-wide MFMA tiles."""
+        stride, pad, opad, act, cache, xshape, slope = ctx.cfg
+        xin, weight, _ = ctx.saved_tensors
+        Cc, K, R, S = weight.shape
+        B, _, Ho, Wo = dy.shape
+        dy4 = torch.zeros((B, Ho, Wo, 4), device=dy.device, dtype=torch.float32)
+        F.copy_channels(dy, dy4.permute(0, 3, 1, 2)[:, :3])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = F.conv2d_fwd_c4(dy4, cache.get(weight, F.PACK_CONV_FWD_C4), None, Cc, R, S, stride, pad)
+            assert tuple(dx.shape) == tuple(xshape), (dx.shape, xshape)
+        dw = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            need_db = bool(ctx.needs_input_grad[2])
+            dw4, db4 = F.deconv2d_wgrad(xin, dy4.permute(0, 3, 1, 2), 4, R, S, stride, pad, opad, need_db=need_db)
+            dw = dw4[:, :3].contiguous()
+            db = db4[:3].contiguous() if need_db else None
         return dx, dw, db, None, None, None, None, None, None
 
 

@@ -68,6 +68,8 @@ def test_avgpool_forward_backward_vs_oracle(F, shape, out):
     (192, 128, 3, 2, True, 8),            # qmap_feature_gs1.0: 3x3 stride-2 transposed
     (128, 192, 1, 1, False, 8),           # qmap_feature_ga4.2
     (3, 128, 5, 2, False, 32),            # ConditionEncoder.0 with a gradient w.r.t. the image
+    (128, 3, 5, 2, True, 16),             # gs4: synthesis output layer, backward through the padded-RGB fast path
+    (32, 3, 3, 2, True, 7),               # same path, odd sizes
 ])
 def test_roi_layer_shapes_vs_oracle(cfg):
     from spatiotemporalentropymodel_amd.layers import conv, deconv
