@@ -233,6 +233,7 @@ UNPACK_DECONV, UNPACK_ACCUMULATE = 1, 2
 def _wgrad_workspace(key, elems, device):
     """Slab / partial-sum / gather-table scratch of one layer geometry.  Kernels of a stream are ordered, so every layer
     with this geometry shares the buffer, and its gather table (a function of the geometry only) is built once."""
+    key = key + (_stream(),)                 # one buffer per launching stream: ordering is only guaranteed within a stream
     hit = _WGRAD_WS.get(key)
     if hit is not None and hit.numel() >= elems:
         return hit, True

@@ -52,6 +52,42 @@ def _flat_grad(p):
     return view if view is not None and p.grad is view else None
 
 
+# Weight gradients are off the critical path of back-propagation (nothing downstream consumes them), so when they are
+# accumulated straight into a flat gradient buffer they are launched on a side stream: the many small layers of the
+# variable-rate models (16x16 .. 4x4 feature maps) then overlap their latency-bound wgrad / column-sum / unpack kernels
+# with the dgrad chain.  All weight-gradient work shares that one stream (ordered among itself, so the shared
+# geometry-keyed workspaces and repeated accumulation into one parameter stay race-free); the compute stream re-joins
+# at the end of every backward pass (autograd engine callback) and wherever gradients are consumed (optim.py).
+_WGRAD_SIDE = {"enabled": True, "streams": {}, "queued": False}
+
+
+def wgrad_side_stream(device):
+    st = _WGRAD_SIDE["streams"].get(device)
+    if st is None:
+        st = _WGRAD_SIDE["streams"][device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_wgrad_stream():
+    """Order all outstanding side-stream weight-gradient work before whatever the current stream does next."""
+    _WGRAD_SIDE["queued"] = False
+    for dev, st in _WGRAD_SIDE["streams"].items():
+        torch.cuda.current_stream(dev).wait_stream(st)
+
+
+def _on_side_stream(fn, *tensors):
+    dev = tensors[0].device
+    side = wgrad_side_stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        fn()
+    for t in tensors:
+        t.record_stream(side)
+    if not _WGRAD_SIDE["queued"]:
+        _WGRAD_SIDE["queued"] = True
+        torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)
+
+
 # ----------------------------------------------------------------------------- autograd functions
 class Conv2dFunction(torch.autograd.Function):
     @staticmethod
@@ -91,7 +127,9 @@ class Conv2dFunction(torch.autograd.Function):
             need_db = bool(ctx.needs_input_grad[2])
             gw, gb = _flat_grad(ctx.params[0]), (_flat_grad(ctx.params[1]) if need_db else None)
             if gw is not None and (gb is not None or not need_db) and not (first and Cc == 3):
-                F.conv2d_wgrad(xin, dy, K, R, S, stride, pad, dw_out=gw, db_out=gb, need_db=need_db, accumulate=True)
+                def run():
+                    F.conv2d_wgrad(xin, dy, K, R, S, stride, pad, dw_out=gw, db_out=gb, need_db=need_db, accumulate=True)
+                _on_side_stream(run, dy, xin) if _WGRAD_SIDE["enabled"] else run()
             else:
                 dw, db = F.conv2d_wgrad(xin, dy, K, R, S, stride, pad, need_db=need_db)
                 if first and Cc == 3:
@@ -130,7 +168,9 @@ class ConvTranspose2dFunction(torch.autograd.Function):
             need_db = bool(ctx.needs_input_grad[2])
             gw, gb = _flat_grad(ctx.params[0]), (_flat_grad(ctx.params[1]) if need_db else None)
             if gw is not None and (gb is not None or not need_db):
-                F.deconv2d_wgrad(xin, dy, K, R, S, stride, pad, opad, dw_out=gw, db_out=gb, need_db=need_db, accumulate=True)
+                def run():
+                    F.deconv2d_wgrad(xin, dy, K, R, S, stride, pad, opad, dw_out=gw, db_out=gb, need_db=need_db, accumulate=True)
+                _on_side_stream(run, dy, xin) if _WGRAD_SIDE["enabled"] else run()
             else:
                 dw, db = F.deconv2d_wgrad(xin, dy, K, R, S, stride, pad, opad, need_db=need_db)
         return dx, dw, db, None, None, None, None, None, None

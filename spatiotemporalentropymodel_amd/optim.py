@@ -11,7 +11,7 @@ from __future__ import annotations
 import torch
 
 from . import functional as F
-from .layers import bump_weight_epoch
+from .layers import bump_weight_epoch, join_wgrad_stream
 
 
 class FlatParameters:
@@ -37,6 +37,7 @@ class FlatParameters:
         bump_weight_epoch()
 
     def zero_grad(self):
+        join_wgrad_stream()
         self.grad.zero_()
         for p in self.params:
             p.grad = p._flat_grad_view
@@ -59,12 +60,14 @@ class FusedClipAdam:
 
     def grad_norm(self):
         """Global L2 norm of the current flat gradient as a 0-dim device tensor (no host sync)."""
+        join_wgrad_stream()
         self._sumsq.zero_()
         F.sumsq(self.flat.grad, self._sumsq)
         return self._sumsq.sqrt().reshape(())
 
     def step(self, grad_scale: float = 1.0):
         """grad_scale multiplies the gradient first (1/world_size after a sum all-reduce)."""
+        join_wgrad_stream()
         self.t += 1
         self.lr = self.param_groups[0]["lr"]
         use_clip = self.max_norm is not None and self.max_norm > 0
@@ -92,6 +95,7 @@ def clip_grad_norm_(optimizers, max_norm, tensors=None):
     before clipping as a 0-dim device tensor.  (The variable-rate training loop clips after every frame while the
     gradients of a GOP keep accumulating: stem_roi/train_stem_roi.py:536,563.)  `tensors` overrides which flat
     buffers are clipped (the data-parallel loop clips the running global sums, distributed.GopGradAccumulator)."""
+    join_wgrad_stream()
     optimizers = [o for o in optimizers if o is not None]
     bufs = list(tensors) if tensors is not None else [o.flat.grad for o in optimizers]
     acc = optimizers[0]._sumsq
