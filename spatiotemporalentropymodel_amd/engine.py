@@ -64,7 +64,19 @@ class _Layer:
 
     def wgrad(self, x, dy):
         """packed slabs now, bias gradient straight into .grad; StemEngine.unpack_all() turns every layer's
-        slabs into .grad tensors with one launch."""
+        slabs into .grad tensors with one launch.  Runs on the engine's weight-gradient stream (nothing on the dgrad
+        chain consumes it), ordered after everything the compute stream has queued so far."""
+        side = self.eng.side_stream(x.device)
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):
+                self._wgrad(x, dy)
+            x.record_stream(side)
+            dy.record_stream(side)
+        else:
+            self._wgrad(x, dy)
+
+    def _wgrad(self, x, dy):
         m = self.mod
         gb = _grad_of(m.bias)
         deconv = self.kind == "deconv"
@@ -115,6 +127,18 @@ class StemEngine:
             first.need_dgrad = False
         self._pack_key = None
         self._pack_descs = None
+        self._side = None
+
+    #: weight gradients (wgrad + bias column sums + unpack + the data-parallel exchange hook) run on their own stream
+    #: and overlap the latency-bound parts of the dgrad chain; set False to keep everything on the compute stream
+    overlap_wgrad = True
+
+    def side_stream(self, device):
+        if not self.overlap_wgrad or device.type != "cuda":
+            return None
+        if self._side is None or self._side.device != device:
+            self._side = torch.cuda.Stream(device=device)
+        return self._side
 
     def ensure_packed(self):
         """(Re)build every layer's packed weight copies with ONE kernel launch when any weight changed."""
@@ -140,6 +164,16 @@ class StemEngine:
     grad_ready_hook = None
 
     def _group_ready(self, layers, extra_params):
+        dev = layers[0].mod.weight.device
+        side = self.side_stream(dev)
+        if side is None:
+            return self._group_ready_on_stream(layers, extra_params)
+        # extra_params (entropy-bottleneck gradients) were produced on the compute stream: order them before the hook
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            self._group_ready_on_stream(layers, extra_params)
+
+    def _group_ready_on_stream(self, layers, extra_params):
         descs = [l.unpack_desc() for l in layers if l.pending is not None]
         if descs:
             arr = (_lib.UnpackDesc * len(descs))(*descs)
@@ -148,6 +182,10 @@ class StemEngine:
             params = [p for l in layers for p in (l.mod.weight, l.mod.bias) if p is not None] + list(extra_params)
             if params:
                 self.grad_ready_hook(params)
+
+    def join_side_stream(self):
+        if self._side is not None:
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
 
     # -------------------------------------------------------------------------------------------
     def forward(self, y_cur, y_cond, training: bool):
@@ -255,6 +293,7 @@ class StemEngine:
         d = self.HE[1].dgrad(d, k["he0"].shape, xact=k["he0"])
         self.HE[0].wgrad(k["he_in"], d)
         self._group_ready(self.HE, [])
+        self.join_side_stream()          # gradients are complete for whatever the compute stream does next
 
 
 class StemFunction(torch.autograd.Function):
