@@ -240,6 +240,14 @@ int stem_ar_finish_encode(const float *gp, const float *table, int T, float scal
                           int32_t *sym, int32_t *idx, int M, void *stream);
 int stem_ar_index(const float *gp, const float *table, int T, float scale_bound, int32_t *idx, int M, void *stream);
 int stem_ar_finish_decode(const float *gp, const int32_t *sym, float *pix, int M, void *stream);
+/* Decoder variants of stem_gemv3 (two launches fewer per position).  sym_prev != NULL: workgroup 0 writes the previous
+ * position's y_hat = sym_prev + mean_prev to pix_prev, and with prev_is_left the second half of segment 2 (the left
+ * neighbour, len2 == 2M) is taken from (sym_prev, mean_prev) instead of memory.  table != NULL: outputs n < M are also
+ * turned into CDF indexes idx[n] (build_indexes, entropy_models.py:556-562).  sym_prev / idx may be pinned host memory. */
+int stem_gemv3_decode(const float *W, int ldw, const float *bias, const float *x0, int len0, int woff0,
+                      const float *x1, int len1, int woff1, const float *x2, int len2, int woff2, float *y, int N,
+                      int act, float slope, const int32_t *sym_prev, const float *mean_prev, float *pix_prev, int M,
+                      int prev_is_left, const float *table, int T, float scale_bound, int32_t *idx, void *stream);
 
 /* Wavefront-parallel encoder: all latent positions with the same t = w + 3h are independent under the 5x5
  * type-A mask, so a H x W frame is coded in W + 3(H-1) batched steps instead of H*W sequential ones.  Input

@@ -47,6 +47,64 @@ __global__ __launch_bounds__(256) void gemv3_kernel(const float *W, int ldw, con
     }
 }
 
+// Decoder variants of the product (two launches fewer per position):
+//   head: the previous position's y_hat = symbol + mean is written back to the latent buffer by workgroup 0 and, when that
+//         pixel is the left neighbour inside this window, every wavefront substitutes it on the fly for the (not yet
+//         visible) buffer contents -- segment 2 is [pixel w-2 | pixel w-1];
+//   tail: the last product also turns each scale into its CDF index (written to the pinned host mailbox).
+struct DecodeExtra {
+    const int32_t *sym_prev;   // null: plain product
+    const float *mean_prev;    // gp + M of the previous position
+    float *pix_prev;           // where its y_hat goes in the latent buffer
+    int M, prev_is_left;
+    const float *table;        // null: no index epilogue
+    int T;
+    float bound;
+    int32_t *idx;
+};
+
+__global__ __launch_bounds__(256) void gemv3_decode_kernel(const float *W, int ldw, const float *bias, Seg s0, Seg s1, Seg s2,
+                                                           float *y, int N, int act, float slope, DecodeExtra e)
+{
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e.sym_prev && blockIdx.x == 0)
+        for (int c = threadIdx.x; c < e.M; c += 256) e.pix_prev[c] = (float)e.sym_prev[c] + e.mean_prev[c];
+    if (n >= N) return;
+    const float *wr = W + (size_t)n * ldw;
+    float acc = 0.f;
+    const Seg segs[3] = {s0, s1, s2};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const Seg s = segs[q];
+        const bool subst = q == 2 && e.sym_prev && e.prev_is_left;
+        for (int k = lane * 4; k < s.len; k += 256) {
+            f32x4 xv;
+            if (subst && k >= e.M) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xv[j] = (float)e.sym_prev[k - e.M + j] + e.mean_prev[k - e.M + j];
+            } else {
+                xv = *reinterpret_cast<const f32x4 *>(s.x + k);
+            }
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(wr + s.woff + k);
+            acc += xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) {
+        float v = acc + (bias ? bias[n] : 0.f);
+        if (act == STEM_ACT_LRELU) v = v > 0.f ? v : v * slope;
+        y[n] = v;
+        if (e.table && n < e.M) {
+            const float sc = fmaxf(v, e.bound);
+            int k = e.T - 1;
+            for (int t = 0; t < e.T - 1; ++t) k -= (sc <= e.table[t]) ? 1 : 0;
+            e.idx[n] = k;
+        }
+    }
+}
+
 // encode side: index = build_indexes(scale), symbol = round(target - mean), buffer <- symbol + mean
 __global__ void ar_finish_encode_kernel(const float *gp, const float *table, int T, float scale_bound, float *pix,
                                         int32_t *sym, int32_t *idx, int M)
@@ -102,6 +160,22 @@ STEM_EXPORT int stem_gemv3(const float *W, int ldw, const float *bias, const flo
     STEM_CHECK_ARG(seg_ok(s0) && seg_ok(s1) && seg_ok(s2), "stem_gemv3: segments must be 16-byte aligned multiples of 4 floats");
     hipLaunchKernelGGL(gemv3_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, W, ldw, bias, s0, s1, s2, y, N, act, slope);
     STEM_LAUNCH_CHECK("gemv3");
+    return 0;
+}
+
+STEM_EXPORT int stem_gemv3_decode(const float *W, int ldw, const float *bias, const float *x0, int len0, int woff0,
+                                  const float *x1, int len1, int woff1, const float *x2, int len2, int woff2, float *y, int N,
+                                  int act, float slope, const int32_t *sym_prev, const float *mean_prev, float *pix_prev, int M,
+                                  int prev_is_left, const float *table, int T, float scale_bound, int32_t *idx, void *stream)
+{
+    STEM_CHECK_ARG(W && y && N > 0 && ldw % 4 == 0 && (((uintptr_t)W & 15) == 0) && M % 4 == 0, "stem_gemv3_decode: bad arguments");
+    Seg s0{x0, len0, woff0}, s1{x1, len1, woff1}, s2{x2, len2, woff2};
+    STEM_CHECK_ARG(seg_ok(s0) && seg_ok(s1) && seg_ok(s2), "stem_gemv3_decode: segments must be 16-byte aligned multiples of 4 floats");
+    STEM_CHECK_ARG(!sym_prev || (mean_prev && pix_prev && (!prev_is_left || len2 == 2 * M)), "stem_gemv3_decode: inconsistent write-back arguments");
+    STEM_CHECK_ARG(!table || (idx && T >= 1 && M <= N), "stem_gemv3_decode: inconsistent index arguments");
+    DecodeExtra e{sym_prev, mean_prev, pix_prev, M, prev_is_left, table, T, scale_bound, idx};
+    hipLaunchKernelGGL(gemv3_decode_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, W, ldw, bias, s0, s1, s2, y, N, act, slope, e);
+    STEM_LAUNCH_CHECK("gemv3_decode");
     return 0;
 }
 
