@@ -9,10 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spatiotemporalentropymodel_amd import functional as F  # noqa: E402
 from spatiotemporalentropymodel_amd import _lib  # noqa: E402
 
-SHAPES = [(8, 4, 256, 256, 192, 3, 1), (8, 4, 256, 256, 128, 5, 2), (8, 128, 128, 128, 128, 3, 1)]
-SHAPES_OLD = [(8, 128, 128, 128, 128, 3, 1), (8, 192, 256, 256, 160, 3, 1), (8, 160, 256, 256, 128, 3, 1), (8, 128, 64, 64, 128, 3, 1),
-          (8, 128, 32, 32, 128, 3, 1), (8, 128, 16, 16, 192, 3, 1), (8, 192, 16, 16, 192, 3, 1), (16, 256, 16, 16, 320, 5, 1),
-          (16, 192, 64, 64, 192, 5, 2), (16, 1152, 16, 16, 768, 1, 1)]
+SHAPES = [(8, 128, 128, 128, 128, 3, 1), (8, 192, 256, 256, 160, 3, 1), (8, 160, 256, 256, 128, 3, 1), (8, 128, 64, 64, 128, 3, 1),
+          (8, 128, 32, 32, 128, 3, 1), (8, 128, 16, 16, 192, 3, 1), (8, 192, 16, 16, 192, 3, 1), (8, 4, 256, 256, 192, 3, 1),
+          (16, 256, 16, 16, 320, 5, 1), (16, 192, 64, 64, 192, 5, 2), (16, 1152, 16, 16, 768, 1, 1)]
 for (B, C, H, W, K, R, st) in SHAPES:
     pd = R // 2
     x = torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
