@@ -69,6 +69,10 @@ int stem_unpack_wgrads_multi(const stem_unpack_desc *descs, int n, void *stream)
 
 /* ---- epilogues --------------------------------------------------------- */
 enum { STEM_ACT_NONE = 0, STEM_ACT_LRELU = 1 };
+/* OR into `act` of stem_conv2d_fwd (and into `kind` of stem_conv_workspace_bytes): the weight is a type-A MaskedConv2d
+ * (compressai/layers/layers.py:39-42), whose taps at row > R/2 or (row == R/2, col >= S/2) are zero -- the kernel skips
+ * them (12 of 25 for the 5x5 context model) instead of multiplying zeros. */
+#define STEM_CONV_MASKED_A 0x100
 
 /* Split-K workspace.  Layers whose output is too small to fill 256 CUs (the 16x16 / 8x8 / 4x4 STEM latents)
  * split their reduction over taps x channels across workgroups; the fp32 partial tiles go to `ws` and a second

@@ -841,10 +841,13 @@ void fill_geometry(IgemmArgs &g, int kind, int B, int H, int W, int C, int K, in
 
 STEM_EXPORT size_t stem_conv_workspace_bytes(int kind, int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad)
 {
+    const bool masked = (kind & STEM_CONV_MASKED_A) != 0;
+    kind &= ~STEM_CONV_MASKED_A;
     if (kind < 0 || kind > 3 || B <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R * S > 25 || R < 1 || S < 1) return 0;
     IgemmArgs g;
     fill_geometry(g, kind, B, H, W, C, K, R, S, stride, pad, opad);
     if (g.OH <= 0 || g.OW <= 0) return 0;
+    if (masked && kind == KIND_CONV_FWD) g.ph[0].ntaps = (R / 2) * S + S / 2;
     return make_plan(g, false).ws_bytes;
 }
 
@@ -856,6 +859,11 @@ STEM_EXPORT int stem_conv2d_fwd(const float *x, int ldx, const float *wp, const 
     IgemmArgs g;
     fill_geometry(g, KIND_CONV_FWD, B, H, W, C, K, R, S, stride, pad, 0);
     STEM_CHECK_ARG(g.OH > 0 && g.OW > 0, "stem_conv2d_fwd: empty output");
+    if (act & STEM_CONV_MASKED_A) {      // type-A mask: the live taps are the first (R/2)*S + S/2 in raster order
+        g.ph[0].ntaps = (R / 2) * S + S / 2;
+        STEM_CHECK_ARG(g.ph[0].ntaps >= 1, "stem_conv2d_fwd: a masked 1x1 convolution has no live tap");
+        act &= ~STEM_CONV_MASKED_A;
+    }
     g.x = x; g.w = wp; g.bias = bias; g.y = y;
     g.ldx = ldx; g.ldy = ldy;
     g.epi = act == STEM_ACT_LRELU ? EPI_LRELU : EPI_BIAS;

@@ -54,6 +54,8 @@ class _Layer:
         self.eng.ensure_packed()
         m = self.mod
         if self.kind == "conv":
+            if self.masked:
+                act |= F.CONV_MASKED_A            # the masked taps are zeros: skip them
             return F.conv2d_fwd(x, self.wp_fwd, m.bias, self.K, self.R, self.R, self.stride, self.pad, act, out=out)
         return F.deconv2d_fwd(x, self.wp_fwd, m.bias, self.K, self.R, self.R, self.stride, self.pad, self.opad, act, out=out)
 

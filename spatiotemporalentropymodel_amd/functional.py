@@ -15,6 +15,7 @@ from . import _lib
 
 PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_DECONV_FWD, PACK_DECONV_DGRAD, PACK_CONV_FWD_C4 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_LRELU = 0, 1
+CONV_MASKED_A = 0x100        # OR into `act`: skip the taps a type-A MaskedConv2d zeroes (include/stem_hip.h)
 LRELU_SLOPE = 0.01
 EB_NPARAM = 58
 
@@ -182,7 +183,7 @@ def conv2d_fwd(x, wp, bias, K, R, S, stride, pad, act=ACT_NONE, out=None, slope=
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
     if out is None:
         out = empty_nhwc(B, K, Ho, Wo, x.device)
-    ws, wsb = _workspace(0, (B, H, W, Cc, K, R, S, stride, pad, 0), x.device)
+    ws, wsb = _workspace(0 | (act & CONV_MASKED_A), (B, H, W, Cc, K, R, S, stride, pad, 0), x.device)
     _chk(_lib.hip().stem_conv2d_fwd(x.data_ptr(), ldx, wp.data_ptr(), _ptr(bias), out.data_ptr(), nhwc_ld(out),
                                     B, H, W, Cc, K, R, S, stride, pad, act, slope, ws, wsb, _stream()))
     return out

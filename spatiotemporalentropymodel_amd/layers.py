@@ -101,7 +101,8 @@ class Conv2dFunction(torch.autograd.Function):
             xin = xin.permute(0, 3, 1, 2)               # [B,4,H,W] NHWC view for the weight gradient
         else:
             xin = F.to_nhwc(x)
-            y = F.conv2d_fwd(xin, cache.get(weight, F.PACK_CONV_FWD, masked), bias, K, R, S, stride, pad, act, slope=slope)
+            y = F.conv2d_fwd(xin, cache.get(weight, F.PACK_CONV_FWD, masked), bias, K, R, S, stride, pad,
+                             act | (F.CONV_MASKED_A if masked else 0), slope=slope)
         if first and act:
             y = F.lrelu_fwd(y, slope)
         ctx.cfg = (stride, pad, act, masked, cache, first, tuple(x.shape), slope)
