@@ -26,6 +26,8 @@ struct WgradArgs {
     const int *ptab;     // [M][2]: byte offset of the gathered pixel for tap (0,0), validity mask of the R*S taps
     int pbytes, gbytes, tbytes;
     int gsq;             // square the gathered operand while staging (GDN: dgamma = sum g (x) x^2)
+    float *dbp;          // [splits][CP] partial column sums of P (the Conv2d bias gradient) written by the tap-0 / first-column
+                         // workgroups from the registers they stage anyway; null = not wanted (vector path only)
 };
 
 // one entry per loop-grid pixel; removes the per-chunk div/mod and bounds tests from the gather
@@ -97,6 +99,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : BM * BN >= 128 * 6
     const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(a.ptab), 0, a.tbytes, 0x00020000);
     const int tapoff = (tr * a.GW + ts) * a.ldg * 4;          // byte offset of this workgroup's tap
     const bool colA_ok = i0 + colA < a.CP, colB_ok = C4 ? t < a.R * a.S : j0 + colB < a.CG;
+    const bool do_bias = VEC && a.dbp != nullptr && tj == 0 && (C4 || t == 0);      // workgroup-uniform
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     typedef int i32x2 __attribute__((ext_vector_type(2)));
     auto gload = [&](int chunk) {
 #pragma unroll
@@ -199,7 +203,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : BM * BN >= 128 * 6
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-                if (ks == 2) stA(cur ^ 1, sa);
+                if (ks == 2) {
+                    stA(cur ^ 1, sa);
+                    if (do_bias && cn - 2 < c_end) {      // `sa` holds chunk cn - 2: count it once, only if it is ours
+#pragma unroll
+                        for (int q = 0; q < NPA; ++q) bsum += sa[q];
+                    }
+                }
                 if (ks == 5) stB(cur ^ 1, sb);
                 if (ks == 9) glA(cn, sa);
                 if (ks == 12) glB(sb, p);
@@ -211,6 +221,10 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : BM * BN >= 128 * 6
             glA(c_begin, ra);
             glB(rb, ptA);
             stA(0, ra);
+            if (do_bias) {
+#pragma unroll
+                for (int q = 0; q < NPA; ++q) bsum += ra[q];
+            }
             stB(0, rb);
             tl(c_begin + 1, ptA);
             tl(c_begin + 2, ptB);
@@ -257,6 +271,18 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128 ? 2 : BM * BN >= 128 * 6
         }
     }
 
+    if (do_bias) {      // column sums of this workgroup's P rows: RPA partial sums per column -> one, written to the split's slab
+        __syncthreads();
+        float *red = smem;                                    // [RPA][BM]
+        *reinterpret_cast<f32x4 *>(&red[rowA * BM + colA]) = bsum;
+        __syncthreads();
+        if (tid < BM && i0 + tid < a.CP) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < RPA; ++r) v += red[r * BM + tid];
+            a.dbp[(size_t)split * a.CP + i0 + tid] = v;
+        }
+    }
     if (C4) {
         float *outs = a.out + (size_t)split * a.R * a.S * a.CP * 4;
 #pragma unroll
@@ -367,11 +393,16 @@ void plan(int CP, int CG, int T, int nchunks, int *cfg, int *splits)
     }
 }
 
+bool wgrad_vec_ok(const float *p, int ldp, int CP, const float *g, int ldg, int CG)
+{
+    return (CP % 4 == 0) && (CG % 4 == 0) && (ldp % 4 == 0) && (ldg % 4 == 0) && (((uintptr_t)p & 15) == 0) && (((uintptr_t)g & 15) == 0);
+}
+
 int run(const float *p, int ldp, int CP, const float *g, int ldg, int CG, float *out, int *ptab, int B, int PH, int PW,
-        int GH, int GW, int R, int S, int stride, int pad, int splits, int flags, hipStream_t st)
+        int GH, int GW, int R, int S, int stride, int pad, int splits, int flags, hipStream_t st, float *dbp = nullptr)
 {
     WgradArgs a;
-    a.p = p; a.g = g; a.out = out;
+    a.p = p; a.g = g; a.out = out; a.dbp = dbp;
     a.ldp = ldp; a.ldg = ldg; a.CP = CP; a.CG = CG;
     a.B = B; a.PH = PH; a.PW = PW; a.GH = GH; a.GW = GW;
     a.stride = stride; a.pad = pad; a.R = R; a.S = S;
@@ -397,8 +428,7 @@ int run(const float *p, int ldp, int CP, const float *g, int ldg, int CG, float 
         hipLaunchKernelGGL(wgrad_pixtab_kernel, dim3(cdiv(Mtot, 256)), dim3(256), 0, st, ptab, Mtot, PH, PW, GH, GW, ldg, stride, pad, R, S);
         STEM_LAUNCH_CHECK("wgrad_pixtab");
     }
-    const bool vec = (CP % 4 == 0) && (CG % 4 == 0) && (ldp % 4 == 0) && (ldg % 4 == 0) &&
-                     (((uintptr_t)p & 15) == 0) && (((uintptr_t)g & 15) == 0);
+    const bool vec = wgrad_vec_ok(p, ldp, CP, g, ldg, CG);
     int cfg, s_unused;
     plan(CP, CG, R * S, a.nchunks, &cfg, &s_unused);
     if (vec && CG == 4 && ldg == 4 && !a.gsq && R * S <= 32) return launch_c4(a, st);
@@ -518,11 +548,21 @@ STEM_EXPORT int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int 
     STEM_CHECK_ARG(splits >= 1, "stem_conv2d_wgrad: splits must be >= 1");
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     hipStream_t st = (hipStream_t)stream;
-    if (db && colsum(dy, lddy, (size_t)B * Ho * Wo, K, dwp + (size_t)splits * R * S * K * C, db, (flags & STEM_WGRAD_ACCUMULATE_DB) ? 1 : 0, st))
-        return -2;
+    float *scratch = dwp + (size_t)splits * R * S * K * C;
+    const int acc_db = (flags & STEM_WGRAD_ACCUMULATE_DB) ? 1 : 0;
+    // The bias gradient is the column sum of dY, the operand the weight-gradient kernel stages on its loop grid: on the vector
+    // path its tap-0 workgroups sum the rows they load (one partial per split) and only the tiny second stage is launched.
+    const bool fused_db = db && splits <= CS_MAX_PARTS && wgrad_vec_ok(dy, lddy, K, x, ldx, C) && !(flags & STEM_WGRAD_SQUARE_G);
+    if (db && !fused_db && colsum(dy, lddy, (size_t)B * Ho * Wo, K, scratch, db, acc_db, st)) return -2;
     // P = dY on the output grid (K channels), G = x gathered at oy*stride - pad + r  ->  [t][K][C]
-    int *ptab = reinterpret_cast<int *>(dwp + (size_t)splits * R * S * K * C + (size_t)CS_MAX_PARTS * K);
-    return run(dy, lddy, K, x, ldx, C, dwp, ptab, B, Ho, Wo, H, W, R, S, stride, pad, splits, flags, st);
+    int *ptab = reinterpret_cast<int *>(scratch + (size_t)CS_MAX_PARTS * K);
+    if (int rc = run(dy, lddy, K, x, ldx, C, dwp, ptab, B, Ho, Wo, H, W, R, S, stride, pad, splits, flags, st, fused_db ? scratch : nullptr))
+        return rc;
+    if (fused_db) {
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(K, 64)), dim3(1024), 0, st, scratch, K, splits, db, acc_db);
+        STEM_LAUNCH_CHECK("colsum_final");
+    }
+    return 0;
 }
 
 STEM_EXPORT int stem_deconv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
