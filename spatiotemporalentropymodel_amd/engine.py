@@ -144,7 +144,7 @@ class StemEngine:
 
     def ensure_packed(self):
         """(Re)build every layer's packed weight copies with ONE kernel launch when any weight changed."""
-        key = (_layers._WEIGHT_EPOCH[0],) + tuple((l.mod.weight._version, l.mod.weight.data_ptr()) for l in self.layers)
+        key = tuple((_layers.weight_epoch(l.mod.weight), l.mod.weight._version, l.mod.weight.data_ptr()) for l in self.layers)
         if key == self._pack_key:
             return
         if self.layers[0].wp_fwd is None or self.layers[0].wp_fwd.device != self.layers[0].mod.weight.device:
@@ -155,7 +155,7 @@ class StemEngine:
         arr = (_lib.PackDesc * len(descs))(*descs)
         F.pack_weights_multi(arr)
         # masked == 2 zeroed taps of the context weight in place: refresh its version in the key
-        self._pack_key = (_layers._WEIGHT_EPOCH[0],) + tuple((l.mod.weight._version, l.mod.weight.data_ptr()) for l in self.layers)
+        self._pack_key = tuple((_layers.weight_epoch(l.mod.weight), l.mod.weight._version, l.mod.weight.data_ptr()) for l in self.layers)
 
     def unpack_all(self):
         self._group_ready(self.layers, [])

@@ -19,9 +19,19 @@ from .ops import NonNegativeParametrizer
 _WEIGHT_EPOCH = [0]
 
 
-def bump_weight_epoch():
-    """Called by the fused optimiser: parameters changed behind torch's version counters."""
-    _WEIGHT_EPOCH[0] += 1
+def bump_weight_epoch(params=None):
+    """Called by the fused optimiser: parameters changed behind torch's version counters.  With `params` only those
+    tensors are marked (each carries its own counter), so packed copies of other models' weights -- e.g. the frozen
+    I-frame transforms next to a training STEM -- stay valid; without, every cache is invalidated."""
+    if params is None:
+        _WEIGHT_EPOCH[0] += 1
+        return
+    for p in params:
+        p._stem_epoch = getattr(p, "_stem_epoch", 0) + 1
+
+
+def weight_epoch(w):
+    return (_WEIGHT_EPOCH[0], getattr(w, "_stem_epoch", 0))
 
 
 class _PackCache:
@@ -31,13 +41,13 @@ class _PackCache:
         self._c = {}
 
     def get(self, w: torch.Tensor, role: int, masked: int = 0):
-        key = (w._version, w.data_ptr(), _WEIGHT_EPOCH[0], tuple(w.shape))
+        key = (w._version, w.data_ptr(), weight_epoch(w), tuple(w.shape))
         hit = self._c.get(role)
         if hit is not None and hit[0] == key:
             return hit[1]
         wp = F.pack_weight(w, role, masked)
         if masked == 2:                          # the kernel zeroed taps of w in place
-            key = (w._version, w.data_ptr(), _WEIGHT_EPOCH[0], tuple(w.shape))
+            key = (w._version, w.data_ptr(), weight_epoch(w), tuple(w.shape))
         self._c[role] = (key, wp)
         return wp
 

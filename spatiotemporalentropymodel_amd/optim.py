@@ -34,7 +34,7 @@ class FlatParameters:
             p.data = self.data[o:o + n].view(p.shape)
             p._flat_grad_view = self.grad[o:o + n].view(p.shape)
             p.grad = p._flat_grad_view
-        bump_weight_epoch()
+        bump_weight_epoch(self.params)
 
     def zero_grad(self):
         join_wgrad_stream()
@@ -77,7 +77,7 @@ class FusedClipAdam:
         F.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self._sumsq if use_clip else None,
                     float(self.max_norm) if use_clip else 0.0, float(grad_scale), self.lr, self.betas[0], self.betas[1],
                     self.eps, self.t)
-        bump_weight_epoch()
+        bump_weight_epoch(self.flat.params)
 
     def state_dict(self):
         return {"t": self.t, "m": self.m, "v": self.v, "lr": self.lr}
