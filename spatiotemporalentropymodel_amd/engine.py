@@ -130,6 +130,7 @@ class StemEngine:
         self._pack_key = None
         self._pack_descs = None
         self._side = None
+        self._checked = False
 
     #: weight gradients (wgrad + bias column sums + unpack + the data-parallel exchange hook) run on their own stream
     #: and overlap the latency-bound parts of the dgrad chain; set False to keep everything on the compute stream
@@ -143,7 +144,10 @@ class StemEngine:
         return self._side
 
     def ensure_packed(self):
-        """(Re)build every layer's packed weight copies with ONE kernel launch when any weight changed."""
+        """(Re)build every layer's packed weight copies with ONE kernel launch when any weight changed.  Inside
+        StemEngine.forward the check has already run for the whole schedule (`_checked`)."""
+        if self._checked:
+            return
         key = tuple((_layers.weight_epoch(l.mod.weight), l.mod.weight._version, l.mod.weight.data_ptr()) for l in self.layers)
         if key == self._pack_key:
             return
@@ -191,6 +195,14 @@ class StemEngine:
 
     # -------------------------------------------------------------------------------------------
     def forward(self, y_cur, y_cond, training: bool):
+        self.ensure_packed()
+        self._checked = True          # weights cannot change inside one forward: skip the per-layer checks
+        try:
+            return self._forward(y_cur, y_cond, training)
+        finally:
+            self._checked = False
+
+    def _forward(self, y_cur, y_cond, training: bool):
         m = self.m
         yc, yd = F.to_nhwc(y_cur.detach()), F.to_nhwc(y_cond.detach())
         B, Cin, H, W = yc.shape

@@ -21,7 +21,12 @@ EB_NPARAM = 58
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current stream on the current device (the C ABI's `stream` argument).  The private fast
+    path costs ~0.3 us instead of ~3 us for torch.cuda.current_stream().cuda_stream -- this runs once per launch."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    except AttributeError:          # torch without these private hooks
+        return torch.cuda.current_stream().cuda_stream
 
 
 def _chk(rc):
@@ -71,10 +76,11 @@ def nhwc_ld(t: torch.Tensor):
 
 
 def empty_nhwc(B, Cc, H, W, device, ld=None):
-    """Uninitialised [B,C,H,W] tensor with NHWC memory; ld > C allocates a wider pitch."""
-    ld = Cc if ld is None else ld
-    buf = torch.empty((B, H, W, ld), device=device, dtype=torch.float32)
-    return buf.permute(0, 3, 1, 2)[:, :Cc]
+    """Uninitialised [B,C,H,W] tensor with NHWC memory; ld > C allocates a wider pitch.  (One allocator call: this runs
+    for every kernel output, ~500 times per training step.)"""
+    if ld is None or ld == Cc:
+        return torch.empty_strided((B, Cc, H, W), (H * W * Cc, 1, W * Cc, Cc), device=device, dtype=torch.float32)
+    return torch.empty((B, H, W, ld), device=device, dtype=torch.float32).permute(0, 3, 1, 2)[:, :Cc]
 
 
 def channel_slice(buf: torch.Tensor, c0: int, c1: int):
