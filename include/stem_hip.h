@@ -252,6 +252,19 @@ int stem_gemv3_decode(const float *W, int ldw, const float *bias, const float *x
                       const float *x1, int len1, int woff1, const float *x2, int len2, int woff2, float *y, int N,
                       int act, float slope, const int32_t *sym_prev, const float *mean_prev, float *pix_prev, int M,
                       int prev_is_left, const float *table, int T, float scale_bound, int32_t *idx, void *stream);
+/* The whole raster-order decode of one image (spatiotemporalpriors.py:1015-1054) in one call: per position the four
+ * products above, a stream synchronisation, and `decode` -- the host symbol decoder, injected as a C function pointer with
+ * the signature of stem_rans_decoder_decode (include/stem_rans.h) so that libstem_hip does not link libstem_rans -- pops M
+ * symbols for the M indexes in the pinned mailbox.  buf: zero-initialised padded latent [(H+4)][(W+4)][M] of this image,
+ * filled with y_hat on return; tp (may be NULL) / hp: [H*W][2M]. */
+typedef int (*stem_symbol_decoder_fn)(void *dec, const int32_t *indexes, size_t n, const int32_t *cdfs, int ncdf, int cdf_stride,
+                                      const int32_t *sizes, const int32_t *offsets, int32_t *out);
+int stem_ar_decode_image(const float *w_ctx, int ld_ctx, const float *b_ctx, const float *w0, int ld0, const float *b0, int n0,
+                         const float *w1, int ld1, const float *b1, int n1, const float *w2, int ld2, const float *b2,
+                         float *buf, int H, int W, int M, int pad, const float *tp, const float *hp,
+                         float *ctx, float *h1, float *h2, float *gp, const float *table, int T, float scale_bound, float slope,
+                         int32_t *idx_host, int32_t *sym_host, stem_symbol_decoder_fn decode, void *dec,
+                         const int32_t *cdfs, int ncdf, int cdf_stride, const int32_t *sizes, const int32_t *offsets, void *stream);
 
 /* Wavefront-parallel encoder: all latent positions with the same t = w + 3h are independent under the 5x5
  * type-A mask, so a H x W frame is coded in W + 3(H-1) batched steps instead of H*W sequential ones.  Input

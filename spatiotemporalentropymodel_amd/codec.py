@@ -5,12 +5,15 @@ rANS on the host (north_star), bitstreams interchangeable with the reference's
 Models without a spatial prior are coded in one shot.  Models with the masked-convolution prior are coded
 in raster order: position (h, w) needs the *decoded* values to its left and above, so each position is a
 chain of four matrix-vector kernels (csrc/ar.hip) on one pixel; the encoder queues the whole frame
-asynchronously (wavefront-parallel, t = w + 3h) and calls the host coder once; the decoder issues four launches per
-position (the first also writes back the previous pixel, the last also emits the CDF indexes), synchronises, and pops
-M symbols from the host rANS state through a pinned mailbox.  (A persistent device loop is the "next" row, DESIGN.md;
-a cooperative single-launch variant was measured slower on ROCm 7.2: 0.74 s vs 0.44 s per 1080p frame.)
+asynchronously (wavefront-parallel, t = w + 3h) and calls the host coder once; the decoder's raster-order loop runs
+inside the library (stem_ar_decode_image): per position four launches (the first also writes back the previous pixel,
+the last also emits the CDF indexes), one stream synchronisation and one call of the host rANS decoder -- injected as a
+C function pointer -- through a pinned mailbox.  (A cooperative single-launch variant was measured slower on ROCm 7.2:
+0.74 s vs 0.44 s per 1080p frame; a persistent device loop remains the "next" row, DESIGN.md.)
 """
 from __future__ import annotations
+
+import os
 
 import numpy as np
 import torch
@@ -39,6 +42,9 @@ def _hyper(model, y_cur, y_cond, strings_z=None, shape=None):
         shape = z.shape[-2:]
     z_hat = eb.decompress(strings_z, shape).to(yd.device).float()
     hp = eng.HD[2].fwd(eng.HD[1].fwd(eng.HD[0].fwd(F.to_nhwc(z_hat), F.ACT_LRELU), F.ACT_LRELU))
+    if tuple(hp.shape[-2:]) != tuple(yd.shape[-2:]):
+        raise ValueError(f"latent size {tuple(yd.shape[-2:])} does not survive the two stride-2 hyper stages (hyper-prior is "
+                         f"{tuple(hp.shape[-2:])}): pad frames to multiples of 64 pixels, as stem/evalSTEM.py:95-108 does")
     tp = None
     if eng.has_tpm:
         tp = eng.TPM[2].fwd(eng.TPM[1].fwd(eng.TPM[0].fwd(yd, F.ACT_LRELU), F.ACT_LRELU))
@@ -117,27 +123,6 @@ class _ARContext:
             F._chk(lib.stem_ar_finish_encode_wave(self._wgp.data_ptr(), self.table.data_ptr(), self.table.numel(), self.bound,
                                                   buf.data_ptr(), sym.data_ptr(), idx.data_ptr(), M, t, H, W, Wp, _P, st))
 
-    def position(self, buf, Wp, h, w, tp_pix, hp_pix):
-        """gp <- EPM(tp, hp, ctx(window at h,w)); buf is the padded [Hp, Wp, M] latent of ONE image."""
-        lib, M, st = _lib.hip(), self.M, F._stream()
-        base = buf.data_ptr()
-        r0 = base + 4 * ((h * Wp + w) * M)
-        r1 = base + 4 * (((h + 1) * Wp + w) * M)
-        r2 = base + 4 * (((h + 2) * Wp + w) * M)
-        F._chk(lib.stem_gemv3(self.w_ctx.data_ptr(), 12 * M, self.b_ctx.data_ptr(), r0, 5 * M, 0, r1, 5 * M, 5 * M,
-                              r2, 2 * M, 10 * M, self.ctx.data_ptr(), 2 * M, 0, 0.0, st))
-        P = 2 * M
-        if self.has_tpm:
-            segs = (tp_pix, P, 0, hp_pix, P, P, self.ctx.data_ptr(), P, 2 * P)
-        else:
-            segs = (hp_pix, P, 0, self.ctx.data_ptr(), P, P, 0, 0, 0)
-        F._chk(lib.stem_gemv3(self.w0.data_ptr(), self.w0.shape[1], self.b0.data_ptr(), *segs, self.h1.data_ptr(),
-                              self.w0.shape[0], F.ACT_LRELU, F.LRELU_SLOPE, st))
-        F._chk(lib.stem_gemv3(self.w1.data_ptr(), self.w1.shape[1], self.b1.data_ptr(), self.h1.data_ptr(), self.w1.shape[1], 0,
-                              0, 0, 0, 0, 0, 0, self.h2.data_ptr(), self.w1.shape[0], F.ACT_LRELU, F.LRELU_SLOPE, st))
-        F._chk(lib.stem_gemv3(self.w2.data_ptr(), self.w2.shape[1], self.b2.data_ptr(), self.h2.data_ptr(), self.w2.shape[1], 0,
-                              0, 0, 0, 0, 0, 0, self.gp.data_ptr(), self.w2.shape[0], 0, 0.0, st))
-
 
 def _position_decode(self, buf, Wp, h, w, tp_pix, hp_pix, sym_prev, pix_prev, prev_is_left, idx_out):
     """Decoder form of _ARContext.position: the first product also writes back the previous position's y_hat (and uses it
@@ -166,6 +151,28 @@ def _position_decode(self, buf, Wp, h, w, tp_pix, hp_pix, sym_prev, pix_prev, pr
 
 
 _ARContext.position_decode = _position_decode
+
+
+def decode_image_stepwise(ar, buf, H, W, tp_b, hp_b, dec, tables, idx_host, sym_host):
+    """The loop of stem_ar_decode_image written with the single-step C-ABI entry points (stem_gemv3_decode, stem_gemv3,
+    stem_ar_finish_decode) and the Python RansDecoder: what a host without the fused call would run; the GPU tests check
+    that both produce the same latents."""
+    lib, M = _lib.hip(), ar.M
+    Wp = W + 2 * _P
+    stream = torch.cuda.current_stream()
+    idx_np, sym_np = idx_host.numpy(), sym_host.numpy()
+    prev_pix = 0
+    for h in range(H):
+        for w in range(W):
+            pos = h * W + w
+            hp_pix = hp_b + 4 * (pos * 2 * M)
+            tp_pix = tp_b + 4 * (pos * 2 * M) if tp_b else 0
+            ar.position_decode(buf, Wp, h, w, tp_pix, hp_pix, sym_host.data_ptr() if prev_pix else 0, prev_pix, w > 0, idx_host.data_ptr())
+            stream.synchronize()
+            sym_np[:] = dec.decode_stream_np(idx_np, tables)
+            prev_pix = buf.data_ptr() + 4 * (((h + _P) * Wp + (w + _P)) * M)
+    if prev_pix:
+        F._chk(lib.stem_ar_finish_decode(ar.gp.data_ptr(), sym_host.data_ptr(), prev_pix, M, F._stream()))
 
 
 def _padded(target_img, H, W, M, device):
@@ -226,25 +233,25 @@ def stem_decompress(model, strings, shape, y_cond):
     # position costs kernel launches + ONE stream synchronisation and no memcpy calls
     idx_host = torch.empty(M, dtype=torch.int32).pin_memory()
     sym_host = torch.empty(M, dtype=torch.int32).pin_memory()
-    idx_np, sym_np = idx_host.numpy(), sym_host.numpy()
-    stream = torch.cuda.current_stream()
+    import ctypes as C
+    decode_fn = C.cast(_lib.rans().stem_rans_decoder_decode, C.c_void_p).value      # host symbol decoder, injected as a C pointer
     for b, s in enumerate(strings[0]):
         buf = _padded(None, H, W, M, dev)
         dec = RansDecoder()
         dec.set_stream(s)
-        prev_pix = 0
-        for h in range(H):
-            for w in range(W):
-                pos = h * W + w
-                hp_pix = hp.data_ptr() + 4 * ((b * H * W + pos) * 2 * M)
-                tp_pix = tp.data_ptr() + 4 * ((b * H * W + pos) * 2 * M) if tp is not None else 0
-                # four launches: context (+ write-back of the previous pixel), EPM.0, EPM.2, EPM.4 (+ CDF indexes -> host mailbox)
-                ar.position_decode(buf, Wp, h, w, tp_pix, hp_pix, sym_host.data_ptr() if prev_pix else 0, prev_pix, w > 0, idx_host.data_ptr())
-                stream.synchronize()
-                sym_np[:] = dec.decode_stream_np(idx_np, tables)
-                prev_pix = buf.data_ptr() + 4 * (((h + _P) * Wp + (w + _P)) * M)
-        if prev_pix:                                          # the last position's write-back
-            F._chk(lib.stem_ar_finish_decode(ar.gp.data_ptr(), sym_host.data_ptr(), prev_pix, M, F._stream()))
+        hp_b = hp.data_ptr() + 4 * (b * H * W * 2 * M)
+        tp_b = tp.data_ptr() + 4 * (b * H * W * 2 * M) if tp is not None else 0
+        if os.environ.get("STEM_AR_STEPWISE"):                # same loop from Python with the single-step entry points (tests)
+            decode_image_stepwise(ar, buf, H, W, tp_b, hp_b, dec, tables, idx_host, sym_host)
+            out[b:b + 1].copy_(buf[_P:_P + H, _P:_P + W].permute(2, 0, 1).unsqueeze(0))
+            continue
+        # the whole raster-order loop of this image runs inside the library (csrc/ar.hip: stem_ar_decode_image)
+        F._chk(lib.stem_ar_decode_image(
+            ar.w_ctx.data_ptr(), 12 * M, ar.b_ctx.data_ptr(), ar.w0.data_ptr(), ar.w0.shape[1], ar.b0.data_ptr(), ar.w0.shape[0],
+            ar.w1.data_ptr(), ar.w1.shape[1], ar.b1.data_ptr(), ar.w1.shape[0], ar.w2.data_ptr(), ar.w2.shape[1], ar.b2.data_ptr(),
+            buf.data_ptr(), H, W, M, _P, tp_b, hp_b, ar.ctx.data_ptr(), ar.h1.data_ptr(), ar.h2.data_ptr(), ar.gp.data_ptr(),
+            ar.table.data_ptr(), ar.table.numel(), ar.bound, F.LRELU_SLOPE, idx_host.data_ptr(), sym_host.data_ptr(),
+            decode_fn, dec._h, *tables.args(), F._stream()))
         out[b:b + 1].copy_(buf[_P:_P + H, _P:_P + W].permute(2, 0, 1).unsqueeze(0))
     if model.RESIDUAL:
         out = F.add(out, _dense(yd))

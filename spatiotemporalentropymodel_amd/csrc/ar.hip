@@ -326,3 +326,61 @@ STEM_EXPORT int stem_ar_finish_encode_wave(const float *gp, const float *table, 
     STEM_LAUNCH_CHECK("ar_finish_encode_wave");
     return 0;
 }
+
+// ================================================================================================
+// DECODER, whole image: the raster-order loop of spatiotemporalpriors.py:1015-1054 as ONE C-ABI call.  Per position: four
+// launches (context + write-back of the previous pixel, EPM.0, EPM.2, EPM.4 + CDF indexes), one stream synchronisation,
+// and one call of the host symbol decoder (a C function pointer -- stem_rans_decoder_decode of libstem_rans -- so the two
+// libraries stay independent) through the pinned mailbox.  No interpreter in the loop: ~30 us per position instead of ~45.
+STEM_EXPORT int stem_ar_decode_image(const float *w_ctx, int ld_ctx, const float *b_ctx, const float *w0, int ld0, const float *b0, int n0,
+                                     const float *w1, int ld1, const float *b1, int n1, const float *w2, int ld2, const float *b2,
+                                     float *buf, int H, int W, int M, int pad, const float *tp, const float *hp,
+                                     float *ctx, float *h1, float *h2, float *gp, const float *table, int T, float scale_bound, float slope,
+                                     int32_t *idx_host, int32_t *sym_host, stem_symbol_decoder_fn decode, void *dec,
+                                     const int32_t *cdfs, int ncdf, int cdf_stride, const int32_t *sizes, const int32_t *offsets, void *stream)
+{
+    STEM_CHECK_ARG(w_ctx && b_ctx && w0 && b0 && w1 && b1 && w2 && b2 && buf && hp && ctx && h1 && h2 && gp && table && idx_host && sym_host && decode,
+                   "stem_ar_decode_image: null pointer");
+    STEM_CHECK_ARG(H > 0 && W > 0 && M > 0 && M % 4 == 0 && n0 % 4 == 0 && n1 % 4 == 0 && ld_ctx % 4 == 0 && ld0 % 4 == 0 && ld1 % 4 == 0 &&
+                   ld2 % 4 == 0 && T >= 1 && pad == 2, "stem_ar_decode_image: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int P = 2 * M, Wp = W + 2 * pad;
+    float *pix_prev = nullptr;
+    const DecodeExtra none{nullptr, nullptr, nullptr, M, 0, nullptr, 0, 0.f, nullptr};
+    for (int h = 0; h < H; ++h)
+        for (int w = 0; w < W; ++w) {
+            const size_t pos = (size_t)h * W + w;
+            const float *r0 = buf + ((size_t)h * Wp + w) * M, *r1 = r0 + (size_t)Wp * M, *r2 = r1 + (size_t)Wp * M;
+            DecodeExtra head = none;
+            if (pix_prev) {
+                head.sym_prev = sym_host; head.mean_prev = gp + M; head.pix_prev = pix_prev; head.prev_is_left = w > 0 ? 1 : 0;
+            }
+            hipLaunchKernelGGL(gemv3_decode_kernel, dim3(cdiv(P, 4)), dim3(256), 0, st, w_ctx, ld_ctx, b_ctx, Seg{r0, 5 * M, 0}, Seg{r1, 5 * M, 5 * M},
+                               Seg{r2, 2 * M, 10 * M}, ctx, P, 0, 0.f, head);
+            const float *hp_pix = hp + pos * P;
+            if (tp)
+                hipLaunchKernelGGL(gemv3_kernel, dim3(cdiv(n0, 4)), dim3(256), 0, st, w0, ld0, b0, Seg{tp + pos * P, P, 0}, Seg{hp_pix, P, P},
+                                   Seg{ctx, P, 2 * P}, h1, n0, (int)STEM_ACT_LRELU, slope);
+            else
+                hipLaunchKernelGGL(gemv3_kernel, dim3(cdiv(n0, 4)), dim3(256), 0, st, w0, ld0, b0, Seg{hp_pix, P, 0}, Seg{ctx, P, P},
+                                   Seg{nullptr, 0, 0}, h1, n0, (int)STEM_ACT_LRELU, slope);
+            hipLaunchKernelGGL(gemv3_kernel, dim3(cdiv(n1, 4)), dim3(256), 0, st, w1, ld1, b1, Seg{h1, n0, 0}, Seg{nullptr, 0, 0},
+                               Seg{nullptr, 0, 0}, h2, n1, (int)STEM_ACT_LRELU, slope);
+            DecodeExtra tail = none;
+            tail.table = table; tail.T = T; tail.bound = scale_bound; tail.idx = idx_host;
+            hipLaunchKernelGGL(gemv3_decode_kernel, dim3(cdiv(P, 4)), dim3(256), 0, st, w2, ld2, b2, Seg{h2, n1, 0}, Seg{nullptr, 0, 0},
+                               Seg{nullptr, 0, 0}, gp, P, 0, 0.f, tail);
+            if (hipStreamSynchronize(st) != hipSuccess) {
+                stem_set_error("stem_ar_decode_image: device error at position (%d, %d): %s", h, w, hipGetErrorString(hipGetLastError()));
+                return -2;
+            }
+            if (int rc = decode(dec, idx_host, (size_t)M, cdfs, ncdf, cdf_stride, sizes, offsets, sym_host)) {
+                stem_set_error("stem_ar_decode_image: host symbol decoder failed (%d) at position (%d, %d)", rc, h, w);
+                return -3;
+            }
+            pix_prev = buf + ((size_t)(h + pad) * Wp + (w + pad)) * M;
+        }
+    hipLaunchKernelGGL(ar_finish_decode_kernel, dim3(cdiv(M, 256)), dim3(256), 0, st, gp, sym_host, pix_prev, M);
+    STEM_LAUNCH_CHECK("ar_decode_image");
+    return 0;
+}

@@ -88,3 +88,26 @@ def test_roundtrip_all_variants(cls_name):
         assert_close(host(y_hat), host(fwd["y_hat"]), 1e-6, what="decode == eval forward reconstruction")
     total_bits = 8 * sum(len(s) for s in enc["strings"][0] + enc["strings"][1])
     assert total_bits > 0
+
+
+@pytest.mark.parametrize("cls_name", ["SpatioTemporalPriorModelWithoutTPM", "SpatioTemporalPriorModel_Res"])
+def test_fused_decode_loop_equals_stepwise_entry_points(cls_name, monkeypatch):
+    """stem_ar_decode_image (the raster loop inside the library, host decoder injected as a C pointer) against the same loop
+    driven from Python through the single-step entry points (stem_gemv3_decode / stem_gemv3 / stem_ar_finish_decode)."""
+    import spatiotemporalentropymodel_amd.models as M
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_, closed_form_input
+    dev = torch.device("cuda:0")
+    m = closed_form_fill_(getattr(M, cls_name)(64, 96)).to(dev).eval()
+    m.update(force=True)
+    y_cur = closed_form_input("fd:y", (2, 96, 4, 12), -6, 6).to(dev)
+    y_cond = closed_form_input("fd:c", (2, 96, 4, 12), -6, 6).to(dev)
+    with torch.no_grad():
+        enc = m.compress(y_cur, y_cond)
+        fused = m.decompress(enc["strings"], enc["shape"], y_cond)
+        monkeypatch.setenv("STEM_AR_STEPWISE", "1")
+        step = m.decompress(enc["strings"], enc["shape"], y_cond)
+    a = fused["y_hat"] if isinstance(fused, dict) else fused
+    b = step["y_hat"] if isinstance(step, dict) else step
+    np.testing.assert_array_equal(host(a), host(b))
+    with pytest.raises(ValueError):          # 5x9 latents do not survive the hyper stages: loud error, not a corrupt stream
+        m.compress(y_cur[:, :, :, :9].contiguous()[:, :, :3], y_cond[:, :, :, :9].contiguous()[:, :, :3])
