@@ -257,6 +257,14 @@ int stem_gemv3_decode(const float *W, int ldw, const float *bias, const float *x
  * the signature of stem_rans_decoder_decode (include/stem_rans.h) so that libstem_hip does not link libstem_rans -- pops M
  * symbols for the M indexes in the pinned mailbox.  buf: zero-initialised padded latent [(H+4)][(W+4)][M] of this image,
  * filled with y_hat on return; tp (may be NULL) / hp: [H*W][2M]. */
+/* Encoder counterpart: the W + 3(H-1) wavefront steps (stem_gemv3_wave x4 + stem_ar_finish_encode_wave each) queued by one
+ * call; wctx/wh1/wh2/wgp: scratch [min(H,(W+2)/3)][2M | n0 | n1 | 2M]; sym/idx: [H*W][M] in raster order for ONE host rANS
+ * call (spatiotemporalpriors.py:916-961).  buf holds the padded target on entry and the reconstruction on return. */
+int stem_ar_encode_image(const float *w_ctx, int ld_ctx, const float *b_ctx, const float *w0, int ld0, const float *b0, int n0,
+                         const float *w1, int ld1, const float *b1, int n1, const float *w2, int ld2, const float *b2,
+                         float *buf, int H, int W, int M, int pad, const float *tp, const float *hp,
+                         float *wctx, float *wh1, float *wh2, float *wgp, const float *table, int T, float scale_bound,
+                         float slope, int32_t *sym, int32_t *idx, void *stream);
 typedef int (*stem_symbol_decoder_fn)(void *dec, const int32_t *indexes, size_t n, const int32_t *cdfs, int ncdf, int cdf_stride,
                                       const int32_t *sizes, const int32_t *offsets, int32_t *out);
 int stem_ar_decode_image(const float *w_ctx, int ld_ctx, const float *b_ctx, const float *w0, int ld0, const float *b0, int n0,

@@ -97,6 +97,14 @@ class _ARContext:
             self._wh2 = torch.empty((npmax, self.w1.shape[0]), device=dev)
             self._wgp = torch.empty((npmax, P), device=dev)
             self._wave_np = npmax
+        if not os.environ.get("STEM_AR_STEPWISE"):
+            # all W + 3(H-1) steps queued by one library call (no interpreter between the 5 launches of a step)
+            F._chk(lib.stem_ar_encode_image(
+                self.w_ctx.data_ptr(), 12 * M, self.b_ctx.data_ptr(), self.w0.data_ptr(), self.w0.shape[1], self.b0.data_ptr(), self.w0.shape[0],
+                self.w1.data_ptr(), self.w1.shape[1], self.b1.data_ptr(), self.w1.shape[0], self.w2.data_ptr(), self.w2.shape[1], self.b2.data_ptr(),
+                buf.data_ptr(), H, W, M, _P, tp_b, hp_b, self._wctx.data_ptr(), self._wh1.data_ptr(), self._wh2.data_ptr(), self._wgp.data_ptr(),
+                self.table.data_ptr(), self.table.numel(), self.bound, F.LRELU_SLOPE, sym.data_ptr(), idx.data_ptr(), st))
+            return
         S = _lib.WaveSeg
         base = buf.data_ptr()
         row = Wp * M

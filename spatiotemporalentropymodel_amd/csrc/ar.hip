@@ -384,3 +384,42 @@ STEM_EXPORT int stem_ar_decode_image(const float *w_ctx, int ld_ctx, const float
     STEM_LAUNCH_CHECK("ar_decode_image");
     return 0;
 }
+
+// ENCODER, whole image: the W + 3(H-1) wavefront steps of the section above queued by one C-ABI call (5 launches per step,
+// no synchronisation): the host then makes a single rANS call on the raster-ordered symbols / indexes.
+STEM_EXPORT int stem_ar_encode_image(const float *w_ctx, int ld_ctx, const float *b_ctx, const float *w0, int ld0, const float *b0, int n0,
+                                     const float *w1, int ld1, const float *b1, int n1, const float *w2, int ld2, const float *b2,
+                                     float *buf, int H, int W, int M, int pad, const float *tp, const float *hp,
+                                     float *wctx, float *wh1, float *wh2, float *wgp, const float *table, int T, float scale_bound,
+                                     float slope, int32_t *sym, int32_t *idx, void *stream)
+{
+    STEM_CHECK_ARG(w_ctx && b_ctx && w0 && b0 && w1 && b1 && w2 && b2 && buf && hp && wctx && wh1 && wh2 && wgp && table && sym && idx,
+                   "stem_ar_encode_image: null pointer");
+    STEM_CHECK_ARG(H > 0 && W > 0 && M > 0 && M % 4 == 0 && n0 % 4 == 0 && n1 % 4 == 0 && pad == 2 && T >= 1, "stem_ar_encode_image: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int P = 2 * M, Wp = W + 2 * pad;
+    const long row = (long)Wp * M;
+    const int maxp = H < (W + 2) / 3 ? H : (W + 2) / 3;
+    const WSeg none{nullptr, 0, 0, 0, 0, 0};
+    // context window of position (h, w): rows h, h+1 (5 pixels) and h+2 (2 pixels) of the padded buffer, starting at column w
+    const WSeg c0{buf, 5 * M, 0, row, M, 0}, c1{buf + row, 5 * M, 5 * M, row, M, 0}, c2{buf + 2 * row, 2 * M, 10 * M, row, M, 0};
+    const WSeg sctx{wctx, P, tp ? 2 * P : P, 0, 0, P};
+    const WSeg stp{tp, P, 0, (long)W * P, P, 0}, shp{hp, P, tp ? P : 0, (long)W * P, P, 0};
+    const WSeg sh1{wh1, n0, 0, 0, 0, n0}, sh2{wh2, n1, 0, 0, 0, n1};
+    for (int t = 0; t < W + 3 * (H - 1); ++t) {
+        hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(P, 4)), dim3(256), 0, st, w_ctx, ld_ctx, b_ctx, c0, c1, c2, wctx, P, P, 0, 0.f, t, H, W);
+        if (tp)
+            hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(n0, 4)), dim3(256), 0, st, w0, ld0, b0, stp, shp, sctx, wh1, n0, n0,
+                               (int)STEM_ACT_LRELU, slope, t, H, W);
+        else
+            hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(n0, 4)), dim3(256), 0, st, w0, ld0, b0, shp, sctx, none, wh1, n0, n0,
+                               (int)STEM_ACT_LRELU, slope, t, H, W);
+        hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(n1, 4)), dim3(256), 0, st, w1, ld1, b1, sh1, none, none, wh2, n1, n1,
+                           (int)STEM_ACT_LRELU, slope, t, H, W);
+        hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(P, 4)), dim3(256), 0, st, w2, ld2, b2, sh2, none, none, wgp, P, P, 0, 0.f, t, H, W);
+        hipLaunchKernelGGL(ar_finish_encode_wave_kernel, dim3(cdiv(maxp * M, 256)), dim3(256), 0, st, wgp, table, T, scale_bound, buf, sym, idx,
+                           M, t, H, W, Wp, pad);
+    }
+    STEM_LAUNCH_CHECK("ar_encode_image");
+    return 0;
+}

@@ -106,6 +106,8 @@ def test_fused_decode_loop_equals_stepwise_entry_points(cls_name, monkeypatch):
         fused = m.decompress(enc["strings"], enc["shape"], y_cond)
         monkeypatch.setenv("STEM_AR_STEPWISE", "1")
         step = m.decompress(enc["strings"], enc["shape"], y_cond)
+        enc_step = m.compress(y_cur, y_cond)                      # encoder: per-step entry points vs stem_ar_encode_image
+        assert enc_step["strings"] == enc["strings"]
     a = fused["y_hat"] if isinstance(fused, dict) else fused
     b = step["y_hat"] if isinstance(step, dict) else step
     np.testing.assert_array_equal(host(a), host(b))
