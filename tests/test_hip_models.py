@@ -12,6 +12,7 @@ import torch
 from conftest import REPO, assert_close
 
 pytestmark = pytest.mark.gpu
+GRAD_RTOL = 1e-4
 
 
 def host(t):
@@ -122,9 +123,9 @@ def test_train_steps_match_reference(S, golden, tag):
                 assert abs(float(gd.abs().sum()) - ref[1]) <= 2e-4 * ref[1] + 1e-12, name
                 sl = host(gd.reshape(-1)[:: max(1, gd.numel() // 64)][:64])
                 rs = g[f"s1:gslice:{name}"]
-                # gradients are dominated by low-likelihood elements (dlik = c/lik) whose relative error is the
-                # forward's 1e-6 error in (mu, sigma) amplified by ~|v|/sigma^2: 1e-3 is the honest fp32 bound here
-                assert_close(sl, rs, 1e-3, atol=1e-7 * float(np.abs(rs).max() + 1e-30), what="grad " + name)
+                # 1e-4 of the element or of the tensor's RMS (the 64-element slice's own max underestimates the scale)
+                rms = float(np.sqrt(ref[2] / p.numel()))
+                assert_close(sl, rs, GRAD_RTOL, atol=GRAD_RTOL * rms, what="grad " + name)
             opt.step()
             aux = stem.aux_loss()
             aux.backward()

@@ -319,7 +319,8 @@ def test_stem_train_step1_gradients(golden, tag):
         assert abs(gd.sum() - ref[0]) <= 2e-4 * ref[1] + 1e-12, name
         assert abs(np.abs(gd).sum() - ref[1]) <= 2e-4 * ref[1] + 1e-12, name
         sl = gd.reshape(-1)[:: max(1, gd.size // 64)][:64]
-        assert_close(sl, g[f"s1:gslice:{name}"], 5e-4, atol=1e-7 * float(np.abs(g[f's1:gslice:{name}']).max() + 1e-30), what="grad " + name)
+        rms = float(np.sqrt(ref[2] / gd.size))          # 1e-4 of the element or of the tensor's RMS
+        assert_close(sl, g[f"s1:gslice:{name}"], 1e-4, atol=1e-4 * rms, what="grad " + name)
     pack = orc.eb_pack_params(ssd)
     target = np.array([-np.log(2 / 1e-9 - 1), 0, np.log(2 / 1e-9 - 1)], np.float32)
     # aux loss is evaluated after optimizer.step in the reference -> only its dquantiles structure is checked here
