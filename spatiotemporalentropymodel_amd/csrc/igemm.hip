@@ -670,6 +670,8 @@ Plan make_plan(const IgemmArgs &g, bool c4)
             }
         }
     }
+    static const int forced_split = getenv("STEM_IGEMM_SPLIT") ? atoi(getenv("STEM_IGEMM_SPLIT")) : 0;      // tuning aid
+    if (forced_split > 0 && can_split) pl.nsplit = forced_split < maxchunks ? forced_split : maxchunks;
     pl.cps = cdiv(maxchunks, pl.nsplit);
     pl.nsplit = cdiv(maxchunks, pl.cps);           // drop empty trailing splits
     static const bool verbose = getenv("STEM_IGEMM_VERBOSE") != nullptr;

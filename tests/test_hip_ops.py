@@ -337,3 +337,75 @@ def test_fused_clip_adam_matches_torch(F):
         assert abs(np.sqrt(acc.item()) - float(total)) < 1e-5 * float(total)
         F.adam_step(p, gd, m, v, acc, 1.0, 1.0, 1e-4, 0.9, 0.999, 1e-8, step)
         assert_close(p.cpu().numpy(), ref.detach().numpy(), 1e-6, what=f"adam step {step}")
+
+
+def _fuzz_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    while len(cases) < n:
+        k = int(rng.choice([1, 3, 5]))
+        st = int(rng.choice([1, 2])) if k > 1 else 1
+        up = bool(rng.integers(0, 2)) and st == 2
+        cin = int(rng.choice([3, 4, 5, 8, 16, 36, 64, 100, 128, 160, 192]))
+        cout = int(rng.choice([3, 4, 6, 8, 32, 64, 96, 128, 130, 192]))
+        H, W = int(rng.integers(1, 20)), int(rng.integers(1, 24))
+        if not up and (H + 2 * (k // 2) < k or W + 2 * (k // 2) < k):
+            continue
+        B = int(rng.integers(1, 4))
+        cases.append((B, cin, cout, k, st, up, H, W))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(36, 20261002), ids=lambda c: "B%d_c%d_k%d_%dx%d_s%d_%s_%dx%d" % (c[0], c[1], c[2], c[3], c[3], c[4], "T" if c[5] else "C", c[6], c[7]))
+def test_conv_layers_fuzz_vs_oracle(case):
+    """Random layer geometries (odd sizes, channel counts off the vector path, 1-pixel images, batch 1..3) through the
+    layer modules: forward, input gradient, weight gradient and bias gradient vs the oracle.  Guards the tile / split /
+    folded-tap / fused-bias / 8-wavefront variants the planner may pick."""
+    from spatiotemporalentropymodel_amd.layers import conv, deconv
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_
+    B, cin, cout, k, st, up, H, W = case
+    m = closed_form_fill_((deconv if up else conv)(cin, cout, k, st)).cuda()
+    gen = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, cin, H, W, generator=gen)
+    xg = x.cuda().requires_grad_(True)
+    y = m(xg)
+    w, b = host(m.weight), host(m.bias)
+    pad = k // 2
+    ref = orc.deconv2d_fwd(x.numpy(), w, b, st, pad, st - 1) if up else orc.conv2d_fwd(x.numpy(), w, b, st, pad)
+    assert_close(host(y), ref, what="forward")
+    dy = torch.randn(*ref.shape, generator=gen)
+    y.backward(dy.cuda().contiguous(memory_format=torch.channels_last))
+    rdx, rdw, rdb = (orc.deconv2d_bwd(x.numpy(), w, dy.numpy(), st, pad, st - 1) if up else orc.conv2d_bwd(x.numpy(), w, dy.numpy(), st, pad))
+    assert_close(host(xg.grad), rdx, what="input gradient")
+    assert_close(host(m.weight.grad), rdw, what="weight gradient")
+    assert_close(host(m.bias.grad), rdb, what="bias gradient")
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(14, 77), ids=lambda c: "B%d_c%d_k%d_%dx%d_s%d_%s_%dx%d" % (c[0], c[1], c[2], c[3], c[3], c[4], "T" if c[5] else "C", c[6], c[7]))
+def test_conv_layers_fuzz_flat_gradient_accumulation(case):
+    """Same random geometries with the parameters living in optim.FlatParameters: two backward passes accumulate
+    straight into the flat gradient buffer (unpack / column-sum kernels with the accumulate flag, on the weight-gradient
+    side stream) and must equal the sum of the two oracle gradients."""
+    from spatiotemporalentropymodel_amd.layers import conv, deconv, join_wgrad_stream
+    from spatiotemporalentropymodel_amd.optim import FlatParameters
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_
+    B, cin, cout, k, st, up, H, W = case
+    m = closed_form_fill_((deconv if up else conv)(cin, cout, k, st)).cuda()
+    flat = FlatParameters(sorted(m.named_parameters(), key=lambda t: t[0]))
+    flat.zero_grad()
+    gen = torch.Generator().manual_seed(hash(case) % (2 ** 31) + 1)
+    w, b = host(m.weight), host(m.bias)
+    pad = k // 2
+    tot_w, tot_b = 0.0, 0.0
+    for _ in range(2):
+        x = torch.randn(B, cin, H, W, generator=gen)
+        y = m(x.cuda())
+        dy = torch.randn(*y.shape, generator=gen)
+        y.backward(dy.cuda().contiguous(memory_format=torch.channels_last))
+        _, rdw, rdb = (orc.deconv2d_bwd(x.numpy(), w, dy.numpy(), st, pad, st - 1, need_dx=False) if up
+                       else orc.conv2d_bwd(x.numpy(), w, dy.numpy(), st, pad, need_dx=False))
+        tot_w, tot_b = tot_w + rdw.astype(np.float64), tot_b + rdb.astype(np.float64)
+    join_wgrad_stream()
+    assert m.weight.grad is m.weight._flat_grad_view and m.weight.grad.data_ptr() >= flat.grad.data_ptr()
+    assert_close(host(m.weight.grad), tot_w, what="accumulated weight gradient")
+    assert_close(host(m.bias.grad), tot_b, what="accumulated bias gradient")
