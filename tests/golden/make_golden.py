@@ -578,6 +578,35 @@ def gen_stem_roi_gop(ref, batch=1, size=64, nframes=3):
     save("stem_roi_gop.npz", d)
 
 
+def gen_stem_variants(ref, batch=1, size=64):
+    """The three remaining classes of compressai/models/stem_roi.py (stem_baseline, stem_baselinev2, stem_roi_wo_gsc):
+    training-mode forward + loss.backward() with the reference, closed-form weights (scaled like the ROI goldens)."""
+    import compressai.models.stem_roi as ref_roi
+    d = {}
+    frames = smooth_frames("variants", batch, 2, size)
+    qmap = closed_form_input("variants:qmap", (batch, 1, size, size), 0.0, 1.0)
+    d["qmap"] = t2n(qmap)
+    for cls in ("stem_baseline", "stem_baselinev2", "stem_roi_wo_gsc"):
+        log = []
+        m = getattr(ref_roi, cls)().train()
+        closed_form_fill_scaled_(m, cls, ROI_CONV_SCALE)
+        m.entropy_bottleneck._get_noise_cached = NoiseFeed(cls + "_eb", log)
+        m.gaussian_conditional._get_noise_cached = NoiseFeed(cls + "_gc", log)
+        if cls == "stem_roi_wo_gsc":
+            out = m(frames[1], frames[0], qmap)
+            oc = ref.PixelwiseRateDistortionLoss()(out, frames[1], ref.quality2lambda(qmap))
+        else:
+            out = m(frames[1], frames[0])
+            oc = ref.RateDistortionLoss(lmbda=0.01)(out, frames[1])
+        oc["loss"].backward()
+        _grad_digest(d, cls, m)
+        d[f"{cls}:x_hat"], d[f"{cls}:y_hat"] = t2n(out["x_hat"]), t2n(out["y_hat"])
+        d[f"{cls}:lik_y"], d[f"{cls}:lik_z"] = t2n(out["likelihoods"]["y"]), t2n(out["likelihoods"]["z"])
+        d[f"{cls}:scalars"] = np.array([float(oc["loss"]), float(oc["mse_loss"]), float(oc["bpp_loss"])])
+    d["cfg"] = np.array([batch, size])
+    save("stem_variants.npz", d)
+
+
 def gen_container(ref):
     """Byte layout of compressai_examples/codec.py's container (:63-119,178-187) from the reference's own writers."""
     import io
@@ -680,7 +709,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     scratch, ref_utils = import_reference()
     try:
-        which = sys.argv[1:] or ["ops", "codec", "fwd", "train_small", "train_big", "stemcodec", "roi", "roiops", "roigop", "container", "dataset"]
+        which = sys.argv[1:] or ["ops", "codec", "fwd", "train_small", "train_big", "stemcodec", "roi", "roiops", "roigop", "container", "dataset", "variants"]
         if "ops" in which:
             gen_ops(ref_utils)
         if "codec" in which:
@@ -701,6 +730,8 @@ if __name__ == "__main__":
             gen_stem_roi_gop(ref_utils)
         if "container" in which:
             gen_container(ref_utils)
+        if "variants" in which:
+            gen_stem_variants(ref_utils)
         if "dataset" in which:
             gen_roi_dataset(ref_utils)
     finally:

@@ -353,3 +353,47 @@ def test_roi_batch_and_nonsquare_consistency():
     assert len(loose) <= 6 and all(e < 3e-3 for _, e in loose), loose
     assert_close(host(gx01[0:1]), host(0.5 * gx0), 1e-4, what="dL/dx_conditioned, sample 0")
     assert_close(host(gx01[1:2]), host(0.5 * gx1), 1e-4, what="dL/dx_conditioned, sample 1")
+
+
+@pytest.mark.parametrize("cls", ["stem_baseline", "stem_baselinev2", "stem_roi_wo_gsc"])
+def test_remaining_pixel_domain_classes_match_reference(golden, cls):
+    """stem_baseline / stem_baselinev2 / stem_roi_wo_gsc: training forward, loss and every parameter gradient vs the
+    reference's own classes (tests/golden/make_golden.py:gen_stem_variants), then a compress / decompress round trip."""
+    import spatiotemporalentropymodel_amd.models as M
+    from spatiotemporalentropymodel_amd.losses import PixelwiseRateDistortionLoss, RateDistortionLoss, quality2lambda
+    from spatiotemporalentropymodel_amd.selfcheck import NoiseFeed
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_scaled_, smooth_frames
+    g = golden("stem_variants.npz")
+    dev = torch.device("cuda:0")
+    B, size = (int(v) for v in g["cfg"])
+    m = closed_form_fill_scaled_(getattr(M, cls)(), cls, ROI_CONV_SCALE).to(dev).train()
+    m.entropy_bottleneck.noise_source = NoiseFeed(cls + "_eb")
+    m.gaussian_conditional.noise_source = NoiseFeed(cls + "_gc")
+    frames = [f.to(dev) for f in smooth_frames("variants", B, 2, size)]
+    qmap = torch.from_numpy(g["qmap"]).to(dev)
+    if cls == "stem_roi_wo_gsc":
+        out = m(frames[1], frames[0], qmap)
+        oc = PixelwiseRateDistortionLoss()(out, frames[1], quality2lambda(qmap))
+    else:
+        out = m(frames[1], frames[0])
+        oc = RateDistortionLoss(lmbda=0.01)(out, frames[1])
+    assert_close(host(out["y_hat"]), g[f"{cls}:y_hat"], what="y_hat")
+    assert_close(host(out["x_hat"]), g[f"{cls}:x_hat"], what="x_hat")
+    assert_close(host(out["likelihoods"]["y"]), g[f"{cls}:lik_y"], 2e-4, atol=1e-9, what="lik_y")
+    assert_close(host(out["likelihoods"]["z"]), g[f"{cls}:lik_z"], atol=1e-9, what="lik_z")
+    for k, ref in zip(("loss", "mse_loss", "bpp_loss"), g[f"{cls}:scalars"]):
+        assert abs(float(oc[k].detach()) - ref) <= 1e-4 * abs(ref), (k, float(oc[k].detach()), ref)
+    oc["loss"].backward()
+    assert _check_grads(g, cls, m) > 50
+    m.eval()
+    m.update(force=True)
+    with torch.no_grad():
+        args = (frames[1], frames[0], qmap) if cls == "stem_roi_wo_gsc" else (frames[1], frames[0])
+        enc = m.compress(*args)
+        dec = m.decompress(enc["strings"], enc["shape"], frames[0])
+        ev = m(*args)
+    np.testing.assert_array_equal(host(dec["y_hat"]), host(ev["y_hat"]))
+    assert_close(host(dec["x_hat"]), host(ev["x_hat"].clamp(0, 1)), 1e-6, what="decoded x_hat")
+    if cls != "stem_roi_wo_gsc":
+        y = m.getY(frames[1][:, :, :50, :40], isEval=True)          # centred zero padding to multiples of 64 (stem_roi.py:141-160)
+        assert tuple(y.shape) == (B, 192, 4, 4)
