@@ -607,6 +607,32 @@ def gen_stem_variants(ref, batch=1, size=64):
     save("stem_variants.npz", d)
 
 
+def gen_stem_ablations(ref, batch=2, ls=8, cin=96):
+    """Training forward + EMLoss backward of the four non-residual STEM variants (spatiotemporalpriors.py:33-788) on
+    closed-form latents: outputs, loss and every parameter gradient."""
+    import compressai.models.spatiotemporalpriors as sp
+    d = {}
+    y_cur = closed_form_input("abl:y", (batch, cin, ls, ls), -5.0, 5.0)
+    y_cond = closed_form_input("abl:c", (batch, cin, ls, ls), -5.0, 5.0)
+    target = torch.zeros(batch, 3, ls * 16, ls * 16)
+    for cls, ebc in (("SpatioTemporalPriorModelWithoutSPMTPM", 256), ("SpatioTemporalPriorModelWithoutSPM", 256),
+                     ("SpatioTemporalPriorModelWithoutTPM", 64), ("SpatioTemporalPriorModel", 64)):
+        log = []
+        m = getattr(sp, cls)(ebc, cin).train()
+        closed_form_fill_wrapped(m, cls)
+        m.entropy_bottleneck._get_noise_cached = NoiseFeed(cls + "_eb", log)
+        m.gaussian_conditional._get_noise_cached = NoiseFeed(cls + "_gc", log)
+        out = m(y_cur, y_cond)
+        oc = ref.EMLoss()(out, target)
+        oc["loss"].backward()
+        _grad_digest(d, cls, m)
+        d[f"{cls}:y_hat"], d[f"{cls}:lik_y"], d[f"{cls}:lik_z"] = t2n(out["y_hat"]), t2n(out["likelihoods"]["y"]), t2n(out["likelihoods"]["z"])
+        d[f"{cls}:scalars"] = np.array([float(oc["loss"]), float(oc["y_bpp_loss"]), float(oc["z_bpp_loss"])])
+        d[f"{cls}:noise_log"] = np.array([f"{n}|{','.join(map(str, s_))}" for n, s_ in log])
+    d["cfg"] = np.array([batch, ls, cin])
+    save("stem_ablations.npz", d)
+
+
 def gen_container(ref):
     """Byte layout of compressai_examples/codec.py's container (:63-119,178-187) from the reference's own writers."""
     import io
@@ -709,7 +735,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     scratch, ref_utils = import_reference()
     try:
-        which = sys.argv[1:] or ["ops", "codec", "fwd", "train_small", "train_big", "stemcodec", "roi", "roiops", "roigop", "container", "dataset", "variants"]
+        which = sys.argv[1:] or ["ops", "codec", "fwd", "train_small", "train_big", "stemcodec", "roi", "roiops", "roigop", "container", "dataset", "variants", "ablations"]
         if "ops" in which:
             gen_ops(ref_utils)
         if "codec" in which:
@@ -732,6 +758,8 @@ if __name__ == "__main__":
             gen_container(ref_utils)
         if "variants" in which:
             gen_stem_variants(ref_utils)
+        if "ablations" in which:
+            gen_stem_ablations(ref_utils)
         if "dataset" in which:
             gen_roi_dataset(ref_utils)
     finally:

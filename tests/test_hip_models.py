@@ -193,3 +193,52 @@ def test_layer_modules_autograd(S):
     assert_close(host(net[2].weight.grad), dw1, what="dw1")
     assert_close(host(net[0].bias.grad), db0, what="db0")
     assert_close(host(net[2].bias.grad), db1, what="db1")
+
+
+@pytest.mark.parametrize("cls,ebc", [("SpatioTemporalPriorModelWithoutSPMTPM", 256), ("SpatioTemporalPriorModelWithoutSPM", 256),
+                                     ("SpatioTemporalPriorModelWithoutTPM", 64), ("SpatioTemporalPriorModel", 64)])
+def test_ablation_variants_training_pass_matches_reference(golden, cls, ebc):
+    """The four non-residual STEM variants (hyper-prior only / + temporal / + spatial / all three): training forward,
+    EMLoss and every parameter gradient vs the reference's own classes (make_golden.py:gen_stem_ablations)."""
+    import spatiotemporalentropymodel_amd.models as M
+    from spatiotemporalentropymodel_amd.losses import EMLoss
+    from spatiotemporalentropymodel_amd.selfcheck import NoiseFeed
+    from spatiotemporalentropymodel_amd.weights import closed_form_input, closed_form_tensor
+    g = golden("stem_ablations.npz")
+    batch, ls, cin = (int(v) for v in g["cfg"])
+    dev = torch.device("cuda:0")
+    m = getattr(M, cls)(ebc, cin)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            t = closed_form_tensor(f"{cls}.{n}", p.shape, p)
+            if t is not None:
+                p.copy_(t)
+    m = m.to(dev).train()
+    m.entropy_bottleneck.noise_source = NoiseFeed(cls + "_eb")
+    m.gaussian_conditional.noise_source = NoiseFeed(cls + "_gc")
+    y_cur = closed_form_input("abl:y", (batch, cin, ls, ls), -5.0, 5.0).to(dev)
+    y_cond = closed_form_input("abl:c", (batch, cin, ls, ls), -5.0, 5.0).to(dev)
+    out = m(y_cur, y_cond)
+    oc = EMLoss()(out, torch.zeros(batch, 3, ls * 16, ls * 16, device=dev))
+    assert_close(host(out["y_hat"]), g[f"{cls}:y_hat"], what="y_hat")
+    assert_close(host(out["likelihoods"]["y"]), g[f"{cls}:lik_y"], 2e-4, atol=1e-9, what="lik_y")
+    assert_close(host(out["likelihoods"]["z"]), g[f"{cls}:lik_z"], atol=1e-9, what="lik_z")
+    for k, ref in zip(("loss", "y_bpp_loss", "z_bpp_loss"), g[f"{cls}:scalars"]):
+        assert abs(float(oc[k].detach()) - ref) <= 1e-4 * abs(ref), (k, float(oc[k].detach()), ref)
+    oc["loss"].backward()
+    seen = 0
+    for n, p in m.named_parameters():
+        key = f"{cls}:gsum:{n}"
+        if key not in g:
+            continue
+        ref = g[key]
+        gd = p.grad.double()
+        assert abs(float(gd.abs().sum()) - ref[1]) <= 2e-4 * ref[1] + 1e-12, n
+        assert abs(float(gd.sum()) - ref[0]) <= 2e-4 * ref[1] + 1e-12, n
+        rms = float(np.sqrt(ref[2] / p.numel()))
+        sl = host(p.grad.reshape(-1)[:: max(1, p.numel() // 64)][:64])
+        # 2e-4: here z is 2x2 at batch 2, so the hyper-path gradients are sums over 8 samples of dlik / lik terms
+        # (one element of HD.0.weight lands at 1.7e-4)
+        assert_close(sl, g[f"{cls}:gslice:{n}"], 2 * GRAD_RTOL, atol=2 * GRAD_RTOL * rms, what=f"grad {n}")
+        seen += 1
+    assert seen >= 25
