@@ -336,11 +336,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
     }
     __syncthreads();
     if (VEC) {
-        for (int q = q_begin; q < q_end; q += 2) {
+        // break-free two-step body (the odd tail runs after the loop): with a mid-loop exit the compiler merged the wait
+        // counters of both exits into vmcnt(0) at the top of the body and copied the accumulators between the steps
+        int q = q_begin;
+        for (; q + 1 < q_end; q += 2) {
             step(0, raA, rbA, clampq(q + 3));                  // chunk q; stage q+1 -> buffer 1; prefetch q+3
             __syncthreads();
-            if (q + 1 >= q_end) break;
             step(1, raB, rbB, clampq(q + 4));                  // chunk q+1; stage q+2 -> buffer 0; prefetch q+4
+            __syncthreads();
+        }
+        if (q < q_end) {
+            step(0, raA, rbA, clampq(q + 3));
             __syncthreads();
         }
     } else {
