@@ -397,3 +397,41 @@ def test_remaining_pixel_domain_classes_match_reference(golden, cls):
     if cls != "stem_roi_wo_gsc":
         y = m.getY(frames[1][:, :, :50, :40], isEval=True)          # centred zero padding to multiples of 64 (stem_roi.py:141-160)
         assert tuple(y.shape) == (B, 192, 4, 4)
+
+
+def test_weighted_mse_loss_and_standalone_clip():
+    """PixelwiseRateDistortionLoss's distortion term (fwd/bwd kernels) against the reference formula (utils.py:69-71) in
+    torch, and optim.clip_grad_norm_ over two flat buffers against torch.nn.utils.clip_grad_norm_."""
+    from spatiotemporalentropymodel_amd.losses import _WeightedMSEFunction
+    from spatiotemporalentropymodel_amd.optim import FlatParameters, FusedClipAdam, clip_grad_norm_
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(9)
+    xh = torch.rand(3, 3, 20, 28, device=dev, generator=g, requires_grad=True)
+    x = torch.rand(3, 3, 20, 28, device=dev, generator=g)
+    lam = torch.rand(3, 1, 20, 28, device=dev, generator=g) * 0.05
+    loss = _WeightedMSEFunction.apply(xh, x, lam)
+    (loss * 3.0).backward()
+    xr = xh.detach().clone().requires_grad_(True)
+    ref = torch.mean(lam.expand_as(x) * torch.nn.functional.mse_loss(xr, x, reduction="none"))
+    (ref * 3.0).backward()
+    assert abs(float(loss) - float(ref)) <= 1e-6 * float(ref)
+    assert_close(host(xh.grad), host(xr.grad), 1e-6, what="weighted-MSE gradient")
+    # clip over the union of two flat buffers; second call below the threshold must not scale
+    a = [torch.nn.Parameter(torch.randn(37, 5, device=dev, generator=g)), torch.nn.Parameter(torch.randn(11, device=dev, generator=g))]
+    b = [torch.nn.Parameter(torch.randn(3, 1, 3, device=dev, generator=g))]
+    oa = FusedClipAdam(FlatParameters([(f"a{i}", p) for i, p in enumerate(a)]), 1e-3)
+    ob = FusedClipAdam(FlatParameters([(f"b{i}", p) for i, p in enumerate(b)]), 1e-3)
+    grads = [torch.randn_like(p) * 3 for p in a + b]
+    for p, gr in zip(a + b, grads):
+        p.grad.copy_(gr)
+    clones = [torch.nn.Parameter(p.detach().clone()) for p in a + b]
+    for c, gr in zip(clones, grads):
+        c.grad = gr.clone()
+    n_ref = torch.nn.utils.clip_grad_norm_(clones, 1.0)
+    n = clip_grad_norm_((oa, ob), 1.0)
+    assert abs(float(n) - float(n_ref)) <= 1e-6 * float(n_ref)
+    for p, c in zip(a + b, clones):
+        assert_close(host(p.grad), host(c.grad), 1e-6, what="clipped gradient")
+    before = [p.grad.clone() for p in a + b]
+    n2 = clip_grad_norm_((oa, ob), 10.0)
+    assert abs(float(n2) - 1.0) < 1e-4 and all(torch.equal(p.grad, q) for p, q in zip(a + b, before))
