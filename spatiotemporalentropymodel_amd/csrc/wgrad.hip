@@ -15,6 +15,9 @@
 namespace {
 
 constexpr int KP = 32;   // pixels per chunk
+#ifndef WGRAD_PAD
+#define WGRAD_PAD 0
+#endif
 
 struct WgradArgs {
     const float *p, *g;
@@ -54,7 +57,7 @@ __global__ void wgrad_pixtab_kernel(int *ptab, int Mtot, int PH, int PW, int GH,
 // are folded into the tile's N axis -- column j = (t mod BN/4) * 4 + c, BN/4 taps per tile -- instead of one workgroup
 // row per tap with a 4-of-BN filled tile.
 template <int BM, int BN, int WM, int WN, bool VEC, bool C4 = false>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) == 8 ? 4 : BM * BN >= 128 * 128 ? 2 : BM * BN >= 128 * 64 ? 3 : 4))
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, ((BM / WM) * (BN / WN) == 8 ? 4 : BM * BN >= 128 * 128 ? 2 : BM * BN >= 128 * 64 ? 3 : 5))
 void wgrad_kernel(const WgradArgs a)
 {
     constexpr int NT = (BM / WM) * (BN / WN) * 64;          // 4 wavefronts, or 8 for the 128x128 tile with 32x64 wave tiles
@@ -62,7 +65,10 @@ void wgrad_kernel(const WgradArgs a)
     constexpr int TPT = BN / 4;                             // taps per tile (C4)
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WCOLS = BN / WN;
-    constexpr int PA = BM + 4, PB = BN + 4;                 // LDS pitches
+    // LDS pitches = tile widths, no padding: the operand fetch is ds_read_b32 (lane groups are the two 32-lane halves, which
+    // read different rows and never share a cycle) and the staging writes are 16-byte runs of 8 consecutive lanes, so both
+    // are conflict-free at any pitch; unpadded, the 64x64 tile takes exactly 32 KiB = five workgroups per CU.
+    constexpr int PA = BM + WGRAD_PAD, PB = BN + WGRAD_PAD;
     constexpr int F4A = BM / 4, F4B = BN / 4;               // float4 per pixel row
     constexpr int RPA = NT / F4A, RPB = NT / F4B;           // pixel rows per pass
     constexpr int NPA = KP / RPA, NPB = KP / RPB;           // passes
@@ -320,7 +326,7 @@ template <int BM, int BN, int WM, int WN>
 int launch_cfg(const WgradArgs &a, bool vec, hipStream_t st)
 {
     dim3 grid(cdiv(a.CP, BM) * cdiv(a.CG, BN), a.R * a.S, a.splits), block((BM / WM) * (BN / WN) * 64);
-    const size_t lds = (size_t)2 * KP * (BM + 4 + BN + 4) * sizeof(float);
+    const size_t lds = (size_t)2 * KP * (BM + BN + 2 * WGRAD_PAD) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void *)wgrad_kernel<BM, BN, WM, WN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -339,7 +345,7 @@ int launch_c4(const WgradArgs &a, hipStream_t st)
 {
     constexpr int BM = 64, BN = 64;
     dim3 grid(cdiv(a.CP, BM) * cdiv(a.R * a.S, BN / 4), 1, a.splits), block(256);
-    const size_t lds = (size_t)2 * KP * (BM + 4 + BN + 4) * sizeof(float);
+    const size_t lds = (size_t)2 * KP * (BM + BN + 2 * WGRAD_PAD) * sizeof(float);
     hipLaunchKernelGGL((wgrad_kernel<BM, BN, 32, 32, true, true>), grid, block, lds, st, a);
     STEM_LAUNCH_CHECK("wgrad_c4");
     return 0;
@@ -371,7 +377,7 @@ void plan(int CP, int CG, int T, int nchunks, int *cfg, int *splits)
         *splits = cdiv(nchunks, cps);
         return;
     }
-    const int slots[NCFG] = {512, 768, 768, 1024, 512};      // co-resident workgroups (LDS: 68 / 51 / 51 / 34 / 68 KB)
+    const int slots[NCFG] = {512, 768, 768, 1280, 512};      // co-resident workgroups (LDS: 64 / 48 / 48 / 32 / 64 KiB)
     const int wps[NCFG] = {1, 1, 1, 1, 2};                   // wavefronts per SIMD contributed by one workgroup
     static const float eff4 = getenv("STEM_WGRAD_EFF4") ? (float)atof(getenv("STEM_WGRAD_EFF4")) : kWT[4].eff;     // tuning aid
     static const int forced = getenv("STEM_WGRAD_CFG") ? atoi(getenv("STEM_WGRAD_CFG")) : -1;      // tuning aid
