@@ -288,7 +288,9 @@ int stem_ar_finish_encode_wave(const float *gp, const float *table, int T, float
                                int32_t *sym, int32_t *idx, int M, int t, int H, int Wd, int Wp, int pad, void *stream);
 
 /* ---- optimiser --------------------------------------------------------- */
-/* sum of squares of a flat gradient buffer accumulated into acc[0] (double)                       */
+/* acc[0] (double) += sum of squares of a flat gradient buffer, in two stages without atomics (bit-reproducible):
+ * `acc` must hold 1 + STEM_SUMSQ_SCRATCH doubles, acc[1..] is scratch for the per-workgroup partial sums. */
+#define STEM_SUMSQ_SCRATCH 2048
 int stem_sumsq(const float *g, size_t n, double *acc, void *stream);
 /* stand-alone torch.nn.utils.clip_grad_norm_ (stem_roi/train_stem_roi.py:536,563 clips once per frame while gradients
  * accumulate over the GOP): g *= min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)); sumsq may span several buffers. */

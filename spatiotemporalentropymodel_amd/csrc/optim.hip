@@ -6,7 +6,10 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const f32x4 *g4, const float *g, size_t n4, size_t n, double *acc)
+// Two deterministic stages (no float atomics: the clip coefficient derived from this sum scales every gradient, so the
+// sum itself must not depend on workgroup scheduling): per-workgroup partials into the caller's scratch, then one
+// workgroup adds them in a fixed order onto acc[0].
+__global__ __launch_bounds__(256) void sumsq_kernel(const f32x4 *g4, const float *g, size_t n4, size_t n, double *part)
 {
     __shared__ double red[256];
     double s = 0.0;
@@ -22,7 +25,20 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const f32x4 *g4, const float
         if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicAdd(acc, red[0]);
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const double *part, int nparts, double *acc)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) acc[0] += red[0];
 }
 
 // torch.optim.Adam single-tensor update (no amsgrad, no weight decay):
@@ -69,9 +85,10 @@ STEM_EXPORT int stem_sumsq(const float *g, size_t n, double *acc, void *stream)
     const bool al = (((uintptr_t)g) & 15) == 0;
     const size_t n4 = al ? n / 4 : 0;
     size_t nb = cdivz(n4 ? n4 : 1, 256);
-    if (nb > 2048) nb = 2048;
+    if (nb > STEM_SUMSQ_SCRATCH) nb = STEM_SUMSQ_SCRATCH;
     hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const f32x4 *>(g), g, n4, n, acc);
+                       reinterpret_cast<const f32x4 *>(g), g, n4, n, acc + 1);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, acc + 1, (int)nb, acc);
     STEM_LAUNCH_CHECK("sumsq");
     return 0;
 }

@@ -571,7 +571,15 @@ def build_indexes(scales, table, scale_bound=0.11):
     return idx
 
 
+SUMSQ_SCRATCH = 2048          # include/stem_hip.h: `acc` holds 1 + SUMSQ_SCRATCH doubles, acc[0] is the running sum
+
+
+def sumsq_accumulator(device):
+    return torch.zeros(1 + SUMSQ_SCRATCH, dtype=torch.float64, device=device)
+
+
 def sumsq(g, acc):
+    assert acc.numel() >= 1 + SUMSQ_SCRATCH
     _chk(_lib.hip().stem_sumsq(g.data_ptr(), g.numel(), acc.data_ptr(), _stream()))
 
 

@@ -52,7 +52,7 @@ class FusedClipAdam:
         self.m = torch.zeros_like(flat.data)
         self.v = torch.zeros_like(flat.data)
         self.t = 0
-        self._sumsq = torch.zeros(1, dtype=torch.float64, device=flat.data.device)
+        self._sumsq = F.sumsq_accumulator(flat.data.device)          # [0] = sum of squares, rest = reduction scratch
         self.param_groups = [{"lr": self.lr, "params": flat.params}]
 
     def zero_grad(self, set_to_none=False):
@@ -61,9 +61,9 @@ class FusedClipAdam:
     def grad_norm(self):
         """Global L2 norm of the current flat gradient as a 0-dim device tensor (no host sync)."""
         join_wgrad_stream()
-        self._sumsq.zero_()
+        self._sumsq[:1].zero_()
         F.sumsq(self.flat.grad, self._sumsq)
-        return self._sumsq.sqrt().reshape(())
+        return self._sumsq[0].sqrt().reshape(())
 
     def step(self, grad_scale: float = 1.0):
         """grad_scale multiplies the gradient first (1/world_size after a sum all-reduce)."""
@@ -72,7 +72,7 @@ class FusedClipAdam:
         self.lr = self.param_groups[0]["lr"]
         use_clip = self.max_norm is not None and self.max_norm > 0
         if use_clip:
-            self._sumsq.zero_()
+            self._sumsq[:1].zero_()
             F.sumsq(self.flat.grad, self._sumsq)
         F.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self._sumsq if use_clip else None,
                     float(self.max_norm) if use_clip else 0.0, float(grad_scale), self.lr, self.betas[0], self.betas[1],
@@ -99,12 +99,12 @@ def clip_grad_norm_(optimizers, max_norm, tensors=None):
     optimizers = [o for o in optimizers if o is not None]
     bufs = list(tensors) if tensors is not None else [o.flat.grad for o in optimizers]
     acc = optimizers[0]._sumsq
-    acc.zero_()
+    acc[:1].zero_()
     for g in bufs:
         F.sumsq(g, acc)
     for g in bufs:
         F.clip_scale(g, acc, max_norm)
-    return acc.sqrt().reshape(())
+    return acc[0].sqrt().reshape(())
 
 
 def configure_optimizers(net, args, fused=True, max_norm=1.0):

@@ -176,6 +176,4 @@ def test_roi_gop_iteration_is_bit_reproducible():
         assert torch.equal(a, b), "accumulated gradients differ between two identical GOP iterations"
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b), "parameters differ between two identical GOP iterations"
-    # the reported norms come from fp64 atomic accumulation (order-dependent in the last bits); what is applied to the
-    # gradients is their float32 rounding, which the bit-identical buffers above show to be the same
-    assert all(abs(a - b) <= 1e-12 * a and np.isfinite(a) and a > 0 for a, b in zip(res[0][2], res[1][2]))
+    assert res[0][2] == res[1][2] and all(np.isfinite(a) and a > 0 for a in res[0][2])      # clip norms: no atomics either

@@ -434,4 +434,5 @@ def test_weighted_mse_loss_and_standalone_clip():
         assert_close(host(p.grad), host(c.grad), 1e-6, what="clipped gradient")
     before = [p.grad.clone() for p in a + b]
     n2 = clip_grad_norm_((oa, ob), 10.0)
+    assert float(clip_grad_norm_((oa, ob), 10.0)) == float(n2)      # deterministic reduction
     assert abs(float(n2) - 1.0) < 1e-4 and all(torch.equal(p.grad, q) for p, q in zip(a + b, before))
