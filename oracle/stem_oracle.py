@@ -461,3 +461,80 @@ def stem_backward(sd, keep, lik_y, lik_z, num_pixels):
     d = lrelu_bwd(k["he0"], d)
     _, g["HE.0.weight"], g["HE.0.bias"] = conv2d_bwd(k["he_in"], sd["HE.0.weight"], d, 1, 1, need_dx=False)
     return g
+
+
+# ---- variable-rate (ROI) pixel-domain models: forward pass (compressai/models/stem_roi.py:353-699, 1017-1325) -----------
+def _seq_lrelu(sd, prefix, x, spec, slope):
+    """nn.Sequential of (transposed) convolutions with LeakyReLU(slope) between them; spec = [(kind, stride, pad[, opad])]."""
+    h = x
+    for i, lay in enumerate(spec):
+        w, b = sd[f"{prefix}{2 * i}.weight"], sd[f"{prefix}{2 * i}.bias"]
+        h = deconv2d_fwd(h, w, b, lay[1], lay[2], lay[3]) if lay[0] == "T" else conv2d_fwd(h, w, b, lay[1], lay[2])
+        if i < len(spec) - 1:
+            h = lrelu_fwd(h, slope)
+    return h
+
+
+_QHEAD = [("C", 1, 1)] * 3                                   # qmap_feature_{ga1,ha1,gs0}: three 3x3 stride-1 convolutions
+_QDOWN = [("C", 2, 1), ("C", 1, 0)]                          # qmap_feature_{ga2..4,ha2,ha3}: 3x3 stride 2, then 1x1
+_QUP = [("T", 2, 1, 1), ("C", 1, 0)]                         # qmap_feature_gs{1..3}: 3x3 stride-2 transposed, then 1x1
+_UP2 = [("T", 2, 2, 1), ("T", 2, 2, 1), ("C", 1, 1)]         # hs / wmap_generator
+_CHAIN5 = [("C", 1, 2)] * 3                                  # TPM
+_CHAIN1 = [("C", 1, 0)] * 3                                  # EPM
+
+
+def _conv_gdn(sd, prefix, x, inverse):
+    """nn.Sequential(conv | deconv (5x5, stride 2), GDN)"""
+    w, b = sd[prefix + "0.weight"], sd[prefix + "0.bias"]
+    h = deconv2d_fwd(x, w, b, 2, 2, 1) if inverse else conv2d_fwd(x, w, b, 2, 2)
+    return gdn_fwd(h, sd[prefix + "1.beta"], sd[prefix + "1.gamma"], inverse=inverse)
+
+
+def stem_roi_forward(sd, x_cur, x_cond, qmap, noise, temporal=True):
+    """stem_roi.forward (temporal=True; :585-608) / stem_roi_i.forward (temporal=False) in training mode.
+    noise = {"z": [B,256,h,w] (already in NCHW), "y": [B,192,H/16,W/16]}.  -> dict(x_hat, y_hat, lik_y, lik_z)."""
+    sd = {n: np.asarray(v, np.float32) for n, v in sd.items() if np.asarray(v).dtype.kind == "f"}
+    sft = lambda pre, x, q, slope=1.0: sft_module_fwd(sd, pre + ".", x, q, slope)[0]
+    res = lambda pre, x, q: sft_resblk_fwd(sd, pre + ".", x, q)[0]
+    # PEncoder (:534-550)
+    q = _seq_lrelu(sd, "qmap_feature_ga1.", np.concatenate([x_cur, qmap], 1), _QHEAD, 0.1)
+    x = x_cur
+    for i in (1, 2, 3):
+        if i > 1:
+            q = _seq_lrelu(sd, f"qmap_feature_ga{i}.", q, _QDOWN, 0.1)
+        x = sft(f"ga{i}_SFT", _conv_gdn(sd, f"ga{i}.", x, False), q)
+    q = _seq_lrelu(sd, "qmap_feature_ga4.", q, _QDOWN, 0.1)
+    x = conv2d_fwd(x, sd["ga4.weight"], sd["ga4.bias"], 2, 2)
+    y_cur = res("ga4_SFTResB2", res("ga4_SFTResB1", x, q), q)
+    y_cond = None
+    if temporal:                                             # ConditionEncoder (:503-511): the mbt2018 analysis ladder
+        y_cond = g_a(sd, x_cond, prefix="ConditionEncoder.")
+    # HE (:575-593)
+    yy = np.concatenate([y_cur, y_cond], 1) if temporal else y_cur
+    q = _seq_lrelu(sd, "qmap_feature_ha1.", np.concatenate([avgpool_fwd(qmap, yy.shape[2], yy.shape[3]), yy], 1), _QHEAD, 0.1)
+    x = sft("ha1_SFT", conv2d_fwd(yy, sd["ha1.weight"], sd["ha1.bias"], 1, 1), q, 0.01)
+    q = _seq_lrelu(sd, "qmap_feature_ha2.", q, _QDOWN, 0.1)
+    x = sft("ha2_SFT", conv2d_fwd(x, sd["ha2.weight"], sd["ha2.bias"], 2, 2), q, 0.01)
+    q = _seq_lrelu(sd, "qmap_feature_ha3.", q, _QDOWN, 0.1)
+    x = conv2d_fwd(x, sd["ha3.weight"], sd["ha3.bias"], 2, 2)
+    z = res("ha3_ResB2", res("ha3_ResB1", x, q), q)
+    # entropy bottleneck in training mode (noise), hyper decoder, priors
+    z_hat = z + noise["z"]
+    lik_z = cl_to_nchw(eb_likelihood_fwd(nchw_to_cl(z_hat), eb_pack_params(sd)), z.shape)
+    hyper = _seq_lrelu(sd, "hs.", z_hat, _UP2, 0.01)
+    if temporal:
+        gp = _seq_lrelu(sd, "EPM.", np.concatenate([_seq_lrelu(sd, "TPM.", y_cond, _CHAIN5, 0.01), hyper], 1), _CHAIN1, 0.01)
+    else:
+        gp = _seq_lrelu(sd, "EPM.", hyper, _CHAIN1, 0.01)
+    M = y_cur.shape[1]
+    scales, means = gp[:, :M], gp[:, M:]
+    y_hat = y_cur + noise["y"]                               # quantize(y, "noise"): the means do not enter (:128-135)
+    lik_y = gc_likelihood_fwd(y_hat, scales, means)
+    # PDecoder (:552-573)
+    w = _seq_lrelu(sd, "qmap_feature_gs0.", np.concatenate([_seq_lrelu(sd, "wmap_generator.", z_hat, _UP2, 0.01), y_hat], 1), _QHEAD, 0.1)
+    x = res("gs0_SFTResB2", res("gs0_SFTResB1", y_hat, w), w)
+    for i in (1, 2, 3):
+        w = _seq_lrelu(sd, f"qmap_feature_gs{i}.", w, _QUP, 0.1)
+        x = sft(f"gs{i}_SFT", _conv_gdn(sd, f"gs{i}.", x, True), w)
+    x_hat = deconv2d_fwd(x, sd["gs4.weight"], sd["gs4.bias"], 2, 2, 1)
+    return {"x_hat": x_hat, "y_hat": y_hat, "lik_y": lik_y, "lik_z": lik_z}

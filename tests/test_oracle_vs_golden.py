@@ -351,3 +351,46 @@ def test_sft_modules(golden, tag):
     assert len(grads) == len(p)
     for k, v in grads.items():
         assert_close(v, g[f"{tag}:g:{k}"], what=f"{tag} grad {k}")
+
+
+def test_stem_roi_iframe_forward(golden):
+    """The oracle's restatement of stem_roi_i.forward (training mode, injected noise) vs the reference run that produced
+    tests/golden/stem_roi.npz: latents, likelihoods and reconstruction."""
+    import torch
+    from spatiotemporalentropymodel_amd.models import stem_roi_i
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_scaled_, closed_form_input, smooth_frames
+    g = golden("stem_roi.npz")
+    B, size = (int(v) for v in g["cfg"])
+    m = closed_form_fill_scaled_(stem_roi_i(), "roi_i", 0.7)          # CPU module: only a parameter container here
+    sd = {k: v.detach().numpy() for k, v in m.state_dict().items() if v.dtype == torch.float32}
+    x = smooth_frames("roi", B, 2, size)[0].numpy()
+    zs = (B, 256, size // 64, size // 64)
+    nz = closed_form_input("noise:roi_i_eb:0", (256, 1, zs[2] * zs[3] * B), -0.5, 0.5).numpy()        # drawn as [C,1,H*W*B]
+    noise = {"z": orc.cl_to_nchw(nz.reshape(256, -1), zs),
+             "y": closed_form_input("noise:roi_i_gc:0", (B, 192, size // 16, size // 16), -0.5, 0.5).numpy()}
+    out = orc.stem_roi_forward(sd, x, None, g["qmap"], noise, temporal=False)
+    assert_close(out["y_hat"], g["i:y_hat"], what="y_hat")
+    assert_close(out["lik_z"], g["i:lik_z"], atol=1e-9, what="lik_z")
+    assert_close(out["lik_y"], g["i:lik_y"], 2e-4, atol=1e-9, what="lik_y")
+    assert_close(out["x_hat"], g["i:x_hat"], what="x_hat")
+
+
+def test_stem_roi_pframe_forward(golden):
+    """Same for stem_roi.forward (P frame: ConditionEncoder on the previous reconstruction, TPM, EPM on both priors)."""
+    import torch
+    from spatiotemporalentropymodel_amd.models import stem_roi
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_scaled_, closed_form_input, smooth_frames
+    g = golden("stem_roi.npz")
+    B, size = (int(v) for v in g["cfg"])
+    m = closed_form_fill_scaled_(stem_roi(), "roi_p", 0.7)
+    sd = {k: v.detach().numpy() for k, v in m.state_dict().items() if v.dtype == torch.float32}
+    x = smooth_frames("roi", B, 2, size)[1].numpy()
+    zs = (B, 256, size // 64, size // 64)
+    nz = closed_form_input("noise:roi_p_eb:0", (256, 1, zs[2] * zs[3] * B), -0.5, 0.5).numpy()
+    noise = {"z": orc.cl_to_nchw(nz.reshape(256, -1), zs),
+             "y": closed_form_input("noise:roi_p_gc:0", (B, 192, size // 16, size // 16), -0.5, 0.5).numpy()}
+    out = orc.stem_roi_forward(sd, x, g["i:x_hat"], g["qmap"], noise, temporal=True)
+    assert_close(out["y_hat"], g["p:y_hat"], what="y_hat")
+    assert_close(out["lik_z"], g["p:lik_z"], atol=1e-9, what="lik_z")
+    assert_close(out["lik_y"], g["p:lik_y"], 2e-4, atol=1e-9, what="lik_y")
+    assert_close(out["x_hat"], g["p:x_hat"], what="x_hat")
