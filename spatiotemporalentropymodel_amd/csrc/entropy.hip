@@ -147,19 +147,22 @@ __global__ __launch_bounds__(256) void eb_forward_kernel(const float *z, int ldz
     lik[i] = fmaxf(l, bound);
 }
 
-// one block (64 threads = one wavefront) per channel; reduces the 58 parameter gradients over pixels
-__global__ __launch_bounds__(64) void eb_backward_kernel(const float *zhat, const float *pack, const float *dlik,
-                                                         const float *dzin, float *dz, float *dpack, size_t npix, int C,
-                                                         float bound)
+// one workgroup (EB_BWD_NT threads) per channel; reduces the 58 parameter gradients over pixels: wavefront shuffles, then a
+// fixed-order sum of the wavefronts' partials through LDS (no atomics)
+constexpr int EB_BWD_NT = 256;
+__global__ __launch_bounds__(EB_BWD_NT) void eb_backward_kernel(const float *zhat, const float *pack, const float *dlik,
+                                                                const float *dzin, float *dz, float *dpack, size_t npix, int C,
+                                                                float bound)
 {
-    const int c = blockIdx.x, lane = threadIdx.x;
+    __shared__ float red[EB_BWD_NT / 64][NP];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *p = pack + (size_t)c * NP;
     EbPrep e;
     eb_prepare(p, e);
     float dp[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) dp[k] = 0.f;
-    for (size_t pix = lane; pix < npix; pix += 64) {
+    for (size_t pix = threadIdx.x; pix < npix; pix += EB_BWD_NT) {
         const size_t i = pix * C + c;
         const float v = zhat[i];
         float pre_lo[4][3], in_lo[4][3], pre_up[4][3], in_up[4][3];
@@ -184,7 +187,14 @@ __global__ __launch_bounds__(64) void eb_backward_kernel(const float *zhat, cons
             float s = dp[k];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-            if (lane == 0) dpack[(size_t)c * NP + k] = s;
+            if (lane == 0) red[wave][k] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < NP) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < EB_BWD_NT / 64; ++w) s += red[w][threadIdx.x];
+            dpack[(size_t)c * NP + threadIdx.x] = s;
         }
     }
 }
@@ -412,7 +422,7 @@ STEM_EXPORT int stem_eb_backward(const float *z_hat, const float *pack, const fl
                                  float *dz, float *dpack, int B, int H, int W, int C, float bound, void *stream)
 {
     STEM_CHECK_ARG(z_hat && pack && dlik, "stem_eb_backward: null pointer");
-    hipLaunchKernelGGL(eb_backward_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, z_hat, pack, dlik, dzhat_in, dz, dpack,
+    hipLaunchKernelGGL(eb_backward_kernel, dim3(C), dim3(EB_BWD_NT), 0, (hipStream_t)stream, z_hat, pack, dlik, dzhat_in, dz, dpack,
                        (size_t)B * H * W, C, bound);
     STEM_LAUNCH_CHECK("eb_backward");
     return 0;
