@@ -65,13 +65,15 @@ class FusedClipAdam:
         F.sumsq(self.flat.grad, self._sumsq)
         return self._sumsq[0].sqrt().reshape(())
 
-    def step(self, grad_scale: float = 1.0):
-        """grad_scale multiplies the gradient first (1/world_size after a sum all-reduce)."""
+    def step(self, grad_scale: float = 1.0, norm_is_current: bool = False):
+        """grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).  norm_is_current: the caller
+        has just called grad_norm() on these very gradients (as the training loop does to report the norm), so the
+        reduction is not repeated."""
         join_wgrad_stream()
         self.t += 1
         self.lr = self.param_groups[0]["lr"]
         use_clip = self.max_norm is not None and self.max_norm > 0
-        if use_clip:
+        if use_clip and not norm_is_current:
             self._sumsq[:1].zero_()
             F.sumsq(self.flat.grad, self._sumsq)
         F.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self._sumsq if use_clip else None,

@@ -56,7 +56,7 @@ def p_frame_step(imodel, stem, criterion, optimizer, aux_optimizer, x, y_cond, g
     if reducer is not None:
         reducer.finish() if hasattr(reducer, "finish") else reducer.all_reduce()
     gn = optimizer.grad_norm() * grad_scale if hasattr(optimizer, "grad_norm") else None
-    optimizer.step(grad_scale) if hasattr(optimizer, "grad_norm") else optimizer.step()
+    optimizer.step(grad_scale, norm_is_current=True) if hasattr(optimizer, "grad_norm") else optimizer.step()
     aux = stem.aux_loss()
     aux.backward()
     aux_optimizer.step()
