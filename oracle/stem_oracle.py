@@ -391,18 +391,26 @@ def stem_forward(sd, y_cur, y_cond, residual: bool, training: bool, noise=None, 
     k["hd0"] = lrelu_fwd(deconv2d_fwd(z_hat, sd["HD.0.weight"], sd["HD.0.bias"], 2, 2, 1))
     k["hd2"] = lrelu_fwd(deconv2d_fwd(k["hd0"], sd["HD.2.weight"], sd["HD.2.bias"], 2, 2, 1))
     hp = conv2d_fwd(k["hd2"], sd["HD.4.weight"], sd["HD.4.bias"], 1, 1)
-    k["tp_in"] = y_cond
-    k["tp0"] = lrelu_fwd(conv2d_fwd(y_cond, sd["TPM.0.weight"], sd["TPM.0.bias"], 1, 2))
-    k["tp2"] = lrelu_fwd(conv2d_fwd(k["tp0"], sd["TPM.2.weight"], sd["TPM.2.bias"], 1, 2))
-    tp = conv2d_fwd(k["tp2"], sd["TPM.4.weight"], sd["TPM.4.bias"], 1, 2)
+    # the ablations drop the temporal prior and / or the spatial (masked-conv) prior: spatiotemporalpriors.py:33-505
+    has_tpm, has_spm = "TPM.0.weight" in sd, "context_prediction.weight" in sd
+    k["has_tpm"], k["has_spm"] = has_tpm, has_spm
+    priors = []
+    if has_tpm:
+        k["tp_in"] = y_cond
+        k["tp0"] = lrelu_fwd(conv2d_fwd(y_cond, sd["TPM.0.weight"], sd["TPM.0.bias"], 1, 2))
+        k["tp2"] = lrelu_fwd(conv2d_fwd(k["tp0"], sd["TPM.2.weight"], sd["TPM.2.bias"], 1, 2))
+        priors.append(conv2d_fwd(k["tp2"], sd["TPM.4.weight"], sd["TPM.4.bias"], 1, 2))
+    priors.append(hp)
     target = (y_cur - y_cond) if residual else y_cur
-    if training:
-        t_hat = target + noise["q"]
-    else:
-        t_hat = quantize_dequantize(target)
-    k["t_hat"] = t_hat
-    ctx = conv2d_fwd(t_hat, masked_weight(sd["context_prediction.weight"]), sd["context_prediction.bias"], 1, 2)
-    k["epm_in"] = np.concatenate([tp, hp, ctx], 1)
+    t_hat = None
+    if has_spm:
+        if training:
+            t_hat = target + noise["q"]
+        else:
+            t_hat = quantize_dequantize(target)
+        k["t_hat"] = t_hat
+        priors.append(conv2d_fwd(t_hat, masked_weight(sd["context_prediction.weight"]), sd["context_prediction.bias"], 1, 2))
+    k["epm_in"] = np.concatenate(priors, 1)
     k["e0"] = lrelu_fwd(conv2d_fwd(k["epm_in"], sd["EPM.0.weight"], sd["EPM.0.bias"], 1, 0))
     k["e2"] = lrelu_fwd(conv2d_fwd(k["e0"], sd["EPM.2.weight"], sd["EPM.2.bias"], 1, 0))
     gp = conv2d_fwd(k["e2"], sd["EPM.4.weight"], sd["EPM.4.bias"], 1, 0)
@@ -414,7 +422,10 @@ def stem_forward(sd, y_cur, y_cond, residual: bool, training: bool, noise=None, 
         out = quantize_dequantize(target, means)
     k["gc_in"], k["scales"], k["means"] = out, scales, means
     lik_y = gc_likelihood_fwd(out, scales, means)
-    y_hat = (t_hat + y_cond) if residual else t_hat
+    if has_spm:
+        y_hat = (t_hat + y_cond) if residual else t_hat
+    else:
+        y_hat = out                                          # models without the spatial prior return the Gaussian's output
     return {"y_hat": y_hat, "lik_y": lik_y, "lik_z": lik_z, "scales": scales, "means": means}
 
 
@@ -433,17 +444,24 @@ def stem_backward(sd, keep, lik_y, lik_z, num_pixels):
     d, g["EPM.2.weight"], g["EPM.2.bias"] = conv2d_bwd(k["e0"], sd["EPM.2.weight"], d, 1, 0)
     d = lrelu_bwd(k["e0"], d)
     d, g["EPM.0.weight"], g["EPM.0.bias"] = conv2d_bwd(k["epm_in"], sd["EPM.0.weight"], d, 1, 0)
-    c_tp = c_hp = k["epm_in"].shape[1] // 3
-    dtp, dhp, dctx = d[:, :c_tp], d[:, c_tp:c_tp + c_hp], d[:, c_tp + c_hp:]
-    # context_prediction: wgrad of all 25 taps (unmasked), no dgrad needed (input is detached data + noise)
-    _, g["context_prediction.weight"], g["context_prediction.bias"] = conv2d_bwd(
-        k["t_hat"], sd["context_prediction.weight"], np.ascontiguousarray(dctx), 1, 2, need_dx=False)
-    # TPM
-    d, g["TPM.4.weight"], g["TPM.4.bias"] = conv2d_bwd(k["tp2"], sd["TPM.4.weight"], np.ascontiguousarray(dtp), 1, 2)
-    d = lrelu_bwd(k["tp2"], d)
-    d, g["TPM.2.weight"], g["TPM.2.bias"] = conv2d_bwd(k["tp0"], sd["TPM.2.weight"], d, 1, 2)
-    d = lrelu_bwd(k["tp0"], d)
-    _, g["TPM.0.weight"], g["TPM.0.bias"] = conv2d_bwd(k["tp_in"], sd["TPM.0.weight"], d, 1, 2, need_dx=False)
+    has_tpm, has_spm = k.get("has_tpm", True), k.get("has_spm", True)
+    P = k["epm_in"].shape[1] // (1 + int(has_tpm) + int(has_spm))
+    o = 0
+    dtp = dctx = None
+    if has_tpm:
+        dtp, o = d[:, o:o + P], o + P
+    dhp, o = d[:, o:o + P], o + P
+    if has_spm:
+        dctx = d[:, o:o + P]
+        # context_prediction: wgrad of all 25 taps (unmasked), no dgrad needed (input is detached data + noise)
+        _, g["context_prediction.weight"], g["context_prediction.bias"] = conv2d_bwd(
+            k["t_hat"], sd["context_prediction.weight"], np.ascontiguousarray(dctx), 1, 2, need_dx=False)
+    if has_tpm:
+        d, g["TPM.4.weight"], g["TPM.4.bias"] = conv2d_bwd(k["tp2"], sd["TPM.4.weight"], np.ascontiguousarray(dtp), 1, 2)
+        d = lrelu_bwd(k["tp2"], d)
+        d, g["TPM.2.weight"], g["TPM.2.bias"] = conv2d_bwd(k["tp0"], sd["TPM.2.weight"], d, 1, 2)
+        d = lrelu_bwd(k["tp0"], d)
+        _, g["TPM.0.weight"], g["TPM.0.bias"] = conv2d_bwd(k["tp_in"], sd["TPM.0.weight"], d, 1, 2, need_dx=False)
     # HD
     d, g["HD.4.weight"], g["HD.4.bias"] = conv2d_bwd(k["hd2"], sd["HD.4.weight"], np.ascontiguousarray(dhp), 1, 1)
     d = lrelu_bwd(k["hd2"], d)
