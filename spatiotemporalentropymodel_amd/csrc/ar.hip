@@ -242,6 +242,8 @@ __device__ __forceinline__ void wave_range(int t, int H, int Wd, int &h0, int &n
     np = hi - lo + 1;
 }
 
+constexpr int WAVE_ROWS = 24;     // workgroup rows over which the positions of one wavefront step are spread (more waves in flight)
+
 __global__ __launch_bounds__(256) void gemv3_wave_kernel(const float *W, int ldw, const float *bias, WSeg s0, WSeg s1, WSeg s2,
                                                          float *y, int ldy, int N, int act, float slope, int t, int H, int Wd)
 {
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void gemv3_wave_kernel(const float *W, int ldw
     const float *wr = W + (size_t)n * ldw;
     const float b = bias ? bias[n] : 0.f;
     const WSeg segs[3] = {s0, s1, s2};
-    for (int p = 0; p < np; ++p) {
+    for (int p = blockIdx.y; p < np; p += gridDim.y) {      // positions of the step are spread over gridDim.y workgroup rows
         const int h = h0 + p, w = t - 3 * h;
         float acc = 0.f;
 #pragma unroll
@@ -310,8 +312,9 @@ STEM_EXPORT int stem_gemv3_wave(const float *W, int ldw, const float *bias, cons
         STEM_CHECK_ARG(s[i].len == 0 || (s[i].x && s[i].len % 4 == 0 && s[i].woff % 4 == 0 && s[i].sh % 4 == 0 && s[i].sw % 4 == 0 && s[i].sp % 4 == 0),
                        "stem_gemv3_wave: segment %d is not 16-byte granular", i);
     }
-    hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, W, ldw, bias, s[0], s[1], s[2], y, ldy, N,
-                       act, slope, t, H, Wd);
+    const int maxp = H < (Wd + 2) / 3 ? H : (Wd + 2) / 3;
+    hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(N, 4), maxp < WAVE_ROWS ? maxp : WAVE_ROWS), dim3(256), 0, (hipStream_t)stream, W, ldw, bias,
+                       s[0], s[1], s[2], y, ldy, N, act, slope, t, H, Wd);
     STEM_LAUNCH_CHECK("gemv3_wave");
     return 0;
 }
@@ -406,17 +409,18 @@ STEM_EXPORT int stem_ar_encode_image(const float *w_ctx, int ld_ctx, const float
     const WSeg sctx{wctx, P, tp ? 2 * P : P, 0, 0, P};
     const WSeg stp{tp, P, 0, (long)W * P, P, 0}, shp{hp, P, tp ? P : 0, (long)W * P, P, 0};
     const WSeg sh1{wh1, n0, 0, 0, 0, n0}, sh2{wh2, n1, 0, 0, 0, n1};
+    const int gy = maxp < WAVE_ROWS ? maxp : WAVE_ROWS;
     for (int t = 0; t < W + 3 * (H - 1); ++t) {
-        hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(P, 4)), dim3(256), 0, st, w_ctx, ld_ctx, b_ctx, c0, c1, c2, wctx, P, P, 0, 0.f, t, H, W);
+        hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(P, 4), gy), dim3(256), 0, st, w_ctx, ld_ctx, b_ctx, c0, c1, c2, wctx, P, P, 0, 0.f, t, H, W);
         if (tp)
-            hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(n0, 4)), dim3(256), 0, st, w0, ld0, b0, stp, shp, sctx, wh1, n0, n0,
+            hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(n0, 4), gy), dim3(256), 0, st, w0, ld0, b0, stp, shp, sctx, wh1, n0, n0,
                                (int)STEM_ACT_LRELU, slope, t, H, W);
         else
-            hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(n0, 4)), dim3(256), 0, st, w0, ld0, b0, shp, sctx, none, wh1, n0, n0,
+            hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(n0, 4), gy), dim3(256), 0, st, w0, ld0, b0, shp, sctx, none, wh1, n0, n0,
                                (int)STEM_ACT_LRELU, slope, t, H, W);
-        hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(n1, 4)), dim3(256), 0, st, w1, ld1, b1, sh1, none, none, wh2, n1, n1,
+        hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(n1, 4), gy), dim3(256), 0, st, w1, ld1, b1, sh1, none, none, wh2, n1, n1,
                            (int)STEM_ACT_LRELU, slope, t, H, W);
-        hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(P, 4)), dim3(256), 0, st, w2, ld2, b2, sh2, none, none, wgp, P, P, 0, 0.f, t, H, W);
+        hipLaunchKernelGGL(gemv3_wave_kernel, dim3(cdiv(P, 4), gy), dim3(256), 0, st, w2, ld2, b2, sh2, none, none, wgp, P, P, 0, 0.f, t, H, W);
         hipLaunchKernelGGL(ar_finish_encode_wave_kernel, dim3(cdiv(maxp * M, 256)), dim3(256), 0, st, wgp, table, T, scale_bound, buf, sym, idx,
                            M, t, H, W, Wp, pad);
     }
