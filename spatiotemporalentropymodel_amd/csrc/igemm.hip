@@ -16,6 +16,10 @@
 // LDS read per operand tile feeds four MFMAs.
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "stem_common.h"
 
 namespace {
@@ -632,7 +636,7 @@ struct Plan {
 
 // Tile / split-K choice: minimise padded MFMA work / efficiency, then split the reduction (taps x channels)
 // over blockIdx.z when the output is too small to fill 256 CUs.
-Plan make_plan(const IgemmArgs &g, bool c4)
+Plan make_plan(const IgemmArgs &g, bool c4, int only_cfg = -1)
 {
     int maxM = 0, maxchunks = 0;
     const int nkc = c4 ? 1 : cdiv(g.C, KC);
@@ -649,7 +653,8 @@ Plan make_plan(const IgemmArgs &g, bool c4)
     double best = 1e300;
     static const int forced = getenv("STEM_IGEMM_CFG") ? atoi(getenv("STEM_IGEMM_CFG")) : -1;     // tuning aid
     for (int c = 0; c < NCFG; ++c) {
-        if (forced >= 0 && c != forced && !g.fuse) continue;
+        if (only_cfg >= 0 && c != only_cfg) continue;
+        if (forced >= 0 && only_cfg < 0 && c != forced && !g.fuse) continue;
         if (g.fuse && !((c == 1 || c == 4) && kCfg[c].bn >= g.N)) continue;      // fused GDN: all channels in one 192-wide tile
         const long tm = cdiv(maxM, kCfg[c].bm), tn = cdiv(g.N, kCfg[c].bn);
         const long tiles = tm * tn * g.nphase;
@@ -746,33 +751,9 @@ int launch_cfg(const IgemmArgs &g, bool vec, bool c4, hipStream_t st)
     return 0;
 }
 
-int launch(IgemmArgs &g, bool c4, void *ws, size_t ws_bytes, hipStream_t st)
+// run one planned launch (+ the split-K reduction); g must already carry pointers, pitches and byte ranges
+int run_plan(IgemmArgs &g, const Plan &pl, bool vec, bool c4, void *ws, hipStream_t st)
 {
-    const bool vec = c4 || ((g.C % 4 == 0) && (g.ldx % 4 == 0) && (g.ldw % 4 == 0) &&
-                            (((uintptr_t)g.x & 15) == 0) && (((uintptr_t)g.w & 15) == 0));
-    Plan pl = make_plan(g, c4);
-    if (pl.nsplit > 1 && (ws == nullptr || ws_bytes < pl.ws_bytes)) {      // no workspace: run unsplit (slower, same result)
-        pl.nsplit = 1;
-        pl.ws_bytes = 0;
-    }
-    {
-        const long xb = (((long)g.B * g.H * g.W - 1) * g.ldx + g.C) * 4;
-        int maxwt = 0;
-        for (int p = 0; p < g.nphase; ++p)
-            for (int t = 0; t < g.ph[p].ntaps; ++t)
-                if (g.ph[p].wt[t] > maxwt) maxwt = g.ph[p].wt[t];
-        const long wb = c4 ? (long)g.N * g.ldw * 4 : ((((long)maxwt + 1) * g.N - 1) * g.ldw + g.C) * 4;
-        if (xb >= 0x7FFFFF00L || wb >= 0x40000000L) {
-            stem_set_error("igemm: tensor view of %ld / %ld bytes exceeds the 2 GiB buffer-descriptor range", xb, wb);
-            return -1;
-        }
-        g.xbytes = (int)xb;
-        g.wbytes = (int)wb;
-    }
-    static const int exper = getenv("STEM_IGEMM_EXPER") ? atoi(getenv("STEM_IGEMM_EXPER")) : 0;
-    g.exper = exper;
-    g.ident = (g.nphase == 1 && g.osy == 1 && g.osx == 1 && g.ph[0].ooy == 0 && g.ph[0].oox == 0 &&
-               g.ph[0].qh == g.OH && g.ph[0].qw == g.OW) ? 1 : 0;
     g.nsplit = pl.nsplit;
     g.cps = pl.cps;
     g.ws = (float *)ws;
@@ -799,6 +780,123 @@ int launch(IgemmArgs &g, bool c4, void *ws, size_t ws_bytes, hipStream_t st)
                            g.nsplit, g.bias, g.z, g.ldz, g.y, g.ldy, npix, g.N, g.epi, g.slope);
     STEM_LAUNCH_CHECK("splitk_reduce");
     return 0;
+}
+
+// Per-geometry choice from measurements (STEM_IGEMM_AUTOTUNE=1): the first launch of a geometry times the model's best
+// split for every tile (plus half / double that split) on the caller's own operands -- the kernels are pure functions of
+// their inputs, so re-running them is harmless -- and the fastest plan is cached for the life of the process.  Costs one
+// stream synchronisation per new geometry; never changes results beyond the summation order split-K already varies.
+struct TuneKey {
+    int maxM, N, C, chunks, nphase, flags;
+    bool operator<(const TuneKey &o) const { return memcmp(this, &o, sizeof(TuneKey)) < 0; }
+};
+std::map<TuneKey, Plan> g_tuned;
+std::mutex g_tuned_mu;
+
+int launch(IgemmArgs &g, bool c4, void *ws, size_t ws_bytes, hipStream_t st)
+{
+    const bool vec = c4 || ((g.C % 4 == 0) && (g.ldx % 4 == 0) && (g.ldw % 4 == 0) &&
+                            (((uintptr_t)g.x & 15) == 0) && (((uintptr_t)g.w & 15) == 0));
+    Plan pl = make_plan(g, c4);
+    if (pl.nsplit > 1 && (ws == nullptr || ws_bytes < pl.ws_bytes)) {      // no workspace: run unsplit (slower, same result)
+        pl.nsplit = 1;
+        pl.ws_bytes = 0;
+        int maxchunks = 0;
+        for (int p = 0; p < g.nphase; ++p) {
+            const int nc = c4 ? cdiv(g.ph[p].ntaps, 8) : g.ph[p].ntaps * cdiv(g.C, KC);
+            if (nc > maxchunks) maxchunks = nc;
+        }
+        pl.cps = maxchunks;
+    }
+    {
+        const long xb = (((long)g.B * g.H * g.W - 1) * g.ldx + g.C) * 4;
+        int maxwt = 0;
+        for (int p = 0; p < g.nphase; ++p)
+            for (int t = 0; t < g.ph[p].ntaps; ++t)
+                if (g.ph[p].wt[t] > maxwt) maxwt = g.ph[p].wt[t];
+        const long wb = c4 ? (long)g.N * g.ldw * 4 : ((((long)maxwt + 1) * g.N - 1) * g.ldw + g.C) * 4;
+        if (xb >= 0x7FFFFF00L || wb >= 0x40000000L) {
+            stem_set_error("igemm: tensor view of %ld / %ld bytes exceeds the 2 GiB buffer-descriptor range", xb, wb);
+            return -1;
+        }
+        g.xbytes = (int)xb;
+        g.wbytes = (int)wb;
+    }
+    static const int exper = getenv("STEM_IGEMM_EXPER") ? atoi(getenv("STEM_IGEMM_EXPER")) : 0;
+    g.exper = exper;
+    g.ident = (g.nphase == 1 && g.osy == 1 && g.osx == 1 && g.ph[0].ooy == 0 && g.ph[0].oox == 0 &&
+               g.ph[0].qh == g.OH && g.ph[0].qw == g.OW) ? 1 : 0;
+    static const bool autotune = getenv("STEM_IGEMM_AUTOTUNE") && atoi(getenv("STEM_IGEMM_AUTOTUNE")) != 0;
+    if (!autotune || c4 || g.fuse || !vec) return run_plan(g, pl, vec, c4, ws, st);
+
+    int maxM = 0, maxchunks = 0;
+    for (int p = 0; p < g.nphase; ++p) {
+        const int m = g.B * g.ph[p].qh * g.ph[p].qw;
+        if (m > maxM) maxM = m;
+        const int nc = g.ph[p].ntaps * cdiv(g.C, KC);
+        if (nc > maxchunks) maxchunks = nc;
+    }
+    const TuneKey key{maxM, g.N, g.C, maxchunks, g.nphase, g.epi * 4 + (ws ? 1 : 0) + (g.ident ? 2 : 0)};
+    {
+        std::lock_guard<std::mutex> lk(g_tuned_mu);
+        auto it = g_tuned.find(key);
+        if (it != g_tuned.end()) {
+            Plan tp = it->second;
+            if (tp.nsplit > 1 && (ws == nullptr || ws_bytes < tp.ws_bytes)) tp = pl;
+            return run_plan(g, tp, vec, c4, ws, st);
+        }
+    }
+    // candidates: for every tile, the model's split and its neighbours, as far as the caller's workspace reaches
+    std::vector<Plan> cands;
+    const bool can_split = g.epi != EPI_GDN && g.epi != EPI_IGDN && g.epi != EPI_NORM;
+    const size_t out_bytes = (size_t)g.B * g.OH * g.OW * g.N * sizeof(float);
+    for (int c = 0; c < NCFG; ++c) {
+        const Plan base = make_plan(g, c4, c);
+        const int trial[3] = {base.nsplit, base.nsplit / 2, base.nsplit * 2};
+        for (int q = 0; q < 3; ++q) {
+            int sp = trial[q] < 1 ? 1 : trial[q];
+            if (!can_split) sp = 1;
+            if (sp > maxchunks) sp = maxchunks;
+            Plan cnd{c, sp, cdiv(maxchunks, sp), 0};
+            cnd.nsplit = cdiv(maxchunks, cnd.cps);
+            cnd.ws_bytes = cnd.nsplit > 1 ? cnd.nsplit * out_bytes : 0;
+            if (cnd.nsplit > 1 && (ws == nullptr || cnd.ws_bytes > ws_bytes)) continue;
+            bool dup = false;
+            for (const Plan &o : cands) dup |= (o.cfg == cnd.cfg && o.nsplit == cnd.nsplit);
+            if (!dup) cands.push_back(cnd);
+        }
+    }
+    hipEvent_t e0, e1;
+    if (cands.size() < 2 || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return run_plan(g, pl, vec, c4, ws, st);
+    Plan best = pl;
+    float best_ms = 1e30f;
+    for (const Plan &cnd : cands) {
+        IgemmArgs t = g;
+        if (run_plan(t, cnd, vec, c4, ws, st)) continue;               // warm (code objects, caches)
+        (void)hipEventRecord(e0, st);
+        t = g;
+        (void)run_plan(t, cnd, vec, c4, ws, st);
+        t = g;
+        (void)run_plan(t, cnd, vec, c4, ws, st);
+        (void)hipEventRecord(e1, st);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) {
+            best_ms = ms;
+            best = cnd;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    static const bool verbose = getenv("STEM_IGEMM_VERBOSE") != nullptr;
+    if (verbose)
+        fprintf(stderr, "[igemm tune] M=%d N=%d C=%d chunks=%d: model %dx%d/%d -> measured %dx%d/%d (%.1f us)\n", maxM, g.N, g.C, maxchunks,
+                kCfg[pl.cfg].bm, kCfg[pl.cfg].bn, pl.nsplit, kCfg[best.cfg].bm, kCfg[best.cfg].bn, best.nsplit, best_ms * 500.f);
+    {
+        std::lock_guard<std::mutex> lk(g_tuned_mu);
+        g_tuned[key] = best;
+    }
+    return run_plan(g, best, vec, c4, ws, st);           // the timed runs already produced the output; one more keeps it simple
 }
 
 int check_common(const char *name, const void *x, const void *w, const void *y, int B, int H, int W, int C, int K,
@@ -856,7 +954,11 @@ STEM_EXPORT size_t stem_conv_workspace_bytes(int kind, int B, int H, int W, int 
     fill_geometry(g, kind, B, H, W, C, K, R, S, stride, pad, opad);
     if (g.OH <= 0 || g.OW <= 0) return 0;
     if (masked && kind == KIND_CONV_FWD) g.ph[0].ntaps = (R / 2) * S + S / 2;
-    return make_plan(g, false).ws_bytes;
+    static const bool autotune = getenv("STEM_IGEMM_AUTOTUNE") && atoi(getenv("STEM_IGEMM_AUTOTUNE")) != 0;
+    const Plan pl = make_plan(g, false);
+    if (!autotune || pl.nsplit <= 1) return pl.ws_bytes;
+    // room for the measured choice to split twice as far as the model would (layers the model leaves unsplit stay so)
+    return (size_t)pl.nsplit * 2 * g.B * g.OH * g.OW * g.N * sizeof(float);
 }
 
 STEM_EXPORT int stem_conv2d_fwd(const float *x, int ldx, const float *wp, const float *bias, float *y, int ldy,
