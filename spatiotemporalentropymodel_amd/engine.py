@@ -13,6 +13,8 @@ producing convolution (forward) and into the consuming dgrad's epilogue (backwar
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -134,7 +136,7 @@ class StemEngine:
 
     #: weight gradients (wgrad + bias column sums + unpack + the data-parallel exchange hook) run on their own stream
     #: and overlap the latency-bound parts of the dgrad chain; set False to keep everything on the compute stream
-    overlap_wgrad = True
+    overlap_wgrad = os.environ.get("STEM_ENGINE_OVERLAP", "1") != "0"
 
     def side_stream(self, device):
         if not self.overlap_wgrad or device.type != "cuda":
