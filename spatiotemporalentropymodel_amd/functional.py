@@ -159,17 +159,18 @@ _WS_BYTES = {}
 
 
 def _workspace(kind, dims, device):
-    """(ptr, nbytes) of the split-K scratch for this layer shape.  One growing buffer per device: kernels on a
-    stream are ordered, so consecutive layers can share it."""
+    """(ptr, nbytes) of the split-K scratch for this layer shape.  One growing buffer per (device, launching stream):
+    kernels of a stream are ordered, so consecutive layers can share it; concurrent streams get their own."""
     key = (kind, dims)
     need = _WS_BYTES.get(key)
     if need is None:
         need = _WS_BYTES[key] = int(_lib.hip().stem_conv_workspace_bytes(kind, *dims))
     if need == 0:
         return 0, 0
-    buf = _WS.get(device)
+    slot = (device, _stream())
+    buf = _WS.get(slot)
     if buf is None or buf.numel() * 4 < need:
-        buf = _WS[device] = torch.empty((need + 3) // 4, device=device, dtype=torch.float32)
+        buf = _WS[slot] = torch.empty((need + 3) // 4, device=device, dtype=torch.float32)
     return buf.data_ptr(), need
 
 
