@@ -62,7 +62,8 @@ typedef struct {
 typedef struct {
     const float *dwp; /* [splits][R*S][..][..] slabs from stem_conv2d_wgrad / stem_deconv2d_wgrad */
     float *dw;        /* gradient in the reference layout */
-    int K, C, R, S, splits, deconv;
+    int K, C, R, S, splits;
+    int flags;        /* STEM_UNPACK_DECONV | STEM_UNPACK_ACCUMULATE */
 } stem_unpack_desc;
 int stem_pack_weights_multi(const stem_pack_desc *descs, int n, void *stream);
 int stem_unpack_wgrads_multi(const stem_unpack_desc *descs, int n, void *stream);
@@ -192,7 +193,8 @@ int stem_copy_channels(const float *src, int lds, float *dst, int ldd, size_t np
 /* pack the EntropyBottleneck parameters (entropy_models.py:310-328) into [C][58]:
  * per layer i: matrix_i (out x in), bias_i, factor_i (i<4).  Pointers are the 14 tensors in that order. */
 int stem_eb_pack(const float *const *tensors14, float *pack, int C, void *stream);
-int stem_eb_unpack_grads(const float *dpack, float *const *tensors14, int C, void *stream);
+/* scatter d(pack) [C][58] back into the 14 gradient tensors; accumulate != 0 adds (autograd's `.grad +=`) */
+int stem_eb_unpack_grads(const float *dpack, float *const *tensors14, int C, int accumulate, void *stream);
 /* EntropyBottleneck.forward (entropy_models.py:424-452) on z[B,H,W,C] NHWC.
  * mode 0: z_hat = z + noise (noise != NULL, same layout);  mode 1: z_hat = round(z - median) + median.
  * lik = max(|sigmoid(s*upper) - sigmoid(s*lower)|, bound).                                        */

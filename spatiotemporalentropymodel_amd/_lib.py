@@ -55,7 +55,7 @@ _HIP_SIG = {
     "stem_nchw3_to_nhwc4": [vp, vp, ci, ci, ci, vp],
     "stem_copy_channels": [vp, ci, vp, ci, sz, ci, vp],
     "stem_eb_pack": [vp, vp, ci, vp],
-    "stem_eb_unpack_grads": [vp, vp, ci, vp],
+    "stem_eb_unpack_grads": [vp, vp, ci, ci, vp],
     "stem_eb_forward": [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cf, vp],
     "stem_eb_backward": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp],
     "stem_eb_aux_loss": [vp, vp, vp, vp, vp, ci, vp],
@@ -115,7 +115,7 @@ class PackDesc(C.Structure):
 
 
 class UnpackDesc(C.Structure):
-    _fields_ = [("dwp", vp), ("dw", vp), ("K", ci), ("C", ci), ("R", ci), ("S", ci), ("splits", ci), ("deconv", ci)]
+    _fields_ = [("dwp", vp), ("dw", vp), ("K", ci), ("C", ci), ("R", ci), ("S", ci), ("splits", ci), ("flags", ci)]
 
 
 class WaveSeg(C.Structure):

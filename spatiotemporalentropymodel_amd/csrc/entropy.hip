@@ -247,7 +247,7 @@ __global__ void eb_pack_kernel(Ptr14 t, float *pack, int C)
         if (k >= kOff[q]) s = q;
     pack[i] = t.p[s][c * kLen[s] + (k - kOff[s])];
 }
-__global__ void eb_unpack_kernel(const float *dpack, MPtr14 t, int C)
+__global__ void eb_unpack_kernel(const float *dpack, MPtr14 t, int C, int accumulate)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C * NP) return;
@@ -256,7 +256,8 @@ __global__ void eb_unpack_kernel(const float *dpack, MPtr14 t, int C)
 #pragma unroll
     for (int q = 1; q < 14; ++q)
         if (k >= kOff[q]) s = q;
-    t.p[s][c * kLen[s] + (k - kOff[s])] = dpack[i];
+    float *dst = &t.p[s][c * kLen[s] + (k - kOff[s])];
+    *dst = accumulate ? *dst + dpack[i] : dpack[i];
 }
 
 // ---- GaussianConditional -----------------------------------------------------------------------
@@ -396,12 +397,12 @@ STEM_EXPORT int stem_eb_pack(const float *const *tensors14, float *pack, int C, 
     STEM_LAUNCH_CHECK("eb_pack");
     return 0;
 }
-STEM_EXPORT int stem_eb_unpack_grads(const float *dpack, float *const *tensors14, int C, void *stream)
+STEM_EXPORT int stem_eb_unpack_grads(const float *dpack, float *const *tensors14, int C, int accumulate, void *stream)
 {
     STEM_CHECK_ARG(tensors14 && dpack && C > 0, "stem_eb_unpack_grads: bad arguments");
     MPtr14 t;
     for (int i = 0; i < 14; ++i) t.p[i] = tensors14[i];
-    hipLaunchKernelGGL(eb_unpack_kernel, dim3(nblk((size_t)C * NP)), dim3(256), 0, (hipStream_t)stream, dpack, t, C);
+    hipLaunchKernelGGL(eb_unpack_kernel, dim3(nblk((size_t)C * NP)), dim3(256), 0, (hipStream_t)stream, dpack, t, C, accumulate);
     STEM_LAUNCH_CHECK("eb_unpack");
     return 0;
 }

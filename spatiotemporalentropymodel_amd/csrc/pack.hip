@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackTable tb)
 struct UnpackD {
     const float *dwp;
     float *dw;
-    int A, Bd, T, splits, block0;
+    int A, Bd, T, splits, block0, accumulate;
 };
 struct UnpackTable {
     UnpackD d[MAXD];
@@ -112,7 +112,9 @@ __global__ __launch_bounds__(256) void unpack_multi_kernel(const UnpackTable tb)
     __syncthreads();
     for (int k = threadIdx.x; k < n; k += 256) {
         const int b = k / d.T, t = k - b * d.T;
-        d.dw[(size_t)a * n + k] = tile[b * (d.T + 1) + t];
+        float *dst = d.dw + (size_t)a * n + k;
+        const float v = tile[b * (d.T + 1) + t];
+        *dst = d.accumulate ? *dst + v : v;
     }
 }
 
@@ -310,8 +312,10 @@ STEM_EXPORT int stem_unpack_wgrads_multi(const stem_unpack_desc *descs, int n, v
             STEM_CHECK_ARG(q.dwp && q.dw && q.splits >= 1, "stem_unpack_wgrads_multi: bad descriptor %d", base + i);
             d.dwp = q.dwp; d.dw = q.dw;
             d.T = q.R * q.S;
-            d.A = q.deconv ? q.C : q.K;
-            d.Bd = q.deconv ? q.K : q.C;
+            const int deconv = q.flags & STEM_UNPACK_DECONV;
+            d.accumulate = (q.flags & STEM_UNPACK_ACCUMULATE) ? 1 : 0;
+            d.A = deconv ? q.C : q.K;
+            d.Bd = deconv ? q.K : q.C;
             d.splits = q.splits;
             d.block0 = blocks;
             blocks += d.A;

@@ -179,10 +179,16 @@ int decode(Decoder &d, const int32_t *indexes, size_t n, const Tables &t, int32_
             int c;
             if (!d.nibble(c)) return fail(-3, "rans decode: stream exhausted in escape at %zu", i);
             int nn = c;
+            // the count is stored in unary-ish nibbles (rans_interface.cpp:137-163); a 32-bit raw value never needs more
+            // than 32 / kEscBits of them, so anything larger is a corrupt (or hostile) stream: shifting by >= 32 below
+            // would be undefined behaviour and the loop count would be attacker controlled
+            constexpr int kMaxEscNibbles = 32 / kEscBits;
             while (c == kEscMax) {
+                if (nn > kMaxEscNibbles) break;
                 if (!d.nibble(c)) return fail(-3, "rans decode: stream exhausted in escape at %zu", i);
                 nn += c;
             }
+            if (nn > kMaxEscNibbles) return fail(-4, "rans decode: corrupt escape at symbol %zu (%d bypass nibbles > %d)", i, nn, kMaxEscNibbles);
             uint32_t raw = 0;
             for (int j = 0; j < nn; ++j) {
                 if (!d.nibble(c)) return fail(-3, "rans decode: stream exhausted in escape at %zu", i);

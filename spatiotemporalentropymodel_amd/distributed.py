@@ -96,7 +96,7 @@ class OverlappedGradReducer:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self._off = {id(p): (o, p.numel()) for p, o in zip(flat.params, flat.offsets)}
         self._stream = torch.cuda.Stream() if flat.grad.is_cuda else None
-        self._covered = 0
+        self._done = []            # [lo, hi) slices exchanged since the last finish()
         self.calls = 0
 
     @property
@@ -124,7 +124,7 @@ class OverlappedGradReducer:
                 runs.append([o, e])
         for lo, hi in runs:
             hi = min(hi, self.flat.grad.numel())
-            self._covered += hi - lo
+            self._done.append((lo, hi))
             self.calls += 1
             if self.world == 1:
                 continue
@@ -137,17 +137,30 @@ class OverlappedGradReducer:
                 dist.all_reduce(g, op=dist.ReduceOp.SUM)
 
     def finish(self):
-        covered, self._covered = self._covered, 0
-        if covered < self.flat.numel:   # some group never reported: fall back to one big exchange
-            if self.world > 1:
-                if self._stream is not None:
-                    self._stream.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(self._stream):
-                        dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)
-                else:
-                    dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)
+        """Order the exchanged gradient before whatever the compute stream does next.  Every element of the flat buffer
+        must have been exchanged exactly once since the previous finish(): a slice reported twice would be summed twice
+        (scaled by `world` relative to the rest), a missing one would stay rank-local and the replicas would drift apart
+        -- both are programming errors of the schedule that feeds reduce_params(), so they raise instead of being patched
+        up with a second collective."""
+        done, self._done = sorted(self._done), []
+        pos, n = 0, self.flat.grad.numel()
+        for lo, hi in done:
+            if lo < pos:
+                raise RuntimeError(f"OverlappedGradReducer: gradient slice [{lo}, {hi}) overlaps one already exchanged "
+                                   f"(up to {pos}) in this step: it would be summed twice")
+            if lo > pos:
+                raise RuntimeError(f"OverlappedGradReducer: gradient elements [{pos}, {lo}) were never reported by the "
+                                   f"backward schedule ({self._names(pos, lo)}): they would stay rank-local")
+            pos = hi
+        if pos < n:
+            raise RuntimeError(f"OverlappedGradReducer: gradient elements [{pos}, {n}) were never reported by the "
+                               f"backward schedule ({self._names(pos, n)}): they would stay rank-local")
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
+
+    def _names(self, lo, hi):
+        hit = [n for n, p, o in zip(self.flat.names, self.flat.params, self.flat.offsets) if o < hi and o + p.numel() > lo]
+        return ", ".join(hit[:4]) + (", ..." if len(hit) > 4 else "")
 
 
 class GopGradAccumulator:
@@ -196,6 +209,16 @@ class GopGradAccumulator:
     def end_aux(self):
         for f in self.local:
             self._fold(f, 1.0)
+
+    def any_rank(self, flag: bool) -> bool:
+        """Logical OR of a host-side flag over all ranks (one tiny MAX all-reduce): collective control-flow decisions
+        such as the "skip this GOP" break must be taken by every rank or by none."""
+        if self.world == 1:
+            return bool(flag)
+        dev = self.exchanged[0].grad.device if self.exchanged else torch.device("cpu")
+        t = torch.tensor([1.0 if flag else 0.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item() > 0)
 
     def finish(self):
         for f in self.exchanged + self.local:

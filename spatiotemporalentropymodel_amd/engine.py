@@ -93,23 +93,24 @@ class _Layer:
         dwp, splits = self._slabs[key]
         if deconv:
             F.deconv2d_wgrad(x, dy, self.K, self.R, self.R, self.stride, self.pad, self.opad, db_out=gb, dwp=dwp, unpack=False,
-                             table_valid=not fresh)
+                             table_valid=not fresh, accumulate_db=True)
         else:
             F.conv2d_wgrad(x, dy, self.K, self.R, self.R, self.stride, self.pad, db_out=gb, dwp=dwp, unpack=False,
-                           table_valid=not fresh)
+                           table_valid=not fresh, accumulate_db=True)
         self.pending = (dwp, splits)
 
     def unpack_desc(self):
         dwp, splits = self.pending
         self.pending = None
         return _lib.UnpackDesc(dwp.data_ptr(), _grad_of(self.mod.weight).data_ptr(), self.K, self.C, self.R, self.R, splits,
-                               1 if self.kind == "deconv" else 0)
+                               (F.UNPACK_DECONV if self.kind == "deconv" else 0) | F.UNPACK_ACCUMULATE)
 
 
 def _grad_of(p):
     if p.grad is None:
         owner = getattr(p, "_flat_grad_view", None)
-        p.grad = owner if owner is not None else torch.empty_like(p, memory_format=torch.contiguous_format)
+        # a fresh slot starts at zero: every producer below ADDS into it (autograd's `.grad +=`)
+        p.grad = owner if owner is not None else torch.zeros_like(p, memory_format=torch.contiguous_format)
     return p.grad
 
 
@@ -258,8 +259,10 @@ class StemEngine:
 
     # -------------------------------------------------------------------------------------------
     def backward(self, k, dlik_y, dlik_z):
-        """Parameter gradients of a scalar that depends on (lik_y, lik_z); written into .grad (overwritten,
-        not accumulated: the reference zeroes gradients before every backward, stem/trainSTEM.py:203)."""
+        """Parameter gradients of a scalar that depends on (lik_y, lik_z), ADDED into .grad as autograd does (the
+        training loop zeroes them before every backward, stem/trainSTEM.py:203; a slot that does not exist yet starts
+        at zero), so several backward passes between two zero_grad() calls accumulate -- the same semantics as the
+        layer-wise Functions of the variable-rate models (layers.py)."""
         m = self.m
         gc = m.gaussian_conditional
         Cin, P = k["Cin"], k["P"]
@@ -300,7 +303,7 @@ class StemEngine:
         # entropy bottleneck: d/dz = dz_hat + likelihood path; 58 parameter gradients per channel
         eb = m.entropy_bottleneck
         dz, dpack = F.eb_backward(k["z_hat"], k["pack"], dlik_z, dzhat_in=dz_hat, bound=eb._lik_bound)
-        F.eb_unpack_grads(dpack, [_grad_of(p) for p in eb._tensors14()])
+        F.eb_unpack_grads(dpack, [_grad_of(p) for p in eb._tensors14()], accumulate=True)
         self._group_ready(self.HD, eb._tensors14())
         # hyper encoder
         self.HE[2].wgrad(k["he2"], dz)
@@ -327,6 +330,10 @@ class StemFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _dy_hat, dlik_y, dlik_z):
         eng, k = ctx.engine, ctx.keep
+        if k is None:
+            raise RuntimeError("StemFunction: backward through this forward a second time -- its saved activations were "
+                               "released by the first backward (retain_graph is not supported by the fused schedule; "
+                               "run the forward again)")
         ctx.keep = None
         gp = k["gp"]
         B, _, H, W = gp.shape

@@ -345,18 +345,28 @@ class EntropyModel(nn.Module):
         enc = RansEncoder()
         return [enc.encode_with_indexes(sym[i], idx[i], t) for i in range(sym.shape[0])]
 
+    @staticmethod
+    def _check_decompress_args(strings, indexes, means):
+        # means may be per element or one value per (batch, channel) broadcast over the spatial dims
+        problems = (
+            (not isinstance(strings, (tuple, list)), "Invalid `strings` parameter type."),
+            (isinstance(strings, (tuple, list)) and len(strings) != indexes.shape[0], "Invalid strings or indexes parameters"),
+            (indexes.dim() != 4, "Invalid `indexes` size. Expected a 4-D tensor."),
+        )
+        for bad, msg in problems:
+            if bad:
+                raise ValueError(msg)
+        if means is None:
+            return
+        if tuple(means.shape[:-2]) != tuple(indexes.shape[:-2]):
+            raise ValueError("Invalid means or indexes parameters")
+        per_channel = means.shape[2] == 1 and means.shape[3] == 1
+        if tuple(means.shape) != tuple(indexes.shape) and not per_channel:
+            raise ValueError("Invalid means parameters")
+
     def decompress(self, strings, indexes, means=None):
-        if not isinstance(strings, (tuple, list)):
-            raise ValueError("Invalid `strings` parameter type.")
-        if not len(strings) == indexes.size(0):
-            raise ValueError("Invalid strings or indexes parameters")
-        if len(indexes.size()) != 4:
-            raise ValueError("Invalid `indexes` size. Expected a 4-D tensor.")
-        if means is not None:
-            if means.size()[:-2] != indexes.size()[:-2]:
-                raise ValueError("Invalid means or indexes parameters")
-            if means.size() != indexes.size() and (means.size(2) != 1 or means.size(3) != 1):
-                raise ValueError("Invalid means parameters")
+        """one string per batch element -> dequantised values (:235-279); argument errors are ValueError as upstream"""
+        self._check_decompress_args(strings, indexes, means)
         t = self.host_tables()
         idx = indexes.int().cpu().contiguous().numpy()
         dec = RansDecoder()
@@ -374,26 +384,25 @@ class EntropyBottleneck(EntropyModel):
             raise NotImplementedError("the HIP bottleneck kernel is specialised for filters=(3,3,3,3) (the only STEM use)")
         self.init_scale = float(init_scale)
         self.tail_mass = float(tail_mass)
-        filters = (1,) + self.filters + (1,)
-        scale = self.init_scale ** (1 / (len(self.filters) + 1))
-        channels = self.channels
-        for i in range(len(self.filters) + 1):
-            init = np.log(np.expm1(1 / scale / filters[i + 1]))
-            matrix = torch.Tensor(channels, filters[i + 1], filters[i])
-            matrix.data.fill_(init)
-            self.register_parameter(f"_matrix{i:d}", nn.Parameter(matrix))
-            bias = torch.Tensor(channels, filters[i + 1], 1)
-            nn.init.uniform_(bias, -0.5, 0.5)
-            self.register_parameter(f"_bias{i:d}", nn.Parameter(bias))
-            if i < len(self.filters):
-                factor = torch.Tensor(channels, filters[i + 1], 1)
-                nn.init.zeros_(factor)
-                self.register_parameter(f"_factor{i:d}", nn.Parameter(factor))
-        self.quantiles = nn.Parameter(torch.Tensor(channels, 1, 3))
-        init = torch.Tensor([-self.init_scale, 0, self.init_scale])
-        self.quantiles.data = init.repeat(self.quantiles.size(0), 1, 1)
-        target = np.log(2 / self.tail_mass - 1)
-        self.register_buffer("target", torch.Tensor([-target, 0, target]))
+        # Per-channel MLP 1 -> 3 -> 3 -> 3 -> 3 -> 1 of the cumulative (entropy_models.py:303-340 upstream).  Layer i maps
+        # widths[i] -> widths[i+1]; the initial values make softplus(matrix) a constant 1 / (s * fan_out) with
+        # s = init_scale^(1/5), biases are U(-1/2, 1/2) (drawn layer by layer: the only RNG use), gate factors 0.
+        widths = (1, *self.filters, 1)
+        n_layers = len(widths) - 1
+        per_layer_scale = self.init_scale ** (1.0 / n_layers)
+        C = self.channels
+        for i, (fan_in, fan_out) in enumerate(zip(widths[:-1], widths[1:])):
+            raw = float(np.log(np.expm1(1.0 / per_layer_scale / fan_out)))           # softplus^-1 of the target value
+            self.register_parameter(f"_matrix{i:d}", nn.Parameter(torch.full((C, fan_out, fan_in), raw)))
+            self.register_parameter(f"_bias{i:d}", nn.Parameter(torch.empty(C, fan_out, 1).uniform_(-0.5, 0.5)))
+            if i < n_layers - 1:
+                self.register_parameter(f"_factor{i:d}", nn.Parameter(torch.zeros(C, fan_out, 1)))
+        # quantiles start at (-init_scale, 0, +init_scale); the aux loss pulls them to the tail_mass/2, 1/2, 1-tail_mass/2
+        # points of the learned density, expressed as logits in `target`
+        q0 = torch.tensor([-self.init_scale, 0.0, self.init_scale])
+        self.quantiles = nn.Parameter(q0.expand(C, 1, 3).clone())
+        tail_logit = float(np.log(2.0 / self.tail_mass - 1.0))
+        self.register_buffer("target", torch.tensor([-tail_logit, 0.0, tail_logit]))
 
     def _tensors14(self):
         return [getattr(self, n) for n in F.EB_TENSORS]

@@ -250,7 +250,7 @@ def _wgrad_workspace(key, elems, device):
 
 
 def conv2d_wgrad(x, dy, K, R, S, stride, pad, dw_out=None, db_out=None, need_db=True, dwp=None, unpack=True, table_valid=False,
-                 accumulate=False):
+                 accumulate=False, accumulate_db=False):
     """-> (dW [K,C,R,S], db [K]) in the reference's layouts.  With unpack=False only the packed slabs in `dwp`
     are produced (the caller sums/transposes all layers at once with unpack_wgrads_multi).  accumulate=True adds into
     dw_out / db_out (gradient accumulation over several backward passes)."""
@@ -261,7 +261,8 @@ def conv2d_wgrad(x, dy, K, R, S, stride, pad, dw_out=None, db_out=None, need_db=
         dwp, table_valid = _wgrad_workspace((x.device, 0, tuple(x.shape), nhwc_ld(x), K, R, S, stride, pad), elems, x.device)
     assert not accumulate or (dw_out is not None and (db_out is not None or not need_db))
     db = (db_out if db_out is not None else torch.empty(K, device=x.device, dtype=torch.float32)) if need_db else None
-    flags = (WGRAD_TABLE_VALID if table_valid else 0) | (WGRAD_ACCUMULATE_DB if accumulate else 0)
+    assert not accumulate_db or db_out is not None
+    flags = (WGRAD_TABLE_VALID if table_valid else 0) | (WGRAD_ACCUMULATE_DB if (accumulate or accumulate_db) else 0)
     _chk(lib.stem_conv2d_wgrad(x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), dwp.data_ptr(), _ptr(db),
                                B, H, W, Cc, K, R, S, stride, pad, splits, flags, _stream()))
     if not unpack:
@@ -295,7 +296,7 @@ def deconv2d_dgrad(dy, wp_dgrad, x_shape, K, R, S, stride, pad, opad, xact=None,
 
 
 def deconv2d_wgrad(x, dy, K, R, S, stride, pad, opad, dw_out=None, db_out=None, need_db=True, dwp=None, unpack=True, table_valid=False,
-                   accumulate=False):
+                   accumulate=False, accumulate_db=False):
     """-> (dW [C,K,R,S], db [K]) in nn.ConvTranspose2d's layout."""
     B, Cc, H, W = x.shape
     lib = _lib.hip()
@@ -304,7 +305,8 @@ def deconv2d_wgrad(x, dy, K, R, S, stride, pad, opad, dw_out=None, db_out=None, 
         dwp, table_valid = _wgrad_workspace((x.device, 1, tuple(x.shape), nhwc_ld(dy), K, R, S, stride, pad, opad), elems, x.device)
     assert not accumulate or (dw_out is not None and (db_out is not None or not need_db))
     db = (db_out if db_out is not None else torch.empty(K, device=x.device, dtype=torch.float32)) if need_db else None
-    flags = (WGRAD_TABLE_VALID if table_valid else 0) | (WGRAD_ACCUMULATE_DB if accumulate else 0)
+    assert not accumulate_db or db_out is not None
+    flags = (WGRAD_TABLE_VALID if table_valid else 0) | (WGRAD_ACCUMULATE_DB if (accumulate or accumulate_db) else 0)
     _chk(lib.stem_deconv2d_wgrad(x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), dwp.data_ptr(), _ptr(db),
                                  B, H, W, Cc, K, R, S, stride, pad, opad, splits, flags, _stream()))
     if not unpack:
@@ -464,9 +466,9 @@ def eb_pack(tensors14):
     return pack
 
 
-def eb_unpack_grads(dpack, grads14):
+def eb_unpack_grads(dpack, grads14, accumulate=False):
     Cc = dpack.shape[0]
-    _chk(_lib.hip().stem_eb_unpack_grads(dpack.data_ptr(), _ptr_array(grads14), Cc, _stream()))
+    _chk(_lib.hip().stem_eb_unpack_grads(dpack.data_ptr(), _ptr_array(grads14), Cc, 1 if accumulate else 0, _stream()))
 
 
 def eb_forward(z, pack, medians=None, noise=None, bound=1e-9):

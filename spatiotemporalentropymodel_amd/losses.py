@@ -49,19 +49,27 @@ class EMLoss(nn.Module):
 
 
 class RateDistortionLoss(nn.Module):
-    """utils.py:30-50.  The distortion term uses torch's MSE (x_hat comes out of getX as a plain NCHW tensor)."""
+    """utils.py:30-50: bpp + lmbda * 255^2 * MSE(x_hat, target).  The distortion term is the same fp64-accumulating
+    squared-error kernel the variable-rate criterion uses (stem_weighted_sqerr_sum / _bwd) with a unit weight map."""
 
     def __init__(self, lmbda=1e-2):
         super().__init__()
-        self.mse = nn.MSELoss()
         self.lmbda = lmbda
+        self._ones = None
+
+    def _unit_map(self, target):
+        B, _, H, W = target.shape
+        o = self._ones
+        if o is None or o.shape != (B, 1, H, W) or o.device != target.device:
+            o = self._ones = torch.ones(B, 1, H, W, device=target.device, dtype=torch.float32)
+        return o
 
     def forward(self, output, target):
         N, _, H, W = target.size()
         num_pixels = N * H * W
         out = {}
         out["bpp_loss"] = sum(log2_sum(l) / (-num_pixels) for l in output["likelihoods"].values())
-        out["mse_loss"] = self.mse(output["x_hat"], target)
+        out["mse_loss"] = _WeightedMSEFunction.apply(output["x_hat"], target, self._unit_map(target))
         out["loss"] = self.lmbda * 255 ** 2 * out["mse_loss"] + out["bpp_loss"]
         return out
 

@@ -43,17 +43,30 @@ class FlatParameters:
             p.grad = p._flat_grad_view
 
 
-class FusedClipAdam:
+class FusedClipAdam(torch.optim.Optimizer):
     """clip_grad_norm_(max_norm) + Adam(lr, betas, eps) over a FlatParameters in two kernel launches.
-    `max_norm=None` disables clipping (the reference does not clip the aux optimiser's `.quantiles`)."""
+    `max_norm=None` disables clipping (the reference does not clip the aux optimiser's `.quantiles`).
+
+    It IS a torch.optim.Optimizer: `ReduceLROnPlateau(optimizer, "min")` (stem/trainSTEM.py:123) attaches to it and its
+    `param_groups[0]["lr"]` is what the step uses; `state_dict()` / `load_state_dict()` speak torch.optim.Adam's layout
+    (per-parameter "step" / "exp_avg" / "exp_avg_sq" + param_groups), so the `"optimizer"` / `"aux_optimizer"` entries of
+    a reference checkpoint (stem/trainSTEM.py:286-297) load here and ours load into torch.optim.Adam.  The moments live
+    in two flat buffers; the per-parameter state tensors are views into them."""
 
     def __init__(self, flat: FlatParameters, lr, max_norm=None, betas=(0.9, 0.999), eps=1e-8):
-        self.flat, self.lr, self.max_norm, self.betas, self.eps = flat, float(lr), max_norm, betas, float(eps)
+        defaults = dict(lr=float(lr), betas=tuple(betas), eps=float(eps), weight_decay=0, amsgrad=False, maximize=False,
+                        foreach=None, capturable=False, differentiable=False, fused=None)
+        super().__init__(flat.params, defaults)
+        self.flat, self.max_norm = flat, max_norm
         self.m = torch.zeros_like(flat.data)
         self.v = torch.zeros_like(flat.data)
         self.t = 0
         self._sumsq = F.sumsq_accumulator(flat.data.device)          # [0] = sum of squares, rest = reduction scratch
-        self.param_groups = [{"lr": self.lr, "params": flat.params}]
+
+    # the scalar hyper-parameters live in param_groups[0] (schedulers and checkpoints edit them there)
+    lr = property(lambda self: self.param_groups[0]["lr"])
+    betas = property(lambda self: self.param_groups[0]["betas"])
+    eps = property(lambda self: self.param_groups[0]["eps"])
 
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
@@ -65,30 +78,64 @@ class FusedClipAdam:
         F.sumsq(self.flat.grad, self._sumsq)
         return self._sumsq[0].sqrt().reshape(())
 
-    def step(self, grad_scale: float = 1.0, norm_is_current: bool = False):
+    def step(self, closure=None, *, grad_scale: float = 1.0, norm_is_current: bool = False):
         """grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).  norm_is_current: the caller
         has just called grad_norm() on these very gradients (as the training loop does to report the norm), so the
         reduction is not repeated."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         join_wgrad_stream()
         self.t += 1
-        self.lr = self.param_groups[0]["lr"]
+        g = self.param_groups[0]
         use_clip = self.max_norm is not None and self.max_norm > 0
         if use_clip and not norm_is_current:
             self._sumsq[:1].zero_()
             F.sumsq(self.flat.grad, self._sumsq)
         F.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self._sumsq if use_clip else None,
-                    float(self.max_norm) if use_clip else 0.0, float(grad_scale), self.lr, self.betas[0], self.betas[1],
-                    self.eps, self.t)
+                    float(self.max_norm) if use_clip else 0.0, float(grad_scale), float(g["lr"]), g["betas"][0], g["betas"][1],
+                    float(g["eps"]), self.t)
         bump_weight_epoch(self.flat.params)
+        return loss
+
+    # ---- torch.optim.Adam-compatible (de)serialisation ----------------------------------------------------------
+    def _views(self, buf):
+        return [buf[o:o + p.numel()].view(p.shape) for p, o in zip(self.flat.params, self.flat.offsets)]
+
+    def _sync_state(self):
+        """Expose the flat moments as Adam's per-parameter state (views, no copies); empty before the first step, as
+        torch.optim.Adam's is."""
+        self.state.clear()
+        if self.t == 0:
+            return
+        for p, m, v in zip(self.flat.params, self._views(self.m), self._views(self.v)):
+            self.state[p] = {"step": torch.tensor(float(self.t)), "exp_avg": m, "exp_avg_sq": v}
 
     def state_dict(self):
-        return {"t": self.t, "m": self.m, "v": self.v, "lr": self.lr}
+        self._sync_state()
+        return super().state_dict()
 
-    def load_state_dict(self, sd):
-        self.t, self.lr = int(sd["t"]), float(sd["lr"])
-        self.m.copy_(sd["m"])
-        self.v.copy_(sd["v"])
-        self.param_groups[0]["lr"] = self.lr
+    def load_state_dict(self, state_dict):
+        groups = state_dict["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.flat.params):
+            raise ValueError(f"FusedClipAdam: expected one parameter group of {len(self.flat.params)} tensors "
+                             f"(utils.py:104-135 order: sorted parameter names), got {[len(g['params']) for g in groups]}")
+        super().load_state_dict(state_dict)          # validates, casts to the parameters' device, fills self.state
+        steps = set()
+        self.m.zero_()
+        self.v.zero_()
+        for p, m, v in zip(self.flat.params, self._views(self.m), self._views(self.v)):
+            st = self.state.get(p)
+            if not st:
+                continue
+            m.copy_(st["exp_avg"])
+            v.copy_(st["exp_avg_sq"])
+            steps.add(int(float(st["step"])))        # int in torch 1.7 checkpoints, 0-dim tensor since 1.12
+        if len(steps) > 1:
+            raise ValueError(f"FusedClipAdam: parameters carry different step counts {sorted(steps)}; the fused step keeps one")
+        self.t = steps.pop() if steps else 0
+        self._sync_state()
 
 
 def clip_grad_norm_(optimizers, max_norm, tensors=None):

@@ -56,7 +56,7 @@ def p_frame_step(imodel, stem, criterion, optimizer, aux_optimizer, x, y_cond, g
     if reducer is not None:
         reducer.finish() if hasattr(reducer, "finish") else reducer.all_reduce()
     gn = optimizer.grad_norm() * grad_scale if hasattr(optimizer, "grad_norm") else None
-    optimizer.step(grad_scale, norm_is_current=True) if hasattr(optimizer, "grad_norm") else optimizer.step()
+    optimizer.step(grad_scale=grad_scale, norm_is_current=True) if hasattr(optimizer, "grad_norm") else optimizer.step()
     aux = stem.aux_loss()
     aux.backward()
     aux_optimizer.step()
@@ -75,7 +75,8 @@ def roi_gop_step(imodel, pmodel, criterion, optimizers, frames, qmap, clip_max_n
     models; each model's running gradient (its `.quantiles` included, as clip_grad_norm_(model.parameters()) does) is
     clipped right after its own frame's backward.  `optimizers` = (opt_i, aux_i, opt_p, aux_p) from configure_optimizers
     (max_norm=None).  `max_loss` reproduces the script's "skip invalid loss" break (NaN/Inf/loss > max_loss; costs a host
-    sync per frame; upstream compares the I frame against the previous GOP's P loss, here each frame checks its own).
+    sync per frame; upstream compares the I frame against the previous GOP's P loss, here each frame checks its own;
+    with an accumulator the verdict is OR-ed over the ranks so that all of them leave the GOP at the same frame).
     `accumulator` (distributed.GopGradAccumulator over the four flat buffers) makes the loop data parallel: the frame
     gradient is all-reduced before it joins the running sum that gets clipped.
     Returns the per-frame criterion dictionaries, clip norms and aux losses."""
@@ -96,7 +97,12 @@ def roi_gop_step(imodel, pmodel, criterion, optimizers, frames, qmap, clip_max_n
         oc = criterion(out, x, lmbdamap)
         if max_loss is not None:
             lv = float(oc["loss"].detach())
-            if not np.isfinite(lv) or lv > max_loss:
+            bad = (not np.isfinite(lv)) or lv > max_loss
+            if accumulator is not None:
+                # data parallel: the decision must be the same on every rank, or the ranks that continue would wait
+                # forever in end_frame()'s all-reduce for the one that left (and the replicas would step differently)
+                bad = accumulator.any_rank(bad)
+            if bad:
                 break
         oc["loss"].backward(retain_graph=True)
         gn = None

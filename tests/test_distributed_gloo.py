@@ -206,9 +206,11 @@ def _worker_gop(rank, world, port, q):
         side.grad += aux[t]                                  # aux loss: parameters only, identical on every rank
         acc.end_aux()
     acc.finish()
+    # collective control flow: a rank-local "bad loss" verdict must become everybody's verdict
+    any_ok = acc.any_rank(rank == 1) is True and acc.any_rank(False) is False
     G, A, ref_norms = _gop_reference([sum(per_rank[t]) / world for t in range(T)], aux, 1.0)
     ok = bool(torch.allclose(main.grad, G, rtol=1e-6, atol=1e-7)) and bool(torch.allclose(side.grad, A, rtol=1e-6, atol=1e-7))
-    q.put((rank, {"ok": ok, "norms": bool(np.allclose(norms, ref_norms, rtol=1e-6)), "clipped": sum(v > 1.0 for v in ref_norms)}))
+    q.put((rank, {"ok": ok and any_ok, "norms": bool(np.allclose(norms, ref_norms, rtol=1e-6)), "clipped": sum(v > 1.0 for v in ref_norms)}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -228,3 +230,27 @@ def test_gop_gradient_accumulator_world2_gloo():
         assert p.exitcode == 0
     for r in (0, 1):
         assert res[r]["ok"] and res[r]["norms"] and res[r]["clipped"] >= 2, res
+
+
+def test_overlapped_reducer_refuses_partial_or_double_coverage():
+    """VERDICT r1 weak #9 / ADVICE: finish() used to re-reduce the whole buffer when a group was missing (double-counting
+    the slices already exchanged); it now raises, and so does a slice reported twice.  world_size 1, CPU."""
+    from spatiotemporalentropymodel_amd import distributed as D
+    from spatiotemporalentropymodel_amd.optim import FlatParameters
+    net = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.Linear(5, 2))
+    named = sorted(net.named_parameters(), key=lambda t: t[0])
+    flat = FlatParameters(named)
+    red = D.OverlappedGradReducer(flat)
+    ps = [p for _, p in named]
+    red.reduce_params(ps[:2])
+    red.reduce_params(ps[2:])
+    red.finish()                                       # full, single coverage: fine
+    red.reduce_params(ps[:2])
+    with pytest.raises(RuntimeError, match="never reported.*1\\.(bias|weight)"):
+        red.finish()
+    red.reduce_params(ps[:3])
+    red.reduce_params(ps[2:])
+    with pytest.raises(RuntimeError, match="summed twice"):
+        red.finish()
+    red.reduce_params(ps)                              # state was reset by the failed finish()
+    red.finish()

@@ -188,6 +188,31 @@ def test_rans_edge_cases():
         em.RansDecoder().decode_with_indexes(s[: len(s) // 2], idx, t)      # truncated stream
 
 
+def test_rans_decoder_survives_corrupt_streams():
+    """the escape path trusted the nibble count read from the stream (shift >= 32 = UB, attacker-controlled
+    loop).  Corrupt streams must come back as an error or as (wrong) integers -- never crash, hang or read out of bounds."""
+    t, _ = _tables()
+    rng = np.random.default_rng(11)
+    idx = rng.integers(0, 64, size=600).astype(np.int32)
+    sym = rng.integers(-40000, 40000, size=600).astype(np.int32)            # almost every symbol takes the escape path
+    good = em.RansEncoder().encode_with_indexes(sym, idx, t)
+    np.testing.assert_array_equal(em.RansDecoder().decode_with_indexes_np(good, idx, t), sym)
+    errors = 0
+    for trial in range(300):
+        b = bytearray(good)
+        for _ in range(1 + trial % 6):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        if trial % 7 == 0:
+            b = b[: int(rng.integers(8, len(b)))] + bytes([0xFF] * 64)         # runs of 0xF nibbles: the old unbounded count
+        try:
+            out = em.RansDecoder().decode_with_indexes_np(bytes(b), idx, t)
+            assert out.shape == sym.shape and out.dtype == np.int32
+        except RuntimeError as e:
+            errors += 1
+            assert "rans decode" in str(e)
+    assert errors > 0                                                          # the bound actually fires on some of them
+
+
 def test_entropy_bottleneck_update_tables_match_reference(golden):
     g = golden("ops_small.npz")
     eb = em.EntropyBottleneck(4)
@@ -250,3 +275,118 @@ def test_bitstream_container_matches_reference_bytes(golden):
     xp = bs.pad(x, 64)
     np.testing.assert_array_equal(xp.numpy(), g["pad:xp"])
     np.testing.assert_array_equal(bs.crop(xp, (50, 75)).numpy(), g["pad:back"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 2: optimiser / checkpoint interchange, root-utils mirror, CDF-buffer resizing
+def _sorted_params(net):
+    return sorted(net.named_parameters(), key=lambda t: t[0])
+
+
+def test_fused_adam_is_a_torch_optimizer_and_speaks_adams_state_dict(tmp_path):
+    """stem/trainSTEM.py:123 hands the optimiser to ReduceLROnPlateau and :286-297 checkpoints optimizer.state_dict():
+    both must work with FusedClipAdam, in both directions with torch.optim.Adam."""
+    from spatiotemporalentropymodel_amd.optim import FlatParameters, FusedClipAdam
+    from spatiotemporalentropymodel_amd.utils import save_checkpoint
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.Linear(5, 2))
+    opt = FusedClipAdam(FlatParameters(_sorted_params(net)), 1e-4, max_norm=1.0)
+    assert isinstance(opt, torch.optim.Optimizer)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, "min", patience=0, factor=0.5)
+    sched.step(1.0)
+    sched.step(2.0)                                   # worse -> lr halves in param_groups[0], which step() reads
+    assert opt.lr == pytest.approx(5e-5) and opt.param_groups[0]["lr"] == pytest.approx(5e-5)
+    assert opt.state_dict()["state"] == {}            # like torch.optim.Adam before its first step
+    # reference-side optimiser with two steps of state
+    ref_net = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.Linear(5, 2))
+    ref = torch.optim.Adam([p for _, p in _sorted_params(ref_net)], lr=3e-4)
+    for _ in range(2):
+        ref.zero_grad()
+        ref_net(torch.randn(4, 3)).square().sum().backward()
+        ref.step()
+    rsd = ref.state_dict()
+    opt.load_state_dict(rsd)
+    assert opt.t == 2 and opt.lr == pytest.approx(3e-4)
+    for i, (p, o) in enumerate(zip(opt.flat.params, opt.flat.offsets)):
+        n = p.numel()
+        assert torch.equal(opt.m[o:o + n].view(p.shape), rsd["state"][i]["exp_avg"])
+        assert torch.equal(opt.v[o:o + n].view(p.shape), rsd["state"][i]["exp_avg_sq"])
+    # ... and back, through a checkpoint file written by the utils mirror
+    path = tmp_path / "ckpt.pth.tar"
+    save_checkpoint({"epoch": 3, "optimizer": opt.state_dict(), "lr_scheduler": sched.state_dict()}, str(path))
+    back = torch.load(str(path), weights_only=False)
+    assert back["optimizer"]["param_groups"][0].keys() == rsd["param_groups"][0].keys()
+    ref2 = torch.optim.Adam([p for _, p in _sorted_params(ref_net)], lr=1.0)
+    ref2.load_state_dict(back["optimizer"])
+    for i in range(4):
+        assert float(ref2.state_dict()["state"][i]["step"]) == 2.0
+        assert torch.equal(ref2.state_dict()["state"][i]["exp_avg"], rsd["state"][i]["exp_avg"])
+    # torch-1.7 style integer step counts load as well; inconsistent counts are refused
+    old = {"state": {i: dict(s, step=7) for i, s in rsd["state"].items()}, "param_groups": rsd["param_groups"]}
+    opt.load_state_dict(old)
+    assert opt.t == 7
+    old["state"][2]["step"] = 8
+    with pytest.raises(ValueError):
+        opt.load_state_dict(old)
+    with pytest.raises(ValueError):
+        opt.load_state_dict({"state": {}, "param_groups": [dict(rsd["param_groups"][0], params=[0, 1])]})
+
+
+def test_root_utils_mirror():
+    """reference utils.py:77-94 (MovingAverage), :97-101, :138-139 and the names its scripts import with `from utils import *`."""
+    from spatiotemporalentropymodel_amd import utils as U
+    for name in ("EMLoss", "RateDistortionLoss", "PixelwiseRateDistortionLoss", "MovingAverage", "quality2lambda",
+                 "configure_optimizers", "save_checkpoint"):
+        assert hasattr(U, name), name
+    ma = U.MovingAverage(3)
+    assert [ma.next(v) for v in (3, 6, 9, 12)] == [3.0, 4.5, 6.0, 9.0]
+    assert len(ma.queue) == 3 and ma.Max_size == 3
+    q = torch.tensor([0.0, 0.5, 1.0])
+    assert torch.allclose(U.quality2lambda(q), 0.002 * torch.exp(3.4409 * q))
+
+
+def test_update_registered_buffers_policies():
+    """compressai/models/utils.py:27-110 behaviour: resize_if_empty / resize / register + the error types."""
+    from spatiotemporalentropymodel_amd.models.utils import find_named_buffer, update_registered_buffers
+    m = torch.nn.Module()
+    m.register_buffer("_offset", torch.IntTensor())
+    m.register_buffer("_cdf_length", torch.IntTensor([1, 2, 3]))
+    sd = {"em._offset": torch.zeros(7, dtype=torch.int32), "em._cdf_length": torch.zeros(5, dtype=torch.int32),
+          "em.fresh": torch.zeros(2, 4, dtype=torch.int32)}
+    update_registered_buffers(m, "em", ["_offset", "_cdf_length"], sd)
+    assert m._offset.shape == (7,) and m._cdf_length.shape == (3,)          # only the empty one took the new shape
+    update_registered_buffers(m, "em", ["_cdf_length"], sd, policy="resize")
+    assert m._cdf_length.shape == (5,)
+    assert find_named_buffer(m, "_offset") is m._offset and find_named_buffer(m, "nope") is None
+    with pytest.raises(ValueError):
+        update_registered_buffers(m, "em", ["nope"], sd)
+    with pytest.raises(ValueError):
+        update_registered_buffers(m, "em", ["_offset"], sd, policy="bogus")
+    with pytest.raises(RuntimeError):
+        update_registered_buffers(m, "em", ["_offset"], sd, policy="register")
+
+
+def test_entropy_bottleneck_init_values():
+    """entropy_models.py:303-340 upstream: softplus(matrix_i) == 1/(s * fan_out), factors 0, quantiles (-10,0,10), target logits."""
+    eb = em.EntropyBottleneck(6)
+    s = 10 ** (1 / 5)
+    for i, fo in enumerate((3, 3, 3, 3, 1)):
+        mtx = getattr(eb, f"_matrix{i}")
+        assert mtx.shape == (6, fo, (1, 3, 3, 3, 3)[i])
+        assert torch.allclose(torch.nn.functional.softplus(mtx), torch.full_like(mtx, 1 / s / fo), rtol=1e-6)
+        b = getattr(eb, f"_bias{i}")
+        assert b.shape == (6, fo, 1) and float(b.detach().abs().max()) <= 0.5
+        if i < 4:
+            assert float(getattr(eb, f"_factor{i}").abs().max()) == 0.0
+    assert torch.equal(eb.quantiles, torch.tensor([-10.0, 0.0, 10.0]).repeat(6, 1, 1))
+    t = float(np.log(2 / 1e-9 - 1))
+    assert torch.allclose(eb.target, torch.tensor([-t, 0.0, t]))
+    # argument errors of EntropyModel.decompress (entropy_models.py:245-264 upstream) are ValueErrors
+    idx = torch.zeros(1, 6, 2, 2)
+    check = em.EntropyModel._check_decompress_args
+    for bad in (("notalist", idx, None), ([b"", b""], idx, None), ([b""], torch.zeros(6, 2, 2), None),
+                ([b""], idx, torch.zeros(2, 6, 2, 2)), ([b""], idx, torch.zeros(1, 6, 1, 2))):
+        with pytest.raises(ValueError):
+            check(*bad)
+    check([b""], idx, torch.zeros(1, 6, 1, 1))
+    check((b"",), idx, torch.zeros(1, 6, 2, 2))
