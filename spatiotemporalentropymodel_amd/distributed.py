@@ -39,12 +39,44 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+_HOST_STAGE = {}
+
+
+def all_reduce_sum_(t: torch.Tensor):
+    """In-place sum all-reduce of `t` on the current stream.  RCCL ("nccl") takes device tensors directly and is
+    stream-ordered.  With the gloo backend (CPU tests; the 2-ranks-on-one-GPU tests, where RCCL refuses to put two ranks
+    on one device) a device tensor is staged through a pinned host buffer: copy out on the current stream, wait for
+    it, exchange on the host, copy back on the same stream -- so callers see the same ordering contract as with RCCL
+    (the result is ordered after prior work and before later work of the current stream), just without the overlap."""
+    if not t.is_cuda or dist.get_backend() != "gloo":
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return
+    key = (t.device, t.numel() > (1 << 22))
+    host = _HOST_STAGE.get(key)
+    if host is None or host.numel() < t.numel():
+        host = _HOST_STAGE[key] = torch.empty(max(t.numel(), 1 << 16), dtype=t.dtype).pin_memory()
+    h = host[:t.numel()].view(t.shape)
+    st = torch.cuda.current_stream(t.device)
+    h.copy_(t, non_blocking=True)
+    st.synchronize()
+    dist.all_reduce(h, op=dist.ReduceOp.SUM)
+    t.copy_(h, non_blocking=True)
+    st.synchronize()                       # the pinned buffer is reused by the next call
+
+
 def broadcast_parameters(module: torch.nn.Module, src=0):
     """Replicas must start identical (weights stay replicated afterwards: same gradient, same update)."""
     if not dist.is_initialized():
         return
+    stage = dist.get_backend() == "gloo"
     for t in list(module.parameters()) + list(module.buffers()):
-        if t.numel():
+        if not t.numel():
+            continue
+        if stage and t.is_cuda:                      # gloo: through the host (see all_reduce_sum_)
+            h = t.data.cpu()
+            dist.broadcast(h, src)
+            t.data.copy_(h)
+        else:
             dist.broadcast(t.data, src)
 
 
@@ -78,7 +110,7 @@ class FlatGradReducer:
         self._stream.wait_stream(cur)                  # gradients are complete on the compute stream
         with torch.cuda.stream(self._stream):
             for s, e in self.ranges:
-                dist.all_reduce(self.grad[s:e], op=dist.ReduceOp.SUM)
+                all_reduce_sum_(self.grad[s:e])
         cur.wait_stream(self._stream)
 
 
@@ -134,7 +166,7 @@ class OverlappedGradReducer:
                 continue
             self._stream.wait_stream(torch.cuda.current_stream())      # the slice is final on the compute stream
             with torch.cuda.stream(self._stream):
-                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                all_reduce_sum_(g)
 
     def finish(self):
         """Order the exchanged gradient before whatever the compute stream does next.  Every element of the flat buffer
@@ -203,7 +235,7 @@ class GopGradAccumulator:
     def end_frame(self):
         for f in self.exchanged:
             if self.world > 1:
-                dist.all_reduce(f.grad, op=dist.ReduceOp.SUM)
+                all_reduce_sum_(f.grad)
             self._fold(f, 1.0 / self.world)
 
     def end_aux(self):
@@ -215,7 +247,7 @@ class GopGradAccumulator:
         such as the "skip this GOP" break must be taken by every rank or by none."""
         if self.world == 1:
             return bool(flag)
-        dev = self.exchanged[0].grad.device if self.exchanged else torch.device("cpu")
+        dev = self.exchanged[0].grad.device if self.exchanged and dist.get_backend() != "gloo" else torch.device("cpu")
         t = torch.tensor([1.0 if flag else 0.0], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return bool(t.item() > 0)
@@ -233,7 +265,7 @@ def shard_seed(base_seed: int, rank: int) -> int:
 def max_over_ranks(value: float, device) -> float:
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

@@ -68,7 +68,7 @@ def _flat_grad(p):
 # with the dgrad chain.  All weight-gradient work shares that one stream (ordered among itself, so the shared
 # geometry-keyed workspaces and repeated accumulation into one parameter stay race-free); the compute stream re-joins
 # at the end of every backward pass (autograd engine callback) and wherever gradients are consumed (optim.py).
-_WGRAD_SIDE = {"enabled": True, "streams": {}, "queued": False}
+_WGRAD_SIDE = {"enabled": True, "streams": {}, "queued": False, "keep": []}
 
 
 def wgrad_side_stream(device):
@@ -83,6 +83,7 @@ def join_wgrad_stream():
     _WGRAD_SIDE["queued"] = False
     for dev, st in _WGRAD_SIDE["streams"].items():
         torch.cuda.current_stream(dev).wait_stream(st)
+    _WGRAD_SIDE["keep"].clear()          # the current stream is now ordered after every reader (see _on_side_stream)
 
 
 def _on_side_stream(fn, *tensors):
@@ -92,7 +93,14 @@ def _on_side_stream(fn, *tensors):
     with torch.cuda.stream(side):
         fn()
     for t in tensors:
-        t.record_stream(side)
+        t.record_stream(side)            # the allocator must not hand the memory out again before the side stream is done
+    # ... and nobody may WRITE it before then either.  autograd sums fan-out gradients in place when it holds the last
+    # reference to a buffer (InputBuffer::accumulate): the gradient of a residual add reaches a convolution's backward
+    # AND, as the very same tensor, the skip connection, where the engine later does `dy.add_(dx_branch)` on the compute
+    # stream -- while the weight-gradient kernel queued here may not have read dy yet.  (Observed as wrong conv_1
+    # gradients of the residual blocks as soon as a second process competed for the GPU and delayed the side stream;
+    # tests/test_hip_dp2.py.)  Holding a reference until the streams are joined keeps such buffers out of place.
+    _WGRAD_SIDE["keep"].extend(tensors)
     if not _WGRAD_SIDE["queued"]:
         _WGRAD_SIDE["queued"] = True
         torch.autograd.Variable._execution_engine.queue_callback(join_wgrad_stream)

@@ -146,16 +146,23 @@ def smoke_check(verbose=False):
         _, y_cond = imodel.getY(frames[0])
     out, oc, aux, gn = p_frame_step(imodel, stem, EMLoss(), opt, aux_opt, frames[1], y_cond)
     torch.cuda.synchronize()
-    loss, ybpp, zbpp, aux_ref, gn_ref = g["s1:scalars"]
+    # Gate values: the float64 run of the reference on the same inputs (tests/golden/stem_f64.npz, written by
+    # make_golden.py:gen_f64) -- the reference's own fp32 numbers are up to 1e-4 away from it (its fp32 clip_grad_norm_:
+    # 9.9e-5), so they are only the secondary check.
+    x = dict(np.load(os.path.join(REPO, "tests", "golden", "stem_f64.npz")))
+    loss, ybpp, zbpp, aux_ref, gn_ref = x["small:s1:scalars"]
 
     def rel(a, b):
         return abs(float(a) - float(b)) / max(abs(float(b)), 1e-30)
 
+    def ratio(a, b):      # tests/conftest.py:close_ratio with floor 0.1, atol 1e-9 (the likelihood bound)
+        return float(np.max(np.maximum(np.abs(a - b) - 1e-9, 0.0) / np.maximum(np.abs(b), 0.1 * np.abs(b).max())))
+
     checks = {"loss": rel(oc["loss"], loss), "y_bpp": rel(oc["y_bpp_loss"], ybpp), "z_bpp": rel(oc["z_bpp_loss"], zbpp),
               "grad_norm": rel(gn, gn_ref), "aux_loss": rel(aux, aux_ref)}
-    lik_y = out["likelihoods"]["y"].detach().cpu().contiguous().numpy()
-    ref_l = g["s1:lik_y"]        # same metric as tests/conftest.py:assert_close (floor = 0.1 x max)
-    checks["lik_y_vs_golden"] = float(np.max(np.abs(lik_y - ref_l) / np.maximum(np.abs(ref_l), 0.1 * ref_l.max())))
+    lik_y = out["likelihoods"]["y"].detach().cpu().contiguous().numpy().astype(np.float64)
+    checks["lik_y_vs_f64"] = ratio(lik_y, x["small:s1:lik_y"])
+    checks["loss_vs_ref_fp32"] = rel(oc["loss"], g["s1:scalars"][0])
     # oracle on the same y_cur / y_cond (g_a through the oracle as well)
     isd = {k: v.detach().cpu().numpy() for k, v in imodel.state_dict().items() if v.dtype == torch.float32}
     y_ref = orc.g_a(isd, frames[1].cpu().numpy())
@@ -165,7 +172,7 @@ def smoke_check(verbose=False):
     if verbose:
         for k, v in checks.items():
             print(f"smoke: {k:18s} rel err {v:.3e}")
-    bad = {k: v for k, v in checks.items() if not v < 2e-4}
+    bad = {k: v for k, v in checks.items() if not v < 1e-4}
     if bad:
         raise AssertionError(f"smoke(): HIP path disagrees with the reference/oracle: {bad}")
     return checks

@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""One data-parallel rank of the 2-rank GPU tests (tests/test_hip_dp2.py).  NOT a pytest module.
+
+Two of these processes share cuda:0 and exchange gradients through torch.distributed's gloo backend (RCCL refuses
+two ranks on one device), so that distributed.OverlappedGradReducer / GopGradAccumulator run against the REAL HIP
+backward -- hooks fired from StemEngine.backward on the weight-gradient stream, slices of the flat gradient buffer
+all-reduced while the rest of backward is still queued -- on the single-GPU test box.  The parent test compares what the
+ranks dump with a single-process run over the concatenated batch.
+
+    python tests/dp_worker.py --case train|gop --rank R --world W --port P --out DIR
+"""
+import argparse
+import os
+import sys
+import types
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+class SlicedNoise:
+    """noise_source for rank `r` of `world`: the rows this rank's samples own in the noise tensor a single process
+    would draw for the concatenated batch (same closed-form stream as selfcheck.NoiseFeed)."""
+
+    def __init__(self, role, rank, world, per_rank, batch_last=False):
+        self.role, self.rank, self.world, self.per, self.k, self.batch_last = role, rank, world, per_rank, 0, batch_last
+
+    def __call__(self, shape, device):
+        from spatiotemporalentropymodel_amd.weights import closed_form_input
+        name = f"noise:{self.role}:{self.k}"
+        self.k += 1
+        lo, hi = self.rank * self.per, (self.rank + 1) * self.per
+        if self.batch_last:                       # EntropyBottleneck asks for [C, 1, H*W*B] with B innermost
+            Cc, one, n = shape
+            hw = n // self.per
+            full = closed_form_input(name, (Cc, 1, hw * self.per * self.world), -0.5, 0.5)
+            return full.reshape(Cc, hw, self.per * self.world)[:, :, lo:hi].reshape(Cc, 1, n).contiguous().to(device)
+        full = closed_form_input(name, (shape[0] * self.world,) + tuple(shape[1:]), -0.5, 0.5)
+        return full[lo:hi].contiguous().to(device)
+
+
+def flat_np(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def case_train(rank, world, out_dir, steps=2):
+    """`steps` P-frame optimisation steps of SpatioTemporalPriorModel_Res (small config) on ONE sample per rank, with the
+    overlapped reducer attached to the engine: dumps losses, the exchanged (averaged) gradient of step 1, and the
+    parameters after the last step."""
+    from spatiotemporalentropymodel_amd import distributed as D
+    from spatiotemporalentropymodel_amd import selfcheck as S
+    from spatiotemporalentropymodel_amd.losses import EMLoss
+    from spatiotemporalentropymodel_amd.optim import configure_optimizers
+    from spatiotemporalentropymodel_amd.weights import smooth_frames
+    dev = torch.device("cuda:0")
+    imodel, stem = S.build_models(64, 96, 64, 96, dev, inject_noise=False)
+    stem.train()
+    imodel.gaussian_conditional.noise_source = SlicedNoise("iframe_gc", rank, world, 1)
+    stem.entropy_bottleneck.noise_source = SlicedNoise("stem_eb", rank, world, 1, batch_last=True)
+    stem.gaussian_conditional.noise_source = SlicedNoise("stem_gc", rank, world, 1)
+    D.broadcast_parameters(stem)
+    opt, aux_opt = configure_optimizers(stem, types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3))
+    red = D.OverlappedGradReducer(opt.flat).attach(stem.engine())
+    crit = EMLoss()
+    frames = [f[rank:rank + 1].contiguous().to(dev) for f in smooth_frames("dp2:train", world, steps + 1, 64)]
+    with torch.no_grad():
+        _, y_cond = imodel.getY(frames[0])
+    dump = {}
+    for t in range(1, steps + 1):
+        if t == 1:                                  # by hand, to look at the exchanged gradient before Adam consumes it
+            opt.zero_grad(), aux_opt.zero_grad()
+            with torch.no_grad():
+                y_cur, _ = imodel.getY(frames[t])
+            out = stem(y_cur, y_cond)
+            oc = crit(out, frames[t])
+            oc["loss"].backward()
+            red.finish()
+            dump["grad_avg"] = flat_np(opt.flat.grad) * red.grad_scale
+            gn = opt.grad_norm() * red.grad_scale
+            opt.step(grad_scale=red.grad_scale, norm_is_current=True)
+            aux = stem.aux_loss()
+            aux.backward()
+            aux_opt.step()
+        else:
+            out, oc, aux, gn = S.p_frame_step(imodel, stem, crit, opt, aux_opt, frames[t], y_cond, grad_scale=red.grad_scale,
+                                              reducer=red)
+        y_cond = out["y_hat"]
+        dump[f"s{t}:loss"] = np.array([float(oc["loss"]), float(gn), float(aux)])
+    torch.cuda.synchronize()
+    dump["params"] = flat_np(opt.flat.data)
+    dump["quantiles"] = flat_np(aux_opt.flat.data)
+    dump["reducer_calls"] = np.array([red.calls])
+    np.savez(os.path.join(out_dir, f"train_rank{rank}.npz"), **dump)
+
+
+def case_gop(rank, world, out_dir, frames_n=3):
+    """One GOP iteration of the variable-rate loop (selfcheck.roi_gop_step) with GopGradAccumulator, one sample per rank."""
+    from spatiotemporalentropymodel_amd import distributed as D
+    from spatiotemporalentropymodel_amd import selfcheck as S
+    from spatiotemporalentropymodel_amd.losses import PixelwiseRateDistortionLoss
+    from spatiotemporalentropymodel_amd.models import stem_roi, stem_roi_i
+    from spatiotemporalentropymodel_amd.optim import configure_optimizers
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_scaled_, closed_form_input, smooth_frames
+    dev = torch.device("cuda:0")
+    imodel, pmodel = stem_roi_i(), stem_roi()
+    closed_form_fill_scaled_(imodel, "stem_roi_i", 0.7)
+    closed_form_fill_scaled_(pmodel, "stem_roi", 0.7)
+    imodel, pmodel = imodel.to(dev).train(), pmodel.to(dev).train()
+    for m, tag in ((imodel, "i"), (pmodel, "p")):
+        m.entropy_bottleneck.noise_source = SlicedNoise(f"roi_{tag}_eb", rank, world, 1, batch_last=True)
+        m.gaussian_conditional.noise_source = SlicedNoise(f"roi_{tag}_gc", rank, world, 1)
+    args = types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3)
+    opt_i, aux_i = configure_optimizers(imodel, args, max_norm=None)
+    opt_p, aux_p = configure_optimizers(pmodel, args, max_norm=None)
+    acc = D.GopGradAccumulator([opt_i.flat, opt_p.flat], [aux_i.flat, aux_p.flat])
+    frames = [f[rank:rank + 1].contiguous().to(dev) for f in smooth_frames("dp2:gop", world, frames_n, 64)]
+    qmap = closed_form_input("dp2:qmap", (world, 1, 64, 64), 0.0, 1.0)[rank:rank + 1].contiguous().to(dev)
+    log = S.roi_gop_step(imodel, pmodel, PixelwiseRateDistortionLoss(), (opt_i, aux_i, opt_p, aux_p), frames, qmap,
+                         clip_max_norm=float(os.environ.get("DP2_CLIP", "1.0")), accumulator=acc)
+    torch.cuda.synchronize()
+    dump = {"losses": np.array([[float(oc["loss"]), float(gn) if gn is not None else 0.0, float(aux)] for oc, gn, aux in log]),
+            "params_i": flat_np(opt_i.flat.data), "params_p": flat_np(opt_p.flat.data),
+            "grad_i": flat_np(opt_i.flat.grad), "grad_p": flat_np(opt_p.flat.grad)}
+    np.savez(os.path.join(out_dir, f"gop_rank{rank}.npz"), **dump)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", required=True)
+    ap.add_argument("--rank", type=int, required=True)
+    ap.add_argument("--world", type=int, default=2)
+    ap.add_argument("--port", type=int, required=True)
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.port), RANK=str(a.rank), WORLD_SIZE=str(a.world),
+                      LOCAL_RANK="0", STEM_DIST_BACKEND="gloo")
+    from spatiotemporalentropymodel_amd import distributed as D
+    D.init_from_env()
+    {"train": case_train, "gop": case_gop}[a.case](a.rank, a.world, a.out)
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

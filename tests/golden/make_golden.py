@@ -286,7 +286,7 @@ def gen_codec(ref):
 
 
 # ---------------------------------------------------------------------------
-def gen_stem_small_forward(ref):
+def gen_stem_small_forward(ref, dtype=torch.float32, write=True):
     """BASELINE.json configs[0]: one 7x256x256 septuplet, I-frame mbt2018(N=64,M=96) transforms +
     SpatioTemporalPriorModel(ebc=64,in=96) forward in eval mode, bpp / MSE plumbing."""
     from compressai.models.priors import JointAutoregressiveHierarchicalPriors
@@ -298,9 +298,10 @@ def gen_stem_small_forward(ref):
     imodel.gaussian_conditional._get_noise_cached = NoiseFeed("iframe_gc", log)
     stem = SpatioTemporalPriorModel(64, 96).eval()
     closed_form_fill_(stem)
+    imodel, stem = imodel.to(dtype), stem.to(dtype)
     cap = {}
     stem.EPM.register_forward_hook(lambda m, i, o: cap.__setitem__("gp", o.detach()))
-    frames = smooth_frames("septuplet0", 1, 7, 256)
+    frames = [f.to(dtype) for f in smooth_frames("septuplet0", 1, 7, 256)]
     d = {"frame0_crop": t2n(frames[0][:, :, :32, :32])}
     bpp_y, bpp_z, mse = [], [], []
     with torch.no_grad():
@@ -324,10 +325,12 @@ def gen_stem_small_forward(ref):
             y_cond = out["y_hat"]
     d["bpp_y"], d["bpp_z"], d["mse"] = np.array(bpp_y), np.array(bpp_z), np.array(mse)
     d["noise_log"] = np.array([f"{n}|{','.join(map(str, s))}" for n, s in log])
-    save("stem_small_forward.npz", d)
+    if write:
+        save("stem_small_forward.npz", d)
+    return d
 
 
-def _train_case(ref, ebc, cin, N, M, batch, size, tag, steps=2):
+def _train_case(ref, ebc, cin, N, M, batch, size, tag, steps=2, dtype=torch.float32, write=True):
     """The per-P-frame loop of stem/trainSTEM.py:194-218 (getY -> stem fwd -> EMLoss -> backward ->
     clip_grad_norm_ -> optimizer.step -> aux_loss.backward -> aux_optimizer.step), reference code."""
     import types
@@ -340,12 +343,13 @@ def _train_case(ref, ebc, cin, N, M, batch, size, tag, steps=2):
     imodel.gaussian_conditional._get_noise_cached = NoiseFeed("iframe_gc", log)
     stem = SpatioTemporalPriorModel_Res(ebc, cin).train()
     closed_form_fill_(stem)
+    imodel, stem = imodel.to(dtype), stem.to(dtype)          # float64: the "exact" run the fp32 results are measured against
     stem.entropy_bottleneck._get_noise_cached = NoiseFeed("stem_eb", log)
     stem.gaussian_conditional._get_noise_cached = NoiseFeed("stem_gc", log)
     args = types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3)
     optimizer, aux_optimizer = ref.configure_optimizers(stem, args)
     criterion = ref.EMLoss()
-    frames = smooth_frames("train:" + tag, batch, steps + 1, size)
+    frames = [f.to(dtype) for f in smooth_frames("train:" + tag, batch, steps + 1, size)]
     d = {}
     with torch.no_grad():
         _, y_cond = imodel.getY(frames[0])
@@ -365,7 +369,7 @@ def _train_case(ref, ebc, cin, N, M, batch, size, tag, steps=2):
                 if p.grad is None:
                     continue
                 g = p.grad.double()          # after clipping
-                d[f"s1:gsum:{n_}"] = np.array([float(g.sum()), float(g.abs().sum()), float((g * g).sum())])
+                d[f"s1:gsum:{n_}"] = np.array([float(g.sum()), float(g.abs().sum()), float((g * g).sum()), float(p.numel())])
                 d[f"s1:gslice:{n_}"] = t2n(p.grad.reshape(-1)[:: max(1, p.numel() // 64)][:64])
         optimizer.step()
         aux = stem.aux_loss()
@@ -380,7 +384,9 @@ def _train_case(ref, ebc, cin, N, M, batch, size, tag, steps=2):
         d[f"final:pslice:{n_}"] = t2n(p.reshape(-1)[:: max(1, p.numel() // 64)][:64])
     d["noise_log"] = np.array([f"{n}|{','.join(map(str, s))}" for n, s in log])
     d["cfg"] = np.array([ebc, cin, N, M, batch, size, steps])
-    save(f"stem_train_{tag}.npz", d)
+    if write:
+        save(f"stem_train_{tag}.npz", d)
+    return d
 
 
 def gen_stem_codec(ref):
@@ -458,7 +464,7 @@ def _grad_digest(d, tag, module):
         if p.grad is None:
             continue
         g = p.grad.double()
-        d[f"{tag}:gsum:{n_}"] = np.array([float(g.sum()), float(g.abs().sum()), float((g * g).sum())])
+        d[f"{tag}:gsum:{n_}"] = np.array([float(g.sum()), float(g.abs().sum()), float((g * g).sum()), float(p.numel())])
         d[f"{tag}:gslice:{n_}"] = t2n(p.grad.reshape(-1)[:: max(1, p.numel() // 64)][:64])
 
 
@@ -607,19 +613,20 @@ def gen_stem_variants(ref, batch=1, size=64):
     save("stem_variants.npz", d)
 
 
-def gen_stem_ablations(ref, batch=2, ls=8, cin=96):
+def gen_stem_ablations(ref, batch=2, ls=8, cin=96, dtype=torch.float32, write=True):
     """Training forward + EMLoss backward of the four non-residual STEM variants (spatiotemporalpriors.py:33-788) on
     closed-form latents: outputs, loss and every parameter gradient."""
     import compressai.models.spatiotemporalpriors as sp
     d = {}
-    y_cur = closed_form_input("abl:y", (batch, cin, ls, ls), -5.0, 5.0)
-    y_cond = closed_form_input("abl:c", (batch, cin, ls, ls), -5.0, 5.0)
+    y_cur = closed_form_input("abl:y", (batch, cin, ls, ls), -5.0, 5.0).to(dtype)
+    y_cond = closed_form_input("abl:c", (batch, cin, ls, ls), -5.0, 5.0).to(dtype)
     target = torch.zeros(batch, 3, ls * 16, ls * 16)
     for cls, ebc in (("SpatioTemporalPriorModelWithoutSPMTPM", 256), ("SpatioTemporalPriorModelWithoutSPM", 256),
                      ("SpatioTemporalPriorModelWithoutTPM", 64), ("SpatioTemporalPriorModel", 64)):
         log = []
         m = getattr(sp, cls)(ebc, cin).train()
         closed_form_fill_wrapped(m, cls)
+        m = m.to(dtype)
         m.entropy_bottleneck._get_noise_cached = NoiseFeed(cls + "_eb", log)
         m.gaussian_conditional._get_noise_cached = NoiseFeed(cls + "_gc", log)
         out = m(y_cur, y_cond)
@@ -630,7 +637,73 @@ def gen_stem_ablations(ref, batch=2, ls=8, cin=96):
         d[f"{cls}:scalars"] = np.array([float(oc["loss"]), float(oc["y_bpp_loss"]), float(oc["z_bpp_loss"])])
         d[f"{cls}:noise_log"] = np.array([f"{n}|{','.join(map(str, s_))}" for n, s_ in log])
     d["cfg"] = np.array([batch, ls, cin])
-    save("stem_ablations.npz", d)
+    if write:
+        save("stem_ablations.npz", d)
+    return d
+
+
+def _close_ratio(a, b, floor=0.1, atol=0.0):
+    """max over elements of |a-b| / (atol/rtol-free part of tests/conftest.py:assert_close): err / max(|b|, floor*max|b|)"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    scale = max(float(np.abs(b).max()), 1e-30)
+    return float((np.maximum(np.abs(a - b) - atol, 0.0) / np.maximum(np.abs(b), floor * scale)).max())
+
+
+def gen_f64(ref):
+    """The same reference code run in float64 (module.double(), identical closed-form weights / inputs / noise): the
+    exact values both fp32 implementations -- the reference's torch-CPU path and the HIP path -- approximate.  Saved:
+    the float64 results the widened parity gates compare against, and `ref32:*` = how far the REFERENCE'S OWN fp32 run
+    is from them in the tests' metrics (e.g. torch's fp32 clip_grad_norm_ is 6e-5..1e-4 off the exact norm)."""
+    d = {}
+    for cfg in ((64, 96, 64, 96, 2, 128, "small"), (256, 192, 192, 192, 2, 64, "big")):
+        tag = cfg[-1]
+        a = _train_case(ref, *cfg[:6], tag=tag, dtype=torch.float32, write=False)
+        b = _train_case(ref, *cfg[:6], tag=tag, dtype=torch.float64, write=False)
+        for k in ("s1:lik_y", "s1:lik_z", "s1:scalars", "s2:scalars", "s1:dquantiles"):
+            d[f"{tag}:{k}"] = b[k]
+        d[f"{tag}:ref32:lik_y"] = np.array([_close_ratio(a["s1:lik_y"], b["s1:lik_y"], atol=1e-9)])
+        d[f"{tag}:ref32:lik_z"] = np.array([_close_ratio(a["s1:lik_z"], b["s1:lik_z"], atol=1e-9)])
+        for t in (1, 2):
+            d[f"{tag}:ref32:s{t}:scalars"] = np.abs(a[f"s{t}:scalars"] - b[f"s{t}:scalars"]) / np.abs(b[f"s{t}:scalars"])
+        worst_slice, worst_sum = 0.0, 0.0
+        for k in b:
+            if k.startswith("s1:gsum:"):
+                n_ = k[len("s1:gsum:"):]
+                d[f"{tag}:{k}"], d[f"{tag}:s1:gslice:{n_}"] = b[k], b[f"s1:gslice:{n_}"]
+                rms = float(np.sqrt(b[k][2] / b[k][3]))
+                sl_err = np.abs(a[f"s1:gslice:{n_}"].astype(np.float64) - b[f"s1:gslice:{n_}"])
+                worst_slice = max(worst_slice, float((sl_err / np.maximum(np.abs(b[f"s1:gslice:{n_}"]), rms)).max()))
+                worst_sum = max(worst_sum, abs(a[k][0] - b[k][0]) / b[k][1], abs(a[k][1] - b[k][1]) / b[k][1])
+        d[f"{tag}:ref32:grad_slice"], d[f"{tag}:ref32:grad_sums"] = np.array([worst_slice]), np.array([worst_sum])
+    a = gen_stem_ablations(ref, dtype=torch.float32, write=False)
+    b = gen_stem_ablations(ref, dtype=torch.float64, write=False)
+    for k in b:
+        if k.endswith(":noise_log") or k == "cfg":
+            continue
+        d["abl:" + k] = b[k]
+    for cls in sorted({k.split(":")[0] for k in b if ":" in k}):
+        d[f"abl:{cls}:ref32:lik_y"] = np.array([_close_ratio(a[f"{cls}:lik_y"], b[f"{cls}:lik_y"], atol=1e-9)])
+        worst = 0.0
+        for k in b:
+            if k.startswith(f"{cls}:gslice:"):
+                n_ = k[len(cls) + 8:]
+                gs = b[f"{cls}:gsum:{n_}"]
+                rms = float(np.sqrt(gs[2] / gs[3]))
+                e = np.abs(a[k].astype(np.float64) - b[k]) / np.maximum(np.abs(b[k]), rms)
+                worst = max(worst, float(e.max()))
+        d[f"abl:{cls}:ref32:grad_slice"] = np.array([worst])
+    # config-1 forward: the float64 STEM evaluated on the SAME (fp32) latents the fp32 golden run saw, as the test feeds them
+    from compressai.models.spatiotemporalpriors import SpatioTemporalPriorModel
+    a = gen_stem_small_forward(ref, dtype=torch.float32, write=False)
+    stem64 = closed_form_fill_(SpatioTemporalPriorModel(64, 96).eval()).double()
+    with torch.no_grad():
+        o64 = stem64(torch.from_numpy(a["f1:y_cur"]).double(), torch.from_numpy(a["f1:y_cond"]).double())
+    d["fwd:f1:lik_y"], d["fwd:f1:lik_z"] = t2n(o64["likelihoods"]["y"]), t2n(o64["likelihoods"]["z"])
+    d["fwd:ref32:lik_y"] = np.array([_close_ratio(a["f1:lik_y"], d["fwd:f1:lik_y"], atol=1e-9)])
+    save("stem_f64.npz", d)
+    for k in sorted(d):
+        if "ref32" in k:
+            print(f"  {k}: {d[k]}")
 
 
 def gen_container(ref):
@@ -735,7 +808,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     scratch, ref_utils = import_reference()
     try:
-        which = sys.argv[1:] or ["ops", "codec", "fwd", "train_small", "train_big", "stemcodec", "roi", "roiops", "roigop", "container", "dataset", "variants", "ablations"]
+        which = sys.argv[1:] or ["ops", "codec", "fwd", "train_small", "train_big", "stemcodec", "roi", "roiops", "roigop", "container", "dataset", "variants", "ablations", "f64"]
         if "ops" in which:
             gen_ops(ref_utils)
         if "codec" in which:
@@ -762,5 +835,7 @@ if __name__ == "__main__":
             gen_stem_ablations(ref_utils)
         if "dataset" in which:
             gen_roi_dataset(ref_utils)
+        if "f64" in which:
+            gen_f64(ref_utils)
     finally:
         shutil.rmtree(scratch, ignore_errors=True)

@@ -42,7 +42,7 @@ def test_host_draws_and_oracle_maps_match_reference(golden, key):
         ref = g[f"{key}:qmap"][i]
         got = dorc.render_qmap(q, c)
         if int(q[0]) == D.MODE_GAUSSIAN:
-            assert_close(got, ref, 1e-6, what=f"gaussian map seed {g[f'{key}:seeds'][i]}")
+            assert_close(got, ref, 1e-6, what=f"gaussian map seed {g[f'{key}:seeds'][i]}", floor=0.1)
         else:
             np.testing.assert_array_equal(got, ref)
     tags = set(str(t) for t in g["train:tags"])
@@ -73,7 +73,7 @@ def test_hip_quality_maps_match_reference(golden):
         for i, (_, _, _, q) in enumerate(draws):
             ref = g[f"{key}:qmap"][i]
             if int(q[0]) == D.MODE_GAUSSIAN:
-                assert_close(maps[i, 0], ref, 2e-5, what="gaussian map")
+                assert_close(maps[i, 0], ref, 2e-5, what="gaussian map", floor=0.1)
             else:
                 np.testing.assert_array_equal(maps[i, 0], ref)
 

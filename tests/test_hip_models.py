@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import REPO, assert_close
+from conftest import REPO, assert_close, close_ratio, f64_gate
 
 pytestmark = pytest.mark.gpu
 GRAD_RTOL = 1e-4
@@ -39,25 +39,30 @@ def test_config1_small_forward_septuplet(S, golden):
     frames = [f.to(dev) for f in smooth_frames("septuplet0", 1, 7, 256)]
     with torch.no_grad():
         y0, y_cond = imodel.getY(frames[0])
-        assert_close(host(y0), g["y0"], what="g_a(frame 0)")
+        assert_close(host(y0), g["y0"], what="g_a(frame 0)", floor=0.1)
         y_cur, _ = imodel.getY(frames[1])
-        assert_close(host(y_cur), g["f1:y_cur"], what="g_a(frame 1)")
-        assert_close(host(y_cond), g["f1:y_cond"], what="y_cond = y0 + injected noise")
+        assert_close(host(y_cur), g["f1:y_cur"], what="g_a(frame 1)", floor=0.1)
+        assert_close(host(y_cond), g["f1:y_cond"], what="y_cond = y0 + injected noise", floor=0.1)
         # frame 1 on the reference's own latents: every tensor
         yc, yd = torch.from_numpy(g["f1:y_cur"]).to(dev), torch.from_numpy(g["f1:y_cond"]).to(dev)
         out = stem(yc, yd)
         gp = stem.engine().forward(yc, yd, False)[3]["gp"]
-        assert_close(host(gp[:, :96]), g["f1:scales"], what="scales")
-        assert_close(host(gp[:, 96:]), g["f1:means"], what="means")
+        assert_close(host(gp[:, :96]), g["f1:scales"], what="scales", floor=0.1)
+        assert_close(host(gp[:, 96:]), g["f1:means"], what="means", floor=0.1)
         np.testing.assert_array_equal(host(out["y_hat"]), g["f1:y_hat"])
-        assert_close(host(out["likelihoods"]["z"]), g["f1:lik_z"], atol=1e-9, what="lik_z")
-        assert_close(host(out["likelihoods"]["y"]), g["f1:lik_y"], 2e-4, atol=1e-9, what="lik_y")
+        assert_close(host(out["likelihoods"]["z"]), g["f1:lik_z"], atol=1e-9, what="lik_z", floor=0.1)
+        # lik_y: gate = 1e-4 of the float64 evaluation of the same latents; against the reference's fp32 values the bound
+        # is 1e-4 + the reference's own distance from exact (both are fp32 roundings of it)
+        f64 = golden("stem_f64.npz")
+        f64_gate(host(out["likelihoods"]["y"]), f64["fwd:f1:lik_y"], f64["fwd:ref32:lik_y"], "config-1 lik_y", atol=1e-9)
+        assert_close(host(out["likelihoods"]["y"]), g["f1:lik_y"], 1e-4 + float(f64["fwd:ref32:lik_y"][0]), atol=1e-9, what="lik_y",
+                     floor=0.1)
         npix = 256 * 256
         assert abs(float(log2_sum(out["likelihoods"]["y"])) / -npix - g["bpp_y"][0]) < 1e-4 * g["bpp_y"][0]
         assert abs(float(log2_sum(out["likelihoods"]["z"])) / -npix - g["bpp_z"][0]) < 1e-4 * g["bpp_z"][0]
         x_hat = imodel.getX(out["y_hat"])
         assert x_hat.is_contiguous() and tuple(x_hat.shape) == (1, 3, 256, 256)
-        assert_close(host(x_hat)[:, :, 100:132, 60:92], g["f1:x_hat_crop"], what="g_s + clamp")
+        assert_close(host(x_hat)[:, :, 100:132, 60:92], g["f1:x_hat_crop"], what="g_s + clamp", floor=0.1)
         mse = float(((x_hat.double() - frames[1].double()) ** 2).mean())
         assert abs(mse - g["mse"][0]) < 1e-4 * g["mse"][0]
         # the whole chain (y_cond <- y_hat): a rounding decision within fp32 noise of .5 may flip, so the
@@ -85,6 +90,11 @@ def test_train_steps_match_reference(S, golden, tag):
     from spatiotemporalentropymodel_amd.optim import configure_optimizers
     from spatiotemporalentropymodel_amd.weights import smooth_frames
     g = golden(f"stem_train_{tag}.npz")
+    f64 = golden("stem_f64.npz")
+
+    def r32(key):
+        return f64[f"{tag}:ref32:{key}"]
+
     ebc, cin, N, M, batch, size, steps = (int(v) for v in g["cfg"])
     dev = torch.device("cuda:0")
     imodel, stem = S.build_models(ebc, cin, N, M, dev)
@@ -106,39 +116,65 @@ def test_train_steps_match_reference(S, golden, tag):
             oc["loss"].backward()
             gn = float(opt.grad_norm())
             loss, ybpp, zbpp, aux_ref, gn_ref = g["s1:scalars"]
-            assert_close(host(y_cur), g["s1:y_cur"], what="y_cur")
-            assert_close(host(out["y_hat"]), g["s1:y_hat"], what="y_hat")
-            assert_close(host(out["likelihoods"]["y"]), g["s1:lik_y"], 2e-4, atol=1e-9, what="lik_y")
-            assert_close(host(out["likelihoods"]["z"]), g["s1:lik_z"], atol=1e-9, what="lik_z")
+            assert_close(host(y_cur), g["s1:y_cur"], what="y_cur", floor=0.1)
+            assert_close(host(out["y_hat"]), g["s1:y_hat"], what="y_hat", floor=0.1)
+            # gates: 1e-4 of the float64 run (exact); vs the fp32 goldens the bound is 1e-4 + the reference's own fp32 error
+            f64_gate(host(out["likelihoods"]["y"]), f64[f"{tag}:s1:lik_y"], r32("lik_y"), f"{tag} lik_y", atol=1e-9)
+            f64_gate(host(out["likelihoods"]["z"]), f64[f"{tag}:s1:lik_z"], r32("lik_z"), f"{tag} lik_z", atol=1e-9)
+            assert_close(host(out["likelihoods"]["y"]), g["s1:lik_y"], 1e-4 + float(r32("lik_y")[0]), atol=1e-9, what="lik_y", floor=0.1)
+            assert_close(host(out["likelihoods"]["z"]), g["s1:lik_z"], atol=1e-9, what="lik_z", floor=0.1)
             assert abs(float(oc["loss"]) - loss) < 1e-4 * loss
             assert abs(float(oc["y_bpp_loss"]) - ybpp) < 1e-4 * ybpp and abs(float(oc["z_bpp_loss"]) - zbpp) < 1e-4 * zbpp
-            assert abs(gn - gn_ref) < 2e-4 * gn_ref, (gn, gn_ref)
+            x_loss, _, _, x_aux, x_gn = f64[f"{tag}:s1:scalars"]
+            f64_gate([float(oc["loss"]), gn], [x_loss, x_gn], r32("s1:scalars")[[0, 4]], f"{tag} step-1 loss / grad norm", floor=0.0)
+            # torch's fp32 clip_grad_norm_ is itself ~1e-4 off the exact norm (ref32 below); ours accumulates in fp64
+            assert abs(gn - gn_ref) < (1e-4 + float(r32("s1:scalars")[4])) * gn_ref, (gn, gn_ref)
             clip = min(1.0, 1.0 / (gn + 1e-6))
+            worst_exact = 0.0
             for name, p in stem.named_parameters():
                 if name.endswith(".quantiles"):
                     continue
-                ref = g[f"s1:gsum:{name}"]
                 gd = p.grad.double() * clip
-                assert abs(float(gd.sum()) - ref[0]) <= 2e-4 * ref[1] + 1e-12, name
-                assert abs(float(gd.abs().sum()) - ref[1]) <= 2e-4 * ref[1] + 1e-12, name
                 sl = host(gd.reshape(-1)[:: max(1, gd.numel() // 64)][:64])
+                # (a) exact: checksums and a 64-element strided slice of the CLIPPED gradient vs the float64 run, 1e-4 of
+                #     the element or of the tensor's RMS (the slice's own max underestimates the scale)
+                ex = f64[f"{tag}:s1:gsum:{name}"]
+                assert abs(float(gd.sum()) - ex[0]) <= 1e-4 * ex[1] + 1e-12, name
+                assert abs(float(gd.abs().sum()) - ex[1]) <= 1e-4 * ex[1] + 1e-12, name
+                rms = float(np.sqrt(ex[2] / p.numel()))
+                xs = f64[f"{tag}:s1:gslice:{name}"]
+                e = float((np.abs(sl - xs) / np.maximum(np.abs(xs), rms)).max())
+                worst_exact = max(worst_exact, e)
+                assert e <= GRAD_RTOL, (name, e)
+                # (b) the reference's fp32 gradients: they carry its fp32 clip coefficient (off by ref32 s1:scalars[4])
+                #     and its own rounding (ref32 grad_slice); the bound says so instead of a flat 2e-4
+                ref = g[f"s1:gsum:{name}"]
+                slack = 1e-4 + float(r32("grad_sums")[0])
+                assert abs(float(gd.sum()) - ref[0]) <= slack * ref[1] + 1e-12, name
+                assert abs(float(gd.abs().sum()) - ref[1]) <= slack * ref[1] + 1e-12, name
                 rs = g[f"s1:gslice:{name}"]
-                # 1e-4 of the element or of the tensor's RMS (the 64-element slice's own max underestimates the scale)
-                rms = float(np.sqrt(ref[2] / p.numel()))
-                assert_close(sl, rs, GRAD_RTOL, atol=GRAD_RTOL * rms, what="grad " + name)
+                tol = GRAD_RTOL + float(r32("grad_slice")[0])
+                assert_close(sl, rs, tol, atol=tol * rms, what="grad " + name, floor=0.1)
+            print(f"[f64 gate] {tag} step-1 gradients: HIP vs exact {worst_exact:.2e}   reference-fp32 vs exact "
+                  f"{float(r32('grad_slice')[0]):.2e}   bound {GRAD_RTOL:.0e}")
             opt.step()
             aux = stem.aux_loss()
             aux.backward()
             assert abs(float(aux) - aux_ref) < 1e-4 * aux_ref
-            assert_close(host(stem.entropy_bottleneck.quantiles.grad), g["s1:dquantiles"], what="dquantiles")
+            assert_close(host(stem.entropy_bottleneck.quantiles.grad), g["s1:dquantiles"], what="dquantiles", floor=0.1)
             aux_opt.step()
             y_cond = out["y_hat"]
         else:
             out, oc, aux, gn = S.p_frame_step(imodel, stem, crit, opt, aux_opt, frames[t], y_cond)
             loss, ybpp, zbpp, aux_ref, gn_ref = g[f"s{t}:scalars"]
-            assert abs(float(oc["loss"]) - loss) < 2e-4 * loss, (float(oc["loss"]), loss)
-            assert abs(float(gn) - gn_ref) < 5e-4 * gn_ref, (float(gn), gn_ref)
-            assert abs(float(aux) - aux_ref) < 2e-4 * aux_ref
+            # step 2 runs on parameters moved by Adam's normalised update (noise-level gradients may step the other way,
+            # see below); its loss / exact grad norm / aux loss still agree with the float64 run to 1e-4
+            x_loss, _, _, x_aux, x_gn = f64[f"{tag}:s{t}:scalars"]
+            f64_gate([float(oc["loss"]), float(gn), float(aux)], [x_loss, x_gn, x_aux], r32(f"s{t}:scalars")[[0, 4, 3]],
+                     f"{tag} step-{t} loss / grad norm / aux", floor=0.0)
+            assert abs(float(oc["loss"]) - loss) < 1e-4 * loss, (float(oc["loss"]), loss)
+            assert abs(float(gn) - gn_ref) < (1e-4 + float(r32(f"s{t}:scalars")[4])) * gn_ref, (float(gn), gn_ref)
+            assert abs(float(aux) - aux_ref) < 1e-4 * aux_ref
             y_cond = out["y_hat"]
     for name, p in stem.named_parameters():
         ref = g[f"final:psum:{name}"]
@@ -185,14 +221,14 @@ def test_layer_modules_autograd(S):
     xn, dyn = host(x), host(dy)
     w0, b0, w1, b1 = (host(t) for t in (net[0].weight, net[0].bias, net[2].weight, net[2].bias))
     h = orc.lrelu_fwd(orc.conv2d_fwd(xn, w0, b0, 1, 1))
-    assert_close(host(y), orc.deconv2d_fwd(h, w1, b1, 2, 2, 1), what="y")
+    assert_close(host(y), orc.deconv2d_fwd(h, w1, b1, 2, 2, 1), what="y", floor=0.1)
     dh, dw1, db1 = orc.deconv2d_bwd(h, w1, dyn, 2, 2, 1)
     dx, dw0, db0 = orc.conv2d_bwd(xn, w0, orc.lrelu_bwd(h, dh), 1, 1)
-    assert_close(host(x.grad), dx, what="dx")
-    assert_close(host(net[0].weight.grad), dw0, what="dw0")
-    assert_close(host(net[2].weight.grad), dw1, what="dw1")
-    assert_close(host(net[0].bias.grad), db0, what="db0")
-    assert_close(host(net[2].bias.grad), db1, what="db1")
+    assert_close(host(x.grad), dx, what="dx", floor=0.1)
+    assert_close(host(net[0].weight.grad), dw0, what="dw0", floor=0.1)
+    assert_close(host(net[2].weight.grad), dw1, what="dw1", floor=0.1)
+    assert_close(host(net[0].bias.grad), db0, what="db0", floor=0.1)
+    assert_close(host(net[2].bias.grad), db1, what="db1", floor=0.1)
 
 
 @pytest.mark.parametrize("cls,ebc", [("SpatioTemporalPriorModelWithoutSPMTPM", 256), ("SpatioTemporalPriorModelWithoutSPM", 256),
@@ -205,6 +241,7 @@ def test_ablation_variants_training_pass_matches_reference(golden, cls, ebc):
     from spatiotemporalentropymodel_amd.selfcheck import NoiseFeed
     from spatiotemporalentropymodel_amd.weights import closed_form_input, closed_form_tensor
     g = golden("stem_ablations.npz")
+    f64 = golden("stem_f64.npz")
     batch, ls, cin = (int(v) for v in g["cfg"])
     dev = torch.device("cuda:0")
     m = getattr(M, cls)(ebc, cin)
@@ -220,25 +257,38 @@ def test_ablation_variants_training_pass_matches_reference(golden, cls, ebc):
     y_cond = closed_form_input("abl:c", (batch, cin, ls, ls), -5.0, 5.0).to(dev)
     out = m(y_cur, y_cond)
     oc = EMLoss()(out, torch.zeros(batch, 3, ls * 16, ls * 16, device=dev))
-    assert_close(host(out["y_hat"]), g[f"{cls}:y_hat"], what="y_hat")
-    assert_close(host(out["likelihoods"]["y"]), g[f"{cls}:lik_y"], 2e-4, atol=1e-9, what="lik_y")
-    assert_close(host(out["likelihoods"]["z"]), g[f"{cls}:lik_z"], atol=1e-9, what="lik_z")
+    assert_close(host(out["y_hat"]), g[f"{cls}:y_hat"], what="y_hat", floor=0.1)
+    r32_lik, r32_grad = f64[f"abl:{cls}:ref32:lik_y"], f64[f"abl:{cls}:ref32:grad_slice"]
+    f64_gate(host(out["likelihoods"]["y"]), f64[f"abl:{cls}:lik_y"], r32_lik, f"{cls} lik_y", atol=1e-9)
+    assert_close(host(out["likelihoods"]["y"]), g[f"{cls}:lik_y"], 1e-4 + float(r32_lik[0]), atol=1e-9, what="lik_y", floor=0.1)
+    assert_close(host(out["likelihoods"]["z"]), g[f"{cls}:lik_z"], atol=1e-9, what="lik_z", floor=0.1)
     for k, ref in zip(("loss", "y_bpp_loss", "z_bpp_loss"), g[f"{cls}:scalars"]):
         assert abs(float(oc[k].detach()) - ref) <= 1e-4 * abs(ref), (k, float(oc[k].detach()), ref)
     oc["loss"].backward()
-    seen = 0
+    seen, worst_exact = 0, 0.0
     for n, p in m.named_parameters():
         key = f"{cls}:gsum:{n}"
         if key not in g:
             continue
-        ref = g[key]
         gd = p.grad.double()
-        assert abs(float(gd.abs().sum()) - ref[1]) <= 2e-4 * ref[1] + 1e-12, n
-        assert abs(float(gd.sum()) - ref[0]) <= 2e-4 * ref[1] + 1e-12, n
-        rms = float(np.sqrt(ref[2] / p.numel()))
         sl = host(p.grad.reshape(-1)[:: max(1, p.numel() // 64)][:64])
-        # 2e-4: here z is 2x2 at batch 2, so the hyper-path gradients are sums over 8 samples of dlik / lik terms
-        # (one element of HD.0.weight lands at 1.7e-4)
-        assert_close(sl, g[f"{cls}:gslice:{n}"], 2 * GRAD_RTOL, atol=2 * GRAD_RTOL * rms, what=f"grad {n}")
+        # (a) vs the float64 run: 1e-4 of the element or the tensor's RMS
+        ex = f64[f"abl:{cls}:gsum:{n}"]
+        assert abs(float(gd.abs().sum()) - ex[1]) <= 1e-4 * ex[1] + 1e-12, n
+        assert abs(float(gd.sum()) - ex[0]) <= 1e-4 * ex[1] + 1e-12, n
+        rms = float(np.sqrt(ex[2] / p.numel()))
+        xs = f64[f"abl:{cls}:gslice:{n}"]
+        e = float((np.abs(sl - xs) / np.maximum(np.abs(xs), rms)).max())
+        worst_exact = max(worst_exact, e)
+        assert e <= GRAD_RTOL, (n, e)
+        # (b) vs the reference's fp32 gradients, whose own distance from exact (z is 2x2 at batch 2: the hyper-path
+        #     gradients are sums over 8 samples of dlik / lik terms) is added to the bound
+        ref = g[key]
+        tol = GRAD_RTOL + float(r32_grad[0])
+        assert abs(float(gd.abs().sum()) - ref[1]) <= tol * ref[1] + 1e-12, n
+        assert abs(float(gd.sum()) - ref[0]) <= tol * ref[1] + 1e-12, n
+        assert_close(sl, g[f"{cls}:gslice:{n}"], tol, atol=tol * rms, what=f"grad {n}", floor=0.1)
         seen += 1
     assert seen >= 25
+    print(f"[f64 gate] {cls} gradients: HIP vs exact {worst_exact:.2e}   reference-fp32 vs exact {float(r32_grad[0]):.2e}   "
+          f"bound {GRAD_RTOL:.0e}")
