@@ -442,3 +442,61 @@ def test_stem_ablation_variants_forward_backward(golden, cls, ebc):
         assert_close(sl, g[f"{cls}:gslice:{name}"], 2e-4, atol=2e-4 * rms, what="grad " + name, floor=0.1)
         seen += 1
     assert seen >= 25
+
+
+def test_blas_port_matches_oracle():
+    """oracle/stem_port_blas.py (the fp32 im2col + SGEMM port bench.py times as `cpu_baseline`) against the C oracle:
+    every dense op on ragged shapes (all strides / kernel sizes / paddings of the path, odd sizes, 1x1, 3-channel input),
+    then a whole STEM training forward + backward run through both back ends."""
+    import stem_port_blas as port
+    from spatiotemporalentropymodel_amd.weights import closed_form_input, closed_form_tensor
+    rng = np.random.default_rng(0)
+
+    def close(a, b, what):
+        e = float(np.abs(np.asarray(a, np.float64) - b).max() / max(float(np.abs(b).max()), 1e-30))
+        assert e < 2e-5, (what, e)
+
+    for (N, Cc, H, W, K, R, st, pd) in [(2, 6, 11, 9, 8, 5, 2, 2), (1, 5, 7, 8, 6, 5, 1, 2), (2, 7, 6, 5, 9, 3, 1, 1), (2, 12, 4, 5, 10, 1, 1, 0),
+                                        (1, 3, 16, 12, 8, 5, 2, 2), (2, 8, 8, 8, 8, 3, 2, 1)]:
+        x, w = rng.standard_normal((N, Cc, H, W)).astype(np.float32), rng.standard_normal((K, Cc, R, R)).astype(np.float32)
+        b = rng.standard_normal(K).astype(np.float32)
+        y = orc.conv2d_fwd(x, w, b, st, pd)
+        close(port.conv2d_fwd(x, w, b, st, pd), y, "conv fwd")
+        dy = rng.standard_normal(y.shape).astype(np.float32)
+        for got, ref, what in zip(port.conv2d_bwd(x, w, dy, st, pd), orc.conv2d_bwd(x, w, dy, st, pd), ("dx", "dw", "db")):
+            close(got, ref, f"conv {what} {(N, Cc, H, W, K, R, st, pd)}")
+        assert port.conv2d_bwd(x, w, dy, st, pd, need_dx=False)[0] is None
+    for (N, Cc, H, W, K, R, st, pd, op) in [(2, 6, 5, 4, 8, 5, 2, 2, 1), (1, 4, 3, 3, 3, 3, 2, 1, 1), (2, 8, 4, 4, 8, 5, 2, 2, 1)]:
+        x, w = rng.standard_normal((N, Cc, H, W)).astype(np.float32), rng.standard_normal((Cc, K, R, R)).astype(np.float32)
+        b = rng.standard_normal(K).astype(np.float32)
+        y = orc.deconv2d_fwd(x, w, b, st, pd, op)
+        close(port.deconv2d_fwd(x, w, b, st, pd, op), y, "deconv fwd")
+        dy = rng.standard_normal(y.shape).astype(np.float32)
+        for got, ref, what in zip(port.deconv2d_bwd(x, w, dy, st, pd, op), orc.deconv2d_bwd(x, w, dy, st, pd, op), ("dx", "dw", "db")):
+            close(got, ref, f"deconv {what}")
+    x = rng.standard_normal((2, 8, 5, 6)).astype(np.float32)
+    be, ga = np.sqrt(1 + 0.2 * rng.random(8)).astype(np.float32), np.sqrt(0.1 * np.eye(8) + 0.02 * rng.random((8, 8))).astype(np.float32)
+    for inv in (False, True):
+        close(port.gdn_fwd(x, be, ga, inv), orc.gdn_fwd(x, be, ga, inv), "gdn")
+    # whole STEM step through both back ends (small config, 4x4 latents)
+    ssd = {k: closed_form_tensor(k, s).numpy() for k, s in _stem_keys(64, 96).items()}
+    B, ls = 2, 4
+    y_cur, y_cond = closed_form_input("bp:y", (B, 96, ls, ls), -4, 4).numpy(), closed_form_input("bp:c", (B, 96, ls, ls), -4, 4).numpy()
+    noise = {"z": closed_form_input("bp:nz", (B, 64, 1, 1), -.5, .5).numpy(), "q": closed_form_input("bp:nq", (B, 96, ls, ls), -.5, .5).numpy(),
+             "lik": closed_form_input("bp:nl", (B, 96, ls, ls), -.5, .5).numpy()}
+
+    def step():
+        keep = {}
+        o = orc.stem_forward(ssd, y_cur, y_cond, residual=True, training=True, noise=noise, keep=keep)
+        return o, orc.stem_backward(ssd, keep, o["lik_y"], o["lik_z"], B * 64 * 64)
+
+    o_ref, g_ref = step()
+    conv_before = orc.conv2d_fwd
+    with port.installed():
+        assert orc.conv2d_fwd is port.conv2d_fwd
+        o_blas, g_blas = step()
+    assert orc.conv2d_fwd is conv_before                      # the swap is undone
+    close(o_blas["lik_y"], o_ref["lik_y"], "lik_y")
+    close(o_blas["lik_z"], o_ref["lik_z"], "lik_z")
+    for k in g_ref:
+        close(g_blas[k], g_ref[k], "grad " + k)
