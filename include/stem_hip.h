@@ -227,6 +227,10 @@ int stem_round(const float *a, float *out, size_t n, void *stream);
 /* counter-based uniform noise in [-0.5, 0.5) (Philox4x32-10), replaces Tensor.uniform_ at
  * entropy_models.py:119; (seed, offset) make the stream reproducible and rank-dependent.          */
 int stem_uniform_noise(float *out, size_t n, uint64_t seed, uint64_t offset, void *stream);
+/* same stream, advanced by a DEVICE-resident draw count: counter = offset + epoch_dev[0] * epoch_stride + i.  For launches
+ * captured in a hipGraph (arguments are frozen at capture; the epoch is bumped by stem_counter_add inside the graph). */
+int stem_uniform_noise_epoch(float *out, size_t n, uint64_t seed, uint64_t offset, const long long *epoch_dev,
+                             uint64_t epoch_stride, void *stream);
 /* GaussianConditional.build_indexes + quantize("symbols") (entropy_models.py:598-604,137-150)     */
 int stem_build_indexes(const float *scales, int lds, const float *table, int T, int32_t *idx, size_t npix, int C,
                        float scale_bound, void *stream);
@@ -303,6 +307,15 @@ int stem_axpy(float *y, const float *x, float a, size_t n, void *stream);
  * scale = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) (max_norm <= 0: no clipping), g *= scale * gscale. */
 int stem_adam_step(float *p, const float *g, float *m, float *v, size_t n, const double *sumsq, float max_norm,
                    float gscale, float lr, float beta1, float beta2, float eps, int step, void *stream);
+/* The same update with the step count and learning rate in DEVICE memory, for optimiser steps captured in a hipGraph
+ * (kernel arguments are frozen at capture): step_dev[0] is incremented first, then the update uses
+ * lr_dev[0] / (1 - beta1^t) and 1 / sqrt(1 - beta2^t); scal_dev = 2 floats of scratch.  A learning-rate scheduler
+ * (ReduceLROnPlateau, stem/trainSTEM.py:123,283) acts by rewriting lr_dev between replays. */
+int stem_adam_step_dev(float *p, const float *g, float *m, float *v, size_t n, const double *sumsq, float max_norm,
+                       float gscale, const float *lr_dev, float beta1, float beta2, float eps, long long *step_dev,
+                       float *scal_dev, void *stream);
+/* ctr[0] += inc on the device (epoch counters of captured graphs) */
+int stem_counter_add(long long *ctr, long long inc, void *stream);
 
 #ifdef __cplusplus
 }

@@ -67,6 +67,8 @@ _HIP_SIG = {
     "stem_add": [vp, vp, vp, sz, vp],
     "stem_round": [vp, vp, sz, vp],
     "stem_uniform_noise": [vp, sz, u64, u64, vp],
+    "stem_uniform_noise_epoch": [vp, sz, u64, u64, vp, u64, vp],
+    "stem_counter_add": [vp, C.c_longlong, vp],
     "stem_build_indexes": [vp, ci, vp, ci, vp, sz, ci, cf, vp],
     "stem_gemv3": [vp, ci, vp, vp, ci, ci, vp, ci, ci, vp, ci, ci, vp, ci, ci, cf, vp],
     "stem_pack_ctx_gemv": [vp, vp, ci, ci, vp],
@@ -84,6 +86,7 @@ _HIP_SIG = {
     "stem_clip_scale": [vp, sz, vp, cf, vp],
     "stem_axpy": [vp, vp, cf, sz, vp],
     "stem_adam_step": [vp, vp, vp, vp, sz, vp, cf, cf, cf, cf, cf, cf, ci, vp],
+    "stem_adam_step_dev": [vp, vp, vp, vp, sz, vp, cf, cf, vp, cf, cf, cf, vp, vp, vp],
     "stem_packed_weight_elems": [ci, ci, ci, ci, ci],
     "stem_abi_version": [],
     "stem_last_error": [],

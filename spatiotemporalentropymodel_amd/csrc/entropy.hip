@@ -352,11 +352,13 @@ __device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_
     const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
-__global__ void noise_kernel(float *out, size_t n, uint64_t seed, uint64_t offset)
+// epoch != nullptr: the counter additionally advances by epoch[0] * epoch_stride, a device-resident draw count, so that a
+// captured hipGraph produces fresh noise on every replay (the host-side offset is frozen into the graph at capture).
+__global__ void noise_kernel(float *out, size_t n, uint64_t seed, uint64_t offset, const long long *epoch, uint64_t epoch_stride)
 {
     const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q * 4 >= n) return;
-    const uint64_t ctr = offset + q;
+    const uint64_t ctr = offset + q + (epoch ? (uint64_t)epoch[0] * epoch_stride : 0);
     uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -520,8 +522,20 @@ STEM_EXPORT int stem_uniform_noise(float *out, size_t n, uint64_t seed, uint64_t
 {
     STEM_CHECK_ARG(out, "stem_uniform_noise: null pointer");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(noise_kernel, dim3(nblk(cdivz(n, 4))), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset);
+    hipLaunchKernelGGL(noise_kernel, dim3(nblk(cdivz(n, 4))), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset,
+                       (const long long *)nullptr, (uint64_t)0);
     STEM_LAUNCH_CHECK("noise");
+    return 0;
+}
+
+STEM_EXPORT int stem_uniform_noise_epoch(float *out, size_t n, uint64_t seed, uint64_t offset, const long long *epoch_dev,
+                                         uint64_t epoch_stride, void *stream)
+{
+    STEM_CHECK_ARG(out && epoch_dev, "stem_uniform_noise_epoch: null pointer");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(noise_kernel, dim3(nblk(cdivz(n, 4))), dim3(256), 0, (hipStream_t)stream, out, n, seed, offset, epoch_dev,
+                       epoch_stride);
+    STEM_LAUNCH_CHECK("noise_epoch");
     return 0;
 }
 

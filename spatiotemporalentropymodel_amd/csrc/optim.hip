@@ -43,10 +43,16 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const double *part, in
 
 // torch.optim.Adam single-tensor update (no amsgrad, no weight decay):
 //   m.lerp_(g, 1-b1); v = v*b2 + (1-b2) g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// dev_scal != nullptr: step_size / inv_sqrt_bc2 come from device memory (written by adam_prepare_kernel), so that a
+// captured hipGraph replays with the CURRENT step count and learning rate instead of the ones baked in at capture.
 __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, float *m, float *v, size_t n, const double *sumsq,
                                                    float max_norm, float gscale, float step_size, float b1, float b2,
-                                                   float inv_sqrt_bc2, float eps)
+                                                   float inv_sqrt_bc2, float eps, const float *dev_scal)
 {
+    if (dev_scal) {
+        step_size = dev_scal[0];
+        inv_sqrt_bc2 = dev_scal[1];
+    }
     float coef = gscale;
     if (max_norm > 0.f && sumsq) {
         const float total = (float)sqrt(sumsq[0]) * gscale;
@@ -61,6 +67,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, flo
         p[i] -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
     }
 }
+
+// One thread: ++step (device-resident), then the two scalars of this step's update exactly as stem_adam_step derives them
+// on the host: step_size = lr / (1 - b1^t), inv_sqrt_bc2 = 1 / sqrt(1 - b2^t), in double.
+__global__ void adam_prepare_kernel(long long *step, const float *lr, float b1, float b2, float *scal)
+{
+    const long long t = step[0] + 1;
+    step[0] = t;
+    const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+    scal[0] = (float)((double)lr[0] / bc1);
+    scal[1] = (float)(1.0 / sqrt(bc2));
+}
+
+__global__ void counter_add_kernel(long long *ctr, long long inc) { ctr[0] += inc; }
 
 // torch.nn.utils.clip_grad_norm_ on its own: g *= min(1, max_norm / (sqrt(sumsq) + 1e-6)), coefficient computed on the device
 __global__ __launch_bounds__(256) void clip_scale_kernel(float *g, size_t n, const double *sumsq, float max_norm)
@@ -102,8 +121,31 @@ STEM_EXPORT int stem_adam_step(float *p, const float *g, float *m, float *v, siz
     size_t nb = cdivz(n, 256);
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm,
-                       gscale, (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps);
+                       gscale, (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, (const float *)nullptr);
     STEM_LAUNCH_CHECK("adam");
+    return 0;
+}
+
+STEM_EXPORT int stem_adam_step_dev(float *p, const float *g, float *m, float *v, size_t n, const double *sumsq, float max_norm,
+                                   float gscale, const float *lr_dev, float beta1, float beta2, float eps, long long *step_dev,
+                                   float *scal_dev, void *stream)
+{
+    STEM_CHECK_ARG(p && g && m && v && lr_dev && step_dev && scal_dev, "stem_adam_step_dev: null pointer");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, lr_dev, beta1, beta2, scal_dev);
+    size_t nb = cdivz(n, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm,
+                       gscale, 0.f, beta1, beta2, 0.f, eps, (const float *)scal_dev);
+    STEM_LAUNCH_CHECK("adam_dev");
+    return 0;
+}
+
+STEM_EXPORT int stem_counter_add(long long *ctr, long long inc, void *stream)
+{
+    STEM_CHECK_ARG(ctr, "stem_counter_add: null pointer");
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ctr, inc);
+    STEM_LAUNCH_CHECK("counter_add");
     return 0;
 }
 

@@ -255,6 +255,7 @@ class EntropyModel(nn.Module):
         self.noise_seed = 0x5713
         self._noise_offset = 0
         self.noise_source = None
+        self.noise_epoch = None       # 1-element int64 device tensor: device-side draw count (captured hipGraphs)
         self._tables = None
 
     offset = property(lambda self: self._offset)
@@ -269,7 +270,7 @@ class EntropyModel(nn.Module):
         if self.noise_source is not None:
             n = self.noise_source(tuple(x_nhwc.shape), x_nhwc.device)
             return _dense(n.to(x_nhwc.device))
-        out = F.uniform_noise_like(x_nhwc, self.noise_seed, self._noise_offset)
+        out = F.uniform_noise_like(x_nhwc, self.noise_seed, self._noise_offset, epoch=self.noise_epoch)
         self._noise_offset += (x_nhwc.numel() + 3) // 4
         return out
 

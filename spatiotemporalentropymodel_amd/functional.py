@@ -560,10 +560,27 @@ def round_(a):
     return out
 
 
-def uniform_noise_like(a, seed: int, offset: int):
+NOISE_EPOCH_STRIDE = 1 << 40          # counter distance between two epochs of a device-counted noise stream
+
+
+def uniform_noise_like(a, seed: int, offset: int, epoch=None):
+    """U(-1/2, 1/2) from the Philox stream (seed, offset).  `epoch` (0-dim int64 device tensor) adds epoch * 2^40 to the
+    counter on the device: inside a captured hipGraph the host-side `offset` is frozen, the epoch is what advances."""
     out = _dense_like(a)
-    _chk(_lib.hip().stem_uniform_noise(out.data_ptr(), out.numel(), seed & (2 ** 64 - 1), offset & (2 ** 64 - 1), _stream()))
+    if epoch is None:
+        _chk(_lib.hip().stem_uniform_noise(out.data_ptr(), out.numel(), seed & (2 ** 64 - 1), offset & (2 ** 64 - 1), _stream()))
+    else:
+        assert epoch.dtype == torch.int64 and epoch.is_cuda
+        _chk(_lib.hip().stem_uniform_noise_epoch(out.data_ptr(), out.numel(), seed & (2 ** 64 - 1), offset & (2 ** 64 - 1),
+                                                 epoch.data_ptr(), NOISE_EPOCH_STRIDE, _stream()))
     return out
+
+
+def counter_add_(ctr, inc=1):
+    """ctr (0-dim / 1-element int64 device tensor) += inc, as a kernel on the current stream (graph-capturable)"""
+    assert ctr.dtype == torch.int64 and ctr.is_cuda
+    _chk(_lib.hip().stem_counter_add(ctr.data_ptr(), int(inc), _stream()))
+    return ctr
 
 
 def build_indexes(scales, table, scale_bound=0.11):
@@ -598,3 +615,10 @@ def axpy_(y, x, a):
 def adam_step(p, g, m, v, sumsq_acc, max_norm, gscale, lr, beta1, beta2, eps, step):
     _chk(_lib.hip().stem_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), _ptr(sumsq_acc),
                                    max_norm, gscale, lr, beta1, beta2, eps, step, _stream()))
+
+
+def adam_step_dev(p, g, m, v, sumsq_acc, max_norm, gscale, lr_dev, beta1, beta2, eps, step_dev, scal_dev):
+    """adam_step with the step count (int64, incremented here) and learning rate (fp32) in device memory"""
+    _chk(_lib.hip().stem_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), _ptr(sumsq_acc),
+                                       max_norm, gscale, lr_dev.data_ptr(), beta1, beta2, eps, step_dev.data_ptr(),
+                                       scal_dev.data_ptr(), _stream()))

@@ -62,6 +62,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.v = torch.zeros_like(flat.data)
         self.t = 0
         self._sumsq = F.sumsq_accumulator(flat.data.device)          # [0] = sum of squares, rest = reduction scratch
+        self._dev = None             # device-resident (step, lr, scratch) once enable_device_state() was called
 
     # the scalar hyper-parameters live in param_groups[0] (schedulers and checkpoints edit them there)
     lr = property(lambda self: self.param_groups[0]["lr"])
@@ -78,6 +79,30 @@ class FusedClipAdam(torch.optim.Optimizer):
         F.sumsq(self.flat.grad, self._sumsq)
         return self._sumsq[0].sqrt().reshape(())
 
+    def enable_device_state(self):
+        """Keep the step count and the learning rate in device memory (stem_adam_step_dev), which is what makes `step()`
+        capturable in a hipGraph: kernel arguments are frozen at capture, device memory is not.  `self.t` and
+        `param_groups[0]["lr"]` stay the source of truth on the host: they are mirrored to the device by step() /
+        sync_device_state() (a replayed graph advances the device counter itself; graphs.GraphedPFrameStep advances
+        `self.t` alongside)."""
+        if self._dev is None:
+            dev = self.flat.data.device
+            self._dev = {"step": torch.zeros(1, dtype=torch.int64, device=dev), "lr": torch.zeros(1, dtype=torch.float32, device=dev),
+                         "scal": torch.zeros(2, dtype=torch.float32, device=dev), "lr_host": None}
+        self.sync_device_state()
+        return self
+
+    def sync_device_state(self):
+        """host -> device: step count always, learning rate when a scheduler / checkpoint changed it"""
+        d = self._dev
+        if d is None:
+            return
+        d["step"].fill_(self.t)
+        lr = float(self.param_groups[0]["lr"])
+        if d["lr_host"] != lr:
+            d["lr"].fill_(lr)
+            d["lr_host"] = lr
+
     def step(self, closure=None, *, grad_scale: float = 1.0, norm_is_current: bool = False):
         """grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).  norm_is_current: the caller
         has just called grad_norm() on these very gradients (as the training loop does to report the norm), so the
@@ -93,9 +118,19 @@ class FusedClipAdam(torch.optim.Optimizer):
         if use_clip and not norm_is_current:
             self._sumsq[:1].zero_()
             F.sumsq(self.flat.grad, self._sumsq)
-        F.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self._sumsq if use_clip else None,
-                    float(self.max_norm) if use_clip else 0.0, float(grad_scale), float(g["lr"]), g["betas"][0], g["betas"][1],
-                    float(g["eps"]), self.t)
+        if self._dev is not None:
+            d = self._dev
+            if not torch.cuda.is_current_stream_capturing():
+                if d["lr_host"] != float(g["lr"]):
+                    d["lr"].fill_(float(g["lr"]))
+                    d["lr_host"] = float(g["lr"])
+            F.adam_step_dev(self.flat.data, self.flat.grad, self.m, self.v, self._sumsq if use_clip else None,
+                            float(self.max_norm) if use_clip else 0.0, float(grad_scale), d["lr"], g["betas"][0], g["betas"][1],
+                            float(g["eps"]), d["step"], d["scal"])
+        else:
+            F.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self._sumsq if use_clip else None,
+                        float(self.max_norm) if use_clip else 0.0, float(grad_scale), float(g["lr"]), g["betas"][0], g["betas"][1],
+                        float(g["eps"]), self.t)
         bump_weight_epoch(self.flat.params)
         return loss
 
@@ -136,6 +171,7 @@ class FusedClipAdam(torch.optim.Optimizer):
             raise ValueError(f"FusedClipAdam: parameters carry different step counts {sorted(steps)}; the fused step keeps one")
         self.t = steps.pop() if steps else 0
         self._sync_state()
+        self.sync_device_state()
 
 
 def clip_grad_norm_(optimizers, max_norm, tensors=None):

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""GPU timeline summary from a rocprofv3 --kernel-trace CSV: busy union vs span (how much of the wall time at least one
+kernel was running), idle gaps, per-queue busy time, and the kernels by total time inside the steady-state window.
+Usage: timeline.py kernel_trace.csv [skip_fraction=0.4]   (the first `skip_fraction` of the kernels = warm-up)."""
+import csv
+import sys
+from collections import defaultdict
+
+rows = []
+with open(sys.argv[1]) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
+rows.sort()
+skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.4
+rows = rows[int(len(rows) * skip):]
+t0, t1 = rows[0][0], max(r[1] for r in rows)
+span = (t1 - t0) / 1e6
+busy, cur_s, cur_e, gaps = 0, rows[0][0], rows[0][1], []
+for s, e, *_ in rows[1:]:
+    if s > cur_e:
+        busy += cur_e - cur_s
+        gaps.append(s - cur_e)
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+busy += cur_e - cur_s
+print(f"kernels {len(rows)}  span {span:.2f} ms  busy(union) {busy / 1e6:.2f} ms = {busy / 1e6 / span:.1%}  kernel-sum {sum(e - s for s, e, *_ in rows) / 1e6:.2f} ms")
+g = sorted(gaps)
+if g:
+    tot = sum(g) / 1e6
+    print(f"idle gaps: {len(g)} totalling {tot:.2f} ms; >5us: {sum(1 for x in g if x > 5000)} ({sum(x for x in g if x > 5000) / 1e6:.2f} ms); "
+          f">20us: {sum(1 for x in g if x > 20000)} ({sum(x for x in g if x > 20000) / 1e6:.2f} ms); median {g[len(g) // 2] / 1e3:.1f} us")
+perq = defaultdict(float)
+for s, e, n, q, st in rows:
+    perq[(q, st)] += (e - s) / 1e6
+print("per queue/stream busy ms:", {k: round(v, 2) for k, v in perq.items()})
+agg = defaultdict(lambda: [0, 0.0])
+for s, e, n, q, st in rows:
+    name = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    name = name.split("(")[0][:70]
+    agg[name][0] += 1
+    agg[name][1] += (e - s) / 1e6
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+    print(f"{v[1]:8.2f} ms {v[1] / span:6.1%} {v[0]:6d} x {v[1] / v[0] * 1e3:8.1f} us  {k}")
+
+# gap contexts: which kernel boundary the big idle gaps sit at
+ctx = defaultdict(lambda: [0, 0.0])
+cur_e, last = rows[0][1], rows[0]
+for r in rows[1:]:
+    s, e = r[0], r[1]
+    if s > cur_e and s - cur_e > 5000:
+        a = last[2].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:38]
+        b = r[2].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:38]
+        ctx[(a, b)][0] += 1
+        ctx[(a, b)][1] += (s - cur_e) / 1e3
+    if e > cur_e:
+        cur_e, last = e, r
+print("largest idle-gap contexts (after -> before), count, total us:")
+for k, v in sorted(ctx.items(), key=lambda kv: -kv[1][1])[:24]:
+    print(f"  {v[1]:8.0f} us {v[0]:4d} x {v[1] / v[0]:6.1f}  {k[0]}  ->  {k[1]}")
