@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--generic", action="store_true", help="run the P-frame step through nn.Module / autograd / torch-style optimiser "
+                    "calls (selfcheck.p_frame_step) instead of the explicit fused schedule (trainer.FusedPFrameStep)")
     ap.add_argument("--graph", action="store_true", help="replay the P-frame step from its hipGraph (graphs.GraphedPFrameStep) instead of "
                     "issuing it kernel by kernel: 2 ms instead of 11-22 ms of host time per step, same GPU time (DESIGN.md §7)")
     args = ap.parse_args()
@@ -232,25 +234,33 @@ def main():
     # step (graphs.GraphedPFrameStep); getY stays eager so that the HIP-event probe can bracket its dominant kernel.  Data
     # parallel runs are always eager: the RCCL exchanges are issued from inside backward.
     use_graph = world == 1 and args.graph
+    fused_step = None
+    if not args.generic and not use_graph:
+        from spatiotemporalentropymodel_amd.trainer import FusedPFrameStep
+        fused_step = FusedPFrameStep(stem, opt, aux_opt)
     graphed = None
     if use_graph:
         from spatiotemporalentropymodel_amd.graphs import GraphedPFrameStep
         graphed = GraphedPFrameStep(stem, crit, opt, aux_opt, (SIZE, SIZE))
 
     def one_step():
+        # The I-frame model is frozen (stem/trainSTEM.py:128, no_grad), so the latents of all 7 frames are computed first:
+        # 7 x 4 long kernels that the host enqueues in ~1 ms and the GPU needs ~12 ms for.  With that head start the host
+        # stays ahead of the GPU through the launch-heavy P-frame steps (measured: the GPU idled ~3.3 ms per step waiting
+        # for launches when getY was issued inside each P-step, tools/timeline.py).
         with torch.no_grad():
-            _, y_cond = imodel.getY(frames[0])
+            ys = [imodel.getY(f) for f in frames]
+        y_cond = ys[0][1]
         last = None
         for t in range(1, FRAMES):
             if graphed is not None:
-                with torch.no_grad():
-                    y_cur, _ = imodel.getY(frames[t])
-                out, oc, aux, gn = graphed.step(y_cur, y_cond)
-                y_cond = out["y_hat"]            # static output buffer: copied into the graph's y_cond input by the next step()
+                out, oc, aux, gn = graphed.step(ys[t][0], y_cond)
+            elif fused_step is not None:
+                out, oc, aux, gn = fused_step.step(ys[t][0], y_cond, BATCH * SIZE * SIZE, grad_scale=1.0 / world, reducer=reducer)
             else:
                 out, oc, aux, gn = p_frame_step(imodel, stem, crit, opt, aux_opt, frames[t], y_cond,
-                                                grad_scale=1.0 / world, reducer=reducer)
-                y_cond = out["y_hat"]
+                                                grad_scale=1.0 / world, reducer=reducer, y_cur=ys[t][0])
+            y_cond = out["y_hat"]                # graph mode: static output buffer, copied into the y_cond input by the next step()
             last = oc
         return last
 
@@ -284,7 +294,8 @@ def main():
                                "16 septuplets x 7 frames x 256x256 per GPU, EMLoss, clip 1.0 + Adam 1e-4 / aux Adam 1e-3",
                    "per_gpu_batch": BATCH, "global_batch": BATCH * world, "frames_per_step": FRAMES * BATCH * world,
                    "p_frame_steps_per_step": FRAMES - 1, "parallelism": f"dp{world}", "final_loss_bpp": loss,
-                   "launch": "hipGraph replay per P-frame step" if use_graph else "eager (kernel by kernel)"},
+                   "launch": "hipGraph replay per P-frame step" if use_graph else
+                             ("explicit fused schedule (trainer.FusedPFrameStep)" if fused_step is not None else "generic nn.Module / autograd route")},
         "roofline": {"bound": "mfma", "kernel": "igemm_kernel<128,192,32,96,FUSE> = g_a.2 conv (192->192, 5x5 s2, 128^2->64^2, B=16) + fused GDN g_a.3",
                      "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                      "flop_per_launch": flop, "avg_launch_ms": kern_ms, "launches_timed": len(probe), "traffic": traffic,

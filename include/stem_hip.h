@@ -76,10 +76,15 @@ enum { STEM_ACT_NONE = 0, STEM_ACT_LRELU = 1 };
 #define STEM_CONV_MASKED_A 0x100
 
 /* Split-K workspace.  Layers whose output is too small to fill 256 CUs (the 16x16 / 8x8 / 4x4 STEM latents)
- * split their reduction over taps x channels across workgroups; the fp32 partial tiles go to `ws` and a second
- * kernel sums them in a fixed order and applies bias / activation (bit-reproducible, no float atomics).
+ * split their reduction over taps x channels across workgroups; the fp32 partial tiles go to `ws` and the LAST
+ * workgroup to arrive at an output tile (integer arrival counter at the head of `ws`) sums them in split order and
+ * applies bias / activation inside the same kernel: bit-reproducible (the order does not depend on who arrives
+ * last, no float atomics), no second launch.
  * kind: 0 conv fwd, 1 conv dgrad, 2 deconv fwd, 3 deconv dgrad; dims are the LAYER's (B,H,W,C in / K out).
- * Passing ws = NULL (or too few bytes) is legal and runs the unsplit schedule.                              */
+ * Passing ws = NULL (or too few bytes) is legal and runs the unsplit schedule.
+ * CONTRACT (ABI version 2): the first 64 KiB of `ws` must be ZERO when the buffer is first handed to the library;
+ * every launch leaves them zero again, so one buffer serves all layers launched on one stream.  Two launches that
+ * may overlap in time (different streams) need different buffers.                                                 */
 enum { STEM_KIND_CONV_FWD = 0, STEM_KIND_CONV_DGRAD = 1, STEM_KIND_DECONV_FWD = 2, STEM_KIND_DECONV_DGRAD = 3 };
 size_t stem_conv_workspace_bytes(int kind, int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int opad);
 
@@ -231,6 +236,37 @@ int stem_uniform_noise(float *out, size_t n, uint64_t seed, uint64_t offset, voi
  * captured in a hipGraph (arguments are frozen at capture; the epoch is bumped by stem_counter_add inside the graph). */
 int stem_uniform_noise_epoch(float *out, size_t n, uint64_t seed, uint64_t offset, const long long *epoch_dev,
                              uint64_t epoch_stride, void *stream);
+/* ---- fused training glue (one P-frame optimisation step, stem/trainSTEM.py:203-218) --------------------------------
+ * The elementwise work between the convolutions, regrouped so that a step issues 4 small kernels instead of ~30.
+ * Noise: `noise` != NULL supplies U(-1/2,1/2) explicitly (dense [npix][C]); otherwise it is drawn from the Philox stream
+ * of stem_uniform_noise at (seed, offset [+ epoch_dev[0] * epoch_stride]) -- the same numbers stem_uniform_noise(out,
+ * npix*C, seed, offset) would produce.
+ * stem_prior_prologue (spatiotemporalpriors.py:846-856,863): he_in[:, :C] = y_cur, he_in[:, C:2C] = y_cond (pitch ldh);
+ *   target = y_cur - y_cond (residual) or y_cur; t_hat (may be NULL) = target + noise (training) / round(target);
+ *   y_hat (may be NULL) = t_hat + y_cond (residual) / t_hat.  target, t_hat, y_hat are dense.
+ * stem_eb_forward_train / stem_gc_forward_train: training-mode forward of the entropy models (entropy_models.py:424-452,
+ *   588-596) that also emits dlik = coef / lik (EMLoss is a sum of logs, utils.py:18-27: coef = -1 / (ln 2 * N*H*W)) and
+ *   per-workgroup partial sums of log2(lik) (double, `partials` holds stem_rate_partials(npix*C) entries).
+ * stem_em_loss_finalize: out3 = {y_bpp, z_bpp, loss} = scale * fixed-order sums of the partials (scale = -1/(N*H*W)).
+ * stem_eb_aux_loss_grad: EntropyBottleneck.loss (entropy_models.py:383-386) and its gradient w.r.t. the quantiles in
+ *   one workgroup: loss[0] is written (not accumulated), dquantiles written or added (accumulate != 0).             */
+int stem_prior_prologue(const float *y_cur, int ldc, const float *y_cond, int ldd, float *he_in, int ldh, float *target,
+                        float *t_hat, float *y_hat, const float *noise, uint64_t seed, uint64_t offset,
+                        const long long *epoch_dev, uint64_t epoch_stride, size_t npix, int C, int residual, int training,
+                        void *stream);
+int stem_rate_partials(size_t n);
+int stem_eb_forward_train(const float *z, int ldz, const float *pack, const float *noise, uint64_t seed, uint64_t offset,
+                          const long long *epoch_dev, uint64_t epoch_stride, float *z_hat, float *lik, float *dlik,
+                          double *partials, size_t npix, int C, float bound, float coef, void *stream);
+int stem_gc_forward_train(const float *y, const float *scales, const float *means, int ldsm, const float *noise,
+                          uint64_t seed, uint64_t offset, const long long *epoch_dev, uint64_t epoch_stride, float *out,
+                          float *lik, float *dlik, double *partials, size_t npix, int C, float scale_bound, float lik_bound,
+                          float coef, void *stream);
+int stem_em_loss_finalize(const double *partials_y, int ny, const double *partials_z, int nz, double scale, double *out3,
+                          void *stream);
+int stem_eb_aux_loss_grad(const float *quantiles, const float *pack, const float *target3, float *loss, float *dquantiles,
+                          int C, int accumulate, void *stream);
+
 /* GaussianConditional.build_indexes + quantize("symbols") (entropy_models.py:598-604,137-150)     */
 int stem_build_indexes(const float *scales, int lds, const float *table, int T, int32_t *idx, size_t npix, int C,
                        float scale_bound, void *stream);
@@ -298,6 +334,8 @@ int stem_ar_finish_encode_wave(const float *gp, const float *table, int T, float
  * `acc` must hold 1 + STEM_SUMSQ_SCRATCH doubles, acc[1..] is scratch for the per-workgroup partial sums. */
 #define STEM_SUMSQ_SCRATCH 2048
 int stem_sumsq(const float *g, size_t n, double *acc, void *stream);
+/* same reduction, acc[0] = sum (no pre-zeroed accumulator needed) */
+int stem_sumsq_set(const float *g, size_t n, double *acc, void *stream);
 /* stand-alone torch.nn.utils.clip_grad_norm_ (stem_roi/train_stem_roi.py:536,563 clips once per frame while gradients
  * accumulate over the GOP): g *= min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)); sumsq may span several buffers. */
 int stem_clip_scale(float *g, size_t n, const double *sumsq, float max_norm, void *stream);

@@ -69,6 +69,12 @@ _HIP_SIG = {
     "stem_uniform_noise": [vp, sz, u64, u64, vp],
     "stem_uniform_noise_epoch": [vp, sz, u64, u64, vp, u64, vp],
     "stem_counter_add": [vp, C.c_longlong, vp],
+    "stem_prior_prologue": [vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, u64, u64, vp, u64, sz, ci, ci, ci, vp],
+    "stem_rate_partials": [sz],
+    "stem_eb_forward_train": [vp, ci, vp, vp, u64, u64, vp, u64, vp, vp, vp, vp, sz, ci, cf, cf, vp],
+    "stem_gc_forward_train": [vp, vp, vp, ci, vp, u64, u64, vp, u64, vp, vp, vp, vp, sz, ci, cf, cf, cf, vp],
+    "stem_em_loss_finalize": [vp, ci, vp, ci, C.c_double, vp, vp],
+    "stem_eb_aux_loss_grad": [vp, vp, vp, vp, vp, ci, ci, vp],
     "stem_build_indexes": [vp, ci, vp, ci, vp, sz, ci, cf, vp],
     "stem_gemv3": [vp, ci, vp, vp, ci, ci, vp, ci, ci, vp, ci, ci, vp, ci, ci, cf, vp],
     "stem_pack_ctx_gemv": [vp, vp, ci, ci, vp],
@@ -83,6 +89,7 @@ _HIP_SIG = {
     "stem_ar_encode_image": [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf,
                              vp, vp, vp],
     "stem_sumsq": [vp, sz, vp, vp],
+    "stem_sumsq_set": [vp, sz, vp, vp],
     "stem_clip_scale": [vp, sz, vp, cf, vp],
     "stem_axpy": [vp, vp, cf, sz, vp],
     "stem_adam_step": [vp, vp, vp, vp, sz, vp, cf, cf, cf, cf, cf, cf, ci, vp],

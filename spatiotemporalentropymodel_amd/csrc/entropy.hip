@@ -548,3 +548,275 @@ STEM_EXPORT int stem_build_indexes(const float *scales, int lds, const float *ta
     STEM_LAUNCH_CHECK("build_indexes");
     return 0;
 }
+
+// =================================================================================================================
+// Fused training glue.  Between the convolutions, one P-frame optimisation step (stem/trainSTEM.py:203-218) issues ~50
+// elementwise / reduction kernels of a few microseconds each (concat copies, residual, three noise draws, quantisation,
+// likelihoods, log-sums, their autograd mirror images, norm / Adam bookkeeping).  On MI355X each dependent dispatch costs
+// ~10 us of queue latency on top of its run time (tools/timeline.py: 4.8 ms of a 32 ms bench step), so the same
+// arithmetic is regrouped into four kernels: prologue, bottleneck (+rate, +d rate), Gaussian (+rate, +d rate), finalise.
+// EMLoss is a sum of logs (utils.py:18-27), so d loss / d likelihood = coef / likelihood is known in the forward pass.
+namespace {
+
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t ctr, float r[4])
+{
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0, c3 = 0;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+        philox_round(c0, c1, c2, c3, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const uint32_t v[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = (float)(v[e] >> 8) * (1.0f / 16777216.0f) - 0.5f;      // == noise_kernel
+}
+
+struct NoiseSrc {            // either an explicit tensor (parity tests) or the Philox stream (seed, offset [+ epoch * stride])
+    const float *ptr;
+    uint64_t seed, offset, stride;
+    const long long *epoch;
+};
+__device__ __forceinline__ uint64_t noise_base(const NoiseSrc &s) { return s.offset + (s.epoch ? (uint64_t)s.epoch[0] * s.stride : 0); }
+
+// he_in = [y_cur | y_cond]; target = y_cur - y_cond (residual) or y_cur; t_hat = target + U(-1/2,1/2) (training) or
+// round(target); y_hat = t_hat + y_cond (residual) or t_hat.     spatiotemporalpriors.py:846-856,863
+__global__ __launch_bounds__(256) void prior_prologue_kernel(const float *ycur, int ldc, const float *ycond, int ldd, float *he_in,
+                                                             int ldh, float *target, float *t_hat, float *y_hat, NoiseSrc nq,
+                                                             size_t npix, int C, int residual, int training)
+{
+    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int c4n = C >> 2;
+    if (i4 >= npix * c4n) return;
+    const size_t pix = i4 / c4n;
+    const int c = (int)(i4 - pix * c4n) * 4;
+    const f32x4 yc = *reinterpret_cast<const f32x4 *>(ycur + pix * ldc + c);
+    const f32x4 yd = *reinterpret_cast<const f32x4 *>(ycond + pix * ldd + c);
+    *reinterpret_cast<f32x4 *>(he_in + pix * ldh + c) = yc;
+    *reinterpret_cast<f32x4 *>(he_in + pix * ldh + C + c) = yd;
+    f32x4 tg = residual ? yc - yd : yc;
+    *reinterpret_cast<f32x4 *>(target + pix * C + c) = tg;
+    if (!t_hat) return;
+    f32x4 th;
+    if (training) {
+        float r[4];
+        if (nq.ptr) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = nq.ptr[pix * C + c + e];
+        } else {
+            philox4(nq.seed, noise_base(nq) + i4, r);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) th[e] = tg[e] + r[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) th[e] = rintf(tg[e]);
+    }
+    *reinterpret_cast<f32x4 *>(t_hat + pix * C + c) = th;
+    if (y_hat) *reinterpret_cast<f32x4 *>(y_hat + pix * C + c) = residual ? th + yd : th;
+}
+
+// block-level sum of log2(lik) in double -> part[blockIdx.x] (fixed order: deterministic, no atomics)
+__device__ __forceinline__ void block_log2_partial(double s, double *part)
+{
+    __shared__ double red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+// EntropyBottleneck.forward in training mode (+noise) with its rate term and d rate / d likelihood
+__global__ __launch_bounds__(256) void eb_forward_train_kernel(const float *z, int ldz, NoiseSrc nz, const float *pack, float *zhat,
+                                                               float *lik, float *dlik, double *part, size_t npix, int C,
+                                                               float bound, float coef)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    double lg = 0.0;
+    if (i < npix * C) {
+        const size_t pix = i / C;
+        const int c = (int)(i - pix * C);
+        EbPrep e;
+        eb_prepare(pack + (size_t)c * NP, e);
+        float v = z[pix * ldz + c];
+        if (nz.ptr) {
+            v += nz.ptr[i];
+        } else {
+            float r[4];
+            philox4(nz.seed, noise_base(nz) + (i >> 2), r);
+            v += r[i & 3];
+        }
+        zhat[i] = v;
+        const float lo = eb_logits<false>(e, v - 0.5f, nullptr, nullptr);
+        const float up = eb_logits<false>(e, v + 0.5f, nullptr, nullptr);
+        const float s = lo + up;
+        const float sg = s > 0.f ? -1.f : (s < 0.f ? 1.f : 0.f);
+        const float l = fmaxf(fabsf(sigmoid_f(sg * up) - sigmoid_f(sg * lo)), bound);
+        lik[i] = l;
+        dlik[i] = coef / l;
+        lg = (double)log2f(l);
+    }
+    block_log2_partial(lg, part);
+}
+
+// GaussianConditional.forward in training mode (+noise; means are ignored by the noise quantiser, entropy_models.py:128-135)
+__global__ __launch_bounds__(256) void gc_forward_train_kernel(const float *y, NoiseSrc nl, const float *scales, const float *means,
+                                                               int ldsm, float *out, float *lik, float *dlik, double *part,
+                                                               size_t npix, int C, float sb, float lb, float coef)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    double lg = 0.0;
+    if (i < npix * C) {
+        const size_t pix = i / C;
+        const int c = (int)(i - pix * C);
+        const float mu = means[pix * ldsm + c], sc = scales[pix * ldsm + c];
+        float o = y[i];
+        if (nl.ptr) {
+            o += nl.ptr[i];
+        } else {
+            float r[4];
+            philox4(nl.seed, noise_base(nl) + (i >> 2), r);
+            o += r[i & 3];
+        }
+        out[i] = o;
+        const float v = fabsf(o - mu);
+        const float s = fmaxf(sc, sb);
+        const float l = fmaxf(std_cum((0.5f - v) / s) - std_cum((-0.5f - v) / s), lb);
+        lik[i] = l;
+        dlik[i] = coef / l;
+        lg = (double)log2f(l);
+    }
+    block_log2_partial(lg, part);
+}
+
+// out[0] = y_bpp, out[1] = z_bpp, out[2] = loss   (EMLoss, utils.py:18-27): sums of the per-block partials in index order
+__global__ __launch_bounds__(256) void em_loss_finalize_kernel(const double *py, int ny, const double *pz, int nz, double scale, double *out)
+{
+    __shared__ double red[2][256];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < ny; i += 256) a += py[i];
+    for (int i = threadIdx.x; i < nz; i += 256) b += pz[i];
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + k];
+            red[1][threadIdx.x] += red[1][threadIdx.x + k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = red[0][0] * scale;
+        out[1] = red[1][0] * scale;
+        out[2] = out[0] + out[1];
+    }
+}
+
+// EntropyBottleneck.loss with its quantile gradient, one workgroup, no pre-zeroed accumulator: loss[0] = sum |logits - target|,
+// dq = d loss / d quantiles (written, or added when accumulate)
+__global__ __launch_bounds__(256) void eb_aux_block_kernel(const float *quant, const float *pack, const float *target, float *loss,
+                                                           float *dq, int C, int accumulate)
+{
+    __shared__ float red[256];
+    float local = 0.f;
+    for (int i = threadIdx.x; i < C * 3; i += 256) {
+        const int c = i / 3, k = i - c * 3;
+        EbPrep e;
+        eb_prepare(pack + (size_t)c * NP, e);
+        float pre[4][3], inp[4][3], dp[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) dp[q] = 0.f;
+        const float v = quant[i];
+        const float d = eb_logits<true>(e, v, pre, inp) - target[k];
+        local += fabsf(d);
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        const float g = eb_logits_bwd(pack + (size_t)c * NP, e, v, pre, inp, sgn, dp);
+        if (dq) dq[i] = accumulate ? dq[i] + g : g;
+    }
+    red[threadIdx.x] = local;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = red[0];
+}
+
+NoiseSrc make_noise(const float *ptr, uint64_t seed, uint64_t offset, const long long *epoch, uint64_t stride)
+{
+    NoiseSrc s;
+    s.ptr = ptr; s.seed = seed; s.offset = offset; s.epoch = epoch; s.stride = stride;
+    return s;
+}
+
+}   // namespace
+
+STEM_EXPORT int stem_prior_prologue(const float *y_cur, int ldc, const float *y_cond, int ldd, float *he_in, int ldh, float *target,
+                                    float *t_hat, float *y_hat, const float *noise, uint64_t seed, uint64_t offset,
+                                    const long long *epoch_dev, uint64_t epoch_stride, size_t npix, int C, int residual,
+                                    int training, void *stream)
+{
+    STEM_CHECK_ARG(y_cur && y_cond && he_in && target, "stem_prior_prologue: null pointer");
+    STEM_CHECK_ARG(C % 4 == 0 && ldc % 4 == 0 && ldd % 4 == 0 && ldh % 4 == 0 && ldh >= 2 * C,
+                   "stem_prior_prologue: channel counts / pitches must be multiples of 4 (C=%d ldc=%d ldd=%d ldh=%d)", C, ldc, ldd, ldh);
+    STEM_CHECK_ARG(((((uintptr_t)y_cur) | ((uintptr_t)y_cond) | ((uintptr_t)he_in) | ((uintptr_t)target) | ((uintptr_t)t_hat) |
+                     ((uintptr_t)y_hat)) & 15) == 0, "stem_prior_prologue: pointers must be 16-byte aligned");
+    if (npix == 0) return 0;
+    hipLaunchKernelGGL(prior_prologue_kernel, dim3(nblk(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, y_cur, ldc, y_cond, ldd,
+                       he_in, ldh, target, t_hat, y_hat, make_noise(noise, seed, offset, epoch_dev, epoch_stride), npix, C, residual,
+                       training);
+    STEM_LAUNCH_CHECK("prior_prologue");
+    return 0;
+}
+
+STEM_EXPORT int stem_rate_partials(size_t n) { return (int)nblk(n); }
+
+STEM_EXPORT int stem_eb_forward_train(const float *z, int ldz, const float *pack, const float *noise, uint64_t seed, uint64_t offset,
+                                      const long long *epoch_dev, uint64_t epoch_stride, float *z_hat, float *lik, float *dlik,
+                                      double *partials, size_t npix, int C, float bound, float coef, void *stream)
+{
+    STEM_CHECK_ARG(z && pack && z_hat && lik && dlik && partials, "stem_eb_forward_train: null pointer");
+    if (npix == 0) return 0;
+    hipLaunchKernelGGL(eb_forward_train_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, z, ldz,
+                       make_noise(noise, seed, offset, epoch_dev, epoch_stride), pack, z_hat, lik, dlik, partials, npix, C, bound, coef);
+    STEM_LAUNCH_CHECK("eb_forward_train");
+    return 0;
+}
+
+STEM_EXPORT int stem_gc_forward_train(const float *y, const float *scales, const float *means, int ldsm, const float *noise,
+                                      uint64_t seed, uint64_t offset, const long long *epoch_dev, uint64_t epoch_stride, float *out,
+                                      float *lik, float *dlik, double *partials, size_t npix, int C, float scale_bound,
+                                      float lik_bound, float coef, void *stream)
+{
+    STEM_CHECK_ARG(y && scales && means && out && lik && dlik && partials, "stem_gc_forward_train: null pointer");
+    if (npix == 0) return 0;
+    hipLaunchKernelGGL(gc_forward_train_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, y,
+                       make_noise(noise, seed, offset, epoch_dev, epoch_stride), scales, means, ldsm, out, lik, dlik, partials, npix, C,
+                       scale_bound, lik_bound, coef);
+    STEM_LAUNCH_CHECK("gc_forward_train");
+    return 0;
+}
+
+STEM_EXPORT int stem_em_loss_finalize(const double *partials_y, int ny, const double *partials_z, int nz, double scale, double *out3,
+                                      void *stream)
+{
+    STEM_CHECK_ARG(partials_y && partials_z && out3 && ny >= 0 && nz >= 0, "stem_em_loss_finalize: bad arguments");
+    hipLaunchKernelGGL(em_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials_y, ny, partials_z, nz, scale, out3);
+    STEM_LAUNCH_CHECK("em_loss_finalize");
+    return 0;
+}
+
+STEM_EXPORT int stem_eb_aux_loss_grad(const float *quantiles, const float *pack, const float *target3, float *loss, float *dquantiles,
+                                      int C, int accumulate, void *stream)
+{
+    STEM_CHECK_ARG(quantiles && pack && target3 && loss, "stem_eb_aux_loss_grad: null pointer");
+    hipLaunchKernelGGL(eb_aux_block_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, quantiles, pack, target3, loss, dquantiles, C,
+                       accumulate);
+    STEM_LAUNCH_CHECK("eb_aux_block");
+    return 0;
+}

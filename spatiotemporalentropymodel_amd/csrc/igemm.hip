@@ -45,9 +45,11 @@ struct IgemmArgs {
     int isy, isx, osy, osx;
     int nphase, epi, asquare, breparam;
     float slope, beta_bound;
-    // split-K: blockIdx.z = phase * nsplit + split; each split reduces chunks [split*cps, (split+1)*cps) and
-    // writes its raw fp32 partial tile to ws[split][out pixel][n]; splitk_reduce_kernel applies the epilogue.
+    // split-K: blockIdx.z = phase * nsplit + split; each split reduces chunks [split*cps, (split+1)*cps) and writes its raw
+    // fp32 partial tile to ws[split][out pixel][n]; the LAST workgroup to arrive at a tile (arrival counter) adds the
+    // partials in split order 0..nsplit-1 -- the result does not depend on who arrives last -- and applies the epilogue.
     float *ws;
+    int *cnt;                // one arrival counter per output tile (zero before and after every launch)
     int nsplit, cps;
     long slab;
     int xbytes, wbytes;      // extents of the x / w views for the range-checked buffer loads
@@ -367,7 +369,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
         }
     }
 
-    if (a.nsplit > 1) {   // raw partial sums; bias / activation happen in splitk_reduce_kernel
+    if (a.nsplit > 1) {   // raw partial sums to the workspace; the last arriver of this tile reduces them
         float *wsp = a.ws + (size_t)zsplit * a.slab;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -385,8 +387,83 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
                         const int qy = rem / ph.qw, qx = rem - qy * ph.qw;
                         opix = (size_t)(b * a.OH + qy * a.osy + ph.ooy) * a.OW + qx * a.osx + ph.oox;
                     }
-                    wsp[opix * a.N + n] = acc[i][j][r];
+                    // agent-scope (sc1) store: written through this XCD's L2 to the device-coherent level
+                    __hip_atomic_store(&wsp[opix * a.N + n], acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+        }
+        // Arrival protocol.  The splits of one tile run on different XCDs, whose L2s are not coherent with each other.  A
+        // device-scope fence (__threadfence) would write back / invalidate the WHOLE L2 per wave -- measured: +25 % on the
+        // bench step, it also evicts the concurrent weight-gradient kernel's working set.  Instead the partials themselves
+        // are moved with agent-scope accesses (sc1: write-through stores, L2-bypassing loads), every thread waits for its
+        // own stores to be acknowledged (vmcnt 0), the workgroup meets at a barrier and ONE thread takes a ticket.  The
+        // workgroup that draws the last ticket knows all nsplit partial tiles are complete; it re-zeroes the counter for
+        // the next launch.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int *flag = tapi;                     // LDS scratch, free after the main loop
+        if (tid == 0) {
+            int *c = a.cnt + ((size_t)zphase * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            const int ticket = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = ticket == a.nsplit - 1;
+            if (last) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag[0] = last;
+        }
+        __syncthreads();
+        if (!flag[0]) return;
+        // y[pix][n] = epi(bias[n] + sum_s ws[s][pix][n]): rows of the tile, 4 channels per thread, fixed split order.  The
+        // partials are fetched with sc1 (agent-scope) buffer loads, 4 splits in flight per thread.
+        constexpr int NQ = BN / 4;
+        constexpr int SC1 = 16;               // cache-policy bit 4 of the buffer instructions = sc1 on gfx94x/gfx950
+        const bool v4 = (a.N % 4 == 0) && (a.ldy % 4 == 0) && (a.epi != EPI_DACT || a.ldz % 4 == 0);
+        const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)(a.slab * a.nsplit * 4), 0x00020000);
+        for (int e = tid; e < BM * NQ; e += NT) {
+            const int row = e / NQ, n = bn0 + (e - row * NQ) * 4;
+            const int m = bm0 + row;
+            if (m >= Mtot || n >= a.N) continue;
+            size_t opix = m;
+            if (!a.ident) {
+                const int b = m / qhw, rem = m - b * qhw;
+                const int qy = rem / ph.qw, qx = rem - qy * ph.qw;
+                opix = (size_t)(b * a.OH + qy * a.osy + ph.ooy) * a.OW + qx * a.osx + ph.oox;
+            }
+            const int nn = a.N - n < 4 ? a.N - n : 4;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int q = 0; q < nn; ++q) v[q] = a.bias ? a.bias[n + q] : 0.f;
+            const int off0 = (int)((opix * a.N + n) * 4), sstep = (int)(a.slab * 4);
+            if (v4) {
+                int sp = 0;
+                for (; sp + 4 <= a.nsplit; sp += 4) {
+                    f32x4 t[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        t[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, off0 + (sp + u) * sstep, 0, SC1));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        v[0] += t[u][0]; v[1] += t[u][1]; v[2] += t[u][2]; v[3] += t[u][3];
+                    }
+                }
+                for (; sp < a.nsplit; ++sp) {
+                    const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, off0 + sp * sstep, 0, SC1));
+                    v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+                }
+            } else {
+                for (int sp = 0; sp < a.nsplit; ++sp)
+                    for (int q = 0; q < nn; ++q)
+                        v[q] += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rws, off0 + sp * sstep + q * 4, 0, SC1));
+            }
+            for (int q = 0; q < nn; ++q) {
+                if (a.epi == EPI_LRELU) {
+                    v[q] = v[q] > 0.f ? v[q] : v[q] * a.slope;
+                } else if (a.epi == EPI_DACT) {
+                    v[q] = a.z[opix * a.ldz + n + q] > 0.f ? v[q] : v[q] * a.slope;
+                }
+            }
+            if (v4) {
+                const f32x4 o = {v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4 *>(a.y + opix * a.ldy + n) = o;
+            } else {
+                for (int q = 0; q < nn; ++q) a.y[opix * a.ldy + n + q] = v[q];
+            }
         }
         return;
     }
@@ -530,42 +607,6 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
     }
 }
 
-// y[pix][n] = epi(bias[n] + sum_s ws[s][pix][n]); one thread per 4 channels when VEC4
-template <bool VEC4>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *ws, long slab, int nsplit, const float *bias,
-                                                            const float *z, int ldz, float *y, int ldy, size_t npix, int N,
-                                                            int epi, float slope)
-{
-    constexpr int V = VEC4 ? 4 : 1;
-    const int nv = N / V;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npix * nv) return;
-    const size_t pix = i / nv;
-    const int n = (int)(i - pix * nv) * V;
-    float v[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) v[e] = bias ? bias[n + e] : 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float *p = ws + (size_t)s * slab + pix * N + n;
-        if (VEC4) {
-            const f32x4 t = *reinterpret_cast<const f32x4 *>(p);
-#pragma unroll
-            for (int e = 0; e < V; ++e) v[e] += t[e];
-        } else {
-            v[0] += p[0];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < V; ++e) {
-        if (epi == EPI_LRELU) {
-            v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
-        } else if (epi == EPI_DACT) {
-            v[e] = z[pix * ldz + n + e] > 0.f ? v[e] : v[e] * slope;
-        }
-        y[pix * ldy + n + e] = v[e];
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 void build_direct(IgemmArgs &g, int R, int S, int stride, int pad, int OH, int OW)
 {
@@ -633,6 +674,8 @@ struct Plan {
     int nsplit, cps;
     size_t ws_bytes;
 };
+// head of the split-K workspace: one int per output tile of the launch (split layers have few tiles by construction)
+constexpr size_t kCntBytes = 64 * 1024;
 
 // Tile / split-K choice: minimise padded MFMA work / efficiency, then split the reduction (taps x channels)
 // over blockIdx.z when the output is too small to fill 256 CUs.
@@ -669,10 +712,20 @@ Plan make_plan(const IgemmArgs &g, bool c4, int only_cfg = -1)
             // (measured with padded LDS: 1 wave 0.75, 2 waves 0.91, 4 waves 1.0 of the same tile's throughput)
             static const int maxblk[NCFG] = {2, 2, 2, 4, 1, 2}, wpb[NCFG] = {1, 1, 1, 1, 2, 2};
             static const double occf[5] = {0.0, 0.75, 0.91, 0.96, 1.0};
-            const int res = (int)(per_cu < maxblk[c] ? per_cu : maxblk[c]) * wpb[c];
             const int resmax = maxblk[c] * wpb[c];
-            const double eff = kCfg[c].eff * occf[res > 4 ? 4 : res] / occf[resmax > 4 ? 4 : resmax];
-            double cost = (double)per_cu * (cps + 3) * kCfg[c].bm * kCfg[c].bn / eff;
+            // Time in units of "one workgroup's chunk with the CU to itself".  n co-resident workgroups share the CU's MFMA
+            // pipes: a round of n costs n / occf(n).  Only maxblk fit (LDS); the rest runs in further rounds, and a partly
+            // filled later round costs a FULL one: when the first round drains, the dispatcher hands the leftovers to the
+            // first CUs that free up, 4 at a time, instead of spreading them (SQ counters on TPM.2: 1280 workgroups = 1.25
+            // rounds ran 424 k cycles with the MFMA pipes busy for 256 k; the old model priced that as 5 units instead of 8).
+            double units;
+            if (per_cu <= maxblk[c]) {
+                const int res = (int)per_cu * wpb[c];
+                units = (double)per_cu / (occf[res > 4 ? 4 : res] / occf[resmax > 4 ? 4 : resmax]);
+            } else {
+                units = (double)cdiv((int)per_cu, maxblk[c]) * maxblk[c];
+            }
+            double cost = units * (cps + 3) * kCfg[c].bm * kCfg[c].bn / kCfg[c].eff;
             if (split > 1) cost += 0.15 * (double)split * maxM * g.N * 32.0 / 256.0;   // slab write + reduce pass
             if (cost < best) {
                 best = cost;
@@ -689,7 +742,15 @@ Plan make_plan(const IgemmArgs &g, bool c4, int only_cfg = -1)
     if (verbose)
         fprintf(stderr, "[igemm plan] M=%d N=%d C=%d phases=%d chunks=%d -> tile %dx%d split %d (cps %d)\n", maxM, g.N, g.C,
                 g.nphase, maxchunks, kCfg[pl.cfg].bm, kCfg[pl.cfg].bn, pl.nsplit, pl.cps);
-    if (pl.nsplit > 1) pl.ws_bytes = (size_t)pl.nsplit * g.B * g.OH * g.OW * g.N * sizeof(float);
+    if (pl.nsplit > 1) {
+        const long tiles = (long)cdiv(maxM, kCfg[pl.cfg].bm) * cdiv(g.N, kCfg[pl.cfg].bn) * g.nphase;
+        if (tiles * (long)sizeof(int) > (long)kCntBytes) {         // cannot happen for the shapes that split; stay correct anyway
+            pl.nsplit = 1;
+            pl.cps = maxchunks;
+        } else {
+            pl.ws_bytes = kCntBytes + (size_t)pl.nsplit * g.B * g.OH * g.OW * g.N * sizeof(float);
+        }
+    }
     return pl;
 }
 
@@ -756,7 +817,8 @@ int run_plan(IgemmArgs &g, const Plan &pl, bool vec, bool c4, void *ws, hipStrea
 {
     g.nsplit = pl.nsplit;
     g.cps = pl.cps;
-    g.ws = (float *)ws;
+    g.cnt = (int *)ws;                                        // [kCntBytes] arrival counters, then the partial slabs
+    g.ws = (float *)((char *)ws + kCntBytes);
     g.slab = (long)g.B * g.OH * g.OW * g.N;
     int rc;
     switch (pl.cfg) {
@@ -767,19 +829,7 @@ int run_plan(IgemmArgs &g, const Plan &pl, bool vec, bool c4, void *ws, hipStrea
     case 5: rc = launch_cfg<128, 128, 32, 64>(g, vec, c4, st); break;
     default: rc = launch_cfg<64, 64, 32, 32>(g, vec, c4, st); break;
     }
-    if (rc || pl.nsplit == 1) return rc;
-    const size_t npix = (size_t)g.B * g.OH * g.OW;
-    const bool v4 = (g.N % 4 == 0) && (g.ldy % 4 == 0) && (((uintptr_t)g.y & 15) == 0) &&
-                    (g.epi != EPI_DACT || (g.ldz % 4 == 0));
-    const size_t nthreads = npix * (v4 ? g.N / 4 : g.N);
-    if (v4)
-        hipLaunchKernelGGL((splitk_reduce_kernel<true>), dim3((unsigned)cdivz(nthreads, 256)), dim3(256), 0, st, g.ws, g.slab,
-                           g.nsplit, g.bias, g.z, g.ldz, g.y, g.ldy, npix, g.N, g.epi, g.slope);
-    else
-        hipLaunchKernelGGL((splitk_reduce_kernel<false>), dim3((unsigned)cdivz(nthreads, 256)), dim3(256), 0, st, g.ws, g.slab,
-                           g.nsplit, g.bias, g.z, g.ldz, g.y, g.ldy, npix, g.N, g.epi, g.slope);
-    STEM_LAUNCH_CHECK("splitk_reduce");
-    return 0;
+    return rc;
 }
 
 // Per-geometry choice from measurements (STEM_IGEMM_AUTOTUNE=1): the first launch of a geometry times the model's best
@@ -859,7 +909,8 @@ int launch(IgemmArgs &g, bool c4, void *ws, size_t ws_bytes, hipStream_t st)
             if (sp > maxchunks) sp = maxchunks;
             Plan cnd{c, sp, cdiv(maxchunks, sp), 0};
             cnd.nsplit = cdiv(maxchunks, cnd.cps);
-            cnd.ws_bytes = cnd.nsplit > 1 ? cnd.nsplit * out_bytes : 0;
+            cnd.ws_bytes = cnd.nsplit > 1 ? kCntBytes + cnd.nsplit * out_bytes : 0;
+            if (cnd.nsplit > 1 && (long)cdiv(maxM, kCfg[c].bm) * cdiv(g.N, kCfg[c].bn) * g.nphase * (long)sizeof(int) > (long)kCntBytes) continue;
             if (cnd.nsplit > 1 && (ws == nullptr || cnd.ws_bytes > ws_bytes)) continue;
             bool dup = false;
             for (const Plan &o : cands) dup |= (o.cfg == cnd.cfg && o.nsplit == cnd.nsplit);
@@ -958,7 +1009,7 @@ STEM_EXPORT size_t stem_conv_workspace_bytes(int kind, int B, int H, int W, int 
     const Plan pl = make_plan(g, false);
     if (!autotune || pl.nsplit <= 1) return pl.ws_bytes;
     // room for the measured choice to split twice as far as the model would (layers the model leaves unsplit stay so)
-    return (size_t)pl.nsplit * 2 * g.B * g.OH * g.OW * g.N * sizeof(float);
+    return kCntBytes + (size_t)pl.nsplit * 2 * g.B * g.OH * g.OW * g.N * sizeof(float);
 }
 
 STEM_EXPORT int stem_conv2d_fwd(const float *x, int ldx, const float *wp, const float *bias, float *y, int ldy,

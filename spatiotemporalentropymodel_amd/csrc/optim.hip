@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const f32x4 *g4, const float
     }
     if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
-__global__ __launch_bounds__(256) void sumsq_final_kernel(const double *part, int nparts, double *acc)
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const double *part, int nparts, double *acc, int overwrite)
 {
     __shared__ double red[256];
     double s = 0.0;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const double *part, in
         if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
         __syncthreads();
     }
-    if (threadIdx.x == 0) acc[0] += red[0];
+    if (threadIdx.x == 0) acc[0] = overwrite ? red[0] : acc[0] + red[0];
 }
 
 // torch.optim.Adam single-tensor update (no amsgrad, no weight decay):
@@ -97,20 +97,30 @@ __global__ __launch_bounds__(256) void axpy_kernel(float *y, const float *x, flo
 
 }   // namespace
 
-STEM_EXPORT int stem_sumsq(const float *g, size_t n, double *acc, void *stream)
+namespace {
+int sumsq_impl(const float *g, size_t n, double *acc, int overwrite, void *stream);
+}
+STEM_EXPORT int stem_sumsq(const float *g, size_t n, double *acc, void *stream) { return sumsq_impl(g, n, acc, 0, stream); }
+STEM_EXPORT int stem_sumsq_set(const float *g, size_t n, double *acc, void *stream) { return sumsq_impl(g, n, acc, 1, stream); }
+namespace {
+int sumsq_impl(const float *g, size_t n, double *acc, int overwrite, void *stream)
 {
     STEM_CHECK_ARG(g && acc, "stem_sumsq: null pointer");
-    if (n == 0) return 0;
+    if (n == 0) {
+        if (overwrite && hipMemsetAsync(acc, 0, sizeof(double), (hipStream_t)stream) != hipSuccess) return -2;
+        return 0;
+    }
     const bool al = (((uintptr_t)g) & 15) == 0;
     const size_t n4 = al ? n / 4 : 0;
     size_t nb = cdivz(n4 ? n4 : 1, 256);
     if (nb > STEM_SUMSQ_SCRATCH) nb = STEM_SUMSQ_SCRATCH;
     hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const f32x4 *>(g), g, n4, n, acc + 1);
-    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, acc + 1, (int)nb, acc);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, acc + 1, (int)nb, acc, overwrite);
     STEM_LAUNCH_CHECK("sumsq");
     return 0;
 }
+}   // namespace
 
 STEM_EXPORT int stem_adam_step(float *p, const float *g, float *m, float *v, size_t n, const double *sumsq, float max_norm,
                                float gscale, float lr, float beta1, float beta2, float eps, int step, void *stream)

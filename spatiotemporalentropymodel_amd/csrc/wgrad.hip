@@ -394,9 +394,19 @@ void plan(int CP, int CG, int T, int nchunks, int *cfg, int *splits)
             // workgroups are dealt round-robin to the 256 CUs and share the CU's MFMA pipes: time ~ (blocks per CU) x
             // (MFMA work per block); fewer co-resident workgroups hide less latency (measured on the igemm twin kernel)
             const long per_cu = cdiv((int)blocks, 256);
-            const long resident = (per_cu < slots[c] / 256 ? per_cu : slots[c] / 256) * wps[c];      // wavefronts per SIMD
-            const double occf = resident >= 4 ? 1.0 : resident == 3 ? 0.96 : resident == 2 ? 0.91 : 0.75;
-            double cost = (double)per_cu * (cps + 3) * kWT[c].bm * kWT[c].bn / (eff * occf);
+            const int maxblk = slots[c] / 256;
+            // one round = up to maxblk co-resident workgroups per CU sharing its MFMA pipes (n of them cost n / occf(n));
+            // what does not fit runs in further rounds, each priced as a FULL round (the dispatcher packs the leftovers onto
+            // the CUs that drain first; see the igemm planner for the counter evidence)
+            double units;
+            if (per_cu <= maxblk) {
+                const long resident = per_cu * wps[c];                                    // wavefronts per SIMD
+                const double occf = resident >= 4 ? 1.0 : resident == 3 ? 0.96 : resident == 2 ? 0.91 : 0.75;
+                units = (double)per_cu / occf;
+            } else {
+                units = (double)cdiv((int)per_cu, maxblk) * maxblk;
+            }
+            double cost = units * (cps + 3) * kWT[c].bm * kWT[c].bn / eff;
             cost += 0.1 * (double)s * CP * CG * T * 32.0 / 256.0;                    // slab write + unpack read
             if (cost < best) {
                 best = cost;

@@ -197,30 +197,43 @@ class StemEngine:
             torch.cuda.current_stream(self._side.device).wait_stream(self._side)
 
     # -------------------------------------------------------------------------------------------
-    def forward(self, y_cur, y_cond, training: bool):
+    def forward(self, y_cur, y_cond, training: bool, rate_coef=None):
+        """rate_coef = (coef, scale) selects the fused training glue (training only): the elementwise work between the
+        convolutions runs as 4 kernels that also produce dlik = coef / lik and (y_bpp, z_bpp, loss) = scale * sum log2 lik,
+        i.e. EMLoss forward AND backward (utils.py:18-27): `k` then carries "dlik_y", "dlik_z", "loss3"."""
         self.ensure_packed()
         self._checked = True          # weights cannot change inside one forward: skip the per-layer checks
         try:
-            return self._forward(y_cur, y_cond, training)
+            return self._forward(y_cur, y_cond, training, rate_coef)
         finally:
             self._checked = False
 
-    def _forward(self, y_cur, y_cond, training: bool):
+    def _forward(self, y_cur, y_cond, training: bool, rate_coef=None):
         m = self.m
         yc, yd = F.to_nhwc(y_cur.detach()), F.to_nhwc(y_cond.detach())
         B, Cin, H, W = yc.shape
         dev = yc.device
         eb, gc = m.entropy_bottleneck, m.gaussian_conditional
+        fused = rate_coef is not None
+        assert not fused or training, "the fused glue is the TRAINING forward"
         k = {}
-        # hyper encoder on cat(y_cur, y_cond): the two halves are written into one buffer
-        he_in = F.empty_nhwc(B, 2 * Cin, H, W, dev)
-        F.copy_channels(yc, he_in[:, :Cin])
-        F.copy_channels(yd, he_in[:, Cin:])
+        target = t_hat = y_hat = None
+        if fused:
+            # one kernel: he_in = [y_cur | y_cond], target, t_hat = target + noise, y_hat = t_hat (+ y_cond)
+            slot = gc._noise_slot(yc) if self.has_spm else {}
+            he_in, target, t_hat, y_hat = F.prior_prologue(yc, yd, self.residual, True, self.has_spm, **slot)
+        else:
+            # hyper encoder on cat(y_cur, y_cond): the two halves are written into one buffer
+            he_in = F.empty_nhwc(B, 2 * Cin, H, W, dev)
+            F.copy_channels(yc, he_in[:, :Cin])
+            F.copy_channels(yd, he_in[:, Cin:])
         he0 = self.HE[0].fwd(he_in, F.ACT_LRELU)
         he2 = self.HE[1].fwd(he0, F.ACT_LRELU)
         z = self.HE[2].fwd(he2)
         pack = F.eb_pack(eb._tensors14())
-        if training:
+        if fused:
+            z_hat, lik_z, k["dlik_z"], part_z = F.eb_forward_train(z, pack, rate_coef[0], bound=eb._lik_bound, **eb._noise_slot(z))
+        elif training:
             z_hat, lik_z = F.eb_forward(z, pack, noise=eb._noise_like(z))
         else:
             z_hat, lik_z = F.eb_forward(z, pack, medians=eb._medians_vec())
@@ -237,22 +250,30 @@ class StemEngine:
             tp0 = self.TPM[0].fwd(yd, F.ACT_LRELU)
             tp2 = self.TPM[1].fwd(tp0, F.ACT_LRELU)
             self.TPM[2].fwd(tp2, out=epm_in[:, o_tp:o_tp + P])
-        target = F.sub(yc, yd) if self.residual else (yc if F.nhwc_ld(yc) == Cin else F.copy_channels(yc, F.empty_nhwc(B, Cin, H, W, dev)))
-        t_hat = None
+        if not fused:
+            target = F.sub(yc, yd) if self.residual else (yc if F.nhwc_ld(yc) == Cin else F.copy_channels(yc, F.empty_nhwc(B, Cin, H, W, dev)))
         if self.has_spm:
             # gaussian_conditional.quantize(target, "noise" | "dequantize") with no means (:570-572, :853-855)
-            t_hat = F.add(target, gc._noise_like(target)) if training else F.round_(target)
+            if not fused:
+                t_hat = F.add(target, gc._noise_like(target)) if training else F.round_(target)
             self.CTX.fwd(t_hat, out=epm_in[:, o_ctx:o_ctx + P])
         e0 = self.EPM[0].fwd(epm_in, F.ACT_LRELU)
         e2 = self.EPM[1].fwd(e0, F.ACT_LRELU)
         gp = self.EPM[2].fwd(e2)                                   # [B, 2*Cin, H, W] = scales | means
         scales, means = gp[:, :Cin], gp[:, Cin:]
-        noise = gc._noise_like(target) if training else None
-        gc_out, lik_y = F.gc_forward(target, scales, means, noise=noise, scale_bound=gc._scale_bound, lik_bound=gc._lik_bound)
-        if self.has_spm:
-            y_hat = F.add(t_hat, yd if F.nhwc_ld(yd) == Cin else F.copy_channels(yd, F.empty_nhwc(B, Cin, H, W, dev))) if self.residual else t_hat
+        if fused:
+            gc_out, lik_y, k["dlik_y"], part_y = F.gc_forward_train(target, scales, means, rate_coef[0], scale_bound=gc._scale_bound,
+                                                                    lik_bound=gc._lik_bound, **gc._noise_slot(target))
+            k["loss3"] = F.em_loss_finalize(part_y, part_z, rate_coef[1])
+            if not self.has_spm:
+                y_hat = gc_out
         else:
-            y_hat = gc_out
+            noise = gc._noise_like(target) if training else None
+            gc_out, lik_y = F.gc_forward(target, scales, means, noise=noise, scale_bound=gc._scale_bound, lik_bound=gc._lik_bound)
+            if self.has_spm:
+                y_hat = F.add(t_hat, yd if F.nhwc_ld(yd) == Cin else F.copy_channels(yd, F.empty_nhwc(B, Cin, H, W, dev))) if self.residual else t_hat
+            else:
+                y_hat = gc_out
         k.update(he_in=he_in, he0=he0, he2=he2, z_hat=z_hat, pack=pack, hd0=hd0, hd2=hd2, epm_in=epm_in, tp0=tp0, tp2=tp2,
                  yd=yd, t_hat=t_hat, e0=e0, e2=e2, gp=gp, gc_out=gc_out, offs=(o_tp, o_hp, o_ctx), P=P, Cin=Cin)
         return y_hat, lik_y, lik_z, k

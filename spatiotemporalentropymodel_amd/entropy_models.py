@@ -274,6 +274,15 @@ class EntropyModel(nn.Module):
         self._noise_offset += (x_nhwc.numel() + 3) // 4
         return out
 
+    def _noise_slot(self, x_nhwc):
+        """For kernels that draw their noise inline: either {"noise": tensor} (injected source) or the Philox coordinates
+        {"seed", "offset", "epoch"} the next _noise_like(x) would have used -- and advance the stream past them."""
+        if self.noise_source is not None:
+            return {"noise": self._noise_like(x_nhwc)}
+        slot = {"seed": self.noise_seed, "offset": self._noise_offset, "epoch": self.noise_epoch}
+        self._noise_offset += (x_nhwc.numel() + 3) // 4
+        return slot
+
     def quantize(self, inputs, mode, means=None):
         if mode not in ("noise", "dequantize", "symbols"):
             raise ValueError(f'Invalid quantization mode: "{mode}"')

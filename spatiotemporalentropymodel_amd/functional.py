@@ -170,7 +170,9 @@ def _workspace(kind, dims, device):
     slot = (device, _stream())
     buf = _WS.get(slot)
     if buf is None or buf.numel() * 4 < need:
-        buf = _WS[slot] = torch.empty((need + 3) // 4, device=device, dtype=torch.float32)
+        # zero-filled: the head of the buffer holds the per-tile arrival counters of the split-K protocol, which every
+        # launch leaves at zero again (include/stem_hip.h)
+        buf = _WS[slot] = torch.zeros((need + 3) // 4, device=device, dtype=torch.float32)
     return buf.data_ptr(), need
 
 
@@ -598,9 +600,11 @@ def sumsq_accumulator(device):
     return torch.zeros(1 + SUMSQ_SCRATCH, dtype=torch.float64, device=device)
 
 
-def sumsq(g, acc):
+def sumsq(g, acc, overwrite=False):
+    """acc[0] += sum(g^2) (or = with overwrite=True: no separately zeroed accumulator)"""
     assert acc.numel() >= 1 + SUMSQ_SCRATCH
-    _chk(_lib.hip().stem_sumsq(g.data_ptr(), g.numel(), acc.data_ptr(), _stream()))
+    fn = _lib.hip().stem_sumsq_set if overwrite else _lib.hip().stem_sumsq
+    _chk(fn(g.data_ptr(), g.numel(), acc.data_ptr(), _stream()))
 
 
 def clip_scale(g, sumsq_acc, max_norm):
@@ -622,3 +626,82 @@ def adam_step_dev(p, g, m, v, sumsq_acc, max_norm, gscale, lr_dev, beta1, beta2,
     _chk(_lib.hip().stem_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), _ptr(sumsq_acc),
                                        max_norm, gscale, lr_dev.data_ptr(), beta1, beta2, eps, step_dev.data_ptr(),
                                        scal_dev.data_ptr(), _stream()))
+
+
+# ----------------------------------------------------------------------------- fused training glue
+_M64 = 2 ** 64 - 1
+
+
+def _noise_args(noise, seed, offset, epoch):
+    """(noise ptr | NULL, seed, offset, epoch ptr | NULL, epoch stride) of the fused kernels' noise source"""
+    if noise is not None:
+        assert noise.is_cuda and noise.dtype == torch.float32
+        return noise.data_ptr(), 0, 0, None, 0
+    return None, int(seed) & _M64, int(offset) & _M64, (None if epoch is None else epoch.data_ptr()), (0 if epoch is None else NOISE_EPOCH_STRIDE)
+
+
+def prior_prologue(yc, yd, residual, training, with_t_hat, noise=None, seed=0, offset=0, epoch=None):
+    """-> (he_in [B,2C,H,W], target, t_hat | None, y_hat | None), all NHWC.  One kernel for cat(y_cur, y_cond), the residual,
+    its noisy / rounded version and y_hat (spatiotemporalpriors.py:846-856,863)."""
+    B, Cc, H, W = yc.shape
+    dev = yc.device
+    he_in, target = empty_nhwc(B, 2 * Cc, H, W, dev), empty_nhwc(B, Cc, H, W, dev)
+    t_hat = empty_nhwc(B, Cc, H, W, dev) if with_t_hat else None
+    y_hat = empty_nhwc(B, Cc, H, W, dev) if with_t_hat else None
+    if noise is not None:
+        assert nhwc_ld(noise) == Cc
+    nptr, sd, off, ep, stride = _noise_args(noise, seed, offset, epoch)
+    _chk(_lib.hip().stem_prior_prologue(yc.data_ptr(), nhwc_ld(yc), yd.data_ptr(), nhwc_ld(yd), he_in.data_ptr(), 2 * Cc, target.data_ptr(),
+                                        _ptr(t_hat), _ptr(y_hat), nptr, sd, off, ep, stride, B * H * W, Cc, int(bool(residual)),
+                                        int(bool(training)), _stream()))
+    return he_in, target, t_hat, y_hat
+
+
+def rate_partials(n):
+    return int(_lib.hip().stem_rate_partials(n))
+
+
+def eb_forward_train(z, pack, coef, noise=None, seed=0, offset=0, epoch=None, bound=1e-9):
+    """-> (z_hat, lik, dlik, partials): training-mode EntropyBottleneck forward + dlik = coef / lik + log2 partial sums"""
+    B, Cc, H, W = z.shape
+    z_hat, lik, dlik = (empty_nhwc(B, Cc, H, W, z.device) for _ in range(3))
+    part = torch.empty(rate_partials(z.numel()), dtype=torch.float64, device=z.device)
+    if noise is not None:
+        assert nhwc_ld(noise) == Cc
+    nptr, sd, off, ep, stride = _noise_args(noise, seed, offset, epoch)
+    _chk(_lib.hip().stem_eb_forward_train(z.data_ptr(), nhwc_ld(z), pack.data_ptr(), nptr, sd, off, ep, stride, z_hat.data_ptr(),
+                                          lik.data_ptr(), dlik.data_ptr(), part.data_ptr(), B * H * W, Cc, bound, coef, _stream()))
+    return z_hat, lik, dlik, part
+
+
+def gc_forward_train(y, scales, means, coef, noise=None, seed=0, offset=0, epoch=None, scale_bound=0.11, lik_bound=1e-9):
+    """-> (out, lik, dlik, partials): training-mode GaussianConditional forward (y + noise; dense y) + dlik + log2 partials"""
+    B, Cc, H, W = y.shape
+    assert nhwc_ld(y) == Cc and nhwc_ld(scales) == nhwc_ld(means)
+    out, lik, dlik = (empty_nhwc(B, Cc, H, W, y.device) for _ in range(3))
+    part = torch.empty(rate_partials(y.numel()), dtype=torch.float64, device=y.device)
+    if noise is not None:
+        assert nhwc_ld(noise) == Cc
+    nptr, sd, off, ep, stride = _noise_args(noise, seed, offset, epoch)
+    _chk(_lib.hip().stem_gc_forward_train(y.data_ptr(), scales.data_ptr(), means.data_ptr(), nhwc_ld(scales), nptr, sd, off, ep, stride,
+                                          out.data_ptr(), lik.data_ptr(), dlik.data_ptr(), part.data_ptr(), B * H * W, Cc, scale_bound,
+                                          lik_bound, coef, _stream()))
+    return out, lik, dlik, part
+
+
+def em_loss_finalize(part_y, part_z, scale, out3=None):
+    """-> fp64 [3] = (y_bpp, z_bpp, loss) from the partial log2 sums (EMLoss, utils.py:18-27)"""
+    if out3 is None:
+        out3 = torch.empty(3, dtype=torch.float64, device=part_y.device)
+    _chk(_lib.hip().stem_em_loss_finalize(part_y.data_ptr(), part_y.numel(), part_z.data_ptr(), part_z.numel(), float(scale),
+                                          out3.data_ptr(), _stream()))
+    return out3
+
+
+def eb_aux_loss_grad(quantiles, pack, target, dq_out, loss_out=None, accumulate=False):
+    """EntropyBottleneck.loss and d loss / d quantiles in one single-workgroup kernel; dq_out is written (or added to)"""
+    if loss_out is None:
+        loss_out = torch.empty(1, dtype=torch.float32, device=quantiles.device)
+    _chk(_lib.hip().stem_eb_aux_loss_grad(quantiles.data_ptr(), pack.data_ptr(), target.data_ptr(), loss_out.data_ptr(),
+                                          _ptr(dq_out), quantiles.shape[0], int(bool(accumulate)), _stream()))
+    return loss_out

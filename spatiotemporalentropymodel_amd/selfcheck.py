@@ -43,13 +43,16 @@ def build_models(ebc, cin, N, M, device, cls=None, closed_form=True, inject_nois
     return imodel, stem
 
 
-def p_frame_step(imodel, stem, criterion, optimizer, aux_optimizer, x, y_cond, grad_scale=1.0, reducer=None):
+def p_frame_step(imodel, stem, criterion, optimizer, aux_optimizer, x, y_cond, grad_scale=1.0, reducer=None, y_cur=None):
     """One P-frame optimisation step, the body of stem/trainSTEM.py:203-218 with the fused optimiser:
-    zero_grad -> getY -> stem forward -> EMLoss -> backward -> [all-reduce] -> clip+Adam -> aux loss/step."""
+    zero_grad -> getY -> stem forward -> EMLoss -> backward -> [all-reduce] -> clip+Adam -> aux loss/step.
+    `y_cur`: the frame's latents when the caller has already run the (frozen, no-grad) analysis transform -- e.g. for
+    all frames of the septuplet up front, which lets the host run ahead of the GPU (bench.py)."""
     optimizer.zero_grad()
     aux_optimizer.zero_grad()
-    with torch.no_grad():
-        y_cur, _ = imodel.getY(x)
+    if y_cur is None:
+        with torch.no_grad():
+            y_cur, _ = imodel.getY(x)
     out = stem(y_cur, y_cond)
     oc = criterion(out, x)
     oc["loss"].backward()                 # an attached OverlappedGradReducer exchanges slices during this call

@@ -1,0 +1,72 @@
+"""The P-frame optimisation step of stem/trainSTEM.py:203-218 as ONE explicit launch schedule (no torch autograd, no
+torch elementwise kernels):
+
+    zero main gradients -> STEM forward with the fused glue (engine.forward(rate_coef=...): EMLoss value and
+    d loss / d likelihood come out of the forward) -> engine.backward -> [data-parallel exchange] -> global norm ->
+    clip + Adam -> auxiliary loss + quantile gradient -> aux Adam
+
+~65 launches instead of ~160 through nn.Module / autograd / torch.optim (selfcheck.p_frame_step, the generic route every
+parity test against the reference's goldens goes through; tests/test_hip_trainer.py ties this route to it: same Philox
+noise -> same likelihoods, gradients and updated parameters).  The arithmetic is the same kernels; what disappears is
+the per-dispatch latency of ~50 few-microsecond glue kernels per step and most of the host time.
+
+Only `EMLoss` (rate-only, the trainSTEM criterion) has this closed form; other criteria use the generic route.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import functional as F
+from .layers import join_wgrad_stream
+
+
+class LazyNorm:
+    """sqrt(sumsq) * scale, evaluated (one tiny kernel + a host sync) only if somebody looks at it"""
+
+    def __init__(self, sumsq0, scale):
+        self._s, self._scale = sumsq0, scale
+
+    def tensor(self):
+        return self._s.sqrt() * self._scale
+
+    def __float__(self):
+        return float(self.tensor())
+
+
+class FusedPFrameStep:
+    def __init__(self, stem, optimizer, aux_optimizer):
+        self.stem, self.opt, self.aux_opt = stem, optimizer, aux_optimizer
+        self.eng = stem.engine()
+        eb = stem.entropy_bottleneck
+        if eb.quantiles.grad is None or getattr(eb.quantiles, "_flat_grad_view", None) is None:
+            raise ValueError("FusedPFrameStep needs the flat-buffer optimisers of optim.configure_optimizers(fused=True)")
+        self._aux_loss = torch.zeros(1, dtype=torch.float32, device=eb.quantiles.device)
+
+    def step(self, y_cur, y_cond, num_pixels, grad_scale=1.0, reducer=None):
+        """y_cur / y_cond: the frame's and the conditioning latents [B,C,h,w]; num_pixels = N*H*W of the FRAMES (EMLoss
+        normalisation).  Returns (out, criterion_out, aux_loss, grad_norm) like selfcheck.p_frame_step; the loss entries
+        are 0-dim fp64 device tensors, grad_norm a LazyNorm."""
+        stem, opt, aux_opt, eng = self.stem, self.opt, self.aux_opt, self.eng
+        eb = stem.entropy_bottleneck
+        opt.flat.zero_grad()                                        # one memset; the aux gradient is overwritten below
+        coef = -1.0 / (math.log(2.0) * num_pixels)
+        y_hat, lik_y, lik_z, k = eng.forward(y_cur, y_cond, True, rate_coef=(coef, -1.0 / num_pixels))
+        eng.backward(k, k["dlik_y"], k["dlik_z"])                   # an attached OverlappedGradReducer exchanges slices in here
+        if reducer is not None:
+            reducer.finish() if hasattr(reducer, "finish") else reducer.all_reduce()
+        join_wgrad_stream()
+        F.sumsq(opt.flat.grad, opt._sumsq, overwrite=True)
+        gn = LazyNorm(opt._sumsq[0], grad_scale)
+        opt.step(grad_scale=grad_scale, norm_is_current=True)
+        # auxiliary loss on the UPDATED parameters (stem/trainSTEM.py:216-218); its gradient goes straight into the aux
+        # optimiser's flat buffer (the only aux parameter is `entropy_bottleneck.quantiles`)
+        pack = F.eb_pack(eb._tensors14())
+        F.eb_aux_loss_grad(eb.quantiles.detach(), pack, eb.target, eb.quantiles._flat_grad_view, loss_out=self._aux_loss)
+        eb.quantiles.grad = eb.quantiles._flat_grad_view
+        aux_opt.step()
+        loss3 = k["loss3"]
+        out = {"y_hat": y_hat, "likelihoods": {"y": lik_y, "z": lik_z}}
+        oc = {"y_bpp_loss": loss3[0], "z_bpp_loss": loss3[1], "loss": loss3[2]}
+        return out, oc, self._aux_loss[0], gn

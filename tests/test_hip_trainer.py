@@ -1,0 +1,122 @@
+"""GPU: the explicit-schedule P-frame step (trainer.FusedPFrameStep: fused glue kernels, no autograd) against the generic
+nn.Module / autograd / optimiser route (selfcheck.p_frame_step) that the reference's goldens pin.
+
+Same weights, same inputs, same noise (both draw the same Philox counters, or both are fed the goldens' injected noise):
+the forward tensors are bit-identical, gradients agree to fp32 rounding of the loss-gradient scalar (coef / lik vs
+(1 / lik) * (g / ln 2)), and the optimiser trajectories stay together."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import f64_gate
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(ebc, cin, N, M, closed_form, inject):
+    from spatiotemporalentropymodel_amd import selfcheck as S
+    from spatiotemporalentropymodel_amd.optim import configure_optimizers
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    imodel, stem = S.build_models(ebc, cin, N, M, dev, closed_form=closed_form, inject_noise=inject)
+    stem.train()
+    opt, aux = configure_optimizers(stem, types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3))
+    return imodel, stem, opt, aux
+
+
+def test_fused_step_tracks_generic_step_philox_noise():
+    from spatiotemporalentropymodel_amd import selfcheck as S
+    from spatiotemporalentropymodel_amd.losses import EMLoss
+    from spatiotemporalentropymodel_amd.trainer import FusedPFrameStep
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(2)
+    frames = [torch.rand(2, 3, 128, 128, device=dev, generator=g) for _ in range(4)]
+    im_a, stem_a, opt_a, aux_a = _pair(64, 96, 64, 96, False, False)
+    im_b, stem_b, opt_b, aux_b = _pair(64, 96, 64, 96, False, False)
+    assert torch.equal(opt_a.flat.data, opt_b.flat.data)
+    fused = FusedPFrameStep(stem_b, opt_b, aux_b)
+    crit = EMLoss()
+    with torch.no_grad():
+        _, y_cond_a = im_a.getY(frames[0])
+        _, y_cond_b = im_b.getY(frames[0])
+    assert torch.equal(y_cond_a, y_cond_b)
+    for t in range(1, 4):
+        out_a, oc_a, aux_la, gn_a = S.p_frame_step(im_a, stem_a, crit, opt_a, aux_a, frames[t], y_cond_a)
+        grad_a = opt_a.flat.grad.clone()
+        with torch.no_grad():
+            y_cur, _ = im_b.getY(frames[t])
+        out_b, oc_b, aux_lb, gn_b = fused.step(y_cur, y_cond_b, 2 * 128 * 128)
+        if t == 1:          # identical parameters: identical forward, down to the noise
+            assert torch.equal(out_a["y_hat"], out_b["y_hat"])
+            assert torch.equal(out_a["likelihoods"]["y"], out_b["likelihoods"]["y"])
+            assert torch.equal(out_a["likelihoods"]["z"], out_b["likelihoods"]["z"])
+            assert abs(float(oc_a["loss"]) - float(oc_b["loss"])) <= 1e-12 * abs(float(oc_b["loss"]))
+            e = float((grad_a - opt_b.flat.grad).abs().max()) / float(grad_a.abs().max())
+            assert e <= 2e-6, e
+        assert abs(float(oc_a["loss"]) - float(oc_b["loss"])) <= 1e-5 * abs(float(oc_b["loss"])), t
+        assert abs(float(oc_a["y_bpp_loss"]) - float(oc_b["y_bpp_loss"])) <= 1e-5 * abs(float(oc_b["y_bpp_loss"]))
+        assert abs(float(gn_a) - float(gn_b)) <= 1e-4 * float(gn_b), (t, float(gn_a), float(gn_b))
+        assert abs(float(aux_la) - float(aux_lb)) <= 1e-5 * abs(float(aux_lb)), (t, float(aux_la), float(aux_lb))
+        y_cond_a, y_cond_b = out_a["y_hat"], out_b["y_hat"]
+    # three Adam steps later the parameters are still together (Adam's normalised update may flip noise-level elements)
+    err = (opt_a.flat.data - opt_b.flat.data).abs()
+    assert float(err.max()) <= 6.3e-4 and float((err <= 2e-6).float().mean()) >= 0.97, (float(err.max()), float((err <= 2e-6).float().mean()))
+    assert float((aux_a.flat.data - aux_b.flat.data).abs().max()) <= 1e-4
+    assert opt_b.t == 3 and aux_b.t == 3
+
+
+@pytest.mark.parametrize("tag", ["small", "big"])
+def test_fused_step_against_reference_fixtures(golden, tag):
+    """The fused route on the reference's own training case (injected noise, closed-form weights): loss, exact gradient norm
+    and every parameter gradient of step 1 against the float64 run of the reference (tests/golden/stem_f64.npz) at 1e-4."""
+    from spatiotemporalentropymodel_amd.trainer import FusedPFrameStep
+    from spatiotemporalentropymodel_amd.weights import smooth_frames
+    g, f64 = golden(f"stem_train_{tag}.npz"), golden("stem_f64.npz")
+    ebc, cin, N, M, batch, size, steps = (int(v) for v in g["cfg"])
+    dev = torch.device("cuda:0")
+    imodel, stem, opt, aux = _pair(ebc, cin, N, M, True, True)
+    fused = FusedPFrameStep(stem, opt, aux)
+    frames = [f.to(dev) for f in smooth_frames("train:" + tag, batch, steps + 1, size)]
+    with torch.no_grad():
+        _, y_cond = imodel.getY(frames[0])
+        y_cur, _ = imodel.getY(frames[1])
+    # look at the gradients before Adam consumes them: run the schedule by hand up to the norm
+    eng = stem.engine()
+    opt.flat.zero_grad()
+    npix = batch * size * size
+    y_hat, lik_y, lik_z, k = eng.forward(y_cur, y_cond, True, rate_coef=(-1.0 / (np.log(2.0) * npix), -1.0 / npix))
+    eng.backward(k, k["dlik_y"], k["dlik_z"])
+    gn = float(opt.grad_norm())
+    x_loss, x_ybpp, x_zbpp, _, x_gn = f64[f"{tag}:s1:scalars"]
+    r32 = f64[f"{tag}:ref32:s1:scalars"]
+    f64_gate([float(k["loss3"][2]), float(k["loss3"][0]), float(k["loss3"][1]), gn], [x_loss, x_ybpp, x_zbpp, x_gn], r32[[0, 1, 2, 4]],
+             f"{tag} fused step: loss / y_bpp / z_bpp / grad norm", floor=0.0)
+    f64_gate(lik_y.cpu().contiguous().numpy(), f64[f"{tag}:s1:lik_y"], f64[f"{tag}:ref32:lik_y"], f"{tag} fused lik_y", atol=1e-9)
+    clip = min(1.0, 1.0 / (gn + 1e-6))
+    worst = 0.0
+    for name, p in stem.named_parameters():
+        if name.endswith(".quantiles"):
+            continue
+        gd = p.grad.double() * clip
+        ex = f64[f"{tag}:s1:gsum:{name}"]
+        assert abs(float(gd.sum()) - ex[0]) <= 1e-4 * ex[1] + 1e-12, name
+        rms = float(np.sqrt(ex[2] / p.numel()))
+        xs = f64[f"{tag}:s1:gslice:{name}"]
+        sl = gd.reshape(-1)[:: max(1, gd.numel() // 64)][:64].cpu().numpy()
+        e = float((np.abs(sl - xs) / np.maximum(np.abs(xs), rms)).max())
+        worst = max(worst, e)
+        assert e <= 1e-4, (name, e)
+    print(f"[f64 gate] {tag} fused-step gradients: HIP vs exact {worst:.2e}   reference-fp32 vs exact "
+          f"{float(f64[f'{tag}:ref32:grad_slice'][0]):.2e}   bound 1e-04")
+    # and the whole step() (a fresh pair: the hand-run above consumed noise draws)
+    imodel2, stem2, opt2, aux2 = _pair(ebc, cin, N, M, True, True)
+    with torch.no_grad():
+        _, y_cond2 = imodel2.getY(frames[0])
+        y_cur2, _ = imodel2.getY(frames[1])
+    out, oc, aux_l, gnl = FusedPFrameStep(stem2, opt2, aux2).step(y_cur2, y_cond2, npix)
+    aux_ref = g["s1:scalars"][3]
+    assert abs(float(oc["loss"]) - x_loss) <= 1e-4 * x_loss and abs(float(gnl) - x_gn) <= 1e-4 * x_gn
+    assert abs(float(aux_l) - aux_ref) <= 1e-4 * abs(aux_ref), (float(aux_l), aux_ref)
+    np.testing.assert_allclose(stem2.entropy_bottleneck.quantiles.grad.cpu().numpy(), g["s1:dquantiles"], rtol=1e-4, atol=1e-6)
