@@ -315,6 +315,17 @@ int stem_ar_decode_image(const float *w_ctx, int ld_ctx, const float *b_ctx, con
                          float *ctx, float *h1, float *h2, float *gp, const float *table, int T, float scale_bound, float slope,
                          int32_t *idx_host, int32_t *sym_host, stem_symbol_decoder_fn decode, void *dec,
                          const int32_t *cdfs, int ncdf, int cdf_stride, const int32_t *sizes, const int32_t *offsets, void *stream);
+/* The same loop for G (1..8) independent images in lockstep -- the batch elements of decompress(), which the reference decodes
+ * one after the other (spatiotemporalpriors.py:1015-1054): one set of four launches + one synchronisation advances all G
+ * images by a position, so the per-position latency (what bounds the decoder) is shared.  Per image the arithmetic, and
+ * therefore every symbol / index / byte, is that of stem_ar_decode_image.  buf [G][(H+4)][(W+4)][M]; tp / hp [G][H*W][2M];
+ * ctx [G][2M], h1 [G][n0], h2 [G][n1], gp [G][2M]; idx_host / sym_host [G][M] pinned; decs[G] = one decoder handle per image. */
+int stem_ar_decode_batch(const float *w_ctx, int ld_ctx, const float *b_ctx, const float *w0, int ld0, const float *b0, int n0,
+                         const float *w1, int ld1, const float *b1, int n1, const float *w2, int ld2, const float *b2,
+                         float *buf, int G, int H, int W, int M, int pad, const float *tp, const float *hp,
+                         float *ctx, float *h1, float *h2, float *gp, const float *table, int T, float scale_bound, float slope,
+                         int32_t *idx_host, int32_t *sym_host, stem_symbol_decoder_fn decode, void *const *decs,
+                         const int32_t *cdfs, int ncdf, int cdf_stride, const int32_t *sizes, const int32_t *offsets, void *stream);
 
 /* Wavefront-parallel encoder: all latent positions with the same t = w + 3h are independent under the 5x5
  * type-A mask, so a H x W frame is coded in W + 3(H-1) batched steps instead of H*W sequential ones.  Input

@@ -243,13 +243,40 @@ def stem_decompress(model, strings, shape, y_cond):
     sym_host = torch.empty(M, dtype=torch.int32).pin_memory()
     import ctypes as C
     decode_fn = C.cast(_lib.rans().stem_rans_decoder_decode, C.c_void_p).value      # host symbol decoder, injected as a C pointer
-    for b, s in enumerate(strings[0]):
+    stepwise = bool(os.environ.get("STEM_AR_STEPWISE"))
+    lockstep = (B > 1 or bool(os.environ.get("STEM_AR_FORCE_BATCH"))) and not stepwise and not os.environ.get("STEM_AR_NO_BATCH")
+    if lockstep:
+        # Independent images advance together (csrc/ar.hip: stem_ar_decode_batch): the loop is bound by the latency of one
+        # position (4 dependent launches + a host round trip), which G images share; each image's arithmetic is unchanged.
+        GMAX = 8
+        for b0 in range(0, B, GMAX):
+            G = min(GMAX, B - b0)
+            buf = torch.zeros((G, H + 2 * _P, Wp, M), device=dev, dtype=torch.float32)
+            scratch = [torch.empty((G, n), device=dev, dtype=torch.float32) for n in (2 * M, ar.w0.shape[0], ar.w1.shape[0], 2 * M)]
+            idx_g = torch.empty((G, M), dtype=torch.int32).pin_memory()
+            sym_g = torch.empty((G, M), dtype=torch.int32).pin_memory()
+            decs = []
+            for s in strings[0][b0:b0 + G]:
+                d = RansDecoder()
+                d.set_stream(s)
+                decs.append(d)
+            handles = (C.c_void_p * G)(*[d._h for d in decs])
+            hp_b = hp.data_ptr() + 4 * (b0 * H * W * 2 * M)
+            tp_b = tp.data_ptr() + 4 * (b0 * H * W * 2 * M) if tp is not None else 0
+            F._chk(lib.stem_ar_decode_batch(
+                ar.w_ctx.data_ptr(), 12 * M, ar.b_ctx.data_ptr(), ar.w0.data_ptr(), ar.w0.shape[1], ar.b0.data_ptr(), ar.w0.shape[0],
+                ar.w1.data_ptr(), ar.w1.shape[1], ar.b1.data_ptr(), ar.w1.shape[0], ar.w2.data_ptr(), ar.w2.shape[1], ar.b2.data_ptr(),
+                buf.data_ptr(), G, H, W, M, _P, tp_b, hp_b, *[t.data_ptr() for t in scratch],
+                ar.table.data_ptr(), ar.table.numel(), ar.bound, F.LRELU_SLOPE, idx_g.data_ptr(), sym_g.data_ptr(),
+                decode_fn, C.addressof(handles), *tables.args(), F._stream()))
+            out[b0:b0 + G].copy_(buf[:, _P:_P + H, _P:_P + W].permute(0, 3, 1, 2))
+    for b, s in enumerate(strings[0] if not lockstep else []):
         buf = _padded(None, H, W, M, dev)
         dec = RansDecoder()
         dec.set_stream(s)
         hp_b = hp.data_ptr() + 4 * (b * H * W * 2 * M)
         tp_b = tp.data_ptr() + 4 * (b * H * W * 2 * M) if tp is not None else 0
-        if os.environ.get("STEM_AR_STEPWISE"):                # same loop from Python with the single-step entry points (tests)
+        if stepwise:                                          # same loop from Python with the single-step entry points (tests)
             decode_image_stepwise(ar, buf, H, W, tp_b, hp_b, dec, tables, idx_host, sym_host)
             out[b:b + 1].copy_(buf[_P:_P + H, _P:_P + W].permute(2, 0, 1).unsqueeze(0))
             continue

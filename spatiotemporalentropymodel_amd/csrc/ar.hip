@@ -10,7 +10,15 @@
 // is HBM/L2-bound (weights are read once per position): one wavefront per output row, 16-byte loads,
 // reduction across the 64 lanes with wavefront shuffles.  The input vector is given as up to three
 // contiguous segments so neither the 5x5 window nor cat(tp, hp, ctx) is ever materialised.
+#include <chrono>
+
 #include "stem_common.h"
+
+// Encoder and decoder must produce the SAME floats for every entropy parameter (a mean that differs in the last bit
+// shifts y_hat, which feeds later contexts; a scale on the other side of a table entry desynchronises the coder), and the
+// encoder's wavefront kernels, the one-image decoder and the lockstep decoder are different kernels.  Their dot products
+// are therefore written once (dot4) and compiled without FMA contraction: products rounded, then added left to right.
+#pragma clang fp contract(off)
 
 namespace {
 
@@ -425,5 +433,200 @@ STEM_EXPORT int stem_ar_encode_image(const float *w_ctx, int ld_ctx, const float
                            M, t, H, W, Wp, pad);
     }
     STEM_LAUNCH_CHECK("ar_encode_image");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// DECODER, G images in lockstep.  The raster-order chain (the context of a position needs the previous position's symbols,
+// which needed that position's entropy parameters ...) makes ONE image latency-bound: ~35 us per position for four
+// dependent dispatches + a host round trip, whatever the arithmetic costs.  Independent images (the batch elements of
+// decompress(), i.e. different sequences / GOPs: spatiotemporalpriors.py:1015-1054 loops over them one after the other)
+// share that latency: the same four launches advance all G images by one position -- every wavefront still owns one
+// output row, loads its weight row ONCE and accumulates G dot products in the single-image order, so every image's floats
+// (hence symbols, indexes and bytes) are exactly those of stem_ar_decode_image.
+namespace {
+
+constexpr int GMAX = 8;
+struct SegB {
+    const float *x;      // image 0
+    int len, woff;
+    long stride;         // floats between consecutive images
+};
+struct DecodeExtraB {
+    const int32_t *sym_prev;   // [G][M] (pinned host), null: plain product
+    const float *mean_prev;    // gp + M of image 0, image stride gp_stride
+    float *pix_prev;           // image 0, image stride buf_stride
+    long gp_stride, buf_stride;
+    int M, prev_is_left;
+    const float *table;
+    int T;
+    float bound;
+    int32_t *idx;              // [G][M] (pinned host)
+};
+
+// One wavefront per output row (the products are latency-bound: what counts is how many independent loads are in flight,
+// row-blocked variants with fewer wavefronts were 2x slower).  G is a template parameter and each segment is walked in up to
+// MAXS fully unrolled 256-column steps, so that the weight loads of a segment, then each image's x loads, are issued back to
+// back instead of one exposed latency per step.  Every (row, image) sum accumulates its steps in ascending k: the order --
+// and therefore the bits -- of gemv3_decode_kernel.
+constexpr int MAXS = 4;          // segments of up to 1024 floats (5 M = 960 for M = 192, n0 = 768)
+template <int G>
+__global__ __launch_bounds__(256) void gemv3b_decode_kernel(const float *W, int ldw, const float *bias, SegB s0, SegB s1, SegB s2,
+                                                            float *y, long ystride, int N, int act, float slope, DecodeExtraB e)
+{
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float *wr = W + (size_t)n * ldw;
+    float acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = 0.f;
+    const SegB segs[3] = {s0, s1, s2};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const SegB s = segs[q];
+        if (s.len == 0) continue;
+        f32x4 wv[MAXS];
+        bool ok[MAXS];
+#pragma unroll
+        for (int t = 0; t < MAXS; ++t) {
+            const int k = lane * 4 + 256 * t;
+            ok[t] = k < s.len;
+            wv[t] = *reinterpret_cast<const f32x4 *>(wr + s.woff + (ok[t] ? k : 0));
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            f32x4 xv[MAXS];
+#pragma unroll
+            for (int t = 0; t < MAXS; ++t) xv[t] = *reinterpret_cast<const f32x4 *>(s.x + g * s.stride + (ok[t] ? lane * 4 + 256 * t : 0));
+#pragma unroll
+            for (int t = 0; t < MAXS; ++t) {
+                const float d = xv[t][0] * wv[t][0] + xv[t][1] * wv[t][1] + xv[t][2] * wv[t][2] + xv[t][3] * wv[t][3];
+                acc[g] = ok[t] ? acc[g] + d : acc[g];
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        float a = acc[g];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+        if (lane == 0) {
+            float v = a + (bias ? bias[n] : 0.f);
+            if (act == STEM_ACT_LRELU) v = v > 0.f ? v : v * slope;
+            y[g * ystride + n] = v;
+            if (e.table && n < e.M) {
+                const float sc = fmaxf(v, e.bound);
+                int k = e.T - 1;
+                for (int t = 0; t < e.T - 1; ++t) k -= (sc <= e.table[t]) ? 1 : 0;
+                e.idx[g * e.M + n] = k;
+            }
+        }
+    }
+}
+
+template <int G>
+void launch_gemv3b(hipStream_t st, int N, const float *W, int ldw, const float *bias, SegB a, SegB b, SegB c, float *y, long ystride, int act,
+                   float slope, const DecodeExtraB &e)
+{
+    hipLaunchKernelGGL((gemv3b_decode_kernel<G>), dim3(cdiv(N, 4)), dim3(256), 0, st, W, ldw, bias, a, b, c, y, ystride, N, act, slope, e);
+}
+void launch_gemv3b_g(int G, hipStream_t st, int N, const float *W, int ldw, const float *bias, SegB a, SegB b, SegB c, float *y, long ystride,
+                     int act, float slope, const DecodeExtraB &e)
+{
+    switch (G) {
+    case 1: launch_gemv3b<1>(st, N, W, ldw, bias, a, b, c, y, ystride, act, slope, e); break;
+    case 2: launch_gemv3b<2>(st, N, W, ldw, bias, a, b, c, y, ystride, act, slope, e); break;
+    case 3: launch_gemv3b<3>(st, N, W, ldw, bias, a, b, c, y, ystride, act, slope, e); break;
+    case 4: launch_gemv3b<4>(st, N, W, ldw, bias, a, b, c, y, ystride, act, slope, e); break;
+    case 5: launch_gemv3b<5>(st, N, W, ldw, bias, a, b, c, y, ystride, act, slope, e); break;
+    case 6: launch_gemv3b<6>(st, N, W, ldw, bias, a, b, c, y, ystride, act, slope, e); break;
+    case 7: launch_gemv3b<7>(st, N, W, ldw, bias, a, b, c, y, ystride, act, slope, e); break;
+    default: launch_gemv3b<8>(st, N, W, ldw, bias, a, b, c, y, ystride, act, slope, e); break;
+    }
+}
+
+__global__ void ar_finish_decode_batch_kernel(const float *gp, long gp_stride, const int32_t *sym, float *pix, long buf_stride, int M, int G)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * G) return;
+    const int g = i / M, c = i - g * M;
+    pix[g * buf_stride + c] = (float)sym[g * M + c] + gp[g * gp_stride + M + c];
+}
+
+}   // namespace
+
+STEM_EXPORT int stem_ar_decode_batch(const float *w_ctx, int ld_ctx, const float *b_ctx, const float *w0, int ld0, const float *b0, int n0,
+                                     const float *w1, int ld1, const float *b1, int n1, const float *w2, int ld2, const float *b2,
+                                     float *buf, int G, int H, int W, int M, int pad, const float *tp, const float *hp,
+                                     float *ctx, float *h1, float *h2, float *gp, const float *table, int T, float scale_bound, float slope,
+                                     int32_t *idx_host, int32_t *sym_host, stem_symbol_decoder_fn decode, void *const *decs,
+                                     const int32_t *cdfs, int ncdf, int cdf_stride, const int32_t *sizes, const int32_t *offsets, void *stream)
+{
+    STEM_CHECK_ARG(w_ctx && b_ctx && w0 && b0 && w1 && b1 && w2 && b2 && buf && hp && ctx && h1 && h2 && gp && table && idx_host && sym_host && decode && decs,
+                   "stem_ar_decode_batch: null pointer");
+    STEM_CHECK_ARG(G >= 1 && G <= GMAX, "stem_ar_decode_batch: 1..%d images per call, got %d", GMAX, G);
+    STEM_CHECK_ARG(5 * M <= 256 * MAXS && n0 <= 256 * MAXS && n1 <= 256 * MAXS, "stem_ar_decode_batch: segments longer than %d floats (M=%d n0=%d n1=%d)",
+                   256 * MAXS, M, n0, n1);
+    STEM_CHECK_ARG(H > 0 && W > 0 && M > 0 && M % 4 == 0 && n0 % 4 == 0 && n1 % 4 == 0 && ld_ctx % 4 == 0 && ld0 % 4 == 0 && ld1 % 4 == 0 &&
+                   ld2 % 4 == 0 && T >= 1 && pad == 2, "stem_ar_decode_batch: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int P = 2 * M, Wp = W + 2 * pad;
+    const long bufs = (long)(H + 2 * pad) * Wp * M, pris = (long)H * W * P;        // image strides of buf and of tp / hp
+    float *pix_prev = nullptr;
+    static const bool prof = getenv("STEM_AR_PROFILE") != nullptr;         // where a position's time goes (launch / wait / host coder)
+    double t_launch = 0, t_wait = 0, t_host = 0;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    DecodeExtraB none;
+    memset(&none, 0, sizeof(none));
+    none.M = M; none.gp_stride = P; none.buf_stride = bufs;
+    const SegB nil{nullptr, 0, 0, 0};
+    for (int h = 0; h < H; ++h)
+        for (int w = 0; w < W; ++w) {
+            const size_t pos = (size_t)h * W + w;
+            const double ta = prof ? now() : 0;
+            const float *r0 = buf + ((size_t)h * Wp + w) * M, *r1 = r0 + (size_t)Wp * M, *r2 = r1 + (size_t)Wp * M;
+            // The previous position's symbols arrive in the pinned host mailbox.  The one-image loop lets every wavefront of
+            // the context product substitute them on the fly (saving a launch); with G images that is 2M x G floats fetched
+            // over PCIe by each of the 2M rows (measured: 90 of 110 us per step at G = 8), so here a one-workgroup kernel
+            // commits y_hat = symbol + mean to the latent buffers first and the product reads device memory only.
+            const DecodeExtraB head = none;
+            if (pix_prev)
+                hipLaunchKernelGGL(ar_finish_decode_batch_kernel, dim3(cdiv(M * G, 256)), dim3(256), 0, st, gp, (long)P, sym_host, pix_prev, bufs, M, G);
+            launch_gemv3b_g(G, st, P, w_ctx, ld_ctx, b_ctx, SegB{r0, 5 * M, 0, bufs}, SegB{r1, 5 * M, 5 * M, bufs}, SegB{r2, 2 * M, 10 * M, bufs},
+                            ctx, (long)P, 0, 0.f, head);
+            const float *hp_pix = hp + pos * P;
+            if (tp)
+                launch_gemv3b_g(G, st, n0, w0, ld0, b0, SegB{tp + pos * P, P, 0, pris}, SegB{hp_pix, P, P, pris}, SegB{ctx, P, 2 * P, (long)P},
+                                h1, (long)n0, (int)STEM_ACT_LRELU, slope, none);
+            else
+                launch_gemv3b_g(G, st, n0, w0, ld0, b0, SegB{hp_pix, P, 0, pris}, SegB{ctx, P, P, (long)P}, nil, h1, (long)n0,
+                                (int)STEM_ACT_LRELU, slope, none);
+            launch_gemv3b_g(G, st, n1, w1, ld1, b1, SegB{h1, n0, 0, (long)n0}, nil, nil, h2, (long)n1, (int)STEM_ACT_LRELU, slope, none);
+            DecodeExtraB tail = none;
+            tail.table = table; tail.T = T; tail.bound = scale_bound; tail.idx = idx_host;
+            launch_gemv3b_g(G, st, P, w2, ld2, b2, SegB{h2, n1, 0, (long)n1}, nil, nil, gp, (long)P, 0, 0.f, tail);
+            const double tb = prof ? now() : 0;
+            if (hipStreamSynchronize(st) != hipSuccess) {
+                stem_set_error("stem_ar_decode_batch: device error at position (%d, %d): %s", h, w, hipGetErrorString(hipGetLastError()));
+                return -2;
+            }
+            const double tc = prof ? now() : 0;
+            for (int g = 0; g < G; ++g)
+                if (int rc = decode(decs[g], idx_host + (size_t)g * M, (size_t)M, cdfs, ncdf, cdf_stride, sizes, offsets, sym_host + (size_t)g * M)) {
+                    stem_set_error("stem_ar_decode_batch: host symbol decoder failed (%d) for image %d at position (%d, %d)", rc, g, h, w);
+                    return -3;
+                }
+            pix_prev = buf + ((size_t)(h + pad) * Wp + (w + pad)) * M;
+            if (prof) {
+                const double td = now();
+                t_launch += tb - ta; t_wait += tc - tb; t_host += td - tc;
+            }
+        }
+    if (prof)
+        fprintf(stderr, "[ar decode batch] G=%d positions=%d: launch %.1f us, wait %.1f us, host coder %.1f us per position step\n", G, H * W,
+                t_launch / (H * W), t_wait / (H * W), t_host / (H * W));
+    hipLaunchKernelGGL(ar_finish_decode_batch_kernel, dim3(cdiv(M * G, 256)), dim3(256), 0, st, gp, (long)P, sym_host, pix_prev, bufs, M, G);
+    STEM_LAUNCH_CHECK("ar_decode_batch");
     return 0;
 }

@@ -113,3 +113,28 @@ def test_fused_decode_loop_equals_stepwise_entry_points(cls_name, monkeypatch):
     np.testing.assert_array_equal(host(a), host(b))
     with pytest.raises(ValueError):          # 5x9 latents do not survive the hyper stages: loud error, not a corrupt stream
         m.compress(y_cur[:, :, :, :9].contiguous()[:, :, :3], y_cond[:, :, :, :9].contiguous()[:, :, :3])
+
+
+def test_lockstep_batch_decode_equals_per_image_decode(monkeypatch):
+    """decompress() of a batch advances the images in lockstep (stem_ar_decode_batch); per image it must reproduce what the
+    one-image-at-a-time loop (stem_ar_decode_image, the reference's order) decodes, bit for bit -- 5 images, non-square."""
+    import spatiotemporalentropymodel_amd.models as M
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_, closed_form_input
+    dev = torch.device("cuda:0")
+    m = closed_form_fill_(M.SpatioTemporalPriorModel_Res(64, 96)).to(dev).eval()
+    m.update(force=True)
+    y_cur = closed_form_input("lb:y", (5, 96, 8, 12), -6, 6).to(dev)
+    y_cond = closed_form_input("lb:c", (5, 96, 8, 12), -6, 6).to(dev)
+    with torch.no_grad():
+        enc = m.compress(y_cur, y_cond)
+        a = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()
+        monkeypatch.setenv("STEM_AR_NO_BATCH", "1")
+        b = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()
+        # and one image on its own equals its slot in the batch
+        one = m.decompress([enc["strings"][0][3:4], enc["strings"][1][3:4]], enc["shape"], y_cond[3:4])["y_hat"]
+    assert torch.equal(a, b)
+    # (decoded alone, the hyper-prior convolutions run at batch 1 and pick another tile / split-K plan: the means move by
+    # an ulp, the symbols do not)
+    assert float((a[3:4] - one).abs().max()) <= 1e-4
+    # within half a quantisation step of the input everywhere (y_hat = round(res - mu) + mu + y_cond)
+    assert float((a - y_cur).abs().max()) <= 0.5 + 1e-4

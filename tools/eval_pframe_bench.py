@@ -3,7 +3,11 @@
 pad to multiples of 64 -> getY -> STEM forward (rate estimate) -> compress -> decompress -> getX -> crop -> PSNR / bpp.
 Times are per frame as the reference measures them (encode = getY + forward + compress, decode = decompress + getX).
 
-    python tools/eval_pframe_bench.py [--frames 4] [--height 1080] [--width 1920]
+    python tools/eval_pframe_bench.py [--frames 4] [--height 1080] [--width 1920] [--sequences G]
+
+--sequences G > 1 codes G independent sequences side by side (batch dimension of compress / decompress): the decoder's
+raster loop is latency-bound per position, and G images share that latency (csrc/ar.hip: stem_ar_decode_batch), so the
+per-frame decode time drops ~G-fold; times are reported per frame (wall time of the batched call / G).
 """
 import argparse
 import math
@@ -25,38 +29,51 @@ def main():
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--sequences", type=int, default=1)
     a = ap.parse_args()
+    G = a.sequences
     dev = torch.device("cuda:0")
     imodel = closed_form_fill_(models["mbt2018"](quality=4)).to(dev).eval()
     stem = closed_form_fill_(SpatioTemporalPriorModel_Res()).to(dev).eval()
     stem.update(force=True)
     yy, xx = torch.meshgrid(torch.arange(a.height, device=dev), torch.arange(a.width, device=dev), indexing="ij")
-    frames = [torch.stack([0.5 + 0.4 * torch.sin((xx + 3 * t) / (40.0 + 10 * c)) * torch.cos((yy + t) / (55.0 - 5 * c)) for c in range(3)]).unsqueeze(0)
-              for t in range(a.frames + 1)]
+    frames = [torch.stack([torch.stack([0.5 + 0.4 * torch.sin((xx + 3 * t + 17 * g) / (40.0 + 10 * c + g)) * torch.cos((yy + t) / (55.0 - 5 * c))
+                                        for c in range(3)]) for g in range(G)]) for t in range(a.frames + 1)]
+    enc_t, dec_t = [], []
+
+    def getY(x):        # the transforms take <= 4 full-HD frames per call (2 GiB buffer-descriptor range of the conv kernels)
+        return torch.cat([imodel.getY(x[i:i + 4])[0] for i in range(0, x.shape[0], 4)])
+
+    def getX(y):
+        return torch.cat([imodel.getX(y[i:i + 4].contiguous(memory_format=torch.channels_last)) for i in range(0, y.shape[0], 4)])
+
     with torch.no_grad():
-        y_cond, _ = imodel.getY(bitstream.pad(frames[0], 64))        # stands in for the decoded I frame's latent
+        y_cond = getY(bitstream.pad(frames[0], 64))        # stands in for the decoded I frame's latent
         y_cond = torch.round(y_cond)
         for t in range(1, a.frames + 1):
             x = frames[t]
             xp = bitstream.pad(x, 64)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            y_cur, _ = imodel.getY(xp)
+            y_cur = getY(xp)
             out_forward = stem(y_cur, y_cond)
             enc = stem.compress(y_cur, y_cond)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             dec = stem.decompress(enc["strings"], enc["shape"], y_cond)
-            x_hat = bitstream.crop(imodel.getX(dec["y_hat"]), (a.height, a.width))
+            x_hat = bitstream.crop(getX(dec["y_hat"]), (a.height, a.width))
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             y_cond = dec["y_hat"]
             npix = a.height * a.width
-            bpp = sum(len(s[0]) for s in enc["strings"]) * 8.0 / npix
-            est = sum(float(torch.log(l).sum()) / (-math.log(2) * npix) for l in out_forward["likelihoods"].values())
+            bpp = sum(len(b) for s in enc["strings"] for b in s) * 8.0 / (npix * G)
+            est = sum(float(torch.log(l).sum()) / (-math.log(2) * npix * G) for l in out_forward["likelihoods"].values())
             mse = float(((x - x_hat) ** 2).mean())
-            print(f"P frame {t}: encode {t1 - t0:.3f} s, decode {t2 - t1:.3f} s, bpp {bpp:.4f} (estimate {est:.4f}), "
-                  f"PSNR {10 * math.log10(1.0 / mse):.2f} dB (untrained closed-form weights)")
+            enc_t.append((t1 - t0) / G)
+            dec_t.append((t2 - t1) / G)
+            print(f"P frame {t} x {G} sequences: encode {(t1 - t0) / G:.3f} s, decode {(t2 - t1) / G:.3f} s per frame, bpp {bpp:.4f} "
+                  f"(estimate {est:.4f}), PSNR {10 * math.log10(1.0 / mse):.2f} dB (untrained closed-form weights)")
+    print(f"mean over {a.frames} P frames x {G} sequences: encode {sum(enc_t) / len(enc_t):.3f} s, decode {sum(dec_t) / len(dec_t):.3f} s per frame")
     print("reference (SURVEY.md 3.2, torch CPU in the survey container): 13 s encode + 39 s decode per 1080p P frame")
 
 
