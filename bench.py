@@ -78,7 +78,7 @@ def cpu_baseline(budget_s=45.0):
     reference; elementwise entropy-model pieces from oracle/stem_oracle.c), all host cores, warm-up then median of 3:
 
       (i)  config 2: one P-frame optimisation step at batch B (g_a of the frame, STEM forward, EMLoss, backward, global-norm
-           clip + Adam) -- B = the largest of 16/8/4/2 whose 4 runs fit the time budget;
+           clip + Adam) -- B = the largest of 16/8/4/2 whose warm-up + 5 timed runs fit the time budget;
       (ii) config 1: forward of one 7x256x256 septuplet through the small model (7 g_a, 6 STEM forwards, 6 g_s).
 
     value = frames/s of (i) over a septuplet schedule (7 g_a + 6 P-steps per 7 frames), like the GPU number."""
@@ -155,9 +155,9 @@ def cpu_baseline(budget_s=45.0):
         t0 = time.perf_counter()
         p_step(2)                                        # warms the BLAS threads / page cache and sizes the real run
         est = (time.perf_counter() - t0) / 2
-        B = next((b for b in (16, 8, 4, 2) if 4 * est * b <= budget_s), 2)
+        B = next((b for b in (16, 8, 4, 2) if 6 * est * b <= 1.5 * budget_s), 2)
         ga_times = []
-        t_step, step_times = _median_time(lambda: ga_times.append(p_step(B)))
+        t_step, step_times = _median_time(lambda: ga_times.append(p_step(B)), repeats=5)
         t_ga = float(np.median(ga_times[1:]))
         t_stem = t_step - t_ga
         # ---- (ii) config 1: small model, one septuplet forward (eval)
@@ -179,14 +179,79 @@ def cpu_baseline(budget_s=45.0):
             "p_step_s": t_step, "p_step_runs_s": [round(t, 4) for t in step_times], "g_a_s": t_ga,
             "config1_septuplet_forward_s": t_sept1,
             "sample": f"oracle/stem_port_blas.py (fp32 im2col + SGEMM on the host BLAS, {blas_threads} threads) on {_cpu_model()}: "
-                      f"config-2 P-frame step at B={B} (g_a {t_ga:.2f} s + STEM fwd/bwd/clip/Adam {t_stem:.2f} s; 1 warm-up, median of 3), "
+                      f"config-2 P-frame step at B={B} (g_a {t_ga:.2f} s + STEM fwd/bwd/clip/Adam {t_stem:.2f} s; 1 warm-up, median of 5), "
                       f"septuplet = 7 g_a + 6 P-steps -> {FRAMES * B / t_sept:.2f} frames/s; config-1 septuplet forward (small model) "
                       f"{t_sept1:.2f} s = {FRAMES / t_sept1:.2f} frames/s"}
+
+
+def bench_roi(args):
+    """--config roi: BASELINE.json configs[4] -- one GOP training iteration of the variable-rate pair (stem_roi_i, stem_roi;
+    stem_roi/train_stem_roi.py:509-631 = selfcheck.roi_gop_step) per step on B=16 GOPs of 7 frames 256x256 per GPU with the
+    four lambda points in one batch (uniform quality maps 0.30 / 0.45 / 0.55 / 0.70, four samples each,
+    stem_roi/eval_stem_roi.py:368-376).  roofline: the forward launch of the full-resolution 3x3 convolution 192 -> 160 of
+    the quality-feature net (qmap_feature_ga1.2: the largest single layer of the model, 2*192*160*9 flop per pixel)."""
+    from spatiotemporalentropymodel_amd import _lib
+    from spatiotemporalentropymodel_amd import distributed as D
+    from spatiotemporalentropymodel_amd.losses import PixelwiseRateDistortionLoss
+    from spatiotemporalentropymodel_amd.models import stem_roi, stem_roi_i
+    from spatiotemporalentropymodel_amd.optim import configure_optimizers
+    from spatiotemporalentropymodel_amd.selfcheck import roi_gop_step
+    _lib.hip()
+    rank, world, local = D.init_from_env()
+    assert world == args.gpus and torch.cuda.is_available()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    B = args.roi_batch
+    torch.manual_seed(1234)
+    imodel, pmodel = stem_roi_i().to(dev).train(), stem_roi().to(dev).train()
+    D.broadcast_parameters(imodel)
+    D.broadcast_parameters(pmodel)
+    for i, m in enumerate((imodel, pmodel)):
+        m.entropy_bottleneck.noise_seed = m.gaussian_conditional.noise_seed = D.shard_seed(1234 + 100 * i, rank)
+    a = types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3)
+    opts = configure_optimizers(imodel, a, max_norm=None) + configure_optimizers(pmodel, a, max_norm=None)
+    acc = D.GopGradAccumulator([opts[0].flat, opts[2].flat], [opts[1].flat, opts[3].flat]) if world > 1 else None
+    frames = synthetic_septuplet(B, SIZE, D.shard_seed(1234, rank), dev)
+    levels = (0.30, 0.45, 0.55, 0.70)
+    qmap = torch.cat([torch.full((B // 4, 1, SIZE, SIZE), q) for q in levels]).to(dev)
+    crit = PixelwiseRateDistortionLoss()
+    probe = []
+    pmodel.qmap_feature_ga1.probe = (2, probe)
+    for _ in range(args.warmup):
+        roi_gop_step(imodel, pmodel, crit, opts, frames, qmap, 1.0, accumulator=acc)
+    probe.clear()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        log = roi_gop_step(imodel, pmodel, crit, opts, frames, qmap, 1.0, accumulator=acc)
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank != 0:
+        return
+    kern_ms = float(np.mean([x.elapsed_time(y) for x, y in probe]))
+    flop = 2.0 * 192 * 160 * 9 * SIZE * SIZE * B
+    achieved = flop / (kern_ms * 1e-3) / 1e12
+    print(json.dumps({
+        "metric": "frames/s", "value": FRAMES * B * world * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[4]: variable-rate stem_roi_i + stem_roi GOP training iteration (I + 6 P frames 256x256, BPTT across the "
+                               "GOP, clip after every frame, one step of 4 Adam optimisers), 4 lambda points (quality 0.30/0.45/0.55/0.70) in one batch",
+                   "per_gpu_batch": B, "global_batch": B * world, "frames_per_step": FRAMES * B * world, "parallelism": f"dp{world}",
+                   "final_loss": float(log[-1][0]["loss"].detach())},
+        "roofline": {"bound": "mfma", "kernel": "igemm conv3x3 192->160 at 256x256 (stem_roi.qmap_feature_ga1.2, forward), B=%d" % B,
+                     "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                     "flop_per_launch": flop, "avg_launch_ms": kern_ms, "launches_timed": len(probe), "traffic": None}}))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--config", default="stem", choices=["stem", "roi"], help="stem = BASELINE configs[1] (the metric's workload, default); "
+                    "roi = configs[4], the variable-rate GOP iteration")
+    ap.add_argument("--roi-batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -195,6 +260,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the P-frame step from its hipGraph (graphs.GraphedPFrameStep) instead of "
                     "issuing it kernel by kernel: 2 ms instead of 11-22 ms of host time per step, same GPU time (DESIGN.md §7)")
     args = ap.parse_args()
+    if args.config == "roi":
+        return bench_roi(args)
 
     from spatiotemporalentropymodel_amd import _lib
     from spatiotemporalentropymodel_amd import distributed as D

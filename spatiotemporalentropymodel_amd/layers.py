@@ -458,7 +458,15 @@ class FusedSequential(nn.Sequential):
                 continue
             if isinstance(m, (Conv2d, ConvTranspose2d)) and i + 1 < len(mods) and isinstance(mods[i + 1], (nn.LeakyReLU, nn.ReLU)):
                 nxt = mods[i + 1]           # LeakyReLU(slope) or ReLU (= slope 0) folded into the conv epilogue
-                x = m(x, act=F.ACT_LRELU, slope=float(nxt.negative_slope) if isinstance(nxt, nn.LeakyReLU) else 0.0)
+                slope = float(nxt.negative_slope) if isinstance(nxt, nn.LeakyReLU) else 0.0
+                if self.probe is not None and self.probe[0] == i:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    x = m(x, act=F.ACT_LRELU, slope=slope)
+                    e1.record()
+                    self.probe[1].append((e0, e1))
+                else:
+                    x = m(x, act=F.ACT_LRELU, slope=slope)
                 i += 2
             else:
                 x = m(x)
