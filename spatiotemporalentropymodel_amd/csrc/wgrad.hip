@@ -10,6 +10,8 @@
 // (bit-reproducible, no float atomics).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "stem_common.h"
 
 namespace {
@@ -192,66 +194,87 @@ void wgrad_kernel(const WgradArgs a)
 #pragma unroll
             for (int q = 0; q < NPA; ++q) *reinterpret_cast<f32x4 *>(&Ps[(buf * KP + rowA + q * RPA) * PA + colA]) = r[q];
         };
-        auto stB = [&](int buf, const f32x4 (&r)[NPB]) {
+        // `gsq` (GDN backward only) and `do_bias` (the tap-0 / first-column workgroups only) are workgroup-uniform, but as
+        // run-time conditions inside the loop they were if-converted into 64 VALU selects / multiplies / adds per pair of
+        // chunks for EVERY workgroup (3.2 VALU instructions per MFMA; each costs ~4 issue cycles next to a 64-cycle MFMA).
+        // The loop is therefore instantiated per (GSQ, BIAS) and chosen by two uniform branches.
+        auto main_loop = [&](auto gsq_c, auto bias_c) {
+            constexpr bool GSQ = decltype(gsq_c)::value, BIAS = decltype(bias_c)::value;
+            auto stB = [&](int buf, const f32x4 (&r)[NPB]) {
 #pragma unroll
-            for (int q = 0; q < NPB; ++q) *reinterpret_cast<f32x4 *>(&Gs[(buf * KP + rowB + q * RPB) * PB + colB]) = a.gsq ? r[q] * r[q] : r[q];
-        };
-        auto step = [&](int cur, f32x4 (&sa)[NPA], f32x4 (&sb)[NPB], i32x2 (&p)[NPB], int cn) {
-            const float *Ab = Ps + (cur * KP + lh) * PA + wm0 + lr;
-            const float *Bb = Gs + (cur * KP + lh) * PB + wn0 + lr;
-#pragma unroll
-            for (int ks = 0; ks < KP / 2; ++ks) {
-                float af[TM], bf[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = Ab[ks * 2 * PA + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = Bb[ks * 2 * PB + j * 32];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-                if (ks == 2) {
-                    stA(cur ^ 1, sa);
-                    if (do_bias && cn - 2 < c_end) {      // `sa` holds chunk cn - 2: count it once, only if it is ours
-#pragma unroll
-                        for (int q = 0; q < NPA; ++q) bsum += sa[q];
-                    }
+                for (int q = 0; q < NPB; ++q) {
+                    if constexpr (GSQ)
+                        *reinterpret_cast<f32x4 *>(&Gs[(buf * KP + rowB + q * RPB) * PB + colB]) = r[q] * r[q];
+                    else
+                        *reinterpret_cast<f32x4 *>(&Gs[(buf * KP + rowB + q * RPB) * PB + colB]) = r[q];
                 }
-                if (ks == 5) stB(cur ^ 1, sb);
-                if (ks == 9) glA(cn, sa);
-                if (ks == 12) glB(sb, p);
-                if (ks == 14) tl(cn + 2, p);
-            }
-        };
-        if (c_begin < c_end) {
-            tl(c_begin, ptA);
-            glA(c_begin, ra);
-            glB(rb, ptA);
-            stA(0, ra);
-            if (do_bias) {
+            };
+            auto step = [&](int cur, f32x4 (&sa)[NPA], f32x4 (&sb)[NPB], i32x2 (&p)[NPB], int cn) {
+                const float *Ab = Ps + (cur * KP + lh) * PA + wm0 + lr;
+                const float *Bb = Gs + (cur * KP + lh) * PB + wn0 + lr;
 #pragma unroll
-                for (int q = 0; q < NPA; ++q) bsum += ra[q];
+                for (int ks = 0; ks < KP / 2; ++ks) {
+                    float af[TM], bf[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[i] = Ab[ks * 2 * PA + i * 32];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[j] = Bb[ks * 2 * PB + j * 32];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    if (ks == 2) {
+                        stA(cur ^ 1, sa);
+                        if constexpr (BIAS) {
+                            if (cn - 2 < c_end) {      // `sa` holds chunk cn - 2: count it once, only if it is ours
+#pragma unroll
+                                for (int q = 0; q < NPA; ++q) bsum += sa[q];
+                            }
+                        }
+                    }
+                    if (ks == 5) stB(cur ^ 1, sb);
+                    if (ks == 9) glA(cn, sa);
+                    if (ks == 12) glB(sb, p);
+                    if (ks == 14) tl(cn + 2, p);
+                }
+            };
+            if (c_begin < c_end) {
+                tl(c_begin, ptA);
+                glA(c_begin, ra);
+                glB(rb, ptA);
+                stA(0, ra);
+                if constexpr (BIAS) {
+#pragma unroll
+                    for (int q = 0; q < NPA; ++q) bsum += ra[q];
+                }
+                stB(0, rb);
+                tl(c_begin + 1, ptA);
+                tl(c_begin + 2, ptB);
+                glA(c_begin + 1, ra);
+                glB(rb, ptA);
+                glA(c_begin + 2, raB);
+                glB(rbB, ptB);
+                tl(c_begin + 3, ptA);
+                tl(c_begin + 4, ptB);
             }
-            stB(0, rb);
-            tl(c_begin + 1, ptA);
-            tl(c_begin + 2, ptB);
-            glA(c_begin + 1, ra);
-            glB(rb, ptA);
-            glA(c_begin + 2, raB);
-            glB(rbB, ptB);
-            tl(c_begin + 3, ptA);
-            tl(c_begin + 4, ptB);
-        }
-        __syncthreads();
-        int c = c_begin;
-        for (; c + 1 < c_end; c += 2) {
-            step(0, ra, rb, ptA, c + 3);          // chunk c; stage c+1 -> buffer 1; prefetch c+3 (table c+5)
             __syncthreads();
-            step(1, raB, rbB, ptB, c + 4);        // chunk c+1; stage c+2 -> buffer 0; prefetch c+4 (table c+6)
-            __syncthreads();
+            int c = c_begin;
+            for (; c + 1 < c_end; c += 2) {
+                step(0, ra, rb, ptA, c + 3);          // chunk c; stage c+1 -> buffer 1; prefetch c+3 (table c+5)
+                __syncthreads();
+                step(1, raB, rbB, ptB, c + 4);        // chunk c+1; stage c+2 -> buffer 0; prefetch c+4 (table c+6)
+                __syncthreads();
+            }
+            if (c < c_end) step(0, ra, rb, ptA, c + 3);      // odd tail (its prefetches are masked out of range)
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        if (a.gsq) {
+            if (do_bias) main_loop(T_{}, T_{}); else main_loop(T_{}, F_{});
+        } else {
+            if (do_bias) main_loop(F_{}, T_{}); else main_loop(F_{}, F_{});
         }
-        if (c < c_end) step(0, ra, rb, ptA, c + 3);      // odd tail (its prefetches are masked out of range)
     } else if (c_begin < c_end) {
         gload(c_begin);
         sstore(0);
