@@ -356,6 +356,9 @@ int stem_axpy(float *y, const float *x, float a, size_t n, void *stream);
  * scale = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) (max_norm <= 0: no clipping), g *= scale * gscale. */
 int stem_adam_step(float *p, const float *g, float *m, float *v, size_t n, const double *sumsq, float max_norm,
                    float gscale, float lr, float beta1, float beta2, float eps, int step, void *stream);
+/* stem_adam_step that also clears `g` in the same pass (explicit training schedule: the next backward accumulates into it) */
+int stem_adam_step_zero(float *p, float *g, float *m, float *v, size_t n, const double *sumsq, float max_norm,
+                        float gscale, float lr, float beta1, float beta2, float eps, int step, void *stream);
 /* The same update with the step count and learning rate in DEVICE memory, for optimiser steps captured in a hipGraph
  * (kernel arguments are frozen at capture): step_dev[0] is incremented first, then the update uses
  * lr_dev[0] / (1 - beta1^t) and 1 / sqrt(1 - beta2^t); scal_dev = 2 floats of scratch.  A learning-rate scheduler

@@ -95,6 +95,7 @@ _HIP_SIG = {
     "stem_clip_scale": [vp, sz, vp, cf, vp],
     "stem_axpy": [vp, vp, cf, sz, vp],
     "stem_adam_step": [vp, vp, vp, vp, sz, vp, cf, cf, cf, cf, cf, cf, ci, vp],
+    "stem_adam_step_zero": [vp, vp, vp, vp, sz, vp, cf, cf, cf, cf, cf, cf, ci, vp],
     "stem_adam_step_dev": [vp, vp, vp, vp, sz, vp, cf, cf, vp, cf, cf, cf, vp, vp, vp],
     "stem_packed_weight_elems": [ci, ci, ci, ci, ci],
     "stem_abi_version": [],

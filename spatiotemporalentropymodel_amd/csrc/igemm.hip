@@ -585,9 +585,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
                 for (int r = 0; r < 16; ++r) nrm[i][j][r] = 0.f;
         const __amdgpu_buffer_rsrc_t rgm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gamma), 0, a.gmbytes, 0x00020000);
         const int nkg = (a.N + KC - 1) / KC;
-        for (int kc = 0; kc < nkg; ++kc) {
+        // gamma chunk kc + 1 is fetched into registers while the MFMAs of chunk kc run (the first layer has only 4 conv
+        // chunks per tile: this second contraction IS its main loop, and an exposed L2 latency per chunk cost 20 % of it)
+        auto gload_gamma = [&](int kc, f32x4 (&g4)[BR]) {
             const int kcol = kc * KC + 4 * c4;
-            f32x4 g4[BR];
 #pragma unroll
             for (int j = 0; j < BR; ++j) {
                 const int n = srow + RPP * j;
@@ -595,6 +596,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
                 const int off = (((n * a.N + kcol) * 4) & mk) | (0x7FFFFF00 & ~mk);
                 g4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgm, off, 0, 0));
             }
+        };
+        f32x4 g4[BR], g4n[BR];
+        gload_gamma(0, g4);
+        for (int kc = 0; kc < nkg; ++kc) {
             __syncthreads();                           // previous chunk's Gs (and, first time, X2) settled
 #pragma unroll
             for (int j = 0; j < BR; ++j) {
@@ -608,6 +613,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
                 *reinterpret_cast<f32x4 *>(&Gs[(srow + RPP * j) * PITCH + 4 * c4]) = v;
             }
             __syncthreads();
+            gload_gamma(kc + 1 < nkg ? kc + 1 : kc, g4n);      // in flight during the MFMAs below (clamped: last one unused)
             const float *Ab = X2 + (wm0 + lr) * XP + kc * KC + 4 * lh;
             const float *Bb = Gs + (wn0 + lr) * PITCH + 4 * lh;
 #pragma unroll
@@ -625,6 +631,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
                         for (int j = 0; j < TN; ++j)
                             nrm[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], nrm[i][j], 0, 0, 0);
             }
+#pragma unroll
+            for (int j = 0; j < BR; ++j) g4[j] = g4n[j];
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -784,6 +792,8 @@ Plan make_plan(const IgemmArgs &g, bool c4, int only_cfg = -1)
         if (only_cfg >= 0 && c != only_cfg) continue;
         if (forced >= 0 && only_cfg < 0 && c != forced && !g.fuse) continue;
         if (g.fuse && !((c == 1 || c == 4) && kCfg[c].bn >= g.N)) continue;      // fused GDN: all channels in one 192-wide tile
+        static const int fuse_cfg = getenv("STEM_IGEMM_FUSE_CFG") ? atoi(getenv("STEM_IGEMM_FUSE_CFG")) : -1;     // tuning aid
+        if (g.fuse && fuse_cfg >= 0 && c != fuse_cfg) continue;
         const long tm = cdiv(maxM, kCfg[c].bm), tn = cdiv(g.N, kCfg[c].bn);
         const long tiles = tm * tn * g.nphase;
         const int min_cps = kCfg[c].bm * kCfg[c].bn >= 128 * 96 ? 8 : 4;

@@ -45,9 +45,11 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const double *part, in
 //   m.lerp_(g, 1-b1); v = v*b2 + (1-b2) g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 // dev_scal != nullptr: step_size / inv_sqrt_bc2 come from device memory (written by adam_prepare_kernel), so that a
 // captured hipGraph replays with the CURRENT step count and learning rate instead of the ones baked in at capture.
-__global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, float *m, float *v, size_t n, const double *sumsq,
+// zero_g: the gradient buffer is cleared in the same pass (the explicit training schedule accumulates into it next step;
+// saves the separate 72 MB memset launch on the critical path)
+__global__ __launch_bounds__(256) void adam_kernel(float *p, float *g, float *m, float *v, size_t n, const double *sumsq,
                                                    float max_norm, float gscale, float step_size, float b1, float b2,
-                                                   float inv_sqrt_bc2, float eps, const float *dev_scal)
+                                                   float inv_sqrt_bc2, float eps, const float *dev_scal, int zero_g)
 {
     if (dev_scal) {
         step_size = dev_scal[0];
@@ -60,6 +62,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float *p, const float *g, flo
     }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float gi = g[i] * coef;
+        if (zero_g) g[i] = 0.f;
         const float mi = m[i] + (gi - m[i]) * (1.f - b1);
         const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
         m[i] = mi;
@@ -130,9 +133,23 @@ STEM_EXPORT int stem_adam_step(float *p, const float *g, float *m, float *v, siz
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     size_t nb = cdivz(n, 256);
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm,
-                       gscale, (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, (const float *)nullptr);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, const_cast<float *>(g), m, v, n, sumsq, max_norm,
+                       gscale, (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, (const float *)nullptr, 0);
     STEM_LAUNCH_CHECK("adam");
+    return 0;
+}
+
+STEM_EXPORT int stem_adam_step_zero(float *p, float *g, float *m, float *v, size_t n, const double *sumsq, float max_norm,
+                                    float gscale, float lr, float beta1, float beta2, float eps, int step, void *stream)
+{
+    STEM_CHECK_ARG(p && g && m && v && step >= 1, "stem_adam_step_zero: bad arguments");
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    size_t nb = cdivz(n, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm,
+                       gscale, (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, (const float *)nullptr, 1);
+    STEM_LAUNCH_CHECK("adam_zero");
     return 0;
 }
 
@@ -145,8 +162,8 @@ STEM_EXPORT int stem_adam_step_dev(float *p, const float *g, float *m, float *v,
     hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, lr_dev, beta1, beta2, scal_dev);
     size_t nb = cdivz(n, 256);
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm,
-                       gscale, 0.f, beta1, beta2, 0.f, eps, (const float *)scal_dev);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, const_cast<float *>(g), m, v, n, sumsq, max_norm,
+                       gscale, 0.f, beta1, beta2, 0.f, eps, (const float *)scal_dev, 0);
     STEM_LAUNCH_CHECK("adam_dev");
     return 0;
 }

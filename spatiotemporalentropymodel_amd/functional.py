@@ -616,9 +616,10 @@ def axpy_(y, x, a):
     return y
 
 
-def adam_step(p, g, m, v, sumsq_acc, max_norm, gscale, lr, beta1, beta2, eps, step):
-    _chk(_lib.hip().stem_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), _ptr(sumsq_acc),
-                                   max_norm, gscale, lr, beta1, beta2, eps, step, _stream()))
+def adam_step(p, g, m, v, sumsq_acc, max_norm, gscale, lr, beta1, beta2, eps, step, zero_grad=False):
+    fn = _lib.hip().stem_adam_step_zero if zero_grad else _lib.hip().stem_adam_step
+    _chk(fn(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), _ptr(sumsq_acc),
+            max_norm, gscale, lr, beta1, beta2, eps, step, _stream()))
 
 
 def adam_step_dev(p, g, m, v, sumsq_acc, max_norm, gscale, lr_dev, beta1, beta2, eps, step_dev, scal_dev):

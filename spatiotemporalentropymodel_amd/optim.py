@@ -103,10 +103,11 @@ class FusedClipAdam(torch.optim.Optimizer):
             d["lr"].fill_(lr)
             d["lr_host"] = lr
 
-    def step(self, closure=None, *, grad_scale: float = 1.0, norm_is_current: bool = False):
+    def step(self, closure=None, *, grad_scale: float = 1.0, norm_is_current: bool = False, zero_grad: bool = False):
         """grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).  norm_is_current: the caller
         has just called grad_norm() on these very gradients (as the training loop does to report the norm), so the
-        reduction is not repeated."""
+        reduction is not repeated.  zero_grad: clear the flat gradient buffer in the same pass (explicit schedules that
+        accumulate into it next step; not available with device-resident state)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -130,7 +131,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         else:
             F.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self._sumsq if use_clip else None,
                         float(self.max_norm) if use_clip else 0.0, float(grad_scale), float(g["lr"]), g["betas"][0], g["betas"][1],
-                        float(g["eps"]), self.t)
+                        float(g["eps"]), self.t, zero_grad=zero_grad)
         bump_weight_epoch(self.flat.params)
         return loss
 

@@ -43,6 +43,11 @@ class FusedPFrameStep:
         if eb.quantiles.grad is None or getattr(eb.quantiles, "_flat_grad_view", None) is None:
             raise ValueError("FusedPFrameStep needs the flat-buffer optimisers of optim.configure_optimizers(fused=True)")
         self._aux_loss = torch.zeros(1, dtype=torch.float32, device=eb.quantiles.device)
+        self._grad_clean = False          # True once our own Adam pass has cleared the flat gradient buffer
+        #: clear the gradient buffer inside the Adam pass (saves the 72 MB memset of the next step); set False to leave the
+        #: gradients in place after step() for inspection -- they are then zeroed at the start of the next step instead
+        self.clear_grad_in_adam = True
+        self._aux_stream = torch.cuda.Stream(device=eb.quantiles.device)
 
     def step(self, y_cur, y_cond, num_pixels, grad_scale=1.0, reducer=None):
         """y_cur / y_cond: the frame's and the conditioning latents [B,C,h,w]; num_pixels = N*H*W of the FRAMES (EMLoss
@@ -50,7 +55,11 @@ class FusedPFrameStep:
         are 0-dim fp64 device tensors, grad_norm a LazyNorm."""
         stem, opt, aux_opt, eng = self.stem, self.opt, self.aux_opt, self.eng
         eb = stem.entropy_bottleneck
-        opt.flat.zero_grad()                                        # one memset; the aux gradient is overwritten below
+        if self._grad_clean and opt._dev is None:                   # cleared by the previous step's Adam pass
+            for p in opt.flat.params:
+                p.grad = p._flat_grad_view
+        else:
+            opt.flat.zero_grad()                                    # one memset; the aux gradient is overwritten below
         coef = -1.0 / (math.log(2.0) * num_pixels)
         y_hat, lik_y, lik_z, k = eng.forward(y_cur, y_cond, True, rate_coef=(coef, -1.0 / num_pixels))
         eng.backward(k, k["dlik_y"], k["dlik_z"])                   # an attached OverlappedGradReducer exchanges slices in here
@@ -59,13 +68,21 @@ class FusedPFrameStep:
         join_wgrad_stream()
         F.sumsq(opt.flat.grad, opt._sumsq, overwrite=True)
         gn = LazyNorm(opt._sumsq[0], grad_scale)
-        opt.step(grad_scale=grad_scale, norm_is_current=True)
+        clean = opt._dev is None and self.clear_grad_in_adam
+        opt.step(grad_scale=grad_scale, norm_is_current=True, zero_grad=clean)
+        self._grad_clean = clean
         # auxiliary loss on the UPDATED parameters (stem/trainSTEM.py:216-218); its gradient goes straight into the aux
-        # optimiser's flat buffer (the only aux parameter is `entropy_bottleneck.quantiles`)
-        pack = F.eb_pack(eb._tensors14())
-        F.eb_aux_loss_grad(eb.quantiles.detach(), pack, eb.target, eb.quantiles._flat_grad_view, loss_out=self._aux_loss)
-        eb.quantiles.grad = eb.quantiles._flat_grad_view
-        aux_opt.step()
+        # optimiser's flat buffer (the only aux parameter is `entropy_bottleneck.quantiles`).  One workgroup of latency-bound
+        # work: it runs on its own stream, next to the weight re-packing of the next forward, and is joined lazily.
+        main = torch.cuda.current_stream(y_hat.device)
+        self._aux_stream.wait_stream(main)
+        with torch.cuda.stream(self._aux_stream):
+            pack = F.eb_pack(eb._tensors14())
+            F.eb_aux_loss_grad(eb.quantiles.detach(), pack, eb.target, eb.quantiles._flat_grad_view, loss_out=self._aux_loss)
+            eb.quantiles.grad = eb.quantiles._flat_grad_view
+            aux_opt.step()
+        eng.ensure_packed()                      # the next forward's weight packing, issued now: the aux work hides behind it
+        main.wait_stream(self._aux_stream)
         loss3 = k["loss3"]
         out = {"y_hat": y_hat, "likelihoods": {"y": lik_y, "z": lik_z}}
         oc = {"y_bpp_loss": loss3[0], "z_bpp_loss": loss3[1], "loss": loss3[2]}

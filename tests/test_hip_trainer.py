@@ -37,6 +37,7 @@ def test_fused_step_tracks_generic_step_philox_noise():
     im_b, stem_b, opt_b, aux_b = _pair(64, 96, 64, 96, False, False)
     assert torch.equal(opt_a.flat.data, opt_b.flat.data)
     fused = FusedPFrameStep(stem_b, opt_b, aux_b)
+    fused.clear_grad_in_adam = False                      # step 1's gradients are inspected below
     crit = EMLoss()
     with torch.no_grad():
         _, y_cond_a = im_a.getY(frames[0])
@@ -48,6 +49,8 @@ def test_fused_step_tracks_generic_step_philox_noise():
         with torch.no_grad():
             y_cur, _ = im_b.getY(frames[t])
         out_b, oc_b, aux_lb, gn_b = fused.step(y_cur, y_cond_b, 2 * 128 * 128)
+        if t == 2:
+            fused.clear_grad_in_adam = True               # the default: Adam clears the buffer, the next step skips its memset
         if t == 1:          # identical parameters: identical forward, down to the noise
             assert torch.equal(out_a["y_hat"], out_b["y_hat"])
             assert torch.equal(out_a["likelihoods"]["y"], out_b["likelihoods"]["y"])
@@ -65,6 +68,7 @@ def test_fused_step_tracks_generic_step_philox_noise():
     assert float(err.max()) <= 6.3e-4 and float((err <= 2e-6).float().mean()) >= 0.97, (float(err.max()), float((err <= 2e-6).float().mean()))
     assert float((aux_a.flat.data - aux_b.flat.data).abs().max()) <= 1e-4
     assert opt_b.t == 3 and aux_b.t == 3
+    assert float(opt_b.flat.grad.abs().max()) == 0.0      # cleared in the Adam pass
 
 
 @pytest.mark.parametrize("tag", ["small", "big"])

@@ -16,6 +16,8 @@ LAYERS = {
     # name: (kind, B, C, H, W, K, R, stride, pad)
     "g_a.2": ("conv", 16, 192, 128, 128, 192, 5, 2, 2),
     "g_a.2+gdn": ("conv_gdn", 16, 192, 128, 128, 192, 5, 2, 2),       # the fused kernel bench.py's roofline is quoted on
+    "g_a.0+gdn": ("conv_c4_gdn", 16, 3, 256, 256, 192, 5, 2, 2),
+    "g_a.4+gdn": ("conv_gdn", 16, 192, 64, 64, 192, 5, 2, 2),
     "g_a.4": ("conv", 16, 192, 64, 64, 192, 5, 2, 2),
     "g_a.6": ("conv", 16, 192, 32, 32, 192, 5, 2, 2),
     "gdn.1": ("gdn", 16, 192, 128, 128, 192, 1, 1, 0),
@@ -55,6 +57,12 @@ def run(name, iters):
         beta, gamma = torch.ones(K, device=dev), (0.1 * torch.eye(K, device=dev) + 0.01).sqrt()
         flop += 2.0 * B * Ho * Wo * K * K + 3.0 * B * Ho * Wo * K
         fn = lambda: F.conv2d_gdn_fwd(x, wp, b, beta, gamma, K, R, R, st, pd)
+    elif kind == "conv_c4_gdn":
+        wp = F.pack_weight(w, F.PACK_CONV_FWD_C4)
+        x4 = torch.rand(B, H, W, 4, device=dev)
+        beta, gamma = torch.ones(K, device=dev), (0.1 * torch.eye(K, device=dev) + 0.01).sqrt()
+        flop += 2.0 * B * Ho * Wo * K * K + 3.0 * B * Ho * Wo * K
+        fn = lambda: F.conv2d_fwd_c4_gdn(x4, wp, b, beta, gamma, K, R, R, st, pd)
     elif kind == "deconv":
         wp = F.pack_weight(w, F.PACK_DECONV_FWD)
         flop = 2.0 * B * H * W * K * C * R * R
