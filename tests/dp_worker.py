@@ -96,6 +96,44 @@ def case_train(rank, world, out_dir, steps=2):
     np.savez(os.path.join(out_dir, f"train_rank{rank}.npz"), **dump)
 
 
+def case_train_fused(rank, world, out_dir, steps=2):
+    """The same two steps through the explicit schedule bench.py times (trainer.FusedPFrameStep) with the overlapped
+    reducer attached -- the code path of `bench.py --gpus N`."""
+    from spatiotemporalentropymodel_amd import distributed as D
+    from spatiotemporalentropymodel_amd import selfcheck as S
+    from spatiotemporalentropymodel_amd.optim import configure_optimizers
+    from spatiotemporalentropymodel_amd.trainer import FusedPFrameStep
+    from spatiotemporalentropymodel_amd.weights import smooth_frames
+    dev = torch.device("cuda:0")
+    imodel, stem = S.build_models(64, 96, 64, 96, dev, inject_noise=False)
+    stem.train()
+    imodel.gaussian_conditional.noise_source = SlicedNoise("iframe_gc", rank, world, 1)
+    stem.entropy_bottleneck.noise_source = SlicedNoise("stem_eb", rank, world, 1, batch_last=True)
+    stem.gaussian_conditional.noise_source = SlicedNoise("stem_gc", rank, world, 1)
+    D.broadcast_parameters(stem)
+    opt, aux_opt = configure_optimizers(stem, types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3))
+    red = D.OverlappedGradReducer(opt.flat).attach(stem.engine())
+    fused = FusedPFrameStep(stem, opt, aux_opt)
+    fused.clear_grad_in_adam = False
+    frames = [f[rank:rank + 1].contiguous().to(dev) for f in smooth_frames("dp2:train", world, steps + 1, 64)]
+    with torch.no_grad():
+        _, y_cond = imodel.getY(frames[0])
+    dump = {}
+    for t in range(1, steps + 1):
+        with torch.no_grad():
+            y_cur, _ = imodel.getY(frames[t])
+        out, oc, aux, gn = fused.step(y_cur, y_cond, 64 * 64, grad_scale=red.grad_scale, reducer=red)
+        if t == 1:
+            dump["grad_avg"] = flat_np(opt.flat.grad) * red.grad_scale
+        y_cond = out["y_hat"]
+        dump[f"s{t}:loss"] = np.array([float(oc["loss"]), float(gn), float(aux)])
+    torch.cuda.synchronize()
+    dump["params"] = flat_np(opt.flat.data)
+    dump["quantiles"] = flat_np(aux_opt.flat.data)
+    dump["reducer_calls"] = np.array([red.calls])
+    np.savez(os.path.join(out_dir, f"train_fused_rank{rank}.npz"), **dump)
+
+
 def case_gop(rank, world, out_dir, frames_n=3):
     """One GOP iteration of the variable-rate loop (selfcheck.roi_gop_step) with GopGradAccumulator, one sample per rank."""
     from spatiotemporalentropymodel_amd import distributed as D
@@ -139,7 +177,7 @@ def main():
                       LOCAL_RANK="0", STEM_DIST_BACKEND="gloo")
     from spatiotemporalentropymodel_amd import distributed as D
     D.init_from_env()
-    {"train": case_train, "gop": case_gop}[a.case](a.rank, a.world, a.out)
+    {"train": case_train, "train_fused": case_train_fused, "gop": case_gop}[a.case](a.rank, a.world, a.out)
     D.barrier()
     torch.distributed.destroy_process_group()
 

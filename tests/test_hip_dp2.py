@@ -89,6 +89,27 @@ def test_overlapped_reducer_two_ranks_equals_full_batch(dp2_results):
     assert float((err <= 2e-6 * np.maximum(np.abs(pf), 1.0)).mean()) >= 0.98
 
 
+@pytest.mark.dp2("train_fused")
+@pytest.mark.dp2("train")
+def test_fused_schedule_with_reducer_two_ranks_matches_generic_route(dp2_results):
+    """`bench.py --gpus N` runs trainer.FusedPFrameStep with the overlapped reducer: two ranks of it must land where two ranks
+    of the generic route (the `train` case, itself checked against the single-process full batch above) land."""
+    f0, f1 = dp2_results("train_fused")
+    g0, _ = dp2_results("train")
+    np.testing.assert_array_equal(f0["grad_avg"], f1["grad_avg"])
+    np.testing.assert_array_equal(f0["params"], f1["params"])
+    np.testing.assert_array_equal(f0["quantiles"], f1["quantiles"])
+    assert int(f0["reducer_calls"][0]) == 12
+    scale = float(np.abs(g0["grad_avg"]).max())
+    assert float(np.abs(f0["grad_avg"] - g0["grad_avg"]).max()) <= 2e-6 * scale        # coef / lik vs (1 / lik) * (g / ln 2)
+    for t in (1, 2):
+        a, b = f0[f"s{t}:loss"], g0[f"s{t}:loss"]
+        assert abs(a[0] - b[0]) <= 1e-5 * abs(b[0]) and abs(a[1] - b[1]) <= 1e-4 * b[1] and abs(a[2] - b[2]) <= 1e-5 * abs(b[2]), (t, a, b)
+    # two Adam steps: elements whose gradient is fp32 noise may step the other way (<= 2 lr per step), the rest agree
+    err = np.abs(f0["params"].astype(np.float64) - g0["params"])
+    assert err.max() <= 4.2e-4 and float((err <= 2e-6 * np.maximum(np.abs(g0["params"]), 1.0)).mean()) >= 0.96
+
+
 @pytest.mark.dp2("gop")
 def test_gop_accumulator_two_ranks_equals_full_batch(dp2_results):
     from spatiotemporalentropymodel_amd import selfcheck as S
