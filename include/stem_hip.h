@@ -41,9 +41,10 @@ enum {
     STEM_PACK_DECONV_DGRAD = 3, /* nn.ConvTranspose2d weight [C,K,R,S] -> [R*S][C][K]                */
     STEM_PACK_CONV_FWD_C4 = 4   /* Conv2d weight [K,3or4,R,S] -> [K][32 taps][4] zero padded         */
 };
-/* `masked` != 0 applies MaskedConv2d's type-A mask (compressai/layers/layers.py:39-47);
- * masked == 2 additionally zeroes the masked taps of `w` itself, which is what the reference's
- * forward does (`self.weight.data *= self.mask`, layers.py:46).                                */
+/* `masked`: bits 0-1 = mode, bit 2 (value 4) = mask type B instead of A (compressai/layers/layers.py:39-47: type A zeroes
+ * the taps at row > R/2 or (row == R/2, col >= S/2); type B keeps the centre tap).  Mode 1 applies the mask to the
+ * packed copy; mode 2 additionally zeroes the masked taps of `w` itself, which is what the reference's forward does
+ * (`self.weight.data *= self.mask`, layers.py:46).                                                                 */
 int stem_pack_weight(const float *w, float *wp, int K, int C, int R, int S, int role, int masked, void *stream);
 size_t stem_packed_weight_elems(int K, int C, int R, int S, int role);
 /* gradient in packed layout [splits][R*S][K][C] (from stem_conv2d_wgrad) -> reference layout,

@@ -29,11 +29,11 @@ __global__ __launch_bounds__(256) void pack_kernel(float *w, float *out, int A, 
     for (int i = threadIdx.x; i < n; i += 256) {
         const int b = i / T, t = i - b * T;
         float v = w[a * sa + b * sb + t];
-        if (masked) {   // MaskedConv2d type A (layers.py:39-42): row > R/2, or row == R/2 and col >= S/2
+        if (masked & 3) {   // MaskedConv2d (layers.py:39-42): row > R/2, or row == R/2 and col >= S/2 (type A) / col > S/2 (type B, bit 2)
             const int r = t / S, s = t - r * S;
-            if (r > R / 2 || (r == R / 2 && s >= S / 2)) {
+            if (r > R / 2 || (r == R / 2 && s >= S / 2 + ((masked >> 2) & 1))) {
                 v = 0.f;
-                if (masked == 2) w[a * sa + b * sb + t] = 0.f;   // `self.weight.data *= self.mask`, in place
+                if ((masked & 3) == 2) w[a * sa + b * sb + t] = 0.f;   // `self.weight.data *= self.mask`, in place
             }
         }
         tile[i] = v;
@@ -69,11 +69,11 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackTable tb)
     for (int k = threadIdx.x; k < n; k += 256) {
         const int b = k / d.T, t = k - b * d.T;
         float v = d.w[a * d.sa + b * d.sb + t];
-        if (d.masked) {
+        if (d.masked & 3) {
             const int r = t / d.S, s = t - r * d.S;
-            if (r > d.R / 2 || (r == d.R / 2 && s >= d.S / 2)) {
+            if (r > d.R / 2 || (r == d.R / 2 && s >= d.S / 2 + ((d.masked >> 2) & 1))) {
                 v = 0.f;
-                if (d.masked == 2) d.w[a * d.sa + b * d.sb + t] = 0.f;
+                if ((d.masked & 3) == 2) d.w[a * d.sa + b * d.sb + t] = 0.f;
             }
         }
         tile[k] = v;

@@ -50,15 +50,15 @@ class _Layer:
                              F.PACK_CONV_FWD if conv else F.PACK_DECONV_FWD, self.masked)]
         if self.need_dgrad:
             out.append(_lib.PackDesc(w.data_ptr(), self.wp_dgrad.data_ptr(), self.K, self.C, self.R, self.R,
-                                     F.PACK_CONV_DGRAD if conv else F.PACK_DECONV_DGRAD, 1 if self.masked else 0))
+                                     F.PACK_CONV_DGRAD if conv else F.PACK_DECONV_DGRAD, (1 | (self.masked & 4)) if self.masked else 0))
         return out
 
     def fwd(self, x, act=F.ACT_NONE, out=None):
         self.eng.ensure_packed()
         m = self.mod
         if self.kind == "conv":
-            if self.masked:
-                act |= F.CONV_MASKED_A            # the masked taps are zeros: skip them
+            if self.masked and not self.masked & 4:
+                act |= F.CONV_MASKED_A            # the masked taps (type A) are zeros: skip them
             return F.conv2d_fwd(x, self.wp_fwd, m.bias, self.K, self.R, self.R, self.stride, self.pad, act, out=out)
         return F.deconv2d_fwd(x, self.wp_fwd, m.bias, self.K, self.R, self.R, self.stride, self.pad, self.opad, act, out=out)
 

@@ -46,7 +46,7 @@ class _PackCache:
         if hit is not None and hit[0] == key:
             return hit[1]
         wp = F.pack_weight(w, role, masked)
-        if masked == 2:                          # the kernel zeroed taps of w in place
+        if (masked & 3) == 2:                    # the kernel zeroed taps of w in place
             key = (w._version, w.data_ptr(), weight_epoch(w), tuple(w.shape))
         self._c[role] = (key, wp)
         return wp
@@ -120,7 +120,7 @@ class Conv2dFunction(torch.autograd.Function):
         else:
             xin = F.to_nhwc(x)
             y = F.conv2d_fwd(xin, cache.get(weight, F.PACK_CONV_FWD, masked), bias, K, R, S, stride, pad,
-                             act | (F.CONV_MASKED_A if masked else 0), slope=slope)
+                             act | (F.CONV_MASKED_A if masked and not masked & 4 else 0), slope=slope)
         if first and act:
             y = F.lrelu_fwd(y, slope)
         ctx.cfg = (stride, pad, act, masked, cache, first, tuple(x.shape), slope)
@@ -140,7 +140,7 @@ class Conv2dFunction(torch.autograd.Function):
             dy = F.lrelu_bwd(y, dy, slope)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = F.conv2d_dgrad(dy, cache.get(weight, F.PACK_CONV_DGRAD, 1 if masked else 0), xshape, K, R, S, stride, pad)
+            dx = F.conv2d_dgrad(dy, cache.get(weight, F.PACK_CONV_DGRAD, (1 | (masked & 4)) if masked else 0), xshape, K, R, S, stride, pad)
         dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             need_db = bool(ctx.needs_input_grad[2])
@@ -391,13 +391,13 @@ class MaskedConv2d(Conv2d):
         super().__init__(*args, **kwargs)
         if mask_type not in ("A", "B"):
             raise ValueError(f'Invalid "mask_type" value "{mask_type}"')
-        if mask_type != "A":
-            raise NotImplementedError("only mask_type='A' is on the STEM path (spatiotemporalpriors.py:546,830)")
         self.register_buffer("mask", torch.ones_like(self.weight.data))
         _, _, h, w = self.mask.size()
-        self.mask[:, :, h // 2, w // 2:] = 0
+        self.mask[:, :, h // 2, w // 2 + (mask_type == "B"):] = 0
         self.mask[:, :, h // 2 + 1:] = 0
-        self._masked = 2
+        # pack-kernel mode 2 (zero the masked taps of `weight` in place, as the reference's forward does) | 4 for type B.
+        # Type A (the STEM context model, spatiotemporalpriors.py:546,830) additionally lets the kernel skip the dead taps.
+        self._masked = 2 | (4 if mask_type == "B" else 0)
 
 
 class GDN(nn.Module):

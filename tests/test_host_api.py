@@ -390,3 +390,18 @@ def test_entropy_bottleneck_init_values():
             check(*bad)
     check([b""], idx, torch.zeros(1, 6, 1, 1))
     check((b"",), idx, torch.zeros(1, 6, 2, 2))
+
+
+def test_masked_conv_mask_layouts():
+    """compressai_tests/test_layers.py:29-115: mask A zeroes the centre tap and everything after it in raster order, B keeps the centre"""
+    from spatiotemporalentropymodel_amd.layers import MaskedConv2d
+    a = MaskedConv2d(1, 1, 5, padding=2, mask_type="A").mask[0, 0]
+    b = MaskedConv2d(1, 1, 5, padding=2, mask_type="B").mask[0, 0]
+    exp_a = torch.tensor([[1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 0, 0, 0], [0, 0, 0, 0, 0], [0, 0, 0, 0, 0]], dtype=torch.float32)
+    exp_b = exp_a.clone()
+    exp_b[2, 2] = 1
+    assert torch.equal(a, exp_a) and torch.equal(b, exp_b)
+    a3 = MaskedConv2d(1, 1, 3, padding=1, mask_type="A").mask[0, 0]
+    assert torch.equal(a3, torch.tensor([[1, 1, 1], [1, 0, 0], [0, 0, 0]], dtype=torch.float32))
+    with pytest.raises(ValueError):
+        MaskedConv2d(1, 1, 3, mask_type="C")
