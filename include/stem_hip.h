@@ -328,6 +328,18 @@ int stem_ar_decode_batch(const float *w_ctx, int ld_ctx, const float *b_ctx, con
                          int32_t *idx_host, int32_t *sym_host, stem_symbol_decoder_fn decode, void *const *decs,
                          const int32_t *cdfs, int ncdf, int cdf_stride, const int32_t *sizes, const int32_t *offsets, void *stream);
 
+/* stem_ar_decode_batch without a stream synchronisation per position: device and host hand the indexes / symbols over
+ * through flags in pinned memory (owned by the library), the launches of position p + 2 are issued while the device works on
+ * p + 1, and the images alternate in two groups so that the host decodes one group while the device advances the other.
+ * Every wait is bounded (device ~1 s, host 5 s -> error return).  Same arithmetic per image, same symbols. */
+int stem_ar_decode_batch_pipelined(const float *w_ctx, int ld_ctx, const float *b_ctx, const float *w0, int ld0, const float *b0,
+                                   int n0, const float *w1, int ld1, const float *b1, int n1, const float *w2, int ld2,
+                                   const float *b2, float *buf, int G, int H, int W, int M, int pad, const float *tp,
+                                   const float *hp, float *ctx, float *h1, float *h2, float *gp, const float *table, int T,
+                                   float scale_bound, float slope, stem_symbol_decoder_fn decode, void *const *decs,
+                                   const int32_t *cdfs, int ncdf, int cdf_stride, const int32_t *sizes, const int32_t *offsets,
+                                   void *stream);
+
 /* Wavefront-parallel encoder: all latent positions with the same t = w + 3h are independent under the 5x5
  * type-A mask, so a H x W frame is coded in W + 3(H-1) batched steps instead of H*W sequential ones.  Input
  * segment of position p at (h, w): x + sh*h + sw*w + sp*p (element offsets); output y[p*ldy + n].            */

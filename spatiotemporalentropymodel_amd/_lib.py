@@ -86,6 +86,8 @@ _HIP_SIG = {
     "stem_gemv3_decode": [vp, ci, vp, vp, ci, ci, vp, ci, ci, vp, ci, ci, vp, ci, ci, cf, vp, vp, vp, ci, ci, vp, ci, cf, vp, vp],
     "stem_ar_decode_image": [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf,
                              vp, vp, vp, vp, vp, ci, ci, vp, vp, vp],
+    "stem_ar_decode_batch_pipelined": [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf,
+                                       vp, vp, vp, ci, ci, vp, vp, vp],
     "stem_ar_decode_batch": [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf,
                              vp, vp, vp, vp, vp, ci, ci, vp, vp, vp],
     "stem_ar_encode_image": [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf,

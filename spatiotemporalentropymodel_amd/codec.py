@@ -263,12 +263,18 @@ def stem_decompress(model, strings, shape, y_cond):
             handles = (C.c_void_p * G)(*[d._h for d in decs])
             hp_b = hp.data_ptr() + 4 * (b0 * H * W * 2 * M)
             tp_b = tp.data_ptr() + 4 * (b0 * H * W * 2 * M) if tp is not None else 0
-            F._chk(lib.stem_ar_decode_batch(
-                ar.w_ctx.data_ptr(), 12 * M, ar.b_ctx.data_ptr(), ar.w0.data_ptr(), ar.w0.shape[1], ar.b0.data_ptr(), ar.w0.shape[0],
-                ar.w1.data_ptr(), ar.w1.shape[1], ar.b1.data_ptr(), ar.w1.shape[0], ar.w2.data_ptr(), ar.w2.shape[1], ar.b2.data_ptr(),
-                buf.data_ptr(), G, H, W, M, _P, tp_b, hp_b, *[t.data_ptr() for t in scratch],
-                ar.table.data_ptr(), ar.table.numel(), ar.bound, F.LRELU_SLOPE, idx_g.data_ptr(), sym_g.data_ptr(),
-                decode_fn, C.addressof(handles), *tables.args(), F._stream()))
+            common = (ar.w_ctx.data_ptr(), 12 * M, ar.b_ctx.data_ptr(), ar.w0.data_ptr(), ar.w0.shape[1], ar.b0.data_ptr(), ar.w0.shape[0],
+                      ar.w1.data_ptr(), ar.w1.shape[1], ar.b1.data_ptr(), ar.w1.shape[0], ar.w2.data_ptr(), ar.w2.shape[1], ar.b2.data_ptr(),
+                      buf.data_ptr(), G, H, W, M, _P, tp_b, hp_b, *[t.data_ptr() for t in scratch],
+                      ar.table.data_ptr(), ar.table.numel(), ar.bound, F.LRELU_SLOPE)
+            if os.environ.get("STEM_AR_PIPELINE", "0") == "1":
+                # flags in pinned memory instead of a stream synchronisation per position, two alternating image groups.
+                # Measured equal for one sequence and slower for 8: the dependent dispatch chain, not the
+                # synchronisation call, is what a position costs.  Kept as a checked alternative, off by default.
+                F._chk(lib.stem_ar_decode_batch_pipelined(*common, decode_fn, C.addressof(handles), *tables.args(), F._stream()))
+            else:
+                F._chk(lib.stem_ar_decode_batch(*common, idx_g.data_ptr(), sym_g.data_ptr(), decode_fn, C.addressof(handles),
+                                                *tables.args(), F._stream()))
             out[b0:b0 + G].copy_(buf[:, _P:_P + H, _P:_P + W].permute(0, 3, 1, 2))
     for b, s in enumerate(strings[0] if not lockstep else []):
         buf = _padded(None, H, W, M, dev)

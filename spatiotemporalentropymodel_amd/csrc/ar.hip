@@ -462,6 +462,12 @@ struct DecodeExtraB {
     int T;
     float bound;
     int32_t *idx;              // [G][M] (pinned host)
+    // pipelined loop (stem_ar_decode_batch with STEM_AR_PIPELINE): the launch that writes `idx` also tells the host, through
+    // a flag in pinned memory, that this position's indexes are complete; every launch returns at once after an abort
+    int *cnt;                  // device arrival counter of this launch (zero before and after)
+    int *flag_idx;             // pinned host word, null: no signalling
+    int flag_val;
+    const int *abort_dev;      // device word, non-zero: a wait timed out or the host gave up
 };
 
 // One wavefront per output row (the products are latency-bound: what counts is how many independent loads are in flight,
@@ -476,6 +482,7 @@ __global__ __launch_bounds__(256) void gemv3b_decode_kernel(const float *W, int 
 {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e.abort_dev && *reinterpret_cast<const volatile int *>(e.abort_dev)) return;
     if (n >= N) return;
     const float *wr = W + (size_t)n * ldw;
     float acc[G];
@@ -519,9 +526,50 @@ __global__ __launch_bounds__(256) void gemv3b_decode_kernel(const float *W, int 
                 const float sc = fmaxf(v, e.bound);
                 int k = e.T - 1;
                 for (int t = 0; t < e.T - 1; ++t) k -= (sc <= e.table[t]) ? 1 : 0;
-                e.idx[g * e.M + n] = k;
+                if (e.flag_idx) __hip_atomic_store(e.idx + g * e.M + n, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // write-through
+                else e.idx[g * e.M + n] = k;
             }
         }
+    }
+    if (e.flag_idx) {      // N is a multiple of 4 here (checked by the host): whole workgroups reach the barrier
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's index words have left for the host (no L2-wide fence)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int ticket = atomicAdd(e.cnt, 1);
+            if (ticket == (int)gridDim.x - 1) {
+                __hip_atomic_store(e.cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(e.flag_idx, e.flag_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
+// Pipelined loop: y_hat of the previous position = symbol + mean, as soon as the host has posted the symbols.  One workgroup;
+// thread 0 polls the host's flag in pinned memory (bounded: ~1 s, then the abort word stops every later launch).
+__global__ __launch_bounds__(256) void ar_commit_wait_kernel(const float *gp, long gp_stride, const int32_t *sym, float *pix, long buf_stride,
+                                                             int M, int G, const int *flag_sym, int need, int *abort_dev)
+{
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        int good = *reinterpret_cast<volatile int *>(abort_dev) ? 0 : 1;
+        long spins = 0;
+        while (good) {
+            const int v = __hip_atomic_load(flag_sym, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (v >= need) break;
+            if (v < 0 || ++spins > 2000000) {          // host gave up / ~1 s without an answer
+                good = 0;
+                __hip_atomic_store(abort_dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        ok = good;
+    }
+    __syncthreads();
+    if (!ok) return;
+    for (int i = threadIdx.x; i < M * G; i += 256) {
+        const int g = i / M, c = i - g * M;
+        const int sv = __hip_atomic_load(sym + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        pix[g * buf_stride + c] = (float)sv + gp[g * gp_stride + M + c];
     }
 }
 
@@ -628,5 +676,147 @@ STEM_EXPORT int stem_ar_decode_batch(const float *w_ctx, int ld_ctx, const float
                 t_launch / (H * W), t_wait / (H * W), t_host / (H * W));
     hipLaunchKernelGGL(ar_finish_decode_batch_kernel, dim3(cdiv(M * G, 256)), dim3(256), 0, st, gp, (long)P, sym_host, pix_prev, bufs, M, G);
     STEM_LAUNCH_CHECK("ar_decode_batch");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The lockstep decoder without a stream synchronisation per position.  stem_ar_decode_batch pays, per position step, the
+// launches (13 us of host time), a hipStreamSynchronize and the host coder one after the other.  Here
+//   * the GPU tells the host that a position's indexes are complete by writing a flag into pinned memory (last workgroup of
+//     the launch that produces them), the host answers the same way after decoding, and the kernel that commits the symbols
+//     (first launch of the next position) polls that flag: no synchronisation call, and the launches of position p + 2 are
+//     issued while the GPU works on p + 1;
+//   * the images are split into two groups that alternate on the stream, so that the host decodes group A's symbols while
+//     the GPU advances group B.
+// Mailboxes are double-buffered per group (slot = position & 1).  Every wait is bounded: a GPU-side poll gives up after ~1 s
+// and raises a device abort word that makes all later launches return at once; the host gives up after 5 s and posts a
+// negative flag.  Arithmetic per image is unchanged (same kernels), so are the decoded symbols.
+namespace {
+
+struct PipeState {
+    int *pinned = nullptr;       // [0..1] flag_idx per group, [2..3] flag_sym per group, then idx / sym mailboxes
+    int *dev = nullptr;          // [0..3] arrival counters (group x slot), [4] abort word
+    size_t pinned_ints = 0;
+};
+thread_local PipeState g_pipe;
+
+int pipe_reserve(size_t mailbox_ints)
+{
+    const size_t need = 16 + 2 * 2 * 2 * mailbox_ints;          // flags + {idx, sym} x 2 groups x 2 slots
+    if (g_pipe.pinned_ints < need) {
+        if (g_pipe.pinned) (void)hipHostFree(g_pipe.pinned);
+        g_pipe.pinned = nullptr;
+        if (hipHostMalloc((void **)&g_pipe.pinned, need * sizeof(int), hipHostMallocDefault) != hipSuccess) return -1;
+        g_pipe.pinned_ints = need;
+    }
+    if (!g_pipe.dev && hipMalloc((void **)&g_pipe.dev, 8 * sizeof(int)) != hipSuccess) return -1;
+    return 0;
+}
+
+}   // namespace
+
+STEM_EXPORT int stem_ar_decode_batch_pipelined(const float *w_ctx, int ld_ctx, const float *b_ctx, const float *w0, int ld0, const float *b0,
+                                               int n0, const float *w1, int ld1, const float *b1, int n1, const float *w2, int ld2,
+                                               const float *b2, float *buf, int G, int H, int W, int M, int pad, const float *tp,
+                                               const float *hp, float *ctx, float *h1, float *h2, float *gp, const float *table, int T,
+                                               float scale_bound, float slope, stem_symbol_decoder_fn decode, void *const *decs,
+                                               const int32_t *cdfs, int ncdf, int cdf_stride, const int32_t *sizes, const int32_t *offsets,
+                                               void *stream)
+{
+    STEM_CHECK_ARG(w_ctx && b_ctx && w0 && b0 && w1 && b1 && w2 && b2 && buf && hp && ctx && h1 && h2 && gp && table && decode && decs,
+                   "stem_ar_decode_batch_pipelined: null pointer");
+    STEM_CHECK_ARG(G >= 1 && G <= GMAX, "stem_ar_decode_batch_pipelined: 1..%d images per call, got %d", GMAX, G);
+    STEM_CHECK_ARG(5 * M <= 256 * MAXS && n0 <= 256 * MAXS && n1 <= 256 * MAXS, "stem_ar_decode_batch_pipelined: segments longer than %d floats",
+                   256 * MAXS);
+    STEM_CHECK_ARG(H > 0 && W > 0 && M > 0 && M % 4 == 0 && n0 % 4 == 0 && n1 % 4 == 0 && ld_ctx % 4 == 0 && ld0 % 4 == 0 && ld1 % 4 == 0 &&
+                   ld2 % 4 == 0 && T >= 1 && pad == 2, "stem_ar_decode_batch_pipelined: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int P = 2 * M, Wp = W + 2 * pad, N = H * W;
+    const long bufs = (long)(H + 2 * pad) * Wp * M, pris = (long)H * W * P;
+    const int ng = G >= 2 ? 2 : 1;
+    const int gsz[2] = {ng == 2 ? (G + 1) / 2 : G, ng == 2 ? G / 2 : 0}, gbeg[2] = {0, gsz[0]};
+    const size_t mb = (size_t)GMAX * M;                          // ints per mailbox
+    if (pipe_reserve(mb)) {
+        stem_set_error("stem_ar_decode_batch_pipelined: cannot allocate the pinned mailboxes");
+        return -2;
+    }
+    int *pin = g_pipe.pinned, *dev = g_pipe.dev;
+    auto mbox = [&](int kind, int k, int slot) { return pin + 16 + ((size_t)(kind * 2 + k) * 2 + slot) * mb; };      // kind 0 idx, 1 sym
+    for (int i = 0; i < 4; ++i) pin[i] = 0;
+    if (hipMemsetAsync(dev, 0, 8 * sizeof(int), st) != hipSuccess) return -2;
+    int *abort_dev = dev + 4;
+
+    DecodeExtraB none;
+    memset(&none, 0, sizeof(none));
+    none.M = M; none.gp_stride = P; none.buf_stride = bufs; none.abort_dev = abort_dev;
+    const SegB nil{nullptr, 0, 0, 0};
+    auto pix_of = [&](int k, int p) { return buf + (size_t)gbeg[k] * bufs + ((size_t)(p / W + pad) * Wp + (p % W + pad)) * M; };
+    auto commit = [&](int k, int p) {      // y_hat of position p of group k, once the host has posted its symbols (flag_sym >= p + 1)
+        hipLaunchKernelGGL(ar_commit_wait_kernel, dim3(1), dim3(256), 0, st, gp + (size_t)gbeg[k] * P, (long)P, mbox(1, k, p & 1), pix_of(k, p),
+                           bufs, M, gsz[k], (const int *)(pin + 2 + k), p + 1, abort_dev);
+    };
+    auto chain = [&](int k, int p) {
+        const int Gk = gsz[k], g0 = gbeg[k], h = p / W, w = p % W;
+        if (p > 0) commit(k, p - 1);
+        const float *r0 = buf + (size_t)g0 * bufs + ((size_t)h * Wp + w) * M, *r1 = r0 + (size_t)Wp * M, *r2 = r1 + (size_t)Wp * M;
+        float *ctx_k = ctx + (size_t)g0 * P, *h1_k = h1 + (size_t)g0 * n0, *h2_k = h2 + (size_t)g0 * n1, *gp_k = gp + (size_t)g0 * P;
+        launch_gemv3b_g(Gk, st, P, w_ctx, ld_ctx, b_ctx, SegB{r0, 5 * M, 0, bufs}, SegB{r1, 5 * M, 5 * M, bufs}, SegB{r2, 2 * M, 10 * M, bufs},
+                        ctx_k, (long)P, 0, 0.f, none);
+        const float *hp_pix = hp + (size_t)g0 * pris + (size_t)p * P;
+        if (tp)
+            launch_gemv3b_g(Gk, st, n0, w0, ld0, b0, SegB{tp + (size_t)g0 * pris + (size_t)p * P, P, 0, pris}, SegB{hp_pix, P, P, pris},
+                            SegB{ctx_k, P, 2 * P, (long)P}, h1_k, (long)n0, (int)STEM_ACT_LRELU, slope, none);
+        else
+            launch_gemv3b_g(Gk, st, n0, w0, ld0, b0, SegB{hp_pix, P, 0, pris}, SegB{ctx_k, P, P, (long)P}, nil, h1_k, (long)n0,
+                            (int)STEM_ACT_LRELU, slope, none);
+        launch_gemv3b_g(Gk, st, n1, w1, ld1, b1, SegB{h1_k, n0, 0, (long)n0}, nil, nil, h2_k, (long)n1, (int)STEM_ACT_LRELU, slope, none);
+        DecodeExtraB tail = none;
+        tail.table = table; tail.T = T; tail.bound = scale_bound; tail.idx = mbox(0, k, p & 1);
+        tail.cnt = dev + k * 2 + (p & 1); tail.flag_idx = pin + k; tail.flag_val = p + 1;
+        launch_gemv3b_g(Gk, st, P, w2, ld2, b2, SegB{h2_k, n1, 0, (long)n1}, nil, nil, gp_k, (long)P, 0, 0.f, tail);
+    };
+    auto give_up = [&](const char *what, int k, int p) {
+        for (int q = 0; q < ng; ++q) __atomic_store_n(pin + 2 + q, -1, __ATOMIC_RELEASE);       // polling kernels stop, later ones return
+        (void)hipStreamSynchronize(st);
+        stem_set_error("stem_ar_decode_batch_pipelined: %s (group %d, position %d)", what, k, p);
+    };
+
+    for (int p = 0; p < 2 && p < N; ++p)
+        for (int k = 0; k < ng; ++k) chain(k, p);
+    if (hipGetLastError() != hipSuccess) {
+        give_up("launch failed", 0, 0);
+        return -2;
+    }
+    for (int p = 0; p < N; ++p)
+        for (int k = 0; k < ng; ++k) {
+            const auto t0 = std::chrono::steady_clock::now();
+            long spins = 0;
+            while (__atomic_load_n(pin + k, __ATOMIC_ACQUIRE) < p + 1) {
+                if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                    give_up("timed out waiting for the device", k, p);
+                    return -2;
+                }
+                __builtin_ia32_pause();
+            }
+            const int32_t *idx = mbox(0, k, p & 1);
+            int32_t *sym = mbox(1, k, p & 1);
+            for (int g = 0; g < gsz[k]; ++g)
+                if (int rc = decode(decs[gbeg[k] + g], idx + (size_t)g * M, (size_t)M, cdfs, ncdf, cdf_stride, sizes, offsets, sym + (size_t)g * M)) {
+                    give_up("host symbol decoder failed", k, p);
+                    return rc < 0 ? -3 : -3;
+                }
+            __atomic_store_n(pin + 2 + k, p + 1, __ATOMIC_RELEASE);
+            if (p + 2 < N) chain(k, p + 2);
+        }
+    for (int k = 0; k < ng; ++k) commit(k, N - 1);
+    if (hipStreamSynchronize(st) != hipSuccess) {
+        stem_set_error("stem_ar_decode_batch_pipelined: device error: %s", hipGetErrorString(hipGetLastError()));
+        return -2;
+    }
+    int aborted = 0;
+    if (hipMemcpy(&aborted, abort_dev, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || aborted) {
+        stem_set_error("stem_ar_decode_batch_pipelined: a device-side wait timed out");
+        return -2;
+    }
     return 0;
 }

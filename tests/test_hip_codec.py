@@ -128,11 +128,19 @@ def test_lockstep_batch_decode_equals_per_image_decode(monkeypatch):
     with torch.no_grad():
         enc = m.compress(y_cur, y_cond)
         a = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()
+        monkeypatch.setenv("STEM_AR_FORCE_BATCH", "1")     # the lockstep loop also for one image
+        monkeypatch.setenv("STEM_AR_PIPELINE", "1")        # flag-polling variant: no stream synchronisation per position
+        c = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()
+        c1 = m.decompress([enc["strings"][0][:1], enc["strings"][1][:1]], enc["shape"], y_cond[:1])["y_hat"].clone()
+        monkeypatch.delenv("STEM_AR_PIPELINE")
+        c1s = m.decompress([enc["strings"][0][:1], enc["strings"][1][:1]], enc["shape"], y_cond[:1])["y_hat"].clone()
+        monkeypatch.delenv("STEM_AR_FORCE_BATCH")
         monkeypatch.setenv("STEM_AR_NO_BATCH", "1")
         b = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()
         # and one image on its own equals its slot in the batch
         one = m.decompress([enc["strings"][0][3:4], enc["strings"][1][3:4]], enc["shape"], y_cond[3:4])["y_hat"]
     assert torch.equal(a, b)
+    assert torch.equal(a, c) and torch.equal(c1, c1s)
     # (decoded alone, the hyper-prior convolutions run at batch 1 and pick another tile / split-K plan: the means move by
     # an ulp, the symbols do not)
     assert float((a[3:4] - one).abs().max()) <= 1e-4

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""How long the host needs to ENQUEUE one bench step (no synchronisation inside) vs how long the GPU needs to run it. Dev tool."""
+"""How long the host needs to ENQUEUE one bench step (no synchronisation inside) vs how long the GPU needs to run it. Dev tool.
+STEM_HOST_TINY=1: B=1, 64x64 (the GPU never back-pressures: wall = pure host cost); STEM_HOST_GENERIC=1: the nn.Module / autograd
+route (selfcheck.p_frame_step) instead of the explicit fused schedule bench.py runs by default (trainer.FusedPFrameStep)."""
 import os
 import sys
 import time
@@ -25,11 +27,22 @@ tiny = bool(os.environ.get("STEM_HOST_TINY"))          # B=1, 64x64: the GPU is 
 frames = bench.synthetic_septuplet(1 if tiny else bench.BATCH, 64 if tiny else bench.SIZE, 1234, dev)
 
 
+generic = bool(os.environ.get("STEM_HOST_GENERIC"))
+if not generic:
+    from spatiotemporalentropymodel_amd.trainer import FusedPFrameStep  # noqa: E402
+    fused = FusedPFrameStep(stem, opt, aux_opt)
+npix = frames[0].shape[0] * frames[0].shape[2] * frames[0].shape[3]
+
+
 def one_step():
     with torch.no_grad():
-        _, y_cond = imodel.getY(frames[0])
+        ys = [imodel.getY(f) for f in frames]
+    y_cond = ys[0][1]
     for t in range(1, bench.FRAMES):
-        out, oc, aux, gn = p_frame_step(imodel, stem, crit, opt, aux_opt, frames[t], y_cond)
+        if generic:
+            out, oc, aux, gn = p_frame_step(imodel, stem, crit, opt, aux_opt, frames[t], y_cond, y_cur=ys[t][0])
+        else:
+            out, oc, aux, gn = fused.step(ys[t][0], y_cond, npix)
         y_cond = out["y_hat"]
 
 
@@ -43,7 +56,7 @@ for _ in range(n):
 t_enq = (time.perf_counter() - t0) / n
 torch.cuda.synchronize()
 t_all = (time.perf_counter() - t0) / n
-print(f"host enqueue {t_enq * 1e3:.1f} ms/step, wall {t_all * 1e3:.1f} ms/step")
+print(f"{'generic' if generic else 'fused'} route{' (tiny problem)' if tiny else ''}: host enqueue {t_enq * 1e3:.1f} ms/step, wall {t_all * 1e3:.1f} ms/step")
 
 if os.environ.get("STEM_HOST_PROFILE"):
     import cProfile
