@@ -340,6 +340,27 @@ int stem_ar_decode_batch_pipelined(const float *w_ctx, int ld_ctx, const float *
                                    const int32_t *cdfs, int ncdf, int cdf_stride, const int32_t *sizes, const int32_t *offsets,
                                    void *stream);
 
+/* ---- fp32-accurate convolution on the bf16 matrix cores (csrc/conv_bf16x6.hip) -----------------------------------------
+ * For the FROZEN analysis transform g_a of the I-frame model (reference: compressai/models/priors.py:613-621 run under
+ * no_grad by stem/trainSTEM.py:128,171 and stem/evalSTEM.py:101-103): every fp32 operand is the exact sum of three bf16
+ * numbers, and the six bf16 products with i + j <= 2 reproduce the fp32 product to 2^-26; accumulation is fp32.
+ * "planes" layout of an NHWC tensor with C % 32 == 0: [pixel][C/32][3][32] bf16 (192 B per pixel and 32-channel slab). */
+size_t stem_bf16x3_planes_bytes(long npix, int C);
+size_t stem_bf16x3_conv_weight_bytes(int C, int R, int S);
+int stem_bf16x3_split_nhwc(const float *x, int ldx, void *xp, long npix, int C, void *stream);
+int stem_bf16x3_merge_nhwc(const void *xp, float *x, int ldx, long npix, int C, void *stream);
+/* w: the torch Conv2d weight [N][C][R][S] (NOT one of the stem_pack_* layouts); N <= 192, R*S <= 25 */
+int stem_bf16x3_pack_conv_weight(const float *w, void *wp, int N, int C, int R, int S, void *stream);
+/* y = conv(x) + bias, followed by GDN when beta/gamma are given (gdn.py:52-67; stored parameters, reparametrised on the fly).
+ * Output as fp32 NHWC (y, ldy) and / or as planes (yp); either may be null. */
+/* first layer (3 input channels, stem_conv2d_fwd_c4_gdn's arguments) with its result written as planes */
+int stem_conv2d_fwd_c4_gdn_planes(const float *x4, const float *wp, const float *bias, const float *beta, const float *gamma,
+                                  void *yp, int B, int H, int W, int K, int R, int S, int stride, int pad, float beta_min,
+                                  void *stream);
+int stem_conv2d_bf16x6_fwd(const void *xp, const void *wp, const float *bias, const float *beta, const float *gamma,
+                           float beta_min, float *y, int ldy, void *yp, int B, int H, int W, int C, int N, int R, int S,
+                           int stride, int pad, void *stream);
+
 /* Wavefront-parallel encoder: all latent positions with the same t = w + 3h are independent under the 5x5
  * type-A mask, so a H x W frame is coded in W + 3(H-1) batched steps instead of H*W sequential ones.  Input
  * segment of position p at (h, w): x + sh*h + sw*w + sp*p (element offsets); output y[p*ldy + n].            */

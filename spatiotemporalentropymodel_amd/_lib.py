@@ -86,6 +86,13 @@ _HIP_SIG = {
     "stem_gemv3_decode": [vp, ci, vp, vp, ci, ci, vp, ci, ci, vp, ci, ci, vp, ci, ci, cf, vp, vp, vp, ci, ci, vp, ci, cf, vp, vp],
     "stem_ar_decode_image": [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf,
                              vp, vp, vp, vp, vp, ci, ci, vp, vp, vp],
+    "stem_bf16x3_planes_bytes": [C.c_long, ci],
+    "stem_bf16x3_conv_weight_bytes": [ci, ci, ci],
+    "stem_bf16x3_split_nhwc": [vp, ci, vp, C.c_long, ci, vp],
+    "stem_bf16x3_merge_nhwc": [vp, vp, ci, C.c_long, ci, vp],
+    "stem_bf16x3_pack_conv_weight": [vp, vp, ci, ci, ci, ci, vp],
+    "stem_conv2d_fwd_c4_gdn_planes": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp],
+    "stem_conv2d_bf16x6_fwd": [vp, vp, vp, vp, vp, cf, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_ar_decode_batch_pipelined": [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf,
                                        vp, vp, vp, ci, ci, vp, vp, vp],
     "stem_ar_decode_batch": [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf,
@@ -103,7 +110,7 @@ _HIP_SIG = {
     "stem_abi_version": [],
     "stem_last_error": [],
 }
-_RESTYPE = {"stem_packed_weight_elems": sz, "stem_gdn_bwd_workspace_bytes": sz, "stem_wgrad_workspace_elems": sz, "stem_conv_workspace_bytes": sz, "stem_last_error": C.c_char_p}
+_RESTYPE = {"stem_bf16x3_planes_bytes": sz, "stem_bf16x3_conv_weight_bytes": sz, "stem_packed_weight_elems": sz, "stem_gdn_bwd_workspace_bytes": sz, "stem_wgrad_workspace_elems": sz, "stem_conv_workspace_bytes": sz, "stem_last_error": C.c_char_p}
 
 _RANS_SIG = {
     "stem_rans_encode": [vp, vp, sz, vp, ci, ci, vp, vp, vp, sz],

@@ -1,0 +1,502 @@
+// fp32-accurate convolution on the bf16 matrix cores of gfx950 (MI355X) for the FROZEN analysis transform.
+//
+// v_mfma_f32_32x32x2_f32 (igemm.hip) is the only MFMA that multiplies fp32 operands, at 64 flop/clk/SIMD; the bf16 form
+// v_mfma_f32_32x32x16_bf16 runs at 1024.  Every fp32 number is the exact sum of three bf16 numbers
+//     a = a0 + a1 + a2,   a0 = rn(a), a1 = rn(a - a0), a2 = a - a0 - a1         (|a1| <= 2^-9 |a|, |a2| <= 2^-18 |a|)
+// so a.b = sum_{i,j} ai.bj exactly, every ai.bj is exact in the fp32 accumulator's input (8 x 8 bit significands), and the six
+// products with i + j <= 2 carry everything down to 2^-26 |a.b| -- below the rounding of an fp32 multiply.  Six bf16 MFMAs
+// (K = 16 each, 32 cycles) replace eight fp32 MFMAs (K = 2 each, 64 cycles): 192 instead of 512 matrix-pipe cycles per 16
+// input channels, with fp32 accumulation throughout, i.e. the numerics of the fp32 path (tests: same 1e-4 gates).
+//
+// Operands live in HBM pre-split ("planes" layout): per pixel and per 32-channel slab three consecutive rows of 32 bf16,
+//     x_planes[pixel][slab][plane 0..2][32]        (192 B per pixel and slab, 1.5x the fp32 bytes)
+// written by the producing kernel's epilogue (or by stem_bf16x3_split_nhwc for the first input); the weights are frozen
+// (stem/trainSTEM.py:128), split once, and stored chunk by chunk as the exact LDS image the kernel wants (swizzled), so
+// that their staging is a straight 36 KiB copy.
+//
+// Tile: 128 pixels x 192 channels per workgroup, 8 wavefronts as 4 (M) x 2 (N), each 32 x 96 = three 32x32 accumulators;
+// K chunk = one tap x 32 input channels = 2 k-steps x 3 tiles x 6 products = 36 MFMAs per wavefront.  LDS rows are 64 B
+// (32 bf16) per plane with the 16-byte piece index XOR-swizzled by (row >> 2) & 3: ds_read_b128 / ds_write_b128 are
+// conflict-free without padding.  Staging is register-based, two chunks ahead, woven between the MFMA groups as in igemm.hip.
+// The GDN that follows every analysis convolution (gdn.py:52-67) is fused exactly as in igemm.hip's FUSE epilogue (second
+// contraction over the squared outputs parked in LDS, fp32 MFMA -- 4 % of the flops).
+#include <math.h>
+#include <stdlib.h>
+
+#include "stem_common.h"
+
+namespace {
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+
+constexpr int BN = 192, KC = 32;
+constexpr int B_PLANE = BN * 64, B_BUF = 3 * B_PLANE;              // bytes of one bf16 plane of a weight chunk; 36864 per chunk
+constexpr int XP = BN + 4, GP = 36;                                // fp32 pitches of the parked tile / the gamma chunk
+// LDS of a BM-pixel tile: main loop 2 x (3 planes x (BM + BN) rows x 64 B), epilogue BM x XP + BN x GP floats, then the tap table
+constexpr int lds_taps(int bm) { return 2 * 3 * (bm + BN) * 64 > (bm * XP + BN * GP) * 4 ? 2 * 3 * (bm + BN) * 64 : (bm * XP + BN * GP) * 4; }
+constexpr int lds_total(int bm) { return lds_taps(bm) + 32 * 4; }
+constexpr int MAXTAP = 25;
+constexpr int OOR = 0x7FFFFF00;                                    // voffset that every buffer view rejects (returns 0)
+
+struct Bx6Args {
+    const void *xp, *wp;
+    const float *bias, *beta, *gamma;
+    float *y;
+    void *yp;
+    int ldy;
+    int B, H, W, C, N, OH, OW, stride, ntaps;
+    int xbytes, wbytes, gmbytes;
+    float beta_bound;
+    int fuse;                      // 0: bias only, 1: GDN
+    int exper;                     // tuning experiments (STEM_BX6_EXPER), 0 in production
+    signed char dy[MAXTAP], dx[MAXTAP];
+};
+
+__device__ inline void split3(const float x, __bf16 &h0, __bf16 &h1, __bf16 &h2)
+{
+    h0 = (__bf16)x;
+    const float r1 = x - (float)h0;           // exact: x and h0 agree in their leading 8 bits
+    h1 = (__bf16)r1;
+    h2 = (__bf16)(r1 - (float)h1);            // exact, and at most 8 significant bits are left
+}
+
+// BM = pixels per workgroup: 128 (8 wavefronts) or 64 (4 wavefronts, for layers with too few 128-pixel tiles to fill the chip).
+// NP = number of bf16 products kept per fp32 product: 6 (i + j <= 2, all three planes), 4 (i, j <= 1) or 3 (i + j <= 1); the
+// last two read only planes 0 and 1 (experiments: DESIGN.md).
+template <int BM, int NP>
+__global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
+{
+    constexpr int NT = BM * 4;
+    constexpr int A_PLANE = BM * 64, A_BUF = 3 * A_PLANE;
+    constexpr int LDS_TAPS = lds_taps(BM);
+    constexpr int PL = NP == 6 ? 3 : 2;                 // planes read
+    constexpr int WPIECES = PL * BN * 4;                // 16-byte pieces of the weight chunk that are read
+    constexpr int BP = (WPIECES + NT - 1) / NT;         // ... per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *As = smem;                       // [2][3][BM][64 B]
+    unsigned char *Bs = smem + 2 * A_BUF;           // [2][3][BN][64 B]
+    int *tapi = reinterpret_cast<int *>(smem + LDS_TAPS);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Mtot = a.B * a.OH * a.OW;
+    int tile_m = blockIdx.x;
+    {   // XCD-aware tile order (see igemm.hip): neighbouring pixel tiles share one L2
+        const int nb = gridDim.x, qq = nb >> 3, rr = nb & 7, xcd = tile_m & 7, idx = tile_m >> 3;
+        if (nb >= 16) tile_m = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int bm0 = tile_m * BM;
+    const int nslab = a.C / KC, pixbytes = nslab * 192;
+    if (tid < 32) tapi[tid] = tid < a.ntaps ? (a.dy[tid] * a.W + a.dx[tid]) * pixbytes : 0;
+
+    // ---- staging assignment.  Activations: thread -> (row = tid / 4, 16-byte column = tid % 4) of all three planes ---------
+    const int srow = tid >> 2, scol = tid & 3;
+    int pb;
+    unsigned pmask = 0;
+    {
+        const int m = bm0 + srow;
+        const bool ok = m < Mtot;
+        const int mm = ok ? m : 0;
+        const int ohw = a.OH * a.OW, b = mm / ohw, rem = mm - b * ohw, qy = rem / a.OW, qx = rem - qy * a.OW;
+        const int by = qy * a.stride, bx = qx * a.stride;
+        pb = ((b * a.H + by) * a.W + bx) * pixbytes + scol * 16;
+        for (int t = 0; t < a.ntaps; ++t) {
+            const int iy = by + a.dy[t], ix = bx + a.dx[t];
+            if (ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) pmask |= 1u << t;
+        }
+    }
+    const int a_st = srow * 64 + ((scol ^ ((srow >> 2) & 3)) << 4);          // LDS byte offset inside a plane
+    // weights: the chunk image is copied linearly, 16 bytes per thread and pass; the last pass may be partial
+    constexpr int WFULL = WPIECES / NT;                 // full passes
+    const int wv0 = tid * 16, wvl = WFULL * NT + tid < WPIECES ? (WFULL * NT + tid) * 16 : OOR;
+    const int nchunks = a.ntaps * nslab;
+    const int q_last = nchunks - 1;
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.xp), 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wp), 0, a.wbytes, 0x00020000);
+
+    f32x4 raA[PL], rbA[BP], raB[PL], rbB[BP];
+    auto gload = [&](int t, int kc, int q, f32x4 (&ra)[PL], f32x4 (&rb)[BP]) {
+        const int tA = __builtin_amdgcn_readfirstlane(tapi[t]), sA = kc * 192, sB = q * B_BUF;
+        const int mk = __builtin_amdgcn_sbfe((int)pmask, (unsigned)t, 1u);                 // 0 / -1: tap t inside the image
+        const int off = ((pb + tA) & mk) | (OOR & ~mk);
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) ra[pl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off + pl * 64, sA, 0));
+#pragma unroll
+        for (int j = 0; j < WFULL; ++j)
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, wv0 + j * (NT * 16), sB, 0));
+        if (BP > WFULL) rb[BP - 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, wvl, sB, 0));
+    };
+    auto sstore = [&](int buf, f32x4 (&ra)[PL], f32x4 (&rb)[BP]) {
+#pragma unroll
+        for (int pl = 0; pl < PL; ++pl) *reinterpret_cast<f32x4 *>(As + buf * A_BUF + pl * A_PLANE + a_st) = ra[pl];
+#pragma unroll
+        for (int j = 0; j < WFULL; ++j) *reinterpret_cast<f32x4 *>(Bs + buf * B_BUF + j * (NT * 16) + tid * 16) = rb[j];
+        if (BP > WFULL && WFULL * NT + tid < WPIECES) *reinterpret_cast<f32x4 *>(Bs + buf * B_BUF + (WFULL * NT + tid) * 16) = rb[BP - 1];
+    };
+
+    // ---- wave tile -----------------------------------------------------------------------------------------------------
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 96;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int sw = (lr >> 2) & 3;                                   // (row >> 2) & 3 of every row this lane reads
+    const int rdA = (wm0 + lr) * 64, rdB = (wn0 + lr) * 64;
+    const int pk0 = ((0 + lh) ^ sw) << 4, pk1 = ((2 + lh) ^ sw) << 4;
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    int pf_q = 0, pf_t = 0, pf_kc = 0;            // prefetch target of the next step (wave-uniform)
+    auto step = [&](int cur, f32x4 (&ra)[PL], f32x4 (&rb)[BP]) {
+        const unsigned char *Ab = As + cur * A_BUF + rdA, *Bb = Bs + cur * B_BUF + rdB;
+        const int t = __builtin_amdgcn_readfirstlane(pf_t), kc = __builtin_amdgcn_readfirstlane(pf_kc), q = __builtin_amdgcn_readfirstlane(pf_q);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pk = ks ? pk1 : pk0;
+            bf16x8 af[PL], bf[PL][3];
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) af[pl] = *reinterpret_cast<const bf16x8 *>(Ab + pl * A_PLANE + pk);
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8 *>(Bb + pl * B_PLANE + j * 32 * 64 + pk);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {      // smallest terms first
+                if constexpr (NP == 6) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PL - 1], bf[0][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[PL - 1][j], acc[j], 0, 0, 0);
+                }
+                if constexpr (NP >= 4) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1][j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0][j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1][j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0][j], acc[j], 0, 0, 0);
+            }
+            if (ks == 0)
+                sstore(cur ^ 1, ra, rb);           // the register set holds the next chunk
+            else
+                gload(t, kc, q, ra, rb);           // refill it two chunks ahead
+        }
+        if (pf_q < q_last) {
+            ++pf_q;
+            if (++pf_t == a.ntaps) {
+                pf_t = 0;
+                ++pf_kc;
+            }
+        }
+    };
+
+    // chunk q = kc * ntaps + t (channel slab outer, taps inner: the taps of one slab re-touch the same input lines)
+    auto chunk_of = [&](int q, int &t, int &kc) {
+        q = q < q_last ? q : q_last;
+        kc = q / a.ntaps;
+        t = q - kc * a.ntaps;
+        return q;
+    };
+    {
+        int t, kc, q;
+        q = chunk_of(0, t, kc);
+        gload(t, kc, q, raA, rbA);
+        sstore(0, raA, rbA);
+        q = chunk_of(1, t, kc);
+        gload(t, kc, q, raA, rbA);
+        q = chunk_of(2, t, kc);
+        gload(t, kc, q, raB, rbB);
+        pf_q = chunk_of(3, pf_t, pf_kc);
+    }
+    __syncthreads();
+    {
+        int q = 0;
+        for (; q + 1 < nchunks; q += 2) {
+            step(0, raA, rbA);
+            __syncthreads();
+            step(1, raB, rbB);
+            __syncthreads();
+        }
+        if (q < nchunks) {
+            step(0, raA, rbA);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane holds column n = wn0 + 32 j + lr, rows (r & 3) + 8 (r >> 2) + 4 lh of each 32x32 tile ---------------
+    float *X2 = reinterpret_cast<float *>(smem);                   // [BM][XP]
+    float *Gs = X2 + BM * XP;                                      // [BN][GP]
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int n = wn0 + j * 32 + lr;
+        const float bias = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] += bias;
+    }
+    if (a.fuse) {
+        // norm[px][i] = beta'[i] + sum_j gamma'[i][j] v[px][j]^2 (gdn.py:52-67): second contraction, K = N, fp32 MFMA; the squared
+        // tile is parked in LDS, gamma (reparametrised on the fly, parametrizers.py:42-45) is streamed 32 columns at a time
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[j][r];
+                X2[(wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * XP + wn0 + j * 32 + lr] = v * v;
+            }
+        f32x16 nrm[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nrm[j][r] = 0.f;
+        const __amdgpu_buffer_rsrc_t rgm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gamma), 0, a.gmbytes, 0x00020000);
+        constexpr int GR = NT / 8, GJ = BN / GR;                   // gamma rows per pass (8 float4 per 32-float row), passes
+        const int grow = tid >> 3, gc4 = tid & 7;
+        const int nkg = (a.N + KC - 1) / KC;
+        auto gload_gamma = [&](int kc, f32x4 (&g4)[GJ]) {
+            const int kcol = kc * KC + 4 * gc4;
+#pragma unroll
+            for (int j = 0; j < GJ; ++j) {
+                const int n = grow + GR * j;
+                const int mk = -(int)(n < a.N && kcol < a.N);
+                const int off = (((n * a.N + kcol) * 4) & mk) | (OOR & ~mk);
+                g4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgm, off, 0, 0));
+            }
+        };
+        f32x4 g4[GJ], g4n[GJ];
+        gload_gamma(0, g4);
+        for (int kc = 0; kc < nkg; ++kc) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < GJ; ++j) {
+                f32x4 v = g4[j];
+                const float bound = 3.814697265625e-06f, ped = 1.4551915228366852e-11f;      // 2^-18, 2^-36
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = fmaxf(v[e], bound);
+                    v[e] = g * g - ped;
+                }
+                *reinterpret_cast<f32x4 *>(&Gs[(grow + GR * j) * GP + 4 * gc4]) = v;
+            }
+            __syncthreads();
+            gload_gamma(kc + 1 < nkg ? kc + 1 : kc, g4n);
+            const float *Ab = X2 + (wm0 + lr) * XP + kc * KC + 4 * lh;
+            const float *Bb = Gs + (wn0 + lr) * GP + 4 * lh;
+#pragma unroll
+            for (int k8 = 0; k8 < KC / 8; ++k8) {
+                const f32x4 af = *reinterpret_cast<const f32x4 *>(Ab + k8 * 8);
+                f32x4 bf[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) bf[j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * GP + k8 * 8);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) nrm[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[j][s], nrm[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < GJ; ++j) g4[j] = g4n[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int n = wn0 + j * 32 + lr;
+            float bt = 1.f;
+            if (n < a.N) {
+                const float bb = fmaxf(a.beta[n], a.beta_bound);
+                bt = bb * bb - 1.4551915228366852e-11f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] *= __builtin_amdgcn_rsqf(nrm[j][r] + bt);
+        }
+    }
+
+    if (a.y) {      // fp32 NHWC output (last layer of the transform)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int n = wn0 + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = bm0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < Mtot && n < a.N) a.y[(size_t)m * a.ldy + n] = acc[j][r];
+            }
+        }
+    }
+    if (a.yp) {     // planes output for the next convolution: through LDS so that every thread stores whole 16-byte pieces
+        __syncthreads();                                   // the parked tile / the main-loop buffers are free
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) X2[(wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * XP + wn0 + j * 32 + lr] = acc[j][r];
+        __syncthreads();
+        const int oslab = a.N / KC, opix = oslab * 192;
+        unsigned char *yp = static_cast<unsigned char *>(a.yp);
+        for (int e = tid; e < BM * oslab * 4; e += NT) {
+            const int row = e / (oslab * 4), rem = e - row * (oslab * 4), sl = rem >> 2, p = rem & 3;
+            const int m = bm0 + row;
+            if (m >= Mtot || ((a.exper & 1) && m >= 0)) continue;
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&X2[row * XP + sl * 32 + p * 8]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(&X2[row * XP + sl * 32 + p * 8 + 4]);
+            bf16x8 h0, h1, h2;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                __bf16 x0, x1, x2;
+                split3(v0[c], x0, x1, x2);
+                h0[c] = x0; h1[c] = x1; h2[c] = x2;
+                split3(v1[c], x0, x1, x2);
+                h0[4 + c] = x0; h1[4 + c] = x1; h2[4 + c] = x2;
+            }
+            unsigned char *dst = yp + (size_t)m * opix + sl * 192 + p * 16;
+            *reinterpret_cast<bf16x8 *>(dst) = h0;
+            *reinterpret_cast<bf16x8 *>(dst + 64) = h1;
+            *reinterpret_cast<bf16x8 *>(dst + 128) = h2;
+        }
+    }
+}
+
+// fp32 NHWC -> planes: one thread per (pixel, slab, 8-channel piece)
+__global__ __launch_bounds__(256) void split_nhwc_kernel(const float *x, int ldx, unsigned char *xp, long npieces, int nslab)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= npieces) return;
+    const long pix = e / (nslab * 4);
+    const int rem = (int)(e - pix * (nslab * 4)), sl = rem >> 2, p = rem & 3;
+    const float *src = x + pix * ldx + sl * 32 + p * 8;
+    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
+    bf16x8 h0, h1, h2;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        __bf16 x0, x1, x2;
+        split3(v0[c], x0, x1, x2);
+        h0[c] = x0; h1[c] = x1; h2[c] = x2;
+        split3(v1[c], x0, x1, x2);
+        h0[4 + c] = x0; h1[4 + c] = x1; h2[4 + c] = x2;
+    }
+    unsigned char *dst = xp + pix * (long)(nslab * 192) + sl * 192 + p * 16;
+    *reinterpret_cast<bf16x8 *>(dst) = h0;
+    *reinterpret_cast<bf16x8 *>(dst + 64) = h1;
+    *reinterpret_cast<bf16x8 *>(dst + 128) = h2;
+}
+
+// planes -> fp32 NHWC (tests / debugging): the three planes add up to the fp32 value exactly
+__global__ __launch_bounds__(256) void merge_planes_kernel(const unsigned char *xp, float *x, int ldx, long nelem, int C)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= nelem) return;
+    const long pix = e / C;
+    const int c = (int)(e - pix * C), sl = c >> 5, k = c & 31;
+    const __bf16 *src = reinterpret_cast<const __bf16 *>(xp + pix * (long)((C / 32) * 192) + sl * 192);
+    x[pix * ldx + c] = ((float)src[k] + (float)src[32 + k]) + (float)src[64 + k];
+}
+
+// torch Conv2d weight [N][C][R][S] fp32 -> per chunk q = slab * R*S + tap the LDS image [plane][192 rows][64 B], piece p of
+// row n stored at p ^ ((n >> 2) & 3); rows n >= N are zero
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, unsigned char *wp, int N, int C, int RS, long npieces)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= npieces) return;
+    const int p = (int)(e & 3), n = (int)((e >> 2) % BN);
+    const long q = e / (4 * BN);
+    const int slab = (int)(q / RS), tap = (int)(q - (long)slab * RS);
+    bf16x8 h[3];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = slab * 32 + p * 8 + c;
+        const float v = n < N ? w[((size_t)n * C + ch) * RS + tap] : 0.f;
+        __bf16 x0, x1, x2;
+        split3(v, x0, x1, x2);
+        h[0][c] = x0; h[1][c] = x1; h[2][c] = x2;
+    }
+    unsigned char *dst = wp + q * B_BUF + n * 64 + ((p ^ ((n >> 2) & 3)) << 4);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8 *>(dst + pl * B_PLANE) = h[pl];
+}
+
+}   // namespace
+
+STEM_EXPORT size_t stem_bf16x3_planes_bytes(long npix, int C) { return C % 32 ? 0 : (size_t)npix * (C / 32) * 192; }
+
+STEM_EXPORT size_t stem_bf16x3_conv_weight_bytes(int C, int R, int S) { return C % 32 ? 0 : (size_t)(C / 32) * R * S * B_BUF; }
+
+STEM_EXPORT int stem_bf16x3_split_nhwc(const float *x, int ldx, void *xp, long npix, int C, void *stream)
+{
+    STEM_CHECK_ARG(x && xp && npix >= 0 && C > 0 && C % 32 == 0 && ldx >= C && ldx % 4 == 0,
+                   "stem_bf16x3_split_nhwc: channels must be a multiple of 32 and rows 16-byte aligned (C=%d ldx=%d)", C, ldx);
+    const long np = npix * (C / 32) * 4;
+    if (np == 0) return 0;
+    hipLaunchKernelGGL(split_nhwc_kernel, dim3((unsigned)cdivz(np, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       static_cast<unsigned char *>(xp), np, C / 32);
+    STEM_LAUNCH_CHECK("stem_bf16x3_split_nhwc");
+    return 0;
+}
+
+STEM_EXPORT int stem_bf16x3_merge_nhwc(const void *xp, float *x, int ldx, long npix, int C, void *stream)
+{
+    STEM_CHECK_ARG(x && xp && npix >= 0 && C > 0 && C % 32 == 0 && ldx >= C, "stem_bf16x3_merge_nhwc: bad arguments (C=%d ldx=%d)", C, ldx);
+    const long ne = npix * C;
+    if (ne == 0) return 0;
+    hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)cdivz(ne, 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const unsigned char *>(xp), x, ldx, ne, C);
+    STEM_LAUNCH_CHECK("stem_bf16x3_merge_nhwc");
+    return 0;
+}
+
+STEM_EXPORT int stem_bf16x3_pack_conv_weight(const float *w, void *wp, int N, int C, int R, int S, void *stream)
+{
+    STEM_CHECK_ARG(w && wp && N >= 1 && N <= BN && C > 0 && C % 32 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP,
+                   "stem_bf16x3_pack_conv_weight: N <= %d, C %% 32 == 0, R*S <= %d (N=%d C=%d R=%d S=%d)", BN, MAXTAP, N, C, R, S);
+    const long np = (long)(C / 32) * R * S * BN * 4;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)cdivz(np, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       static_cast<unsigned char *>(wp), N, C, R * S, np);
+    STEM_LAUNCH_CHECK("stem_bf16x3_pack_conv_weight");
+    return 0;
+}
+
+STEM_EXPORT int stem_conv2d_bf16x6_fwd(const void *xp, const void *wp, const float *bias, const float *beta, const float *gamma,
+                                       float beta_min, float *y, int ldy, void *yp, int B, int H, int W, int C, int N, int R, int S,
+                                       int stride, int pad, void *stream)
+{
+    STEM_CHECK_ARG(xp && wp && (y || yp), "stem_conv2d_bf16x6_fwd: null pointer");
+    STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && C >= 32 && C % 32 == 0 && N >= 1 && N <= BN && R >= 1 && S >= 1 && R * S <= MAXTAP &&
+                   stride >= 1 && pad >= 0, "stem_conv2d_bf16x6_fwd: C %% 32 == 0, N <= %d, R*S <= %d (C=%d N=%d R=%d S=%d)", BN, MAXTAP, C, N, R, S);
+    STEM_CHECK_ARG(!yp || N % 32 == 0, "stem_conv2d_bf16x6_fwd: planes output needs N %% 32 == 0 (N=%d)", N);
+    STEM_CHECK_ARG(!y || ldy >= N, "stem_conv2d_bf16x6_fwd: ldy < N");
+    STEM_CHECK_ARG((beta == nullptr) == (gamma == nullptr), "stem_conv2d_bf16x6_fwd: beta and gamma come together");
+    const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+    STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_bf16x6_fwd: empty output");
+    const size_t xb = stem_bf16x3_planes_bytes((long)B * H * W, C), wb = stem_bf16x3_conv_weight_bytes(C, R, S);
+    STEM_CHECK_ARG(xb < 0x7FFFFF00ull && wb < 0x7FFFFF00ull && (size_t)B * OH * OW < 0x7FFFFFFFull,
+                   "stem_conv2d_bf16x6_fwd: operand views must stay below 2 GiB (split the batch)");
+    Bx6Args a;
+    memset(&a, 0, sizeof(a));
+    a.xp = xp; a.wp = wp; a.bias = bias; a.beta = beta; a.gamma = gamma; a.y = y; a.yp = yp; a.ldy = ldy;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.OH = OH; a.OW = OW; a.stride = stride; a.ntaps = R * S;
+    a.xbytes = (int)xb; a.wbytes = (int)wb; a.gmbytes = N * N * 4;
+    a.fuse = gamma ? 1 : 0;
+    a.beta_bound = (float)sqrt((double)beta_min + 1.4551915228366852e-11);
+    for (int r = 0; r < R; ++r)
+        for (int s = 0; s < S; ++s) {
+            a.dy[r * S + s] = (signed char)(r - pad);
+            a.dx[r * S + s] = (signed char)(s - pad);
+        }
+    static bool attr_done = false;      // > 64 KiB of dynamic LDS needs an explicit opt-in
+    static int nprod = 6;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<128, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
+        const char *e = getenv("STEM_BF16_PRODUCTS");
+        if (e) nprod = atoi(e);
+        attr_done = true;
+    }
+    a.exper = getenv("STEM_BX6_EXPER") ? atoi(getenv("STEM_BX6_EXPER")) : 0;
+    const int np_now = getenv("STEM_BF16_PRODUCTS_DYN") ? atoi(getenv("STEM_BF16_PRODUCTS_DYN")) : nprod;     // experiments only
+    const int M = B * OH * OW;
+    hipStream_t st = (hipStream_t)stream;
+    // 128-pixel tiles (8 wavefronts) when they fill the 256 CUs at least once, 64-pixel tiles (4 wavefronts) below that
+    const bool small = cdiv(M, 128) < 256 && !(a.exper & 2);
+    if (small && np_now == 6)
+        hipLaunchKernelGGL((conv_bf16x6_kernel<64, 6>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
+    else if (np_now == 3)
+        hipLaunchKernelGGL((conv_bf16x6_kernel<128, 3>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
+    else if (np_now == 4)
+        hipLaunchKernelGGL((conv_bf16x6_kernel<128, 4>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
+    else
+        hipLaunchKernelGGL((conv_bf16x6_kernel<128, 6>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
+    STEM_LAUNCH_CHECK("stem_conv2d_bf16x6_fwd");
+    return 0;
+}

@@ -349,6 +349,76 @@ def conv2d_gdn_fwd(x, wp, bias, beta, gamma, K, R, S, stride, pad, inverse=False
     return out
 
 
+class Bf16Planes:
+    """An NHWC activation tensor pre-split for the bf16 matrix cores (csrc/conv_bf16x6.hip): every fp32 value is stored as the
+    three bf16 numbers that add up to it exactly, [pixel][C/32][3][32].  Only produced and consumed by the frozen analysis
+    transform's kernels (conv2d_bf16x6_fwd); `shape` is the logical [B,C,H,W]."""
+    __slots__ = ("data", "shape")
+
+    def __init__(self, data, shape):
+        self.data, self.shape = data, tuple(shape)
+
+    @staticmethod
+    def empty(B, Cc, H, W, device):
+        nbytes = _lib.hip().stem_bf16x3_planes_bytes(B * H * W, Cc)
+        if nbytes == 0:
+            raise ValueError(f"the planes layout needs a channel count that is a multiple of 32, got {Cc}")
+        return Bf16Planes(torch.empty(nbytes, device=device, dtype=torch.uint8), (B, Cc, H, W))
+
+    @staticmethod
+    def split(x):
+        x = to_nhwc(x)
+        B, Cc, H, W = x.shape
+        out = Bf16Planes.empty(B, Cc, H, W, x.device)
+        _chk(_lib.hip().stem_bf16x3_split_nhwc(x.data_ptr(), nhwc_ld(x), out.data.data_ptr(), B * H * W, Cc, _stream()))
+        return out
+
+    def merge(self):
+        B, Cc, H, W = self.shape
+        out = empty_nhwc(B, Cc, H, W, self.data.device)
+        _chk(_lib.hip().stem_bf16x3_merge_nhwc(self.data.data_ptr(), out.data_ptr(), Cc, B * H * W, Cc, _stream()))
+        return out
+
+
+def pack_weight_bf16x3(w: torch.Tensor) -> torch.Tensor:
+    """torch Conv2d weight [K,C,R,S] -> the chunked, pre-split LDS image conv2d_bf16x6_fwd streams."""
+    _require_cuda(w)
+    K, Cc, R, S = w.shape
+    nbytes = _lib.hip().stem_bf16x3_conv_weight_bytes(Cc, R, S)
+    if nbytes == 0:
+        raise ValueError(f"bf16x3 weights need an input channel count that is a multiple of 32, got {Cc}")
+    out = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+    _chk(_lib.hip().stem_bf16x3_pack_conv_weight(w.detach().contiguous().data_ptr(), out.data_ptr(), K, Cc, R, S, _stream()))
+    return out
+
+
+def conv2d_bf16x6_fwd(xp: Bf16Planes, wp, bias, K, R, S, stride, pad, beta=None, gamma=None, beta_min=1e-6, planes_out=False):
+    """Conv2d (+ GDN when beta / gamma are given) of a planes tensor with fp32 accuracy on the bf16 matrix cores.
+    Returns an NHWC fp32 tensor, or a Bf16Planes for the next convolution of the chain."""
+    B, Cc, H, W = xp.shape
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    dev = xp.data.device
+    if planes_out:
+        out = Bf16Planes.empty(B, K, Ho, Wo, dev)
+        y, ldy, yp = None, 0, out.data.data_ptr()
+    else:
+        out = empty_nhwc(B, K, Ho, Wo, dev)
+        y, ldy, yp = out.data_ptr(), nhwc_ld(out), None
+    _chk(_lib.hip().stem_conv2d_bf16x6_fwd(xp.data.data_ptr(), wp.data_ptr(), _ptr(bias), _ptr(beta), _ptr(gamma), beta_min,
+                                           y, ldy, yp, B, H, W, Cc, K, R, S, stride, pad, _stream()))
+    return out
+
+
+def conv2d_fwd_c4_gdn_planes(x4, wp, bias, beta, gamma, K, R, S, stride, pad, beta_min=1e-6):
+    """conv2d_fwd_c4_gdn whose result is handed to conv2d_bf16x6_fwd: written pre-split (Bf16Planes), no fp32 copy."""
+    B, H, W, _ = x4.shape
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    out = Bf16Planes.empty(B, K, Ho, Wo, x4.device)
+    _chk(_lib.hip().stem_conv2d_fwd_c4_gdn_planes(x4.data_ptr(), wp.data_ptr(), _ptr(bias), beta.data_ptr(), gamma.data_ptr(),
+                                                  out.data.data_ptr(), B, H, W, K, R, S, stride, pad, beta_min, _stream()))
+    return out
+
+
 def conv2d_fwd_c4_gdn(x4, wp, bias, beta, gamma, K, R, S, stride, pad, inverse=False, beta_min=1e-6, out=None):
     B, H, W, _ = x4.shape
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)

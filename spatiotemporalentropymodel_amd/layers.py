@@ -9,6 +9,7 @@ forward/backward run the HIP kernels through the C ABI.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -34,6 +35,9 @@ def weight_epoch(w):
     return (_WEIGHT_EPOCH[0], getattr(w, "_stem_epoch", 0))
 
 
+PACK_BF16X3 = -3          # _PackCache role of the pre-split bf16 image (csrc/conv_bf16x6.hip); not a stem_pack_* role
+
+
 class _PackCache:
     """Packed weight copies, rebuilt only when the parameter changed."""
 
@@ -45,7 +49,7 @@ class _PackCache:
         hit = self._c.get(role)
         if hit is not None and hit[0] == key:
             return hit[1]
-        wp = F.pack_weight(w, role, masked)
+        wp = F.pack_weight_bf16x3(w) if role == PACK_BF16X3 else F.pack_weight(w, role, masked)
         if (masked & 3) == 2:                    # the kernel zeroed taps of w in place
             key = (w._version, w.data_ptr(), weight_epoch(w), tuple(w.shape))
         self._c[role] = (key, wp)
@@ -434,39 +438,91 @@ def _conv_gdn_fused(conv_mod, gdn, x):
                             conv_mod.stride, conv_mod.padding, gdn.inverse, gdn.beta_min)
 
 
+def _bf16x6_enabled():
+    """fp32-accurate convolutions on the bf16 matrix cores for inference-only chains (csrc/conv_bf16x6.hip).  STEM_BF16X6=0
+    selects the fp32-MFMA kernels everywhere."""
+    return os.environ.get("STEM_BF16X6", "1") != "0"
+
+
+#: fewest output pixels for which the bf16 kernel beats the fp32-MFMA one (64-pixel tiles, no split-K: below ~3/4 of the CUs
+#: the split-K fp32 kernel wins; measured on g_a.6 at B=16: 4096 pixels)
+_BF16X6_MIN_PIXELS = 12288
+
+
+def _bf16x6_eligible(m, in_shape):
+    """Can conv `m`, applied to an input of logical shape `in_shape` = (B, C, H, W), run on csrc/conv_bf16x6.hip?"""
+    if not (type(m) is Conv2d and not m._masked and m.in_channels % 32 == 0 and m.out_channels <= 192
+            and m.kernel_size * m.kernel_size <= 25 and m.weight.is_cuda):
+        return False
+    B, _, H, W = in_shape
+    Ho, Wo = F.conv_out_hw(H, W, m.kernel_size, m.kernel_size, m.stride, m.padding)
+    return B * Ho * Wo >= _BF16X6_MIN_PIXELS
+
+
+def _conv_out_shape(m, in_shape):
+    B, _, H, W = in_shape
+    Ho, Wo = F.conv_out_hw(H, W, m.kernel_size, m.kernel_size, m.stride, m.padding)
+    return (B, m.out_channels, Ho, Wo)
+
+
 class FusedSequential(nn.Sequential):
     #: optional (index, list) pair set by bench.py: HIP events are recorded around the kernel(s) of child `index`
     probe = None
 
+    def _timed(self, i, fn):
+        if self.probe is None or self.probe[0] != i:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.probe[1].append((e0, e1))
+        return out
+
     def forward(self, x):
         mods = list(self)
+        nograd = not torch.is_grad_enabled()
+        bx6 = nograd and _bf16x6_enabled()
         i = 0
         while i < len(mods):
             m = mods[i]
-            if (isinstance(m, (Conv2d, ConvTranspose2d)) and i + 1 < len(mods) and isinstance(mods[i + 1], GDN)
-                    and not torch.is_grad_enabled() and m.out_channels <= 192 and m.out_channels % 4 == 0
-                    and m.in_channels % 4 in (0, 3)):
-                if self.probe is not None and self.probe[0] == i:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    x = _conv_gdn_fused(m, mods[i + 1], x)
-                    e1.record()
-                    self.probe[1].append((e0, e1))
-                else:
-                    x = _conv_gdn_fused(m, mods[i + 1], x)
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if bx6 and type(m) is Conv2d:
+                # frozen / inference chain of convolutions (the analysis transform): operands pre-split into bf16 planes, the
+                # following GDN fused, the output written as planes again when the next convolution takes them.  A chain
+                # starts where the next convolution is eligible too -- either at the 3-channel first layer, whose fp32 kernel
+                # then writes planes, or with a split pass over an fp32 tensor -- and runs until one is not eligible.
+                gdn = nxt if isinstance(nxt, GDN) and not nxt.inverse else None
+                j = i + (2 if gdn is not None else 1)
+                K, R = m.out_channels, m.kernel_size
+                out_shape = _conv_out_shape(m, x.shape)
+                chain = K % 32 == 0 and j < len(mods) and mods[j].__class__ is Conv2d and mods[j].in_channels == K \
+                    and _bf16x6_eligible(mods[j], out_shape)
+                if (chain and gdn is not None and m.in_channels == 3 and not isinstance(x, F.Bf16Planes) and F.nhwc_ld(x) is None
+                        and K <= 192):
+                    wp = m._packs.get(m.weight, F.PACK_CONV_FWD_C4)
+                    x = self._timed(i, lambda: F.conv2d_fwd_c4_gdn_planes(F.nchw3_to_nhwc4(x), wp, m.bias, gdn.beta, gdn.gamma, K, R, R,
+                                                                          m.stride, m.padding, gdn.beta_min))
+                    i = j
+                    continue
+                if _bf16x6_eligible(m, x.shape) and (isinstance(x, F.Bf16Planes) or (chain and x.is_cuda)):
+                    xin = x if isinstance(x, F.Bf16Planes) else F.Bf16Planes.split(x)
+                    wp = m._packs.get(m.weight, PACK_BF16X3)
+                    x = self._timed(i, lambda: F.conv2d_bf16x6_fwd(xin, wp, m.bias, K, R, R, m.stride, m.padding,
+                                                                   gdn.beta if gdn is not None else None,
+                                                                   gdn.gamma if gdn is not None else None,
+                                                                   gdn.beta_min if gdn is not None else 1e-6, planes_out=chain))
+                    i = j
+                    continue
+            if (isinstance(m, (Conv2d, ConvTranspose2d)) and isinstance(nxt, GDN) and nograd and m.out_channels <= 192
+                    and m.out_channels % 4 == 0 and m.in_channels % 4 in (0, 3)):
+                x = self._timed(i, lambda: _conv_gdn_fused(m, nxt, x))
                 i += 2
                 continue
-            if isinstance(m, (Conv2d, ConvTranspose2d)) and i + 1 < len(mods) and isinstance(mods[i + 1], (nn.LeakyReLU, nn.ReLU)):
-                nxt = mods[i + 1]           # LeakyReLU(slope) or ReLU (= slope 0) folded into the conv epilogue
+            if isinstance(m, (Conv2d, ConvTranspose2d)) and isinstance(nxt, (nn.LeakyReLU, nn.ReLU)):
+                # LeakyReLU(slope) or ReLU (= slope 0) folded into the conv epilogue
                 slope = float(nxt.negative_slope) if isinstance(nxt, nn.LeakyReLU) else 0.0
-                if self.probe is not None and self.probe[0] == i:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    x = m(x, act=F.ACT_LRELU, slope=slope)
-                    e1.record()
-                    self.probe[1].append((e0, e1))
-                else:
-                    x = m(x, act=F.ACT_LRELU, slope=slope)
+                x = self._timed(i, lambda: m(x, act=F.ACT_LRELU, slope=slope))
                 i += 2
             else:
                 x = m(x)
