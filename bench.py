@@ -30,6 +30,9 @@ BATCH, SIZE, FRAMES = 16, 256, 7
 # the 192-ch 5x5 stride-2 analysis conv g_a.2 (7.550 GF/frame) + the GDN contraction fused
 # into its epilogue (g_a.3, 0.302 GF/frame): one kernel launch per frame batch
 GA2_FLOP_PER_FRAME = 2 * 192 * 192 * 25 * 64 * 64 + 2 * 192 * 192 * 64 * 64
+GA2_CONV_FLOP_PER_FRAME = 2 * 192 * 192 * 25 * 64 * 64           # the convolution alone (the part that runs as 6 bf16 MFMAs per product)
+GA0_FLOP_PER_FRAME = 2 * 192 * 3 * 25 * 128 * 128 + 2 * 192 * 192 * 128 * 128      # g_a.0 (3 -> 192, 5x5 s2) + fused GDN g_a.1
+PEAK_BF16_MFMA_TFLOPS = 2516.6       # same guide: v_mfma_f32_32x32x16_bf16, 1024 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz (dense)
 
 
 def synthetic_septuplet(batch, size, seed, device):
@@ -220,6 +223,7 @@ def bench_roi(args):
     for _ in range(args.warmup):
         roi_gop_step(imodel, pmodel, crit, opts, frames, qmap, 1.0, accumulator=acc)
     probe.clear()
+    probe0.clear()
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -294,8 +298,9 @@ def main():
 
     # HIP-event probe around the dominant kernel (g_a.2 + fused GDN, the 192-ch 5x5 stride-2 analysis conv) on the
     # stream it is launched on (= torch's current stream, which is what the C ABI receives)
-    probe = []
-    imodel.g_a.probe = (2, probe)
+    probe, probe0 = [], []
+    imodel.g_a.probe = {2: probe, 0: probe0}
+    bf16_chain = os.environ.get("STEM_BF16X6", "1") != "0"
 
     # --graph (single device): the P-frame step (zero_grad .. aux Adam, ~160 launches) is replayed from ONE hipGraph per
     # step (graphs.GraphedPFrameStep); getY stays eager so that the HIP-event probe can bracket its dominant kernel.  Data
@@ -334,6 +339,7 @@ def main():
     for _ in range(args.warmup):
         one_step()
     probe.clear()
+    probe0.clear()
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -347,12 +353,43 @@ def main():
     loss = float(last["loss"].detach())
     if rank != 0:
         return
+    kern0_ms = float(np.mean([a.elapsed_time(b) for a, b in probe0])) if probe0 else float("nan")
     flop = GA2_FLOP_PER_FRAME * BATCH
-    achieved = flop / (kern_ms * 1e-3) / 1e12
-    traffic = None
-    tf = os.path.join(REPO, "profiles", "hbm_traffic.json")
-    if os.path.exists(tf):
-        traffic = json.load(open(tf)).get("g_a2_bytes_per_launch")
+    tfile = os.path.join(REPO, "profiles", "hbm_traffic.json")
+    tj = json.load(open(tfile)) if os.path.exists(tfile) else {}
+    # the largest fp32-MFMA kernel of the step, measured the same way (HIP events on the launching stream)
+    flop0 = GA0_FLOP_PER_FRAME * BATCH
+    fp32_line = {"bound": "mfma", "kernel": "igemm_kernel<128,192,32,96,C4,FUSE> = g_a.0 conv (3->192, 5x5 s2, 256^2->128^2, B=16) + fused GDN g_a.1 "
+                                            "(v_mfma_f32_32x32x2_f32; the GDN contraction is 72 % of its flop)",
+                 "achieved": flop0 / (kern0_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                 "frac": flop0 / (kern0_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, "flop_per_launch": flop0, "avg_launch_ms": kern0_ms,
+                 "launches_timed": len(probe0), "traffic": None}
+    if bf16_chain:
+        # Dominant kernel: g_a.2 + GDN on the bf16 matrix cores.  Every fp32 product is SIX bf16 MFMA products (conv_bf16x6.hip), so
+        # the matrix pipe executes 6x the convolution's algorithmic flop; `achieved` / `frac` are that executed bf16 rate against
+        # the dense bf16 peak (reported against the bf16 peak, never mixed into the fp32 fraction).  The
+        # algorithmic (fp32-equivalent) rate is given next to it, with its ratio to the fp32-MFMA peak the previous kernel was held to.
+        executed = 6 * GA2_CONV_FLOP_PER_FRAME * BATCH
+        achieved = executed / (kern_ms * 1e-3) / 1e12
+        alg = flop / (kern_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_bf16x6_kernel<128,6> = g_a.2 conv (192->192, 5x5 s2, 128^2->64^2, B=16) + fused GDN g_a.3: operands "
+                                           "pre-split into 3 bf16 planes, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate",
+                "achieved": achieved, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_MFMA_TFLOPS,
+                "flop_per_launch": executed, "flop_definition": "executed bf16 MFMA flop = 6 x algorithmic conv flop (the fused GDN's 4.8 GF of fp32 MFMA not counted)",
+                "algorithmic_flop_per_launch": flop, "algorithmic_tflops": alg, "algorithmic_vs_fp32_mfma_peak": alg / PEAK_FP32_MFMA_TFLOPS,
+                "avg_launch_ms": kern_ms, "launches_timed": len(probe),
+                "clock_note": "power-bound: GRBM_GUI_ACTIVE / duration = 1.54 GHz under this kernel (2.4 GHz nominal), matrix pipe busy 62 % of "
+                              "those cycles (profiles/r02_pmc_bf16x6_*.csv); the guide's sustained bf16 rate on random data is ~1250 TFLOP/s",
+                "traffic": tj.get("g_a2_bf16x6_bytes_per_launch"),
+                "traffic_source": "profiles/hbm_traffic.json: separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE) over "
+                                  "tools/debug/bf16x6_prof.py planes, NOT re-measured in this run"}
+    else:
+        achieved = flop / (kern_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "igemm_kernel<128,192,32,96,FUSE> = g_a.2 conv (192->192, 5x5 s2, 128^2->64^2, B=16) + fused GDN g_a.3",
+                "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "flop_per_launch": flop, "avg_launch_ms": kern_ms, "launches_timed": len(probe), "traffic": tj.get("g_a2_bytes_per_launch"),
+                "traffic_source": "profiles/hbm_traffic.json: HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + "
+                                  "WRITE_SIZE, tools/kernel_bench.py --only g_a.2+gdn), NOT re-measured in this run"}
     res = {
         "metric": "frames/s", "value": FRAMES * BATCH * world * args.steps / dt, "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -361,13 +398,11 @@ def main():
                                "16 septuplets x 7 frames x 256x256 per GPU, EMLoss, clip 1.0 + Adam 1e-4 / aux Adam 1e-3",
                    "per_gpu_batch": BATCH, "global_batch": BATCH * world, "frames_per_step": FRAMES * BATCH * world,
                    "p_frame_steps_per_step": FRAMES - 1, "parallelism": f"dp{world}", "final_loss_bpp": loss,
+                   "analysis_transform": "bf16 matrix cores, 6 products per fp32 product (conv_bf16x6.hip)" if bf16_chain else "fp32 MFMA",
                    "launch": "hipGraph replay per P-frame step" if use_graph else
                              ("explicit fused schedule (trainer.FusedPFrameStep)" if fused_step is not None else "generic nn.Module / autograd route")},
-        "roofline": {"bound": "mfma", "kernel": "igemm_kernel<128,192,32,96,FUSE> = g_a.2 conv (192->192, 5x5 s2, 128^2->64^2, B=16) + fused GDN g_a.3",
-                     "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                     "flop_per_launch": flop, "avg_launch_ms": kern_ms, "launches_timed": len(probe), "traffic": traffic,
-                     "traffic_source": "profiles/hbm_traffic.json: HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE x2 + "
-                                       "WRITE_SIZE, tools/kernel_bench.py --only g_a.2+gdn), NOT re-measured in this run"},
+        "roofline": roof,
+        "roofline_fp32_mfma": fp32_line,
     }
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()

@@ -361,6 +361,30 @@ int stem_conv2d_bf16x6_fwd(const void *xp, const void *wp, const float *bias, co
                            float beta_min, float *y, int ldy, void *yp, int B, int H, int W, int C, int N, int R, int S,
                            int stride, int pad, void *stream);
 
+/* General variant of stem_conv2d_bf16x6_fwd for the small-M layers of the STEM network at training time: any N (tiles of 128
+ * output channels), split-K with an in-kernel deterministic reduction, epilogue epi = 0 bias | 1 bias + leaky ReLU(slope) |
+ * 2 times the leaky ReLU derivative selected by z (the input-gradient of a convolution whose input was activated:
+ * torch autograd of spatiotemporalpriors.py:814-838).  Weights: stem_bf16x3_pack_conv_weight_gen of the torch weight
+ * [K][C][R][S]; flip = 1 packs the operand of the input-gradient of a stride-1 convolution (then N = C, and the planes input is
+ * dy with K channels).  ws: stem_conv2d_bf16x6_gen_workspace_bytes bytes whose first 64 KiB are zero before the first use
+ * (the kernel leaves them zero -- the same contract as stem_conv_workspace_bytes, the buffer may be shared); null = unsplit.  Results do not depend on which workgroup arrives last. */
+size_t stem_bf16x3_conv_weight_gen_bytes(int N, int C, int R, int S);
+int stem_bf16x3_pack_conv_weight_gen(const float *w, void *wp, int N, int C, int R, int S, int flip, void *stream);
+/* all layers of a training model with one launch (their weights change every optimiser step); N, C as in the single call, i.e.
+ * already swapped for flip = 1 */
+typedef struct {
+    const void *w;
+    void *wp;
+    int N, C, R, S, flip, reserved;
+} stem_bf16x3_pack_desc;
+int stem_bf16x3_pack_conv_weights_multi(const stem_bf16x3_pack_desc *descs, int n, void *stream);
+size_t stem_conv2d_bf16x6_gen_workspace_bytes(int B, int H, int W, int C, int N, int R, int S, int stride, int pad);
+/* xpix: bytes per pixel of the planes buffer xp points into (0 = dense, (C/32) * 192); xp may point at a 32-channel-aligned
+ * slab of a wider planes tensor */
+int stem_conv2d_bf16x6_gen_fwd(const void *xp, int xpix, const void *wp, const float *bias, int epi, float slope, const float *z, int ldz,
+                               float *y, int ldy, void *yp, int B, int H, int W, int C, int N, int R, int S, int stride, int pad,
+                               void *ws, size_t ws_bytes, void *stream);
+
 /* Wavefront-parallel encoder: all latent positions with the same t = w + 3h are independent under the 5x5
  * type-A mask, so a H x W frame is coded in W + 3(H-1) batched steps instead of H*W sequential ones.  Input
  * segment of position p at (h, w): x + sh*h + sw*w + sp*p (element offsets); output y[p*ldy + n].            */

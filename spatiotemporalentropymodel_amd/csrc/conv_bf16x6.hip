@@ -49,8 +49,18 @@ struct Bx6Args {
     float beta_bound;
     int fuse;                      // 0: bias only, 1: GDN
     int exper;                     // tuning experiments (STEM_BX6_EXPER), 0 in production
+    // general variant (conv_bf16x6_gen_kernel): activation epilogue, N tiles, split-K
+    const float *z;                // EPI_DACT: the activation output the slope is selected by (z > 0 ? 1 : slope)
+    int ldz, epi;                  // epi: 0 bias, 1 bias + leaky ReLU, 2 times d(leaky ReLU)(z)
+    float slope;
+    float *ws;                     // split-K partial tiles [nsplit][M][gridDim.y * BN]
+    int *cnt;                      // one arrival counter per output tile, zero before and after every launch
+    int nsplit, cps;               // blockIdx.z = split, chunks [split * cps, (split + 1) * cps)
+    int xpix;                      // bytes per pixel of the planes buffer x lives in (a 32-channel-aligned slice of a wider tensor)
     signed char dy[MAXTAP], dx[MAXTAP];
 };
+
+__device__ inline int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
 __device__ inline void split3(const float x, __bf16 &h0, __bf16 &h1, __bf16 &h2)
 {
@@ -347,6 +357,319 @@ __global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// General variant for the small-M layers of the STEM network at training time (16x16 latents: 4096 pixels per batch of 16):
+// 64 pixels x 128 channels per workgroup (4 wavefronts as 2 x 2, each 32 x 64), N tiles over blockIdx.y, split-K over
+// blockIdx.z with the in-kernel last-arriver reduction of igemm.hip (agent-scope partials, integer ticket, fixed summation
+// order), 72 KiB of LDS so that two workgroups share a CU.  Epilogue through an LDS tile: bias, leaky ReLU or its derivative
+// (dgrad of a conv whose input was activated), fp32 rows with a pitch (the result may be a channel slice of a wider buffer)
+// and / or planes for the next layer.  Weight image per (N tile, chunk): [3][128][64 B], swizzled like the 192-row one.
+enum { GEN_EPI_BIAS = 0, GEN_EPI_LRELU = 1, GEN_EPI_DACT = 2 };
+constexpr int GBM = 64, GBN = 128, GNT = 256;
+constexpr int GA_PLANE = GBM * 64, GA_BUF = 3 * GA_PLANE;            // 12288
+constexpr int GB_PLANE = GBN * 64, GB_BUF = 3 * GB_PLANE;            // 24576
+constexpr int GTP = GBN + 4;                                         // fp32 pitch of the epilogue tile
+constexpr int GLDS = 2 * (GA_BUF + GB_BUF) + 32 * 4;                 // 73856 (the 64 x 132 float epilogue tile reuses the front)
+
+__global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *As = smem;                        // [2][3][64][64 B]
+    unsigned char *Bs = smem + 2 * GA_BUF;           // [2][3][128][64 B]
+    int *tapi = reinterpret_cast<int *>(smem + 2 * (GA_BUF + GB_BUF));
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Mtot = a.B * a.OH * a.OW;
+    const int bm0 = blockIdx.x * GBM, bn0 = blockIdx.y * GBN, zsplit = blockIdx.z;
+    const int nslab = a.C / KC, pixbytes = a.xpix;
+    if (tid < 32) tapi[tid] = tid < a.ntaps ? (a.dy[tid] * a.W + a.dx[tid]) * pixbytes : 0;
+
+    const int srow = tid >> 2, scol = tid & 3;
+    int pb;
+    unsigned pmask = 0;
+    {
+        const int m = bm0 + srow;
+        const bool ok = m < Mtot;
+        const int mm = ok ? m : 0;
+        const int ohw = a.OH * a.OW, b = mm / ohw, rem = mm - b * ohw, qy = rem / a.OW, qx = rem - qy * a.OW;
+        const int by = qy * a.stride, bx = qx * a.stride;
+        pb = ((b * a.H + by) * a.W + bx) * pixbytes + scol * 16;
+        for (int t = 0; t < a.ntaps; ++t) {
+            const int iy = by + a.dy[t], ix = bx + a.dx[t];
+            if (ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) pmask |= 1u << t;
+        }
+    }
+    const int a_st = srow * 64 + ((scol ^ ((srow >> 2) & 3)) << 4);
+    const int nchunks = a.ntaps * nslab;
+    const int q_begin = zsplit * a.cps;
+    const int q_end = q_begin + a.cps < nchunks ? q_begin + a.cps : nchunks;
+    const int q_last = q_end - 1;
+    const int wbase = blockIdx.y * nchunks;          // this N tile's chunk sequence inside the packed weights
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.xp), 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wp), 0, a.wbytes, 0x00020000);
+
+    f32x4 raA[3], rbA[6], raB[3], rbB[6];
+    auto gload = [&](int t, int kc, int q, f32x4 (&ra)[3], f32x4 (&rb)[6]) {
+        const int tA = __builtin_amdgcn_readfirstlane(tapi[t]), sA = kc * 192, sB = (wbase + q) * GB_BUF;
+        const int mk = __builtin_amdgcn_sbfe((int)pmask, (unsigned)t, 1u);
+        const int off = ((pb + tA) & mk) | (OOR & ~mk);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) ra[pl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off + pl * 64, sA, 0));
+#pragma unroll
+        for (int j = 0; j < 6; ++j) rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, tid * 16 + j * 4096, sB, 0));
+    };
+    auto sstore = [&](int buf, f32x4 (&ra)[3], f32x4 (&rb)[6]) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<f32x4 *>(As + buf * GA_BUF + pl * GA_PLANE + a_st) = ra[pl];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4 *>(Bs + buf * GB_BUF + j * 4096 + tid * 16) = rb[j];
+    };
+
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int sw = (lr >> 2) & 3;
+    const int rdA = (wm0 + lr) * 64, rdB = (wn0 + lr) * 64;
+    const int pk0 = ((0 + lh) ^ sw) << 4, pk1 = ((2 + lh) ^ sw) << 4;
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    int pf_q = 0, pf_t = 0, pf_kc = 0;
+    auto step = [&](int cur, f32x4 (&ra)[3], f32x4 (&rb)[6]) {
+        const unsigned char *Ab = As + cur * GA_BUF + rdA, *Bb = Bs + cur * GB_BUF + rdB;
+        const int t = __builtin_amdgcn_readfirstlane(pf_t), kc = __builtin_amdgcn_readfirstlane(pf_kc), q = __builtin_amdgcn_readfirstlane(pf_q);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pk = ks ? pk1 : pk0;
+            bf16x8 af[3], bf[3][2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const bf16x8 *>(Ab + pl * GA_PLANE + pk);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8 *>(Bb + pl * GB_PLANE + j * 32 * 64 + pk);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0][j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2][j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1][j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0][j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1][j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0][j], acc[j], 0, 0, 0);
+            }
+            if (ks == 0)
+                sstore(cur ^ 1, ra, rb);
+            else
+                gload(t, kc, q, ra, rb);
+        }
+        if (pf_q < q_last) {
+            ++pf_q;
+            if (++pf_t == a.ntaps) {
+                pf_t = 0;
+                ++pf_kc;
+            }
+        }
+    };
+    auto chunk_of = [&](int q, int &t, int &kc) {
+        q = q < q_last ? q : q_last;
+        kc = q / a.ntaps;
+        t = q - kc * a.ntaps;
+        return q;
+    };
+    if (q_begin < q_end) {
+        int t, kc, q;
+        q = chunk_of(q_begin, t, kc);
+        gload(t, kc, q, raA, rbA);
+        sstore(0, raA, rbA);
+        q = chunk_of(q_begin + 1, t, kc);
+        gload(t, kc, q, raA, rbA);
+        q = chunk_of(q_begin + 2, t, kc);
+        gload(t, kc, q, raB, rbB);
+        pf_q = chunk_of(q_begin + 3, pf_t, pf_kc);
+    }
+    __syncthreads();
+    {
+        int q = q_begin;
+        for (; q + 1 < q_end; q += 2) {
+            step(0, raA, rbA);
+            __syncthreads();
+            step(1, raB, rbB);
+            __syncthreads();
+        }
+        if (q < q_end) {
+            step(0, raA, rbA);
+            __syncthreads();
+        }
+    }
+
+    // ---- sums of this workgroup -> the epilogue tile T (directly, or through the split-K workspace) -----------------------
+    float *T = reinterpret_cast<float *>(smem);                     // [GBM][GTP]
+    const int Npad = gridDim.y * GBN;
+    if (a.nsplit > 1) {
+        float *wsp = a.ws + (size_t)zsplit * Mtot * Npad;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = bn0 + wn0 + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = bm0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m < Mtot) __hip_atomic_store(&wsp[(size_t)m * Npad + n], acc[j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // arrival protocol of igemm.hip: partials moved with agent-scope accesses (no device-wide fence), stores acknowledged,
+        // one ticket per workgroup; the last arriver owns the tile and re-zeroes the counter
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            int *c = a.cnt + blockIdx.y * gridDim.x + blockIdx.x;
+            const int ticket = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = ticket == a.nsplit - 1;
+            if (last) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tapi[0] = last;
+        }
+        __syncthreads();
+        if (!tapi[0]) return;
+        constexpr int SC1 = 16;               // sc1: read at the device-coherent level, not this XCD's L2
+        const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)((size_t)a.nsplit * Mtot * Npad * 4), 0x00020000);
+        const int sstep = Mtot * Npad * 4;
+        for (int e = tid; e < GBM * (GBN / 4); e += GNT) {
+            const int row = e / (GBN / 4), c4 = e - row * (GBN / 4);
+            const int m = bm0 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < Mtot) {
+                const int off0 = (m * Npad + bn0 + c4 * 4) * 4;
+                int sp = 0;
+                for (; sp + 4 <= a.nsplit; sp += 4) {
+                    f32x4 t[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) t[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, off0 + (sp + u) * sstep, 0, SC1));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v += t[u];
+                }
+                for (; sp < a.nsplit; ++sp) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, off0 + sp * sstep, 0, SC1));
+            }
+            *reinterpret_cast<f32x4 *>(&T[row * GTP + c4 * 4]) = v;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[(wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * GTP + wn0 + j * 32 + lr] = acc[j][r];
+    }
+    __syncthreads();
+    // ---- bias / activation, fp32 rows (16 bytes per thread), activated values back into T for the planes pass -----------------
+    for (int e = tid; e < GBM * (GBN / 4); e += GNT) {
+        const int row = e / (GBN / 4), c4 = e - row * (GBN / 4);
+        const int m = bm0 + row, n = bn0 + c4 * 4;
+        if (m >= Mtot || n >= a.N) continue;                // N % 4 == 0 (host check)
+        f32x4 v = *reinterpret_cast<const f32x4 *>(&T[row * GTP + c4 * 4]);
+        if (a.bias) {               // parameters may sit at any 4-byte offset of a flat buffer: scalar loads
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += a.bias[n + c];
+        }
+        if (a.epi == GEN_EPI_LRELU) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] : v[c] * a.slope;
+        } else if (a.epi == GEN_EPI_DACT) {
+            const f32x4 zz = *reinterpret_cast<const f32x4 *>(a.z + (size_t)m * a.ldz + n);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = zz[c] > 0.f ? v[c] : v[c] * a.slope;
+        }
+        if (a.y) *reinterpret_cast<f32x4 *>(a.y + (size_t)m * a.ldy + n) = v;
+        *reinterpret_cast<f32x4 *>(&T[row * GTP + c4 * 4]) = v;
+    }
+    if (a.yp) {
+        __syncthreads();
+        const int oslab = a.N / KC, opix = oslab * 192;
+        unsigned char *yp = static_cast<unsigned char *>(a.yp);
+        for (int e = tid; e < GBM * (GBN / 8); e += GNT) {
+            const int row = e / (GBN / 8), c8 = e - row * (GBN / 8);
+            const int m = bm0 + row, n = bn0 + c8 * 8;
+            if (m >= Mtot || n >= a.N) continue;            // N % 32 == 0 for planes (host check)
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&T[row * GTP + c8 * 8]);
+            const f32x4 v1 = *reinterpret_cast<const f32x4 *>(&T[row * GTP + c8 * 8 + 4]);
+            bf16x8 h0, h1, h2;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                __bf16 x0, x1, x2;
+                split3(v0[c], x0, x1, x2);
+                h0[c] = x0; h1[c] = x1; h2[c] = x2;
+                split3(v1[c], x0, x1, x2);
+                h0[4 + c] = x0; h1[4 + c] = x1; h2[4 + c] = x2;
+            }
+            unsigned char *dst = yp + (size_t)m * opix + (n >> 5) * 192 + ((n >> 3) & 3) * 16;
+            *reinterpret_cast<bf16x8 *>(dst) = h0;
+            *reinterpret_cast<bf16x8 *>(dst + 64) = h1;
+            *reinterpret_cast<bf16x8 *>(dst + 128) = h2;
+        }
+    }
+}
+
+// weights for conv_bf16x6_gen_kernel: [N tile][chunk q = slab * R*S + tap][plane][128 rows][64 B].  flip: the input-gradient of
+// a stride-1 convolution is a convolution of dy with w'[c][k][r][s] = w[k][c][R-1-r][S-1-s]: `w` is still the torch weight
+// [K][C][R][S], the packed rows are its input channels c (N = C outputs) and the packed channels its output channels k.
+__global__ __launch_bounds__(256) void pack_weight_gen_kernel(const float *w, unsigned char *wp, int N, int C, int RS, int flip, long npieces)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= npieces) return;
+    const int nchunks = (C / 32) * RS;
+    const int p = (int)(e & 3), nl = (int)((e >> 2) % GBN);
+    const long qq = e / (4 * GBN);                       // ntile * nchunks + q
+    const int ntile = (int)(qq / nchunks), q = (int)(qq - (long)ntile * nchunks);
+    const int slab = q / RS, tap = q - slab * RS, n = ntile * GBN + nl;
+    bf16x8 h[3];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = slab * 32 + p * 8 + c;
+        float v = 0.f;
+        if (n < N) v = flip ? w[((size_t)ch * N + n) * RS + (RS - 1 - tap)] : w[((size_t)n * C + ch) * RS + tap];
+        __bf16 x0, x1, x2;
+        split3(v, x0, x1, x2);
+        h[0][c] = x0; h[1][c] = x1; h[2][c] = x2;
+    }
+    unsigned char *dst = wp + qq * GB_BUF + nl * 64 + ((p ^ ((nl >> 2) & 3)) << 4);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8 *>(dst + pl * GB_PLANE) = h[pl];
+}
+
+// every layer's weight image with one launch: blockIdx.y = descriptor (the weights of a training model change every step).  The
+// table travels by value in the kernel arguments: no staging buffer whose lifetime would have to outlast the queued launch.
+constexpr int MAXPACK = 24;
+struct PackTable {
+    stem_bf16x3_pack_desc d[MAXPACK];
+};
+__global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTable tab)
+{
+    const stem_bf16x3_pack_desc &d = tab.d[blockIdx.y];
+    const int RS = d.R * d.S, nchunks = (d.C / 32) * RS;
+    const long npieces = (long)cdiv_dev(d.N, GBN) * nchunks * GBN * 4;
+    const float *w = static_cast<const float *>(d.w);
+    unsigned char *wp = static_cast<unsigned char *>(d.wp);
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < npieces; e += (long)gridDim.x * 256) {
+        const int p = (int)(e & 3), nl = (int)((e >> 2) % GBN);
+        const long qq = e / (4 * GBN);
+        const int ntile = (int)(qq / nchunks), q = (int)(qq - (long)ntile * nchunks);
+        const int slab = q / RS, tap = q - slab * RS, n = ntile * GBN + nl;
+        bf16x8 h[3];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int ch = slab * 32 + p * 8 + c;
+            float v = 0.f;
+            if (n < d.N) v = d.flip ? w[((size_t)ch * d.N + n) * RS + (RS - 1 - tap)] : w[((size_t)n * d.C + ch) * RS + tap];
+            __bf16 x0, x1, x2;
+            split3(v, x0, x1, x2);
+            h[0][c] = x0; h[1][c] = x1; h[2][c] = x2;
+        }
+        unsigned char *dst = wp + qq * GB_BUF + nl * 64 + ((p ^ ((nl >> 2) & 3)) << 4);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8 *>(dst + pl * GB_PLANE) = h[pl];
+    }
+}
+
 // fp32 NHWC -> planes: one thread per (pixel, slab, 8-channel piece)
 __global__ __launch_bounds__(256) void split_nhwc_kernel(const float *x, int ldx, unsigned char *xp, long npieces, int nslab)
 {
@@ -488,7 +811,7 @@ STEM_EXPORT int stem_conv2d_bf16x6_fwd(const void *xp, const void *wp, const flo
     const int M = B * OH * OW;
     hipStream_t st = (hipStream_t)stream;
     // 128-pixel tiles (8 wavefronts) when they fill the 256 CUs at least once, 64-pixel tiles (4 wavefronts) below that
-    const bool small = cdiv(M, 128) < 256 && !(a.exper & 2);
+    const bool small = (cdiv(M, 128) < 256 && !(a.exper & 2)) || (a.exper & 4);
     if (small && np_now == 6)
         hipLaunchKernelGGL((conv_bf16x6_kernel<64, 6>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
     else if (np_now == 3)
@@ -498,5 +821,126 @@ STEM_EXPORT int stem_conv2d_bf16x6_fwd(const void *xp, const void *wp, const flo
     else
         hipLaunchKernelGGL((conv_bf16x6_kernel<128, 6>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
     STEM_LAUNCH_CHECK("stem_conv2d_bf16x6_fwd");
+    return 0;
+}
+
+// ---- general variant: N tiles of 128, split-K, activation epilogues (training-time STEM layers) --------------------------------
+STEM_EXPORT size_t stem_bf16x3_conv_weight_gen_bytes(int N, int C, int R, int S)
+{
+    return C % 32 ? 0 : (size_t)cdiv(N, GBN) * (C / 32) * R * S * GB_BUF;
+}
+
+STEM_EXPORT int stem_bf16x3_pack_conv_weight_gen(const float *w, void *wp, int N, int C, int R, int S, int flip, void *stream)
+{
+    STEM_CHECK_ARG(w && wp && N >= 1 && C > 0 && C % 32 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP,
+                   "stem_bf16x3_pack_conv_weight_gen: C %% 32 == 0, R*S <= %d (N=%d C=%d R=%d S=%d)", MAXTAP, N, C, R, S);
+    const long np = (long)cdiv(N, GBN) * (C / 32) * R * S * GBN * 4;
+    hipLaunchKernelGGL(pack_weight_gen_kernel, dim3((unsigned)cdivz(np, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       static_cast<unsigned char *>(wp), N, C, R * S, flip, np);
+    STEM_LAUNCH_CHECK("stem_bf16x3_pack_conv_weight_gen");
+    return 0;
+}
+
+STEM_EXPORT int stem_bf16x3_pack_conv_weights_multi(const stem_bf16x3_pack_desc *descs_host, int n, void *stream)
+{
+    STEM_CHECK_ARG(descs_host && n >= 1 && n <= MAXPACK, "stem_bf16x3_pack_conv_weights_multi: 1..%d descriptors per call, got %d", MAXPACK, n);
+    size_t maxp = 0;
+    for (int i = 0; i < n; ++i) {
+        const stem_bf16x3_pack_desc &d = descs_host[i];
+        STEM_CHECK_ARG(d.w && d.wp && d.N >= 1 && d.C > 0 && d.C % 32 == 0 && d.R >= 1 && d.S >= 1 && d.R * d.S <= MAXTAP,
+                       "stem_bf16x3_pack_conv_weights_multi: descriptor %d: C %% 32 == 0, R*S <= %d (N=%d C=%d R=%d S=%d)", i, MAXTAP, d.N, d.C, d.R, d.S);
+        const size_t np = (size_t)cdiv(d.N, GBN) * (d.C / 32) * d.R * d.S * GBN * 4;
+        if (np > maxp) maxp = np;
+    }
+    PackTable tab;
+    memset(&tab, 0, sizeof(tab));
+    memcpy(tab.d, descs_host, n * sizeof(stem_bf16x3_pack_desc));
+    const unsigned gx = (unsigned)(cdivz(maxp, 256) < 512 ? cdivz(maxp, 256) : 512);
+    hipLaunchKernelGGL(pack_weight_gen_multi_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, tab);
+    STEM_LAUNCH_CHECK("stem_bf16x3_pack_conv_weights_multi");
+    return 0;
+}
+
+namespace {
+constexpr size_t kGenCntBytes = 64 * 1024;          // arrival counters in front of the split-K slabs: the layout of igemm.hip's
+                                                    // workspace, so that one zero-headed buffer per stream serves both kernels
+
+// Split factor.  Two workgroups fit a CU; the launch runs in R = ceil(workgroups / 256) "CU rounds", each as long as one
+// workgroup's chunks (+ ~6 chunks of ramp-up per workgroup) -- except that a lone workgroup per CU (R = 1) leaves the matrix
+// pipes ~40 % idle (one wavefront per SIMD).  Every split also pays its slab in the reduction.  Measured on TPM.0 / .2 / .4
+// with splits 1..10 (tools/debug/bf16x6_gen_check.py, STEM_BX6_SPLIT): the model ranks them as measured, optimum 4 / 4 / 4.
+int gen_split(int tiles, int nchunks)
+{
+    static const int forced = getenv("STEM_BX6_SPLIT") ? atoi(getenv("STEM_BX6_SPLIT")) : 0;
+    if (forced > 0) return forced < nchunks ? forced : nchunks;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 16 && s * 8 <= nchunks; ++s) {
+        const int cps = cdiv(nchunks, s), ns = cdiv(nchunks, cps), rounds = cdiv(tiles * ns, 256);
+        const double cost = rounds * (cps + 6.0) * (rounds == 1 ? 1.67 : 1.0) + (ns > 1 ? 0.3 * ns : 0.0);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = ns;
+        }
+    }
+    return best;
+}
+}   // namespace
+
+STEM_EXPORT size_t stem_conv2d_bf16x6_gen_workspace_bytes(int B, int H, int W, int C, int N, int R, int S, int stride, int pad)
+{
+    const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+    if (OH < 1 || OW < 1 || C % 32) return 0;
+    const int M = B * OH * OW, tiles = cdiv(M, GBM) * cdiv(N, GBN), nchunks = (C / 32) * R * S;
+    const int s = gen_split(tiles, nchunks);
+    return s > 1 ? kGenCntBytes + (size_t)s * M * cdiv(N, GBN) * GBN * sizeof(float) : 0;
+}
+
+STEM_EXPORT int stem_conv2d_bf16x6_gen_fwd(const void *xp, int xpix, const void *wp, const float *bias, int epi, float slope, const float *z, int ldz,
+                                           float *y, int ldy, void *yp, int B, int H, int W, int C, int N, int R, int S, int stride, int pad,
+                                           void *ws, size_t ws_bytes, void *stream)
+{
+    STEM_CHECK_ARG(xp && wp && (y || yp), "stem_conv2d_bf16x6_gen_fwd: null pointer");
+    STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && C >= 32 && C % 32 == 0 && N >= 4 && N % 4 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP &&
+                   stride >= 1 && pad >= 0, "stem_conv2d_bf16x6_gen_fwd: C %% 32 == 0, N %% 4 == 0, R*S <= %d (C=%d N=%d R=%d S=%d)", MAXTAP, C, N, R, S);
+    STEM_CHECK_ARG(!yp || N % 32 == 0, "stem_conv2d_bf16x6_gen_fwd: planes output needs N %% 32 == 0 (N=%d)", N);
+    STEM_CHECK_ARG(!y || (ldy >= N && ldy % 4 == 0 && ((uintptr_t)y & 15) == 0), "stem_conv2d_bf16x6_gen_fwd: y rows must be 16-byte aligned, ldy >= N");
+    STEM_CHECK_ARG(epi >= GEN_EPI_BIAS && epi <= GEN_EPI_DACT, "stem_conv2d_bf16x6_gen_fwd: unknown epilogue %d", epi);
+    STEM_CHECK_ARG(epi != GEN_EPI_DACT || (z && ldz >= N && ldz % 4 == 0 && ((uintptr_t)z & 15) == 0), "stem_conv2d_bf16x6_gen_fwd: DACT needs z (16-byte aligned rows)");
+    const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+    STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_bf16x6_gen_fwd: empty output");
+    if (xpix == 0) xpix = (C / 32) * 192;
+    STEM_CHECK_ARG(xpix >= (C / 32) * 192 && xpix % 192 == 0, "stem_conv2d_bf16x6_gen_fwd: xpix must be a multiple of 192 bytes covering C channels");
+    const size_t xb = (size_t)B * H * W * xpix, wb = stem_bf16x3_conv_weight_gen_bytes(N, C, R, S);
+    const int M = B * OH * OW, ntn = cdiv(N, GBN), tiles = cdiv(M, GBM) * ntn, nchunks = (C / 32) * R * S;
+    STEM_CHECK_ARG(xb < 0x7FFFFF00ull && wb < 0x7FFFFF00ull && (size_t)M * ntn * GBN * 4 * 16 < 0x7FFFFF00ull,
+                   "stem_conv2d_bf16x6_gen_fwd: operand views must stay below 2 GiB (split the batch)");
+    Bx6Args a;
+    memset(&a, 0, sizeof(a));
+    a.xp = xp; a.wp = wp; a.bias = bias; a.y = y; a.yp = yp; a.ldy = ldy; a.z = z; a.ldz = ldz; a.epi = epi; a.slope = slope;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.OH = OH; a.OW = OW; a.stride = stride; a.ntaps = R * S;
+    a.xbytes = (int)xb; a.wbytes = (int)wb; a.xpix = xpix;
+    for (int r = 0; r < R; ++r)
+        for (int s = 0; s < S; ++s) {
+            a.dy[r * S + s] = (signed char)(r - pad);
+            a.dx[r * S + s] = (signed char)(s - pad);
+        }
+    int split = gen_split(tiles, nchunks);
+    const size_t need = kGenCntBytes + (size_t)split * M * ntn * GBN * sizeof(float);
+    if (split > 1 && (!ws || ws_bytes < need || (size_t)tiles * sizeof(int) > kGenCntBytes)) split = 1;      // no workspace: unsplit, same result up to summation order
+    a.nsplit = split;
+    a.cps = cdiv(nchunks, split);
+    a.nsplit = cdiv(nchunks, a.cps);
+    if (a.nsplit > 1) {
+        a.cnt = static_cast<int *>(ws);
+        a.ws = reinterpret_cast<float *>(static_cast<unsigned char *>(ws) + kGenCntBytes);
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(conv_bf16x6_gen_kernel, dim3(cdiv(M, GBM), ntn, a.nsplit), dim3(GNT), GLDS, (hipStream_t)stream, a);
+    STEM_LAUNCH_CHECK("stem_conv2d_bf16x6_gen_fwd");
     return 0;
 }

@@ -35,13 +35,43 @@ class _Layer:
         self.masked = getattr(mod, "_masked", 0)
         self.wp_fwd = self.wp_dgrad = None
         self.need_dgrad = True
+        # forward / input-gradient on the bf16 matrix cores (csrc/conv_bf16x6.hip, general variant): stride-1 convolutions whose
+        # contraction channels are multiples of 32; decided once by the engine (StemEngine._select_bx6)
+        self.bx6 = False
+        self.wp6_fwd = self.wp6_dgrad = None
         self._slabs = {}
         self.pending = None       # (dwp, splits) of the last wgrad, consumed by StemEngine.unpack_all
 
+    def bx6_eligible(self):
+        return (self.kind == "conv" and self.stride == 1 and not self.masked and self.C % 32 == 0 and self.K % 32 == 0
+                and self.R * self.R <= 25 and self.pad == self.R // 2)
+
     def alloc_packs(self, device):
+        if self.bx6:
+            self.wp6_fwd = torch.empty(F.bf16x3_gen_weight_bytes(self.K, self.C, self.R, self.R), device=device, dtype=torch.uint8)
+            self.wp6_dgrad = torch.empty(F.bf16x3_gen_weight_bytes(self.C, self.K, self.R, self.R), device=device,
+                                         dtype=torch.uint8) if self.need_dgrad else None
+            return
         n = self.K * self.C * self.R * self.R
         self.wp_fwd = torch.empty(n, device=device, dtype=torch.float32)
         self.wp_dgrad = torch.empty(n, device=device, dtype=torch.float32) if self.need_dgrad else None
+
+    def pack_descs6(self):
+        w = self.mod.weight
+        out = [_lib.Bf16PackDesc(w.data_ptr(), self.wp6_fwd.data_ptr(), self.K, self.C, self.R, self.R, 0, 0)]
+        if self.need_dgrad:       # the input-gradient of a stride-1 convolution is a convolution with the mirrored, transposed weight
+            out.append(_lib.Bf16PackDesc(w.data_ptr(), self.wp6_dgrad.data_ptr(), self.C, self.K, self.R, self.R, 1, 0))
+        return out
+
+    def fwd6(self, xp, act=F.ACT_NONE, out=None, planes=False):
+        """-> (fp32 output, planes output or None); `xp` a Bf16Planes (possibly a channel view)"""
+        return F.conv2d_bf16x6_gen(xp, self.wp6_fwd, self.mod.bias, self.K, self.R, self.R, 1, self.pad,
+                                   epi=F.GEN_EPI_LRELU if act == F.ACT_LRELU else F.GEN_EPI_BIAS, out=out, want_planes=planes)
+
+    def dgrad6(self, dyp, xact=None, planes=False):
+        """-> (dx fp32, dx planes or None); xact: the activated input of this layer (leaky-ReLU derivative folded in)"""
+        return F.conv2d_bf16x6_gen(dyp, self.wp6_dgrad, None, self.C, self.R, self.R, 1, self.pad,
+                                   epi=F.GEN_EPI_DACT if xact is not None else F.GEN_EPI_BIAS, z=xact, want_planes=planes)
 
     def pack_descs(self):
         w = self.mod.weight
@@ -55,6 +85,8 @@ class _Layer:
 
     def fwd(self, x, act=F.ACT_NONE, out=None):
         self.eng.ensure_packed()
+        if self.bx6:          # callers outside the training schedule (codec.py) hand over fp32 tensors
+            return self.fwd6(F.Bf16Planes.split(x), act, out=out)[0]
         m = self.mod
         if self.kind == "conv":
             if self.masked and not self.masked & 4:
@@ -135,6 +167,13 @@ class StemEngine:
         self._pack_descs = None
         self._side = None
         self._checked = False
+        if self.use_bx6:
+            for l in self.layers:
+                l.bx6 = l.bx6_eligible()
+
+    #: forward and input-gradient of the stride-1 layers (TPM, HE.0, HD.4, EPM) on the bf16 matrix cores with fp32-exact products
+    #: (six bf16 MFMAs per fp32 product, csrc/conv_bf16x6.hip); STEM_ENGINE_BF16X6=0 keeps every layer on the fp32-MFMA kernels
+    use_bx6 = os.environ.get("STEM_ENGINE_BF16X6", "1") != "0"
 
     #: weight gradients (wgrad + bias column sums + unpack + the data-parallel exchange hook) run on their own stream
     #: and overlap the latency-bound parts of the dgrad chain; set False to keep everything on the compute stream
@@ -167,13 +206,19 @@ class StemEngine:
         key = tuple((_layers.weight_epoch(l.mod.weight), l.mod.weight._version, l.mod.weight.data_ptr()) for l in self.layers)
         if key == self._pack_key:
             return
-        if self.layers[0].wp_fwd is None or self.layers[0].wp_fwd.device != self.layers[0].mod.weight.device:
+        first = self.layers[0]
+        have = first.wp6_fwd if first.bx6 else first.wp_fwd
+        if have is None or have.device != first.mod.weight.device:
             for l in self.layers:
                 l.alloc_packs(l.mod.weight.device)
             self._pack_descs = None
-        descs = [d for l in self.layers for d in l.pack_descs()]
-        arr = (_lib.PackDesc * len(descs))(*descs)
-        F.pack_weights_multi(arr)
+        descs = [d for l in self.layers if not l.bx6 for d in l.pack_descs()]
+        if descs:
+            arr = (_lib.PackDesc * len(descs))(*descs)
+            F.pack_weights_multi(arr)
+        descs6 = [d for l in self.layers if l.bx6 for d in l.pack_descs6()]
+        if descs6:
+            F.pack_weights_bf16x3_multi((_lib.Bf16PackDesc * len(descs6))(*descs6))
         # masked == 2 zeroed taps of the context weight in place: refresh its version in the key
         self._pack_key = tuple((_layers.weight_epoch(l.mod.weight), l.mod.weight._version, l.mod.weight.data_ptr()) for l in self.layers)
 
@@ -248,8 +293,9 @@ class StemEngine:
         main = torch.cuda.current_stream(dev) if bs is not None else None
         if bs is not None:
             bs.wait_stream(main)
+        split = F.Bf16Planes.split
         with (torch.cuda.stream(bs) if bs is not None else contextlib.nullcontext()):
-            he0 = self.HE[0].fwd(he_in, F.ACT_LRELU)
+            he0 = self.HE[0].fwd6(split(he_in), F.ACT_LRELU)[0] if self.HE[0].bx6 else self.HE[0].fwd(he_in, F.ACT_LRELU)
             he2 = self.HE[1].fwd(he0, F.ACT_LRELU)
             z = self.HE[2].fwd(he2)
             pack = F.eb_pack(eb._tensors14())
@@ -262,9 +308,17 @@ class StemEngine:
             # hyper decoder; its last conv writes the `hp` slice of the EPM input
             hd0 = self.HD[0].fwd(z_hat, F.ACT_LRELU)
             hd2 = self.HD[1].fwd(hd0, F.ACT_LRELU)
-            self.HD[2].fwd(hd2, out=epm_in[:, o_hp:o_hp + P])
+            if self.HD[2].bx6:
+                self.HD[2].fwd6(split(hd2), out=epm_in[:, o_hp:o_hp + P])
+            else:
+                self.HD[2].fwd(hd2, out=epm_in[:, o_hp:o_hp + P])
         tp0 = tp2 = None
-        if self.has_tpm:
+        if self.has_tpm and self.TPM[0].bx6:
+            # planes travel from layer to layer (written by the producing epilogue next to the fp32 copy backward needs)
+            tp0, tp0p = self.TPM[0].fwd6(split(yd), F.ACT_LRELU, planes=True)
+            tp2, tp2p = self.TPM[1].fwd6(tp0p, F.ACT_LRELU, planes=True)
+            self.TPM[2].fwd6(tp2p, out=epm_in[:, o_tp:o_tp + P])
+        elif self.has_tpm:
             tp0 = self.TPM[0].fwd(yd, F.ACT_LRELU)
             tp2 = self.TPM[1].fwd(tp0, F.ACT_LRELU)
             self.TPM[2].fwd(tp2, out=epm_in[:, o_tp:o_tp + P])
@@ -277,9 +331,14 @@ class StemEngine:
             self.CTX.fwd(t_hat, out=epm_in[:, o_ctx:o_ctx + P])
         if bs is not None:
             main.wait_stream(bs)
-        e0 = self.EPM[0].fwd(epm_in, F.ACT_LRELU)
-        e2 = self.EPM[1].fwd(e0, F.ACT_LRELU)
-        gp = self.EPM[2].fwd(e2)                                   # [B, 2*Cin, H, W] = scales | means
+        if self.EPM[0].bx6:
+            e0, e0p = self.EPM[0].fwd6(split(epm_in), F.ACT_LRELU, planes=True)
+            e2, e2p = self.EPM[1].fwd6(e0p, F.ACT_LRELU, planes=True)
+            gp = self.EPM[2].fwd6(e2p)[0]                          # [B, 2*Cin, H, W] = scales | means
+        else:
+            e0 = self.EPM[0].fwd(epm_in, F.ACT_LRELU)
+            e2 = self.EPM[1].fwd(e0, F.ACT_LRELU)
+            gp = self.EPM[2].fwd(e2)                               # [B, 2*Cin, H, W] = scales | means
         scales, means = gp[:, :Cin], gp[:, Cin:]
         if fused:
             gc_out, lik_y, k["dlik_y"], part_y = F.gc_forward_train(target, scales, means, rate_coef[0], scale_bound=gc._scale_bound,
@@ -314,19 +373,28 @@ class StemEngine:
         F.gc_backward(k["gc_out"], gp[:, :Cin], gp[:, Cin:], dlik_y, dgp[:, :Cin], dgp[:, Cin:], dy=None,
                       scale_bound=gc._scale_bound, lik_bound=gc._lik_bound)
         # EPM (1x1 chain)
-        self.EPM[2].wgrad(k["e2"], dgp)
-        de2 = self.EPM[2].dgrad(dgp, k["e2"].shape, xact=k["e2"])
-        self.EPM[1].wgrad(k["e0"], de2)
-        de0 = self.EPM[1].dgrad(de2, k["e0"].shape, xact=k["e0"])
-        self.EPM[0].wgrad(k["epm_in"], de0)
-        dpri = self.EPM[0].dgrad(de0, k["epm_in"].shape)
+        dprip = None
+        if self.EPM[0].bx6:
+            self.EPM[2].wgrad(k["e2"], dgp)
+            de2, de2p = self.EPM[2].dgrad6(F.Bf16Planes.split(dgp), xact=k["e2"], planes=True)
+            self.EPM[1].wgrad(k["e0"], de2)
+            de0, de0p = self.EPM[1].dgrad6(de2p, xact=k["e0"], planes=True)
+            self.EPM[0].wgrad(k["epm_in"], de0)
+            dpri, dprip = self.EPM[0].dgrad6(de0p, planes=True)    # the prior branches read 32-aligned channel views of the planes
+        else:
+            self.EPM[2].wgrad(k["e2"], dgp)
+            de2 = self.EPM[2].dgrad(dgp, k["e2"].shape, xact=k["e2"])
+            self.EPM[1].wgrad(k["e0"], de2)
+            de0 = self.EPM[1].dgrad(de2, k["e0"].shape, xact=k["e0"])
+            self.EPM[0].wgrad(k["epm_in"], de0)
+            dpri = self.EPM[0].dgrad(de0, k["epm_in"].shape)
         self._group_ready(self.EPM, [])
         bs = self._branch(gp.device)
         if bs is not None:                # hyper chain (HD -> bottleneck -> HE) on its own stream, next to the TPM chain
             main = torch.cuda.current_stream(gp.device)
             bs.wait_stream(main)
             with torch.cuda.stream(bs):
-                self._backward_hyper(k, dpri, dlik_z)
+                self._backward_hyper(k, dpri, dlik_z, dprip)
         # spatial prior: weight gradient of all 25 taps, no input gradient (its input is data + noise)
         if self.has_spm:
             self.CTX.wgrad(k["t_hat"], dpri[:, o_ctx:o_ctx + P])
@@ -334,25 +402,35 @@ class StemEngine:
         if self.has_tpm:
             dtp = dpri[:, o_tp:o_tp + P]
             self.TPM[2].wgrad(k["tp2"], dtp)
-            d = self.TPM[2].dgrad(dtp, k["tp2"].shape, xact=k["tp2"])
-            self.TPM[1].wgrad(k["tp0"], d)
-            d = self.TPM[1].dgrad(d, k["tp0"].shape, xact=k["tp0"])
+            if self.TPM[2].bx6:
+                dtpp = dprip.channels(o_tp, o_tp + P) if dprip is not None else F.Bf16Planes.split(dtp)
+                d, dp = self.TPM[2].dgrad6(dtpp, xact=k["tp2"], planes=True)
+                self.TPM[1].wgrad(k["tp0"], d)
+                d = self.TPM[1].dgrad6(dp, xact=k["tp0"])[0]
+            else:
+                d = self.TPM[2].dgrad(dtp, k["tp2"].shape, xact=k["tp2"])
+                self.TPM[1].wgrad(k["tp0"], d)
+                d = self.TPM[1].dgrad(d, k["tp0"].shape, xact=k["tp0"])
             self.TPM[0].wgrad(k["yd"], d)
             self._group_ready(self.TPM, [])
         if bs is None:
-            self._backward_hyper(k, dpri, dlik_z)
+            self._backward_hyper(k, dpri, dlik_z, dprip)
         else:
             main.wait_stream(bs)
         self.join_side_stream()          # gradients are complete for whatever the compute stream does next
 
-    def _backward_hyper(self, k, dpri, dlik_z):
+    def _backward_hyper(self, k, dpri, dlik_z, dprip=None):
         m = self.m
         P = k["P"]
         o_tp, o_hp, o_ctx = k["offs"]
         # hyper decoder
         dhp = dpri[:, o_hp:o_hp + P]
         self.HD[2].wgrad(k["hd2"], dhp)
-        d = self.HD[2].dgrad(dhp, k["hd2"].shape, xact=k["hd2"])
+        if self.HD[2].bx6:
+            dhpp = dprip.channels(o_hp, o_hp + P) if dprip is not None else F.Bf16Planes.split(dhp)
+            d = self.HD[2].dgrad6(dhpp, xact=k["hd2"])[0]
+        else:
+            d = self.HD[2].dgrad(dhp, k["hd2"].shape, xact=k["hd2"])
         self.HD[1].wgrad(k["hd0"], d)
         d = self.HD[1].dgrad(d, k["hd0"].shape, xact=k["hd0"])
         self.HD[0].wgrad(k["z_hat"], d)

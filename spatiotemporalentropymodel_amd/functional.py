@@ -351,12 +351,28 @@ def conv2d_gdn_fwd(x, wp, bias, beta, gamma, K, R, S, stride, pad, inverse=False
 
 class Bf16Planes:
     """An NHWC activation tensor pre-split for the bf16 matrix cores (csrc/conv_bf16x6.hip): every fp32 value is stored as the
-    three bf16 numbers that add up to it exactly, [pixel][C/32][3][32].  Only produced and consumed by the frozen analysis
-    transform's kernels (conv2d_bf16x6_fwd); `shape` is the logical [B,C,H,W]."""
-    __slots__ = ("data", "shape")
+    three bf16 numbers that add up to it exactly, [pixel][C/32][3][32].  Only produced and consumed by the bf16 convolution
+    kernels; `shape` is the logical [B,C,H,W].  `channels(c0, c1)` is a view of a 32-aligned channel range (same storage,
+    same pixel pitch), accepted as an INPUT by conv2d_bf16x6_gen."""
+    __slots__ = ("data", "shape", "pix_bytes", "byte_offset")
 
-    def __init__(self, data, shape):
+    def __init__(self, data, shape, pix_bytes=None, byte_offset=0):
         self.data, self.shape = data, tuple(shape)
+        self.pix_bytes = (self.shape[1] // 32) * 192 if pix_bytes is None else pix_bytes
+        self.byte_offset = byte_offset
+
+    @property
+    def dense(self):
+        return self.byte_offset == 0 and self.pix_bytes == (self.shape[1] // 32) * 192
+
+    def data_ptr(self):
+        return self.data.data_ptr() + self.byte_offset
+
+    def channels(self, c0, c1):
+        if c0 % 32 or c1 % 32 or not 0 <= c0 < c1 <= self.shape[1]:
+            raise ValueError(f"planes views are 32-channel aligned, got [{c0}, {c1}) of {self.shape[1]}")
+        B, _, H, W = self.shape
+        return Bf16Planes(self.data, (B, c1 - c0, H, W), self.pix_bytes, self.byte_offset + (c0 // 32) * 192)
 
     @staticmethod
     def empty(B, Cc, H, W, device):
@@ -374,6 +390,7 @@ class Bf16Planes:
         return out
 
     def merge(self):
+        assert self.dense, "merge() of a channel view is not implemented"
         B, Cc, H, W = self.shape
         out = empty_nhwc(B, Cc, H, W, self.data.device)
         _chk(_lib.hip().stem_bf16x3_merge_nhwc(self.data.data_ptr(), out.data_ptr(), Cc, B * H * W, Cc, _stream()))
@@ -404,9 +421,69 @@ def conv2d_bf16x6_fwd(xp: Bf16Planes, wp, bias, K, R, S, stride, pad, beta=None,
     else:
         out = empty_nhwc(B, K, Ho, Wo, dev)
         y, ldy, yp = out.data_ptr(), nhwc_ld(out), None
+    assert xp.dense, "the analysis-transform kernel takes whole planes tensors"
     _chk(_lib.hip().stem_conv2d_bf16x6_fwd(xp.data.data_ptr(), wp.data_ptr(), _ptr(bias), _ptr(beta), _ptr(gamma), beta_min,
                                            y, ldy, yp, B, H, W, Cc, K, R, S, stride, pad, _stream()))
     return out
+
+
+_WS_GEN_BYTES = {}
+GEN_EPI_BIAS, GEN_EPI_LRELU, GEN_EPI_DACT = 0, 1, 2
+
+
+def pack_weight_bf16x3_gen(w: torch.Tensor, flip: bool = False, out=None) -> torch.Tensor:
+    """torch Conv2d weight [K,C,R,S] -> the image conv2d_bf16x6_gen streams; flip=True packs the operand of the input-gradient of
+    a stride-1 convolution (rows = input channels, packed channels = output channels, taps mirrored)."""
+    _require_cuda(w)
+    K, Cc, R, S = w.shape
+    N, Cin = (Cc, K) if flip else (K, Cc)
+    nbytes = _lib.hip().stem_bf16x3_conv_weight_gen_bytes(N, Cin, R, S)
+    if nbytes == 0:
+        raise ValueError(f"bf16x3 weights need a contraction channel count that is a multiple of 32, got {Cin}")
+    if out is None:
+        out = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+    assert out.numel() == nbytes
+    _chk(_lib.hip().stem_bf16x3_pack_conv_weight_gen(w.detach().contiguous().data_ptr(), out.data_ptr(), N, Cin, R, S, int(flip), _stream()))
+    return out
+
+
+def bf16x3_gen_weight_bytes(N, C, R, S):
+    return int(_lib.hip().stem_bf16x3_conv_weight_gen_bytes(N, C, R, S))
+
+
+def pack_weights_bf16x3_multi(descs):
+    """descs: ctypes array of _lib.Bf16PackDesc (at most 24 per call: the table is a kernel argument)"""
+    for i in range(0, len(descs), 24):
+        n = min(24, len(descs) - i)
+        _chk(_lib.hip().stem_bf16x3_pack_conv_weights_multi(C.byref(descs, i * C.sizeof(_lib.Bf16PackDesc)), n, _stream()))
+
+
+def conv2d_bf16x6_gen(xp: Bf16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EPI_BIAS, slope=LRELU_SLOPE, z=None, out=None,
+                      want_fp32=True, want_planes=False):
+    """General bf16x6 convolution (training-time STEM layers): returns (fp32 NHWC tensor or None, Bf16Planes or None).
+    `out` may be a channel slice of a wider NHWC buffer; epi = GEN_EPI_DACT multiplies by the leaky-ReLU derivative at z."""
+    B, Cc, H, W = xp.shape
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    dev = xp.data.device
+    y = None
+    if want_fp32 or out is not None:
+        y = out if out is not None else empty_nhwc(B, N, Ho, Wo, dev)
+    yp = Bf16Planes.empty(B, N, Ho, Wo, dev) if want_planes else None
+    dims = (B, H, W, Cc, N, R, S, stride, pad)
+    need = _WS_GEN_BYTES.get(dims)
+    if need is None:
+        need = _WS_GEN_BYTES[dims] = int(_lib.hip().stem_conv2d_bf16x6_gen_workspace_bytes(*dims))
+    ws_ptr = 0
+    if need:
+        slot = (dev, _stream())
+        buf = _WS.get(slot)
+        if buf is None or buf.numel() * 4 < need:
+            buf = _WS[slot] = torch.zeros((need + 3) // 4, device=dev, dtype=torch.float32)       # zero head: arrival counters
+        ws_ptr = buf.data_ptr()
+    _chk(_lib.hip().stem_conv2d_bf16x6_gen_fwd(xp.data_ptr(), xp.pix_bytes, wp.data_ptr(), _ptr(bias), epi, slope, _ptr(z), nhwc_ld(z) if z is not None else 0,
+                                               _ptr(y), nhwc_ld(y) if y is not None else 0, yp.data.data_ptr() if yp is not None else None,
+                                               B, H, W, Cc, N, R, S, stride, pad, ws_ptr, need, _stream()))
+    return y, yp
 
 
 def conv2d_fwd_c4_gdn_planes(x4, wp, bias, beta, gamma, K, R, S, stride, pad, beta_min=1e-6):

@@ -466,17 +466,23 @@ def _conv_out_shape(m, in_shape):
 
 
 class FusedSequential(nn.Sequential):
-    #: optional (index, list) pair set by bench.py: HIP events are recorded around the kernel(s) of child `index`
+    #: optional (index, list) pair -- or a dict {index: list} -- set by bench.py: HIP events are recorded on the launching stream
+    #: around the kernel(s) of child `index`
     probe = None
 
     def _timed(self, i, fn):
-        if self.probe is None or self.probe[0] != i:
+        sink = None
+        if isinstance(self.probe, dict):
+            sink = self.probe.get(i)
+        elif self.probe is not None and self.probe[0] == i:
+            sink = self.probe[1]
+        if sink is None:
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = fn()
         e1.record()
-        self.probe[1].append((e0, e1))
+        sink.append((e0, e1))
         return out
 
     def forward(self, x):
