@@ -871,7 +871,8 @@ constexpr size_t kGenCntBytes = 64 * 1024;          // arrival counters in front
 // with splits 1..10 (tools/debug/bf16x6_gen_check.py, STEM_BX6_SPLIT): the model ranks them as measured, optimum 4 / 4 / 4.
 int gen_split(int tiles, int nchunks)
 {
-    static const int forced = getenv("STEM_BX6_SPLIT") ? atoi(getenv("STEM_BX6_SPLIT")) : 0;
+    static const int forced_once = getenv("STEM_BX6_SPLIT") ? atoi(getenv("STEM_BX6_SPLIT")) : 0;
+    const int forced = getenv("STEM_BX6_SPLIT_DYN") ? atoi(getenv("STEM_BX6_SPLIT_DYN")) : forced_once;      // tuning / tests
     if (forced > 0) return forced < nchunks ? forced : nchunks;
     int best = 1;
     double best_cost = 1e30;

@@ -8,6 +8,7 @@ computes with torch ops.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -471,7 +472,7 @@ def conv2d_bf16x6_gen(xp: Bf16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EP
     yp = Bf16Planes.empty(B, N, Ho, Wo, dev) if want_planes else None
     dims = (B, H, W, Cc, N, R, S, stride, pad)
     need = _WS_GEN_BYTES.get(dims)
-    if need is None:
+    if need is None or "STEM_BX6_SPLIT_DYN" in os.environ:          # (the env var forces a split factor per call: tests / tuning)
         need = _WS_GEN_BYTES[dims] = int(_lib.hip().stem_conv2d_bf16x6_gen_workspace_bytes(*dims))
     ws_ptr = 0
     if need:

@@ -149,3 +149,102 @@ def test_chain_is_selected_at_the_bench_size_and_not_under_autograd(F, monkeypat
     n = len(seen)
     y_grad = imodel.g_a(x)
     assert len(seen) == n and y_grad.requires_grad
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# General variant (training-time STEM layers): N tiles, split-K, activation epilogues, planes views
+GEN_CASES = [  # B, C, H, W, K, R
+    (2, 64, 9, 11, 96, 3),
+    (1, 96, 13, 7, 160, 5),
+    (4, 192, 16, 16, 256, 5),        # TPM.0 geometry at a quarter of the batch
+    (2, 576, 8, 8, 384, 1),          # EPM.4-like 1x1
+]
+
+
+@pytest.mark.parametrize("case", GEN_CASES)
+@pytest.mark.parametrize("split", [0, 1, 3])
+def test_gen_forward_and_input_gradient_vs_oracle(F, monkeypatch, case, split):
+    """forward + leaky ReLU and input-gradient x leaky-ReLU derivative (what autograd derives for conv(lrelu(u))) against the
+    oracle, with the planner's split-K factor (0), unsplit (1) and a forced 3-way split; planes output = fp32 output."""
+    B, C, H, W, K, R = case
+    if split:
+        monkeypatch.setenv("STEM_BX6_SPLIT_DYN", str(split))
+    pad, sl = R // 2, 0.01
+    x, w, b = rnd((B, C, H, W), 31, -2, 2), (rnd((K, C, R, R), 32) / np.sqrt(C * R * R)).astype(np.float32), rnd((K,), 33, -0.1, 0.1)
+    dy = rnd((B, K, H, W), 34)
+    ref = orc.conv2d_fwd(x, w, b, 1, pad)
+    ref = np.where(ref > 0, ref, ref * sl).astype(np.float32)
+    dx_ref = orc.conv2d_bwd(x, w, dy, 1, pad)[0]
+    dx_ref = np.where(x > 0, dx_ref, dx_ref * sl).astype(np.float32)
+    xd = dev(x).contiguous(memory_format=torch.channels_last)
+    y, yp = F.conv2d_bf16x6_gen(F.Bf16Planes.split(xd), F.pack_weight_bf16x3_gen(dev(w)), dev(b), K, R, R, 1, pad,
+                                epi=F.GEN_EPI_LRELU, slope=sl, want_planes=True)
+    assert_close(host(y), ref, what=f"gen fwd {case} split={split}", floor=0.1)
+    assert torch.equal(yp.merge(), y)
+    d, dp = F.conv2d_bf16x6_gen(F.Bf16Planes.split(dev(dy)), F.pack_weight_bf16x3_gen(dev(w), flip=True), None, C, R, R, 1, pad,
+                                epi=F.GEN_EPI_DACT, slope=sl, z=xd, want_planes=True)
+    assert_close(host(d), dx_ref, what=f"gen dgrad {case} split={split}", floor=0.1)
+    assert torch.equal(dp.merge(), d)
+
+
+def test_gen_channel_views_strided_output_and_multi_pack(F):
+    """A 32-aligned channel view of a wider planes tensor as input, the result written into a channel slice of a wider fp32
+    buffer (the engine's epm_in), and the one-launch weight packing equal to the single-layer packing."""
+    from spatiotemporalentropymodel_amd import _lib
+    B, H, W = 2, 8, 8
+    big = rnd((B, 160, H, W), 41, -2, 2)
+    w = (rnd((96, 64, 3, 3), 42) / np.sqrt(64 * 9)).astype(np.float32)
+    b = rnd((96,), 43, -0.1, 0.1)
+    bigp = F.Bf16Planes.split(dev(big))
+    wide = torch.zeros(B, H, W, 224, device="cuda").permute(0, 3, 1, 2)           # NHWC buffer, 224 channels
+    out = wide[:, 64:160]
+    wp = F.pack_weight_bf16x3_gen(dev(w))
+    y, _ = F.conv2d_bf16x6_gen(bigp.channels(32, 96), wp, dev(b), 96, 3, 3, 1, 1, out=out)
+    assert y.data_ptr() == out.data_ptr()
+    assert_close(host(out), orc.conv2d_fwd(big[:, 32:96], w, b, 1, 1), what="view in, slice out", floor=0.1)
+    assert float(wide[:, :64].abs().max()) == 0 and float(wide[:, 160:].abs().max()) == 0
+    with pytest.raises(ValueError):
+        bigp.channels(16, 80)
+    # multi pack == single packs (forward and mirrored)
+    w2 = (rnd((64, 96, 5, 5), 44) / 50).astype(np.float32)
+    wd, w2d = dev(w), dev(w2)
+    singles = [F.pack_weight_bf16x3_gen(wd), F.pack_weight_bf16x3_gen(wd, flip=True), F.pack_weight_bf16x3_gen(w2d)]
+    outs = [torch.empty_like(s) for s in singles]
+    descs = (_lib.Bf16PackDesc * 3)(_lib.Bf16PackDesc(wd.data_ptr(), outs[0].data_ptr(), 96, 64, 3, 3, 0, 0),
+                                    _lib.Bf16PackDesc(wd.data_ptr(), outs[1].data_ptr(), 64, 96, 3, 3, 1, 0),
+                                    _lib.Bf16PackDesc(w2d.data_ptr(), outs[2].data_ptr(), 64, 96, 5, 5, 0, 0))
+    F.pack_weights_bf16x3_multi(descs)
+    for a, s in zip(outs, singles):
+        assert torch.equal(a, s)
+
+
+def test_engine_schedule_with_and_without_bf16_layers(monkeypatch):
+    """One training forward / backward of the full-size STEM model through the explicit schedule with the stride-1 layers on the
+    bf16 kernels and with every layer on the fp32-MFMA kernels: likelihoods and every parameter gradient agree to the parity
+    bound (both are checked against the reference elsewhere; this pins the two routes to each other at B=2, 16x16 latents)."""
+    from spatiotemporalentropymodel_amd import engine as E
+    from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel_Res
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_, closed_form_input
+    d = torch.device("cuda:0")
+    y_cur = closed_form_input("eng:y", (2, 192, 16, 16), -6, 6).to(d)
+    y_cond = closed_form_input("eng:c", (2, 192, 16, 16), -6, 6).to(d)
+    res = {}
+    for tag, on in (("bf16", True), ("fp32", False)):
+        monkeypatch.setattr(E.StemEngine, "use_bx6", on)
+        torch.manual_seed(0)
+        m = closed_form_fill_(SpatioTemporalPriorModel_Res()).to(d).train()
+        eng = m.engine()
+        assert any(l.bx6 for l in eng.layers) == on
+        for p in m.parameters():
+            p.grad = None
+        out = m(y_cur, y_cond)
+        loss = sum(torch.log(l).sum() for l in out["likelihoods"].values()) / (-np.log(2) * 2 * 256 * 256)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[tag] = (float(loss), {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters() if p.grad is not None})
+    assert abs(res["bf16"][0] - res["fp32"][0]) <= 1e-5 * abs(res["fp32"][0])
+    assert res["bf16"][1].keys() == res["fp32"][1].keys() and len(res["fp32"][1]) > 30
+    # two fp32-accurate routes: each is within 1e-4 of the float64 reference in tests/test_hip_models.py; against each other the
+    # weight gradients (sums over pixels with cancellation) may sit up to 2e-4 of the tensor's largest entry apart
+    for n, g32 in res["fp32"][1].items():
+        assert_close(res["bf16"][1][n], g32, rtol=2e-4, what=f"grad {n}", floor=1.0)
