@@ -36,6 +36,7 @@ def weight_epoch(w):
 
 
 PACK_BF16X3 = -3          # _PackCache role of the pre-split bf16 image (csrc/conv_bf16x6.hip); not a stem_pack_* role
+PACK_BF16X3_GEN = -4      # ... in the layout of the general (128-column tiles, split-K) kernel
 
 
 class _PackCache:
@@ -49,7 +50,12 @@ class _PackCache:
         hit = self._c.get(role)
         if hit is not None and hit[0] == key:
             return hit[1]
-        wp = F.pack_weight_bf16x3(w) if role == PACK_BF16X3 else F.pack_weight(w, role, masked)
+        if role == PACK_BF16X3:
+            wp = F.pack_weight_bf16x3(w)
+        elif role == PACK_BF16X3_GEN:
+            wp = F.pack_weight_bf16x3_gen(w)
+        else:
+            wp = F.pack_weight(w, role, masked)
         if (masked & 3) == 2:                    # the kernel zeroed taps of w in place
             key = (w._version, w.data_ptr(), weight_epoch(w), tuple(w.shape))
         self._c[role] = (key, wp)
@@ -459,6 +465,13 @@ def _bf16x6_eligible(m, in_shape):
     return B * Ho * Wo >= _BF16X6_MIN_PIXELS
 
 
+def _bf16x6_gen_eligible(m, follows_gdn):
+    """Small layers that end a planes chain (the last convolution of the analysis transform: 4096 output pixels at the bench
+    size) go to the general split-K kernel, which has no fused GDN."""
+    return (type(m) is Conv2d and not m._masked and not follows_gdn and m.in_channels % 32 == 0 and m.out_channels % 4 == 0
+            and m.kernel_size * m.kernel_size <= 25 and m.weight.is_cuda)
+
+
 def _conv_out_shape(m, in_shape):
     B, _, H, W = in_shape
     Ho, Wo = F.conv_out_hw(H, W, m.kernel_size, m.kernel_size, m.stride, m.padding)
@@ -502,8 +515,10 @@ class FusedSequential(nn.Sequential):
                 j = i + (2 if gdn is not None else 1)
                 K, R = m.out_channels, m.kernel_size
                 out_shape = _conv_out_shape(m, x.shape)
-                chain = K % 32 == 0 and j < len(mods) and mods[j].__class__ is Conv2d and mods[j].in_channels == K \
-                    and _bf16x6_eligible(mods[j], out_shape)
+                chain = False
+                if K % 32 == 0 and j < len(mods) and mods[j].__class__ is Conv2d and mods[j].in_channels == K:
+                    nxt_gdn = j + 1 < len(mods) and isinstance(mods[j + 1], GDN)
+                    chain = _bf16x6_eligible(mods[j], out_shape) or _bf16x6_gen_eligible(mods[j], nxt_gdn)
                 if (chain and gdn is not None and m.in_channels == 3 and not isinstance(x, F.Bf16Planes) and F.nhwc_ld(x) is None
                         and K <= 192):
                     wp = m._packs.get(m.weight, F.PACK_CONV_FWD_C4)
@@ -518,6 +533,12 @@ class FusedSequential(nn.Sequential):
                                                                    gdn.beta if gdn is not None else None,
                                                                    gdn.gamma if gdn is not None else None,
                                                                    gdn.beta_min if gdn is not None else 1e-6, planes_out=chain))
+                    i = j
+                    continue
+                if isinstance(x, F.Bf16Planes) and _bf16x6_gen_eligible(m, gdn is not None):
+                    wp = m._packs.get(m.weight, PACK_BF16X3_GEN)
+                    x = self._timed(i, lambda: F.conv2d_bf16x6_gen(x, wp, m.bias, K, R, R, m.stride, m.padding, want_fp32=not chain,
+                                                                   want_planes=chain)[1 if chain else 0])
                     i = j
                     continue
             if (isinstance(m, (Conv2d, ConvTranspose2d)) and isinstance(nxt, GDN) and nograd and m.out_channels <= 192

@@ -117,7 +117,7 @@ def test_analysis_transform_chain_vs_golden_and_fp32_kernels(F, golden, monkeypa
     with torch.no_grad():
         y0, _ = imodel.getY(frames[0])
         y1, _ = imodel.getY(frames[1])
-        assert len(calls) == 6, calls                   # g_a.2, g_a.4, g_a.6 of both frames ran on the bf16 kernel
+        assert len(calls) == 6, calls                   # g_a.2, g_a.4, g_a.6 of both frames ran on the 192-wide bf16 kernel
         monkeypatch.setenv("STEM_BF16X6", "0")
         y0_32, _ = imodel.getY(frames[0])
         assert len(calls) == 6
@@ -127,8 +127,8 @@ def test_analysis_transform_chain_vs_golden_and_fp32_kernels(F, golden, monkeypa
 
 
 def test_chain_is_selected_at_the_bench_size_and_not_under_autograd(F, monkeypatch):
-    """B=16 x 256x256 (the bench workload): g_a.0 hands planes to g_a.2, g_a.2 to g_a.4, g_a.4 returns fp32 for the small last
-    layer; with autograd enabled (trainable transform) nothing is routed to the inference-only kernels."""
+    """B=16 x 256x256 (the bench workload): g_a.0 hands planes to g_a.2, g_a.2 to g_a.4, g_a.4 to the small last layer, which
+    runs on the general split-K kernel; with autograd enabled (trainable transform) nothing is routed to the inference-only kernels."""
     from spatiotemporalentropymodel_amd.zoo import models
     torch.manual_seed(5)
     imodel = models["mbt2018"](quality=4).cuda().eval()
@@ -137,9 +137,11 @@ def test_chain_is_selected_at_the_bench_size_and_not_under_autograd(F, monkeypat
     orig6, orig4 = F.conv2d_bf16x6_fwd, F.conv2d_fwd_c4_gdn_planes
     monkeypatch.setattr(F, "conv2d_bf16x6_fwd", lambda *a, **k: (seen.append(("bx6", a[0].shape, k.get("planes_out"))), orig6(*a, **k))[1])
     monkeypatch.setattr(F, "conv2d_fwd_c4_gdn_planes", lambda *a, **k: (seen.append(("c4",)), orig4(*a, **k))[1])
+    origg = F.conv2d_bf16x6_gen
+    monkeypatch.setattr(F, "conv2d_bf16x6_gen", lambda *a, **k: (seen.append(("gen", a[0].shape)), origg(*a, **k))[1])
     with torch.no_grad():
         y = imodel.g_a(x)
-    assert seen == [("c4",), ("bx6", (16, 192, 128, 128), True), ("bx6", (16, 192, 64, 64), False)], seen
+    assert seen == [("c4",), ("bx6", (16, 192, 128, 128), True), ("bx6", (16, 192, 64, 64), True), ("gen", (16, 192, 32, 32))], seen
     monkeypatch.setenv("STEM_BF16X6", "0")
     with torch.no_grad():
         y32 = imodel.g_a(x)
