@@ -30,7 +30,14 @@ fn = {"planes": lambda: F.conv2d_bf16x6_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamm
       "conv": lambda: F.conv2d_bf16x6_fwd(xp, wp, b, K, 5, 5, 2, 2),
       "convplanes": lambda: F.conv2d_bf16x6_fwd(xp, wp, b, K, 5, 5, 2, 2, planes_out=True),
       "split": lambda: F.Bf16Planes.split(x),
+      "c4planes": None, "c4fp32": None,
       "ref": lambda: F.conv2d_gdn_fwd(xn, wp32, b, beta, gamma, K, 5, 5, 2, 2)}[variant]
+if variant in ("c4planes", "c4fp32"):      # g_a.0 + GDN: 3 -> 192 channels, 256^2 -> 128^2
+    w0 = torch.randn(K, 3, 5, 5, device=dev) / 75 ** 0.5
+    x4 = torch.rand(B, 256, 256, 4, device=dev)
+    wp0 = F.pack_weight(w0, F.PACK_CONV_FWD_C4)
+    fn = (lambda: F.conv2d_fwd_c4_gdn_planes(x4, wp0, b, beta, gamma, K, 5, 5, 2, 2)) if variant == "c4planes" else \
+        (lambda: F.conv2d_fwd_c4_gdn(x4, wp0, b, beta, gamma, K, 5, 5, 2, 2))
 for _ in range(iters):
     out = fn()
 torch.cuda.synchronize()
