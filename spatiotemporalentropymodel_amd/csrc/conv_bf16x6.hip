@@ -644,29 +644,40 @@ struct PackTable {
 };
 __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTable tab)
 {
+    // One workgroup per (output row n, 32-channel slab) unit, grid-strided: the RS x 32 source values of a unit are RS-long
+    // contiguous runs of the torch weight (one run per channel; in flip mode per output channel of the forward layer): read
+    // coalesced into LDS, then every thread emits whole 16-byte pieces (8 channels of one tap, three planes).
+    __shared__ float tile[32 * MAXTAP];               // [channel in slab][tap]
     const stem_bf16x3_pack_desc &d = tab.d[blockIdx.y];
-    const int RS = d.R * d.S, nchunks = (d.C / 32) * RS;
-    const long npieces = (long)cdiv_dev(d.N, GBN) * nchunks * GBN * 4;
+    const int RS = d.R * d.S, nslab = d.C / 32, nchunks = nslab * RS, ntile = cdiv_dev(d.N, GBN);
     const float *w = static_cast<const float *>(d.w);
     unsigned char *wp = static_cast<unsigned char *>(d.wp);
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < npieces; e += (long)gridDim.x * 256) {
-        const int p = (int)(e & 3), nl = (int)((e >> 2) % GBN);
-        const long qq = e / (4 * GBN);
-        const int ntile = (int)(qq / nchunks), q = (int)(qq - (long)ntile * nchunks);
-        const int slab = q / RS, tap = q - slab * RS, n = ntile * GBN + nl;
-        bf16x8 h[3];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int ch = slab * 32 + p * 8 + c;
+    const int units = ntile * GBN * nslab;
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        const int slab = u % nslab, n = u / nslab;            // n runs over the padded rows of all N tiles
+        __syncthreads();
+        for (int e = threadIdx.x; e < 32 * RS; e += 256) {
+            const int c = e / RS, tap = e - c * RS, ch = slab * 32 + c;
             float v = 0.f;
             if (n < d.N) v = d.flip ? w[((size_t)ch * d.N + n) * RS + (RS - 1 - tap)] : w[((size_t)n * d.C + ch) * RS + tap];
-            __bf16 x0, x1, x2;
-            split3(v, x0, x1, x2);
-            h[0][c] = x0; h[1][c] = x1; h[2][c] = x2;
+            tile[c * MAXTAP + tap] = v;
         }
-        unsigned char *dst = wp + qq * GB_BUF + nl * 64 + ((p ^ ((nl >> 2) & 3)) << 4);
+        __syncthreads();
+        const int nt = n / GBN, nl = n - nt * GBN;
+        for (int e = threadIdx.x; e < RS * 4; e += 256) {
+            const int tap = e >> 2, p = e & 3;
+            bf16x8 h[3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8 *>(dst + pl * GB_PLANE) = h[pl];
+            for (int c = 0; c < 8; ++c) {
+                __bf16 x0, x1, x2;
+                split3(tile[(p * 8 + c) * MAXTAP + tap], x0, x1, x2);
+                h[0][c] = x0; h[1][c] = x1; h[2][c] = x2;
+            }
+            const long qq = (long)nt * nchunks + slab * RS + tap;
+            unsigned char *dst = wp + qq * GB_BUF + nl * 64 + ((p ^ ((nl >> 2) & 3)) << 4);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8 *>(dst + pl * GB_PLANE) = h[pl];
+        }
     }
 }
 
@@ -844,18 +855,18 @@ STEM_EXPORT int stem_bf16x3_pack_conv_weight_gen(const float *w, void *wp, int N
 STEM_EXPORT int stem_bf16x3_pack_conv_weights_multi(const stem_bf16x3_pack_desc *descs_host, int n, void *stream)
 {
     STEM_CHECK_ARG(descs_host && n >= 1 && n <= MAXPACK, "stem_bf16x3_pack_conv_weights_multi: 1..%d descriptors per call, got %d", MAXPACK, n);
-    size_t maxp = 0;
+    size_t maxu = 0;
     for (int i = 0; i < n; ++i) {
         const stem_bf16x3_pack_desc &d = descs_host[i];
         STEM_CHECK_ARG(d.w && d.wp && d.N >= 1 && d.C > 0 && d.C % 32 == 0 && d.R >= 1 && d.S >= 1 && d.R * d.S <= MAXTAP,
                        "stem_bf16x3_pack_conv_weights_multi: descriptor %d: C %% 32 == 0, R*S <= %d (N=%d C=%d R=%d S=%d)", i, MAXTAP, d.N, d.C, d.R, d.S);
-        const size_t np = (size_t)cdiv(d.N, GBN) * (d.C / 32) * d.R * d.S * GBN * 4;
-        if (np > maxp) maxp = np;
+        const size_t nu = (size_t)cdiv(d.N, GBN) * GBN * (d.C / 32);
+        if (nu > maxu) maxu = nu;
     }
     PackTable tab;
     memset(&tab, 0, sizeof(tab));
     memcpy(tab.d, descs_host, n * sizeof(stem_bf16x3_pack_desc));
-    const unsigned gx = (unsigned)(cdivz(maxp, 256) < 512 ? cdivz(maxp, 256) : 512);
+    const unsigned gx = (unsigned)(maxu < 2048 ? maxu : 2048);
     hipLaunchKernelGGL(pack_weight_gen_multi_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, tab);
     STEM_LAUNCH_CHECK("stem_bf16x3_pack_conv_weights_multi");
     return 0;
