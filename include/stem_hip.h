@@ -385,6 +385,16 @@ int stem_conv2d_bf16x6_gen_fwd(const void *xp, int xpix, const void *wp, const f
                                float *y, int ldy, void *yp, int B, int H, int W, int C, int N, int R, int S, int stride, int pad,
                                void *ws, size_t ws_bytes, void *stream);
 
+/* Weight gradient of a stride-1 nn.Conv2d on the bf16 matrix cores (csrc/wgrad_bf16x6.hip): x and dy as planes (pitches in
+ * bytes per pixel, 0 = dense; 32-aligned channel views allowed), result as `splits` slabs [R*S][K][C] like stem_conv2d_wgrad
+ * (sum / transpose with stem_unpack_wgrads_multi).  splits = stem_wgrad_bf16x6_splits(...); dwp holds splits*R*S*K*C floats.
+ * The bias gradient (column sums of the fp32 dy) is stem_bias_grad. */
+int stem_wgrad_bf16x6_splits(int B, int H, int W, int C, int K, int R, int S, int pad);
+int stem_conv2d_wgrad_bf16x6(const void *xp, int xpix, const void *dyp, int dypix, float *dwp, int B, int H, int W, int C, int K,
+                             int R, int S, int pad, int splits, void *stream);
+size_t stem_bias_grad_scratch_elems(long npix, int K);
+int stem_bias_grad(const float *dy, int lddy, long npix, int K, float *scratch, float *db, int accumulate, void *stream);
+
 /* Wavefront-parallel encoder: all latent positions with the same t = w + 3h are independent under the 5x5
  * type-A mask, so a H x W frame is coded in W + 3(H-1) batched steps instead of H*W sequential ones.  Input
  * segment of position p at (h, w): x + sh*h + sw*w + sp*p (element offsets); output y[p*ldy + n].            */

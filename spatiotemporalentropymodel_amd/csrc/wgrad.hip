@@ -575,6 +575,15 @@ int colsum(const float *dy, int ld, size_t npix, int K, float *scratch, float *d
 
 }   // namespace
 
+// bias gradient on its own (for the weight-gradient kernel of wgrad_bf16x6.hip, which does not touch the fp32 dy)
+STEM_EXPORT size_t stem_bias_grad_scratch_elems(long npix, int K) { return (size_t)colsum_parts((size_t)npix, K) * K; }
+
+STEM_EXPORT int stem_bias_grad(const float *dy, int lddy, long npix, int K, float *scratch, float *db, int accumulate, void *stream)
+{
+    STEM_CHECK_ARG(dy && scratch && db && npix >= 1 && K >= 1 && lddy >= K, "stem_bias_grad: bad arguments");
+    return colsum(dy, lddy, (size_t)npix, K, scratch, db, accumulate, (hipStream_t)stream);
+}
+
 STEM_EXPORT size_t stem_wgrad_workspace_elems(int splits, int C, int K, int R, int S, int npix)
 {
     // slabs | bias-gradient partial sums | per-pixel gather table (offset, tap mask)

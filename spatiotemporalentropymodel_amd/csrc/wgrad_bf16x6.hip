@@ -1,0 +1,251 @@
+// Weight gradient of a stride-1 convolution on the bf16 matrix cores with fp32-exact products (see conv_bf16x6.hip for the
+// arithmetic: operands pre-split into three bf16 planes, six MFMAs per fp32 product, fp32 accumulate).
+//
+//   dW[k][c][r][s] = sum over output pixels m = (b, y, x) of dy[m][k] * x[b, y + r - pad, x + s - pad][c]
+//
+// Per tap this is a GEMM dW_t[K x C] = dY^T[K x M] . X_t[M x C] whose contraction runs over PIXELS, while both operands are
+// stored pixel-major ([pixel][C/32][3][32] bf16).  The MFMA wants, per lane, 8 consecutive contraction elements of one row /
+// column, i.e. 8 pixels of one channel: the chunk (32 pixels x 128 channels per operand and plane) is staged in LDS as it comes
+// (256-byte pixel rows) and read back with gfx950's transposing LDS read (ds_read_b64_tr_b16: a 4-pixel x 16-channel block per
+// 16 lanes, delivered channel-major) -- two reads per operand fragment, no shuffles.  LDS image: the guide's 256-byte-row form
+// off(row, chunk) = 256 row + 16 (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))), conflict-free for these reads.
+//
+// Workgroup: 128 (k) x 128 (c) outputs of ONE tap over a range of pixels, 4 wavefronts x (64 x 64); grid = (k tiles x c tiles,
+// taps, pixel splits); partial sums go to slabs [split][tap][K][C] -- the layout of wgrad.hip, summed and transposed into the
+// torch layout by stem_unpack_wgrads_multi.  The tap's shift is applied when the x rows are fetched (rows outside the image read
+// as zeros through the range-checked buffer loads).
+#include <stdlib.h>
+
+#include "stem_common.h"
+
+namespace {
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef short v4s __attribute__((ext_vector_type(4)));
+
+constexpr int TK = 128, TC = 128, NT = 256, PX = 16;      // output tile, threads, pixels per chunk (= one MFMA k-step)
+constexpr int PLANE = PX * 256;                            // 4096 B: 16 pixel rows x 128 channels of one plane
+constexpr int OP_BUF = 3 * PLANE;                          // one operand, one buffer
+constexpr int LDS_BYTES = 2 * 2 * OP_BUF;                  // 49152: two workgroups per CU (register-limited), 2 wavefronts per SIMD
+constexpr int OOR = 0x7FFFFF00;
+constexpr int MAXTAP = 25;
+
+struct Wg6Args {
+    const void *xp, *dyp;
+    float *dwp;
+    int xpix, dypix;               // bytes per pixel of the planes buffers (channel views allowed)
+    int B, H, W, C, K, OH, OW, T;
+    int nsplit, cps;               // pixel chunks per split
+    int xbytes, dybytes;
+    signed char dy[MAXTAP], dx[MAXTAP];
+};
+
+__device__ inline int lds_off(int row, int chunk) { return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+__device__ inline bf16x8 tr_frag(const unsigned char *base, int a0, int a1)
+{
+    // two transposing reads: pixels 8h .. 8h+3 and 8h+4 .. 8h+7 of this lane's channel
+    typedef __attribute__((address_space(3))) v4s *lp;
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + a0));
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + a1));
+    typedef short v8s __attribute__((ext_vector_type(8)));
+    const v8s v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *As = smem;                        // [2][3][16 px][256 B]   dy
+    unsigned char *Bs = smem + 2 * OP_BUF;           // [2][3][16 px][256 B]   x (shifted by the tap)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_c = (a.C + TC - 1) / TC;
+    const int tk = blockIdx.x / tiles_c, tc = blockIdx.x - tk * tiles_c;
+    const int k0 = tk * TK, c0 = tc * TC, tap = blockIdx.y, split = blockIdx.z;
+    const int M = a.B * a.OH * a.OW, nchunks = (M + PX - 1) / PX;
+    const int q_begin = split * a.cps, q_end = q_begin + a.cps < nchunks ? q_begin + a.cps : nchunks;
+    const int tdy = a.dy[tap], tdx = a.dx[tap];
+
+    // ---- staging: thread -> pixel row (tid / 16), 32-channel slab (tid / 4 % 4), 16-byte piece of the slab's 64-byte plane rows ----
+    const int srow = tid >> 4, sslab = (tid >> 2) & 3, spc = tid & 3;
+    const int st0 = lds_off(srow, sslab * 4 + spc);
+    const bool ka_ok = k0 / 32 + sslab < a.K / 32, cb_ok = c0 / 32 + sslab < a.C / 32;
+    const int a_col = (k0 / 32 + sslab) * 192 + spc * 16, b_col = (c0 / 32 + sslab) * 192 + spc * 16;
+    const int ohw = a.OH * a.OW;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.xp), 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.dyp), 0, a.dybytes, 0x00020000);
+
+    f32x4 raA[3], rbA[3], raB[3], rbB[3];
+    auto gload = [&](int q, f32x4 (&ra)[3], f32x4 (&rb)[3]) {
+        const int m = q * PX + srow;
+        const bool ok = m < M;
+        const int mm = ok ? m : 0;
+        const int b = mm / ohw, rem = mm - b * ohw, oy = rem / a.OW, ox = rem - oy * a.OW;
+        const int iy = oy + tdy, ix = ox + tdx;
+        const int offa = (ok && ka_ok) ? m * a.dypix + a_col : OOR;
+        const int offb = (ok && cb_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? ((b * a.H + iy) * a.W + ix) * a.xpix + b_col : OOR;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            ra[pl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, offa + pl * 64, 0, 0));
+            rb[pl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, offb + pl * 64, 0, 0));
+        }
+    };
+    auto sstore = [&](int buf, f32x4 (&ra)[3], f32x4 (&rb)[3]) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            *reinterpret_cast<f32x4 *>(As + buf * OP_BUF + pl * PLANE + st0) = ra[pl];
+            *reinterpret_cast<f32x4 *>(Bs + buf * OP_BUF + pl * PLANE + st0) = rb[pl];
+        }
+    };
+
+    // ---- operand fragments: lane (r = lane & 31, h = lane >> 5) needs pixels 8h .. 8h+7 of channel r of its 32-channel tile ------
+    // 16-lane group g = lane / 16 covers channels 16 (g & 1) .. +15 and the pixel half h = g >> 1; inside the group lane 4q + p
+    // supplies the address of pixel row q, channels 4p .. 4p+3 of the block (cdna guide, T10)
+    const int wk0 = (wave >> 1) * 64, wc0 = (wave & 1) * 64;
+    const int g = lane >> 4, cg = g & 1, hh = g >> 1, qq = (lane >> 2) & 3, pp = lane & 3;
+    int adr[2][2][2];          // [operand 0 = dy / 1 = x][32-channel tile][read 0 / 1]
+#pragma unroll
+    for (int op = 0; op < 2; ++op)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int row = 8 * hh + 4 * u + qq;
+                const int chunk = ((op ? wc0 : wk0) + t * 32) / 8 + 2 * cg + (pp >> 1);
+                adr[op][t][u] = lds_off(row, chunk) + 8 * (pp & 1);
+            }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto step = [&](int cur, f32x4 (&ra)[3], f32x4 (&rb)[3], int qn) {
+        const unsigned char *Ab = As + cur * OP_BUF, *Bb = Bs + cur * OP_BUF;
+        bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                af[t][pl] = tr_frag(Ab + pl * PLANE, adr[0][t][0], adr[0][t][1]);
+                bf[t][pl] = tr_frag(Bb + pl * PLANE, adr[1][t][0], adr[1][t][1]);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+            }
+            if (i == 0)
+                sstore(cur ^ 1, ra, rb);
+            else
+                gload(qn, ra, rb);
+        }
+    };
+    const int q_last = q_end - 1;
+    auto clampq = [&](int q) { return q < q_last ? q : q_last; };
+    if (q_begin < q_end) {
+        gload(q_begin, raA, rbA);
+        sstore(0, raA, rbA);
+        gload(clampq(q_begin + 1), raA, rbA);
+        gload(clampq(q_begin + 2), raB, rbB);
+    }
+    __syncthreads();
+    {
+        int q = q_begin;
+        for (; q + 1 < q_end; q += 2) {
+            step(0, raA, rbA, clampq(q + 3));
+            __syncthreads();
+            step(1, raB, rbB, clampq(q + 4));
+            __syncthreads();
+        }
+        if (q < q_end) {
+            step(0, raA, rbA, clampq(q + 3));
+            __syncthreads();
+        }
+    }
+
+    // ---- partial sums -> slab [split][tap][K][C]; lane holds column c = .. + (lane & 31), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) --
+    float *out = a.dwp + ((size_t)split * a.T + tap) * a.K * a.C;
+    const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + wc0 + j * 32 + lr;
+            if (c >= a.C) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wk0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (k < a.K) out[(size_t)k * a.C + c] = acc[i][j][r];
+            }
+        }
+}
+
+int plan_splits(int B, int OH, int OW, int C, int K, int T)
+{
+    static const int forced_once = getenv("STEM_WG6_SPLIT") ? atoi(getenv("STEM_WG6_SPLIT")) : 0;
+    const int forced = getenv("STEM_WG6_SPLIT_DYN") ? atoi(getenv("STEM_WG6_SPLIT_DYN")) : forced_once;      // tuning / tests
+    const int nchunks = cdiv(B * OH * OW, PX), tiles = cdiv(K, TK) * cdiv(C, TC) * T;
+    int s = forced > 0 ? forced : (512 + tiles / 2) / tiles;       // two workgroups per CU: aim at ~512 workgroups
+    if (s < 1) s = 1;
+    if (s > nchunks / 16) s = nchunks / 16 > 0 ? nchunks / 16 : 1;
+    const int cps = cdiv(nchunks, s);
+    return cdiv(nchunks, cps);
+}
+
+}   // namespace
+
+STEM_EXPORT int stem_wgrad_bf16x6_splits(int B, int H, int W, int C, int K, int R, int S, int pad)
+{
+    const int OH = H + 2 * pad - R + 1, OW = W + 2 * pad - S + 1;
+    if (OH < 1 || OW < 1) return 0;
+    return plan_splits(B, OH, OW, C, K, R * S);
+}
+
+STEM_EXPORT int stem_conv2d_wgrad_bf16x6(const void *xp, int xpix, const void *dyp, int dypix, float *dwp, int B, int H, int W, int C, int K,
+                                         int R, int S, int pad, int splits, void *stream)
+{
+    STEM_CHECK_ARG(xp && dyp && dwp, "stem_conv2d_wgrad_bf16x6: null pointer");
+    STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && C >= 32 && C % 32 == 0 && K >= 32 && K % 32 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP && pad >= 0,
+                   "stem_conv2d_wgrad_bf16x6: C %% 32 == 0, K %% 32 == 0, R*S <= %d (C=%d K=%d R=%d S=%d)", MAXTAP, C, K, R, S);
+    const int OH = H + 2 * pad - R + 1, OW = W + 2 * pad - S + 1;
+    STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_wgrad_bf16x6: empty output");
+    if (xpix == 0) xpix = (C / 32) * 192;
+    if (dypix == 0) dypix = (K / 32) * 192;
+    STEM_CHECK_ARG(xpix >= (C / 32) * 192 && xpix % 192 == 0 && dypix >= (K / 32) * 192 && dypix % 192 == 0,
+                   "stem_conv2d_wgrad_bf16x6: pixel pitches must be multiples of 192 bytes covering the channels");
+    const size_t xb = (size_t)B * H * W * xpix, db = (size_t)B * OH * OW * dypix;
+    STEM_CHECK_ARG(xb < 0x7FFFFF00ull && db < 0x7FFFFF00ull, "stem_conv2d_wgrad_bf16x6: operand views must stay below 2 GiB");
+    STEM_CHECK_ARG(splits == plan_splits(B, OH, OW, C, K, R * S), "stem_conv2d_wgrad_bf16x6: splits must come from stem_wgrad_bf16x6_splits");
+    Wg6Args a;
+    memset(&a, 0, sizeof(a));
+    a.xp = xp; a.dyp = dyp; a.dwp = dwp; a.xpix = xpix; a.dypix = dypix;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.K = K; a.OH = OH; a.OW = OW; a.T = R * S;
+    a.xbytes = (int)xb; a.dybytes = (int)db;
+    const int nchunks = cdiv(B * OH * OW, PX);
+    a.nsplit = splits;
+    a.cps = cdiv(nchunks, splits);
+    for (int r = 0; r < R; ++r)
+        for (int s = 0; s < S; ++s) {
+            a.dy[r * S + s] = (signed char)(r - pad);
+            a.dx[r * S + s] = (signed char)(s - pad);
+        }
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)wgrad_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(wgrad_bf16x6_kernel, dim3(cdiv(K, TK) * cdiv(C, TC), R * S, splits), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+    STEM_LAUNCH_CHECK("stem_conv2d_wgrad_bf16x6");
+    return 0;
+}

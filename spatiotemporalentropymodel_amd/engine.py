@@ -38,6 +38,7 @@ class _Layer:
         # forward / input-gradient on the bf16 matrix cores (csrc/conv_bf16x6.hip, general variant): stride-1 convolutions whose
         # contraction channels are multiples of 32; decided once by the engine (StemEngine._select_bx6)
         self.bx6 = False
+        self.wg6 = False
         self.wp6_fwd = self.wp6_dgrad = None
         self._slabs = {}
         self.pending = None       # (dwp, splits) of the last wgrad, consumed by StemEngine.unpack_all
@@ -72,6 +73,38 @@ class _Layer:
         """-> (dx fp32, dx planes or None); xact: the activated input of this layer (leaky-ReLU derivative folded in)"""
         return F.conv2d_bf16x6_gen(dyp, self.wp6_dgrad, None, self.C, self.R, self.R, 1, self.pad,
                                    epi=F.GEN_EPI_DACT if xact is not None else F.GEN_EPI_BIAS, z=xact, want_planes=planes)
+
+    def wg6_eligible(self):
+        """weight gradient on csrc/wgrad_bf16x6.hip: stride-1 convolutions (all taps are produced, as autograd does for the
+        masked context convolution too)"""
+        return (self.kind == "conv" and self.stride == 1 and self.C % 32 == 0 and self.K % 32 == 0 and self.R * self.R <= 25
+                and self.pad == self.R // 2)
+
+    def wgrad_any(self, x, dy, xp=None, dyp=None):
+        """weight + bias gradient from the planes operands when this layer runs its weight gradient on the bf16 kernel and both
+        are at hand, else from the fp32 tensors"""
+        if not (self.wg6 and xp is not None and dyp is not None):
+            return self.wgrad(x, dy)
+        side = self.eng.side_stream(dy.device)
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(dy.device))
+            with torch.cuda.stream(side):
+                self._wgrad6(xp, dyp, dy)
+            for t in (xp.data, dyp.data, dy):
+                t.record_stream(side)
+        else:
+            self._wgrad6(xp, dyp, dy)
+
+    def _wgrad6(self, xp, dyp, dy):
+        key = ("bf16",) + tuple(xp.shape)
+        if key not in self._slabs:
+            splits, elems = F.wgrad_bf16x6_plan(xp.shape, self.K, self.R, self.R, self.pad)
+            self._slabs[key] = (torch.empty(elems, device=dy.device, dtype=torch.float32), splits)
+        dwp, splits = self._slabs[key]
+        F.conv2d_wgrad_bf16x6(xp, dyp, self.K, self.R, self.R, self.pad, dwp, splits)
+        if self.mod.bias is not None:
+            F.bias_grad(dy, _grad_of(self.mod.bias), accumulate=True)
+        self.pending = (dwp, splits)
 
     def pack_descs(self):
         w = self.mod.weight
@@ -170,10 +203,13 @@ class StemEngine:
         if self.use_bx6:
             for l in self.layers:
                 l.bx6 = l.bx6_eligible()
+                l.wg6 = self.use_wg6 and l.wg6_eligible()
 
     #: forward and input-gradient of the stride-1 layers (TPM, HE.0, HD.4, EPM) on the bf16 matrix cores with fp32-exact products
     #: (six bf16 MFMAs per fp32 product, csrc/conv_bf16x6.hip); STEM_ENGINE_BF16X6=0 keeps every layer on the fp32-MFMA kernels
     use_bx6 = os.environ.get("STEM_ENGINE_BF16X6", "1") != "0"
+    #: ... and their weight gradients (csrc/wgrad_bf16x6.hip); STEM_ENGINE_WGRAD_BF16X6=0 keeps those on wgrad.hip
+    use_wg6 = os.environ.get("STEM_ENGINE_WGRAD_BF16X6", "1") != "0"
 
     #: weight gradients (wgrad + bias column sums + unpack + the data-parallel exchange hook) run on their own stream
     #: and overlap the latency-bound parts of the dgrad chain; set False to keep everything on the compute stream
@@ -294,8 +330,13 @@ class StemEngine:
         if bs is not None:
             bs.wait_stream(main)
         split = F.Bf16Planes.split
+        pl = {}             # planes copies of activations, kept for the weight gradients
         with (torch.cuda.stream(bs) if bs is not None else contextlib.nullcontext()):
-            he0 = self.HE[0].fwd6(split(he_in), F.ACT_LRELU)[0] if self.HE[0].bx6 else self.HE[0].fwd(he_in, F.ACT_LRELU)
+            if self.HE[0].bx6:
+                pl["he_in"] = split(he_in)
+                he0 = self.HE[0].fwd6(pl["he_in"], F.ACT_LRELU)[0]
+            else:
+                he0 = self.HE[0].fwd(he_in, F.ACT_LRELU)
             he2 = self.HE[1].fwd(he0, F.ACT_LRELU)
             z = self.HE[2].fwd(he2)
             pack = F.eb_pack(eb._tensors14())
@@ -309,15 +350,17 @@ class StemEngine:
             hd0 = self.HD[0].fwd(z_hat, F.ACT_LRELU)
             hd2 = self.HD[1].fwd(hd0, F.ACT_LRELU)
             if self.HD[2].bx6:
-                self.HD[2].fwd6(split(hd2), out=epm_in[:, o_hp:o_hp + P])
+                pl["hd2"] = split(hd2)
+                self.HD[2].fwd6(pl["hd2"], out=epm_in[:, o_hp:o_hp + P])
             else:
                 self.HD[2].fwd(hd2, out=epm_in[:, o_hp:o_hp + P])
         tp0 = tp2 = None
         if self.has_tpm and self.TPM[0].bx6:
             # planes travel from layer to layer (written by the producing epilogue next to the fp32 copy backward needs)
-            tp0, tp0p = self.TPM[0].fwd6(split(yd), F.ACT_LRELU, planes=True)
-            tp2, tp2p = self.TPM[1].fwd6(tp0p, F.ACT_LRELU, planes=True)
-            self.TPM[2].fwd6(tp2p, out=epm_in[:, o_tp:o_tp + P])
+            pl["yd"] = split(yd)
+            tp0, pl["tp0"] = self.TPM[0].fwd6(pl["yd"], F.ACT_LRELU, planes=True)
+            tp2, pl["tp2"] = self.TPM[1].fwd6(pl["tp0"], F.ACT_LRELU, planes=True)
+            self.TPM[2].fwd6(pl["tp2"], out=epm_in[:, o_tp:o_tp + P])
         elif self.has_tpm:
             tp0 = self.TPM[0].fwd(yd, F.ACT_LRELU)
             tp2 = self.TPM[1].fwd(tp0, F.ACT_LRELU)
@@ -332,9 +375,10 @@ class StemEngine:
         if bs is not None:
             main.wait_stream(bs)
         if self.EPM[0].bx6:
-            e0, e0p = self.EPM[0].fwd6(split(epm_in), F.ACT_LRELU, planes=True)
-            e2, e2p = self.EPM[1].fwd6(e0p, F.ACT_LRELU, planes=True)
-            gp = self.EPM[2].fwd6(e2p)[0]                          # [B, 2*Cin, H, W] = scales | means
+            pl["epm_in"] = split(epm_in)
+            e0, pl["e0"] = self.EPM[0].fwd6(pl["epm_in"], F.ACT_LRELU, planes=True)
+            e2, pl["e2"] = self.EPM[1].fwd6(pl["e0"], F.ACT_LRELU, planes=True)
+            gp = self.EPM[2].fwd6(pl["e2"])[0]                     # [B, 2*Cin, H, W] = scales | means
         else:
             e0 = self.EPM[0].fwd(epm_in, F.ACT_LRELU)
             e2 = self.EPM[1].fwd(e0, F.ACT_LRELU)
@@ -354,7 +398,7 @@ class StemEngine:
             else:
                 y_hat = gc_out
         k.update(he_in=he_in, he0=he0, he2=he2, z_hat=z_hat, pack=pack, hd0=hd0, hd2=hd2, epm_in=epm_in, tp0=tp0, tp2=tp2,
-                 yd=yd, t_hat=t_hat, e0=e0, e2=e2, gp=gp, gc_out=gc_out, offs=(o_tp, o_hp, o_ctx), P=P, Cin=Cin)
+                 yd=yd, t_hat=t_hat, e0=e0, e2=e2, gp=gp, gc_out=gc_out, offs=(o_tp, o_hp, o_ctx), P=P, Cin=Cin, planes=pl)
         return y_hat, lik_y, lik_z, k
 
     # -------------------------------------------------------------------------------------------
@@ -374,12 +418,14 @@ class StemEngine:
                       scale_bound=gc._scale_bound, lik_bound=gc._lik_bound)
         # EPM (1x1 chain)
         dprip = None
+        pl = k.get("planes", {})
         if self.EPM[0].bx6:
-            self.EPM[2].wgrad(k["e2"], dgp)
-            de2, de2p = self.EPM[2].dgrad6(F.Bf16Planes.split(dgp), xact=k["e2"], planes=True)
-            self.EPM[1].wgrad(k["e0"], de2)
+            dgpp = F.Bf16Planes.split(dgp)
+            self.EPM[2].wgrad_any(k["e2"], dgp, pl.get("e2"), dgpp)
+            de2, de2p = self.EPM[2].dgrad6(dgpp, xact=k["e2"], planes=True)
+            self.EPM[1].wgrad_any(k["e0"], de2, pl.get("e0"), de2p)
             de0, de0p = self.EPM[1].dgrad6(de2p, xact=k["e0"], planes=True)
-            self.EPM[0].wgrad(k["epm_in"], de0)
+            self.EPM[0].wgrad_any(k["epm_in"], de0, pl.get("epm_in"), de0p)
             dpri, dprip = self.EPM[0].dgrad6(de0p, planes=True)    # the prior branches read 32-aligned channel views of the planes
         else:
             self.EPM[2].wgrad(k["e2"], dgp)
@@ -397,21 +443,26 @@ class StemEngine:
                 self._backward_hyper(k, dpri, dlik_z, dprip)
         # spatial prior: weight gradient of all 25 taps, no input gradient (its input is data + noise)
         if self.has_spm:
-            self.CTX.wgrad(k["t_hat"], dpri[:, o_ctx:o_ctx + P])
+            if self.CTX.wg6 and dprip is not None:
+                self.CTX.wgrad_any(k["t_hat"], dpri[:, o_ctx:o_ctx + P], F.Bf16Planes.split(k["t_hat"]), dprip.channels(o_ctx, o_ctx + P))
+            else:
+                self.CTX.wgrad(k["t_hat"], dpri[:, o_ctx:o_ctx + P])
             self._group_ready([self.CTX], [])
         if self.has_tpm:
             dtp = dpri[:, o_tp:o_tp + P]
-            self.TPM[2].wgrad(k["tp2"], dtp)
             if self.TPM[2].bx6:
                 dtpp = dprip.channels(o_tp, o_tp + P) if dprip is not None else F.Bf16Planes.split(dtp)
+                self.TPM[2].wgrad_any(k["tp2"], dtp, pl.get("tp2"), dtpp)
                 d, dp = self.TPM[2].dgrad6(dtpp, xact=k["tp2"], planes=True)
-                self.TPM[1].wgrad(k["tp0"], d)
-                d = self.TPM[1].dgrad6(dp, xact=k["tp0"])[0]
+                self.TPM[1].wgrad_any(k["tp0"], d, pl.get("tp0"), dp)
+                d, dp = self.TPM[1].dgrad6(dp, xact=k["tp0"], planes=self.TPM[0].wg6)
+                self.TPM[0].wgrad_any(k["yd"], d, pl.get("yd"), dp)
             else:
+                self.TPM[2].wgrad(k["tp2"], dtp)
                 d = self.TPM[2].dgrad(dtp, k["tp2"].shape, xact=k["tp2"])
                 self.TPM[1].wgrad(k["tp0"], d)
                 d = self.TPM[1].dgrad(d, k["tp0"].shape, xact=k["tp0"])
-            self.TPM[0].wgrad(k["yd"], d)
+                self.TPM[0].wgrad(k["yd"], d)
             self._group_ready(self.TPM, [])
         if bs is None:
             self._backward_hyper(k, dpri, dlik_z, dprip)
@@ -425,11 +476,13 @@ class StemEngine:
         o_tp, o_hp, o_ctx = k["offs"]
         # hyper decoder
         dhp = dpri[:, o_hp:o_hp + P]
-        self.HD[2].wgrad(k["hd2"], dhp)
+        pl = k.get("planes", {})
         if self.HD[2].bx6:
             dhpp = dprip.channels(o_hp, o_hp + P) if dprip is not None else F.Bf16Planes.split(dhp)
+            self.HD[2].wgrad_any(k["hd2"], dhp, pl.get("hd2"), dhpp)
             d = self.HD[2].dgrad6(dhpp, xact=k["hd2"])[0]
         else:
+            self.HD[2].wgrad(k["hd2"], dhp)
             d = self.HD[2].dgrad(dhp, k["hd2"].shape, xact=k["hd2"])
         self.HD[1].wgrad(k["hd0"], d)
         d = self.HD[1].dgrad(d, k["hd0"].shape, xact=k["hd0"])
@@ -445,7 +498,7 @@ class StemEngine:
         d = self.HE[2].dgrad(dz, k["he2"].shape, xact=k["he2"])
         self.HE[1].wgrad(k["he0"], d)
         d = self.HE[1].dgrad(d, k["he0"].shape, xact=k["he0"])
-        self.HE[0].wgrad(k["he_in"], d)
+        self.HE[0].wgrad_any(k["he_in"], d, pl.get("he_in"), F.Bf16Planes.split(d) if self.HE[0].wg6 and "he_in" in pl else None)
         self._group_ready(self.HE, [])
 
 

@@ -487,6 +487,34 @@ def conv2d_bf16x6_gen(xp: Bf16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EP
     return y, yp
 
 
+def wgrad_bf16x6_plan(x_shape, K, R, S, pad):
+    """(splits, slab elements) of conv2d_wgrad_bf16x6 for this geometry"""
+    B, Cc, H, W = x_shape
+    splits = int(_lib.hip().stem_wgrad_bf16x6_splits(B, H, W, Cc, K, R, S, pad))
+    return splits, splits * R * S * K * Cc
+
+
+def conv2d_wgrad_bf16x6(xp: Bf16Planes, dyp: Bf16Planes, K, R, S, pad, dwp, splits):
+    """packed weight-gradient slabs [splits][R*S][K][C] of a stride-1 convolution from planes operands (channel views allowed)"""
+    B, Cc, H, W = xp.shape
+    _chk(_lib.hip().stem_conv2d_wgrad_bf16x6(xp.data_ptr(), xp.pix_bytes, dyp.data_ptr(), dyp.pix_bytes, dwp.data_ptr(), B, H, W, Cc, K, R, S, pad,
+                                             splits, _stream()))
+
+
+_BIAS_SCRATCH = {}
+
+
+def bias_grad(dy, db, accumulate=False):
+    """db (+)= column sums of the NHWC tensor dy (the Conv2d bias gradient), deterministic two-stage reduction"""
+    B, K, H, W = dy.shape
+    key = (dy.device, _stream(), B * H * W, K)
+    sc = _BIAS_SCRATCH.get(key)
+    if sc is None:
+        sc = _BIAS_SCRATCH[key] = torch.empty(int(_lib.hip().stem_bias_grad_scratch_elems(B * H * W, K)), device=dy.device, dtype=torch.float32)
+    _chk(_lib.hip().stem_bias_grad(dy.data_ptr(), nhwc_ld(dy), B * H * W, K, sc.data_ptr(), db.data_ptr(), int(accumulate), _stream()))
+    return db
+
+
 def conv2d_fwd_c4_gdn_planes(x4, wp, bias, beta, gamma, K, R, S, stride, pad, beta_min=1e-6):
     """conv2d_fwd_c4_gdn whose result is handed to conv2d_bf16x6_fwd: written pre-split (Bf16Planes), no fp32 copy."""
     B, H, W, _ = x4.shape

@@ -250,3 +250,51 @@ def test_engine_schedule_with_and_without_bf16_layers(monkeypatch):
     # weight gradients (sums over pixels with cancellation) may sit up to 2e-4 of the tensor's largest entry apart
     for n, g32 in res["fp32"][1].items():
         assert_close(res["bf16"][1][n], g32, rtol=2e-4, what=f"grad {n}", floor=1.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Weight gradient (csrc/wgrad_bf16x6.hip): contraction over pixels through the transposing LDS reads
+WG_CASES = [  # B, C, H, W, K, R
+    (2, 64, 9, 11, 96, 3),           # ragged pixel count (198 = 12 chunks of 16 + 6), one tile
+    (1, 160, 13, 7, 96, 5),          # C = 160: second channel tile half empty
+    (3, 32, 16, 16, 288, 1),         # 1x1, three k tiles
+    (4, 192, 16, 16, 256, 5),        # TPM.0 geometry at a quarter of the batch
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES)
+@pytest.mark.parametrize("split", [0, 1, 3])
+def test_weight_gradient_vs_oracle(F, monkeypatch, case, split):
+    B, C, H, W, K, R = case
+    if split:
+        monkeypatch.setenv("STEM_WG6_SPLIT_DYN", str(split))
+    pad = R // 2
+    x, dy = rnd((B, C, H, W), 51, -2, 2), rnd((B, K, H, W), 52)
+    w0 = np.zeros((K, C, R, R), np.float32)
+    _, dw_ref, db_ref = orc.conv2d_bwd(x, w0, dy, 1, pad, need_dx=False)
+    xd, dyd = dev(x), dev(dy)
+    splits, elems = F.wgrad_bf16x6_plan(xd.shape, K, R, R, pad)
+    assert split == 0 or splits <= split             # clamped to >= 16 pixel chunks per split
+    dwp = torch.empty(elems, device="cuda")
+    F.conv2d_wgrad_bf16x6(F.Bf16Planes.split(xd), F.Bf16Planes.split(dyd), K, R, R, pad, dwp, splits)
+    dw = dwp.view(splits, R * R, K, C).sum(0).permute(1, 2, 0).reshape(K, C, R, R)
+    assert_close(host(dw), dw_ref, what=f"wgrad {case} split={split}", floor=0.1)
+    db = torch.zeros(K, device="cuda")
+    F.bias_grad(dyd.contiguous(memory_format=torch.channels_last), db)
+    assert_close(host(db), db_ref, what="bias gradient", floor=0.1)
+    F.bias_grad(dyd.contiguous(memory_format=torch.channels_last), db, accumulate=True)
+    assert_close(host(db), 2 * db_ref, what="bias gradient, accumulated", floor=0.1)
+
+
+def test_weight_gradient_from_channel_views(F):
+    """x and dy as 32-aligned channel views of wider planes tensors (how the engine feeds the prior branches' slices)"""
+    B, H, W = 2, 8, 8
+    xb, dyb = rnd((B, 160, H, W), 61, -2, 2), rnd((B, 224, H, W), 62)
+    xp, dyp = F.Bf16Planes.split(dev(xb)).channels(32, 96), F.Bf16Planes.split(dev(dyb)).channels(64, 160)
+    splits, elems = F.wgrad_bf16x6_plan(xp.shape, 96, 3, 3, 1)
+    dwp = torch.empty(elems, device="cuda")
+    F.conv2d_wgrad_bf16x6(xp, dyp, 96, 3, 3, 1, dwp, splits)
+    dw = dwp.view(splits, 9, 96, 64).sum(0).permute(1, 2, 0).reshape(96, 64, 3, 3)
+    ref = orc.conv2d_bwd(np.ascontiguousarray(xb[:, 32:96]), np.zeros((96, 64, 3, 3), np.float32), np.ascontiguousarray(dyb[:, 64:160]), 1, 1,
+                         need_dx=False)[1]
+    assert_close(host(dw), ref, what="wgrad from views", floor=0.1)
