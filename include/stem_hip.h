@@ -390,8 +390,10 @@ int stem_conv2d_bf16x6_gen_fwd(const void *xp, int xpix, const void *wp, const f
  * (sum / transpose with stem_unpack_wgrads_multi).  splits = stem_wgrad_bf16x6_splits(...); dwp holds splits*R*S*K*C floats.
  * The bias gradient (column sums of the fp32 dy) is stem_bias_grad. */
 int stem_wgrad_bf16x6_splits(int B, int H, int W, int C, int K, int R, int S, int pad);
-int stem_conv2d_wgrad_bf16x6(const void *xp, int xpix, const void *dyp, int dypix, float *dwp, int B, int H, int W, int C, int K,
-                             int R, int S, int pad, int splits, void *stream);
+/* bias_part (optional, splits * K floats): per-split column sums of dy, to be finished by stem_bias_grad_final */
+int stem_conv2d_wgrad_bf16x6(const void *xp, int xpix, const void *dyp, int dypix, float *dwp, float *bias_part, int B, int H, int W,
+                             int C, int K, int R, int S, int pad, int splits, void *stream);
+int stem_bias_grad_final(const float *part, int K, int parts, float *db, int accumulate, void *stream);
 size_t stem_bias_grad_scratch_elems(long npix, int K);
 int stem_bias_grad(const float *dy, int lddy, long npix, int K, float *scratch, float *db, int accumulate, void *stream);
 

@@ -96,7 +96,8 @@ _HIP_SIG = {
     "stem_conv2d_bf16x6_gen_workspace_bytes": [ci, ci, ci, ci, ci, ci, ci, ci, ci],
     "stem_bf16x3_pack_conv_weights_multi": [vp, ci, vp],
     "stem_wgrad_bf16x6_splits": [ci, ci, ci, ci, ci, ci, ci, ci],
-    "stem_conv2d_wgrad_bf16x6": [vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_conv2d_wgrad_bf16x6": [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_bias_grad_final": [vp, ci, ci, vp, ci, vp],
     "stem_bias_grad_scratch_elems": [C.c_long, ci],
     "stem_bias_grad": [vp, ci, C.c_long, ci, vp, vp, ci, vp],
     "stem_conv2d_bf16x6_gen_fwd": [vp, ci, vp, vp, ci, cf, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],

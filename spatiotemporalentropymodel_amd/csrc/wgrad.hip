@@ -578,6 +578,15 @@ int colsum(const float *dy, int ld, size_t npix, int K, float *scratch, float *d
 // bias gradient on its own (for the weight-gradient kernel of wgrad_bf16x6.hip, which does not touch the fp32 dy)
 STEM_EXPORT size_t stem_bias_grad_scratch_elems(long npix, int K) { return (size_t)colsum_parts((size_t)npix, K) * K; }
 
+/* second stage only: db (+)= sum over `parts` rows of part[parts][K] (first stage done by stem_conv2d_wgrad_bf16x6) */
+STEM_EXPORT int stem_bias_grad_final(const float *part, int K, int parts, float *db, int accumulate, void *stream)
+{
+    STEM_CHECK_ARG(part && db && K >= 1 && parts >= 1, "stem_bias_grad_final: bad arguments");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(K, 64)), dim3(1024), 0, (hipStream_t)stream, part, K, parts, db, accumulate);
+    STEM_LAUNCH_CHECK("stem_bias_grad_final");
+    return 0;
+}
+
 STEM_EXPORT int stem_bias_grad(const float *dy, int lddy, long npix, int K, float *scratch, float *db, int accumulate, void *stream)
 {
     STEM_CHECK_ARG(dy && scratch && db && npix >= 1 && K >= 1 && lddy >= K, "stem_bias_grad: bad arguments");

@@ -33,6 +33,7 @@ constexpr int MAXTAP = 25;
 struct Wg6Args {
     const void *xp, *dyp;
     float *dwp;
+    float *bias_part;              // optional [nsplit][K]: per-split column sums of dy (the bias gradient's first stage)
     int xpix, dypix;               // bytes per pixel of the planes buffers (channel views allowed)
     int B, H, W, C, K, OH, OW, T;
     int nsplit, cps;               // pixel chunks per split
@@ -92,11 +93,29 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
             rb[pl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, offb + pl * 64, 0, 0));
         }
     };
-    auto sstore = [&](int buf, f32x4 (&ra)[3], f32x4 (&rb)[3]) {
+    // bias gradient: the workgroups of tap 0 / channel tile 0 see every dy row of their k tile and pixel range exactly once on
+    // its way to LDS; they add the three planes up again (exact) and keep per-thread column sums of their 8 channels
+    const bool do_bias = a.bias_part != nullptr && tap == 0 && tc == 0;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto sstore = [&](int buf, f32x4 (&ra)[3], f32x4 (&rb)[3], bool fresh) {       // fresh: not a clamped repeat of the last chunk
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             *reinterpret_cast<f32x4 *>(As + buf * OP_BUF + pl * PLANE + st0) = ra[pl];
             *reinterpret_cast<f32x4 *>(Bs + buf * OP_BUF + pl * PLANE + st0) = rb[pl];
+        }
+        if (do_bias && fresh) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 w0 = __builtin_bit_cast(u32x4, ra[0]), w1 = __builtin_bit_cast(u32x4, ra[1]), w2 = __builtin_bit_cast(u32x4, ra[2]);
+            auto lo = [](unsigned u) { return __builtin_bit_cast(float, u << 16); };
+            auto hi = [](unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); };
+            bsum[0] += (lo(w0.x) + lo(w1.x)) + lo(w2.x);
+            bsum[1] += (hi(w0.x) + hi(w1.x)) + hi(w2.x);
+            bsum[2] += (lo(w0.y) + lo(w1.y)) + lo(w2.y);
+            bsum[3] += (hi(w0.y) + hi(w1.y)) + hi(w2.y);
+            bsum[4] += (lo(w0.z) + lo(w1.z)) + lo(w2.z);
+            bsum[5] += (hi(w0.z) + hi(w1.z)) + hi(w2.z);
+            bsum[6] += (lo(w0.w) + lo(w1.w)) + lo(w2.w);
+            bsum[7] += (hi(w0.w) + hi(w1.w)) + hi(w2.w);
         }
     };
 
@@ -124,7 +143,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto step = [&](int cur, f32x4 (&ra)[3], f32x4 (&rb)[3], int qn) {
+    auto step = [&](int cur, f32x4 (&ra)[3], f32x4 (&rb)[3], int qcur, int qn) {
         const unsigned char *Ab = As + cur * OP_BUF, *Bb = Bs + cur * OP_BUF;
         bf16x8 af[2][3], bf[2][3];
 #pragma unroll
@@ -146,7 +165,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
             }
             if (i == 0)
-                sstore(cur ^ 1, ra, rb);
+                sstore(cur ^ 1, ra, rb, qcur + 1 < q_end);
             else
                 gload(qn, ra, rb);
         }
@@ -155,7 +174,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
     auto clampq = [&](int q) { return q < q_last ? q : q_last; };
     if (q_begin < q_end) {
         gload(q_begin, raA, rbA);
-        sstore(0, raA, rbA);
+        sstore(0, raA, rbA, true);
         gload(clampq(q_begin + 1), raA, rbA);
         gload(clampq(q_begin + 2), raB, rbB);
     }
@@ -163,14 +182,27 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
     {
         int q = q_begin;
         for (; q + 1 < q_end; q += 2) {
-            step(0, raA, rbA, clampq(q + 3));
+            step(0, raA, rbA, q, clampq(q + 3));
             __syncthreads();
-            step(1, raB, rbB, clampq(q + 4));
+            step(1, raB, rbB, q + 1, clampq(q + 4));
             __syncthreads();
         }
         if (q < q_end) {
-            step(0, raA, rbA, clampq(q + 3));
+            step(0, raA, rbA, q, clampq(q + 3));
             __syncthreads();
+        }
+    }
+
+    if (do_bias) {       // 16 pixel rows x 128 channels of per-thread sums -> one row per split
+        float *red = reinterpret_cast<float *>(smem);                 // the main loop ended with a barrier
+#pragma unroll
+        for (int c = 0; c < 8; ++c) red[srow * 128 + sslab * 32 + spc * 8 + c] = bsum[c];
+        __syncthreads();
+        if (tid < 128 && k0 + tid < a.K) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v += red[r * 128 + tid];
+            a.bias_part[(size_t)split * a.K + k0 + tid] = v;
         }
     }
 
@@ -212,8 +244,8 @@ STEM_EXPORT int stem_wgrad_bf16x6_splits(int B, int H, int W, int C, int K, int 
     return plan_splits(B, OH, OW, C, K, R * S);
 }
 
-STEM_EXPORT int stem_conv2d_wgrad_bf16x6(const void *xp, int xpix, const void *dyp, int dypix, float *dwp, int B, int H, int W, int C, int K,
-                                         int R, int S, int pad, int splits, void *stream)
+STEM_EXPORT int stem_conv2d_wgrad_bf16x6(const void *xp, int xpix, const void *dyp, int dypix, float *dwp, float *bias_part, int B, int H, int W,
+                                         int C, int K, int R, int S, int pad, int splits, void *stream)
 {
     STEM_CHECK_ARG(xp && dyp && dwp, "stem_conv2d_wgrad_bf16x6: null pointer");
     STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && C >= 32 && C % 32 == 0 && K >= 32 && K % 32 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP && pad >= 0,
@@ -229,7 +261,7 @@ STEM_EXPORT int stem_conv2d_wgrad_bf16x6(const void *xp, int xpix, const void *d
     STEM_CHECK_ARG(splits == plan_splits(B, OH, OW, C, K, R * S), "stem_conv2d_wgrad_bf16x6: splits must come from stem_wgrad_bf16x6_splits");
     Wg6Args a;
     memset(&a, 0, sizeof(a));
-    a.xp = xp; a.dyp = dyp; a.dwp = dwp; a.xpix = xpix; a.dypix = dypix;
+    a.xp = xp; a.dyp = dyp; a.dwp = dwp; a.bias_part = bias_part; a.xpix = xpix; a.dypix = dypix;
     a.B = B; a.H = H; a.W = W; a.C = C; a.K = K; a.OH = OH; a.OW = OW; a.T = R * S;
     a.xbytes = (int)xb; a.dybytes = (int)db;
     const int nchunks = cdiv(B * OH * OW, PX);

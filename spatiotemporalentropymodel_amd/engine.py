@@ -99,11 +99,11 @@ class _Layer:
         key = ("bf16",) + tuple(xp.shape)
         if key not in self._slabs:
             splits, elems = F.wgrad_bf16x6_plan(xp.shape, self.K, self.R, self.R, self.pad)
-            self._slabs[key] = (torch.empty(elems, device=dy.device, dtype=torch.float32), splits)
-        dwp, splits = self._slabs[key]
-        F.conv2d_wgrad_bf16x6(xp, dyp, self.K, self.R, self.R, self.pad, dwp, splits)
-        if self.mod.bias is not None:
-            F.bias_grad(dy, _grad_of(self.mod.bias), accumulate=True)
+            self._slabs[key] = (torch.empty(elems, device=dy.device, dtype=torch.float32), splits,
+                                torch.empty(splits * self.K, device=dy.device, dtype=torch.float32))
+        dwp, splits, bpart = self._slabs[key]
+        gb = _grad_of(self.mod.bias) if self.mod.bias is not None else None
+        F.conv2d_wgrad_bf16x6(xp, dyp, self.K, self.R, self.R, self.pad, dwp, splits, db=gb, bias_part=bpart, accumulate_db=True)
         self.pending = (dwp, splits)
 
     def pack_descs(self):

@@ -494,11 +494,17 @@ def wgrad_bf16x6_plan(x_shape, K, R, S, pad):
     return splits, splits * R * S * K * Cc
 
 
-def conv2d_wgrad_bf16x6(xp: Bf16Planes, dyp: Bf16Planes, K, R, S, pad, dwp, splits):
-    """packed weight-gradient slabs [splits][R*S][K][C] of a stride-1 convolution from planes operands (channel views allowed)"""
+def conv2d_wgrad_bf16x6(xp: Bf16Planes, dyp: Bf16Planes, K, R, S, pad, dwp, splits, db=None, bias_part=None, accumulate_db=False):
+    """packed weight-gradient slabs [splits][R*S][K][C] of a stride-1 convolution from planes operands (channel views allowed).
+    With `db` (and a `bias_part` scratch of splits * K floats) the bias gradient comes out of the same pass: the kernel leaves
+    per-split column sums of dy, a second tiny launch adds them into db."""
     B, Cc, H, W = xp.shape
-    _chk(_lib.hip().stem_conv2d_wgrad_bf16x6(xp.data_ptr(), xp.pix_bytes, dyp.data_ptr(), dyp.pix_bytes, dwp.data_ptr(), B, H, W, Cc, K, R, S, pad,
-                                             splits, _stream()))
+    if db is not None and bias_part is None:
+        bias_part = torch.empty(splits * K, device=dwp.device, dtype=torch.float32)
+    _chk(_lib.hip().stem_conv2d_wgrad_bf16x6(xp.data_ptr(), xp.pix_bytes, dyp.data_ptr(), dyp.pix_bytes, dwp.data_ptr(), _ptr(bias_part) if db is not None else None,
+                                             B, H, W, Cc, K, R, S, pad, splits, _stream()))
+    if db is not None:
+        _chk(_lib.hip().stem_bias_grad_final(bias_part.data_ptr(), K, splits, db.data_ptr(), int(accumulate_db), _stream()))
 
 
 _BIAS_SCRATCH = {}

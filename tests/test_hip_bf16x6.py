@@ -276,9 +276,11 @@ def test_weight_gradient_vs_oracle(F, monkeypatch, case, split):
     splits, elems = F.wgrad_bf16x6_plan(xd.shape, K, R, R, pad)
     assert split == 0 or splits <= split             # clamped to >= 16 pixel chunks per split
     dwp = torch.empty(elems, device="cuda")
-    F.conv2d_wgrad_bf16x6(F.Bf16Planes.split(xd), F.Bf16Planes.split(dyd), K, R, R, pad, dwp, splits)
+    dbf = torch.full((K,), 1.0, device="cuda")
+    F.conv2d_wgrad_bf16x6(F.Bf16Planes.split(xd), F.Bf16Planes.split(dyd), K, R, R, pad, dwp, splits, db=dbf, accumulate_db=True)
     dw = dwp.view(splits, R * R, K, C).sum(0).permute(1, 2, 0).reshape(K, C, R, R)
     assert_close(host(dw), dw_ref, what=f"wgrad {case} split={split}", floor=0.1)
+    assert_close(host(dbf) - 1.0, db_ref, rtol=2e-4, what="bias gradient from the weight-gradient pass (accumulated onto 1)", floor=0.1)
     db = torch.zeros(K, device="cuda")
     F.bias_grad(dyd.contiguous(memory_format=torch.channels_last), db)
     assert_close(host(db), db_ref, what="bias gradient", floor=0.1)
