@@ -22,6 +22,66 @@ from . import functional as F
 from .layers import join_wgrad_stream
 
 
+class LatentPrefetcher:
+    """Latents of the frozen I-frame model (getY, compressai priors.py:686-694; frozen in stem/trainSTEM.py:128) computed on their
+    own stream, ahead of the P-frame steps that consume them.  The reference calls getY(frame t) inside the loop over the
+    frames (stem/trainSTEM.py:171-179); the transform does not depend on the STEM weights, so frame t + `ahead`'s latents can be
+    in flight while P-step t runs: their long matrix kernels fill the stretches where a P-frame step cannot use the chip (norm
+    reduction -> clip -> Adam -> weight packing, and the small 4x4 / 8x8 layers).
+
+        pf = LatentPrefetcher(imodel)
+        pf.start(frames)                      # enqueues frames 0 .. ahead
+        for t in range(1, len(frames)):
+            y_cur, _ = pf.get(t)              # compute stream waits for frame t's event; frame t + ahead is enqueued
+            ...
+    """
+
+    def __init__(self, imodel, ahead=1):
+        self.imodel, self.ahead = imodel, int(ahead)
+        self._stream = None
+        self._frames = self._ys = self._events = None
+        self._next = 0
+
+    def _enqueue(self, t):
+        dev = self._frames[t].device
+        if self._stream is None or self._stream.device != dev:
+            self._stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(self._stream), torch.no_grad():
+            self._ys[t] = self.imodel.getY(self._frames[t])
+            self._events[t] = torch.cuda.Event()
+            self._events[t].record(self._stream)
+
+    def start(self, frames, frames_ready=False):
+        """frames_ready=True: the frame tensors are not being written by work queued on the compute stream (a data loader's
+        finished batch), so the first transforms need not wait for what that stream still has queued -- they then overlap the
+        tail of the previous optimisation step"""
+        self._frames = list(frames)
+        n = len(self._frames)
+        self._ys, self._events = [None] * n, [None] * n
+        dev = self._frames[0].device
+        if self._stream is None or self._stream.device != dev:
+            self._stream = torch.cuda.Stream(device=dev)
+        if not frames_ready:
+            self._stream.wait_stream(torch.cuda.current_stream(dev))      # the frames were produced on the compute stream
+        self._next = 0
+        while self._next < n and self._next <= self.ahead:
+            self._enqueue(self._next)
+            self._next += 1
+        return self
+
+    def get(self, t):
+        """(y, y + noise) of frame t, ordered before whatever the current stream does next"""
+        while self._next < len(self._frames) and self._next <= t + self.ahead:
+            self._enqueue(self._next)
+            self._next += 1
+        cur = torch.cuda.current_stream(self._frames[t].device)
+        cur.wait_event(self._events[t])
+        y, yq = self._ys[t]
+        y.record_stream(cur)
+        yq.record_stream(cur)
+        return y, yq
+
+
 class LazyNorm:
     """sqrt(sumsq) * scale, evaluated (one tiny kernel + a host sync) only if somebody looks at it"""
 

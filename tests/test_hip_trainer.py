@@ -124,3 +124,25 @@ def test_fused_step_against_reference_fixtures(golden, tag):
     assert abs(float(oc["loss"]) - x_loss) <= 1e-4 * x_loss and abs(float(gnl) - x_gn) <= 1e-4 * x_gn
     assert abs(float(aux_l) - aux_ref) <= 1e-4 * abs(aux_ref), (float(aux_l), aux_ref)
     np.testing.assert_allclose(stem2.entropy_bottleneck.quantiles.grad.cpu().numpy(), g["s1:dquantiles"], rtol=1e-4, atol=1e-6)
+
+
+def test_latent_prefetcher_equals_direct_calls():
+    """trainer.LatentPrefetcher computes getY of the frames on its own stream, ahead of the consumer: same latents as direct
+    calls (the transform is deterministic), noise within [-1/2, 1/2], every frame delivered in order for ahead = 1 and 3."""
+    from spatiotemporalentropymodel_amd.trainer import LatentPrefetcher
+    from spatiotemporalentropymodel_amd.zoo import models
+    torch.manual_seed(4)
+    d = torch.device("cuda:0")
+    imodel = models["mbt2018"](quality=4).to(d).eval()
+    frames = [torch.rand(2, 3, 128, 128, device=d) for _ in range(5)]
+    with torch.no_grad():
+        direct = [imodel.getY(f)[0].clone() for f in frames]
+    for ahead in (1, 3):
+        pf = LatentPrefetcher(imodel, ahead=ahead).start(frames)
+        for t in range(len(frames)):
+            y, yq = pf.get(t)
+            scratch = torch.zeros(1 << 20, device=d).sum()          # unrelated work on the consumer stream between the gets
+            assert torch.equal(y, direct[t]), (ahead, t)
+            assert float((yq - y).abs().max()) <= 0.5
+            del scratch
+    torch.cuda.synchronize()
