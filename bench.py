@@ -223,7 +223,6 @@ def bench_roi(args):
     for _ in range(args.warmup):
         roi_gop_step(imodel, pmodel, crit, opts, frames, qmap, 1.0, accumulator=acc)
     probe.clear()
-    probe0.clear()
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
