@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """GPU timeline summary from a rocprofv3 --kernel-trace CSV: busy union vs span (how much of the wall time at least one
 kernel was running), idle gaps, per-queue busy time, and the kernels by total time inside the steady-state window.
-Usage: timeline.py kernel_trace.csv [skip_fraction=0.4]   (the first `skip_fraction` of the kernels = warm-up)."""
+Usage: timeline.py kernel_trace.csv [skip_fraction=0.4] [NAME N]   (the first `skip_fraction` of the kernels = warm-up; with NAME N
+also the mean duration of the LAST N launches whose name contains NAME -- bench.py times its roofline kernel on launches it
+repeats alone after the timed region)."""
 import csv
 import sys
 from collections import defaultdict
@@ -11,6 +13,11 @@ with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
 rows.sort()
+if len(sys.argv) > 4:
+    sel = [r for r in rows if sys.argv[3] in r[2]][-int(sys.argv[4]):]
+    if sel:
+        d = [(e - s) / 1e3 for s, e, *_ in sel]
+        print(f"last {len(sel)} launches of '{sys.argv[3]}': mean {sum(d) / len(d):.1f} us (min {min(d):.1f}, max {max(d):.1f})")
 skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.4
 rows = rows[int(len(rows) * skip):]
 t0, t1 = rows[0][0], max(r[1] for r in rows)
