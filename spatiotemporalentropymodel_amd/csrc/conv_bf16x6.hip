@@ -1,4 +1,5 @@
-// fp32-accurate convolution on the bf16 matrix cores of gfx950 (MI355X) for the FROZEN analysis transform.
+// fp32-accurate convolutions on the bf16 matrix cores of gfx950 (MI355X): the FROZEN analysis transform (first part of this
+// file) and the general kernel for the training-time STEM layers (second part); weight gradients: wgrad_bf16x6.hip.
 //
 // v_mfma_f32_32x32x2_f32 (igemm.hip) is the only MFMA that multiplies fp32 operands, at 64 flop/clk/SIMD; the bf16 form
 // v_mfma_f32_32x32x16_bf16 runs at 1024.  Every fp32 number is the exact sum of three bf16 numbers

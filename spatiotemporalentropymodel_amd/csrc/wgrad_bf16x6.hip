@@ -5,12 +5,13 @@
 //
 // Per tap this is a GEMM dW_t[K x C] = dY^T[K x M] . X_t[M x C] whose contraction runs over PIXELS, while both operands are
 // stored pixel-major ([pixel][C/32][3][32] bf16).  The MFMA wants, per lane, 8 consecutive contraction elements of one row /
-// column, i.e. 8 pixels of one channel: the chunk (32 pixels x 128 channels per operand and plane) is staged in LDS as it comes
+// column, i.e. 8 pixels of one channel: the chunk (16 pixels x 128 channels per operand and plane) is staged in LDS as it comes
 // (256-byte pixel rows) and read back with gfx950's transposing LDS read (ds_read_b64_tr_b16: a 4-pixel x 16-channel block per
 // 16 lanes, delivered channel-major) -- two reads per operand fragment, no shuffles.  LDS image: the guide's 256-byte-row form
 // off(row, chunk) = 256 row + 16 (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))), conflict-free for these reads.
 //
-// Workgroup: 128 (k) x 128 (c) outputs of ONE tap over a range of pixels, 4 wavefronts x (64 x 64); grid = (k tiles x c tiles,
+// Workgroup: 128 (k) x 128 (c) outputs of ONE tap over a range of pixels, 4 wavefronts x (64 x 64), 48 KiB of LDS (two workgroups
+// per CU); grid = (k tiles x c tiles,
 // taps, pixel splits); partial sums go to slabs [split][tap][K][C] -- the layout of wgrad.hip, summed and transposed into the
 // torch layout by stem_unpack_wgrads_multi.  The tap's shift is applied when the x rows are fetched (rows outside the image read
 // as zeros through the range-checked buffer loads).
