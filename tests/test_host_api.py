@@ -405,3 +405,28 @@ def test_masked_conv_mask_layouts():
     assert torch.equal(a3, torch.tensor([[1, 1, 1], [1, 0, 0], [0, 0, 0]], dtype=torch.float32))
     with pytest.raises(ValueError):
         MaskedConv2d(1, 1, 3, mask_type="C")
+
+
+def test_bf16_planes_views_and_engine_routing_table():
+    """Host logic of the bf16 route (no device work): channel views of a planes tensor (32-aligned, same storage and pitch), and which
+    layers of the full-size STEM model the engine sends to the bf16 kernels: forward / input gradient of the stride-1 unmasked
+    convolutions, weight gradient of every stride-1 convolution (the masked context model included), nothing for the stride-2
+    and transposed layers."""
+    import torch
+    from spatiotemporalentropymodel_amd import functional as F
+    from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel_Res
+    data = torch.zeros(2 * 4 * 4 * (160 // 32) * 192, dtype=torch.uint8)
+    p = F.Bf16Planes(data, (2, 160, 4, 4))
+    assert p.dense and p.pix_bytes == 5 * 192
+    v = p.channels(32, 128)
+    assert v.shape == (2, 96, 4, 4) and v.pix_bytes == p.pix_bytes and v.byte_offset == 192 and not v.dense
+    assert v.channels(32, 64).byte_offset == 2 * 192 and v.data is data
+    for bad in ((16, 80), (0, 200), (64, 64)):
+        with pytest.raises(ValueError):
+            p.channels(*bad)
+    eng = SpatioTemporalPriorModel_Res().engine()
+    fwd = {n: l.bx6 for n, l in zip(("HE0", "HE2", "HE4", "HD0", "HD2", "HD4", "TPM0", "TPM2", "TPM4", "CTX", "EPM0", "EPM2", "EPM4"), eng.layers)}
+    wg = {n: l.wg6 for n, l in zip(fwd, eng.layers)}
+    assert fwd == {"HE0": True, "HE2": False, "HE4": False, "HD0": False, "HD2": False, "HD4": True, "TPM0": True, "TPM2": True, "TPM4": True,
+                   "CTX": False, "EPM0": True, "EPM2": True, "EPM4": True}
+    assert wg == dict(fwd, CTX=True)
