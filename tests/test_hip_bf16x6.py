@@ -114,6 +114,7 @@ def test_analysis_transform_chain_vs_golden_and_fp32_kernels(F, golden, monkeypa
     orig = F.conv2d_bf16x6_fwd
     monkeypatch.setattr(F, "conv2d_bf16x6_fwd", lambda *a, **k: (calls.append(a[0].shape), orig(*a, **k))[1])
     monkeypatch.setattr(L, "_BF16X6_MIN_PIXELS", 0)
+    monkeypatch.setenv("STEM_BF16X6", "1")             # whatever the suite was started with
     with torch.no_grad():
         y0, _ = imodel.getY(frames[0])
         y1, _ = imodel.getY(frames[1])
@@ -134,6 +135,7 @@ def test_chain_is_selected_at_the_bench_size_and_not_under_autograd(F, monkeypat
     imodel = models["mbt2018"](quality=4).cuda().eval()
     x = torch.rand(16, 3, 256, 256, device="cuda")
     seen = []
+    monkeypatch.setenv("STEM_BF16X6", "1")             # whatever the suite was started with
     orig6, orig4 = F.conv2d_bf16x6_fwd, F.conv2d_fwd_c4_gdn_planes
     monkeypatch.setattr(F, "conv2d_bf16x6_fwd", lambda *a, **k: (seen.append(("bx6", a[0].shape, k.get("planes_out"))), orig6(*a, **k))[1])
     monkeypatch.setattr(F, "conv2d_fwd_c4_gdn_planes", lambda *a, **k: (seen.append(("c4",)), orig4(*a, **k))[1])
@@ -147,7 +149,7 @@ def test_chain_is_selected_at_the_bench_size_and_not_under_autograd(F, monkeypat
         y32 = imodel.g_a(x)
     assert_close(host(y), host(y32), what="g_a at B=16, bf16 chain vs fp32-MFMA kernels", floor=0.1)
     assert float((y - y32).abs().max()) <= 1e-5 * float(y32.abs().max())          # measured: 2.7e-6 of the largest latent
-    monkeypatch.delenv("STEM_BF16X6")
+    monkeypatch.setenv("STEM_BF16X6", "1")
     n = len(seen)
     y_grad = imodel.g_a(x)
     assert len(seen) == n and y_grad.requires_grad
