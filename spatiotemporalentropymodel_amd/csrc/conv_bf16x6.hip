@@ -372,8 +372,10 @@ constexpr int GB_PLANE = GBN * 64, GB_BUF = 3 * GB_PLANE;            // 24576
 constexpr int GTP = GBN + 4;                                         // fp32 pitch of the epilogue tile
 constexpr int GLDS = 2 * (GA_BUF + GB_BUF) + 32 * 4;                 // 73856 (the 64 x 132 float epilogue tile reuses the front)
 
+template <int NP>       // products kept per fp32 product: 6 (default), 4 or 3 (measurement switches, two planes read)
 __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a)
 {
+    constexpr int PL = NP == 6 ? 3 : 2, BPC = PL * 2;          // planes read; 16-byte weight pieces per thread and chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *As = smem;                        // [2][3][64][64 B]
     unsigned char *Bs = smem + 2 * GA_BUF;           // [2][3][128][64 B]
@@ -411,21 +413,21 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.xp), 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wp), 0, a.wbytes, 0x00020000);
 
-    f32x4 raA[3], rbA[6], raB[3], rbB[6];
-    auto gload = [&](int t, int kc, int q, f32x4 (&ra)[3], f32x4 (&rb)[6]) {
+    f32x4 raA[PL], rbA[BPC], raB[PL], rbB[BPC];
+    auto gload = [&](int t, int kc, int q, f32x4 (&ra)[PL], f32x4 (&rb)[BPC]) {
         const int tA = __builtin_amdgcn_readfirstlane(tapi[t]), sA = kc * 192, sB = (wbase + q) * GB_BUF;
         const int mk = __builtin_amdgcn_sbfe((int)pmask, (unsigned)t, 1u);
         const int off = ((pb + tA) & mk) | (OOR & ~mk);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) ra[pl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off + pl * 64, sA, 0));
+        for (int pl = 0; pl < PL; ++pl) ra[pl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off + pl * 64, sA, 0));
 #pragma unroll
-        for (int j = 0; j < 6; ++j) rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, tid * 16 + j * 4096, sB, 0));
+        for (int j = 0; j < BPC; ++j) rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, tid * 16 + j * 4096, sB, 0));
     };
-    auto sstore = [&](int buf, f32x4 (&ra)[3], f32x4 (&rb)[6]) {
+    auto sstore = [&](int buf, f32x4 (&ra)[PL], f32x4 (&rb)[BPC]) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<f32x4 *>(As + buf * GA_BUF + pl * GA_PLANE + a_st) = ra[pl];
+        for (int pl = 0; pl < PL; ++pl) *reinterpret_cast<f32x4 *>(As + buf * GA_BUF + pl * GA_PLANE + a_st) = ra[pl];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4 *>(Bs + buf * GB_BUF + j * 4096 + tid * 16) = rb[j];
+        for (int j = 0; j < BPC; ++j) *reinterpret_cast<f32x4 *>(Bs + buf * GB_BUF + j * 4096 + tid * 16) = rb[j];
     };
 
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
@@ -440,24 +442,26 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     int pf_q = 0, pf_t = 0, pf_kc = 0;
-    auto step = [&](int cur, f32x4 (&ra)[3], f32x4 (&rb)[6]) {
+    auto step = [&](int cur, f32x4 (&ra)[PL], f32x4 (&rb)[BPC]) {
         const unsigned char *Ab = As + cur * GA_BUF + rdA, *Bb = Bs + cur * GB_BUF + rdB;
         const int t = __builtin_amdgcn_readfirstlane(pf_t), kc = __builtin_amdgcn_readfirstlane(pf_kc), q = __builtin_amdgcn_readfirstlane(pf_q);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int pk = ks ? pk1 : pk0;
-            bf16x8 af[3], bf[3][2];
+            bf16x8 af[PL], bf[PL][2];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const bf16x8 *>(Ab + pl * GA_PLANE + pk);
+            for (int pl = 0; pl < PL; ++pl) af[pl] = *reinterpret_cast<const bf16x8 *>(Ab + pl * GA_PLANE + pk);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
+            for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8 *>(Bb + pl * GB_PLANE + j * 32 * 64 + pk);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0][j], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2][j], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1][j], acc[j], 0, 0, 0);
+                if constexpr (NP == 6) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PL - 1], bf[0][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[PL - 1][j], acc[j], 0, 0, 0);
+                }
+                if constexpr (NP >= 4) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1][j], acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0][j], acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1][j], acc[j], 0, 0, 0);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0][j], acc[j], 0, 0, 0);
@@ -814,6 +818,8 @@ STEM_EXPORT int stem_conv2d_bf16x6_fwd(const void *xp, const void *wp, const flo
         (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
         (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
         (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
         const char *e = getenv("STEM_BF16_PRODUCTS");
         if (e) nprod = atoi(e);
         attr_done = true;
@@ -824,7 +830,11 @@ STEM_EXPORT int stem_conv2d_bf16x6_fwd(const void *xp, const void *wp, const flo
     hipStream_t st = (hipStream_t)stream;
     // 128-pixel tiles (8 wavefronts) when they fill the 256 CUs at least once, 64-pixel tiles (4 wavefronts) below that
     const bool small = (cdiv(M, 128) < 256 && !(a.exper & 2)) || (a.exper & 4);
-    if (small && np_now == 6)
+    if (small && np_now == 3)
+        hipLaunchKernelGGL((conv_bf16x6_kernel<64, 3>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
+    else if (small && np_now == 4)
+        hipLaunchKernelGGL((conv_bf16x6_kernel<64, 4>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
+    else if (small)
         hipLaunchKernelGGL((conv_bf16x6_kernel<64, 6>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
     else if (np_now == 3)
         hipLaunchKernelGGL((conv_bf16x6_kernel<128, 3>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
@@ -950,10 +960,19 @@ STEM_EXPORT int stem_conv2d_bf16x6_gen_fwd(const void *xp, int xpix, const void 
     }
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_gen_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_gen_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_gen_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
         attr_done = true;
     }
-    hipLaunchKernelGGL(conv_bf16x6_gen_kernel, dim3(cdiv(M, GBM), ntn, a.nsplit), dim3(GNT), GLDS, (hipStream_t)stream, a);
+    static const int nprod = getenv("STEM_BF16_PRODUCTS") ? atoi(getenv("STEM_BF16_PRODUCTS")) : 6;       // measurement switch
+    const dim3 grid(cdiv(M, GBM), ntn, a.nsplit);
+    if (nprod == 3)
+        hipLaunchKernelGGL(conv_bf16x6_gen_kernel<3>, grid, dim3(GNT), GLDS, (hipStream_t)stream, a);
+    else if (nprod == 4)
+        hipLaunchKernelGGL(conv_bf16x6_gen_kernel<4>, grid, dim3(GNT), GLDS, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(conv_bf16x6_gen_kernel<6>, grid, dim3(GNT), GLDS, (hipStream_t)stream, a);
     STEM_LAUNCH_CHECK("stem_conv2d_bf16x6_gen_fwd");
     return 0;
 }

@@ -55,8 +55,10 @@ __device__ inline bf16x8 tr_frag(const unsigned char *base, int a0, int a1)
     return __builtin_bit_cast(bf16x8, v);
 }
 
+template <int NP>       // products kept per fp32 product: 6 (default), 4 or 3 (measurement switches, two planes read)
 __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
 {
+    constexpr int PL = NP == 6 ? 3 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *As = smem;                        // [2][3][16 px][256 B]   dy
     unsigned char *Bs = smem + 2 * OP_BUF;           // [2][3][16 px][256 B]   x (shifted by the tap)
@@ -79,8 +81,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.xp), 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.dyp), 0, a.dybytes, 0x00020000);
 
-    f32x4 raA[3], rbA[3], raB[3], rbB[3];
-    auto gload = [&](int q, f32x4 (&ra)[3], f32x4 (&rb)[3]) {
+    f32x4 raA[PL], rbA[PL], raB[PL], rbB[PL];
+    auto gload = [&](int q, f32x4 (&ra)[PL], f32x4 (&rb)[PL]) {
         const int m = q * PX + srow;
         const bool ok = m < M;
         const int mm = ok ? m : 0;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
         const int offa = (ok && ka_ok) ? m * a.dypix + a_col : OOR;
         const int offb = (ok && cb_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? ((b * a.H + iy) * a.W + ix) * a.xpix + b_col : OOR;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < PL; ++pl) {
             ra[pl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, offa + pl * 64, 0, 0));
             rb[pl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, offb + pl * 64, 0, 0));
         }
@@ -98,15 +100,16 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
     // its way to LDS; they add the three planes up again (exact) and keep per-thread column sums of their 8 channels
     const bool do_bias = a.bias_part != nullptr && tap == 0 && tc == 0;
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto sstore = [&](int buf, f32x4 (&ra)[3], f32x4 (&rb)[3], bool fresh) {       // fresh: not a clamped repeat of the last chunk
+    auto sstore = [&](int buf, f32x4 (&ra)[PL], f32x4 (&rb)[PL], bool fresh) {       // fresh: not a clamped repeat of the last chunk
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < PL; ++pl) {
             *reinterpret_cast<f32x4 *>(As + buf * OP_BUF + pl * PLANE + st0) = ra[pl];
             *reinterpret_cast<f32x4 *>(Bs + buf * OP_BUF + pl * PLANE + st0) = rb[pl];
         }
         if (do_bias && fresh) {
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 w0 = __builtin_bit_cast(u32x4, ra[0]), w1 = __builtin_bit_cast(u32x4, ra[1]), w2 = __builtin_bit_cast(u32x4, ra[2]);
+            const u32x4 w0 = __builtin_bit_cast(u32x4, ra[0]), w1 = __builtin_bit_cast(u32x4, ra[1]);
+            const u32x4 w2 = PL == 3 ? __builtin_bit_cast(u32x4, ra[PL - 1]) : u32x4{0u, 0u, 0u, 0u};
             auto lo = [](unsigned u) { return __builtin_bit_cast(float, u << 16); };
             auto hi = [](unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); };
             bsum[0] += (lo(w0.x) + lo(w1.x)) + lo(w2.x);
@@ -144,13 +147,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto step = [&](int cur, f32x4 (&ra)[3], f32x4 (&rb)[3], int qcur, int qn) {
+    auto step = [&](int cur, f32x4 (&ra)[PL], f32x4 (&rb)[PL], int qcur, int qn) {
         const unsigned char *Ab = As + cur * OP_BUF, *Bb = Bs + cur * OP_BUF;
-        bf16x8 af[2][3], bf[2][3];
+        bf16x8 af[2][PL], bf[2][PL];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < PL; ++pl) {
                 af[t][pl] = tr_frag(Ab + pl * PLANE, adr[0][t][0], adr[0][t][1]);
                 bf[t][pl] = tr_frag(Bb + pl * PLANE, adr[1][t][0], adr[1][t][1]);
             }
@@ -158,9 +161,11 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                if constexpr (NP == 6) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PL - 1], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][PL - 1], acc[i][j], 0, 0, 0);
+                }
+                if constexpr (NP >= 4) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
@@ -275,10 +280,19 @@ STEM_EXPORT int stem_conv2d_wgrad_bf16x6(const void *xp, int xpix, const void *d
         }
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)wgrad_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)wgrad_bf16x6_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)wgrad_bf16x6_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)wgrad_bf16x6_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL(wgrad_bf16x6_kernel, dim3(cdiv(K, TK) * cdiv(C, TC), R * S, splits), dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+    static const int nprod = getenv("STEM_BF16_PRODUCTS") ? atoi(getenv("STEM_BF16_PRODUCTS")) : 6;       // measurement switch
+    const dim3 grid(cdiv(K, TK) * cdiv(C, TC), R * S, splits);
+    if (nprod == 3)
+        hipLaunchKernelGGL(wgrad_bf16x6_kernel<3>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+    else if (nprod == 4)
+        hipLaunchKernelGGL(wgrad_bf16x6_kernel<4>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(wgrad_bf16x6_kernel<6>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
     STEM_LAUNCH_CHECK("stem_conv2d_wgrad_bf16x6");
     return 0;
 }
