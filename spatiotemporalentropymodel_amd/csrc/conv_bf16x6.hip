@@ -915,7 +915,8 @@ STEM_EXPORT size_t stem_conv2d_bf16x6_gen_workspace_bytes(int B, int H, int W, i
     const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
     if (OH < 1 || OW < 1 || C % 32) return 0;
     const int M = B * OH * OW, tiles = cdiv(M, GBM) * cdiv(N, GBN), nchunks = (C / 32) * R * S;
-    const int s = gen_split(tiles, nchunks);
+    int s = gen_split(tiles, nchunks);
+    while (s > 1 && (size_t)s * M * cdiv(N, GBN) * GBN * sizeof(float) >= 0x7FFFFF00ull) --s;
     return s > 1 ? kGenCntBytes + (size_t)s * M * cdiv(N, GBN) * GBN * sizeof(float) : 0;
 }
 
@@ -936,7 +937,7 @@ STEM_EXPORT int stem_conv2d_bf16x6_gen_fwd(const void *xp, int xpix, const void 
     STEM_CHECK_ARG(xpix >= (C / 32) * 192 && xpix % 192 == 0, "stem_conv2d_bf16x6_gen_fwd: xpix must be a multiple of 192 bytes covering C channels");
     const size_t xb = (size_t)B * H * W * xpix, wb = stem_bf16x3_conv_weight_gen_bytes(N, C, R, S);
     const int M = B * OH * OW, ntn = cdiv(N, GBN), tiles = cdiv(M, GBM) * ntn, nchunks = (C / 32) * R * S;
-    STEM_CHECK_ARG(xb < 0x7FFFFF00ull && wb < 0x7FFFFF00ull && (size_t)M * ntn * GBN * 4 * 16 < 0x7FFFFF00ull,
+    STEM_CHECK_ARG(xb < 0x7FFFFF00ull && wb < 0x7FFFFF00ull && (size_t)M * ntn * GBN * 4 < 0x7FFFFF00ull,
                    "stem_conv2d_bf16x6_gen_fwd: operand views must stay below 2 GiB (split the batch)");
     Bx6Args a;
     memset(&a, 0, sizeof(a));
@@ -949,6 +950,7 @@ STEM_EXPORT int stem_conv2d_bf16x6_gen_fwd(const void *xp, int xpix, const void 
             a.dx[r * S + s] = (signed char)(s - pad);
         }
     int split = gen_split(tiles, nchunks);
+    while (split > 1 && (size_t)split * M * ntn * GBN * sizeof(float) >= 0x7FFFFF00ull) --split;      // the slabs are read through one buffer view
     const size_t need = kGenCntBytes + (size_t)split * M * ntn * GBN * sizeof(float);
     if (split > 1 && (!ws || ws_bytes < need || (size_t)tiles * sizeof(int) > kGenCntBytes)) split = 1;      // no workspace: unsplit, same result up to summation order
     a.nsplit = split;

@@ -460,14 +460,27 @@ def _bf16x6_eligible(m, in_shape):
     if not (type(m) is Conv2d and not m._masked and m.in_channels % 32 == 0 and m.out_channels <= 192
             and m.kernel_size * m.kernel_size <= 25 and m.weight.is_cuda):
         return False
+    return _bf16x6_shape_ok(m, in_shape)
+
+
+def _bf16x6_shape_ok(m, in_shape):
     B, _, H, W = in_shape
     Ho, Wo = F.conv_out_hw(H, W, m.kernel_size, m.kernel_size, m.stride, m.padding)
+    if not (_planes_fit(B * H * W, m.in_channels) and _planes_fit(B * Ho * Wo, m.out_channels)):
+        return False          # the kernels address their operands through 2 GiB buffer views: such a batch stays on the fp32 kernels
     return B * Ho * Wo >= _BF16X6_MIN_PIXELS
 
 
-def _bf16x6_gen_eligible(m, follows_gdn):
+def _planes_fit(npix, channels):
+    """does a planes tensor of this size (6 bytes per element) stay inside one 2 GiB buffer view?"""
+    return npix * ((channels + 31) // 32) * 192 < 0x7FFFFF00
+
+
+def _bf16x6_gen_eligible(m, follows_gdn, in_shape=None):
     """Small layers that end a planes chain (the last convolution of the analysis transform: 4096 output pixels at the bench
     size) go to the general split-K kernel, which has no fused GDN."""
+    if in_shape is not None and not _planes_fit(in_shape[0] * in_shape[2] * in_shape[3], m.in_channels):
+        return False
     return (type(m) is Conv2d and not m._masked and not follows_gdn and m.in_channels % 32 == 0 and m.out_channels % 4 == 0
             and m.kernel_size * m.kernel_size <= 25 and m.weight.is_cuda)
 
@@ -518,7 +531,7 @@ class FusedSequential(nn.Sequential):
                 chain = False
                 if K % 32 == 0 and j < len(mods) and mods[j].__class__ is Conv2d and mods[j].in_channels == K:
                     nxt_gdn = j + 1 < len(mods) and isinstance(mods[j + 1], GDN)
-                    chain = _bf16x6_eligible(mods[j], out_shape) or _bf16x6_gen_eligible(mods[j], nxt_gdn)
+                    chain = _bf16x6_eligible(mods[j], out_shape) or _bf16x6_gen_eligible(mods[j], nxt_gdn, out_shape)
                 if (chain and gdn is not None and m.in_channels == 3 and not isinstance(x, F.Bf16Planes) and F.nhwc_ld(x) is None
                         and K <= 192):
                     wp = m._packs.get(m.weight, F.PACK_CONV_FWD_C4)

@@ -302,3 +302,17 @@ def test_weight_gradient_from_channel_views(F):
     ref = orc.conv2d_bwd(np.ascontiguousarray(xb[:, 32:96]), np.zeros((96, 64, 3, 3), np.float32), np.ascontiguousarray(dyb[:, 64:160]), 1, 1,
                          need_dx=False)[1]
     assert_close(host(dw), ref, what="wgrad from views", floor=0.1)
+
+
+def test_gen_kernel_at_eight_full_hd_sequences(F):
+    """The entropy-parameter network's first layer shape when 8 full-HD sequences are coded side by side (65280 latent pixels,
+    768 outputs): the split-K slabs must be sized by the split actually used (an earlier bound assumed 16 and refused the call);
+    checked against the fp32-MFMA kernel."""
+    B, C, H, W, K = 8, 512, 68, 120, 768
+    torch.manual_seed(1)
+    x = torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = torch.randn(K, C, 1, 1, device="cuda") / C ** 0.5
+    b = torch.randn(K, device="cuda") * 0.1
+    y, _ = F.conv2d_bf16x6_gen(F.Bf16Planes.split(x), F.pack_weight_bf16x3_gen(w), b, K, 1, 1, 1, 0, epi=F.GEN_EPI_LRELU, slope=0.01)
+    y32 = F.conv2d_fwd(x, F.pack_weight(w, F.PACK_CONV_FWD), b, K, 1, 1, 1, 0, F.ACT_LRELU, slope=0.01)
+    assert_close(host(y), host(y32), what="gen kernel, 65280 pixels x 768 channels", floor=0.1)

@@ -430,3 +430,15 @@ def test_bf16_planes_views_and_engine_routing_table():
     assert fwd == {"HE0": True, "HE2": False, "HE4": False, "HD0": False, "HD2": False, "HD4": True, "TPM0": True, "TPM2": True, "TPM4": True,
                    "CTX": False, "EPM0": True, "EPM2": True, "EPM4": True}
     assert wg == dict(fwd, CTX=True)
+
+
+def test_bf16_chain_is_not_selected_when_planes_exceed_a_buffer_view():
+    """4 full-HD frames per call are fine for the fp32 kernels (1.6 GB activations) but their planes would be 2.4 GB: the chain
+    must not start (the kernels address operands through 2 GiB views); 3 frames fit."""
+    from spatiotemporalentropymodel_amd import layers as L
+    from spatiotemporalentropymodel_amd.zoo import models
+    conv1 = models["mbt2018"](quality=4).g_a[2]
+    assert L._bf16x6_shape_ok(conv1, (3, 192, 544, 960))
+    assert not L._bf16x6_shape_ok(conv1, (4, 192, 544, 960))
+    assert L._planes_fit(3 * 544 * 960, 192) and not L._planes_fit(4 * 544 * 960, 192)
+    assert not L._bf16x6_shape_ok(conv1, (1, 192, 32, 32))          # too few output pixels for the 192-wide kernel
