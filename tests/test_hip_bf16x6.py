@@ -316,3 +316,14 @@ def test_gen_kernel_at_eight_full_hd_sequences(F):
     y, _ = F.conv2d_bf16x6_gen(F.Bf16Planes.split(x), F.pack_weight_bf16x3_gen(w), b, K, 1, 1, 1, 0, epi=F.GEN_EPI_LRELU, slope=0.01)
     y32 = F.conv2d_fwd(x, F.pack_weight(w, F.PACK_CONV_FWD), b, K, 1, 1, 1, 0, F.ACT_LRELU, slope=0.01)
     assert_close(host(y), host(y32), what="gen kernel, 65280 pixels x 768 channels", floor=0.1)
+
+
+def test_random_shapes_through_all_three_kernels():
+    """tools/debug/bf16x6_fuzz.py: 40 random (batch, size, channels, kernel, stride) combinations through the analysis-transform
+    kernel (+ GDN), the general kernel (forward, input gradient) and the weight-gradient kernel (+ bias gradient) against float64
+    torch references; every planes output must equal its fp32 twin."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "debug", "bf16x6_fuzz.py"), "40", "7"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    worst = float(out.stdout.strip().splitlines()[-1].split(":")[1])
+    assert worst <= 1e-5, out.stdout[-3000:]
