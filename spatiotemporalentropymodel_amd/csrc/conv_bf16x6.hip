@@ -820,7 +820,8 @@ STEM_EXPORT int stem_conv2d_bf16x6_fwd(const void *xp, const void *wp, const flo
         (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
         (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
         (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
-        const char *e = getenv("STEM_BF16_PRODUCTS");
+        // STEM_BF16_PRODUCTS: all bf16 kernels; STEM_GA_BF16_PRODUCTS: this kernel (the frozen, inference-only analysis transform) alone
+        const char *e = getenv("STEM_GA_BF16_PRODUCTS") ? getenv("STEM_GA_BF16_PRODUCTS") : getenv("STEM_BF16_PRODUCTS");
         if (e) nprod = atoi(e);
         attr_done = true;
     }
