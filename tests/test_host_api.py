@@ -442,3 +442,12 @@ def test_bf16_chain_is_not_selected_when_planes_exceed_a_buffer_view():
     assert not L._bf16x6_shape_ok(conv1, (4, 192, 544, 960))
     assert L._planes_fit(3 * 544 * 960, 192) and not L._planes_fit(4 * 544 * 960, 192)
     assert not L._bf16x6_shape_ok(conv1, (1, 192, 32, 32))          # too few output pixels for the 192-wide kernel
+
+
+def test_planes_byte_count_matches_the_library():
+    """Bf16Planes.empty sizes its storage in Python (hot path); the C ABI's stem_bf16x3_planes_bytes is the definition."""
+    from spatiotemporalentropymodel_amd import _lib
+    lib = _lib.hip()
+    for npix, C in ((1, 32), (4096, 192), (65280, 1152), (7, 96)):
+        assert lib.stem_bf16x3_planes_bytes(npix, C) == npix * (C // 32) * 192
+    assert lib.stem_bf16x3_planes_bytes(10, 48) == 0
