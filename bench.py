@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N rank processes (launch_ranks:
+plain child processes with torch.distributed.run's environment contract, started before this process has made any GPU call)
+and relays rank 0's JSON line; with more ranks than GPUs (the one-GPU test box) the ranks share devices and exchange through
+gloo instead of RCCL (distributed.init_from_env).
+
 One "step" = one pass of the hot path over one batch of 16 synthetic septuplets per GPU (configs[1]):
 7x I-frame analysis transform g_a (getY) + 6 P-frame optimisation steps of SpatioTemporalPriorModel_Res(256,192)
 (forward, EMLoss, backward, [RCCL all-reduce], fused clip+Adam, aux loss + aux Adam) = the loop body of
@@ -213,7 +218,7 @@ def bench_roi(args):
         m.entropy_bottleneck.noise_seed = m.gaussian_conditional.noise_seed = D.shard_seed(1234 + 100 * i, rank)
     a = types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3)
     opts = configure_optimizers(imodel, a, max_norm=None) + configure_optimizers(pmodel, a, max_norm=None)
-    acc = D.GopGradAccumulator([opts[0].flat, opts[2].flat], [opts[1].flat, opts[3].flat]) if world > 1 else None
+    acc = D.GopGradAccumulator([opts[0].flat, opts[2].flat], [opts[1].flat, opts[3].flat]) if D.dist.is_initialized() else None
     frames = synthetic_septuplet(B, SIZE, D.shard_seed(1234, rank), dev)
     levels = (0.30, 0.45, 0.55, 0.70)
     qmap = torch.cat([torch.full((B // 4, 1, SIZE, SIZE), q) for q in levels]).to(dev)
@@ -249,6 +254,67 @@ def bench_roi(args):
                      "flop_per_launch": flop, "avg_launch_ms": kern_ms, "launches_timed": len(probe), "traffic": None}}))
 
 
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` typed without a launcher: start the N ranks here.  This parent never touches the GPU (no HIP call,
+    no torch.cuda query): it only spawns `python bench.py <same arguments>` N times with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set (children are fresh processes, nothing is exec'ed over a GPU-initialised one), forwards
+    rank 0's stdout (the ONE JSON line), sends the other ranks' output to stderr, and returns non-zero if any rank failed --
+    the remaining ranks are then terminated by PID so that a dead peer cannot leave the others hanging in a collective."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    rc, pending = 0, set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()
+        if pending:
+            time.sleep(0.05)
+    out = procs[0].stdout.read().decode()              # rank 0 prints one line at the very end: the pipe cannot fill up before
+    for line in out.splitlines():                      # stdout carries the JSON line only (gloo / RCCL banners go to stderr)
+        print(line, file=sys.stdout if line.lstrip().startswith("{") else sys.stderr)
+    sys.stdout.flush()
+    if rc == 0 and not any(line.lstrip().startswith("{") for line in out.splitlines()):
+        print("bench.py: rank 0 finished without a result line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+def rendezvous_only(args):
+    """--rendezvous-only: the distributed plumbing of a run without the workload -- process group from the environment, one
+    sum all-reduce through distributed.all_reduce_sum_ (device tensor when there is a GPU), the max-over-ranks reduction
+    the timing uses, a barrier; rank 0 prints one JSON line.  This is what the CPU test of the launcher runs (gloo)."""
+    import torch.distributed as dist
+    from spatiotemporalentropymodel_amd import distributed as D
+    rank, world, local = D.init_from_env()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local) if torch.cuda.is_available() else torch.device("cpu")
+    t = torch.full((1 << 16,), float(rank + 1), device=dev)
+    D.all_reduce_sum_(t)
+    slowest = D.max_over_ranks(float(rank), dev)
+    D.barrier()
+    if rank == 0:
+        print(json.dumps({"rendezvous": "ok", "n_gpus": world, "backend": dist.get_backend() if dist.is_initialized() else None,
+                          "device": str(dev), "all_reduce_sum": float(t[0]), "expected_sum": world * (world + 1) / 2,
+                          "max_over_ranks": slowest}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,7 +331,13 @@ def main():
                     "calls (selfcheck.p_frame_step) instead of the explicit fused schedule (trainer.FusedPFrameStep)")
     ap.add_argument("--graph", action="store_true", help="replay the P-frame step from its hipGraph (graphs.GraphedPFrameStep) instead of "
                     "issuing it kernel by kernel: 2 ms instead of 11-22 ms of host time per step, same GPU time (DESIGN.md §7)")
+    ap.add_argument("--rendezvous-only", action="store_true", help="set up the ranks, run one all-reduce and the timing reduction, exit "
+                    "(launcher / process-group check without the workload; works without a GPU)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.rendezvous_only:
+        return rendezvous_only(args)
     if args.config == "roi":
         return bench_roi(args)
 
@@ -294,7 +366,8 @@ def main():
         m.noise_seed = seed * 7919 + id(m) % 1000
     opt, aux_opt = configure_optimizers(stem, types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3))
     # gradient slices are all-reduced (RCCL, side stream) as backward finishes each module group
-    reducer = D.OverlappedGradReducer(opt.flat).attach(stem.engine()) if world > 1 else None
+    # (also at world size 1 when STEM_DIST_SINGLE=1 created a one-rank RCCL group: same calls, same stream ordering)
+    reducer = D.OverlappedGradReducer(opt.flat).attach(stem.engine()) if D.dist.is_initialized() else None
     crit = EMLoss()
     frames = synthetic_septuplet(BATCH, SIZE, seed, dev)
 

@@ -21,16 +21,25 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torch.distributed.run contract)."""
+def init_from_env(backend=None, single=None):
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torch.distributed.run contract).
+
+    Backend: STEM_DIST_BACKEND, else RCCL ("nccl") when every rank has a GPU of its own, else gloo -- RCCL refuses two
+    ranks on one device, so WORLD_SIZE > device count (the one-GPU test box, the CPU tests) exchanges through the host
+    (`all_reduce_sum_`).  `single` (or STEM_DIST_SINGLE=1) creates the process group at world size 1 as well, so that a
+    one-GPU box executes the very RCCL calls, stream ordering and reducer bookkeeping of a multi-rank run."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if torch.cuda.is_available() and local >= torch.cuda.device_count():
-        local = local % torch.cuda.device_count()      # more ranks than GPUs (single-GPU test box): share devices
-    if world > 1 and not dist.is_initialized():
+    ndev = torch.cuda.device_count()                   # counting devices does not initialise the GPU
+    shared = ndev > 0 and world > ndev
+    if shared:
+        local = local % ndev                           # more ranks than GPUs (single-GPU test box): share devices
+    if single is None:
+        single = os.environ.get("STEM_DIST_SINGLE", "0") == "1"
+    if (world > 1 or single) and not dist.is_initialized():
         if backend is None:
-            backend = os.environ.get("STEM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+            backend = os.environ.get("STEM_DIST_BACKEND") or ("nccl" if ndev > 0 and not shared else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -51,7 +60,7 @@ def all_reduce_sum_(t: torch.Tensor):
     if not t.is_cuda or dist.get_backend() != "gloo":
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return
-    key = (t.device, t.numel() > (1 << 22))
+    key = (t.device, t.dtype, t.numel() > (1 << 22))
     host = _HOST_STAGE.get(key)
     if host is None or host.numel() < t.numel():
         host = _HOST_STAGE[key] = torch.empty(max(t.numel(), 1 << 16), dtype=t.dtype).pin_memory()
@@ -91,6 +100,7 @@ class FlatGradReducer:
         step = (step + 3) // 4 * 4
         self.ranges = [(s, min(n, s + step)) for s in range(0, n, step)]
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.active = dist.is_initialized()            # a world-size-1 group still runs its collectives (init_from_env(single=True))
         self._stream = torch.cuda.Stream() if flat_grad.is_cuda else None
 
     @property
@@ -100,7 +110,7 @@ class FlatGradReducer:
     def all_reduce(self):
         """Call after backward and before the optimiser step.  Returns once the reduced gradient is
         ordered before subsequent work on the current stream."""
-        if self.world == 1:
+        if not self.active:
             return
         if self._stream is None:                       # CPU / gloo
             for s, e in self.ranges:
@@ -126,6 +136,7 @@ class OverlappedGradReducer:
     def __init__(self, flat):
         self.flat = flat
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.active = dist.is_initialized()
         self._off = {id(p): (o, p.numel()) for p, o in zip(flat.params, flat.offsets)}
         self._stream = torch.cuda.Stream() if flat.grad.is_cuda else None
         self._done = []            # [lo, hi) slices exchanged since the last finish()
@@ -158,7 +169,7 @@ class OverlappedGradReducer:
             hi = min(hi, self.flat.grad.numel())
             self._done.append((lo, hi))
             self.calls += 1
-            if self.world == 1:
+            if not self.active:
                 continue
             g = self.flat.grad[lo:hi]
             if self._stream is None:
@@ -213,6 +224,7 @@ class GopGradAccumulator:
     def __init__(self, exchanged, local=()):
         self.exchanged, self.local = list(exchanged), list(local)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.active = dist.is_initialized()
         self.sums = {id(f): torch.zeros_like(f.grad) for f in self.exchanged + self.local}
 
     def running(self, flat):
@@ -234,7 +246,7 @@ class GopGradAccumulator:
 
     def end_frame(self):
         for f in self.exchanged:
-            if self.world > 1:
+            if self.active:
                 all_reduce_sum_(f.grad)
             self._fold(f, 1.0 / self.world)
 
@@ -245,7 +257,7 @@ class GopGradAccumulator:
     def any_rank(self, flag: bool) -> bool:
         """Logical OR of a host-side flag over all ranks (one tiny MAX all-reduce): collective control-flow decisions
         such as the "skip this GOP" break must be taken by every rank or by none."""
-        if self.world == 1:
+        if not self.active:
             return bool(flag)
         dev = self.exchanged[0].grad.device if self.exchanged and dist.get_backend() != "gloo" else torch.device("cpu")
         t = torch.tensor([1.0 if flag else 0.0], device=dev)

@@ -40,11 +40,12 @@ def pytest_collection_finish(session):
     env = dict(os.environ, PYTHONPATH=REPO + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
     for case in cases:                                   # one pair at a time would serialise; pairs are small, run them all
         port = _free_port()
+        world = 1 if case.startswith("rccl1_") else 2    # rccl1_*: ONE rank in a world-size-1 RCCL ("nccl") process group
         DP2["procs"][case] = [
             subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "dp_worker.py"), "--case", case, "--rank", str(r),
-                              "--world", "2", "--port", str(port), "--out", DP2["dir"]], env=env,
+                              "--world", str(world), "--port", str(port), "--out", DP2["dir"]], env=env,
                              stdout=open(os.path.join(DP2["dir"], f"{case}_rank{r}.log"), "w"), stderr=subprocess.STDOUT)
-            for r in range(2)]
+            for r in range(world)]
 
 
 def pytest_sessionfinish(session, exitstatus):
@@ -69,7 +70,7 @@ def dp2_results():
             if rc != 0:
                 log = open(os.path.join(DP2["dir"], f"{case}_rank{r}.log")).read()[-4000:]
                 pytest.fail(f"dp2 worker {case} rank {r} exited with {rc}:\n{log}")
-        return [dict(np.load(os.path.join(DP2["dir"], f"{case}_rank{r}.npz"))) for r in range(2)]
+        return [dict(np.load(os.path.join(DP2["dir"], f"{case}_rank{r}.npz"))) for r in range(len(procs))]
     return wait
 
 

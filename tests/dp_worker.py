@@ -7,7 +7,11 @@ backward -- hooks fired from StemEngine.backward on the weight-gradient stream, 
 all-reduced while the rest of backward is still queued -- on the single-GPU test box.  The parent test compares what the
 ranks dump with a single-process run over the concatenated batch.
 
-    python tests/dp_worker.py --case train|gop --rank R --world W --port P --out DIR
+    python tests/dp_worker.py --case train|train_fused|gop|rccl1_train_fused|rccl1_gop --rank R --world W --port P --out DIR
+
+The `rccl1_*` cases are ONE rank in a world-size-1 process group on the RCCL ("nccl") backend: the collectives are
+identities, but every RCCL call of the reducers, their side-stream ordering and the device-tensor reductions of bench.py
+(`max_over_ranks`, `any_rank`) execute for real -- as far as the RCCL path can go on a one-GPU box.
 """
 import argparse
 import os
@@ -96,7 +100,7 @@ def case_train(rank, world, out_dir, steps=2):
     np.savez(os.path.join(out_dir, f"train_rank{rank}.npz"), **dump)
 
 
-def case_train_fused(rank, world, out_dir, steps=2):
+def case_train_fused(rank, world, out_dir, steps=2, tag="train_fused"):
     """The same two steps through the explicit schedule bench.py times (trainer.FusedPFrameStep) with the overlapped
     reducer attached -- the code path of `bench.py --gpus N`."""
     from spatiotemporalentropymodel_amd import distributed as D
@@ -131,10 +135,13 @@ def case_train_fused(rank, world, out_dir, steps=2):
     dump["params"] = flat_np(opt.flat.data)
     dump["quantiles"] = flat_np(aux_opt.flat.data)
     dump["reducer_calls"] = np.array([red.calls])
-    np.savez(os.path.join(out_dir, f"train_fused_rank{rank}.npz"), **dump)
+    import torch.distributed as dist
+    dump["backend"] = np.array([dist.get_backend() if dist.is_initialized() else "none"])
+    dump["max_over_ranks"] = np.array([D.max_over_ranks(3.25, dev)])
+    np.savez(os.path.join(out_dir, f"{tag}_rank{rank}.npz"), **dump)
 
 
-def case_gop(rank, world, out_dir, frames_n=3):
+def case_gop(rank, world, out_dir, frames_n=3, tag="gop"):
     """One GOP iteration of the variable-rate loop (selfcheck.roi_gop_step) with GopGradAccumulator, one sample per rank."""
     from spatiotemporalentropymodel_amd import distributed as D
     from spatiotemporalentropymodel_amd import selfcheck as S
@@ -161,8 +168,9 @@ def case_gop(rank, world, out_dir, frames_n=3):
     torch.cuda.synchronize()
     dump = {"losses": np.array([[float(oc["loss"]), float(gn) if gn is not None else 0.0, float(aux)] for oc, gn, aux in log]),
             "params_i": flat_np(opt_i.flat.data), "params_p": flat_np(opt_p.flat.data),
-            "grad_i": flat_np(opt_i.flat.grad), "grad_p": flat_np(opt_p.flat.grad)}
-    np.savez(os.path.join(out_dir, f"gop_rank{rank}.npz"), **dump)
+            "grad_i": flat_np(opt_i.flat.grad), "grad_p": flat_np(opt_p.flat.grad),
+            "any_rank": np.array([acc.any_rank(False), acc.any_rank(True)]), "active": np.array([acc.active])}
+    np.savez(os.path.join(out_dir, f"{tag}_rank{rank}.npz"), **dump)
 
 
 def main():
@@ -173,11 +181,16 @@ def main():
     ap.add_argument("--port", type=int, required=True)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
+    rccl1 = a.case.startswith("rccl1_")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.port), RANK=str(a.rank), WORLD_SIZE=str(a.world),
-                      LOCAL_RANK="0", STEM_DIST_BACKEND="gloo")
+                      LOCAL_RANK="0", STEM_DIST_BACKEND="nccl" if rccl1 else "gloo")
     from spatiotemporalentropymodel_amd import distributed as D
-    D.init_from_env()
-    {"train": case_train, "train_fused": case_train_fused, "gop": case_gop}[a.case](a.rank, a.world, a.out)
+    D.init_from_env(single=rccl1)
+    if rccl1:
+        assert a.world == 1 and torch.distributed.get_backend() == "nccl"
+        {"rccl1_train_fused": case_train_fused, "rccl1_gop": case_gop}[a.case](a.rank, a.world, a.out, tag=a.case)
+    else:
+        {"train": case_train, "train_fused": case_train_fused, "gop": case_gop}[a.case](a.rank, a.world, a.out)
     D.barrier()
     torch.distributed.destroy_process_group()
 

@@ -254,3 +254,52 @@ def test_overlapped_reducer_refuses_partial_or_double_coverage():
         red.finish()
     red.reduce_params(ps)                              # state was reset by the failed finish()
     red.finish()
+
+
+def _run_bench(*argv, timeout=300):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_launches_its_own_ranks_gloo():
+    """`python bench.py --gpus 2` typed bare (the driver's N=1 command form with another N): bench.launch_ranks starts the
+    two ranks, which rendezvous (gloo here: no GPU), run one all_reduce_sum_ and the timing reduction; stdout of the parent
+    is exactly rank 0's JSON line."""
+    import json
+    p = _run_bench("--gpus", "2", "--rendezvous-only")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["rendezvous"] == "ok" and rec["n_gpus"] == 2 and rec["backend"] == "gloo"
+    assert rec["all_reduce_sum"] == rec["expected_sum"] == 3.0 and rec["max_over_ranks"] == 1.0
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """Without a GPU the workload itself refuses to run: every rank exits non-zero, and so must the launcher (no JSON line)."""
+    p = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline")
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.lstrip().startswith("{")], p.stdout
+
+
+def test_backend_choice_follows_device_count(monkeypatch):
+    """init_from_env: RCCL only when every rank has its own GPU; more ranks than devices (or no device) -> gloo."""
+    from spatiotemporalentropymodel_amd import distributed as D
+    seen = {}
+    monkeypatch.setattr(D.dist, "is_initialized", lambda: False)
+    monkeypatch.setattr(D.dist, "init_process_group", lambda backend, rank, world_size: seen.update(b=backend, r=rank, w=world_size))
+    monkeypatch.setattr(D.torch.cuda, "set_device", lambda d: seen.update(dev=d))
+    monkeypatch.delenv("STEM_DIST_BACKEND", raising=False)
+    for ndev, world, rank, want, local in ((8, 8, 5, "nccl", 5), (1, 2, 1, "gloo", 0), (0, 2, 1, "gloo", 1), (1, 1, 0, "nccl", 0)):
+        monkeypatch.setattr(D.torch.cuda, "device_count", lambda n=ndev: n)
+        monkeypatch.setenv("WORLD_SIZE", str(world)); monkeypatch.setenv("RANK", str(rank)); monkeypatch.setenv("LOCAL_RANK", str(rank))
+        seen.clear()
+        assert D.init_from_env(single=True) == (rank, world, local)
+        assert seen["b"] == want and seen["w"] == world, (ndev, world, seen)
+    # world size 1 without `single`: no process group at all
+    seen.clear()
+    monkeypatch.setenv("WORLD_SIZE", "1"); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.delenv("STEM_DIST_SINGLE", raising=False)
+    D.init_from_env()
+    assert not seen

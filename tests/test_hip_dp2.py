@@ -171,3 +171,34 @@ def test_gop_accumulator_two_ranks_equals_full_batch(dp2_results):
     # the frame-0 gradient it is compared against has been clipped from norm ~3000 to 1 before the BPTT terms are added
     assert errs[0][0] < 5e-2 and len(loose) <= 0.05 * len(errs), errs[:8]
     assert all(".qmap_feature_" in n or "qmap_feature_" in n for _, n in loose), loose
+
+
+# ---- RCCL itself, as far as one GPU allows: a world-size-1 "nccl" process group ------------------------------------------
+# RCCL refuses two ranks on one device, so the 2-rank tests above exchange through gloo.  These two run ONE rank in a real
+# RCCL group (distributed.init_from_env(single=True)): every all-reduce of the reducers is issued to RCCL on the side stream
+# with the product's wait_stream ordering, `max_over_ranks` / `any_rank` reduce DEVICE tensors -- and since a one-rank sum is
+# the identity, the run must be bit-identical to the same schedule without any process group.
+@pytest.mark.dp2("rccl1_train_fused")
+def test_rccl_world1_fused_schedule_bit_identical_to_no_process_group(dp2_results, tmp_path):
+    import dp_worker
+    (r,) = dp2_results("rccl1_train_fused")
+    assert str(r["backend"][0]) == "nccl" and int(r["reducer_calls"][0]) == 12 and float(r["max_over_ranks"][0]) == 3.25
+    assert not torch.distributed.is_initialized()
+    dp_worker.case_train_fused(0, 1, str(tmp_path), tag="local")
+    loc = dict(np.load(tmp_path / "local_rank0.npz"))
+    assert str(loc["backend"][0]) == "none"
+    for k in ("grad_avg", "params", "quantiles", "s1:loss", "s2:loss"):
+        np.testing.assert_array_equal(r[k], loc[k], err_msg=k)
+
+
+@pytest.mark.dp2("rccl1_gop")
+def test_rccl_world1_gop_accumulator_bit_identical_to_no_process_group(dp2_results, tmp_path):
+    import dp_worker
+    (r,) = dp2_results("rccl1_gop")
+    assert bool(r["active"][0]) and list(r["any_rank"]) == [False, True]
+    dp_worker.case_gop(0, 1, str(tmp_path), tag="local_gop")
+    loc = dict(np.load(tmp_path / "local_gop_rank0.npz"))
+    assert not bool(loc["active"][0])
+    np.testing.assert_array_equal(r["losses"], loc["losses"])
+    for k in ("params_i", "params_p", "grad_i", "grad_p"):
+        np.testing.assert_array_equal(r[k], loc[k], err_msg=k)
