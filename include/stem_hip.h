@@ -32,6 +32,17 @@ extern "C" {
 const char *stem_last_error(void);
 int stem_abi_version(void);
 
+/* Plan selectors for tests and sweep tools: force a tile shape / split factor that the library would otherwise choose
+ * ("bx6_tile": 0 automatic | 64 | 128 pixel workgroups of stem_conv2d_bf16x6_fwd; "bx6_split" / "wg6_split": split factor
+ * of stem_conv2d_bf16x6_gen_fwd / stem_conv2d_wgrad_bf16x6, 0 = the planner's).  Every setting computes the same
+ * contraction (summation order aside); process-wide; not for concurrent use with launches.  There is no reference
+ * counterpart (torch picks its kernels internally).  Nothing in the library reads the environment to change results:
+ * reduced-precision / ablated variants exist only in builds with -DSTEM_EXPERIMENTS, which
+ * stem_built_with_experiments() reports (0 for the shipped library).                                                  */
+int stem_tuning_set(const char *name, int value);
+int stem_tuning_get(const char *name);
+int stem_built_with_experiments(void);
+
 /* ---- weight packing ------------------------------------------------------
  * roles (what the packed copy will be multiplied with):                       */
 enum {

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-HIP_SO = os.path.join(_PKG, "libstem_hip.so")
+# STEM_HIP_LIBRARY names another build of the same ABI (tools/debug use `make EXPERIMENTS=1` -> libstem_hip_exper.so)
+HIP_SO = os.environ.get("STEM_HIP_LIBRARY") or os.path.join(_PKG, "libstem_hip.so")
 RANS_SO = os.path.join(_PKG, "libstem_rans.so")
 
 _hip = None
@@ -118,6 +119,9 @@ _HIP_SIG = {
     "stem_adam_step_dev": [vp, vp, vp, vp, sz, vp, cf, cf, vp, cf, cf, cf, vp, vp, vp],
     "stem_packed_weight_elems": [ci, ci, ci, ci, ci],
     "stem_abi_version": [],
+    "stem_built_with_experiments": [],
+    "stem_tuning_set": [C.c_char_p, ci],
+    "stem_tuning_get": [C.c_char_p],
     "stem_last_error": [],
 }
 _RESTYPE = {"stem_bias_grad_scratch_elems": sz, "stem_bf16x3_conv_weight_gen_bytes": sz, "stem_conv2d_bf16x6_gen_workspace_bytes": sz, "stem_bf16x3_planes_bytes": sz, "stem_bf16x3_conv_weight_bytes": sz, "stem_packed_weight_elems": sz, "stem_gdn_bwd_workspace_bytes": sz, "stem_wgrad_workspace_elems": sz, "stem_conv_workspace_bytes": sz, "stem_last_error": C.c_char_p}

@@ -812,35 +812,41 @@ STEM_EXPORT int stem_conv2d_bf16x6_fwd(const void *xp, const void *wp, const flo
             a.dx[r * S + s] = (signed char)(s - pad);
         }
     static bool attr_done = false;      // > 64 KiB of dynamic LDS needs an explicit opt-in
-    static int nprod = 6;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<128, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
+#ifdef STEM_EXPERIMENTS
         (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
         (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
         (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
         (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
-        // STEM_BF16_PRODUCTS: all bf16 kernels; STEM_GA_BF16_PRODUCTS: this kernel (the frozen, inference-only analysis transform) alone
-        const char *e = getenv("STEM_GA_BF16_PRODUCTS") ? getenv("STEM_GA_BF16_PRODUCTS") : getenv("STEM_BF16_PRODUCTS");
-        if (e) nprod = atoi(e);
+#endif
         attr_done = true;
     }
-    a.exper = getenv("STEM_BX6_EXPER") ? atoi(getenv("STEM_BX6_EXPER")) : 0;
-    const int np_now = getenv("STEM_BF16_PRODUCTS_DYN") ? atoi(getenv("STEM_BF16_PRODUCTS_DYN")) : nprod;     // experiments only
     const int M = B * OH * OW;
     hipStream_t st = (hipStream_t)stream;
     // 128-pixel tiles (8 wavefronts) when they fill the 256 CUs at least once, 64-pixel tiles (4 wavefronts) below that
-    const bool small = (cdiv(M, 128) < 256 && !(a.exper & 2)) || (a.exper & 4);
+    const int tile = stem_tuning(STEM_TUNE_BX6_TILE);
+    const bool small = tile ? tile == 64 : cdiv(M, 128) < 256;
+#ifdef STEM_EXPERIMENTS
+    // measurement-only variants: fewer bf16 products per fp32 product, an epilogue-free main loop.
+    // STEM_BF16_PRODUCTS: all bf16 kernels; STEM_GA_BF16_PRODUCTS: this kernel (the frozen analysis transform) alone
+    const char *e = getenv("STEM_BF16_PRODUCTS_DYN") ? getenv("STEM_BF16_PRODUCTS_DYN")
+                  : getenv("STEM_GA_BF16_PRODUCTS") ? getenv("STEM_GA_BF16_PRODUCTS") : getenv("STEM_BF16_PRODUCTS");
+    const int np_now = e ? atoi(e) : 6;
+    a.exper = getenv("STEM_BX6_EXPER") ? atoi(getenv("STEM_BX6_EXPER")) & 1 : 0;
     if (small && np_now == 3)
         hipLaunchKernelGGL((conv_bf16x6_kernel<64, 3>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
     else if (small && np_now == 4)
         hipLaunchKernelGGL((conv_bf16x6_kernel<64, 4>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
-    else if (small)
-        hipLaunchKernelGGL((conv_bf16x6_kernel<64, 6>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
-    else if (np_now == 3)
+    else if (!small && np_now == 3)
         hipLaunchKernelGGL((conv_bf16x6_kernel<128, 3>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
-    else if (np_now == 4)
+    else if (!small && np_now == 4)
         hipLaunchKernelGGL((conv_bf16x6_kernel<128, 4>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
+    else
+#endif
+    if (small)
+        hipLaunchKernelGGL((conv_bf16x6_kernel<64, 6>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
     else
         hipLaunchKernelGGL((conv_bf16x6_kernel<128, 6>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
     STEM_LAUNCH_CHECK("stem_conv2d_bf16x6_fwd");
@@ -894,8 +900,7 @@ constexpr size_t kGenCntBytes = 64 * 1024;          // arrival counters in front
 // with splits 1..10 (tools/debug/bf16x6_gen_check.py, STEM_BX6_SPLIT): the model ranks them as measured, optimum 4 / 4 / 4.
 int gen_split(int tiles, int nchunks)
 {
-    static const int forced_once = getenv("STEM_BX6_SPLIT") ? atoi(getenv("STEM_BX6_SPLIT")) : 0;
-    const int forced = getenv("STEM_BX6_SPLIT_DYN") ? atoi(getenv("STEM_BX6_SPLIT_DYN")) : forced_once;      // tuning / tests
+    const int forced = stem_tuning(STEM_TUNE_BX6_SPLIT);      // stem_tuning_set("bx6_split", n): tests / sweeps
     if (forced > 0) return forced < nchunks ? forced : nchunks;
     int best = 1;
     double best_cost = 1e30;
@@ -964,17 +969,21 @@ STEM_EXPORT int stem_conv2d_bf16x6_gen_fwd(const void *xp, int xpix, const void 
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void *)conv_bf16x6_gen_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
+#ifdef STEM_EXPERIMENTS
         (void)hipFuncSetAttribute((const void *)conv_bf16x6_gen_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
         (void)hipFuncSetAttribute((const void *)conv_bf16x6_gen_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
+#endif
         attr_done = true;
     }
-    static const int nprod = getenv("STEM_BF16_PRODUCTS") ? atoi(getenv("STEM_BF16_PRODUCTS")) : 6;       // measurement switch (DESIGN.md 7)
     const dim3 grid(cdiv(M, GBM), ntn, a.nsplit);
+#ifdef STEM_EXPERIMENTS
+    static const int nprod = getenv("STEM_BF16_PRODUCTS") ? atoi(getenv("STEM_BF16_PRODUCTS")) : 6;       // measurement switch (DESIGN.md 7)
     if (nprod == 3)
         hipLaunchKernelGGL(conv_bf16x6_gen_kernel<3>, grid, dim3(GNT), GLDS, (hipStream_t)stream, a);
     else if (nprod == 4)
         hipLaunchKernelGGL(conv_bf16x6_gen_kernel<4>, grid, dim3(GNT), GLDS, (hipStream_t)stream, a);
     else
+#endif
         hipLaunchKernelGGL(conv_bf16x6_gen_kernel<6>, grid, dim3(GNT), GLDS, (hipStream_t)stream, a);
     STEM_LAUNCH_CHECK("stem_conv2d_bf16x6_gen_fwd");
     return 0;

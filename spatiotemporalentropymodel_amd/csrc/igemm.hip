@@ -1008,7 +1008,7 @@ int launch(IgemmArgs &g, bool c4, void *ws, size_t ws_bytes, hipStream_t st)
         g.xbytes = (int)xb;
         g.wbytes = (int)wb;
     }
-    static const int exper = getenv("STEM_IGEMM_EXPER") ? atoi(getenv("STEM_IGEMM_EXPER")) : 0;
+    static const int exper = STEM_EXPER_ENV("STEM_IGEMM_EXPER") ? atoi(STEM_EXPER_ENV("STEM_IGEMM_EXPER")) : 0;     // ablations: -DSTEM_EXPERIMENTS builds only
     g.exper = exper;
     g.ident = (g.nphase == 1 && g.osy == 1 && g.osx == 1 && g.ph[0].ooy == 0 && g.ph[0].oox == 0 &&
                g.ph[0].qh == g.OH && g.ph[0].qw == g.OW) ? 1 : 0;

@@ -14,7 +14,37 @@ void stem_set_error(const char *fmt, ...)
     va_end(ap);
 }
 STEM_EXPORT const char *stem_last_error(void) { return g_err; }
-STEM_EXPORT int stem_abi_version(void) { return 2; }
+STEM_EXPORT int stem_abi_version(void) { return 3; }
+STEM_EXPORT int stem_built_with_experiments(void)
+{
+#ifdef STEM_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+static int g_tuning[STEM_TUNE_COUNT] = {0};
+static const char *const kTuningNames[STEM_TUNE_COUNT] = {"bx6_tile", "bx6_split", "wg6_split"};
+int stem_tuning(int id) { return g_tuning[id]; }
+STEM_EXPORT int stem_tuning_set(const char *name, int value)
+{
+    STEM_CHECK_ARG(name && value >= 0, "stem_tuning_set: null name or negative value");
+    for (int i = 0; i < STEM_TUNE_COUNT; ++i)
+        if (!strcmp(name, kTuningNames[i])) {
+            STEM_CHECK_ARG(i != STEM_TUNE_BX6_TILE || value == 0 || value == 64 || value == 128, "stem_tuning_set: bx6_tile is 0 (automatic), 64 or 128");
+            g_tuning[i] = value;
+            return 0;
+        }
+    stem_set_error("stem_tuning_set: unknown selector '%s' (bx6_tile, bx6_split, wg6_split)", name);
+    return -1;
+}
+STEM_EXPORT int stem_tuning_get(const char *name)
+{
+    for (int i = 0; name && i < STEM_TUNE_COUNT; ++i)
+        if (!strcmp(name, kTuningNames[i])) return g_tuning[i];
+    return -1;
+}
 
 namespace {
 

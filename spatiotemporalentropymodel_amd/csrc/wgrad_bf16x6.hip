@@ -231,8 +231,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
 
 int plan_splits(int B, int OH, int OW, int C, int K, int T)
 {
-    static const int forced_once = getenv("STEM_WG6_SPLIT") ? atoi(getenv("STEM_WG6_SPLIT")) : 0;
-    const int forced = getenv("STEM_WG6_SPLIT_DYN") ? atoi(getenv("STEM_WG6_SPLIT_DYN")) : forced_once;      // tuning / tests
+    const int forced = stem_tuning(STEM_TUNE_WG6_SPLIT);      // stem_tuning_set("wg6_split", n): tests / sweeps
     const int nchunks = cdiv(B * OH * OW, PX), tiles = cdiv(K, TK) * cdiv(C, TC) * T;
     int s = forced > 0 ? forced : (512 + tiles / 2) / tiles;       // two workgroups per CU: aim at ~512 workgroups
     if (s < 1) s = 1;
@@ -281,17 +280,21 @@ STEM_EXPORT int stem_conv2d_wgrad_bf16x6(const void *xp, int xpix, const void *d
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void *)wgrad_bf16x6_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+#ifdef STEM_EXPERIMENTS
         (void)hipFuncSetAttribute((const void *)wgrad_bf16x6_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         (void)hipFuncSetAttribute((const void *)wgrad_bf16x6_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+#endif
         attr_done = true;
     }
-    static const int nprod = getenv("STEM_BF16_PRODUCTS") ? atoi(getenv("STEM_BF16_PRODUCTS")) : 6;       // measurement switch (DESIGN.md 7)
     const dim3 grid(cdiv(K, TK) * cdiv(C, TC), R * S, splits);
+#ifdef STEM_EXPERIMENTS
+    static const int nprod = getenv("STEM_BF16_PRODUCTS") ? atoi(getenv("STEM_BF16_PRODUCTS")) : 6;       // measurement switch (DESIGN.md 7)
     if (nprod == 3)
         hipLaunchKernelGGL(wgrad_bf16x6_kernel<3>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
     else if (nprod == 4)
         hipLaunchKernelGGL(wgrad_bf16x6_kernel<4>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
     else
+#endif
         hipLaunchKernelGGL(wgrad_bf16x6_kernel<6>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
     STEM_LAUNCH_CHECK("stem_conv2d_wgrad_bf16x6");
     return 0;

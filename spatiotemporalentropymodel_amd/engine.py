@@ -200,10 +200,24 @@ class StemEngine:
         self._pack_descs = None
         self._side = None
         self._checked = False
-        if self.use_bx6:
-            for l in self.layers:
-                l.bx6 = l.bx6_eligible()
-                l.wg6 = self.use_wg6 and l.wg6_eligible()
+        self._select_bx6()
+
+    def _select_bx6(self):
+        """Which layers run on the bf16 kernels.  HE.0 and HD.4 are routed one by one; the TPM and EPM chains hand planes from
+        layer to layer (and the EPM input gradient is read through channel views at multiples of P = 2 * Cin), so each chain is
+        routed as a whole: bf16 only if EVERY layer of it is eligible (channel counts multiples of 32) and, for the EPM, the
+        views are 32-aligned -- otherwise the whole chain stays on the fp32-MFMA kernels, which only need C % 4 == 0."""
+        for l in self.layers:
+            l.bx6 = self.use_bx6 and l.bx6_eligible()
+        P = self.HE[0].C                                # HE.0 reads cat(y_cur, y_cond): its C is 2 * Cin = P
+        for group, need_aligned in ((self.TPM, False), (self.EPM, True)):
+            if group and not (all(l.bx6 for l in group) and (not need_aligned or P % 32 == 0)):
+                for l in group:
+                    l.bx6 = False
+        for l in self.layers:
+            # weight gradients take whatever planes the forward / input-gradient route left behind (wgrad_any falls back to the
+            # fp32 kernel when there are none), so they follow the layer's own eligibility
+            l.wg6 = self.use_bx6 and self.use_wg6 and l.wg6_eligible()
 
     #: forward and input-gradient of the stride-1 layers (TPM, HE.0, HD.4, EPM) on the bf16 matrix cores with fp32-exact products
     #: (six bf16 MFMAs per fp32 product, csrc/conv_bf16x6.hip); STEM_ENGINE_BF16X6=0 keeps every layer on the fp32-MFMA kernels
@@ -242,9 +256,11 @@ class StemEngine:
         key = tuple((_layers.weight_epoch(l.mod.weight), l.mod.weight._version, l.mod.weight.data_ptr()) for l in self.layers)
         if key == self._pack_key:
             return
-        first = self.layers[0]
-        have = first.wp6_fwd if first.bx6 else first.wp_fwd
-        if have is None or have.device != first.mod.weight.device:
+        stale = False
+        for l in self.layers:
+            have = l.wp6_fwd if l.bx6 else l.wp_fwd
+            stale = stale or have is None or have.device != l.mod.weight.device
+        if stale:
             for l in self.layers:
                 l.alloc_packs(l.mod.weight.device)
             self._pack_descs = None

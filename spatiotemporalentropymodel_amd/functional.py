@@ -39,6 +39,31 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+class tuning:
+    """`with F.tuning(bx6_split=3): ...` -- force a plan selector of the library (stem_tuning_set: "bx6_tile", "bx6_split",
+    "wg6_split") for the calls inside the block; tests and sweep tools only.  The workspace-size cache of the general bf16
+    kernel depends on the split factor and is dropped on entry and exit."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        lib = _lib.hip()
+        for k, v in self.kv.items():
+            self.old[k] = int(lib.stem_tuning_get(k.encode()))
+            _chk(lib.stem_tuning_set(k.encode(), int(v)))
+        _WS_GEN_BYTES.clear()
+        return self
+
+    def __exit__(self, *exc):
+        lib = _lib.hip()
+        for k, v in self.old.items():
+            if v >= 0:
+                lib.stem_tuning_set(k.encode(), v)
+        _WS_GEN_BYTES.clear()
+        return False
+
+
 def _require_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -472,7 +497,7 @@ def conv2d_bf16x6_gen(xp: Bf16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EP
     yp = Bf16Planes.empty(B, N, Ho, Wo, dev) if want_planes else None
     dims = (B, H, W, Cc, N, R, S, stride, pad)
     need = _WS_GEN_BYTES.get(dims)
-    if need is None or "STEM_BX6_SPLIT_DYN" in os.environ:          # (the env var forces a split factor per call: tests / tuning)
+    if need is None:
         need = _WS_GEN_BYTES[dims] = int(_lib.hip().stem_conv2d_bf16x6_gen_workspace_bytes(*dims))
     ws_ptr = 0
     if need:

@@ -143,6 +143,7 @@ def case_train_fused(rank, world, out_dir, steps=2, tag="train_fused"):
 
 def case_gop(rank, world, out_dir, frames_n=3, tag="gop"):
     """One GOP iteration of the variable-rate loop (selfcheck.roi_gop_step) with GopGradAccumulator, one sample per rank."""
+    out_tag = tag
     from spatiotemporalentropymodel_amd import distributed as D
     from spatiotemporalentropymodel_amd import selfcheck as S
     from spatiotemporalentropymodel_amd.losses import PixelwiseRateDistortionLoss
@@ -170,7 +171,7 @@ def case_gop(rank, world, out_dir, frames_n=3, tag="gop"):
             "params_i": flat_np(opt_i.flat.data), "params_p": flat_np(opt_p.flat.data),
             "grad_i": flat_np(opt_i.flat.grad), "grad_p": flat_np(opt_p.flat.grad),
             "any_rank": np.array([acc.any_rank(False), acc.any_rank(True)]), "active": np.array([acc.active])}
-    np.savez(os.path.join(out_dir, f"{tag}_rank{rank}.npz"), **dump)
+    np.savez(os.path.join(out_dir, f"{out_tag}_rank{rank}.npz"), **dump)
 
 
 def main():

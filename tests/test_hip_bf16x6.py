@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import REPO, assert_close
+from conftest import REPO, assert_close, close_ratio
 
 sys.path.insert(0, os.path.join(REPO, "oracle"))
 import stem_oracle as orc  # noqa: E402
@@ -63,12 +63,16 @@ CASES = [  # B, C, H, W, K, R, stride
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("tile128", [False, True])
 @pytest.mark.parametrize("gdn", [False, True])
-def test_conv_gdn_vs_oracle(F, monkeypatch, case, tile128, gdn):
+def test_conv_gdn_vs_oracle(F, case, tile128, gdn):
     """conv (+ fused GDN) against the oracle, both workgroup tiles (64 pixels x 4 wavefronts, 128 pixels x 8 wavefronts),
     fp32 and planes output; ragged pixel counts and channel counts below the 192-wide tile."""
     B, C, H, W, K, R, st = case
-    if tile128:
-        monkeypatch.setenv("STEM_BX6_EXPER", "2")
+    with F.tuning(bx6_tile=128 if tile128 else 64):
+        _conv_gdn_vs_oracle(F, case, gdn)
+
+
+def _conv_gdn_vs_oracle(F, case, gdn):
+    B, C, H, W, K, R, st = case
     x, w, b = rnd((B, C, H, W), 11, -2, 2), (rnd((K, C, R, R), 12) / np.sqrt(C * R * R)).astype(np.float32), rnd((K,), 13, -0.1, 0.1)
     beta, gamma = rnd((K,), 14, 0.5, 1.5), (rnd((K, K), 15, 0.0, 0.1) + 0.1 * np.eye(K, dtype=np.float32)).astype(np.float32)
     ref = orc.conv2d_fwd(x, w, b, st, R // 2)
@@ -167,12 +171,15 @@ GEN_CASES = [  # B, C, H, W, K, R
 
 @pytest.mark.parametrize("case", GEN_CASES)
 @pytest.mark.parametrize("split", [0, 1, 3])
-def test_gen_forward_and_input_gradient_vs_oracle(F, monkeypatch, case, split):
+def test_gen_forward_and_input_gradient_vs_oracle(F, case, split):
     """forward + leaky ReLU and input-gradient x leaky-ReLU derivative (what autograd derives for conv(lrelu(u))) against the
     oracle, with the planner's split-K factor (0), unsplit (1) and a forced 3-way split; planes output = fp32 output."""
+    with F.tuning(bx6_split=split):
+        _gen_forward_and_input_gradient(F, case, split)
+
+
+def _gen_forward_and_input_gradient(F, case, split):
     B, C, H, W, K, R = case
-    if split:
-        monkeypatch.setenv("STEM_BX6_SPLIT_DYN", str(split))
     pad, sl = R // 2, 0.01
     x, w, b = rnd((B, C, H, W), 31, -2, 2), (rnd((K, C, R, R), 32) / np.sqrt(C * R * R)).astype(np.float32), rnd((K,), 33, -0.1, 0.1)
     dy = rnd((B, K, H, W), 34)
@@ -250,8 +257,10 @@ def test_engine_schedule_with_and_without_bf16_layers(monkeypatch):
     assert res["bf16"][1].keys() == res["fp32"][1].keys() and len(res["fp32"][1]) > 30
     # two fp32-accurate routes: each is within 1e-4 of the float64 reference in tests/test_hip_models.py; against each other the
     # weight gradients (sums over pixels with cancellation) may sit up to 2e-4 of the tensor's largest entry apart
+    worst = max((close_ratio(res["bf16"][1][n], g32, 0.1), n) for n, g32 in res["fp32"][1].items())
+    print(f"bf16 route vs fp32-MFMA route: worst gradient tensor {worst[1]} at {worst[0]:.2e} (elements below 0.1 max held to 1e-5 max)")
     for n, g32 in res["fp32"][1].items():
-        assert_close(res["bf16"][1][n], g32, rtol=2e-4, what=f"grad {n}", floor=1.0)
+        assert_close(res["bf16"][1][n], g32, rtol=1e-4, what=f"grad {n}", floor=0.1)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -266,10 +275,13 @@ WG_CASES = [  # B, C, H, W, K, R
 
 @pytest.mark.parametrize("case", WG_CASES)
 @pytest.mark.parametrize("split", [0, 1, 3])
-def test_weight_gradient_vs_oracle(F, monkeypatch, case, split):
+def test_weight_gradient_vs_oracle(F, case, split):
+    with F.tuning(wg6_split=split):
+        _weight_gradient_vs_oracle(F, case, split)
+
+
+def _weight_gradient_vs_oracle(F, case, split):
     B, C, H, W, K, R = case
-    if split:
-        monkeypatch.setenv("STEM_WG6_SPLIT_DYN", str(split))
     pad = R // 2
     x, dy = rnd((B, C, H, W), 51, -2, 2), rnd((B, K, H, W), 52)
     w0 = np.zeros((K, C, R, R), np.float32)
@@ -278,11 +290,14 @@ def test_weight_gradient_vs_oracle(F, monkeypatch, case, split):
     splits, elems = F.wgrad_bf16x6_plan(xd.shape, K, R, R, pad)
     assert split == 0 or splits <= split             # clamped to >= 16 pixel chunks per split
     dwp = torch.empty(elems, device="cuda")
-    dbf = torch.full((K,), 1.0, device="cuda")
-    F.conv2d_wgrad_bf16x6(F.Bf16Planes.split(xd), F.Bf16Planes.split(dyd), K, R, R, pad, dwp, splits, db=dbf, accumulate_db=True)
+    dbf = torch.full((K,), float("nan"), device="cuda")
+    F.conv2d_wgrad_bf16x6(F.Bf16Planes.split(xd), F.Bf16Planes.split(dyd), K, R, R, pad, dwp, splits, db=dbf)
     dw = dwp.view(splits, R * R, K, C).sum(0).permute(1, 2, 0).reshape(K, C, R, R)
     assert_close(host(dw), dw_ref, what=f"wgrad {case} split={split}", floor=0.1)
-    assert_close(host(dbf) - 1.0, db_ref, rtol=2e-4, what="bias gradient from the weight-gradient pass (accumulated onto 1)", floor=0.1)
+    assert_close(host(dbf), db_ref, what="bias gradient from the weight-gradient pass", floor=0.1)
+    dbacc = dbf.clone()
+    F.conv2d_wgrad_bf16x6(F.Bf16Planes.split(xd), F.Bf16Planes.split(dyd), K, R, R, pad, dwp, splits, db=dbacc, accumulate_db=True)
+    assert_close(host(dbacc), 2 * db_ref, what="bias gradient from the weight-gradient pass, accumulated", floor=0.1)
     db = torch.zeros(K, device="cuda")
     F.bias_grad(dyd.contiguous(memory_format=torch.channels_last), db)
     assert_close(host(db), db_ref, what="bias gradient", floor=0.1)

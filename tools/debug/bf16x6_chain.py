@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Error of the whole analysis transform g_a (mbt2018, N = M = 192) against an fp64 evaluation, for the fp32-MFMA kernels and for
-the bf16 kernels keeping 6 / 4 / 3 products per fp32 product."""
+the bf16 kernels keeping 6 / 4 / 3 products per fp32 product.
+
+The 4 / 3-product variants are not in the shipped library: build `make -C spatiotemporalentropymodel_amd/csrc experiments` and run
+with STEM_HIP_LIBRARY=spatiotemporalentropymodel_amd/libstem_hip_exper.so (the shipped library ignores STEM_BF16_PRODUCTS_DYN)."""
 import os
 import sys
 
