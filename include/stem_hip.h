@@ -371,6 +371,19 @@ int stem_conv2d_fwd_c4_gdn_planes(const float *x4, const float *wp, const float 
 int stem_conv2d_bf16x6_fwd(const void *xp, const void *wp, const float *bias, const float *beta, const float *gamma,
                            float beta_min, float *y, int ldy, void *yp, int B, int H, int W, int C, int N, int R, int S,
                            int stride, int pad, void *stream);
+/* First analysis layer + its GDN as ONE kernel on the bf16 matrix cores (csrc/c4gdn_bf16x6.hip): replaces
+ * `self.g_a[0:2]` = conv(3, N) ; GDN(N) of compressai/models/priors.py:421-423 (gdn.py:52-67) under no_grad
+ * (stem/trainSTEM.py:128,171).  N = 64, 128 or 192 (stem_c4gdn_supported), R*S <= 25.  Both contractions run as six bf16
+ * MFMAs per fp32 product, fp32 accumulation; the squared conv outputs go from the accumulators into the GDN contraction as
+ * registers.  stem_c4gdn_pack builds the A-operand stream (stem_c4gdn_stream_bytes bytes) from the STEM_PACK_CONV_FWD_C4
+ * weight and the STORED gamma (reparametrised there: max(gamma, 2^-18)^2 - 2^-36); repack when either changes.
+ * x4 = stem_nchw3_to_nhwc4's buffer; output as fp32 NHWC (y, ldy) and / or planes (yp), either may be null.              */
+int stem_c4gdn_supported(int N, int R, int S);
+size_t stem_c4gdn_stream_bytes(int N, int R, int S);
+int stem_c4gdn_pack(const float *wp_c4, const float *gamma, void *astream, int N, int R, int S, void *stream);
+int stem_conv2d_c4_gdn_bf16x6(const float *x4, const void *astream, const float *bias, const float *beta, float beta_min,
+                              float *y, int ldy, void *yp, int B, int H, int W, int N, int R, int S, int stride, int pad,
+                              void *stream);
 
 /* General variant of stem_conv2d_bf16x6_fwd for the small-M layers of the STEM network at training time: any N (tiles of 128
  * output channels), split-K with an in-kernel deterministic reduction, epilogue epi = 0 bias | 1 bias + leaky ReLU(slope) |

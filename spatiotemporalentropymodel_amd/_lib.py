@@ -103,6 +103,10 @@ _HIP_SIG = {
     "stem_bias_grad": [vp, ci, C.c_long, ci, vp, vp, ci, vp],
     "stem_conv2d_bf16x6_gen_fwd": [vp, ci, vp, vp, ci, cf, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],
     "stem_conv2d_fwd_c4_gdn_planes": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp],
+    "stem_c4gdn_supported": [ci, ci, ci],
+    "stem_c4gdn_stream_bytes": [ci, ci, ci],
+    "stem_c4gdn_pack": [vp, vp, vp, ci, ci, ci, vp],
+    "stem_conv2d_c4_gdn_bf16x6": [vp, vp, vp, vp, cf, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_conv2d_bf16x6_fwd": [vp, vp, vp, vp, vp, cf, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_ar_decode_batch_pipelined": [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf,
                                        vp, vp, vp, ci, ci, vp, vp, vp],
@@ -124,7 +128,7 @@ _HIP_SIG = {
     "stem_tuning_get": [C.c_char_p],
     "stem_last_error": [],
 }
-_RESTYPE = {"stem_bias_grad_scratch_elems": sz, "stem_bf16x3_conv_weight_gen_bytes": sz, "stem_conv2d_bf16x6_gen_workspace_bytes": sz, "stem_bf16x3_planes_bytes": sz, "stem_bf16x3_conv_weight_bytes": sz, "stem_packed_weight_elems": sz, "stem_gdn_bwd_workspace_bytes": sz, "stem_wgrad_workspace_elems": sz, "stem_conv_workspace_bytes": sz, "stem_last_error": C.c_char_p}
+_RESTYPE = {"stem_c4gdn_stream_bytes": sz, "stem_bias_grad_scratch_elems": sz, "stem_bf16x3_conv_weight_gen_bytes": sz, "stem_conv2d_bf16x6_gen_workspace_bytes": sz, "stem_bf16x3_planes_bytes": sz, "stem_bf16x3_conv_weight_bytes": sz, "stem_packed_weight_elems": sz, "stem_gdn_bwd_workspace_bytes": sz, "stem_wgrad_workspace_elems": sz, "stem_conv_workspace_bytes": sz, "stem_last_error": C.c_char_p}
 
 _RANS_SIG = {
     "stem_rans_encode": [vp, vp, sz, vp, ci, ci, vp, vp, vp, sz],

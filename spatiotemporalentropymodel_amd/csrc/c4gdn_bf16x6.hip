@@ -1,0 +1,378 @@
+// First analysis layer g_a.0 + GDN g_a.1 (compressai/models/priors.py:421-423, gdn.py:52-67) as ONE kernel on the bf16 matrix
+// cores with fp32-exact products: a 3-channel image -> N = 64 / 128 / 192 channels (5x5 stride 2 in the reference), divided by
+// sqrt(beta + gamma . x^2), written pre-split as bf16 planes for conv_bf16x6.hip (and / or as fp32 NHWC).
+//
+// The fp32-MFMA kernel this replaces (igemm.hip, C4 + FUSE) ran at 0.29 of its pipe: 72 % of its flop is the K = N GDN
+// contraction on the 64-flop/clk instruction, its 128 x 192 tile with the squared values parked in LDS left one workgroup per
+// CU, and nothing overlapped the 302 MB planes write.  Here
+//   * both contractions are computed TRANSPOSED, D[channel][pixel] = A[channel][k] . B[k][pixel]: the accumulator of
+//     v_mfma_f32_32x32x16_bf16 keeps one PIXEL per lane (column) and 16 channels in its registers -- exactly the B-operand
+//     shape of the next MFMA that sums over channels.  The squared conv outputs therefore go from the accumulators into the
+//     GDN contraction as registers (square, split into three bf16 planes, pack): no LDS tile, no cross-lane movement;
+//   * a wavefront owns 32 pixels x ALL N channels (x: N/32 accumulators), so a workgroup needs LDS only for the A-operand
+//     stream (conv weights, then gamma), which is the same for every workgroup: it is pre-split into bf16 planes and stored in
+//     fragment order by c4gdn_pack_kernel, and every 18 KiB chunk of it is copied global -> LDS by global_load_lds (no
+//     registers) one chunk ahead of its use; 36 KiB of LDS per workgroup, several workgroups per CU, so that the epilogue
+//     stores of one overlap the MFMAs of another;
+//   * six bf16 MFMAs per fp32 product as in conv_bf16x6.hip (operands split as a = a0 + a1 + a2, the six products with
+//     i + j <= 2): fp32 accuracy, fp32 accumulation;
+//   * the image patch of a pixel is read straight from the NHWC4 image (two 16-byte loads per lane and k-step: taps s, s + 1
+//     of one filter row x 4 channels = the 8 consecutive k of the lane's fragment), zero-filled outside the image.
+//
+// Channel order inside a 32-row MFMA tile: row r of the A operand holds channel 16 ((r >> 2) & 1) + 4 (r >> 3) + (r & 3), which
+// makes the 16 accumulator registers of lane (pixel p, half h) the CONTIGUOUS channels 16 h .. 16 h + 15 of the tile: k-step s
+// of the GDN contraction takes registers 8 s .. 8 s + 7 (channels 16 h + 8 s + j, what the gamma fragments are packed for), and
+// the epilogue stores 16 consecutive channels per lane (32 bytes per plane, 64 bytes of fp32).
+#include <math.h>
+
+#include "stem_common.h"
+
+namespace {
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+
+constexpr int CHUNK = 18432;                    // bytes of one A-operand chunk: 18 fragments x 64 lanes x 16 B
+constexpr int OOR = 0x7FFFFF00;                 // voffset that every buffer view rejects (returns 0)
+constexpr int WG_PIX = 128, NTHREADS = 256;     // 4 wavefronts x 32 pixels
+
+__host__ __device__ inline int rho(int r) { return 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3); }
+__host__ __device__ inline int group_size(int nb) { return nb == 6 ? 3 : (nb == 4 ? 2 : nb); }       // n-blocks per GDN pass
+
+__device__ inline void split3(const float x, __bf16 &h0, __bf16 &h1, __bf16 &h2)
+{
+    h0 = (__bf16)x;
+    const float r1 = x - (float)h0;
+    h1 = (__bf16)r1;
+    h2 = (__bf16)(r1 - (float)h1);
+}
+
+struct C4gArgs {
+    const float *x4;               // [B][H][W][4] fp32 (stem_nchw3_to_nhwc4)
+    const unsigned char *astream;  // c4gdn_pack_kernel's output
+    const float *bias, *beta;
+    float *y;
+    void *yp;
+    int ldy;
+    int B, H, W, N, OH, OW, R, S, stride, pad;
+    int ksc;                       // conv k-steps: ceil(R * ceil(S / 2) / 2)
+    int xbytes;
+    float beta_bound;
+};
+
+// ---- A-operand stream -------------------------------------------------------------------------------------------------------
+// chunk t < ksc (conv k-step t): fragment (nb, plane) at ((nb * 3 + plane) * 64 + lane) * 16; lane (r, h) element j is the
+//   weight of channel nb * 32 + rho(r) for K slot (pair q = 2 t + h, tap j >> 2 of the pair, image channel j & 3), where pair q
+//   = (filter row q / PR, taps 2 (q % PR) and 2 (q % PR) + 1), PR = ceil(S / 2); slots beyond the filter hold 0;
+// chunk ksc + g * NB + kb (GDN pass g over k-block kb): fragment (s, nbl, plane) at (((s * GS + nbl) * 3 + plane) * 64 + lane) * 16;
+//   lane (r, h) element j = gamma'[(g * GS + nbl) * 32 + rho(r)][kb * 32 + 16 h + 8 s + j], gamma' = max(gamma, 2^-18)^2 - 2^-36
+//   (parametrizers.py:42-45).
+__global__ __launch_bounds__(256) void c4gdn_pack_kernel(const float *wp_c4, const float *gamma, unsigned char *out, int N, int R, int S, int ksc)
+{
+    const int NB = N / 32, GS = group_size(NB), NG = NB / GS, PR = (S + 1) / 2;
+    const int nchunks = ksc + NG * NB;
+    const int e = blockIdx.x * 256 + threadIdx.x;           // (chunk, fragment position without the plane, lane)
+    const int lane = e & 63, fp = (e >> 6) % 6, c = (e >> 6) / 6;
+    if (c >= nchunks) return;
+    const int r = lane & 31, h = lane >> 5;
+    float v[8];
+    bool used = true;
+    if (c < ksc) {
+        const int nb = fp;
+        used = nb < NB;
+        const int ch = nb * 32 + rho(r), q = 2 * c + h, prow = q / PR, s0 = 2 * (q % PR);
+        for (int j = 0; j < 8; ++j) {
+            const int s = s0 + (j >> 2), cc = j & 3;
+            v[j] = (used && prow < R && s < S) ? wp_c4[(ch * 32 + prow * S + s) * 4 + cc] : 0.f;      // channel 3 of the C4 pack is zero
+        }
+    } else {
+        const int gi = c - ksc, g = gi / NB, kb = gi - g * NB, s = fp / GS, nbl = fp - s * GS;
+        used = s < 2;
+        const int n = (g * GS + nbl) * 32 + rho(r), k0 = kb * 32 + 16 * h + 8 * s;
+        for (int j = 0; j < 8; ++j) {
+            float gv = 0.f;
+            if (used) {
+                gv = fmaxf(gamma[n * N + k0 + j], 3.814697265625e-06f);
+                gv = gv * gv - 1.4551915228366852e-11f;
+            }
+            v[j] = gv;
+        }
+    }
+    if (!used) return;
+    bf16x8 p0, p1, p2;
+    for (int j = 0; j < 8; ++j) {
+        __bf16 a, b, cc;
+        split3(v[j], a, b, cc);
+        p0[j] = a; p1[j] = b; p2[j] = cc;
+    }
+    unsigned char *dst = out + (size_t)c * CHUNK + ((size_t)(fp * 3) * 64 + lane) * 16;
+    *reinterpret_cast<bf16x8 *>(dst) = p0;
+    *reinterpret_cast<bf16x8 *>(dst + 1024) = p1;
+    *reinterpret_cast<bf16x8 *>(dst + 2048) = p2;
+}
+
+// six products of one fp32 product, smallest terms first (as conv_bf16x6.hip)
+__device__ inline f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    return acc;
+}
+
+// the three planes of one A fragment (consecutive 1 KiB pieces of the chunk, lane-linear: conflict-free ds_read_b128)
+__device__ inline void lda(const unsigned char *p, bf16x8 (&af)[3])
+{
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const bf16x8 *>(p + pl * 1024);
+}
+
+template <int NB>
+__global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs a)
+{
+    constexpr int GS = NB == 6 ? 3 : (NB == 4 ? 2 : NB), NG = NB / GS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];          // [2][CHUNK]: the A-operand ring
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const int Mtot = a.B * a.OH * a.OW;
+    const int m = blockIdx.x * WG_PIX + wave * 32 + p;
+    const bool ok = m < Mtot;
+    int by, bx, pix0;
+    {
+        const int mm = ok ? m : 0, ohw = a.OH * a.OW, b = mm / ohw, rem = mm - b * ohw, qy = rem / a.OW, qx = rem - qy * a.OW;
+        by = qy * a.stride - a.pad;
+        bx = qx * a.stride - a.pad;
+        pix0 = (b * a.H + by) * a.W + bx;              // pixel index of tap (0, 0); may be negative at the border (masked below)
+    }
+    const int nchunks = a.ksc + NG * NB;
+    const int PR = (a.S + 1) / 2, npairs = a.R * PR;
+
+    // ---- A-operand ring: chunk c -> buffer c & 1, 4.5 KiB per wavefront as four 1 KiB pieces and one half piece ---------------
+    // (wavefront w copies bytes [4096 w, 4096 w + 4096) and the half piece at 16384 + 512 w: one lane address, immediate offsets)
+    const unsigned char *ring_src = a.astream + wave * 4096 + lane * 16;
+    const unsigned char *ring_src_tail = a.astream + 16384 + wave * 512 + (lane & 31) * 16;
+    auto ring_issue = [&](int c) {
+        if (c >= nchunks) return;
+        const size_t co = (size_t)c * CHUNK;
+        unsigned char *dst = smem + (c & 1) * CHUNK;
+        const auto *gs = (const __attribute__((address_space(1))) void *)(ring_src + co);
+        auto *ls = (__attribute__((address_space(3))) void *)(dst + wave * 4096);
+        __builtin_amdgcn_global_load_lds(gs, ls, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(gs, ls, 16, 1024, 0);
+        __builtin_amdgcn_global_load_lds(gs, ls, 16, 2048, 0);
+        __builtin_amdgcn_global_load_lds(gs, ls, 16, 3072, 0);
+        if (lane < 32)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ring_src_tail + co),
+                                             (__attribute__((address_space(3))) void *)(dst + 16384 + wave * 512), 16, 0, 0);
+    };
+    // every wavefront waits for its own pieces, the barrier publishes all of them (and retires the buffer read last step)
+    auto ring_wait = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    // ---- image patch of this lane's pixel for conv k-step t: pair q = 2 t + h = (filter row, taps s0 and s0 + 1) ---------------
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x4), 0, a.xbytes, 0x00020000);
+    auto patch_load = [&](int t, f32x4 &v0, f32x4 &v1) {
+        const int q = 2 * t + h, prow = q / PR, s0 = 2 * (q - prow * PR);
+        const int iy = by + prow, ix = bx + s0;
+        const bool rowok = ok && q < npairs && iy >= 0 && iy < a.H;
+        const int off = (pix0 + prow * a.W + s0) * 16;
+        const int o0 = (rowok && ix >= 0 && ix < a.W) ? off : OOR;
+        const int o1 = (rowok && ix + 1 >= 0 && ix + 1 < a.W && s0 + 1 < a.S) ? off + 16 : OOR;
+        v0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o0, 0, 0));
+        v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o1, 0, 0));
+    };
+
+    // ---- x[nb][i] = conv output of channel nb * 32 + 16 h + i at this lane's pixel, starting from the bias ---------------------
+    f32x16 x[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        if (a.bias) {
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias + nb * 32 + 16 * h + 4 * i4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[nb][4 * i4 + e] = bv[e];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[nb][i] = 0.f;
+        }
+    }
+
+    ring_issue(0);
+    f32x4 pv0, pv1;
+    patch_load(0, pv0, pv1);
+
+    // ---- convolution: ksc chunks of one k-step x NB tiles x 6 products -----------------------------------------------------------
+#pragma unroll 1
+    for (int t = 0; t < a.ksc; ++t) {
+        ring_wait();
+        ring_issue(t + 1);
+        bf16x8 b[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __bf16 h0, h1, h2;
+            split3(pv0[j], h0, h1, h2);
+            b[0][j] = h0; b[1][j] = h1; b[2][j] = h2;
+            split3(pv1[j], h0, h1, h2);
+            b[0][4 + j] = h0; b[1][4 + j] = h1; b[2][4 + j] = h2;
+        }
+        patch_load(t + 1 < a.ksc ? t + 1 : t, pv0, pv1);
+        const unsigned char *buf = smem + (t & 1) * CHUNK + lane * 16;
+        bf16x8 af[2][3];
+        lda(buf, af[0]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {          // fragments of tile nb + 1 are fetched behind the MFMAs of tile nb
+            if (nb + 1 < NB) lda(buf + (nb + 1) * 3072, af[(nb + 1) & 1]);
+            x[nb] = mfma6(af[nb & 1], b, x[nb]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- GDN: NG passes over the k-blocks, GS output tiles each; B operand = the squared accumulators -----------------------------
+    const int opix = NB * 192;
+    unsigned char *ypl = a.yp ? static_cast<unsigned char *>(a.yp) + (size_t)(ok ? m : 0) * opix + 32 * h : nullptr;
+    float *yf = a.y ? a.y + (size_t)(ok ? m : 0) * a.ldy + 16 * h : nullptr;
+    int c = a.ksc;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        f32x16 nrm[GS];
+#pragma unroll
+        for (int nbl = 0; nbl < GS; ++nbl)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) nrm[nbl][i] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb, ++c) {
+            ring_wait();
+            ring_issue(c + 1);
+            const unsigned char *buf = smem + (c & 1) * CHUNK + lane * 16;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 b[3];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = x[kb][8 * s + j];
+                    __bf16 h0, h1, h2;
+                    split3(v * v, h0, h1, h2);
+                    b[0][j] = h0; b[1][j] = h1; b[2][j] = h2;
+                }
+                bf16x8 af[2][3];
+                lda(buf + (s * GS) * 3072, af[0]);
+#pragma unroll
+                for (int nbl = 0; nbl < GS; ++nbl) {
+                    if (nbl + 1 < GS) lda(buf + (s * GS + nbl + 1) * 3072, af[(nbl + 1) & 1]);
+                    nrm[nbl] = mfma6(af[nbl & 1], b, nrm[nbl]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // epilogue of this pass: y = x * rsqrt(beta' + norm), 16 consecutive channels per lane and tile
+#pragma unroll
+        for (int nbl = 0; nbl < GS; ++nbl) {
+            const int nb = g * GS + nbl;
+            float yv[16];
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const f32x4 bt = *reinterpret_cast<const f32x4 *>(a.beta + nb * 32 + 16 * h + 4 * i4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float bb = fmaxf(bt[e], a.beta_bound);
+                    yv[4 * i4 + e] = x[nb][4 * i4 + e] * __builtin_amdgcn_rsqf(nrm[nbl][4 * i4 + e] + (bb * bb - 1.4551915228366852e-11f));
+                }
+            }
+            if (!ok) continue;
+            if (yf) {
+#pragma unroll
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = yv[4 * i4 + e];
+                    *reinterpret_cast<f32x4 *>(yf + nb * 32 + 4 * i4) = o;
+                }
+            }
+            if (ypl) {
+                bf16x8 q0[2], q1[2], q2[2];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    __bf16 h0, h1, h2;
+                    split3(yv[i], h0, h1, h2);
+                    q0[i >> 3][i & 7] = h0; q1[i >> 3][i & 7] = h1; q2[i >> 3][i & 7] = h2;
+                }
+                unsigned char *dst = ypl + nb * 192;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    *reinterpret_cast<bf16x8 *>(dst + 16 * e) = q0[e];
+                    *reinterpret_cast<bf16x8 *>(dst + 64 + 16 * e) = q1[e];
+                    *reinterpret_cast<bf16x8 *>(dst + 128 + 16 * e) = q2[e];
+                }
+            }
+        }
+    }
+}
+
+int conv_ksteps(int R, int S) { return (R * ((S + 1) / 2) + 1) / 2; }
+
+}   // namespace
+
+// ---- C ABI --------------------------------------------------------------------------------------------------------------------
+STEM_EXPORT int stem_c4gdn_supported(int N, int R, int S)
+{
+    return (N == 64 || N == 128 || N == 192) && R >= 1 && S >= 1 && R * S <= 25 && conv_ksteps(R, S) >= 1;
+}
+
+STEM_EXPORT size_t stem_c4gdn_stream_bytes(int N, int R, int S)
+{
+    if (!stem_c4gdn_supported(N, R, S)) return 0;
+    const int NB = N / 32, NG = NB / group_size(NB);
+    return (size_t)(conv_ksteps(R, S) + NG * NB) * CHUNK;
+}
+
+STEM_EXPORT int stem_c4gdn_pack(const float *wp_c4, const float *gamma, void *astream, int N, int R, int S, void *stream)
+{
+    STEM_CHECK_ARG(wp_c4 && gamma && astream, "stem_c4gdn_pack: null pointer");
+    STEM_CHECK_ARG(stem_c4gdn_supported(N, R, S), "stem_c4gdn_pack: N must be 64, 128 or 192 and R*S <= 25 (N=%d R=%d S=%d)", N, R, S);
+    const int NB = N / 32, NG = NB / group_size(NB), ksc = conv_ksteps(R, S), nchunks = ksc + NG * NB;
+    (void)hipMemsetAsync(astream, 0, (size_t)nchunks * CHUNK, (hipStream_t)stream);
+    const int n = nchunks * 6 * 64;
+    hipLaunchKernelGGL(c4gdn_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, wp_c4, gamma,
+                       static_cast<unsigned char *>(astream), N, R, S, ksc);
+    STEM_LAUNCH_CHECK("stem_c4gdn_pack");
+    return 0;
+}
+
+STEM_EXPORT int stem_conv2d_c4_gdn_bf16x6(const float *x4, const void *astream, const float *bias, const float *beta, float beta_min,
+                                          float *y, int ldy, void *yp, int B, int H, int W, int N, int R, int S, int stride, int pad, void *stream)
+{
+    STEM_CHECK_ARG(x4 && astream && beta && (y || yp), "stem_conv2d_c4_gdn_bf16x6: null pointer");
+    STEM_CHECK_ARG(stem_c4gdn_supported(N, R, S), "stem_conv2d_c4_gdn_bf16x6: N must be 64, 128 or 192 and R*S <= 25 (N=%d R=%d S=%d)", N, R, S);
+    STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && stride >= 1 && pad >= 0, "stem_conv2d_c4_gdn_bf16x6: bad geometry");
+    STEM_CHECK_ARG(!y || (ldy >= N && ldy % 4 == 0 && ((uintptr_t)y & 15) == 0), "stem_conv2d_c4_gdn_bf16x6: y rows must be 16-byte aligned, ldy >= N");
+    STEM_CHECK_ARG(!bias || ((uintptr_t)bias & 15) == 0, "stem_conv2d_c4_gdn_bf16x6: bias must be 16-byte aligned");
+    STEM_CHECK_ARG(((uintptr_t)beta & 15) == 0 && ((uintptr_t)astream & 15) == 0, "stem_conv2d_c4_gdn_bf16x6: beta / stream must be 16-byte aligned");
+    const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+    STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_c4_gdn_bf16x6: empty output");
+    const size_t xb = (size_t)B * H * W * 16;
+    STEM_CHECK_ARG(xb < 0x7FFFFF00ull && (size_t)B * OH * OW < 0x7FFFFFFFull, "stem_conv2d_c4_gdn_bf16x6: image batch must stay below 2 GiB");
+    C4gArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x4 = x4; a.astream = static_cast<const unsigned char *>(astream); a.bias = bias; a.beta = beta; a.y = y; a.yp = yp; a.ldy = ldy;
+    a.B = B; a.H = H; a.W = W; a.N = N; a.OH = OH; a.OW = OW; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
+    a.ksc = conv_ksteps(R, S);
+    a.xbytes = (int)xb;
+    a.beta_bound = (float)sqrt((double)beta_min + 1.4551915228366852e-11);
+    const int M = B * OH * OW;
+    const dim3 grid(cdiv(M, WG_PIX)), block(NTHREADS);
+    hipStream_t st = (hipStream_t)stream;
+    if (N == 192)
+        hipLaunchKernelGGL(c4gdn_bf16x6_kernel<6>, grid, block, 2 * CHUNK, st, a);
+    else if (N == 128)
+        hipLaunchKernelGGL(c4gdn_bf16x6_kernel<4>, grid, block, 2 * CHUNK, st, a);
+    else
+        hipLaunchKernelGGL(c4gdn_bf16x6_kernel<2>, grid, block, 2 * CHUNK, st, a);
+    STEM_LAUNCH_CHECK("stem_conv2d_c4_gdn_bf16x6");
+    return 0;
+}

@@ -546,8 +546,46 @@ def bias_grad(dy, db, accumulate=False):
     return db
 
 
-def conv2d_fwd_c4_gdn_planes(x4, wp, bias, beta, gamma, K, R, S, stride, pad, beta_min=1e-6):
-    """conv2d_fwd_c4_gdn whose result is handed to conv2d_bf16x6_fwd: written pre-split (Bf16Planes), no fp32 copy."""
+def _aligned16(*ts):
+    return all(t is None or t.data_ptr() % 16 == 0 for t in ts)
+
+
+def c4gdn_supported(K, R, S, inverse=False):
+    """first layer + GDN on the bf16 kernel of csrc/c4gdn_bf16x6.hip: N = 64 / 128 / 192 output channels, filters up to 25 taps;
+    STEM_C4GDN_BF16X6=0 keeps the fp32-MFMA kernel of igemm.hip (routing switch: both are fp32-exact forms)"""
+    return (not inverse and os.environ.get("STEM_C4GDN_BF16X6", "1") != "0" and bool(_lib.hip().stem_c4gdn_supported(K, R, S)))
+
+
+def c4gdn_stream(wp_c4, gamma, K, R, S):
+    """A-operand stream of conv2d_c4_gdn_bf16x6: the C4-packed first-layer weight and the reparametrised gamma of the following
+    GDN, split into bf16 planes in MFMA-fragment order (one small launch; cache it while the parameters do not change)."""
+    out = torch.empty(int(_lib.hip().stem_c4gdn_stream_bytes(K, R, S)), device=wp_c4.device, dtype=torch.uint8)
+    _chk(_lib.hip().stem_c4gdn_pack(wp_c4.data_ptr(), gamma.data_ptr(), out.data_ptr(), K, R, S, _stream()))
+    return out
+
+
+def conv2d_c4_gdn_bf16x6(x4, astream, bias, beta, K, R, S, stride, pad, beta_min=1e-6, out=None, planes_out=False):
+    """conv (3 -> K channels, x4 = [B,H,W,4] from nchw3_to_nhwc4) + GDN in one kernel, six bf16 MFMAs per fp32 product;
+    result as an NHWC fp32 tensor or, with planes_out, pre-split for conv2d_bf16x6_fwd"""
+    B, H, W, _ = x4.shape
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    if planes_out:
+        res = Bf16Planes.empty(B, K, Ho, Wo, x4.device)
+        y, ldy, yp = None, 0, res.data.data_ptr()
+    else:
+        res = out if out is not None else empty_nhwc(B, K, Ho, Wo, x4.device)
+        y, ldy, yp = res.data_ptr(), nhwc_ld(res), None
+    _chk(_lib.hip().stem_conv2d_c4_gdn_bf16x6(x4.data_ptr(), astream.data_ptr(), _ptr(bias), beta.data_ptr(), beta_min, y, ldy, yp,
+                                              B, H, W, K, R, S, stride, pad, _stream()))
+    return res
+
+
+def conv2d_fwd_c4_gdn_planes(x4, wp, bias, beta, gamma, K, R, S, stride, pad, beta_min=1e-6, astream=None):
+    """conv2d_fwd_c4_gdn whose result is handed to conv2d_bf16x6_fwd: written pre-split (Bf16Planes), no fp32 copy.
+    `astream`: a cached c4gdn_stream(wp, gamma, ...) (built per call otherwise)."""
+    if c4gdn_supported(K, R, S) and _aligned16(bias, beta):
+        return conv2d_c4_gdn_bf16x6(x4, astream if astream is not None else c4gdn_stream(wp, gamma, K, R, S), bias, beta, K, R, S,
+                                    stride, pad, beta_min, planes_out=True)
     B, H, W, _ = x4.shape
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
     out = Bf16Planes.empty(B, K, Ho, Wo, x4.device)
@@ -556,7 +594,10 @@ def conv2d_fwd_c4_gdn_planes(x4, wp, bias, beta, gamma, K, R, S, stride, pad, be
     return out
 
 
-def conv2d_fwd_c4_gdn(x4, wp, bias, beta, gamma, K, R, S, stride, pad, inverse=False, beta_min=1e-6, out=None):
+def conv2d_fwd_c4_gdn(x4, wp, bias, beta, gamma, K, R, S, stride, pad, inverse=False, beta_min=1e-6, out=None, astream=None):
+    if c4gdn_supported(K, R, S, inverse) and _aligned16(bias, beta) and (out is None or _aligned16(out)):
+        return conv2d_c4_gdn_bf16x6(x4, astream if astream is not None else c4gdn_stream(wp, gamma, K, R, S), bias, beta, K, R, S,
+                                    stride, pad, beta_min, out=out)
     B, H, W, _ = x4.shape
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
     if out is None:

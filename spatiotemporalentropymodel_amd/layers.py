@@ -37,6 +37,7 @@ def weight_epoch(w):
 
 PACK_BF16X3 = -3          # _PackCache role of the pre-split bf16 image (csrc/conv_bf16x6.hip); not a stem_pack_* role
 PACK_BF16X3_GEN = -4      # ... in the layout of the general (128-column tiles, split-K) kernel
+PACK_C4GDN = -5           # A-operand stream of csrc/c4gdn_bf16x6.hip: first-layer weight AND the following GDN's gamma
 
 
 class _PackCache:
@@ -60,6 +61,16 @@ class _PackCache:
             key = (w._version, w.data_ptr(), weight_epoch(w), tuple(w.shape))
         self._c[role] = (key, wp)
         return wp
+
+    def get_c4gdn(self, w: torch.Tensor, gamma: torch.Tensor, K: int, R: int):
+        """the combined (first-layer weight, GDN gamma) stream of F.conv2d_c4_gdn_bf16x6, rebuilt when either parameter changed"""
+        key = tuple((t._version, t.data_ptr(), weight_epoch(t), tuple(t.shape)) for t in (w, gamma))
+        hit = self._c.get(PACK_C4GDN)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        st = F.c4gdn_stream(self.get(w, F.PACK_CONV_FWD_C4), gamma, K, R, R)
+        self._c[PACK_C4GDN] = (key, st)
+        return st
 
 
 def _flat_grad(p):
@@ -438,8 +449,9 @@ def _conv_gdn_fused(conv_mod, gdn, x):
         return F.deconv2d_gdn_fwd(F.to_nhwc(x), conv_mod._packs.get(w, F.PACK_DECONV_FWD), b, gdn.beta, gdn.gamma, K, R, R,
                                   conv_mod.stride, conv_mod.padding, conv_mod.output_padding, gdn.inverse, gdn.beta_min)
     if conv_mod.in_channels == 3 and F.nhwc_ld(x) is None:
+        ast = conv_mod._packs.get_c4gdn(w, gdn.gamma, K, R) if F.c4gdn_supported(K, R, R, gdn.inverse) else None
         return F.conv2d_fwd_c4_gdn(F.nchw3_to_nhwc4(x), conv_mod._packs.get(w, F.PACK_CONV_FWD_C4), b, gdn.beta, gdn.gamma, K, R, R,
-                                   conv_mod.stride, conv_mod.padding, gdn.inverse, gdn.beta_min)
+                                   conv_mod.stride, conv_mod.padding, gdn.inverse, gdn.beta_min, astream=ast)
     return F.conv2d_gdn_fwd(F.to_nhwc(x), conv_mod._packs.get(w, F.PACK_CONV_FWD, conv_mod._masked), b, gdn.beta, gdn.gamma, K, R, R,
                             conv_mod.stride, conv_mod.padding, gdn.inverse, gdn.beta_min)
 
@@ -535,8 +547,9 @@ class FusedSequential(nn.Sequential):
                 if (chain and gdn is not None and m.in_channels == 3 and not isinstance(x, F.Bf16Planes) and F.nhwc_ld(x) is None
                         and K <= 192):
                     wp = m._packs.get(m.weight, F.PACK_CONV_FWD_C4)
+                    ast = m._packs.get_c4gdn(m.weight, gdn.gamma, K, R) if F.c4gdn_supported(K, R, R) else None
                     x = self._timed(i, lambda: F.conv2d_fwd_c4_gdn_planes(F.nchw3_to_nhwc4(x), wp, m.bias, gdn.beta, gdn.gamma, K, R, R,
-                                                                          m.stride, m.padding, gdn.beta_min))
+                                                                          m.stride, m.padding, gdn.beta_min, astream=ast))
                     i = j
                     continue
                 if _bf16x6_eligible(m, x.shape) and (isinstance(x, F.Bf16Planes) or (chain and x.is_cuda)):

@@ -91,8 +91,11 @@ def _conv_gdn_vs_oracle(F, case, gdn):
             F.conv2d_bf16x6_fwd(xp, wp, dev(b), K, R, R, st, R // 2, planes_out=True, **kw)
 
 
-def test_first_layer_writes_the_same_values_as_planes(F):
-    """The 3-channel first layer stays on the fp32-MFMA kernel; its planes epilogue must hold exactly the fp32 result."""
+@pytest.mark.parametrize("route", ["bf16x6", "fp32-mfma"])
+def test_first_layer_writes_the_same_values_as_planes(F, monkeypatch, route):
+    """The 3-channel first layer + GDN (csrc/c4gdn_bf16x6.hip by default, igemm.hip's fp32-MFMA kernel with STEM_C4GDN_BF16X6=0):
+    its planes epilogue must hold exactly the fp32 result, and that result is the oracle's."""
+    monkeypatch.setenv("STEM_C4GDN_BF16X6", "1" if route == "bf16x6" else "0")
     x, w, b = rnd((2, 3, 40, 56), 21, 0, 1), (rnd((192, 3, 5, 5), 22) / np.sqrt(75)).astype(np.float32), rnd((192,), 23, -0.1, 0.1)
     beta, gamma = rnd((192,), 24, 0.5, 1.5), rnd((192, 192), 25, 0.0, 0.1)
     x4 = F.nchw3_to_nhwc4(dev(x))
@@ -101,6 +104,42 @@ def test_first_layer_writes_the_same_values_as_planes(F):
     yp = F.conv2d_fwd_c4_gdn_planes(x4, wp, dev(b), dev(beta), dev(gamma), 192, 5, 5, 2, 2)
     assert torch.equal(yp.merge(), y)
     assert_close(host(y), orc.gdn_fwd(orc.conv2d_fwd(x, w, b, 2, 2), beta, gamma), what="g_a.0 + GDN", floor=0.1)
+
+
+C4_CASES = [  # B, H, W, K, R, stride, pad
+    (2, 40, 56, 192, 5, 2, 2),
+    (1, 33, 47, 64, 5, 2, 2),        # ragged: 17 x 24 outputs, partial last workgroup, N = 64
+    (2, 24, 24, 128, 3, 1, 1),       # 3x3 stride 1, N = 128
+    (1, 9, 150, 192, 5, 2, 2),       # rows longer than a workgroup tile: tiles that straddle output rows
+    (3, 16, 16, 192, 1, 1, 0),       # 1x1: a single conv k-step with one pair
+]
+
+
+@pytest.mark.parametrize("case", C4_CASES)
+def test_first_layer_gdn_kernel_vs_oracle(F, case):
+    """csrc/c4gdn_bf16x6.hip on its own: conv (3 -> N) + GDN with the transposed contractions and the register hand-over of
+    the squared outputs, fp32 and planes output, against the oracle (priors.py:421-423, gdn.py:52-67); image borders, ragged
+    tiles, every supported N, bias present / absent."""
+    B, H, W, K, R, st, pad = case
+    x = rnd((B, 3, H, W), 71, 0, 1)
+    w, b = (rnd((K, 3, R, R), 72) / np.sqrt(3 * R * R)).astype(np.float32), rnd((K,), 73, -0.1, 0.1)
+    beta, gamma = rnd((K,), 74, 0.5, 1.5), (rnd((K, K), 75, 0.0, 0.1) + 0.1 * np.eye(K, dtype=np.float32)).astype(np.float32)
+    gamma[0, :4] = [0.0, 1e-7, -0.5, 3.0e-6]                     # below the reparametrisation bound 2^-18
+    assert F.c4gdn_supported(K, R, R)
+    x4 = F.nchw3_to_nhwc4(dev(x))
+    ast = F.c4gdn_stream(F.pack_weight(dev(w), F.PACK_CONV_FWD_C4), dev(gamma), K, R, R)
+    assert torch.equal(ast, F.c4gdn_stream(F.pack_weight(dev(w), F.PACK_CONV_FWD_C4), dev(gamma), K, R, R))
+    ref = orc.gdn_fwd(orc.conv2d_fwd(x, w, b, st, pad), beta, gamma)
+    y = F.conv2d_c4_gdn_bf16x6(x4, ast, dev(b), dev(beta), K, R, R, st, pad)
+    assert_close(host(y), ref, what=f"c4gdn {case}", floor=0.1)
+    yp = F.conv2d_c4_gdn_bf16x6(x4, ast, dev(b), dev(beta), K, R, R, st, pad, planes_out=True)
+    assert torch.equal(yp.merge(), y), "planes output != fp32 output"
+    y0 = F.conv2d_c4_gdn_bf16x6(x4, ast, None, dev(beta), K, R, R, st, pad)
+    assert_close(host(y0), orc.gdn_fwd(orc.conv2d_fwd(x, w, np.zeros(K, np.float32), st, pad), beta, gamma), what="no bias", floor=0.1)
+    # into a channel slice of a wider NHWC buffer
+    wide = torch.zeros(B, y.shape[2], y.shape[3], K + 64, device="cuda").permute(0, 3, 1, 2)
+    F.conv2d_c4_gdn_bf16x6(x4, ast, dev(b), dev(beta), K, R, R, st, pad, out=wide[:, 32:32 + K])
+    assert torch.equal(wide[:, 32:32 + K], y) and float(wide[:, :32].abs().max()) == 0 and float(wide[:, 32 + K:].abs().max()) == 0
 
 
 def test_analysis_transform_chain_vs_golden_and_fp32_kernels(F, golden, monkeypatch):
@@ -239,7 +278,7 @@ def test_engine_schedule_with_and_without_bf16_layers(monkeypatch):
     d = torch.device("cuda:0")
     y_cur = closed_form_input("eng:y", (2, 192, 16, 16), -6, 6).to(d)
     y_cond = closed_form_input("eng:c", (2, 192, 16, 16), -6, 6).to(d)
-    res = {}
+    res, acts = {}, {}
     for tag, on in (("bf16", True), ("fp32", False)):
         monkeypatch.setattr(E.StemEngine, "use_bx6", on)
         torch.manual_seed(0)
@@ -248,19 +287,39 @@ def test_engine_schedule_with_and_without_bf16_layers(monkeypatch):
         assert any(l.bx6 for l in eng.layers) == on
         for p in m.parameters():
             p.grad = None
+        kept = {}
+
+        def forward_keeping_activations(*a, _inner=eng.forward, _kept=kept, **kw):
+            r = _inner(*a, **kw)
+            _kept.update(r[3])
+            return r
+
+        eng.forward = forward_keeping_activations
         out = m(y_cur, y_cond)
         loss = sum(torch.log(l).sum() for l in out["likelihoods"].values()) / (-np.log(2) * 2 * 256 * 256)
         loss.backward()
         torch.cuda.synchronize()
-        res[tag] = (float(loss), {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters() if p.grad is not None})
+        res[tag] = (float(loss.detach()), {n: p.grad.detach().cpu().numpy().copy() for n, p in m.named_parameters() if p.grad is not None})
+        acts[tag] = {n: (kept[n] > 0).cpu() for n in ("he0", "he2", "hd0", "hd2", "tp0", "tp2", "e0", "e2")}
     assert abs(res["bf16"][0] - res["fp32"][0]) <= 1e-5 * abs(res["fp32"][0])
     assert res["bf16"][1].keys() == res["fp32"][1].keys() and len(res["fp32"][1]) > 30
-    # two fp32-accurate routes: each is within 1e-4 of the float64 reference in tests/test_hip_models.py; against each other the
-    # weight gradients (sums over pixels with cancellation) may sit up to 2e-4 of the tensor's largest entry apart
+    # Two fp32-accurate routes (each within 1e-4 of the float64 reference in tests/test_hip_models.py) compute every leaky-ReLU
+    # pre-activation to ~1e-6: an element that close to 0 can land on the other side of the kink, and its slope (1 vs 0.01) then
+    # changes that pixel's back-propagated gradient outright.  The kink decisions of both runs are compared element by element:
+    # with none flipped every gradient tensor is held to the parity bound (1e-4, elements below 0.1 max to 1e-5 max); each flip
+    # moves the weight gradients it feeds by ~1 / (pixels x sqrt(channels)) of their maximum, so with flips the bound is 2e-4 of
+    # the tensor's maximum and the flips are reported.
+    flips = {n: int((acts["bf16"][n] != acts["fp32"][n]).sum()) for n in acts["fp32"]}
+    nflip = sum(flips.values())
     worst = max((close_ratio(res["bf16"][1][n], g32, 0.1), n) for n, g32 in res["fp32"][1].items())
-    print(f"bf16 route vs fp32-MFMA route: worst gradient tensor {worst[1]} at {worst[0]:.2e} (elements below 0.1 max held to 1e-5 max)")
+    print(f"bf16 route vs fp32-MFMA route: {nflip} leaky-ReLU decisions differ {dict((k, v) for k, v in flips.items() if v)}; "
+          f"worst gradient tensor {worst[1]} at {worst[0]:.2e} (elements below 0.1 max held to 1e-5 max)")
+    assert nflip <= 4, flips
     for n, g32 in res["fp32"][1].items():
-        assert_close(res["bf16"][1][n], g32, rtol=1e-4, what=f"grad {n}", floor=0.1)
+        if nflip == 0:
+            assert_close(res["bf16"][1][n], g32, rtol=1e-4, what=f"grad {n}", floor=0.1)
+        else:
+            assert_close(res["bf16"][1][n], g32, rtol=2e-4, what=f"grad {n} ({nflip} kink flips)", floor=1.0)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -199,6 +199,9 @@ def test_rccl_world1_gop_accumulator_bit_identical_to_no_process_group(dp2_resul
     dp_worker.case_gop(0, 1, str(tmp_path), tag="local_gop")
     loc = dict(np.load(tmp_path / "local_gop_rank0.npz"))
     assert not bool(loc["active"][0])
-    np.testing.assert_array_equal(r["losses"], loc["losses"])
+    # loss / aux values are float64 sums of per-workgroup partials (last bit may differ run to run); clip norms, gradients and
+    # parameters come from fixed-order reductions and must be bit-identical
+    np.testing.assert_allclose(r["losses"], loc["losses"], rtol=1e-12)
+    np.testing.assert_array_equal(r["losses"][:, 1], loc["losses"][:, 1])
     for k in ("params_i", "params_p", "grad_i", "grad_p"):
         np.testing.assert_array_equal(r[k], loc[k], err_msg=k)

@@ -107,6 +107,24 @@ def test_bf16x6_analysis_conv_gdn_fullsize_vs_oracle(F):
     assert_close(y64.cpu().contiguous().numpy(), ref, what="bf16x6 g_a.2 + GDN at B=16, 64-pixel tiles", floor=0.1)
 
 
+def test_first_layer_gdn_fullsize_vs_oracle(F):
+    """g_a.0 + GDN g_a.1 at the benchmark shape (B=16, 3 x 256^2 -> 192 x 128^2) on csrc/c4gdn_bf16x6.hip, planes out (what the
+    bench's analysis transform runs), whole tensor against the oracle.  priors.py:421-423."""
+    from spatiotemporalentropymodel_amd.weights import closed_form_tensor
+    torch.manual_seed(22)
+    B, K = 16, 192
+    x = torch.rand(B, 3, 256, 256, device="cuda")
+    w, b = closed_form_tensor("g_a.0.weight", (K, 3, 5, 5)), closed_form_tensor("g_a.0.bias", (K,))
+    beta, gamma = closed_form_tensor("g_a.1.beta", (K,)), closed_form_tensor("g_a.1.gamma", (K, K))
+    assert F.c4gdn_supported(K, 5, 5)
+    ast = F.c4gdn_stream(F.pack_weight(w.cuda(), F.PACK_CONV_FWD_C4), gamma.cuda(), K, 5, 5)
+    yp = F.conv2d_c4_gdn_bf16x6(F.nchw3_to_nhwc4(x), ast, b.cuda(), beta.cuda(), K, 5, 5, 2, 2, planes_out=True)
+    y = yp.merge()
+    assert tuple(y.shape) == (B, K, 128, 128)
+    ref = orc.gdn_fwd(orc.conv2d_fwd(x.cpu().numpy(), w.numpy(), b.numpy(), 2, 2), beta.numpy(), gamma.numpy())
+    assert_close(y.cpu().contiguous().numpy(), ref, what="g_a.0 + GDN at B=16 (c4gdn_bf16x6, planes)", floor=0.1)
+
+
 @pytest.mark.parametrize("name,shape", [("TPM.2", (16, 256, 16, 16, 320, 5)), ("TPM.4", (16, 320, 16, 16, 384, 5)), ("EPM.0", (16, 1152, 16, 16, 768, 1))])
 def test_bf16x6_training_kernels_fullsize_vs_oracle(F, name, shape):
     """The kernels the bench's P-frame step runs for the stride-1 STEM layers, at their B=16 shapes and with the planner's own
