@@ -30,13 +30,14 @@
 namespace {
 
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CHUNK = 18432;                    // bytes of one A-operand chunk: 18 fragments x 64 lanes x 16 B
 constexpr int OOR = 0x7FFFFF00;                 // voffset that every buffer view rejects (returns 0)
+constexpr int OOR_ST = 0x7FFF0000;              // the same with room for the stores' constant offsets (views are < 0x7FFF0000 bytes)
 constexpr int WG_PIX = 128, NTHREADS = 256;     // 4 wavefronts x 32 pixels
 
 __host__ __device__ inline int rho(int r) { return 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3); }
-__host__ __device__ inline int group_size(int nb) { return nb == 6 ? 3 : (nb == 4 ? 2 : nb); }       // n-blocks per GDN pass
 
 __device__ inline void split3(const float x, __bf16 &h0, __bf16 &h1, __bf16 &h2)
 {
@@ -63,31 +64,28 @@ struct C4gArgs {
 // chunk t < ksc (conv k-step t): fragment (nb, plane) at ((nb * 3 + plane) * 64 + lane) * 16; lane (r, h) element j is the
 //   weight of channel nb * 32 + rho(r) for K slot (pair q = 2 t + h, tap j >> 2 of the pair, image channel j & 3), where pair q
 //   = (filter row q / PR, taps 2 (q % PR) and 2 (q % PR) + 1), PR = ceil(S / 2); slots beyond the filter hold 0;
-// chunk ksc + g * NB + kb (GDN pass g over k-block kb): fragment (s, nbl, plane) at (((s * GS + nbl) * 3 + plane) * 64 + lane) * 16;
-//   lane (r, h) element j = gamma'[(g * GS + nbl) * 32 + rho(r)][kb * 32 + 16 h + 8 s + j], gamma' = max(gamma, 2^-18)^2 - 2^-36
-//   (parametrizers.py:42-45).
+// chunk ksc + 2 kb + s (GDN k-step s of k-block kb): fragment (nb, plane) at the same place; lane (r, h) element j =
+//   gamma'[nb * 32 + rho(r)][kb * 32 + 16 h + 8 s + j], gamma' = max(gamma, 2^-18)^2 - 2^-36 (parametrizers.py:42-45).
 __global__ __launch_bounds__(256) void c4gdn_pack_kernel(const float *wp_c4, const float *gamma, unsigned char *out, int N, int R, int S, int ksc)
 {
-    const int NB = N / 32, GS = group_size(NB), NG = NB / GS, PR = (S + 1) / 2;
-    const int nchunks = ksc + NG * NB;
+    const int NB = N / 32, PR = (S + 1) / 2;
+    const int nchunks = ksc + 2 * NB;
     const int e = blockIdx.x * 256 + threadIdx.x;           // (chunk, fragment position without the plane, lane)
     const int lane = e & 63, fp = (e >> 6) % 6, c = (e >> 6) / 6;
     if (c >= nchunks) return;
     const int r = lane & 31, h = lane >> 5;
     float v[8];
-    bool used = true;
+    const int nb = fp;
+    const bool used = nb < NB;
     if (c < ksc) {
-        const int nb = fp;
-        used = nb < NB;
         const int ch = nb * 32 + rho(r), q = 2 * c + h, prow = q / PR, s0 = 2 * (q % PR);
         for (int j = 0; j < 8; ++j) {
             const int s = s0 + (j >> 2), cc = j & 3;
             v[j] = (used && prow < R && s < S) ? wp_c4[(ch * 32 + prow * S + s) * 4 + cc] : 0.f;      // channel 3 of the C4 pack is zero
         }
     } else {
-        const int gi = c - ksc, g = gi / NB, kb = gi - g * NB, s = fp / GS, nbl = fp - s * GS;
-        used = s < 2;
-        const int n = (g * GS + nbl) * 32 + rho(r), k0 = kb * 32 + 16 * h + 8 * s;
+        const int gi = c - ksc, kb = gi >> 1, s = gi & 1;
+        const int n = nb * 32 + rho(r), k0 = kb * 32 + 16 * h + 8 * s;
         for (int j = 0; j < 8; ++j) {
             float gv = 0.f;
             if (used) {
@@ -132,7 +130,6 @@ __device__ inline void lda(const unsigned char *p, bf16x8 (&af)[3])
 template <int NB>
 __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs a)
 {
-    constexpr int GS = NB == 6 ? 3 : (NB == 4 ? 2 : NB), NG = NB / GS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];          // [2][CHUNK]: the A-operand ring
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int p = lane & 31, h = lane >> 5;
@@ -146,26 +143,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
         bx = qx * a.stride - a.pad;
         pix0 = (b * a.H + by) * a.W + bx;              // pixel index of tap (0, 0); may be negative at the border (masked below)
     }
-    const int nchunks = a.ksc + NG * NB;
+    const int nchunks = a.ksc + 2 * NB;
     const int PR = (a.S + 1) / 2, npairs = a.R * PR;
 
     // ---- A-operand ring: chunk c -> buffer c & 1, 4.5 KiB per wavefront as four 1 KiB pieces and one half piece ---------------
-    // (wavefront w copies bytes [4096 w, 4096 w + 4096) and the half piece at 16384 + 512 w: one lane address, immediate offsets)
-    const unsigned char *ring_src = a.astream + wave * 4096 + lane * 16;
-    const unsigned char *ring_src_tail = a.astream + 16384 + wave * 512 + (lane & 31) * 16;
+    // (wavefront w copies bytes [4096 w, 4096 w + 4096) and the half piece at 16384 + 512 w; buffer form: one VGPR of lane
+    // offset, the chunk offset in an SGPR, the piece offsets as immediates)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(a.astream), 0, nchunks * CHUNK, 0x00020000);
+    const int ring_v = wave * 4096 + lane * 16, ring_vt = 16384 + wave * 512 + (lane & 31) * 16;
     auto ring_issue = [&](int c) {
         if (c >= nchunks) return;
-        const size_t co = (size_t)c * CHUNK;
+        const int co = c * CHUNK;
         unsigned char *dst = smem + (c & 1) * CHUNK;
-        const auto *gs = (const __attribute__((address_space(1))) void *)(ring_src + co);
         auto *ls = (__attribute__((address_space(3))) void *)(dst + wave * 4096);
-        __builtin_amdgcn_global_load_lds(gs, ls, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(gs, ls, 16, 1024, 0);
-        __builtin_amdgcn_global_load_lds(gs, ls, 16, 2048, 0);
-        __builtin_amdgcn_global_load_lds(gs, ls, 16, 3072, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, ls, 16, ring_v, co, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, ls, 16, ring_v, co, 1024, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, ls, 16, ring_v, co, 2048, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, ls, 16, ring_v, co, 3072, 0);
         if (lane < 32)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ring_src_tail + co),
-                                             (__attribute__((address_space(3))) void *)(dst + 16384 + wave * 512), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst + 16384 + wave * 512), 16, ring_vt, co, 0, 0);
     };
     // every wavefront waits for its own pieces, the barrier publishes all of them (and retires the buffer read last step)
     auto ring_wait = [&]() {
@@ -233,47 +229,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
         }
     }
 
-    // ---- GDN: NG passes over the k-blocks, GS output tiles each; B operand = the squared accumulators -----------------------------
+    // ---- GDN: 2 NB chunks of one k-step (16 channels of x^2) x NB output tiles; B operand = the squared accumulators ----------------
+    // outputs through buffer stores: one VGPR of pixel offset each (out of range for the pixels beyond M: dropped by the hardware)
     const int opix = NB * 192;
-    unsigned char *ypl = a.yp ? static_cast<unsigned char *>(a.yp) + (size_t)(ok ? m : 0) * opix + 32 * h : nullptr;
-    float *yf = a.y ? a.y + (size_t)(ok ? m : 0) * a.ldy + 16 * h : nullptr;
+    const __amdgpu_buffer_rsrc_t ryp = __builtin_amdgcn_make_buffer_rsrc(a.yp, 0, a.yp ? Mtot * opix : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ryf = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y ? (Mtot - 1) * a.ldy * 4 + a.N * 4 : 0, 0x00020000);
+    const int vyp = ok ? m * opix + 32 * h : OOR_ST, vyf = ok ? m * a.ldy * 4 + 64 * h : OOR_ST;
+    f32x16 nrm[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) nrm[nb][i] = 0.f;
     int c = a.ksc;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        f32x16 nrm[GS];
+    for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
-        for (int nbl = 0; nbl < GS; ++nbl)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) nrm[nbl][i] = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < NB; ++kb, ++c) {
+        for (int s = 0; s < 2; ++s, ++c) {
             ring_wait();
             ring_issue(c + 1);
             const unsigned char *buf = smem + (c & 1) * CHUNK + lane * 16;
+            bf16x8 b[3];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 b[3];
+            for (int j = 0; j < 8; ++j) {
+                const float v = x[kb][8 * s + j];
+                __bf16 h0, h1, h2;
+                split3(v * v, h0, h1, h2);
+                b[0][j] = h0; b[1][j] = h1; b[2][j] = h2;
+            }
+            bf16x8 af[2][3];
+            lda(buf, af[0]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float v = x[kb][8 * s + j];
-                    __bf16 h0, h1, h2;
-                    split3(v * v, h0, h1, h2);
-                    b[0][j] = h0; b[1][j] = h1; b[2][j] = h2;
-                }
-                bf16x8 af[2][3];
-                lda(buf + (s * GS) * 3072, af[0]);
-#pragma unroll
-                for (int nbl = 0; nbl < GS; ++nbl) {
-                    if (nbl + 1 < GS) lda(buf + (s * GS + nbl + 1) * 3072, af[(nbl + 1) & 1]);
-                    nrm[nbl] = mfma6(af[nbl & 1], b, nrm[nbl]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int nb = 0; nb < NB; ++nb) {
+                if (nb + 1 < NB) lda(buf + (nb + 1) * 3072, af[(nb + 1) & 1]);
+                nrm[nb] = mfma6(af[nb & 1], b, nrm[nb]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // epilogue of this pass: y = x * rsqrt(beta' + norm), 16 consecutive channels per lane and tile
+    }
+    {
+        // epilogue: y = x * rsqrt(beta' + norm), 16 consecutive channels per lane and tile
 #pragma unroll
-        for (int nbl = 0; nbl < GS; ++nbl) {
-            const int nb = g * GS + nbl;
+        for (int nb = 0; nb < NB; ++nb) {
             float yv[16];
 #pragma unroll
             for (int i4 = 0; i4 < 4; ++i4) {
@@ -281,20 +277,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float bb = fmaxf(bt[e], a.beta_bound);
-                    yv[4 * i4 + e] = x[nb][4 * i4 + e] * __builtin_amdgcn_rsqf(nrm[nbl][4 * i4 + e] + (bb * bb - 1.4551915228366852e-11f));
+                    yv[4 * i4 + e] = x[nb][4 * i4 + e] * __builtin_amdgcn_rsqf(nrm[nb][4 * i4 + e] + (bb * bb - 1.4551915228366852e-11f));
                 }
             }
-            if (!ok) continue;
-            if (yf) {
+            if (a.y) {
 #pragma unroll
                 for (int i4 = 0; i4 < 4; ++i4) {
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = yv[4 * i4 + e];
-                    *reinterpret_cast<f32x4 *>(yf + nb * 32 + 4 * i4) = o;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ryf, vyf + nb * 128 + 16 * i4, 0, 0);
                 }
             }
-            if (ypl) {
+            if (a.yp) {
                 bf16x8 q0[2], q1[2], q2[2];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -302,14 +297,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
                     split3(yv[i], h0, h1, h2);
                     q0[i >> 3][i & 7] = h0; q1[i >> 3][i & 7] = h1; q2[i >> 3][i & 7] = h2;
                 }
-                unsigned char *dst = ypl + nb * 192;
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    *reinterpret_cast<bf16x8 *>(dst + 16 * e) = q0[e];
-                    *reinterpret_cast<bf16x8 *>(dst + 64 + 16 * e) = q1[e];
-                    *reinterpret_cast<bf16x8 *>(dst + 128 + 16 * e) = q2[e];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0[e]), ryp, vyp + nb * 192 + 16 * e, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1[e]), ryp, vyp + nb * 192 + 64 + 16 * e, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q2[e]), ryp, vyp + nb * 192 + 128 + 16 * e, 0, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);         // one tile's epilogue at a time: 56 live registers instead of 3 x 56
         }
     }
 }
@@ -327,15 +322,14 @@ STEM_EXPORT int stem_c4gdn_supported(int N, int R, int S)
 STEM_EXPORT size_t stem_c4gdn_stream_bytes(int N, int R, int S)
 {
     if (!stem_c4gdn_supported(N, R, S)) return 0;
-    const int NB = N / 32, NG = NB / group_size(NB);
-    return (size_t)(conv_ksteps(R, S) + NG * NB) * CHUNK;
+    return (size_t)(conv_ksteps(R, S) + 2 * (N / 32)) * CHUNK;
 }
 
 STEM_EXPORT int stem_c4gdn_pack(const float *wp_c4, const float *gamma, void *astream, int N, int R, int S, void *stream)
 {
     STEM_CHECK_ARG(wp_c4 && gamma && astream, "stem_c4gdn_pack: null pointer");
     STEM_CHECK_ARG(stem_c4gdn_supported(N, R, S), "stem_c4gdn_pack: N must be 64, 128 or 192 and R*S <= 25 (N=%d R=%d S=%d)", N, R, S);
-    const int NB = N / 32, NG = NB / group_size(NB), ksc = conv_ksteps(R, S), nchunks = ksc + NG * NB;
+    const int ksc = conv_ksteps(R, S), nchunks = ksc + 2 * (N / 32);
     (void)hipMemsetAsync(astream, 0, (size_t)nchunks * CHUNK, (hipStream_t)stream);
     const int n = nchunks * 6 * 64;
     hipLaunchKernelGGL(c4gdn_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, wp_c4, gamma,
