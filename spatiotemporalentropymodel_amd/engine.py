@@ -42,6 +42,7 @@ class _Layer:
         self.wp6_fwd = self.wp6_dgrad = None
         self._slabs = {}
         self.pending = None       # (dwp, splits) of the last wgrad, consumed by StemEngine.unpack_all
+        self.lane = 0             # which weight-gradient stream this layer's wgrad / unpack runs on (StemEngine.side_stream)
 
     def bx6_eligible(self):
         return (self.kind == "conv" and self.stride == 1 and not self.masked and self.C % 32 == 0 and self.K % 32 == 0
@@ -85,7 +86,7 @@ class _Layer:
         are at hand, else from the fp32 tensors"""
         if not (self.wg6 and xp is not None and dyp is not None):
             return self.wgrad(x, dy)
-        side = self.eng.side_stream(dy.device)
+        side = self.eng.side_stream(dy.device, self.lane)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(dy.device))
             with torch.cuda.stream(side):
@@ -136,7 +137,7 @@ class _Layer:
         """packed slabs now, bias gradient straight into .grad; StemEngine.unpack_all() turns every layer's
         slabs into .grad tensors with one launch.  Runs on the engine's weight-gradient stream (nothing on the dgrad
         chain consumes it), ordered after everything the compute stream has queued so far."""
-        side = self.eng.side_stream(x.device)
+        side = self.eng.side_stream(x.device, self.lane)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(x.device))
             with torch.cuda.stream(side):
@@ -198,8 +199,14 @@ class StemEngine:
             first.need_dgrad = False
         self._pack_key = None
         self._pack_descs = None
-        self._side = None
+        self._side = {}
         self._checked = False
+        self._dgrad_pack_event = None
+        # the hyper path's weight gradients (HE, HD) queue on their own stream: the 13 weight-gradient launches of a step would
+        # otherwise run one after the other and finish ~0.3 ms after the last input-gradient kernel
+        if self.wgrad_lanes > 1:
+            for l in self.HE + self.HD:
+                l.lane = 1
         self._select_bx6()
 
     def _select_bx6(self):
@@ -229,24 +236,41 @@ class StemEngine:
     #: and overlap the latency-bound parts of the dgrad chain; set False to keep everything on the compute stream
     overlap_wgrad = os.environ.get("STEM_ENGINE_OVERLAP", "1") != "0"
 
-    def side_stream(self, device):
+    #: number of weight-gradient streams; 2 puts the hyper path's weight gradients on a stream of their own (measured on the
+    #: bench step, same box: 22.65-22.94 ms against 22.67-22.82 ms with one -- no gain, the step is throughput-bound; default 1)
+    wgrad_lanes = int(os.environ.get("STEM_ENGINE_WGRAD_LANES", "1"))
+    #: the next forward's weight packing is split: forward-role copies on the compute stream (the forward waits for them), the
+    #: input-gradient copies on a weight-gradient stream (only backward waits): 22.48-22.62 ms against 22.67-22.82 ms per bench
+    #: step; STEM_ENGINE_SPLIT_PACK=0: one launch each as before
+    split_pack = os.environ.get("STEM_ENGINE_SPLIT_PACK", "1") != "0"
+    #: the context model's convolution on a third forward stream (it depends on neither the TPM nor the hyper chain): measured
+    #: 24.3 ms against 22.7 ms per bench step -- three concurrent chains slow each other down more than the overlap gains;
+    #: off by default, kept as a switch
+    ctx_branch = os.environ.get("STEM_ENGINE_CTX_BRANCH", "0") != "0"
+
+    def side_stream(self, device, lane=0):
         if not self.overlap_wgrad or device.type != "cuda":
             return None
-        if self._side is None or self._side.device != device:
-            self._side = torch.cuda.Stream(device=device)
-        return self._side
+        st = self._side.get(lane)
+        if st is None or st.device != device:
+            st = self._side[lane] = F.make_stream(device, "side")
+        return st
 
     #: the hyper path (HE -> bottleneck -> HD) and the temporal / spatial priors are independent until the entropy-parameter
     #: network joins them: the hyper path runs on its own stream in forward and backward so that the ramp-up / drain of its
     #: small launches overlaps the other branch's kernels (30.90 -> 30.75 ms per bench step; STEM_ENGINE_BRANCH=0 disables)
     branch_streams = os.environ.get("STEM_ENGINE_BRANCH", "1") != "0"
 
-    def _branch(self, device):
+    def _branch(self, device, which=0):
         if not self.branch_streams or device.type != "cuda":
             return None
-        if getattr(self, "_bstream", None) is None or self._bstream.device != device:
-            self._bstream = torch.cuda.Stream(device=device)
-        return self._bstream
+        bs = getattr(self, "_bstreams", None)
+        if bs is None:
+            bs = self._bstreams = {}
+        st = bs.get(which)
+        if st is None or st.device != device:
+            st = bs[which] = F.make_stream(device, "side")
+        return st
 
     def ensure_packed(self):
         """(Re)build every layer's packed weight copies with ONE kernel launch when any weight changed.  Inside
@@ -264,18 +288,29 @@ class StemEngine:
             for l in self.layers:
                 l.alloc_packs(l.mod.weight.device)
             self._pack_descs = None
-        descs = [d for l in self.layers if not l.bx6 for d in l.pack_descs()]
-        if descs:
-            arr = (_lib.PackDesc * len(descs))(*descs)
-            F.pack_weights_multi(arr)
-        descs6 = [d for l in self.layers if l.bx6 for d in l.pack_descs6()]
-        if descs6:
-            F.pack_weights_bf16x3_multi((_lib.Bf16PackDesc * len(descs6))(*descs6))
+        dev = self.layers[0].mod.weight.device
+        side = self.side_stream(dev) if self.split_pack and not torch.cuda.is_current_stream_capturing() else None
+        roles = ((0, 1), (1, 2)) if side is not None else ((0, 2),)
+        for lo, hi in roles:                     # descriptor 0 of a layer = forward role, descriptor 1 = input-gradient role
+            on_side = side is not None and lo == 1
+            if on_side:
+                side.wait_stream(torch.cuda.current_stream(dev))      # the optimiser step that changed the weights
+            with (torch.cuda.stream(side) if on_side else contextlib.nullcontext()):
+                descs = [d for l in self.layers if not l.bx6 for d in l.pack_descs()[lo:hi]]
+                if descs:
+                    F.pack_weights_multi((_lib.PackDesc * len(descs))(*descs))
+                descs6 = [d for l in self.layers if l.bx6 for d in l.pack_descs6()[lo:hi]]
+                if descs6:
+                    F.pack_weights_bf16x3_multi((_lib.Bf16PackDesc * len(descs6))(*descs6))
+                if on_side:
+                    self._dgrad_pack_event = torch.cuda.Event()
+                    self._dgrad_pack_event.record(side)
         # masked == 2 zeroed taps of the context weight in place: refresh its version in the key
         self._pack_key = tuple((_layers.weight_epoch(l.mod.weight), l.mod.weight._version, l.mod.weight.data_ptr()) for l in self.layers)
 
     def unpack_all(self):
-        self._group_ready(self.layers, [])
+        for lane in sorted({l.lane for l in self.layers}):
+            self._group_ready([l for l in self.layers if l.lane == lane], [])
 
     #: optional callable(list_of_parameters): invoked during backward as soon as the gradients of a module group
     #: (EPM, context_prediction, TPM, HD + entropy_bottleneck, HE -- the order backward produces them) are final,
@@ -284,7 +319,7 @@ class StemEngine:
 
     def _group_ready(self, layers, extra_params):
         dev = layers[0].mod.weight.device
-        side = self.side_stream(dev)
+        side = self.side_stream(dev, layers[0].lane)
         if side is None:
             return self._group_ready_on_stream(layers, extra_params)
         # extra_params (entropy-bottleneck gradients) were produced on the compute stream: order them before the hook
@@ -303,8 +338,14 @@ class StemEngine:
                 self.grad_ready_hook(params)
 
     def join_side_stream(self):
-        if self._side is not None:
-            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+        for st in self._side.values():
+            torch.cuda.current_stream(st.device).wait_stream(st)
+
+    def _wait_dgrad_packs(self):
+        """backward's first consumer of an input-gradient weight copy: order it after the side-stream packing"""
+        if self._dgrad_pack_event is not None:
+            torch.cuda.current_stream().wait_event(self._dgrad_pack_event)
+            self._dgrad_pack_event = None
 
     # -------------------------------------------------------------------------------------------
     def forward(self, y_cur, y_cond, training: bool, rate_coef=None):
@@ -345,6 +386,15 @@ class StemEngine:
         main = torch.cuda.current_stream(dev) if bs is not None else None
         if bs is not None:
             bs.wait_stream(main)
+        # the context model's convolution needs only t_hat (the prologue's output): on a stream of its own, enqueued first so
+        # that it runs next to the hyper and TPM chains instead of after them
+        cs = self._branch(dev, 1) if (bs is not None and self.ctx_branch and fused and self.has_spm and self.has_tpm) else None
+        if cs is not None:
+            cs.wait_stream(main)
+            with torch.cuda.stream(cs):
+                self.CTX.fwd(t_hat, out=epm_in[:, o_ctx:o_ctx + P])
+            t_hat.record_stream(cs)
+            epm_in.record_stream(cs)
         split = F.Bf16Planes.split
         pl = {}             # planes copies of activations, kept for the weight gradients
         with (torch.cuda.stream(bs) if bs is not None else contextlib.nullcontext()):
@@ -387,7 +437,10 @@ class StemEngine:
             # gaussian_conditional.quantize(target, "noise" | "dequantize") with no means (:570-572, :853-855)
             if not fused:
                 t_hat = F.add(target, gc._noise_like(target)) if training else F.round_(target)
-            self.CTX.fwd(t_hat, out=epm_in[:, o_ctx:o_ctx + P])
+            if cs is not None:
+                main.wait_stream(cs)
+            else:
+                self.CTX.fwd(t_hat, out=epm_in[:, o_ctx:o_ctx + P])
         if bs is not None:
             main.wait_stream(bs)
         if self.EPM[0].bx6:
@@ -429,6 +482,7 @@ class StemEngine:
         o_tp, o_hp, o_ctx = k["offs"]
         gp = k["gp"]
         B, _, H, W = gp.shape
+        self._wait_dgrad_packs()
         dgp = F.empty_nhwc(B, 2 * Cin, H, W, gp.device)
         F.gc_backward(k["gc_out"], gp[:, :Cin], gp[:, Cin:], dlik_y, dgp[:, :Cin], dgp[:, Cin:], dy=None,
                       scale_bound=gc._scale_bound, lik_bound=gc._lik_bound)

@@ -30,6 +30,24 @@ def _stream():
         return torch.cuda.current_stream().cuda_stream
 
 
+_STREAM_PRIO = None
+
+
+def make_stream(device, role):
+    """A HIP stream for one of the schedule's roles -- "side" (weight gradients, hyper branch, auxiliary loss: work on or next to
+    the critical path of a P-frame step) or "latents" (the frozen analysis transform of the NEXT frame: long, throughput-only
+    kernels).  STEM_STREAM_PRIO="side=-1,latents=0" maps roles to HIP stream priorities (lower = more urgent; torch's default
+    stream has 0): with it the command processor dispatches the step's own small kernels ahead of the prefetch stream's."""
+    global _STREAM_PRIO
+    if _STREAM_PRIO is None:
+        _STREAM_PRIO = {}
+        for kv in os.environ.get("STEM_STREAM_PRIO", "").split(","):
+            if "=" in kv:
+                k, v = kv.split("=")
+                _STREAM_PRIO[k.strip()] = int(v)
+    return torch.cuda.Stream(device=device, priority=_STREAM_PRIO.get(role, 0))
+
+
 def _chk(rc):
     if rc != 0:
         _lib.check(rc)

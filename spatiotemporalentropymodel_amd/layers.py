@@ -95,7 +95,7 @@ _WGRAD_SIDE = {"enabled": True, "streams": {}, "queued": False, "keep": []}
 def wgrad_side_stream(device):
     st = _WGRAD_SIDE["streams"].get(device)
     if st is None:
-        st = _WGRAD_SIDE["streams"][device] = torch.cuda.Stream(device=device)
+        st = _WGRAD_SIDE["streams"][device] = F.make_stream(device, "side")
     return st
 
 

@@ -45,7 +45,7 @@ class LatentPrefetcher:
     def _enqueue(self, t):
         dev = self._frames[t].device
         if self._stream is None or self._stream.device != dev:
-            self._stream = torch.cuda.Stream(device=dev)
+            self._stream = F.make_stream(dev, "latents")
         with torch.cuda.stream(self._stream), torch.no_grad():
             self._ys[t] = self.imodel.getY(self._frames[t])
             self._events[t] = torch.cuda.Event()
@@ -60,7 +60,7 @@ class LatentPrefetcher:
         self._ys, self._events = [None] * n, [None] * n
         dev = self._frames[0].device
         if self._stream is None or self._stream.device != dev:
-            self._stream = torch.cuda.Stream(device=dev)
+            self._stream = F.make_stream(dev, "latents")
         if not frames_ready:
             self._stream.wait_stream(torch.cuda.current_stream(dev))      # the frames were produced on the compute stream
         self._next = 0
@@ -82,14 +82,18 @@ class LatentPrefetcher:
         return y, yq
 
 
-class LazyNorm:
-    """sqrt(sumsq) * scale, evaluated (one tiny kernel + a host sync) only if somebody looks at it"""
+class LazyScalar:
+    """A scalar that the step left in device memory on the auxiliary stream: a private copy (later steps do not overwrite it)
+    plus the event after which it is valid.  float() / tensor() wait for that event -- no host synchronisation unless
+    somebody looks at the value."""
 
-    def __init__(self, sumsq0, scale):
-        self._s, self._scale = sumsq0, scale
+    def __init__(self, value, event, scale=1.0, sqrt=False):
+        self._v, self._e, self._scale, self._sqrt = value, event, scale, sqrt
 
     def tensor(self):
-        return self._s.sqrt() * self._scale
+        torch.cuda.current_stream(self._v.device).wait_event(self._e)
+        v = self._v.reshape(())
+        return (v.sqrt() if self._sqrt else v) * self._scale if (self._sqrt or self._scale != 1.0) else v
 
     def __float__(self):
         return float(self.tensor())
@@ -107,12 +111,14 @@ class FusedPFrameStep:
         #: clear the gradient buffer inside the Adam pass (saves the 72 MB memset of the next step); set False to leave the
         #: gradients in place after step() for inspection -- they are then zeroed at the start of the next step instead
         self.clear_grad_in_adam = True
-        self._aux_stream = torch.cuda.Stream(device=eb.quantiles.device)
+        self._aux_stream = F.make_stream(eb.quantiles.device, "side")
+        self._aux_pending = False
 
     def step(self, y_cur, y_cond, num_pixels, grad_scale=1.0, reducer=None):
         """y_cur / y_cond: the frame's and the conditioning latents [B,C,h,w]; num_pixels = N*H*W of the FRAMES (EMLoss
         normalisation).  Returns (out, criterion_out, aux_loss, grad_norm) like selfcheck.p_frame_step; the loss entries
-        are 0-dim fp64 device tensors, grad_norm a LazyNorm."""
+        are 0-dim fp64 device tensors; aux_loss and grad_norm are LazyScalars (private copies, valid whenever they are read).
+        Call finish() before reading `entropy_bottleneck.quantiles` / the aux optimiser outside of step()."""
         stem, opt, aux_opt, eng = self.stem, self.opt, self.aux_opt, self.eng
         eb = stem.entropy_bottleneck
         if self._grad_clean and opt._dev is None:                   # cleared by the previous step's Adam pass
@@ -126,24 +132,38 @@ class FusedPFrameStep:
         if reducer is not None:
             reducer.finish() if hasattr(reducer, "finish") else reducer.all_reduce()
         join_wgrad_stream()
+        main = torch.cuda.current_stream(y_hat.device)
+        if self._aux_pending:                    # the previous step's auxiliary work reads the parameters Adam is about to change
+            main.wait_stream(self._aux_stream)
+            self._aux_pending = False
         F.sumsq(opt.flat.grad, opt._sumsq, overwrite=True)
-        gn = LazyNorm(opt._sumsq[0], grad_scale)
         clean = opt._dev is None and self.clear_grad_in_adam
         opt.step(grad_scale=grad_scale, norm_is_current=True, zero_grad=clean)
         self._grad_clean = clean
         # auxiliary loss on the UPDATED parameters (stem/trainSTEM.py:216-218); its gradient goes straight into the aux
         # optimiser's flat buffer (the only aux parameter is `entropy_bottleneck.quantiles`).  One workgroup of latency-bound
-        # work: it runs on its own stream, next to the weight re-packing of the next forward, and is joined lazily.
-        main = torch.cuda.current_stream(y_hat.device)
+        # work on its own stream; the training forward does not read the quantiles, so nothing waits for it until the NEXT
+        # optimiser step (above) or until the caller looks at the returned values (LazyScalar).
         self._aux_stream.wait_stream(main)
         with torch.cuda.stream(self._aux_stream):
+            gn_copy = opt._sumsq[:1].clone()     # private copies: the persistent buffers are overwritten by the next step
             pack = F.eb_pack(eb._tensors14())
             F.eb_aux_loss_grad(eb.quantiles.detach(), pack, eb.target, eb.quantiles._flat_grad_view, loss_out=self._aux_loss)
             eb.quantiles.grad = eb.quantiles._flat_grad_view
             aux_opt.step()
-        eng.ensure_packed()                      # the next forward's weight packing, issued now: the aux work hides behind it
-        main.wait_stream(self._aux_stream)
+            aux_copy = self._aux_loss.clone()
+            done = torch.cuda.Event()
+            done.record(self._aux_stream)
+        self._aux_pending = True
+        eng.ensure_packed()                      # the next forward's weight packing, issued now
         loss3 = k["loss3"]
         out = {"y_hat": y_hat, "likelihoods": {"y": lik_y, "z": lik_z}}
         oc = {"y_bpp_loss": loss3[0], "z_bpp_loss": loss3[1], "loss": loss3[2]}
-        return out, oc, self._aux_loss[0], gn
+        return out, oc, LazyScalar(aux_copy, done), LazyScalar(gn_copy, done, scale=grad_scale, sqrt=True)
+
+    def finish(self):
+        """order everything the step left on its auxiliary stream before the current stream (end of training, checkpointing,
+        evaluation: anything that reads `entropy_bottleneck.quantiles` or the aux optimiser's state)"""
+        if self._aux_pending:
+            torch.cuda.current_stream(self._aux_loss.device).wait_stream(self._aux_stream)
+            self._aux_pending = False

@@ -131,6 +131,7 @@ def case_train_fused(rank, world, out_dir, steps=2, tag="train_fused"):
             dump["grad_avg"] = flat_np(opt.flat.grad) * red.grad_scale
         y_cond = out["y_hat"]
         dump[f"s{t}:loss"] = np.array([float(oc["loss"]), float(gn), float(aux)])
+    fused.finish()
     torch.cuda.synchronize()
     dump["params"] = flat_np(opt.flat.data)
     dump["quantiles"] = flat_np(aux_opt.flat.data)

@@ -65,3 +65,19 @@ for r in rows[1:]:
 print("largest idle-gap contexts (after -> before), count, total us:")
 for k, v in sorted(ctx.items(), key=lambda kv: -kv[1][1])[:24]:
     print(f"  {v[1]:8.0f} us {v[0]:4d} x {v[1] / v[0]:6.1f}  {k[0]}  ->  {k[1]}")
+
+# optional Gantt listing: TIMELINE_DUMP_MS=<ms> prints every kernel that starts within that many ms after the LAST launch of
+# TIMELINE_DUMP_FROM (default: adam_kernel) in the first half of the window -- one optimisation step, stream by stream
+import os
+if os.environ.get("TIMELINE_DUMP_MS"):
+    span_ns = float(os.environ["TIMELINE_DUMP_MS"]) * 1e6
+    key = os.environ.get("TIMELINE_DUMP_FROM", "adam_kernel")
+    marks = [r for r in rows if key in r[2]]
+    start = marks[len(marks) // 2][0] if marks else rows[0][0]
+    streams = {}
+    print(f"\nkernels starting within {span_ns / 1e6:.1f} ms of a '{key}' launch (start us, duration us, stream, name):")
+    for s, e, n, q, st in rows:
+        if start <= s < start + span_ns:
+            sid = streams.setdefault((q, st), len(streams))
+            name = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
+            print(f"{(s - start) / 1e3:9.1f} {(e - s) / 1e3:8.1f}  s{sid}  {'    ' * sid}{name}")
