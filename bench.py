@@ -70,24 +70,45 @@ def _cpu_model():
     return "unknown"
 
 
-def _median_time(fn, repeats=3):
-    """one untimed warm-up call, then the median wall time of `repeats` calls"""
-    fn()
+def _physical_cores():
+    """distinct (socket, core) pairs of /proc/cpuinfo; os.cpu_count() (logical CPUs) when that cannot be read"""
+    try:
+        cores, phys = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cores.add((phys, line.split(":", 1)[1].strip()))
+        if cores:
+            return len(cores)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
+def _median_time(fn, repeats=3, warmup=1, budget_s=None):
+    """`warmup` untimed calls, then the median wall time of up to `repeats` calls (at least 3; stops early once `budget_s`
+    seconds of timed calls have been spent)"""
+    for _ in range(warmup):
+        fn()
     ts = []
     for _ in range(repeats):
         t0 = time.perf_counter()
         fn()
         ts.append(time.perf_counter() - t0)
+        if budget_s is not None and len(ts) >= 3 and sum(ts) + ts[-1] > budget_s:
+            break
     return float(np.median(ts)), ts
 
 
-def cpu_baseline(budget_s=45.0):
-    """The reference's CPU path as it can be represented on this box: the fp32 port of the
-    path on the host BLAS (oracle/stem_port_blas.py: im2col + SGEMM per convolution, what torch-CPU/MKL-DNN does for the
-    reference; elementwise entropy-model pieces from oracle/stem_oracle.c), all host cores, warm-up then median of 3:
+def cpu_baseline(budget_s=75.0):
+    """The reference's CPU path as it can be represented on this box: the fp32 port of
+    the path on the host BLAS (oracle/stem_port_blas.py: im2col + SGEMM per convolution, what torch-CPU / MKL-DNN does for the
+    reference; elementwise entropy-model pieces from oracle/stem_oracle.c), BLAS threads = the box's PHYSICAL cores:
 
-      (i)  config 2: one P-frame optimisation step at batch B (g_a of the frame, STEM forward, EMLoss, backward, global-norm
-           clip + Adam) -- B = the largest of 16/8/4/2 whose warm-up + 5 timed runs fit the time budget;
+      (i)  config 2: one P-frame optimisation step at B = 16 (g_a of the frame, STEM forward, EMLoss, backward, global-norm
+           clip + Adam): 2 warm-ups, then the median of up to 10 runs -- fewer (never under 3) when 10 would take more than
+           `budget_s` seconds, because the default bench run has to finish within minutes; the record says how many;
       (ii) config 1: forward of one 7x256x256 septuplet through the small model (7 g_a, 6 STEM forwards, 6 g_s).
 
     value = frames/s of (i) over a septuplet schedule (7 g_a + 6 P-steps per 7 frames), like the GPU number."""
@@ -95,8 +116,11 @@ def cpu_baseline(budget_s=45.0):
     import stem_oracle as orc
     import stem_port_blas as port
     from spatiotemporalentropymodel_amd.weights import closed_form_tensor
+    cores = _physical_cores()
+    limiter = None
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
+        limiter = threadpool_limits(limits=cores, user_api="blas")
         blas_threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
     except Exception:
         blas_threads = os.cpu_count() or 1
@@ -161,13 +185,10 @@ def cpu_baseline(budget_s=45.0):
                 ssd[k] -= np.float32(1e-4 / c1) * m / (np.sqrt(v / np.float32(c2)) + np.float32(1e-8))
             return t_ga
 
-        t0 = time.perf_counter()
-        p_step(2)                                        # warms the BLAS threads / page cache and sizes the real run
-        est = (time.perf_counter() - t0) / 2
-        B = next((b for b in (16, 8, 4, 2) if 6 * est * b <= 1.5 * budget_s), 2)
+        B = BATCH
         ga_times = []
-        t_step, step_times = _median_time(lambda: ga_times.append(p_step(B)), repeats=5)
-        t_ga = float(np.median(ga_times[1:]))
+        t_step, step_times = _median_time(lambda: ga_times.append(p_step(B)), repeats=10, warmup=2, budget_s=budget_s)
+        t_ga = float(np.median(ga_times[2:]))
         t_stem = t_step - t_ga
         # ---- (ii) config 1: small model, one septuplet forward (eval)
         isd1, ssd1 = transforms(64, 96), stem_weights(64, 96)
@@ -183,12 +204,16 @@ def cpu_baseline(budget_s=45.0):
 
         t_sept1, _ = _median_time(septuplet_forward)
     t_sept = FRAMES * t_ga + (FRAMES - 1) * t_stem
+    if limiter is not None:
+        limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
     return {"value": FRAMES * B / t_sept, "unit": "frames/s", "cores": int(blas_threads), "kind": "port",
-            "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(), "batch": B,
+            "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(), "host_physical_cores": cores, "batch": B,
+            "warmup_runs": 2, "timed_runs": len(step_times),
             "p_step_s": t_step, "p_step_runs_s": [round(t, 4) for t in step_times], "g_a_s": t_ga,
             "config1_septuplet_forward_s": t_sept1,
             "sample": f"oracle/stem_port_blas.py (fp32 im2col + SGEMM on the host BLAS, {blas_threads} threads) on {_cpu_model()}: "
-                      f"config-2 P-frame step at B={B} (g_a {t_ga:.2f} s + STEM fwd/bwd/clip/Adam {t_stem:.2f} s; 1 warm-up, median of 5), "
+                      f"config-2 P-frame step at B={B} (g_a {t_ga:.2f} s + STEM fwd/bwd/clip/Adam {t_stem:.2f} s; 2 warm-ups, median of "
+                      f"{len(step_times)} runs{'' if len(step_times) == 10 else ' (10 would exceed the %d s budget of a default bench run)' % int(budget_s)}), "
                       f"septuplet = 7 g_a + 6 P-steps -> {FRAMES * B / t_sept:.2f} frames/s; config-1 septuplet forward (small model) "
                       f"{t_sept1:.2f} s = {FRAMES / t_sept1:.2f} frames/s"}
 

@@ -309,30 +309,30 @@ class EntropyModel(nn.Module):
         return outputs
 
     def _pmf_to_cdf(self, pmf, tail_mass, pmf_length, max_length):
-        cdf = torch.zeros((len(pmf_length), max_length + 2), dtype=torch.int32)
-        for i, p in enumerate(pmf):
-            prob = torch.cat((p[: pmf_length[i]], tail_mass[i]), dim=0)
-            _cdf = pmf_to_quantized_cdf(prob, self.entropy_coder_precision)
-            cdf[i, : _cdf.size(0)] = _cdf
-        return cdf
+        """One quantised CDF row per distribution: its first pmf_length[i] masses followed by the tail mass, through
+        pmf_to_quantized_cdf at the coder's precision, zero-padded to max_length + 2 entries (entropy_models.py:170-176)."""
+        rows = torch.zeros((len(pmf_length), int(max_length) + 2), dtype=torch.int32)
+        for row, masses, tail, n in zip(rows, pmf, tail_mass, pmf_length):
+            q = pmf_to_quantized_cdf(torch.cat((masses[: int(n)], tail), dim=0), self.entropy_coder_precision)
+            row[: q.numel()] = q
+        return rows
+
+    @staticmethod
+    def _require_table(t, ndim, missing, what):
+        # the reference's messages (entropy_models.py:178-199): callers and tests match on them
+        if t.numel() == 0:
+            raise ValueError(f"Uninitialized {missing}. Run update() first")
+        if t.dim() != ndim:
+            raise ValueError(f"Invalid {what} size {t.size()}")
 
     def _check_cdf_size(self):
-        if self._quantized_cdf.numel() == 0:
-            raise ValueError("Uninitialized CDFs. Run update() first")
-        if len(self._quantized_cdf.size()) != 2:
-            raise ValueError(f"Invalid CDF size {self._quantized_cdf.size()}")
+        self._require_table(self._quantized_cdf, 2, "CDFs", "CDF")
 
     def _check_offsets_size(self):
-        if self._offset.numel() == 0:
-            raise ValueError("Uninitialized offsets. Run update() first")
-        if len(self._offset.size()) != 1:
-            raise ValueError(f"Invalid offsets size {self._offset.size()}")
+        self._require_table(self._offset, 1, "offsets", "offsets")
 
     def _check_cdf_length(self):
-        if self._cdf_length.numel() == 0:
-            raise ValueError("Uninitialized CDF lengths. Run update() first")
-        if len(self._cdf_length.size()) != 1:
-            raise ValueError(f"Invalid offsets size {self._cdf_length.size()}")
+        self._require_table(self._cdf_length, 1, "CDF lengths", "offsets")
 
     def host_tables(self) -> _Tables:
         """(cdf, length, offset) as dense host arrays, cached until the next update()/load_state_dict."""
@@ -437,28 +437,24 @@ class EntropyBottleneck(EntropyModel):
         return logits
 
     def update(self, force=False):
+        """Host side, once per model: the integer CDF tables of the learned density on the support the quantiles span
+        (entropy_models.py:341-381; the arithmetic order is the reference's, the tables are compared entry by entry)."""
         if self._offset.numel() > 0 and not force:
             return False
-        q = self.quantiles.detach().cpu()
-        medians = q[:, 0, 1]
-        minima = torch.clamp(torch.ceil(medians - q[:, 0, 0]).int(), min=0)
-        maxima = torch.clamp(torch.ceil(q[:, 0, 2] - medians).int(), min=0)
-        pmf_start = medians - minima
-        pmf_length = maxima + minima + 1
-        max_length = pmf_length.max()
-        samples = torch.arange(max_length)
-        samples = samples[None, :] + pmf_start[:, None, None]
-        half = float(0.5)
-        lower = self._logits_cumulative_host(samples - half)
-        upper = self._logits_cumulative_host(samples + half)
-        sign = -torch.sign(lower + upper)
-        pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
-        pmf = pmf[:, 0, :]
-        tail_mass = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
+        lo_q, med, hi_q = self.quantiles.detach().cpu()[:, 0, :].unbind(dim=1)
+        left = torch.clamp(torch.ceil(med - lo_q).int(), min=0)           # integer steps covered below / above the median
+        right = torch.clamp(torch.ceil(hi_q - med).int(), min=0)
+        length = right + left + 1
+        longest = length.max()
+        grid = torch.arange(longest)[None, :] + (med - left)[:, None, None]      # [C, 1, longest] sample positions
+        lower, upper = self._logits_cumulative_host(grid - 0.5), self._logits_cumulative_host(grid + 0.5)
+        flip = -torch.sign(lower + upper)                  # evaluate the difference of sigmoids on the numerically safe side
+        mass = torch.abs(torch.sigmoid(flip * upper) - torch.sigmoid(flip * lower))[:, 0, :]
+        tails = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
         dev = self.quantiles.device
-        self._quantized_cdf = self._pmf_to_cdf(pmf, tail_mass, pmf_length, max_length).to(dev)
-        self._offset = (-minima).to(dev)
-        self._cdf_length = (pmf_length + 2).to(dev)
+        self._quantized_cdf = self._pmf_to_cdf(mass, tails, length, longest).to(dev)
+        self._offset = (-left).to(dev)
+        self._cdf_length = (length + 2).to(dev)
         self._tables = None
         return True
 
@@ -553,30 +549,29 @@ class GaussianConditional(EntropyModel):
         return scipy.stats.norm.ppf(quantile)
 
     def update_scale_table(self, scale_table, force=False):
+        """Install a scale table and rebuild the CDF tables; a no-op (False) when tables exist and force is not set
+        (entropy_models.py:535-541)."""
         if self._offset.numel() > 0 and not force:
             return False
-        device = self.scale_table.device
-        self.scale_table = self._prepare_scale_table(scale_table).to(device)
+        self.scale_table = self._prepare_scale_table(scale_table).to(self.scale_table.device)
         self.update()
         return True
 
     def update(self):
-        """Host side, once per model (entropy_models.py:543-568)."""
-        table = self.scale_table.detach().cpu()
-        multiplier = -self._standardized_quantile(self.tail_mass / 2)
-        pmf_center = torch.ceil(table * multiplier).int()
-        pmf_length = 2 * pmf_center + 1
-        max_length = torch.max(pmf_length).item()
-        samples = torch.abs(torch.arange(max_length).int() - pmf_center[:, None]).float()
-        samples_scale = table.unsqueeze(1).float()
-        upper = self._standardized_cumulative((0.5 - samples) / samples_scale)
-        lower = self._standardized_cumulative((-0.5 - samples) / samples_scale)
-        pmf = upper - lower
-        tail_mass = 2 * lower[:, :1]
+        """Host side, once per model (entropy_models.py:543-568): per table scale the zero-mean Gaussian's mass on the integers
+        within the tail_mass quantile, symmetric about 0, as integer CDF rows."""
+        sigma = self.scale_table.detach().cpu()
+        reach = torch.ceil(sigma * (-self._standardized_quantile(self.tail_mass / 2))).int()      # half width of the support
+        length = 2 * reach + 1
+        longest = torch.max(length).item()
+        dist = torch.abs(torch.arange(longest).int() - reach[:, None]).float()                    # |k - centre|
+        s = sigma.unsqueeze(1).float()
+        upper = self._standardized_cumulative((0.5 - dist) / s)
+        lower = self._standardized_cumulative((-0.5 - dist) / s)
         dev = self.scale_table.device
-        self._quantized_cdf = self._pmf_to_cdf(pmf, tail_mass, pmf_length, max_length).to(dev)
-        self._offset = (-pmf_center).to(dev)
-        self._cdf_length = (pmf_length + 2).to(dev)
+        self._quantized_cdf = self._pmf_to_cdf(upper - lower, 2 * lower[:, :1], length, longest).to(dev)
+        self._offset = (-reach).to(dev)
+        self._cdf_length = (length + 2).to(dev)
         self._tables = None
 
     def forward(self, inputs, scales, means=None):
