@@ -231,6 +231,8 @@ def bench_roi(args):
     from spatiotemporalentropymodel_amd.optim import configure_optimizers
     from spatiotemporalentropymodel_amd.selfcheck import roi_gop_step
     _lib.hip()
+    if os.environ.get("STEM_BENCH_BX6_TILE"):                   # sweep aid: force the 192-column kernel's pixel tile (64 / 128)
+        _lib.check(_lib.hip().stem_tuning_set(b"bx6_tile", int(os.environ["STEM_BENCH_BX6_TILE"])))
     rank, world, local = D.init_from_env()
     assert world == args.gpus and torch.cuda.is_available()
     dev = torch.device("cuda", local)

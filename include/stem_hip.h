@@ -360,6 +360,11 @@ size_t stem_bf16x3_planes_bytes(long npix, int C);
 size_t stem_bf16x3_conv_weight_bytes(int C, int R, int S);
 int stem_bf16x3_split_nhwc(const float *x, int ldx, void *xp, long npix, int C, void *stream);
 int stem_bf16x3_merge_nhwc(const void *xp, float *x, int ldx, long npix, int C, void *stream);
+/* planes of x * (z > 0 ? 1 : slope): the gradient entering a convolution whose output z went through leaky_relu(., slope)
+ * (what autograd computes as LeakyReluBackward before ConvolutionBackward, stem_roi.py's conv + LeakyReLU pairs), split in
+ * the same pass for the bf16 input-gradient / weight-gradient kernels */
+int stem_bf16x3_split_dact_nhwc(const float *x, int ldx, const float *z, int ldz, float slope, void *xp, long npix, int C,
+                                void *stream);
 /* w: the torch Conv2d weight [N][C][R][S] (NOT one of the stem_pack_* layouts); N <= 192, R*S <= 25 */
 int stem_bf16x3_pack_conv_weight(const float *w, void *wp, int N, int C, int R, int S, void *stream);
 /* y = conv(x) + bias, followed by GDN when beta/gamma are given (gdn.py:52-67; stored parameters, reparametrised on the fly).
@@ -371,6 +376,13 @@ int stem_conv2d_fwd_c4_gdn_planes(const float *x4, const float *wp, const float 
 int stem_conv2d_bf16x6_fwd(const void *xp, const void *wp, const float *bias, const float *beta, const float *gamma,
                            float beta_min, float *y, int ldy, void *yp, int B, int H, int W, int C, int N, int R, int S,
                            int stride, int pad, void *stream);
+/* the same kernel for the conv + LeakyReLU / ReLU pairs of the layer-wise models at large pixel counts (stem_roi.py:520-608,
+ * stem_utils.py:24-63): act = 1 applies leaky_relu(., slope) after the bias.  stem_bf16x3_pack_conv_weight_flip packs the
+ * operand of the INPUT GRADIENT of a stride-1 convolution with torch weight w[C][N][R][S] (N = its input channels <= 192):
+ * that gradient is stem_conv2d_bf16x6_fwd_act(dy planes, flipped pack, no bias) with the same padding.                      */
+int stem_conv2d_bf16x6_fwd_act(const void *xp, const void *wp, const float *bias, int act, float slope, float *y, int ldy, void *yp,
+                               int B, int H, int W, int C, int N, int R, int S, int stride, int pad, void *stream);
+int stem_bf16x3_pack_conv_weight_flip(const float *w, void *wp, int N, int C, int R, int S, void *stream);
 /* First analysis layer + its GDN as ONE kernel on the bf16 matrix cores (csrc/c4gdn_bf16x6.hip): replaces
  * `self.g_a[0:2]` = conv(3, N) ; GDN(N) of compressai/models/priors.py:421-423 (gdn.py:52-67) under no_grad
  * (stem/trainSTEM.py:128,171).  N = 64, 128 or 192 (stem_c4gdn_supported), R*S <= 25.  Both contractions run as six bf16

@@ -91,6 +91,7 @@ _HIP_SIG = {
     "stem_bf16x3_conv_weight_bytes": [ci, ci, ci],
     "stem_bf16x3_split_nhwc": [vp, ci, vp, C.c_long, ci, vp],
     "stem_bf16x3_merge_nhwc": [vp, vp, ci, C.c_long, ci, vp],
+    "stem_bf16x3_split_dact_nhwc": [vp, ci, vp, ci, cf, vp, C.c_long, ci, vp],
     "stem_bf16x3_pack_conv_weight": [vp, vp, ci, ci, ci, ci, vp],
     "stem_bf16x3_conv_weight_gen_bytes": [ci, ci, ci, ci],
     "stem_bf16x3_pack_conv_weight_gen": [vp, vp, ci, ci, ci, ci, ci, vp],
@@ -107,6 +108,8 @@ _HIP_SIG = {
     "stem_c4gdn_stream_bytes": [ci, ci, ci],
     "stem_c4gdn_pack": [vp, vp, vp, ci, ci, ci, vp],
     "stem_conv2d_c4_gdn_bf16x6": [vp, vp, vp, vp, cf, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_conv2d_bf16x6_fwd_act": [vp, vp, vp, ci, cf, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_bf16x3_pack_conv_weight_flip": [vp, vp, ci, ci, ci, ci, vp],
     "stem_conv2d_bf16x6_fwd": [vp, vp, vp, vp, vp, cf, vp, ci, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_ar_decode_batch_pipelined": [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf,
                                        vp, vp, vp, ci, ci, vp, vp, vp],

@@ -239,6 +239,10 @@ __global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
         const float bias = (a.bias && n < a.N) ? a.bias[n] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] += bias;
+        if (a.epi == 1) {          // leaky ReLU (slope 0 = ReLU) of a conv + activation pair (layer-wise models)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = acc[j][r] > 0.f ? acc[j][r] : acc[j][r] * a.slope;
+        }
     }
     if (a.fuse) {
         // norm[px][i] = beta'[i] + sum_j gamma'[i][j] v[px][j]^2 (gdn.py:52-67): second contraction, K = N, fp32 MFMA; the squared
@@ -710,6 +714,33 @@ __global__ __launch_bounds__(256) void split_nhwc_kernel(const float *x, int ldx
     *reinterpret_cast<bf16x8 *>(dst + 128) = h2;
 }
 
+// dy * (z > 0 ? 1 : slope) -> planes: the gradient that reaches a convolution whose output was activated (z = that output),
+// split for the bf16 input-gradient / weight-gradient kernels in the pass that applies the leaky-ReLU derivative
+__global__ __launch_bounds__(256) void split_dact_nhwc_kernel(const float *x, int ldx, const float *z, int ldz, float slope, unsigned char *xp,
+                                                              long npieces, int nslab)
+{
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= npieces) return;
+    const long pix = e / (nslab * 4);
+    const int rem = (int)(e - pix * (nslab * 4)), sl = rem >> 2, p = rem & 3;
+    const float *src = x + pix * ldx + sl * 32 + p * 8, *zs = z + pix * ldz + sl * 32 + p * 8;
+    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
+    const f32x4 z0 = *reinterpret_cast<const f32x4 *>(zs), z1 = *reinterpret_cast<const f32x4 *>(zs + 4);
+    bf16x8 h0, h1, h2;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        __bf16 x0, x1, x2;
+        split3(z0[c] > 0.f ? v0[c] : v0[c] * slope, x0, x1, x2);
+        h0[c] = x0; h1[c] = x1; h2[c] = x2;
+        split3(z1[c] > 0.f ? v1[c] : v1[c] * slope, x0, x1, x2);
+        h0[4 + c] = x0; h1[4 + c] = x1; h2[4 + c] = x2;
+    }
+    unsigned char *dst = xp + pix * (long)(nslab * 192) + sl * 192 + p * 16;
+    *reinterpret_cast<bf16x8 *>(dst) = h0;
+    *reinterpret_cast<bf16x8 *>(dst + 64) = h1;
+    *reinterpret_cast<bf16x8 *>(dst + 128) = h2;
+}
+
 // planes -> fp32 NHWC (tests / debugging): the three planes add up to the fp32 value exactly
 __global__ __launch_bounds__(256) void merge_planes_kernel(const unsigned char *xp, float *x, int ldx, long nelem, int C)
 {
@@ -723,7 +754,9 @@ __global__ __launch_bounds__(256) void merge_planes_kernel(const unsigned char *
 
 // torch Conv2d weight [N][C][R][S] fp32 -> per chunk q = slab * R*S + tap the LDS image [plane][192 rows][64 B], piece p of
 // row n stored at p ^ ((n >> 2) & 3); rows n >= N are zero
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, unsigned char *wp, int N, int C, int RS, long npieces)
+// flip: the operand of the INPUT GRADIENT of a stride-1 convolution whose torch weight is w[C][N][R][S] (rows n = the forward
+// layer's input channels, contraction channels = its output channels, taps mirrored)
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, unsigned char *wp, int N, int C, int RS, long npieces, int flip)
 {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= npieces) return;
@@ -734,7 +767,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, unsign
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int ch = slab * 32 + p * 8 + c;
-        const float v = n < N ? w[((size_t)n * C + ch) * RS + tap] : 0.f;
+        const float v = n < N ? (flip ? w[((size_t)ch * N + n) * RS + (RS - 1 - tap)] : w[((size_t)n * C + ch) * RS + tap]) : 0.f;
         __bf16 x0, x1, x2;
         split3(v, x0, x1, x2);
         h[0][c] = x0; h[1][c] = x1; h[2][c] = x2;
@@ -762,6 +795,18 @@ STEM_EXPORT int stem_bf16x3_split_nhwc(const float *x, int ldx, void *xp, long n
     return 0;
 }
 
+STEM_EXPORT int stem_bf16x3_split_dact_nhwc(const float *x, int ldx, const float *z, int ldz, float slope, void *xp, long npix, int C, void *stream)
+{
+    STEM_CHECK_ARG(x && z && xp && npix >= 0 && C > 0 && C % 32 == 0 && ldx >= C && ldx % 4 == 0 && ldz >= C && ldz % 4 == 0,
+                   "stem_bf16x3_split_dact_nhwc: channels must be a multiple of 32 and rows 16-byte aligned (C=%d ldx=%d ldz=%d)", C, ldx, ldz);
+    const long np = npix * (C / 32) * 4;
+    if (np == 0) return 0;
+    hipLaunchKernelGGL(split_dact_nhwc_kernel, dim3((unsigned)cdivz(np, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, z, ldz, slope,
+                       static_cast<unsigned char *>(xp), np, C / 32);
+    STEM_LAUNCH_CHECK("stem_bf16x3_split_dact_nhwc");
+    return 0;
+}
+
 STEM_EXPORT int stem_bf16x3_merge_nhwc(const void *xp, float *x, int ldx, long npix, int C, void *stream)
 {
     STEM_CHECK_ARG(x && xp && npix >= 0 && C > 0 && C % 32 == 0 && ldx >= C, "stem_bf16x3_merge_nhwc: bad arguments (C=%d ldx=%d)", C, ldx);
@@ -779,14 +824,43 @@ STEM_EXPORT int stem_bf16x3_pack_conv_weight(const float *w, void *wp, int N, in
                    "stem_bf16x3_pack_conv_weight: N <= %d, C %% 32 == 0, R*S <= %d (N=%d C=%d R=%d S=%d)", BN, MAXTAP, N, C, R, S);
     const long np = (long)(C / 32) * R * S * BN * 4;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)cdivz(np, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       static_cast<unsigned char *>(wp), N, C, R * S, np);
+                       static_cast<unsigned char *>(wp), N, C, R * S, np, 0);
     STEM_LAUNCH_CHECK("stem_bf16x3_pack_conv_weight");
     return 0;
 }
 
+STEM_EXPORT int stem_bf16x3_pack_conv_weight_flip(const float *w, void *wp, int N, int C, int R, int S, void *stream)
+{
+    STEM_CHECK_ARG(w && wp && N >= 1 && N <= BN && C > 0 && C % 32 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP,
+                   "stem_bf16x3_pack_conv_weight_flip: N <= %d, C %% 32 == 0, R*S <= %d (N=%d C=%d R=%d S=%d)", BN, MAXTAP, N, C, R, S);
+    const long np = (long)(C / 32) * R * S * BN * 4;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)cdivz(np, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       static_cast<unsigned char *>(wp), N, C, R * S, np, 1);
+    STEM_LAUNCH_CHECK("stem_bf16x3_pack_conv_weight_flip");
+    return 0;
+}
+
+static int conv2d_bf16x6_launch(const void *xp, const void *wp, const float *bias, const float *beta, const float *gamma, float beta_min, int act,
+                                float slope, float *y, int ldy, void *yp, int B, int H, int W, int C, int N, int R, int S, int stride, int pad,
+                                void *stream);
+
 STEM_EXPORT int stem_conv2d_bf16x6_fwd(const void *xp, const void *wp, const float *bias, const float *beta, const float *gamma,
                                        float beta_min, float *y, int ldy, void *yp, int B, int H, int W, int C, int N, int R, int S,
                                        int stride, int pad, void *stream)
+{
+    return conv2d_bf16x6_launch(xp, wp, bias, beta, gamma, beta_min, 0, 0.f, y, ldy, yp, B, H, W, C, N, R, S, stride, pad, stream);
+}
+
+STEM_EXPORT int stem_conv2d_bf16x6_fwd_act(const void *xp, const void *wp, const float *bias, int act, float slope, float *y, int ldy, void *yp,
+                                           int B, int H, int W, int C, int N, int R, int S, int stride, int pad, void *stream)
+{
+    STEM_CHECK_ARG(act == 0 || act == 1, "stem_conv2d_bf16x6_fwd_act: act is 0 (none) or 1 (leaky ReLU with `slope`)");
+    return conv2d_bf16x6_launch(xp, wp, bias, nullptr, nullptr, 1e-6f, act, slope, y, ldy, yp, B, H, W, C, N, R, S, stride, pad, stream);
+}
+
+static int conv2d_bf16x6_launch(const void *xp, const void *wp, const float *bias, const float *beta, const float *gamma, float beta_min, int act,
+                                float slope, float *y, int ldy, void *yp, int B, int H, int W, int C, int N, int R, int S, int stride, int pad,
+                                void *stream)
 {
     STEM_CHECK_ARG(xp && wp && (y || yp), "stem_conv2d_bf16x6_fwd: null pointer");
     STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && C >= 32 && C % 32 == 0 && N >= 1 && N <= BN && R >= 1 && S >= 1 && R * S <= MAXTAP &&
@@ -805,6 +879,7 @@ STEM_EXPORT int stem_conv2d_bf16x6_fwd(const void *xp, const void *wp, const flo
     a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.OH = OH; a.OW = OW; a.stride = stride; a.ntaps = R * S;
     a.xbytes = (int)xb; a.wbytes = (int)wb; a.gmbytes = N * N * 4;
     a.fuse = gamma ? 1 : 0;
+    a.epi = act; a.slope = slope;
     a.beta_bound = (float)sqrt((double)beta_min + 1.4551915228366852e-11);
     for (int r = 0; r < R; ++r)
         for (int s = 0; s < S; ++s) {

@@ -433,6 +433,16 @@ class Bf16Planes:
         _chk(_lib.hip().stem_bf16x3_split_nhwc(x.data_ptr(), nhwc_ld(x), out.data.data_ptr(), B * H * W, Cc, _stream()))
         return out
 
+    @staticmethod
+    def split_dact(dy, z, slope):
+        """planes of dy * (z > 0 ? 1 : slope): the leaky-ReLU derivative applied while splitting (z = the activated output)"""
+        dy, z = to_nhwc(dy), to_nhwc(z)
+        B, Cc, H, W = dy.shape
+        out = Bf16Planes.empty(B, Cc, H, W, dy.device)
+        _chk(_lib.hip().stem_bf16x3_split_dact_nhwc(dy.data_ptr(), nhwc_ld(dy), z.data_ptr(), nhwc_ld(z), float(slope), out.data.data_ptr(),
+                                                     B * H * W, Cc, _stream()))
+        return out
+
     def merge(self):
         assert self.dense, "merge() of a channel view is not implemented"
         B, Cc, H, W = self.shape
@@ -441,16 +451,33 @@ class Bf16Planes:
         return out
 
 
-def pack_weight_bf16x3(w: torch.Tensor) -> torch.Tensor:
-    """torch Conv2d weight [K,C,R,S] -> the chunked, pre-split LDS image conv2d_bf16x6_fwd streams."""
+def pack_weight_bf16x3(w: torch.Tensor, flip: bool = False) -> torch.Tensor:
+    """torch Conv2d weight [K,C,R,S] -> the chunked, pre-split LDS image conv2d_bf16x6_fwd streams; flip=True: the operand of
+    the input gradient of a stride-1 convolution (rows = input channels, contraction = output channels, taps mirrored)."""
     _require_cuda(w)
     K, Cc, R, S = w.shape
-    nbytes = _lib.hip().stem_bf16x3_conv_weight_bytes(Cc, R, S)
+    N, Cin = (Cc, K) if flip else (K, Cc)
+    nbytes = _lib.hip().stem_bf16x3_conv_weight_bytes(Cin, R, S)
     if nbytes == 0:
-        raise ValueError(f"bf16x3 weights need an input channel count that is a multiple of 32, got {Cc}")
+        raise ValueError(f"bf16x3 weights need a contraction channel count that is a multiple of 32, got {Cin}")
     out = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
-    _chk(_lib.hip().stem_bf16x3_pack_conv_weight(w.detach().contiguous().data_ptr(), out.data_ptr(), K, Cc, R, S, _stream()))
+    fn = _lib.hip().stem_bf16x3_pack_conv_weight_flip if flip else _lib.hip().stem_bf16x3_pack_conv_weight
+    _chk(fn(w.detach().contiguous().data_ptr(), out.data_ptr(), N, Cin, R, S, _stream()))
     return out
+
+
+def conv2d_bf16x6_act(xp: Bf16Planes, wp, bias, K, R, S, stride, pad, act=False, slope=LRELU_SLOPE, want_planes=False):
+    """Conv2d (+ leaky ReLU) of a planes tensor on the 192-column kernel (K <= 192): the large-pixel-count layers of the layer-wise
+    models.  -> (NHWC fp32 tensor, planes copy or None)"""
+    B, Cc, H, W = xp.shape
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    dev = xp.data.device
+    assert xp.dense, "the 192-column kernel takes whole planes tensors"
+    y = empty_nhwc(B, K, Ho, Wo, dev)
+    yp = Bf16Planes.empty(B, K, Ho, Wo, dev) if want_planes else None
+    _chk(_lib.hip().stem_conv2d_bf16x6_fwd_act(xp.data.data_ptr(), wp.data_ptr(), _ptr(bias), 1 if act else 0, float(slope), y.data_ptr(), nhwc_ld(y),
+                                               yp.data.data_ptr() if yp is not None else None, B, H, W, Cc, K, R, S, stride, pad, _stream()))
+    return y, yp
 
 
 def conv2d_bf16x6_fwd(xp: Bf16Planes, wp, bias, K, R, S, stride, pad, beta=None, gamma=None, beta_min=1e-6, planes_out=False):
@@ -535,6 +562,17 @@ def wgrad_bf16x6_plan(x_shape, K, R, S, pad):
     B, Cc, H, W = x_shape
     splits = int(_lib.hip().stem_wgrad_bf16x6_splits(B, H, W, Cc, K, R, S, pad))
     return splits, splits * R * S * K * Cc
+
+
+def conv2d_wgrad_bf16x6_into(xp: Bf16Planes, dyp: Bf16Planes, K, R, S, pad, dw_out, db_out=None, accumulate=True):
+    """weight (and bias) gradient of a stride-1 convolution from planes operands straight into the reference-layout
+    buffers dw_out [K,C,R,S] / db_out [K] (accumulating: autograd's `.grad +=`); slabs from the per-geometry workspace"""
+    B, Cc, H, W = xp.shape
+    splits, elems = wgrad_bf16x6_plan(xp.shape, K, R, S, pad)
+    ws, _ = _wgrad_workspace(("bf16x6", xp.data.device, tuple(xp.shape), K, R, S, pad), elems + splits * K, xp.data.device)
+    dwp, bpart = ws[:elems], ws[elems:elems + splits * K]
+    conv2d_wgrad_bf16x6(xp, dyp, K, R, S, pad, dwp, splits, db=db_out, bias_part=bpart, accumulate_db=accumulate)
+    _chk(_lib.hip().stem_unpack_wgrad(dwp.data_ptr(), dw_out.data_ptr(), K, Cc, R, S, splits, UNPACK_ACCUMULATE if accumulate else 0, _stream()))
 
 
 def conv2d_wgrad_bf16x6(xp: Bf16Planes, dyp: Bf16Planes, K, R, S, pad, dwp, splits, db=None, bias_part=None, accumulate_db=False):

@@ -37,6 +37,8 @@ def weight_epoch(w):
 
 PACK_BF16X3 = -3          # _PackCache role of the pre-split bf16 image (csrc/conv_bf16x6.hip); not a stem_pack_* role
 PACK_BF16X3_GEN = -4      # ... in the layout of the general (128-column tiles, split-K) kernel
+PACK_BF16X3_FLIP = -7     # PACK_BF16X3 of the mirrored, transposed weight (input gradient on the 192-column kernel)
+PACK_BF16X3_GEN_FLIP = -6 # ... of the mirrored, transposed weight: the input-gradient of a stride-1 convolution as a convolution
 PACK_C4GDN = -5           # A-operand stream of csrc/c4gdn_bf16x6.hip: first-layer weight AND the following GDN's gamma
 
 
@@ -53,8 +55,12 @@ class _PackCache:
             return hit[1]
         if role == PACK_BF16X3:
             wp = F.pack_weight_bf16x3(w)
+        elif role == PACK_BF16X3_FLIP:
+            wp = F.pack_weight_bf16x3(w, flip=True)
         elif role == PACK_BF16X3_GEN:
             wp = F.pack_weight_bf16x3_gen(w)
+        elif role == PACK_BF16X3_GEN_FLIP:
+            wp = F.pack_weight_bf16x3_gen(w, flip=True)
         else:
             wp = F.pack_weight(w, role, masked)
         if (masked & 3) == 2:                    # the kernel zeroed taps of w in place
@@ -128,12 +134,68 @@ def _on_side_stream(fn, *tensors):
 
 
 # ----------------------------------------------------------------------------- autograd functions
+def _layers_bf16x6_enabled():
+    """stride-1 convolutions of the layer-wise (autograd) models -- the variable-rate family of models/stem_roi.py -- on the bf16
+    matrix cores (six products per fp32 product, csrc/conv_bf16x6.hip / wgrad_bf16x6.hip); STEM_LAYERS_BF16X6=0: fp32 MFMA"""
+    return os.environ.get("STEM_LAYERS_BF16X6", "1") != "0"
+
+
+def _conv_bf16x6_route(weight, stride, pad, masked, x_shape):
+    """forward, input gradient and weight gradient of this convolution on the bf16 kernels: stride 1, 'same' padding, channel
+    counts that are multiples of 32, operands within the kernels' 2 GiB buffer views"""
+    K, Cc, R, S = weight.shape
+    B, _, H, W = x_shape
+    return (stride == 1 and R == S and pad == R // 2 and not masked and Cc % 32 == 0 and K % 32 == 0 and R * S <= 25
+            and B * H * W <= _LAYERS_BF16X6_MAXPIX
+            and _planes_fit(B * H * W, max(Cc, K)) and B * H * W * ((max(K, Cc) + 127) // 128) * 512 < 0x7FFFFF00)
+
+
+#: The general bf16 kernel streams its weight tile once per 64-pixel workgroup and the bf16 weight-gradient kernel re-reads both
+#: operands once per tap: at full-resolution feature maps (a million pixels per batch) both are bound by L2 -> LDS traffic and
+#: lose to the 128x128-tile fp32-MFMA kernels; below this pixel count the bf16 route wins (sweep: DESIGN.md section 9)
+_LAYERS_BF16X6_MAXPIX = int(os.environ.get("STEM_LAYERS_BF16X6_MAXPIX", str(1 << 30)))
+
+
+def _wide_kernel(n_out, x_shape):
+    """large pixel counts with at most 192 output channels: the 192-column kernel (128-pixel workgroups, one weight stream per
+    128 pixels) instead of the general one (64-pixel workgroups x 128-column tiles, built for the 16x16 latents)"""
+    B, _, H, W = x_shape
+    return n_out <= 192 and B * H * W >= _WIDE_MINPIX
+
+
+_WIDE_MINPIX = int(os.environ.get("STEM_LAYERS_WIDE_MINPIX", "32768"))
+
+
+def planes_of(t):
+    """the bf16 planes copy a producing kernel left next to an activation tensor (same values), if any"""
+    return getattr(t, "_stem_planes", None)
+
+
 class Conv2dFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, masked, cache, slope=F.LRELU_SLOPE):
+    def forward(ctx, x, weight, bias, stride, pad, act, masked, cache, slope=F.LRELU_SLOPE, want_planes=False):
         K, Cc, R, S = weight.shape
         # <=4 input channels: the image (NCHW, fused layout change: g_a.0) or image+quality map (stem_roi.py:529)
         first = (Cc == 3 and F.nhwc_ld(x) is None) or (Cc == 4 and R * S <= 32)
+        if not first and x.is_cuda and _layers_bf16x6_enabled() and _conv_bf16x6_route(weight, stride, pad, masked, x.shape):
+            # bf16 route: the input as planes (left by the producer, or split here), kept for the weight gradient instead
+            # of the fp32 input; the activation is the kernel's epilogue
+            xp = planes_of(x)
+            if xp is None or tuple(xp.shape) != tuple(x.shape):
+                xp = F.Bf16Planes.split(x)
+            if _wide_kernel(K, x.shape) and xp.dense:
+                y, yp = F.conv2d_bf16x6_act(xp, cache.get(weight, PACK_BF16X3), bias, K, R, S, 1, pad, bool(act), slope, want_planes)
+            else:
+                y, yp = F.conv2d_bf16x6_gen(xp, cache.get(weight, PACK_BF16X3_GEN), bias, K, R, S, 1, pad,
+                                            epi=F.GEN_EPI_LRELU if act else F.GEN_EPI_BIAS, slope=slope, want_planes=want_planes)
+            if yp is not None:
+                y._stem_planes = yp
+            ctx.cfg = (stride, pad, act, masked, cache, False, tuple(x.shape), slope)
+            ctx.params = (weight, bias)
+            ctx.bx6 = (xp.pix_bytes, xp.byte_offset)
+            ctx.save_for_backward(xp.data, weight, y if act else None)
+            return y
+        ctx.bx6 = None
         if first:
             xin = F.nchw3_to_nhwc4(x) if Cc == 3 else F.dense_nhwc(x).permute(0, 2, 3, 1)
             y = F.conv2d_fwd_c4(xin, cache.get(weight, F.PACK_CONV_FWD_C4), bias, K, R, S, stride, pad)
@@ -150,7 +212,38 @@ class Conv2dFunction(torch.autograd.Function):
         return y
 
     @staticmethod
+    def _backward_bx6(ctx, dy):
+        stride, pad, act, masked, cache, first, xshape, slope = ctx.cfg
+        xdata, weight, y = ctx.saved_tensors
+        K, Cc, R, S = weight.shape
+        xp = F.Bf16Planes(xdata, xshape, *ctx.bx6)
+        dy = F.to_nhwc(dy)
+        # the gradient as planes, with this layer's leaky-ReLU derivative applied in the splitting pass
+        dyp = F.Bf16Planes.split_dact(dy, y, slope) if act else F.Bf16Planes.split(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if _wide_kernel(Cc, xshape):
+                dx = F.conv2d_bf16x6_act(dyp, cache.get(weight, PACK_BF16X3_FLIP), None, Cc, R, S, 1, pad)[0]
+            else:
+                dx = F.conv2d_bf16x6_gen(dyp, cache.get(weight, PACK_BF16X3_GEN_FLIP), None, Cc, R, S, 1, pad, epi=F.GEN_EPI_BIAS)[0]
+        dw = db = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            need_db = bool(ctx.needs_input_grad[2])
+            gw, gb = _flat_grad(ctx.params[0]), (_flat_grad(ctx.params[1]) if need_db else None)
+            if gw is not None and (gb is not None or not need_db):
+                def run():
+                    F.conv2d_wgrad_bf16x6_into(xp, dyp, K, R, S, pad, gw, gb if need_db else None, accumulate=True)
+                _on_side_stream(run, dyp.data, xdata) if _WGRAD_SIDE["enabled"] else run()
+            else:
+                dw = torch.zeros((K, Cc, R, S), device=dy.device, dtype=torch.float32)
+                db = torch.zeros(K, device=dy.device, dtype=torch.float32) if need_db else None
+                F.conv2d_wgrad_bf16x6_into(xp, dyp, K, R, S, pad, dw, db, accumulate=True)
+        return dx, dw, db, None, None, None, None, None, None, None
+
+    @staticmethod
     def backward(ctx, dy):
+        if ctx.bx6 is not None:
+            return Conv2dFunction._backward_bx6(ctx, dy)
         stride, pad, act, masked, cache, first, xshape, slope = ctx.cfg
         xin, weight, y = ctx.saved_tensors
         K, Cc, R, S = weight.shape
@@ -174,7 +267,7 @@ class Conv2dFunction(torch.autograd.Function):
                 dw, db = F.conv2d_wgrad(xin, dy, K, R, S, stride, pad, need_db=need_db)
                 if first and Cc == 3:
                     dw = dw[:, :3].contiguous()
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 class ConvTranspose2dFunction(torch.autograd.Function):
@@ -375,8 +468,12 @@ class Conv2d(nn.Module):
             bound = 1 / math.sqrt(self.weight[0].numel())
             nn.init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, x, act=F.ACT_NONE, slope=F.LRELU_SLOPE):
-        return Conv2dFunction.apply(x, self.weight, self.bias, self.stride, self.padding, act, self._masked, self._packs, slope)
+    def forward(self, x, act=F.ACT_NONE, slope=F.LRELU_SLOPE, planes=False):
+        """planes=True: the consumer is another bf16-routed convolution -- leave the pre-split copy next to the output"""
+        return Conv2dFunction.apply(x, self.weight, self.bias, self.stride, self.padding, act, self._masked, self._packs, slope, planes)
+
+    def bf16x6_route(self, x_shape):
+        return _layers_bf16x6_enabled() and _conv_bf16x6_route(self.weight, self.stride, self.padding, self._masked, x_shape)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}"
@@ -575,7 +672,14 @@ class FusedSequential(nn.Sequential):
             if isinstance(m, (Conv2d, ConvTranspose2d)) and isinstance(nxt, (nn.LeakyReLU, nn.ReLU)):
                 # LeakyReLU(slope) or ReLU (= slope 0) folded into the conv epilogue
                 slope = float(nxt.negative_slope) if isinstance(nxt, nn.LeakyReLU) else 0.0
-                x = self._timed(i, lambda: m(x, act=F.ACT_LRELU, slope=slope))
+                if type(m) is Conv2d and x.is_cuda:
+                    # hand planes to the next convolution when both run on the bf16 kernels (a conv -> LeakyReLU -> conv chain)
+                    after = mods[i + 2] if i + 2 < len(mods) else None
+                    out_shape = _conv_out_shape(m, x.shape)
+                    hand = type(after) is Conv2d and m.bf16x6_route(x.shape) and after.bf16x6_route(out_shape)
+                    x = self._timed(i, lambda: m(x, act=F.ACT_LRELU, slope=slope, planes=hand))
+                else:
+                    x = self._timed(i, lambda: m(x, act=F.ACT_LRELU, slope=slope))
                 i += 2
             else:
                 x = m(x)
