@@ -327,6 +327,18 @@ int stem_ar_decode_image(const float *w_ctx, int ld_ctx, const float *b_ctx, con
                          float *ctx, float *h1, float *h2, float *gp, const float *table, int T, float scale_bound, float slope,
                          int32_t *idx_host, int32_t *sym_host, stem_symbol_decoder_fn decode, void *dec,
                          const int32_t *cdfs, int ncdf, int cdf_stride, const int32_t *sizes, const int32_t *offsets, void *stream);
+/* The same loop as ONE persistent kernel (csrc/ar_persistent.hip): 64 resident workgroups taken from one XCD walk through
+ * the positions together, grid barriers instead of kernel boundaries between the four products of a position, the host's
+ * symbol decoder reached through pinned mailboxes and sequence flags (held by the library, per calling thread) instead of a
+ * stream synchronisation.  Same arguments and results as stem_ar_decode_image (bit for bit: same dot-product order) without
+ * the caller's mailboxes; every wait is bounded, a non-zero return leaves `buf` and the decoder state undefined (decode the
+ * image again with stem_ar_decode_image from a fresh decoder).  Replaces the loop body of spatiotemporalpriors.py:1015-1054. */
+int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, const float *b_ctx, const float *w0, int ld0, const float *b0, int n0,
+                                    const float *w1, int ld1, const float *b1, int n1, const float *w2, int ld2, const float *b2,
+                                    float *buf, int H, int W, int M, int pad, const float *tp, const float *hp,
+                                    float *ctx, float *h1, float *h2, float *gp, const float *table, int T, float scale_bound, float slope,
+                                    stem_symbol_decoder_fn decode, void *dec,
+                                    const int32_t *cdfs, int ncdf, int cdf_stride, const int32_t *sizes, const int32_t *offsets, void *stream);
 /* The same loop for G (1..8) independent images in lockstep -- the batch elements of decompress(), which the reference decodes
  * one after the other (spatiotemporalpriors.py:1015-1054): one set of four launches + one synchronisation advances all G
  * images by a position, so the per-position latency (what bounds the decoder) is shared.  Per image the arithmetic, and

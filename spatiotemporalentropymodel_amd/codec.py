@@ -286,7 +286,25 @@ def stem_decompress(model, strings, shape, y_cond):
             decode_image_stepwise(ar, buf, H, W, tp_b, hp_b, dec, tables, idx_host, sym_host)
             out[b:b + 1].copy_(buf[_P:_P + H, _P:_P + W].permute(2, 0, 1).unsqueeze(0))
             continue
-        # the whole raster-order loop of this image runs inside the library (csrc/ar.hip: stem_ar_decode_image)
+        # The whole raster-order loop of this image runs inside the library.  STEM_AR_PERSISTENT=1 runs it as ONE persistent kernel
+        # (csrc/ar_persistent.hip: resident workgroups of one XCD, grid barriers, pinned mailboxes) -- bit-identical, and measured
+        # SLOWER than the per-position loop on MI355X (0.49 s against 0.30 s per 1080p P frame: 2 us per L2-local grid barrier
+        # and 6-11 us per 64-workgroup matrix-vector product against ~6 us per dependent dispatch), so it is
+        # opt-in; should it give up (a bounded wait timed out) the image is decoded again by the per-position loop.
+        if os.environ.get("STEM_AR_PERSISTENT", "0") == "1":
+            rc = lib.stem_ar_decode_image_persistent(
+                ar.w_ctx.data_ptr(), 12 * M, ar.b_ctx.data_ptr(), ar.w0.data_ptr(), ar.w0.shape[1], ar.b0.data_ptr(), ar.w0.shape[0],
+                ar.w1.data_ptr(), ar.w1.shape[1], ar.b1.data_ptr(), ar.w1.shape[0], ar.w2.data_ptr(), ar.w2.shape[1], ar.b2.data_ptr(),
+                buf.data_ptr(), H, W, M, _P, tp_b, hp_b, ar.ctx.data_ptr(), ar.h1.data_ptr(), ar.h2.data_ptr(), ar.gp.data_ptr(),
+                ar.table.data_ptr(), ar.table.numel(), ar.bound, F.LRELU_SLOPE, decode_fn, dec._h, *tables.args(), F._stream())
+            if rc == 0:
+                out[b:b + 1].copy_(buf[_P:_P + H, _P:_P + W].permute(2, 0, 1).unsqueeze(0))
+                continue
+            import warnings
+            warnings.warn("persistent decoder gave up (" + (lib.stem_last_error() or b"").decode() + "); decoding this image with the per-position loop")
+            buf = _padded(None, H, W, M, dev)
+            dec = RansDecoder()
+            dec.set_stream(s)
         F._chk(lib.stem_ar_decode_image(
             ar.w_ctx.data_ptr(), 12 * M, ar.b_ctx.data_ptr(), ar.w0.data_ptr(), ar.w0.shape[1], ar.b0.data_ptr(), ar.w0.shape[0],
             ar.w1.data_ptr(), ar.w1.shape[1], ar.b1.data_ptr(), ar.w1.shape[0], ar.w2.data_ptr(), ar.w2.shape[1], ar.b2.data_ptr(),

@@ -25,7 +25,7 @@ STEM_EXPORT int stem_built_with_experiments(void)
 }
 
 static int g_tuning[STEM_TUNE_COUNT] = {0};
-static const char *const kTuningNames[STEM_TUNE_COUNT] = {"bx6_tile", "bx6_split", "wg6_split"};
+static const char *const kTuningNames[STEM_TUNE_COUNT] = {"bx6_tile", "bx6_split", "wg6_split", "arp_workers"};
 int stem_tuning(int id) { return g_tuning[id]; }
 STEM_EXPORT int stem_tuning_set(const char *name, int value)
 {
@@ -36,7 +36,7 @@ STEM_EXPORT int stem_tuning_set(const char *name, int value)
             g_tuning[i] = value;
             return 0;
         }
-    stem_set_error("stem_tuning_set: unknown selector '%s' (bx6_tile, bx6_split, wg6_split)", name);
+    stem_set_error("stem_tuning_set: unknown selector '%s' (bx6_tile, bx6_split, wg6_split, arp_workers)", name);
     return -1;
 }
 STEM_EXPORT int stem_tuning_get(const char *name)

@@ -146,3 +146,36 @@ def test_lockstep_batch_decode_equals_per_image_decode(monkeypatch):
     assert float((a[3:4] - one).abs().max()) <= 1e-4
     # within half a quantisation step of the input everywhere (y_hat = round(res - mu) + mu + y_cond)
     assert float((a - y_cur).abs().max()) <= 0.5 + 1e-4
+
+
+@pytest.mark.parametrize("cls_name", ["SpatioTemporalPriorModelWithoutTPM", "SpatioTemporalPriorModel_Res"])
+def test_persistent_decoder_equals_per_position_loop(cls_name, monkeypatch):
+    """csrc/ar_persistent.hip (one launch per image: resident workgroups, grid barriers between the four products of a position,
+    host symbol decoder behind pinned mailboxes; opt-in, STEM_AR_PERSISTENT=1) against stem_ar_decode_image (four launches + a
+    synchronisation per position) and the Python-driven single-step loop: identical reconstructions, bit for bit, no fallback
+    taken, and the stream decodes to within half a quantisation step of the input.  spatiotemporalpriors.py:1015-1054."""
+    import warnings
+    import spatiotemporalentropymodel_amd.models as M
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_, closed_form_input
+    dev = torch.device("cuda:0")
+    m = closed_form_fill_(getattr(M, cls_name)(64, 96)).to(dev).eval()
+    m.update(force=True)
+    y_cur = closed_form_input("pd:y", (1, 96, 8, 20), -6, 6).to(dev)
+    y_cond = closed_form_input("pd:c", (1, 96, 8, 20), -6, 6).to(dev)
+
+    def y_hat(res):
+        return (res["y_hat"] if isinstance(res, dict) else res).clone()
+
+    with torch.no_grad():
+        enc = m.compress(y_cur, y_cond)
+        monkeypatch.setenv("STEM_AR_PERSISTENT", "1")
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                                      # the fallback announces itself with a warning
+            a = y_hat(m.decompress(enc["strings"], enc["shape"], y_cond))
+            a2 = y_hat(m.decompress(enc["strings"], enc["shape"], y_cond))      # the library's flags / mailboxes are reusable
+        monkeypatch.setenv("STEM_AR_PERSISTENT", "0")
+        b = y_hat(m.decompress(enc["strings"], enc["shape"], y_cond))
+        monkeypatch.setenv("STEM_AR_STEPWISE", "1")
+        c = y_hat(m.decompress(enc["strings"], enc["shape"], y_cond))
+    assert torch.equal(a, b) and torch.equal(a, a2) and torch.equal(b, c)
+    assert float((a - y_cur).abs().max()) <= 0.5 + 1e-4

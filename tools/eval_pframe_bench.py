@@ -30,7 +30,11 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--sequences", type=int, default=1)
+    ap.add_argument("--workers", type=int, default=0, help="workgroups of the persistent decoder (0 = the library's default)")
     a = ap.parse_args()
+    if a.workers:
+        from spatiotemporalentropymodel_amd import _lib
+        _lib.check(_lib.hip().stem_tuning_set(b"arp_workers", a.workers))
     G = a.sequences
     dev = torch.device("cuda:0")
     imodel = closed_form_fill_(models["mbt2018"](quality=4)).to(dev).eval()
