@@ -272,7 +272,7 @@ def bench_roi(args):
     kern_ms = float(np.mean([x.elapsed_time(y) for x, y in probe]))
     flop = 2.0 * 192 * 160 * 9 * SIZE * SIZE * B
     achieved = flop / (kern_ms * 1e-3) / 1e12
-    print(json.dumps({
+    _emit({
         "metric": "frames/s", "value": FRAMES * B * world * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -282,7 +282,18 @@ def bench_roi(args):
                    "final_loss": float(log[-1][0]["loss"].detach())},
         "roofline": {"bound": "mfma", "kernel": "igemm conv3x3 192->160 at 256x256 (stem_roi.qmap_feature_ga1.2, forward), B=%d" % B,
                      "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                     "flop_per_launch": flop, "avg_launch_ms": kern_ms, "launches_timed": len(probe), "traffic": None}}))
+                     "flop_per_launch": flop, "avg_launch_ms": kern_ms, "launches_timed": len(probe), "traffic": None}})
+
+
+def _emit(res):
+    """the ONE JSON line, as the LAST line of stdout: RCCL prints its version banner through C stdio, which (not a terminal) is
+    flushed at exit, i.e. after a Python print -- flush it first"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(res), flush=True)
 
 
 def launch_ranks(n, argv):
@@ -571,7 +582,7 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()
-    print(json.dumps(res))
+    _emit(res)
 
 
 if __name__ == "__main__":

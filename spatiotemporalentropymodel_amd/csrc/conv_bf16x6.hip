@@ -483,6 +483,22 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
             }
         }
     };
+    // A wavefront whose 64 columns lie entirely beyond N (the second column pair of the last tile of a 320-channel layer: a
+    // sixth of the launch's matrix work) only takes part in the staging: same loads, LDS writes and barriers, no LDS reads and
+    // no MFMAs.  The choice is made once per wavefront, OUTSIDE the woven block (a per-sub-tile branch inside it was slower).
+    const bool dead = bn0 + wn0 >= a.N;
+    auto step_dead = [&](int cur, f32x4 (&ra)[PL], f32x4 (&rb)[BPC]) {
+        const int t = __builtin_amdgcn_readfirstlane(pf_t), kc = __builtin_amdgcn_readfirstlane(pf_kc), q = __builtin_amdgcn_readfirstlane(pf_q);
+        sstore(cur ^ 1, ra, rb);
+        gload(t, kc, q, ra, rb);
+        if (pf_q < q_last) {
+            ++pf_q;
+            if (++pf_t == a.ntaps) {
+                pf_t = 0;
+                ++pf_kc;
+            }
+        }
+    };
     auto chunk_of = [&](int q, int &t, int &kc) {
         q = q < q_last ? q : q_last;
         kc = q / a.ntaps;
@@ -501,7 +517,7 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
         pf_q = chunk_of(q_begin + 3, pf_t, pf_kc);
     }
     __syncthreads();
-    {
+    if (!dead) {
         int q = q_begin;
         for (; q + 1 < q_end; q += 2) {
             step(0, raA, rbA);
@@ -511,6 +527,18 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
         }
         if (q < q_end) {
             step(0, raA, rbA);
+            __syncthreads();
+        }
+    } else {
+        int q = q_begin;
+        for (; q + 1 < q_end; q += 2) {
+            step_dead(0, raA, rbA);
+            __syncthreads();
+            step_dead(1, raB, rbB);
+            __syncthreads();
+        }
+        if (q < q_end) {
+            step_dead(0, raA, rbA);
             __syncthreads();
         }
     }
@@ -651,35 +679,47 @@ constexpr int MAXPACK = 24;
 struct PackTable {
     stem_bf16x3_pack_desc d[MAXPACK];
 };
+constexpr int PKR = 8;                                  // output rows per unit
 __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTable tab)
 {
-    // One workgroup per (output row n, 32-channel slab) unit, grid-strided: the RS x 32 source values of a unit are RS-long
-    // contiguous runs of the torch weight (one run per channel; in flip mode per output channel of the forward layer): read
-    // coalesced into LDS, then every thread emits whole 16-byte pieces (8 channels of one tap, three planes).
-    __shared__ float tile[32 * MAXTAP];               // [channel in slab][tap]
+    // One workgroup per unit = (8 consecutive output rows n, one 32-channel slab), grid-strided.  The 8 x 32 x RS source values
+    // of a unit are read in long contiguous runs of the torch weight -- forward role: per row n the slab's 32 x RS values are
+    // one run; flip role (rows = input channels of the forward layer): per contraction channel the 8 rows' RS values are one
+    // run -- into LDS, then every thread emits whole 16-byte pieces (8 channels of one tap and row, three planes).  (The first
+    // version handled one row per unit: 100-byte runs in flip mode and two barriers per 800 values.)
+    __shared__ float tile[PKR * 32 * MAXTAP];         // [row][channel in slab][tap]
     const stem_bf16x3_pack_desc &d = tab.d[blockIdx.y];
     const int RS = d.R * d.S, nslab = d.C / 32, nchunks = nslab * RS, ntile = cdiv_dev(d.N, GBN);
     const float *w = static_cast<const float *>(d.w);
     unsigned char *wp = static_cast<unsigned char *>(d.wp);
-    const int units = ntile * GBN * nslab;
+    const int units = ntile * (GBN / PKR) * nslab;
     for (int u = blockIdx.x; u < units; u += gridDim.x) {
-        const int slab = u % nslab, n = u / nslab;            // n runs over the padded rows of all N tiles
+        const int slab = u % nslab, n0 = (u / nslab) * PKR;   // n runs over the padded rows of all N tiles
         __syncthreads();
-        for (int e = threadIdx.x; e < 32 * RS; e += 256) {
-            const int c = e / RS, tap = e - c * RS, ch = slab * 32 + c;
-            float v = 0.f;
-            if (n < d.N) v = d.flip ? w[((size_t)ch * d.N + n) * RS + (RS - 1 - tap)] : w[((size_t)n * d.C + ch) * RS + tap];
-            tile[c * MAXTAP + tap] = v;
+        if (d.flip) {
+            // element (row r, channel c, tap): w[((slab * 32 + c) * N + n0 + r) * RS + (RS - 1 - tap)]: for fixed c, PKR * RS contiguous floats
+            for (int e = threadIdx.x; e < 32 * PKR * RS; e += 256) {
+                const int c = e / (PKR * RS), rem = e - c * (PKR * RS), r = rem / RS, tp = rem - r * RS;
+                const int n = n0 + r;
+                tile[(r * 32 + c) * MAXTAP + (RS - 1 - tp)] = n < d.N ? w[((size_t)(slab * 32 + c) * d.N + n) * RS + tp] : 0.f;
+            }
+        } else {
+            // element (row r, channel c, tap): w[((n0 + r) * C + slab * 32 + c) * RS + tap]: for fixed r, 32 * RS contiguous floats
+            for (int e = threadIdx.x; e < PKR * 32 * RS; e += 256) {
+                const int r = e / (32 * RS), rem = e - r * (32 * RS), c = rem / RS, tp = rem - c * RS;
+                const int n = n0 + r;
+                tile[(r * 32 + c) * MAXTAP + tp] = n < d.N ? w[((size_t)n * d.C + slab * 32 + c) * RS + tp] : 0.f;
+            }
         }
         __syncthreads();
-        const int nt = n / GBN, nl = n - nt * GBN;
-        for (int e = threadIdx.x; e < RS * 4; e += 256) {
-            const int tap = e >> 2, p = e & 3;
+        for (int e = threadIdx.x; e < PKR * RS * 4; e += 256) {
+            const int p = e & 3, r = (e >> 2) % PKR, tap = (e >> 2) / PKR;
+            const int n = n0 + r, nt = n / GBN, nl = n - nt * GBN;
             bf16x8 h[3];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 __bf16 x0, x1, x2;
-                split3(tile[(p * 8 + c) * MAXTAP + tap], x0, x1, x2);
+                split3(tile[(r * 32 + p * 8 + c) * MAXTAP + tap], x0, x1, x2);
                 h[0][c] = x0; h[1][c] = x1; h[2][c] = x2;
             }
             const long qq = (long)nt * nchunks + slab * RS + tap;
@@ -953,7 +993,7 @@ STEM_EXPORT int stem_bf16x3_pack_conv_weights_multi(const stem_bf16x3_pack_desc 
         const stem_bf16x3_pack_desc &d = descs_host[i];
         STEM_CHECK_ARG(d.w && d.wp && d.N >= 1 && d.C > 0 && d.C % 32 == 0 && d.R >= 1 && d.S >= 1 && d.R * d.S <= MAXTAP,
                        "stem_bf16x3_pack_conv_weights_multi: descriptor %d: C %% 32 == 0, R*S <= %d (N=%d C=%d R=%d S=%d)", i, MAXTAP, d.N, d.C, d.R, d.S);
-        const size_t nu = (size_t)cdiv(d.N, GBN) * GBN * (d.C / 32);
+        const size_t nu = (size_t)cdiv(d.N, GBN) * (GBN / PKR) * (d.C / 32);
         if (nu > maxu) maxu = nu;
     }
     PackTable tab;

@@ -176,6 +176,14 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
                 gload(qn, ra, rb);
         }
     };
+    // A wavefront whose 64 x 64 outputs lie entirely beyond K or C (half of the last tile of a 320-channel operand: a sixth of
+    // the launch's matrix work) only takes part in the staging -- same loads, LDS writes, bias sums and barriers, no LDS reads,
+    // no MFMAs.  Decided once per wavefront, outside the woven block.
+    const bool dead = k0 + wk0 >= a.K || c0 + wc0 >= a.C;
+    auto step_dead = [&](int cur, f32x4 (&ra)[PL], f32x4 (&rb)[PL], int qcur, int qn) {
+        sstore(cur ^ 1, ra, rb, qcur + 1 < q_end);
+        gload(qn, ra, rb);
+    };
     const int q_last = q_end - 1;
     auto clampq = [&](int q) { return q < q_last ? q : q_last; };
     if (q_begin < q_end) {
@@ -185,7 +193,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
         gload(clampq(q_begin + 2), raB, rbB);
     }
     __syncthreads();
-    {
+    if (!dead) {
         int q = q_begin;
         for (; q + 1 < q_end; q += 2) {
             step(0, raA, rbA, q, clampq(q + 3));
@@ -195,6 +203,18 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
         }
         if (q < q_end) {
             step(0, raA, rbA, q, clampq(q + 3));
+            __syncthreads();
+        }
+    } else {
+        int q = q_begin;
+        for (; q + 1 < q_end; q += 2) {
+            step_dead(0, raA, rbA, q, clampq(q + 3));
+            __syncthreads();
+            step_dead(1, raB, rbB, q + 1, clampq(q + 4));
+            __syncthreads();
+        }
+        if (q < q_end) {
+            step_dead(0, raA, rbA, q, clampq(q + 3));
             __syncthreads();
         }
     }

@@ -42,13 +42,29 @@ def init_from_env(backend=None, single=None):
             backend = os.environ.get("STEM_DIST_BACKEND") or ("nccl" if ndev > 0 and not shared else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            # RCCL's kernels run on a stream torch makes for the process group: at HIP's high priority, like the schedule's own
+            # side streams (functional.make_stream) -- at normal priority an all-reduce queued behind the long kernels of the
+            # latent-prefetch stream reached the CUs up to ~0.6 ms late, and the optimiser step waits for it (measured with a
+            # one-rank group: 25.5 ms per bench step against 22.4 ms without a group)
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+                kw["pg_options"] = opts
+            except Exception:
+                pass
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
 _HOST_STAGE = {}
+
+
+def _side_stream(device):
+    from . import functional as F
+    return F.make_stream(device, "side")
 
 
 def all_reduce_sum_(t: torch.Tensor):
@@ -101,7 +117,7 @@ class FlatGradReducer:
         self.ranges = [(s, min(n, s + step)) for s in range(0, n, step)]
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.active = dist.is_initialized()            # a world-size-1 group still runs its collectives (init_from_env(single=True))
-        self._stream = torch.cuda.Stream() if flat_grad.is_cuda else None
+        self._stream = _side_stream(flat_grad.device) if flat_grad.is_cuda else None
 
     @property
     def grad_scale(self):
@@ -133,14 +149,22 @@ class OverlappedGradReducer:
         red.finish()             # compute stream waits for the last slice; then opt.step(red.grad_scale)
     """
 
-    def __init__(self, flat):
+    def __init__(self, flat, min_bytes=None):
         self.flat = flat
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.active = dist.is_initialized()
         self._off = {id(p): (o, p.numel()) for p, o in zip(flat.params, flat.offsets)}
-        self._stream = torch.cuda.Stream() if flat.grad.is_cuda else None
-        self._done = []            # [lo, hi) slices exchanged since the last finish()
-        self.calls = 0
+        self._stream = _side_stream(flat.grad.device) if flat.grad.is_cuda else None
+        self._done = []            # [lo, hi) slices reported since the last finish()
+        self._pending = []         # reported, final, not yet exchanged: merged contiguous runs [lo, hi]
+        self.calls = 0             # slices reported (schedule bookkeeping)
+        self.collectives = 0       # all-reduce calls issued
+        #: a run of final gradients is exchanged once it holds this many bytes (and whatever is left at finish()): every RCCL
+        #: call costs ~0.1 ms of stream time even at world size 1 (6 calls per P-frame step: +4 ms per bench step measured
+        #: with a one-rank RCCL group), so neighbouring module groups travel together -- 3 calls per step for the STEM model
+        #: (TPM + context model 32 MB while the hyper path is still in backward, then EPM + HD + HE 39 MB, then the bottleneck);
+        #: STEM_DP_MIN_BYTES=0 exchanges every group as soon as it is final
+        self.min_bytes = int(os.environ.get("STEM_DP_MIN_BYTES", str(24 << 20))) if min_bytes is None else int(min_bytes)
 
     @property
     def grad_scale(self):
@@ -150,9 +174,22 @@ class OverlappedGradReducer:
         engine.grad_ready_hook = self.reduce_params
         return self
 
+    def _exchange(self, lo, hi):
+        self.collectives += 1
+        if not self.active:
+            return
+        g = self.flat.grad[lo:hi]
+        if self._stream is None:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            return
+        self._stream.wait_stream(torch.cuda.current_stream())      # the slice is final on the stream that reported it
+        with torch.cuda.stream(self._stream):
+            all_reduce_sum_(g)
+
     def reduce_params(self, params):
-        """Exchange the smallest contiguous slice of the flat buffer that covers `params` (module groups are
-        contiguous because the flat order is sorted by parameter name)."""
+        """Report the gradients of `params` as final.  They join the pending runs (module groups are contiguous in the flat
+        buffer because its order is sorted by parameter name; neighbouring groups merge); a run is exchanged as soon as it
+        holds `min_bytes`."""
         spans = sorted(self._off[id(p)] for p in params if id(p) in self._off)
         if not spans:
             return
@@ -169,15 +206,21 @@ class OverlappedGradReducer:
             hi = min(hi, self.flat.grad.numel())
             self._done.append((lo, hi))
             self.calls += 1
-            if not self.active:
-                continue
-            g = self.flat.grad[lo:hi]
-            if self._stream is None:
-                dist.all_reduce(g, op=dist.ReduceOp.SUM)
-                continue
-            self._stream.wait_stream(torch.cuda.current_stream())      # the slice is final on the compute stream
-            with torch.cuda.stream(self._stream):
-                all_reduce_sum_(g)
+            self._pending.append([lo, hi])
+        self._pending.sort()
+        merged = []
+        for lo, hi in self._pending:
+            if merged and lo <= merged[-1][1]:
+                merged[-1][1] = max(merged[-1][1], hi)
+            else:
+                merged.append([lo, hi])
+        keep = []
+        for lo, hi in merged:
+            if (hi - lo) * self.flat.grad.element_size() >= self.min_bytes:
+                self._exchange(lo, hi)
+            else:
+                keep.append([lo, hi])
+        self._pending = keep
 
     def finish(self):
         """Order the exchanged gradient before whatever the compute stream does next.  Every element of the flat buffer
@@ -186,6 +229,7 @@ class OverlappedGradReducer:
         -- both are programming errors of the schedule that feeds reduce_params(), so they raise instead of being patched
         up with a second collective."""
         done, self._done = sorted(self._done), []
+        pending, self._pending = self._pending, []
         pos, n = 0, self.flat.grad.numel()
         for lo, hi in done:
             if lo < pos:
@@ -198,6 +242,8 @@ class OverlappedGradReducer:
         if pos < n:
             raise RuntimeError(f"OverlappedGradReducer: gradient elements [{pos}, {n}) were never reported by the "
                                f"backward schedule ({self._names(pos, n)}): they would stay rank-local")
+        for lo, hi in pending:                     # what never reached min_bytes on its own
+            self._exchange(lo, hi)
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
 

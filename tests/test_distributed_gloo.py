@@ -112,7 +112,7 @@ def _worker_overlap(rank, world, port, q):
     m = SpatioTemporalPriorModel_Res(64, 96)
     main = sorted([(n, p) for n, p in m.named_parameters() if not n.endswith(".quantiles")], key=lambda t: t[0])
     flat = FlatParameters(main)
-    red = D.OverlappedGradReducer(flat)
+    red = D.OverlappedGradReducer(flat, min_bytes=0)            # every module group is exchanged as soon as it is reported
     eng = m.engine()
     red.attach(eng)
     flat.grad.copy_(torch.arange(flat.numel, dtype=torch.float32) % 1000 * (rank + 1))
@@ -134,7 +134,19 @@ def _worker_overlap(rank, world, port, q):
     ok_runs = red.calls - calls == 2 and torch.equal(flat.grad[he_slice][:256], before)
     eng.grad_ready_hook(groups[4])
     red.finish()
-    q.put((rank, {"ok": bool(torch.equal(flat.grad, expect)), "runs": bool(ok_runs), "calls": red.calls, "scale": red.grad_scale}))
+    ok_a, n_a = bool(torch.equal(flat.grad, expect)), red.collectives
+    # default mode: neighbouring groups travel together (a run is exchanged once it holds min_bytes, the rest at finish());
+    # nothing may be exchanged before it was reported, everything exactly once
+    red2 = D.OverlappedGradReducer(flat, min_bytes=1 << 40).attach(eng)       # nothing reaches the threshold: one run at finish()
+    flat.grad.copy_(torch.arange(flat.numel, dtype=torch.float32) % 1000 * (rank + 1))
+    for grp in groups[:3]:
+        eng.grad_ready_hook(grp)
+    untouched = bool(torch.equal(flat.grad[he_slice][:256], before))          # HE not reported yet: still this rank's values
+    eng.grad_ready_hook(groups[3])
+    eng.grad_ready_hook(groups[4])
+    red2.finish()
+    ok_b = bool(torch.equal(flat.grad, expect)) and untouched and red2.collectives == 1 and n_a == 6 and red2.calls == 6
+    q.put((rank, {"ok": ok_a and ok_b, "runs": bool(ok_runs), "calls": red.calls, "scale": red.grad_scale}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -288,7 +300,7 @@ def test_backend_choice_follows_device_count(monkeypatch):
     from spatiotemporalentropymodel_amd import distributed as D
     seen = {}
     monkeypatch.setattr(D.dist, "is_initialized", lambda: False)
-    monkeypatch.setattr(D.dist, "init_process_group", lambda backend, rank, world_size: seen.update(b=backend, r=rank, w=world_size))
+    monkeypatch.setattr(D.dist, "init_process_group", lambda backend, rank, world_size, **kw: seen.update(b=backend, r=rank, w=world_size, kw=kw))
     monkeypatch.setattr(D.torch.cuda, "set_device", lambda d: seen.update(dev=d))
     monkeypatch.delenv("STEM_DIST_BACKEND", raising=False)
     for ndev, world, rank, want, local in ((8, 8, 5, "nccl", 5), (1, 2, 1, "gloo", 0), (0, 2, 1, "gloo", 1), (1, 1, 0, "nccl", 0)):
@@ -297,6 +309,8 @@ def test_backend_choice_follows_device_count(monkeypatch):
         seen.clear()
         assert D.init_from_env(single=True) == (rank, world, local)
         assert seen["b"] == want and seen["w"] == world, (ndev, world, seen)
+        if want == "nccl" and "pg_options" in seen["kw"]:          # RCCL's own stream at high priority, like the schedule's side streams
+            assert seen["kw"]["pg_options"].is_high_priority_stream
     # world size 1 without `single`: no process group at all
     seen.clear()
     monkeypatch.setenv("WORLD_SIZE", "1"); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("LOCAL_RANK", "0")

@@ -170,7 +170,10 @@ def test_gop_accumulator_two_ranks_equals_full_batch(dp2_results):
     # the I model's quality-map feature net holds the known kink element (see above); its effect is amplified here because
     # the frame-0 gradient it is compared against has been clipped from norm ~3000 to 1 before the BPTT terms are added
     assert errs[0][0] < 5e-2 and len(loose) <= 0.05 * len(errs), errs[:8]
-    assert all(".qmap_feature_" in n or "qmap_feature_" in n for _, n in loose), loose
+    # ... and it sits in one of the kink-bearing conditioning nets of the I model: the quality-feature stacks (leaky ReLU 0.1) or
+    # an SFT block's shared MLP (ReLU) -- which of them holds the element within fp32 noise of 0 depends on the kernels' tile /
+    # split plans (with the stride-1 layers on the bf16 kernels since round 3 it is ga1_SFT.mlp_shared)
+    assert all("qmap_feature_" in n or "_SFT.mlp_" in n for _, n in loose), loose
 
 
 # ---- RCCL itself, as far as one GPU allows: a world-size-1 "nccl" process group ------------------------------------------

@@ -9,50 +9,60 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from spatiotemporalentropymodel_amd import functional as F  # noqa: E402
 
-n, seed = (int(sys.argv[1]) if len(sys.argv) > 1 else 40), (int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-rng = np.random.default_rng(seed)
-dev = torch.device("cuda:0")
-worst = 0.0
-for it in range(n):
-    B = int(rng.integers(1, 4)); H = int(rng.integers(3, 24)); W = int(rng.integers(3, 24))
-    C = 32 * int(rng.integers(1, 7)); K = 32 * int(rng.integers(1, 9)); R = int(rng.choice([1, 3, 5])); st = int(rng.choice([1, 1, 2]))
-    pad = R // 2
-    if (H + 2 * pad - R) // st + 1 < 1 or (W + 2 * pad - R) // st + 1 < 1:
-        continue
-    torch.manual_seed(it + 1000 * seed)
-    x = torch.randn(B, C, H, W, device=dev) * 2; w = torch.randn(K, C, R, R, device=dev) / (C * R * R) ** 0.5; b = torch.randn(K, device=dev) * 0.1
-    x64, w64, b64 = x.double().cpu(), w.double().cpu(), b.double().cpu()
-    ref = torch.nn.functional.conv2d(x64, w64, b64, stride=st, padding=pad)
-    xp = F.Bf16Planes.split(x)
-    errs = {}
-    # general kernel, forward (+ leaky ReLU), planes out
-    y, yp = F.conv2d_bf16x6_gen(xp, F.pack_weight_bf16x3_gen(w), b, K, R, R, st, pad, epi=F.GEN_EPI_LRELU, slope=0.01, want_planes=True)
-    r = torch.nn.functional.leaky_relu(ref, 0.01)
-    errs["gen"] = float((y.double().cpu() - r).abs().max() / r.abs().max())
-    assert torch.equal(yp.merge(), y)
-    # analysis-transform kernel (K <= 192), with GDN
-    if K <= 192:
-        beta = torch.rand(K, device=dev) + 0.5; gamma = torch.rand(K, K, device=dev) * 0.1
-        yg = F.conv2d_bf16x6_fwd(xp, F.pack_weight_bf16x3(w), b, K, R, R, st, pad, beta, gamma)
-        ped = 2.0 ** -36
-        bb = torch.clamp(beta.double().cpu(), min=(1e-6 + ped) ** 0.5) ** 2 - ped; gg = torch.clamp(gamma.double().cpu(), min=2.0 ** -18) ** 2 - ped
-        rg = ref / torch.sqrt(torch.nn.functional.conv2d(ref * ref, gg[:, :, None, None], bb))
-        errs["g_a"] = float((yg.double().cpu() - rg).abs().max() / rg.abs().max())
-    if st == 1:
-        dy = torch.randn(B, K, H, W, device=dev); dy64 = dy.double().cpu()
-        dyp = F.Bf16Planes.split(dy)
-        d, _ = F.conv2d_bf16x6_gen(dyp, F.pack_weight_bf16x3_gen(w, flip=True), None, C, R, R, 1, pad, epi=F.GEN_EPI_DACT, slope=0.01, z=F.to_nhwc(x))
-        rd = torch.nn.grad.conv2d_input(x.shape, w64, dy64, padding=pad); rd = torch.where(x64 > 0, rd, rd * 0.01)
-        errs["dgrad"] = float((d.double().cpu() - rd).abs().max() / rd.abs().max())
-        splits, elems = F.wgrad_bf16x6_plan(x.shape, K, R, R, pad)
-        dwp = torch.empty(elems, device=dev); db = torch.zeros(K, device=dev)
-        F.conv2d_wgrad_bf16x6(xp, dyp, K, R, R, pad, dwp, splits, db=db)
-        dw = dwp.view(splits, R * R, K, C).sum(0).permute(1, 2, 0).reshape(K, C, R, R)
-        rw = torch.nn.grad.conv2d_weight(x64, (K, C, R, R), dy64, padding=pad)
-        errs["wgrad"] = float((dw.double().cpu() - rw).abs().max() / rw.abs().max())
-        errs["bias"] = float((db.double().cpu() - dy64.sum((0, 2, 3))).abs().max() / dy64.sum((0, 2, 3)).abs().max())
-    torch.cuda.synchronize()
-    m = max(errs.values()); worst = max(worst, m)
-    flag = "  <-- !!" if m > 2e-5 else ""
-    print(f"B{B} {H}x{W} C{C} K{K} k{R} s{st}: " + " ".join(f"{k} {v:.1e}" for k, v in errs.items()) + flag)
-print(f"worst relative error over the run: {worst:.2e}")
+
+
+def run(n=40, seed=0, verbose=True):
+    """-> worst relative error over `n` random cases (importable: tests call it in-process, a GPU-initialised process must not
+    start GPU children on this pool)"""
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    worst = 0.0
+    for it in range(n):
+        B = int(rng.integers(1, 4)); H = int(rng.integers(3, 24)); W = int(rng.integers(3, 24))
+        C = 32 * int(rng.integers(1, 7)); K = 32 * int(rng.integers(1, 9)); R = int(rng.choice([1, 3, 5])); st = int(rng.choice([1, 1, 2]))
+        pad = R // 2
+        if (H + 2 * pad - R) // st + 1 < 1 or (W + 2 * pad - R) // st + 1 < 1:
+            continue
+        torch.manual_seed(it + 1000 * seed)
+        x = torch.randn(B, C, H, W, device=dev) * 2; w = torch.randn(K, C, R, R, device=dev) / (C * R * R) ** 0.5; b = torch.randn(K, device=dev) * 0.1
+        x64, w64, b64 = x.double().cpu(), w.double().cpu(), b.double().cpu()
+        ref = torch.nn.functional.conv2d(x64, w64, b64, stride=st, padding=pad)
+        xp = F.Bf16Planes.split(x)
+        errs = {}
+        # general kernel, forward (+ leaky ReLU), planes out
+        y, yp = F.conv2d_bf16x6_gen(xp, F.pack_weight_bf16x3_gen(w), b, K, R, R, st, pad, epi=F.GEN_EPI_LRELU, slope=0.01, want_planes=True)
+        r = torch.nn.functional.leaky_relu(ref, 0.01)
+        errs["gen"] = float((y.double().cpu() - r).abs().max() / r.abs().max())
+        assert torch.equal(yp.merge(), y)
+        # analysis-transform kernel (K <= 192), with GDN
+        if K <= 192:
+            beta = torch.rand(K, device=dev) + 0.5; gamma = torch.rand(K, K, device=dev) * 0.1
+            yg = F.conv2d_bf16x6_fwd(xp, F.pack_weight_bf16x3(w), b, K, R, R, st, pad, beta, gamma)
+            ped = 2.0 ** -36
+            bb = torch.clamp(beta.double().cpu(), min=(1e-6 + ped) ** 0.5) ** 2 - ped; gg = torch.clamp(gamma.double().cpu(), min=2.0 ** -18) ** 2 - ped
+            rg = ref / torch.sqrt(torch.nn.functional.conv2d(ref * ref, gg[:, :, None, None], bb))
+            errs["g_a"] = float((yg.double().cpu() - rg).abs().max() / rg.abs().max())
+        if st == 1:
+            dy = torch.randn(B, K, H, W, device=dev); dy64 = dy.double().cpu()
+            dyp = F.Bf16Planes.split(dy)
+            d, _ = F.conv2d_bf16x6_gen(dyp, F.pack_weight_bf16x3_gen(w, flip=True), None, C, R, R, 1, pad, epi=F.GEN_EPI_DACT, slope=0.01, z=F.to_nhwc(x))
+            rd = torch.nn.grad.conv2d_input(x.shape, w64, dy64, padding=pad); rd = torch.where(x64 > 0, rd, rd * 0.01)
+            errs["dgrad"] = float((d.double().cpu() - rd).abs().max() / rd.abs().max())
+            splits, elems = F.wgrad_bf16x6_plan(x.shape, K, R, R, pad)
+            dwp = torch.empty(elems, device=dev); db = torch.zeros(K, device=dev)
+            F.conv2d_wgrad_bf16x6(xp, dyp, K, R, R, pad, dwp, splits, db=db)
+            dw = dwp.view(splits, R * R, K, C).sum(0).permute(1, 2, 0).reshape(K, C, R, R)
+            rw = torch.nn.grad.conv2d_weight(x64, (K, C, R, R), dy64, padding=pad)
+            errs["wgrad"] = float((dw.double().cpu() - rw).abs().max() / rw.abs().max())
+            errs["bias"] = float((db.double().cpu() - dy64.sum((0, 2, 3))).abs().max() / dy64.sum((0, 2, 3)).abs().max())
+        torch.cuda.synchronize()
+        m = max(errs.values()); worst = max(worst, m)
+        flag = "  <-- !!" if m > 2e-5 else ""
+        print(f"B{B} {H}x{W} C{C} K{K} k{R} s{st}: " + " ".join(f"{k} {v:.1e}" for k, v in errs.items()) + flag)
+    if verbose:
+        print(f"worst relative error over the run: {worst:.2e}")
+    return worst
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 0)

@@ -1,0 +1,22 @@
+#!/bin/bash
+# collect_round_profiles.sh <tag>: everything profiles/ quotes for a round, in one gpurun call -> gpurun_out/<tag>/
+tag=$1; R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/$tag; mkdir -p $out
+cd $R
+python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
+python3 bench.py --gpus 2 --steps 2 --warmup 1 > $out/bench_gpus2_one_device.json 2> $out/bench_gpus2.err
+STEM_DIST_SINGLE=1 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_rccl_world1.json 2> $out/bench_rccl_world1.err
+python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_no_group.json 2>/dev/null
+python3 bench.py --config roi --steps 2 --warmup 1 > $out/bench_roi_b16.json 2> $out/bench_roi.err
+STEM_LAYERS_BF16X6=0 python3 bench.py --config roi --steps 2 --warmup 1 > $out/bench_roi_b16_fp32_layers.json 2>/dev/null
+bash tools/debug/prof_bench.sh $tag/bench_trace > /dev/null 2>&1
+bash tools/debug/prof_pmc.sh $tag/pmc_c4gdn tools/debug/c4gdn_prof.py > $out/pmc_c4gdn.log 2>&1
+bash tools/debug/prof_tcc.sh $tag/tcc_c4gdn tools/debug/c4gdn_prof.py > $out/tcc_c4gdn.log 2>&1
+python3 tools/debug/c4gdn_time.py > $out/c4gdn_time.log 2>&1
+python3 tools/debug/route_vs_oracle.py > $out/route_vs_oracle.log 2>&1
+python3 tools/eval_pframe_bench.py --frames 3 > $out/eval_1080p_per_position_loop.log 2>&1
+python3 tools/eval_pframe_bench.py --frames 3 --sequences 8 > $out/eval_1080p_8_sequences_lockstep.log 2>&1
+if [ -f spatiotemporalentropymodel_amd/libstem_hip_exper.so ]; then
+  STEM_AR_PERSISTENT=1 STEM_HIP_LIBRARY=$R/spatiotemporalentropymodel_amd/libstem_hip_exper.so python3 tools/eval_pframe_bench.py --frames 2 > $out/eval_1080p_persistent_kernel.log 2>&1
+fi
+python3 tools/debug/host_lag.py > $out/host_lag.log 2>&1
+ls -la $out
