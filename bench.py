@@ -210,7 +210,7 @@ def cpu_baseline(budget_s=75.0):
     if limiter is not None:
         limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
     return {"value": FRAMES * B / t_sept, "unit": "frames/s", "cores": int(blas_threads), "kind": "port",
-            "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(), "host_physical_cores": cores, "batch": B,
+            "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(), "host_physical_cores": cores, "blas_threads_requested": cores, "batch": B,
             "warmup_runs": 2, "timed_runs": len(step_times),
             "p_step_s": t_step, "p_step_runs_s": [round(t, 4) for t in step_times], "g_a_s": t_ga,
             "config1_septuplet_forward_s": t_sept1,
