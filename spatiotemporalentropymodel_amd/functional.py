@@ -45,7 +45,39 @@ def make_stream(device, role):
             if "=" in kv:
                 k, v = kv.split("=")
                 _STREAM_PRIO[k.strip()] = int(v)
+    mask = _cu_mask(role)
+    if mask is not None:
+        return _masked_stream(device, mask)
     return torch.cuda.Stream(device=device, priority=_STREAM_PRIO.get(role, 0))
+
+
+def _cu_mask(role):
+    """STEM_STREAM_CUMASK="latents=block:96" / "latents=mod8:3": restrict a role's stream to a subset of the 256 CUs -- the
+    first n CU bits, or the bits i with i % 8 < k (whole XCDs if the mask enumerates CUs XCD-interleaved).  Experiment: keeps
+    the long analysis-transform kernels of the prefetch stream off most of the chip so that the P-frame step's short kernels
+    always find free CUs."""
+    for kv in os.environ.get("STEM_STREAM_CUMASK", "").split(","):
+        if "=" in kv:
+            k, v = kv.split("=")
+            if k.strip() == role:
+                kind, n = v.split(":")
+                n = int(n)
+                bits = [i < n for i in range(256)] if kind == "block" else [(i % 8) < n for i in range(256)]
+                words = [sum(1 << b for b in range(32) if bits[32 * w + b]) for w in range(8)]
+                return words
+    return None
+
+
+def _masked_stream(device, words):
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    st = ctypes.c_void_p()
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    with torch.cuda.device(device):
+        rc = lib.hipExtStreamCreateWithCUMask(ctypes.byref(st), len(words), arr)
+    if rc != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(st.value, device=device)
 
 
 def _chk(rc):

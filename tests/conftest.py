@@ -14,6 +14,7 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "dp2: two data-parallel ranks sharing cuda:0 (workers start at collection time)")
+    config.addinivalue_line("markers", "bench_gpus2: `python bench.py --gpus 2` launched bare at collection time")
 
 
 # ---- 2-rank data-parallel GPU tests ---------------------------------------------------------------------------------
@@ -32,7 +33,8 @@ def _free_port():
 
 def pytest_collection_finish(session):
     cases = sorted({m.args[0] for item in session.items for m in item.iter_markers("dp2") if m.args})
-    if not cases or session.config.option.collectonly:
+    want_bench = any(item.get_closest_marker("bench_gpus2") for item in session.items)
+    if (not cases and not want_bench) or session.config.option.collectonly:
         return
     import subprocess
     import tempfile
@@ -48,11 +50,23 @@ def pytest_collection_finish(session):
             for r in range(world)]
 
 
+    # `python bench.py --gpus 2` typed bare on the GPU box (the command form the driver uses): started here for the same reason
+    if any(item.get_closest_marker("bench_gpus2") for item in session.items):
+        env_b = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+        env_b["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        DP2["bench2"] = subprocess.Popen([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                          "--no-cpu-baseline"], env=env_b, stdout=open(os.path.join(DP2["dir"], "bench2.out"), "w"),
+                                         stderr=open(os.path.join(DP2["dir"], "bench2.err"), "w"))
+
+
 def pytest_sessionfinish(session, exitstatus):
     for procs in DP2["procs"].values():
         for p in procs:
             if p.poll() is None:
                 p.kill()
+    b = DP2.get("bench2")
+    if b is not None and b.poll() is None:
+        b.kill()
 
 
 @pytest.fixture(scope="session")

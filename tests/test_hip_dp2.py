@@ -208,3 +208,28 @@ def test_rccl_world1_gop_accumulator_bit_identical_to_no_process_group(dp2_resul
     np.testing.assert_array_equal(r["losses"][:, 1], loc["losses"][:, 1])
     for k in ("params_i", "params_p", "grad_i", "grad_p"):
         np.testing.assert_array_equal(r[k], loc[k], err_msg=k)
+
+
+@pytest.mark.bench_gpus2
+def test_bench_gpus2_typed_bare_runs_two_ranks_on_one_device():
+    """`python bench.py --gpus 2 --steps 2 --warmup 1` without any launcher (the driver's command form with N = 2): the parent
+    starts the two ranks itself before touching the GPU, they share cuda:0 and exchange through gloo (RCCL refuses two ranks on
+    one device), and stdout ends with rank 0's ONE JSON line."""
+    import json
+    import os
+    from conftest import DP2
+    proc = DP2.get("bench2")
+    assert proc is not None, "bench.py --gpus 2 was not started at collection time"
+    try:
+        rc = proc.wait(timeout=900)
+    except Exception:
+        proc.kill()
+        rc = "timeout"
+    out = open(os.path.join(DP2["dir"], "bench2.out")).read()
+    err = open(os.path.join(DP2["dir"], "bench2.err")).read()
+    assert rc == 0, f"bench.py --gpus 2 exited with {rc}:\n{err[-3000:]}"
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, out[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["config"]["global_batch"] == 32 and rec["config"]["parallelism"] == "dp2"
+    assert rec["value"] > 0 and rec["scaling"] == "weak" and "roofline" in rec and "cpu_baseline" not in rec
