@@ -271,7 +271,11 @@ def bench_roi(args):
         return
     kern_ms = float(np.mean([x.elapsed_time(y) for x, y in probe]))
     flop = 2.0 * 192 * 160 * 9 * SIZE * SIZE * B
-    achieved = flop / (kern_ms * 1e-3) / 1e12
+    bf16_layers = os.environ.get("STEM_LAYERS_BF16X6", "1") != "0"
+    # the probed layer runs on the 192-column bf16 kernel since round 3 (six bf16 MFMAs per fp32 product: executed = 6 x algorithmic,
+    # against the bf16 peak); with STEM_LAYERS_BF16X6=0 on the fp32-MFMA kernel against its own peak
+    work, peak = (6 * flop, PEAK_BF16_MFMA_TFLOPS) if bf16_layers else (flop, PEAK_FP32_MFMA_TFLOPS)
+    achieved = work / (kern_ms * 1e-3) / 1e12
     _emit({
         "metric": "frames/s", "value": FRAMES * B * world * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -279,10 +283,14 @@ def bench_roi(args):
         "config": {"workload": "configs[4]: variable-rate stem_roi_i + stem_roi GOP training iteration (I + 6 P frames 256x256, BPTT across the "
                                "GOP, clip after every frame, one step of 4 Adam optimisers), 4 lambda points (quality 0.30/0.45/0.55/0.70) in one batch",
                    "per_gpu_batch": B, "global_batch": B * world, "frames_per_step": FRAMES * B * world, "parallelism": f"dp{world}",
+                   "stride1_convolutions": "bf16 matrix cores, 6 products per fp32 product (layers.Conv2dFunction)" if bf16_layers else "fp32 MFMA",
                    "final_loss": float(log[-1][0]["loss"].detach())},
-        "roofline": {"bound": "mfma", "kernel": "igemm conv3x3 192->160 at 256x256 (stem_roi.qmap_feature_ga1.2, forward), B=%d" % B,
-                     "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                     "flop_per_launch": flop, "avg_launch_ms": kern_ms, "launches_timed": len(probe), "traffic": None}})
+        "roofline": {"bound": "mfma",
+                     "kernel": ("conv_bf16x6_kernel<128,6> with activation epilogue" if bf16_layers else "igemm") +
+                               " = conv3x3 192->160 at 256x256 (stem_roi.qmap_feature_ga1.2, forward), B=%d" % B,
+                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                     "flop_per_launch": work, "useful_flop_per_launch": flop, "useful_tflops": flop / (kern_ms * 1e-3) / 1e12,
+                     "avg_launch_ms": kern_ms, "launches_timed": len(probe), "traffic": None}})
 
 
 def _emit(res):
@@ -363,8 +371,8 @@ def main():
     ap.add_argument("--config", default="stem", choices=["stem", "roi"], help="stem = BASELINE configs[1] (the metric's workload, default); "
                     "roi = configs[4], the variable-rate GOP iteration")
     ap.add_argument("--roi-batch", type=int, default=16)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 10; 2 for --config roi)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 1 for --config roi)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latents", default="prefetch", choices=["first", "prefetch"], help="prefetch (default): getY of frame t + 1 runs on a second "
                     "stream while P-frame step t runs (trainer.LatentPrefetcher); first: getY of all 7 frames before the P-frame steps")
@@ -376,6 +384,10 @@ def main():
     ap.add_argument("--rendezvous-only", action="store_true", help="set up the ranks, run one all-reduce and the timing reduction, exit "
                     "(launcher / process-group check without the workload; works without a GPU)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 2 if args.config == "roi" else 10
+    if args.warmup is None:
+        args.warmup = 1 if args.config == "roi" else 3
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.rendezvous_only:
