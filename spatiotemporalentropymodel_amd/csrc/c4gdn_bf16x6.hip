@@ -351,6 +351,8 @@ STEM_EXPORT int stem_conv2d_c4_gdn_bf16x6(const float *x4, const void *astream, 
     STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_c4_gdn_bf16x6: empty output");
     const size_t xb = (size_t)B * H * W * 16;
     STEM_CHECK_ARG(xb < 0x7FFFFF00ull && (size_t)B * OH * OW < 0x7FFFFFFFull, "stem_conv2d_c4_gdn_bf16x6: image batch must stay below 2 GiB");
+    STEM_CHECK_ARG((!yp || (size_t)B * OH * OW * (N / 32) * 192 < 0x7FFF0000ull) && (!y || (size_t)B * OH * OW * ldy * 4 < 0x7FFF0000ull),
+                   "stem_conv2d_c4_gdn_bf16x6: outputs are addressed through 2 GiB buffer views (split the batch)");
     C4gArgs a;
     memset(&a, 0, sizeof(a));
     a.x4 = x4; a.astream = static_cast<const unsigned char *>(astream); a.bias = bias; a.beta = beta; a.y = y; a.yp = yp; a.ldy = ldy;

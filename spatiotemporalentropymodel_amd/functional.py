@@ -644,6 +644,14 @@ def c4gdn_supported(K, R, S, inverse=False):
     return (not inverse and os.environ.get("STEM_C4GDN_BF16X6", "1") != "0" and bool(_lib.hip().stem_c4gdn_supported(K, R, S)))
 
 
+def _c4gdn_fits(x4, K, R, S, stride, pad, ld=None, planes=False):
+    """operands of the bf16 first-layer kernel are addressed through 2 GiB buffer views"""
+    B, H, W, _ = x4.shape
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    out_bytes = B * Ho * Wo * ((K // 32) * 192 if planes else (ld or K) * 4)
+    return B * H * W * 16 < 0x7FFFFF00 and out_bytes < 0x7FFF0000
+
+
 def c4gdn_stream(wp_c4, gamma, K, R, S):
     """A-operand stream of conv2d_c4_gdn_bf16x6: the C4-packed first-layer weight and the reparametrised gamma of the following
     GDN, split into bf16 planes in MFMA-fragment order (one small launch; cache it while the parameters do not change)."""
@@ -671,7 +679,7 @@ def conv2d_c4_gdn_bf16x6(x4, astream, bias, beta, K, R, S, stride, pad, beta_min
 def conv2d_fwd_c4_gdn_planes(x4, wp, bias, beta, gamma, K, R, S, stride, pad, beta_min=1e-6, astream=None):
     """conv2d_fwd_c4_gdn whose result is handed to conv2d_bf16x6_fwd: written pre-split (Bf16Planes), no fp32 copy.
     `astream`: a cached c4gdn_stream(wp, gamma, ...) (built per call otherwise)."""
-    if c4gdn_supported(K, R, S) and _aligned16(bias, beta):
+    if c4gdn_supported(K, R, S) and _aligned16(bias, beta) and _c4gdn_fits(x4, K, R, S, stride, pad, planes=True):
         return conv2d_c4_gdn_bf16x6(x4, astream if astream is not None else c4gdn_stream(wp, gamma, K, R, S), bias, beta, K, R, S,
                                     stride, pad, beta_min, planes_out=True)
     B, H, W, _ = x4.shape
@@ -683,7 +691,8 @@ def conv2d_fwd_c4_gdn_planes(x4, wp, bias, beta, gamma, K, R, S, stride, pad, be
 
 
 def conv2d_fwd_c4_gdn(x4, wp, bias, beta, gamma, K, R, S, stride, pad, inverse=False, beta_min=1e-6, out=None, astream=None):
-    if c4gdn_supported(K, R, S, inverse) and _aligned16(bias, beta) and (out is None or _aligned16(out)):
+    if (c4gdn_supported(K, R, S, inverse) and _aligned16(bias, beta) and (out is None or _aligned16(out))
+            and _c4gdn_fits(x4, K, R, S, stride, pad, ld=nhwc_ld(out) if out is not None else K)):
         return conv2d_c4_gdn_bf16x6(x4, astream if astream is not None else c4gdn_stream(wp, gamma, K, R, S), bias, beta, K, R, S,
                                     stride, pad, beta_min, out=out)
     B, H, W, _ = x4.shape
