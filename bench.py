@@ -399,6 +399,8 @@ def main():
     from spatiotemporalentropymodel_amd import _lib
     from spatiotemporalentropymodel_amd import distributed as D
     _lib.hip()                                    # no HIP library -> fail loudly, nothing to measure
+    if os.environ.get("STEM_BENCH_BX6_TILE"):     # sweep aid: force the 192-column kernel's pixel tile (64 / 128)
+        _lib.check(_lib.hip().stem_tuning_set(b"bx6_tile", int(os.environ["STEM_BENCH_BX6_TILE"])))
     rank, world, local = D.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
