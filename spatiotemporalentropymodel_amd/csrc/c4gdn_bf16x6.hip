@@ -29,7 +29,7 @@
 
 namespace {
 
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef hp8 bf16x8;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CHUNK = 18432;                    // bytes of one A-operand chunk: 18 fragments x 64 lanes x 16 B
@@ -39,17 +39,13 @@ constexpr int WG_PIX = 128, NTHREADS = 256;     // 4 wavefronts x 32 pixels
 
 __host__ __device__ inline int rho(int r) { return 16 * ((r >> 2) & 1) + 4 * (r >> 3) + (r & 3); }
 
-__device__ inline void split3(const float x, __bf16 &h0, __bf16 &h1, __bf16 &h2)
-{
-    h0 = (__bf16)x;
-    const float r1 = x - (float)h0;
-    h1 = (__bf16)r1;
-    h2 = (__bf16)(r1 - (float)h1);
-}
 
 struct C4gArgs {
     const float *x4;               // [B][H][W][4] fp32 (stem_nchw3_to_nhwc4)
+    const float *xq;               // scale record of the image: slots = max |x| (stem_nchw3_to_nhwc4 / stem_amax_nhwc)
     const unsigned char *astream;  // c4gdn_pack_kernel's output
+    const float *wq, *gq;          // scale records of the two parts of the stream (conv weights, gamma'), behind its chunks
+    float *yq;                     // scale record of the output
     const float *bias, *beta;
     float *y;
     void *yp;
@@ -66,10 +62,20 @@ struct C4gArgs {
 //   = (filter row q / PR, taps 2 (q % PR) and 2 (q % PR) + 1), PR = ceil(S / 2); slots beyond the filter hold 0;
 // chunk ksc + 2 kb + s (GDN k-step s of k-block kb): fragment (nb, plane) at the same place; lane (r, h) element j =
 //   gamma'[nb * 32 + rho(r)][kb * 32 + 16 h + 8 s + j], gamma' = max(gamma, 2^-18)^2 - 2^-36 (parametrizers.py:42-45).
-__global__ __launch_bounds__(256) void c4gdn_pack_kernel(const float *wp_c4, const float *gamma, unsigned char *out, int N, int R, int S, int ksc)
+__global__ __launch_bounds__(256) void c4gdn_pack_kernel(const float *wp_c4, const float *gamma, unsigned char *out, int N, int R, int S, int ksc,
+                                                         float *wq, float *gq)
 {
     const int NB = N / 32, PR = (S + 1) / 2;
     const int nchunks = ksc + 2 * NB;
+    // scales: the weights by their maximum, gamma' = max(gamma, 2^-18)^2 - 2^-36 by the bound max(|gamma|max, 2^-18)^2
+    __shared__ float qred[16];
+    const int we = q_exp(q_amax(wq, qred));
+    const float gm = fmaxf(q_amax(gq, qred), 3.814697265625e-06f);
+    const int ge = q_exp(gm * gm);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        wq[1] = q_pow2(-we);
+        gq[1] = q_pow2(-ge);
+    }
     const int e = blockIdx.x * 256 + threadIdx.x;           // (chunk, fragment position without the plane, lane)
     const int lane = e & 63, fp = (e >> 6) % 6, c = (e >> 6) / 6;
     if (c >= nchunks) return;
@@ -97,9 +103,10 @@ __global__ __launch_bounds__(256) void c4gdn_pack_kernel(const float *wp_c4, con
     }
     if (!used) return;
     bf16x8 p0, p1, p2;
+    const float sc = q_pow2(c < ksc ? we : ge);
     for (int j = 0; j < 8; ++j) {
-        __bf16 a, b, cc;
-        split3(v[j], a, b, cc);
+        hp_t a, b, cc;
+        q_split(v[j], sc, a, b, cc);
         p0[j] = a; p1[j] = b; p2[j] = cc;
     }
     unsigned char *dst = out + (size_t)c * CHUNK + ((size_t)(fp * 3) * 64 + lane) * 16;
@@ -111,12 +118,14 @@ __global__ __launch_bounds__(256) void c4gdn_pack_kernel(const float *wp_c4, con
 // six products of one fp32 product, smallest terms first (as conv_bf16x6.hip)
 __device__ inline f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 acc)
 {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    if constexpr (STEM_NP == 6) {
+        acc = STEM_MFMA16(a[2], b[0], acc);
+        acc = STEM_MFMA16(a[0], b[2], acc);
+        acc = STEM_MFMA16(a[1], b[1], acc);
+    }
+    acc = STEM_MFMA16(a[1], b[0], acc);
+    acc = STEM_MFMA16(a[0], b[1], acc);
+    acc = STEM_MFMA16(a[0], b[0], acc);
     return acc;
 }
 
@@ -124,7 +133,7 @@ __device__ inline f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x1
 __device__ inline void lda(const unsigned char *p, bf16x8 (&af)[3])
 {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const bf16x8 *>(p + pl * 1024);
+    for (int pl = 0; pl < (STEM_NP == 6 ? 3 : 2); ++pl) af[pl] = *reinterpret_cast<const bf16x8 *>(p + pl * 1024);
 }
 
 template <int NB>
@@ -182,6 +191,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
         v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o1, 0, 0));
     };
 
+    // ---- scales (stem_common.h): the image by its measured maximum; the squares and the output by upper bounds derived from it --
+    __shared__ float qred[16];
+    float xscale, cfac, sqscale, nfac, oscale;
+    {
+        const float xmax = q_amax(a.xq, qred), wmax = q_amax(a.wq, qred);
+        float bm = 0.f, btm = 3.0e38f;
+        if (tid < a.N) {
+            if (a.bias) bm = fabsf(a.bias[tid]);
+            const float bb = fmaxf(a.beta[tid], a.beta_bound);
+            btm = bb * bb - 1.4551915228366852e-11f;
+        }
+        bm = block_max(bm, qred);
+        btm = -block_max(-btm, qred);
+        const float vb = (float)(3 * a.R * a.S) * xmax * wmax + bm;        // |conv output| <= K |x|max |w|max + |bias|max
+        const int xe = q_exp(xmax), se = q_exp(vb * vb), oe = q_exp(vb * __builtin_amdgcn_rsqf(fmaxf(btm, 1e-30f)));
+        xscale = q_pow2(xe);
+        cfac = q_pow2(-xe) * q_inv(a.wq);
+        sqscale = q_pow2(se);
+        nfac = q_pow2(-se) * q_inv(a.gq);
+        oscale = q_pow2(oe);
+        if (a.yq && blockIdx.x == 0 && tid == 0) {
+            q_header(a.yq, gridDim.x);
+            a.yq[1] = a.yp ? q_pow2(-oe) : 1.f;
+        }
+    }
+    const float binit = 1.f / cfac;                      // the accumulators hold conv * 2^(ex + ew): the bias enters scaled alike
+
     // ---- x[nb][i] = conv output of channel nb * 32 + 16 h + i at this lane's pixel, starting from the bias ---------------------
     f32x16 x[NB];
 #pragma unroll
@@ -191,7 +227,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
             for (int i4 = 0; i4 < 4; ++i4) {
                 const f32x4 bv = *reinterpret_cast<const f32x4 *>(a.bias + nb * 32 + 16 * h + 4 * i4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) x[nb][4 * i4 + e] = bv[e];
+                for (int e = 0; e < 4; ++e) x[nb][4 * i4 + e] = bv[e] * binit;
             }
         } else {
 #pragma unroll
@@ -211,10 +247,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
         bf16x8 b[3];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            __bf16 h0, h1, h2;
-            split3(pv0[j], h0, h1, h2);
+            hp_t h0, h1, h2;
+            q_split(pv0[j], xscale, h0, h1, h2);
             b[0][j] = h0; b[1][j] = h1; b[2][j] = h2;
-            split3(pv1[j], h0, h1, h2);
+            q_split(pv1[j], xscale, h0, h1, h2);
             b[0][4 + j] = h0; b[1][4 + j] = h1; b[2][4 + j] = h2;
         }
         patch_load(t + 1 < a.ksc ? t + 1 : t, pv0, pv1);
@@ -239,7 +275,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) nrm[nb][i] = 0.f;
+        for (int i = 0; i < 16; ++i) {
+            nrm[nb][i] = 0.f;
+            x[nb][i] *= cfac;                            // back to true units (exact: a power of two)
+        }
     int c = a.ksc;
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
@@ -252,8 +291,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float v = x[kb][8 * s + j];
-                __bf16 h0, h1, h2;
-                split3(v * v, h0, h1, h2);
+                hp_t h0, h1, h2;
+                q_split(v * v, sqscale, h0, h1, h2);
                 b[0][j] = h0; b[1][j] = h1; b[2][j] = h2;
             }
             bf16x8 af[2][3];
@@ -266,6 +305,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
             }
         }
     }
+    float omax = 0.f;
     {
         // epilogue: y = x * rsqrt(beta' + norm), 16 consecutive channels per lane and tile
 #pragma unroll
@@ -277,8 +317,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float bb = fmaxf(bt[e], a.beta_bound);
-                    yv[4 * i4 + e] = x[nb][4 * i4 + e] * __builtin_amdgcn_rsqf(nrm[nb][4 * i4 + e] + (bb * bb - 1.4551915228366852e-11f));
+                    yv[4 * i4 + e] = x[nb][4 * i4 + e] * __builtin_amdgcn_rsqf(nrm[nb][4 * i4 + e] * nfac + (bb * bb - 1.4551915228366852e-11f));
                 }
+            }
+            if (ok) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) omax = fmaxf(omax, fabsf(yv[i]));
             }
             if (a.y) {
 #pragma unroll
@@ -293,8 +337,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
                 bf16x8 q0[2], q1[2], q2[2];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    __bf16 h0, h1, h2;
-                    split3(yv[i], h0, h1, h2);
+                    hp_t h0, h1, h2;
+                    q_split(yv[i], oscale, h0, h1, h2);
                     q0[i >> 3][i & 7] = h0; q1[i >> 3][i & 7] = h1; q2[i >> 3][i & 7] = h2;
                 }
 #pragma unroll
@@ -307,9 +351,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
             __builtin_amdgcn_sched_barrier(0);         // one tile's epilogue at a time: 56 live registers instead of 3 x 56
         }
     }
+    if (a.yq) {
+        omax = block_max(omax, qred);
+        if (tid == 0) a.yq[QREC_HDR + blockIdx.x] = omax;
+    }
 }
 
 int conv_ksteps(int R, int S) { return (R * ((S + 1) / 2) + 1) / 2; }
+constexpr int QSLOTS = 16;
+constexpr size_t QREC_BYTES = (QREC_HDR + QSLOTS) * sizeof(float);
+
+__global__ __launch_bounds__(256) void c4gdn_amax_kernel(const float *w, long nw, const float *g, long ng, float *wq, float *gq)
+{
+    __shared__ float qred[16];
+    const float *src = blockIdx.y ? g : w;
+    const long n = blockIdx.y ? ng : nw;
+    float m = 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) m = fmaxf(m, fabsf(src[e]));
+    m = block_max(m, qred);
+    if (threadIdx.x == 0) {
+        float *q = blockIdx.y ? gq : wq;
+        q[QREC_HDR + blockIdx.x] = m;
+        if (blockIdx.x == 0) q_header(q, gridDim.x);
+    }
+}
 
 }   // namespace
 
@@ -322,7 +387,7 @@ STEM_EXPORT int stem_c4gdn_supported(int N, int R, int S)
 STEM_EXPORT size_t stem_c4gdn_stream_bytes(int N, int R, int S)
 {
     if (!stem_c4gdn_supported(N, R, S)) return 0;
-    return (size_t)(conv_ksteps(R, S) + 2 * (N / 32)) * CHUNK;
+    return (size_t)(conv_ksteps(R, S) + 2 * (N / 32)) * CHUNK + 2 * QREC_BYTES;       // + the scale records of weights and gamma'
 }
 
 STEM_EXPORT int stem_c4gdn_pack(const float *wp_c4, const float *gamma, void *astream, int N, int R, int S, void *stream)
@@ -331,17 +396,21 @@ STEM_EXPORT int stem_c4gdn_pack(const float *wp_c4, const float *gamma, void *as
     STEM_CHECK_ARG(stem_c4gdn_supported(N, R, S), "stem_c4gdn_pack: N must be 64, 128 or 192 and R*S <= 25 (N=%d R=%d S=%d)", N, R, S);
     const int ksc = conv_ksteps(R, S), nchunks = ksc + 2 * (N / 32);
     (void)hipMemsetAsync(astream, 0, (size_t)nchunks * CHUNK, (hipStream_t)stream);
+    float *wq = reinterpret_cast<float *>(static_cast<unsigned char *>(astream) + (size_t)nchunks * CHUNK);
+    float *gq = wq + QREC_HDR + QSLOTS;
+    hipLaunchKernelGGL(c4gdn_amax_kernel, dim3(QSLOTS, 2), dim3(256), 0, (hipStream_t)stream, wp_c4, (long)N * 32 * 4, gamma, (long)N * N, wq, gq);
     const int n = nchunks * 6 * 64;
     hipLaunchKernelGGL(c4gdn_pack_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, wp_c4, gamma,
-                       static_cast<unsigned char *>(astream), N, R, S, ksc);
+                       static_cast<unsigned char *>(astream), N, R, S, ksc, wq, gq);
     STEM_LAUNCH_CHECK("stem_c4gdn_pack");
     return 0;
 }
 
-STEM_EXPORT int stem_conv2d_c4_gdn_bf16x6(const float *x4, const void *astream, const float *bias, const float *beta, float beta_min,
-                                          float *y, int ldy, void *yp, int B, int H, int W, int N, int R, int S, int stride, int pad, void *stream)
+STEM_EXPORT int stem_conv2d_c4_gdn_bf16x6(const float *x4, const float *xq, const void *astream, const float *bias, const float *beta, float beta_min,
+                                          float *y, int ldy, void *yp, float *yq, int B, int H, int W, int N, int R, int S, int stride, int pad,
+                                          void *stream)
 {
-    STEM_CHECK_ARG(x4 && astream && beta && (y || yp), "stem_conv2d_c4_gdn_bf16x6: null pointer");
+    STEM_CHECK_ARG(x4 && xq && astream && beta && (y || yp) && (yq || !yp), "stem_conv2d_c4_gdn_bf16x6: null pointer (planes come with their scale record)");
     STEM_CHECK_ARG(stem_c4gdn_supported(N, R, S), "stem_conv2d_c4_gdn_bf16x6: N must be 64, 128 or 192 and R*S <= 25 (N=%d R=%d S=%d)", N, R, S);
     STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && stride >= 1 && pad >= 0, "stem_conv2d_c4_gdn_bf16x6: bad geometry");
     STEM_CHECK_ARG(!y || (ldy >= N && ldy % 4 == 0 && ((uintptr_t)y & 15) == 0), "stem_conv2d_c4_gdn_bf16x6: y rows must be 16-byte aligned, ldy >= N");
@@ -355,7 +424,9 @@ STEM_EXPORT int stem_conv2d_c4_gdn_bf16x6(const float *x4, const void *astream, 
                    "stem_conv2d_c4_gdn_bf16x6: outputs are addressed through 2 GiB buffer views (split the batch)");
     C4gArgs a;
     memset(&a, 0, sizeof(a));
-    a.x4 = x4; a.astream = static_cast<const unsigned char *>(astream); a.bias = bias; a.beta = beta; a.y = y; a.yp = yp; a.ldy = ldy;
+    a.x4 = x4; a.xq = xq; a.yq = yq; a.astream = static_cast<const unsigned char *>(astream);
+    a.wq = reinterpret_cast<const float *>(a.astream + (size_t)(conv_ksteps(R, S) + 2 * (N / 32)) * CHUNK);
+    a.gq = a.wq + QREC_HDR + QSLOTS; a.bias = bias; a.beta = beta; a.y = y; a.yp = yp; a.ldy = ldy;
     a.B = B; a.H = H; a.W = W; a.N = N; a.OH = OH; a.OW = OW; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
     a.ksc = conv_ksteps(R, S);
     a.xbytes = (int)xb;

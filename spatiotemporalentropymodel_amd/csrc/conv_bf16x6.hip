@@ -28,7 +28,7 @@
 
 namespace {
 
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef hp8 bf16x8;
 
 constexpr int BN = 192, KC = 32;
 constexpr int B_PLANE = BN * 64, B_BUF = 3 * B_PLANE;              // bytes of one bf16 plane of a weight chunk; 36864 per chunk
@@ -41,6 +41,8 @@ constexpr int OOR = 0x7FFFFF00;                                    // voffset th
 
 struct Bx6Args {
     const void *xp, *wp;
+    const float *xq, *wq;          // scale records of the two operands (stem_common.h)
+    float *yq;                     // ... of the output: slots always, the scale when planes are written (may be null without planes)
     const float *bias, *beta, *gamma;
     float *y;
     void *yp;
@@ -49,7 +51,6 @@ struct Bx6Args {
     int xbytes, wbytes, gmbytes;
     float beta_bound;
     int fuse;                      // 0: bias only, 1: GDN
-    int exper;                     // tuning experiments (STEM_BX6_EXPER), 0 in production
     // general variant (conv_bf16x6_gen_kernel): activation epilogue, N tiles, split-K
     const float *z;                // EPI_DACT: the activation output the slope is selected by (z > 0 ? 1 : slope)
     int ldz, epi;                  // epi: 0 bias, 1 bias + leaky ReLU, 2 times d(leaky ReLU)(z)
@@ -63,13 +64,6 @@ struct Bx6Args {
 
 __device__ inline int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
-__device__ inline void split3(const float x, __bf16 &h0, __bf16 &h1, __bf16 &h2)
-{
-    h0 = (__bf16)x;
-    const float r1 = x - (float)h0;           // exact: x and h0 agree in their leading 8 bits
-    h1 = (__bf16)r1;
-    h2 = (__bf16)(r1 - (float)h1);            // exact, and at most 8 significant bits are left
-}
 
 // BM = pixels per workgroup: 128 (8 wavefronts) or 64 (4 wavefronts, for layers with too few 128-pixel tiles to fill the chip).
 // NP = number of bf16 products kept per fp32 product: 6 (i + j <= 2, all three planes), 4 (i, j <= 1) or 3 (i + j <= 1); the
@@ -175,13 +169,13 @@ __global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {      // smallest terms first
                 if constexpr (NP == 6) {
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PL - 1], bf[0][j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[PL - 1][j], acc[j], 0, 0, 0);
+                    acc[j] = STEM_MFMA16(af[PL - 1], bf[0][j], acc[j]);
+                    acc[j] = STEM_MFMA16(af[0], bf[PL - 1][j], acc[j]);
                 }
-                if constexpr (NP >= 4) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1][j], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0][j], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1][j], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0][j], acc[j], 0, 0, 0);
+                if constexpr (NP >= 4) acc[j] = STEM_MFMA16(af[1], bf[1][j], acc[j]);
+                acc[j] = STEM_MFMA16(af[1], bf[0][j], acc[j]);
+                acc[j] = STEM_MFMA16(af[0], bf[1][j], acc[j]);
+                acc[j] = STEM_MFMA16(af[0], bf[0][j], acc[j]);
             }
             if (ks == 0)
                 sstore(cur ^ 1, ra, rb);           // the register set holds the next chunk
@@ -233,12 +227,35 @@ __global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
     // ---- epilogue: lane holds column n = wn0 + 32 j + lr, rows (r & 3) + 8 (r >> 2) + 4 lh of each 32x32 tile ---------------
     float *X2 = reinterpret_cast<float *>(smem);                   // [BM][XP]
     float *Gs = X2 + BM * XP;                                      // [BN][GP]
+    __shared__ float qred[16];
+    const float fac = q_inv(a.xq) * q_inv(a.wq);                   // the operands were stored times 2^ex, 2^ew
+    float oscale = 1.f;                                            // 2^e of the planes output
+    if (a.yp) {
+        // upper bound of |output| from the operands' maxima: K terms of at most xmax * wmax each, plus the bias; GDN divides by
+        // at least sqrt(min beta').  One layer's worth of over-estimation (the inputs' maxima are measured, not bounded).
+        const float xmax = q_amax(a.xq, qred), wmax = q_amax(a.wq, qred);
+        float bm = 0.f, btm = 3.0e38f;
+        for (int n = tid; n < a.N; n += NT) {
+            if (a.bias) bm = fmaxf(bm, fabsf(a.bias[n]));
+            if (a.fuse) {
+                const float bb = fmaxf(a.beta[n], a.beta_bound);
+                btm = fminf(btm, bb * bb - 1.4551915228366852e-11f);
+            }
+        }
+        bm = block_max(bm, qred);
+        float ob = (float)(a.C * a.ntaps) * xmax * wmax + bm;
+        if (a.fuse) ob *= __builtin_amdgcn_rsqf(fmaxf(-block_max(-btm, qred), 1e-30f));
+        const int oe = q_exp(ob);
+        oscale = q_pow2(oe);
+        if (blockIdx.x == 0 && tid == 0) a.yq[1] = q_pow2(-oe);
+    }
+    float omax = 0.f;                                              // max |output| of this thread
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int n = wn0 + j * 32 + lr;
         const float bias = (a.bias && n < a.N) ? a.bias[n] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] += bias;
+        for (int r = 0; r < 16; ++r) acc[j][r] = acc[j][r] * fac + bias;
         if (a.epi == 1) {          // leaky ReLU (slope 0 = ReLU) of a conv + activation pair (layer-wise models)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = acc[j][r] > 0.f ? acc[j][r] : acc[j][r] * a.slope;
@@ -318,6 +335,23 @@ __global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
             for (int r = 0; r < 16; ++r) acc[j][r] *= __builtin_amdgcn_rsqf(nrm[j][r] + bt);
         }
     }
+    if (a.yq) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const bool okn = wn0 + j * 32 + lr < a.N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (okn && bm0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh < Mtot) omax = fmaxf(omax, fabsf(acc[j][r]));
+        }
+        omax = block_max(omax, qred);
+        if (tid == 0) {
+            a.yq[QREC_HDR + blockIdx.x] = omax;
+            if (blockIdx.x == 0) {
+                q_header(a.yq, gridDim.x);
+                if (!a.yp) a.yq[1] = 1.f;
+            }
+        }
+    }
 
     if (a.y) {      // fp32 NHWC output (last layer of the transform)
 #pragma unroll
@@ -342,16 +376,16 @@ __global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
         for (int e = tid; e < BM * oslab * 4; e += NT) {
             const int row = e / (oslab * 4), rem = e - row * (oslab * 4), sl = rem >> 2, p = rem & 3;
             const int m = bm0 + row;
-            if (m >= Mtot || ((a.exper & 1) && m >= 0)) continue;
+            if (m >= Mtot) continue;
             const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&X2[row * XP + sl * 32 + p * 8]);
             const f32x4 v1 = *reinterpret_cast<const f32x4 *>(&X2[row * XP + sl * 32 + p * 8 + 4]);
             bf16x8 h0, h1, h2;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                __bf16 x0, x1, x2;
-                split3(v0[c], x0, x1, x2);
+                hp_t x0, x1, x2;
+                q_split(v0[c], oscale, x0, x1, x2);
                 h0[c] = x0; h1[c] = x1; h2[c] = x2;
-                split3(v1[c], x0, x1, x2);
+                q_split(v1[c], oscale, x0, x1, x2);
                 h0[4 + c] = x0; h1[4 + c] = x1; h2[4 + c] = x2;
             }
             unsigned char *dst = yp + (size_t)m * opix + sl * 192 + p * 16;
@@ -462,13 +496,13 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if constexpr (NP == 6) {
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PL - 1], bf[0][j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[PL - 1][j], acc[j], 0, 0, 0);
+                    acc[j] = STEM_MFMA16(af[PL - 1], bf[0][j], acc[j]);
+                    acc[j] = STEM_MFMA16(af[0], bf[PL - 1][j], acc[j]);
                 }
-                if constexpr (NP >= 4) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1][j], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0][j], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1][j], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0][j], acc[j], 0, 0, 0);
+                if constexpr (NP >= 4) acc[j] = STEM_MFMA16(af[1], bf[1][j], acc[j]);
+                acc[j] = STEM_MFMA16(af[1], bf[0][j], acc[j]);
+                acc[j] = STEM_MFMA16(af[0], bf[1][j], acc[j]);
+                acc[j] = STEM_MFMA16(af[0], bf[0][j], acc[j]);
             }
             if (ks == 0)
                 sstore(cur ^ 1, ra, rb);
@@ -598,12 +632,26 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
             for (int r = 0; r < 16; ++r) T[(wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * GTP + wn0 + j * 32 + lr] = acc[j][r];
     }
     __syncthreads();
+    __shared__ float qred[16];
+    const float fac = q_inv(a.xq) * q_inv(a.wq);                   // the operands were stored times 2^ex, 2^ew
+    float oscale = 1.f;
+    if (a.yp) {     // scale of the planes output from an upper bound of |output| (see conv_bf16x6_kernel)
+        const float xmax = q_amax(a.xq, qred), wmax = q_amax(a.wq, qred);
+        float bm = 0.f;
+        if (a.bias)
+            for (int n = tid; n < a.N; n += GNT) bm = fmaxf(bm, fabsf(a.bias[n]));
+        bm = block_max(bm, qred);
+        const int oe = q_exp((float)(a.C * a.ntaps) * xmax * wmax + bm);
+        oscale = q_pow2(oe);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.yq[1] = q_pow2(-oe);
+    }
+    float omax = 0.f;
     // ---- bias / activation, fp32 rows (16 bytes per thread), activated values back into T for the planes pass -----------------
     for (int e = tid; e < GBM * (GBN / 4); e += GNT) {
         const int row = e / (GBN / 4), c4 = e - row * (GBN / 4);
         const int m = bm0 + row, n = bn0 + c4 * 4;
         if (m >= Mtot || n >= a.N) continue;                // N % 4 == 0 (host check)
-        f32x4 v = *reinterpret_cast<const f32x4 *>(&T[row * GTP + c4 * 4]);
+        f32x4 v = *reinterpret_cast<const f32x4 *>(&T[row * GTP + c4 * 4]) * fac;
         if (a.bias) {               // parameters may sit at any 4-byte offset of a flat buffer: scalar loads
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] += a.bias[n + c];
@@ -618,6 +666,17 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
         }
         if (a.y) *reinterpret_cast<f32x4 *>(a.y + (size_t)m * a.ldy + n) = v;
         *reinterpret_cast<f32x4 *>(&T[row * GTP + c4 * 4]) = v;
+        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if (a.yq) {
+        omax = block_max(omax, qred);
+        if (tid == 0) {
+            a.yq[QREC_HDR + blockIdx.y * gridDim.x + blockIdx.x] = omax;
+            if (blockIdx.x == 0 && blockIdx.y == 0) {
+                q_header(a.yq, gridDim.x * gridDim.y);
+                if (!a.yp) a.yq[1] = 1.f;
+            }
+        }
     }
     if (a.yp) {
         __syncthreads();
@@ -632,10 +691,10 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
             bf16x8 h0, h1, h2;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                __bf16 x0, x1, x2;
-                split3(v0[c], x0, x1, x2);
+                hp_t x0, x1, x2;
+                q_split(v0[c], oscale, x0, x1, x2);
                 h0[c] = x0; h1[c] = x1; h2[c] = x2;
-                split3(v1[c], x0, x1, x2);
+                q_split(v1[c], oscale, x0, x1, x2);
                 h0[4 + c] = x0; h1[4 + c] = x1; h2[4 + c] = x2;
             }
             unsigned char *dst = yp + (size_t)m * opix + (n >> 5) * 192 + ((n >> 3) & 3) * 16;
@@ -649,8 +708,13 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
 // weights for conv_bf16x6_gen_kernel: [N tile][chunk q = slab * R*S + tap][plane][128 rows][64 B].  flip: the input-gradient of
 // a stride-1 convolution is a convolution of dy with w'[c][k][r][s] = w[k][c][R-1-r][S-1-s]: `w` is still the torch weight
 // [K][C][R][S], the packed rows are its input channels c (N = C outputs) and the packed channels its output channels k.
-__global__ __launch_bounds__(256) void pack_weight_gen_kernel(const float *w, unsigned char *wp, int N, int C, int RS, int flip, long npieces)
+__global__ __launch_bounds__(256) void pack_weight_gen_kernel(const float *w, unsigned char *wp, int N, int C, int RS, int flip, long npieces,
+                                                              float *wq)
 {
+    __shared__ float qred[16];
+    const int we = q_exp(q_amax(wq, qred));
+    const float wscale = q_pow2(we);
+    if (blockIdx.x == 0 && threadIdx.x == 0) wq[1] = q_pow2(-we);
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= npieces) return;
     const int nchunks = (C / 32) * RS;
@@ -664,8 +728,8 @@ __global__ __launch_bounds__(256) void pack_weight_gen_kernel(const float *w, un
         const int ch = slab * 32 + p * 8 + c;
         float v = 0.f;
         if (n < N) v = flip ? w[((size_t)ch * N + n) * RS + (RS - 1 - tap)] : w[((size_t)n * C + ch) * RS + tap];
-        __bf16 x0, x1, x2;
-        split3(v, x0, x1, x2);
+        hp_t x0, x1, x2;
+        q_split(v, wscale, x0, x1, x2);
         h[0][c] = x0; h[1][c] = x1; h[2][c] = x2;
     }
     unsigned char *dst = wp + qq * GB_BUF + nl * 64 + ((p ^ ((nl >> 2) & 3)) << 4);
@@ -692,6 +756,11 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
     const int RS = d.R * d.S, nslab = d.C / 32, nchunks = nslab * RS, ntile = cdiv_dev(d.N, GBN);
     const float *w = static_cast<const float *>(d.w);
     unsigned char *wp = static_cast<unsigned char *>(d.wp);
+    float *wq = reinterpret_cast<float *>(wp + (size_t)ntile * nchunks * GB_BUF);       // the image's scale record (amax_multi_kernel ran)
+    __shared__ float qred[16];
+    const int we = q_exp(q_amax(wq, qred));
+    const float wscale = q_pow2(we);
+    if (blockIdx.x == 0 && threadIdx.x == 0) wq[1] = q_pow2(-we);
     const int units = ntile * (GBN / PKR) * nslab;
     for (int u = blockIdx.x; u < units; u += gridDim.x) {
         const int slab = u % nslab, n0 = (u / nslab) * PKR;   // n runs over the padded rows of all N tiles
@@ -718,8 +787,8 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
             bf16x8 h[3];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                __bf16 x0, x1, x2;
-                split3(tile[(r * 32 + p * 8 + c) * MAXTAP + tap], x0, x1, x2);
+                hp_t x0, x1, x2;
+                q_split(tile[(r * 32 + p * 8 + c) * MAXTAP + tap], wscale, x0, x1, x2);
                 h[0][c] = x0; h[1][c] = x1; h[2][c] = x2;
             }
             const long qq = (long)nt * nchunks + slab * RS + tap;
@@ -731,8 +800,21 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
 }
 
 // fp32 NHWC -> planes: one thread per (pixel, slab, 8-channel piece)
-__global__ __launch_bounds__(256) void split_nhwc_kernel(const float *x, int ldx, unsigned char *xp, long npieces, int nslab)
+__global__ __launch_bounds__(256) void split_nhwc_kernel(const float *x, int ldx, unsigned char *xp, long npieces, int nslab, float *q,
+                                                         const float *qsrc)
 {
+    // qsrc: the record whose slots hold max |x| -- q itself (amax_nhwc_kernel ran on it) or the record of the kernel that produced x
+    __shared__ float qred[16];
+    const float xmax = q_amax(qsrc, qred);
+    const int xe = q_exp(xmax);
+    const float xscale = q_pow2(xe);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        q[1] = q_pow2(-xe);
+        if (qsrc != q) {
+            q_header(q, 1);
+            q[QREC_HDR] = xmax;
+        }
+    }
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= npieces) return;
     const long pix = e / (nslab * 4);
@@ -742,10 +824,10 @@ __global__ __launch_bounds__(256) void split_nhwc_kernel(const float *x, int ldx
     bf16x8 h0, h1, h2;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        __bf16 x0, x1, x2;
-        split3(v0[c], x0, x1, x2);
+        hp_t x0, x1, x2;
+        q_split(v0[c], xscale, x0, x1, x2);
         h0[c] = x0; h1[c] = x1; h2[c] = x2;
-        split3(v1[c], x0, x1, x2);
+        q_split(v1[c], xscale, x0, x1, x2);
         h0[4 + c] = x0; h1[4 + c] = x1; h2[4 + c] = x2;
     }
     unsigned char *dst = xp + pix * (long)(nslab * 192) + sl * 192 + p * 16;
@@ -754,11 +836,62 @@ __global__ __launch_bounds__(256) void split_nhwc_kernel(const float *x, int ldx
     *reinterpret_cast<bf16x8 *>(dst + 128) = h2;
 }
 
+// max |x| of an NHWC tensor (rows of C floats at pitch ldx) -> one slot per workgroup of the record q: the pass in front of a
+// split whose input no kernel of this library has measured
+__global__ __launch_bounds__(256) void amax_nhwc_kernel(const float *x, int ldx, long npix, int c4n, float *q)
+{
+    __shared__ float qred[16];
+    float m = 0.f;
+    const long n4 = npix * c4n;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n4; e += (long)gridDim.x * 256) {
+        const long pix = e / c4n;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + pix * ldx + (e - pix * c4n) * 4);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    m = block_max(m, qred);
+    if (threadIdx.x == 0) {
+        q[QREC_HDR + blockIdx.x] = m;
+        if (blockIdx.x == 0) q_header(q, gridDim.x);
+    }
+}
+
+// the same for flat fp32 arrays (weights), blockIdx.y = tensor
+struct AmaxTable {
+    const float *w[24];
+    float *q[24];
+    long n[24];
+};
+__global__ __launch_bounds__(256) void amax_multi_kernel(const AmaxTable tab)
+{
+    __shared__ float qred[16];
+    const float *w = tab.w[blockIdx.y];
+    const long n = tab.n[blockIdx.y];
+    float m = 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) m = fmaxf(m, fabsf(w[e]));
+    m = block_max(m, qred);
+    if (threadIdx.x == 0) {
+        float *q = tab.q[blockIdx.y];
+        q[QREC_HDR + blockIdx.x] = m;
+        if (blockIdx.x == 0) q_header(q, gridDim.x);
+    }
+}
+
 // dy * (z > 0 ? 1 : slope) -> planes: the gradient that reaches a convolution whose output was activated (z = that output),
 // split for the bf16 input-gradient / weight-gradient kernels in the pass that applies the leaky-ReLU derivative
 __global__ __launch_bounds__(256) void split_dact_nhwc_kernel(const float *x, int ldx, const float *z, int ldz, float slope, unsigned char *xp,
-                                                              long npieces, int nslab)
+                                                              long npieces, int nslab, float *q, const float *qsrc)
 {
+    __shared__ float qred[16];
+    const float xmax = q_amax(qsrc, qred) * fmaxf(1.f, fabsf(slope));        // slots: max |dy|
+    const int xe = q_exp(xmax);
+    const float xscale = q_pow2(xe);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        q[1] = q_pow2(-xe);
+        if (qsrc != q) {
+            q_header(q, 1);
+            q[QREC_HDR] = xmax;
+        }
+    }
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= npieces) return;
     const long pix = e / (nslab * 4);
@@ -769,10 +902,10 @@ __global__ __launch_bounds__(256) void split_dact_nhwc_kernel(const float *x, in
     bf16x8 h0, h1, h2;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        __bf16 x0, x1, x2;
-        split3(z0[c] > 0.f ? v0[c] : v0[c] * slope, x0, x1, x2);
+        hp_t x0, x1, x2;
+        q_split(z0[c] > 0.f ? v0[c] : v0[c] * slope, xscale, x0, x1, x2);
         h0[c] = x0; h1[c] = x1; h2[c] = x2;
-        split3(z1[c] > 0.f ? v1[c] : v1[c] * slope, x0, x1, x2);
+        q_split(z1[c] > 0.f ? v1[c] : v1[c] * slope, xscale, x0, x1, x2);
         h0[4 + c] = x0; h1[4 + c] = x1; h2[4 + c] = x2;
     }
     unsigned char *dst = xp + pix * (long)(nslab * 192) + sl * 192 + p * 16;
@@ -782,22 +915,27 @@ __global__ __launch_bounds__(256) void split_dact_nhwc_kernel(const float *x, in
 }
 
 // planes -> fp32 NHWC (tests / debugging): the three planes add up to the fp32 value exactly
-__global__ __launch_bounds__(256) void merge_planes_kernel(const unsigned char *xp, float *x, int ldx, long nelem, int C)
+__global__ __launch_bounds__(256) void merge_planes_kernel(const unsigned char *xp, float *x, int ldx, long nelem, int C, const float *q)
 {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= nelem) return;
     const long pix = e / C;
     const int c = (int)(e - pix * C), sl = c >> 5, k = c & 31;
-    const __bf16 *src = reinterpret_cast<const __bf16 *>(xp + pix * (long)((C / 32) * 192) + sl * 192);
-    x[pix * ldx + c] = ((float)src[k] + (float)src[32 + k]) + (float)src[64 + k];
+    const hp_t *src = reinterpret_cast<const hp_t *>(xp + pix * (long)((C / 32) * 192) + sl * 192);
+    x[pix * ldx + c] = (((float)src[k] + (float)src[32 + k]) + (float)src[64 + k]) * q_inv(q);
 }
 
 // torch Conv2d weight [N][C][R][S] fp32 -> per chunk q = slab * R*S + tap the LDS image [plane][192 rows][64 B], piece p of
 // row n stored at p ^ ((n >> 2) & 3); rows n >= N are zero
 // flip: the operand of the INPUT GRADIENT of a stride-1 convolution whose torch weight is w[C][N][R][S] (rows n = the forward
 // layer's input channels, contraction channels = its output channels, taps mirrored)
-__global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, unsigned char *wp, int N, int C, int RS, long npieces, int flip)
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, unsigned char *wp, int N, int C, int RS, long npieces, int flip,
+                                                          float *wq)
 {
+    __shared__ float qred[16];
+    const int we = q_exp(q_amax(wq, qred));
+    const float wscale = q_pow2(we);
+    if (blockIdx.x == 0 && threadIdx.x == 0) wq[1] = q_pow2(-we);
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= npieces) return;
     const int p = (int)(e & 3), n = (int)((e >> 2) % BN);
@@ -808,8 +946,8 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, unsign
     for (int c = 0; c < 8; ++c) {
         const int ch = slab * 32 + p * 8 + c;
         const float v = n < N ? (flip ? w[((size_t)ch * N + n) * RS + (RS - 1 - tap)] : w[((size_t)n * C + ch) * RS + tap]) : 0.f;
-        __bf16 x0, x1, x2;
-        split3(v, x0, x1, x2);
+        hp_t x0, x1, x2;
+        q_split(v, wscale, x0, x1, x2);
         h[0][c] = x0; h[1][c] = x1; h[2][c] = x2;
     }
     unsigned char *dst = wp + q * B_BUF + n * 64 + ((p ^ ((n >> 2) & 3)) << 4);
@@ -819,90 +957,132 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, unsign
 
 }   // namespace
 
-STEM_EXPORT size_t stem_bf16x3_planes_bytes(long npix, int C) { return C % 32 ? 0 : (size_t)npix * (C / 32) * 192; }
+namespace {
+constexpr int WQ_SLOTS = 64;                                        // workgroups of the weights' max pass
+constexpr size_t WQ_BYTES = (QREC_HDR + WQ_SLOTS) * sizeof(float);  // the record behind every packed weight image
+size_t planes_payload(long npix, int C) { return (size_t)npix * (C / 32) * 192; }
+// one slot per producing workgroup: the smallest output tile of any producer is 64 pixels x 128 channels
+long planes_slots(long npix, int C) { return (long)cdivz((size_t)npix, 64) * cdiv(C, 128); }
+size_t w_image_bytes(int C, int R, int S) { return (size_t)(C / 32) * R * S * B_BUF; }
+size_t gen_image_bytes(int N, int C, int R, int S) { return (size_t)cdiv(N, GBN) * (C / 32) * R * S * GB_BUF; }
 
-STEM_EXPORT size_t stem_bf16x3_conv_weight_bytes(int C, int R, int S) { return C % 32 ? 0 : (size_t)(C / 32) * R * S * B_BUF; }
-
-STEM_EXPORT int stem_bf16x3_split_nhwc(const float *x, int ldx, void *xp, long npix, int C, void *stream)
+int amax_flat(const float *w, long n, float *q, hipStream_t st)
 {
-    STEM_CHECK_ARG(x && xp && npix >= 0 && C > 0 && C % 32 == 0 && ldx >= C && ldx % 4 == 0,
+    AmaxTable t;
+    memset(&t, 0, sizeof(t));
+    t.w[0] = w; t.q[0] = q; t.n[0] = n;
+    hipLaunchKernelGGL(amax_multi_kernel, dim3(WQ_SLOTS, 1), dim3(256), 0, st, t);      // always all slots: images compare equal
+    return 0;
+}
+}   // namespace
+
+STEM_EXPORT size_t stem_bf16x3_planes_qrec_offset(long npix, int C) { return C % 32 ? 0 : planes_payload(npix, C); }
+
+STEM_EXPORT size_t stem_bf16x3_planes_bytes(long npix, int C)
+{
+    return C % 32 ? 0 : planes_payload(npix, C) + (((QREC_HDR + planes_slots(npix, C)) * sizeof(float) + 15) & ~(size_t)15);
+}
+
+STEM_EXPORT size_t stem_bf16x3_conv_weight_bytes(int C, int R, int S) { return C % 32 ? 0 : w_image_bytes(C, R, S) + WQ_BYTES; }
+
+STEM_EXPORT int stem_amax_nhwc(const float *x, int ldx, long npix, int C, float *q, long max_slots, void *stream)
+{
+    STEM_CHECK_ARG(x && q && npix >= 0 && C > 0 && C % 4 == 0 && ldx >= C && ldx % 4 == 0 && max_slots >= 1,
+                   "stem_amax_nhwc: rows of C %% 4 == 0 floats, 16-byte aligned (C=%d ldx=%d)", C, ldx);
+    long wg = (long)cdivz((size_t)npix * (C / 4), 2048);
+    if (wg < 1) wg = 1;
+    if (wg > max_slots) wg = max_slots;
+    if (wg > 1024) wg = 1024;
+    hipLaunchKernelGGL(amax_nhwc_kernel, dim3((unsigned)wg), dim3(256), 0, (hipStream_t)stream, x, ldx, npix, C / 4, q);
+    STEM_LAUNCH_CHECK("stem_amax_nhwc");
+    return 0;
+}
+
+STEM_EXPORT int stem_bf16x3_split_nhwc(const float *x, int ldx, void *xp, float *xq, const float *src_q, long npix, int C, void *stream)
+{
+    STEM_CHECK_ARG(x && xp && xq && npix >= 0 && C > 0 && C % 32 == 0 && ldx >= C && ldx % 4 == 0,
                    "stem_bf16x3_split_nhwc: channels must be a multiple of 32 and rows 16-byte aligned (C=%d ldx=%d)", C, ldx);
     const long np = npix * (C / 32) * 4;
     if (np == 0) return 0;
+    if (!src_q && stem_amax_nhwc(x, ldx, npix, C, xq, planes_slots(npix, C), stream)) return -2;
     hipLaunchKernelGGL(split_nhwc_kernel, dim3((unsigned)cdivz(np, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
-                       static_cast<unsigned char *>(xp), np, C / 32);
+                       static_cast<unsigned char *>(xp), np, C / 32, xq, src_q ? src_q : xq);
     STEM_LAUNCH_CHECK("stem_bf16x3_split_nhwc");
     return 0;
 }
 
-STEM_EXPORT int stem_bf16x3_split_dact_nhwc(const float *x, int ldx, const float *z, int ldz, float slope, void *xp, long npix, int C, void *stream)
+STEM_EXPORT int stem_bf16x3_split_dact_nhwc(const float *x, int ldx, const float *z, int ldz, float slope, void *xp, float *xq, const float *src_q,
+                                            long npix, int C, void *stream)
 {
-    STEM_CHECK_ARG(x && z && xp && npix >= 0 && C > 0 && C % 32 == 0 && ldx >= C && ldx % 4 == 0 && ldz >= C && ldz % 4 == 0,
+    STEM_CHECK_ARG(x && z && xp && xq && npix >= 0 && C > 0 && C % 32 == 0 && ldx >= C && ldx % 4 == 0 && ldz >= C && ldz % 4 == 0,
                    "stem_bf16x3_split_dact_nhwc: channels must be a multiple of 32 and rows 16-byte aligned (C=%d ldx=%d ldz=%d)", C, ldx, ldz);
     const long np = npix * (C / 32) * 4;
     if (np == 0) return 0;
+    if (!src_q && stem_amax_nhwc(x, ldx, npix, C, xq, planes_slots(npix, C), stream)) return -2;
     hipLaunchKernelGGL(split_dact_nhwc_kernel, dim3((unsigned)cdivz(np, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, z, ldz, slope,
-                       static_cast<unsigned char *>(xp), np, C / 32);
+                       static_cast<unsigned char *>(xp), np, C / 32, xq, src_q ? src_q : xq);
     STEM_LAUNCH_CHECK("stem_bf16x3_split_dact_nhwc");
     return 0;
 }
 
-STEM_EXPORT int stem_bf16x3_merge_nhwc(const void *xp, float *x, int ldx, long npix, int C, void *stream)
+STEM_EXPORT int stem_bf16x3_merge_nhwc(const void *xp, const float *xq, float *x, int ldx, long npix, int C, void *stream)
 {
-    STEM_CHECK_ARG(x && xp && npix >= 0 && C > 0 && C % 32 == 0 && ldx >= C, "stem_bf16x3_merge_nhwc: bad arguments (C=%d ldx=%d)", C, ldx);
+    STEM_CHECK_ARG(x && xp && xq && npix >= 0 && C > 0 && C % 32 == 0 && ldx >= C, "stem_bf16x3_merge_nhwc: bad arguments (C=%d ldx=%d)", C, ldx);
     const long ne = npix * C;
     if (ne == 0) return 0;
     hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)cdivz(ne, 256)), dim3(256), 0, (hipStream_t)stream,
-                       static_cast<const unsigned char *>(xp), x, ldx, ne, C);
+                       static_cast<const unsigned char *>(xp), x, ldx, ne, C, xq);
     STEM_LAUNCH_CHECK("stem_bf16x3_merge_nhwc");
+    return 0;
+}
+
+static int pack_conv_weight(const float *w, void *wp, int N, int C, int R, int S, int flip, void *stream, const char *who)
+{
+    STEM_CHECK_ARG(w && wp && N >= 1 && N <= BN && C > 0 && C % 32 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP,
+                   "%s: N <= %d, C %% 32 == 0, R*S <= %d (N=%d C=%d R=%d S=%d)", who, BN, MAXTAP, N, C, R, S);
+    const long np = (long)(C / 32) * R * S * BN * 4;
+    float *wq = reinterpret_cast<float *>(static_cast<unsigned char *>(wp) + w_image_bytes(C, R, S));
+    amax_flat(w, (long)N * C * R * S, wq, (hipStream_t)stream);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)cdivz(np, 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       static_cast<unsigned char *>(wp), N, C, R * S, np, flip, wq);
+    STEM_LAUNCH_CHECK(who);
     return 0;
 }
 
 STEM_EXPORT int stem_bf16x3_pack_conv_weight(const float *w, void *wp, int N, int C, int R, int S, void *stream)
 {
-    STEM_CHECK_ARG(w && wp && N >= 1 && N <= BN && C > 0 && C % 32 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP,
-                   "stem_bf16x3_pack_conv_weight: N <= %d, C %% 32 == 0, R*S <= %d (N=%d C=%d R=%d S=%d)", BN, MAXTAP, N, C, R, S);
-    const long np = (long)(C / 32) * R * S * BN * 4;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)cdivz(np, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       static_cast<unsigned char *>(wp), N, C, R * S, np, 0);
-    STEM_LAUNCH_CHECK("stem_bf16x3_pack_conv_weight");
-    return 0;
+    return pack_conv_weight(w, wp, N, C, R, S, 0, stream, "stem_bf16x3_pack_conv_weight");
 }
 
 STEM_EXPORT int stem_bf16x3_pack_conv_weight_flip(const float *w, void *wp, int N, int C, int R, int S, void *stream)
 {
-    STEM_CHECK_ARG(w && wp && N >= 1 && N <= BN && C > 0 && C % 32 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP,
-                   "stem_bf16x3_pack_conv_weight_flip: N <= %d, C %% 32 == 0, R*S <= %d (N=%d C=%d R=%d S=%d)", BN, MAXTAP, N, C, R, S);
-    const long np = (long)(C / 32) * R * S * BN * 4;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)cdivz(np, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       static_cast<unsigned char *>(wp), N, C, R * S, np, 1);
-    STEM_LAUNCH_CHECK("stem_bf16x3_pack_conv_weight_flip");
-    return 0;
+    return pack_conv_weight(w, wp, N, C, R, S, 1, stream, "stem_bf16x3_pack_conv_weight_flip");
 }
 
-static int conv2d_bf16x6_launch(const void *xp, const void *wp, const float *bias, const float *beta, const float *gamma, float beta_min, int act,
-                                float slope, float *y, int ldy, void *yp, int B, int H, int W, int C, int N, int R, int S, int stride, int pad,
-                                void *stream);
+static int conv2d_bf16x6_launch(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const float *gamma,
+                                float beta_min, int act, float slope, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N,
+                                int R, int S, int stride, int pad, void *stream);
 
-STEM_EXPORT int stem_conv2d_bf16x6_fwd(const void *xp, const void *wp, const float *bias, const float *beta, const float *gamma,
-                                       float beta_min, float *y, int ldy, void *yp, int B, int H, int W, int C, int N, int R, int S,
+STEM_EXPORT int stem_conv2d_bf16x6_fwd(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const float *gamma,
+                                       float beta_min, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R, int S,
                                        int stride, int pad, void *stream)
 {
-    return conv2d_bf16x6_launch(xp, wp, bias, beta, gamma, beta_min, 0, 0.f, y, ldy, yp, B, H, W, C, N, R, S, stride, pad, stream);
+    return conv2d_bf16x6_launch(xp, xq, wp, bias, beta, gamma, beta_min, 0, 0.f, y, ldy, yp, yq, B, H, W, C, N, R, S, stride, pad, stream);
 }
 
-STEM_EXPORT int stem_conv2d_bf16x6_fwd_act(const void *xp, const void *wp, const float *bias, int act, float slope, float *y, int ldy, void *yp,
-                                           int B, int H, int W, int C, int N, int R, int S, int stride, int pad, void *stream)
+STEM_EXPORT int stem_conv2d_bf16x6_fwd_act(const void *xp, const float *xq, const void *wp, const float *bias, int act, float slope, float *y, int ldy,
+                                           void *yp, float *yq, int B, int H, int W, int C, int N, int R, int S, int stride, int pad, void *stream)
 {
     STEM_CHECK_ARG(act == 0 || act == 1, "stem_conv2d_bf16x6_fwd_act: act is 0 (none) or 1 (leaky ReLU with `slope`)");
-    return conv2d_bf16x6_launch(xp, wp, bias, nullptr, nullptr, 1e-6f, act, slope, y, ldy, yp, B, H, W, C, N, R, S, stride, pad, stream);
+    STEM_CHECK_ARG(!act || fabsf(slope) <= 1.f, "stem_conv2d_bf16x6_fwd_act: |slope| <= 1");
+    return conv2d_bf16x6_launch(xp, xq, wp, bias, nullptr, nullptr, 1e-6f, act, slope, y, ldy, yp, yq, B, H, W, C, N, R, S, stride, pad, stream);
 }
 
-static int conv2d_bf16x6_launch(const void *xp, const void *wp, const float *bias, const float *beta, const float *gamma, float beta_min, int act,
-                                float slope, float *y, int ldy, void *yp, int B, int H, int W, int C, int N, int R, int S, int stride, int pad,
-                                void *stream)
+static int conv2d_bf16x6_launch(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const float *gamma,
+                                float beta_min, int act, float slope, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N,
+                                int R, int S, int stride, int pad, void *stream)
 {
-    STEM_CHECK_ARG(xp && wp && (y || yp), "stem_conv2d_bf16x6_fwd: null pointer");
+    STEM_CHECK_ARG(xp && xq && wp && (y || yp) && (yq || !yp), "stem_conv2d_bf16x6_fwd: null pointer (planes come with their scale records)");
     STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && C >= 32 && C % 32 == 0 && N >= 1 && N <= BN && R >= 1 && S >= 1 && R * S <= MAXTAP &&
                    stride >= 1 && pad >= 0, "stem_conv2d_bf16x6_fwd: C %% 32 == 0, N <= %d, R*S <= %d (C=%d N=%d R=%d S=%d)", BN, MAXTAP, C, N, R, S);
     STEM_CHECK_ARG(!yp || N % 32 == 0, "stem_conv2d_bf16x6_fwd: planes output needs N %% 32 == 0 (N=%d)", N);
@@ -910,12 +1090,13 @@ static int conv2d_bf16x6_launch(const void *xp, const void *wp, const float *bia
     STEM_CHECK_ARG((beta == nullptr) == (gamma == nullptr), "stem_conv2d_bf16x6_fwd: beta and gamma come together");
     const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
     STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_bf16x6_fwd: empty output");
-    const size_t xb = stem_bf16x3_planes_bytes((long)B * H * W, C), wb = stem_bf16x3_conv_weight_bytes(C, R, S);
+    const size_t xb = planes_payload((long)B * H * W, C), wb = w_image_bytes(C, R, S);
     STEM_CHECK_ARG(xb < 0x7FFFFF00ull && wb < 0x7FFFFF00ull && (size_t)B * OH * OW < 0x7FFFFFFFull,
                    "stem_conv2d_bf16x6_fwd: operand views must stay below 2 GiB (split the batch)");
     Bx6Args a;
     memset(&a, 0, sizeof(a));
     a.xp = xp; a.wp = wp; a.bias = bias; a.beta = beta; a.gamma = gamma; a.y = y; a.yp = yp; a.ldy = ldy;
+    a.xq = xq; a.yq = yq; a.wq = reinterpret_cast<const float *>(static_cast<const unsigned char *>(wp) + wb);
     a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.OH = OH; a.OW = OW; a.stride = stride; a.ntaps = R * S;
     a.xbytes = (int)xb; a.wbytes = (int)wb; a.gmbytes = N * N * 4;
     a.fuse = gamma ? 1 : 0;
@@ -928,14 +1109,8 @@ static int conv2d_bf16x6_launch(const void *xp, const void *wp, const float *bia
         }
     static bool attr_done = false;      // > 64 KiB of dynamic LDS needs an explicit opt-in
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<128, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
-#ifdef STEM_EXPERIMENTS
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
-#endif
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<128, STEM_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64, STEM_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
         attr_done = true;
     }
     const int M = B * OH * OW;
@@ -943,27 +1118,10 @@ static int conv2d_bf16x6_launch(const void *xp, const void *wp, const float *bia
     // 128-pixel tiles (8 wavefronts) when they fill the 256 CUs at least once, 64-pixel tiles (4 wavefronts) below that
     const int tile = stem_tuning(STEM_TUNE_BX6_TILE);
     const bool small = tile ? tile == 64 : cdiv(M, 128) < 256;
-#ifdef STEM_EXPERIMENTS
-    // measurement-only variants: fewer bf16 products per fp32 product, an epilogue-free main loop.
-    // STEM_BF16_PRODUCTS: all bf16 kernels; STEM_GA_BF16_PRODUCTS: this kernel (the frozen analysis transform) alone
-    const char *e = getenv("STEM_BF16_PRODUCTS_DYN") ? getenv("STEM_BF16_PRODUCTS_DYN")
-                  : getenv("STEM_GA_BF16_PRODUCTS") ? getenv("STEM_GA_BF16_PRODUCTS") : getenv("STEM_BF16_PRODUCTS");
-    const int np_now = e ? atoi(e) : 6;
-    a.exper = getenv("STEM_BX6_EXPER") ? atoi(getenv("STEM_BX6_EXPER")) & 1 : 0;
-    if (small && np_now == 3)
-        hipLaunchKernelGGL((conv_bf16x6_kernel<64, 3>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
-    else if (small && np_now == 4)
-        hipLaunchKernelGGL((conv_bf16x6_kernel<64, 4>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
-    else if (!small && np_now == 3)
-        hipLaunchKernelGGL((conv_bf16x6_kernel<128, 3>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
-    else if (!small && np_now == 4)
-        hipLaunchKernelGGL((conv_bf16x6_kernel<128, 4>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
-    else
-#endif
     if (small)
-        hipLaunchKernelGGL((conv_bf16x6_kernel<64, 6>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
+        hipLaunchKernelGGL((conv_bf16x6_kernel<64, STEM_NP>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
     else
-        hipLaunchKernelGGL((conv_bf16x6_kernel<128, 6>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
+        hipLaunchKernelGGL((conv_bf16x6_kernel<128, STEM_NP>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
     STEM_LAUNCH_CHECK("stem_conv2d_bf16x6_fwd");
     return 0;
 }
@@ -971,7 +1129,7 @@ static int conv2d_bf16x6_launch(const void *xp, const void *wp, const float *bia
 // ---- general variant: N tiles of 128, split-K, activation epilogues (training-time STEM layers) --------------------------------
 STEM_EXPORT size_t stem_bf16x3_conv_weight_gen_bytes(int N, int C, int R, int S)
 {
-    return C % 32 ? 0 : (size_t)cdiv(N, GBN) * (C / 32) * R * S * GB_BUF;
+    return C % 32 ? 0 : gen_image_bytes(N, C, R, S) + WQ_BYTES;
 }
 
 STEM_EXPORT int stem_bf16x3_pack_conv_weight_gen(const float *w, void *wp, int N, int C, int R, int S, int flip, void *stream)
@@ -979,8 +1137,10 @@ STEM_EXPORT int stem_bf16x3_pack_conv_weight_gen(const float *w, void *wp, int N
     STEM_CHECK_ARG(w && wp && N >= 1 && C > 0 && C % 32 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP,
                    "stem_bf16x3_pack_conv_weight_gen: C %% 32 == 0, R*S <= %d (N=%d C=%d R=%d S=%d)", MAXTAP, N, C, R, S);
     const long np = (long)cdiv(N, GBN) * (C / 32) * R * S * GBN * 4;
+    float *wq = reinterpret_cast<float *>(static_cast<unsigned char *>(wp) + gen_image_bytes(N, C, R, S));
+    amax_flat(w, (long)N * C * R * S, wq, (hipStream_t)stream);
     hipLaunchKernelGGL(pack_weight_gen_kernel, dim3((unsigned)cdivz(np, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       static_cast<unsigned char *>(wp), N, C, R * S, flip, np);
+                       static_cast<unsigned char *>(wp), N, C, R * S, flip, np, wq);
     STEM_LAUNCH_CHECK("stem_bf16x3_pack_conv_weight_gen");
     return 0;
 }
@@ -999,6 +1159,15 @@ STEM_EXPORT int stem_bf16x3_pack_conv_weights_multi(const stem_bf16x3_pack_desc 
     PackTable tab;
     memset(&tab, 0, sizeof(tab));
     memcpy(tab.d, descs_host, n * sizeof(stem_bf16x3_pack_desc));
+    AmaxTable mt;                           // max |w| of every tensor first: the scale its image is stored with
+    memset(&mt, 0, sizeof(mt));
+    for (int i = 0; i < n; ++i) {
+        const stem_bf16x3_pack_desc &d = descs_host[i];
+        mt.w[i] = static_cast<const float *>(d.w);
+        mt.q[i] = reinterpret_cast<float *>(static_cast<unsigned char *>(d.wp) + gen_image_bytes(d.N, d.C, d.R, d.S));
+        mt.n[i] = (long)d.N * d.C * d.R * d.S;
+    }
+    hipLaunchKernelGGL(amax_multi_kernel, dim3(WQ_SLOTS, n), dim3(256), 0, (hipStream_t)stream, mt);
     const unsigned gx = (unsigned)(maxu < 2048 ? maxu : 2048);
     hipLaunchKernelGGL(pack_weight_gen_multi_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, tab);
     STEM_LAUNCH_CHECK("stem_bf16x3_pack_conv_weights_multi");
@@ -1041,11 +1210,12 @@ STEM_EXPORT size_t stem_conv2d_bf16x6_gen_workspace_bytes(int B, int H, int W, i
     return s > 1 ? kGenCntBytes + (size_t)s * M * cdiv(N, GBN) * GBN * sizeof(float) : 0;
 }
 
-STEM_EXPORT int stem_conv2d_bf16x6_gen_fwd(const void *xp, int xpix, const void *wp, const float *bias, int epi, float slope, const float *z, int ldz,
-                                           float *y, int ldy, void *yp, int B, int H, int W, int C, int N, int R, int S, int stride, int pad,
-                                           void *ws, size_t ws_bytes, void *stream)
+STEM_EXPORT int stem_conv2d_bf16x6_gen_fwd(const void *xp, const float *xq, int xpix, const void *wp, const float *bias, int epi, float slope,
+                                           const float *z, int ldz, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R,
+                                           int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream)
 {
-    STEM_CHECK_ARG(xp && wp && (y || yp), "stem_conv2d_bf16x6_gen_fwd: null pointer");
+    STEM_CHECK_ARG(xp && xq && wp && (y || yp) && (yq || !yp), "stem_conv2d_bf16x6_gen_fwd: null pointer (planes come with their scale records)");
+    STEM_CHECK_ARG(epi == GEN_EPI_BIAS || fabsf(slope) <= 1.f, "stem_conv2d_bf16x6_gen_fwd: |slope| <= 1");
     STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && C >= 32 && C % 32 == 0 && N >= 4 && N % 4 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP &&
                    stride >= 1 && pad >= 0, "stem_conv2d_bf16x6_gen_fwd: C %% 32 == 0, N %% 4 == 0, R*S <= %d (C=%d N=%d R=%d S=%d)", MAXTAP, C, N, R, S);
     STEM_CHECK_ARG(!yp || N % 32 == 0, "stem_conv2d_bf16x6_gen_fwd: planes output needs N %% 32 == 0 (N=%d)", N);
@@ -1056,13 +1226,14 @@ STEM_EXPORT int stem_conv2d_bf16x6_gen_fwd(const void *xp, int xpix, const void 
     STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_bf16x6_gen_fwd: empty output");
     if (xpix == 0) xpix = (C / 32) * 192;
     STEM_CHECK_ARG(xpix >= (C / 32) * 192 && xpix % 192 == 0, "stem_conv2d_bf16x6_gen_fwd: xpix must be a multiple of 192 bytes covering C channels");
-    const size_t xb = (size_t)B * H * W * xpix, wb = stem_bf16x3_conv_weight_gen_bytes(N, C, R, S);
+    const size_t xb = (size_t)B * H * W * xpix, wb = gen_image_bytes(N, C, R, S);
     const int M = B * OH * OW, ntn = cdiv(N, GBN), tiles = cdiv(M, GBM) * ntn, nchunks = (C / 32) * R * S;
     STEM_CHECK_ARG(xb < 0x7FFFFF00ull && wb < 0x7FFFFF00ull && (size_t)M * ntn * GBN * 4 < 0x7FFFFF00ull,
                    "stem_conv2d_bf16x6_gen_fwd: operand views must stay below 2 GiB (split the batch)");
     Bx6Args a;
     memset(&a, 0, sizeof(a));
     a.xp = xp; a.wp = wp; a.bias = bias; a.y = y; a.yp = yp; a.ldy = ldy; a.z = z; a.ldz = ldz; a.epi = epi; a.slope = slope;
+    a.xq = xq; a.yq = yq; a.wq = reinterpret_cast<const float *>(static_cast<const unsigned char *>(wp) + wb);
     a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.OH = OH; a.OW = OW; a.stride = stride; a.ntaps = R * S;
     a.xbytes = (int)xb; a.wbytes = (int)wb; a.xpix = xpix;
     for (int r = 0; r < R; ++r)
@@ -1083,23 +1254,11 @@ STEM_EXPORT int stem_conv2d_bf16x6_gen_fwd(const void *xp, int xpix, const void 
     }
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_gen_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
-#ifdef STEM_EXPERIMENTS
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_gen_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_gen_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
-#endif
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_gen_kernel<STEM_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
         attr_done = true;
     }
     const dim3 grid(cdiv(M, GBM), ntn, a.nsplit);
-#ifdef STEM_EXPERIMENTS
-    static const int nprod = getenv("STEM_BF16_PRODUCTS") ? atoi(getenv("STEM_BF16_PRODUCTS")) : 6;       // measurement switch
-    if (nprod == 3)
-        hipLaunchKernelGGL(conv_bf16x6_gen_kernel<3>, grid, dim3(GNT), GLDS, (hipStream_t)stream, a);
-    else if (nprod == 4)
-        hipLaunchKernelGGL(conv_bf16x6_gen_kernel<4>, grid, dim3(GNT), GLDS, (hipStream_t)stream, a);
-    else
-#endif
-        hipLaunchKernelGGL(conv_bf16x6_gen_kernel<6>, grid, dim3(GNT), GLDS, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(conv_bf16x6_gen_kernel<STEM_NP>, grid, dim3(GNT), GLDS, (hipStream_t)stream, a);
     STEM_LAUNCH_CHECK("stem_conv2d_bf16x6_gen_fwd");
     return 0;
 }

@@ -57,7 +57,6 @@ struct IgemmArgs {
     int fuse, gmbytes;       // 0 none, 1 GDN, 2 IGDN
     int exper;               // tuning experiments (STEM_IGEMM_EXPER), 0 in production
     int ident;               // output pixel index == m (stride-1, single phase): no div/mod in the epilogue
-    void *yplanes;           // FUSE kernels: write the result pre-split into bf16 planes (conv_bf16x6.hip) instead of fp32 `y`
     TapPhase ph[4];
 };
 
@@ -658,47 +657,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
                     }
                     const float nv = nrm[i][j][r] + bt;
                     const float o = acc[i][j][r] * (a.fuse == 2 ? __builtin_amdgcn_sqrtf(nv) : __builtin_amdgcn_rsqf(nv));
-                    if (a.yplanes)
-                        acc[i][j][r] = o;
-                    else
-                        a.y[opix * a.ldy + n] = o;
+                    a.y[opix * a.ldy + n] = o;
                 }
-        }
-        if (a.yplanes) {
-            // The next layer is conv_bf16x6.hip: hand it the tile as three bf16 planes per 32-channel slab (fp32 value = their exact
-            // sum), through LDS so that every thread stores whole 16-byte pieces.  Single phase, stride-1 output (ident) only.
-            typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
-            __syncthreads();                           // last gamma chunk consumed: the parked tile is free
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        X2[(wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * XP + wn0 + j * 32 + lr] = acc[i][j][r];
-            __syncthreads();
-            const int oslab = a.N / 32, opixb = oslab * 192;
-            unsigned char *yp = static_cast<unsigned char *>(a.yplanes);
-            for (int e = tid; e < BM * oslab * 4; e += NT) {
-                const int row = e / (oslab * 4), rem = e - row * (oslab * 4), sl = rem >> 2, p = rem & 3;
-                const int m = bm0 + row;
-                if (m >= Mtot) continue;
-                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&X2[row * XP + sl * 32 + p * 8]);
-                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(&X2[row * XP + sl * 32 + p * 8 + 4]);
-                bf16x8 h0, h1, h2;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float x = c < 4 ? v0[c & 3] : v1[c & 3];
-                    const __bf16 b0 = (__bf16)x;
-                    const float r1 = x - (float)b0;
-                    const __bf16 b1 = (__bf16)r1;
-                    h0[c] = b0; h1[c] = b1; h2[c] = (__bf16)(r1 - (float)b1);
-                }
-                unsigned char *dst = yp + (size_t)m * opixb + sl * 192 + p * 16;
-                *reinterpret_cast<bf16x8 *>(dst) = h0;
-                *reinterpret_cast<bf16x8 *>(dst + 64) = h1;
-                *reinterpret_cast<bf16x8 *>(dst + 128) = h2;
-            }
         }
         return;
     }
@@ -1262,21 +1222,6 @@ STEM_EXPORT int stem_conv2d_fwd_c4_gdn(const float *x4, const float *wp, const f
     g.x = x4; g.w = wp; g.bias = bias; g.y = y;
     g.ldx = 4; g.ldw = 128; g.ldy = ldy;
     if (set_fuse(g, beta, gamma, inverse, beta_min, "stem_conv2d_fwd_c4_gdn")) return -1;
-    return launch(g, true, nullptr, 0, (hipStream_t)stream);
-}
-
-// First layer of the analysis transform feeding csrc/conv_bf16x6.hip: same kernel, result written pre-split into bf16 planes.
-STEM_EXPORT int stem_conv2d_fwd_c4_gdn_planes(const float *x4, const float *wp, const float *bias, const float *beta,
-                                              const float *gamma, void *yp, int B, int H, int W, int K, int R, int S,
-                                              int stride, int pad, float beta_min, void *stream)
-{
-    if (check_common("stem_conv2d_fwd_c4_gdn_planes", x4, wp, yp, B, H, W, 4, K, R, S, stride)) return -1;
-    STEM_CHECK_ARG(K % 32 == 0, "stem_conv2d_fwd_c4_gdn_planes: the planes layout needs K %% 32 == 0 (K=%d)", K);
-    IgemmArgs g;
-    fill_geometry(g, KIND_CONV_FWD, B, H, W, 4, K, R, S, stride, pad, 0);
-    g.x = x4; g.w = wp; g.bias = bias; g.yplanes = yp;
-    g.ldx = 4; g.ldw = 128; g.ldy = K;
-    if (set_fuse(g, beta, gamma, 0, beta_min, "stem_conv2d_fwd_c4_gdn_planes")) return -1;
     return launch(g, true, nullptr, 0, (hipStream_t)stream);
 }
 

@@ -14,7 +14,7 @@ void stem_set_error(const char *fmt, ...)
     va_end(ap);
 }
 STEM_EXPORT const char *stem_last_error(void) { return g_err; }
-STEM_EXPORT int stem_abi_version(void) { return 3; }
+STEM_EXPORT int stem_abi_version(void) { return 4; }
 STEM_EXPORT int stem_built_with_experiments(void)
 {
 #ifdef STEM_EXPERIMENTS
@@ -247,14 +247,31 @@ __global__ void copy2d_kernel(const float *src, int lds, float *dst, int ldd, si
     dst[p * ldd + c] = src[p * lds + c];
 }
 
-__global__ void nchw3_to_nhwc4_kernel(const float *x, f32x4 *y, size_t HW, size_t total)
+// 1024 pixels per workgroup; q (optional): scale record of the image, one slot of max |x| per workgroup (stem_common.h) --
+// what the first-layer kernel c4gdn_bf16x6.hip scales its in-register fp16 split of the patches by
+__global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const float *x, f32x4 *y, size_t HW, size_t total, float *q)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const size_t b = i / HW, p = i - b * HW;
-    const float *src = x + b * 3 * HW + p;
-    f32x4 v = {src[0], src[HW], src[2 * HW], 0.f};
-    y[i] = v;
+    __shared__ float qred[16];
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t i = ((size_t)blockIdx.x * 4 + k) * 256 + threadIdx.x;
+        if (i >= total) break;
+        const size_t b = i / HW, p = i - b * HW;
+        const float *src = x + b * 3 * HW + p;
+        f32x4 v = {src[0], src[HW], src[2 * HW], 0.f};
+        y[i] = v;
+        m = fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2])));
+    }
+    if (!q) return;
+    m = block_max(m, qred);
+    if (threadIdx.x == 0) {
+        q[QREC_HDR + blockIdx.x] = m;
+        if (blockIdx.x == 0) {
+            q_header(q, gridDim.x);
+            q[1] = 1.f;
+        }
+    }
 }
 
 }   // namespace
@@ -405,12 +422,15 @@ STEM_EXPORT int stem_nhwc_to_nchw(const float *x, int ldx, float *y, int B, int 
     return 0;
 }
 
-STEM_EXPORT int stem_nchw3_to_nhwc4(const float *x, float *y, int B, int H, int W, void *stream)
+STEM_EXPORT size_t stem_nhwc4_qrec_floats(int B, int H, int W) { return QREC_HDR + cdivz((size_t)B * H * W, 1024); }
+
+STEM_EXPORT int stem_nchw3_to_nhwc4(const float *x, float *y, int B, int H, int W, float *q, void *stream)
 {
     STEM_CHECK_ARG(x && y, "stem_nchw3_to_nhwc4: null pointer");
     const size_t HW = (size_t)H * W, total = HW * B;
-    hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3((unsigned)cdivz(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                       reinterpret_cast<f32x4 *>(y), HW, total);
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3((unsigned)cdivz(total, 1024)), dim3(256), 0, (hipStream_t)stream, x,
+                       reinterpret_cast<f32x4 *>(y), HW, total, q);
     STEM_LAUNCH_CHECK("nchw3_to_nhwc4");
     return 0;
 }

@@ -50,3 +50,90 @@ int stem_tuning(int id);
 #else
 #define STEM_EXPER_ENV(name) (static_cast<const char *>(nullptr))
 #endif
+
+// ---- the 16-bit operand type of the split-operand kernels (conv_bf16x6 / wgrad_bf16x6 / c4gdn_bf16x6) ----------------------------
+// Default: two fp16 planes, three products (a = a0 + a1 to 2^-22 |a|, every product exact in the fp32 accumulator).  fp16 has
+// 5 exponent bits, so every planes tensor / packed weight image carries a power-of-two scale 2^e chosen by its producer from an
+// upper bound of its values (scale records below).  -DSTEM_BF16X6 builds the round-2 form instead: three bf16 planes, six
+// products, no scaling (e = 0 everywhere).
+#ifndef STEM_BF16X6
+#define STEM_F16X3 1
+typedef _Float16 hp_t;
+#define STEM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+constexpr int STEM_NP = 3;
+#else
+typedef __bf16 hp_t;
+#define STEM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+constexpr int STEM_NP = 6;
+#endif
+typedef hp_t hp8 __attribute__((ext_vector_type(8)));
+
+// Scale record of a planes tensor / packed weight image (device memory, behind the payload; include/stem_hip.h: stem_qrec):
+//   word 0: int nslots    word 1: float inv = 2^-e (the planes hold v * 2^e)    words 16 .. 16 + nslots: float max|v| per
+//   producing workgroup.  Plain stores only (one slot per workgroup, the header by the workgroup that owns slot 0): nothing
+//   to zero, no atomics, bit-reproducible; a consumer takes the maximum over the slots in its prologue / epilogue.
+constexpr int QREC_HDR = 16;                       // floats in front of the slots
+#ifdef __HIPCC__
+__device__ inline int q_nslots(const float *q) { return reinterpret_cast<const int *>(q)[0]; }
+__device__ inline float q_inv(const float *q) { return q[1]; }
+// header of a record with n slots (one thread): the reserved words are zeroed so that records compare equal byte for byte
+__device__ inline void q_header(float *q, int n)
+{
+    reinterpret_cast<int *>(q)[0] = n;
+#pragma unroll
+    for (int i = 2; i < QREC_HDR; ++i) q[i] = 0.f;
+}
+// e with bound * 2^e in [2^14, 2^15): twice the room fp16 (max 65504) needs, so that bounds rounded in fp32 stay safe
+__device__ inline int q_exp(float bound)
+{
+#ifdef STEM_F16X3
+    const unsigned b = __float_as_uint(bound) & 0x7FFFFFFFu;
+    int eb = (int)(b >> 23) - 127;                 // floor(log2(bound)) of a normal number
+    if (b == 0u || eb == 128) return 0;            // zero tensor / non-finite bound: nothing to protect
+    if (eb < -126) eb = -126;
+    const int e = 14 - eb;
+    return e > 126 ? 126 : e;                      // eb <= 127, so e >= -113: q_pow2(+-e) stays a normal number
+#else
+    return 0;
+#endif
+}
+__device__ inline float q_pow2(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+__device__ inline float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// maximum over the workgroup (nthreads a multiple of 64, <= 1024); red: >= 16 floats of LDS; two barriers
+__device__ inline float block_max(float v, float *red)
+{
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float m = red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
+    return m;
+}
+// max over the slots of a record (every thread gets it)
+__device__ inline float q_amax(const float *q, float *red)
+{
+    const int ns = q_nslots(q);
+    float m = 0.f;
+    for (int i = threadIdx.x; i < ns; i += blockDim.x) m = fmaxf(m, q[QREC_HDR + i]);
+    return block_max(m, red);
+}
+// the two fp16 (three bf16) numbers whose sum is x * s
+__device__ inline void q_split(const float x, const float s, hp_t &h0, hp_t &h1, hp_t &h2)
+{
+    const float xs = x * s;
+    h0 = (hp_t)xs;
+    const float r1 = xs - (float)h0;               // exact
+    h1 = (hp_t)r1;
+#ifdef STEM_F16X3
+    h2 = (hp_t)0.f;
+#else
+    h2 = (hp_t)(r1 - (float)h1);
+#endif
+}
+#endif

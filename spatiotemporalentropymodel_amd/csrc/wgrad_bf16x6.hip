@@ -21,7 +21,7 @@
 
 namespace {
 
-typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef hp8 bf16x8;
 typedef short v4s __attribute__((ext_vector_type(4)));
 
 constexpr int TK = 128, TC = 128, NT = 256, PX = 16;      // output tile, threads, pixels per chunk (= one MFMA k-step)
@@ -33,6 +33,7 @@ constexpr int MAXTAP = 25;
 
 struct Wg6Args {
     const void *xp, *dyp;
+    const float *xq, *dyq;         // scale records of the two planes tensors (stem_common.h)
     float *dwp;
     float *bias_part;              // optional [nsplit][K]: per-split column sums of dy (the bias gradient's first stage)
     int xpix, dypix;               // bytes per pixel of the planes buffers (channel views allowed)
@@ -107,19 +108,14 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
             *reinterpret_cast<f32x4 *>(Bs + buf * OP_BUF + pl * PLANE + st0) = rb[pl];
         }
         if (do_bias && fresh) {
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 w0 = __builtin_bit_cast(u32x4, ra[0]), w1 = __builtin_bit_cast(u32x4, ra[1]);
-            const u32x4 w2 = PL == 3 ? __builtin_bit_cast(u32x4, ra[PL - 1]) : u32x4{0u, 0u, 0u, 0u};
-            auto lo = [](unsigned u) { return __builtin_bit_cast(float, u << 16); };
-            auto hi = [](unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); };
-            bsum[0] += (lo(w0.x) + lo(w1.x)) + lo(w2.x);
-            bsum[1] += (hi(w0.x) + hi(w1.x)) + hi(w2.x);
-            bsum[2] += (lo(w0.y) + lo(w1.y)) + lo(w2.y);
-            bsum[3] += (hi(w0.y) + hi(w1.y)) + hi(w2.y);
-            bsum[4] += (lo(w0.z) + lo(w1.z)) + lo(w2.z);
-            bsum[5] += (hi(w0.z) + hi(w1.z)) + hi(w2.z);
-            bsum[6] += (lo(w0.w) + lo(w1.w)) + lo(w2.w);
-            bsum[7] += (hi(w0.w) + hi(w1.w)) + hi(w2.w);
+            const hp8 p0 = __builtin_bit_cast(hp8, ra[0]), p1 = __builtin_bit_cast(hp8, ra[1]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if constexpr (PL == 3)
+                    bsum[c] += ((float)p0[c] + (float)p1[c]) + (float)__builtin_bit_cast(hp8, ra[PL - 1])[c];
+                else
+                    bsum[c] += (float)p0[c] + (float)p1[c];
+            }
         }
     };
 
@@ -162,13 +158,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if constexpr (NP == 6) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PL - 1], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][PL - 1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = STEM_MFMA16(af[i][PL - 1], bf[j][0], acc[i][j]);
+                    acc[i][j] = STEM_MFMA16(af[i][0], bf[j][PL - 1], acc[i][j]);
                 }
-                if constexpr (NP >= 4) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                if constexpr (NP >= 4) acc[i][j] = STEM_MFMA16(af[i][1], bf[j][1], acc[i][j]);
+                acc[i][j] = STEM_MFMA16(af[i][1], bf[j][0], acc[i][j]);
+                acc[i][j] = STEM_MFMA16(af[i][0], bf[j][1], acc[i][j]);
+                acc[i][j] = STEM_MFMA16(af[i][0], bf[j][0], acc[i][j]);
             }
             if (i == 0)
                 sstore(cur ^ 1, ra, rb, qcur + 1 < q_end);
@@ -228,12 +224,13 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
             float v = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) v += red[r * 128 + tid];
-            a.bias_part[(size_t)split * a.K + k0 + tid] = v;
+            a.bias_part[(size_t)split * a.K + k0 + tid] = v * q_inv(a.dyq);
         }
     }
 
     // ---- partial sums -> slab [split][tap][K][C]; lane holds column c = .. + (lane & 31), rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5) --
     float *out = a.dwp + ((size_t)split * a.T + tap) * a.K * a.C;
+    const float fac = q_inv(a.xq) * q_inv(a.dyq);                  // the planes hold x * 2^ex and dy * 2^ed
     const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -244,7 +241,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = k0 + wk0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (k < a.K) out[(size_t)k * a.C + c] = acc[i][j][r];
+                if (k < a.K) out[(size_t)k * a.C + c] = acc[i][j][r] * fac;
             }
         }
 }
@@ -269,10 +266,10 @@ STEM_EXPORT int stem_wgrad_bf16x6_splits(int B, int H, int W, int C, int K, int 
     return plan_splits(B, OH, OW, C, K, R * S);
 }
 
-STEM_EXPORT int stem_conv2d_wgrad_bf16x6(const void *xp, int xpix, const void *dyp, int dypix, float *dwp, float *bias_part, int B, int H, int W,
-                                         int C, int K, int R, int S, int pad, int splits, void *stream)
+STEM_EXPORT int stem_conv2d_wgrad_bf16x6(const void *xp, const float *xq, int xpix, const void *dyp, const float *dyq, int dypix, float *dwp,
+                                         float *bias_part, int B, int H, int W, int C, int K, int R, int S, int pad, int splits, void *stream)
 {
-    STEM_CHECK_ARG(xp && dyp && dwp, "stem_conv2d_wgrad_bf16x6: null pointer");
+    STEM_CHECK_ARG(xp && xq && dyp && dyq && dwp, "stem_conv2d_wgrad_bf16x6: null pointer");
     STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && C >= 32 && C % 32 == 0 && K >= 32 && K % 32 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP && pad >= 0,
                    "stem_conv2d_wgrad_bf16x6: C %% 32 == 0, K %% 32 == 0, R*S <= %d (C=%d K=%d R=%d S=%d)", MAXTAP, C, K, R, S);
     const int OH = H + 2 * pad - R + 1, OW = W + 2 * pad - S + 1;
@@ -286,7 +283,7 @@ STEM_EXPORT int stem_conv2d_wgrad_bf16x6(const void *xp, int xpix, const void *d
     STEM_CHECK_ARG(splits == plan_splits(B, OH, OW, C, K, R * S), "stem_conv2d_wgrad_bf16x6: splits must come from stem_wgrad_bf16x6_splits");
     Wg6Args a;
     memset(&a, 0, sizeof(a));
-    a.xp = xp; a.dyp = dyp; a.dwp = dwp; a.bias_part = bias_part; a.xpix = xpix; a.dypix = dypix;
+    a.xp = xp; a.dyp = dyp; a.xq = xq; a.dyq = dyq; a.dwp = dwp; a.bias_part = bias_part; a.xpix = xpix; a.dypix = dypix;
     a.B = B; a.H = H; a.W = W; a.C = C; a.K = K; a.OH = OH; a.OW = OW; a.T = R * S;
     a.xbytes = (int)xb; a.dybytes = (int)db;
     const int nchunks = cdiv(B * OH * OW, PX);
@@ -299,23 +296,11 @@ STEM_EXPORT int stem_conv2d_wgrad_bf16x6(const void *xp, int xpix, const void *d
         }
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)wgrad_bf16x6_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-#ifdef STEM_EXPERIMENTS
-        (void)hipFuncSetAttribute((const void *)wgrad_bf16x6_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void *)wgrad_bf16x6_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-#endif
+        (void)hipFuncSetAttribute((const void *)wgrad_bf16x6_kernel<STEM_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_done = true;
     }
     const dim3 grid(cdiv(K, TK) * cdiv(C, TC), R * S, splits);
-#ifdef STEM_EXPERIMENTS
-    static const int nprod = getenv("STEM_BF16_PRODUCTS") ? atoi(getenv("STEM_BF16_PRODUCTS")) : 6;       // measurement switch
-    if (nprod == 3)
-        hipLaunchKernelGGL(wgrad_bf16x6_kernel<3>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
-    else if (nprod == 4)
-        hipLaunchKernelGGL(wgrad_bf16x6_kernel<4>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
-    else
-#endif
-        hipLaunchKernelGGL(wgrad_bf16x6_kernel<6>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(wgrad_bf16x6_kernel<STEM_NP>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
     STEM_LAUNCH_CHECK("stem_conv2d_wgrad_bf16x6");
     return 0;
 }

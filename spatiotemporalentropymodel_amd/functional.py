@@ -210,8 +210,22 @@ def nchw3_to_nhwc4(x: torch.Tensor) -> torch.Tensor:
     B, Cc, H, W = x.shape
     assert Cc == 3
     out = torch.empty((B, H, W, 4), device=x.device, dtype=torch.float32)
-    _chk(_lib.hip().stem_nchw3_to_nhwc4(x.data_ptr(), out.data_ptr(), B, H, W, _stream()))
+    # the image's scale record (max |x| per workgroup) rides along as an attribute: the first-layer kernel scales its fp16 split by it
+    q = torch.empty(16 + (B * H * W + 1023) // 1024, device=x.device, dtype=torch.float32)
+    _chk(_lib.hip().stem_nchw3_to_nhwc4(x.data_ptr(), out.data_ptr(), B, H, W, q.data_ptr(), _stream()))
+    out._stem_q = q
     return out
+
+
+def _nhwc4_record(x4: torch.Tensor) -> torch.Tensor:
+    """scale record of an NHWC4 image: the one nchw3_to_nhwc4 attached, or measured here (stem_amax_nhwc)"""
+    q = getattr(x4, "_stem_q", None)
+    if q is None:
+        B, H, W, _ = x4.shape
+        q = torch.empty(16 + 256, device=x4.device, dtype=torch.float32)
+        _chk(_lib.hip().stem_amax_nhwc(x4.data_ptr(), 4, B * H * W, 4, q.data_ptr(), 256, _stream()))
+        x4._stem_q = q
+    return q
 
 
 # ----------------------------------------------------------------------------- weights
@@ -426,16 +440,18 @@ def conv2d_gdn_fwd(x, wp, bias, beta, gamma, K, R, S, stride, pad, inverse=False
 
 
 class Bf16Planes:
-    """An NHWC activation tensor pre-split for the bf16 matrix cores (csrc/conv_bf16x6.hip): every fp32 value is stored as the
-    three bf16 numbers that add up to it exactly, [pixel][C/32][3][32].  Only produced and consumed by the bf16 convolution
-    kernels; `shape` is the logical [B,C,H,W].  `channels(c0, c1)` is a view of a 32-aligned channel range (same storage,
-    same pixel pitch), accepted as an INPUT by conv2d_bf16x6_gen."""
-    __slots__ = ("data", "shape", "pix_bytes", "byte_offset")
+    """An NHWC activation tensor pre-split for the 16-bit matrix cores (csrc/conv_bf16x6.hip): every fp32 value v is stored as two
+    fp16 numbers whose sum is v * 2^e (to 2^-22 |v|), [pixel][C/32][3][32] (plane 2 unused), followed in the same buffer by the
+    tensor's scale record (2^-e and the measured max |v| per producing workgroup: include/stem_hip.h).  Only produced and
+    consumed by the split-operand convolution kernels; `shape` is the logical [B,C,H,W].  `channels(c0, c1)` is a view of a
+    32-aligned channel range (same storage, same pixel pitch, same record), accepted as an INPUT by conv2d_bf16x6_gen."""
+    __slots__ = ("data", "shape", "pix_bytes", "byte_offset", "q_offset")
 
-    def __init__(self, data, shape, pix_bytes=None, byte_offset=0):
+    def __init__(self, data, shape, q_offset, pix_bytes=None, byte_offset=0):
         self.data, self.shape = data, tuple(shape)
         self.pix_bytes = (self.shape[1] // 32) * 192 if pix_bytes is None else pix_bytes
         self.byte_offset = byte_offset
+        self.q_offset = q_offset
 
     @property
     def dense(self):
@@ -444,43 +460,61 @@ class Bf16Planes:
     def data_ptr(self):
         return self.data.data_ptr() + self.byte_offset
 
+    def q_ptr(self):
+        """device address of the scale record"""
+        return self.data.data_ptr() + self.q_offset
+
     def channels(self, c0, c1):
         if c0 % 32 or c1 % 32 or not 0 <= c0 < c1 <= self.shape[1]:
             raise ValueError(f"planes views are 32-channel aligned, got [{c0}, {c1}) of {self.shape[1]}")
         B, _, H, W = self.shape
-        return Bf16Planes(self.data, (B, c1 - c0, H, W), self.pix_bytes, self.byte_offset + (c0 // 32) * 192)
+        return Bf16Planes(self.data, (B, c1 - c0, H, W), self.q_offset, self.pix_bytes, self.byte_offset + (c0 // 32) * 192)
+
+    @staticmethod
+    def nbytes(npix, Cc):
+        """(payload bytes = offset of the scale record, total bytes) = stem_bf16x3_planes_qrec_offset / _planes_bytes"""
+        payload = npix * (Cc // 32) * 192
+        return payload, payload + (((16 + ((npix + 63) // 64) * ((Cc + 127) // 128)) * 4 + 15) & ~15)
 
     @staticmethod
     def empty(B, Cc, H, W, device):
         if Cc % 32:
             raise ValueError(f"the planes layout needs a channel count that is a multiple of 32, got {Cc}")
-        nbytes = B * H * W * (Cc // 32) * 192            # = stem_bf16x3_planes_bytes (this runs ~60 times per training step)
-        return Bf16Planes(torch.empty(nbytes, device=device, dtype=torch.uint8), (B, Cc, H, W))
+        payload, total = Bf16Planes.nbytes(B * H * W, Cc)            # in Python: this runs ~60 times per training step
+        return Bf16Planes(torch.empty(total, device=device, dtype=torch.uint8), (B, Cc, H, W), payload)
 
     @staticmethod
-    def split(x):
+    def split(x, src_q=None):
+        """src_q: data_ptr of a scale record whose slots hold max |x| already (left by the kernel that produced x)"""
         x = to_nhwc(x)
         B, Cc, H, W = x.shape
         out = Bf16Planes.empty(B, Cc, H, W, x.device)
-        _chk(_lib.hip().stem_bf16x3_split_nhwc(x.data_ptr(), nhwc_ld(x), out.data.data_ptr(), B * H * W, Cc, _stream()))
+        _chk(_lib.hip().stem_bf16x3_split_nhwc(x.data_ptr(), nhwc_ld(x), out.data.data_ptr(), out.q_ptr(), src_q, B * H * W, Cc, _stream()))
         return out
 
     @staticmethod
-    def split_dact(dy, z, slope):
+    def split_dact(dy, z, slope, src_q=None):
         """planes of dy * (z > 0 ? 1 : slope): the leaky-ReLU derivative applied while splitting (z = the activated output)"""
         dy, z = to_nhwc(dy), to_nhwc(z)
         B, Cc, H, W = dy.shape
         out = Bf16Planes.empty(B, Cc, H, W, dy.device)
         _chk(_lib.hip().stem_bf16x3_split_dact_nhwc(dy.data_ptr(), nhwc_ld(dy), z.data_ptr(), nhwc_ld(z), float(slope), out.data.data_ptr(),
-                                                     B * H * W, Cc, _stream()))
+                                                     out.q_ptr(), src_q, B * H * W, Cc, _stream()))
         return out
 
     def merge(self):
         assert self.dense, "merge() of a channel view is not implemented"
         B, Cc, H, W = self.shape
         out = empty_nhwc(B, Cc, H, W, self.data.device)
-        _chk(_lib.hip().stem_bf16x3_merge_nhwc(self.data.data_ptr(), out.data_ptr(), Cc, B * H * W, Cc, _stream()))
+        _chk(_lib.hip().stem_bf16x3_merge_nhwc(self.data.data_ptr(), self.q_ptr(), out.data_ptr(), Cc, B * H * W, Cc, _stream()))
         return out
+
+    def record(self):
+        """(2^-e, max |v| over the slots) -- synchronises; tests / debugging"""
+        n = (self.data.numel() - self.q_offset) // 4
+        q = self.data[self.q_offset:].view(torch.float32)[:n].cpu()
+        ns = int(q[:1].view(torch.int32)[0])
+        return float(q[1]), float(q[16:16 + ns].max()) if ns else 0.0
 
 
 def pack_weight_bf16x3(w: torch.Tensor, flip: bool = False) -> torch.Tensor:
@@ -507,8 +541,9 @@ def conv2d_bf16x6_act(xp: Bf16Planes, wp, bias, K, R, S, stride, pad, act=False,
     assert xp.dense, "the 192-column kernel takes whole planes tensors"
     y = empty_nhwc(B, K, Ho, Wo, dev)
     yp = Bf16Planes.empty(B, K, Ho, Wo, dev) if want_planes else None
-    _chk(_lib.hip().stem_conv2d_bf16x6_fwd_act(xp.data.data_ptr(), wp.data_ptr(), _ptr(bias), 1 if act else 0, float(slope), y.data_ptr(), nhwc_ld(y),
-                                               yp.data.data_ptr() if yp is not None else None, B, H, W, Cc, K, R, S, stride, pad, _stream()))
+    _chk(_lib.hip().stem_conv2d_bf16x6_fwd_act(xp.data.data_ptr(), xp.q_ptr(), wp.data_ptr(), _ptr(bias), 1 if act else 0, float(slope), y.data_ptr(), nhwc_ld(y),
+                                               yp.data.data_ptr() if yp is not None else None, yp.q_ptr() if yp is not None else None,
+                                               B, H, W, Cc, K, R, S, stride, pad, _stream()))
     return y, yp
 
 
@@ -520,13 +555,13 @@ def conv2d_bf16x6_fwd(xp: Bf16Planes, wp, bias, K, R, S, stride, pad, beta=None,
     dev = xp.data.device
     if planes_out:
         out = Bf16Planes.empty(B, K, Ho, Wo, dev)
-        y, ldy, yp = None, 0, out.data.data_ptr()
+        y, ldy, yp, yq = None, 0, out.data.data_ptr(), out.q_ptr()
     else:
         out = empty_nhwc(B, K, Ho, Wo, dev)
-        y, ldy, yp = out.data_ptr(), nhwc_ld(out), None
+        y, ldy, yp, yq = out.data_ptr(), nhwc_ld(out), None, None
     assert xp.dense, "the analysis-transform kernel takes whole planes tensors"
-    _chk(_lib.hip().stem_conv2d_bf16x6_fwd(xp.data.data_ptr(), wp.data_ptr(), _ptr(bias), _ptr(beta), _ptr(gamma), beta_min,
-                                           y, ldy, yp, B, H, W, Cc, K, R, S, stride, pad, _stream()))
+    _chk(_lib.hip().stem_conv2d_bf16x6_fwd(xp.data.data_ptr(), xp.q_ptr(), wp.data_ptr(), _ptr(bias), _ptr(beta), _ptr(gamma), beta_min,
+                                           y, ldy, yp, yq, B, H, W, Cc, K, R, S, stride, pad, _stream()))
     return out
 
 
@@ -583,8 +618,9 @@ def conv2d_bf16x6_gen(xp: Bf16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EP
         if buf is None or buf.numel() * 4 < need:
             buf = _WS[slot] = torch.zeros((need + 3) // 4, device=dev, dtype=torch.float32)       # zero head: arrival counters
         ws_ptr = buf.data_ptr()
-    _chk(_lib.hip().stem_conv2d_bf16x6_gen_fwd(xp.data_ptr(), xp.pix_bytes, wp.data_ptr(), _ptr(bias), epi, slope, _ptr(z), nhwc_ld(z) if z is not None else 0,
-                                               _ptr(y), nhwc_ld(y) if y is not None else 0, yp.data.data_ptr() if yp is not None else None,
+    _chk(_lib.hip().stem_conv2d_bf16x6_gen_fwd(xp.data_ptr(), xp.q_ptr(), xp.pix_bytes, wp.data_ptr(), _ptr(bias), epi, slope, _ptr(z),
+                                               nhwc_ld(z) if z is not None else 0, _ptr(y), nhwc_ld(y) if y is not None else 0,
+                                               yp.data.data_ptr() if yp is not None else None, yp.q_ptr() if yp is not None else None,
                                                B, H, W, Cc, N, R, S, stride, pad, ws_ptr, need, _stream()))
     return y, yp
 
@@ -614,7 +650,8 @@ def conv2d_wgrad_bf16x6(xp: Bf16Planes, dyp: Bf16Planes, K, R, S, pad, dwp, spli
     B, Cc, H, W = xp.shape
     if db is not None and bias_part is None:
         bias_part = torch.empty(splits * K, device=dwp.device, dtype=torch.float32)
-    _chk(_lib.hip().stem_conv2d_wgrad_bf16x6(xp.data_ptr(), xp.pix_bytes, dyp.data_ptr(), dyp.pix_bytes, dwp.data_ptr(), _ptr(bias_part) if db is not None else None,
+    _chk(_lib.hip().stem_conv2d_wgrad_bf16x6(xp.data_ptr(), xp.q_ptr(), xp.pix_bytes, dyp.data_ptr(), dyp.q_ptr(), dyp.pix_bytes, dwp.data_ptr(),
+                                             _ptr(bias_part) if db is not None else None,
                                              B, H, W, Cc, K, R, S, pad, splits, _stream()))
     if db is not None:
         _chk(_lib.hip().stem_bias_grad_final(bias_part.data_ptr(), K, splits, db.data_ptr(), int(accumulate_db), _stream()))
@@ -667,12 +704,12 @@ def conv2d_c4_gdn_bf16x6(x4, astream, bias, beta, K, R, S, stride, pad, beta_min
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
     if planes_out:
         res = Bf16Planes.empty(B, K, Ho, Wo, x4.device)
-        y, ldy, yp = None, 0, res.data.data_ptr()
+        y, ldy, yp, yq = None, 0, res.data.data_ptr(), res.q_ptr()
     else:
         res = out if out is not None else empty_nhwc(B, K, Ho, Wo, x4.device)
-        y, ldy, yp = res.data_ptr(), nhwc_ld(res), None
-    _chk(_lib.hip().stem_conv2d_c4_gdn_bf16x6(x4.data_ptr(), astream.data_ptr(), _ptr(bias), beta.data_ptr(), beta_min, y, ldy, yp,
-                                              B, H, W, K, R, S, stride, pad, _stream()))
+        y, ldy, yp, yq = res.data_ptr(), nhwc_ld(res), None, None
+    _chk(_lib.hip().stem_conv2d_c4_gdn_bf16x6(x4.data_ptr(), _nhwc4_record(x4).data_ptr(), astream.data_ptr(), _ptr(bias), beta.data_ptr(), beta_min,
+                                              y, ldy, yp, yq, B, H, W, K, R, S, stride, pad, _stream()))
     return res
 
 
@@ -682,12 +719,8 @@ def conv2d_fwd_c4_gdn_planes(x4, wp, bias, beta, gamma, K, R, S, stride, pad, be
     if c4gdn_supported(K, R, S) and _aligned16(bias, beta) and _c4gdn_fits(x4, K, R, S, stride, pad, planes=True):
         return conv2d_c4_gdn_bf16x6(x4, astream if astream is not None else c4gdn_stream(wp, gamma, K, R, S), bias, beta, K, R, S,
                                     stride, pad, beta_min, planes_out=True)
-    B, H, W, _ = x4.shape
-    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
-    out = Bf16Planes.empty(B, K, Ho, Wo, x4.device)
-    _chk(_lib.hip().stem_conv2d_fwd_c4_gdn_planes(x4.data_ptr(), wp.data_ptr(), _ptr(bias), beta.data_ptr(), gamma.data_ptr(),
-                                                  out.data.data_ptr(), B, H, W, K, R, S, stride, pad, beta_min, _stream()))
-    return out
+    # channel counts the one-kernel form does not cover: the fp32-MFMA kernel, then a split pass
+    return Bf16Planes.split(conv2d_fwd_c4_gdn(x4, wp, bias, beta, gamma, K, R, S, stride, pad, beta_min=beta_min))
 
 
 def conv2d_fwd_c4_gdn(x4, wp, bias, beta, gamma, K, R, S, stride, pad, inverse=False, beta_min=1e-6, out=None, astream=None):

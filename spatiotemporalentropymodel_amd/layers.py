@@ -192,7 +192,7 @@ class Conv2dFunction(torch.autograd.Function):
                 y._stem_planes = yp
             ctx.cfg = (stride, pad, act, masked, cache, False, tuple(x.shape), slope)
             ctx.params = (weight, bias)
-            ctx.bx6 = (xp.pix_bytes, xp.byte_offset)
+            ctx.bx6 = (xp.q_offset, xp.pix_bytes, xp.byte_offset)
             ctx.save_for_backward(xp.data, weight, y if act else None)
             return y
         ctx.bx6 = None

@@ -85,7 +85,9 @@ def test_roundtrip_all_variants(cls_name):
         enc2 = m.compress(y_hat if not m.RESIDUAL else y_hat, y_cond)      # re-encoding the reconstruction is idempotent in size
         assert abs(len(enc2["strings"][0][0]) - len(enc["strings"][0][0])) <= max(8, len(enc["strings"][0][0]) // 10)
     else:
-        assert_close(host(y_hat), host(fwd["y_hat"]), 1e-6, what="decode == eval forward reconstruction", floor=0.1)
+        # (the decoder's per-position products and the forward's layer kernels are different fp32-class routes: same symbols, the
+        # means agree to the routes' rounding, ~1e-6 of the largest latent)
+        assert_close(host(y_hat), host(fwd["y_hat"]), 2e-5, what="decode == eval forward reconstruction", floor=0.1)
     total_bits = 8 * sum(len(s) for s in enc["strings"][0] + enc["strings"][1])
     assert total_bits > 0
 

@@ -415,12 +415,14 @@ def test_bf16_planes_views_and_engine_routing_table():
     import torch
     from spatiotemporalentropymodel_amd import functional as F
     from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel_Res
-    data = torch.zeros(2 * 4 * 4 * (160 // 32) * 192, dtype=torch.uint8)
-    p = F.Bf16Planes(data, (2, 160, 4, 4))
-    assert p.dense and p.pix_bytes == 5 * 192
+    payload, total = F.Bf16Planes.nbytes(2 * 4 * 4, 160)
+    data = torch.zeros(total, dtype=torch.uint8)
+    p = F.Bf16Planes(data, (2, 160, 4, 4), payload)
+    assert p.dense and p.pix_bytes == 5 * 192 and p.q_ptr() == data.data_ptr() + payload
     v = p.channels(32, 128)
     assert v.shape == (2, 96, 4, 4) and v.pix_bytes == p.pix_bytes and v.byte_offset == 192 and not v.dense
     assert v.channels(32, 64).byte_offset == 2 * 192 and v.data is data
+    assert v.q_ptr() == p.q_ptr()                             # a channel view shares the scale record of the whole tensor
     for bad in ((16, 80), (0, 200), (64, 64)):
         with pytest.raises(ValueError):
             p.channels(*bad)
@@ -470,7 +472,12 @@ def test_bf16_chain_is_not_selected_when_planes_exceed_a_buffer_view():
 def test_planes_byte_count_matches_the_library():
     """Bf16Planes.empty sizes its storage in Python (hot path); the C ABI's stem_bf16x3_planes_bytes is the definition."""
     from spatiotemporalentropymodel_amd import _lib
+    from spatiotemporalentropymodel_amd import functional as F
     lib = _lib.hip()
-    for npix, C in ((1, 32), (4096, 192), (65280, 1152), (7, 96)):
-        assert lib.stem_bf16x3_planes_bytes(npix, C) == npix * (C // 32) * 192
+    for npix, C in ((1, 32), (4096, 192), (65280, 1152), (7, 96), (64, 128), (65, 160), (16 * 128 * 128, 192)):
+        payload, total = F.Bf16Planes.nbytes(npix, C)
+        assert lib.stem_bf16x3_planes_qrec_offset(npix, C) == payload == npix * (C // 32) * 192
+        assert lib.stem_bf16x3_planes_bytes(npix, C) == total
+        # the scale record: 16 header words + one slot per 64-pixel x 128-channel producer tile, 16-byte granules
+        assert total - payload >= (16 + -(-npix // 64) * -(-C // 128)) * 4 and (total - payload) % 16 == 0
     assert lib.stem_bf16x3_planes_bytes(10, 48) == 0

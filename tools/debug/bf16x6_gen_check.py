@@ -43,7 +43,7 @@ def case(name, B, C, H, W, K, R, timing=True):
     torch.cuda.synchronize()
     sc = float(ref.abs().max())
     e6, e32 = float((y.double().cpu() - ref).abs().max()) / sc, float((y32.double().cpu() - ref).abs().max()) / sc
-    okp = yp is None or torch.equal(yp.merge(), y)
+    okp = yp is None or (lambda _p, _y: bool(((_p.merge().double() - _y.double()).abs() <= _y.double().abs() * 2.0 ** -22 + _p.record()[0] * 2.0 ** -25).all()))(yp, y)
     line = f"{name:8s} fwd  err bf16x6 {e6:.2e} fp32 {e32:.2e} planes_ok={okp}"
     if timing:
         t6 = timeit(lambda: F.conv2d_bf16x6_gen(xp, wp, b, K, R, R, 1, pad, epi=F.GEN_EPI_LRELU, slope=SL, want_planes=K % 32 == 0))
