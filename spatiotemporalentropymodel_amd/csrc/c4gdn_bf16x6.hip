@@ -32,7 +32,7 @@ namespace {
 typedef hp8 bf16x8;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int CHUNK = 18432;                    // bytes of one A-operand chunk: 18 fragments x 64 lanes x 16 B
+constexpr int CHUNK = 12288;                    // bytes of one A-operand chunk: 6 tiles x 2 planes x 64 lanes x 16 B
 constexpr int OOR = 0x7FFFFF00;                 // voffset that every buffer view rejects (returns 0)
 constexpr int OOR_ST = 0x7FFF0000;              // the same with room for the stores' constant offsets (views are < 0x7FFF0000 bytes)
 constexpr int WG_PIX = 128, NTHREADS = 256;     // 4 wavefronts x 32 pixels
@@ -57,7 +57,7 @@ struct C4gArgs {
 };
 
 // ---- A-operand stream -------------------------------------------------------------------------------------------------------
-// chunk t < ksc (conv k-step t): fragment (nb, plane) at ((nb * 3 + plane) * 64 + lane) * 16; lane (r, h) element j is the
+// chunk t < ksc (conv k-step t): fragment (nb, plane) at ((nb * 2 + plane) * 64 + lane) * 16; lane (r, h) element j is the
 //   weight of channel nb * 32 + rho(r) for K slot (pair q = 2 t + h, tap j >> 2 of the pair, image channel j & 3), where pair q
 //   = (filter row q / PR, taps 2 (q % PR) and 2 (q % PR) + 1), PR = ceil(S / 2); slots beyond the filter hold 0;
 // chunk ksc + 2 kb + s (GDN k-step s of k-block kb): fragment (nb, plane) at the same place; lane (r, h) element j =
@@ -102,38 +102,32 @@ __global__ __launch_bounds__(256) void c4gdn_pack_kernel(const float *wp_c4, con
         }
     }
     if (!used) return;
-    bf16x8 p0, p1, p2;
+    bf16x8 p0, p1;
     const float sc = q_pow2(c < ksc ? we : ge);
     for (int j = 0; j < 8; ++j) {
-        hp_t a, b, cc;
-        q_split(v[j], sc, a, b, cc);
-        p0[j] = a; p1[j] = b; p2[j] = cc;
+        hp_t a, b;
+        q_split(v[j], sc, a, b);
+        p0[j] = a; p1[j] = b;
     }
-    unsigned char *dst = out + (size_t)c * CHUNK + ((size_t)(fp * 3) * 64 + lane) * 16;
+    unsigned char *dst = out + (size_t)c * CHUNK + ((size_t)(fp * 2) * 64 + lane) * 16;
     *reinterpret_cast<bf16x8 *>(dst) = p0;
     *reinterpret_cast<bf16x8 *>(dst + 1024) = p1;
-    *reinterpret_cast<bf16x8 *>(dst + 2048) = p2;
 }
 
-// six products of one fp32 product, smallest terms first (as conv_bf16x6.hip)
-__device__ inline f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 acc)
+// the three products of one fp32 product, smallest terms first (as conv_bf16x6.hip)
+__device__ inline f32x16 mfma3(const bf16x8 (&a)[2], const bf16x8 (&b)[2], f32x16 acc)
 {
-    if constexpr (STEM_NP == 6) {
-        acc = STEM_MFMA16(a[2], b[0], acc);
-        acc = STEM_MFMA16(a[0], b[2], acc);
-        acc = STEM_MFMA16(a[1], b[1], acc);
-    }
     acc = STEM_MFMA16(a[1], b[0], acc);
     acc = STEM_MFMA16(a[0], b[1], acc);
     acc = STEM_MFMA16(a[0], b[0], acc);
     return acc;
 }
 
-// the three planes of one A fragment (consecutive 1 KiB pieces of the chunk, lane-linear: conflict-free ds_read_b128)
-__device__ inline void lda(const unsigned char *p, bf16x8 (&af)[3])
+// the two planes of one A fragment (consecutive 1 KiB pieces of the chunk, lane-linear: conflict-free ds_read_b128)
+__device__ inline void lda(const unsigned char *p, bf16x8 (&af)[2])
 {
-#pragma unroll
-    for (int pl = 0; pl < (STEM_NP == 6 ? 3 : 2); ++pl) af[pl] = *reinterpret_cast<const bf16x8 *>(p + pl * 1024);
+    af[0] = *reinterpret_cast<const bf16x8 *>(p);
+    af[1] = *reinterpret_cast<const bf16x8 *>(p + 1024);
 }
 
 template <int NB>
@@ -155,22 +149,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
     const int nchunks = a.ksc + 2 * NB;
     const int PR = (a.S + 1) / 2, npairs = a.R * PR;
 
-    // ---- A-operand ring: chunk c -> buffer c & 1, 4.5 KiB per wavefront as four 1 KiB pieces and one half piece ---------------
-    // (wavefront w copies bytes [4096 w, 4096 w + 4096) and the half piece at 16384 + 512 w; buffer form: one VGPR of lane
-    // offset, the chunk offset in an SGPR, the piece offsets as immediates)
+    // ---- A-operand ring: chunk c -> buffer c & 1, 3 KiB per wavefront as three 1 KiB pieces (wavefront w copies bytes
+    // [3072 w, 3072 w + 3072); buffer form: one VGPR of lane offset, the chunk offset in an SGPR, the piece offsets as immediates)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(a.astream), 0, nchunks * CHUNK, 0x00020000);
-    const int ring_v = wave * 4096 + lane * 16, ring_vt = 16384 + wave * 512 + (lane & 31) * 16;
+    const int ring_v = wave * 3072 + lane * 16;
     auto ring_issue = [&](int c) {
         if (c >= nchunks) return;
         const int co = c * CHUNK;
         unsigned char *dst = smem + (c & 1) * CHUNK;
-        auto *ls = (__attribute__((address_space(3))) void *)(dst + wave * 4096);
+        auto *ls = (__attribute__((address_space(3))) void *)(dst + wave * 3072);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, ls, 16, ring_v, co, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, ls, 16, ring_v, co, 1024, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, ls, 16, ring_v, co, 2048, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, ls, 16, ring_v, co, 3072, 0);
-        if (lane < 32)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst + 16384 + wave * 512), 16, ring_vt, co, 0, 0);
     };
     // every wavefront waits for its own pieces, the barrier publishes all of them (and retires the buffer read last step)
     auto ring_wait = [&]() {
@@ -244,30 +234,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
     for (int t = 0; t < a.ksc; ++t) {
         ring_wait();
         ring_issue(t + 1);
-        bf16x8 b[3];
+        bf16x8 b[2];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            hp_t h0, h1, h2;
-            q_split(pv0[j], xscale, h0, h1, h2);
-            b[0][j] = h0; b[1][j] = h1; b[2][j] = h2;
-            q_split(pv1[j], xscale, h0, h1, h2);
-            b[0][4 + j] = h0; b[1][4 + j] = h1; b[2][4 + j] = h2;
+            hp_t h0, h1;
+            q_split(pv0[j], xscale, h0, h1);
+            b[0][j] = h0; b[1][j] = h1;
+            q_split(pv1[j], xscale, h0, h1);
+            b[0][4 + j] = h0; b[1][4 + j] = h1;
         }
         patch_load(t + 1 < a.ksc ? t + 1 : t, pv0, pv1);
         const unsigned char *buf = smem + (t & 1) * CHUNK + lane * 16;
-        bf16x8 af[2][3];
+        bf16x8 af[2][2];
         lda(buf, af[0]);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {          // fragments of tile nb + 1 are fetched behind the MFMAs of tile nb
-            if (nb + 1 < NB) lda(buf + (nb + 1) * 3072, af[(nb + 1) & 1]);
-            x[nb] = mfma6(af[nb & 1], b, x[nb]);
+            if (nb + 1 < NB) lda(buf + (nb + 1) * 2048, af[(nb + 1) & 1]);
+            x[nb] = mfma3(af[nb & 1], b, x[nb]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
     // ---- GDN: 2 NB chunks of one k-step (16 channels of x^2) x NB output tiles; B operand = the squared accumulators ----------------
     // outputs through buffer stores: one VGPR of pixel offset each (out of range for the pixels beyond M: dropped by the hardware)
-    const int opix = NB * 192;
+    const int opix = NB * 128;
     const __amdgpu_buffer_rsrc_t ryp = __builtin_amdgcn_make_buffer_rsrc(a.yp, 0, a.yp ? Mtot * opix : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t ryf = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y ? (Mtot - 1) * a.ldy * 4 + a.N * 4 : 0, 0x00020000);
     const int vyp = ok ? m * opix + 32 * h : OOR_ST, vyf = ok ? m * a.ldy * 4 + 64 * h : OOR_ST;
@@ -287,20 +277,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
             ring_wait();
             ring_issue(c + 1);
             const unsigned char *buf = smem + (c & 1) * CHUNK + lane * 16;
-            bf16x8 b[3];
+            bf16x8 b[2];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float v = x[kb][8 * s + j];
-                hp_t h0, h1, h2;
-                q_split(v * v, sqscale, h0, h1, h2);
-                b[0][j] = h0; b[1][j] = h1; b[2][j] = h2;
+                hp_t h0, h1;
+                q_split(v * v, sqscale, h0, h1);
+                b[0][j] = h0; b[1][j] = h1;
             }
-            bf16x8 af[2][3];
+            bf16x8 af[2][2];
             lda(buf, af[0]);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                if (nb + 1 < NB) lda(buf + (nb + 1) * 3072, af[(nb + 1) & 1]);
-                nrm[nb] = mfma6(af[nb & 1], b, nrm[nb]);
+                if (nb + 1 < NB) lda(buf + (nb + 1) * 2048, af[(nb + 1) & 1]);
+                nrm[nb] = mfma3(af[nb & 1], b, nrm[nb]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -334,18 +324,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
                 }
             }
             if (a.yp) {
-                bf16x8 q0[2], q1[2], q2[2];
+                bf16x8 q0[2], q1[2];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    hp_t h0, h1, h2;
-                    q_split(yv[i], oscale, h0, h1, h2);
-                    q0[i >> 3][i & 7] = h0; q1[i >> 3][i & 7] = h1; q2[i >> 3][i & 7] = h2;
+                    hp_t h0, h1;
+                    q_split(yv[i], oscale, h0, h1);
+                    q0[i >> 3][i & 7] = h0; q1[i >> 3][i & 7] = h1;
                 }
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0[e]), ryp, vyp + nb * 192 + 16 * e, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1[e]), ryp, vyp + nb * 192 + 64 + 16 * e, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q2[e]), ryp, vyp + nb * 192 + 128 + 16 * e, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0[e]), ryp, vyp + nb * 128 + 16 * e, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1[e]), ryp, vyp + nb * 128 + 64 + 16 * e, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);         // one tile's epilogue at a time: 56 live registers instead of 3 x 56
@@ -420,7 +409,7 @@ STEM_EXPORT int stem_conv2d_c4_gdn_bf16x6(const float *x4, const float *xq, cons
     STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_c4_gdn_bf16x6: empty output");
     const size_t xb = (size_t)B * H * W * 16;
     STEM_CHECK_ARG(xb < 0x7FFFFF00ull && (size_t)B * OH * OW < 0x7FFFFFFFull, "stem_conv2d_c4_gdn_bf16x6: image batch must stay below 2 GiB");
-    STEM_CHECK_ARG((!yp || (size_t)B * OH * OW * (N / 32) * 192 < 0x7FFF0000ull) && (!y || (size_t)B * OH * OW * ldy * 4 < 0x7FFF0000ull),
+    STEM_CHECK_ARG((!yp || (size_t)B * OH * OW * (N / 32) * 128 < 0x7FFF0000ull) && (!y || (size_t)B * OH * OW * ldy * 4 < 0x7FFF0000ull),
                    "stem_conv2d_c4_gdn_bf16x6: outputs are addressed through 2 GiB buffer views (split the batch)");
     C4gArgs a;
     memset(&a, 0, sizeof(a));

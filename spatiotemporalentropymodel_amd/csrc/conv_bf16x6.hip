@@ -31,10 +31,11 @@ namespace {
 typedef hp8 bf16x8;
 
 constexpr int BN = 192, KC = 32;
-constexpr int B_PLANE = BN * 64, B_BUF = 3 * B_PLANE;              // bytes of one bf16 plane of a weight chunk; 36864 per chunk
+constexpr int NPL = 2, SLAB = NPL * 64;                            // planes per value; bytes per pixel and 32-channel slab
+constexpr int B_PLANE = BN * 64, B_BUF = NPL * B_PLANE;            // bytes of one plane of a weight chunk; 24576 per chunk
 constexpr int XP = BN + 4, GP = 36;                                // fp32 pitches of the parked tile / the gamma chunk
 // LDS of a BM-pixel tile: main loop 2 x (3 planes x (BM + BN) rows x 64 B), epilogue BM x XP + BN x GP floats, then the tap table
-constexpr int lds_taps(int bm) { return 2 * 3 * (bm + BN) * 64 > (bm * XP + BN * GP) * 4 ? 2 * 3 * (bm + BN) * 64 : (bm * XP + BN * GP) * 4; }
+constexpr int lds_taps(int bm) { return 2 * NPL * (bm + BN) * 64 > (bm * XP + BN * GP) * 4 ? 2 * NPL * (bm + BN) * 64 : (bm * XP + BN * GP) * 4; }
 constexpr int lds_total(int bm) { return lds_taps(bm) + 32 * 4; }
 constexpr int MAXTAP = 25;
 constexpr int OOR = 0x7FFFFF00;                                    // voffset that every buffer view rejects (returns 0)
@@ -66,20 +67,18 @@ __device__ inline int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
 
 // BM = pixels per workgroup: 128 (8 wavefronts) or 64 (4 wavefronts, for layers with too few 128-pixel tiles to fill the chip).
-// NP = number of bf16 products kept per fp32 product: 6 (i + j <= 2, all three planes), 4 (i, j <= 1) or 3 (i + j <= 1); the
-// last two read only planes 0 and 1 (experiments: DESIGN.md).
-template <int BM, int NP>
+template <int BM>
 __global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
 {
     constexpr int NT = BM * 4;
-    constexpr int A_PLANE = BM * 64, A_BUF = 3 * A_PLANE;
+    constexpr int A_PLANE = BM * 64, A_BUF = NPL * A_PLANE;
     constexpr int LDS_TAPS = lds_taps(BM);
-    constexpr int PL = NP == 6 ? 3 : 2;                 // planes read
+    constexpr int PL = NPL;
     constexpr int WPIECES = PL * BN * 4;                // 16-byte pieces of the weight chunk that are read
     constexpr int BP = (WPIECES + NT - 1) / NT;         // ... per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *As = smem;                       // [2][3][BM][64 B]
-    unsigned char *Bs = smem + 2 * A_BUF;           // [2][3][BN][64 B]
+    unsigned char *As = smem;                       // [2][NPL][BM][64 B]
+    unsigned char *Bs = smem + 2 * A_BUF;           // [2][NPL][BN][64 B]
     int *tapi = reinterpret_cast<int *>(smem + LDS_TAPS);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -90,7 +89,7 @@ __global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
         if (nb >= 16) tile_m = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
     }
     const int bm0 = tile_m * BM;
-    const int nslab = a.C / KC, pixbytes = nslab * 192;
+    const int nslab = a.C / KC, pixbytes = nslab * SLAB;
     if (tid < 32) tapi[tid] = tid < a.ntaps ? (a.dy[tid] * a.W + a.dx[tid]) * pixbytes : 0;
 
     // ---- staging assignment.  Activations: thread -> (row = tid / 4, 16-byte column = tid % 4) of all three planes ---------
@@ -122,7 +121,7 @@ __global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
 
     f32x4 raA[PL], rbA[BP], raB[PL], rbB[BP];
     auto gload = [&](int t, int kc, int q, f32x4 (&ra)[PL], f32x4 (&rb)[BP]) {
-        const int tA = __builtin_amdgcn_readfirstlane(tapi[t]), sA = kc * 192, sB = q * B_BUF;
+        const int tA = __builtin_amdgcn_readfirstlane(tapi[t]), sA = kc * SLAB, sB = q * B_BUF;
         const int mk = __builtin_amdgcn_sbfe((int)pmask, (unsigned)t, 1u);                 // 0 / -1: tap t inside the image
         const int off = ((pb + tA) & mk) | (OOR & ~mk);
 #pragma unroll
@@ -168,11 +167,6 @@ __global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
                 for (int j = 0; j < 3; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8 *>(Bb + pl * B_PLANE + j * 32 * 64 + pk);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {      // smallest terms first
-                if constexpr (NP == 6) {
-                    acc[j] = STEM_MFMA16(af[PL - 1], bf[0][j], acc[j]);
-                    acc[j] = STEM_MFMA16(af[0], bf[PL - 1][j], acc[j]);
-                }
-                if constexpr (NP >= 4) acc[j] = STEM_MFMA16(af[1], bf[1][j], acc[j]);
                 acc[j] = STEM_MFMA16(af[1], bf[0][j], acc[j]);
                 acc[j] = STEM_MFMA16(af[0], bf[1][j], acc[j]);
                 acc[j] = STEM_MFMA16(af[0], bf[0][j], acc[j]);
@@ -371,7 +365,7 @@ __global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) X2[(wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * XP + wn0 + j * 32 + lr] = acc[j][r];
         __syncthreads();
-        const int oslab = a.N / KC, opix = oslab * 192;
+        const int oslab = a.N / KC, opix = oslab * SLAB;
         unsigned char *yp = static_cast<unsigned char *>(a.yp);
         for (int e = tid; e < BM * oslab * 4; e += NT) {
             const int row = e / (oslab * 4), rem = e - row * (oslab * 4), sl = rem >> 2, p = rem & 3;
@@ -379,19 +373,18 @@ __global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
             if (m >= Mtot) continue;
             const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&X2[row * XP + sl * 32 + p * 8]);
             const f32x4 v1 = *reinterpret_cast<const f32x4 *>(&X2[row * XP + sl * 32 + p * 8 + 4]);
-            bf16x8 h0, h1, h2;
+            bf16x8 h0, h1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                hp_t x0, x1, x2;
-                q_split(v0[c], oscale, x0, x1, x2);
-                h0[c] = x0; h1[c] = x1; h2[c] = x2;
-                q_split(v1[c], oscale, x0, x1, x2);
-                h0[4 + c] = x0; h1[4 + c] = x1; h2[4 + c] = x2;
+                hp_t x0, x1;
+                q_split(v0[c], oscale, x0, x1);
+                h0[c] = x0; h1[c] = x1;
+                q_split(v1[c], oscale, x0, x1);
+                h0[4 + c] = x0; h1[4 + c] = x1;
             }
-            unsigned char *dst = yp + (size_t)m * opix + sl * 192 + p * 16;
+            unsigned char *dst = yp + (size_t)m * opix + sl * SLAB + p * 16;
             *reinterpret_cast<bf16x8 *>(dst) = h0;
             *reinterpret_cast<bf16x8 *>(dst + 64) = h1;
-            *reinterpret_cast<bf16x8 *>(dst + 128) = h2;
         }
     }
 }
@@ -405,18 +398,17 @@ __global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
 // and / or planes for the next layer.  Weight image per (N tile, chunk): [3][128][64 B], swizzled like the 192-row one.
 enum { GEN_EPI_BIAS = 0, GEN_EPI_LRELU = 1, GEN_EPI_DACT = 2 };
 constexpr int GBM = 64, GBN = 128, GNT = 256;
-constexpr int GA_PLANE = GBM * 64, GA_BUF = 3 * GA_PLANE;            // 12288
-constexpr int GB_PLANE = GBN * 64, GB_BUF = 3 * GB_PLANE;            // 24576
+constexpr int GA_PLANE = GBM * 64, GA_BUF = NPL * GA_PLANE;          // 8192
+constexpr int GB_PLANE = GBN * 64, GB_BUF = NPL * GB_PLANE;          // 16384
 constexpr int GTP = GBN + 4;                                         // fp32 pitch of the epilogue tile
-constexpr int GLDS = 2 * (GA_BUF + GB_BUF) + 32 * 4;                 // 73856 (the 64 x 132 float epilogue tile reuses the front)
+constexpr int GLDS = 2 * (GA_BUF + GB_BUF) + 32 * 4;                 // 49280 (the 64 x 132 float epilogue tile reuses the front)
 
-template <int NP>       // products kept per fp32 product: 6 (default), 4 or 3 (measurement switches, two planes read)
 __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a)
 {
-    constexpr int PL = NP == 6 ? 3 : 2, BPC = PL * 2;          // planes read; 16-byte weight pieces per thread and chunk
+    constexpr int PL = NPL, BPC = PL * 2;                      // planes; 16-byte weight pieces per thread and chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *As = smem;                        // [2][3][64][64 B]
-    unsigned char *Bs = smem + 2 * GA_BUF;           // [2][3][128][64 B]
+    unsigned char *As = smem;                        // [2][NPL][64][64 B]
+    unsigned char *Bs = smem + 2 * GA_BUF;           // [2][NPL][128][64 B]
     int *tapi = reinterpret_cast<int *>(smem + 2 * (GA_BUF + GB_BUF));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -453,7 +445,7 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
 
     f32x4 raA[PL], rbA[BPC], raB[PL], rbB[BPC];
     auto gload = [&](int t, int kc, int q, f32x4 (&ra)[PL], f32x4 (&rb)[BPC]) {
-        const int tA = __builtin_amdgcn_readfirstlane(tapi[t]), sA = kc * 192, sB = (wbase + q) * GB_BUF;
+        const int tA = __builtin_amdgcn_readfirstlane(tapi[t]), sA = kc * SLAB, sB = (wbase + q) * GB_BUF;
         const int mk = __builtin_amdgcn_sbfe((int)pmask, (unsigned)t, 1u);
         const int off = ((pb + tA) & mk) | (OOR & ~mk);
 #pragma unroll
@@ -495,11 +487,6 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
                 for (int j = 0; j < 2; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8 *>(Bb + pl * GB_PLANE + j * 32 * 64 + pk);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if constexpr (NP == 6) {
-                    acc[j] = STEM_MFMA16(af[PL - 1], bf[0][j], acc[j]);
-                    acc[j] = STEM_MFMA16(af[0], bf[PL - 1][j], acc[j]);
-                }
-                if constexpr (NP >= 4) acc[j] = STEM_MFMA16(af[1], bf[1][j], acc[j]);
                 acc[j] = STEM_MFMA16(af[1], bf[0][j], acc[j]);
                 acc[j] = STEM_MFMA16(af[0], bf[1][j], acc[j]);
                 acc[j] = STEM_MFMA16(af[0], bf[0][j], acc[j]);
@@ -680,7 +667,7 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
     }
     if (a.yp) {
         __syncthreads();
-        const int oslab = a.N / KC, opix = oslab * 192;
+        const int oslab = a.N / KC, opix = oslab * SLAB;
         unsigned char *yp = static_cast<unsigned char *>(a.yp);
         for (int e = tid; e < GBM * (GBN / 8); e += GNT) {
             const int row = e / (GBN / 8), c8 = e - row * (GBN / 8);
@@ -688,19 +675,18 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
             if (m >= Mtot || n >= a.N) continue;            // N % 32 == 0 for planes (host check)
             const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&T[row * GTP + c8 * 8]);
             const f32x4 v1 = *reinterpret_cast<const f32x4 *>(&T[row * GTP + c8 * 8 + 4]);
-            bf16x8 h0, h1, h2;
+            bf16x8 h0, h1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                hp_t x0, x1, x2;
-                q_split(v0[c], oscale, x0, x1, x2);
-                h0[c] = x0; h1[c] = x1; h2[c] = x2;
-                q_split(v1[c], oscale, x0, x1, x2);
-                h0[4 + c] = x0; h1[4 + c] = x1; h2[4 + c] = x2;
+                hp_t x0, x1;
+                q_split(v0[c], oscale, x0, x1);
+                h0[c] = x0; h1[c] = x1;
+                q_split(v1[c], oscale, x0, x1);
+                h0[4 + c] = x0; h1[4 + c] = x1;
             }
-            unsigned char *dst = yp + (size_t)m * opix + (n >> 5) * 192 + ((n >> 3) & 3) * 16;
+            unsigned char *dst = yp + (size_t)m * opix + (n >> 5) * SLAB + ((n >> 3) & 3) * 16;
             *reinterpret_cast<bf16x8 *>(dst) = h0;
             *reinterpret_cast<bf16x8 *>(dst + 64) = h1;
-            *reinterpret_cast<bf16x8 *>(dst + 128) = h2;
         }
     }
 }
@@ -722,19 +708,19 @@ __global__ __launch_bounds__(256) void pack_weight_gen_kernel(const float *w, un
     const long qq = e / (4 * GBN);                       // ntile * nchunks + q
     const int ntile = (int)(qq / nchunks), q = (int)(qq - (long)ntile * nchunks);
     const int slab = q / RS, tap = q - slab * RS, n = ntile * GBN + nl;
-    bf16x8 h[3];
+    bf16x8 h[NPL];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int ch = slab * 32 + p * 8 + c;
         float v = 0.f;
         if (n < N) v = flip ? w[((size_t)ch * N + n) * RS + (RS - 1 - tap)] : w[((size_t)n * C + ch) * RS + tap];
-        hp_t x0, x1, x2;
-        q_split(v, wscale, x0, x1, x2);
-        h[0][c] = x0; h[1][c] = x1; h[2][c] = x2;
+        hp_t x0, x1;
+        q_split(v, wscale, x0, x1);
+        h[0][c] = x0; h[1][c] = x1;
     }
     unsigned char *dst = wp + qq * GB_BUF + nl * 64 + ((p ^ ((nl >> 2) & 3)) << 4);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8 *>(dst + pl * GB_PLANE) = h[pl];
+    for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<bf16x8 *>(dst + pl * GB_PLANE) = h[pl];
 }
 
 // every layer's weight image with one launch: blockIdx.y = descriptor (the weights of a training model change every step).  The
@@ -784,17 +770,17 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
         for (int e = threadIdx.x; e < PKR * RS * 4; e += 256) {
             const int p = e & 3, r = (e >> 2) % PKR, tap = (e >> 2) / PKR;
             const int n = n0 + r, nt = n / GBN, nl = n - nt * GBN;
-            bf16x8 h[3];
+            bf16x8 h[NPL];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                hp_t x0, x1, x2;
-                q_split(tile[(r * 32 + p * 8 + c) * MAXTAP + tap], wscale, x0, x1, x2);
-                h[0][c] = x0; h[1][c] = x1; h[2][c] = x2;
+                hp_t x0, x1;
+                q_split(tile[(r * 32 + p * 8 + c) * MAXTAP + tap], wscale, x0, x1);
+                h[0][c] = x0; h[1][c] = x1;
             }
             const long qq = (long)nt * nchunks + slab * RS + tap;
             unsigned char *dst = wp + qq * GB_BUF + nl * 64 + ((p ^ ((nl >> 2) & 3)) << 4);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8 *>(dst + pl * GB_PLANE) = h[pl];
+            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<bf16x8 *>(dst + pl * GB_PLANE) = h[pl];
         }
     }
 }
@@ -821,19 +807,18 @@ __global__ __launch_bounds__(256) void split_nhwc_kernel(const float *x, int ldx
     const int rem = (int)(e - pix * (nslab * 4)), sl = rem >> 2, p = rem & 3;
     const float *src = x + pix * ldx + sl * 32 + p * 8;
     const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
-    bf16x8 h0, h1, h2;
+    bf16x8 h0, h1;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        hp_t x0, x1, x2;
-        q_split(v0[c], xscale, x0, x1, x2);
-        h0[c] = x0; h1[c] = x1; h2[c] = x2;
-        q_split(v1[c], xscale, x0, x1, x2);
-        h0[4 + c] = x0; h1[4 + c] = x1; h2[4 + c] = x2;
+        hp_t x0, x1;
+        q_split(v0[c], xscale, x0, x1);
+        h0[c] = x0; h1[c] = x1;
+        q_split(v1[c], xscale, x0, x1);
+        h0[4 + c] = x0; h1[4 + c] = x1;
     }
-    unsigned char *dst = xp + pix * (long)(nslab * 192) + sl * 192 + p * 16;
+    unsigned char *dst = xp + pix * (long)(nslab * SLAB) + sl * SLAB + p * 16;
     *reinterpret_cast<bf16x8 *>(dst) = h0;
     *reinterpret_cast<bf16x8 *>(dst + 64) = h1;
-    *reinterpret_cast<bf16x8 *>(dst + 128) = h2;
 }
 
 // max |x| of an NHWC tensor (rows of C floats at pitch ldx) -> one slot per workgroup of the record q: the pass in front of a
@@ -899,19 +884,18 @@ __global__ __launch_bounds__(256) void split_dact_nhwc_kernel(const float *x, in
     const float *src = x + pix * ldx + sl * 32 + p * 8, *zs = z + pix * ldz + sl * 32 + p * 8;
     const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
     const f32x4 z0 = *reinterpret_cast<const f32x4 *>(zs), z1 = *reinterpret_cast<const f32x4 *>(zs + 4);
-    bf16x8 h0, h1, h2;
+    bf16x8 h0, h1;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        hp_t x0, x1, x2;
-        q_split(z0[c] > 0.f ? v0[c] : v0[c] * slope, xscale, x0, x1, x2);
-        h0[c] = x0; h1[c] = x1; h2[c] = x2;
-        q_split(z1[c] > 0.f ? v1[c] : v1[c] * slope, xscale, x0, x1, x2);
-        h0[4 + c] = x0; h1[4 + c] = x1; h2[4 + c] = x2;
+        hp_t x0, x1;
+        q_split(z0[c] > 0.f ? v0[c] : v0[c] * slope, xscale, x0, x1);
+        h0[c] = x0; h1[c] = x1;
+        q_split(z1[c] > 0.f ? v1[c] : v1[c] * slope, xscale, x0, x1);
+        h0[4 + c] = x0; h1[4 + c] = x1;
     }
-    unsigned char *dst = xp + pix * (long)(nslab * 192) + sl * 192 + p * 16;
+    unsigned char *dst = xp + pix * (long)(nslab * SLAB) + sl * SLAB + p * 16;
     *reinterpret_cast<bf16x8 *>(dst) = h0;
     *reinterpret_cast<bf16x8 *>(dst + 64) = h1;
-    *reinterpret_cast<bf16x8 *>(dst + 128) = h2;
 }
 
 // planes -> fp32 NHWC (tests / debugging): the three planes add up to the fp32 value exactly
@@ -921,8 +905,8 @@ __global__ __launch_bounds__(256) void merge_planes_kernel(const unsigned char *
     if (e >= nelem) return;
     const long pix = e / C;
     const int c = (int)(e - pix * C), sl = c >> 5, k = c & 31;
-    const hp_t *src = reinterpret_cast<const hp_t *>(xp + pix * (long)((C / 32) * 192) + sl * 192);
-    x[pix * ldx + c] = (((float)src[k] + (float)src[32 + k]) + (float)src[64 + k]) * q_inv(q);
+    const hp_t *src = reinterpret_cast<const hp_t *>(xp + pix * (long)((C / 32) * SLAB) + sl * SLAB);
+    x[pix * ldx + c] = ((float)src[k] + (float)src[32 + k]) * q_inv(q);
 }
 
 // torch Conv2d weight [N][C][R][S] fp32 -> per chunk q = slab * R*S + tap the LDS image [plane][192 rows][64 B], piece p of
@@ -941,18 +925,18 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, unsign
     const int p = (int)(e & 3), n = (int)((e >> 2) % BN);
     const long q = e / (4 * BN);
     const int slab = (int)(q / RS), tap = (int)(q - (long)slab * RS);
-    bf16x8 h[3];
+    bf16x8 h[NPL];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int ch = slab * 32 + p * 8 + c;
         const float v = n < N ? (flip ? w[((size_t)ch * N + n) * RS + (RS - 1 - tap)] : w[((size_t)n * C + ch) * RS + tap]) : 0.f;
-        hp_t x0, x1, x2;
-        q_split(v, wscale, x0, x1, x2);
-        h[0][c] = x0; h[1][c] = x1; h[2][c] = x2;
+        hp_t x0, x1;
+        q_split(v, wscale, x0, x1);
+        h[0][c] = x0; h[1][c] = x1;
     }
     unsigned char *dst = wp + q * B_BUF + n * 64 + ((p ^ ((n >> 2) & 3)) << 4);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<bf16x8 *>(dst + pl * B_PLANE) = h[pl];
+    for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<bf16x8 *>(dst + pl * B_PLANE) = h[pl];
 }
 
 }   // namespace
@@ -960,7 +944,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, unsign
 namespace {
 constexpr int WQ_SLOTS = 64;                                        // workgroups of the weights' max pass
 constexpr size_t WQ_BYTES = (QREC_HDR + WQ_SLOTS) * sizeof(float);  // the record behind every packed weight image
-size_t planes_payload(long npix, int C) { return (size_t)npix * (C / 32) * 192; }
+size_t planes_payload(long npix, int C) { return (size_t)npix * (C / 32) * SLAB; }
 // one slot per producing workgroup: the smallest output tile of any producer is 64 pixels x 128 channels
 long planes_slots(long npix, int C) { return (long)cdivz((size_t)npix, 64) * cdiv(C, 128); }
 size_t w_image_bytes(int C, int R, int S) { return (size_t)(C / 32) * R * S * B_BUF; }
@@ -1109,8 +1093,8 @@ static int conv2d_bf16x6_launch(const void *xp, const float *xq, const void *wp,
         }
     static bool attr_done = false;      // > 64 KiB of dynamic LDS needs an explicit opt-in
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<128, STEM_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64, STEM_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
         attr_done = true;
     }
     const int M = B * OH * OW;
@@ -1119,9 +1103,9 @@ static int conv2d_bf16x6_launch(const void *xp, const float *xq, const void *wp,
     const int tile = stem_tuning(STEM_TUNE_BX6_TILE);
     const bool small = tile ? tile == 64 : cdiv(M, 128) < 256;
     if (small)
-        hipLaunchKernelGGL((conv_bf16x6_kernel<64, STEM_NP>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
+        hipLaunchKernelGGL((conv_bf16x6_kernel<64>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
     else
-        hipLaunchKernelGGL((conv_bf16x6_kernel<128, STEM_NP>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
+        hipLaunchKernelGGL((conv_bf16x6_kernel<128>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
     STEM_LAUNCH_CHECK("stem_conv2d_bf16x6_fwd");
     return 0;
 }
@@ -1224,8 +1208,8 @@ STEM_EXPORT int stem_conv2d_bf16x6_gen_fwd(const void *xp, const float *xq, int 
     STEM_CHECK_ARG(epi != GEN_EPI_DACT || (z && ldz >= N && ldz % 4 == 0 && ((uintptr_t)z & 15) == 0), "stem_conv2d_bf16x6_gen_fwd: DACT needs z (16-byte aligned rows)");
     const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
     STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_bf16x6_gen_fwd: empty output");
-    if (xpix == 0) xpix = (C / 32) * 192;
-    STEM_CHECK_ARG(xpix >= (C / 32) * 192 && xpix % 192 == 0, "stem_conv2d_bf16x6_gen_fwd: xpix must be a multiple of 192 bytes covering C channels");
+    if (xpix == 0) xpix = (C / 32) * SLAB;
+    STEM_CHECK_ARG(xpix >= (C / 32) * SLAB && xpix % SLAB == 0, "stem_conv2d_bf16x6_gen_fwd: xpix must be a multiple of %d bytes covering C channels", SLAB);
     const size_t xb = (size_t)B * H * W * xpix, wb = gen_image_bytes(N, C, R, S);
     const int M = B * OH * OW, ntn = cdiv(N, GBN), tiles = cdiv(M, GBM) * ntn, nchunks = (C / 32) * R * S;
     STEM_CHECK_ARG(xb < 0x7FFFFF00ull && wb < 0x7FFFFF00ull && (size_t)M * ntn * GBN * 4 < 0x7FFFFF00ull,
@@ -1254,11 +1238,11 @@ STEM_EXPORT int stem_conv2d_bf16x6_gen_fwd(const void *xp, const float *xq, int 
     }
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_gen_kernel<STEM_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
+        (void)hipFuncSetAttribute((const void *)conv_bf16x6_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
         attr_done = true;
     }
     const dim3 grid(cdiv(M, GBM), ntn, a.nsplit);
-        hipLaunchKernelGGL(conv_bf16x6_gen_kernel<STEM_NP>, grid, dim3(GNT), GLDS, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(conv_bf16x6_gen_kernel, grid, dim3(GNT), GLDS, (hipStream_t)stream, a);
     STEM_LAUNCH_CHECK("stem_conv2d_bf16x6_gen_fwd");
     return 0;
 }

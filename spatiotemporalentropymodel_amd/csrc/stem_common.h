@@ -51,22 +51,16 @@ int stem_tuning(int id);
 #define STEM_EXPER_ENV(name) (static_cast<const char *>(nullptr))
 #endif
 
-// ---- the 16-bit operand type of the split-operand kernels (conv_bf16x6 / wgrad_bf16x6 / c4gdn_bf16x6) ----------------------------
-// Default: two fp16 planes, three products (a = a0 + a1 to 2^-22 |a|, every product exact in the fp32 accumulator).  fp16 has
-// 5 exponent bits, so every planes tensor / packed weight image carries a power-of-two scale 2^e chosen by its producer from an
-// upper bound of its values (scale records below).  -DSTEM_BF16X6 builds the round-2 form instead: three bf16 planes, six
-// products, no scaling (e = 0 everywhere).
-#ifndef STEM_BF16X6
-#define STEM_F16X3 1
+// ---- the 16-bit operands of the split-operand kernels (conv_bf16x6 / wgrad_bf16x6 / c4gdn_bf16x6) -------------------------------
+// Every fp32 value a travels as TWO fp16 numbers a0 = rn(a * 2^e), a1 = rn(a * 2^e - a0): |a * 2^e - a0 - a1| <= 2^-22 |a| 2^e
+// (two 11-bit significands), and the three products a0.b0, a0.b1, a1.b0 are exact in the MFMA's fp32 accumulator input, so
+// three v_mfma_f32_32x32x16_f16 carry an fp32 product to ~2^-21 (the dropped a1.b1 is <= 2^-22 |a.b|).  fp16 has 5 exponent
+// bits, so every planes tensor / packed weight image carries a power-of-two scale 2^e chosen by its producer from an upper
+// bound of its values (scale records below); fp16 subnormals are kept by the MFMA (tools/debug/probe/f16_denorm.hip), the
+// absolute floor of a stored value is 2^-25 2^-e.
 typedef _Float16 hp_t;
-#define STEM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
-constexpr int STEM_NP = 3;
-#else
-typedef __bf16 hp_t;
-#define STEM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
-constexpr int STEM_NP = 6;
-#endif
 typedef hp_t hp8 __attribute__((ext_vector_type(8)));
+#define STEM_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 
 // Scale record of a planes tensor / packed weight image (device memory, behind the payload; include/stem_hip.h: stem_qrec):
 //   word 0: int nslots    word 1: float inv = 2^-e (the planes hold v * 2^e)    words 16 .. 16 + nslots: float max|v| per
@@ -86,16 +80,12 @@ __device__ inline void q_header(float *q, int n)
 // e with bound * 2^e in [2^14, 2^15): twice the room fp16 (max 65504) needs, so that bounds rounded in fp32 stay safe
 __device__ inline int q_exp(float bound)
 {
-#ifdef STEM_F16X3
     const unsigned b = __float_as_uint(bound) & 0x7FFFFFFFu;
     int eb = (int)(b >> 23) - 127;                 // floor(log2(bound)) of a normal number
     if (b == 0u || eb == 128) return 0;            // zero tensor / non-finite bound: nothing to protect
     if (eb < -126) eb = -126;
     const int e = 14 - eb;
     return e > 126 ? 126 : e;                      // eb <= 127, so e >= -113: q_pow2(+-e) stays a normal number
-#else
-    return 0;
-#endif
 }
 __device__ inline float q_pow2(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
 __device__ inline float wave_max(float v)
@@ -123,17 +113,11 @@ __device__ inline float q_amax(const float *q, float *red)
     for (int i = threadIdx.x; i < ns; i += blockDim.x) m = fmaxf(m, q[QREC_HDR + i]);
     return block_max(m, red);
 }
-// the two fp16 (three bf16) numbers whose sum is x * s
-__device__ inline void q_split(const float x, const float s, hp_t &h0, hp_t &h1, hp_t &h2)
+// the two fp16 numbers whose sum is x * s (s a power of two)
+__device__ inline void q_split(const float x, const float s, hp_t &h0, hp_t &h1)
 {
     const float xs = x * s;
     h0 = (hp_t)xs;
-    const float r1 = xs - (float)h0;               // exact
-    h1 = (hp_t)r1;
-#ifdef STEM_F16X3
-    h2 = (hp_t)0.f;
-#else
-    h2 = (hp_t)(r1 - (float)h1);
-#endif
+    h1 = (hp_t)(xs - (float)h0);                   // the subtraction is exact
 }
 #endif

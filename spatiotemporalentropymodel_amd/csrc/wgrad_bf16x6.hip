@@ -26,8 +26,9 @@ typedef short v4s __attribute__((ext_vector_type(4)));
 
 constexpr int TK = 128, TC = 128, NT = 256, PX = 16;      // output tile, threads, pixels per chunk (= one MFMA k-step)
 constexpr int PLANE = PX * 256;                            // 4096 B: 16 pixel rows x 128 channels of one plane
-constexpr int OP_BUF = 3 * PLANE;                          // one operand, one buffer
-constexpr int LDS_BYTES = 2 * 2 * OP_BUF;                  // 49152: two workgroups per CU (register-limited), 2 wavefronts per SIMD
+constexpr int NPL = 2, SLAB = NPL * 64;                    // planes per value; bytes per pixel and 32-channel slab
+constexpr int OP_BUF = NPL * PLANE;                        // one operand, one buffer
+constexpr int LDS_BYTES = 2 * 2 * OP_BUF;                  // 32768: two workgroups per CU (register-limited), 2 wavefronts per SIMD
 constexpr int OOR = 0x7FFFFF00;
 constexpr int MAXTAP = 25;
 
@@ -56,13 +57,12 @@ __device__ inline bf16x8 tr_frag(const unsigned char *base, int a0, int a1)
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int NP>       // products kept per fp32 product: 6 (default), 4 or 3 (measurement switches, two planes read)
 __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
 {
-    constexpr int PL = NP == 6 ? 3 : 2;
+    constexpr int PL = NPL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *As = smem;                        // [2][3][16 px][256 B]   dy
-    unsigned char *Bs = smem + 2 * OP_BUF;           // [2][3][16 px][256 B]   x (shifted by the tap)
+    unsigned char *Bs = smem + 2 * OP_BUF;           // [2][NPL][16 px][256 B]   x (shifted by the tap)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_c = (a.C + TC - 1) / TC;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
     const int srow = tid >> 4, sslab = (tid >> 2) & 3, spc = tid & 3;
     const int st0 = lds_off(srow, sslab * 4 + spc);
     const bool ka_ok = k0 / 32 + sslab < a.K / 32, cb_ok = c0 / 32 + sslab < a.C / 32;
-    const int a_col = (k0 / 32 + sslab) * 192 + spc * 16, b_col = (c0 / 32 + sslab) * 192 + spc * 16;
+    const int a_col = (k0 / 32 + sslab) * SLAB + spc * 16, b_col = (c0 / 32 + sslab) * SLAB + spc * 16;
     const int ohw = a.OH * a.OW;
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.xp), 0, a.xbytes, 0x00020000);
@@ -111,10 +111,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
             const hp8 p0 = __builtin_bit_cast(hp8, ra[0]), p1 = __builtin_bit_cast(hp8, ra[1]);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                if constexpr (PL == 3)
-                    bsum[c] += ((float)p0[c] + (float)p1[c]) + (float)__builtin_bit_cast(hp8, ra[PL - 1])[c];
-                else
-                    bsum[c] += (float)p0[c] + (float)p1[c];
+                bsum[c] += (float)p0[c] + (float)p1[c];
             }
         }
     };
@@ -157,11 +154,6 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if constexpr (NP == 6) {
-                    acc[i][j] = STEM_MFMA16(af[i][PL - 1], bf[j][0], acc[i][j]);
-                    acc[i][j] = STEM_MFMA16(af[i][0], bf[j][PL - 1], acc[i][j]);
-                }
-                if constexpr (NP >= 4) acc[i][j] = STEM_MFMA16(af[i][1], bf[j][1], acc[i][j]);
                 acc[i][j] = STEM_MFMA16(af[i][1], bf[j][0], acc[i][j]);
                 acc[i][j] = STEM_MFMA16(af[i][0], bf[j][1], acc[i][j]);
                 acc[i][j] = STEM_MFMA16(af[i][0], bf[j][0], acc[i][j]);
@@ -274,10 +266,10 @@ STEM_EXPORT int stem_conv2d_wgrad_bf16x6(const void *xp, const float *xq, int xp
                    "stem_conv2d_wgrad_bf16x6: C %% 32 == 0, K %% 32 == 0, R*S <= %d (C=%d K=%d R=%d S=%d)", MAXTAP, C, K, R, S);
     const int OH = H + 2 * pad - R + 1, OW = W + 2 * pad - S + 1;
     STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_wgrad_bf16x6: empty output");
-    if (xpix == 0) xpix = (C / 32) * 192;
-    if (dypix == 0) dypix = (K / 32) * 192;
-    STEM_CHECK_ARG(xpix >= (C / 32) * 192 && xpix % 192 == 0 && dypix >= (K / 32) * 192 && dypix % 192 == 0,
-                   "stem_conv2d_wgrad_bf16x6: pixel pitches must be multiples of 192 bytes covering the channels");
+    if (xpix == 0) xpix = (C / 32) * SLAB;
+    if (dypix == 0) dypix = (K / 32) * SLAB;
+    STEM_CHECK_ARG(xpix >= (C / 32) * SLAB && xpix % SLAB == 0 && dypix >= (K / 32) * SLAB && dypix % SLAB == 0,
+                   "stem_conv2d_wgrad_bf16x6: pixel pitches must be multiples of %d bytes covering the channels", SLAB);
     const size_t xb = (size_t)B * H * W * xpix, db = (size_t)B * OH * OW * dypix;
     STEM_CHECK_ARG(xb < 0x7FFFFF00ull && db < 0x7FFFFF00ull, "stem_conv2d_wgrad_bf16x6: operand views must stay below 2 GiB");
     STEM_CHECK_ARG(splits == plan_splits(B, OH, OW, C, K, R * S), "stem_conv2d_wgrad_bf16x6: splits must come from stem_wgrad_bf16x6_splits");
@@ -296,11 +288,11 @@ STEM_EXPORT int stem_conv2d_wgrad_bf16x6(const void *xp, const float *xq, int xp
         }
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)wgrad_bf16x6_kernel<STEM_NP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)wgrad_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_done = true;
     }
     const dim3 grid(cdiv(K, TK) * cdiv(C, TC), R * S, splits);
-        hipLaunchKernelGGL(wgrad_bf16x6_kernel<STEM_NP>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(wgrad_bf16x6_kernel, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
     STEM_LAUNCH_CHECK("stem_conv2d_wgrad_bf16x6");
     return 0;
 }

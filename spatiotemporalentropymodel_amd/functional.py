@@ -439,9 +439,13 @@ def conv2d_gdn_fwd(x, wp, bias, beta, gamma, K, R, S, stride, pad, inverse=False
     return out
 
 
+#: bytes per pixel and 32-channel slab of the planes layout: two fp16 planes of 32 values
+PLANES_SLAB_BYTES = 128
+
+
 class Bf16Planes:
     """An NHWC activation tensor pre-split for the 16-bit matrix cores (csrc/conv_bf16x6.hip): every fp32 value v is stored as two
-    fp16 numbers whose sum is v * 2^e (to 2^-22 |v|), [pixel][C/32][3][32] (plane 2 unused), followed in the same buffer by the
+    fp16 numbers whose sum is v * 2^e (to 2^-22 |v|), [pixel][C/32][2][32], followed in the same buffer by the
     tensor's scale record (2^-e and the measured max |v| per producing workgroup: include/stem_hip.h).  Only produced and
     consumed by the split-operand convolution kernels; `shape` is the logical [B,C,H,W].  `channels(c0, c1)` is a view of a
     32-aligned channel range (same storage, same pixel pitch, same record), accepted as an INPUT by conv2d_bf16x6_gen."""
@@ -449,13 +453,13 @@ class Bf16Planes:
 
     def __init__(self, data, shape, q_offset, pix_bytes=None, byte_offset=0):
         self.data, self.shape = data, tuple(shape)
-        self.pix_bytes = (self.shape[1] // 32) * 192 if pix_bytes is None else pix_bytes
+        self.pix_bytes = (self.shape[1] // 32) * PLANES_SLAB_BYTES if pix_bytes is None else pix_bytes
         self.byte_offset = byte_offset
         self.q_offset = q_offset
 
     @property
     def dense(self):
-        return self.byte_offset == 0 and self.pix_bytes == (self.shape[1] // 32) * 192
+        return self.byte_offset == 0 and self.pix_bytes == (self.shape[1] // 32) * PLANES_SLAB_BYTES
 
     def data_ptr(self):
         return self.data.data_ptr() + self.byte_offset
@@ -468,12 +472,12 @@ class Bf16Planes:
         if c0 % 32 or c1 % 32 or not 0 <= c0 < c1 <= self.shape[1]:
             raise ValueError(f"planes views are 32-channel aligned, got [{c0}, {c1}) of {self.shape[1]}")
         B, _, H, W = self.shape
-        return Bf16Planes(self.data, (B, c1 - c0, H, W), self.q_offset, self.pix_bytes, self.byte_offset + (c0 // 32) * 192)
+        return Bf16Planes(self.data, (B, c1 - c0, H, W), self.q_offset, self.pix_bytes, self.byte_offset + (c0 // 32) * PLANES_SLAB_BYTES)
 
     @staticmethod
     def nbytes(npix, Cc):
         """(payload bytes = offset of the scale record, total bytes) = stem_bf16x3_planes_qrec_offset / _planes_bytes"""
-        payload = npix * (Cc // 32) * 192
+        payload = npix * (Cc // 32) * PLANES_SLAB_BYTES
         return payload, payload + (((16 + ((npix + 63) // 64) * ((Cc + 127) // 128)) * 4 + 15) & ~15)
 
     @staticmethod
@@ -685,7 +689,7 @@ def _c4gdn_fits(x4, K, R, S, stride, pad, ld=None, planes=False):
     """operands of the bf16 first-layer kernel are addressed through 2 GiB buffer views"""
     B, H, W, _ = x4.shape
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
-    out_bytes = B * Ho * Wo * ((K // 32) * 192 if planes else (ld or K) * 4)
+    out_bytes = B * Ho * Wo * ((K // 32) * PLANES_SLAB_BYTES if planes else (ld or K) * 4)
     return B * H * W * 16 < 0x7FFFFF00 and out_bytes < 0x7FFF0000
 
 

@@ -581,8 +581,8 @@ def _bf16x6_shape_ok(m, in_shape):
 
 
 def _planes_fit(npix, channels):
-    """does a planes tensor of this size (6 bytes per element) stay inside one 2 GiB buffer view?"""
-    return npix * ((channels + 31) // 32) * 192 < 0x7FFFFF00
+    """does a planes tensor of this size (4 bytes per element) stay inside one 2 GiB buffer view?"""
+    return npix * ((channels + 31) // 32) * F.PLANES_SLAB_BYTES < 0x7FFFFF00
 
 
 def _bf16x6_gen_eligible(m, follows_gdn, in_shape=None):

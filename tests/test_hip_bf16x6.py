@@ -59,11 +59,11 @@ def test_split_is_a_scaled_fp16_pair(F, mag):
     ref = torch.from_numpy(x).contiguous(memory_format=torch.channels_last)
     err = (xp.merge().cpu().double() - ref.double()).abs()
     assert bool((err <= ref.double().abs() * 2.0 ** -22 + amax * 2.0 ** -39).all()), float(err.max())
-    payload = 3 * 5 * 7 * 2 * 192
-    raw = xp.data[:payload].view(torch.float16).view(3 * 5 * 7, 2, 3, 32).float().cpu()       # [pixel][slab][plane][32]
+    payload = 3 * 5 * 7 * 2 * 128
+    raw = xp.data[:payload].view(torch.float16).view(3 * 5 * 7, 2, 2, 32).float().cpu()       # [pixel][slab][plane][32]
     nhwc = torch.from_numpy(x).permute(0, 2, 3, 1).reshape(3 * 5 * 7, 2, 32)
     assert torch.equal(raw[:, :, 0], (nhwc / inv).to(torch.float16).float())             # round-to-nearest-even leading plane
-    assert bool(torch.isfinite(raw).all()) and float(raw[:, :, 0].abs().max()) <= 2.0 ** 15 and float(raw[:, :, 2].abs().max()) == 0.0
+    assert bool(torch.isfinite(raw).all()) and float(raw[:, :, 0].abs().max()) <= 2.0 ** 15
     with pytest.raises(ValueError):
         F.Bf16Planes.empty(1, 48, 4, 4, torch.device("cuda:0"))
 

@@ -418,10 +418,10 @@ def test_bf16_planes_views_and_engine_routing_table():
     payload, total = F.Bf16Planes.nbytes(2 * 4 * 4, 160)
     data = torch.zeros(total, dtype=torch.uint8)
     p = F.Bf16Planes(data, (2, 160, 4, 4), payload)
-    assert p.dense and p.pix_bytes == 5 * 192 and p.q_ptr() == data.data_ptr() + payload
+    assert p.dense and p.pix_bytes == 5 * 128 and p.q_ptr() == data.data_ptr() + payload
     v = p.channels(32, 128)
-    assert v.shape == (2, 96, 4, 4) and v.pix_bytes == p.pix_bytes and v.byte_offset == 192 and not v.dense
-    assert v.channels(32, 64).byte_offset == 2 * 192 and v.data is data
+    assert v.shape == (2, 96, 4, 4) and v.pix_bytes == p.pix_bytes and v.byte_offset == 128 and not v.dense
+    assert v.channels(32, 64).byte_offset == 2 * 128 and v.data is data
     assert v.q_ptr() == p.q_ptr()                             # a channel view shares the scale record of the whole tensor
     for bad in ((16, 80), (0, 200), (64, 64)):
         with pytest.raises(ValueError):
@@ -458,14 +458,14 @@ def test_bf16_planes_views_and_engine_routing_table():
 
 
 def test_bf16_chain_is_not_selected_when_planes_exceed_a_buffer_view():
-    """4 full-HD frames per call are fine for the fp32 kernels (1.6 GB activations) but their planes would be 2.4 GB: the chain
-    must not start (the kernels address operands through 2 GiB views); 3 frames fit."""
+    """6 full-HD frames per call: their planes (two fp16 numbers per value, 2.4 GB) exceed the 2 GiB views the kernels address
+    operands through: the chain must not start; 5 frames fit."""
     from spatiotemporalentropymodel_amd import layers as L
     from spatiotemporalentropymodel_amd.zoo import models
     conv1 = models["mbt2018"](quality=4).g_a[2]
-    assert L._bf16x6_shape_ok(conv1, (3, 192, 544, 960))
-    assert not L._bf16x6_shape_ok(conv1, (4, 192, 544, 960))
-    assert L._planes_fit(3 * 544 * 960, 192) and not L._planes_fit(4 * 544 * 960, 192)
+    assert L._bf16x6_shape_ok(conv1, (5, 192, 544, 960))
+    assert not L._bf16x6_shape_ok(conv1, (6, 192, 544, 960))
+    assert L._planes_fit(5 * 544 * 960, 192) and not L._planes_fit(6 * 544 * 960, 192)
     assert not L._bf16x6_shape_ok(conv1, (1, 192, 32, 32))          # too few output pixels for the 192-wide kernel
 
 
@@ -476,7 +476,7 @@ def test_planes_byte_count_matches_the_library():
     lib = _lib.hip()
     for npix, C in ((1, 32), (4096, 192), (65280, 1152), (7, 96), (64, 128), (65, 160), (16 * 128 * 128, 192)):
         payload, total = F.Bf16Planes.nbytes(npix, C)
-        assert lib.stem_bf16x3_planes_qrec_offset(npix, C) == payload == npix * (C // 32) * 192
+        assert lib.stem_bf16x3_planes_qrec_offset(npix, C) == payload == npix * (C // 32) * 128
         assert lib.stem_bf16x3_planes_bytes(npix, C) == total
         # the scale record: 16 header words + one slot per 64-pixel x 128-channel producer tile, 16-byte granules
         assert total - payload >= (16 + -(-npix // 64) * -(-C // 128)) * 4 and (total - payload) % 16 == 0
