@@ -36,12 +36,13 @@ BATCH, SIZE, FRAMES = 16, 256, 7
 # the 192-ch 5x5 stride-2 analysis conv g_a.2 (7.550 GF/frame) + the GDN contraction fused
 # into its epilogue (g_a.3, 0.302 GF/frame): one kernel launch per frame batch
 GA2_FLOP_PER_FRAME = 2 * 192 * 192 * 25 * 64 * 64 + 2 * 192 * 192 * 64 * 64
-GA2_CONV_FLOP_PER_FRAME = 2 * 192 * 192 * 25 * 64 * 64           # the convolution alone (the part that runs as 6 bf16 MFMAs per product)
+GA2_CONV_FLOP_PER_FRAME = 2 * 192 * 192 * 25 * 64 * 64           # the convolution alone (the part that runs as 3 fp16 MFMAs per product)
 GA0_FLOP_PER_FRAME = 2 * 192 * 3 * 25 * 128 * 128 + 2 * 192 * 192 * 128 * 128      # g_a.0 (3 -> 192, 5x5 s2) + fused GDN g_a.1
 # useful (algorithmic) flop of one bench step: 187.1 GF per septuplet (7 x g_a 11.966 GF + 6 P-frame steps of
 # 17.228 GF = STEM forward 6.418 + weight gradients 6.418 + input gradients 4.392), 16 septuplets per GPU
 USEFUL_FLOP_PER_STEP = 187.1e9 * BATCH
-PEAK_BF16_MFMA_TFLOPS = 2516.6       # same guide: v_mfma_f32_32x32x16_bf16, 1024 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz (dense)
+PEAK_F16_MFMA_TFLOPS = 2516.6        # same guide: v_mfma_f32_32x32x16_f16 (the fp16 form's cycles), 1024 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz (dense)
+F16_PRODUCTS = 3                     # fp16 MFMA products per fp32 product in the split-operand kernels (csrc/stem_common.h)
 
 
 def synthetic_septuplet(batch, size, seed, device):
@@ -234,8 +235,8 @@ def bench_roi(args):
     from spatiotemporalentropymodel_amd.optim import configure_optimizers
     from spatiotemporalentropymodel_amd.selfcheck import roi_gop_step
     _lib.hip()
-    if os.environ.get("STEM_BENCH_BX6_TILE"):                   # sweep aid: force the 192-column kernel's pixel tile (64 / 128)
-        _lib.check(_lib.hip().stem_tuning_set(b"bx6_tile", int(os.environ["STEM_BENCH_BX6_TILE"])))
+    if os.environ.get("STEM_BENCH_FX3_TILE"):                   # sweep aid: force the 192-column kernel's pixel tile (64 / 128)
+        _lib.check(_lib.hip().stem_tuning_set(b"fx3_tile", int(os.environ["STEM_BENCH_FX3_TILE"])))
     rank, world, local = D.init_from_env()
     assert world == args.gpus and torch.cuda.is_available()
     dev = torch.device("cuda", local)
@@ -271,10 +272,10 @@ def bench_roi(args):
         return
     kern_ms = float(np.mean([x.elapsed_time(y) for x, y in probe]))
     flop = 2.0 * 192 * 160 * 9 * SIZE * SIZE * B
-    bf16_layers = os.environ.get("STEM_LAYERS_BF16X6", "1") != "0"
-    # the probed layer runs on the 192-column bf16 kernel since round 3 (six bf16 MFMAs per fp32 product: executed = 6 x algorithmic,
-    # against the bf16 peak); with STEM_LAYERS_BF16X6=0 on the fp32-MFMA kernel against its own peak
-    work, peak = (6 * flop, PEAK_BF16_MFMA_TFLOPS) if bf16_layers else (flop, PEAK_FP32_MFMA_TFLOPS)
+    f16_layers = os.environ.get("STEM_LAYERS_F16X3", "1") != "0"
+    # the probed layer runs on the 192-column split-operand kernel (three fp16 MFMAs per fp32 product: executed = 3 x algorithmic,
+    # against the fp16 peak); with STEM_LAYERS_F16X3=0 on the fp32-MFMA kernel against its own peak
+    work, peak = (F16_PRODUCTS * flop, PEAK_F16_MFMA_TFLOPS) if f16_layers else (flop, PEAK_FP32_MFMA_TFLOPS)
     achieved = work / (kern_ms * 1e-3) / 1e12
     _emit({
         "metric": "frames/s", "value": FRAMES * B * world * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -283,10 +284,10 @@ def bench_roi(args):
         "config": {"workload": "configs[4]: variable-rate stem_roi_i + stem_roi GOP training iteration (I + 6 P frames 256x256, BPTT across the "
                                "GOP, clip after every frame, one step of 4 Adam optimisers), 4 lambda points (quality 0.30/0.45/0.55/0.70) in one batch",
                    "per_gpu_batch": B, "global_batch": B * world, "frames_per_step": FRAMES * B * world, "parallelism": f"dp{world}",
-                   "stride1_convolutions": "bf16 matrix cores, 6 products per fp32 product (layers.Conv2dFunction)" if bf16_layers else "fp32 MFMA",
+                   "stride1_convolutions": "fp16 matrix cores, two fp16 planes per operand, 3 products per fp32 product (layers.Conv2dFunction)" if f16_layers else "fp32 MFMA",
                    "final_loss": float(log[-1][0]["loss"].detach())},
         "roofline": {"bound": "mfma",
-                     "kernel": ("conv_bf16x6_kernel<128,6> with activation epilogue" if bf16_layers else "igemm") +
+                     "kernel": ("conv_f16x3_kernel<128> with activation epilogue" if f16_layers else "igemm") +
                                " = conv3x3 192->160 at 256x256 (stem_roi.qmap_feature_ga1.2, forward), B=%d" % B,
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                      "flop_per_launch": work, "useful_flop_per_launch": flop, "useful_tflops": flop / (kern_ms * 1e-3) / 1e12,
@@ -399,8 +400,8 @@ def main():
     from spatiotemporalentropymodel_amd import _lib
     from spatiotemporalentropymodel_amd import distributed as D
     _lib.hip()                                    # no HIP library -> fail loudly, nothing to measure
-    if os.environ.get("STEM_BENCH_BX6_TILE"):     # sweep aid: force the 192-column kernel's pixel tile (64 / 128)
-        _lib.check(_lib.hip().stem_tuning_set(b"bx6_tile", int(os.environ["STEM_BENCH_BX6_TILE"])))
+    if os.environ.get("STEM_BENCH_FX3_TILE"):     # sweep aid: force the 192-column kernel's pixel tile (64 / 128)
+        _lib.check(_lib.hip().stem_tuning_set(b"fx3_tile", int(os.environ["STEM_BENCH_FX3_TILE"])))
     rank, world, local = D.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -433,7 +434,7 @@ def main():
     probe, probe0 = [], []
     if os.environ.get("STEM_BENCH_NOPROBE", "0") != "1":
         imodel.g_a.probe = {2: probe, 0: probe0}
-    bf16_chain = os.environ.get("STEM_BF16X6", "1") != "0"
+    f16_chain = os.environ.get("STEM_F16X3", "1") != "0"
 
     # --graph (single device): the P-frame step (zero_grad .. aux Adam, ~160 launches) is replayed from ONE hipGraph per
     # step (graphs.GraphedPFrameStep); getY stays eager so that the HIP-event probe can bracket its dominant kernel.  Data
@@ -524,16 +525,16 @@ def main():
     flop = GA2_FLOP_PER_FRAME * BATCH
     tfile = os.path.join(REPO, "profiles", "hbm_traffic.json")
     tj = json.load(open(tfile)) if os.path.exists(tfile) else {}
-    # g_a.0 + GDN g_a.1 (csrc/c4gdn_bf16x6.hip since round 3; igemm.hip's fp32-MFMA kernel with STEM_C4GDN_BF16X6=0), measured the same
+    # g_a.0 + GDN g_a.1 (csrc/c4gdn_f16x3.hip since round 3; igemm.hip's fp32-MFMA kernel with STEM_C4GDN_F16X3=0), measured the same
     # way; the probe brackets the NCHW -> NHWC4 layout kernel (~20 us) and the convolution kernel
     flop0 = GA0_FLOP_PER_FRAME * BATCH
-    c4_bf16 = os.environ.get("STEM_C4GDN_BF16X6", "1") != "0" and bf16_chain
-    exec0 = 6 * (2 * 192 * 128 * 128 * 128 + 2 * 192 * 192 * 128 * 128) * BATCH      # conv K padded 75 -> 128 slots, GDN K = 192; x6 products
-    peak0 = PEAK_BF16_MFMA_TFLOPS if c4_bf16 else PEAK_FP32_MFMA_TFLOPS
-    work0 = exec0 if c4_bf16 else flop0
+    c4_f16 = os.environ.get("STEM_C4GDN_F16X3", "1") != "0" and f16_chain
+    exec0 = F16_PRODUCTS * (2 * 192 * 128 * 128 * 128 + 2 * 192 * 192 * 128 * 128) * BATCH      # conv K padded 75 -> 128 slots, GDN K = 192; x3 products
+    peak0 = PEAK_F16_MFMA_TFLOPS if c4_f16 else PEAK_FP32_MFMA_TFLOPS
+    work0 = exec0 if c4_f16 else flop0
     first_line = {"bound": "mfma",
-                  "kernel": ("c4gdn_bf16x6_kernel<6> = g_a.0 conv (3->192, 5x5 s2, 256^2->128^2, B=16) + GDN g_a.1 in one kernel: transposed "
-                             "contractions, squared outputs handed accumulator -> B operand in registers, 6 bf16 MFMAs per fp32 product") if c4_bf16 else
+                  "kernel": ("c4gdn_f16x3_kernel<6> = g_a.0 conv (3->192, 5x5 s2, 256^2->128^2, B=16) + GDN g_a.1 in one kernel: transposed "
+                             "contractions, squared outputs handed accumulator -> B operand in registers, 3 fp16 MFMAs per fp32 product") if c4_f16 else
                             "igemm_kernel<128,192,32,96,C4,FUSE> = g_a.0 + fused GDN g_a.1 (v_mfma_f32_32x32x2_f32)",
                   "achieved": work0 / (kern0_ms_overlap * 1e-3) / 1e12, "peak": peak0, "unit": "TFLOP/s",
                   "frac": work0 / (kern0_ms_overlap * 1e-3) / 1e12 / peak0, "flop_per_launch": work0,
@@ -542,21 +543,21 @@ def main():
                                "launches_timed": len(probe0)},
                   "useful_flop_per_launch": flop0, "useful_tflops": flop0 / (kern0_ms_overlap * 1e-3) / 1e12,
                   "useful_tflops_isolated": flop0 / (kern0_ms * 1e-3) / 1e12, "traffic": tj.get("g_a0_c4gdn_bytes_per_launch")}
-    if bf16_chain:
-        # Dominant kernel: g_a.2 + GDN on the bf16 matrix cores.  Every fp32 product is SIX bf16 MFMA products (conv_bf16x6.hip), so
-        # the matrix pipe executes 6x the convolution's algorithmic flop; `achieved` / `frac` are that executed bf16 rate against
-        # the dense bf16 peak (never mixed into an fp32 fraction), taken on the launches INSIDE the timed region (the
+    if f16_chain:
+        # Dominant kernel: g_a.2 + GDN on the fp16 matrix cores.  Every fp32 product is THREE fp16 MFMA products (conv_f16x3.hip), so
+        # the matrix pipe executes 3x the convolution's algorithmic flop; `achieved` / `frac` are that executed fp16 rate against
+        # the dense fp16 peak (never mixed into an fp32 fraction), taken on the launches INSIDE the timed region (the
         # headline is the in-region figure); the same launches alone on the chip are under "isolated", the algorithmic
         # (fp32-equivalent, "useful") rate next to both.
-        executed = 6 * GA2_CONV_FLOP_PER_FRAME * BATCH
+        executed = F16_PRODUCTS * GA2_CONV_FLOP_PER_FRAME * BATCH
         in_ms = kern_ms_overlap if prefetch is not None else kern_ms
-        roof = {"bound": "mfma", "kernel": "conv_bf16x6_kernel<128,6> = g_a.2 conv (192->192, 5x5 s2, 128^2->64^2, B=16) + fused GDN g_a.3: operands "
-                                           "pre-split into 3 bf16 planes, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulate",
-                "achieved": executed / (in_ms * 1e-3) / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": executed / (in_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-                "flop_per_launch": executed, "flop_definition": "executed bf16 MFMA flop = 6 x algorithmic conv flop (the fused GDN's 4.8 GF of fp32 MFMA not counted)",
+        roof = {"bound": "mfma", "kernel": "conv_f16x3_kernel<128> = g_a.2 conv (192->192, 5x5 s2, 128^2->64^2, B=16) + fused GDN g_a.3: operands "
+                                           "pre-split into 2 scaled fp16 planes, 3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate",
+                "achieved": executed / (in_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": executed / (in_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                "flop_per_launch": executed, "flop_definition": "executed fp16 MFMA flop = 3 x algorithmic conv flop (the fused GDN's 4.8 GF of fp32 MFMA not counted)",
                 "avg_launch_ms": in_ms, "launches_timed": n_overlap if prefetch is not None else len(probe),
-                "isolated": {"achieved": executed / (kern_ms * 1e-3) / 1e12, "frac": executed / (kern_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                "isolated": {"achieved": executed / (kern_ms * 1e-3) / 1e12, "frac": executed / (kern_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
                              "avg_launch_ms": kern_ms, "launches_timed": len(probe)},
                 "useful_flop_per_launch": flop, "useful_tflops": flop / (in_ms * 1e-3) / 1e12, "useful_tflops_isolated": flop / (kern_ms * 1e-3) / 1e12,
                 "useful_isolated_vs_fp32_mfma_peak": flop / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
@@ -564,11 +565,11 @@ def main():
                                 "a P-frame step (HIP events on the launching stream); isolated: the same launches (same frames, weights) repeated 3 x 7 "
                                 "times right after the timed region with the chip to themselves") if prefetch is not None else
                                "the launches of the timed region run alone (latents first): in-region = isolated",
-                "clock_note": "power-bound: GRBM_GUI_ACTIVE / duration = 1.54 GHz under this kernel (2.4 GHz nominal), matrix pipe busy 62 % of "
-                              "those cycles (profiles/r02_pmc_bf16x6_*.csv); the guide's sustained bf16 rate on random data is ~1250 TFLOP/s",
-                "traffic": tj.get("g_a2_bf16x6_bytes_per_launch"),
+                "clock_note": "counters of this kernel: profiles/r03_pmc_f16x3_*.csv (DESIGN.md 7); the guide's sustained 16-bit MFMA rate on "
+                              "random data is ~1250 TFLOP/s (power-limited clock)",
+                "traffic": tj.get("g_a2_f16x3_bytes_per_launch"),
                 "traffic_source": "profiles/hbm_traffic.json: separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE) over "
-                                  "tools/debug/bf16x6_prof.py planes, NOT re-measured in this run"}
+                                  "tools/debug/f16x3_prof.py planes, NOT re-measured in this run"}
     else:
         achieved = flop / (kern_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "igemm_kernel<128,192,32,96,FUSE> = g_a.2 conv (192->192, 5x5 s2, 128^2->64^2, B=16) + fused GDN g_a.3",
@@ -586,7 +587,7 @@ def main():
                    "p_frame_steps_per_step": FRAMES - 1, "parallelism": f"dp{world}", "final_loss_bpp": loss,
                    "latents": "getY of frame t + 1 on a second stream during P-frame step t (trainer.LatentPrefetcher)" if prefetch is not None
                               else "getY of all 7 frames before the P-frame steps",
-                   "analysis_transform": "bf16 matrix cores, 6 products per fp32 product (conv_bf16x6.hip)" if bf16_chain else "fp32 MFMA",
+                   "analysis_transform": "fp16 matrix cores, two fp16 planes per operand, 3 products per fp32 product (conv_f16x3.hip)" if f16_chain else "fp32 MFMA",
                    "stream_priorities": os.environ.get("STEM_STREAM_PRIO", ""),
                    "launch": "hipGraph replay per P-frame step" if use_graph else
                              ("explicit fused schedule (trainer.FusedPFrameStep)" if fused_step is not None else "generic nn.Module / autograd route")},

@@ -33,8 +33,8 @@ const char *stem_last_error(void);
 int stem_abi_version(void);
 
 /* Plan selectors for tests and sweep tools: force a tile shape / split factor that the library would otherwise choose
- * ("bx6_tile": 0 automatic | 64 | 128 pixel workgroups of stem_conv2d_bf16x6_fwd; "bx6_split" / "wg6_split": split factor
- * of stem_conv2d_bf16x6_gen_fwd / stem_conv2d_wgrad_bf16x6, 0 = the planner's).  Every setting computes the same
+ * ("fx3_tile": 0 automatic | 64 | 128 pixel workgroups of stem_conv2d_f16x3_fwd; "fx3_split" / "wg3_split": split factor
+ * of stem_conv2d_f16x3_gen_fwd / stem_conv2d_wgrad_f16x3, 0 = the planner's).  Every setting computes the same
  * contraction (summation order aside); process-wide; not for concurrent use with launches.  There is no reference
  * counterpart (torch picks its kernels internally).  Nothing in the library reads the environment to change results:
  * reduced-precision / ablated variants exist only in builds with -DSTEM_EXPERIMENTS, which
@@ -200,7 +200,7 @@ int stem_qmap_render(const double *params, float *out, int B, int crop, float in
 /* ---- layout ------------------------------------------------------------ */
 int stem_nchw_to_nhwc(const float *x, float *y, int ldy, int B, int C, int H, int W, void *stream);
 int stem_nhwc_to_nchw(const float *x, int ldx, float *y, int B, int C, int H, int W, int clamp01, void *stream);
-/* q (optional): scale record of the image for stem_conv2d_c4_gdn_bf16x6, stem_nhwc4_qrec_floats(B, H, W) floats */
+/* q (optional): scale record of the image for stem_conv2d_c4_gdn_f16x3, stem_nhwc4_qrec_floats(B, H, W) floats */
 size_t stem_nhwc4_qrec_floats(int B, int H, int W);
 int stem_nchw3_to_nhwc4(const float *x, float *y, int B, int H, int W, float *q, void *stream);
 /* dst[p][c] = src[p][c] for c < C with independent pixel pitches: writes a tensor into a channel slice
@@ -365,49 +365,49 @@ int stem_ar_decode_batch_pipelined(const float *w_ctx, int ld_ctx, const float *
                                    const int32_t *cdfs, int ncdf, int cdf_stride, const int32_t *sizes, const int32_t *offsets,
                                    void *stream);
 
-/* ---- fp32-accurate convolution on the 16-bit matrix cores (csrc/conv_bf16x6.hip, wgrad_bf16x6.hip, c4gdn_bf16x6.hip) --------
+/* ---- fp32-accurate convolution on the 16-bit matrix cores (csrc/conv_f16x3.hip, wgrad_f16x3.hip, c4gdn_f16x3.hip) --------
  * Replaces the fp32 convolutions of the reference on this path (compressai/models/priors.py:613-621 under no_grad in
  * stem/trainSTEM.py:128,171; spatiotemporalpriors.py:814-838 with torch autograd).  Every fp32 operand a is stored as two fp16
  * numbers a0 = rn(a * 2^e), a1 = rn(a * 2^e - a0) (|a * 2^e - a0 - a1| <= 2^-22 |a| 2^e); the three fp16 products a0.b0, a0.b1,
- * a1.b0 are exact in the fp32 accumulator and carry the fp32 product to 2^-21; accumulation is fp32.  (-DSTEM_BF16X6 builds the
- * round-2 form: three bf16 planes, six products, e = 0.)
- * "planes" layout of an NHWC tensor with C % 32 == 0: [pixel][C/32][3][32] 16-bit (192 B per pixel and 32-channel slab; plane 2
- * is unused in the fp16 form), followed by the tensor's SCALE RECORD at byte stem_bf16x3_planes_qrec_offset():
+ * a1.b0 are exact in the fp32 accumulator and carry the fp32 product to 2^-21; accumulation is fp32.  (Round 2 used three
+ * bf16 planes and six products: no scaling, twice the matrix instructions.)
+ * "planes" layout of an NHWC tensor with C % 32 == 0: [pixel][C/32][2][32] fp16 (128 B per pixel and 32-channel slab),
+ * followed by the tensor's SCALE RECORD at byte stem_f16x2_planes_qrec_offset():
  *     int nslots; float inv = 2^-e; 14 reserved words; float max_abs[nslots]   (one slot per producing workgroup)
  * The record is written by whatever kernel writes the planes (plain stores, nothing to initialise): a split takes e from the
  * measured maximum of its input, a convolution from the bound K * max|x| * max|w| + max|bias| and records the measured
  * maximum of its output for the next consumer.  Records travel as explicit pointers (`xq`, `yq`) because channel views of a
  * planes tensor share the record of the whole tensor.  Packed weight images carry their record behind the image
- * (stem_bf16x3_conv_weight*_bytes include it).  Operands must satisfy K * max|x| * max|w| < 3e38.                          */
-size_t stem_bf16x3_planes_bytes(long npix, int C);        /* payload + scale record */
-size_t stem_bf16x3_planes_qrec_offset(long npix, int C);  /* = payload bytes */
-size_t stem_bf16x3_conv_weight_bytes(int C, int R, int S);
+ * (stem_f16x2_conv_weight*_bytes include it).  Operands must satisfy K * max|x| * max|w| < 3e38.                          */
+size_t stem_f16x2_planes_bytes(long npix, int C);        /* payload + scale record */
+size_t stem_f16x2_planes_qrec_offset(long npix, int C);  /* = payload bytes */
+size_t stem_f16x2_conv_weight_bytes(int C, int R, int S);
 /* max |x| of an NHWC fp32 tensor into the slots of record q (at most max_slots of them, <= 1024) */
 int stem_amax_nhwc(const float *x, int ldx, long npix, int C, float *q, long max_slots, void *stream);
 /* src_q: a record whose slots already hold max |x| (written by the kernel that produced x); null = measure here first */
-int stem_bf16x3_split_nhwc(const float *x, int ldx, void *xp, float *xq, const float *src_q, long npix, int C, void *stream);
-int stem_bf16x3_merge_nhwc(const void *xp, const float *xq, float *x, int ldx, long npix, int C, void *stream);
+int stem_f16x2_split_nhwc(const float *x, int ldx, void *xp, float *xq, const float *src_q, long npix, int C, void *stream);
+int stem_f16x2_merge_nhwc(const void *xp, const float *xq, float *x, int ldx, long npix, int C, void *stream);
 /* planes of x * (z > 0 ? 1 : slope): the gradient entering a convolution whose output z went through leaky_relu(., slope)
  * (what autograd computes as LeakyReluBackward before ConvolutionBackward, stem_roi.py's conv + LeakyReLU pairs), split in
  * the same pass for the input-gradient / weight-gradient kernels */
-int stem_bf16x3_split_dact_nhwc(const float *x, int ldx, const float *z, int ldz, float slope, void *xp, float *xq, const float *src_q,
+int stem_f16x2_split_dact_nhwc(const float *x, int ldx, const float *z, int ldz, float slope, void *xp, float *xq, const float *src_q,
                                 long npix, int C, void *stream);
 /* w: the torch Conv2d weight [N][C][R][S] (NOT one of the stem_pack_* layouts); N <= 192, R*S <= 25 */
-int stem_bf16x3_pack_conv_weight(const float *w, void *wp, int N, int C, int R, int S, void *stream);
+int stem_f16x2_pack_conv_weight(const float *w, void *wp, int N, int C, int R, int S, void *stream);
 /* y = conv(x) + bias, followed by GDN when beta/gamma are given (gdn.py:52-67; stored parameters, reparametrised on the fly).
  * Output as fp32 NHWC (y, ldy) and / or as planes (yp, with its record yq); either may be null.  yq without yp: only the
- * measured maximum of y is recorded (for a later stem_bf16x3_split_nhwc(..., src_q = yq)). */
-int stem_conv2d_bf16x6_fwd(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const float *gamma,
+ * measured maximum of y is recorded (for a later stem_f16x2_split_nhwc(..., src_q = yq)). */
+int stem_conv2d_f16x3_fwd(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const float *gamma,
                            float beta_min, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R, int S,
                            int stride, int pad, void *stream);
 /* the same kernel for the conv + LeakyReLU / ReLU pairs of the layer-wise models at large pixel counts (stem_roi.py:520-608,
- * stem_utils.py:24-63): act = 1 applies leaky_relu(., slope) after the bias.  stem_bf16x3_pack_conv_weight_flip packs the
+ * stem_utils.py:24-63): act = 1 applies leaky_relu(., slope) after the bias.  stem_f16x2_pack_conv_weight_flip packs the
  * operand of the INPUT GRADIENT of a stride-1 convolution with torch weight w[C][N][R][S] (N = its input channels <= 192):
- * that gradient is stem_conv2d_bf16x6_fwd_act(dy planes, flipped pack, no bias) with the same padding.                      */
-int stem_conv2d_bf16x6_fwd_act(const void *xp, const float *xq, const void *wp, const float *bias, int act, float slope, float *y, int ldy,
+ * that gradient is stem_conv2d_f16x3_fwd_act(dy planes, flipped pack, no bias) with the same padding.                      */
+int stem_conv2d_f16x3_fwd_act(const void *xp, const float *xq, const void *wp, const float *bias, int act, float slope, float *y, int ldy,
                                void *yp, float *yq, int B, int H, int W, int C, int N, int R, int S, int stride, int pad, void *stream);
-int stem_bf16x3_pack_conv_weight_flip(const float *w, void *wp, int N, int C, int R, int S, void *stream);
-/* First analysis layer + its GDN as ONE kernel (csrc/c4gdn_bf16x6.hip): replaces `self.g_a[0:2]` = conv(3, N) ; GDN(N) of
+int stem_f16x2_pack_conv_weight_flip(const float *w, void *wp, int N, int C, int R, int S, void *stream);
+/* First analysis layer + its GDN as ONE kernel (csrc/c4gdn_f16x3.hip): replaces `self.g_a[0:2]` = conv(3, N) ; GDN(N) of
  * compressai/models/priors.py:421-423 (gdn.py:52-67) under no_grad (stem/trainSTEM.py:128,171).  N = 64, 128 or 192
  * (stem_c4gdn_supported), R*S <= 25.  Both contractions run on the 16-bit matrix cores with fp32-class products and fp32
  * accumulation; the squared conv outputs go from the accumulators into the GDN contraction as registers.  stem_c4gdn_pack
@@ -417,41 +417,41 @@ int stem_bf16x3_pack_conv_weight_flip(const float *w, void *wp, int N, int C, in
 int stem_c4gdn_supported(int N, int R, int S);
 size_t stem_c4gdn_stream_bytes(int N, int R, int S);
 int stem_c4gdn_pack(const float *wp_c4, const float *gamma, void *astream, int N, int R, int S, void *stream);
-int stem_conv2d_c4_gdn_bf16x6(const float *x4, const float *xq, const void *astream, const float *bias, const float *beta, float beta_min,
+int stem_conv2d_c4_gdn_f16x3(const float *x4, const float *xq, const void *astream, const float *bias, const float *beta, float beta_min,
                               float *y, int ldy, void *yp, float *yq, int B, int H, int W, int N, int R, int S, int stride, int pad,
                               void *stream);
 
-/* General variant of stem_conv2d_bf16x6_fwd for the small-M layers of the STEM network at training time: any N (tiles of 128
+/* General variant of stem_conv2d_f16x3_fwd for the small-M layers of the STEM network at training time: any N (tiles of 128
  * output channels), split-K with an in-kernel deterministic reduction, epilogue epi = 0 bias | 1 bias + leaky ReLU(slope) |
  * 2 times the leaky ReLU derivative selected by z (the input-gradient of a convolution whose input was activated:
- * torch autograd of spatiotemporalpriors.py:814-838).  Weights: stem_bf16x3_pack_conv_weight_gen of the torch weight
+ * torch autograd of spatiotemporalpriors.py:814-838).  Weights: stem_f16x2_pack_conv_weight_gen of the torch weight
  * [K][C][R][S]; flip = 1 packs the operand of the input-gradient of a stride-1 convolution (then N = C, and the planes input is
- * dy with K channels).  ws: stem_conv2d_bf16x6_gen_workspace_bytes bytes whose first 64 KiB are zero before the first use
+ * dy with K channels).  ws: stem_conv2d_f16x3_gen_workspace_bytes bytes whose first 64 KiB are zero before the first use
  * (the kernel leaves them zero -- the same contract as stem_conv_workspace_bytes, the buffer may be shared); null = unsplit.  Results do not depend on which workgroup arrives last. */
-size_t stem_bf16x3_conv_weight_gen_bytes(int N, int C, int R, int S);
-int stem_bf16x3_pack_conv_weight_gen(const float *w, void *wp, int N, int C, int R, int S, int flip, void *stream);
+size_t stem_f16x2_conv_weight_gen_bytes(int N, int C, int R, int S);
+int stem_f16x2_pack_conv_weight_gen(const float *w, void *wp, int N, int C, int R, int S, int flip, void *stream);
 /* all layers of a training model with two launches (maxima, images: their weights change every optimiser step); N, C as in
  * the single call, i.e. already swapped for flip = 1 */
 typedef struct {
     const void *w;
     void *wp;
     int N, C, R, S, flip, reserved;
-} stem_bf16x3_pack_desc;
-int stem_bf16x3_pack_conv_weights_multi(const stem_bf16x3_pack_desc *descs, int n, void *stream);
-size_t stem_conv2d_bf16x6_gen_workspace_bytes(int B, int H, int W, int C, int N, int R, int S, int stride, int pad);
-/* xpix: bytes per pixel of the planes buffer xp points into (0 = dense, (C/32) * 192); xp may point at a 32-channel-aligned
+} stem_f16x2_pack_desc;
+int stem_f16x2_pack_conv_weights_multi(const stem_f16x2_pack_desc *descs, int n, void *stream);
+size_t stem_conv2d_f16x3_gen_workspace_bytes(int B, int H, int W, int C, int N, int R, int S, int stride, int pad);
+/* xpix: bytes per pixel of the planes buffer xp points into (0 = dense, (C/32) * 128); xp may point at a 32-channel-aligned
  * slab of a wider planes tensor (xq: the record of that whole tensor) */
-int stem_conv2d_bf16x6_gen_fwd(const void *xp, const float *xq, int xpix, const void *wp, const float *bias, int epi, float slope,
+int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int xpix, const void *wp, const float *bias, int epi, float slope,
                                const float *z, int ldz, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R,
                                int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream);
 
-/* Weight gradient of a stride-1 nn.Conv2d on the 16-bit matrix cores (csrc/wgrad_bf16x6.hip): x and dy as planes with their
+/* Weight gradient of a stride-1 nn.Conv2d on the 16-bit matrix cores (csrc/wgrad_f16x3.hip): x and dy as planes with their
  * records (pitches in bytes per pixel, 0 = dense; 32-aligned channel views allowed), result as `splits` slabs [R*S][K][C] like
- * stem_conv2d_wgrad (sum / transpose with stem_unpack_wgrads_multi).  splits = stem_wgrad_bf16x6_splits(...); dwp holds
+ * stem_conv2d_wgrad (sum / transpose with stem_unpack_wgrads_multi).  splits = stem_wgrad_f16x3_splits(...); dwp holds
  * splits*R*S*K*C floats.  The bias gradient (column sums of the fp32 dy) is stem_bias_grad. */
-int stem_wgrad_bf16x6_splits(int B, int H, int W, int C, int K, int R, int S, int pad);
+int stem_wgrad_f16x3_splits(int B, int H, int W, int C, int K, int R, int S, int pad);
 /* bias_part (optional, splits * K floats): per-split column sums of dy, to be finished by stem_bias_grad_final */
-int stem_conv2d_wgrad_bf16x6(const void *xp, const float *xq, int xpix, const void *dyp, const float *dyq, int dypix, float *dwp,
+int stem_conv2d_wgrad_f16x3(const void *xp, const float *xq, int xpix, const void *dyp, const float *dyq, int dypix, float *dwp,
                              float *bias_part, int B, int H, int W, int C, int K, int R, int S, int pad, int splits, void *stream);
 int stem_bias_grad_final(const float *part, int K, int parts, float *db, int accumulate, void *stream);
 size_t stem_bias_grad_scratch_elems(long npix, int K);

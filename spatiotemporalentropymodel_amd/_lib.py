@@ -88,31 +88,31 @@ _HIP_SIG = {
     "stem_gemv3_decode": [vp, ci, vp, vp, ci, ci, vp, ci, ci, vp, ci, ci, vp, ci, ci, cf, vp, vp, vp, ci, ci, vp, ci, cf, vp, vp],
     "stem_ar_decode_image": [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf,
                              vp, vp, vp, vp, vp, ci, ci, vp, vp, vp],
-    "stem_bf16x3_planes_bytes": [C.c_long, ci],
-    "stem_bf16x3_conv_weight_bytes": [ci, ci, ci],
-    "stem_bf16x3_planes_qrec_offset": [C.c_long, ci],
+    "stem_f16x2_planes_bytes": [C.c_long, ci],
+    "stem_f16x2_conv_weight_bytes": [ci, ci, ci],
+    "stem_f16x2_planes_qrec_offset": [C.c_long, ci],
     "stem_amax_nhwc": [vp, ci, C.c_long, ci, vp, C.c_long, vp],
-    "stem_bf16x3_split_nhwc": [vp, ci, vp, vp, vp, C.c_long, ci, vp],
-    "stem_bf16x3_merge_nhwc": [vp, vp, vp, ci, C.c_long, ci, vp],
-    "stem_bf16x3_split_dact_nhwc": [vp, ci, vp, ci, cf, vp, vp, vp, C.c_long, ci, vp],
-    "stem_bf16x3_pack_conv_weight": [vp, vp, ci, ci, ci, ci, vp],
-    "stem_bf16x3_conv_weight_gen_bytes": [ci, ci, ci, ci],
-    "stem_bf16x3_pack_conv_weight_gen": [vp, vp, ci, ci, ci, ci, ci, vp],
-    "stem_conv2d_bf16x6_gen_workspace_bytes": [ci, ci, ci, ci, ci, ci, ci, ci, ci],
-    "stem_bf16x3_pack_conv_weights_multi": [vp, ci, vp],
-    "stem_wgrad_bf16x6_splits": [ci, ci, ci, ci, ci, ci, ci, ci],
-    "stem_conv2d_wgrad_bf16x6": [vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_f16x2_split_nhwc": [vp, ci, vp, vp, vp, C.c_long, ci, vp],
+    "stem_f16x2_merge_nhwc": [vp, vp, vp, ci, C.c_long, ci, vp],
+    "stem_f16x2_split_dact_nhwc": [vp, ci, vp, ci, cf, vp, vp, vp, C.c_long, ci, vp],
+    "stem_f16x2_pack_conv_weight": [vp, vp, ci, ci, ci, ci, vp],
+    "stem_f16x2_conv_weight_gen_bytes": [ci, ci, ci, ci],
+    "stem_f16x2_pack_conv_weight_gen": [vp, vp, ci, ci, ci, ci, ci, vp],
+    "stem_conv2d_f16x3_gen_workspace_bytes": [ci, ci, ci, ci, ci, ci, ci, ci, ci],
+    "stem_f16x2_pack_conv_weights_multi": [vp, ci, vp],
+    "stem_wgrad_f16x3_splits": [ci, ci, ci, ci, ci, ci, ci, ci],
+    "stem_conv2d_wgrad_f16x3": [vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_bias_grad_final": [vp, ci, ci, vp, ci, vp],
     "stem_bias_grad_scratch_elems": [C.c_long, ci],
     "stem_bias_grad": [vp, ci, C.c_long, ci, vp, vp, ci, vp],
-    "stem_conv2d_bf16x6_gen_fwd": [vp, vp, ci, vp, vp, ci, cf, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],
+    "stem_conv2d_f16x3_gen_fwd": [vp, vp, ci, vp, vp, ci, cf, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],
     "stem_c4gdn_supported": [ci, ci, ci],
     "stem_c4gdn_stream_bytes": [ci, ci, ci],
     "stem_c4gdn_pack": [vp, vp, vp, ci, ci, ci, vp],
-    "stem_conv2d_c4_gdn_bf16x6": [vp, vp, vp, vp, vp, cf, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
-    "stem_conv2d_bf16x6_fwd_act": [vp, vp, vp, vp, ci, cf, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
-    "stem_bf16x3_pack_conv_weight_flip": [vp, vp, ci, ci, ci, ci, vp],
-    "stem_conv2d_bf16x6_fwd": [vp, vp, vp, vp, vp, vp, cf, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_conv2d_c4_gdn_f16x3": [vp, vp, vp, vp, vp, cf, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_conv2d_f16x3_fwd_act": [vp, vp, vp, vp, ci, cf, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_f16x2_pack_conv_weight_flip": [vp, vp, ci, ci, ci, ci, vp],
+    "stem_conv2d_f16x3_fwd": [vp, vp, vp, vp, vp, vp, cf, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_ar_decode_image_persistent": [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf,
                                         vp, vp, vp, ci, ci, vp, vp, vp],
     "stem_ar_decode_batch_pipelined": [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf,
@@ -135,7 +135,7 @@ _HIP_SIG = {
     "stem_tuning_get": [C.c_char_p],
     "stem_last_error": [],
 }
-_RESTYPE = {"stem_c4gdn_stream_bytes": sz, "stem_bf16x3_planes_qrec_offset": sz, "stem_nhwc4_qrec_floats": sz, "stem_bias_grad_scratch_elems": sz, "stem_bf16x3_conv_weight_gen_bytes": sz, "stem_conv2d_bf16x6_gen_workspace_bytes": sz, "stem_bf16x3_planes_bytes": sz, "stem_bf16x3_conv_weight_bytes": sz, "stem_packed_weight_elems": sz, "stem_gdn_bwd_workspace_bytes": sz, "stem_wgrad_workspace_elems": sz, "stem_conv_workspace_bytes": sz, "stem_last_error": C.c_char_p}
+_RESTYPE = {"stem_c4gdn_stream_bytes": sz, "stem_f16x2_planes_qrec_offset": sz, "stem_nhwc4_qrec_floats": sz, "stem_bias_grad_scratch_elems": sz, "stem_f16x2_conv_weight_gen_bytes": sz, "stem_conv2d_f16x3_gen_workspace_bytes": sz, "stem_f16x2_planes_bytes": sz, "stem_f16x2_conv_weight_bytes": sz, "stem_packed_weight_elems": sz, "stem_gdn_bwd_workspace_bytes": sz, "stem_wgrad_workspace_elems": sz, "stem_conv_workspace_bytes": sz, "stem_last_error": C.c_char_p}
 
 _RANS_SIG = {
     "stem_rans_encode": [vp, vp, sz, vp, ci, ci, vp, vp, vp, sz],
@@ -161,7 +161,7 @@ class PackDesc(C.Structure):
     _fields_ = [("w", vp), ("wp", vp), ("K", ci), ("C", ci), ("R", ci), ("S", ci), ("role", ci), ("masked", ci)]
 
 
-class Bf16PackDesc(C.Structure):
+class F16PackDesc(C.Structure):
     _fields_ = [("w", vp), ("wp", vp), ("N", ci), ("C", ci), ("R", ci), ("S", ci), ("flip", ci), ("reserved", ci)]
 
 

@@ -1,21 +1,22 @@
-// First analysis layer g_a.0 + GDN g_a.1 (compressai/models/priors.py:421-423, gdn.py:52-67) as ONE kernel on the bf16 matrix
-// cores with fp32-exact products: a 3-channel image -> N = 64 / 128 / 192 channels (5x5 stride 2 in the reference), divided by
-// sqrt(beta + gamma . x^2), written pre-split as bf16 planes for conv_bf16x6.hip (and / or as fp32 NHWC).
+// First analysis layer g_a.0 + GDN g_a.1 (compressai/models/priors.py:421-423, gdn.py:52-67) as ONE kernel on the fp16 matrix
+// cores with fp32-class products: a 3-channel image -> N = 64 / 128 / 192 channels (5x5 stride 2 in the reference), divided by
+// sqrt(beta + gamma . x^2), written pre-split as two fp16 planes for conv_f16x3.hip (and / or as fp32 NHWC).
 //
 // The fp32-MFMA kernel this replaces (igemm.hip, C4 + FUSE) ran at 0.29 of its pipe: 72 % of its flop is the K = N GDN
 // contraction on the 64-flop/clk instruction, its 128 x 192 tile with the squared values parked in LDS left one workgroup per
-// CU, and nothing overlapped the 302 MB planes write.  Here
+// CU, and nothing overlapped the planes write.  Here
 //   * both contractions are computed TRANSPOSED, D[channel][pixel] = A[channel][k] . B[k][pixel]: the accumulator of
-//     v_mfma_f32_32x32x16_bf16 keeps one PIXEL per lane (column) and 16 channels in its registers -- exactly the B-operand
+//     v_mfma_f32_32x32x16_f16 keeps one PIXEL per lane (column) and 16 channels in its registers -- exactly the B-operand
 //     shape of the next MFMA that sums over channels.  The squared conv outputs therefore go from the accumulators into the
-//     GDN contraction as registers (square, split into three bf16 planes, pack): no LDS tile, no cross-lane movement;
+//     GDN contraction as registers (square, scale, split into two fp16 planes, pack): no LDS tile, no cross-lane movement;
 //   * a wavefront owns 32 pixels x ALL N channels (x: N/32 accumulators), so a workgroup needs LDS only for the A-operand
-//     stream (conv weights, then gamma), which is the same for every workgroup: it is pre-split into bf16 planes and stored in
-//     fragment order by c4gdn_pack_kernel, and every 18 KiB chunk of it is copied global -> LDS by global_load_lds (no
-//     registers) one chunk ahead of its use; 36 KiB of LDS per workgroup, several workgroups per CU, so that the epilogue
+//     stream (conv weights, then gamma), which is the same for every workgroup: it is pre-split into fp16 planes and stored in
+//     fragment order by c4gdn_pack_kernel, and every 12 KiB chunk of it is copied global -> LDS by global_load_lds (no
+//     registers) one chunk ahead of its use; 24 KiB of LDS per workgroup, several workgroups per CU, so that the epilogue
 //     stores of one overlap the MFMAs of another;
-//   * six bf16 MFMAs per fp32 product as in conv_bf16x6.hip (operands split as a = a0 + a1 + a2, the six products with
-//     i + j <= 2): fp32 accuracy, fp32 accumulation;
+//   * three fp16 MFMAs per fp32 product as in conv_f16x3.hip (operands as two fp16 numbers of a power-of-two-scaled copy,
+//     the products a0.b0, a0.b1, a1.b0): fp32-class accuracy, fp32 accumulation; the image is scaled by its measured maximum,
+//     the squared conv outputs and the result by upper bounds derived from it (scale records, stem_common.h);
 //   * the image patch of a pixel is read straight from the NHWC4 image (two 16-byte loads per lane and k-step: taps s, s + 1
 //     of one filter row x 4 channels = the 8 consecutive k of the lane's fragment), zero-filled outside the image.
 //
@@ -29,7 +30,7 @@
 
 namespace {
 
-typedef hp8 bf16x8;
+typedef hp8 h16x8;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CHUNK = 12288;                    // bytes of one A-operand chunk: 6 tiles x 2 planes x 64 lanes x 16 B
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void c4gdn_pack_kernel(const float *wp_c4, con
         }
     }
     if (!used) return;
-    bf16x8 p0, p1;
+    h16x8 p0, p1;
     const float sc = q_pow2(c < ksc ? we : ge);
     for (int j = 0; j < 8; ++j) {
         hp_t a, b;
@@ -110,12 +111,12 @@ __global__ __launch_bounds__(256) void c4gdn_pack_kernel(const float *wp_c4, con
         p0[j] = a; p1[j] = b;
     }
     unsigned char *dst = out + (size_t)c * CHUNK + ((size_t)(fp * 2) * 64 + lane) * 16;
-    *reinterpret_cast<bf16x8 *>(dst) = p0;
-    *reinterpret_cast<bf16x8 *>(dst + 1024) = p1;
+    *reinterpret_cast<h16x8 *>(dst) = p0;
+    *reinterpret_cast<h16x8 *>(dst + 1024) = p1;
 }
 
-// the three products of one fp32 product, smallest terms first (as conv_bf16x6.hip)
-__device__ inline f32x16 mfma3(const bf16x8 (&a)[2], const bf16x8 (&b)[2], f32x16 acc)
+// the three products of one fp32 product, smallest terms first (as conv_f16x3.hip)
+__device__ inline f32x16 mfma3(const h16x8 (&a)[2], const h16x8 (&b)[2], f32x16 acc)
 {
     acc = STEM_MFMA16(a[1], b[0], acc);
     acc = STEM_MFMA16(a[0], b[1], acc);
@@ -124,14 +125,14 @@ __device__ inline f32x16 mfma3(const bf16x8 (&a)[2], const bf16x8 (&b)[2], f32x1
 }
 
 // the two planes of one A fragment (consecutive 1 KiB pieces of the chunk, lane-linear: conflict-free ds_read_b128)
-__device__ inline void lda(const unsigned char *p, bf16x8 (&af)[2])
+__device__ inline void lda(const unsigned char *p, h16x8 (&af)[2])
 {
-    af[0] = *reinterpret_cast<const bf16x8 *>(p);
-    af[1] = *reinterpret_cast<const bf16x8 *>(p + 1024);
+    af[0] = *reinterpret_cast<const h16x8 *>(p);
+    af[1] = *reinterpret_cast<const h16x8 *>(p + 1024);
 }
 
 template <int NB>
-__global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs a)
+__global__ __launch_bounds__(NTHREADS, 2) void c4gdn_f16x3_kernel(const C4gArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];          // [2][CHUNK]: the A-operand ring
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -229,12 +230,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
     f32x4 pv0, pv1;
     patch_load(0, pv0, pv1);
 
-    // ---- convolution: ksc chunks of one k-step x NB tiles x 6 products -----------------------------------------------------------
+    // ---- convolution: ksc chunks of one k-step x NB tiles x 3 products -----------------------------------------------------------
 #pragma unroll 1
     for (int t = 0; t < a.ksc; ++t) {
         ring_wait();
         ring_issue(t + 1);
-        bf16x8 b[2];
+        h16x8 b[2];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             hp_t h0, h1;
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
         }
         patch_load(t + 1 < a.ksc ? t + 1 : t, pv0, pv1);
         const unsigned char *buf = smem + (t & 1) * CHUNK + lane * 16;
-        bf16x8 af[2][2];
+        h16x8 af[2][2];
         lda(buf, af[0]);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {          // fragments of tile nb + 1 are fetched behind the MFMAs of tile nb
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
             ring_wait();
             ring_issue(c + 1);
             const unsigned char *buf = smem + (c & 1) * CHUNK + lane * 16;
-            bf16x8 b[2];
+            h16x8 b[2];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float v = x[kb][8 * s + j];
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
                 q_split(v * v, sqscale, h0, h1);
                 b[0][j] = h0; b[1][j] = h1;
             }
-            bf16x8 af[2][2];
+            h16x8 af[2][2];
             lda(buf, af[0]);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_bf16x6_kernel(const C4gArgs
                 }
             }
             if (a.yp) {
-                bf16x8 q0[2], q1[2];
+                h16x8 q0[2], q1[2];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     hp_t h0, h1;
@@ -395,22 +396,22 @@ STEM_EXPORT int stem_c4gdn_pack(const float *wp_c4, const float *gamma, void *as
     return 0;
 }
 
-STEM_EXPORT int stem_conv2d_c4_gdn_bf16x6(const float *x4, const float *xq, const void *astream, const float *bias, const float *beta, float beta_min,
+STEM_EXPORT int stem_conv2d_c4_gdn_f16x3(const float *x4, const float *xq, const void *astream, const float *bias, const float *beta, float beta_min,
                                           float *y, int ldy, void *yp, float *yq, int B, int H, int W, int N, int R, int S, int stride, int pad,
                                           void *stream)
 {
-    STEM_CHECK_ARG(x4 && xq && astream && beta && (y || yp) && (yq || !yp), "stem_conv2d_c4_gdn_bf16x6: null pointer (planes come with their scale record)");
-    STEM_CHECK_ARG(stem_c4gdn_supported(N, R, S), "stem_conv2d_c4_gdn_bf16x6: N must be 64, 128 or 192 and R*S <= 25 (N=%d R=%d S=%d)", N, R, S);
-    STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && stride >= 1 && pad >= 0, "stem_conv2d_c4_gdn_bf16x6: bad geometry");
-    STEM_CHECK_ARG(!y || (ldy >= N && ldy % 4 == 0 && ((uintptr_t)y & 15) == 0), "stem_conv2d_c4_gdn_bf16x6: y rows must be 16-byte aligned, ldy >= N");
-    STEM_CHECK_ARG(!bias || ((uintptr_t)bias & 15) == 0, "stem_conv2d_c4_gdn_bf16x6: bias must be 16-byte aligned");
-    STEM_CHECK_ARG(((uintptr_t)beta & 15) == 0 && ((uintptr_t)astream & 15) == 0, "stem_conv2d_c4_gdn_bf16x6: beta / stream must be 16-byte aligned");
+    STEM_CHECK_ARG(x4 && xq && astream && beta && (y || yp) && (yq || !yp), "stem_conv2d_c4_gdn_f16x3: null pointer (planes come with their scale record)");
+    STEM_CHECK_ARG(stem_c4gdn_supported(N, R, S), "stem_conv2d_c4_gdn_f16x3: N must be 64, 128 or 192 and R*S <= 25 (N=%d R=%d S=%d)", N, R, S);
+    STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && stride >= 1 && pad >= 0, "stem_conv2d_c4_gdn_f16x3: bad geometry");
+    STEM_CHECK_ARG(!y || (ldy >= N && ldy % 4 == 0 && ((uintptr_t)y & 15) == 0), "stem_conv2d_c4_gdn_f16x3: y rows must be 16-byte aligned, ldy >= N");
+    STEM_CHECK_ARG(!bias || ((uintptr_t)bias & 15) == 0, "stem_conv2d_c4_gdn_f16x3: bias must be 16-byte aligned");
+    STEM_CHECK_ARG(((uintptr_t)beta & 15) == 0 && ((uintptr_t)astream & 15) == 0, "stem_conv2d_c4_gdn_f16x3: beta / stream must be 16-byte aligned");
     const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
-    STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_c4_gdn_bf16x6: empty output");
+    STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_c4_gdn_f16x3: empty output");
     const size_t xb = (size_t)B * H * W * 16;
-    STEM_CHECK_ARG(xb < 0x7FFFFF00ull && (size_t)B * OH * OW < 0x7FFFFFFFull, "stem_conv2d_c4_gdn_bf16x6: image batch must stay below 2 GiB");
+    STEM_CHECK_ARG(xb < 0x7FFFFF00ull && (size_t)B * OH * OW < 0x7FFFFFFFull, "stem_conv2d_c4_gdn_f16x3: image batch must stay below 2 GiB");
     STEM_CHECK_ARG((!yp || (size_t)B * OH * OW * (N / 32) * 128 < 0x7FFF0000ull) && (!y || (size_t)B * OH * OW * ldy * 4 < 0x7FFF0000ull),
-                   "stem_conv2d_c4_gdn_bf16x6: outputs are addressed through 2 GiB buffer views (split the batch)");
+                   "stem_conv2d_c4_gdn_f16x3: outputs are addressed through 2 GiB buffer views (split the batch)");
     C4gArgs a;
     memset(&a, 0, sizeof(a));
     a.x4 = x4; a.xq = xq; a.yq = yq; a.astream = static_cast<const unsigned char *>(astream);
@@ -424,11 +425,11 @@ STEM_EXPORT int stem_conv2d_c4_gdn_bf16x6(const float *x4, const float *xq, cons
     const dim3 grid(cdiv(M, WG_PIX)), block(NTHREADS);
     hipStream_t st = (hipStream_t)stream;
     if (N == 192)
-        hipLaunchKernelGGL(c4gdn_bf16x6_kernel<6>, grid, block, 2 * CHUNK, st, a);
+        hipLaunchKernelGGL(c4gdn_f16x3_kernel<6>, grid, block, 2 * CHUNK, st, a);
     else if (N == 128)
-        hipLaunchKernelGGL(c4gdn_bf16x6_kernel<4>, grid, block, 2 * CHUNK, st, a);
+        hipLaunchKernelGGL(c4gdn_f16x3_kernel<4>, grid, block, 2 * CHUNK, st, a);
     else
-        hipLaunchKernelGGL(c4gdn_bf16x6_kernel<2>, grid, block, 2 * CHUNK, st, a);
-    STEM_LAUNCH_CHECK("stem_conv2d_c4_gdn_bf16x6");
+        hipLaunchKernelGGL(c4gdn_f16x3_kernel<2>, grid, block, 2 * CHUNK, st, a);
+    STEM_LAUNCH_CHECK("stem_conv2d_c4_gdn_f16x3");
     return 0;
 }

@@ -1,26 +1,31 @@
-// fp32-accurate convolutions on the bf16 matrix cores of gfx950 (MI355X): the FROZEN analysis transform (first part of this
-// file) and the general kernel for the training-time STEM layers (second part); weight gradients: wgrad_bf16x6.hip.
+// fp32-accurate convolutions on the fp16 matrix cores of gfx950 (MI355X): the FROZEN analysis transform (first part of this
+// file) and the general kernel for the training-time STEM layers (second part); weight gradients: wgrad_f16x3.hip.
 //
-// v_mfma_f32_32x32x2_f32 (igemm.hip) is the only MFMA that multiplies fp32 operands, at 64 flop/clk/SIMD; the bf16 form
-// v_mfma_f32_32x32x16_bf16 runs at 1024.  Every fp32 number is the exact sum of three bf16 numbers
-//     a = a0 + a1 + a2,   a0 = rn(a), a1 = rn(a - a0), a2 = a - a0 - a1         (|a1| <= 2^-9 |a|, |a2| <= 2^-18 |a|)
-// so a.b = sum_{i,j} ai.bj exactly, every ai.bj is exact in the fp32 accumulator's input (8 x 8 bit significands), and the six
-// products with i + j <= 2 carry everything down to 2^-26 |a.b| -- below the rounding of an fp32 multiply.  Six bf16 MFMAs
-// (K = 16 each, 32 cycles) replace eight fp32 MFMAs (K = 2 each, 64 cycles): 192 instead of 512 matrix-pipe cycles per 16
-// input channels, with fp32 accumulation throughout, i.e. the numerics of the fp32 path (tests: same 1e-4 gates).
+// v_mfma_f32_32x32x2_f32 (igemm.hip) is the only MFMA that multiplies fp32 operands, at 64 flop/clk/SIMD; the 16-bit forms
+// (v_mfma_f32_32x32x16_f16 / _bf16) run at 1024.  Every fp32 number a is stored as TWO fp16 numbers of a scaled copy,
+//     a 2^e = a0 + a1 + r,   a0 = rn16(a 2^e), a1 = rn16(a 2^e - a0),   |r| <= 2^-22 |a| 2^e   (two 11-bit significands)
+// so a.b 2^(ea+eb) = a0.b0 + a0.b1 + a1.b0 + O(2^-21 |a.b|): every product of two fp16 numbers is exact in the MFMA's fp32
+// accumulator input (11 x 11 bit significands), the dropped a1.b1 is <= 2^-22 |a.b|.  Three fp16 MFMAs (K = 16 each, 32
+// cycles) replace eight fp32 MFMAs (K = 2 each, 64 cycles): 96 instead of 512 matrix-pipe cycles per 16 input channels, with
+// fp32 accumulation throughout (tests: the 1e-4 gates of the fp32 path; measured 1-2.5e-6 of max|ref| per layer, the fp32-MFMA
+// kernels' own distance from fp64).  Round 2 used three bf16 planes and six products (no scaling needed, twice the MFMAs).
+// fp16's range is handled by the power-of-two scale 2^e per tensor (scale records, stem_common.h): a split takes e from the
+// measured max |a|, a convolution epilogue from the bound K max|x| max|w| + max|bias| (one layer's worth of over-estimate:
+// the inputs' maxima are measured), placing the bound in [2^14, 2^15); stored values keep an absolute floor of 2^-25 2^-e
+// (fp16 subnormals, kept by the MFMA), i.e. 2^-39 of the bound.
 //
-// Operands live in HBM pre-split ("planes" layout): per pixel and per 32-channel slab three consecutive rows of 32 bf16,
-//     x_planes[pixel][slab][plane 0..2][32]        (192 B per pixel and slab, 1.5x the fp32 bytes)
-// written by the producing kernel's epilogue (or by stem_bf16x3_split_nhwc for the first input); the weights are frozen
+// Operands live in HBM pre-split ("planes" layout): per pixel and per 32-channel slab two consecutive rows of 32 fp16,
+//     x_planes[pixel][slab][plane 0..1][32]        (128 B per pixel and slab = the fp32 bytes)
+// written by the producing kernel's epilogue (or by stem_f16x2_split_nhwc for the first input); the weights are frozen
 // (stem/trainSTEM.py:128), split once, and stored chunk by chunk as the exact LDS image the kernel wants (swizzled), so
-// that their staging is a straight 36 KiB copy.
+// that their staging is a straight 24 KiB copy.
 //
 // Tile: 128 pixels x 192 channels per workgroup, 8 wavefronts as 4 (M) x 2 (N), each 32 x 96 = three 32x32 accumulators;
-// K chunk = one tap x 32 input channels = 2 k-steps x 3 tiles x 6 products = 36 MFMAs per wavefront.  LDS rows are 64 B
-// (32 bf16) per plane with the 16-byte piece index XOR-swizzled by (row >> 2) & 3: ds_read_b128 / ds_write_b128 are
+// K chunk = one tap x 32 input channels = 2 k-steps x 3 tiles x 3 products = 18 MFMAs per wavefront.  LDS rows are 64 B
+// (32 fp16) per plane with the 16-byte piece index XOR-swizzled by (row >> 2) & 3: ds_read_b128 / ds_write_b128 are
 // conflict-free without padding.  Staging is register-based, two chunks ahead, woven between the MFMA groups as in igemm.hip.
 // The GDN that follows every analysis convolution (gdn.py:52-67) is fused exactly as in igemm.hip's FUSE epilogue (second
-// contraction over the squared outputs parked in LDS, fp32 MFMA -- 4 % of the flops).
+// contraction over the squared outputs parked in LDS, fp32 MFMA -- 8 % of the matrix time now).
 #include <math.h>
 #include <stdlib.h>
 
@@ -28,7 +33,7 @@
 
 namespace {
 
-typedef hp8 bf16x8;
+typedef hp8 h16x8;
 
 constexpr int BN = 192, KC = 32;
 constexpr int NPL = 2, SLAB = NPL * 64;                            // planes per value; bytes per pixel and 32-channel slab
@@ -40,7 +45,7 @@ constexpr int lds_total(int bm) { return lds_taps(bm) + 32 * 4; }
 constexpr int MAXTAP = 25;
 constexpr int OOR = 0x7FFFFF00;                                    // voffset that every buffer view rejects (returns 0)
 
-struct Bx6Args {
+struct Fx3Args {
     const void *xp, *wp;
     const float *xq, *wq;          // scale records of the two operands (stem_common.h)
     float *yq;                     // ... of the output: slots always, the scale when planes are written (may be null without planes)
@@ -52,7 +57,7 @@ struct Bx6Args {
     int xbytes, wbytes, gmbytes;
     float beta_bound;
     int fuse;                      // 0: bias only, 1: GDN
-    // general variant (conv_bf16x6_gen_kernel): activation epilogue, N tiles, split-K
+    // general variant (conv_f16x3_gen_kernel): activation epilogue, N tiles, split-K
     const float *z;                // EPI_DACT: the activation output the slope is selected by (z > 0 ? 1 : slope)
     int ldz, epi;                  // epi: 0 bias, 1 bias + leaky ReLU, 2 times d(leaky ReLU)(z)
     float slope;
@@ -68,7 +73,7 @@ __device__ inline int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
 // BM = pixels per workgroup: 128 (8 wavefronts) or 64 (4 wavefronts, for layers with too few 128-pixel tiles to fill the chip).
 template <int BM>
-__global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
+__global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
 {
     constexpr int NT = BM * 4;
     constexpr int A_PLANE = BM * 64, A_BUF = NPL * A_PLANE;
@@ -158,13 +163,13 @@ __global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int pk = ks ? pk1 : pk0;
-            bf16x8 af[PL], bf[PL][3];
+            h16x8 af[PL], bf[PL][3];
 #pragma unroll
-            for (int pl = 0; pl < PL; ++pl) af[pl] = *reinterpret_cast<const bf16x8 *>(Ab + pl * A_PLANE + pk);
+            for (int pl = 0; pl < PL; ++pl) af[pl] = *reinterpret_cast<const h16x8 *>(Ab + pl * A_PLANE + pk);
 #pragma unroll
             for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8 *>(Bb + pl * B_PLANE + j * 32 * 64 + pk);
+                for (int j = 0; j < 3; ++j) bf[pl][j] = *reinterpret_cast<const h16x8 *>(Bb + pl * B_PLANE + j * 32 * 64 + pk);
 #pragma unroll
             for (int j = 0; j < 3; ++j) {      // smallest terms first
                 acc[j] = STEM_MFMA16(af[1], bf[0][j], acc[j]);
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
             if (m >= Mtot) continue;
             const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&X2[row * XP + sl * 32 + p * 8]);
             const f32x4 v1 = *reinterpret_cast<const f32x4 *>(&X2[row * XP + sl * 32 + p * 8 + 4]);
-            bf16x8 h0, h1;
+            h16x8 h0, h1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 hp_t x0, x1;
@@ -383,8 +388,8 @@ __global__ __launch_bounds__(BM * 4) void conv_bf16x6_kernel(const Bx6Args a)
                 h0[4 + c] = x0; h1[4 + c] = x1;
             }
             unsigned char *dst = yp + (size_t)m * opix + sl * SLAB + p * 16;
-            *reinterpret_cast<bf16x8 *>(dst) = h0;
-            *reinterpret_cast<bf16x8 *>(dst + 64) = h1;
+            *reinterpret_cast<h16x8 *>(dst) = h0;
+            *reinterpret_cast<h16x8 *>(dst + 64) = h1;
         }
     }
 }
@@ -403,7 +408,7 @@ constexpr int GB_PLANE = GBN * 64, GB_BUF = NPL * GB_PLANE;          // 16384
 constexpr int GTP = GBN + 4;                                         // fp32 pitch of the epilogue tile
 constexpr int GLDS = 2 * (GA_BUF + GB_BUF) + 32 * 4;                 // 49280 (the 64 x 132 float epilogue tile reuses the front)
 
-__global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a)
+__global__ __launch_bounds__(GNT, 2) void conv_f16x3_gen_kernel(const Fx3Args a)
 {
     constexpr int PL = NPL, BPC = PL * 2;                      // planes; 16-byte weight pieces per thread and chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -478,13 +483,13 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int pk = ks ? pk1 : pk0;
-            bf16x8 af[PL], bf[PL][2];
+            h16x8 af[PL], bf[PL][2];
 #pragma unroll
-            for (int pl = 0; pl < PL; ++pl) af[pl] = *reinterpret_cast<const bf16x8 *>(Ab + pl * GA_PLANE + pk);
+            for (int pl = 0; pl < PL; ++pl) af[pl] = *reinterpret_cast<const h16x8 *>(Ab + pl * GA_PLANE + pk);
 #pragma unroll
             for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[pl][j] = *reinterpret_cast<const bf16x8 *>(Bb + pl * GB_PLANE + j * 32 * 64 + pk);
+                for (int j = 0; j < 2; ++j) bf[pl][j] = *reinterpret_cast<const h16x8 *>(Bb + pl * GB_PLANE + j * 32 * 64 + pk);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 acc[j] = STEM_MFMA16(af[1], bf[0][j], acc[j]);
@@ -622,7 +627,7 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
     __shared__ float qred[16];
     const float fac = q_inv(a.xq) * q_inv(a.wq);                   // the operands were stored times 2^ex, 2^ew
     float oscale = 1.f;
-    if (a.yp) {     // scale of the planes output from an upper bound of |output| (see conv_bf16x6_kernel)
+    if (a.yp) {     // scale of the planes output from an upper bound of |output| (see conv_f16x3_kernel)
         const float xmax = q_amax(a.xq, qred), wmax = q_amax(a.wq, qred);
         float bm = 0.f;
         if (a.bias)
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
             if (m >= Mtot || n >= a.N) continue;            // N % 32 == 0 for planes (host check)
             const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&T[row * GTP + c8 * 8]);
             const f32x4 v1 = *reinterpret_cast<const f32x4 *>(&T[row * GTP + c8 * 8 + 4]);
-            bf16x8 h0, h1;
+            h16x8 h0, h1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 hp_t x0, x1;
@@ -685,13 +690,13 @@ __global__ __launch_bounds__(GNT, 2) void conv_bf16x6_gen_kernel(const Bx6Args a
                 h0[4 + c] = x0; h1[4 + c] = x1;
             }
             unsigned char *dst = yp + (size_t)m * opix + (n >> 5) * SLAB + ((n >> 3) & 3) * 16;
-            *reinterpret_cast<bf16x8 *>(dst) = h0;
-            *reinterpret_cast<bf16x8 *>(dst + 64) = h1;
+            *reinterpret_cast<h16x8 *>(dst) = h0;
+            *reinterpret_cast<h16x8 *>(dst + 64) = h1;
         }
     }
 }
 
-// weights for conv_bf16x6_gen_kernel: [N tile][chunk q = slab * R*S + tap][plane][128 rows][64 B].  flip: the input-gradient of
+// weights for conv_f16x3_gen_kernel: [N tile][chunk q = slab * R*S + tap][plane][128 rows][64 B].  flip: the input-gradient of
 // a stride-1 convolution is a convolution of dy with w'[c][k][r][s] = w[k][c][R-1-r][S-1-s]: `w` is still the torch weight
 // [K][C][R][S], the packed rows are its input channels c (N = C outputs) and the packed channels its output channels k.
 __global__ __launch_bounds__(256) void pack_weight_gen_kernel(const float *w, unsigned char *wp, int N, int C, int RS, int flip, long npieces,
@@ -708,7 +713,7 @@ __global__ __launch_bounds__(256) void pack_weight_gen_kernel(const float *w, un
     const long qq = e / (4 * GBN);                       // ntile * nchunks + q
     const int ntile = (int)(qq / nchunks), q = (int)(qq - (long)ntile * nchunks);
     const int slab = q / RS, tap = q - slab * RS, n = ntile * GBN + nl;
-    bf16x8 h[NPL];
+    h16x8 h[NPL];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int ch = slab * 32 + p * 8 + c;
@@ -720,14 +725,14 @@ __global__ __launch_bounds__(256) void pack_weight_gen_kernel(const float *w, un
     }
     unsigned char *dst = wp + qq * GB_BUF + nl * 64 + ((p ^ ((nl >> 2) & 3)) << 4);
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<bf16x8 *>(dst + pl * GB_PLANE) = h[pl];
+    for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<h16x8 *>(dst + pl * GB_PLANE) = h[pl];
 }
 
 // every layer's weight image with one launch: blockIdx.y = descriptor (the weights of a training model change every step).  The
 // table travels by value in the kernel arguments: no staging buffer whose lifetime would have to outlast the queued launch.
 constexpr int MAXPACK = 24;
 struct PackTable {
-    stem_bf16x3_pack_desc d[MAXPACK];
+    stem_f16x2_pack_desc d[MAXPACK];
 };
 constexpr int PKR = 8;                                  // output rows per unit
 __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTable tab)
@@ -738,7 +743,7 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
     // run -- into LDS, then every thread emits whole 16-byte pieces (8 channels of one tap and row, three planes).  (The first
     // version handled one row per unit: 100-byte runs in flip mode and two barriers per 800 values.)
     __shared__ float tile[PKR * 32 * MAXTAP];         // [row][channel in slab][tap]
-    const stem_bf16x3_pack_desc &d = tab.d[blockIdx.y];
+    const stem_f16x2_pack_desc &d = tab.d[blockIdx.y];
     const int RS = d.R * d.S, nslab = d.C / 32, nchunks = nslab * RS, ntile = cdiv_dev(d.N, GBN);
     const float *w = static_cast<const float *>(d.w);
     unsigned char *wp = static_cast<unsigned char *>(d.wp);
@@ -770,7 +775,7 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
         for (int e = threadIdx.x; e < PKR * RS * 4; e += 256) {
             const int p = e & 3, r = (e >> 2) % PKR, tap = (e >> 2) / PKR;
             const int n = n0 + r, nt = n / GBN, nl = n - nt * GBN;
-            bf16x8 h[NPL];
+            h16x8 h[NPL];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 hp_t x0, x1;
@@ -780,7 +785,7 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
             const long qq = (long)nt * nchunks + slab * RS + tap;
             unsigned char *dst = wp + qq * GB_BUF + nl * 64 + ((p ^ ((nl >> 2) & 3)) << 4);
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<bf16x8 *>(dst + pl * GB_PLANE) = h[pl];
+            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<h16x8 *>(dst + pl * GB_PLANE) = h[pl];
         }
     }
 }
@@ -807,7 +812,7 @@ __global__ __launch_bounds__(256) void split_nhwc_kernel(const float *x, int ldx
     const int rem = (int)(e - pix * (nslab * 4)), sl = rem >> 2, p = rem & 3;
     const float *src = x + pix * ldx + sl * 32 + p * 8;
     const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
-    bf16x8 h0, h1;
+    h16x8 h0, h1;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         hp_t x0, x1;
@@ -817,8 +822,8 @@ __global__ __launch_bounds__(256) void split_nhwc_kernel(const float *x, int ldx
         h0[4 + c] = x0; h1[4 + c] = x1;
     }
     unsigned char *dst = xp + pix * (long)(nslab * SLAB) + sl * SLAB + p * 16;
-    *reinterpret_cast<bf16x8 *>(dst) = h0;
-    *reinterpret_cast<bf16x8 *>(dst + 64) = h1;
+    *reinterpret_cast<h16x8 *>(dst) = h0;
+    *reinterpret_cast<h16x8 *>(dst + 64) = h1;
 }
 
 // max |x| of an NHWC tensor (rows of C floats at pitch ldx) -> one slot per workgroup of the record q: the pass in front of a
@@ -862,7 +867,7 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const AmaxTable tab)
 }
 
 // dy * (z > 0 ? 1 : slope) -> planes: the gradient that reaches a convolution whose output was activated (z = that output),
-// split for the bf16 input-gradient / weight-gradient kernels in the pass that applies the leaky-ReLU derivative
+// split for the fp16 input-gradient / weight-gradient kernels in the pass that applies the leaky-ReLU derivative
 __global__ __launch_bounds__(256) void split_dact_nhwc_kernel(const float *x, int ldx, const float *z, int ldz, float slope, unsigned char *xp,
                                                               long npieces, int nslab, float *q, const float *qsrc)
 {
@@ -884,7 +889,7 @@ __global__ __launch_bounds__(256) void split_dact_nhwc_kernel(const float *x, in
     const float *src = x + pix * ldx + sl * 32 + p * 8, *zs = z + pix * ldz + sl * 32 + p * 8;
     const f32x4 v0 = *reinterpret_cast<const f32x4 *>(src), v1 = *reinterpret_cast<const f32x4 *>(src + 4);
     const f32x4 z0 = *reinterpret_cast<const f32x4 *>(zs), z1 = *reinterpret_cast<const f32x4 *>(zs + 4);
-    bf16x8 h0, h1;
+    h16x8 h0, h1;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         hp_t x0, x1;
@@ -894,8 +899,8 @@ __global__ __launch_bounds__(256) void split_dact_nhwc_kernel(const float *x, in
         h0[4 + c] = x0; h1[4 + c] = x1;
     }
     unsigned char *dst = xp + pix * (long)(nslab * SLAB) + sl * SLAB + p * 16;
-    *reinterpret_cast<bf16x8 *>(dst) = h0;
-    *reinterpret_cast<bf16x8 *>(dst + 64) = h1;
+    *reinterpret_cast<h16x8 *>(dst) = h0;
+    *reinterpret_cast<h16x8 *>(dst + 64) = h1;
 }
 
 // planes -> fp32 NHWC (tests / debugging): the three planes add up to the fp32 value exactly
@@ -925,7 +930,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, unsign
     const int p = (int)(e & 3), n = (int)((e >> 2) % BN);
     const long q = e / (4 * BN);
     const int slab = (int)(q / RS), tap = (int)(q - (long)slab * RS);
-    bf16x8 h[NPL];
+    h16x8 h[NPL];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int ch = slab * 32 + p * 8 + c;
@@ -936,7 +941,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, unsign
     }
     unsigned char *dst = wp + q * B_BUF + n * 64 + ((p ^ ((n >> 2) & 3)) << 4);
 #pragma unroll
-    for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<bf16x8 *>(dst + pl * B_PLANE) = h[pl];
+    for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<h16x8 *>(dst + pl * B_PLANE) = h[pl];
 }
 
 }   // namespace
@@ -960,14 +965,14 @@ int amax_flat(const float *w, long n, float *q, hipStream_t st)
 }
 }   // namespace
 
-STEM_EXPORT size_t stem_bf16x3_planes_qrec_offset(long npix, int C) { return C % 32 ? 0 : planes_payload(npix, C); }
+STEM_EXPORT size_t stem_f16x2_planes_qrec_offset(long npix, int C) { return C % 32 ? 0 : planes_payload(npix, C); }
 
-STEM_EXPORT size_t stem_bf16x3_planes_bytes(long npix, int C)
+STEM_EXPORT size_t stem_f16x2_planes_bytes(long npix, int C)
 {
     return C % 32 ? 0 : planes_payload(npix, C) + (((QREC_HDR + planes_slots(npix, C)) * sizeof(float) + 15) & ~(size_t)15);
 }
 
-STEM_EXPORT size_t stem_bf16x3_conv_weight_bytes(int C, int R, int S) { return C % 32 ? 0 : w_image_bytes(C, R, S) + WQ_BYTES; }
+STEM_EXPORT size_t stem_f16x2_conv_weight_bytes(int C, int R, int S) { return C % 32 ? 0 : w_image_bytes(C, R, S) + WQ_BYTES; }
 
 STEM_EXPORT int stem_amax_nhwc(const float *x, int ldx, long npix, int C, float *q, long max_slots, void *stream)
 {
@@ -982,41 +987,41 @@ STEM_EXPORT int stem_amax_nhwc(const float *x, int ldx, long npix, int C, float 
     return 0;
 }
 
-STEM_EXPORT int stem_bf16x3_split_nhwc(const float *x, int ldx, void *xp, float *xq, const float *src_q, long npix, int C, void *stream)
+STEM_EXPORT int stem_f16x2_split_nhwc(const float *x, int ldx, void *xp, float *xq, const float *src_q, long npix, int C, void *stream)
 {
     STEM_CHECK_ARG(x && xp && xq && npix >= 0 && C > 0 && C % 32 == 0 && ldx >= C && ldx % 4 == 0,
-                   "stem_bf16x3_split_nhwc: channels must be a multiple of 32 and rows 16-byte aligned (C=%d ldx=%d)", C, ldx);
+                   "stem_f16x2_split_nhwc: channels must be a multiple of 32 and rows 16-byte aligned (C=%d ldx=%d)", C, ldx);
     const long np = npix * (C / 32) * 4;
     if (np == 0) return 0;
     if (!src_q && stem_amax_nhwc(x, ldx, npix, C, xq, planes_slots(npix, C), stream)) return -2;
     hipLaunchKernelGGL(split_nhwc_kernel, dim3((unsigned)cdivz(np, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
                        static_cast<unsigned char *>(xp), np, C / 32, xq, src_q ? src_q : xq);
-    STEM_LAUNCH_CHECK("stem_bf16x3_split_nhwc");
+    STEM_LAUNCH_CHECK("stem_f16x2_split_nhwc");
     return 0;
 }
 
-STEM_EXPORT int stem_bf16x3_split_dact_nhwc(const float *x, int ldx, const float *z, int ldz, float slope, void *xp, float *xq, const float *src_q,
+STEM_EXPORT int stem_f16x2_split_dact_nhwc(const float *x, int ldx, const float *z, int ldz, float slope, void *xp, float *xq, const float *src_q,
                                             long npix, int C, void *stream)
 {
     STEM_CHECK_ARG(x && z && xp && xq && npix >= 0 && C > 0 && C % 32 == 0 && ldx >= C && ldx % 4 == 0 && ldz >= C && ldz % 4 == 0,
-                   "stem_bf16x3_split_dact_nhwc: channels must be a multiple of 32 and rows 16-byte aligned (C=%d ldx=%d ldz=%d)", C, ldx, ldz);
+                   "stem_f16x2_split_dact_nhwc: channels must be a multiple of 32 and rows 16-byte aligned (C=%d ldx=%d ldz=%d)", C, ldx, ldz);
     const long np = npix * (C / 32) * 4;
     if (np == 0) return 0;
     if (!src_q && stem_amax_nhwc(x, ldx, npix, C, xq, planes_slots(npix, C), stream)) return -2;
     hipLaunchKernelGGL(split_dact_nhwc_kernel, dim3((unsigned)cdivz(np, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, z, ldz, slope,
                        static_cast<unsigned char *>(xp), np, C / 32, xq, src_q ? src_q : xq);
-    STEM_LAUNCH_CHECK("stem_bf16x3_split_dact_nhwc");
+    STEM_LAUNCH_CHECK("stem_f16x2_split_dact_nhwc");
     return 0;
 }
 
-STEM_EXPORT int stem_bf16x3_merge_nhwc(const void *xp, const float *xq, float *x, int ldx, long npix, int C, void *stream)
+STEM_EXPORT int stem_f16x2_merge_nhwc(const void *xp, const float *xq, float *x, int ldx, long npix, int C, void *stream)
 {
-    STEM_CHECK_ARG(x && xp && xq && npix >= 0 && C > 0 && C % 32 == 0 && ldx >= C, "stem_bf16x3_merge_nhwc: bad arguments (C=%d ldx=%d)", C, ldx);
+    STEM_CHECK_ARG(x && xp && xq && npix >= 0 && C > 0 && C % 32 == 0 && ldx >= C, "stem_f16x2_merge_nhwc: bad arguments (C=%d ldx=%d)", C, ldx);
     const long ne = npix * C;
     if (ne == 0) return 0;
     hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)cdivz(ne, 256)), dim3(256), 0, (hipStream_t)stream,
                        static_cast<const unsigned char *>(xp), x, ldx, ne, C, xq);
-    STEM_LAUNCH_CHECK("stem_bf16x3_merge_nhwc");
+    STEM_LAUNCH_CHECK("stem_f16x2_merge_nhwc");
     return 0;
 }
 
@@ -1033,51 +1038,51 @@ static int pack_conv_weight(const float *w, void *wp, int N, int C, int R, int S
     return 0;
 }
 
-STEM_EXPORT int stem_bf16x3_pack_conv_weight(const float *w, void *wp, int N, int C, int R, int S, void *stream)
+STEM_EXPORT int stem_f16x2_pack_conv_weight(const float *w, void *wp, int N, int C, int R, int S, void *stream)
 {
-    return pack_conv_weight(w, wp, N, C, R, S, 0, stream, "stem_bf16x3_pack_conv_weight");
+    return pack_conv_weight(w, wp, N, C, R, S, 0, stream, "stem_f16x2_pack_conv_weight");
 }
 
-STEM_EXPORT int stem_bf16x3_pack_conv_weight_flip(const float *w, void *wp, int N, int C, int R, int S, void *stream)
+STEM_EXPORT int stem_f16x2_pack_conv_weight_flip(const float *w, void *wp, int N, int C, int R, int S, void *stream)
 {
-    return pack_conv_weight(w, wp, N, C, R, S, 1, stream, "stem_bf16x3_pack_conv_weight_flip");
+    return pack_conv_weight(w, wp, N, C, R, S, 1, stream, "stem_f16x2_pack_conv_weight_flip");
 }
 
-static int conv2d_bf16x6_launch(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const float *gamma,
+static int conv2d_f16x3_launch(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const float *gamma,
                                 float beta_min, int act, float slope, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N,
                                 int R, int S, int stride, int pad, void *stream);
 
-STEM_EXPORT int stem_conv2d_bf16x6_fwd(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const float *gamma,
+STEM_EXPORT int stem_conv2d_f16x3_fwd(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const float *gamma,
                                        float beta_min, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R, int S,
                                        int stride, int pad, void *stream)
 {
-    return conv2d_bf16x6_launch(xp, xq, wp, bias, beta, gamma, beta_min, 0, 0.f, y, ldy, yp, yq, B, H, W, C, N, R, S, stride, pad, stream);
+    return conv2d_f16x3_launch(xp, xq, wp, bias, beta, gamma, beta_min, 0, 0.f, y, ldy, yp, yq, B, H, W, C, N, R, S, stride, pad, stream);
 }
 
-STEM_EXPORT int stem_conv2d_bf16x6_fwd_act(const void *xp, const float *xq, const void *wp, const float *bias, int act, float slope, float *y, int ldy,
+STEM_EXPORT int stem_conv2d_f16x3_fwd_act(const void *xp, const float *xq, const void *wp, const float *bias, int act, float slope, float *y, int ldy,
                                            void *yp, float *yq, int B, int H, int W, int C, int N, int R, int S, int stride, int pad, void *stream)
 {
-    STEM_CHECK_ARG(act == 0 || act == 1, "stem_conv2d_bf16x6_fwd_act: act is 0 (none) or 1 (leaky ReLU with `slope`)");
-    STEM_CHECK_ARG(!act || fabsf(slope) <= 1.f, "stem_conv2d_bf16x6_fwd_act: |slope| <= 1");
-    return conv2d_bf16x6_launch(xp, xq, wp, bias, nullptr, nullptr, 1e-6f, act, slope, y, ldy, yp, yq, B, H, W, C, N, R, S, stride, pad, stream);
+    STEM_CHECK_ARG(act == 0 || act == 1, "stem_conv2d_f16x3_fwd_act: act is 0 (none) or 1 (leaky ReLU with `slope`)");
+    STEM_CHECK_ARG(!act || fabsf(slope) <= 1.f, "stem_conv2d_f16x3_fwd_act: |slope| <= 1");
+    return conv2d_f16x3_launch(xp, xq, wp, bias, nullptr, nullptr, 1e-6f, act, slope, y, ldy, yp, yq, B, H, W, C, N, R, S, stride, pad, stream);
 }
 
-static int conv2d_bf16x6_launch(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const float *gamma,
+static int conv2d_f16x3_launch(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const float *gamma,
                                 float beta_min, int act, float slope, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N,
                                 int R, int S, int stride, int pad, void *stream)
 {
-    STEM_CHECK_ARG(xp && xq && wp && (y || yp) && (yq || !yp), "stem_conv2d_bf16x6_fwd: null pointer (planes come with their scale records)");
+    STEM_CHECK_ARG(xp && xq && wp && (y || yp) && (yq || !yp), "stem_conv2d_f16x3_fwd: null pointer (planes come with their scale records)");
     STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && C >= 32 && C % 32 == 0 && N >= 1 && N <= BN && R >= 1 && S >= 1 && R * S <= MAXTAP &&
-                   stride >= 1 && pad >= 0, "stem_conv2d_bf16x6_fwd: C %% 32 == 0, N <= %d, R*S <= %d (C=%d N=%d R=%d S=%d)", BN, MAXTAP, C, N, R, S);
-    STEM_CHECK_ARG(!yp || N % 32 == 0, "stem_conv2d_bf16x6_fwd: planes output needs N %% 32 == 0 (N=%d)", N);
-    STEM_CHECK_ARG(!y || ldy >= N, "stem_conv2d_bf16x6_fwd: ldy < N");
-    STEM_CHECK_ARG((beta == nullptr) == (gamma == nullptr), "stem_conv2d_bf16x6_fwd: beta and gamma come together");
+                   stride >= 1 && pad >= 0, "stem_conv2d_f16x3_fwd: C %% 32 == 0, N <= %d, R*S <= %d (C=%d N=%d R=%d S=%d)", BN, MAXTAP, C, N, R, S);
+    STEM_CHECK_ARG(!yp || N % 32 == 0, "stem_conv2d_f16x3_fwd: planes output needs N %% 32 == 0 (N=%d)", N);
+    STEM_CHECK_ARG(!y || ldy >= N, "stem_conv2d_f16x3_fwd: ldy < N");
+    STEM_CHECK_ARG((beta == nullptr) == (gamma == nullptr), "stem_conv2d_f16x3_fwd: beta and gamma come together");
     const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
-    STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_bf16x6_fwd: empty output");
+    STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_f16x3_fwd: empty output");
     const size_t xb = planes_payload((long)B * H * W, C), wb = w_image_bytes(C, R, S);
     STEM_CHECK_ARG(xb < 0x7FFFFF00ull && wb < 0x7FFFFF00ull && (size_t)B * OH * OW < 0x7FFFFFFFull,
-                   "stem_conv2d_bf16x6_fwd: operand views must stay below 2 GiB (split the batch)");
-    Bx6Args a;
+                   "stem_conv2d_f16x3_fwd: operand views must stay below 2 GiB (split the batch)");
+    Fx3Args a;
     memset(&a, 0, sizeof(a));
     a.xp = xp; a.wp = wp; a.bias = bias; a.beta = beta; a.gamma = gamma; a.y = y; a.yp = yp; a.ldy = ldy;
     a.xq = xq; a.yq = yq; a.wq = reinterpret_cast<const float *>(static_cast<const unsigned char *>(wp) + wb);
@@ -1093,60 +1098,60 @@ static int conv2d_bf16x6_launch(const void *xp, const float *xq, const void *wp,
         }
     static bool attr_done = false;      // > 64 KiB of dynamic LDS needs an explicit opt-in
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
         attr_done = true;
     }
     const int M = B * OH * OW;
     hipStream_t st = (hipStream_t)stream;
     // 128-pixel tiles (8 wavefronts) when they fill the 256 CUs at least once, 64-pixel tiles (4 wavefronts) below that
-    const int tile = stem_tuning(STEM_TUNE_BX6_TILE);
+    const int tile = stem_tuning(STEM_TUNE_FX3_TILE);
     const bool small = tile ? tile == 64 : cdiv(M, 128) < 256;
     if (small)
-        hipLaunchKernelGGL((conv_bf16x6_kernel<64>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
+        hipLaunchKernelGGL((conv_f16x3_kernel<64>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
     else
-        hipLaunchKernelGGL((conv_bf16x6_kernel<128>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
-    STEM_LAUNCH_CHECK("stem_conv2d_bf16x6_fwd");
+        hipLaunchKernelGGL((conv_f16x3_kernel<128>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
+    STEM_LAUNCH_CHECK("stem_conv2d_f16x3_fwd");
     return 0;
 }
 
 // ---- general variant: N tiles of 128, split-K, activation epilogues (training-time STEM layers) --------------------------------
-STEM_EXPORT size_t stem_bf16x3_conv_weight_gen_bytes(int N, int C, int R, int S)
+STEM_EXPORT size_t stem_f16x2_conv_weight_gen_bytes(int N, int C, int R, int S)
 {
     return C % 32 ? 0 : gen_image_bytes(N, C, R, S) + WQ_BYTES;
 }
 
-STEM_EXPORT int stem_bf16x3_pack_conv_weight_gen(const float *w, void *wp, int N, int C, int R, int S, int flip, void *stream)
+STEM_EXPORT int stem_f16x2_pack_conv_weight_gen(const float *w, void *wp, int N, int C, int R, int S, int flip, void *stream)
 {
     STEM_CHECK_ARG(w && wp && N >= 1 && C > 0 && C % 32 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP,
-                   "stem_bf16x3_pack_conv_weight_gen: C %% 32 == 0, R*S <= %d (N=%d C=%d R=%d S=%d)", MAXTAP, N, C, R, S);
+                   "stem_f16x2_pack_conv_weight_gen: C %% 32 == 0, R*S <= %d (N=%d C=%d R=%d S=%d)", MAXTAP, N, C, R, S);
     const long np = (long)cdiv(N, GBN) * (C / 32) * R * S * GBN * 4;
     float *wq = reinterpret_cast<float *>(static_cast<unsigned char *>(wp) + gen_image_bytes(N, C, R, S));
     amax_flat(w, (long)N * C * R * S, wq, (hipStream_t)stream);
     hipLaunchKernelGGL(pack_weight_gen_kernel, dim3((unsigned)cdivz(np, 256)), dim3(256), 0, (hipStream_t)stream, w,
                        static_cast<unsigned char *>(wp), N, C, R * S, flip, np, wq);
-    STEM_LAUNCH_CHECK("stem_bf16x3_pack_conv_weight_gen");
+    STEM_LAUNCH_CHECK("stem_f16x2_pack_conv_weight_gen");
     return 0;
 }
 
-STEM_EXPORT int stem_bf16x3_pack_conv_weights_multi(const stem_bf16x3_pack_desc *descs_host, int n, void *stream)
+STEM_EXPORT int stem_f16x2_pack_conv_weights_multi(const stem_f16x2_pack_desc *descs_host, int n, void *stream)
 {
-    STEM_CHECK_ARG(descs_host && n >= 1 && n <= MAXPACK, "stem_bf16x3_pack_conv_weights_multi: 1..%d descriptors per call, got %d", MAXPACK, n);
+    STEM_CHECK_ARG(descs_host && n >= 1 && n <= MAXPACK, "stem_f16x2_pack_conv_weights_multi: 1..%d descriptors per call, got %d", MAXPACK, n);
     size_t maxu = 0;
     for (int i = 0; i < n; ++i) {
-        const stem_bf16x3_pack_desc &d = descs_host[i];
+        const stem_f16x2_pack_desc &d = descs_host[i];
         STEM_CHECK_ARG(d.w && d.wp && d.N >= 1 && d.C > 0 && d.C % 32 == 0 && d.R >= 1 && d.S >= 1 && d.R * d.S <= MAXTAP,
-                       "stem_bf16x3_pack_conv_weights_multi: descriptor %d: C %% 32 == 0, R*S <= %d (N=%d C=%d R=%d S=%d)", i, MAXTAP, d.N, d.C, d.R, d.S);
+                       "stem_f16x2_pack_conv_weights_multi: descriptor %d: C %% 32 == 0, R*S <= %d (N=%d C=%d R=%d S=%d)", i, MAXTAP, d.N, d.C, d.R, d.S);
         const size_t nu = (size_t)cdiv(d.N, GBN) * (GBN / PKR) * (d.C / 32);
         if (nu > maxu) maxu = nu;
     }
     PackTable tab;
     memset(&tab, 0, sizeof(tab));
-    memcpy(tab.d, descs_host, n * sizeof(stem_bf16x3_pack_desc));
+    memcpy(tab.d, descs_host, n * sizeof(stem_f16x2_pack_desc));
     AmaxTable mt;                           // max |w| of every tensor first: the scale its image is stored with
     memset(&mt, 0, sizeof(mt));
     for (int i = 0; i < n; ++i) {
-        const stem_bf16x3_pack_desc &d = descs_host[i];
+        const stem_f16x2_pack_desc &d = descs_host[i];
         mt.w[i] = static_cast<const float *>(d.w);
         mt.q[i] = reinterpret_cast<float *>(static_cast<unsigned char *>(d.wp) + gen_image_bytes(d.N, d.C, d.R, d.S));
         mt.n[i] = (long)d.N * d.C * d.R * d.S;
@@ -1154,7 +1159,7 @@ STEM_EXPORT int stem_bf16x3_pack_conv_weights_multi(const stem_bf16x3_pack_desc 
     hipLaunchKernelGGL(amax_multi_kernel, dim3(WQ_SLOTS, n), dim3(256), 0, (hipStream_t)stream, mt);
     const unsigned gx = (unsigned)(maxu < 2048 ? maxu : 2048);
     hipLaunchKernelGGL(pack_weight_gen_multi_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, tab);
-    STEM_LAUNCH_CHECK("stem_bf16x3_pack_conv_weights_multi");
+    STEM_LAUNCH_CHECK("stem_f16x2_pack_conv_weights_multi");
     return 0;
 }
 
@@ -1165,10 +1170,10 @@ constexpr size_t kGenCntBytes = 64 * 1024;          // arrival counters in front
 // Split factor.  Two workgroups fit a CU; the launch runs in R = ceil(workgroups / 256) "CU rounds", each as long as one
 // workgroup's chunks (+ ~6 chunks of ramp-up per workgroup) -- except that a lone workgroup per CU (R = 1) leaves the matrix
 // pipes ~40 % idle (one wavefront per SIMD).  Every split also pays its slab in the reduction.  Measured on TPM.0 / .2 / .4
-// with splits 1..10 (tools/debug/bf16x6_gen_check.py, STEM_BX6_SPLIT): the model ranks them as measured, optimum 4 / 4 / 4.
+// with splits 1..10 (tools/debug/f16x3_gen_check.py, STEM_FX3_SPLIT): the model ranks them as measured, optimum 4 / 4 / 4.
 int gen_split(int tiles, int nchunks)
 {
-    const int forced = stem_tuning(STEM_TUNE_BX6_SPLIT);      // stem_tuning_set("bx6_split", n): tests / sweeps
+    const int forced = stem_tuning(STEM_TUNE_FX3_SPLIT);      // stem_tuning_set("fx3_split", n): tests / sweeps
     if (forced > 0) return forced < nchunks ? forced : nchunks;
     int best = 1;
     double best_cost = 1e30;
@@ -1184,7 +1189,7 @@ int gen_split(int tiles, int nchunks)
 }
 }   // namespace
 
-STEM_EXPORT size_t stem_conv2d_bf16x6_gen_workspace_bytes(int B, int H, int W, int C, int N, int R, int S, int stride, int pad)
+STEM_EXPORT size_t stem_conv2d_f16x3_gen_workspace_bytes(int B, int H, int W, int C, int N, int R, int S, int stride, int pad)
 {
     const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
     if (OH < 1 || OW < 1 || C % 32) return 0;
@@ -1194,27 +1199,27 @@ STEM_EXPORT size_t stem_conv2d_bf16x6_gen_workspace_bytes(int B, int H, int W, i
     return s > 1 ? kGenCntBytes + (size_t)s * M * cdiv(N, GBN) * GBN * sizeof(float) : 0;
 }
 
-STEM_EXPORT int stem_conv2d_bf16x6_gen_fwd(const void *xp, const float *xq, int xpix, const void *wp, const float *bias, int epi, float slope,
+STEM_EXPORT int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int xpix, const void *wp, const float *bias, int epi, float slope,
                                            const float *z, int ldz, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R,
                                            int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream)
 {
-    STEM_CHECK_ARG(xp && xq && wp && (y || yp) && (yq || !yp), "stem_conv2d_bf16x6_gen_fwd: null pointer (planes come with their scale records)");
-    STEM_CHECK_ARG(epi == GEN_EPI_BIAS || fabsf(slope) <= 1.f, "stem_conv2d_bf16x6_gen_fwd: |slope| <= 1");
+    STEM_CHECK_ARG(xp && xq && wp && (y || yp) && (yq || !yp), "stem_conv2d_f16x3_gen_fwd: null pointer (planes come with their scale records)");
+    STEM_CHECK_ARG(epi == GEN_EPI_BIAS || fabsf(slope) <= 1.f, "stem_conv2d_f16x3_gen_fwd: |slope| <= 1");
     STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && C >= 32 && C % 32 == 0 && N >= 4 && N % 4 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP &&
-                   stride >= 1 && pad >= 0, "stem_conv2d_bf16x6_gen_fwd: C %% 32 == 0, N %% 4 == 0, R*S <= %d (C=%d N=%d R=%d S=%d)", MAXTAP, C, N, R, S);
-    STEM_CHECK_ARG(!yp || N % 32 == 0, "stem_conv2d_bf16x6_gen_fwd: planes output needs N %% 32 == 0 (N=%d)", N);
-    STEM_CHECK_ARG(!y || (ldy >= N && ldy % 4 == 0 && ((uintptr_t)y & 15) == 0), "stem_conv2d_bf16x6_gen_fwd: y rows must be 16-byte aligned, ldy >= N");
-    STEM_CHECK_ARG(epi >= GEN_EPI_BIAS && epi <= GEN_EPI_DACT, "stem_conv2d_bf16x6_gen_fwd: unknown epilogue %d", epi);
-    STEM_CHECK_ARG(epi != GEN_EPI_DACT || (z && ldz >= N && ldz % 4 == 0 && ((uintptr_t)z & 15) == 0), "stem_conv2d_bf16x6_gen_fwd: DACT needs z (16-byte aligned rows)");
+                   stride >= 1 && pad >= 0, "stem_conv2d_f16x3_gen_fwd: C %% 32 == 0, N %% 4 == 0, R*S <= %d (C=%d N=%d R=%d S=%d)", MAXTAP, C, N, R, S);
+    STEM_CHECK_ARG(!yp || N % 32 == 0, "stem_conv2d_f16x3_gen_fwd: planes output needs N %% 32 == 0 (N=%d)", N);
+    STEM_CHECK_ARG(!y || (ldy >= N && ldy % 4 == 0 && ((uintptr_t)y & 15) == 0), "stem_conv2d_f16x3_gen_fwd: y rows must be 16-byte aligned, ldy >= N");
+    STEM_CHECK_ARG(epi >= GEN_EPI_BIAS && epi <= GEN_EPI_DACT, "stem_conv2d_f16x3_gen_fwd: unknown epilogue %d", epi);
+    STEM_CHECK_ARG(epi != GEN_EPI_DACT || (z && ldz >= N && ldz % 4 == 0 && ((uintptr_t)z & 15) == 0), "stem_conv2d_f16x3_gen_fwd: DACT needs z (16-byte aligned rows)");
     const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
-    STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_bf16x6_gen_fwd: empty output");
+    STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_f16x3_gen_fwd: empty output");
     if (xpix == 0) xpix = (C / 32) * SLAB;
-    STEM_CHECK_ARG(xpix >= (C / 32) * SLAB && xpix % SLAB == 0, "stem_conv2d_bf16x6_gen_fwd: xpix must be a multiple of %d bytes covering C channels", SLAB);
+    STEM_CHECK_ARG(xpix >= (C / 32) * SLAB && xpix % SLAB == 0, "stem_conv2d_f16x3_gen_fwd: xpix must be a multiple of %d bytes covering C channels", SLAB);
     const size_t xb = (size_t)B * H * W * xpix, wb = gen_image_bytes(N, C, R, S);
     const int M = B * OH * OW, ntn = cdiv(N, GBN), tiles = cdiv(M, GBM) * ntn, nchunks = (C / 32) * R * S;
     STEM_CHECK_ARG(xb < 0x7FFFFF00ull && wb < 0x7FFFFF00ull && (size_t)M * ntn * GBN * 4 < 0x7FFFFF00ull,
-                   "stem_conv2d_bf16x6_gen_fwd: operand views must stay below 2 GiB (split the batch)");
-    Bx6Args a;
+                   "stem_conv2d_f16x3_gen_fwd: operand views must stay below 2 GiB (split the batch)");
+    Fx3Args a;
     memset(&a, 0, sizeof(a));
     a.xp = xp; a.wp = wp; a.bias = bias; a.y = y; a.yp = yp; a.ldy = ldy; a.z = z; a.ldz = ldz; a.epi = epi; a.slope = slope;
     a.xq = xq; a.yq = yq; a.wq = reinterpret_cast<const float *>(static_cast<const unsigned char *>(wp) + wb);
@@ -1238,11 +1243,11 @@ STEM_EXPORT int stem_conv2d_bf16x6_gen_fwd(const void *xp, const float *xq, int 
     }
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)conv_bf16x6_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
         attr_done = true;
     }
     const dim3 grid(cdiv(M, GBM), ntn, a.nsplit);
-        hipLaunchKernelGGL(conv_bf16x6_gen_kernel, grid, dim3(GNT), GLDS, (hipStream_t)stream, a);
-    STEM_LAUNCH_CHECK("stem_conv2d_bf16x6_gen_fwd");
+        hipLaunchKernelGGL(conv_f16x3_gen_kernel, grid, dim3(GNT), GLDS, (hipStream_t)stream, a);
+    STEM_LAUNCH_CHECK("stem_conv2d_f16x3_gen_fwd");
     return 0;
 }

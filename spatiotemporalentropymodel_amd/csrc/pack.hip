@@ -25,18 +25,18 @@ STEM_EXPORT int stem_built_with_experiments(void)
 }
 
 static int g_tuning[STEM_TUNE_COUNT] = {0};
-static const char *const kTuningNames[STEM_TUNE_COUNT] = {"bx6_tile", "bx6_split", "wg6_split", "arp_workers"};
+static const char *const kTuningNames[STEM_TUNE_COUNT] = {"fx3_tile", "fx3_split", "wg3_split", "arp_workers"};
 int stem_tuning(int id) { return g_tuning[id]; }
 STEM_EXPORT int stem_tuning_set(const char *name, int value)
 {
     STEM_CHECK_ARG(name && value >= 0, "stem_tuning_set: null name or negative value");
     for (int i = 0; i < STEM_TUNE_COUNT; ++i)
         if (!strcmp(name, kTuningNames[i])) {
-            STEM_CHECK_ARG(i != STEM_TUNE_BX6_TILE || value == 0 || value == 64 || value == 128, "stem_tuning_set: bx6_tile is 0 (automatic), 64 or 128");
+            STEM_CHECK_ARG(i != STEM_TUNE_FX3_TILE || value == 0 || value == 64 || value == 128, "stem_tuning_set: fx3_tile is 0 (automatic), 64 or 128");
             g_tuning[i] = value;
             return 0;
         }
-    stem_set_error("stem_tuning_set: unknown selector '%s' (bx6_tile, bx6_split, wg6_split, arp_workers)", name);
+    stem_set_error("stem_tuning_set: unknown selector '%s' (fx3_tile, fx3_split, wg3_split, arp_workers)", name);
     return -1;
 }
 STEM_EXPORT int stem_tuning_get(const char *name)
@@ -248,7 +248,7 @@ __global__ void copy2d_kernel(const float *src, int lds, float *dst, int ldd, si
 }
 
 // 1024 pixels per workgroup; q (optional): scale record of the image, one slot of max |x| per workgroup (stem_common.h) --
-// what the first-layer kernel c4gdn_bf16x6.hip scales its in-register fp16 split of the patches by
+// what the first-layer kernel c4gdn_f16x3.hip scales its in-register fp16 split of the patches by
 __global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const float *x, f32x4 *y, size_t HW, size_t total, float *q)
 {
     __shared__ float qred[16];

@@ -39,11 +39,11 @@ static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 // Plan selectors (a tile shape, a split factor: every choice computes the same contraction, differing at most in summation
 // order) are integers set through the exported stem_tuning_set() -- tests and sweep tools use them; nothing reads the
 // environment per launch.
-enum { STEM_TUNE_BX6_TILE = 0, STEM_TUNE_BX6_SPLIT, STEM_TUNE_WG6_SPLIT, STEM_TUNE_ARP_WORKERS, STEM_TUNE_COUNT };
+enum { STEM_TUNE_FX3_TILE = 0, STEM_TUNE_FX3_SPLIT, STEM_TUNE_WG3_SPLIT, STEM_TUNE_ARP_WORKERS, STEM_TUNE_COUNT };
 int stem_tuning(int id);
-// Switches that CHANGE RESULTS (fewer bf16 products per fp32 product, ablated kernel stages) exist only in a library built
-// with -DSTEM_EXPERIMENTS (`make EXPERIMENTS=1` -> libstem_hip_exper.so, for tools/debug): in the shipped library the macro
-// below is a constant null pointer and the reduced-precision kernel variants are not even instantiated.
+// Switches that CHANGE RESULTS (ablated kernel stages, instrumentation) exist only in a library built with
+// -DSTEM_EXPERIMENTS (`make experiments` -> libstem_hip_exper.so, for tools/debug): in the shipped library the macro below is
+// a constant null pointer.
 #ifdef STEM_EXPERIMENTS
 #include <stdlib.h>
 #define STEM_EXPER_ENV(name) getenv(name)
@@ -51,7 +51,7 @@ int stem_tuning(int id);
 #define STEM_EXPER_ENV(name) (static_cast<const char *>(nullptr))
 #endif
 
-// ---- the 16-bit operands of the split-operand kernels (conv_bf16x6 / wgrad_bf16x6 / c4gdn_bf16x6) -------------------------------
+// ---- the 16-bit operands of the split-operand kernels (conv_f16x3 / wgrad_f16x3 / c4gdn_f16x3) -------------------------------
 // Every fp32 value a travels as TWO fp16 numbers a0 = rn(a * 2^e), a1 = rn(a * 2^e - a0): |a * 2^e - a0 - a1| <= 2^-22 |a| 2^e
 // (two 11-bit significands), and the three products a0.b0, a0.b1, a1.b0 are exact in the MFMA's fp32 accumulator input, so
 // three v_mfma_f32_32x32x16_f16 carry an fp32 product to ~2^-21 (the dropped a1.b1 is <= 2^-22 |a.b|).  fp16 has 5 exponent

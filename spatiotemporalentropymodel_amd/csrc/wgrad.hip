@@ -575,10 +575,10 @@ int colsum(const float *dy, int ld, size_t npix, int K, float *scratch, float *d
 
 }   // namespace
 
-// bias gradient on its own (for the weight-gradient kernel of wgrad_bf16x6.hip, which does not touch the fp32 dy)
+// bias gradient on its own (for the weight-gradient kernel of wgrad_f16x3.hip, which does not touch the fp32 dy)
 STEM_EXPORT size_t stem_bias_grad_scratch_elems(long npix, int K) { return (size_t)colsum_parts((size_t)npix, K) * K; }
 
-/* second stage only: db (+)= sum over `parts` rows of part[parts][K] (first stage done by stem_conv2d_wgrad_bf16x6) */
+/* second stage only: db (+)= sum over `parts` rows of part[parts][K] (first stage done by stem_conv2d_wgrad_f16x3) */
 STEM_EXPORT int stem_bias_grad_final(const float *part, int K, int parts, float *db, int accumulate, void *stream)
 {
     STEM_CHECK_ARG(part && db && K >= 1 && parts >= 1, "stem_bias_grad_final: bad arguments");

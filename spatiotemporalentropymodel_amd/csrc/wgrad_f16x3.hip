@@ -1,18 +1,17 @@
-// Weight gradient of a stride-1 convolution on the bf16 matrix cores with fp32-exact products (see conv_bf16x6.hip for the
-// arithmetic: operands pre-split into three bf16 planes, six MFMAs per fp32 product, fp32 accumulate).
+// Weight gradient of a stride-1 convolution on the fp16 matrix cores with fp32-class products (see conv_f16x3.hip for the
+// arithmetic: operands pre-split into two fp16 planes, three MFMAs per fp32 product, fp32 accumulate).
 //
 //   dW[k][c][r][s] = sum over output pixels m = (b, y, x) of dy[m][k] * x[b, y + r - pad, x + s - pad][c]
 //
 // Per tap this is a GEMM dW_t[K x C] = dY^T[K x M] . X_t[M x C] whose contraction runs over PIXELS, while both operands are
-// stored pixel-major ([pixel][C/32][3][32] bf16).  The MFMA wants, per lane, 8 consecutive contraction elements of one row /
+// stored pixel-major ([pixel][C/32][2][32] fp16).  The MFMA wants, per lane, 8 consecutive contraction elements of one row /
 // column, i.e. 8 pixels of one channel: the chunk (16 pixels x 128 channels per operand and plane) is staged in LDS as it comes
 // (256-byte pixel rows) and read back with gfx950's transposing LDS read (ds_read_b64_tr_b16: a 4-pixel x 16-channel block per
 // 16 lanes, delivered channel-major) -- two reads per operand fragment, no shuffles.  LDS image: the guide's 256-byte-row form
 // off(row, chunk) = 256 row + 16 (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))), conflict-free for these reads.
 //
-// Workgroup: 128 (k) x 128 (c) outputs of ONE tap over a range of pixels, 4 wavefronts x (64 x 64), 48 KiB of LDS (two workgroups
-// per CU); grid = (k tiles x c tiles,
-// taps, pixel splits); partial sums go to slabs [split][tap][K][C] -- the layout of wgrad.hip, summed and transposed into the
+// Workgroup: 128 (k) x 128 (c) outputs of ONE tap over a range of pixels, 4 wavefronts x (64 x 64), 32 KiB of LDS (two workgroups
+// per CU); grid = (k tiles x c tiles, taps, pixel splits); partial sums go to slabs [split][tap][K][C] -- the layout of wgrad.hip, summed and transposed into the
 // torch layout by stem_unpack_wgrads_multi.  The tap's shift is applied when the x rows are fetched (rows outside the image read
 // as zeros through the range-checked buffer loads).
 #include <stdlib.h>
@@ -21,7 +20,7 @@
 
 namespace {
 
-typedef hp8 bf16x8;
+typedef hp8 h16x8;
 typedef short v4s __attribute__((ext_vector_type(4)));
 
 constexpr int TK = 128, TC = 128, NT = 256, PX = 16;      // output tile, threads, pixels per chunk (= one MFMA k-step)
@@ -32,7 +31,7 @@ constexpr int LDS_BYTES = 2 * 2 * OP_BUF;                  // 32768: two workgro
 constexpr int OOR = 0x7FFFFF00;
 constexpr int MAXTAP = 25;
 
-struct Wg6Args {
+struct Wg3Args {
     const void *xp, *dyp;
     const float *xq, *dyq;         // scale records of the two planes tensors (stem_common.h)
     float *dwp;
@@ -46,7 +45,7 @@ struct Wg6Args {
 
 __device__ inline int lds_off(int row, int chunk) { return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
-__device__ inline bf16x8 tr_frag(const unsigned char *base, int a0, int a1)
+__device__ inline h16x8 tr_frag(const unsigned char *base, int a0, int a1)
 {
     // two transposing reads: pixels 8h .. 8h+3 and 8h+4 .. 8h+7 of this lane's channel
     typedef __attribute__((address_space(3))) v4s *lp;
@@ -54,14 +53,14 @@ __device__ inline bf16x8 tr_frag(const unsigned char *base, int a0, int a1)
     const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + a1));
     typedef short v8s __attribute__((ext_vector_type(8)));
     const v8s v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(h16x8, v);
 }
 
-__global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
+__global__ __launch_bounds__(NT, 2) void wgrad_f16x3_kernel(const Wg3Args a)
 {
     constexpr int PL = NPL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *As = smem;                        // [2][3][16 px][256 B]   dy
+    unsigned char *As = smem;                        // [2][NPL][16 px][256 B]   dy
     unsigned char *Bs = smem + 2 * OP_BUF;           // [2][NPL][16 px][256 B]   x (shifted by the tap)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -142,7 +141,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
 
     auto step = [&](int cur, f32x4 (&ra)[PL], f32x4 (&rb)[PL], int qcur, int qn) {
         const unsigned char *Ab = As + cur * OP_BUF, *Bb = Bs + cur * OP_BUF;
-        bf16x8 af[2][PL], bf[2][PL];
+        h16x8 af[2][PL], bf[2][PL];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -240,7 +239,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_bf16x6_kernel(const Wg6Args a)
 
 int plan_splits(int B, int OH, int OW, int C, int K, int T)
 {
-    const int forced = stem_tuning(STEM_TUNE_WG6_SPLIT);      // stem_tuning_set("wg6_split", n): tests / sweeps
+    const int forced = stem_tuning(STEM_TUNE_WG3_SPLIT);      // stem_tuning_set("wg3_split", n): tests / sweeps
     const int nchunks = cdiv(B * OH * OW, PX), tiles = cdiv(K, TK) * cdiv(C, TC) * T;
     int s = forced > 0 ? forced : (512 + tiles / 2) / tiles;       // two workgroups per CU: aim at ~512 workgroups
     if (s < 1) s = 1;
@@ -251,29 +250,29 @@ int plan_splits(int B, int OH, int OW, int C, int K, int T)
 
 }   // namespace
 
-STEM_EXPORT int stem_wgrad_bf16x6_splits(int B, int H, int W, int C, int K, int R, int S, int pad)
+STEM_EXPORT int stem_wgrad_f16x3_splits(int B, int H, int W, int C, int K, int R, int S, int pad)
 {
     const int OH = H + 2 * pad - R + 1, OW = W + 2 * pad - S + 1;
     if (OH < 1 || OW < 1) return 0;
     return plan_splits(B, OH, OW, C, K, R * S);
 }
 
-STEM_EXPORT int stem_conv2d_wgrad_bf16x6(const void *xp, const float *xq, int xpix, const void *dyp, const float *dyq, int dypix, float *dwp,
+STEM_EXPORT int stem_conv2d_wgrad_f16x3(const void *xp, const float *xq, int xpix, const void *dyp, const float *dyq, int dypix, float *dwp,
                                          float *bias_part, int B, int H, int W, int C, int K, int R, int S, int pad, int splits, void *stream)
 {
-    STEM_CHECK_ARG(xp && xq && dyp && dyq && dwp, "stem_conv2d_wgrad_bf16x6: null pointer");
+    STEM_CHECK_ARG(xp && xq && dyp && dyq && dwp, "stem_conv2d_wgrad_f16x3: null pointer");
     STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && C >= 32 && C % 32 == 0 && K >= 32 && K % 32 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP && pad >= 0,
-                   "stem_conv2d_wgrad_bf16x6: C %% 32 == 0, K %% 32 == 0, R*S <= %d (C=%d K=%d R=%d S=%d)", MAXTAP, C, K, R, S);
+                   "stem_conv2d_wgrad_f16x3: C %% 32 == 0, K %% 32 == 0, R*S <= %d (C=%d K=%d R=%d S=%d)", MAXTAP, C, K, R, S);
     const int OH = H + 2 * pad - R + 1, OW = W + 2 * pad - S + 1;
-    STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_wgrad_bf16x6: empty output");
+    STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_wgrad_f16x3: empty output");
     if (xpix == 0) xpix = (C / 32) * SLAB;
     if (dypix == 0) dypix = (K / 32) * SLAB;
     STEM_CHECK_ARG(xpix >= (C / 32) * SLAB && xpix % SLAB == 0 && dypix >= (K / 32) * SLAB && dypix % SLAB == 0,
-                   "stem_conv2d_wgrad_bf16x6: pixel pitches must be multiples of %d bytes covering the channels", SLAB);
+                   "stem_conv2d_wgrad_f16x3: pixel pitches must be multiples of %d bytes covering the channels", SLAB);
     const size_t xb = (size_t)B * H * W * xpix, db = (size_t)B * OH * OW * dypix;
-    STEM_CHECK_ARG(xb < 0x7FFFFF00ull && db < 0x7FFFFF00ull, "stem_conv2d_wgrad_bf16x6: operand views must stay below 2 GiB");
-    STEM_CHECK_ARG(splits == plan_splits(B, OH, OW, C, K, R * S), "stem_conv2d_wgrad_bf16x6: splits must come from stem_wgrad_bf16x6_splits");
-    Wg6Args a;
+    STEM_CHECK_ARG(xb < 0x7FFFFF00ull && db < 0x7FFFFF00ull, "stem_conv2d_wgrad_f16x3: operand views must stay below 2 GiB");
+    STEM_CHECK_ARG(splits == plan_splits(B, OH, OW, C, K, R * S), "stem_conv2d_wgrad_f16x3: splits must come from stem_wgrad_f16x3_splits");
+    Wg3Args a;
     memset(&a, 0, sizeof(a));
     a.xp = xp; a.dyp = dyp; a.xq = xq; a.dyq = dyq; a.dwp = dwp; a.bias_part = bias_part; a.xpix = xpix; a.dypix = dypix;
     a.B = B; a.H = H; a.W = W; a.C = C; a.K = K; a.OH = OH; a.OW = OW; a.T = R * S;
@@ -288,11 +287,11 @@ STEM_EXPORT int stem_conv2d_wgrad_bf16x6(const void *xp, const float *xq, int xp
         }
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)wgrad_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void *)wgrad_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_done = true;
     }
     const dim3 grid(cdiv(K, TK) * cdiv(C, TC), R * S, splits);
-        hipLaunchKernelGGL(wgrad_bf16x6_kernel, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
-    STEM_LAUNCH_CHECK("stem_conv2d_wgrad_bf16x6");
+        hipLaunchKernelGGL(wgrad_f16x3_kernel, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+    STEM_LAUNCH_CHECK("stem_conv2d_wgrad_f16x3");
     return 0;
 }

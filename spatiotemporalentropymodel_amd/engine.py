@@ -35,23 +35,23 @@ class _Layer:
         self.masked = getattr(mod, "_masked", 0)
         self.wp_fwd = self.wp_dgrad = None
         self.need_dgrad = True
-        # forward / input-gradient on the bf16 matrix cores (csrc/conv_bf16x6.hip, general variant): stride-1 convolutions whose
-        # contraction channels are multiples of 32; decided once by the engine (StemEngine._select_bx6)
-        self.bx6 = False
-        self.wg6 = False
+        # forward / input-gradient on the fp16 matrix cores (csrc/conv_f16x3.hip, general variant): stride-1 convolutions whose
+        # contraction channels are multiples of 32; decided once by the engine (StemEngine._select_fx3)
+        self.fx3 = False
+        self.wg3 = False
         self.wp6_fwd = self.wp6_dgrad = None
         self._slabs = {}
         self.pending = None       # (dwp, splits) of the last wgrad, consumed by StemEngine.unpack_all
         self.lane = 0             # which weight-gradient stream this layer's wgrad / unpack runs on (StemEngine.side_stream)
 
-    def bx6_eligible(self):
+    def fx3_eligible(self):
         return (self.kind == "conv" and self.stride == 1 and not self.masked and self.C % 32 == 0 and self.K % 32 == 0
                 and self.R * self.R <= 25 and self.pad == self.R // 2)
 
     def alloc_packs(self, device):
-        if self.bx6:
-            self.wp6_fwd = torch.empty(F.bf16x3_gen_weight_bytes(self.K, self.C, self.R, self.R), device=device, dtype=torch.uint8)
-            self.wp6_dgrad = torch.empty(F.bf16x3_gen_weight_bytes(self.C, self.K, self.R, self.R), device=device,
+        if self.fx3:
+            self.wp6_fwd = torch.empty(F.f16x2_gen_weight_bytes(self.K, self.C, self.R, self.R), device=device, dtype=torch.uint8)
+            self.wp6_dgrad = torch.empty(F.f16x2_gen_weight_bytes(self.C, self.K, self.R, self.R), device=device,
                                          dtype=torch.uint8) if self.need_dgrad else None
             return
         n = self.K * self.C * self.R * self.R
@@ -60,51 +60,51 @@ class _Layer:
 
     def pack_descs6(self):
         w = self.mod.weight
-        out = [_lib.Bf16PackDesc(w.data_ptr(), self.wp6_fwd.data_ptr(), self.K, self.C, self.R, self.R, 0, 0)]
+        out = [_lib.F16PackDesc(w.data_ptr(), self.wp6_fwd.data_ptr(), self.K, self.C, self.R, self.R, 0, 0)]
         if self.need_dgrad:       # the input-gradient of a stride-1 convolution is a convolution with the mirrored, transposed weight
-            out.append(_lib.Bf16PackDesc(w.data_ptr(), self.wp6_dgrad.data_ptr(), self.C, self.K, self.R, self.R, 1, 0))
+            out.append(_lib.F16PackDesc(w.data_ptr(), self.wp6_dgrad.data_ptr(), self.C, self.K, self.R, self.R, 1, 0))
         return out
 
     def fwd6(self, xp, act=F.ACT_NONE, out=None, planes=False):
-        """-> (fp32 output, planes output or None); `xp` a Bf16Planes (possibly a channel view)"""
-        return F.conv2d_bf16x6_gen(xp, self.wp6_fwd, self.mod.bias, self.K, self.R, self.R, 1, self.pad,
+        """-> (fp32 output, planes output or None); `xp` a F16Planes (possibly a channel view)"""
+        return F.conv2d_f16x3_gen(xp, self.wp6_fwd, self.mod.bias, self.K, self.R, self.R, 1, self.pad,
                                    epi=F.GEN_EPI_LRELU if act == F.ACT_LRELU else F.GEN_EPI_BIAS, out=out, want_planes=planes)
 
     def dgrad6(self, dyp, xact=None, planes=False):
         """-> (dx fp32, dx planes or None); xact: the activated input of this layer (leaky-ReLU derivative folded in)"""
-        return F.conv2d_bf16x6_gen(dyp, self.wp6_dgrad, None, self.C, self.R, self.R, 1, self.pad,
+        return F.conv2d_f16x3_gen(dyp, self.wp6_dgrad, None, self.C, self.R, self.R, 1, self.pad,
                                    epi=F.GEN_EPI_DACT if xact is not None else F.GEN_EPI_BIAS, z=xact, want_planes=planes)
 
-    def wg6_eligible(self):
-        """weight gradient on csrc/wgrad_bf16x6.hip: stride-1 convolutions (all taps are produced, as autograd does for the
+    def wg3_eligible(self):
+        """weight gradient on csrc/wgrad_f16x3.hip: stride-1 convolutions (all taps are produced, as autograd does for the
         masked context convolution too)"""
         return (self.kind == "conv" and self.stride == 1 and self.C % 32 == 0 and self.K % 32 == 0 and self.R * self.R <= 25
                 and self.pad == self.R // 2)
 
     def wgrad_any(self, x, dy, xp=None, dyp=None):
-        """weight + bias gradient from the planes operands when this layer runs its weight gradient on the bf16 kernel and both
+        """weight + bias gradient from the planes operands when this layer runs its weight gradient on the fp16 kernel and both
         are at hand, else from the fp32 tensors"""
-        if not (self.wg6 and xp is not None and dyp is not None):
+        if not (self.wg3 and xp is not None and dyp is not None):
             return self.wgrad(x, dy)
         side = self.eng.side_stream(dy.device, self.lane)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(dy.device))
             with torch.cuda.stream(side):
-                self._wgrad6(xp, dyp, dy)
+                self._wgrad3(xp, dyp, dy)
             for t in (xp.data, dyp.data, dy):
                 t.record_stream(side)
         else:
-            self._wgrad6(xp, dyp, dy)
+            self._wgrad3(xp, dyp, dy)
 
-    def _wgrad6(self, xp, dyp, dy):
-        key = ("bf16",) + tuple(xp.shape)
+    def _wgrad3(self, xp, dyp, dy):
+        key = ("fp16",) + tuple(xp.shape)
         if key not in self._slabs:
-            splits, elems = F.wgrad_bf16x6_plan(xp.shape, self.K, self.R, self.R, self.pad)
+            splits, elems = F.wgrad_f16x3_plan(xp.shape, self.K, self.R, self.R, self.pad)
             self._slabs[key] = (torch.empty(elems, device=dy.device, dtype=torch.float32), splits,
                                 torch.empty(splits * self.K, device=dy.device, dtype=torch.float32))
         dwp, splits, bpart = self._slabs[key]
         gb = _grad_of(self.mod.bias) if self.mod.bias is not None else None
-        F.conv2d_wgrad_bf16x6(xp, dyp, self.K, self.R, self.R, self.pad, dwp, splits, db=gb, bias_part=bpart, accumulate_db=True)
+        F.conv2d_wgrad_f16x3(xp, dyp, self.K, self.R, self.R, self.pad, dwp, splits, db=gb, bias_part=bpart, accumulate_db=True)
         self.pending = (dwp, splits)
 
     def pack_descs(self):
@@ -119,8 +119,8 @@ class _Layer:
 
     def fwd(self, x, act=F.ACT_NONE, out=None):
         self.eng.ensure_packed()
-        if self.bx6:          # callers outside the training schedule (codec.py) hand over fp32 tensors
-            return self.fwd6(F.Bf16Planes.split(x), act, out=out)[0]
+        if self.fx3:          # callers outside the training schedule (codec.py) hand over fp32 tensors
+            return self.fwd6(F.F16Planes.split(x), act, out=out)[0]
         m = self.mod
         if self.kind == "conv":
             if self.masked and not self.masked & 4:
@@ -207,30 +207,30 @@ class StemEngine:
         if self.wgrad_lanes > 1:
             for l in self.HE + self.HD:
                 l.lane = 1
-        self._select_bx6()
+        self._select_fx3()
 
-    def _select_bx6(self):
-        """Which layers run on the bf16 kernels.  HE.0 and HD.4 are routed one by one; the TPM and EPM chains hand planes from
+    def _select_fx3(self):
+        """Which layers run on the fp16 kernels.  HE.0 and HD.4 are routed one by one; the TPM and EPM chains hand planes from
         layer to layer (and the EPM input gradient is read through channel views at multiples of P = 2 * Cin), so each chain is
-        routed as a whole: bf16 only if EVERY layer of it is eligible (channel counts multiples of 32) and, for the EPM, the
+        routed as a whole: fp16 only if EVERY layer of it is eligible (channel counts multiples of 32) and, for the EPM, the
         views are 32-aligned -- otherwise the whole chain stays on the fp32-MFMA kernels, which only need C % 4 == 0."""
         for l in self.layers:
-            l.bx6 = self.use_bx6 and l.bx6_eligible()
+            l.fx3 = self.use_fx3 and l.fx3_eligible()
         P = self.HE[0].C                                # HE.0 reads cat(y_cur, y_cond): its C is 2 * Cin = P
         for group, need_aligned in ((self.TPM, False), (self.EPM, True)):
-            if group and not (all(l.bx6 for l in group) and (not need_aligned or P % 32 == 0)):
+            if group and not (all(l.fx3 for l in group) and (not need_aligned or P % 32 == 0)):
                 for l in group:
-                    l.bx6 = False
+                    l.fx3 = False
         for l in self.layers:
             # weight gradients take whatever planes the forward / input-gradient route left behind (wgrad_any falls back to the
             # fp32 kernel when there are none), so they follow the layer's own eligibility
-            l.wg6 = self.use_bx6 and self.use_wg6 and l.wg6_eligible()
+            l.wg3 = self.use_fx3 and self.use_wg3 and l.wg3_eligible()
 
-    #: forward and input-gradient of the stride-1 layers (TPM, HE.0, HD.4, EPM) on the bf16 matrix cores with fp32-exact products
-    #: (six bf16 MFMAs per fp32 product, csrc/conv_bf16x6.hip); STEM_ENGINE_BF16X6=0 keeps every layer on the fp32-MFMA kernels
-    use_bx6 = os.environ.get("STEM_ENGINE_BF16X6", "1") != "0"
-    #: ... and their weight gradients (csrc/wgrad_bf16x6.hip); STEM_ENGINE_WGRAD_BF16X6=0 keeps those on wgrad.hip
-    use_wg6 = os.environ.get("STEM_ENGINE_WGRAD_BF16X6", "1") != "0"
+    #: forward and input-gradient of the stride-1 layers (TPM, HE.0, HD.4, EPM) on the fp16 matrix cores with fp32-exact products
+    #: (three fp16 MFMAs per fp32 product, csrc/conv_f16x3.hip); STEM_ENGINE_F16X3=0 keeps every layer on the fp32-MFMA kernels
+    use_fx3 = os.environ.get("STEM_ENGINE_F16X3", "1") != "0"
+    #: ... and their weight gradients (csrc/wgrad_f16x3.hip); STEM_ENGINE_WGRAD_F16X3=0 keeps those on wgrad.hip
+    use_wg3 = os.environ.get("STEM_ENGINE_WGRAD_F16X3", "1") != "0"
 
     #: weight gradients (wgrad + bias column sums + unpack + the data-parallel exchange hook) run on their own stream
     #: and overlap the latency-bound parts of the dgrad chain; set False to keep everything on the compute stream
@@ -282,7 +282,7 @@ class StemEngine:
             return
         stale = False
         for l in self.layers:
-            have = l.wp6_fwd if l.bx6 else l.wp_fwd
+            have = l.wp6_fwd if l.fx3 else l.wp_fwd
             stale = stale or have is None or have.device != l.mod.weight.device
         if stale:
             for l in self.layers:
@@ -296,12 +296,12 @@ class StemEngine:
             if on_side:
                 side.wait_stream(torch.cuda.current_stream(dev))      # the optimiser step that changed the weights
             with (torch.cuda.stream(side) if on_side else contextlib.nullcontext()):
-                descs = [d for l in self.layers if not l.bx6 for d in l.pack_descs()[lo:hi]]
+                descs = [d for l in self.layers if not l.fx3 for d in l.pack_descs()[lo:hi]]
                 if descs:
                     F.pack_weights_multi((_lib.PackDesc * len(descs))(*descs))
-                descs6 = [d for l in self.layers if l.bx6 for d in l.pack_descs6()[lo:hi]]
+                descs6 = [d for l in self.layers if l.fx3 for d in l.pack_descs6()[lo:hi]]
                 if descs6:
-                    F.pack_weights_bf16x3_multi((_lib.Bf16PackDesc * len(descs6))(*descs6))
+                    F.pack_weights_f16x2_multi((_lib.F16PackDesc * len(descs6))(*descs6))
                 if on_side:
                     self._dgrad_pack_event = torch.cuda.Event()
                     self._dgrad_pack_event.record(side)
@@ -395,10 +395,10 @@ class StemEngine:
                 self.CTX.fwd(t_hat, out=epm_in[:, o_ctx:o_ctx + P])
             t_hat.record_stream(cs)
             epm_in.record_stream(cs)
-        split = F.Bf16Planes.split
+        split = F.F16Planes.split
         pl = {}             # planes copies of activations, kept for the weight gradients
         with (torch.cuda.stream(bs) if bs is not None else contextlib.nullcontext()):
-            if self.HE[0].bx6:
+            if self.HE[0].fx3:
                 pl["he_in"] = split(he_in)
                 he0 = self.HE[0].fwd6(pl["he_in"], F.ACT_LRELU)[0]
             else:
@@ -415,13 +415,13 @@ class StemEngine:
             # hyper decoder; its last conv writes the `hp` slice of the EPM input
             hd0 = self.HD[0].fwd(z_hat, F.ACT_LRELU)
             hd2 = self.HD[1].fwd(hd0, F.ACT_LRELU)
-            if self.HD[2].bx6:
+            if self.HD[2].fx3:
                 pl["hd2"] = split(hd2)
                 self.HD[2].fwd6(pl["hd2"], out=epm_in[:, o_hp:o_hp + P])
             else:
                 self.HD[2].fwd(hd2, out=epm_in[:, o_hp:o_hp + P])
         tp0 = tp2 = None
-        if self.has_tpm and self.TPM[0].bx6:
+        if self.has_tpm and self.TPM[0].fx3:
             # planes travel from layer to layer (written by the producing epilogue next to the fp32 copy backward needs)
             pl["yd"] = split(yd)
             tp0, pl["tp0"] = self.TPM[0].fwd6(pl["yd"], F.ACT_LRELU, planes=True)
@@ -443,7 +443,7 @@ class StemEngine:
                 self.CTX.fwd(t_hat, out=epm_in[:, o_ctx:o_ctx + P])
         if bs is not None:
             main.wait_stream(bs)
-        if self.EPM[0].bx6:
+        if self.EPM[0].fx3:
             pl["epm_in"] = split(epm_in)
             e0, pl["e0"] = self.EPM[0].fwd6(pl["epm_in"], F.ACT_LRELU, planes=True)
             e2, pl["e2"] = self.EPM[1].fwd6(pl["e0"], F.ACT_LRELU, planes=True)
@@ -489,8 +489,8 @@ class StemEngine:
         # EPM (1x1 chain)
         dprip = None
         pl = k.get("planes", {})
-        if self.EPM[0].bx6:
-            dgpp = F.Bf16Planes.split(dgp)
+        if self.EPM[0].fx3:
+            dgpp = F.F16Planes.split(dgp)
             self.EPM[2].wgrad_any(k["e2"], dgp, pl.get("e2"), dgpp)
             de2, de2p = self.EPM[2].dgrad6(dgpp, xact=k["e2"], planes=True)
             self.EPM[1].wgrad_any(k["e0"], de2, pl.get("e0"), de2p)
@@ -513,19 +513,19 @@ class StemEngine:
                 self._backward_hyper(k, dpri, dlik_z, dprip)
         # spatial prior: weight gradient of all 25 taps, no input gradient (its input is data + noise)
         if self.has_spm:
-            if self.CTX.wg6 and dprip is not None:
-                self.CTX.wgrad_any(k["t_hat"], dpri[:, o_ctx:o_ctx + P], F.Bf16Planes.split(k["t_hat"]), dprip.channels(o_ctx, o_ctx + P))
+            if self.CTX.wg3 and dprip is not None:
+                self.CTX.wgrad_any(k["t_hat"], dpri[:, o_ctx:o_ctx + P], F.F16Planes.split(k["t_hat"]), dprip.channels(o_ctx, o_ctx + P))
             else:
                 self.CTX.wgrad(k["t_hat"], dpri[:, o_ctx:o_ctx + P])
             self._group_ready([self.CTX], [])
         if self.has_tpm:
             dtp = dpri[:, o_tp:o_tp + P]
-            if self.TPM[2].bx6:
-                dtpp = dprip.channels(o_tp, o_tp + P) if dprip is not None else F.Bf16Planes.split(dtp)
+            if self.TPM[2].fx3:
+                dtpp = dprip.channels(o_tp, o_tp + P) if dprip is not None else F.F16Planes.split(dtp)
                 self.TPM[2].wgrad_any(k["tp2"], dtp, pl.get("tp2"), dtpp)
                 d, dp = self.TPM[2].dgrad6(dtpp, xact=k["tp2"], planes=True)
                 self.TPM[1].wgrad_any(k["tp0"], d, pl.get("tp0"), dp)
-                d, dp = self.TPM[1].dgrad6(dp, xact=k["tp0"], planes=self.TPM[0].wg6)
+                d, dp = self.TPM[1].dgrad6(dp, xact=k["tp0"], planes=self.TPM[0].wg3)
                 self.TPM[0].wgrad_any(k["yd"], d, pl.get("yd"), dp)
             else:
                 self.TPM[2].wgrad(k["tp2"], dtp)
@@ -547,8 +547,8 @@ class StemEngine:
         # hyper decoder
         dhp = dpri[:, o_hp:o_hp + P]
         pl = k.get("planes", {})
-        if self.HD[2].bx6:
-            dhpp = dprip.channels(o_hp, o_hp + P) if dprip is not None else F.Bf16Planes.split(dhp)
+        if self.HD[2].fx3:
+            dhpp = dprip.channels(o_hp, o_hp + P) if dprip is not None else F.F16Planes.split(dhp)
             self.HD[2].wgrad_any(k["hd2"], dhp, pl.get("hd2"), dhpp)
             d = self.HD[2].dgrad6(dhpp, xact=k["hd2"])[0]
         else:
@@ -568,7 +568,7 @@ class StemEngine:
         d = self.HE[2].dgrad(dz, k["he2"].shape, xact=k["he2"])
         self.HE[1].wgrad(k["he0"], d)
         d = self.HE[1].dgrad(d, k["he0"].shape, xact=k["he0"])
-        self.HE[0].wgrad_any(k["he_in"], d, pl.get("he_in"), F.Bf16Planes.split(d) if self.HE[0].wg6 and "he_in" in pl else None)
+        self.HE[0].wgrad_any(k["he_in"], d, pl.get("he_in"), F.F16Planes.split(d) if self.HE[0].wg3 and "he_in" in pl else None)
         self._group_ready(self.HE, [])
 
 

@@ -90,8 +90,8 @@ def _ptr(t):
 
 
 class tuning:
-    """`with F.tuning(bx6_split=3): ...` -- force a plan selector of the library (stem_tuning_set: "bx6_tile", "bx6_split",
-    "wg6_split") for the calls inside the block; tests and sweep tools only.  The workspace-size cache of the general bf16
+    """`with F.tuning(fx3_split=3): ...` -- force a plan selector of the library (stem_tuning_set: "fx3_tile", "fx3_split",
+    "wg3_split") for the calls inside the block; tests and sweep tools only.  The workspace-size cache of the general fp16
     kernel depends on the split factor and is dropped on entry and exit."""
 
     def __init__(self, **kv):
@@ -443,12 +443,12 @@ def conv2d_gdn_fwd(x, wp, bias, beta, gamma, K, R, S, stride, pad, inverse=False
 PLANES_SLAB_BYTES = 128
 
 
-class Bf16Planes:
-    """An NHWC activation tensor pre-split for the 16-bit matrix cores (csrc/conv_bf16x6.hip): every fp32 value v is stored as two
+class F16Planes:
+    """An NHWC activation tensor pre-split for the 16-bit matrix cores (csrc/conv_f16x3.hip): every fp32 value v is stored as two
     fp16 numbers whose sum is v * 2^e (to 2^-22 |v|), [pixel][C/32][2][32], followed in the same buffer by the
     tensor's scale record (2^-e and the measured max |v| per producing workgroup: include/stem_hip.h).  Only produced and
     consumed by the split-operand convolution kernels; `shape` is the logical [B,C,H,W].  `channels(c0, c1)` is a view of a
-    32-aligned channel range (same storage, same pixel pitch, same record), accepted as an INPUT by conv2d_bf16x6_gen."""
+    32-aligned channel range (same storage, same pixel pitch, same record), accepted as an INPUT by conv2d_f16x3_gen."""
     __slots__ = ("data", "shape", "pix_bytes", "byte_offset", "q_offset")
 
     def __init__(self, data, shape, q_offset, pix_bytes=None, byte_offset=0):
@@ -472,11 +472,11 @@ class Bf16Planes:
         if c0 % 32 or c1 % 32 or not 0 <= c0 < c1 <= self.shape[1]:
             raise ValueError(f"planes views are 32-channel aligned, got [{c0}, {c1}) of {self.shape[1]}")
         B, _, H, W = self.shape
-        return Bf16Planes(self.data, (B, c1 - c0, H, W), self.q_offset, self.pix_bytes, self.byte_offset + (c0 // 32) * PLANES_SLAB_BYTES)
+        return F16Planes(self.data, (B, c1 - c0, H, W), self.q_offset, self.pix_bytes, self.byte_offset + (c0 // 32) * PLANES_SLAB_BYTES)
 
     @staticmethod
     def nbytes(npix, Cc):
-        """(payload bytes = offset of the scale record, total bytes) = stem_bf16x3_planes_qrec_offset / _planes_bytes"""
+        """(payload bytes = offset of the scale record, total bytes) = stem_f16x2_planes_qrec_offset / _planes_bytes"""
         payload = npix * (Cc // 32) * PLANES_SLAB_BYTES
         return payload, payload + (((16 + ((npix + 63) // 64) * ((Cc + 127) // 128)) * 4 + 15) & ~15)
 
@@ -484,16 +484,16 @@ class Bf16Planes:
     def empty(B, Cc, H, W, device):
         if Cc % 32:
             raise ValueError(f"the planes layout needs a channel count that is a multiple of 32, got {Cc}")
-        payload, total = Bf16Planes.nbytes(B * H * W, Cc)            # in Python: this runs ~60 times per training step
-        return Bf16Planes(torch.empty(total, device=device, dtype=torch.uint8), (B, Cc, H, W), payload)
+        payload, total = F16Planes.nbytes(B * H * W, Cc)            # in Python: this runs ~60 times per training step
+        return F16Planes(torch.empty(total, device=device, dtype=torch.uint8), (B, Cc, H, W), payload)
 
     @staticmethod
     def split(x, src_q=None):
         """src_q: data_ptr of a scale record whose slots hold max |x| already (left by the kernel that produced x)"""
         x = to_nhwc(x)
         B, Cc, H, W = x.shape
-        out = Bf16Planes.empty(B, Cc, H, W, x.device)
-        _chk(_lib.hip().stem_bf16x3_split_nhwc(x.data_ptr(), nhwc_ld(x), out.data.data_ptr(), out.q_ptr(), src_q, B * H * W, Cc, _stream()))
+        out = F16Planes.empty(B, Cc, H, W, x.device)
+        _chk(_lib.hip().stem_f16x2_split_nhwc(x.data_ptr(), nhwc_ld(x), out.data.data_ptr(), out.q_ptr(), src_q, B * H * W, Cc, _stream()))
         return out
 
     @staticmethod
@@ -501,8 +501,8 @@ class Bf16Planes:
         """planes of dy * (z > 0 ? 1 : slope): the leaky-ReLU derivative applied while splitting (z = the activated output)"""
         dy, z = to_nhwc(dy), to_nhwc(z)
         B, Cc, H, W = dy.shape
-        out = Bf16Planes.empty(B, Cc, H, W, dy.device)
-        _chk(_lib.hip().stem_bf16x3_split_dact_nhwc(dy.data_ptr(), nhwc_ld(dy), z.data_ptr(), nhwc_ld(z), float(slope), out.data.data_ptr(),
+        out = F16Planes.empty(B, Cc, H, W, dy.device)
+        _chk(_lib.hip().stem_f16x2_split_dact_nhwc(dy.data_ptr(), nhwc_ld(dy), z.data_ptr(), nhwc_ld(z), float(slope), out.data.data_ptr(),
                                                      out.q_ptr(), src_q, B * H * W, Cc, _stream()))
         return out
 
@@ -510,7 +510,7 @@ class Bf16Planes:
         assert self.dense, "merge() of a channel view is not implemented"
         B, Cc, H, W = self.shape
         out = empty_nhwc(B, Cc, H, W, self.data.device)
-        _chk(_lib.hip().stem_bf16x3_merge_nhwc(self.data.data_ptr(), self.q_ptr(), out.data_ptr(), Cc, B * H * W, Cc, _stream()))
+        _chk(_lib.hip().stem_f16x2_merge_nhwc(self.data.data_ptr(), self.q_ptr(), out.data_ptr(), Cc, B * H * W, Cc, _stream()))
         return out
 
     def record(self):
@@ -521,22 +521,22 @@ class Bf16Planes:
         return float(q[1]), float(q[16:16 + ns].max()) if ns else 0.0
 
 
-def pack_weight_bf16x3(w: torch.Tensor, flip: bool = False) -> torch.Tensor:
-    """torch Conv2d weight [K,C,R,S] -> the chunked, pre-split LDS image conv2d_bf16x6_fwd streams; flip=True: the operand of
+def pack_weight_f16x2(w: torch.Tensor, flip: bool = False) -> torch.Tensor:
+    """torch Conv2d weight [K,C,R,S] -> the chunked, pre-split LDS image conv2d_f16x3_fwd streams; flip=True: the operand of
     the input gradient of a stride-1 convolution (rows = input channels, contraction = output channels, taps mirrored)."""
     _require_cuda(w)
     K, Cc, R, S = w.shape
     N, Cin = (Cc, K) if flip else (K, Cc)
-    nbytes = _lib.hip().stem_bf16x3_conv_weight_bytes(Cin, R, S)
+    nbytes = _lib.hip().stem_f16x2_conv_weight_bytes(Cin, R, S)
     if nbytes == 0:
-        raise ValueError(f"bf16x3 weights need a contraction channel count that is a multiple of 32, got {Cin}")
+        raise ValueError(f"f16x2 weights need a contraction channel count that is a multiple of 32, got {Cin}")
     out = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
-    fn = _lib.hip().stem_bf16x3_pack_conv_weight_flip if flip else _lib.hip().stem_bf16x3_pack_conv_weight
+    fn = _lib.hip().stem_f16x2_pack_conv_weight_flip if flip else _lib.hip().stem_f16x2_pack_conv_weight
     _chk(fn(w.detach().contiguous().data_ptr(), out.data_ptr(), N, Cin, R, S, _stream()))
     return out
 
 
-def conv2d_bf16x6_act(xp: Bf16Planes, wp, bias, K, R, S, stride, pad, act=False, slope=LRELU_SLOPE, want_planes=False):
+def conv2d_f16x3_act(xp: F16Planes, wp, bias, K, R, S, stride, pad, act=False, slope=LRELU_SLOPE, want_planes=False):
     """Conv2d (+ leaky ReLU) of a planes tensor on the 192-column kernel (K <= 192): the large-pixel-count layers of the layer-wise
     models.  -> (NHWC fp32 tensor, planes copy or None)"""
     B, Cc, H, W = xp.shape
@@ -544,27 +544,27 @@ def conv2d_bf16x6_act(xp: Bf16Planes, wp, bias, K, R, S, stride, pad, act=False,
     dev = xp.data.device
     assert xp.dense, "the 192-column kernel takes whole planes tensors"
     y = empty_nhwc(B, K, Ho, Wo, dev)
-    yp = Bf16Planes.empty(B, K, Ho, Wo, dev) if want_planes else None
-    _chk(_lib.hip().stem_conv2d_bf16x6_fwd_act(xp.data.data_ptr(), xp.q_ptr(), wp.data_ptr(), _ptr(bias), 1 if act else 0, float(slope), y.data_ptr(), nhwc_ld(y),
+    yp = F16Planes.empty(B, K, Ho, Wo, dev) if want_planes else None
+    _chk(_lib.hip().stem_conv2d_f16x3_fwd_act(xp.data.data_ptr(), xp.q_ptr(), wp.data_ptr(), _ptr(bias), 1 if act else 0, float(slope), y.data_ptr(), nhwc_ld(y),
                                                yp.data.data_ptr() if yp is not None else None, yp.q_ptr() if yp is not None else None,
                                                B, H, W, Cc, K, R, S, stride, pad, _stream()))
     return y, yp
 
 
-def conv2d_bf16x6_fwd(xp: Bf16Planes, wp, bias, K, R, S, stride, pad, beta=None, gamma=None, beta_min=1e-6, planes_out=False):
-    """Conv2d (+ GDN when beta / gamma are given) of a planes tensor with fp32 accuracy on the bf16 matrix cores.
-    Returns an NHWC fp32 tensor, or a Bf16Planes for the next convolution of the chain."""
+def conv2d_f16x3_fwd(xp: F16Planes, wp, bias, K, R, S, stride, pad, beta=None, gamma=None, beta_min=1e-6, planes_out=False):
+    """Conv2d (+ GDN when beta / gamma are given) of a planes tensor with fp32 accuracy on the fp16 matrix cores.
+    Returns an NHWC fp32 tensor, or a F16Planes for the next convolution of the chain."""
     B, Cc, H, W = xp.shape
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
     dev = xp.data.device
     if planes_out:
-        out = Bf16Planes.empty(B, K, Ho, Wo, dev)
+        out = F16Planes.empty(B, K, Ho, Wo, dev)
         y, ldy, yp, yq = None, 0, out.data.data_ptr(), out.q_ptr()
     else:
         out = empty_nhwc(B, K, Ho, Wo, dev)
         y, ldy, yp, yq = out.data_ptr(), nhwc_ld(out), None, None
     assert xp.dense, "the analysis-transform kernel takes whole planes tensors"
-    _chk(_lib.hip().stem_conv2d_bf16x6_fwd(xp.data.data_ptr(), xp.q_ptr(), wp.data_ptr(), _ptr(bias), _ptr(beta), _ptr(gamma), beta_min,
+    _chk(_lib.hip().stem_conv2d_f16x3_fwd(xp.data.data_ptr(), xp.q_ptr(), wp.data_ptr(), _ptr(bias), _ptr(beta), _ptr(gamma), beta_min,
                                            y, ldy, yp, yq, B, H, W, Cc, K, R, S, stride, pad, _stream()))
     return out
 
@@ -573,36 +573,36 @@ _WS_GEN_BYTES = {}
 GEN_EPI_BIAS, GEN_EPI_LRELU, GEN_EPI_DACT = 0, 1, 2
 
 
-def pack_weight_bf16x3_gen(w: torch.Tensor, flip: bool = False, out=None) -> torch.Tensor:
-    """torch Conv2d weight [K,C,R,S] -> the image conv2d_bf16x6_gen streams; flip=True packs the operand of the input-gradient of
+def pack_weight_f16x2_gen(w: torch.Tensor, flip: bool = False, out=None) -> torch.Tensor:
+    """torch Conv2d weight [K,C,R,S] -> the image conv2d_f16x3_gen streams; flip=True packs the operand of the input-gradient of
     a stride-1 convolution (rows = input channels, packed channels = output channels, taps mirrored)."""
     _require_cuda(w)
     K, Cc, R, S = w.shape
     N, Cin = (Cc, K) if flip else (K, Cc)
-    nbytes = _lib.hip().stem_bf16x3_conv_weight_gen_bytes(N, Cin, R, S)
+    nbytes = _lib.hip().stem_f16x2_conv_weight_gen_bytes(N, Cin, R, S)
     if nbytes == 0:
-        raise ValueError(f"bf16x3 weights need a contraction channel count that is a multiple of 32, got {Cin}")
+        raise ValueError(f"f16x2 weights need a contraction channel count that is a multiple of 32, got {Cin}")
     if out is None:
         out = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
     assert out.numel() == nbytes
-    _chk(_lib.hip().stem_bf16x3_pack_conv_weight_gen(w.detach().contiguous().data_ptr(), out.data_ptr(), N, Cin, R, S, int(flip), _stream()))
+    _chk(_lib.hip().stem_f16x2_pack_conv_weight_gen(w.detach().contiguous().data_ptr(), out.data_ptr(), N, Cin, R, S, int(flip), _stream()))
     return out
 
 
-def bf16x3_gen_weight_bytes(N, C, R, S):
-    return int(_lib.hip().stem_bf16x3_conv_weight_gen_bytes(N, C, R, S))
+def f16x2_gen_weight_bytes(N, C, R, S):
+    return int(_lib.hip().stem_f16x2_conv_weight_gen_bytes(N, C, R, S))
 
 
-def pack_weights_bf16x3_multi(descs):
-    """descs: ctypes array of _lib.Bf16PackDesc (at most 24 per call: the table is a kernel argument)"""
+def pack_weights_f16x2_multi(descs):
+    """descs: ctypes array of _lib.F16PackDesc (at most 24 per call: the table is a kernel argument)"""
     for i in range(0, len(descs), 24):
         n = min(24, len(descs) - i)
-        _chk(_lib.hip().stem_bf16x3_pack_conv_weights_multi(C.byref(descs, i * C.sizeof(_lib.Bf16PackDesc)), n, _stream()))
+        _chk(_lib.hip().stem_f16x2_pack_conv_weights_multi(C.byref(descs, i * C.sizeof(_lib.F16PackDesc)), n, _stream()))
 
 
-def conv2d_bf16x6_gen(xp: Bf16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EPI_BIAS, slope=LRELU_SLOPE, z=None, out=None,
+def conv2d_f16x3_gen(xp: F16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EPI_BIAS, slope=LRELU_SLOPE, z=None, out=None,
                       want_fp32=True, want_planes=False):
-    """General bf16x6 convolution (training-time STEM layers): returns (fp32 NHWC tensor or None, Bf16Planes or None).
+    """General f16x3 convolution (training-time STEM layers): returns (fp32 NHWC tensor or None, F16Planes or None).
     `out` may be a channel slice of a wider NHWC buffer; epi = GEN_EPI_DACT multiplies by the leaky-ReLU derivative at z."""
     B, Cc, H, W = xp.shape
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
@@ -610,11 +610,11 @@ def conv2d_bf16x6_gen(xp: Bf16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EP
     y = None
     if want_fp32 or out is not None:
         y = out if out is not None else empty_nhwc(B, N, Ho, Wo, dev)
-    yp = Bf16Planes.empty(B, N, Ho, Wo, dev) if want_planes else None
+    yp = F16Planes.empty(B, N, Ho, Wo, dev) if want_planes else None
     dims = (B, H, W, Cc, N, R, S, stride, pad)
     need = _WS_GEN_BYTES.get(dims)
     if need is None:
-        need = _WS_GEN_BYTES[dims] = int(_lib.hip().stem_conv2d_bf16x6_gen_workspace_bytes(*dims))
+        need = _WS_GEN_BYTES[dims] = int(_lib.hip().stem_conv2d_f16x3_gen_workspace_bytes(*dims))
     ws_ptr = 0
     if need:
         slot = (dev, _stream())
@@ -622,39 +622,39 @@ def conv2d_bf16x6_gen(xp: Bf16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EP
         if buf is None or buf.numel() * 4 < need:
             buf = _WS[slot] = torch.zeros((need + 3) // 4, device=dev, dtype=torch.float32)       # zero head: arrival counters
         ws_ptr = buf.data_ptr()
-    _chk(_lib.hip().stem_conv2d_bf16x6_gen_fwd(xp.data_ptr(), xp.q_ptr(), xp.pix_bytes, wp.data_ptr(), _ptr(bias), epi, slope, _ptr(z),
+    _chk(_lib.hip().stem_conv2d_f16x3_gen_fwd(xp.data_ptr(), xp.q_ptr(), xp.pix_bytes, wp.data_ptr(), _ptr(bias), epi, slope, _ptr(z),
                                                nhwc_ld(z) if z is not None else 0, _ptr(y), nhwc_ld(y) if y is not None else 0,
                                                yp.data.data_ptr() if yp is not None else None, yp.q_ptr() if yp is not None else None,
                                                B, H, W, Cc, N, R, S, stride, pad, ws_ptr, need, _stream()))
     return y, yp
 
 
-def wgrad_bf16x6_plan(x_shape, K, R, S, pad):
-    """(splits, slab elements) of conv2d_wgrad_bf16x6 for this geometry"""
+def wgrad_f16x3_plan(x_shape, K, R, S, pad):
+    """(splits, slab elements) of conv2d_wgrad_f16x3 for this geometry"""
     B, Cc, H, W = x_shape
-    splits = int(_lib.hip().stem_wgrad_bf16x6_splits(B, H, W, Cc, K, R, S, pad))
+    splits = int(_lib.hip().stem_wgrad_f16x3_splits(B, H, W, Cc, K, R, S, pad))
     return splits, splits * R * S * K * Cc
 
 
-def conv2d_wgrad_bf16x6_into(xp: Bf16Planes, dyp: Bf16Planes, K, R, S, pad, dw_out, db_out=None, accumulate=True):
+def conv2d_wgrad_f16x3_into(xp: F16Planes, dyp: F16Planes, K, R, S, pad, dw_out, db_out=None, accumulate=True):
     """weight (and bias) gradient of a stride-1 convolution from planes operands straight into the reference-layout
     buffers dw_out [K,C,R,S] / db_out [K] (accumulating: autograd's `.grad +=`); slabs from the per-geometry workspace"""
     B, Cc, H, W = xp.shape
-    splits, elems = wgrad_bf16x6_plan(xp.shape, K, R, S, pad)
-    ws, _ = _wgrad_workspace(("bf16x6", xp.data.device, tuple(xp.shape), K, R, S, pad), elems + splits * K, xp.data.device)
+    splits, elems = wgrad_f16x3_plan(xp.shape, K, R, S, pad)
+    ws, _ = _wgrad_workspace(("f16x3", xp.data.device, tuple(xp.shape), K, R, S, pad), elems + splits * K, xp.data.device)
     dwp, bpart = ws[:elems], ws[elems:elems + splits * K]
-    conv2d_wgrad_bf16x6(xp, dyp, K, R, S, pad, dwp, splits, db=db_out, bias_part=bpart, accumulate_db=accumulate)
+    conv2d_wgrad_f16x3(xp, dyp, K, R, S, pad, dwp, splits, db=db_out, bias_part=bpart, accumulate_db=accumulate)
     _chk(_lib.hip().stem_unpack_wgrad(dwp.data_ptr(), dw_out.data_ptr(), K, Cc, R, S, splits, UNPACK_ACCUMULATE if accumulate else 0, _stream()))
 
 
-def conv2d_wgrad_bf16x6(xp: Bf16Planes, dyp: Bf16Planes, K, R, S, pad, dwp, splits, db=None, bias_part=None, accumulate_db=False):
+def conv2d_wgrad_f16x3(xp: F16Planes, dyp: F16Planes, K, R, S, pad, dwp, splits, db=None, bias_part=None, accumulate_db=False):
     """packed weight-gradient slabs [splits][R*S][K][C] of a stride-1 convolution from planes operands (channel views allowed).
     With `db` (and a `bias_part` scratch of splits * K floats) the bias gradient comes out of the same pass: the kernel leaves
     per-split column sums of dy, a second tiny launch adds them into db."""
     B, Cc, H, W = xp.shape
     if db is not None and bias_part is None:
         bias_part = torch.empty(splits * K, device=dwp.device, dtype=torch.float32)
-    _chk(_lib.hip().stem_conv2d_wgrad_bf16x6(xp.data_ptr(), xp.q_ptr(), xp.pix_bytes, dyp.data_ptr(), dyp.q_ptr(), dyp.pix_bytes, dwp.data_ptr(),
+    _chk(_lib.hip().stem_conv2d_wgrad_f16x3(xp.data_ptr(), xp.q_ptr(), xp.pix_bytes, dyp.data_ptr(), dyp.q_ptr(), dyp.pix_bytes, dwp.data_ptr(),
                                              _ptr(bias_part) if db is not None else None,
                                              B, H, W, Cc, K, R, S, pad, splits, _stream()))
     if db is not None:
@@ -680,13 +680,13 @@ def _aligned16(*ts):
 
 
 def c4gdn_supported(K, R, S, inverse=False):
-    """first layer + GDN on the bf16 kernel of csrc/c4gdn_bf16x6.hip: N = 64 / 128 / 192 output channels, filters up to 25 taps;
-    STEM_C4GDN_BF16X6=0 keeps the fp32-MFMA kernel of igemm.hip (routing switch: both are fp32-exact forms)"""
-    return (not inverse and os.environ.get("STEM_C4GDN_BF16X6", "1") != "0" and bool(_lib.hip().stem_c4gdn_supported(K, R, S)))
+    """first layer + GDN on the fp16 kernel of csrc/c4gdn_f16x3.hip: N = 64 / 128 / 192 output channels, filters up to 25 taps;
+    STEM_C4GDN_F16X3=0 keeps the fp32-MFMA kernel of igemm.hip (routing switch: both are fp32-exact forms)"""
+    return (not inverse and os.environ.get("STEM_C4GDN_F16X3", "1") != "0" and bool(_lib.hip().stem_c4gdn_supported(K, R, S)))
 
 
 def _c4gdn_fits(x4, K, R, S, stride, pad, ld=None, planes=False):
-    """operands of the bf16 first-layer kernel are addressed through 2 GiB buffer views"""
+    """operands of the fp16 first-layer kernel are addressed through 2 GiB buffer views"""
     B, H, W, _ = x4.shape
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
     out_bytes = B * Ho * Wo * ((K // 32) * PLANES_SLAB_BYTES if planes else (ld or K) * 4)
@@ -694,43 +694,43 @@ def _c4gdn_fits(x4, K, R, S, stride, pad, ld=None, planes=False):
 
 
 def c4gdn_stream(wp_c4, gamma, K, R, S):
-    """A-operand stream of conv2d_c4_gdn_bf16x6: the C4-packed first-layer weight and the reparametrised gamma of the following
-    GDN, split into bf16 planes in MFMA-fragment order (one small launch; cache it while the parameters do not change)."""
+    """A-operand stream of conv2d_c4_gdn_f16x3: the C4-packed first-layer weight and the reparametrised gamma of the following
+    GDN, split into fp16 planes in MFMA-fragment order (one small launch; cache it while the parameters do not change)."""
     out = torch.empty(int(_lib.hip().stem_c4gdn_stream_bytes(K, R, S)), device=wp_c4.device, dtype=torch.uint8)
     _chk(_lib.hip().stem_c4gdn_pack(wp_c4.data_ptr(), gamma.data_ptr(), out.data_ptr(), K, R, S, _stream()))
     return out
 
 
-def conv2d_c4_gdn_bf16x6(x4, astream, bias, beta, K, R, S, stride, pad, beta_min=1e-6, out=None, planes_out=False):
-    """conv (3 -> K channels, x4 = [B,H,W,4] from nchw3_to_nhwc4) + GDN in one kernel, six bf16 MFMAs per fp32 product;
-    result as an NHWC fp32 tensor or, with planes_out, pre-split for conv2d_bf16x6_fwd"""
+def conv2d_c4_gdn_f16x3(x4, astream, bias, beta, K, R, S, stride, pad, beta_min=1e-6, out=None, planes_out=False):
+    """conv (3 -> K channels, x4 = [B,H,W,4] from nchw3_to_nhwc4) + GDN in one kernel, three fp16 MFMAs per fp32 product;
+    result as an NHWC fp32 tensor or, with planes_out, pre-split for conv2d_f16x3_fwd"""
     B, H, W, _ = x4.shape
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
     if planes_out:
-        res = Bf16Planes.empty(B, K, Ho, Wo, x4.device)
+        res = F16Planes.empty(B, K, Ho, Wo, x4.device)
         y, ldy, yp, yq = None, 0, res.data.data_ptr(), res.q_ptr()
     else:
         res = out if out is not None else empty_nhwc(B, K, Ho, Wo, x4.device)
         y, ldy, yp, yq = res.data_ptr(), nhwc_ld(res), None, None
-    _chk(_lib.hip().stem_conv2d_c4_gdn_bf16x6(x4.data_ptr(), _nhwc4_record(x4).data_ptr(), astream.data_ptr(), _ptr(bias), beta.data_ptr(), beta_min,
+    _chk(_lib.hip().stem_conv2d_c4_gdn_f16x3(x4.data_ptr(), _nhwc4_record(x4).data_ptr(), astream.data_ptr(), _ptr(bias), beta.data_ptr(), beta_min,
                                               y, ldy, yp, yq, B, H, W, K, R, S, stride, pad, _stream()))
     return res
 
 
 def conv2d_fwd_c4_gdn_planes(x4, wp, bias, beta, gamma, K, R, S, stride, pad, beta_min=1e-6, astream=None):
-    """conv2d_fwd_c4_gdn whose result is handed to conv2d_bf16x6_fwd: written pre-split (Bf16Planes), no fp32 copy.
+    """conv2d_fwd_c4_gdn whose result is handed to conv2d_f16x3_fwd: written pre-split (F16Planes), no fp32 copy.
     `astream`: a cached c4gdn_stream(wp, gamma, ...) (built per call otherwise)."""
     if c4gdn_supported(K, R, S) and _aligned16(bias, beta) and _c4gdn_fits(x4, K, R, S, stride, pad, planes=True):
-        return conv2d_c4_gdn_bf16x6(x4, astream if astream is not None else c4gdn_stream(wp, gamma, K, R, S), bias, beta, K, R, S,
+        return conv2d_c4_gdn_f16x3(x4, astream if astream is not None else c4gdn_stream(wp, gamma, K, R, S), bias, beta, K, R, S,
                                     stride, pad, beta_min, planes_out=True)
     # channel counts the one-kernel form does not cover: the fp32-MFMA kernel, then a split pass
-    return Bf16Planes.split(conv2d_fwd_c4_gdn(x4, wp, bias, beta, gamma, K, R, S, stride, pad, beta_min=beta_min))
+    return F16Planes.split(conv2d_fwd_c4_gdn(x4, wp, bias, beta, gamma, K, R, S, stride, pad, beta_min=beta_min))
 
 
 def conv2d_fwd_c4_gdn(x4, wp, bias, beta, gamma, K, R, S, stride, pad, inverse=False, beta_min=1e-6, out=None, astream=None):
     if (c4gdn_supported(K, R, S, inverse) and _aligned16(bias, beta) and (out is None or _aligned16(out))
             and _c4gdn_fits(x4, K, R, S, stride, pad, ld=nhwc_ld(out) if out is not None else K)):
-        return conv2d_c4_gdn_bf16x6(x4, astream if astream is not None else c4gdn_stream(wp, gamma, K, R, S), bias, beta, K, R, S,
+        return conv2d_c4_gdn_f16x3(x4, astream if astream is not None else c4gdn_stream(wp, gamma, K, R, S), bias, beta, K, R, S,
                                     stride, pad, beta_min, out=out)
     B, H, W, _ = x4.shape
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)

@@ -35,11 +35,11 @@ def weight_epoch(w):
     return (_WEIGHT_EPOCH[0], getattr(w, "_stem_epoch", 0))
 
 
-PACK_BF16X3 = -3          # _PackCache role of the pre-split bf16 image (csrc/conv_bf16x6.hip); not a stem_pack_* role
-PACK_BF16X3_GEN = -4      # ... in the layout of the general (128-column tiles, split-K) kernel
-PACK_BF16X3_FLIP = -7     # PACK_BF16X3 of the mirrored, transposed weight (input gradient on the 192-column kernel)
-PACK_BF16X3_GEN_FLIP = -6 # ... of the mirrored, transposed weight: the input-gradient of a stride-1 convolution as a convolution
-PACK_C4GDN = -5           # A-operand stream of csrc/c4gdn_bf16x6.hip: first-layer weight AND the following GDN's gamma
+PACK_F16X2 = -3          # _PackCache role of the pre-split fp16 image (csrc/conv_f16x3.hip); not a stem_pack_* role
+PACK_F16X2_GEN = -4      # ... in the layout of the general (128-column tiles, split-K) kernel
+PACK_F16X2_FLIP = -7     # PACK_F16X2 of the mirrored, transposed weight (input gradient on the 192-column kernel)
+PACK_F16X2_GEN_FLIP = -6 # ... of the mirrored, transposed weight: the input-gradient of a stride-1 convolution as a convolution
+PACK_C4GDN = -5           # A-operand stream of csrc/c4gdn_f16x3.hip: first-layer weight AND the following GDN's gamma
 
 
 class _PackCache:
@@ -53,14 +53,14 @@ class _PackCache:
         hit = self._c.get(role)
         if hit is not None and hit[0] == key:
             return hit[1]
-        if role == PACK_BF16X3:
-            wp = F.pack_weight_bf16x3(w)
-        elif role == PACK_BF16X3_FLIP:
-            wp = F.pack_weight_bf16x3(w, flip=True)
-        elif role == PACK_BF16X3_GEN:
-            wp = F.pack_weight_bf16x3_gen(w)
-        elif role == PACK_BF16X3_GEN_FLIP:
-            wp = F.pack_weight_bf16x3_gen(w, flip=True)
+        if role == PACK_F16X2:
+            wp = F.pack_weight_f16x2(w)
+        elif role == PACK_F16X2_FLIP:
+            wp = F.pack_weight_f16x2(w, flip=True)
+        elif role == PACK_F16X2_GEN:
+            wp = F.pack_weight_f16x2_gen(w)
+        elif role == PACK_F16X2_GEN_FLIP:
+            wp = F.pack_weight_f16x2_gen(w, flip=True)
         else:
             wp = F.pack_weight(w, role, masked)
         if (masked & 3) == 2:                    # the kernel zeroed taps of w in place
@@ -69,7 +69,7 @@ class _PackCache:
         return wp
 
     def get_c4gdn(self, w: torch.Tensor, gamma: torch.Tensor, K: int, R: int):
-        """the combined (first-layer weight, GDN gamma) stream of F.conv2d_c4_gdn_bf16x6, rebuilt when either parameter changed"""
+        """the combined (first-layer weight, GDN gamma) stream of F.conv2d_c4_gdn_f16x3, rebuilt when either parameter changed"""
         key = tuple((t._version, t.data_ptr(), weight_epoch(t), tuple(t.shape)) for t in (w, gamma))
         hit = self._c.get(PACK_C4GDN)
         if hit is not None and hit[0] == key:
@@ -134,26 +134,26 @@ def _on_side_stream(fn, *tensors):
 
 
 # ----------------------------------------------------------------------------- autograd functions
-def _layers_bf16x6_enabled():
-    """stride-1 convolutions of the layer-wise (autograd) models -- the variable-rate family of models/stem_roi.py -- on the bf16
-    matrix cores (six products per fp32 product, csrc/conv_bf16x6.hip / wgrad_bf16x6.hip); STEM_LAYERS_BF16X6=0: fp32 MFMA"""
-    return os.environ.get("STEM_LAYERS_BF16X6", "1") != "0"
+def _layers_f16x3_enabled():
+    """stride-1 convolutions of the layer-wise (autograd) models -- the variable-rate family of models/stem_roi.py -- on the fp16
+    matrix cores (six products per fp32 product, csrc/conv_f16x3.hip / wgrad_f16x3.hip); STEM_LAYERS_F16X3=0: fp32 MFMA"""
+    return os.environ.get("STEM_LAYERS_F16X3", "1") != "0"
 
 
-def _conv_bf16x6_route(weight, stride, pad, masked, x_shape):
-    """forward, input gradient and weight gradient of this convolution on the bf16 kernels: stride 1, 'same' padding, channel
+def _conv_f16x3_route(weight, stride, pad, masked, x_shape):
+    """forward, input gradient and weight gradient of this convolution on the fp16 kernels: stride 1, 'same' padding, channel
     counts that are multiples of 32, operands within the kernels' 2 GiB buffer views"""
     K, Cc, R, S = weight.shape
     B, _, H, W = x_shape
     return (stride == 1 and R == S and pad == R // 2 and not masked and Cc % 32 == 0 and K % 32 == 0 and R * S <= 25
-            and B * H * W <= _LAYERS_BF16X6_MAXPIX
+            and B * H * W <= _LAYERS_F16X3_MAXPIX
             and _planes_fit(B * H * W, max(Cc, K)) and B * H * W * ((max(K, Cc) + 127) // 128) * 512 < 0x7FFFFF00)
 
 
-#: The general bf16 kernel streams its weight tile once per 64-pixel workgroup and the bf16 weight-gradient kernel re-reads both
+#: The general fp16 kernel streams its weight tile once per 64-pixel workgroup and the fp16 weight-gradient kernel re-reads both
 #: operands once per tap: at full-resolution feature maps (a million pixels per batch) both are bound by L2 -> LDS traffic and
-#: lose to the 128x128-tile fp32-MFMA kernels; below this pixel count the bf16 route wins (sweep: DESIGN.md section 9)
-_LAYERS_BF16X6_MAXPIX = int(os.environ.get("STEM_LAYERS_BF16X6_MAXPIX", str(1 << 30)))
+#: lose to the 128x128-tile fp32-MFMA kernels; below this pixel count the fp16 route wins (sweep: DESIGN.md section 9)
+_LAYERS_F16X3_MAXPIX = int(os.environ.get("STEM_LAYERS_F16X3_MAXPIX", str(1 << 30)))
 
 
 def _wide_kernel(n_out, x_shape):
@@ -167,7 +167,7 @@ _WIDE_MINPIX = int(os.environ.get("STEM_LAYERS_WIDE_MINPIX", "32768"))
 
 
 def planes_of(t):
-    """the bf16 planes copy a producing kernel left next to an activation tensor (same values), if any"""
+    """the fp16 planes copy a producing kernel left next to an activation tensor (same values), if any"""
     return getattr(t, "_stem_planes", None)
 
 
@@ -177,25 +177,25 @@ class Conv2dFunction(torch.autograd.Function):
         K, Cc, R, S = weight.shape
         # <=4 input channels: the image (NCHW, fused layout change: g_a.0) or image+quality map (stem_roi.py:529)
         first = (Cc == 3 and F.nhwc_ld(x) is None) or (Cc == 4 and R * S <= 32)
-        if not first and x.is_cuda and _layers_bf16x6_enabled() and _conv_bf16x6_route(weight, stride, pad, masked, x.shape):
-            # bf16 route: the input as planes (left by the producer, or split here), kept for the weight gradient instead
+        if not first and x.is_cuda and _layers_f16x3_enabled() and _conv_f16x3_route(weight, stride, pad, masked, x.shape):
+            # fp16 route: the input as planes (left by the producer, or split here), kept for the weight gradient instead
             # of the fp32 input; the activation is the kernel's epilogue
             xp = planes_of(x)
             if xp is None or tuple(xp.shape) != tuple(x.shape):
-                xp = F.Bf16Planes.split(x)
+                xp = F.F16Planes.split(x)
             if _wide_kernel(K, x.shape) and xp.dense:
-                y, yp = F.conv2d_bf16x6_act(xp, cache.get(weight, PACK_BF16X3), bias, K, R, S, 1, pad, bool(act), slope, want_planes)
+                y, yp = F.conv2d_f16x3_act(xp, cache.get(weight, PACK_F16X2), bias, K, R, S, 1, pad, bool(act), slope, want_planes)
             else:
-                y, yp = F.conv2d_bf16x6_gen(xp, cache.get(weight, PACK_BF16X3_GEN), bias, K, R, S, 1, pad,
+                y, yp = F.conv2d_f16x3_gen(xp, cache.get(weight, PACK_F16X2_GEN), bias, K, R, S, 1, pad,
                                             epi=F.GEN_EPI_LRELU if act else F.GEN_EPI_BIAS, slope=slope, want_planes=want_planes)
             if yp is not None:
                 y._stem_planes = yp
             ctx.cfg = (stride, pad, act, masked, cache, False, tuple(x.shape), slope)
             ctx.params = (weight, bias)
-            ctx.bx6 = (xp.q_offset, xp.pix_bytes, xp.byte_offset)
+            ctx.fx3 = (xp.q_offset, xp.pix_bytes, xp.byte_offset)
             ctx.save_for_backward(xp.data, weight, y if act else None)
             return y
-        ctx.bx6 = None
+        ctx.fx3 = None
         if first:
             xin = F.nchw3_to_nhwc4(x) if Cc == 3 else F.dense_nhwc(x).permute(0, 2, 3, 1)
             y = F.conv2d_fwd_c4(xin, cache.get(weight, F.PACK_CONV_FWD_C4), bias, K, R, S, stride, pad)
@@ -212,38 +212,38 @@ class Conv2dFunction(torch.autograd.Function):
         return y
 
     @staticmethod
-    def _backward_bx6(ctx, dy):
+    def _backward_fx3(ctx, dy):
         stride, pad, act, masked, cache, first, xshape, slope = ctx.cfg
         xdata, weight, y = ctx.saved_tensors
         K, Cc, R, S = weight.shape
-        xp = F.Bf16Planes(xdata, xshape, *ctx.bx6)
+        xp = F.F16Planes(xdata, xshape, *ctx.fx3)
         dy = F.to_nhwc(dy)
         # the gradient as planes, with this layer's leaky-ReLU derivative applied in the splitting pass
-        dyp = F.Bf16Planes.split_dact(dy, y, slope) if act else F.Bf16Planes.split(dy)
+        dyp = F.F16Planes.split_dact(dy, y, slope) if act else F.F16Planes.split(dy)
         dx = None
         if ctx.needs_input_grad[0]:
             if _wide_kernel(Cc, xshape):
-                dx = F.conv2d_bf16x6_act(dyp, cache.get(weight, PACK_BF16X3_FLIP), None, Cc, R, S, 1, pad)[0]
+                dx = F.conv2d_f16x3_act(dyp, cache.get(weight, PACK_F16X2_FLIP), None, Cc, R, S, 1, pad)[0]
             else:
-                dx = F.conv2d_bf16x6_gen(dyp, cache.get(weight, PACK_BF16X3_GEN_FLIP), None, Cc, R, S, 1, pad, epi=F.GEN_EPI_BIAS)[0]
+                dx = F.conv2d_f16x3_gen(dyp, cache.get(weight, PACK_F16X2_GEN_FLIP), None, Cc, R, S, 1, pad, epi=F.GEN_EPI_BIAS)[0]
         dw = db = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             need_db = bool(ctx.needs_input_grad[2])
             gw, gb = _flat_grad(ctx.params[0]), (_flat_grad(ctx.params[1]) if need_db else None)
             if gw is not None and (gb is not None or not need_db):
                 def run():
-                    F.conv2d_wgrad_bf16x6_into(xp, dyp, K, R, S, pad, gw, gb if need_db else None, accumulate=True)
+                    F.conv2d_wgrad_f16x3_into(xp, dyp, K, R, S, pad, gw, gb if need_db else None, accumulate=True)
                 _on_side_stream(run, dyp.data, xdata) if _WGRAD_SIDE["enabled"] else run()
             else:
                 dw = torch.zeros((K, Cc, R, S), device=dy.device, dtype=torch.float32)
                 db = torch.zeros(K, device=dy.device, dtype=torch.float32) if need_db else None
-                F.conv2d_wgrad_bf16x6_into(xp, dyp, K, R, S, pad, dw, db, accumulate=True)
+                F.conv2d_wgrad_f16x3_into(xp, dyp, K, R, S, pad, dw, db, accumulate=True)
         return dx, dw, db, None, None, None, None, None, None, None
 
     @staticmethod
     def backward(ctx, dy):
-        if ctx.bx6 is not None:
-            return Conv2dFunction._backward_bx6(ctx, dy)
+        if ctx.fx3 is not None:
+            return Conv2dFunction._backward_fx3(ctx, dy)
         stride, pad, act, masked, cache, first, xshape, slope = ctx.cfg
         xin, weight, y = ctx.saved_tensors
         K, Cc, R, S = weight.shape
@@ -469,11 +469,11 @@ class Conv2d(nn.Module):
             nn.init.uniform_(self.bias, -bound, bound)
 
     def forward(self, x, act=F.ACT_NONE, slope=F.LRELU_SLOPE, planes=False):
-        """planes=True: the consumer is another bf16-routed convolution -- leave the pre-split copy next to the output"""
+        """planes=True: the consumer is another fp16-routed convolution -- leave the pre-split copy next to the output"""
         return Conv2dFunction.apply(x, self.weight, self.bias, self.stride, self.padding, act, self._masked, self._packs, slope, planes)
 
-    def bf16x6_route(self, x_shape):
-        return _layers_bf16x6_enabled() and _conv_bf16x6_route(self.weight, self.stride, self.padding, self._masked, x_shape)
+    def f16x3_route(self, x_shape):
+        return _layers_f16x3_enabled() and _conv_f16x3_route(self.weight, self.stride, self.padding, self._masked, x_shape)
 
     def extra_repr(self):
         return f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, padding={self.padding}"
@@ -553,31 +553,31 @@ def _conv_gdn_fused(conv_mod, gdn, x):
                             conv_mod.stride, conv_mod.padding, gdn.inverse, gdn.beta_min)
 
 
-def _bf16x6_enabled():
-    """fp32-accurate convolutions on the bf16 matrix cores for inference-only chains (csrc/conv_bf16x6.hip).  STEM_BF16X6=0
+def _f16x3_enabled():
+    """fp32-accurate convolutions on the fp16 matrix cores for inference-only chains (csrc/conv_f16x3.hip).  STEM_F16X3=0
     selects the fp32-MFMA kernels everywhere."""
-    return os.environ.get("STEM_BF16X6", "1") != "0"
+    return os.environ.get("STEM_F16X3", "1") != "0"
 
 
-#: fewest output pixels for which the bf16 kernel beats the fp32-MFMA one (64-pixel tiles, no split-K: below ~3/4 of the CUs
+#: fewest output pixels for which the fp16 kernel beats the fp32-MFMA one (64-pixel tiles, no split-K: below ~3/4 of the CUs
 #: the split-K fp32 kernel wins; measured on g_a.6 at B=16: 4096 pixels)
-_BF16X6_MIN_PIXELS = 12288
+_F16X3_MIN_PIXELS = 12288
 
 
-def _bf16x6_eligible(m, in_shape):
-    """Can conv `m`, applied to an input of logical shape `in_shape` = (B, C, H, W), run on csrc/conv_bf16x6.hip?"""
+def _f16x3_eligible(m, in_shape):
+    """Can conv `m`, applied to an input of logical shape `in_shape` = (B, C, H, W), run on csrc/conv_f16x3.hip?"""
     if not (type(m) is Conv2d and not m._masked and m.in_channels % 32 == 0 and m.out_channels <= 192
             and m.kernel_size * m.kernel_size <= 25 and m.weight.is_cuda):
         return False
-    return _bf16x6_shape_ok(m, in_shape)
+    return _f16x3_shape_ok(m, in_shape)
 
 
-def _bf16x6_shape_ok(m, in_shape):
+def _f16x3_shape_ok(m, in_shape):
     B, _, H, W = in_shape
     Ho, Wo = F.conv_out_hw(H, W, m.kernel_size, m.kernel_size, m.stride, m.padding)
     if not (_planes_fit(B * H * W, m.in_channels) and _planes_fit(B * Ho * Wo, m.out_channels)):
         return False          # the kernels address their operands through 2 GiB buffer views: such a batch stays on the fp32 kernels
-    return B * Ho * Wo >= _BF16X6_MIN_PIXELS
+    return B * Ho * Wo >= _F16X3_MIN_PIXELS
 
 
 def _planes_fit(npix, channels):
@@ -585,7 +585,7 @@ def _planes_fit(npix, channels):
     return npix * ((channels + 31) // 32) * F.PLANES_SLAB_BYTES < 0x7FFFFF00
 
 
-def _bf16x6_gen_eligible(m, follows_gdn, in_shape=None):
+def _f16x3_gen_eligible(m, follows_gdn, in_shape=None):
     """Small layers that end a planes chain (the last convolution of the analysis transform: 4096 output pixels at the bench
     size) go to the general split-K kernel, which has no fused GDN."""
     if in_shape is not None and not _planes_fit(in_shape[0] * in_shape[2] * in_shape[3], m.in_channels):
@@ -623,13 +623,13 @@ class FusedSequential(nn.Sequential):
     def forward(self, x):
         mods = list(self)
         nograd = not torch.is_grad_enabled()
-        bx6 = nograd and _bf16x6_enabled()
+        fx3 = nograd and _f16x3_enabled()
         i = 0
         while i < len(mods):
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < len(mods) else None
-            if bx6 and type(m) is Conv2d:
-                # frozen / inference chain of convolutions (the analysis transform): operands pre-split into bf16 planes, the
+            if fx3 and type(m) is Conv2d:
+                # frozen / inference chain of convolutions (the analysis transform): operands pre-split into fp16 planes, the
                 # following GDN fused, the output written as planes again when the next convolution takes them.  A chain
                 # starts where the next convolution is eligible too -- either at the 3-channel first layer, whose fp32 kernel
                 # then writes planes, or with a split pass over an fp32 tensor -- and runs until one is not eligible.
@@ -640,8 +640,8 @@ class FusedSequential(nn.Sequential):
                 chain = False
                 if K % 32 == 0 and j < len(mods) and mods[j].__class__ is Conv2d and mods[j].in_channels == K:
                     nxt_gdn = j + 1 < len(mods) and isinstance(mods[j + 1], GDN)
-                    chain = _bf16x6_eligible(mods[j], out_shape) or _bf16x6_gen_eligible(mods[j], nxt_gdn, out_shape)
-                if (chain and gdn is not None and m.in_channels == 3 and not isinstance(x, F.Bf16Planes) and F.nhwc_ld(x) is None
+                    chain = _f16x3_eligible(mods[j], out_shape) or _f16x3_gen_eligible(mods[j], nxt_gdn, out_shape)
+                if (chain and gdn is not None and m.in_channels == 3 and not isinstance(x, F.F16Planes) and F.nhwc_ld(x) is None
                         and K <= 192):
                     wp = m._packs.get(m.weight, F.PACK_CONV_FWD_C4)
                     ast = m._packs.get_c4gdn(m.weight, gdn.gamma, K, R) if F.c4gdn_supported(K, R, R) else None
@@ -649,18 +649,18 @@ class FusedSequential(nn.Sequential):
                                                                           m.stride, m.padding, gdn.beta_min, astream=ast))
                     i = j
                     continue
-                if _bf16x6_eligible(m, x.shape) and (isinstance(x, F.Bf16Planes) or (chain and x.is_cuda)):
-                    xin = x if isinstance(x, F.Bf16Planes) else F.Bf16Planes.split(x)
-                    wp = m._packs.get(m.weight, PACK_BF16X3)
-                    x = self._timed(i, lambda: F.conv2d_bf16x6_fwd(xin, wp, m.bias, K, R, R, m.stride, m.padding,
+                if _f16x3_eligible(m, x.shape) and (isinstance(x, F.F16Planes) or (chain and x.is_cuda)):
+                    xin = x if isinstance(x, F.F16Planes) else F.F16Planes.split(x)
+                    wp = m._packs.get(m.weight, PACK_F16X2)
+                    x = self._timed(i, lambda: F.conv2d_f16x3_fwd(xin, wp, m.bias, K, R, R, m.stride, m.padding,
                                                                    gdn.beta if gdn is not None else None,
                                                                    gdn.gamma if gdn is not None else None,
                                                                    gdn.beta_min if gdn is not None else 1e-6, planes_out=chain))
                     i = j
                     continue
-                if isinstance(x, F.Bf16Planes) and _bf16x6_gen_eligible(m, gdn is not None):
-                    wp = m._packs.get(m.weight, PACK_BF16X3_GEN)
-                    x = self._timed(i, lambda: F.conv2d_bf16x6_gen(x, wp, m.bias, K, R, R, m.stride, m.padding, want_fp32=not chain,
+                if isinstance(x, F.F16Planes) and _f16x3_gen_eligible(m, gdn is not None):
+                    wp = m._packs.get(m.weight, PACK_F16X2_GEN)
+                    x = self._timed(i, lambda: F.conv2d_f16x3_gen(x, wp, m.bias, K, R, R, m.stride, m.padding, want_fp32=not chain,
                                                                    want_planes=chain)[1 if chain else 0])
                     i = j
                     continue
@@ -673,10 +673,10 @@ class FusedSequential(nn.Sequential):
                 # LeakyReLU(slope) or ReLU (= slope 0) folded into the conv epilogue
                 slope = float(nxt.negative_slope) if isinstance(nxt, nn.LeakyReLU) else 0.0
                 if type(m) is Conv2d and x.is_cuda:
-                    # hand planes to the next convolution when both run on the bf16 kernels (a conv -> LeakyReLU -> conv chain)
+                    # hand planes to the next convolution when both run on the fp16 kernels (a conv -> LeakyReLU -> conv chain)
                     after = mods[i + 2] if i + 2 < len(mods) else None
                     out_shape = _conv_out_shape(m, x.shape)
-                    hand = type(after) is Conv2d and m.bf16x6_route(x.shape) and after.bf16x6_route(out_shape)
+                    hand = type(after) is Conv2d and m.f16x3_route(x.shape) and after.f16x3_route(out_shape)
                     x = self._timed(i, lambda: m(x, act=F.ACT_LRELU, slope=slope, planes=hand))
                 else:
                     x = self._timed(i, lambda: m(x, act=F.ACT_LRELU, slope=slope))

@@ -44,18 +44,18 @@ def test_ops_fail_loudly_without_gpu():
 
 
 def test_shipped_library_has_no_result_changing_switches():
-    """The contract of libstem_hip.so is fp32-exact products: the reduced-precision (4 / 3 bf16 products) and ablated kernel
-    variants exist only in `make experiments` builds (-DSTEM_EXPERIMENTS -> libstem_hip_exper.so).  The shipped binary reports
+    """The contract of libstem_hip.so is fp32-class products everywhere: ablated / instrumented kernel variants exist only in
+    `make experiments` builds (-DSTEM_EXPERIMENTS -> libstem_hip_exper.so), no product-count switch exists at all.  The shipped binary reports
     so, does not contain the switches' names, and its plan selectors go through stem_tuning_set (validated, no environment)."""
     from spatiotemporalentropymodel_amd import _lib
     lib = _lib.hip()
     assert lib.stem_built_with_experiments() == 0
     blob = open(_lib.HIP_SO, "rb").read()
-    for name in (b"STEM_BF16_PRODUCTS", b"STEM_GA_BF16_PRODUCTS", b"STEM_BF16_PRODUCTS_DYN", b"STEM_IGEMM_EXPER", b"STEM_BX6_EXPER",
-                 b"STEM_BX6_SPLIT", b"STEM_WG6_SPLIT"):
+    for name in (b"STEM_BF16_PRODUCTS", b"STEM_GA_BF16_PRODUCTS", b"STEM_BF16_PRODUCTS_DYN", b"STEM_IGEMM_EXPER", b"STEM_FX3_EXPER",
+                 b"STEM_FX3_SPLIT", b"STEM_WG3_SPLIT"):
         assert name not in blob, name
-    assert lib.stem_tuning_get(b"bx6_split") == 0 and lib.stem_tuning_get(b"no_such") == -1
-    assert lib.stem_tuning_set(b"bx6_split", 3) == 0 and lib.stem_tuning_get(b"bx6_split") == 3
-    assert lib.stem_tuning_set(b"bx6_split", 0) == 0
-    assert lib.stem_tuning_set(b"bx6_tile", 96) != 0 and b"bx6_tile" in lib.stem_last_error()
+    assert lib.stem_tuning_get(b"fx3_split") == 0 and lib.stem_tuning_get(b"no_such") == -1
+    assert lib.stem_tuning_set(b"fx3_split", 3) == 0 and lib.stem_tuning_get(b"fx3_split") == 3
+    assert lib.stem_tuning_set(b"fx3_split", 0) == 0
+    assert lib.stem_tuning_set(b"fx3_tile", 96) != 0 and b"fx3_tile" in lib.stem_last_error()
     assert lib.stem_tuning_set(b"products", 4) != 0

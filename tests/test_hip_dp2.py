@@ -172,7 +172,7 @@ def test_gop_accumulator_two_ranks_equals_full_batch(dp2_results):
     assert errs[0][0] < 5e-2 and len(loose) <= 0.05 * len(errs), errs[:8]
     # ... and it sits in one of the kink-bearing conditioning nets of the I model: the quality-feature stacks (leaky ReLU 0.1) or
     # an SFT block's shared MLP (ReLU) -- which of them holds the element within fp32 noise of 0 depends on the kernels' tile /
-    # split plans (with the stride-1 layers on the bf16 kernels since round 3 it is ga1_SFT.mlp_shared)
+    # split plans (with the stride-1 layers on the fp16 kernels since round 3 it is ga1_SFT.mlp_shared)
     assert all("qmap_feature_" in n or "_SFT.mlp_" in n for _, n in loose), loose
 
 

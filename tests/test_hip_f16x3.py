@@ -1,6 +1,6 @@
-"""GPU parity tests of the analysis transform on the bf16 matrix cores (csrc/conv_bf16x6.hip, through the C ABI): the frozen
+"""GPU parity tests of the analysis transform on the fp16 matrix cores (csrc/conv_f16x3.hip, through the C ABI): the frozen
 g_a chain of the I-frame model (compressai/models/priors.py:613-621 under no_grad, stem/trainSTEM.py:128,171) with every fp32
-operand pre-split into three bf16 numbers and six MFMAs per fp32 product.  Same bound as the fp32-MFMA kernels: 1e-4 relative
+operand pre-split into two fp16 numbers and three MFMAs per fp32 product.  Same bound as the fp32-MFMA kernels: 1e-4 relative
 (north_star), against the CPU oracle and the golden vectors captured from the reference.
 """
 import os
@@ -53,7 +53,7 @@ def test_split_is_a_scaled_fp16_pair(F, mag):
     x = (rnd((3, 64, 5, 7), 1, -4, 4) * np.float32(mag)).astype(np.float32)
     x.reshape(-1)[:6] = np.array([0.0, -0.0, 1.0, -1.0, 2.0 ** -20, -3.0], np.float32) * np.float32(mag)
     amax = float(np.abs(x).max())
-    xp = F.Bf16Planes.split(dev(x))
+    xp = F.F16Planes.split(dev(x))
     inv, rec_max = xp.record()
     assert rec_max == amax and np.log2(inv) == np.round(np.log2(inv)) and 2.0 ** 14 <= amax / inv < 2.0 ** 15
     ref = torch.from_numpy(x).contiguous(memory_format=torch.channels_last)
@@ -65,7 +65,7 @@ def test_split_is_a_scaled_fp16_pair(F, mag):
     assert torch.equal(raw[:, :, 0], (nhwc / inv).to(torch.float16).float())             # round-to-nearest-even leading plane
     assert bool(torch.isfinite(raw).all()) and float(raw[:, :, 0].abs().max()) <= 2.0 ** 15
     with pytest.raises(ValueError):
-        F.Bf16Planes.empty(1, 48, 4, 4, torch.device("cuda:0"))
+        F.F16Planes.empty(1, 48, 4, 4, torch.device("cuda:0"))
 
 
 CASES = [  # B, C, H, W, K, R, stride
@@ -84,7 +84,7 @@ def test_conv_gdn_vs_oracle(F, case, tile128, gdn):
     """conv (+ fused GDN) against the oracle, both workgroup tiles (64 pixels x 4 wavefronts, 128 pixels x 8 wavefronts),
     fp32 and planes output; ragged pixel counts and channel counts below the 192-wide tile."""
     B, C, H, W, K, R, st = case
-    with F.tuning(bx6_tile=128 if tile128 else 64):
+    with F.tuning(fx3_tile=128 if tile128 else 64):
         _conv_gdn_vs_oracle(F, case, gdn)
 
 
@@ -95,24 +95,24 @@ def _conv_gdn_vs_oracle(F, case, gdn):
     ref = orc.conv2d_fwd(x, w, b, st, R // 2)
     if gdn:
         ref = orc.gdn_fwd(ref, beta, gamma)
-    xp = F.Bf16Planes.split(dev(x))
-    wp = F.pack_weight_bf16x3(dev(w))
+    xp = F.F16Planes.split(dev(x))
+    wp = F.pack_weight_f16x2(dev(w))
     kw = dict(beta=dev(beta), gamma=dev(gamma)) if gdn else {}
-    y = F.conv2d_bf16x6_fwd(xp, wp, dev(b), K, R, R, st, R // 2, **kw)
-    assert_close(host(y), ref, what=f"bf16x6 conv {case} gdn={gdn}", floor=0.1)
+    y = F.conv2d_f16x3_fwd(xp, wp, dev(b), K, R, R, st, R // 2, **kw)
+    assert_close(host(y), ref, what=f"f16x3 conv {case} gdn={gdn}", floor=0.1)
     if K % 32 == 0:
-        yp = F.conv2d_bf16x6_fwd(xp, wp, dev(b), K, R, R, st, R // 2, planes_out=True, **kw)
+        yp = F.conv2d_f16x3_fwd(xp, wp, dev(b), K, R, R, st, R // 2, planes_out=True, **kw)
         assert planes_match(yp, y), "planes output != fp32 output"
     else:
         with pytest.raises(Exception):
-            F.conv2d_bf16x6_fwd(xp, wp, dev(b), K, R, R, st, R // 2, planes_out=True, **kw)
+            F.conv2d_f16x3_fwd(xp, wp, dev(b), K, R, R, st, R // 2, planes_out=True, **kw)
 
 
-@pytest.mark.parametrize("route", ["bf16x6", "fp32-mfma"])
+@pytest.mark.parametrize("route", ["f16x3", "fp32-mfma"])
 def test_first_layer_writes_the_same_values_as_planes(F, monkeypatch, route):
-    """The 3-channel first layer + GDN (csrc/c4gdn_bf16x6.hip by default, igemm.hip's fp32-MFMA kernel with STEM_C4GDN_BF16X6=0):
+    """The 3-channel first layer + GDN (csrc/c4gdn_f16x3.hip by default, igemm.hip's fp32-MFMA kernel with STEM_C4GDN_F16X3=0):
     its planes epilogue must hold exactly the fp32 result, and that result is the oracle's."""
-    monkeypatch.setenv("STEM_C4GDN_BF16X6", "1" if route == "bf16x6" else "0")
+    monkeypatch.setenv("STEM_C4GDN_F16X3", "1" if route == "f16x3" else "0")
     x, w, b = rnd((2, 3, 40, 56), 21, 0, 1), (rnd((192, 3, 5, 5), 22) / np.sqrt(75)).astype(np.float32), rnd((192,), 23, -0.1, 0.1)
     beta, gamma = rnd((192,), 24, 0.5, 1.5), rnd((192, 192), 25, 0.0, 0.1)
     x4 = F.nchw3_to_nhwc4(dev(x))
@@ -134,7 +134,7 @@ C4_CASES = [  # B, H, W, K, R, stride, pad
 
 @pytest.mark.parametrize("case", C4_CASES)
 def test_first_layer_gdn_kernel_vs_oracle(F, case):
-    """csrc/c4gdn_bf16x6.hip on its own: conv (3 -> N) + GDN with the transposed contractions and the register hand-over of
+    """csrc/c4gdn_f16x3.hip on its own: conv (3 -> N) + GDN with the transposed contractions and the register hand-over of
     the squared outputs, fp32 and planes output, against the oracle (priors.py:421-423, gdn.py:52-67); image borders, ragged
     tiles, every supported N, bias present / absent."""
     B, H, W, K, R, st, pad = case
@@ -147,20 +147,20 @@ def test_first_layer_gdn_kernel_vs_oracle(F, case):
     ast = F.c4gdn_stream(F.pack_weight(dev(w), F.PACK_CONV_FWD_C4), dev(gamma), K, R, R)
     assert torch.equal(ast, F.c4gdn_stream(F.pack_weight(dev(w), F.PACK_CONV_FWD_C4), dev(gamma), K, R, R))
     ref = orc.gdn_fwd(orc.conv2d_fwd(x, w, b, st, pad), beta, gamma)
-    y = F.conv2d_c4_gdn_bf16x6(x4, ast, dev(b), dev(beta), K, R, R, st, pad)
+    y = F.conv2d_c4_gdn_f16x3(x4, ast, dev(b), dev(beta), K, R, R, st, pad)
     assert_close(host(y), ref, what=f"c4gdn {case}", floor=0.1)
-    yp = F.conv2d_c4_gdn_bf16x6(x4, ast, dev(b), dev(beta), K, R, R, st, pad, planes_out=True)
+    yp = F.conv2d_c4_gdn_f16x3(x4, ast, dev(b), dev(beta), K, R, R, st, pad, planes_out=True)
     assert planes_match(yp, y), "planes output != fp32 output"
-    y0 = F.conv2d_c4_gdn_bf16x6(x4, ast, None, dev(beta), K, R, R, st, pad)
+    y0 = F.conv2d_c4_gdn_f16x3(x4, ast, None, dev(beta), K, R, R, st, pad)
     assert_close(host(y0), orc.gdn_fwd(orc.conv2d_fwd(x, w, np.zeros(K, np.float32), st, pad), beta, gamma), what="no bias", floor=0.1)
     # into a channel slice of a wider NHWC buffer
     wide = torch.zeros(B, y.shape[2], y.shape[3], K + 64, device="cuda").permute(0, 3, 1, 2)
-    F.conv2d_c4_gdn_bf16x6(x4, ast, dev(b), dev(beta), K, R, R, st, pad, out=wide[:, 32:32 + K])
+    F.conv2d_c4_gdn_f16x3(x4, ast, dev(b), dev(beta), K, R, R, st, pad, out=wide[:, 32:32 + K])
     assert torch.equal(wide[:, 32:32 + K], y) and float(wide[:, :32].abs().max()) == 0 and float(wide[:, 32 + K:].abs().max()) == 0
 
 
 def test_analysis_transform_chain_vs_golden_and_fp32_kernels(F, golden, monkeypatch):
-    """getY of the reference's I-frame model on the golden frames, forced through the bf16 chain (the golden batch is far below
+    """getY of the reference's I-frame model on the golden frames, forced through the fp16 chain (the golden batch is far below
     the size at which the chain is selected by itself): within 1e-4 of the reference's output, and next to the fp32-MFMA result."""
     import spatiotemporalentropymodel_amd.layers as L
     from spatiotemporalentropymodel_amd import selfcheck
@@ -171,20 +171,20 @@ def test_analysis_transform_chain_vs_golden_and_fp32_kernels(F, golden, monkeypa
     imodel, _ = selfcheck.build_models(64, 96, 64, 96, d, cls=SpatioTemporalPriorModel)
     frames = [f.to(d) for f in smooth_frames("septuplet0", 1, 7, 256)][:2]
     calls = []
-    orig = F.conv2d_bf16x6_fwd
-    monkeypatch.setattr(F, "conv2d_bf16x6_fwd", lambda *a, **k: (calls.append(a[0].shape), orig(*a, **k))[1])
-    monkeypatch.setattr(L, "_BF16X6_MIN_PIXELS", 0)
-    monkeypatch.setenv("STEM_BF16X6", "1")             # whatever the suite was started with
+    orig = F.conv2d_f16x3_fwd
+    monkeypatch.setattr(F, "conv2d_f16x3_fwd", lambda *a, **k: (calls.append(a[0].shape), orig(*a, **k))[1])
+    monkeypatch.setattr(L, "_F16X3_MIN_PIXELS", 0)
+    monkeypatch.setenv("STEM_F16X3", "1")             # whatever the suite was started with
     with torch.no_grad():
         y0, _ = imodel.getY(frames[0])
         y1, _ = imodel.getY(frames[1])
-        assert len(calls) == 6, calls                   # g_a.2, g_a.4, g_a.6 of both frames ran on the 192-wide bf16 kernel
-        monkeypatch.setenv("STEM_BF16X6", "0")
+        assert len(calls) == 6, calls                   # g_a.2, g_a.4, g_a.6 of both frames ran on the 192-wide fp16 kernel
+        monkeypatch.setenv("STEM_F16X3", "0")
         y0_32, _ = imodel.getY(frames[0])
         assert len(calls) == 6
-    assert_close(host(y0), g["y0"], what="g_a(frame 0), bf16 chain", floor=0.1)
-    assert_close(host(y1), g["f1:y_cur"], what="g_a(frame 1), bf16 chain", floor=0.1)
-    assert_close(host(y0), host(y0_32), what="bf16 chain vs fp32-MFMA kernels", floor=0.1)
+    assert_close(host(y0), g["y0"], what="g_a(frame 0), fp16 chain", floor=0.1)
+    assert_close(host(y1), g["f1:y_cur"], what="g_a(frame 1), fp16 chain", floor=0.1)
+    assert_close(host(y0), host(y0_32), what="fp16 chain vs fp32-MFMA kernels", floor=0.1)
 
 
 def test_chain_is_selected_at_the_bench_size_and_not_under_autograd(F, monkeypatch):
@@ -195,21 +195,21 @@ def test_chain_is_selected_at_the_bench_size_and_not_under_autograd(F, monkeypat
     imodel = models["mbt2018"](quality=4).cuda().eval()
     x = torch.rand(16, 3, 256, 256, device="cuda")
     seen = []
-    monkeypatch.setenv("STEM_BF16X6", "1")             # whatever the suite was started with
-    orig6, orig4 = F.conv2d_bf16x6_fwd, F.conv2d_fwd_c4_gdn_planes
-    monkeypatch.setattr(F, "conv2d_bf16x6_fwd", lambda *a, **k: (seen.append(("bx6", a[0].shape, k.get("planes_out"))), orig6(*a, **k))[1])
+    monkeypatch.setenv("STEM_F16X3", "1")             # whatever the suite was started with
+    orig6, orig4 = F.conv2d_f16x3_fwd, F.conv2d_fwd_c4_gdn_planes
+    monkeypatch.setattr(F, "conv2d_f16x3_fwd", lambda *a, **k: (seen.append(("fx3", a[0].shape, k.get("planes_out"))), orig6(*a, **k))[1])
     monkeypatch.setattr(F, "conv2d_fwd_c4_gdn_planes", lambda *a, **k: (seen.append(("c4",)), orig4(*a, **k))[1])
-    origg = F.conv2d_bf16x6_gen
-    monkeypatch.setattr(F, "conv2d_bf16x6_gen", lambda *a, **k: (seen.append(("gen", a[0].shape)), origg(*a, **k))[1])
+    origg = F.conv2d_f16x3_gen
+    monkeypatch.setattr(F, "conv2d_f16x3_gen", lambda *a, **k: (seen.append(("gen", a[0].shape)), origg(*a, **k))[1])
     with torch.no_grad():
         y = imodel.g_a(x)
-    assert seen == [("c4",), ("bx6", (16, 192, 128, 128), True), ("bx6", (16, 192, 64, 64), True), ("gen", (16, 192, 32, 32))], seen
-    monkeypatch.setenv("STEM_BF16X6", "0")
+    assert seen == [("c4",), ("fx3", (16, 192, 128, 128), True), ("fx3", (16, 192, 64, 64), True), ("gen", (16, 192, 32, 32))], seen
+    monkeypatch.setenv("STEM_F16X3", "0")
     with torch.no_grad():
         y32 = imodel.g_a(x)
-    assert_close(host(y), host(y32), what="g_a at B=16, bf16 chain vs fp32-MFMA kernels", floor=0.1)
+    assert_close(host(y), host(y32), what="g_a at B=16, fp16 chain vs fp32-MFMA kernels", floor=0.1)
     assert float((y - y32).abs().max()) <= 1e-5 * float(y32.abs().max())          # measured: 2.7e-6 of the largest latent
-    monkeypatch.setenv("STEM_BF16X6", "1")
+    monkeypatch.setenv("STEM_F16X3", "1")
     n = len(seen)
     y_grad = imodel.g_a(x)
     assert len(seen) == n and y_grad.requires_grad
@@ -230,7 +230,7 @@ GEN_CASES = [  # B, C, H, W, K, R
 def test_gen_forward_and_input_gradient_vs_oracle(F, case, split):
     """forward + leaky ReLU and input-gradient x leaky-ReLU derivative (what autograd derives for conv(lrelu(u))) against the
     oracle, with the planner's split-K factor (0), unsplit (1) and a forced 3-way split; planes output = fp32 output."""
-    with F.tuning(bx6_split=split):
+    with F.tuning(fx3_split=split):
         _gen_forward_and_input_gradient(F, case, split)
 
 
@@ -244,11 +244,11 @@ def _gen_forward_and_input_gradient(F, case, split):
     dx_ref = orc.conv2d_bwd(x, w, dy, 1, pad)[0]
     dx_ref = np.where(x > 0, dx_ref, dx_ref * sl).astype(np.float32)
     xd = dev(x).contiguous(memory_format=torch.channels_last)
-    y, yp = F.conv2d_bf16x6_gen(F.Bf16Planes.split(xd), F.pack_weight_bf16x3_gen(dev(w)), dev(b), K, R, R, 1, pad,
+    y, yp = F.conv2d_f16x3_gen(F.F16Planes.split(xd), F.pack_weight_f16x2_gen(dev(w)), dev(b), K, R, R, 1, pad,
                                 epi=F.GEN_EPI_LRELU, slope=sl, want_planes=True)
     assert_close(host(y), ref, what=f"gen fwd {case} split={split}", floor=0.1)
     assert planes_match(yp, y)
-    d, dp = F.conv2d_bf16x6_gen(F.Bf16Planes.split(dev(dy)), F.pack_weight_bf16x3_gen(dev(w), flip=True), None, C, R, R, 1, pad,
+    d, dp = F.conv2d_f16x3_gen(F.F16Planes.split(dev(dy)), F.pack_weight_f16x2_gen(dev(w), flip=True), None, C, R, R, 1, pad,
                                 epi=F.GEN_EPI_DACT, slope=sl, z=xd, want_planes=True)
     assert_close(host(d), dx_ref, what=f"gen dgrad {case} split={split}", floor=0.1)
     assert planes_match(dp, d)
@@ -262,11 +262,11 @@ def test_gen_channel_views_strided_output_and_multi_pack(F):
     big = rnd((B, 160, H, W), 41, -2, 2)
     w = (rnd((96, 64, 3, 3), 42) / np.sqrt(64 * 9)).astype(np.float32)
     b = rnd((96,), 43, -0.1, 0.1)
-    bigp = F.Bf16Planes.split(dev(big))
+    bigp = F.F16Planes.split(dev(big))
     wide = torch.zeros(B, H, W, 224, device="cuda").permute(0, 3, 1, 2)           # NHWC buffer, 224 channels
     out = wide[:, 64:160]
-    wp = F.pack_weight_bf16x3_gen(dev(w))
-    y, _ = F.conv2d_bf16x6_gen(bigp.channels(32, 96), wp, dev(b), 96, 3, 3, 1, 1, out=out)
+    wp = F.pack_weight_f16x2_gen(dev(w))
+    y, _ = F.conv2d_f16x3_gen(bigp.channels(32, 96), wp, dev(b), 96, 3, 3, 1, 1, out=out)
     assert y.data_ptr() == out.data_ptr()
     assert_close(host(out), orc.conv2d_fwd(big[:, 32:96], w, b, 1, 1), what="view in, slice out", floor=0.1)
     assert float(wide[:, :64].abs().max()) == 0 and float(wide[:, 160:].abs().max()) == 0
@@ -275,27 +275,27 @@ def test_gen_channel_views_strided_output_and_multi_pack(F):
     # multi pack == single packs (forward and mirrored)
     w2 = (rnd((64, 96, 5, 5), 44) / 50).astype(np.float32)
     wd, w2d = dev(w), dev(w2)
-    singles = [F.pack_weight_bf16x3_gen(wd), F.pack_weight_bf16x3_gen(wd, flip=True), F.pack_weight_bf16x3_gen(w2d)]
+    singles = [F.pack_weight_f16x2_gen(wd), F.pack_weight_f16x2_gen(wd, flip=True), F.pack_weight_f16x2_gen(w2d)]
     outs = [torch.empty_like(s) for s in singles]
-    descs = (_lib.Bf16PackDesc * 3)(_lib.Bf16PackDesc(wd.data_ptr(), outs[0].data_ptr(), 96, 64, 3, 3, 0, 0),
-                                    _lib.Bf16PackDesc(wd.data_ptr(), outs[1].data_ptr(), 64, 96, 3, 3, 1, 0),
-                                    _lib.Bf16PackDesc(w2d.data_ptr(), outs[2].data_ptr(), 64, 96, 5, 5, 0, 0))
-    F.pack_weights_bf16x3_multi(descs)
+    descs = (_lib.F16PackDesc * 3)(_lib.F16PackDesc(wd.data_ptr(), outs[0].data_ptr(), 96, 64, 3, 3, 0, 0),
+                                    _lib.F16PackDesc(wd.data_ptr(), outs[1].data_ptr(), 64, 96, 3, 3, 1, 0),
+                                    _lib.F16PackDesc(w2d.data_ptr(), outs[2].data_ptr(), 64, 96, 5, 5, 0, 0))
+    F.pack_weights_f16x2_multi(descs)
     for a, s in zip(outs, singles):
         assert torch.equal(a, s)
 
 
 def test_engine_schedule_with_and_without_bf16_layers(monkeypatch):
     """One training forward / backward of the full-size STEM model (B=2, 16x16 latents) through the explicit schedule with the
-    stride-1 layers on the bf16 kernels and with every layer on the fp32-MFMA kernels, BOTH measured against the CPU oracle
+    stride-1 layers on the fp16 kernels and with every layer on the fp32-MFMA kernels, BOTH measured against the CPU oracle
     (double accumulation) on the same weights, inputs and noise (the two routes used to be compared only
     with each other, at 2e-4 of the tensor maximum).
 
     Metric per gradient tensor: max |err| / max(|ref|, rms(ref)) over ALL elements.  Measured on MI355X
-    (tools/debug/route_vs_oracle.py, these inputs): fp32-MFMA route 5.8e-4 / bf16 route 4.2e-4 on the worst tensor (HE.4 / HD.2
+    (tools/debug/route_vs_oracle.py, these inputs): fp32-MFMA route 5.8e-4 / fp16 route 4.2e-4 on the worst tensor (HE.4 / HD.2
     weights: hyper-path gradients are sums of a few dlik / lik terms over 4x4 latents, where the fp32 rounding of z decides
     ~1e-4 of the result on either side -- the reference's own fp32 run is that far from its float64 run, test_hip_models.py),
-    1e-4 .. 3e-4 elsewhere.  So: (a) the bf16 route is held to the fp32-MFMA route's distance from the oracle, tensor by
+    1e-4 .. 3e-4 elsewhere.  So: (a) the fp16 route is held to the fp32-MFMA route's distance from the oracle, tensor by
     tensor (it is consistently the closer one); (b) both are held to an absolute 1e-3 in that strict metric; (c) the discrete
     decisions (leaky-ReLU sides, likelihood bound) of both runs and the oracle are compared, and with none flipped the two
     routes must also agree to 2e-4 of every tensor's maximum."""
@@ -307,36 +307,36 @@ def test_engine_schedule_with_and_without_bf16_layers(monkeypatch):
     y_cur = closed_form_input("eng:y", (2, 192, 16, 16), -6, 6).to(d)
     y_cond = closed_form_input("eng:c", (2, 192, 16, 16), -6, 6).to(d)
     runs = {}
-    for tag, on in (("bf16", True), ("fp32", False)):
-        monkeypatch.setattr(E.StemEngine, "use_bx6", on)
+    for tag, on in (("fp16", True), ("fp32", False)):
+        monkeypatch.setattr(E.StemEngine, "use_fx3", on)
         m = closed_form_fill_(SpatioTemporalPriorModel_Res()).to(d).train()
-        assert any(l.bx6 for l in m.engine().layers) == on
+        assert any(l.fx3 for l in m.engine().layers) == on
         runs[tag] = OP.hip_train_pass(m, y_cur, y_cond, "eng")
     ref, rgrads, racts = OP.oracle_train_pass(m, y_cur, y_cond, runs["fp32"][4], residual=True)
-    assert abs(runs["bf16"][1] - runs["fp32"][1]) <= 1e-5 * abs(runs["fp32"][1])
-    assert runs["bf16"][2].keys() == runs["fp32"][2].keys() and len(rgrads) > 30
+    assert abs(runs["fp16"][1] - runs["fp32"][1]) <= 1e-5 * abs(runs["fp32"][1])
+    assert runs["fp16"][2].keys() == runs["fp32"][2].keys() and len(rgrads) > 30
     dist = {tag: {n: OP.grad_distance(runs[tag][2][n], g) for n, g in rgrads.items() if n in runs[tag][2]} for tag in runs}
     flips = {tag: OP.decisions_flipped(runs[tag][3], racts, OP.host(runs[tag][0]["likelihoods"]["y"]), ref["lik_y"]) for tag in runs}
-    flips["bf16 vs fp32"] = OP.decisions_flipped(runs["bf16"][3], runs["fp32"][3])
+    flips["fp16 vs fp32"] = OP.decisions_flipped(runs["fp16"][3], runs["fp32"][3])
     for tag in runs:
         worst = sorted(((v, n) for n, v in dist[tag].items()), reverse=True)[:4]
         print(f"{tag} route vs oracle: decisions flipped {flips[tag] or 'none'}; worst gradients " + ", ".join(f"{n} {v:.1e}" for v, n in worst))
     assert sum(sum(f.values()) for f in flips.values()) <= 4, flips
     flipped = any(flips.values())
     for n in rgrads:
-        if n not in dist["bf16"]:
+        if n not in dist["fp16"]:
             continue
-        db, df = dist["bf16"][n], dist["fp32"][n]
+        db, df = dist["fp16"][n], dist["fp32"][n]
         if not flipped:
-            assert db <= 1.5 * df + 1e-4, f"{n}: bf16 route {db:.2e} from the oracle, fp32-MFMA route {df:.2e}"
+            assert db <= 1.5 * df + 1e-4, f"{n}: fp16 route {db:.2e} from the oracle, fp32-MFMA route {df:.2e}"
             assert max(db, df) <= 1e-3, (n, db, df)
-            assert_close(runs["bf16"][2][n], runs["fp32"][2][n], rtol=2e-4, what=f"grad {n}, route vs route", floor=1.0)
+            assert_close(runs["fp16"][2][n], runs["fp32"][2][n], rtol=2e-4, what=f"grad {n}, route vs route", floor=1.0)
     if flipped:
         print("decisions flipped: per-tensor gates skipped for this run", flips)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
-# Weight gradient (csrc/wgrad_bf16x6.hip): contraction over pixels through the transposing LDS reads
+# Weight gradient (csrc/wgrad_f16x3.hip): contraction over pixels through the transposing LDS reads
 WG_CASES = [  # B, C, H, W, K, R
     (2, 64, 9, 11, 96, 3),           # ragged pixel count (198 = 12 chunks of 16 + 6), one tile
     (1, 160, 13, 7, 96, 5),          # C = 160: second channel tile half empty
@@ -348,7 +348,7 @@ WG_CASES = [  # B, C, H, W, K, R
 @pytest.mark.parametrize("case", WG_CASES)
 @pytest.mark.parametrize("split", [0, 1, 3])
 def test_weight_gradient_vs_oracle(F, case, split):
-    with F.tuning(wg6_split=split):
+    with F.tuning(wg3_split=split):
         _weight_gradient_vs_oracle(F, case, split)
 
 
@@ -359,16 +359,16 @@ def _weight_gradient_vs_oracle(F, case, split):
     w0 = np.zeros((K, C, R, R), np.float32)
     _, dw_ref, db_ref = orc.conv2d_bwd(x, w0, dy, 1, pad, need_dx=False)
     xd, dyd = dev(x), dev(dy)
-    splits, elems = F.wgrad_bf16x6_plan(xd.shape, K, R, R, pad)
+    splits, elems = F.wgrad_f16x3_plan(xd.shape, K, R, R, pad)
     assert split == 0 or splits <= split             # clamped to >= 16 pixel chunks per split
     dwp = torch.empty(elems, device="cuda")
     dbf = torch.full((K,), float("nan"), device="cuda")
-    F.conv2d_wgrad_bf16x6(F.Bf16Planes.split(xd), F.Bf16Planes.split(dyd), K, R, R, pad, dwp, splits, db=dbf)
+    F.conv2d_wgrad_f16x3(F.F16Planes.split(xd), F.F16Planes.split(dyd), K, R, R, pad, dwp, splits, db=dbf)
     dw = dwp.view(splits, R * R, K, C).sum(0).permute(1, 2, 0).reshape(K, C, R, R)
     assert_close(host(dw), dw_ref, what=f"wgrad {case} split={split}", floor=0.1)
     assert_close(host(dbf), db_ref, what="bias gradient from the weight-gradient pass", floor=0.1)
     dbacc = dbf.clone()
-    F.conv2d_wgrad_bf16x6(F.Bf16Planes.split(xd), F.Bf16Planes.split(dyd), K, R, R, pad, dwp, splits, db=dbacc, accumulate_db=True)
+    F.conv2d_wgrad_f16x3(F.F16Planes.split(xd), F.F16Planes.split(dyd), K, R, R, pad, dwp, splits, db=dbacc, accumulate_db=True)
     assert_close(host(dbacc), 2 * db_ref, what="bias gradient from the weight-gradient pass, accumulated", floor=0.1)
     db = torch.zeros(K, device="cuda")
     F.bias_grad(dyd.contiguous(memory_format=torch.channels_last), db)
@@ -381,10 +381,10 @@ def test_weight_gradient_from_channel_views(F):
     """x and dy as 32-aligned channel views of wider planes tensors (how the engine feeds the prior branches' slices)"""
     B, H, W = 2, 8, 8
     xb, dyb = rnd((B, 160, H, W), 61, -2, 2), rnd((B, 224, H, W), 62)
-    xp, dyp = F.Bf16Planes.split(dev(xb)).channels(32, 96), F.Bf16Planes.split(dev(dyb)).channels(64, 160)
-    splits, elems = F.wgrad_bf16x6_plan(xp.shape, 96, 3, 3, 1)
+    xp, dyp = F.F16Planes.split(dev(xb)).channels(32, 96), F.F16Planes.split(dev(dyb)).channels(64, 160)
+    splits, elems = F.wgrad_f16x3_plan(xp.shape, 96, 3, 3, 1)
     dwp = torch.empty(elems, device="cuda")
-    F.conv2d_wgrad_bf16x6(xp, dyp, 96, 3, 3, 1, dwp, splits)
+    F.conv2d_wgrad_f16x3(xp, dyp, 96, 3, 3, 1, dwp, splits)
     dw = dwp.view(splits, 9, 96, 64).sum(0).permute(1, 2, 0).reshape(96, 64, 3, 3)
     ref = orc.conv2d_bwd(np.ascontiguousarray(xb[:, 32:96]), np.zeros((96, 64, 3, 3), np.float32), np.ascontiguousarray(dyb[:, 64:160]), 1, 1,
                          need_dx=False)[1]
@@ -400,17 +400,17 @@ def test_gen_kernel_at_eight_full_hd_sequences(F):
     x = torch.randn(B, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
     w = torch.randn(K, C, 1, 1, device="cuda") / C ** 0.5
     b = torch.randn(K, device="cuda") * 0.1
-    y, _ = F.conv2d_bf16x6_gen(F.Bf16Planes.split(x), F.pack_weight_bf16x3_gen(w), b, K, 1, 1, 1, 0, epi=F.GEN_EPI_LRELU, slope=0.01)
+    y, _ = F.conv2d_f16x3_gen(F.F16Planes.split(x), F.pack_weight_f16x2_gen(w), b, K, 1, 1, 1, 0, epi=F.GEN_EPI_LRELU, slope=0.01)
     y32 = F.conv2d_fwd(x, F.pack_weight(w, F.PACK_CONV_FWD), b, K, 1, 1, 1, 0, F.ACT_LRELU, slope=0.01)
     assert_close(host(y), host(y32), what="gen kernel, 65280 pixels x 768 channels", floor=0.1)
 
 
 def test_random_shapes_through_all_three_kernels():
-    """tools/debug/bf16x6_fuzz.py: 40 random (batch, size, channels, kernel, stride) combinations through the analysis-transform
+    """tools/debug/f16x3_fuzz.py: 40 random (batch, size, channels, kernel, stride) combinations through the analysis-transform
     kernel (+ GDN), the general kernel (forward, input gradient) and the weight-gradient kernel (+ bias gradient) against float64
     torch references; every planes output must equal its fp32 twin.  Called in-process (a GPU-initialised pytest
     process must not start GPU children on this pool)."""
     sys.path.insert(0, os.path.join(REPO, "tools", "debug"))
-    import bf16x6_fuzz
-    worst = bf16x6_fuzz.run(40, 7, verbose=False)
+    import f16x3_fuzz
+    worst = f16x3_fuzz.run(40, 7, verbose=False)
     assert worst <= 1e-5, worst

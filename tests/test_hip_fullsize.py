@@ -88,35 +88,35 @@ def test_fused_analysis_conv_gdn_fullsize_vs_oracle(F):
     assert_close(y2.cpu().contiguous().numpy(), ref, what="g_a.2 then GDN at B=16", floor=0.1)
 
 
-def test_bf16x6_analysis_conv_gdn_fullsize_vs_oracle(F):
-    """THE roofline kernel of bench.py since round 2 -- conv_bf16x6_kernel<128,6>: g_a.2 (192->192, 5x5 s2, 128^2 -> 64^2) with
+def test_f16x3_analysis_conv_gdn_fullsize_vs_oracle(F):
+    """THE roofline kernel of bench.py since round 2 -- conv_f16x3_kernel<128,6>: g_a.2 (192->192, 5x5 s2, 128^2 -> 64^2) with
     GDN g_a.3 fused, B=16, planes in -> planes out, 128-pixel workgroups (the tile the library picks at this size) -- against
     the oracle's conv2d_fwd + gdn_fwd on the WHOLE tensor (the full-size check still exercised the fp32
     igemm kernel).  priors.py:424-425."""
     from spatiotemporalentropymodel_amd import _lib
     from spatiotemporalentropymodel_amd.weights import closed_form_tensor
-    assert _lib.hip().stem_tuning_get(b"bx6_tile") == 0          # the library's own choice
+    assert _lib.hip().stem_tuning_get(b"fx3_tile") == 0          # the library's own choice
     torch.manual_seed(21)
     B, C, H, W, K = 16, 192, 128, 128, 192
     x = cl(torch.randn(B, C, H, W, device="cuda"))
     w = closed_form_tensor("g_a.2.weight", (K, C, 5, 5))
     b = closed_form_tensor("g_a.2.bias", (K,))
     beta, gamma = closed_form_tensor("g_a.3.beta", (K,)), closed_form_tensor("g_a.3.gamma", (K, K))
-    xp = F.Bf16Planes.split(x)
+    xp = F.F16Planes.split(x)
     assert planes_match(xp, x)
-    yp = F.conv2d_bf16x6_fwd(xp, F.pack_weight_bf16x3(w.cuda()), b.cuda(), K, 5, 5, 2, 2, planes_out=True, beta=beta.cuda(), gamma=gamma.cuda())
+    yp = F.conv2d_f16x3_fwd(xp, F.pack_weight_f16x2(w.cuda()), b.cuda(), K, 5, 5, 2, 2, planes_out=True, beta=beta.cuda(), gamma=gamma.cuda())
     y = yp.merge()
     assert tuple(y.shape) == (B, K, 64, 64)
     ref = orc.gdn_fwd(orc.conv2d_fwd(x.cpu().contiguous().numpy(), w.numpy(), b.numpy(), 2, 2), beta.numpy(), gamma.numpy())
-    assert_close(y.cpu().contiguous().numpy(), ref, what="bf16x6 g_a.2 + GDN at B=16 (planes -> planes)", floor=0.1)
+    assert_close(y.cpu().contiguous().numpy(), ref, what="f16x3 g_a.2 + GDN at B=16 (planes -> planes)", floor=0.1)
     # 64-pixel workgroups (the other tile of the same kernel) give the same tensor up to summation order
-    with F.tuning(bx6_tile=64):
-        y64 = F.conv2d_bf16x6_fwd(xp, F.pack_weight_bf16x3(w.cuda()), b.cuda(), K, 5, 5, 2, 2, beta=beta.cuda(), gamma=gamma.cuda())
-    assert_close(y64.cpu().contiguous().numpy(), ref, what="bf16x6 g_a.2 + GDN at B=16, 64-pixel tiles", floor=0.1)
+    with F.tuning(fx3_tile=64):
+        y64 = F.conv2d_f16x3_fwd(xp, F.pack_weight_f16x2(w.cuda()), b.cuda(), K, 5, 5, 2, 2, beta=beta.cuda(), gamma=gamma.cuda())
+    assert_close(y64.cpu().contiguous().numpy(), ref, what="f16x3 g_a.2 + GDN at B=16, 64-pixel tiles", floor=0.1)
 
 
 def test_first_layer_gdn_fullsize_vs_oracle(F):
-    """g_a.0 + GDN g_a.1 at the benchmark shape (B=16, 3 x 256^2 -> 192 x 128^2) on csrc/c4gdn_bf16x6.hip, planes out (what the
+    """g_a.0 + GDN g_a.1 at the benchmark shape (B=16, 3 x 256^2 -> 192 x 128^2) on csrc/c4gdn_f16x3.hip, planes out (what the
     bench's analysis transform runs), whole tensor against the oracle.  priors.py:421-423."""
     from spatiotemporalentropymodel_amd.weights import closed_form_tensor
     torch.manual_seed(22)
@@ -126,49 +126,49 @@ def test_first_layer_gdn_fullsize_vs_oracle(F):
     beta, gamma = closed_form_tensor("g_a.1.beta", (K,)), closed_form_tensor("g_a.1.gamma", (K, K))
     assert F.c4gdn_supported(K, 5, 5)
     ast = F.c4gdn_stream(F.pack_weight(w.cuda(), F.PACK_CONV_FWD_C4), gamma.cuda(), K, 5, 5)
-    yp = F.conv2d_c4_gdn_bf16x6(F.nchw3_to_nhwc4(x), ast, b.cuda(), beta.cuda(), K, 5, 5, 2, 2, planes_out=True)
+    yp = F.conv2d_c4_gdn_f16x3(F.nchw3_to_nhwc4(x), ast, b.cuda(), beta.cuda(), K, 5, 5, 2, 2, planes_out=True)
     y = yp.merge()
     assert tuple(y.shape) == (B, K, 128, 128)
     ref = orc.gdn_fwd(orc.conv2d_fwd(x.cpu().numpy(), w.numpy(), b.numpy(), 2, 2), beta.numpy(), gamma.numpy())
-    assert_close(y.cpu().contiguous().numpy(), ref, what="g_a.0 + GDN at B=16 (c4gdn_bf16x6, planes)", floor=0.1)
+    assert_close(y.cpu().contiguous().numpy(), ref, what="g_a.0 + GDN at B=16 (c4gdn_f16x3, planes)", floor=0.1)
 
 
 @pytest.mark.parametrize("name,shape", [("TPM.2", (16, 256, 16, 16, 320, 5)), ("TPM.4", (16, 320, 16, 16, 384, 5)), ("EPM.0", (16, 1152, 16, 16, 768, 1))])
-def test_bf16x6_training_kernels_fullsize_vs_oracle(F, name, shape):
+def test_f16x3_training_kernels_fullsize_vs_oracle(F, name, shape):
     """The kernels the bench's P-frame step runs for the stride-1 STEM layers, at their B=16 shapes and with the planner's own
-    split factors: conv_bf16x6_gen_kernel forward (+ leaky ReLU, planes out) and input gradient (mirrored weight, x leaky-ReLU'),
-    wgrad_bf16x6_kernel with the bias gradient of the same pass -- whole tensors against the oracle
+    split factors: conv_f16x3_gen_kernel forward (+ leaky ReLU, planes out) and input gradient (mirrored weight, x leaky-ReLU'),
+    wgrad_f16x3_kernel with the bias gradient of the same pass -- whole tensors against the oracle
     (spatiotemporalpriors.py:807-838; VERDICT r2 weak #1: until now only route-vs-route agreement covered these plans)."""
     from spatiotemporalentropymodel_amd import _lib
     B, C, H, W, K, R = shape
     pad, sl = R // 2, 0.01
-    assert _lib.hip().stem_tuning_get(b"bx6_split") == 0 and _lib.hip().stem_tuning_get(b"wg6_split") == 0
+    assert _lib.hip().stem_tuning_get(b"fx3_split") == 0 and _lib.hip().stem_tuning_get(b"wg3_split") == 0
     torch.manual_seed(33)
     x = cl(torch.randn(B, C, H, W, device="cuda"))
     w = torch.randn(K, C, R, R, device="cuda") * (1.0 / (C * R * R) ** 0.5)
     b = torch.randn(K, device="cuda") * 0.1
     dy = cl(torch.randn(B, K, H, W, device="cuda"))
     xn, wn, bn, dyn = x.cpu().contiguous().numpy(), w.cpu().numpy(), b.cpu().numpy(), dy.cpu().contiguous().numpy()
-    xp, dyp = F.Bf16Planes.split(x), F.Bf16Planes.split(dy)
+    xp, dyp = F.F16Planes.split(x), F.F16Planes.split(dy)
     # forward
-    y, yp = F.conv2d_bf16x6_gen(xp, F.pack_weight_bf16x3_gen(w), b, K, R, R, 1, pad, epi=F.GEN_EPI_LRELU, slope=sl, want_planes=True)
+    y, yp = F.conv2d_f16x3_gen(xp, F.pack_weight_f16x2_gen(w), b, K, R, R, 1, pad, epi=F.GEN_EPI_LRELU, slope=sl, want_planes=True)
     ref = orc.conv2d_fwd(xn, wn, bn, 1, pad)
     ref = np.where(ref > 0, ref, ref * sl).astype(np.float32)
-    assert_close(y.cpu().contiguous().numpy(), ref, what=f"{name} forward (bf16x6 general kernel)", floor=0.1)
+    assert_close(y.cpu().contiguous().numpy(), ref, what=f"{name} forward (f16x3 general kernel)", floor=0.1)
     assert planes_match(yp, y)
     # input gradient and weight / bias gradient
     rdx, rdw, rdb = orc.conv2d_bwd(xn, wn, dyn, 1, pad)
     rdx = np.where(xn > 0, rdx, rdx * sl).astype(np.float32)
-    d, _ = F.conv2d_bf16x6_gen(dyp, F.pack_weight_bf16x3_gen(w, flip=True), None, C, R, R, 1, pad, epi=F.GEN_EPI_DACT, slope=sl, z=x)
-    assert_close(d.cpu().contiguous().numpy(), rdx, what=f"{name} input gradient (bf16x6 general kernel)", floor=0.1)
-    splits, elems = F.wgrad_bf16x6_plan(x.shape, K, R, R, pad)
+    d, _ = F.conv2d_f16x3_gen(dyp, F.pack_weight_f16x2_gen(w, flip=True), None, C, R, R, 1, pad, epi=F.GEN_EPI_DACT, slope=sl, z=x)
+    assert_close(d.cpu().contiguous().numpy(), rdx, what=f"{name} input gradient (f16x3 general kernel)", floor=0.1)
+    splits, elems = F.wgrad_f16x3_plan(x.shape, K, R, R, pad)
     dwp = torch.empty(elems, device="cuda")
     db = torch.full((K,), float("nan"), device="cuda")
-    F.conv2d_wgrad_bf16x6(xp, dyp, K, R, R, pad, dwp, splits, db=db)
+    F.conv2d_wgrad_f16x3(xp, dyp, K, R, R, pad, dwp, splits, db=db)
     dw = dwp.view(splits, R * R, K, C).sum(0).permute(1, 2, 0).reshape(K, C, R, R)
     print(f"{name}: wgrad splits {splits}")
-    assert_close(dw.cpu().numpy(), rdw, what=f"{name} weight gradient (wgrad_bf16x6)", floor=0.1)
-    assert_close(db.cpu().numpy(), rdb, what=f"{name} bias gradient (wgrad_bf16x6 pass)", floor=0.1)
+    assert_close(dw.cpu().numpy(), rdw, what=f"{name} weight gradient (wgrad_f16x3)", floor=0.1)
+    assert_close(db.cpu().numpy(), rdb, what=f"{name} bias gradient (wgrad_f16x3 pass)", floor=0.1)
 
 
 @pytest.mark.parametrize("name,shape", [("TPM.2", (16, 256, 16, 16, 320, 5, 1, 2)), ("HE.2", (16, 256, 16, 16, 256, 5, 2, 2)),

@@ -297,10 +297,10 @@ def test_ablation_variants_training_pass_matches_reference(golden, cls, ebc):
 @pytest.mark.parametrize("cin", [24, 48, 64])
 def test_latent_channel_counts_off_the_bf16_grid_train_pass_vs_oracle(cin):
     """Latent channel counts that are not multiples of 16: some layers of the TPM / EPM chains cannot run on the
-    bf16 kernels (C % 32), so the engine must keep the WHOLE chain on the fp32-MFMA kernels -- a half-routed chain used to
+    fp16 kernels (C % 32), so the engine must keep the WHOLE chain on the fp32-MFMA kernels -- a half-routed chain used to
     call a kernel whose packed weights were never allocated.  Training forward, likelihoods and every parameter gradient of
     SpatioTemporalPriorModel_Res(64, cin) against the oracle on the same weights, inputs and noise (24: both chains fp32;
-    48: EPM bf16, TPM fp32; 64: both bf16).  spatiotemporalpriors.py:807-868.
+    48: EPM fp16, TPM fp32; 64: both fp16).  spatiotemporalpriors.py:807-868.
 
     Gradient metric: max |err| / max(|ref|, rms) over all elements.  Both sides are fp32 implementations (the oracle stores
     activations in fp32 and accumulates in double), so the bound is 1e-4 for each side: 2e-4, and 5e-4 on the hyper path
@@ -313,7 +313,7 @@ def test_latent_channel_counts_off_the_bf16_grid_train_pass_vs_oracle(cin):
     B, ebc, ls = 2, 64, 8
     m = closed_form_fill_(SpatioTemporalPriorModel_Res(ebc, cin)).to(dev).train()
     eng = m.engine()
-    routed = {"TPM": eng.TPM[0].bx6, "EPM": eng.EPM[0].bx6}
+    routed = {"TPM": eng.TPM[0].fx3, "EPM": eng.EPM[0].fx3}
     assert routed == {24: {"TPM": False, "EPM": False}, 48: {"TPM": False, "EPM": True}, 64: {"TPM": True, "EPM": True}}[cin]
     y_cond = closed_form_input("odd:c", (B, cin, ls, ls), -4.0, 4.0).to(dev)
     y_cur = y_cond + closed_form_input("odd:r", (B, cin, ls, ls), -1.5, 1.5).to(dev)

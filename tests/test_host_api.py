@@ -408,16 +408,16 @@ def test_masked_conv_mask_layouts():
 
 
 def test_bf16_planes_views_and_engine_routing_table():
-    """Host logic of the bf16 route (no device work): channel views of a planes tensor (32-aligned, same storage and pitch), and which
-    layers of the full-size STEM model the engine sends to the bf16 kernels: forward / input gradient of the stride-1 unmasked
+    """Host logic of the fp16 route (no device work): channel views of a planes tensor (32-aligned, same storage and pitch), and which
+    layers of the full-size STEM model the engine sends to the fp16 kernels: forward / input gradient of the stride-1 unmasked
     convolutions, weight gradient of every stride-1 convolution (the masked context model included), nothing for the stride-2
     and transposed layers."""
     import torch
     from spatiotemporalentropymodel_amd import functional as F
     from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel_Res
-    payload, total = F.Bf16Planes.nbytes(2 * 4 * 4, 160)
+    payload, total = F.F16Planes.nbytes(2 * 4 * 4, 160)
     data = torch.zeros(total, dtype=torch.uint8)
-    p = F.Bf16Planes(data, (2, 160, 4, 4), payload)
+    p = F.F16Planes(data, (2, 160, 4, 4), payload)
     assert p.dense and p.pix_bytes == 5 * 128 and p.q_ptr() == data.data_ptr() + payload
     v = p.channels(32, 128)
     assert v.shape == (2, 96, 4, 4) and v.pix_bytes == p.pix_bytes and v.byte_offset == 128 and not v.dense
@@ -427,8 +427,8 @@ def test_bf16_planes_views_and_engine_routing_table():
         with pytest.raises(ValueError):
             p.channels(*bad)
     eng = SpatioTemporalPriorModel_Res().engine()
-    fwd = {n: l.bx6 for n, l in zip(("HE0", "HE2", "HE4", "HD0", "HD2", "HD4", "TPM0", "TPM2", "TPM4", "CTX", "EPM0", "EPM2", "EPM4"), eng.layers)}
-    wg = {n: l.wg6 for n, l in zip(fwd, eng.layers)}
+    fwd = {n: l.fx3 for n, l in zip(("HE0", "HE2", "HE4", "HD0", "HD2", "HD4", "TPM0", "TPM2", "TPM4", "CTX", "EPM0", "EPM2", "EPM4"), eng.layers)}
+    wg = {n: l.wg3 for n, l in zip(fwd, eng.layers)}
     assert fwd == {"HE0": True, "HE2": False, "HE4": False, "HD0": False, "HD2": False, "HD4": True, "TPM0": True, "TPM2": True, "TPM4": True,
                    "CTX": False, "EPM0": True, "EPM2": True, "EPM4": True}
     assert wg == dict(fwd, CTX=True)
@@ -441,20 +441,20 @@ def test_bf16_planes_views_and_engine_routing_table():
         e = cls(64, cin).engine()
         for group in (e.TPM, e.EPM):
             if group:
-                assert len({l.bx6 for l in group}) == 1, (cls.__name__, cin, [l.bx6 for l in group])
-        if e.EPM[0].bx6:
+                assert len({l.fx3 for l in group}) == 1, (cls.__name__, cin, [l.fx3 for l in group])
+        if e.EPM[0].fx3:
             assert (2 * cin) % 32 == 0                        # the EPM input gradient is read through 32-aligned channel views
         for l in e.layers:
-            assert not l.bx6 or l.bx6_eligible()
+            assert not l.fx3 or l.fx3_eligible()
             # every layer has exactly the packed weights its route needs once allocated (CPU: allocation only)
             l.alloc_packs(torch.device("cpu"))
-            assert (l.wp6_fwd is not None) == l.bx6 and (l.wp_fwd is not None) == (not l.bx6)
+            assert (l.wp6_fwd is not None) == l.fx3 and (l.wp_fwd is not None) == (not l.fx3)
     e24 = SpatioTemporalPriorModel_Res(64, 24).engine()
-    assert not any(l.bx6 for l in e24.TPM + e24.EPM)          # 2 * 24 = 48 channels: not a multiple of 32
+    assert not any(l.fx3 for l in e24.TPM + e24.EPM)          # 2 * 24 = 48 channels: not a multiple of 32
     e48 = SpatioTemporalPriorModel_Res(64, 48).engine()
-    assert all(l.bx6 for l in e48.EPM) and not any(l.bx6 for l in e48.TPM)     # TPM.0 contracts over Cin = 48 channels
+    assert all(l.fx3 for l in e48.EPM) and not any(l.fx3 for l in e48.TPM)     # TPM.0 contracts over Cin = 48 channels
     e64 = SpatioTemporalPriorModel_Res(64, 64).engine()
-    assert all(l.bx6 for l in e64.EPM + e64.TPM)
+    assert all(l.fx3 for l in e64.EPM + e64.TPM)
 
 
 def test_bf16_chain_is_not_selected_when_planes_exceed_a_buffer_view():
@@ -463,21 +463,21 @@ def test_bf16_chain_is_not_selected_when_planes_exceed_a_buffer_view():
     from spatiotemporalentropymodel_amd import layers as L
     from spatiotemporalentropymodel_amd.zoo import models
     conv1 = models["mbt2018"](quality=4).g_a[2]
-    assert L._bf16x6_shape_ok(conv1, (5, 192, 544, 960))
-    assert not L._bf16x6_shape_ok(conv1, (6, 192, 544, 960))
+    assert L._f16x3_shape_ok(conv1, (5, 192, 544, 960))
+    assert not L._f16x3_shape_ok(conv1, (6, 192, 544, 960))
     assert L._planes_fit(5 * 544 * 960, 192) and not L._planes_fit(6 * 544 * 960, 192)
-    assert not L._bf16x6_shape_ok(conv1, (1, 192, 32, 32))          # too few output pixels for the 192-wide kernel
+    assert not L._f16x3_shape_ok(conv1, (1, 192, 32, 32))          # too few output pixels for the 192-wide kernel
 
 
 def test_planes_byte_count_matches_the_library():
-    """Bf16Planes.empty sizes its storage in Python (hot path); the C ABI's stem_bf16x3_planes_bytes is the definition."""
+    """F16Planes.empty sizes its storage in Python (hot path); the C ABI's stem_f16x2_planes_bytes is the definition."""
     from spatiotemporalentropymodel_amd import _lib
     from spatiotemporalentropymodel_amd import functional as F
     lib = _lib.hip()
     for npix, C in ((1, 32), (4096, 192), (65280, 1152), (7, 96), (64, 128), (65, 160), (16 * 128 * 128, 192)):
-        payload, total = F.Bf16Planes.nbytes(npix, C)
-        assert lib.stem_bf16x3_planes_qrec_offset(npix, C) == payload == npix * (C // 32) * 128
-        assert lib.stem_bf16x3_planes_bytes(npix, C) == total
+        payload, total = F.F16Planes.nbytes(npix, C)
+        assert lib.stem_f16x2_planes_qrec_offset(npix, C) == payload == npix * (C // 32) * 128
+        assert lib.stem_f16x2_planes_bytes(npix, C) == total
         # the scale record: 16 header words + one slot per 64-pixel x 128-channel producer tile, 16-byte granules
         assert total - payload >= (16 + -(-npix // 64) * -(-C // 128)) * 4 and (total - payload) % 16 == 0
-    assert lib.stem_bf16x3_planes_bytes(10, 48) == 0
+    assert lib.stem_f16x2_planes_bytes(10, 48) == 0

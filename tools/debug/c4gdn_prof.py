@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""20 launches of g_a.0 + GDN (csrc/c4gdn_bf16x6.hip, planes out) at the bench shape: the target of tools/debug/prof_pmc.sh"""
+"""20 launches of g_a.0 + GDN (csrc/c4gdn_f16x3.hip, planes out) at the bench shape: the target of tools/debug/prof_pmc.sh"""
 import os
 import sys
 
@@ -16,5 +16,5 @@ b, beta = torch.randn(K, device="cuda") * 0.1, torch.rand(K, device="cuda") + 0.
 gamma = torch.rand(K, K, device="cuda") * 0.1 + 0.1 * torch.eye(K, device="cuda")
 ast = F.c4gdn_stream(wp, gamma, K, 5, 5)
 for _ in range(20):
-    y = F.conv2d_c4_gdn_bf16x6(x4, ast, b, beta, K, 5, 5, 2, 2, planes_out=True)
+    y = F.conv2d_c4_gdn_f16x3(x4, ast, b, beta, K, 5, 5, 2, 2, planes_out=True)
 torch.cuda.synchronize()

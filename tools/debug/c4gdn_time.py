@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""g_a.0 + GDN at the bench shape (B=16, 256x256): the bf16 kernel of csrc/c4gdn_bf16x6.hip next to the fp32-MFMA kernel of
-igemm.hip (STEM_C4GDN_BF16X6=0), isolated launches timed with HIP events; max difference of the two results."""
+"""g_a.0 + GDN at the bench shape (B=16, 256x256): the fp16 kernel of csrc/c4gdn_f16x3.hip next to the fp32-MFMA kernel of
+igemm.hip (STEM_C4GDN_F16X3=0), isolated launches timed with HIP events; max difference of the two results."""
 import os
 import sys
 
@@ -22,7 +22,7 @@ ast = F.c4gdn_stream(wp, gamma, K, 5, 5)
 flop = (2 * 192 * 3 * 25 + 2 * 192 * 192) * 128 * 128 * B
 res = {}
 for route in ("1", "0"):
-    os.environ["STEM_C4GDN_BF16X6"] = route
+    os.environ["STEM_C4GDN_F16X3"] = route
     for planes in (True, False):
         fn = (lambda: F.conv2d_fwd_c4_gdn_planes(x4, wp, b, beta, gamma, K, 5, 5, 2, 2, astream=ast)) if planes else \
              (lambda: F.conv2d_fwd_c4_gdn(x4, wp, b, beta, gamma, K, 5, 5, 2, 2, astream=ast))
@@ -38,7 +38,7 @@ for route in ("1", "0"):
             ts.append(e0.elapsed_time(e1))
         ts.sort()
         res[(route, planes)] = y.merge() if planes else y
-        print(f"route {'bf16x6 ' if route == '1' else 'fp32-mfma'} {'planes' if planes else 'fp32  '}: median {ts[5] * 1e3:7.1f} us  min {ts[0] * 1e3:7.1f} us  "
+        print(f"route {'f16x3 ' if route == '1' else 'fp32-mfma'} {'planes' if planes else 'fp32  '}: median {ts[5] * 1e3:7.1f} us  min {ts[0] * 1e3:7.1f} us  "
               f"{flop / ts[5] / 1e9:6.1f} TFLOP/s algorithmic")
 d = (res[("1", True)] - res[("0", True)]).abs().max() / res[("0", True)].abs().max()
-print(f"max |bf16x6 - fp32-mfma| / max = {float(d):.2e}")
+print(f"max |f16x3 - fp32-mfma| / max = {float(d):.2e}")

@@ -7,7 +7,7 @@ python3 bench.py --gpus 2 --steps 2 --warmup 1 > $out/bench_gpus2_one_device.jso
 STEM_DIST_SINGLE=1 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_rccl_world1.json 2> $out/bench_rccl_world1.err
 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_no_group.json 2>/dev/null
 python3 bench.py --config roi --steps 2 --warmup 1 > $out/bench_roi_b16.json 2> $out/bench_roi.err
-STEM_LAYERS_BF16X6=0 python3 bench.py --config roi --steps 2 --warmup 1 > $out/bench_roi_b16_fp32_layers.json 2>/dev/null
+STEM_LAYERS_F16X3=0 python3 bench.py --config roi --steps 2 --warmup 1 > $out/bench_roi_b16_fp32_layers.json 2>/dev/null
 bash tools/debug/prof_bench.sh $tag/bench_trace > /dev/null 2>&1
 bash tools/debug/prof_pmc.sh $tag/pmc_c4gdn tools/debug/c4gdn_prof.py > $out/pmc_c4gdn.log 2>&1
 bash tools/debug/prof_tcc.sh $tag/tcc_c4gdn tools/debug/c4gdn_prof.py > $out/tcc_c4gdn.log 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/f16
-timeout 2800 python3 -m pytest tests -m gpu -q -x --deselect tests/test_hip_dp2.py 2>&1 | grep -v "^E    *+\|tensor(\[" | tail -40 > gpurun_out/f16/pytest.log
-timeout 300 python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300 > gpurun_out/f16/bench.log
-bash tools/debug/prof_bench.sh f16/trace > /dev/null 2>&1
+for t in f16x3_check f16x3_chain wgrad3_check; do echo "=== $t"; timeout 300 python3 tools/debug/$t.py 2>&1 | grep -v "amdgpu.ids\|Consider\|scale =" | tail -14; done > gpurun_out/f16/acc.log 2>&1
+echo "=== gen TPM.2" >> gpurun_out/f16/acc.log; timeout 300 python3 tools/debug/f16x3_gen_check.py TPM.2 2>&1 | tail -12 >> gpurun_out/f16/acc.log
+timeout 600 python3 -m pytest tests/test_hip_dp2.py -m gpu -q -x 2>&1 | tail -3 >> gpurun_out/f16/acc.log

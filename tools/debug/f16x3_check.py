@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dev check of csrc/conv_bf16x6.hip: split/merge exactness, conv(+GDN) against fp64 and against the fp32-MFMA kernel, timing."""
+"""Dev check of csrc/conv_f16x3.hip: split/merge exactness, conv(+GDN) against fp64 and against the fp32-MFMA kernel, timing."""
 import os
 import sys
 import time
@@ -31,10 +31,10 @@ def case(B, H, W, C, K, R, stride, gdn, planes_out):
     b = torch.randn(K, device=dev) * 0.1
     beta = (torch.rand(K, device=dev) + 0.5) if gdn else None
     gamma = (torch.rand(K, K, device=dev) * 0.1 + 0.1 * torch.eye(K, device=dev)) if gdn else None
-    xp = F.Bf16Planes.split(x)
+    xp = F.F16Planes.split(x)
     assert (lambda _p, _y: bool(((_p.merge().double() - _y.double()).abs() <= _y.double().abs() * 2.0 ** -22 + _p.record()[0] * 2.0 ** -25).all()))(xp, F.to_nhwc(x)), "split/merge beyond 2^-22"
-    wp = F.pack_weight_bf16x3(w)
-    out = F.conv2d_bf16x6_fwd(xp, wp, b, K, R, R, stride, R // 2, beta, gamma, planes_out=planes_out)
+    wp = F.pack_weight_f16x2(w)
+    out = F.conv2d_f16x3_fwd(xp, wp, b, K, R, R, stride, R // 2, beta, gamma, planes_out=planes_out)
     y = out.merge() if planes_out else out
     r = ref64(x, w, b, beta, gamma, stride, R // 2)
     wp32 = F.pack_weight(w, F.PACK_CONV_FWD)
@@ -44,7 +44,7 @@ def case(B, H, W, C, K, R, stride, gdn, planes_out):
     scale = float(r.abs().max())
     e6 = float((y.double().cpu() - r).abs().max()) / scale
     e32 = float((y32.double().cpu() - r).abs().max()) / scale
-    print(f"B{B} {H}x{W} C{C}->K{K} k{R} s{stride} gdn={int(gdn)} planes_out={int(planes_out)}: max err / max|ref|  bf16x6 {e6:.2e}   fp32-MFMA {e32:.2e}")
+    print(f"B{B} {H}x{W} C{C}->K{K} k{R} s{stride} gdn={int(gdn)} planes_out={int(planes_out)}: max err / max|ref|  f16x3 {e6:.2e}   fp32-MFMA {e32:.2e}")
     return e6, e32
 
 
@@ -62,15 +62,15 @@ w = torch.randn(K, C, 5, 5, device=dev) / (C * 25) ** 0.5
 b = torch.randn(K, device=dev) * 0.1
 beta = torch.rand(K, device=dev) + 0.5
 gamma = torch.rand(K, K, device=dev) * 0.1
-xp = F.Bf16Planes.split(x)
-wp = F.pack_weight_bf16x3(w)
+xp = F.F16Planes.split(x)
+wp = F.pack_weight_f16x2(w)
 wp32 = F.pack_weight(w, F.PACK_CONV_FWD)
 xn = F.to_nhwc(x)
-for name, fn in (("bf16x6 conv+GDN -> planes", lambda: F.conv2d_bf16x6_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamma, planes_out=True)),
-                 ("bf16x6 conv+GDN -> fp32", lambda: F.conv2d_bf16x6_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamma)),
-                 ("bf16x6 conv only -> fp32", lambda: F.conv2d_bf16x6_fwd(xp, wp, b, K, 5, 5, 2, 2)),
+for name, fn in (("f16x3 conv+GDN -> planes", lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamma, planes_out=True)),
+                 ("f16x3 conv+GDN -> fp32", lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamma)),
+                 ("f16x3 conv only -> fp32", lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2)),
                  ("fp32-MFMA conv+GDN", lambda: F.conv2d_gdn_fwd(xn, wp32, b, beta, gamma, K, 5, 5, 2, 2)),
-                 ("split 16x128x128x192", lambda: F.Bf16Planes.split(x))):
+                 ("split 16x128x128x192", lambda: F.F16Planes.split(x))):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised shapes through the three bf16 kernels against float64 torch references (dev tool): bf16x6_fuzz.py [cases] [seed]"""
+"""Randomised shapes through the three fp16 kernels against float64 torch references (dev tool): f16x3_fuzz.py [cases] [seed]"""
 import os
 import sys
 
@@ -27,30 +27,30 @@ def run(n=40, seed=0, verbose=True):
         x = torch.randn(B, C, H, W, device=dev) * 2; w = torch.randn(K, C, R, R, device=dev) / (C * R * R) ** 0.5; b = torch.randn(K, device=dev) * 0.1
         x64, w64, b64 = x.double().cpu(), w.double().cpu(), b.double().cpu()
         ref = torch.nn.functional.conv2d(x64, w64, b64, stride=st, padding=pad)
-        xp = F.Bf16Planes.split(x)
+        xp = F.F16Planes.split(x)
         errs = {}
         # general kernel, forward (+ leaky ReLU), planes out
-        y, yp = F.conv2d_bf16x6_gen(xp, F.pack_weight_bf16x3_gen(w), b, K, R, R, st, pad, epi=F.GEN_EPI_LRELU, slope=0.01, want_planes=True)
+        y, yp = F.conv2d_f16x3_gen(xp, F.pack_weight_f16x2_gen(w), b, K, R, R, st, pad, epi=F.GEN_EPI_LRELU, slope=0.01, want_planes=True)
         r = torch.nn.functional.leaky_relu(ref, 0.01)
         errs["gen"] = float((y.double().cpu() - r).abs().max() / r.abs().max())
         assert (lambda _p, _y: bool(((_p.merge().double() - _y.double()).abs() <= _y.double().abs() * 2.0 ** -22 + _p.record()[0] * 2.0 ** -25).all()))(yp, y)
         # analysis-transform kernel (K <= 192), with GDN
         if K <= 192:
             beta = torch.rand(K, device=dev) + 0.5; gamma = torch.rand(K, K, device=dev) * 0.1
-            yg = F.conv2d_bf16x6_fwd(xp, F.pack_weight_bf16x3(w), b, K, R, R, st, pad, beta, gamma)
+            yg = F.conv2d_f16x3_fwd(xp, F.pack_weight_f16x2(w), b, K, R, R, st, pad, beta, gamma)
             ped = 2.0 ** -36
             bb = torch.clamp(beta.double().cpu(), min=(1e-6 + ped) ** 0.5) ** 2 - ped; gg = torch.clamp(gamma.double().cpu(), min=2.0 ** -18) ** 2 - ped
             rg = ref / torch.sqrt(torch.nn.functional.conv2d(ref * ref, gg[:, :, None, None], bb))
             errs["g_a"] = float((yg.double().cpu() - rg).abs().max() / rg.abs().max())
         if st == 1:
             dy = torch.randn(B, K, H, W, device=dev); dy64 = dy.double().cpu()
-            dyp = F.Bf16Planes.split(dy)
-            d, _ = F.conv2d_bf16x6_gen(dyp, F.pack_weight_bf16x3_gen(w, flip=True), None, C, R, R, 1, pad, epi=F.GEN_EPI_DACT, slope=0.01, z=F.to_nhwc(x))
+            dyp = F.F16Planes.split(dy)
+            d, _ = F.conv2d_f16x3_gen(dyp, F.pack_weight_f16x2_gen(w, flip=True), None, C, R, R, 1, pad, epi=F.GEN_EPI_DACT, slope=0.01, z=F.to_nhwc(x))
             rd = torch.nn.grad.conv2d_input(x.shape, w64, dy64, padding=pad); rd = torch.where(x64 > 0, rd, rd * 0.01)
             errs["dgrad"] = float((d.double().cpu() - rd).abs().max() / rd.abs().max())
-            splits, elems = F.wgrad_bf16x6_plan(x.shape, K, R, R, pad)
+            splits, elems = F.wgrad_f16x3_plan(x.shape, K, R, R, pad)
             dwp = torch.empty(elems, device=dev); db = torch.zeros(K, device=dev)
-            F.conv2d_wgrad_bf16x6(xp, dyp, K, R, R, pad, dwp, splits, db=db)
+            F.conv2d_wgrad_f16x3(xp, dyp, K, R, R, pad, dwp, splits, db=db)
             dw = dwp.view(splits, R * R, K, C).sum(0).permute(1, 2, 0).reshape(K, C, R, R)
             rw = torch.nn.grad.conv2d_weight(x64, (K, C, R, R), dy64, padding=pad)
             errs["wgrad"] = float((dw.double().cpu() - rw).abs().max() / rw.abs().max())

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dev check of the general bf16x6 kernel on the TPM layer shapes: forward (+ leaky ReLU) and input-gradient (+ DACT) against
+"""Dev check of the general f16x3 kernel on the TPM layer shapes: forward (+ leaky ReLU) and input-gradient (+ DACT) against
 fp64 and against the fp32-MFMA kernels; timing of both."""
 import os
 import sys
@@ -35,18 +35,18 @@ def case(name, B, C, H, W, K, R, timing=True):
     xn = F.to_nhwc(x)
     # forward + leaky ReLU
     ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=pad), SL)
-    xp = F.Bf16Planes.split(x)
-    wp = F.pack_weight_bf16x3_gen(w)
-    y, yp = F.conv2d_bf16x6_gen(xp, wp, b, K, R, R, 1, pad, epi=F.GEN_EPI_LRELU, slope=SL, want_planes=K % 32 == 0)
+    xp = F.F16Planes.split(x)
+    wp = F.pack_weight_f16x2_gen(w)
+    y, yp = F.conv2d_f16x3_gen(xp, wp, b, K, R, R, 1, pad, epi=F.GEN_EPI_LRELU, slope=SL, want_planes=K % 32 == 0)
     wp32 = F.pack_weight(w, F.PACK_CONV_FWD)
     y32 = F.conv2d_fwd(xn, wp32, b, K, R, R, 1, pad, F.ACT_LRELU, slope=SL)
     torch.cuda.synchronize()
     sc = float(ref.abs().max())
     e6, e32 = float((y.double().cpu() - ref).abs().max()) / sc, float((y32.double().cpu() - ref).abs().max()) / sc
     okp = yp is None or (lambda _p, _y: bool(((_p.merge().double() - _y.double()).abs() <= _y.double().abs() * 2.0 ** -22 + _p.record()[0] * 2.0 ** -25).all()))(yp, y)
-    line = f"{name:8s} fwd  err bf16x6 {e6:.2e} fp32 {e32:.2e} planes_ok={okp}"
+    line = f"{name:8s} fwd  err f16x3 {e6:.2e} fp32 {e32:.2e} planes_ok={okp}"
     if timing:
-        t6 = timeit(lambda: F.conv2d_bf16x6_gen(xp, wp, b, K, R, R, 1, pad, epi=F.GEN_EPI_LRELU, slope=SL, want_planes=K % 32 == 0))
+        t6 = timeit(lambda: F.conv2d_f16x3_gen(xp, wp, b, K, R, R, 1, pad, epi=F.GEN_EPI_LRELU, slope=SL, want_planes=K % 32 == 0))
         t32 = timeit(lambda: F.conv2d_fwd(xn, wp32, b, K, R, R, 1, pad, F.ACT_LRELU, slope=SL))
         gf = 2 * B * H * W * K * C * R * R / 1e9
         line += f"   {t6:7.1f} us ({gf / t6 * 1e3:5.1f} TF)  vs fp32 {t32:7.1f} us ({gf / t32 * 1e3:5.1f} TF)"
@@ -55,18 +55,18 @@ def case(name, B, C, H, W, K, R, timing=True):
     dy = torch.randn(B, K, H, W, device=dev)
     dref = torch.nn.grad.conv2d_input(x.shape, w.double().cpu(), dy.double().cpu(), padding=pad)
     dref = torch.where(x.double().cpu() > 0, dref, dref * SL)
-    dyp = F.Bf16Planes.split(dy)
-    wpd = F.pack_weight_bf16x3_gen(w, flip=True)
-    d6, _ = F.conv2d_bf16x6_gen(dyp, wpd, None, C, R, R, 1, pad, epi=F.GEN_EPI_DACT, slope=SL, z=xn)
+    dyp = F.F16Planes.split(dy)
+    wpd = F.pack_weight_f16x2_gen(w, flip=True)
+    d6, _ = F.conv2d_f16x3_gen(dyp, wpd, None, C, R, R, 1, pad, epi=F.GEN_EPI_DACT, slope=SL, z=xn)
     wpd32 = F.pack_weight(w, F.PACK_CONV_DGRAD)
     d32 = F.conv2d_dgrad(F.to_nhwc(dy), wpd32, x.shape, K, R, R, 1, pad, xact=xn)
     torch.cuda.synchronize()
     sc = float(dref.abs().max())
     e6, e32 = float((d6.double().cpu() - dref).abs().max()) / sc, float((d32.double().cpu() - dref).abs().max()) / sc
-    line = f"{name:8s} dgrad err bf16x6 {e6:.2e} fp32 {e32:.2e}"
+    line = f"{name:8s} dgrad err f16x3 {e6:.2e} fp32 {e32:.2e}"
     if timing:
         dyn = F.to_nhwc(dy)
-        t6 = timeit(lambda: F.conv2d_bf16x6_gen(dyp, wpd, None, C, R, R, 1, pad, epi=F.GEN_EPI_DACT, slope=SL, z=xn))
+        t6 = timeit(lambda: F.conv2d_f16x3_gen(dyp, wpd, None, C, R, R, 1, pad, epi=F.GEN_EPI_DACT, slope=SL, z=xn))
         t32 = timeit(lambda: F.conv2d_dgrad(dyn, wpd32, x.shape, K, R, R, 1, pad, xact=xn))
         line += f"   {t6:7.1f} us ({gf / t6 * 1e3:5.1f} TF)  vs fp32 {t32:7.1f} us ({gf / t32 * 1e3:5.1f} TF)"
     print(line)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Profiling driver for csrc/conv_bf16x6.hip at the bench's g_a.2 / g_a.4 sizes: bf16x6_prof.py [variant] [iters] [layer]
+"""Profiling driver for csrc/conv_f16x3.hip at the bench's g_a.2 / g_a.4 sizes: f16x3_prof.py [variant] [iters] [layer]
 variant: planes | fp32 | conv | split | ref (fp32-MFMA kernel); layer: 2 (128^2 -> 64^2) or 4 (64^2 -> 32^2)."""
 import os
 import sys
@@ -21,15 +21,15 @@ w = torch.randn(K, C, 5, 5, device=dev) / (C * 25) ** 0.5
 b = torch.randn(K, device=dev) * 0.1
 beta = torch.rand(K, device=dev) + 0.5
 gamma = torch.rand(K, K, device=dev) * 0.1
-xp = F.Bf16Planes.split(x)
-wp = F.pack_weight_bf16x3(w)
+xp = F.F16Planes.split(x)
+wp = F.pack_weight_f16x2(w)
 wp32 = F.pack_weight(w, F.PACK_CONV_FWD)
 xn = F.to_nhwc(x)
-fn = {"planes": lambda: F.conv2d_bf16x6_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamma, planes_out=True),
-      "fp32": lambda: F.conv2d_bf16x6_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamma),
-      "conv": lambda: F.conv2d_bf16x6_fwd(xp, wp, b, K, 5, 5, 2, 2),
-      "convplanes": lambda: F.conv2d_bf16x6_fwd(xp, wp, b, K, 5, 5, 2, 2, planes_out=True),
-      "split": lambda: F.Bf16Planes.split(x),
+fn = {"planes": lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamma, planes_out=True),
+      "fp32": lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamma),
+      "conv": lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2),
+      "convplanes": lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, planes_out=True),
+      "split": lambda: F.F16Planes.split(x),
       "c4planes": None, "c4fp32": None,
       "ref": lambda: F.conv2d_gdn_fwd(xn, wp32, b, beta, gamma, K, 5, 5, 2, 2)}[variant]
 if variant in ("c4planes", "c4fp32"):      # g_a.0 + GDN: 3 -> 192 channels, 256^2 -> 128^2

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dev check of csrc/wgrad_bf16x6.hip: weight gradients of the stride-1 STEM layers against fp64 and the fp32-MFMA kernel, timing."""
+"""Dev check of csrc/wgrad_f16x3.hip: weight gradients of the stride-1 STEM layers against fp64 and the fp32-MFMA kernel, timing."""
 import os
 import sys
 
@@ -30,19 +30,19 @@ def case(name, B, C, H, W, K, R, timing=True):
     x = torch.randn(B, C, H, W, device=dev)
     dy = torch.randn(B, K, H, W, device=dev)
     ref = torch.nn.grad.conv2d_weight(x.double().cpu(), (K, C, R, R), dy.double().cpu(), padding=pad)
-    xp, dyp = F.Bf16Planes.split(x), F.Bf16Planes.split(dy)
-    splits, elems = F.wgrad_bf16x6_plan(x.shape, K, R, R, pad)
+    xp, dyp = F.F16Planes.split(x), F.F16Planes.split(dy)
+    splits, elems = F.wgrad_f16x3_plan(x.shape, K, R, R, pad)
     dwp = torch.empty(elems, device=dev)
-    F.conv2d_wgrad_bf16x6(xp, dyp, K, R, R, pad, dwp, splits)
+    F.conv2d_wgrad_f16x3(xp, dyp, K, R, R, pad, dwp, splits)
     dw6 = dwp.view(splits, R * R, K, C).sum(0).permute(1, 2, 0).reshape(K, C, R, R)
     xn, dyn = F.to_nhwc(x), F.to_nhwc(dy)
     dw32, _ = F.conv2d_wgrad(xn, dyn, K, R, R, 1, pad)
     torch.cuda.synchronize()
     sc = float(ref.abs().max())
     e6, e32 = float((dw6.double().cpu() - ref).abs().max()) / sc, float((dw32.double().cpu() - ref).abs().max()) / sc
-    line = f"{name:8s} splits {splits:2d}  err bf16x6 {e6:.2e}  fp32 {e32:.2e}"
+    line = f"{name:8s} splits {splits:2d}  err f16x3 {e6:.2e}  fp32 {e32:.2e}"
     if timing:
-        t6 = timeit(lambda: F.conv2d_wgrad_bf16x6(xp, dyp, K, R, R, pad, dwp, splits))
+        t6 = timeit(lambda: F.conv2d_wgrad_f16x3(xp, dyp, K, R, R, pad, dwp, splits))
         t32 = timeit(lambda: F.conv2d_wgrad(xn, dyn, K, R, R, 1, pad, unpack=False, need_db=False))
         gf = 2 * B * H * W * K * C * R * R / 1e9
         line += f"   {t6:7.1f} us ({gf / t6 * 1e3:5.1f} TF)  vs fp32 {t32:7.1f} us ({gf / t32 * 1e3:5.1f} TF)"
