@@ -1175,6 +1175,9 @@ int gen_split(int tiles, int nchunks)
 {
     const int forced = stem_tuning(STEM_TUNE_FX3_SPLIT);      // stem_tuning_set("fx3_split", n): tests / sweeps
     if (forced > 0) return forced < nchunks ? forced : nchunks;
+    // 1x1 layers (EPM: 18-36 chunks): a split costs its slab round trip and a second epilogue pass, more than the shorter loop
+    // returns (tools/debug/f16x3_split_sweep.py, round 3: unsplit 39 / 29 / 20 us against 43 / 33 / 26 us)
+    if (nchunks <= 40 && tiles >= 128) return 1;
     int best = 1;
     double best_cost = 1e30;
     for (int s = 1; s <= 16 && s * 8 <= nchunks; ++s) {

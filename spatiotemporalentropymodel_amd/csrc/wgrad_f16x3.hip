@@ -244,6 +244,9 @@ int plan_splits(int B, int OH, int OW, int C, int K, int T)
     int s = forced > 0 ? forced : (512 + tiles / 2) / tiles;       // two workgroups per CU: aim at ~512 workgroups
     if (s < 1) s = 1;
     if (s > nchunks / 16) s = nchunks / 16 > 0 ? nchunks / 16 : 1;
+    // one-tap layers have few output tiles: past 32 pixel chunks per workgroup the slabs' write + unpack traffic costs more
+    // than the extra workgroups return (sweep: EPM.0 / EPM.2 63 / 42 us at 4-8 splits against 69 / 49 us at 9 / 16)
+    if (forced <= 0 && T == 1 && s > nchunks / 32 && nchunks >= 64) s = nchunks / 32;
     const int cps = cdiv(nchunks, s);
     return cdiv(nchunks, cps);
 }
