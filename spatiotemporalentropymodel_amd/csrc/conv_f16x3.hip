@@ -72,9 +72,11 @@ __device__ inline int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
 
 // BM = pixels per workgroup: 128 (8 wavefronts) or 64 (4 wavefronts, for layers with too few 128-pixel tiles to fill the chip).
-template <int BM>
+// DEPTH = chunks in flight in registers: 2 (default) or 4 (sweep aid, tools/debug/f16x3_depth_sweep.py: no gain).
+template <int BM, int DEPTH>
 __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
 {
+    static_assert(DEPTH == 2 || DEPTH == 4, "register sets rotate with the LDS double buffer: an even depth");
     constexpr int NT = BM * 4;
     constexpr int A_PLANE = BM * 64, A_BUF = NPL * A_PLANE;
     constexpr int LDS_TAPS = lds_taps(BM);
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.xp), 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wp), 0, a.wbytes, 0x00020000);
 
-    f32x4 raA[PL], rbA[BP], raB[PL], rbB[BP];
+    f32x4 rsa[DEPTH][PL], rsb[DEPTH][BP];       // register set s holds a chunk on its way to LDS
     auto gload = [&](int t, int kc, int q, f32x4 (&ra)[PL], f32x4 (&rb)[BP]) {
         const int tA = __builtin_amdgcn_readfirstlane(tapi[t]), sA = kc * SLAB, sB = q * B_BUF;
         const int mk = __builtin_amdgcn_sbfe((int)pmask, (unsigned)t, 1u);                 // 0 / -1: tap t inside the image
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
             if (ks == 0)
                 sstore(cur ^ 1, ra, rb);           // the register set holds the next chunk
             else
-                gload(t, kc, q, ra, rb);           // refill it two chunks ahead
+                gload(t, kc, q, ra, rb);           // refill it DEPTH chunks ahead
         }
         if (pf_q < q_last) {
             ++pf_q;
@@ -200,27 +202,31 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
     {
         int t, kc, q;
         q = chunk_of(0, t, kc);
-        gload(t, kc, q, raA, rbA);
-        sstore(0, raA, rbA);
-        q = chunk_of(1, t, kc);
-        gload(t, kc, q, raA, rbA);
-        q = chunk_of(2, t, kc);
-        gload(t, kc, q, raB, rbB);
-        pf_q = chunk_of(3, pf_t, pf_kc);
+        gload(t, kc, q, rsa[0], rsb[0]);
+        sstore(0, rsa[0], rsb[0]);
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {          // set s <- chunk 1 + s
+            q = chunk_of(1 + s, t, kc);
+            gload(t, kc, q, rsa[s], rsb[s]);
+        }
+        pf_q = chunk_of(1 + DEPTH, pf_t, pf_kc);
     }
     __syncthreads();
     {
         int q = 0;
-        for (; q + 1 < nchunks; q += 2) {
-            step(0, raA, rbA);
-            __syncthreads();
-            step(1, raB, rbB);
-            __syncthreads();
+        for (; q + DEPTH - 1 < nchunks; q += DEPTH) {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) {
+                step(s & 1, rsa[s], rsb[s]);
+                __syncthreads();
+            }
         }
-        if (q < nchunks) {
-            step(0, raA, rbA);
-            __syncthreads();
-        }
+#pragma unroll
+        for (int s = 0; s < DEPTH - 1; ++s)
+            if (q + s < nchunks) {
+                step(s & 1, rsa[s], rsb[s]);
+                __syncthreads();
+            }
     }
 
     // ---- epilogue: lane holds column n = wn0 + 32 j + lr, rows (r & 3) + 8 (r >> 2) + 4 lh of each 32x32 tile ---------------
@@ -857,7 +863,17 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const AmaxTable tab)
     const float *w = tab.w[blockIdx.y];
     const long n = tab.n[blockIdx.y];
     float m = 0.f;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) m = fmaxf(m, fabsf(w[e]));
+    // eight independent loads in flight per thread (a flat parameter buffer guarantees 4-byte alignment only: scalar loads)
+    const long stride = (long)gridDim.x * 256;
+    long e = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; e + 7 * stride < n; e += 8 * stride) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = w[e + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m = fmaxf(m, fabsf(v[u]));
+    }
+    for (; e < n; e += stride) m = fmaxf(m, fabsf(w[e]));
     m = block_max(m, qred);
     if (threadIdx.x == 0) {
         float *q = tab.q[blockIdx.y];
@@ -1098,8 +1114,10 @@ static int conv2d_f16x3_launch(const void *xp, const float *xq, const void *wp, 
         }
     static bool attr_done = false;      // > 64 KiB of dynamic LDS needs an explicit opt-in
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
-        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
         attr_done = true;
     }
     const int M = B * OH * OW;
@@ -1107,10 +1125,18 @@ static int conv2d_f16x3_launch(const void *xp, const float *xq, const void *wp, 
     // 128-pixel tiles (8 wavefronts) when they fill the 256 CUs at least once, 64-pixel tiles (4 wavefronts) below that
     const int tile = stem_tuning(STEM_TUNE_FX3_TILE);
     const bool small = tile ? tile == 64 : cdiv(M, 128) < 256;
-    if (small)
-        hipLaunchKernelGGL((conv_f16x3_kernel<64>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
+    // chunks in flight: 2.  Four (stem_tuning_set("fx3_depth", 4)) measured 129 vs 131 us on g_a.4 and 380 vs 380 us on g_a.2:
+    // with three products the kernel is bound by L2 -> LDS operand traffic (40 KB per chunk and workgroup), not by load latency
+    const int dsel = stem_tuning(STEM_TUNE_FX3_DEPTH);
+    const int depth = dsel ? dsel : 2;
+    if (small && depth == 4)
+        hipLaunchKernelGGL((conv_f16x3_kernel<64, 4>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
+    else if (small)
+        hipLaunchKernelGGL((conv_f16x3_kernel<64, 2>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
+    else if (depth == 4)
+        hipLaunchKernelGGL((conv_f16x3_kernel<128, 4>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
     else
-        hipLaunchKernelGGL((conv_f16x3_kernel<128>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
+        hipLaunchKernelGGL((conv_f16x3_kernel<128, 2>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
     STEM_LAUNCH_CHECK("stem_conv2d_f16x3_fwd");
     return 0;
 }
