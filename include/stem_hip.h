@@ -35,7 +35,7 @@ int stem_abi_version(void);
 /* Plan selectors for tests and sweep tools: force a tile shape / split factor that the library would otherwise choose
  * ("fx3_tile": 0 automatic | 64 | 128 pixel workgroups of stem_conv2d_f16x3_fwd; "fx3_split" / "wg3_split": split factor
  * of stem_conv2d_f16x3_gen_fwd / stem_conv2d_wgrad_f16x3, 0 = the planner's; "fx3_depth": 0 automatic | 2 | 4 chunks in
- * flight in stem_conv2d_f16x3_fwd; "arp_workers": workgroups of the persistent decoder).  Every setting computes the same
+ * flight in stem_conv2d_f16x3_fwd; "fx3_gen_tile": 0 automatic | 64 | 128 pixel workgroups of stem_conv2d_f16x3_gen_fwd; "arp_workers": workgroups of the persistent decoder).  Every setting computes the same
  * contraction (summation order aside); process-wide; not for concurrent use with launches.  There is no reference
  * counterpart (torch picks its kernels internally).  Nothing in the library reads the environment to change results:
  * ablated / instrumented variants exist only in builds with -DSTEM_EXPERIMENTS, which

@@ -408,19 +408,25 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
 // (dgrad of a conv whose input was activated), fp32 rows with a pitch (the result may be a channel slice of a wider buffer)
 // and / or planes for the next layer.  Weight image per (N tile, chunk): [3][128][64 B], swizzled like the 192-row one.
 enum { GEN_EPI_BIAS = 0, GEN_EPI_LRELU = 1, GEN_EPI_DACT = 2 };
-constexpr int GBM = 64, GBN = 128, GNT = 256;
-constexpr int GA_PLANE = GBM * 64, GA_BUF = NPL * GA_PLANE;          // 8192
+constexpr int GBN = 128;
 constexpr int GB_PLANE = GBN * 64, GB_BUF = NPL * GB_PLANE;          // 16384
 constexpr int GTP = GBN + 4;                                         // fp32 pitch of the epilogue tile
-constexpr int GLDS = 2 * (GA_BUF + GB_BUF) + 32 * 4;                 // 49280 (the 64 x 132 float epilogue tile reuses the front)
+// LDS of a GBM-pixel tile: main loop 2 x (GBM + 128) rows x 64 B x NPL planes, reused by the GBM x 132 float epilogue tile; + tap table
+constexpr int glds_main(int gbm) { return 2 * NPL * (gbm + GBN) * 64 > gbm * GTP * 4 ? 2 * NPL * (gbm + GBN) * 64 : gbm * GTP * 4; }
+constexpr int glds(int gbm) { return glds_main(gbm) + 32 * 4; }          // 49280 (64 pixels: three workgroups per CU) / 67712 (128: two)
 
-__global__ __launch_bounds__(GNT, 2) void conv_f16x3_gen_kernel(const Fx3Args a)
+// GBM = pixels per workgroup: 64 (4 wavefronts as 2 x 2) or 128 (8 wavefronts as 4 x 2).  The weight tile of a chunk (16 KB) is
+// fetched once per workgroup: with three products per fp32 product the 64-pixel form is bound by that L2 -> LDS traffic
+// (24 KB per chunk for 1.6 MF), the 128-pixel form moves 32 KB for twice the work.
+template <int GBM>
+__global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Args a)
 {
-    constexpr int PL = NPL, BPC = PL * 2;                      // planes; 16-byte weight pieces per thread and chunk
+    constexpr int GNT = GBM * 4, GA_PLANE = GBM * 64, GA_BUF = NPL * GA_PLANE;
+    constexpr int PL = NPL, BPC = NPL * GBN * 4 / GNT;         // planes; 16-byte weight pieces per thread and chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *As = smem;                        // [2][NPL][64][64 B]
+    unsigned char *As = smem;                        // [2][NPL][GBM][64 B]
     unsigned char *Bs = smem + 2 * GA_BUF;           // [2][NPL][128][64 B]
-    int *tapi = reinterpret_cast<int *>(smem + 2 * (GA_BUF + GB_BUF));
+    int *tapi = reinterpret_cast<int *>(smem + glds_main(GBM));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Mtot = a.B * a.OH * a.OW;
@@ -462,13 +468,13 @@ __global__ __launch_bounds__(GNT, 2) void conv_f16x3_gen_kernel(const Fx3Args a)
 #pragma unroll
         for (int pl = 0; pl < PL; ++pl) ra[pl] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off + pl * 64, sA, 0));
 #pragma unroll
-        for (int j = 0; j < BPC; ++j) rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, tid * 16 + j * 4096, sB, 0));
+        for (int j = 0; j < BPC; ++j) rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, tid * 16 + j * (GNT * 16), sB, 0));
     };
     auto sstore = [&](int buf, f32x4 (&ra)[PL], f32x4 (&rb)[BPC]) {
 #pragma unroll
         for (int pl = 0; pl < PL; ++pl) *reinterpret_cast<f32x4 *>(As + buf * GA_BUF + pl * GA_PLANE + a_st) = ra[pl];
 #pragma unroll
-        for (int j = 0; j < BPC; ++j) *reinterpret_cast<f32x4 *>(Bs + buf * GB_BUF + j * 4096 + tid * 16) = rb[j];
+        for (int j = 0; j < BPC; ++j) *reinterpret_cast<f32x4 *>(Bs + buf * GB_BUF + j * (GNT * 16) + tid * 16) = rb[j];
     };
 
     const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
@@ -1216,13 +1222,23 @@ int gen_split(int tiles, int nchunks)
     }
     return best;
 }
+
+// Pixel tile: 128 when that still leaves enough tiles to spread over the chip with a moderate split and the loop is long enough
+// to pay for the larger epilogue, else 64 (tools/debug/f16x3_split_sweep.py: TPM.0 / .2 / .4 52 / 78 / 100 -> 49 / 73 / 90 us,
+// EPM.0 / .2 41 / 31 -> 38 / 28 us, EPM.4 with its 18 chunks 20 -> 23 us)
+int gen_bm(int M, int ntn, int nchunks)
+{
+    const int forced = stem_tuning(STEM_TUNE_FX3_GEN_TILE);   // stem_tuning_set("fx3_gen_tile", 64 | 128): tests / sweeps
+    if (forced) return forced;
+    return cdiv(M, 128) * ntn >= 64 && nchunks > 20 ? 128 : 64;
+}
 }   // namespace
 
 STEM_EXPORT size_t stem_conv2d_f16x3_gen_workspace_bytes(int B, int H, int W, int C, int N, int R, int S, int stride, int pad)
 {
     const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
     if (OH < 1 || OW < 1 || C % 32) return 0;
-    const int M = B * OH * OW, tiles = cdiv(M, GBM) * cdiv(N, GBN), nchunks = (C / 32) * R * S;
+    const int M = B * OH * OW, nchunks = (C / 32) * R * S, tiles = cdiv(M, gen_bm(M, cdiv(N, GBN), nchunks)) * cdiv(N, GBN);
     int s = gen_split(tiles, nchunks);
     while (s > 1 && (size_t)s * M * cdiv(N, GBN) * GBN * sizeof(float) >= 0x7FFFFF00ull) --s;
     return s > 1 ? kGenCntBytes + (size_t)s * M * cdiv(N, GBN) * GBN * sizeof(float) : 0;
@@ -1245,7 +1261,7 @@ STEM_EXPORT int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int x
     if (xpix == 0) xpix = (C / 32) * SLAB;
     STEM_CHECK_ARG(xpix >= (C / 32) * SLAB && xpix % SLAB == 0, "stem_conv2d_f16x3_gen_fwd: xpix must be a multiple of %d bytes covering C channels", SLAB);
     const size_t xb = (size_t)B * H * W * xpix, wb = gen_image_bytes(N, C, R, S);
-    const int M = B * OH * OW, ntn = cdiv(N, GBN), tiles = cdiv(M, GBM) * ntn, nchunks = (C / 32) * R * S;
+    const int M = B * OH * OW, ntn = cdiv(N, GBN), nchunks = (C / 32) * R * S, bm = gen_bm(M, ntn, nchunks), tiles = cdiv(M, bm) * ntn;
     STEM_CHECK_ARG(xb < 0x7FFFFF00ull && wb < 0x7FFFFF00ull && (size_t)M * ntn * GBN * 4 < 0x7FFFFF00ull,
                    "stem_conv2d_f16x3_gen_fwd: operand views must stay below 2 GiB (split the batch)");
     Fx3Args a;
@@ -1272,11 +1288,15 @@ STEM_EXPORT int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int x
     }
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)conv_f16x3_gen_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GLDS);
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_gen_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, glds(64));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_gen_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, glds(128));
         attr_done = true;
     }
-    const dim3 grid(cdiv(M, GBM), ntn, a.nsplit);
-        hipLaunchKernelGGL(conv_f16x3_gen_kernel, grid, dim3(GNT), GLDS, (hipStream_t)stream, a);
+    const dim3 grid(cdiv(M, bm), ntn, a.nsplit);
+    if (bm == 128)
+        hipLaunchKernelGGL(conv_f16x3_gen_kernel<128>, grid, dim3(512), glds(128), (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(conv_f16x3_gen_kernel<64>, grid, dim3(256), glds(64), (hipStream_t)stream, a);
     STEM_LAUNCH_CHECK("stem_conv2d_f16x3_gen_fwd");
     return 0;
 }

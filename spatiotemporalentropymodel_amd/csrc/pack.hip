@@ -25,7 +25,7 @@ STEM_EXPORT int stem_built_with_experiments(void)
 }
 
 static int g_tuning[STEM_TUNE_COUNT] = {0};
-static const char *const kTuningNames[STEM_TUNE_COUNT] = {"fx3_tile", "fx3_split", "wg3_split", "arp_workers", "fx3_depth"};
+static const char *const kTuningNames[STEM_TUNE_COUNT] = {"fx3_tile", "fx3_split", "wg3_split", "arp_workers", "fx3_depth", "fx3_gen_tile"};
 int stem_tuning(int id) { return g_tuning[id]; }
 STEM_EXPORT int stem_tuning_set(const char *name, int value)
 {
@@ -33,11 +33,12 @@ STEM_EXPORT int stem_tuning_set(const char *name, int value)
     for (int i = 0; i < STEM_TUNE_COUNT; ++i)
         if (!strcmp(name, kTuningNames[i])) {
             STEM_CHECK_ARG(i != STEM_TUNE_FX3_TILE || value == 0 || value == 64 || value == 128, "stem_tuning_set: fx3_tile is 0 (automatic), 64 or 128");
+            STEM_CHECK_ARG(i != STEM_TUNE_FX3_GEN_TILE || value == 0 || value == 64 || value == 128, "stem_tuning_set: fx3_gen_tile is 0 (automatic), 64 or 128");
             STEM_CHECK_ARG(i != STEM_TUNE_FX3_DEPTH || value == 0 || value == 2 || value == 4, "stem_tuning_set: fx3_depth is 0 (automatic), 2 or 4");
             g_tuning[i] = value;
             return 0;
         }
-    stem_set_error("stem_tuning_set: unknown selector '%s' (fx3_tile, fx3_split, wg3_split, arp_workers, fx3_depth)", name);
+    stem_set_error("stem_tuning_set: unknown selector '%s' (fx3_tile, fx3_split, wg3_split, arp_workers, fx3_depth, fx3_gen_tile)", name);
     return -1;
 }
 STEM_EXPORT int stem_tuning_get(const char *name)

@@ -227,10 +227,12 @@ GEN_CASES = [  # B, C, H, W, K, R
 
 @pytest.mark.parametrize("case", GEN_CASES)
 @pytest.mark.parametrize("split", [0, 1, 3])
-def test_gen_forward_and_input_gradient_vs_oracle(F, case, split):
+@pytest.mark.parametrize("tile", [0, 64, 128])
+def test_gen_forward_and_input_gradient_vs_oracle(F, case, split, tile):
     """forward + leaky ReLU and input-gradient x leaky-ReLU derivative (what autograd derives for conv(lrelu(u))) against the
-    oracle, with the planner's split-K factor (0), unsplit (1) and a forced 3-way split; planes output = fp32 output."""
-    with F.tuning(fx3_split=split):
+    oracle, with the planner's split-K factor (0), unsplit (1) and a forced 3-way split, and with the library's pixel tile (0),
+    64-pixel (4 wavefronts) and 128-pixel (8 wavefronts) workgroups; planes output = fp32 output."""
+    with F.tuning(fx3_split=split, fx3_gen_tile=tile):
         _gen_forward_and_input_gradient(F, case, split)
 
 

@@ -43,9 +43,17 @@ for name, C, K, R in LAYERS:
     res = {}
     if which == "gen":
         wp = F.pack_weight_f16x2_gen(w)
-        for s in [0] + list(range(1, 17)):
-            with F.tuning(fx3_split=s):
-                res[s] = timeit(lambda: F.conv2d_f16x3_gen(xp, wp, b, K, R, R, stride, pad, epi=F.GEN_EPI_LRELU, slope=0.01, want_planes=K % 32 == 0))
+        for tile in (64, 128):
+            res = {}
+            for s in [0] + list(range(1, 17)):
+                with F.tuning(fx3_split=s, fx3_gen_tile=tile):
+                    res[s] = timeit(lambda: F.conv2d_f16x3_gen(xp, wp, b, K, R, R, stride, pad, epi=F.GEN_EPI_LRELU, slope=0.01, want_planes=K % 32 == 0))
+            best = min((v, k) for k, v in res.items() if k)
+            print(f"{name:7s} tile {tile:3d} planner {res[0]:6.1f} us   best split {best[1]:2d}: {best[0]:6.1f} us   " + " ".join(f"{k}:{v:.0f}" for k, v in res.items() if k))
+        with F.tuning():
+            t0 = timeit(lambda: F.conv2d_f16x3_gen(xp, wp, b, K, R, R, stride, pad, epi=F.GEN_EPI_LRELU, slope=0.01, want_planes=K % 32 == 0))
+        print(f"{name:7s} library's own plan: {t0:6.1f} us")
+        continue
     else:
         if stride != 1:
             continue
