@@ -430,21 +430,24 @@ int stem_conv2d_c4_gdn_f16x3(const float *x4, const float *xq, const void *astre
  * dy with K channels).  ws: stem_conv2d_f16x3_gen_workspace_bytes bytes whose first 64 KiB are zero before the first use
  * (the kernel leaves them zero -- the same contract as stem_conv_workspace_bytes, the buffer may be shared); null = unsplit.  Results do not depend on which workgroup arrives last. */
 size_t stem_f16x2_conv_weight_gen_bytes(int N, int C, int R, int S);
-int stem_f16x2_pack_conv_weight_gen(const float *w, void *wp, int N, int C, int R, int S, int flip, void *stream);
+/* taps: 0 = all R*S taps; 0 < taps < R*S = a MASKED convolution (layers.py:21-47: mask type A keeps the first (R/2)*S + S/2 taps in
+ * row-major order, type B one more): only those are packed, and the others are ZEROED IN PLACE in w, as the reference does at
+ * every forward (`self.weight.data *= self.mask`); forward role only.  The same value goes to stem_conv2d_f16x3_gen_fwd. */
+int stem_f16x2_pack_conv_weight_gen(const float *w, void *wp, int N, int C, int R, int S, int flip, int taps, void *stream);
 /* all layers of a training model with two launches (maxima, images: their weights change every optimiser step); N, C as in
  * the single call, i.e. already swapped for flip = 1 */
 typedef struct {
     const void *w;
     void *wp;
-    int N, C, R, S, flip, reserved;
+    int N, C, R, S, flip, taps;
 } stem_f16x2_pack_desc;
 int stem_f16x2_pack_conv_weights_multi(const stem_f16x2_pack_desc *descs, int n, void *stream);
-size_t stem_conv2d_f16x3_gen_workspace_bytes(int B, int H, int W, int C, int N, int R, int S, int stride, int pad);
+size_t stem_conv2d_f16x3_gen_workspace_bytes(int B, int H, int W, int C, int N, int R, int S, int stride, int pad, int taps);
 /* xpix: bytes per pixel of the planes buffer xp points into (0 = dense, (C/32) * 128); xp may point at a 32-channel-aligned
  * slab of a wider planes tensor (xq: the record of that whole tensor) */
 int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int xpix, const void *wp, const float *bias, int epi, float slope,
                                const float *z, int ldz, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R,
-                               int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream);
+                               int S, int stride, int pad, int taps, void *ws, size_t ws_bytes, void *stream);
 
 /* Weight gradient of a stride-1 nn.Conv2d on the 16-bit matrix cores (csrc/wgrad_f16x3.hip): x and dy as planes with their
  * records (pitches in bytes per pixel, 0 = dense; 32-aligned channel views allowed), result as `splits` slabs [R*S][K][C] like

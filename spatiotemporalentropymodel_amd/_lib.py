@@ -97,15 +97,15 @@ _HIP_SIG = {
     "stem_f16x2_split_dact_nhwc": [vp, ci, vp, ci, cf, vp, vp, vp, C.c_long, ci, vp],
     "stem_f16x2_pack_conv_weight": [vp, vp, ci, ci, ci, ci, vp],
     "stem_f16x2_conv_weight_gen_bytes": [ci, ci, ci, ci],
-    "stem_f16x2_pack_conv_weight_gen": [vp, vp, ci, ci, ci, ci, ci, vp],
-    "stem_conv2d_f16x3_gen_workspace_bytes": [ci, ci, ci, ci, ci, ci, ci, ci, ci],
+    "stem_f16x2_pack_conv_weight_gen": [vp, vp, ci, ci, ci, ci, ci, ci, vp],
+    "stem_conv2d_f16x3_gen_workspace_bytes": [ci, ci, ci, ci, ci, ci, ci, ci, ci, ci],
     "stem_f16x2_pack_conv_weights_multi": [vp, ci, vp],
     "stem_wgrad_f16x3_splits": [ci, ci, ci, ci, ci, ci, ci, ci],
     "stem_conv2d_wgrad_f16x3": [vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_bias_grad_final": [vp, ci, ci, vp, ci, vp],
     "stem_bias_grad_scratch_elems": [C.c_long, ci],
     "stem_bias_grad": [vp, ci, C.c_long, ci, vp, vp, ci, vp],
-    "stem_conv2d_f16x3_gen_fwd": [vp, vp, ci, vp, vp, ci, cf, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],
+    "stem_conv2d_f16x3_gen_fwd": [vp, vp, ci, vp, vp, ci, cf, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],
     "stem_c4gdn_supported": [ci, ci, ci],
     "stem_c4gdn_stream_bytes": [ci, ci, ci],
     "stem_c4gdn_pack": [vp, vp, vp, ci, ci, ci, vp],
@@ -162,7 +162,7 @@ class PackDesc(C.Structure):
 
 
 class F16PackDesc(C.Structure):
-    _fields_ = [("w", vp), ("wp", vp), ("N", ci), ("C", ci), ("R", ci), ("S", ci), ("flip", ci), ("reserved", ci)]
+    _fields_ = [("w", vp), ("wp", vp), ("N", ci), ("C", ci), ("R", ci), ("S", ci), ("flip", ci), ("taps", ci)]
 
 
 class UnpackDesc(C.Structure):

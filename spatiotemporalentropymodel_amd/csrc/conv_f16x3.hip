@@ -711,7 +711,8 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
 // weights for conv_f16x3_gen_kernel: [N tile][chunk q = slab * R*S + tap][plane][128 rows][64 B].  flip: the input-gradient of
 // a stride-1 convolution is a convolution of dy with w'[c][k][r][s] = w[k][c][R-1-r][S-1-s]: `w` is still the torch weight
 // [K][C][R][S], the packed rows are its input channels c (N = C outputs) and the packed channels its output channels k.
-__global__ __launch_bounds__(256) void pack_weight_gen_kernel(const float *w, unsigned char *wp, int N, int C, int RS, int flip, long npieces,
+// T <= RS: only the first T taps (row-major) are packed -- the live taps of a type-A / type-B masked convolution (layers.py:21-47)
+__global__ __launch_bounds__(256) void pack_weight_gen_kernel(const float *w, unsigned char *wp, int N, int C, int RS, int T, int flip, long npieces,
                                                               float *wq)
 {
     __shared__ float qred[16];
@@ -720,11 +721,11 @@ __global__ __launch_bounds__(256) void pack_weight_gen_kernel(const float *w, un
     if (blockIdx.x == 0 && threadIdx.x == 0) wq[1] = q_pow2(-we);
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= npieces) return;
-    const int nchunks = (C / 32) * RS;
+    const int nchunks = (C / 32) * T;
     const int p = (int)(e & 3), nl = (int)((e >> 2) % GBN);
     const long qq = e / (4 * GBN);                       // ntile * nchunks + q
     const int ntile = (int)(qq / nchunks), q = (int)(qq - (long)ntile * nchunks);
-    const int slab = q / RS, tap = q - slab * RS, n = ntile * GBN + nl;
+    const int slab = q / T, tap = q - slab * T, n = ntile * GBN + nl;
     h16x8 h[NPL];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -756,10 +757,10 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
     // version handled one row per unit: 100-byte runs in flip mode and two barriers per 800 values.)
     __shared__ float tile[PKR * 32 * MAXTAP];         // [row][channel in slab][tap]
     const stem_f16x2_pack_desc &d = tab.d[blockIdx.y];
-    const int RS = d.R * d.S, nslab = d.C / 32, nchunks = nslab * RS, ntile = cdiv_dev(d.N, GBN);
+    const int RS = d.R * d.S, T = d.taps > 0 ? d.taps : RS, nslab = d.C / 32, nchunks = nslab * T, ntile = cdiv_dev(d.N, GBN);
     const float *w = static_cast<const float *>(d.w);
     unsigned char *wp = static_cast<unsigned char *>(d.wp);
-    float *wq = reinterpret_cast<float *>(wp + (size_t)ntile * nchunks * GB_BUF);       // the image's scale record (amax_multi_kernel ran)
+    float *wq = reinterpret_cast<float *>(wp + (size_t)ntile * nslab * RS * GB_BUF);    // the scale record sits behind the FULL image's size (amax_multi_kernel ran)
     __shared__ float qred[16];
     const int we = q_exp(q_amax(wq, qred));
     const float wscale = q_pow2(we);
@@ -784,7 +785,7 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
             }
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < PKR * RS * 4; e += 256) {
+        for (int e = threadIdx.x; e < PKR * T * 4; e += 256) {
             const int p = e & 3, r = (e >> 2) % PKR, tap = (e >> 2) / PKR;
             const int n = n0 + r, nt = n / GBN, nl = n - nt * GBN;
             h16x8 h[NPL];
@@ -794,7 +795,7 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
                 q_split(tile[(r * 32 + p * 8 + c) * MAXTAP + tap], wscale, x0, x1);
                 h[0][c] = x0; h[1][c] = x1;
             }
-            const long qq = (long)nt * nchunks + slab * RS + tap;
+            const long qq = (long)nt * nchunks + slab * T + tap;
             unsigned char *dst = wp + qq * GB_BUF + nl * 64 + ((p ^ ((nl >> 2) & 3)) << 4);
 #pragma unroll
             for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<h16x8 *>(dst + pl * GB_PLANE) = h[pl];
@@ -859,19 +860,30 @@ __global__ __launch_bounds__(256) void amax_nhwc_kernel(const float *x, int ldx,
 
 // the same for flat fp32 arrays (weights), blockIdx.y = tensor
 struct AmaxTable {
-    const float *w[24];
+    float *w[24];
     float *q[24];
     long n[24];
+    short rs[24], taps[24];        // taps > 0: a masked convolution -- taps >= taps[i] of every filter are ZEROED IN PLACE (what the
+                                   // reference does at every forward: layers.py:44 `self.weight.data *= self.mask`) and not counted
 };
 __global__ __launch_bounds__(256) void amax_multi_kernel(const AmaxTable tab)
 {
     __shared__ float qred[16];
-    const float *w = tab.w[blockIdx.y];
+    float *w = tab.w[blockIdx.y];
     const long n = tab.n[blockIdx.y];
     float m = 0.f;
-    // eight independent loads in flight per thread (a flat parameter buffer guarantees 4-byte alignment only: scalar loads)
     const long stride = (long)gridDim.x * 256;
     long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (tab.taps[blockIdx.y] > 0) {
+        const int rs = tab.rs[blockIdx.y], live = tab.taps[blockIdx.y];
+        for (; e < n; e += stride) {
+            if ((int)(e % rs) >= live)
+                w[e] = 0.f;
+            else
+                m = fmaxf(m, fabsf(w[e]));
+        }
+    }
+    // eight independent loads in flight per thread (a flat parameter buffer guarantees 4-byte alignment only: scalar loads)
     for (; e + 7 * stride < n; e += 8 * stride) {
         float v[8];
 #pragma unroll
@@ -977,11 +989,11 @@ long planes_slots(long npix, int C) { return (long)cdivz((size_t)npix, 64) * cdi
 size_t w_image_bytes(int C, int R, int S) { return (size_t)(C / 32) * R * S * B_BUF; }
 size_t gen_image_bytes(int N, int C, int R, int S) { return (size_t)cdiv(N, GBN) * (C / 32) * R * S * GB_BUF; }
 
-int amax_flat(const float *w, long n, float *q, hipStream_t st)
+int amax_flat(const float *w, long n, float *q, hipStream_t st, int rs = 0, int taps = 0)
 {
     AmaxTable t;
     memset(&t, 0, sizeof(t));
-    t.w[0] = w; t.q[0] = q; t.n[0] = n;
+    t.w[0] = const_cast<float *>(w); t.q[0] = q; t.n[0] = n; t.rs[0] = (short)rs; t.taps[0] = (short)taps;
     hipLaunchKernelGGL(amax_multi_kernel, dim3(WQ_SLOTS, 1), dim3(256), 0, st, t);      // always all slots: images compare equal
     return 0;
 }
@@ -1153,15 +1165,17 @@ STEM_EXPORT size_t stem_f16x2_conv_weight_gen_bytes(int N, int C, int R, int S)
     return C % 32 ? 0 : gen_image_bytes(N, C, R, S) + WQ_BYTES;
 }
 
-STEM_EXPORT int stem_f16x2_pack_conv_weight_gen(const float *w, void *wp, int N, int C, int R, int S, int flip, void *stream)
+STEM_EXPORT int stem_f16x2_pack_conv_weight_gen(const float *w, void *wp, int N, int C, int R, int S, int flip, int taps, void *stream)
 {
     STEM_CHECK_ARG(w && wp && N >= 1 && C > 0 && C % 32 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP,
                    "stem_f16x2_pack_conv_weight_gen: C %% 32 == 0, R*S <= %d (N=%d C=%d R=%d S=%d)", MAXTAP, N, C, R, S);
-    const long np = (long)cdiv(N, GBN) * (C / 32) * R * S * GBN * 4;
+    STEM_CHECK_ARG(taps >= 0 && taps <= R * S && (taps == 0 || !flip), "stem_f16x2_pack_conv_weight_gen: 0 <= taps <= R*S, forward role only (taps=%d)", taps);
+    const int T = taps > 0 ? taps : R * S;
+    const long np = (long)cdiv(N, GBN) * (C / 32) * T * GBN * 4;
     float *wq = reinterpret_cast<float *>(static_cast<unsigned char *>(wp) + gen_image_bytes(N, C, R, S));
-    amax_flat(w, (long)N * C * R * S, wq, (hipStream_t)stream);
+    amax_flat(w, (long)N * C * R * S, wq, (hipStream_t)stream, R * S, taps < R * S ? taps : 0);
     hipLaunchKernelGGL(pack_weight_gen_kernel, dim3((unsigned)cdivz(np, 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       static_cast<unsigned char *>(wp), N, C, R * S, flip, np, wq);
+                       static_cast<unsigned char *>(wp), N, C, R * S, T, flip, np, wq);
     STEM_LAUNCH_CHECK("stem_f16x2_pack_conv_weight_gen");
     return 0;
 }
@@ -1184,9 +1198,12 @@ STEM_EXPORT int stem_f16x2_pack_conv_weights_multi(const stem_f16x2_pack_desc *d
     memset(&mt, 0, sizeof(mt));
     for (int i = 0; i < n; ++i) {
         const stem_f16x2_pack_desc &d = descs_host[i];
-        mt.w[i] = static_cast<const float *>(d.w);
+        STEM_CHECK_ARG(d.taps >= 0 && d.taps <= d.R * d.S && (d.taps == 0 || !d.flip), "stem_f16x2_pack_conv_weights_multi: descriptor %d: taps", i);
+        mt.w[i] = static_cast<float *>(const_cast<void *>(d.w));
         mt.q[i] = reinterpret_cast<float *>(static_cast<unsigned char *>(d.wp) + gen_image_bytes(d.N, d.C, d.R, d.S));
         mt.n[i] = (long)d.N * d.C * d.R * d.S;
+        mt.rs[i] = (short)(d.R * d.S);
+        mt.taps[i] = (short)(d.taps > 0 && d.taps < d.R * d.S ? d.taps : 0);
     }
     hipLaunchKernelGGL(amax_multi_kernel, dim3(WQ_SLOTS, n), dim3(256), 0, (hipStream_t)stream, mt);
     const unsigned gx = (unsigned)(maxu < 2048 ? maxu : 2048);
@@ -1234,11 +1251,11 @@ int gen_bm(int M, int ntn, int nchunks)
 }
 }   // namespace
 
-STEM_EXPORT size_t stem_conv2d_f16x3_gen_workspace_bytes(int B, int H, int W, int C, int N, int R, int S, int stride, int pad)
+STEM_EXPORT size_t stem_conv2d_f16x3_gen_workspace_bytes(int B, int H, int W, int C, int N, int R, int S, int stride, int pad, int taps)
 {
     const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
     if (OH < 1 || OW < 1 || C % 32) return 0;
-    const int M = B * OH * OW, nchunks = (C / 32) * R * S, tiles = cdiv(M, gen_bm(M, cdiv(N, GBN), nchunks)) * cdiv(N, GBN);
+    const int M = B * OH * OW, nchunks = (C / 32) * (taps > 0 ? taps : R * S), tiles = cdiv(M, gen_bm(M, cdiv(N, GBN), nchunks)) * cdiv(N, GBN);
     int s = gen_split(tiles, nchunks);
     while (s > 1 && (size_t)s * M * cdiv(N, GBN) * GBN * sizeof(float) >= 0x7FFFFF00ull) --s;
     return s > 1 ? kGenCntBytes + (size_t)s * M * cdiv(N, GBN) * GBN * sizeof(float) : 0;
@@ -1246,8 +1263,10 @@ STEM_EXPORT size_t stem_conv2d_f16x3_gen_workspace_bytes(int B, int H, int W, in
 
 STEM_EXPORT int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int xpix, const void *wp, const float *bias, int epi, float slope,
                                            const float *z, int ldz, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R,
-                                           int S, int stride, int pad, void *ws, size_t ws_bytes, void *stream)
+                                           int S, int stride, int pad, int taps, void *ws, size_t ws_bytes, void *stream)
 {
+    STEM_CHECK_ARG(taps >= 0 && taps <= R * S, "stem_conv2d_f16x3_gen_fwd: 0 <= taps <= R*S (taps=%d)", taps);
+    const int T = taps > 0 ? taps : R * S;
     STEM_CHECK_ARG(xp && xq && wp && (y || yp) && (yq || !yp), "stem_conv2d_f16x3_gen_fwd: null pointer (planes come with their scale records)");
     STEM_CHECK_ARG(epi == GEN_EPI_BIAS || fabsf(slope) <= 1.f, "stem_conv2d_f16x3_gen_fwd: |slope| <= 1");
     STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && C >= 32 && C % 32 == 0 && N >= 4 && N % 4 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP &&
@@ -1261,14 +1280,14 @@ STEM_EXPORT int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int x
     if (xpix == 0) xpix = (C / 32) * SLAB;
     STEM_CHECK_ARG(xpix >= (C / 32) * SLAB && xpix % SLAB == 0, "stem_conv2d_f16x3_gen_fwd: xpix must be a multiple of %d bytes covering C channels", SLAB);
     const size_t xb = (size_t)B * H * W * xpix, wb = gen_image_bytes(N, C, R, S);
-    const int M = B * OH * OW, ntn = cdiv(N, GBN), nchunks = (C / 32) * R * S, bm = gen_bm(M, ntn, nchunks), tiles = cdiv(M, bm) * ntn;
+    const int M = B * OH * OW, ntn = cdiv(N, GBN), nchunks = (C / 32) * T, bm = gen_bm(M, ntn, nchunks), tiles = cdiv(M, bm) * ntn;
     STEM_CHECK_ARG(xb < 0x7FFFFF00ull && wb < 0x7FFFFF00ull && (size_t)M * ntn * GBN * 4 < 0x7FFFFF00ull,
                    "stem_conv2d_f16x3_gen_fwd: operand views must stay below 2 GiB (split the batch)");
     Fx3Args a;
     memset(&a, 0, sizeof(a));
     a.xp = xp; a.wp = wp; a.bias = bias; a.y = y; a.yp = yp; a.ldy = ldy; a.z = z; a.ldz = ldz; a.epi = epi; a.slope = slope;
     a.xq = xq; a.yq = yq; a.wq = reinterpret_cast<const float *>(static_cast<const unsigned char *>(wp) + wb);
-    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.OH = OH; a.OW = OW; a.stride = stride; a.ntaps = R * S;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.OH = OH; a.OW = OW; a.stride = stride; a.ntaps = T;
     a.xbytes = (int)xb; a.wbytes = (int)wb; a.xpix = xpix;
     for (int r = 0; r < R; ++r)
         for (int s = 0; s < S; ++s) {

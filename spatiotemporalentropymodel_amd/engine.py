@@ -39,6 +39,7 @@ class _Layer:
         # contraction channels are multiples of 32; decided once by the engine (StemEngine._select_fx3)
         self.fx3 = False
         self.wg3 = False
+        self.taps = 0             # masked convolution on the fp16 kernel: the number of live taps (a prefix of the row-major order)
         self.wp6_fwd = self.wp6_dgrad = None
         self._slabs = {}
         self.pending = None       # (dwp, splits) of the last wgrad, consumed by StemEngine.unpack_all
@@ -47,6 +48,12 @@ class _Layer:
     def fx3_eligible(self):
         return (self.kind == "conv" and self.stride == 1 and not self.masked and self.C % 32 == 0 and self.K % 32 == 0
                 and self.R * self.R <= 25 and self.pad == self.R // 2)
+
+    def fx3_masked_eligible(self):
+        """the context model's masked convolution, forward only (its input is data + noise: no input gradient): the general
+        kernel runs over the live taps alone -- 12 of 25 for the 5x5 type-A mask (layers.py:21-47)"""
+        return (self.kind == "conv" and self.stride == 1 and bool(self.masked) and not self.need_dgrad and self.C % 32 == 0
+                and self.K % 4 == 0 and self.R * self.R <= 25 and self.pad == self.R // 2)
 
     def alloc_packs(self, device):
         if self.fx3:
@@ -60,7 +67,7 @@ class _Layer:
 
     def pack_descs6(self):
         w = self.mod.weight
-        out = [_lib.F16PackDesc(w.data_ptr(), self.wp6_fwd.data_ptr(), self.K, self.C, self.R, self.R, 0, 0)]
+        out = [_lib.F16PackDesc(w.data_ptr(), self.wp6_fwd.data_ptr(), self.K, self.C, self.R, self.R, 0, self.taps)]
         if self.need_dgrad:       # the input-gradient of a stride-1 convolution is a convolution with the mirrored, transposed weight
             out.append(_lib.F16PackDesc(w.data_ptr(), self.wp6_dgrad.data_ptr(), self.C, self.K, self.R, self.R, 1, 0))
         return out
@@ -68,7 +75,7 @@ class _Layer:
     def fwd6(self, xp, act=F.ACT_NONE, out=None, planes=False):
         """-> (fp32 output, planes output or None); `xp` a F16Planes (possibly a channel view)"""
         return F.conv2d_f16x3_gen(xp, self.wp6_fwd, self.mod.bias, self.K, self.R, self.R, 1, self.pad,
-                                   epi=F.GEN_EPI_LRELU if act == F.ACT_LRELU else F.GEN_EPI_BIAS, out=out, want_planes=planes)
+                                   epi=F.GEN_EPI_LRELU if act == F.ACT_LRELU else F.GEN_EPI_BIAS, out=out, want_planes=planes, taps=self.taps)
 
     def dgrad6(self, dyp, xact=None, planes=False):
         """-> (dx fp32, dx planes or None); xact: the activated input of this layer (leaky-ReLU derivative folded in)"""
@@ -216,6 +223,10 @@ class StemEngine:
         views are 32-aligned -- otherwise the whole chain stays on the fp32-MFMA kernels, which only need C % 4 == 0."""
         for l in self.layers:
             l.fx3 = self.use_fx3 and l.fx3_eligible()
+            l.taps = 0
+        if self.has_spm and self.use_fx3 and self.use_ctx3 and self.CTX.fx3_masked_eligible():
+            self.CTX.fx3 = True
+            self.CTX.taps = F.masked_live_taps(self.CTX.R, self.CTX.R, "B" if self.CTX.masked & 4 else "A")
         P = self.HE[0].C                                # HE.0 reads cat(y_cur, y_cond): its C is 2 * Cin = P
         for group, need_aligned in ((self.TPM, False), (self.EPM, True)):
             if group and not (all(l.fx3 for l in group) and (not need_aligned or P % 32 == 0)):
@@ -229,6 +240,8 @@ class StemEngine:
     #: forward and input-gradient of the stride-1 layers (TPM, HE.0, HD.4, EPM) on the fp16 matrix cores with fp32-exact products
     #: (three fp16 MFMAs per fp32 product, csrc/conv_f16x3.hip); STEM_ENGINE_F16X3=0 keeps every layer on the fp32-MFMA kernels
     use_fx3 = os.environ.get("STEM_ENGINE_F16X3", "1") != "0"
+    #: the masked context convolution's forward on the same kernel over its live taps; STEM_ENGINE_CTX_F16X3=0: igemm.hip
+    use_ctx3 = os.environ.get("STEM_ENGINE_CTX_F16X3", "1") != "0"
     #: ... and their weight gradients (csrc/wgrad_f16x3.hip); STEM_ENGINE_WGRAD_F16X3=0 keeps those on wgrad.hip
     use_wg3 = os.environ.get("STEM_ENGINE_WGRAD_F16X3", "1") != "0"
 
@@ -388,15 +401,15 @@ class StemEngine:
             bs.wait_stream(main)
         # the context model's convolution needs only t_hat (the prologue's output): on a stream of its own, enqueued first so
         # that it runs next to the hyper and TPM chains instead of after them
+        pl = {}             # planes copies of activations, kept for the weight gradients
         cs = self._branch(dev, 1) if (bs is not None and self.ctx_branch and fused and self.has_spm and self.has_tpm) else None
         if cs is not None:
             cs.wait_stream(main)
             with torch.cuda.stream(cs):
-                self.CTX.fwd(t_hat, out=epm_in[:, o_ctx:o_ctx + P])
+                self._ctx_forward(t_hat, epm_in[:, o_ctx:o_ctx + P], pl)
             t_hat.record_stream(cs)
             epm_in.record_stream(cs)
         split = F.F16Planes.split
-        pl = {}             # planes copies of activations, kept for the weight gradients
         with (torch.cuda.stream(bs) if bs is not None else contextlib.nullcontext()):
             if self.HE[0].fx3:
                 pl["he_in"] = split(he_in)
@@ -440,7 +453,7 @@ class StemEngine:
             if cs is not None:
                 main.wait_stream(cs)
             else:
-                self.CTX.fwd(t_hat, out=epm_in[:, o_ctx:o_ctx + P])
+                self._ctx_forward(t_hat, epm_in[:, o_ctx:o_ctx + P], pl)
         if bs is not None:
             main.wait_stream(bs)
         if self.EPM[0].fx3:
@@ -514,7 +527,8 @@ class StemEngine:
         # spatial prior: weight gradient of all 25 taps, no input gradient (its input is data + noise)
         if self.has_spm:
             if self.CTX.wg3 and dprip is not None:
-                self.CTX.wgrad_any(k["t_hat"], dpri[:, o_ctx:o_ctx + P], F.F16Planes.split(k["t_hat"]), dprip.channels(o_ctx, o_ctx + P))
+                thp = pl.get("t_hat") or F.F16Planes.split(k["t_hat"])         # left by the forward when it ran on the fp16 kernel
+                self.CTX.wgrad_any(k["t_hat"], dpri[:, o_ctx:o_ctx + P], thp, dprip.channels(o_ctx, o_ctx + P))
             else:
                 self.CTX.wgrad(k["t_hat"], dpri[:, o_ctx:o_ctx + P])
             self._group_ready([self.CTX], [])
@@ -539,6 +553,15 @@ class StemEngine:
         else:
             main.wait_stream(bs)
         self.join_side_stream()          # gradients are complete for whatever the compute stream does next
+
+    def _ctx_forward(self, t_hat, out, pl):
+        """context_prediction(t_hat) -> its channel slice of the EPM input (spatiotemporalpriors.py:857): on the fp16 kernel over
+        the live taps of the mask (the planes of t_hat stay for the weight gradient), else on igemm.hip's masked form"""
+        if self.CTX.fx3:
+            pl["t_hat"] = F.F16Planes.split(t_hat)
+            self.CTX.fwd6(pl["t_hat"], out=out)
+        else:
+            self.CTX.fwd(t_hat, out=out)
 
     def _backward_hyper(self, k, dpri, dlik_z, dprip=None):
         m = self.m

@@ -573,7 +573,12 @@ _WS_GEN_BYTES = {}
 GEN_EPI_BIAS, GEN_EPI_LRELU, GEN_EPI_DACT = 0, 1, 2
 
 
-def pack_weight_f16x2_gen(w: torch.Tensor, flip: bool = False, out=None) -> torch.Tensor:
+def masked_live_taps(R, S, mask_type="A"):
+    """taps of an R x S type-A / type-B masked convolution that are not zeroed (layers.py:21-47): a prefix of the row-major order"""
+    return (R // 2) * S + S // 2 + (1 if mask_type == "B" else 0)
+
+
+def pack_weight_f16x2_gen(w: torch.Tensor, flip: bool = False, out=None, taps: int = 0) -> torch.Tensor:
     """torch Conv2d weight [K,C,R,S] -> the image conv2d_f16x3_gen streams; flip=True packs the operand of the input-gradient of
     a stride-1 convolution (rows = input channels, packed channels = output channels, taps mirrored)."""
     _require_cuda(w)
@@ -585,7 +590,9 @@ def pack_weight_f16x2_gen(w: torch.Tensor, flip: bool = False, out=None) -> torc
     if out is None:
         out = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
     assert out.numel() == nbytes
-    _chk(_lib.hip().stem_f16x2_pack_conv_weight_gen(w.detach().contiguous().data_ptr(), out.data_ptr(), N, Cin, R, S, int(flip), _stream()))
+    wc = w.detach()
+    assert taps == 0 or wc.is_contiguous(), "a masked weight is zeroed in place: it must be contiguous"
+    _chk(_lib.hip().stem_f16x2_pack_conv_weight_gen(wc.contiguous().data_ptr(), out.data_ptr(), N, Cin, R, S, int(flip), int(taps), _stream()))
     return out
 
 
@@ -601,9 +608,10 @@ def pack_weights_f16x2_multi(descs):
 
 
 def conv2d_f16x3_gen(xp: F16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EPI_BIAS, slope=LRELU_SLOPE, z=None, out=None,
-                      want_fp32=True, want_planes=False):
+                      want_fp32=True, want_planes=False, taps=0):
     """General f16x3 convolution (training-time STEM layers): returns (fp32 NHWC tensor or None, F16Planes or None).
-    `out` may be a channel slice of a wider NHWC buffer; epi = GEN_EPI_DACT multiplies by the leaky-ReLU derivative at z."""
+    `out` may be a channel slice of a wider NHWC buffer; epi = GEN_EPI_DACT multiplies by the leaky-ReLU derivative at z;
+    taps > 0: a masked convolution whose weight image holds only its first `taps` taps (pack_weight_f16x2_gen(..., taps=))."""
     B, Cc, H, W = xp.shape
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
     dev = xp.data.device
@@ -611,7 +619,7 @@ def conv2d_f16x3_gen(xp: F16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EPI_
     if want_fp32 or out is not None:
         y = out if out is not None else empty_nhwc(B, N, Ho, Wo, dev)
     yp = F16Planes.empty(B, N, Ho, Wo, dev) if want_planes else None
-    dims = (B, H, W, Cc, N, R, S, stride, pad)
+    dims = (B, H, W, Cc, N, R, S, stride, pad, taps)
     need = _WS_GEN_BYTES.get(dims)
     if need is None:
         need = _WS_GEN_BYTES[dims] = int(_lib.hip().stem_conv2d_f16x3_gen_workspace_bytes(*dims))
@@ -625,7 +633,7 @@ def conv2d_f16x3_gen(xp: F16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EPI_
     _chk(_lib.hip().stem_conv2d_f16x3_gen_fwd(xp.data_ptr(), xp.q_ptr(), xp.pix_bytes, wp.data_ptr(), _ptr(bias), epi, slope, _ptr(z),
                                                nhwc_ld(z) if z is not None else 0, _ptr(y), nhwc_ld(y) if y is not None else 0,
                                                yp.data.data_ptr() if yp is not None else None, yp.q_ptr() if yp is not None else None,
-                                               B, H, W, Cc, N, R, S, stride, pad, ws_ptr, need, _stream()))
+                                               B, H, W, Cc, N, R, S, stride, pad, taps, ws_ptr, need, _stream()))
     return y, yp
 
 

@@ -236,6 +236,28 @@ def test_gen_forward_and_input_gradient_vs_oracle(F, case, split, tile):
         _gen_forward_and_input_gradient(F, case, split)
 
 
+@pytest.mark.parametrize("mask_type", ["A", "B"])
+@pytest.mark.parametrize("R", [3, 5])
+def test_masked_convolution_on_the_general_kernel(F, mask_type, R):
+    """MaskedConv2d (layers.py:21-47) on the general f16x3 kernel: the weight image holds only the live taps (a prefix of the
+    row-major order: 12 of 25 for the 5x5 type-A mask), the masked taps of the torch weight are zeroed IN PLACE by the pack (what
+    the reference does at every forward), result against the oracle's convolution with the masked weight."""
+    B, C, H, W, K = 2, 64, 11, 13, 96
+    x, w, b = rnd((B, C, H, W), 81, -2, 2), (rnd((K, C, R, R), 82) / np.sqrt(C * R * R)).astype(np.float32), rnd((K,), 83, -0.1, 0.1)
+    mask = np.ones((R, R), np.float32)
+    mask[R // 2, R // 2 + (mask_type == "B"):] = 0
+    mask[R // 2 + 1:] = 0
+    taps = F.masked_live_taps(R, R, mask_type)
+    assert taps == int(mask.sum()) and mask.reshape(-1)[:taps].all()
+    wd = dev(w)
+    wp = F.pack_weight_f16x2_gen(wd, taps=taps)
+    assert np.array_equal(host(wd), w * mask)                        # zeroed in place, live taps untouched
+    for tile in (64, 128):
+        with F.tuning(fx3_gen_tile=tile):
+            y, _ = F.conv2d_f16x3_gen(F.F16Planes.split(dev(x)), wp, dev(b), K, R, R, 1, R // 2, taps=taps)
+        assert_close(host(y), orc.conv2d_fwd(x, w * mask, b, 1, R // 2), what=f"masked {mask_type} {R}x{R} tile {tile}", floor=0.1)
+
+
 def _gen_forward_and_input_gradient(F, case, split):
     B, C, H, W, K, R = case
     pad, sl = R // 2, 0.01

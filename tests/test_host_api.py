@@ -410,8 +410,8 @@ def test_masked_conv_mask_layouts():
 def test_bf16_planes_views_and_engine_routing_table():
     """Host logic of the fp16 route (no device work): channel views of a planes tensor (32-aligned, same storage and pitch), and which
     layers of the full-size STEM model the engine sends to the fp16 kernels: forward / input gradient of the stride-1 unmasked
-    convolutions, weight gradient of every stride-1 convolution (the masked context model included), nothing for the stride-2
-    and transposed layers."""
+    convolutions and of the masked context convolution (forward, over its live taps), weight gradient of every stride-1
+    convolution, nothing for the stride-2 and transposed layers."""
     import torch
     from spatiotemporalentropymodel_amd import functional as F
     from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel_Res
@@ -430,8 +430,9 @@ def test_bf16_planes_views_and_engine_routing_table():
     fwd = {n: l.fx3 for n, l in zip(("HE0", "HE2", "HE4", "HD0", "HD2", "HD4", "TPM0", "TPM2", "TPM4", "CTX", "EPM0", "EPM2", "EPM4"), eng.layers)}
     wg = {n: l.wg3 for n, l in zip(fwd, eng.layers)}
     assert fwd == {"HE0": True, "HE2": False, "HE4": False, "HD0": False, "HD2": False, "HD4": True, "TPM0": True, "TPM2": True, "TPM4": True,
-                   "CTX": False, "EPM0": True, "EPM2": True, "EPM4": True}
-    assert wg == dict(fwd, CTX=True)
+                   "CTX": True, "EPM0": True, "EPM2": True, "EPM4": True}
+    assert wg == fwd
+    assert eng.CTX.taps == 12 and all(l.taps == 0 for l in eng.layers if l is not eng.CTX)     # 5x5 type-A mask: 12 live taps
     # Chains are routed as a whole: with latent channel counts that are not multiples of 16 some layers of a chain
     # are ineligible (C % 32), and a half-routed chain would call a kernel whose packed weights were never allocated
     from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel, SpatioTemporalPriorModelWithoutTPM

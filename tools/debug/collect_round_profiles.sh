@@ -9,10 +9,17 @@ python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_no_group.j
 python3 bench.py --config roi --steps 2 --warmup 1 > $out/bench_roi_b16.json 2> $out/bench_roi.err
 STEM_LAYERS_F16X3=0 python3 bench.py --config roi --steps 2 --warmup 1 > $out/bench_roi_b16_fp32_layers.json 2>/dev/null
 bash tools/debug/prof_bench.sh $tag/bench_trace > /dev/null 2>&1
+bash tools/debug/prof_pmc.sh $tag/pmc_ga2 tools/debug/f16x3_prof.py planes 5 > $out/pmc_ga2.log 2>&1
+bash tools/debug/prof_tcc.sh $tag/tcc_ga2 tools/debug/f16x3_prof.py planes 5 > $out/tcc_ga2.log 2>&1
+bash tools/debug/prof_pmc.sh $tag/pmc_gen_tpm4 tools/debug/f16x3_gen_check.py TPM.4 > $out/pmc_gen_tpm4.log 2>&1
 bash tools/debug/prof_pmc.sh $tag/pmc_c4gdn tools/debug/c4gdn_prof.py > $out/pmc_c4gdn.log 2>&1
 bash tools/debug/prof_tcc.sh $tag/tcc_c4gdn tools/debug/c4gdn_prof.py > $out/tcc_c4gdn.log 2>&1
 python3 tools/debug/c4gdn_time.py > $out/c4gdn_time.log 2>&1
 python3 tools/debug/route_vs_oracle.py > $out/route_vs_oracle.log 2>&1
+for t in f16x3_check f16x3_chain wgrad3_check f16x3_gen_check; do python3 tools/debug/$t.py 2>&1 | grep -v "amdgpu.ids\|Warning\|scale =" > $out/accuracy_$t.log; done
+python3 tools/debug/f16x3_split_sweep.py gen 2>&1 | grep -v amdgpu > $out/split_sweep_gen.log
+python3 tools/debug/f16x3_split_sweep.py wgrad 2>&1 | grep -v amdgpu > $out/split_sweep_wgrad.log
+python3 tools/debug/f16x3_depth_sweep.py 2>&1 | grep -v amdgpu > $out/depth_sweep.log
 python3 tools/eval_pframe_bench.py --frames 3 > $out/eval_1080p_per_position_loop.log 2>&1
 python3 tools/eval_pframe_bench.py --frames 3 --sequences 8 > $out/eval_1080p_8_sequences_lockstep.log 2>&1
 if [ -f spatiotemporalentropymodel_amd/libstem_hip_exper.so ]; then

@@ -1,5 +1,3 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/f16
-for t in f16x3_check f16x3_chain wgrad3_check; do echo "=== $t"; timeout 300 python3 tools/debug/$t.py 2>&1 | grep -v "amdgpu.ids\|Consider\|scale =" | tail -14; done > gpurun_out/f16/acc.log 2>&1
-echo "=== gen TPM.2" >> gpurun_out/f16/acc.log; timeout 300 python3 tools/debug/f16x3_gen_check.py TPM.2 2>&1 | tail -12 >> gpurun_out/f16/acc.log
-timeout 600 python3 -m pytest tests/test_hip_dp2.py -m gpu -q -x 2>&1 | tail -3 >> gpurun_out/f16/acc.log
+for v in "" "fx3_gen_tile=64" "fx3_gen_tile=128"; do echo "== $v"; python3 tools/debug/pytest_tuned.py $v -- tests/test_hip_roi.py tests/test_hip_f16x3.py -m gpu -q 2>&1 | tail -2; done > gpurun_out/f16/pytest.log

@@ -13,4 +13,4 @@ for pmc in "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCL
 done
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $out/pmc.csv /tmp/p_pmc1 /tmp/p_pmc2 /tmp/p_pmc3 > /dev/null 2>&1
 head -4 $out/kernel_stats.csv
-grep -E "^kernel|conv_f16x3|igemm|c4gdn" $out/pmc.csv
+grep -E "^kernel|conv_f16x3|igemm|c4gdn|wgrad_f16x3" $out/pmc.csv

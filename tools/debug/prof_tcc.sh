@@ -8,4 +8,4 @@ for pmc in "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" "TCC_REQ_sum TCC
     timeout 240 rocprofv3 --pmc $pmc --kernel-trace --output-format csv -d /tmp/q_pmc$i -o p -- python3 $script "$@" > $out/tcc$i.log 2>&1
 done
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $out/tcc.csv /tmp/q_pmc1 /tmp/q_pmc2 /tmp/q_pmc3 /tmp/q_pmc4 /tmp/q_pmc5 > /dev/null 2>&1
-grep -E "^kernel|conv_f16x3|igemm|c4gdn" $out/tcc.csv
+grep -E "^kernel|conv_f16x3|igemm|c4gdn|wgrad_f16x3" $out/tcc.csv
