@@ -236,6 +236,34 @@ def test_gen_forward_and_input_gradient_vs_oracle(F, case, split, tile):
         _gen_forward_and_input_gradient(F, case, split)
 
 
+@pytest.mark.parametrize("kx,kw", [(-70, 0), (0, -40), (45, 20), (-30, 50)])
+def test_power_of_two_scaling_of_the_operands_is_exact(F, kx, kw):
+    """What the scale records buy: conv(2^kx x, 2^kw w) == 2^(kx+kw) conv(x, w) BIT FOR BIT -- forward (both kernels, fp32 and
+    planes output), input gradient and weight gradient -- for operands 21 decades below and 13 above the range fp16 itself
+    covers; and an all-zero operand gives exact zeros (its record says max = 0, scale 1)."""
+    B, C, H, W, K, R = 2, 64, 12, 20, 96, 3
+    x, w, dy = rnd((B, C, H, W), 91, -2, 2), (rnd((K, C, R, R), 92) / np.sqrt(C * R * R)).astype(np.float32), rnd((B, K, H, W), 93)
+    sx, sw = np.float32(2.0 ** kx), np.float32(2.0 ** kw)
+
+    def run(xs, ws, dys):
+        xp, dyp = F.F16Planes.split(dev(xs)), F.F16Planes.split(dev(dys))
+        y, yp = F.conv2d_f16x3_gen(xp, F.pack_weight_f16x2_gen(dev(ws)), None, K, R, R, 1, 1, want_planes=True)
+        y192 = F.conv2d_f16x3_fwd(xp, F.pack_weight_f16x2(dev(ws)), None, K, R, R, 1, 1)
+        dx, _ = F.conv2d_f16x3_gen(dyp, F.pack_weight_f16x2_gen(dev(ws), flip=True), None, C, R, R, 1, 1)
+        dw = torch.zeros(K, C, R, R, device="cuda")
+        F.conv2d_wgrad_f16x3_into(xp, dyp, K, R, R, 1, dw, None, accumulate=False)
+        return y, yp.merge(), y192, dx, dw
+
+    base = run(x, w, dy)
+    big = run(x * sx, w * sw, dy)
+    for name, a, b, f in zip(("general kernel", "its planes output", "192-column kernel", "input gradient", "weight gradient"), base, big,
+                             (sx * sw, sx * sw, sx * sw, sw, sx)):
+        assert torch.equal(a * float(f), b), f"{name}: scaling the operands by 2^{kx}, 2^{kw} changed more than the exponent"
+    z = run(np.zeros_like(x), w, dy)
+    assert float(z[0].abs().max()) == 0.0 and float(z[2].abs().max()) == 0.0 and float(z[4].abs().max()) == 0.0
+    assert F.F16Planes.split(dev(np.zeros_like(x))).record() == (1.0, 0.0)
+
+
 @pytest.mark.parametrize("mask_type", ["A", "B"])
 @pytest.mark.parametrize("R", [3, 5])
 def test_masked_convolution_on_the_general_kernel(F, mask_type, R):
