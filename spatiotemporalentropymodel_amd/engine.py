@@ -40,6 +40,10 @@ class _Layer:
         self.fx3 = False
         self.wg3 = False
         self.taps = 0             # masked convolution on the fp16 kernel: the number of live taps (a prefix of the row-major order)
+        # fx3s: the STRIDED-CONVOLUTION face of a stride-2 layer on the general fp16 kernel -- the forward of a strided Conv2d
+        # (HE.2 / HE.4), the input gradient of a ConvTranspose2d (HD.0 / HD.2: a strided convolution of dy with the stored weight
+        # [C][K][R][S] read as a Conv2d weight with C outputs); the transposed face stays on igemm.hip's sub-pixel phases
+        self.fx3s = False
         self.wp6_fwd = self.wp6_dgrad = None
         self._slabs = {}
         self.pending = None       # (dwp, splits) of the last wgrad, consumed by StemEngine.unpack_all
@@ -55,7 +59,25 @@ class _Layer:
         return (self.kind == "conv" and self.stride == 1 and bool(self.masked) and not self.need_dgrad and self.C % 32 == 0
                 and self.K % 4 == 0 and self.R * self.R <= 25 and self.pad == self.R // 2)
 
+    def fx3s_eligible(self):
+        n_out, n_red = (self.K, self.C) if self.kind == "conv" else (self.C, self.K)       # outputs / contraction channels of that face
+        return (self.stride == 2 and not self.masked and n_red % 32 == 0 and n_out % 4 == 0 and self.R * self.R <= 25
+                and (self.kind == "conv" or self.need_dgrad))
+
     def alloc_packs(self, device):
+        if self.fx3s:
+            n = self.K * self.C * self.R * self.R
+            nb = F.f16x2_gen_weight_bytes(*((self.K, self.C) if self.kind == "conv" else (self.C, self.K)), self.R, self.R)
+            img = torch.empty(nb, device=device, dtype=torch.uint8)
+            if self.kind == "conv":      # forward on the fp16 kernel, input gradient on igemm.hip
+                self.wp6_fwd, self.wp6_dgrad = img, None
+                self.wp_fwd = torch.empty(0, device=device)          # never read: marks the layer as allocated
+                self.wp_dgrad = torch.empty(n, device=device, dtype=torch.float32) if self.need_dgrad else None
+            else:                        # forward on igemm.hip, input gradient on the fp16 kernel
+                self.wp6_fwd, self.wp6_dgrad = None, img
+                self.wp_fwd = torch.empty(n, device=device, dtype=torch.float32)
+                self.wp_dgrad = None
+            return
         if self.fx3:
             self.wp6_fwd = torch.empty(F.f16x2_gen_weight_bytes(self.K, self.C, self.R, self.R), device=device, dtype=torch.uint8)
             self.wp6_dgrad = torch.empty(F.f16x2_gen_weight_bytes(self.C, self.K, self.R, self.R), device=device,
@@ -64,6 +86,19 @@ class _Layer:
         n = self.K * self.C * self.R * self.R
         self.wp_fwd = torch.empty(n, device=device, dtype=torch.float32)
         self.wp_dgrad = torch.empty(n, device=device, dtype=torch.float32) if self.need_dgrad else None
+
+    def role_descs(self, role):
+        """(fp32 descriptors, fp16 descriptors) of this layer's packed copies for role 0 (forward) / 1 (input gradient)"""
+        if self.fx3s:
+            w, conv = self.mod.weight, self.kind == "conv"
+            if role == 0:
+                return ([], [_lib.F16PackDesc(w.data_ptr(), self.wp6_fwd.data_ptr(), self.K, self.C, self.R, self.R, 0, 0)]) if conv \
+                    else ([self._desc32(0)], [])
+            if not self.need_dgrad:
+                return [], []
+            return ([self._desc32(1)], []) if conv \
+                else ([], [_lib.F16PackDesc(w.data_ptr(), self.wp6_dgrad.data_ptr(), self.C, self.K, self.R, self.R, 0, 0)])
+        return ([], self.pack_descs6()[role:role + 1]) if self.fx3 else (self.pack_descs()[role:role + 1], [])
 
     def pack_descs6(self):
         w = self.mod.weight
@@ -74,12 +109,17 @@ class _Layer:
 
     def fwd6(self, xp, act=F.ACT_NONE, out=None, planes=False):
         """-> (fp32 output, planes output or None); `xp` a F16Planes (possibly a channel view)"""
-        return F.conv2d_f16x3_gen(xp, self.wp6_fwd, self.mod.bias, self.K, self.R, self.R, 1, self.pad,
+        return F.conv2d_f16x3_gen(xp, self.wp6_fwd, self.mod.bias, self.K, self.R, self.R, self.stride, self.pad,
                                    epi=F.GEN_EPI_LRELU if act == F.ACT_LRELU else F.GEN_EPI_BIAS, out=out, want_planes=planes, taps=self.taps)
 
     def dgrad6(self, dyp, xact=None, planes=False):
         """-> (dx fp32, dx planes or None); xact: the activated input of this layer (leaky-ReLU derivative folded in)"""
         return F.conv2d_f16x3_gen(dyp, self.wp6_dgrad, None, self.C, self.R, self.R, 1, self.pad,
+                                   epi=F.GEN_EPI_DACT if xact is not None else F.GEN_EPI_BIAS, z=xact, want_planes=planes)
+
+    def dgrad6s(self, dyp, xact=None, planes=False):
+        """input gradient of a ConvTranspose2d = the strided convolution of dy with the stored weight (fx3s)"""
+        return F.conv2d_f16x3_gen(dyp, self.wp6_dgrad, None, self.C, self.R, self.R, self.stride, self.pad,
                                    epi=F.GEN_EPI_DACT if xact is not None else F.GEN_EPI_BIAS, z=xact, want_planes=planes)
 
     def wg3_eligible(self):
@@ -114,19 +154,21 @@ class _Layer:
         F.conv2d_wgrad_f16x3(xp, dyp, self.K, self.R, self.R, self.pad, dwp, splits, db=gb, bias_part=bpart, accumulate_db=True)
         self.pending = (dwp, splits)
 
-    def pack_descs(self):
+    def _desc32(self, role):
         w = self.mod.weight
         conv = self.kind == "conv"
-        out = [_lib.PackDesc(w.data_ptr(), self.wp_fwd.data_ptr(), self.K, self.C, self.R, self.R,
-                             F.PACK_CONV_FWD if conv else F.PACK_DECONV_FWD, self.masked)]
-        if self.need_dgrad:
-            out.append(_lib.PackDesc(w.data_ptr(), self.wp_dgrad.data_ptr(), self.K, self.C, self.R, self.R,
-                                     F.PACK_CONV_DGRAD if conv else F.PACK_DECONV_DGRAD, (1 | (self.masked & 4)) if self.masked else 0))
-        return out
+        if role == 0:
+            return _lib.PackDesc(w.data_ptr(), self.wp_fwd.data_ptr(), self.K, self.C, self.R, self.R,
+                                 F.PACK_CONV_FWD if conv else F.PACK_DECONV_FWD, self.masked)
+        return _lib.PackDesc(w.data_ptr(), self.wp_dgrad.data_ptr(), self.K, self.C, self.R, self.R,
+                             F.PACK_CONV_DGRAD if conv else F.PACK_DECONV_DGRAD, (1 | (self.masked & 4)) if self.masked else 0)
+
+    def pack_descs(self):
+        return [self._desc32(0)] + ([self._desc32(1)] if self.need_dgrad else [])
 
     def fwd(self, x, act=F.ACT_NONE, out=None):
         self.eng.ensure_packed()
-        if self.fx3:          # callers outside the training schedule (codec.py) hand over fp32 tensors
+        if self.fx3 or (self.fx3s and self.kind == "conv"):          # callers outside the training schedule (codec.py) hand over fp32 tensors
             return self.fwd6(F.F16Planes.split(x), act, out=out)[0]
         m = self.mod
         if self.kind == "conv":
@@ -224,6 +266,15 @@ class StemEngine:
         for l in self.layers:
             l.fx3 = self.use_fx3 and l.fx3_eligible()
             l.taps = 0
+            l.fx3s = False
+        if self.use_fx3 and self.use_fx3s:
+            # the hyper path's strided faces; each needs its neighbour's planes (HE.0 -> HE.2 -> HE.4, HD.4 -> HD.2 -> HD.0)
+            if self.HE[0].fx3 and self.HE[1].fx3s_eligible():
+                self.HE[1].fx3s = True
+                self.HE[2].fx3s = self.HE[2].fx3s_eligible() and self.HE[1].K % 32 == 0
+            if self.HD[2].fx3 and self.HD[1].fx3s_eligible():
+                self.HD[1].fx3s = True
+                self.HD[0].fx3s = self.HD[0].fx3s_eligible() and self.HD[1].C % 32 == 0
         if self.has_spm and self.use_fx3 and self.use_ctx3 and self.CTX.fx3_masked_eligible():
             self.CTX.fx3 = True
             self.CTX.taps = F.masked_live_taps(self.CTX.R, self.CTX.R, "B" if self.CTX.masked & 4 else "A")
@@ -240,6 +291,9 @@ class StemEngine:
     #: forward and input-gradient of the stride-1 layers (TPM, HE.0, HD.4, EPM) on the fp16 matrix cores with fp32-exact products
     #: (three fp16 MFMAs per fp32 product, csrc/conv_f16x3.hip); STEM_ENGINE_F16X3=0 keeps every layer on the fp32-MFMA kernels
     use_fx3 = os.environ.get("STEM_ENGINE_F16X3", "1") != "0"
+    #: the strided-convolution faces of the hyper path's stride-2 layers (HE.2 / HE.4 forward, HD.2 / HD.0 input gradient) on the
+    #: general fp16 kernel; STEM_ENGINE_STRIDED_F16X3=0: igemm.hip
+    use_fx3s = os.environ.get("STEM_ENGINE_STRIDED_F16X3", "1") != "0"
     #: the masked context convolution's forward on the same kernel over its live taps; STEM_ENGINE_CTX_F16X3=0: igemm.hip
     use_ctx3 = os.environ.get("STEM_ENGINE_CTX_F16X3", "1") != "0"
     #: ... and their weight gradients (csrc/wgrad_f16x3.hip); STEM_ENGINE_WGRAD_F16X3=0 keeps those on wgrad.hip
@@ -295,7 +349,7 @@ class StemEngine:
             return
         stale = False
         for l in self.layers:
-            have = l.wp6_fwd if l.fx3 else l.wp_fwd
+            have = l.wp_fwd if (l.fx3s or not l.fx3) else l.wp6_fwd
             stale = stale or have is None or have.device != l.mod.weight.device
         if stale:
             for l in self.layers:
@@ -309,10 +363,11 @@ class StemEngine:
             if on_side:
                 side.wait_stream(torch.cuda.current_stream(dev))      # the optimiser step that changed the weights
             with (torch.cuda.stream(side) if on_side else contextlib.nullcontext()):
-                descs = [d for l in self.layers if not l.fx3 for d in l.pack_descs()[lo:hi]]
+                both = [l.role_descs(r) for l in self.layers for r in range(lo, hi)]
+                descs = [d for a, _ in both for d in a]
                 if descs:
                     F.pack_weights_multi((_lib.PackDesc * len(descs))(*descs))
-                descs6 = [d for l in self.layers if l.fx3 for d in l.pack_descs6()[lo:hi]]
+                descs6 = [d for _, b in both for d in b]
                 if descs6:
                     F.pack_weights_f16x2_multi((_lib.F16PackDesc * len(descs6))(*descs6))
                 if on_side:
@@ -413,11 +468,15 @@ class StemEngine:
         with (torch.cuda.stream(bs) if bs is not None else contextlib.nullcontext()):
             if self.HE[0].fx3:
                 pl["he_in"] = split(he_in)
-                he0 = self.HE[0].fwd6(pl["he_in"], F.ACT_LRELU)[0]
+                he0, he0p = self.HE[0].fwd6(pl["he_in"], F.ACT_LRELU, planes=self.HE[1].fx3s)
             else:
                 he0 = self.HE[0].fwd(he_in, F.ACT_LRELU)
-            he2 = self.HE[1].fwd(he0, F.ACT_LRELU)
-            z = self.HE[2].fwd(he2)
+            if self.HE[1].fx3s:           # the strided forwards on the general fp16 kernel, planes handed down
+                he2, he2p = self.HE[1].fwd6(he0p, F.ACT_LRELU, planes=self.HE[2].fx3s)
+                z = self.HE[2].fwd6(he2p)[0] if self.HE[2].fx3s else self.HE[2].fwd(he2)
+            else:
+                he2 = self.HE[1].fwd(he0, F.ACT_LRELU)
+                z = self.HE[2].fwd(he2)
             pack = F.eb_pack(eb._tensors14())
             if fused:
                 z_hat, lik_z, k["dlik_z"], part_z = F.eb_forward_train(z, pack, rate_coef[0], bound=eb._lik_bound, **eb._noise_slot(z))
@@ -573,14 +632,17 @@ class StemEngine:
         if self.HD[2].fx3:
             dhpp = dprip.channels(o_hp, o_hp + P) if dprip is not None else F.F16Planes.split(dhp)
             self.HD[2].wgrad_any(k["hd2"], dhp, pl.get("hd2"), dhpp)
-            d = self.HD[2].dgrad6(dhpp, xact=k["hd2"])[0]
+            d, dp = self.HD[2].dgrad6(dhpp, xact=k["hd2"], planes=self.HD[1].fx3s)
         else:
             self.HD[2].wgrad(k["hd2"], dhp)
             d = self.HD[2].dgrad(dhp, k["hd2"].shape, xact=k["hd2"])
         self.HD[1].wgrad(k["hd0"], d)
-        d = self.HD[1].dgrad(d, k["hd0"].shape, xact=k["hd0"])
+        if self.HD[1].fx3s:               # input gradients of the transposed layers = strided convolutions of dy, planes handed down
+            d, dp = self.HD[1].dgrad6s(dp, xact=k["hd0"], planes=self.HD[0].fx3s)
+        else:
+            d = self.HD[1].dgrad(d, k["hd0"].shape, xact=k["hd0"])
         self.HD[0].wgrad(k["z_hat"], d)
-        dz_hat = self.HD[0].dgrad(d, k["z_hat"].shape)
+        dz_hat = self.HD[0].dgrad6s(dp)[0] if self.HD[0].fx3s else self.HD[0].dgrad(d, k["z_hat"].shape)
         # entropy bottleneck: d/dz = dz_hat + likelihood path; 58 parameter gradients per channel
         eb = m.entropy_bottleneck
         dz, dpack = F.eb_backward(k["z_hat"], k["pack"], dlik_z, dzhat_in=dz_hat, bound=eb._lik_bound)

@@ -433,6 +433,8 @@ def test_bf16_planes_views_and_engine_routing_table():
                    "CTX": True, "EPM0": True, "EPM2": True, "EPM4": True}
     assert wg == fwd
     assert eng.CTX.taps == 12 and all(l.taps == 0 for l in eng.layers if l is not eng.CTX)     # 5x5 type-A mask: 12 live taps
+    # the strided-convolution faces of the hyper path's stride-2 layers (HE.2 / HE.4 forward, HD.0 / HD.2 input gradient)
+    assert {n: l.fx3s for n, l in zip(fwd, eng.layers)} == dict({n: False for n in fwd}, HE2=True, HE4=True, HD0=True, HD2=True)
     # Chains are routed as a whole: with latent channel counts that are not multiples of 16 some layers of a chain
     # are ineligible (C % 32), and a half-routed chain would call a kernel whose packed weights were never allocated
     from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel, SpatioTemporalPriorModelWithoutTPM
@@ -446,10 +448,17 @@ def test_bf16_planes_views_and_engine_routing_table():
         if e.EPM[0].fx3:
             assert (2 * cin) % 32 == 0                        # the EPM input gradient is read through 32-aligned channel views
         for l in e.layers:
-            assert not l.fx3 or l.fx3_eligible()
+            assert not l.fx3 or l.fx3_eligible() or l.fx3_masked_eligible()
+            assert not l.fx3s or (l.fx3s_eligible() and not l.fx3)
             # every layer has exactly the packed weights its route needs once allocated (CPU: allocation only)
             l.alloc_packs(torch.device("cpu"))
-            assert (l.wp6_fwd is not None) == l.fx3 and (l.wp_fwd is not None) == (not l.fx3)
+            if l.fx3s:      # one face on the fp16 kernel, the other on igemm.hip
+                assert (l.wp6_fwd is not None) == (l.kind == "conv") and (l.wp6_dgrad is not None) == (l.kind == "deconv")
+                assert l.wp_fwd is not None and (l.wp_dgrad is not None) == (l.kind == "conv" and l.need_dgrad)
+            else:
+                assert (l.wp6_fwd is not None) == l.fx3 and (l.wp_fwd is not None) == (not l.fx3)
+            for role in (0, 1):     # descriptors can be built for both roles (every buffer they name exists)
+                l.role_descs(role)
     e24 = SpatioTemporalPriorModel_Res(64, 24).engine()
     assert not any(l.fx3 for l in e24.TPM + e24.EPM)          # 2 * 24 = 48 channels: not a multiple of 32
     e48 = SpatioTemporalPriorModel_Res(64, 48).engine()

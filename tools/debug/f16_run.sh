@@ -1,3 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/f16
-for v in "" "fx3_gen_tile=64" "fx3_gen_tile=128"; do echo "== $v"; python3 tools/debug/pytest_tuned.py $v -- tests/test_hip_roi.py tests/test_hip_f16x3.py -m gpu -q 2>&1 | tail -2; done > gpurun_out/f16/pytest.log
+timeout 2800 python3 -m pytest tests -m gpu -q -x --deselect tests/test_hip_dp2.py 2>&1 | grep -v "^E    *+\|tensor(\[" | tail -25 > gpurun_out/f16/pytest.log
+for i in 1 2; do for v in 0 1; do echo -n "strided_f16x3=$v: "; STEM_ENGINE_STRIDED_F16X3=$v python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d[\"ms_per_step\"],3))"; done; done > gpurun_out/f16/ab.log 2>&1
