@@ -211,27 +211,8 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
         }
         pf_q = chunk_of(1 + DEPTH, pf_t, pf_kc);
     }
-    __syncthreads();
-    {
-        int q = 0;
-        for (; q + DEPTH - 1 < nchunks; q += DEPTH) {
-#pragma unroll
-            for (int s = 0; s < DEPTH; ++s) {
-                step(s & 1, rsa[s], rsb[s]);
-                __syncthreads();
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < DEPTH - 1; ++s)
-            if (q + s < nchunks) {
-                step(s & 1, rsa[s], rsb[s]);
-                __syncthreads();
-            }
-    }
-
-    // ---- epilogue: lane holds column n = wn0 + 32 j + lr, rows (r & 3) + 8 (r >> 2) + 4 lh of each 32x32 tile ---------------
-    float *X2 = reinterpret_cast<float *>(smem);                   // [BM][XP]
-    float *Gs = X2 + BM * XP;                                      // [BN][GP]
+    // ---- scales of the epilogue, computed HERE: their slot / bias / beta loads and block reductions run while the first chunks
+    // are in flight instead of after the last MFMA (one workgroup per CU: nothing else would hide them there)
     __shared__ float qred[16];
     const float fac = q_inv(a.xq) * q_inv(a.wq);                   // the operands were stored times 2^ex, 2^ew
     float oscale = 1.f;                                            // 2^e of the planes output
@@ -254,6 +235,27 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
         oscale = q_pow2(oe);
         if (blockIdx.x == 0 && tid == 0) a.yq[1] = q_pow2(-oe);
     }
+    __syncthreads();
+    {
+        int q = 0;
+        for (; q + DEPTH - 1 < nchunks; q += DEPTH) {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) {
+                step(s & 1, rsa[s], rsb[s]);
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < DEPTH - 1; ++s)
+            if (q + s < nchunks) {
+                step(s & 1, rsa[s], rsb[s]);
+                __syncthreads();
+            }
+    }
+
+    // ---- epilogue: lane holds column n = wn0 + 32 j + lr, rows (r & 3) + 8 (r >> 2) + 4 lh of each 32x32 tile ---------------
+    float *X2 = reinterpret_cast<float *>(smem);                   // [BM][XP]
+    float *Gs = X2 + BM * XP;                                      // [BN][GP]
     float omax = 0.f;                                              // max |output| of this thread
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -554,6 +556,21 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
         gload(t, kc, q, raB, rbB);
         pf_q = chunk_of(q_begin + 3, pf_t, pf_kc);
     }
+    // scales of the epilogue, computed while the first chunks are in flight (see conv_f16x3_kernel; every split of a tile
+    // computes the same values, the last arriver uses them)
+    __shared__ float qred[16];
+    const float fac = q_inv(a.xq) * q_inv(a.wq);                   // the operands were stored times 2^ex, 2^ew
+    float oscale = 1.f;
+    if (a.yp) {     // scale of the planes output from an upper bound of |output| (see conv_f16x3_kernel)
+        const float xmax = q_amax(a.xq, qred), wmax = q_amax(a.wq, qred);
+        float bm = 0.f;
+        if (a.bias)
+            for (int n = tid; n < a.N; n += GNT) bm = fmaxf(bm, fabsf(a.bias[n]));
+        bm = block_max(bm, qred);
+        const int oe = q_exp((float)(a.C * a.ntaps) * xmax * wmax + bm);
+        oscale = q_pow2(oe);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.yq[1] = q_pow2(-oe);
+    }
     __syncthreads();
     if (!dead) {
         int q = q_begin;
@@ -636,19 +653,6 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
             for (int r = 0; r < 16; ++r) T[(wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * GTP + wn0 + j * 32 + lr] = acc[j][r];
     }
     __syncthreads();
-    __shared__ float qred[16];
-    const float fac = q_inv(a.xq) * q_inv(a.wq);                   // the operands were stored times 2^ex, 2^ew
-    float oscale = 1.f;
-    if (a.yp) {     // scale of the planes output from an upper bound of |output| (see conv_f16x3_kernel)
-        const float xmax = q_amax(a.xq, qred), wmax = q_amax(a.wq, qred);
-        float bm = 0.f;
-        if (a.bias)
-            for (int n = tid; n < a.N; n += GNT) bm = fmaxf(bm, fabsf(a.bias[n]));
-        bm = block_max(bm, qred);
-        const int oe = q_exp((float)(a.C * a.ntaps) * xmax * wmax + bm);
-        oscale = q_pow2(oe);
-        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.yq[1] = q_pow2(-oe);
-    }
     float omax = 0.f;
     // ---- bias / activation, fp32 rows (16 bytes per thread), activated values back into T for the planes pass -----------------
     for (int e = tid; e < GBM * (GBN / 4); e += GNT) {
