@@ -545,17 +545,17 @@ def main():
                   "useful_tflops_isolated": flop0 / (kern0_ms * 1e-3) / 1e12, "traffic": tj.get("g_a0_c4gdn_bytes_per_launch")}
     if f16_chain:
         # Dominant kernel: g_a.2 + GDN on the fp16 matrix cores.  Every fp32 product is THREE fp16 MFMA products (conv_f16x3.hip), so
-        # the matrix pipe executes 3x the convolution's algorithmic flop; `achieved` / `frac` are that executed fp16 rate against
+        # the matrix pipe executes 3x the algorithmic flop (convolution and GDN contraction); `achieved` / `frac` are that executed fp16 rate against
         # the dense fp16 peak (never mixed into an fp32 fraction), taken on the launches INSIDE the timed region (the
         # headline is the in-region figure); the same launches alone on the chip are under "isolated", the algorithmic
         # (fp32-equivalent, "useful") rate next to both.
-        executed = F16_PRODUCTS * GA2_CONV_FLOP_PER_FRAME * BATCH
+        executed = F16_PRODUCTS * GA2_FLOP_PER_FRAME * BATCH        # convolution and the fused GDN contraction, both on the fp16 instruction
         in_ms = kern_ms_overlap if prefetch is not None else kern_ms
         roof = {"bound": "mfma", "kernel": "conv_f16x3_kernel<128> = g_a.2 conv (192->192, 5x5 s2, 128^2->64^2, B=16) + fused GDN g_a.3: operands "
                                            "pre-split into 2 scaled fp16 planes, 3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate",
                 "achieved": executed / (in_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": executed / (in_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
-                "flop_per_launch": executed, "flop_definition": "executed fp16 MFMA flop = 3 x algorithmic conv flop (the fused GDN's 4.8 GF of fp32 MFMA not counted)",
+                "flop_per_launch": executed, "flop_definition": "executed fp16 MFMA flop = 3 x algorithmic flop of the convolution and of the fused GDN contraction",
                 "avg_launch_ms": in_ms, "launches_timed": n_overlap if prefetch is not None else len(probe),
                 "isolated": {"achieved": executed / (kern_ms * 1e-3) / 1e12, "frac": executed / (kern_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
                              "avg_launch_ms": kern_ms, "launches_timed": len(probe)},

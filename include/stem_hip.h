@@ -395,10 +395,14 @@ int stem_f16x2_split_dact_nhwc(const float *x, int ldx, const float *z, int ldz,
                                 long npix, int C, void *stream);
 /* w: the torch Conv2d weight [N][C][R][S] (NOT one of the stem_pack_* layouts); N <= 192, R*S <= 25 */
 int stem_f16x2_pack_conv_weight(const float *w, void *wp, int N, int C, int R, int S, void *stream);
-/* y = conv(x) + bias, followed by GDN when beta/gamma are given (gdn.py:52-67; stored parameters, reparametrised on the fly).
+/* y = conv(x) + bias, followed by GDN when beta / gp are given (gdn.py:52-67).  beta: the STORED parameter (reparametrised on
+ * the fly); gp: gamma' = max(gamma, 2^-18)^2 - 2^-36 (parametrizers.py:42-45) as the packed image of a 1x1 convolution weight
+ * [N][ceil32(N)] (zero-padded columns), i.e. stem_f16x2_pack_conv_weight(gamma', gp, N, ceil32(N), 1, 1): the GDN's
+ * contraction over the squared outputs runs on the same fp16 instruction as the convolution, with the squares scaled by
+ * the workgroup tile's own maximum.  Repack when gamma changes.
  * Output as fp32 NHWC (y, ldy) and / or as planes (yp, with its record yq); either may be null.  yq without yp: only the
  * measured maximum of y is recorded (for a later stem_f16x2_split_nhwc(..., src_q = yq)). */
-int stem_conv2d_f16x3_fwd(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const float *gamma,
+int stem_conv2d_f16x3_fwd(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const void *gp,
                            float beta_min, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R, int S,
                            int stride, int pad, void *stream);
 /* the same kernel for the conv + LeakyReLU / ReLU pairs of the layer-wise models at large pixel counts (stem_roi.py:520-608,

@@ -38,9 +38,11 @@ typedef hp8 h16x8;
 constexpr int BN = 192, KC = 32;
 constexpr int NPL = 2, SLAB = NPL * 64;                            // planes per value; bytes per pixel and 32-channel slab
 constexpr int B_PLANE = BN * 64, B_BUF = NPL * B_PLANE;            // bytes of one plane of a weight chunk; 24576 per chunk
-constexpr int XP = BN + 4, GP = 36;                                // fp32 pitches of the parked tile / the gamma chunk
-// LDS of a BM-pixel tile: main loop 2 x (3 planes x (BM + BN) rows x 64 B), epilogue BM x XP + BN x GP floats, then the tap table
-constexpr int lds_taps(int bm) { return 2 * NPL * (bm + BN) * 64 > (bm * XP + BN * GP) * 4 ? 2 * NPL * (bm + BN) * 64 : (bm * XP + BN * GP) * 4; }
+constexpr int XP = BN + 4;                                         // fp32 pitch of the tile parked for the planes pass
+// LDS of a BM-pixel tile: the largest of the main loop (2 x NPL planes x (BM + BN) rows x 64 B), the fused GDN (the squares of six
+// 32-channel slabs as A-operand images + one chunk of gamma') and the planes pass (BM x XP floats); then the tap table
+constexpr int imax(int a, int b) { return a > b ? a : b; }
+constexpr int lds_taps(int bm) { return imax(imax(2 * NPL * (bm + BN) * 64, 6 * NPL * bm * 64 + NPL * BN * 64), bm * XP * 4); }
 constexpr int lds_total(int bm) { return lds_taps(bm) + 32 * 4; }
 constexpr int MAXTAP = 25;
 constexpr int OOR = 0x7FFFFF00;                                    // voffset that every buffer view rejects (returns 0)
@@ -49,12 +51,14 @@ struct Fx3Args {
     const void *xp, *wp;
     const float *xq, *wq;          // scale records of the two operands (stem_common.h)
     float *yq;                     // ... of the output: slots always, the scale when planes are written (may be null without planes)
-    const float *bias, *beta, *gamma;
+    const float *bias, *beta;
+    const void *gp;                // fused GDN: gamma' as the packed weight image of a 1x1 convolution (N x ceil32(N)), its record behind it
+    const float *gq;
     float *y;
     void *yp;
     int ldy;
     int B, H, W, C, N, OH, OW, stride, ntaps;
-    int xbytes, wbytes, gmbytes;
+    int xbytes, wbytes, gbytes;
     float beta_bound;
     int fuse;                      // 0: bias only, 1: GDN
     // general variant (conv_f16x3_gen_kernel): activation epilogue, N tiles, split-K
@@ -255,7 +259,6 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
 
     // ---- epilogue: lane holds column n = wn0 + 32 j + lr, rows (r & 3) + 8 (r >> 2) + 4 lh of each 32x32 tile ---------------
     float *X2 = reinterpret_cast<float *>(smem);                   // [BM][XP]
-    float *Gs = X2 + BM * XP;                                      // [BN][GP]
     float omax = 0.f;                                              // max |output| of this thread
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -269,67 +272,78 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
         }
     }
     if (a.fuse) {
-        // norm[px][i] = beta'[i] + sum_j gamma'[i][j] v[px][j]^2 (gdn.py:52-67): second contraction, K = N, fp32 MFMA; the squared
-        // tile is parked in LDS, gamma (reparametrised on the fly, parametrizers.py:42-45) is streamed 32 columns at a time
+        // norm[px][i] = beta'[i] + sum_j gamma'[i][j] v[px][j]^2 (gdn.py:52-67): a second contraction, K = N, on the same fp16
+        // instruction.  The squares are this workgroup's own data and the contraction runs inside one pixel, so they get a
+        // scale of their own from the TILE's maximum (measured, no over-estimate): t = v 2^ev with |t| < 2^7, t^2 < 2^14, split
+        // into two fp16 planes and parked in LDS in the A-operand layout of the main loop (one [plane][BM][64 B] image per
+        // 32-channel slab); gamma' arrives pre-split as the weight image of a 1x1 convolution (stem_f16x2_pack_conv_weight of the
+        // reparametrised matrix, parametrizers.py:42-45; frozen: packed once) and is streamed through one LDS buffer.
+        float vm = 0.f;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
+            for (int r = 0; r < 16; ++r) vm = fmaxf(vm, fabsf(acc[j][r]));
+        vm = block_max(vm, qred);                          // (its barriers also retire the main loop's last LDS reads)
+        const int ev = q_exp(vm) - 8;
+        const float vs = q_pow2(ev), vsi = q_pow2(-ev);
+        const int nkg = (a.N + KC - 1) / KC;
+        unsigned char *Sq = smem;                          // [6][NPL][BM][64 B]
+        unsigned char *Bg = smem + 6 * NPL * A_PLANE;      // [NPL][BN][64 B]: one chunk of gamma'
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int slab = (wn0 >> 5) + j;
+            if (slab >= nkg) continue;
+#pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = acc[j][r];
-                X2[(wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * XP + wn0 + j * 32 + lr] = v * v;
+                const int m = wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float t = acc[j][r] * vs;
+                hp_t h0, h1;
+                q_split(t * t, 1.f, h0, h1);
+                unsigned char *d = Sq + slab * (NPL * A_PLANE) + m * 64 + ((((lr >> 3) ^ ((m >> 2) & 3)) << 4) | ((lr & 7) << 1));
+                *reinterpret_cast<hp_t *>(d) = h0;
+                *reinterpret_cast<hp_t *>(d + A_PLANE) = h1;
             }
+        }
         f32x16 nrm[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) nrm[j][r] = 0.f;
-        const __amdgpu_buffer_rsrc_t rgm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.gamma), 0, a.gmbytes, 0x00020000);
-        constexpr int GR = NT / 8, GJ = BN / GR;                   // gamma rows per pass (8 float4 per 32-float row), passes
-        const int grow = tid >> 3, gc4 = tid & 7;
-        const int nkg = (a.N + KC - 1) / KC;
-        auto gload_gamma = [&](int kc, f32x4 (&g4)[GJ]) {
-            const int kcol = kc * KC + 4 * gc4;
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.gp), 0, a.gbytes, 0x00020000);
+        f32x4 gb[BP];
+        auto gload_g = [&](int kc) {
 #pragma unroll
-            for (int j = 0; j < GJ; ++j) {
-                const int n = grow + GR * j;
-                const int mk = -(int)(n < a.N && kcol < a.N);
-                const int off = (((n * a.N + kcol) * 4) & mk) | (OOR & ~mk);
-                g4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgm, off, 0, 0));
-            }
+            for (int u = 0; u < WFULL; ++u) gb[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, wv0 + u * (NT * 16), kc * B_BUF, 0));
+            if (BP > WFULL) gb[BP - 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, wvl, kc * B_BUF, 0));
         };
-        f32x4 g4[GJ], g4n[GJ];
-        gload_gamma(0, g4);
+        gload_g(0);
         for (int kc = 0; kc < nkg; ++kc) {
+            __syncthreads();                               // squares written (kc = 0) / previous chunk's fragments read
+#pragma unroll
+            for (int u = 0; u < WFULL; ++u) *reinterpret_cast<f32x4 *>(Bg + u * (NT * 16) + tid * 16) = gb[u];
+            if (BP > WFULL && WFULL * NT + tid < WPIECES) *reinterpret_cast<f32x4 *>(Bg + (WFULL * NT + tid) * 16) = gb[BP - 1];
             __syncthreads();
+            if (kc + 1 < nkg) gload_g(kc + 1);
+            const unsigned char *Ab = Sq + kc * (NPL * A_PLANE) + rdA, *Bb = Bg + rdB;
 #pragma unroll
-            for (int j = 0; j < GJ; ++j) {
-                f32x4 v = g4[j];
-                const float bound = 3.814697265625e-06f, ped = 1.4551915228366852e-11f;      // 2^-18, 2^-36
+            for (int ks = 0; ks < 2; ++ks) {
+                const int pk = ks ? pk1 : pk0;
+                h16x8 af[NPL], bf[NPL][3];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float g = fmaxf(v[e], bound);
-                    v[e] = g * g - ped;
+                for (int pl = 0; pl < NPL; ++pl) af[pl] = *reinterpret_cast<const h16x8 *>(Ab + pl * A_PLANE + pk);
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) bf[pl][j] = *reinterpret_cast<const h16x8 *>(Bb + pl * B_PLANE + j * 32 * 64 + pk);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    nrm[j] = STEM_MFMA16(af[1], bf[0][j], nrm[j]);
+                    nrm[j] = STEM_MFMA16(af[0], bf[1][j], nrm[j]);
+                    nrm[j] = STEM_MFMA16(af[0], bf[0][j], nrm[j]);
                 }
-                *reinterpret_cast<f32x4 *>(&Gs[(grow + GR * j) * GP + 4 * gc4]) = v;
             }
-            __syncthreads();
-            gload_gamma(kc + 1 < nkg ? kc + 1 : kc, g4n);
-            const float *Ab = X2 + (wm0 + lr) * XP + kc * KC + 4 * lh;
-            const float *Bb = Gs + (wn0 + lr) * GP + 4 * lh;
-#pragma unroll
-            for (int k8 = 0; k8 < KC / 8; ++k8) {
-                const f32x4 af = *reinterpret_cast<const f32x4 *>(Ab + k8 * 8);
-                f32x4 bf[3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j) bf[j] = *reinterpret_cast<const f32x4 *>(Bb + j * 32 * GP + k8 * 8);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) nrm[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[j][s], nrm[j], 0, 0, 0);
-            }
-#pragma unroll
-            for (int j = 0; j < GJ; ++j) g4[j] = g4n[j];
         }
+        const float gfac = q_inv(a.gq);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int n = wn0 + j * 32 + lr;
@@ -339,8 +353,9 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
                 bt = bb * bb - 1.4551915228366852e-11f;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] *= __builtin_amdgcn_rsqf(nrm[j][r] + bt);
+            for (int r = 0; r < 16; ++r) acc[j][r] *= __builtin_amdgcn_rsqf(nrm[j][r] * gfac * vsi * vsi + bt);
         }
+        __syncthreads();                                   // the parked squares are free (the planes pass reuses the front of LDS)
     }
     if (a.yq) {
 #pragma unroll
@@ -1086,15 +1101,15 @@ STEM_EXPORT int stem_f16x2_pack_conv_weight_flip(const float *w, void *wp, int N
     return pack_conv_weight(w, wp, N, C, R, S, 1, stream, "stem_f16x2_pack_conv_weight_flip");
 }
 
-static int conv2d_f16x3_launch(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const float *gamma,
+static int conv2d_f16x3_launch(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const void *gp,
                                 float beta_min, int act, float slope, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N,
                                 int R, int S, int stride, int pad, void *stream);
 
-STEM_EXPORT int stem_conv2d_f16x3_fwd(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const float *gamma,
+STEM_EXPORT int stem_conv2d_f16x3_fwd(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const void *gp,
                                        float beta_min, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R, int S,
                                        int stride, int pad, void *stream)
 {
-    return conv2d_f16x3_launch(xp, xq, wp, bias, beta, gamma, beta_min, 0, 0.f, y, ldy, yp, yq, B, H, W, C, N, R, S, stride, pad, stream);
+    return conv2d_f16x3_launch(xp, xq, wp, bias, beta, gp, beta_min, 0, 0.f, y, ldy, yp, yq, B, H, W, C, N, R, S, stride, pad, stream);
 }
 
 STEM_EXPORT int stem_conv2d_f16x3_fwd_act(const void *xp, const float *xq, const void *wp, const float *bias, int act, float slope, float *y, int ldy,
@@ -1105,7 +1120,7 @@ STEM_EXPORT int stem_conv2d_f16x3_fwd_act(const void *xp, const float *xq, const
     return conv2d_f16x3_launch(xp, xq, wp, bias, nullptr, nullptr, 1e-6f, act, slope, y, ldy, yp, yq, B, H, W, C, N, R, S, stride, pad, stream);
 }
 
-static int conv2d_f16x3_launch(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const float *gamma,
+static int conv2d_f16x3_launch(const void *xp, const float *xq, const void *wp, const float *bias, const float *beta, const void *gp,
                                 float beta_min, int act, float slope, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N,
                                 int R, int S, int stride, int pad, void *stream)
 {
@@ -1114,7 +1129,7 @@ static int conv2d_f16x3_launch(const void *xp, const float *xq, const void *wp, 
                    stride >= 1 && pad >= 0, "stem_conv2d_f16x3_fwd: C %% 32 == 0, N <= %d, R*S <= %d (C=%d N=%d R=%d S=%d)", BN, MAXTAP, C, N, R, S);
     STEM_CHECK_ARG(!yp || N % 32 == 0, "stem_conv2d_f16x3_fwd: planes output needs N %% 32 == 0 (N=%d)", N);
     STEM_CHECK_ARG(!y || ldy >= N, "stem_conv2d_f16x3_fwd: ldy < N");
-    STEM_CHECK_ARG((beta == nullptr) == (gamma == nullptr), "stem_conv2d_f16x3_fwd: beta and gamma come together");
+    STEM_CHECK_ARG((beta == nullptr) == (gp == nullptr), "stem_conv2d_f16x3_fwd: beta and the packed gamma come together");
     const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
     STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_f16x3_fwd: empty output");
     const size_t xb = planes_payload((long)B * H * W, C), wb = w_image_bytes(C, R, S);
@@ -1122,11 +1137,16 @@ static int conv2d_f16x3_launch(const void *xp, const float *xq, const void *wp, 
                    "stem_conv2d_f16x3_fwd: operand views must stay below 2 GiB (split the batch)");
     Fx3Args a;
     memset(&a, 0, sizeof(a));
-    a.xp = xp; a.wp = wp; a.bias = bias; a.beta = beta; a.gamma = gamma; a.y = y; a.yp = yp; a.ldy = ldy;
+    a.xp = xp; a.wp = wp; a.bias = bias; a.beta = beta; a.gp = gp; a.y = y; a.yp = yp; a.ldy = ldy;
+    if (gp) {       // gamma' = the packed image of an [N][ceil32(N)] 1x1 weight, its scale record behind it
+        const int cpad = cdiv(N, 32) * 32;
+        a.gbytes = (int)w_image_bytes(cpad, 1, 1);
+        a.gq = reinterpret_cast<const float *>(static_cast<const unsigned char *>(gp) + a.gbytes);
+    }
     a.xq = xq; a.yq = yq; a.wq = reinterpret_cast<const float *>(static_cast<const unsigned char *>(wp) + wb);
     a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.OH = OH; a.OW = OW; a.stride = stride; a.ntaps = R * S;
-    a.xbytes = (int)xb; a.wbytes = (int)wb; a.gmbytes = N * N * 4;
-    a.fuse = gamma ? 1 : 0;
+    a.xbytes = (int)xb; a.wbytes = (int)wb;
+    a.fuse = gp ? 1 : 0;
     a.epi = act; a.slope = slope;
     a.beta_bound = (float)sqrt((double)beta_min + 1.4551915228366852e-11);
     for (int r = 0; r < R; ++r)

@@ -551,7 +551,20 @@ def conv2d_f16x3_act(xp: F16Planes, wp, bias, K, R, S, stride, pad, act=False, s
     return y, yp
 
 
-def conv2d_f16x3_fwd(xp: F16Planes, wp, bias, K, R, S, stride, pad, beta=None, gamma=None, beta_min=1e-6, planes_out=False):
+def pack_gdn_gamma_f16x2(gamma: torch.Tensor) -> torch.Tensor:
+    """The STORED gamma [N, N] of a GDN -> what conv2d_f16x3_fwd's fused GDN streams: gamma' = max(gamma, 2^-18)^2 - 2^-36
+    (parametrizers.py:42-45) packed as the weight image of a 1x1 convolution [N][ceil32(N)].  A handful of small launches:
+    callers on a hot path keep the result while gamma does not change (layers._PackCache, role PACK_GDN_GAMMA)."""
+    N = gamma.shape[0]
+    g = torch.clamp(gamma.detach(), min=2.0 ** -18)
+    g = g * g - 2.0 ** -36
+    cpad = (N + 31) // 32 * 32
+    if cpad != N:
+        g = torch.nn.functional.pad(g, (0, cpad - N))
+    return pack_weight_f16x2(g.reshape(N, cpad, 1, 1).contiguous())
+
+
+def conv2d_f16x3_fwd(xp: F16Planes, wp, bias, K, R, S, stride, pad, beta=None, gamma=None, beta_min=1e-6, planes_out=False, gp=None):
     """Conv2d (+ GDN when beta / gamma are given) of a planes tensor with fp32 accuracy on the fp16 matrix cores.
     Returns an NHWC fp32 tensor, or a F16Planes for the next convolution of the chain."""
     B, Cc, H, W = xp.shape
@@ -564,7 +577,9 @@ def conv2d_f16x3_fwd(xp: F16Planes, wp, bias, K, R, S, stride, pad, beta=None, g
         out = empty_nhwc(B, K, Ho, Wo, dev)
         y, ldy, yp, yq = out.data_ptr(), nhwc_ld(out), None, None
     assert xp.dense, "the analysis-transform kernel takes whole planes tensors"
-    _chk(_lib.hip().stem_conv2d_f16x3_fwd(xp.data.data_ptr(), xp.q_ptr(), wp.data_ptr(), _ptr(bias), _ptr(beta), _ptr(gamma), beta_min,
+    if gp is None and gamma is not None:      # gp: a kept pack_gdn_gamma_f16x2(gamma)
+        gp = pack_gdn_gamma_f16x2(gamma)
+    _chk(_lib.hip().stem_conv2d_f16x3_fwd(xp.data.data_ptr(), xp.q_ptr(), wp.data_ptr(), _ptr(bias), _ptr(beta), _ptr(gp), beta_min,
                                            y, ldy, yp, yq, B, H, W, Cc, K, R, S, stride, pad, _stream()))
     return out
 

@@ -40,6 +40,7 @@ PACK_F16X2_GEN = -4      # ... in the layout of the general (128-column tiles, s
 PACK_F16X2_FLIP = -7     # PACK_F16X2 of the mirrored, transposed weight (input gradient on the 192-column kernel)
 PACK_F16X2_GEN_FLIP = -6 # ... of the mirrored, transposed weight: the input-gradient of a stride-1 convolution as a convolution
 PACK_C4GDN = -5           # A-operand stream of csrc/c4gdn_f16x3.hip: first-layer weight AND the following GDN's gamma
+PACK_GDN_GAMMA = -8       # reparametrised gamma of the GDN fused into conv_f16x3_kernel, packed as a 1x1 weight image
 
 
 class _PackCache:
@@ -61,6 +62,8 @@ class _PackCache:
             wp = F.pack_weight_f16x2_gen(w)
         elif role == PACK_F16X2_GEN_FLIP:
             wp = F.pack_weight_f16x2_gen(w, flip=True)
+        elif role == PACK_GDN_GAMMA:
+            wp = F.pack_gdn_gamma_f16x2(w)
         else:
             wp = F.pack_weight(w, role, masked)
         if (masked & 3) == 2:                    # the kernel zeroed taps of w in place
@@ -652,10 +655,11 @@ class FusedSequential(nn.Sequential):
                 if _f16x3_eligible(m, x.shape) and (isinstance(x, F.F16Planes) or (chain and x.is_cuda)):
                     xin = x if isinstance(x, F.F16Planes) else F.F16Planes.split(x)
                     wp = m._packs.get(m.weight, PACK_F16X2)
+                    gp = m._packs.get(gdn.gamma, PACK_GDN_GAMMA) if gdn is not None else None     # kept in the convolution's cache
                     x = self._timed(i, lambda: F.conv2d_f16x3_fwd(xin, wp, m.bias, K, R, R, m.stride, m.padding,
                                                                    gdn.beta if gdn is not None else None,
                                                                    gdn.gamma if gdn is not None else None,
-                                                                   gdn.beta_min if gdn is not None else 1e-6, planes_out=chain))
+                                                                   gdn.beta_min if gdn is not None else 1e-6, planes_out=chain, gp=gp))
                     i = j
                     continue
                 if isinstance(x, F.F16Planes) and _f16x3_gen_eligible(m, gdn is not None):

@@ -1,6 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/f16
-P=$GRAFT_REPO_ROOT/spatiotemporalentropymodel_amd/libstem_hip_prev.so
-for i in 1 2; do for v in prev new; do echo -n "$v: "; if [ $v = prev ]; then export STEM_HIP_LIBRARY=$P; else unset STEM_HIP_LIBRARY; fi; python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d[\"ms_per_step\"],3), round(d[\"roofline\"][\"isolated\"][\"avg_launch_ms\"],4))"; done; done > gpurun_out/f16/ab.log 2>&1
-unset STEM_HIP_LIBRARY
 timeout 2800 python3 -m pytest tests -m gpu -q -x --deselect tests/test_hip_dp2.py 2>&1 | grep -v "^E    *+\|tensor(\[" | tail -8 > gpurun_out/f16/pytest.log
+P=$GRAFT_REPO_ROOT/spatiotemporalentropymodel_amd/libstem_hip_prev.so
+for i in 1 2; do echo -n "new: "; python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d[\"ms_per_step\"],3), round(d[\"roofline\"][\"isolated\"][\"avg_launch_ms\"],4), round(d[\"roofline\"][\"avg_launch_ms\"],4))"; done > gpurun_out/f16/ab.log 2>&1
