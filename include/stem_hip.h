@@ -235,7 +235,8 @@ int stem_gc_forward(const float *y, const float *noise, const float *scales, con
                     void *stream);
 int stem_gc_backward(const float *out, const float *scales, const float *means, int ldsm, const float *dlik,
                      float *dscales, float *dmeans, int lddsm, float *dy, size_t npix, int C,
-                     float scale_bound, float lik_bound, void *stream);
+                     float scale_bound, float lik_bound, float *q, void *stream);
+/* q (optional, stem_rate_partials(npix * C) + 16 floats): scale record of (dscales | dmeans), one max |value| per workgroup */
 /* sum(log2(lik)) accumulated in double: acc[0] += sum.  (EMLoss, utils.py:18-27)                   */
 int stem_log2_sum(const float *lik, size_t n, double *acc, void *stream);
 /* dlik = coef / lik  (gradient of coef*sum(log lik))                                              */
@@ -268,7 +269,9 @@ int stem_uniform_noise_epoch(float *out, size_t n, uint64_t seed, uint64_t offse
 int stem_prior_prologue(const float *y_cur, int ldc, const float *y_cond, int ldd, float *he_in, int ldh, float *target,
                         float *t_hat, float *y_hat, const float *noise, uint64_t seed, uint64_t offset,
                         const long long *epoch_dev, uint64_t epoch_stride, size_t npix, int C, int residual, int training,
-                        void *stream);
+                        float *q_in, float *q_t, void *stream);
+/* q_in / q_t (optional, stem_rate_partials(npix * C / 4) + 16 floats each): scale records of he_in (max over y_cur and y_cond)
+ * and of t_hat, for stem_f16x2_split_nhwc(..., src_q) of these tensors */
 int stem_rate_partials(size_t n);
 int stem_eb_forward_train(const float *z, int ldz, const float *pack, const float *noise, uint64_t seed, uint64_t offset,
                           const long long *epoch_dev, uint64_t epoch_stride, float *z_hat, float *lik, float *dlik,

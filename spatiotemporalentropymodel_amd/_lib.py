@@ -62,7 +62,7 @@ _HIP_SIG = {
     "stem_eb_backward": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp],
     "stem_eb_aux_loss": [vp, vp, vp, vp, vp, ci, vp],
     "stem_gc_forward": [vp, vp, vp, vp, ci, vp, vp, sz, ci, ci, cf, cf, vp],
-    "stem_gc_backward": [vp, vp, vp, ci, vp, vp, vp, ci, vp, sz, ci, cf, cf, vp],
+    "stem_gc_backward": [vp, vp, vp, ci, vp, vp, vp, ci, vp, sz, ci, cf, cf, vp, vp],
     "stem_log2_sum": [vp, sz, vp, vp],
     "stem_dlog": [vp, vp, sz, cf, vp],
     "stem_sub": [vp, vp, vp, sz, vp],
@@ -71,7 +71,7 @@ _HIP_SIG = {
     "stem_uniform_noise": [vp, sz, u64, u64, vp],
     "stem_uniform_noise_epoch": [vp, sz, u64, u64, vp, u64, vp],
     "stem_counter_add": [vp, C.c_longlong, vp],
-    "stem_prior_prologue": [vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, u64, u64, vp, u64, sz, ci, ci, ci, vp],
+    "stem_prior_prologue": [vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, u64, u64, vp, u64, sz, ci, ci, ci, vp, vp, vp],
     "stem_rate_partials": [sz],
     "stem_eb_forward_train": [vp, ci, vp, vp, u64, u64, vp, u64, vp, vp, vp, vp, sz, ci, cf, cf, vp],
     "stem_gc_forward_train": [vp, vp, vp, ci, vp, u64, u64, vp, u64, vp, vp, vp, vp, sz, ci, cf, cf, cf, vp],

@@ -286,10 +286,12 @@ __global__ __launch_bounds__(256) void gc_forward_kernel(const float *y, const f
 
 __global__ __launch_bounds__(256) void gc_backward_kernel(const float *out, const float *scales, const float *means, int ldsm,
                                                           const float *dlik, float *dsc, float *dmu, int ldd, float *dy,
-                                                          size_t npix, int C, float sb, float lb)
+                                                          size_t npix, int C, float sb, float lb, float *q)
 {
+    // q (optional): scale record of (dscales | dmeans): max |value| per workgroup, for the fp16 split of the EPM's output gradient
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npix * C) return;
+    float m = 0.f;
+    if (i < npix * C) {
     const size_t pix = i / C;
     const int c = (int)(i - pix * C);
     const float mu = means[pix * ldsm + c], sc = scales[pix * ldsm + c];
@@ -308,6 +310,9 @@ __global__ __launch_bounds__(256) void gc_backward_kernel(const float *out, cons
     if (dsc) dsc[pix * ldd + c] = ds;
     if (dmu) dmu[pix * ldd + c] = -dv * sgn;
     if (dy) dy[i] = dv * sgn;
+    m = fmaxf(fabsf(ds), fabsf(dv));
+    }
+    if (q) record_block_max(q, m);
 }
 
 __global__ __launch_bounds__(256) void log2_sum_kernel(const float *lik, size_t n, double *acc)
@@ -459,11 +464,11 @@ STEM_EXPORT int stem_gc_forward(const float *y, const float *noise, const float 
 
 STEM_EXPORT int stem_gc_backward(const float *out, const float *scales, const float *means, int ldsm, const float *dlik,
                                  float *dscales, float *dmeans, int lddsm, float *dy, size_t npix, int C,
-                                 float scale_bound, float lik_bound, void *stream)
+                                 float scale_bound, float lik_bound, float *q, void *stream)
 {
     STEM_CHECK_ARG(out && scales && means && dlik, "stem_gc_backward: null pointer");
     hipLaunchKernelGGL(gc_backward_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, out, scales, means, ldsm,
-                       dlik, dscales, dmeans, lddsm, dy, npix, C, scale_bound, lik_bound);
+                       dlik, dscales, dmeans, lddsm, dy, npix, C, scale_bound, lik_bound, q);
     STEM_LAUNCH_CHECK("gc_backward");
     return 0;
 }
@@ -582,19 +587,35 @@ __device__ __forceinline__ uint64_t noise_base(const NoiseSrc &s) { return s.off
 
 // he_in = [y_cur | y_cond]; target = y_cur - y_cond (residual) or y_cur; t_hat = target + U(-1/2,1/2) (training) or
 // round(target); y_hat = t_hat + y_cond (residual) or t_hat.     spatiotemporalpriors.py:846-856,863
+// q_in / q_t (optional): scale records (stem_common.h) of he_in (= of y_cur and y_cond) and of t_hat: one slot of max |value| per
+// workgroup, so that the fp16 splits of these tensors need no maximum pass of their own
+__device__ inline float max4(const f32x4 v) { return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))); }
+__device__ inline void prior_prologue_body(const float *ycur, int ldc, const float *ycond, int ldd, float *he_in, int ldh, float *target,
+                                           float *t_hat, float *y_hat, const NoiseSrc &nq, size_t i4, int C, int residual, int training,
+                                           float &m_in, float &m_t);
 __global__ __launch_bounds__(256) void prior_prologue_kernel(const float *ycur, int ldc, const float *ycond, int ldd, float *he_in,
                                                              int ldh, float *target, float *t_hat, float *y_hat, NoiseSrc nq,
-                                                             size_t npix, int C, int residual, int training)
+                                                             size_t npix, int C, int residual, int training, float *q_in, float *q_t)
 {
     const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float m_in = 0.f, m_t = 0.f;
+    if (i4 < npix * (C >> 2))
+        prior_prologue_body(ycur, ldc, ycond, ldd, he_in, ldh, target, t_hat, y_hat, nq, i4, C, residual, training, m_in, m_t);
+    if (q_in) record_block_max(q_in, m_in);
+    if (q_t) record_block_max(q_t, m_t);
+}
+__device__ inline void prior_prologue_body(const float *ycur, int ldc, const float *ycond, int ldd, float *he_in, int ldh, float *target,
+                                           float *t_hat, float *y_hat, const NoiseSrc &nq, size_t i4, int C, int residual, int training,
+                                           float &m_in, float &m_t)
+{
     const int c4n = C >> 2;
-    if (i4 >= npix * c4n) return;
     const size_t pix = i4 / c4n;
     const int c = (int)(i4 - pix * c4n) * 4;
     const f32x4 yc = *reinterpret_cast<const f32x4 *>(ycur + pix * ldc + c);
     const f32x4 yd = *reinterpret_cast<const f32x4 *>(ycond + pix * ldd + c);
     *reinterpret_cast<f32x4 *>(he_in + pix * ldh + c) = yc;
     *reinterpret_cast<f32x4 *>(he_in + pix * ldh + C + c) = yd;
+    m_in = fmaxf(max4(yc), max4(yd));
     f32x4 tg = residual ? yc - yd : yc;
     *reinterpret_cast<f32x4 *>(target + pix * C + c) = tg;
     if (!t_hat) return;
@@ -614,6 +635,7 @@ __global__ __launch_bounds__(256) void prior_prologue_kernel(const float *ycur, 
         for (int e = 0; e < 4; ++e) th[e] = rintf(tg[e]);
     }
     *reinterpret_cast<f32x4 *>(t_hat + pix * C + c) = th;
+    m_t = max4(th);
     if (y_hat) *reinterpret_cast<f32x4 *>(y_hat + pix * C + c) = residual ? th + yd : th;
 }
 
@@ -759,7 +781,7 @@ NoiseSrc make_noise(const float *ptr, uint64_t seed, uint64_t offset, const long
 STEM_EXPORT int stem_prior_prologue(const float *y_cur, int ldc, const float *y_cond, int ldd, float *he_in, int ldh, float *target,
                                     float *t_hat, float *y_hat, const float *noise, uint64_t seed, uint64_t offset,
                                     const long long *epoch_dev, uint64_t epoch_stride, size_t npix, int C, int residual,
-                                    int training, void *stream)
+                                    int training, float *q_in, float *q_t, void *stream)
 {
     STEM_CHECK_ARG(y_cur && y_cond && he_in && target, "stem_prior_prologue: null pointer");
     STEM_CHECK_ARG(C % 4 == 0 && ldc % 4 == 0 && ldd % 4 == 0 && ldh % 4 == 0 && ldh >= 2 * C,
@@ -769,7 +791,7 @@ STEM_EXPORT int stem_prior_prologue(const float *y_cur, int ldc, const float *y_
     if (npix == 0) return 0;
     hipLaunchKernelGGL(prior_prologue_kernel, dim3(nblk(npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, y_cur, ldc, y_cond, ldd,
                        he_in, ldh, target, t_hat, y_hat, make_noise(noise, seed, offset, epoch_dev, epoch_stride), npix, C, residual,
-                       training);
+                       training, q_in, t_hat ? q_t : nullptr);
     STEM_LAUNCH_CHECK("prior_prologue");
     return 0;
 }

@@ -108,10 +108,24 @@ __device__ inline float block_max(float v, float *red)
 // max over the slots of a record (every thread gets it)
 __device__ inline float q_amax(const float *q, float *red)
 {
-    const int ns = q_nslots(q);
+    int ns = q_nslots(q);
+    ns = ns < 0 ? 0 : (ns > (1 << 20) ? (1 << 20) : ns);      // a record nobody wrote must not turn into an unbounded read
     float m = 0.f;
     for (int i = threadIdx.x; i < ns; i += blockDim.x) m = fmaxf(m, q[QREC_HDR + i]);
     return block_max(m, red);
+}
+// a producer of an fp32 tensor records its workgroup's max |value| (every thread of the workgroup calls this; 256-thread 1-D grids)
+__device__ inline void record_block_max(float *q, float m)
+{
+    __shared__ float qred_rec[16];
+    m = block_max(m, qred_rec);
+    if (threadIdx.x == 0) {
+        q[QREC_HDR + blockIdx.x] = m;
+        if (blockIdx.x == 0) {
+            q_header(q, gridDim.x);
+            q[1] = 1.f;
+        }
+    }
 }
 // the two fp16 numbers whose sum is x * s (s a power of two)
 __device__ inline void q_split(const float x, const float s, hp_t &h0, hp_t &h1)

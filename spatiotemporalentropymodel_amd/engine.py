@@ -222,6 +222,11 @@ class _Layer:
                                (F.UNPACK_DECONV if self.kind == "deconv" else 0) | F.UNPACK_ACCUMULATE)
 
 
+def _qp(rec):
+    """address of a scale record tensor, or None"""
+    return None if rec is None else rec.data_ptr()
+
+
 def _grad_of(p):
     if p.grad is None:
         owner = getattr(p, "_flat_grad_view", None)
@@ -291,6 +296,9 @@ class StemEngine:
     #: forward and input-gradient of the stride-1 layers (TPM, HE.0, HD.4, EPM) on the fp16 matrix cores with fp32-exact products
     #: (three fp16 MFMAs per fp32 product, csrc/conv_f16x3.hip); STEM_ENGINE_F16X3=0 keeps every layer on the fp32-MFMA kernels
     use_fx3 = os.environ.get("STEM_ENGINE_F16X3", "1") != "0"
+    #: the entropy glue (prologue, Gaussian backward) records the maxima of the fp32 tensors it writes, so that their fp16 splits
+    #: skip the maximum pass (four launches per P-frame step); STEM_ENGINE_RECORDS=0: every split measures its input itself
+    use_records = os.environ.get("STEM_ENGINE_RECORDS", "1") != "0"
     #: the strided-convolution faces of the hyper path's stride-2 layers (HE.2 / HE.4 forward, HD.2 / HD.0 input gradient) on the
     #: general fp16 kernel; STEM_ENGINE_STRIDED_F16X3=0: igemm.hip
     use_fx3s = os.environ.get("STEM_ENGINE_STRIDED_F16X3", "1") != "0"
@@ -437,10 +445,12 @@ class StemEngine:
         assert not fused or training, "the fused glue is the TRAINING forward"
         k = {}
         target = t_hat = y_hat = None
+        rec = self._rec = {}    # scale records left by the producers of fp32 tensors that are split for the fp16 kernels below
         if fused:
-            # one kernel: he_in = [y_cur | y_cond], target, t_hat = target + noise, y_hat = t_hat (+ y_cond)
+            # one kernel: he_in = [y_cur | y_cond], target, t_hat = target + noise, y_hat = t_hat (+ y_cond); it also records
+            # max |y_cur|, |y_cond| and max |t_hat| per workgroup: the splits of he_in, y_cond and t_hat need no maximum pass
             slot = gc._noise_slot(yc) if self.has_spm else {}
-            he_in, target, t_hat, y_hat = F.prior_prologue(yc, yd, self.residual, True, self.has_spm, **slot)
+            he_in, target, t_hat, y_hat = F.prior_prologue(yc, yd, self.residual, True, self.has_spm, records=rec if self.use_fx3 and self.use_records else None, **slot)
         else:
             # hyper encoder on cat(y_cur, y_cond): the two halves are written into one buffer
             he_in = F.empty_nhwc(B, 2 * Cin, H, W, dev)
@@ -467,7 +477,7 @@ class StemEngine:
         split = F.F16Planes.split
         with (torch.cuda.stream(bs) if bs is not None else contextlib.nullcontext()):
             if self.HE[0].fx3:
-                pl["he_in"] = split(he_in)
+                pl["he_in"] = split(he_in, src_q=_qp(rec.get("in")))
                 he0, he0p = self.HE[0].fwd6(pl["he_in"], F.ACT_LRELU, planes=self.HE[1].fx3s)
             else:
                 he0 = self.HE[0].fwd(he_in, F.ACT_LRELU)
@@ -495,7 +505,7 @@ class StemEngine:
         tp0 = tp2 = None
         if self.has_tpm and self.TPM[0].fx3:
             # planes travel from layer to layer (written by the producing epilogue next to the fp32 copy backward needs)
-            pl["yd"] = split(yd)
+            pl["yd"] = split(yd, src_q=_qp(rec.get("in")))       # max(|y_cur|, |y_cond|) bounds y_cond
             tp0, pl["tp0"] = self.TPM[0].fwd6(pl["yd"], F.ACT_LRELU, planes=True)
             tp2, pl["tp2"] = self.TPM[1].fwd6(pl["tp0"], F.ACT_LRELU, planes=True)
             self.TPM[2].fwd6(pl["tp2"], out=epm_in[:, o_tp:o_tp + P])
@@ -556,13 +566,13 @@ class StemEngine:
         B, _, H, W = gp.shape
         self._wait_dgrad_packs()
         dgp = F.empty_nhwc(B, 2 * Cin, H, W, gp.device)
-        F.gc_backward(k["gc_out"], gp[:, :Cin], gp[:, Cin:], dlik_y, dgp[:, :Cin], dgp[:, Cin:], dy=None,
-                      scale_bound=gc._scale_bound, lik_bound=gc._lik_bound)
+        qg = F.gc_backward(k["gc_out"], gp[:, :Cin], gp[:, Cin:], dlik_y, dgp[:, :Cin], dgp[:, Cin:], dy=None,
+                           scale_bound=gc._scale_bound, lik_bound=gc._lik_bound, record=self.EPM[0].fx3 and self.use_records)
         # EPM (1x1 chain)
         dprip = None
         pl = k.get("planes", {})
         if self.EPM[0].fx3:
-            dgpp = F.F16Planes.split(dgp)
+            dgpp = F.F16Planes.split(dgp, src_q=_qp(qg))
             self.EPM[2].wgrad_any(k["e2"], dgp, pl.get("e2"), dgpp)
             de2, de2p = self.EPM[2].dgrad6(dgpp, xact=k["e2"], planes=True)
             self.EPM[1].wgrad_any(k["e0"], de2, pl.get("e0"), de2p)
@@ -617,7 +627,7 @@ class StemEngine:
         """context_prediction(t_hat) -> its channel slice of the EPM input (spatiotemporalpriors.py:857): on the fp16 kernel over
         the live taps of the mask (the planes of t_hat stay for the weight gradient), else on igemm.hip's masked form"""
         if self.CTX.fx3:
-            pl["t_hat"] = F.F16Planes.split(t_hat)
+            pl["t_hat"] = F.F16Planes.split(t_hat, src_q=_qp(self._rec.get("t_hat")))
             self.CTX.fwd6(pl["t_hat"], out=out)
         else:
             self.CTX.fwd(t_hat, out=out)

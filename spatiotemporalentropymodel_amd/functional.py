@@ -921,13 +921,21 @@ def gc_forward(y, scales, means, noise=None, scale_bound=0.11, lik_bound=1e-9):
     return out, lik
 
 
-def gc_backward(out, scales, means, dlik, dscales, dmeans, dy=None, scale_bound=0.11, lik_bound=1e-9):
+def qrec_for(nelem, device):
+    """an (uninitialised) scale record for an elementwise producer of `nelem` outputs, 256 per workgroup (stem_common.h)"""
+    return torch.empty(16 + (nelem + 255) // 256, device=device, dtype=torch.float32)
+
+
+def gc_backward(out, scales, means, dlik, dscales, dmeans, dy=None, scale_bound=0.11, lik_bound=1e-9, record=False):
+    """record=True: also returns the scale record of (dscales | dmeans) for F16Planes.split(..., src_q=)"""
     B, Cc, H, W = out.shape
     ldd = nhwc_ld(dscales)
     assert ldd == nhwc_ld(dmeans)
+    q = qrec_for(B * H * W * Cc, out.device) if record else None
     _chk(_lib.hip().stem_gc_backward(out.data_ptr(), scales.data_ptr(), means.data_ptr(), nhwc_ld(scales), dlik.data_ptr(),
                                      dscales.data_ptr(), dmeans.data_ptr(), ldd, _ptr(dy), B * H * W, Cc, scale_bound,
-                                     lik_bound, _stream()))
+                                     lik_bound, _ptr(q), _stream()))
+    return q
 
 
 def log2_sum(lik, acc):
@@ -1046,9 +1054,10 @@ def _noise_args(noise, seed, offset, epoch):
     return None, int(seed) & _M64, int(offset) & _M64, (None if epoch is None else epoch.data_ptr()), (0 if epoch is None else NOISE_EPOCH_STRIDE)
 
 
-def prior_prologue(yc, yd, residual, training, with_t_hat, noise=None, seed=0, offset=0, epoch=None):
+def prior_prologue(yc, yd, residual, training, with_t_hat, noise=None, seed=0, offset=0, epoch=None, records=None):
     """-> (he_in [B,2C,H,W], target, t_hat | None, y_hat | None), all NHWC.  One kernel for cat(y_cur, y_cond), the residual,
-    its noisy / rounded version and y_hat (spatiotemporalpriors.py:846-856,863)."""
+    its noisy / rounded version and y_hat (spatiotemporalpriors.py:846-856,863).  records: a dict that receives the scale
+    records "in" (max over y_cur and y_cond: serves he_in and y_cond) and "t_hat" for F16Planes.split(..., src_q=)."""
     B, Cc, H, W = yc.shape
     dev = yc.device
     he_in, target = empty_nhwc(B, 2 * Cc, H, W, dev), empty_nhwc(B, Cc, H, W, dev)
@@ -1057,9 +1066,14 @@ def prior_prologue(yc, yd, residual, training, with_t_hat, noise=None, seed=0, o
     if noise is not None:
         assert nhwc_ld(noise) == Cc
     nptr, sd, off, ep, stride = _noise_args(noise, seed, offset, epoch)
+    q_in = q_t = None
+    if records is not None:
+        q_in = records["in"] = qrec_for(B * H * W * Cc // 4, dev)
+        if with_t_hat:
+            q_t = records["t_hat"] = qrec_for(B * H * W * Cc // 4, dev)
     _chk(_lib.hip().stem_prior_prologue(yc.data_ptr(), nhwc_ld(yc), yd.data_ptr(), nhwc_ld(yd), he_in.data_ptr(), 2 * Cc, target.data_ptr(),
                                         _ptr(t_hat), _ptr(y_hat), nptr, sd, off, ep, stride, B * H * W, Cc, int(bool(residual)),
-                                        int(bool(training)), _stream()))
+                                        int(bool(training)), _ptr(q_in), _ptr(q_t), _stream()))
     return he_in, target, t_hat, y_hat
 
 

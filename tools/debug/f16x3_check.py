@@ -66,8 +66,9 @@ xp = F.F16Planes.split(x)
 wp = F.pack_weight_f16x2(w)
 wp32 = F.pack_weight(w, F.PACK_CONV_FWD)
 xn = F.to_nhwc(x)
-for name, fn in (("f16x3 conv+GDN -> planes", lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamma, planes_out=True)),
-                 ("f16x3 conv+GDN -> fp32", lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamma)),
+gp = F.pack_gdn_gamma_f16x2(gamma)          # kept while gamma does not change, as layers._PackCache does
+for name, fn in (("f16x3 conv+GDN -> planes", lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamma, planes_out=True, gp=gp)),
+                 ("f16x3 conv+GDN -> fp32", lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamma, gp=gp)),
                  ("f16x3 conv only -> fp32", lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2)),
                  ("fp32-MFMA conv+GDN", lambda: F.conv2d_gdn_fwd(xn, wp32, b, beta, gamma, K, 5, 5, 2, 2)),
                  ("split 16x128x128x192", lambda: F.F16Planes.split(x))):

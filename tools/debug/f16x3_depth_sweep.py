@@ -31,11 +31,11 @@ for name, H in (("g_a.2", 128), ("g_a.4", 64), ("g_a.6", 32)):
     w = torch.randn(K, C, 5, 5, device=dev) / (C * 25) ** 0.5
     b = torch.randn(K, device=dev) * 0.1
     beta, gamma = torch.rand(K, device=dev) + 0.5, torch.rand(K, K, device=dev) * 0.1
-    xp, wp = F.F16Planes.split(x), F.pack_weight_f16x2(w)
+    xp, wp, gp = F.F16Planes.split(x), F.pack_weight_f16x2(w), F.pack_gdn_gamma_f16x2(gamma)
     line = f"{name} ({B}x{H}x{H}):"
     for tile in (64, 128):
         for depth in (2, 4):
             with F.tuning(fx3_tile=tile, fx3_depth=depth):
-                t = timeit(lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta=beta, gamma=gamma, planes_out=True))
+                t = timeit(lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta=beta, gamma=gamma, planes_out=True, gp=gp))
             line += f"   tile {tile} depth {depth}: {t:6.1f} us"
     print(line)

@@ -15,11 +15,11 @@ x = torch.randn(B, C, H, H, device=dev)
 w = torch.randn(K, C, 5, 5, device=dev) / (C * 25) ** 0.5
 b = torch.randn(K, device=dev) * 0.1
 beta, gamma = torch.rand(K, device=dev) + 0.5, torch.rand(K, K, device=dev) * 0.1
-xp, wp = F.F16Planes.split(x), F.pack_weight_f16x2(w)
+xp, wp, gp = F.F16Planes.split(x), F.pack_weight_f16x2(w), F.pack_gdn_gamma_f16x2(gamma)
 variants = {"conv -> fp32": lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2),
             "conv -> planes": lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, planes_out=True),
-            "conv + GDN -> fp32": lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta=beta, gamma=gamma),
-            "conv + GDN -> planes": lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta=beta, gamma=gamma, planes_out=True)}
+            "conv + GDN -> fp32": lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta=beta, gamma=gamma, gp=gp),
+            "conv + GDN -> planes": lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta=beta, gamma=gamma, planes_out=True, gp=gp)}
 ev = {k: [] for k in variants}
 for it in range(12):
     for k, fn in variants.items():

@@ -25,8 +25,9 @@ xp = F.F16Planes.split(x)
 wp = F.pack_weight_f16x2(w)
 wp32 = F.pack_weight(w, F.PACK_CONV_FWD)
 xn = F.to_nhwc(x)
-fn = {"planes": lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamma, planes_out=True),
-      "fp32": lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamma),
+gp = F.pack_gdn_gamma_f16x2(gamma)
+fn = {"planes": lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamma, planes_out=True, gp=gp),
+      "fp32": lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta, gamma, gp=gp),
       "conv": lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2),
       "convplanes": lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, planes_out=True),
       "split": lambda: F.F16Planes.split(x),
