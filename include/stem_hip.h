@@ -447,6 +447,8 @@ typedef struct {
     const void *w;
     void *wp;
     int N, C, R, S, flip, taps;
+    const float *bmax;      /* optional: per-chunk maxima left by stem_adam_step_bmax for the flat buffer w lives in ... */
+    int b0, nb, rsv0, rsv1; /* ... chunks b0 .. b0 + nb - 1 cover the tensor: no maximum pass is launched when EVERY descriptor has them */
 } stem_f16x2_pack_desc;
 int stem_f16x2_pack_conv_weights_multi(const stem_f16x2_pack_desc *descs, int n, void *stream);
 size_t stem_conv2d_f16x3_gen_workspace_bytes(int B, int H, int W, int C, int N, int R, int S, int stride, int pad, int taps);
@@ -498,6 +500,11 @@ int stem_axpy(float *y, const float *x, float a, size_t n, void *stream);
 int stem_adam_step(float *p, const float *g, float *m, float *v, size_t n, const double *sumsq, float max_norm,
                    float gscale, float lr, float beta1, float beta2, float eps, int step, void *stream);
 /* stem_adam_step that also clears `g` in the same pass (explicit training schedule: the next backward accumulates into it) */
+/* stem_adam_step[_zero] over contiguous chunks of stem_adam_chunk() parameters, leaving max |p_new| per chunk in bmax
+ * (cdiv(n, chunk) floats): what stem_f16x2_pack_conv_weights_multi takes its scales from right after an optimiser step */
+size_t stem_adam_chunk(void);
+int stem_adam_step_bmax(float *p, float *g, float *m, float *v, size_t n, const double *sumsq, float max_norm, float gscale,
+                        float lr, float beta1, float beta2, float eps, int step, int zero_grad, float *bmax, void *stream);
 int stem_adam_step_zero(float *p, float *g, float *m, float *v, size_t n, const double *sumsq, float max_norm,
                         float gscale, float lr, float beta1, float beta2, float eps, int step, void *stream);
 /* The same update with the step count and learning rate in DEVICE memory, for optimiser steps captured in a hipGraph

@@ -779,11 +779,24 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
     const int RS = d.R * d.S, T = d.taps > 0 ? d.taps : RS, nslab = d.C / 32, nchunks = nslab * T, ntile = cdiv_dev(d.N, GBN);
     const float *w = static_cast<const float *>(d.w);
     unsigned char *wp = static_cast<unsigned char *>(d.wp);
-    float *wq = reinterpret_cast<float *>(wp + (size_t)ntile * nslab * RS * GB_BUF);    // the scale record sits behind the FULL image's size (amax_multi_kernel ran)
+    float *wq = reinterpret_cast<float *>(wp + (size_t)ntile * nslab * RS * GB_BUF);    // the scale record sits behind the FULL image's size
     __shared__ float qred[16];
-    const int we = q_exp(q_amax(wq, qred));
+    float wmax;
+    if (d.bmax) {       // maxima of the optimiser pass's chunks that cover this tensor (an upper bound: neighbours may share a chunk)
+        float mm = 0.f;
+        for (int i = threadIdx.x; i < d.nb; i += 256) mm = fmaxf(mm, d.bmax[d.b0 + i]);
+        wmax = block_max(mm, qred);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            q_header(wq, 1);
+            wq[QREC_HDR] = wmax;
+        }
+    } else {
+        wmax = q_amax(wq, qred);                                                       // amax_multi_kernel ran
+    }
+    const int we = q_exp(wmax);
     const float wscale = q_pow2(we);
     if (blockIdx.x == 0 && threadIdx.x == 0) wq[1] = q_pow2(-we);
+    float *wz = (d.bmax && T < RS) ? static_cast<float *>(const_cast<void *>(d.w)) : nullptr;      // masked taps zeroed here (no maximum pass did it)
     const int units = ntile * (GBN / PKR) * nslab;
     for (int u = blockIdx.x; u < units; u += gridDim.x) {
         const int slab = u % nslab, n0 = (u / nslab) * PKR;   // n runs over the padded rows of all N tiles
@@ -800,7 +813,13 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
             for (int e = threadIdx.x; e < PKR * 32 * RS; e += 256) {
                 const int r = e / (32 * RS), rem = e - r * (32 * RS), c = rem / RS, tp = rem - c * RS;
                 const int n = n0 + r;
-                tile[(r * 32 + c) * MAXTAP + tp] = n < d.N ? w[((size_t)n * d.C + slab * 32 + c) * RS + tp] : 0.f;
+                const size_t wi = ((size_t)n * d.C + slab * 32 + c) * RS + tp;
+                float wv = n < d.N ? w[wi] : 0.f;
+                if (wz && tp >= T && n < d.N) {
+                    wz[wi] = 0.f;
+                    wv = 0.f;
+                }
+                tile[(r * 32 + c) * MAXTAP + tp] = wv;
             }
         }
         __syncthreads();
@@ -1229,7 +1248,12 @@ STEM_EXPORT int stem_f16x2_pack_conv_weights_multi(const stem_f16x2_pack_desc *d
         mt.rs[i] = (short)(d.R * d.S);
         mt.taps[i] = (short)(d.taps > 0 && d.taps < d.R * d.S ? d.taps : 0);
     }
-    hipLaunchKernelGGL(amax_multi_kernel, dim3(WQ_SLOTS, n), dim3(256), 0, (hipStream_t)stream, mt);
+    bool all_bmax = true;
+    for (int i = 0; i < n; ++i) all_bmax = all_bmax && descs_host[i].bmax != nullptr && descs_host[i].nb >= 1;
+    if (!all_bmax) {
+        for (int i = 0; i < n; ++i) tab.d[i].bmax = nullptr;        // one source of the maximum per call
+        hipLaunchKernelGGL(amax_multi_kernel, dim3(WQ_SLOTS, n), dim3(256), 0, (hipStream_t)stream, mt);
+    }
     const unsigned gx = (unsigned)(maxu < 2048 ? maxu : 2048);
     hipLaunchKernelGGL(pack_weight_gen_multi_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, tab);
     STEM_LAUNCH_CHECK("stem_f16x2_pack_conv_weights_multi");

@@ -71,6 +71,40 @@ __global__ __launch_bounds__(256) void adam_kernel(float *p, float *g, float *m,
     }
 }
 
+// The same update over contiguous chunks of STEM_ADAM_CHUNK parameters per workgroup, which also leaves max |p_new| of every chunk
+// in bmax[chunk]: the fp16 weight packing that follows an optimiser step (conv_f16x3.hip) takes its power-of-two scale from the
+// maxima of the chunks a tensor touches instead of a reduction pass of its own (a chunk shared with a neighbouring tensor can
+// only raise the bound).  Same arithmetic per element as adam_kernel.
+__global__ __launch_bounds__(256) void adam_bmax_kernel(float *p, float *g, float *m, float *v, size_t n, const double *sumsq,
+                                                        float max_norm, float gscale, float step_size, float b1, float b2,
+                                                        float inv_sqrt_bc2, float eps, int zero_g, float *bmax)
+{
+    __shared__ float red[16];
+    float coef = gscale;
+    if (max_norm > 0.f && sumsq) {
+        const float total = (float)sqrt(sumsq[0]) * gscale;
+        coef *= fminf(max_norm / (total + 1e-6f), 1.0f);
+    }
+    const size_t base = (size_t)blockIdx.x * STEM_ADAM_CHUNK;
+    float mx = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < STEM_ADAM_CHUNK / 256; ++k) {
+        const size_t i = base + (size_t)k * 256 + threadIdx.x;
+        if (i >= n) break;
+        const float gi = g[i] * coef;
+        if (zero_g) g[i] = 0.f;
+        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float pn = p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+        p[i] = pn;
+        mx = fmaxf(mx, fabsf(pn));
+    }
+    mx = block_max(mx, red);
+    if (threadIdx.x == 0) bmax[blockIdx.x] = mx;
+}
+
 // One thread: ++step (device-resident), then the two scalars of this step's update exactly as stem_adam_step derives them
 // on the host: step_size = lr / (1 - b1^t), inv_sqrt_bc2 = 1 / sqrt(1 - b2^t), in double.
 __global__ void adam_prepare_kernel(long long *step, const float *lr, float b1, float b2, float *scal)
@@ -150,6 +184,21 @@ STEM_EXPORT int stem_adam_step_zero(float *p, float *g, float *m, float *v, size
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, max_norm,
                        gscale, (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, (const float *)nullptr, 1);
     STEM_LAUNCH_CHECK("adam_zero");
+    return 0;
+}
+
+STEM_EXPORT size_t stem_adam_chunk(void) { return STEM_ADAM_CHUNK; }
+
+STEM_EXPORT int stem_adam_step_bmax(float *p, float *g, float *m, float *v, size_t n, const double *sumsq, float max_norm,
+                                    float gscale, float lr, float beta1, float beta2, float eps, int step, int zero_grad, float *bmax,
+                                    void *stream)
+{
+    STEM_CHECK_ARG(p && g && m && v && bmax && step >= 1, "stem_adam_step_bmax: bad arguments");
+    if (n == 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_bmax_kernel, dim3((unsigned)cdivz(n, STEM_ADAM_CHUNK)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq,
+                       max_norm, gscale, (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, zero_grad, bmax);
+    STEM_LAUNCH_CHECK("adam_bmax");
     return 0;
 }
 

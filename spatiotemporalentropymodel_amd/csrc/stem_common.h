@@ -51,6 +51,9 @@ int stem_tuning(int id);
 #define STEM_EXPER_ENV(name) (static_cast<const char *>(nullptr))
 #endif
 
+// parameters per workgroup of the optimiser pass that leaves per-chunk maxima for the fp16 weight packing (optim.hip, conv_f16x3.hip)
+#define STEM_ADAM_CHUNK 4096
+
 // ---- the 16-bit operands of the split-operand kernels (conv_f16x3 / wgrad_f16x3 / c4gdn_f16x3) -------------------------------
 // Every fp32 value a travels as TWO fp16 numbers a0 = rn(a * 2^e), a1 = rn(a * 2^e - a0): |a * 2^e - a0 - a1| <= 2^-22 |a| 2^e
 // (two 11-bit significands), and the three products a0.b0, a0.b1, a1.b0 are exact in the MFMA's fp32 accumulator input, so

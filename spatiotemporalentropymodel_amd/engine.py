@@ -222,6 +222,18 @@ class _Layer:
                                (F.UNPACK_DECONV if self.kind == "deconv" else 0) | F.UNPACK_ACCUMULATE)
 
 
+def _attach_block_maxima(descs, maxima, flat):
+    """point every fp16 pack descriptor whose weight lies inside the flat parameter buffer at the optimiser's chunk maxima"""
+    ch = F.adam_chunk()
+    base, n = flat.data_ptr(), flat.numel()
+    for d in descs:
+        off = (d.w - base) // 4
+        numel = d.N * d.C * d.R * d.S
+        if (d.w - base) % 4 == 0 and 0 <= off and off + numel <= n:
+            d.bmax, d.b0 = maxima.data_ptr(), off // ch
+            d.nb = (off + numel - 1) // ch - d.b0 + 1
+
+
 def _qp(rec):
     """address of a scale record tensor, or None"""
     return None if rec is None else rec.data_ptr()
@@ -347,9 +359,12 @@ class StemEngine:
             st = bs[which] = F.make_stream(device, "side")
         return st
 
-    def ensure_packed(self):
+    def ensure_packed(self, block_max=None):
         """(Re)build every layer's packed weight copies with ONE kernel launch when any weight changed.  Inside
-        StemEngine.forward the check has already run for the whole schedule (`_checked`)."""
+        StemEngine.forward the check has already run for the whole schedule (`_checked`).
+        block_max = (maxima, flat): the per-chunk maxima an optimiser pass just left for the flat parameter buffer `flat`
+        (optim.step(block_max=True)); the fp16 images of weights inside that buffer take their scales from them instead of a
+        maximum launch.  Only meaningful in the call that directly follows that optimiser step."""
         if self._checked:
             return
         key = tuple((_layers.weight_epoch(l.mod.weight), l.mod.weight._version, l.mod.weight.data_ptr()) for l in self.layers)
@@ -376,6 +391,8 @@ class StemEngine:
                 if descs:
                     F.pack_weights_multi((_lib.PackDesc * len(descs))(*descs))
                 descs6 = [d for _, b in both for d in b]
+                if descs6 and block_max is not None:
+                    _attach_block_maxima(descs6, *block_max)
                 if descs6:
                     F.pack_weights_f16x2_multi((_lib.F16PackDesc * len(descs6))(*descs6))
                 if on_side:

@@ -1035,6 +1035,17 @@ def adam_step(p, g, m, v, sumsq_acc, max_norm, gscale, lr, beta1, beta2, eps, st
             max_norm, gscale, lr, beta1, beta2, eps, step, _stream()))
 
 
+def adam_step_bmax(p, g, m, v, sumsq_acc, max_norm, gscale, lr, beta1, beta2, eps, step, bmax, zero_grad=False):
+    """adam_step that also leaves max |p_new| per chunk of stem_adam_chunk() parameters in `bmax` (the fp16 weight packing that
+    follows takes its scales from them: engine.ensure_packed(block_max=...))"""
+    _chk(_lib.hip().stem_adam_step_bmax(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), _ptr(sumsq_acc),
+                                        max_norm, gscale, lr, beta1, beta2, eps, step, int(bool(zero_grad)), bmax.data_ptr(), _stream()))
+
+
+def adam_chunk():
+    return int(_lib.hip().stem_adam_chunk())
+
+
 def adam_step_dev(p, g, m, v, sumsq_acc, max_norm, gscale, lr_dev, beta1, beta2, eps, step_dev, scal_dev):
     """adam_step with the step count (int64, incremented here) and learning rate (fp32) in device memory"""
     _chk(_lib.hip().stem_adam_step_dev(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), _ptr(sumsq_acc),

@@ -103,11 +103,14 @@ class FusedClipAdam(torch.optim.Optimizer):
             d["lr"].fill_(lr)
             d["lr_host"] = lr
 
-    def step(self, closure=None, *, grad_scale: float = 1.0, norm_is_current: bool = False, zero_grad: bool = False):
+    def step(self, closure=None, *, grad_scale: float = 1.0, norm_is_current: bool = False, zero_grad: bool = False,
+             block_max: bool = False):
         """grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).  norm_is_current: the caller
         has just called grad_norm() on these very gradients (as the training loop does to report the norm), so the
         reduction is not repeated.  zero_grad: clear the flat gradient buffer in the same pass (explicit schedules that
-        accumulate into it next step; not available with device-resident state)."""
+        accumulate into it next step; not available with device-resident state).  block_max: the pass also leaves the
+        maximum |parameter| of every chunk of F.adam_chunk() parameters in `self.block_maxima` (host-resident state only):
+        valid until the parameters change again."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -128,6 +131,13 @@ class FusedClipAdam(torch.optim.Optimizer):
             F.adam_step_dev(self.flat.data, self.flat.grad, self.m, self.v, self._sumsq if use_clip else None,
                             float(self.max_norm) if use_clip else 0.0, float(grad_scale), d["lr"], g["betas"][0], g["betas"][1],
                             float(g["eps"]), d["step"], d["scal"])
+        elif block_max:
+            if getattr(self, "block_maxima", None) is None:
+                ch = F.adam_chunk()
+                self.block_maxima = torch.empty((self.flat.data.numel() + ch - 1) // ch, device=self.flat.data.device, dtype=torch.float32)
+            F.adam_step_bmax(self.flat.data, self.flat.grad, self.m, self.v, self._sumsq if use_clip else None,
+                             float(self.max_norm) if use_clip else 0.0, float(grad_scale), float(g["lr"]), g["betas"][0], g["betas"][1],
+                             float(g["eps"]), self.t, self.block_maxima, zero_grad=zero_grad)
         else:
             F.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self._sumsq if use_clip else None,
                         float(self.max_norm) if use_clip else 0.0, float(grad_scale), float(g["lr"]), g["betas"][0], g["betas"][1],

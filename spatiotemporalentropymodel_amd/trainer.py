@@ -15,6 +15,7 @@ Only `EMLoss` (rate-only, the trainSTEM criterion) has this closed form; other c
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -111,6 +112,8 @@ class FusedPFrameStep:
         #: clear the gradient buffer inside the Adam pass (saves the 72 MB memset of the next step); set False to leave the
         #: gradients in place after step() for inspection -- they are then zeroed at the start of the next step instead
         self.clear_grad_in_adam = True
+        #: the optimiser pass leaves per-chunk maxima of the updated parameters for the fp16 weight packing (no maximum launches)
+        self.adam_block_max = os.environ.get("STEM_ADAM_BLOCK_MAX", "1") != "0"
         self._aux_stream = F.make_stream(eb.quantiles.device, "side")
         self._aux_pending = False
 
@@ -138,7 +141,8 @@ class FusedPFrameStep:
             self._aux_pending = False
         F.sumsq(opt.flat.grad, opt._sumsq, overwrite=True)
         clean = opt._dev is None and self.clear_grad_in_adam
-        opt.step(grad_scale=grad_scale, norm_is_current=True, zero_grad=clean)
+        use_bmax = opt._dev is None and eng.use_fx3 and self.adam_block_max
+        opt.step(grad_scale=grad_scale, norm_is_current=True, zero_grad=clean, block_max=use_bmax)
         self._grad_clean = clean
         # auxiliary loss on the UPDATED parameters (stem/trainSTEM.py:216-218); its gradient goes straight into the aux
         # optimiser's flat buffer (the only aux parameter is `entropy_bottleneck.quantiles`).  One workgroup of latency-bound
@@ -155,7 +159,8 @@ class FusedPFrameStep:
             done = torch.cuda.Event()
             done.record(self._aux_stream)
         self._aux_pending = True
-        eng.ensure_packed()                      # the next forward's weight packing, issued now
+        # the next forward's weight packing, issued now; the fp16 images take their scales from the maxima the optimiser pass left
+        eng.ensure_packed(block_max=(opt.block_maxima, opt.flat.data) if use_bmax else None)
         loss3 = k["loss3"]
         out = {"y_hat": y_hat, "likelihoods": {"y": lik_y, "z": lik_z}}
         oc = {"y_bpp_loss": loss3[0], "z_bpp_loss": loss3[1], "loss": loss3[2]}

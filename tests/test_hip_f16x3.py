@@ -264,6 +264,58 @@ def test_power_of_two_scaling_of_the_operands_is_exact(F, kx, kw):
     assert F.F16Planes.split(dev(np.zeros_like(x))).record() == (1.0, 0.0)
 
 
+def test_weight_scales_from_the_optimiser_pass(F):
+    """stem_adam_step_bmax leaves max |p| per 4096-parameter chunk; stem_f16x2_pack_conv_weights_multi with those maxima (no maximum
+    launch) must scale every image by an upper bound of its tensor's maximum that is at most the maximum of the chunks it touches
+    (a neighbour can share a chunk), update the parameters exactly like stem_adam_step, zero the masked taps in place, and the
+    convolutions with these images must match the oracle."""
+    import ctypes as C
+    from spatiotemporalentropymodel_amd import _lib
+    ch = F.adam_chunk()
+    shapes = [(96, 64, 3, 3), (7,), (64, 64, 5, 5), (128, 96, 1, 1)]             # conv, a bias in between, masked conv, 1x1
+    sizes = [int(np.prod(sh)) for sh in shapes]
+    offs = np.concatenate([[0], np.cumsum(sizes)])[:-1]
+    n = int(sum(sizes))
+    rng = np.random.default_rng(5)
+    p0 = (rng.standard_normal(n) * np.repeat([0.05, 30.0, 0.5, 2e-4], sizes)).astype(np.float32)     # very different magnitudes side by side
+    g0 = rng.standard_normal(n).astype(np.float32)
+    pa, pb = dev(p0), dev(p0)
+    ma, va, mb, vb = (torch.zeros(n, device="cuda") for _ in range(4))
+    ga, gb = dev(g0), dev(g0)
+    bmax = torch.empty((n + ch - 1) // ch, device="cuda")
+    F.adam_step(pa, ga, ma, va, None, 0.0, 1.0, 1e-3, 0.9, 0.999, 1e-8, 1, zero_grad=True)
+    F.adam_step_bmax(pb, gb, mb, vb, None, 0.0, 1.0, 1e-3, 0.9, 0.999, 1e-8, 1, bmax, zero_grad=True)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and float(gb.abs().max()) == 0.0
+    pn = host(pb)
+    assert np.array_equal(host(bmax), np.array([np.abs(pn[i:i + ch]).max() for i in range(0, n, ch)], np.float32))
+    descs, imgs = [], []
+    for (sh, off, taps) in ((shapes[0], offs[0], 0), (shapes[2], offs[2], 12), (shapes[3], offs[3], 0)):
+        K, Cc, R, S = sh
+        img = torch.empty(F.f16x2_gen_weight_bytes(K, Cc, R, S), device="cuda", dtype=torch.uint8)
+        b0 = int(off) // ch
+        descs.append(_lib.F16PackDesc(pb.data_ptr() + 4 * int(off), img.data_ptr(), K, Cc, R, S, 0, taps, bmax.data_ptr(), b0,
+                                      (int(off) + K * Cc * R * S - 1) // ch - b0 + 1, 0, 0))
+        imgs.append(img)
+    F.pack_weights_f16x2_multi((_lib.F16PackDesc * 3)(*descs))
+    pz = host(pb)
+    mask = np.ones(25, np.float32)
+    mask[12:] = 0
+    w2 = pn[offs[2]:offs[2] + sizes[2]].reshape(64, 64, 25) * mask
+    assert np.array_equal(pz[offs[2]:offs[2] + sizes[2]].reshape(64, 64, 25), w2)          # masked taps zeroed in place, nothing else touched
+    assert np.array_equal(np.delete(pz, np.s_[offs[2]:offs[2] + sizes[2]]), np.delete(pn, np.s_[offs[2]:offs[2] + sizes[2]]))
+    for (sh, off, taps), img in zip(((shapes[0], offs[0], 0), (shapes[2], offs[2], 12), (shapes[3], offs[3], 0)), imgs):
+        K, Cc, R, S = sh
+        w = pz[off:off + K * Cc * R * S].reshape(sh)
+        nrec = (img.numel() - 320) // 4
+        rec = img.view(torch.float32)[nrec:nrec + 17].cpu()
+        inv, bound = float(rec[1]), float(rec[16])
+        lo, hi = int(off) // ch, (int(off) + w.size - 1) // ch
+        assert np.abs(pn[off:off + w.size]).max() <= bound == float(host(bmax)[lo:hi + 1].max()) and 2.0 ** 14 <= bound / inv < 2.0 ** 15
+        x = rnd((2, Cc, 9, 11), 7 + K, -1, 1)
+        y, _ = F.conv2d_f16x3_gen(F.F16Planes.split(dev(x)), img, None, K, R, S, 1, R // 2, taps=taps)
+        assert_close(host(y), orc.conv2d_fwd(x, w, np.zeros(K, np.float32), 1, R // 2), what=f"conv with the optimiser-scaled image {sh}", floor=0.1)
+
+
 @pytest.mark.parametrize("mask_type", ["A", "B"])
 @pytest.mark.parametrize("R", [3, 5])
 def test_masked_convolution_on_the_general_kernel(F, mask_type, R):
