@@ -171,6 +171,7 @@ class _Layer:
         if self.fx3 or (self.fx3s and self.kind == "conv"):          # callers outside the training schedule (codec.py) hand over fp32 tensors
             return self.fwd6(F.F16Planes.split(x), act, out=out)[0]
         m = self.mod
+        self.eng._wait_fwd32_packs()
         if self.kind == "conv":
             if self.masked and not self.masked & 4:
                 act |= F.CONV_MASKED_A            # the masked taps (type A) are zeros: skip them
@@ -268,6 +269,7 @@ class StemEngine:
         self._side = {}
         self._checked = False
         self._dgrad_pack_event = None
+        self._fwd32_pack_event = None
         # the hyper path's weight gradients (HE, HD) queue on their own stream: the 13 weight-gradient launches of a step would
         # otherwise run one after the other and finish ~0.3 ms after the last input-gradient kernel
         if self.wgrad_lanes > 1:
@@ -388,13 +390,24 @@ class StemEngine:
             with (torch.cuda.stream(side) if on_side else contextlib.nullcontext()):
                 both = [l.role_descs(r) for l in self.layers for r in range(lo, hi)]
                 descs = [d for a, _ in both for d in a]
-                if descs:
-                    F.pack_weights_multi((_lib.PackDesc * len(descs))(*descs))
                 descs6 = [d for _, b in both for d in b]
                 if descs6 and block_max is not None:
                     _attach_block_maxima(descs6, *block_max)
-                if descs6:
+                if descs6:          # first: the forward's first kernels (HE.0, TPM.0, the context model) wait for these
                     F.pack_weights_f16x2_multi((_lib.F16PackDesc * len(descs6))(*descs6))
+                # the fp32 copies of the forward role (the transposed hyper-decoder layers: consumed on the hyper branch, half a
+                # forward later) are packed on that branch's stream, off the compute stream's optimiser -> forward chain
+                bs = self._branch(dev) if (descs and side is not None and not on_side and lo == 0 and hi == 1) else None
+                if descs and bs is not None:
+                    bs.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(bs):
+                        F.pack_weights_multi((_lib.PackDesc * len(descs))(*descs))
+                        self._fwd32_pack_event = torch.cuda.Event()
+                        self._fwd32_pack_event.record(bs)
+                elif descs:
+                    F.pack_weights_multi((_lib.PackDesc * len(descs))(*descs))
+                    if not on_side:
+                        self._fwd32_pack_event = None
                 if on_side:
                     self._dgrad_pack_event = torch.cuda.Event()
                     self._dgrad_pack_event.record(side)
@@ -433,6 +446,12 @@ class StemEngine:
     def join_side_stream(self):
         for st in self._side.values():
             torch.cuda.current_stream(st.device).wait_stream(st)
+
+    def _wait_fwd32_packs(self):
+        """a consumer of a forward-role fp32 weight copy: order it after the packing on the hyper branch's stream (a no-op
+        for the hyper branch itself, which runs on that stream)"""
+        if self._fwd32_pack_event is not None:
+            torch.cuda.current_stream().wait_event(self._fwd32_pack_event)
 
     def _wait_dgrad_packs(self):
         """backward's first consumer of an input-gradient weight copy: order it after the side-stream packing"""
