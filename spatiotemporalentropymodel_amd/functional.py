@@ -211,6 +211,7 @@ def nchw3_to_nhwc4(x: torch.Tensor) -> torch.Tensor:
     assert Cc == 3
     out = torch.empty((B, H, W, 4), device=x.device, dtype=torch.float32)
     # the image's scale record (max |x| per workgroup) rides along as an attribute: the first-layer kernel scales its fp16 split by it
+    # (the returned tensor is a temporary of the analysis transform: whoever writes into it afterwards must drop `_stem_q`)
     q = torch.empty(16 + (B * H * W + 1023) // 1024, device=x.device, dtype=torch.float32)
     _chk(_lib.hip().stem_nchw3_to_nhwc4(x.data_ptr(), out.data_ptr(), B, H, W, q.data_ptr(), _stream()))
     out._stem_q = q
