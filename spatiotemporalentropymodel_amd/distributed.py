@@ -159,12 +159,13 @@ class OverlappedGradReducer:
         self._pending = []         # reported, final, not yet exchanged: merged contiguous runs [lo, hi]
         self.calls = 0             # slices reported (schedule bookkeeping)
         self.collectives = 0       # all-reduce calls issued
-        #: a run of final gradients is exchanged once it holds this many bytes (and whatever is left at finish()): every RCCL
-        #: call costs ~0.1 ms of stream time even at world size 1 (6 calls per P-frame step: +4 ms per bench step measured
-        #: with a one-rank RCCL group), so neighbouring module groups travel together -- 3 calls per step for the STEM model
-        #: (TPM + context model 32 MB while the hyper path is still in backward, then EPM + HD + HE 39 MB, then the bottleneck);
+        #: a run of final gradients is exchanged once it holds this many bytes (and whatever is left at finish()).  What is
+        #: exchanged at finish() is exposed: nothing of backward is left to hide it.  With RCCL's stream at high priority a call no
+        #: longer costs stream time of its own (one-rank RCCL group, 24 / 12 / 8 / 4 MB: 16.7-16.9 ms per bench step each; it was
+        #: +4 ms for 6 calls per P-frame step before), so the threshold only keeps tiny groups (the bottleneck's 60 KB) from
+        #: travelling alone: 8 MB leaves the last group (the hyper encoder, ~10 MB) for finish() instead of a 39 MB run.
         #: STEM_DP_MIN_BYTES=0 exchanges every group as soon as it is final
-        self.min_bytes = int(os.environ.get("STEM_DP_MIN_BYTES", str(24 << 20))) if min_bytes is None else int(min_bytes)
+        self.min_bytes = int(os.environ.get("STEM_DP_MIN_BYTES", str(8 << 20))) if min_bytes is None else int(min_bytes)
 
     @property
     def grad_scale(self):
