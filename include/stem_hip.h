@@ -501,7 +501,8 @@ int stem_adam_step(float *p, const float *g, float *m, float *v, size_t n, const
                    float gscale, float lr, float beta1, float beta2, float eps, int step, void *stream);
 /* stem_adam_step that also clears `g` in the same pass (explicit training schedule: the next backward accumulates into it) */
 /* stem_adam_step[_zero] over contiguous chunks of stem_adam_chunk() parameters, leaving max |p_new| per chunk in bmax
- * (cdiv(n, chunk) floats): what stem_f16x2_pack_conv_weights_multi takes its scales from right after an optimiser step */
+ * (4 * cdiv(n, chunk) floats: one value per wavefront of the chunk's workgroup): what stem_f16x2_pack_conv_weights_multi
+ * takes its scales from right after an optimiser step */
 size_t stem_adam_chunk(void);
 int stem_adam_step_bmax(float *p, float *g, float *m, float *v, size_t n, const double *sumsq, float max_norm, float gscale,
                         float lr, float beta1, float beta2, float eps, int step, int zero_grad, float *bmax, void *stream);

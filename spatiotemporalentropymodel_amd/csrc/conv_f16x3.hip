@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
     float wmax;
     if (d.bmax) {       // maxima of the optimiser pass's chunks that cover this tensor (an upper bound: neighbours may share a chunk)
         float mm = 0.f;
-        for (int i = threadIdx.x; i < d.nb; i += 256) mm = fmaxf(mm, d.bmax[d.b0 + i]);
+        for (int i = threadIdx.x; i < 4 * d.nb; i += 256) mm = fmaxf(mm, d.bmax[4 * d.b0 + i]);      // four wavefront maxima per chunk
         wmax = block_max(mm, qred);
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             q_header(wq, 1);

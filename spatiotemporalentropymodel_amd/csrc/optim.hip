@@ -72,14 +72,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float *p, float *g, float *m,
 }
 
 // The same update over contiguous chunks of STEM_ADAM_CHUNK parameters per workgroup, which also leaves max |p_new| of every chunk
-// in bmax[chunk]: the fp16 weight packing that follows an optimiser step (conv_f16x3.hip) takes its power-of-two scale from the
+// in bmax[4 * chunk .. 4 * chunk + 3] (one value per wavefront): the fp16 weight packing that follows an optimiser step (conv_f16x3.hip) takes its power-of-two scale from the
 // maxima of the chunks a tensor touches instead of a reduction pass of its own (a chunk shared with a neighbouring tensor can
 // only raise the bound).  Same arithmetic per element as adam_kernel.
 __global__ __launch_bounds__(256) void adam_bmax_kernel(float *p, float *g, float *m, float *v, size_t n, const double *sumsq,
                                                         float max_norm, float gscale, float step_size, float b1, float b2,
                                                         float inv_sqrt_bc2, float eps, int zero_g, float *bmax)
 {
-    __shared__ float red[16];
     float coef = gscale;
     if (max_norm > 0.f && sumsq) {
         const float total = (float)sqrt(sumsq[0]) * gscale;
@@ -87,22 +86,37 @@ __global__ __launch_bounds__(256) void adam_bmax_kernel(float *p, float *g, floa
     }
     const size_t base = (size_t)blockIdx.x * STEM_ADAM_CHUNK;
     float mx = 0.f;
-#pragma unroll 4
-    for (int k = 0; k < STEM_ADAM_CHUNK / 256; ++k) {
-        const size_t i = base + (size_t)k * 256 + threadIdx.x;
-        if (i >= n) break;
-        const float gi = g[i] * coef;
-        if (zero_g) g[i] = 0.f;
-        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
-        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
-        m[i] = mi;
-        v[i] = vi;
-        const float pn = p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
-        p[i] = pn;
-        mx = fmaxf(mx, fabsf(pn));
+    // four elements per thread and pass, all sixteen loads issued before the first use (the pass is HBM-bound: 28 B per parameter)
+#pragma unroll 1
+    for (int k0 = 0; k0 < STEM_ADAM_CHUNK / 256; k0 += 4) {
+        float gi[4], mi[4], vi[4], pi[4];
+        size_t idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            idx[u] = base + (size_t)(k0 + u) * 256 + threadIdx.x;
+            const bool ok = idx[u] < n;
+            const size_t j = ok ? idx[u] : 0;
+            gi[u] = ok ? g[j] : 0.f;
+            mi[u] = ok ? m[j] : 0.f;
+            vi[u] = ok ? v[j] : 0.f;
+            pi[u] = ok ? p[j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (idx[u] >= n) continue;
+            const float gs = gi[u] * coef;
+            if (zero_g) g[idx[u]] = 0.f;
+            const float mn = mi[u] + (gs - mi[u]) * (1.f - b1);
+            const float vn = vi[u] * b2 + (1.f - b2) * gs * gs;
+            m[idx[u]] = mn;
+            v[idx[u]] = vn;
+            const float pn = pi[u] - step_size * (mn / (sqrtf(vn) * inv_sqrt_bc2 + eps));
+            p[idx[u]] = pn;
+            mx = fmaxf(mx, fabsf(pn));
+        }
     }
-    mx = block_max(mx, red);
-    if (threadIdx.x == 0) bmax[blockIdx.x] = mx;
+    mx = wave_max(mx);                                         // one slot per wavefront: no barrier in an HBM-bound pass
+    if ((threadIdx.x & 63) == 0) bmax[blockIdx.x * 4 + (threadIdx.x >> 6)] = mx;
 }
 
 // One thread: ++step (device-resident), then the two scalars of this step's update exactly as stem_adam_step derives them

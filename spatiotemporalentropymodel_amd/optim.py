@@ -134,7 +134,7 @@ class FusedClipAdam(torch.optim.Optimizer):
         elif block_max:
             if getattr(self, "block_maxima", None) is None:
                 ch = F.adam_chunk()
-                self.block_maxima = torch.empty((self.flat.data.numel() + ch - 1) // ch, device=self.flat.data.device, dtype=torch.float32)
+                self.block_maxima = torch.empty(4 * ((self.flat.data.numel() + ch - 1) // ch), device=self.flat.data.device, dtype=torch.float32)
             F.adam_step_bmax(self.flat.data, self.flat.grad, self.m, self.v, self._sumsq if use_clip else None,
                              float(self.max_norm) if use_clip else 0.0, float(grad_scale), float(g["lr"]), g["betas"][0], g["betas"][1],
                              float(g["eps"]), self.t, self.block_maxima, zero_grad=zero_grad)

@@ -282,12 +282,13 @@ def test_weight_scales_from_the_optimiser_pass(F):
     pa, pb = dev(p0), dev(p0)
     ma, va, mb, vb = (torch.zeros(n, device="cuda") for _ in range(4))
     ga, gb = dev(g0), dev(g0)
-    bmax = torch.empty((n + ch - 1) // ch, device="cuda")
+    bmax = torch.empty(4 * ((n + ch - 1) // ch), device="cuda")          # one value per wavefront of a chunk's workgroup
     F.adam_step(pa, ga, ma, va, None, 0.0, 1.0, 1e-3, 0.9, 0.999, 1e-8, 1, zero_grad=True)
     F.adam_step_bmax(pb, gb, mb, vb, None, 0.0, 1.0, 1e-3, 0.9, 0.999, 1e-8, 1, bmax, zero_grad=True)
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and float(gb.abs().max()) == 0.0
     pn = host(pb)
-    assert np.array_equal(host(bmax), np.array([np.abs(pn[i:i + ch]).max() for i in range(0, n, ch)], np.float32))
+    cmax = np.array([np.abs(pn[i:i + ch]).max() for i in range(0, n, ch)], np.float32)
+    assert np.array_equal(host(bmax).reshape(-1, 4).max(1), cmax)
     descs, imgs = [], []
     for (sh, off, taps) in ((shapes[0], offs[0], 0), (shapes[2], offs[2], 12), (shapes[3], offs[3], 0)):
         K, Cc, R, S = sh
@@ -310,7 +311,7 @@ def test_weight_scales_from_the_optimiser_pass(F):
         rec = img.view(torch.float32)[nrec:nrec + 17].cpu()
         inv, bound = float(rec[1]), float(rec[16])
         lo, hi = int(off) // ch, (int(off) + w.size - 1) // ch
-        assert np.abs(pn[off:off + w.size]).max() <= bound == float(host(bmax)[lo:hi + 1].max()) and 2.0 ** 14 <= bound / inv < 2.0 ** 15
+        assert np.abs(pn[off:off + w.size]).max() <= bound == float(cmax[lo:hi + 1].max()) and 2.0 ** 14 <= bound / inv < 2.0 ** 15
         x = rnd((2, Cc, 9, 11), 7 + K, -1, 1)
         y, _ = F.conv2d_f16x3_gen(F.F16Planes.split(dev(x)), img, None, K, R, S, 1, R // 2, taps=taps)
         assert_close(host(y), orc.conv2d_fwd(x, w, np.zeros(K, np.float32), 1, R // 2), what=f"conv with the optimiser-scaled image {sh}", floor=0.1)
