@@ -41,6 +41,40 @@ __device__ void eb_prepare(const float *p, EbPrep &e)
     e.b4 = p[57];
 }
 
+// eb_prepare for a whole workgroup that works on ONE channel: threads 0 .. 57 transform one parameter each (softplus for the
+// matrices, identity for the biases, tanh for the factors -- most of the arithmetic of the per-element kernels when every thread
+// repeats it), every thread then reads the 58 results from LDS.  Two barriers; `prep` holds NP floats.
+__device__ inline void eb_prepare_shared(const float *p, float *prep, EbPrep &e)
+{
+    __syncthreads();
+    if (threadIdx.x < NP) {
+        const int k = threadIdx.x;
+        const float pv = p[k];
+        const int r = k < 9 ? k / 3 : (k < 54 ? ((k - 9) % 15 < 9 ? 0 : ((k - 9) % 15 < 12 ? 1 : 2)) : (k < 57 ? 0 : 1));
+        prep[k] = r == 0 ? softplus_f(pv) : (r == 1 ? pv : tanhf(pv));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        e.sp0[o] = prep[o];
+        e.b0[o] = prep[3 + o];
+        e.tf0[o] = prep[6 + o];
+    }
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) e.sp[l][k] = prep[9 + 15 * l + k];
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            e.b[l][o] = prep[9 + 15 * l + 9 + o];
+            e.tf[l][o] = prep[9 + 15 * l + 12 + o];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) e.sp4[k] = prep[54 + k];
+    e.b4 = prep[57];
+}
+
 // _logits_cumulative (entropy_models.py:388-407).  pre[l][o] = value before the tanh gate of layer l,
 // in[l][o] = input of layer l (l=1..4); kept for the backward when KEEP.
 template <bool KEEP>
@@ -147,6 +181,36 @@ __global__ __launch_bounds__(256) void eb_forward_kernel(const float *z, int ldz
     lik[i] = fmaxf(l, bound);
 }
 
+// eb_forward_kernel with one workgroup per channel (threads over pixels, eb_prepare_shared): the form for tensors with few pixels
+// per channel (the hyper-latents); identical arithmetic per element to eb_forward_train_cm_kernel
+__global__ __launch_bounds__(256) void eb_forward_cm_kernel(const float *z, int ldz, const float *noise, const float *pack,
+                                                            const float *med, float *zhat, float *lik, size_t npix, int C,
+                                                            int mode, float bound)
+{
+    __shared__ float prep[NP];
+    for (int c = blockIdx.x; c < C; c += gridDim.x) {
+        EbPrep e;
+        eb_prepare_shared(pack + (size_t)c * NP, prep, e);
+        for (size_t pix = threadIdx.x; pix < npix; pix += 256) {
+            const size_t i = pix * C + c;
+            float v = z[pix * ldz + c];
+            if (mode == 0) {
+                v += noise[i];
+            } else {
+                const float m = med[c];
+                v = rintf(v - m) + m;
+            }
+            zhat[i] = v;
+            const float lo = eb_logits<false>(e, v - 0.5f, nullptr, nullptr);
+            const float up = eb_logits<false>(e, v + 0.5f, nullptr, nullptr);
+            const float s = lo + up;
+            const float sg = s > 0.f ? -1.f : (s < 0.f ? 1.f : 0.f);
+            const float l = fabsf(sigmoid_f(sg * up) - sigmoid_f(sg * lo));
+            lik[i] = fmaxf(l, bound);
+        }
+    }
+}
+
 // one workgroup (EB_BWD_NT threads) per channel; reduces the 58 parameter gradients over pixels: wavefront shuffles, then a
 // fixed-order sum of the wavefronts' partials through LDS (no atomics)
 constexpr int EB_BWD_NT = 256;
@@ -157,8 +221,9 @@ __global__ __launch_bounds__(EB_BWD_NT) void eb_backward_kernel(const float *zha
     __shared__ float red[EB_BWD_NT / 64][NP];
     const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *p = pack + (size_t)c * NP;
+    __shared__ float prep[NP];
     EbPrep e;
-    eb_prepare(p, e);
+    eb_prepare_shared(p, prep, e);
     float dp[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) dp[k] = 0.f;
@@ -420,7 +485,7 @@ STEM_EXPORT int stem_eb_forward(const float *z, int ldz, const float *noise, con
     STEM_CHECK_ARG(z && pack && z_hat && lik, "stem_eb_forward: null pointer");
     STEM_CHECK_ARG((mode == 0 && noise) || (mode == 1 && medians), "stem_eb_forward: mode %d needs %s", mode, mode ? "medians" : "noise");
     const size_t npix = (size_t)B * H * W;
-    hipLaunchKernelGGL(eb_forward_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, z, ldz, noise, pack, medians,
+    hipLaunchKernelGGL(npix <= 4096 ? eb_forward_cm_kernel : eb_forward_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, z, ldz, noise, pack, medians,
                        z_hat, lik, npix, C, mode, bound);
     STEM_LAUNCH_CHECK("eb_forward");
     return 0;
@@ -685,6 +750,43 @@ __global__ __launch_bounds__(256) void eb_forward_train_kernel(const float *z, i
     block_log2_partial(lg, part);
 }
 
+// The same with one workgroup per CHANNEL (threads over pixels): the 48 softplus / tanh values of a channel's parameters
+// (eb_prepare: most of the kernel's arithmetic when every thread repeats it) are computed once per workgroup and shared through
+// LDS.  For the hyper-latents of the STEM model (a few hundred pixels per channel) this is the form used: the accesses along a
+// channel are strided, which only matters for large tensors.  Same arithmetic per element, same Philox counters.
+__global__ __launch_bounds__(256) void eb_forward_train_cm_kernel(const float *z, int ldz, NoiseSrc nz, const float *pack, float *zhat,
+                                                                  float *lik, float *dlik, double *part, size_t npix, int C,
+                                                                  float bound, float coef)
+{
+    __shared__ float prep[NP];
+    double lg = 0.0;
+    for (int c = blockIdx.x; c < C; c += gridDim.x) {
+        EbPrep e;
+        eb_prepare_shared(pack + (size_t)c * NP, prep, e);
+        for (size_t pix = threadIdx.x; pix < npix; pix += 256) {
+            const size_t i = pix * C + c;
+            float v = z[pix * ldz + c];
+            if (nz.ptr) {
+                v += nz.ptr[i];
+            } else {
+                float r[4];
+                philox4(nz.seed, noise_base(nz) + (i >> 2), r);
+                v += r[i & 3];
+            }
+            zhat[i] = v;
+            const float lo = eb_logits<false>(e, v - 0.5f, nullptr, nullptr);
+            const float up = eb_logits<false>(e, v + 0.5f, nullptr, nullptr);
+            const float s = lo + up;
+            const float sg = s > 0.f ? -1.f : (s < 0.f ? 1.f : 0.f);
+            const float l = fmaxf(fabsf(sigmoid_f(sg * up) - sigmoid_f(sg * lo)), bound);
+            lik[i] = l;
+            dlik[i] = coef / l;
+            lg += (double)log2f(l);
+        }
+    }
+    block_log2_partial(lg, part);
+}
+
 // GaussianConditional.forward in training mode (+noise; means are ignored by the noise quantiser, entropy_models.py:128-135)
 __global__ __launch_bounds__(256) void gc_forward_train_kernel(const float *y, NoiseSrc nl, const float *scales, const float *means,
                                                                int ldsm, float *out, float *lik, float *dlik, double *part,
@@ -804,8 +906,12 @@ STEM_EXPORT int stem_eb_forward_train(const float *z, int ldz, const float *pack
 {
     STEM_CHECK_ARG(z && pack && z_hat && lik && dlik && partials, "stem_eb_forward_train: null pointer");
     if (npix == 0) return 0;
-    hipLaunchKernelGGL(eb_forward_train_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, z, ldz,
-                       make_noise(noise, seed, offset, epoch_dev, epoch_stride), pack, z_hat, lik, dlik, partials, npix, C, bound, coef);
+    if (npix <= 4096)        // few pixels per channel (hyper-latents): one workgroup per channel shares the prepared parameters
+        hipLaunchKernelGGL(eb_forward_train_cm_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, z, ldz,
+                           make_noise(noise, seed, offset, epoch_dev, epoch_stride), pack, z_hat, lik, dlik, partials, npix, C, bound, coef);
+    else
+        hipLaunchKernelGGL(eb_forward_train_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, z, ldz,
+                           make_noise(noise, seed, offset, epoch_dev, epoch_stride), pack, z_hat, lik, dlik, partials, npix, C, bound, coef);
     STEM_LAUNCH_CHECK("eb_forward_train");
     return 0;
 }
