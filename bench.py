@@ -397,6 +397,11 @@ def main():
         return bench_roi(args)
 
     os.environ.setdefault("STEM_STREAM_PRIO", "latents=0,side=-1,compute=-1")      # read when the first stream is made (see below)
+    # The latent-prefetch stream is confined to 192 of the 256 CUs (hipExtStreamCreateWithCUMask): a running workgroup of the long
+    # analysis-transform kernels cannot be pre-empted, so without the mask the P-frame step's short, high-priority launches wait for
+    # CUs to drain (HE.2's 25 us launch took 200 us next to g_a.2).  Same box: 15.82 -> 15.58 ms per step (208 CUs 15.73, 160 CUs
+    # 15.58, 144 CUs 16.4); with the round's earlier, slower kernels the same mask cost time.  STEM_STREAM_CUMASK="" removes it.
+    os.environ.setdefault("STEM_STREAM_CUMASK", "latents=block:192")
     from spatiotemporalentropymodel_amd import _lib
     from spatiotemporalentropymodel_amd import distributed as D
     _lib.hip()                                    # no HIP library -> fail loudly, nothing to measure
@@ -561,7 +566,8 @@ def main():
                              "avg_launch_ms": kern_ms, "launches_timed": len(probe)},
                 "useful_flop_per_launch": flop, "useful_tflops": flop / (in_ms * 1e-3) / 1e12, "useful_tflops_isolated": flop / (kern_ms * 1e-3) / 1e12,
                 "useful_isolated_vs_fp32_mfma_peak": flop / (kern_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                "timing_note": ("achieved / frac / avg_launch_ms: the launches of the timed region, which run on the latent-prefetch stream next to "
+                "timing_note": ("achieved / frac / avg_launch_ms: the launches of the timed region, which run on the latent-prefetch stream "
+                                "(confined to the CUs of config.stream_cu_masks; the isolated launches below run on the unmasked compute stream) next to "
                                 "a P-frame step (HIP events on the launching stream); isolated: the same launches (same frames, weights) repeated 3 x 7 "
                                 "times right after the timed region with the chip to themselves") if prefetch is not None else
                                "the launches of the timed region run alone (latents first): in-region = isolated",
@@ -589,6 +595,7 @@ def main():
                               else "getY of all 7 frames before the P-frame steps",
                    "analysis_transform": "fp16 matrix cores, two fp16 planes per operand, 3 products per fp32 product (conv_f16x3.hip)" if f16_chain else "fp32 MFMA",
                    "stream_priorities": os.environ.get("STEM_STREAM_PRIO", ""),
+                   "stream_cu_masks": os.environ.get("STEM_STREAM_CUMASK", "") or "none",
                    "launch": "hipGraph replay per P-frame step" if use_graph else
                              ("explicit fused schedule (trainer.FusedPFrameStep)" if fused_step is not None else "generic nn.Module / autograd route")},
         "roofline": roof,
