@@ -45,6 +45,17 @@ PEAK_F16_MFMA_TFLOPS = 2516.6        # same guide: v_mfma_f32_32x32x16_f16 (the 
 F16_PRODUCTS = 3                     # fp16 MFMA products per fp32 product in the split-operand kernels (csrc/stem_common.h)
 
 
+def _apply_bench_tuning(_lib):
+    """sweep aid: STEM_BENCH_TUNING="fx3_tile=64,fx3_depth=2" forces plan selectors of the library (stem_tuning_set: validated names
+    and values, none of them changes a result); STEM_BENCH_FX3_TILE=64 is the older spelling of fx3_tile=64"""
+    spec = os.environ.get("STEM_BENCH_TUNING", "")
+    if os.environ.get("STEM_BENCH_FX3_TILE"):
+        spec = f"fx3_tile={os.environ['STEM_BENCH_FX3_TILE']}," + spec
+    for kv in filter(None, spec.split(",")):
+        k, v = kv.split("=")
+        _lib.check(_lib.hip().stem_tuning_set(k.strip().encode(), int(v)))
+
+
 def synthetic_septuplet(batch, size, seed, device):
     """7 x [B,3,size,size] in [0,1]: low-frequency sinusoid images translated by (t, 2t) px + N(0, 0.01^2)
     (SURVEY.md §8(d)); generated on the device, shape contract of stem/dataset_vidseq.py:57-88."""
@@ -235,8 +246,7 @@ def bench_roi(args):
     from spatiotemporalentropymodel_amd.optim import configure_optimizers
     from spatiotemporalentropymodel_amd.selfcheck import roi_gop_step
     _lib.hip()
-    if os.environ.get("STEM_BENCH_FX3_TILE"):                   # sweep aid: force the 192-column kernel's pixel tile (64 / 128)
-        _lib.check(_lib.hip().stem_tuning_set(b"fx3_tile", int(os.environ["STEM_BENCH_FX3_TILE"])))
+    _apply_bench_tuning(_lib)
     rank, world, local = D.init_from_env()
     assert world == args.gpus and torch.cuda.is_available()
     dev = torch.device("cuda", local)
@@ -405,8 +415,7 @@ def main():
     from spatiotemporalentropymodel_amd import _lib
     from spatiotemporalentropymodel_amd import distributed as D
     _lib.hip()                                    # no HIP library -> fail loudly, nothing to measure
-    if os.environ.get("STEM_BENCH_FX3_TILE"):     # sweep aid: force the 192-column kernel's pixel tile (64 / 128)
-        _lib.check(_lib.hip().stem_tuning_set(b"fx3_tile", int(os.environ["STEM_BENCH_FX3_TILE"])))
+    _apply_bench_tuning(_lib)
     rank, world, local = D.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -596,6 +605,7 @@ def main():
                    "analysis_transform": "fp16 matrix cores, two fp16 planes per operand, 3 products per fp32 product (conv_f16x3.hip)" if f16_chain else "fp32 MFMA",
                    "stream_priorities": os.environ.get("STEM_STREAM_PRIO", ""),
                    "stream_cu_masks": os.environ.get("STEM_STREAM_CUMASK", "") or "none",
+                   "plan_selectors": os.environ.get("STEM_BENCH_TUNING", "") or "library defaults",
                    "launch": "hipGraph replay per P-frame step" if use_graph else
                              ("explicit fused schedule (trainer.FusedPFrameStep)" if fused_step is not None else "generic nn.Module / autograd route")},
         "roofline": roof,

@@ -42,8 +42,9 @@ constexpr int XP = BN + 4;                                         // fp32 pitch
 // LDS of a BM-pixel tile: the largest of the main loop (2 x NPL planes x (BM + BN) rows x 64 B), the fused GDN (the squares of six
 // 32-channel slabs as A-operand images + one chunk of gamma') and the planes pass (BM x XP floats); then the tap table
 constexpr int imax(int a, int b) { return a > b ? a : b; }
-constexpr int lds_taps(int bm) { return imax(imax(2 * NPL * (bm + BN) * 64, 6 * NPL * bm * 64 + NPL * BN * 64), bm * XP * 4); }
-constexpr int lds_total(int bm) { return lds_taps(bm) + 32 * 4; }
+constexpr int lds_stages(int depth) { return depth == 3 ? 3 : 2; }
+constexpr int lds_taps(int bm, int depth) { return imax(imax(lds_stages(depth) * NPL * (bm + BN) * 64, 6 * NPL * bm * 64 + NPL * BN * 64), bm * XP * 4); }
+constexpr int lds_total(int bm, int depth) { return lds_taps(bm, depth) + 32 * 4; }
 constexpr int MAXTAP = 25;
 constexpr int OOR = 0x7FFFFF00;                                    // voffset that every buffer view rejects (returns 0)
 
@@ -58,6 +59,7 @@ struct Fx3Args {
     void *yp;
     int ldy;
     int B, H, W, C, N, OH, OW, stride, ntaps;
+    int S;                         // taps per filter row: tap t = (t / S, t % S) of the R x S window (ntaps may be a prefix)
     int xbytes, wbytes, gbytes;
     float beta_bound;
     int fuse;                      // 0: bias only, 1: GDN
@@ -74,23 +76,39 @@ struct Fx3Args {
 
 __device__ inline int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
+// Byte offset of tap t = (t / S, t % S) relative to a pixel's own position in the planes.  The kernels walk it in scalar
+// registers (TAP_WALK_NEXT): a table lookup in LDS would drain the wavefront's LDS queue in the middle of the woven block.
+#define TAP_OFFSET(t) (tw_first + ((t) / tw_S) * tw_line + ((t) % tw_S) * tw_col)
+#define TAP_WALK_NEXT()                                                                         \
+    do {                                                                                        \
+        const bool wrap_ = pf_t + 1 == a.ntaps, rowend_ = pf_ts + 1 == tw_S;                    \
+        ++pf_q;                                                                                 \
+        pf_to = wrap_ ? tw_first : pf_to + (rowend_ ? tw_line - (tw_S - 1) * tw_col : tw_col);  \
+        pf_ts = (wrap_ || rowend_) ? 0 : pf_ts + 1;                                             \
+        pf_t = wrap_ ? 0 : pf_t + 1;                                                            \
+        pf_kc += wrap_ ? 1 : 0;                                                                 \
+    } while (0)
+
 
 // BM = pixels per workgroup: 128 (8 wavefronts) or 64 (4 wavefronts, for layers with too few 128-pixel tiles to fill the chip).
-// DEPTH = chunks in flight in registers: 2 (default) or 4 (sweep aid, tools/debug/f16x3_depth_sweep.py: no gain).
+// DEPTH 2: two LDS stages, two chunks in flight in registers; the fragments of a 16-channel step are read right before its MFMAs.
+// DEPTH 3: three LDS stages -- chunk c + 2 is written while chunk c is multiplied, so the fragments of the NEXT 16-channel step
+//          (the first one of chunk c + 1 included) are read and the LDS stores issued between the MFMAs of the current one; only
+//          the barrier itself is left between two chunks.  120 KB of LDS with 128-pixel tiles (one workgroup per CU either way).
 template <int BM, int DEPTH>
 __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
 {
-    static_assert(DEPTH == 2 || DEPTH == 4, "register sets rotate with the LDS double buffer: an even depth");
+    static_assert(DEPTH == 2 || DEPTH == 3, "two or three LDS stages");
+    constexpr int NSET = 2;                             // register sets (chunks on their way to LDS)
     constexpr int NT = BM * 4;
     constexpr int A_PLANE = BM * 64, A_BUF = NPL * A_PLANE;
-    constexpr int LDS_TAPS = lds_taps(BM);
     constexpr int PL = NPL;
     constexpr int WPIECES = PL * BN * 4;                // 16-byte pieces of the weight chunk that are read
     constexpr int BP = (WPIECES + NT - 1) / NT;         // ... per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *As = smem;                       // [2][NPL][BM][64 B]
-    unsigned char *Bs = smem + 2 * A_BUF;           // [2][NPL][BN][64 B]
-    int *tapi = reinterpret_cast<int *>(smem + LDS_TAPS);
+    constexpr int NST = lds_stages(DEPTH);
+    unsigned char *As = smem;                       // [NST][NPL][BM][64 B]
+    unsigned char *Bs = smem + NST * A_BUF;         // [NST][NPL][BN][64 B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Mtot = a.B * a.OH * a.OW;
@@ -101,7 +119,6 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
     }
     const int bm0 = tile_m * BM;
     const int nslab = a.C / KC, pixbytes = nslab * SLAB;
-    if (tid < 32) tapi[tid] = tid < a.ntaps ? (a.dy[tid] * a.W + a.dx[tid]) * pixbytes : 0;
 
     // ---- staging assignment.  Activations: thread -> (row = tid / 4, 16-byte column = tid % 4) of all three planes ---------
     const int srow = tid >> 2, scol = tid & 3;
@@ -130,9 +147,9 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.xp), 0, a.xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wp), 0, a.wbytes, 0x00020000);
 
-    f32x4 rsa[DEPTH][PL], rsb[DEPTH][BP];       // register set s holds a chunk on its way to LDS
-    auto gload = [&](int t, int kc, int q, f32x4 (&ra)[PL], f32x4 (&rb)[BP]) {
-        const int tA = __builtin_amdgcn_readfirstlane(tapi[t]), sA = kc * SLAB, sB = q * B_BUF;
+    f32x4 rsa[NSET][PL], rsb[NSET][BP];         // register set s holds a chunk on its way to LDS
+    auto gload = [&](int t, int tA, int kc, int q, f32x4 (&ra)[PL], f32x4 (&rb)[BP]) {
+        const int sA = kc * SLAB, sB = q * B_BUF;
         const int mk = __builtin_amdgcn_sbfe((int)pmask, (unsigned)t, 1u);                 // 0 / -1: tap t inside the image
         const int off = ((pb + tA) & mk) | (OOR & ~mk);
 #pragma unroll
@@ -162,10 +179,14 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    int pf_q = 0, pf_t = 0, pf_kc = 0;            // prefetch target of the next step (wave-uniform)
+    // prefetch target of the next step (wave-uniform).  The byte offset of tap t inside the planes is carried along in scalar
+    // registers (pf_ts = t % S): a table lookup in LDS would drain the wavefront's LDS queue in the middle of the woven block.
+    int pf_q = 0, pf_t = 0, pf_kc = 0, pf_ts = 0, pf_to = 0;
+    const int tw_S = a.S, tw_col = pixbytes, tw_line = a.W * pixbytes, tw_first = (a.dy[0] * a.W + a.dx[0]) * pixbytes;
     auto step = [&](int cur, f32x4 (&ra)[PL], f32x4 (&rb)[BP]) {
         const unsigned char *Ab = As + cur * A_BUF + rdA, *Bb = Bs + cur * B_BUF + rdB;
         const int t = __builtin_amdgcn_readfirstlane(pf_t), kc = __builtin_amdgcn_readfirstlane(pf_kc), q = __builtin_amdgcn_readfirstlane(pf_q);
+        const int to = __builtin_amdgcn_readfirstlane(pf_to);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int pk = ks ? pk1 : pk0;
@@ -185,15 +206,65 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
             if (ks == 0)
                 sstore(cur ^ 1, ra, rb);           // the register set holds the next chunk
             else
-                gload(t, kc, q, ra, rb);           // refill it DEPTH chunks ahead
+                gload(t, to, kc, q, ra, rb);       // refill it two chunks ahead
         }
-        if (pf_q < q_last) {
-            ++pf_q;
-            if (++pf_t == a.ntaps) {
-                pf_t = 0;
-                ++pf_kc;
-            }
+        if (pf_q < q_last) TAP_WALK_NEXT();
+    };
+    // DEPTH 3: F0 holds the fragments of (stage rd, channels 0..15) on entry and of (stage nx, channels 0..15) on exit
+    h16x8 f0a[PL], f0b[PL][3], f1a[PL], f1b[PL][3];
+    auto lfrag = [&](int stage, int pk, h16x8 (&af)[PL], h16x8 (&bf)[PL][3]) {       // in the order the MFMAs consume them
+        const unsigned char *Ab = As + stage * A_BUF + rdA + pk, *Bb = Bs + stage * B_BUF + rdB + pk;
+        af[1] = *reinterpret_cast<const h16x8 *>(Ab + A_PLANE);
+        bf[0][0] = *reinterpret_cast<const h16x8 *>(Bb);
+        af[0] = *reinterpret_cast<const h16x8 *>(Ab);
+        bf[1][0] = *reinterpret_cast<const h16x8 *>(Bb + B_PLANE);
+#pragma unroll
+        for (int j = 1; j < 3; ++j) {
+            bf[0][j] = *reinterpret_cast<const h16x8 *>(Bb + j * 32 * 64);
+            bf[1][j] = *reinterpret_cast<const h16x8 *>(Bb + B_PLANE + j * 32 * 64);
         }
+    };
+    auto mfma9 = [&](h16x8 (&af)[PL], h16x8 (&bf)[PL][3]) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            acc[j] = STEM_MFMA16(af[1], bf[0][j], acc[j]);
+            acc[j] = STEM_MFMA16(af[0], bf[1][j], acc[j]);
+            acc[j] = STEM_MFMA16(af[0], bf[0][j], acc[j]);
+        }
+    };
+    auto step3 = [&](int rd, int nx, int wr, f32x4 (&ra)[PL], f32x4 (&rb)[BP]) {
+        const int t = __builtin_amdgcn_readfirstlane(pf_t), kc = __builtin_amdgcn_readfirstlane(pf_kc), q = __builtin_amdgcn_readfirstlane(pf_q);
+        const int to = __builtin_amdgcn_readfirstlane(pf_to);
+        lfrag(rd, pk1, f1a, f1b);
+        mfma9(f0a, f0b);
+        sstore(wr, ra, rb);
+        lfrag(nx, pk0, f0a, f0b);
+        mfma9(f1a, f1b);
+        gload(t, to, kc, q, ra, rb);
+        // issue order: one LDS read behind each MFMA of the first half; the stores, then the reads, behind those of the second
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        constexpr int NW = PL + BP;                                  // LDS stores per thread and chunk
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, (NW + 3) / 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, (NW + 2) / 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, (NW + 1) / 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, NW / 4, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, PL + BP, 0);
+        if (pf_q < q_last) TAP_WALK_NEXT();
     };
 
     // chunk q = kc * ntaps + t (channel slab outer, taps inner: the taps of one slab re-touch the same input lines)
@@ -205,15 +276,21 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
     };
     {
         int t, kc, q;
-        q = chunk_of(0, t, kc);
-        gload(t, kc, q, rsa[0], rsb[0]);
-        sstore(0, rsa[0], rsb[0]);
+        constexpr int PRE = NST - 1;               // chunks that are in LDS before the loop starts
 #pragma unroll
-        for (int s = 0; s < DEPTH; ++s) {          // set s <- chunk 1 + s
-            q = chunk_of(1 + s, t, kc);
-            gload(t, kc, q, rsa[s], rsb[s]);
+        for (int c = 0; c < PRE; ++c) {
+            q = chunk_of(c, t, kc);
+            gload(t, TAP_OFFSET(t), kc, q, rsa[0], rsb[0]);
+            sstore(c, rsa[0], rsb[0]);
         }
-        pf_q = chunk_of(1 + DEPTH, pf_t, pf_kc);
+#pragma unroll
+        for (int s = 0; s < NSET; ++s) {           // set s <- chunk PRE + s
+            q = chunk_of(PRE + s, t, kc);
+            gload(t, TAP_OFFSET(t), kc, q, rsa[s], rsb[s]);
+        }
+        pf_q = chunk_of(PRE + NSET, pf_t, pf_kc);
+        pf_ts = pf_t % tw_S;
+        pf_to = TAP_OFFSET(pf_t);
     }
     // ---- scales of the epilogue, computed HERE: their slot / bias / beta loads and block reductions run while the first chunks
     // are in flight instead of after the last MFMA (one workgroup per CU: nothing else would hide them there)
@@ -240,21 +317,36 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
         if (blockIdx.x == 0 && tid == 0) a.yq[1] = q_pow2(-oe);
     }
     __syncthreads();
-    {
+    if constexpr (DEPTH == 3) {
+        int rd = 0, nx = 1, wr = 2;
+        lfrag(0, pk0, f0a, f0b);
         int q = 0;
-        for (; q + DEPTH - 1 < nchunks; q += DEPTH) {
+        for (; q + 1 < nchunks; q += 2) {
 #pragma unroll
-            for (int s = 0; s < DEPTH; ++s) {
-                step(s & 1, rsa[s], rsb[s]);
+            for (int s = 0; s < 2; ++s) {
+                step3(rd, nx, wr, rsa[s], rsb[s]);
+                __syncthreads();
+                const int o = rd;
+                rd = nx; nx = wr; wr = o;
+            }
+        }
+        if (q < nchunks) {
+            step3(rd, nx, wr, rsa[0], rsb[0]);
+            __syncthreads();
+        }
+    } else {
+        int q = 0;
+        for (; q + 1 < nchunks; q += 2) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                step(s, rsa[s], rsb[s]);
                 __syncthreads();
             }
         }
-#pragma unroll
-        for (int s = 0; s < DEPTH - 1; ++s)
-            if (q + s < nchunks) {
-                step(s & 1, rsa[s], rsb[s]);
-                __syncthreads();
-            }
+        if (q < nchunks) {
+            step(0, rsa[0], rsb[0]);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: lane holds column n = wn0 + 32 j + lr, rows (r & 3) + 8 (r >> 2) + 4 lh of each 32x32 tile ---------------
@@ -449,7 +541,6 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
     const int Mtot = a.B * a.OH * a.OW;
     const int bm0 = blockIdx.x * GBM, bn0 = blockIdx.y * GBN, zsplit = blockIdx.z;
     const int nslab = a.C / KC, pixbytes = a.xpix;
-    if (tid < 32) tapi[tid] = tid < a.ntaps ? (a.dy[tid] * a.W + a.dx[tid]) * pixbytes : 0;
 
     const int srow = tid >> 2, scol = tid & 3;
     int pb;
@@ -478,8 +569,8 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wp), 0, a.wbytes, 0x00020000);
 
     f32x4 raA[PL], rbA[BPC], raB[PL], rbB[BPC];
-    auto gload = [&](int t, int kc, int q, f32x4 (&ra)[PL], f32x4 (&rb)[BPC]) {
-        const int tA = __builtin_amdgcn_readfirstlane(tapi[t]), sA = kc * SLAB, sB = (wbase + q) * GB_BUF;
+    auto gload = [&](int t, int tA, int kc, int q, f32x4 (&ra)[PL], f32x4 (&rb)[BPC]) {
+        const int sA = kc * SLAB, sB = (wbase + q) * GB_BUF;
         const int mk = __builtin_amdgcn_sbfe((int)pmask, (unsigned)t, 1u);
         const int off = ((pb + tA) & mk) | (OOR & ~mk);
 #pragma unroll
@@ -505,10 +596,12 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    int pf_q = 0, pf_t = 0, pf_kc = 0;
+    int pf_q = 0, pf_t = 0, pf_kc = 0, pf_ts = 0, pf_to = 0;          // see conv_f16x3_kernel
+    const int tw_S = a.S, tw_col = pixbytes, tw_line = a.W * pixbytes, tw_first = (a.dy[0] * a.W + a.dx[0]) * pixbytes;
     auto step = [&](int cur, f32x4 (&ra)[PL], f32x4 (&rb)[BPC]) {
         const unsigned char *Ab = As + cur * GA_BUF + rdA, *Bb = Bs + cur * GB_BUF + rdB;
         const int t = __builtin_amdgcn_readfirstlane(pf_t), kc = __builtin_amdgcn_readfirstlane(pf_kc), q = __builtin_amdgcn_readfirstlane(pf_q);
+        const int to = __builtin_amdgcn_readfirstlane(pf_to);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int pk = ks ? pk1 : pk0;
@@ -528,15 +621,9 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
             if (ks == 0)
                 sstore(cur ^ 1, ra, rb);
             else
-                gload(t, kc, q, ra, rb);
+                gload(t, to, kc, q, ra, rb);
         }
-        if (pf_q < q_last) {
-            ++pf_q;
-            if (++pf_t == a.ntaps) {
-                pf_t = 0;
-                ++pf_kc;
-            }
-        }
+        if (pf_q < q_last) TAP_WALK_NEXT();
     };
     // A wavefront whose 64 columns lie entirely beyond N (the second column pair of the last tile of a 320-channel layer: a
     // sixth of the launch's matrix work) only takes part in the staging: same loads, LDS writes and barriers, no LDS reads and
@@ -544,15 +631,10 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
     const bool dead = bn0 + wn0 >= a.N;
     auto step_dead = [&](int cur, f32x4 (&ra)[PL], f32x4 (&rb)[BPC]) {
         const int t = __builtin_amdgcn_readfirstlane(pf_t), kc = __builtin_amdgcn_readfirstlane(pf_kc), q = __builtin_amdgcn_readfirstlane(pf_q);
+        const int to = __builtin_amdgcn_readfirstlane(pf_to);
         sstore(cur ^ 1, ra, rb);
-        gload(t, kc, q, ra, rb);
-        if (pf_q < q_last) {
-            ++pf_q;
-            if (++pf_t == a.ntaps) {
-                pf_t = 0;
-                ++pf_kc;
-            }
-        }
+        gload(t, to, kc, q, ra, rb);
+        if (pf_q < q_last) TAP_WALK_NEXT();
     };
     auto chunk_of = [&](int q, int &t, int &kc) {
         q = q < q_last ? q : q_last;
@@ -563,13 +645,15 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
     if (q_begin < q_end) {
         int t, kc, q;
         q = chunk_of(q_begin, t, kc);
-        gload(t, kc, q, raA, rbA);
+        gload(t, TAP_OFFSET(t), kc, q, raA, rbA);
         sstore(0, raA, rbA);
         q = chunk_of(q_begin + 1, t, kc);
-        gload(t, kc, q, raA, rbA);
+        gload(t, TAP_OFFSET(t), kc, q, raA, rbA);
         q = chunk_of(q_begin + 2, t, kc);
-        gload(t, kc, q, raB, rbB);
+        gload(t, TAP_OFFSET(t), kc, q, raB, rbB);
         pf_q = chunk_of(q_begin + 3, pf_t, pf_kc);
+        pf_ts = pf_t % tw_S;
+        pf_to = TAP_OFFSET(pf_t);
     }
     // scales of the epilogue, computed while the first chunks are in flight (see conv_f16x3_kernel; every split of a tile
     // computes the same values, the last arriver uses them)
@@ -1163,7 +1247,7 @@ static int conv2d_f16x3_launch(const void *xp, const float *xq, const void *wp, 
         a.gq = reinterpret_cast<const float *>(static_cast<const unsigned char *>(gp) + a.gbytes);
     }
     a.xq = xq; a.yq = yq; a.wq = reinterpret_cast<const float *>(static_cast<const unsigned char *>(wp) + wb);
-    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.OH = OH; a.OW = OW; a.stride = stride; a.ntaps = R * S;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.OH = OH; a.OW = OW; a.stride = stride; a.ntaps = R * S; a.S = S;
     a.xbytes = (int)xb; a.wbytes = (int)wb;
     a.fuse = gp ? 1 : 0;
     a.epi = act; a.slope = slope;
@@ -1175,10 +1259,10 @@ static int conv2d_f16x3_launch(const void *xp, const float *xq, const void *wp, 
         }
     static bool attr_done = false;      // > 64 KiB of dynamic LDS needs an explicit opt-in
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
-        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128));
-        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
-        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128, 2));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128, 3));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64, 2));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64, 3));
         attr_done = true;
     }
     const int M = B * OH * OW;
@@ -1186,18 +1270,19 @@ static int conv2d_f16x3_launch(const void *xp, const float *xq, const void *wp, 
     // 128-pixel tiles (8 wavefronts) when they fill the 256 CUs at least once, 64-pixel tiles (4 wavefronts) below that
     const int tile = stem_tuning(STEM_TUNE_FX3_TILE);
     const bool small = tile ? tile == 64 : cdiv(M, 128) < 256;
-    // chunks in flight: 2.  Four (stem_tuning_set("fx3_depth", 4)) measured 129 vs 131 us on g_a.4 and 380 vs 380 us on g_a.2:
-    // with three products the kernel is bound by L2 -> LDS operand traffic (40 KB per chunk and workgroup), not by load latency
+    // main-loop form (see the kernel): stem_tuning_set("fx3_depth", 2 | 3); 0 = default
+    // default: three stages with 128-pixel tiles (g_a.2 365 -> 357 us), two with 64-pixel tiles -- 96 KB of LDS would leave room
+    // for ONE such workgroup per CU, and layers with 256 .. 511 tiles (g_a.4) run two per CU next to other streams' work
     const int dsel = stem_tuning(STEM_TUNE_FX3_DEPTH);
-    const int depth = dsel ? dsel : 2;
-    if (small && depth == 4)
-        hipLaunchKernelGGL((conv_f16x3_kernel<64, 4>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
+    const int depth = dsel ? dsel : (small ? 2 : 3);
+    if (small && depth == 3)
+        hipLaunchKernelGGL((conv_f16x3_kernel<64, 3>), dim3(cdiv(M, 64)), dim3(256), lds_total(64, 3), st, a);
     else if (small)
-        hipLaunchKernelGGL((conv_f16x3_kernel<64, 2>), dim3(cdiv(M, 64)), dim3(256), lds_total(64), st, a);
-    else if (depth == 4)
-        hipLaunchKernelGGL((conv_f16x3_kernel<128, 4>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
+        hipLaunchKernelGGL((conv_f16x3_kernel<64, 2>), dim3(cdiv(M, 64)), dim3(256), lds_total(64, 2), st, a);
+    else if (depth == 3)
+        hipLaunchKernelGGL((conv_f16x3_kernel<128, 3>), dim3(cdiv(M, 128)), dim3(512), lds_total(128, 3), st, a);
     else
-        hipLaunchKernelGGL((conv_f16x3_kernel<128, 2>), dim3(cdiv(M, 128)), dim3(512), lds_total(128), st, a);
+        hipLaunchKernelGGL((conv_f16x3_kernel<128, 2>), dim3(cdiv(M, 128)), dim3(512), lds_total(128, 2), st, a);
     STEM_LAUNCH_CHECK("stem_conv2d_f16x3_fwd");
     return 0;
 }
@@ -1335,7 +1420,7 @@ STEM_EXPORT int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int x
     memset(&a, 0, sizeof(a));
     a.xp = xp; a.wp = wp; a.bias = bias; a.y = y; a.yp = yp; a.ldy = ldy; a.z = z; a.ldz = ldz; a.epi = epi; a.slope = slope;
     a.xq = xq; a.yq = yq; a.wq = reinterpret_cast<const float *>(static_cast<const unsigned char *>(wp) + wb);
-    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.OH = OH; a.OW = OW; a.stride = stride; a.ntaps = T;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.OH = OH; a.OW = OW; a.stride = stride; a.ntaps = T; a.S = S;
     a.xbytes = (int)xb; a.wbytes = (int)wb; a.xpix = xpix;
     for (int r = 0; r < R; ++r)
         for (int s = 0; s < S; ++s) {

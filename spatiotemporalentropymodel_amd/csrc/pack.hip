@@ -34,7 +34,7 @@ STEM_EXPORT int stem_tuning_set(const char *name, int value)
         if (!strcmp(name, kTuningNames[i])) {
             STEM_CHECK_ARG(i != STEM_TUNE_FX3_TILE || value == 0 || value == 64 || value == 128, "stem_tuning_set: fx3_tile is 0 (automatic), 64 or 128");
             STEM_CHECK_ARG(i != STEM_TUNE_FX3_GEN_TILE || value == 0 || value == 64 || value == 128, "stem_tuning_set: fx3_gen_tile is 0 (automatic), 64 or 128");
-            STEM_CHECK_ARG(i != STEM_TUNE_FX3_DEPTH || value == 0 || value == 2 || value == 4, "stem_tuning_set: fx3_depth is 0 (automatic), 2 or 4");
+            STEM_CHECK_ARG(i != STEM_TUNE_FX3_DEPTH || value == 0 || value == 2 || value == 3, "stem_tuning_set: fx3_depth is 0 (automatic), 2 or 3 (LDS stages of the split-operand main loops)");
             g_tuning[i] = value;
             return 0;
         }

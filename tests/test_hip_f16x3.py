@@ -79,12 +79,14 @@ CASES = [  # B, C, H, W, K, R, stride
 
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("tile128", [False, True])
+@pytest.mark.parametrize("stages", [2, 3])
 @pytest.mark.parametrize("gdn", [False, True])
-def test_conv_gdn_vs_oracle(F, case, tile128, gdn):
-    """conv (+ fused GDN) against the oracle, both workgroup tiles (64 pixels x 4 wavefronts, 128 pixels x 8 wavefronts),
-    fp32 and planes output; ragged pixel counts and channel counts below the 192-wide tile."""
+def test_conv_gdn_vs_oracle(F, case, tile128, stages, gdn):
+    """conv (+ fused GDN) against the oracle, both workgroup tiles (64 pixels x 4 wavefronts, 128 pixels x 8 wavefronts) and both
+    main-loop forms (two / three LDS stages: a 1x1 case has fewer chunks than the three-stage prologue loads), fp32 and planes
+    output; ragged pixel counts and channel counts below the 192-wide tile."""
     B, C, H, W, K, R, st = case
-    with F.tuning(fx3_tile=128 if tile128 else 64):
+    with F.tuning(fx3_tile=128 if tile128 else 64, fx3_depth=stages):
         _conv_gdn_vs_oracle(F, case, gdn)
 
 
