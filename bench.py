@@ -406,12 +406,6 @@ def main():
     if args.config == "roi":
         return bench_roi(args)
 
-    os.environ.setdefault("STEM_STREAM_PRIO", "latents=0,side=-1,compute=-1")      # read when the first stream is made (see below)
-    # The latent-prefetch stream is confined to 192 of the 256 CUs (hipExtStreamCreateWithCUMask): a running workgroup of the long
-    # analysis-transform kernels cannot be pre-empted, so without the mask the P-frame step's short, high-priority launches wait for
-    # CUs to drain (HE.2's 25 us launch took 200 us next to g_a.2).  Same box: 15.82 -> 15.58 ms per step (208 CUs 15.73, 160 CUs
-    # 15.58, 144 CUs 16.4); with the round's earlier, slower kernels the same mask cost time.  STEM_STREAM_CUMASK="" removes it.
-    os.environ.setdefault("STEM_STREAM_CUMASK", "latents=block:192")
     from spatiotemporalentropymodel_amd import _lib
     from spatiotemporalentropymodel_amd import distributed as D
     _lib.hip()                                    # no HIP library -> fail loudly, nothing to measure
@@ -420,7 +414,18 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = torch.device("cuda", local)
+    # The library's tuned schedule (trainer.tuned_schedule; the environment overrides its two settings):
+    #  * stream priorities: the P-frame step's own streams -- a dedicated compute stream instead of torch's default stream, the
+    #    weight-gradient / branch / auxiliary streams -- at HIP's high priority, the latent-prefetch stream at normal priority: the
+    #    command processor then dispatches the step's small kernels ahead of the long analysis-transform kernels (22.4 against
+    #    22.7 ms per step on the same box).  STEM_STREAM_PRIO="" runs everything at one priority;
+    #  * the latent-prefetch stream is confined to 192 of the 256 CUs (hipExtStreamCreateWithCUMask): a running workgroup of the
+    #    long analysis-transform kernels cannot be pre-empted, so without the mask the step's short, high-priority launches wait for
+    #    CUs to drain (HE.2's 25 us launch took 200 us next to g_a.2).  Same box: 15.74 -> 15.39-15.43 ms per step (208 CUs 15.73,
+    #    160 CUs 15.58, 144 CUs 16.4); with the round's earlier, slower kernels the same mask cost time.  STEM_STREAM_CUMASK="" removes it.
+    from spatiotemporalentropymodel_amd.trainer import tuned_schedule
     torch.cuda.set_device(dev)
+    compute = tuned_schedule(dev)          # before anything creates a stream; entered around the steps below
 
     from spatiotemporalentropymodel_amd.losses import EMLoss
     from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel_Res
@@ -495,13 +500,6 @@ def main():
             last = oc
         return last
 
-    # Stream priorities (functional.make_stream): the P-frame step's own streams -- a dedicated compute stream instead of torch's
-    # default stream, the weight-gradient / branch / auxiliary streams -- at HIP's high priority, the latent-prefetch stream at
-    # normal priority: the command processor then dispatches the step's small kernels ahead of the long analysis-transform
-    # kernels (22.4 against 22.7 ms per step on the same box).  STEM_STREAM_PRIO="" runs everything at one priority.
-    from spatiotemporalentropymodel_amd import functional as F
-    F.make_stream(dev, "side")                                    # parses STEM_STREAM_PRIO
-    compute = torch.cuda.stream(F.make_stream(dev, "compute")) if "compute" in (F._STREAM_PRIO or {}) else contextlib.nullcontext()
     with compute:
         for _ in range(args.warmup):
             one_step()

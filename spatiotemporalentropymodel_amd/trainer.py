@@ -14,6 +14,7 @@ Only `EMLoss` (rate-only, the trainSTEM criterion) has this closed form; other c
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 
@@ -21,6 +22,31 @@ import torch
 
 from . import functional as F
 from .layers import join_wgrad_stream
+
+
+#: the stream set-up bench.py measures; the environment variables of the same names override them ("" disables)
+SCHEDULE_DEFAULTS = {"STEM_STREAM_PRIO": "latents=0,side=-1,compute=-1", "STEM_STREAM_CUMASK": "latents=block:192"}
+
+
+def tuned_schedule(device):
+    """-> a context manager that makes a high-priority compute stream current.  Call it BEFORE anything creates a stream (the
+    first FusedPFrameStep / LatentPrefetcher / engine call), enter it around the training loop:
+
+        sched = tuned_schedule(dev)
+        fused, pf = FusedPFrameStep(stem, opt, aux_opt), LatentPrefetcher(imodel)
+        with sched:
+            for frames in loader: ...
+
+    Installs the stream priorities and the CU mask of SCHEDULE_DEFAULTS unless the environment already sets them: the P-frame
+    step's own streams at HIP's high priority, the latent-prefetch stream at normal priority and confined to 192 of the 256 CUs,
+    so that the step's short kernels never queue behind running workgroups of the long analysis-transform kernels.  Scheduling
+    only: no result depends on it."""
+    for k, v in SCHEDULE_DEFAULTS.items():
+        os.environ.setdefault(k, v)
+    F.make_stream(device, "side")                      # parses STEM_STREAM_PRIO once
+    if "compute" in (F._STREAM_PRIO or {}):
+        return torch.cuda.stream(F.make_stream(device, "compute"))
+    return contextlib.nullcontext()
 
 
 class LatentPrefetcher:

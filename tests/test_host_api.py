@@ -1,5 +1,6 @@
 """CPU tests of the host-side product code: module surface / state-dict compatibility, the host rANS
 library (bit-exact vs the reference's bytes), CDF tables from update(), flat parameter buffers."""
+import os
 import types
 import zlib
 
@@ -491,3 +492,25 @@ def test_planes_byte_count_matches_the_library():
         # the scale record: 16 header words + one slot per 64-pixel x 128-channel producer tile, 16-byte granules
         assert total - payload >= (16 + -(-npix // 64) * -(-C // 128)) * 4 and (total - payload) % 16 == 0
     assert lib.stem_f16x2_planes_bytes(10, 48) == 0
+
+
+def test_tuned_schedule_defaults_and_cu_mask_words(monkeypatch):
+    """trainer.tuned_schedule installs the schedule bench.py measures unless the environment already decides, and the CU-mask
+    words handed to hipExtStreamCreateWithCUMask cover exactly the requested CUs (CPU: parsing only, no stream is created)."""
+    from spatiotemporalentropymodel_amd import functional as F
+    from spatiotemporalentropymodel_amd import trainer
+    assert trainer.SCHEDULE_DEFAULTS == {"STEM_STREAM_PRIO": "latents=0,side=-1,compute=-1", "STEM_STREAM_CUMASK": "latents=block:192"}
+    monkeypatch.setenv("STEM_STREAM_CUMASK", "latents=block:192")
+    words = F._cu_mask("latents")
+    assert len(words) == 8 and sum(bin(w).count("1") for w in words) == 192 and words[:6] == [0xFFFFFFFF] * 6 and words[6:] == [0, 0]
+    assert F._cu_mask("side") is None
+    monkeypatch.setenv("STEM_STREAM_CUMASK", "latents=mod8:3,side=block:32")
+    assert all(w == 0x07070707 for w in F._cu_mask("latents")) and F._cu_mask("side") == [0xFFFFFFFF] + [0] * 7
+    monkeypatch.setenv("STEM_STREAM_CUMASK", "")          # set and empty: no mask, and tuned_schedule must not overwrite it
+    assert F._cu_mask("latents") is None
+    monkeypatch.setenv("STEM_STREAM_PRIO", "")
+    monkeypatch.setattr(F, "_STREAM_PRIO", None)
+    monkeypatch.setattr(F, "make_stream", lambda device, role: (F.__dict__.__setitem__("_STREAM_PRIO", {}), None)[1])
+    import contextlib
+    assert isinstance(trainer.tuned_schedule(torch.device("cpu")), contextlib.nullcontext)
+    assert os.environ["STEM_STREAM_CUMASK"] == "" and os.environ["STEM_STREAM_PRIO"] == ""
