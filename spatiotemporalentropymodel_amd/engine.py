@@ -135,8 +135,8 @@ class _Layer:
             return self.wgrad(x, dy)
         side = self.eng.side_stream(dy.device, self.lane)
         if side is not None:
-            side.wait_stream(torch.cuda.current_stream(dy.device))
-            with torch.cuda.stream(side):
+            F.stream_wait(side, F.cur_stream(dy.device))
+            with F.on_stream(side):
                 self._wgrad3(xp, dyp, dy)
             for t in (xp.data, dyp.data, dy):
                 t.record_stream(side)
@@ -189,8 +189,8 @@ class _Layer:
         chain consumes it), ordered after everything the compute stream has queued so far."""
         side = self.eng.side_stream(x.device, self.lane)
         if side is not None:
-            side.wait_stream(torch.cuda.current_stream(x.device))
-            with torch.cuda.stream(side):
+            F.stream_wait(side, F.cur_stream(x.device))
+            with F.on_stream(side):
                 self._wgrad(x, dy)
             x.record_stream(side)
             dy.record_stream(side)
@@ -386,8 +386,8 @@ class StemEngine:
         for lo, hi in roles:                     # descriptor 0 of a layer = forward role, descriptor 1 = input-gradient role
             on_side = side is not None and lo == 1
             if on_side:
-                side.wait_stream(torch.cuda.current_stream(dev))      # the optimiser step that changed the weights
-            with (torch.cuda.stream(side) if on_side else contextlib.nullcontext()):
+                F.stream_wait(side, F.cur_stream(dev))      # the optimiser step that changed the weights
+            with F.on_stream(side if on_side else None):
                 both = [l.role_descs(r) for l in self.layers for r in range(lo, hi)]
                 descs = [d for a, _ in both for d in a]
                 descs6 = [d for _, b in both for d in b]
@@ -399,8 +399,8 @@ class StemEngine:
                 # forward later) are packed on that branch's stream, off the compute stream's optimiser -> forward chain
                 bs = self._branch(dev) if (descs and side is not None and not on_side and lo == 0 and hi == 1) else None
                 if descs and bs is not None:
-                    bs.wait_stream(torch.cuda.current_stream(dev))
-                    with torch.cuda.stream(bs):
+                    F.stream_wait(bs, F.cur_stream(dev))
+                    with F.on_stream(bs):
                         F.pack_weights_multi((_lib.PackDesc * len(descs))(*descs))
                         self._fwd32_pack_event = torch.cuda.Event()
                         self._fwd32_pack_event.record(bs)
@@ -429,8 +429,8 @@ class StemEngine:
         if side is None:
             return self._group_ready_on_stream(layers, extra_params)
         # extra_params (entropy-bottleneck gradients) were produced on the compute stream: order them before the hook
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
+        F.stream_wait(side, F.cur_stream(dev))
+        with F.on_stream(side):
             self._group_ready_on_stream(layers, extra_params)
 
     def _group_ready_on_stream(self, layers, extra_params):
@@ -445,18 +445,18 @@ class StemEngine:
 
     def join_side_stream(self):
         for st in self._side.values():
-            torch.cuda.current_stream(st.device).wait_stream(st)
+            F.stream_wait(F.cur_stream(st.device), st)
 
     def _wait_fwd32_packs(self):
         """a consumer of a forward-role fp32 weight copy: order it after the packing on the hyper branch's stream (a no-op
         for the hyper branch itself, which runs on that stream)"""
         if self._fwd32_pack_event is not None:
-            torch.cuda.current_stream().wait_event(self._fwd32_pack_event)
+            F.cur_stream().wait_event(self._fwd32_pack_event)
 
     def _wait_dgrad_packs(self):
         """backward's first consumer of an input-gradient weight copy: order it after the side-stream packing"""
         if self._dgrad_pack_event is not None:
-            torch.cuda.current_stream().wait_event(self._dgrad_pack_event)
+            F.cur_stream().wait_event(self._dgrad_pack_event)
             self._dgrad_pack_event = None
 
     # -------------------------------------------------------------------------------------------
@@ -497,21 +497,21 @@ class StemEngine:
         o_tp, o_hp = (0, P) if self.has_tpm else (None, 0)
         o_ctx = o_hp + P
         bs = self._branch(dev)
-        main = torch.cuda.current_stream(dev) if bs is not None else None
+        main = F.cur_stream(dev) if bs is not None else None
         if bs is not None:
-            bs.wait_stream(main)
+            F.stream_wait(bs, main)
         # the context model's convolution needs only t_hat (the prologue's output): on a stream of its own, enqueued first so
         # that it runs next to the hyper and TPM chains instead of after them
         pl = {}             # planes copies of activations, kept for the weight gradients
         cs = self._branch(dev, 1) if (bs is not None and self.ctx_branch and fused and self.has_spm and self.has_tpm) else None
         if cs is not None:
-            cs.wait_stream(main)
-            with torch.cuda.stream(cs):
+            F.stream_wait(cs, main)
+            with F.on_stream(cs):
                 self._ctx_forward(t_hat, epm_in[:, o_ctx:o_ctx + P], pl)
             t_hat.record_stream(cs)
             epm_in.record_stream(cs)
         split = F.F16Planes.split
-        with (torch.cuda.stream(bs) if bs is not None else contextlib.nullcontext()):
+        with F.on_stream(bs):
             if self.HE[0].fx3:
                 pl["he_in"] = split(he_in, src_q=_qp(rec.get("in")))
                 he0, he0p = self.HE[0].fwd6(pl["he_in"], F.ACT_LRELU, planes=self.HE[1].fx3s)
@@ -556,11 +556,11 @@ class StemEngine:
             if not fused:
                 t_hat = F.add(target, gc._noise_like(target)) if training else F.round_(target)
             if cs is not None:
-                main.wait_stream(cs)
+                F.stream_wait(main, cs)
             else:
                 self._ctx_forward(t_hat, epm_in[:, o_ctx:o_ctx + P], pl)
         if bs is not None:
-            main.wait_stream(bs)
+            F.stream_wait(main, bs)
         if self.EPM[0].fx3:
             pl["epm_in"] = split(epm_in)
             e0, pl["e0"] = self.EPM[0].fwd6(pl["epm_in"], F.ACT_LRELU, planes=True)
@@ -625,9 +625,9 @@ class StemEngine:
         self._group_ready(self.EPM, [])
         bs = self._branch(gp.device)
         if bs is not None:                # hyper chain (HD -> bottleneck -> HE) on its own stream, next to the TPM chain
-            main = torch.cuda.current_stream(gp.device)
-            bs.wait_stream(main)
-            with torch.cuda.stream(bs):
+            main = F.cur_stream(gp.device)
+            F.stream_wait(bs, main)
+            with F.on_stream(bs):
                 self._backward_hyper(k, dpri, dlik_z, dprip)
         # spatial prior: weight gradient of all 25 taps, no input gradient (its input is data + noise)
         if self.has_spm:
@@ -656,7 +656,7 @@ class StemEngine:
         if bs is None:
             self._backward_hyper(k, dpri, dlik_z, dprip)
         else:
-            main.wait_stream(bs)
+            F.stream_wait(main, bs)
         self.join_side_stream()          # gradients are complete for whatever the compute stream does next
 
     def _ctx_forward(self, t_hat, out, pl):

@@ -112,15 +112,15 @@ def join_wgrad_stream():
     """Order all outstanding side-stream weight-gradient work before whatever the current stream does next."""
     _WGRAD_SIDE["queued"] = False
     for dev, st in _WGRAD_SIDE["streams"].items():
-        torch.cuda.current_stream(dev).wait_stream(st)
+        F.stream_wait(F.cur_stream(dev), st)
     _WGRAD_SIDE["keep"].clear()          # the current stream is now ordered after every reader (see _on_side_stream)
 
 
 def _on_side_stream(fn, *tensors):
     dev = tensors[0].device
     side = wgrad_side_stream(dev)
-    side.wait_stream(torch.cuda.current_stream(dev))
-    with torch.cuda.stream(side):
+    F.stream_wait(side, F.cur_stream(dev))
+    with F.on_stream(side):
         fn()
     for t in tensors:
         t.record_stream(side)            # the allocator must not hand the memory out again before the side stream is done

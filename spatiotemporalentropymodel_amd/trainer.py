@@ -73,7 +73,7 @@ class LatentPrefetcher:
         dev = self._frames[t].device
         if self._stream is None or self._stream.device != dev:
             self._stream = F.make_stream(dev, "latents")
-        with torch.cuda.stream(self._stream), torch.no_grad():
+        with F.on_stream(self._stream), torch.no_grad():
             self._ys[t] = self.imodel.getY(self._frames[t])
             self._events[t] = torch.cuda.Event()
             self._events[t].record(self._stream)
@@ -89,7 +89,7 @@ class LatentPrefetcher:
         if self._stream is None or self._stream.device != dev:
             self._stream = F.make_stream(dev, "latents")
         if not frames_ready:
-            self._stream.wait_stream(torch.cuda.current_stream(dev))      # the frames were produced on the compute stream
+            F.stream_wait(self._stream, F.cur_stream(dev))      # the frames were produced on the compute stream
         self._next = 0
         while self._next < n and self._next <= self.ahead:
             self._enqueue(self._next)
@@ -101,7 +101,7 @@ class LatentPrefetcher:
         while self._next < len(self._frames) and self._next <= t + self.ahead:
             self._enqueue(self._next)
             self._next += 1
-        cur = torch.cuda.current_stream(self._frames[t].device)
+        cur = F.cur_stream(self._frames[t].device)
         cur.wait_event(self._events[t])
         y, yq = self._ys[t]
         y.record_stream(cur)
@@ -118,7 +118,7 @@ class LazyScalar:
         self._v, self._e, self._scale, self._sqrt = value, event, scale, sqrt
 
     def tensor(self):
-        torch.cuda.current_stream(self._v.device).wait_event(self._e)
+        F.cur_stream(self._v.device).wait_event(self._e)
         v = self._v.reshape(())
         return (v.sqrt() if self._sqrt else v) * self._scale if (self._sqrt or self._scale != 1.0) else v
 
@@ -161,9 +161,9 @@ class FusedPFrameStep:
         if reducer is not None:
             reducer.finish() if hasattr(reducer, "finish") else reducer.all_reduce()
         join_wgrad_stream()
-        main = torch.cuda.current_stream(y_hat.device)
+        main = F.cur_stream(y_hat.device)
         if self._aux_pending:                    # the previous step's auxiliary work reads the parameters Adam is about to change
-            main.wait_stream(self._aux_stream)
+            F.stream_wait(main, self._aux_stream)
             self._aux_pending = False
         F.sumsq(opt.flat.grad, opt._sumsq, overwrite=True)
         clean = opt._dev is None and self.clear_grad_in_adam
@@ -174,8 +174,8 @@ class FusedPFrameStep:
         # optimiser's flat buffer (the only aux parameter is `entropy_bottleneck.quantiles`).  One workgroup of latency-bound
         # work on its own stream; the training forward does not read the quantiles, so nothing waits for it until the NEXT
         # optimiser step (above) or until the caller looks at the returned values (LazyScalar).
-        self._aux_stream.wait_stream(main)
-        with torch.cuda.stream(self._aux_stream):
+        F.stream_wait(self._aux_stream, main)
+        with F.on_stream(self._aux_stream):
             gn_copy = opt._sumsq[:1].clone()     # private copies: the persistent buffers are overwritten by the next step
             pack = F.eb_pack(eb._tensors14())
             F.eb_aux_loss_grad(eb.quantiles.detach(), pack, eb.target, eb.quantiles._flat_grad_view, loss_out=self._aux_loss)
@@ -196,5 +196,5 @@ class FusedPFrameStep:
         """order everything the step left on its auxiliary stream before the current stream (end of training, checkpointing,
         evaluation: anything that reads `entropy_bottleneck.quantiles` or the aux optimiser's state)"""
         if self._aux_pending:
-            torch.cuda.current_stream(self._aux_loss.device).wait_stream(self._aux_stream)
+            F.stream_wait(F.cur_stream(self._aux_loss.device), self._aux_stream)
             self._aux_pending = False

@@ -67,4 +67,4 @@ if os.environ.get("STEM_HOST_PROFILE"):
         one_step()
     pr.disable()
     torch.cuda.synchronize()
-    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+    pstats.Stats(pr).sort_stats(os.environ.get("STEM_HOST_PROFILE_SORT", "tottime")).print_stats(int(os.environ.get("STEM_HOST_PROFILE_LINES", "28")))
