@@ -149,3 +149,47 @@ def test_latent_prefetcher_equals_direct_calls():
             assert float((yq - y).abs().max()) <= 0.5
             del scratch
     torch.cuda.synchronize()
+
+
+def test_tuned_schedule_changes_no_result(monkeypatch):
+    """trainer.tuned_schedule (what bench.py runs under: step streams at high priority on a dedicated compute stream, the
+    prefetch stream masked to 192 CUs through hipExtStreamCreateWithCUMask) is scheduling only: three P-frame steps with the
+    latents prefetched give bit-identical parameters, losses and latents with and without it."""
+    from spatiotemporalentropymodel_amd import functional as F
+    from spatiotemporalentropymodel_amd import trainer
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    frames = [torch.rand(2, 3, 128, 128, device=dev, generator=g) for _ in range(4)]
+    results = []
+    for tuned in (False, True):
+        for k in trainer.SCHEDULE_DEFAULTS:
+            monkeypatch.delenv(k, raising=False)
+        if not tuned:
+            for k in trainer.SCHEDULE_DEFAULTS:
+                monkeypatch.setenv(k, "")                     # explicitly none: every stream at one priority, no mask
+        monkeypatch.setattr(F, "_STREAM_PRIO", None)          # parsed again by the next make_stream
+        imodel, stem, opt, aux = _pair(64, 96, 64, 96, False, False)
+        sched = trainer.tuned_schedule(dev)
+        if tuned:
+            assert F._STREAM_PRIO == {"latents": 0, "side": -1, "compute": -1} and F._cu_mask("latents") is not None
+        else:
+            assert F._STREAM_PRIO == {} and F._cu_mask("latents") is None
+        fused = trainer.FusedPFrameStep(stem, opt, aux)
+        pf = trainer.LatentPrefetcher(imodel)
+        losses = []
+        torch.cuda.synchronize()
+        with sched:
+            pf.start(frames, frames_ready=True)
+            y_cond = pf.get(0)[1]
+            for t in range(1, 4):
+                out, oc, aux_l, gn = fused.step(pf.get(t)[0], y_cond, 2 * 128 * 128)
+                losses.append((float(oc["loss"]), float(gn), float(aux_l)))
+                y_cond = out["y_hat"]
+            fused.finish()
+        torch.cuda.synchronize()
+        if tuned:
+            assert isinstance(pf._stream, torch.cuda.ExternalStream)       # the masked stream (hipExtStreamCreateWithCUMask)
+        results.append((opt.flat.data.clone(), aux.flat.data.clone(), y_cond.clone(), losses))
+    a, b = results
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[3] == b[3], (a[3], b[3])
