@@ -98,7 +98,11 @@ def make_stream(device, role):
                 _STREAM_PRIO[k.strip()] = int(v)
     mask = _cu_mask(role)
     if mask is not None:
-        return _masked_stream(device, mask)
+        try:
+            return _masked_stream(device, mask)
+        except (RuntimeError, OSError, AttributeError) as e:      # a scheduling hint, not a result: run unmasked rather than not at all
+            import warnings
+            warnings.warn(f"CU mask for the '{role}' stream not applied ({e}); using an unmasked stream")
     return torch.cuda.Stream(device=device, priority=_STREAM_PRIO.get(role, 0))
 
 
