@@ -95,10 +95,19 @@ __device__ inline int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 // DEPTH 3: three LDS stages -- chunk c + 2 is written while chunk c is multiplied, so the fragments of the NEXT 16-channel step
 //          (the first one of chunk c + 1 included) are read and the LDS stores issued between the MFMAs of the current one; only
 //          the barrier itself is left between two chunks.  120 KB of LDS with 128-pixel tiles (one workgroup per CU either way).
-template <int BM, int DEPTH>
+// MS = rows of the MFMA shape: 32 (v_mfma_f32_32x32x16_f16) or 16 (v_mfma_f32_16x16x32_f16, three-stage loop only): the same
+//      operands, LDS traffic and flop in twice as many instructions of half the size, which the chip runs at a higher clock where a
+//      launch fills it and sits at the power limit (g_a.2: -6 %); smaller launches lose with it (more issue slots), so it is a
+//      second instantiation.  MFMA row (column) m of a 16-block reads image row 4 PI[m >> 2] + (m & 3), PI = 0,2,3,1 -- with the
+//      64-byte-row image and its XOR swizzle that makes the 16-lane groups of ds_read_b128 conflict-free -- so lane l holds
+//      channels 16 nj + 4 PI[(l & 15) >> 2] + (l & 3) and pixel rows 16 mi + 4 PI[l >> 4] + i of the wavefront's 32 x 96 tile.
+__device__ inline int pi4(int x) { return (0x78 >> (2 * x)) & 3; }
+
+template <int BM, int DEPTH, int MS>
 __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
 {
     static_assert(DEPTH == 2 || DEPTH == 3, "two or three LDS stages");
+    static_assert(MS == 32 || (MS == 16 && DEPTH == 3), "the 16-row MFMA shape exists for the three-stage loop");
     constexpr int NSET = 2;                             // register sets (chunks on their way to LDS)
     constexpr int NT = BM * 4;
     constexpr int A_PLANE = BM * 64, A_BUF = NPL * A_PLANE;
@@ -173,6 +182,13 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
     const int sw = (lr >> 2) & 3;                                   // (row >> 2) & 3 of every row this lane reads
     const int rdA = (wm0 + lr) * 64, rdB = (wn0 + lr) * 64;
     const int pk0 = ((0 + lh) ^ sw) << 4, pk1 = ((2 + lh) ^ sw) << 4;
+    // MS == 16 (see the kernel's header)
+    const int l16 = lane & 15, lq = lane >> 4;
+    const int cm = 4 * pi4(l16 >> 2) + (l16 & 3), rq = 4 * pi4(lq);
+    const int rdA16 = (wm0 + cm) * 64 + ((lq ^ pi4(l16 >> 2)) << 4), rdB16 = (wn0 + cm) * 64 + ((lq ^ pi4(l16 >> 2)) << 4);
+    // element (j, r) of this lane's accumulators: local pixel row / local channel inside the workgroup's tile
+    auto ROWL = [&](int r) { return MS == 32 ? wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh : wm0 + ((r >> 2) & 1) * 16 + rq + (r & 3); };
+    auto COLL = [&](int j, int r) { return MS == 32 ? wn0 + j * 32 + lr : wn0 + j * 32 + (r >> 3) * 16 + cm; };
     f32x16 acc[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j)
@@ -267,6 +283,74 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
         if (pf_q < q_last) TAP_WALK_NEXT();
     };
 
+    // MS == 16: a chunk is ONE k-step of the 16x16x32 instruction; its two halves are the channel blocks 0..2 / 3..5 of the
+    // wavefront's 96 columns.  ga[s] = pixel fragments of the chunk in flight (two sets: the next chunk's are read during the
+    // second half), gb0 / gb1 = weight fragments of the two halves.
+    h16x8 ga[2][2][PL], gb0[3][PL], gb1[3][PL];
+    f32x4 a16[2][6];
+    if constexpr (MS == 16) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 6; ++nj) a16[mi][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto lfragA16 = [&](const unsigned char *base, h16x8 (&A)[2][PL]) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) A[mi][pl] = *reinterpret_cast<const h16x8 *>(base + rdA16 + mi * 16 * 64 + pl * A_PLANE);
+    };
+    auto lfragB16 = [&](const unsigned char *base, int half, h16x8 (&B)[3][PL]) {
+#pragma unroll
+        for (int n3 = 0; n3 < 3; ++n3)
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) B[n3][pl] = *reinterpret_cast<const h16x8 *>(base + rdB16 + (half * 3 + n3) * 16 * 64 + pl * B_PLANE);
+    };
+    auto mma18 = [&](h16x8 (&A)[2][PL], h16x8 (&B)[3][PL], int half, f32x4 (&d)[2][6]) {
+        // smallest terms first; the six accumulators of a product follow each other (independent instructions back to back)
+#pragma unroll
+        for (int prod = 0; prod < 3; ++prod)
+#pragma unroll
+            for (int n3 = 0; n3 < 3; ++n3)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    d[mi][half * 3 + n3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[mi][prod == 0 ? 1 : 0], B[n3][prod == 1 ? 1 : 0],
+                                                                                   d[mi][half * 3 + n3], 0, 0, 0);
+    };
+    auto step3_16 = [&](int rd, int nx, int wr, f32x4 (&ra)[PL], f32x4 (&rb)[BP], h16x8 (&Acur)[2][PL], h16x8 (&Anext)[2][PL]) {
+        const int t = __builtin_amdgcn_readfirstlane(pf_t), kc = __builtin_amdgcn_readfirstlane(pf_kc), q = __builtin_amdgcn_readfirstlane(pf_q);
+        const int to = __builtin_amdgcn_readfirstlane(pf_to);
+        lfragB16(Bs + rd * B_BUF, 1, gb1);
+        mma18(Acur, gb0, 0, a16);
+        sstore(wr, ra, rb);
+        lfragA16(As + nx * A_BUF, Anext);
+        lfragB16(Bs + nx * B_BUF, 0, gb0);
+        mma18(Acur, gb1, 1, a16);
+        gload(t, to, kc, q, ra, rb);
+        // issue order: 18 MFMAs + 6 LDS reads, then 18 MFMAs + the stores + 10 reads, the global loads last
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        constexpr int NW = PL + BP;
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, (NW + 3) / 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, (NW + 2) / 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, (NW + 1) / 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, NW / 4, 0);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, PL + BP, 0);
+        if (pf_q < q_last) TAP_WALK_NEXT();
+    };
+
     // chunk q = kc * ntaps + t (channel slab outer, taps inner: the taps of one slab re-touch the same input lines)
     auto chunk_of = [&](int q, int &t, int &kc) {
         q = q < q_last ? q : q_last;
@@ -317,7 +401,28 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
         if (blockIdx.x == 0 && tid == 0) a.yq[1] = q_pow2(-oe);
     }
     __syncthreads();
-    if constexpr (DEPTH == 3) {
+    if constexpr (MS == 16) {
+        int rd = 0, nx = 1, wr = 2;
+        lfragA16(As, ga[0]);
+        lfragB16(Bs, 0, gb0);
+        int q = 0;
+        for (; q + 1 < nchunks; q += 2) {
+            step3_16(rd, nx, wr, rsa[0], rsb[0], ga[0], ga[1]);
+            __syncthreads();
+            step3_16(nx, wr, rd, rsa[1], rsb[1], ga[1], ga[0]);
+            __syncthreads();
+            const int o = rd;
+            rd = wr; wr = nx; nx = o;
+        }
+        if (q < nchunks) {
+            step3_16(rd, nx, wr, rsa[0], rsb[0], ga[0], ga[1]);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = a16[(r >> 2) & 1][2 * j + (r >> 3)][r & 3];
+    } else if constexpr (DEPTH == 3) {
         int rd = 0, nx = 1, wr = 2;
         lfrag(0, pk0, f0a, f0b);
         int q = 0;
@@ -349,15 +454,20 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
         }
     }
 
-    // ---- epilogue: lane holds column n = wn0 + 32 j + lr, rows (r & 3) + 8 (r >> 2) + 4 lh of each 32x32 tile ---------------
+    // ---- epilogue: element (j, r) of the lane is local pixel row ROWL(r), local channel COLL(j, r) (MS == 32: column
+    // wn0 + 32 j + lr, rows (r & 3) + 8 (r >> 2) + 4 lh of each 32x32 tile; MS == 16: two channels per j, selected by r >> 3) ---
     float *X2 = reinterpret_cast<float *>(smem);                   // [BM][XP]
     float omax = 0.f;                                              // max |output| of this thread
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int n = wn0 + j * 32 + lr;
-        const float bias = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+        float bias2[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = acc[j][r] * fac + bias;
+        for (int h = 0; h < 2; ++h) {
+            const int n = COLL(j, h * 8);
+            bias2[h] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = acc[j][r] * fac + bias2[r >> 3];
         if (a.epi == 1) {          // leaky ReLU (slope 0 = ReLU) of a conv + activation pair (layer-wise models)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = acc[j][r] > 0.f ? acc[j][r] : acc[j][r] * a.slope;
@@ -387,11 +497,11 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
             if (slab >= nkg) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = ROWL(r), c = COLL(j, r) & 31;                 // channel inside the 32-channel slab
                 const float t = acc[j][r] * vs;
                 hp_t h0, h1;
                 q_split(t * t, 1.f, h0, h1);
-                unsigned char *d = Sq + slab * (NPL * A_PLANE) + m * 64 + ((((lr >> 3) ^ ((m >> 2) & 3)) << 4) | ((lr & 7) << 1));
+                unsigned char *d = Sq + slab * (NPL * A_PLANE) + m * 64 + ((((c >> 3) ^ ((m >> 2) & 3)) << 4) | ((c & 7) << 1));
                 *reinterpret_cast<hp_t *>(d) = h0;
                 *reinterpret_cast<hp_t *>(d + A_PLANE) = h1;
             }
@@ -401,6 +511,11 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) nrm[j][r] = 0.f;
+        f32x4 n16[2][6];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 6; ++nj) n16[mi][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
         const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.gp), 0, a.gbytes, 0x00020000);
         f32x4 gb[BP];
         auto gload_g = [&](int kc) {
@@ -416,6 +531,15 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
             if (BP > WFULL && WFULL * NT + tid < WPIECES) *reinterpret_cast<f32x4 *>(Bg + (WFULL * NT + tid) * 16) = gb[BP - 1];
             __syncthreads();
             if (kc + 1 < nkg) gload_g(kc + 1);
+            if constexpr (MS == 16) {
+                h16x8 A[2][PL], B0[3][PL], B1[3][PL];
+                lfragA16(Sq + kc * (NPL * A_PLANE), A);
+                lfragB16(Bg, 0, B0);
+                lfragB16(Bg, 1, B1);
+                mma18(A, B0, 0, n16);
+                mma18(A, B1, 1, n16);
+                continue;
+            }
             const unsigned char *Ab = Sq + kc * (NPL * A_PLANE) + rdA, *Bb = Bg + rdB;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -435,28 +559,36 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
                 }
             }
         }
+        if constexpr (MS == 16) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nrm[j][r] = n16[(r >> 2) & 1][2 * j + (r >> 3)][r & 3];
+        }
         const float gfac = q_inv(a.gq);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int n = wn0 + j * 32 + lr;
-            float bt = 1.f;
-            if (n < a.N) {
-                const float bb = fmaxf(a.beta[n], a.beta_bound);
-                bt = bb * bb - 1.4551915228366852e-11f;
+            float bt2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = COLL(j, h * 8);
+                bt2[h] = 1.f;
+                if (n < a.N) {
+                    const float bb = fmaxf(a.beta[n], a.beta_bound);
+                    bt2[h] = bb * bb - 1.4551915228366852e-11f;
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] *= __builtin_amdgcn_rsqf(nrm[j][r] * gfac * vsi * vsi + bt);
+            for (int r = 0; r < 16; ++r) acc[j][r] *= __builtin_amdgcn_rsqf(nrm[j][r] * gfac * vsi * vsi + bt2[r >> 3]);
         }
         __syncthreads();                                   // the parked squares are free (the planes pass reuses the front of LDS)
     }
     if (a.yq) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const bool okn = wn0 + j * 32 + lr < a.N;
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (okn && bm0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh < Mtot) omax = fmaxf(omax, fabsf(acc[j][r]));
-        }
+                if (COLL(j, r) < a.N && bm0 + ROWL(r) < Mtot) omax = fmaxf(omax, fabsf(acc[j][r]));
         omax = block_max(omax, qred);
         if (tid == 0) {
             a.yq[QREC_HDR + blockIdx.x] = omax;
@@ -469,21 +601,19 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
 
     if (a.y) {      // fp32 NHWC output (last layer of the transform)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int n = wn0 + j * 32 + lr;
+        for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = bm0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = bm0 + ROWL(r), n = COLL(j, r);
                 if (m < Mtot && n < a.N) a.y[(size_t)m * a.ldy + n] = acc[j][r];
             }
-        }
     }
     if (a.yp) {     // planes output for the next convolution: through LDS so that every thread stores whole 16-byte pieces
         __syncthreads();                                   // the parked tile / the main-loop buffers are free
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) X2[(wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * XP + wn0 + j * 32 + lr] = acc[j][r];
+            for (int r = 0; r < 16; ++r) X2[ROWL(r) * XP + COLL(j, r)] = acc[j][r];
         __syncthreads();
         const int oslab = a.N / KC, opix = oslab * SLAB;
         unsigned char *yp = static_cast<unsigned char *>(a.yp);
@@ -1259,10 +1389,12 @@ static int conv2d_f16x3_launch(const void *xp, const float *xq, const void *wp, 
         }
     static bool attr_done = false;      // > 64 KiB of dynamic LDS needs an explicit opt-in
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128, 2));
-        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128, 3));
-        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<64, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64, 2));
-        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64, 3));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<128, 2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128, 2));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<128, 3, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128, 3));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<128, 3, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(128, 3));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<64, 2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64, 2));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<64, 3, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64, 3));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_kernel<64, 3, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_total(64, 3));
         attr_done = true;
     }
     const int M = B * OH * OW;
@@ -1275,14 +1407,22 @@ static int conv2d_f16x3_launch(const void *xp, const float *xq, const void *wp, 
     // for ONE such workgroup per CU, and layers with 256 .. 511 tiles (g_a.4) run two per CU next to other streams' work
     const int dsel = stem_tuning(STEM_TUNE_FX3_DEPTH);
     const int depth = dsel ? dsel : (small ? 2 : 3);
-    if (small && depth == 3)
-        hipLaunchKernelGGL((conv_f16x3_kernel<64, 3>), dim3(cdiv(M, 64)), dim3(256), lds_total(64, 3), st, a);
+    // MFMA shape (see the kernel): 16x16x32 where the launch fills the chip with 128-pixel tiles and runs the three-stage loop,
+    // 32x32x16 otherwise; stem_tuning_set("fx3_mfma", 16 | 32) forces it where the loop form allows
+    const int msel = stem_tuning(STEM_TUNE_FX3_MFMA);
+    const bool m16 = depth == 3 && (msel ? msel == 16 : !small);
+    if (small && m16)
+        hipLaunchKernelGGL((conv_f16x3_kernel<64, 3, 16>), dim3(cdiv(M, 64)), dim3(256), lds_total(64, 3), st, a);
+    else if (small && depth == 3)
+        hipLaunchKernelGGL((conv_f16x3_kernel<64, 3, 32>), dim3(cdiv(M, 64)), dim3(256), lds_total(64, 3), st, a);
     else if (small)
-        hipLaunchKernelGGL((conv_f16x3_kernel<64, 2>), dim3(cdiv(M, 64)), dim3(256), lds_total(64, 2), st, a);
+        hipLaunchKernelGGL((conv_f16x3_kernel<64, 2, 32>), dim3(cdiv(M, 64)), dim3(256), lds_total(64, 2), st, a);
+    else if (m16)
+        hipLaunchKernelGGL((conv_f16x3_kernel<128, 3, 16>), dim3(cdiv(M, 128)), dim3(512), lds_total(128, 3), st, a);
     else if (depth == 3)
-        hipLaunchKernelGGL((conv_f16x3_kernel<128, 3>), dim3(cdiv(M, 128)), dim3(512), lds_total(128, 3), st, a);
+        hipLaunchKernelGGL((conv_f16x3_kernel<128, 3, 32>), dim3(cdiv(M, 128)), dim3(512), lds_total(128, 3), st, a);
     else
-        hipLaunchKernelGGL((conv_f16x3_kernel<128, 2>), dim3(cdiv(M, 128)), dim3(512), lds_total(128, 2), st, a);
+        hipLaunchKernelGGL((conv_f16x3_kernel<128, 2, 32>), dim3(cdiv(M, 128)), dim3(512), lds_total(128, 2), st, a);
     STEM_LAUNCH_CHECK("stem_conv2d_f16x3_fwd");
     return 0;
 }

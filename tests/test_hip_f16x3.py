@@ -79,14 +79,15 @@ CASES = [  # B, C, H, W, K, R, stride
 
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("tile128", [False, True])
-@pytest.mark.parametrize("stages", [2, 3])
+@pytest.mark.parametrize("loop", [(2, 32), (3, 32), (3, 16)], ids=["2stage", "3stage", "3stage-mfma16"])
 @pytest.mark.parametrize("gdn", [False, True])
-def test_conv_gdn_vs_oracle(F, case, tile128, stages, gdn):
-    """conv (+ fused GDN) against the oracle, both workgroup tiles (64 pixels x 4 wavefronts, 128 pixels x 8 wavefronts) and both
-    main-loop forms (two / three LDS stages: a 1x1 case has fewer chunks than the three-stage prologue loads), fp32 and planes
-    output; ragged pixel counts and channel counts below the 192-wide tile."""
+def test_conv_gdn_vs_oracle(F, case, tile128, loop, gdn):
+    """conv (+ fused GDN) against the oracle, both workgroup tiles (64 pixels x 4 wavefronts, 128 pixels x 8 wavefronts), the
+    main-loop forms (two / three LDS stages: a 1x1 case has fewer chunks than the three-stage prologue loads) and both MFMA shapes
+    (32x32x16, 16x16x32 with its permuted accumulator layout through every epilogue), fp32 and planes output; ragged pixel
+    counts and channel counts below the 192-wide tile."""
     B, C, H, W, K, R, st = case
-    with F.tuning(fx3_tile=128 if tile128 else 64, fx3_depth=stages):
+    with F.tuning(fx3_tile=128 if tile128 else 64, fx3_depth=loop[0], fx3_mfma=loop[1]):
         _conv_gdn_vs_oracle(F, case, gdn)
 
 

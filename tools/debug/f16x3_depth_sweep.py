@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""g_a.2 / g_a.4 / g_a.6-sized launches of the 192-column kernel (+ fused GDN, planes out) per pixel tile and main-loop form (fx3_depth: LDS stages)."""
+"""g_a.2 / g_a.4 / g_a.6-sized launches of the 192-column kernel (+ fused GDN, planes out) per pixel tile, main-loop form (fx3_depth: LDS stages) and MFMA shape (fx3_mfma)."""
 import os
 import sys
 
@@ -34,8 +34,8 @@ for name, H in (("g_a.2", 128), ("g_a.4", 64), ("g_a.6", 32)):
     xp, wp, gp = F.F16Planes.split(x), F.pack_weight_f16x2(w), F.pack_gdn_gamma_f16x2(gamma)
     line = f"{name} ({B}x{H}x{H}):"
     for tile in (64, 128):
-        for depth in (2, 3):
-            with F.tuning(fx3_tile=tile, fx3_depth=depth):
+        for depth, mfma in ((2, 32), (3, 32), (3, 16)):
+            with F.tuning(fx3_tile=tile, fx3_depth=depth, fx3_mfma=mfma):
                 t = timeit(lambda: F.conv2d_f16x3_fwd(xp, wp, b, K, 5, 5, 2, 2, beta=beta, gamma=gamma, planes_out=True, gp=gp))
-            line += f"   tile {tile} depth {depth}: {t:6.1f} us"
+            line += f"   tile {tile} stages {depth} mfma {mfma}: {t:6.1f} us"
     print(line)
