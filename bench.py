@@ -41,7 +41,7 @@ GA0_FLOP_PER_FRAME = 2 * 192 * 3 * 25 * 128 * 128 + 2 * 192 * 192 * 128 * 128   
 # useful (algorithmic) flop of one bench step: 187.1 GF per septuplet (7 x g_a 11.966 GF + 6 P-frame steps of
 # 17.228 GF = STEM forward 6.418 + weight gradients 6.418 + input gradients 4.392), 16 septuplets per GPU
 USEFUL_FLOP_PER_STEP = 187.1e9 * BATCH
-PEAK_F16_MFMA_TFLOPS = 2516.6        # same guide: v_mfma_f32_32x32x16_f16 (the fp16 form's cycles), 1024 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz (dense)
+PEAK_F16_MFMA_TFLOPS = 2516.6        # same guide: v_mfma_f32_32x32x16_f16 / 16x16x32 (equal flop per cycle), 1024 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz (dense)
 F16_PRODUCTS = 3                     # fp16 MFMA products per fp32 product in the split-operand kernels (csrc/stem_common.h)
 
 
@@ -564,7 +564,7 @@ def main():
         executed = F16_PRODUCTS * GA2_FLOP_PER_FRAME * BATCH        # convolution and the fused GDN contraction, both on the fp16 instruction
         in_ms = kern_ms_overlap if prefetch is not None else kern_ms
         roof = {"bound": "mfma", "kernel": "conv_f16x3_kernel<128> = g_a.2 conv (192->192, 5x5 s2, 128^2->64^2, B=16) + fused GDN g_a.3: operands "
-                                           "pre-split into 2 scaled fp16 planes, 3 x v_mfma_f32_32x32x16_f16 per fp32 product, fp32 accumulate",
+                                           "pre-split into 2 scaled fp16 planes, 3 fp16 MFMAs (v_mfma_f32_16x16x32_f16 in this launch) per fp32 product, fp32 accumulate",
                 "achieved": executed / (in_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": executed / (in_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
                 "flop_per_launch": executed, "flop_definition": "executed fp16 MFMA flop = 3 x algorithmic flop of the convolution and of the fused GDN contraction",
