@@ -12,6 +12,7 @@ from spatiotemporalentropymodel_amd.weights import closed_form_fill_  # noqa: E4
 from spatiotemporalentropymodel_amd.zoo import models  # noqa: E402
 
 dev = torch.device("cuda:0")
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16      # 16 = the bench batch: the split-operand chain with its 128-pixel tiles (below 12288 output pixels a layer stays on fp32)
 
 
 def ga64(imodel, x):
@@ -35,12 +36,12 @@ for fill in ("closed_form", "default_init"):
     imodel = imodel.to(dev).eval()
     yy, xx = torch.meshgrid(torch.arange(256, device=dev), torch.arange(256, device=dev), indexing="ij")
     x = torch.stack([torch.stack([0.5 + 0.4 * torch.sin((xx + 17 * g) / (9.0 + 3 * c + g)) * torch.cos(yy / (7.0 - c)) for c in range(3)])
-                     for g in range(2)]) + 0.05 * torch.rand(2, 3, 256, 256, device=dev)
+                     for g in range(B)]) + 0.05 * torch.rand(B, 3, 256, 256, device=dev)
     x = x.clamp(0, 1)
     ref = ga64(imodel, x)
     scale = float(ref.abs().max())
     rms = float(ref.pow(2).mean().sqrt())
-    print(f"{fill}: max|y| {scale:.3f} rms {rms:.3f}")
+    print(f"{fill} (B = {B}): max|y| {scale:.3f} rms {rms:.3f}")
     for name, env in (("fp32-MFMA", {"STEM_F16X3": "0"}), ("fp16 x3", {})):
         os.environ.pop("STEM_F16X3", None)
         os.environ.update(env)
