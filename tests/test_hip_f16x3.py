@@ -522,3 +522,17 @@ def test_random_shapes_through_all_three_kernels():
     import f16x3_fuzz
     worst = f16x3_fuzz.run(40, 7, verbose=False)
     assert worst <= 1e-5, worst
+
+
+@pytest.mark.parametrize("plan", [dict(fx3_tile=128, fx3_depth=3, fx3_mfma=16, fx3_gen_tile=128), dict(fx3_tile=64, fx3_depth=3, fx3_mfma=16),
+                                  dict(fx3_tile=128, fx3_depth=3, fx3_mfma=32, fx3_gen_tile=64)],
+                         ids=["tile128-3stage-mfma16", "tile64-3stage-mfma16", "tile128-3stage-mfma32"])
+def test_random_shapes_under_forced_plans(F, plan):
+    """the same fuzz with the plan selectors forced to the forms the library only picks for large launches (three LDS stages,
+    the 16x16x32 MFMA shape and its permuted accumulator layout, 128-pixel tiles): ragged tiles, partial channel blocks, every
+    epilogue"""
+    sys.path.insert(0, os.path.join(REPO, "tools", "debug"))
+    import f16x3_fuzz
+    with F.tuning(**plan):
+        worst = f16x3_fuzz.run(24, 11, verbose=False)
+    assert worst <= 1e-5, worst
