@@ -1399,9 +1399,12 @@ static int conv2d_f16x3_launch(const void *xp, const float *xq, const void *wp, 
     }
     const int M = B * OH * OW;
     hipStream_t st = (hipStream_t)stream;
-    // 128-pixel tiles (8 wavefronts) when they fill the 256 CUs at least once, 64-pixel tiles (4 wavefronts) below that
+    // 128-pixel tiles (8 wavefronts) when there is one for at least half of the 256 CUs, 64-pixel tiles (4 wavefronts) below
+    // that.  Alone, 64-pixel tiles are faster up to 255 tiles (g_a.4 at B=16, 128 tiles: 127 against 140 us); next to other
+    // streams' work -- where such a launch runs in the training step -- one workgroup per CU on half the chip beats two small
+    // ones per CU everywhere (bench step 15.46-15.54 -> 15.27-15.33 ms), so the threshold follows the loaded machine.
     const int tile = stem_tuning(STEM_TUNE_FX3_TILE);
-    const bool small = tile ? tile == 64 : cdiv(M, 128) < 256;
+    const bool small = tile ? tile == 64 : cdiv(M, 128) < 128;
     // main-loop form (see the kernel): stem_tuning_set("fx3_depth", 2 | 3); 0 = default
     // default: three stages with 128-pixel tiles (g_a.2 365 -> 357 us), two with 64-pixel tiles -- 96 KB of LDS would leave room
     // for ONE such workgroup per CU, and layers with 256 .. 511 tiles (g_a.4) run two per CU next to other streams' work
