@@ -13,7 +13,6 @@ producing convolution (forward) and into the consuming dgrad's epilogue (backwar
 """
 from __future__ import annotations
 
-import contextlib
 import os
 
 import torch
