@@ -651,15 +651,20 @@ constexpr int GBN = 128;
 constexpr int GB_PLANE = GBN * 64, GB_BUF = NPL * GB_PLANE;          // 16384
 constexpr int GTP = GBN + 4;                                         // fp32 pitch of the epilogue tile
 // LDS of a GBM-pixel tile: main loop 2 x (GBM + 128) rows x 64 B x NPL planes, reused by the GBM x 132 float epilogue tile; + tap table
+// 16x16x32 by default: alone the STEM layers are 0-8 % slower with it (more issue slots), inside the training step -- a loaded,
+// power-limited chip -- the step is 0.2 ms faster
+constexpr bool GEN_DEFAULT_MFMA16 = true;
 constexpr int glds_main(int gbm) { return 2 * NPL * (gbm + GBN) * 64 > gbm * GTP * 4 ? 2 * NPL * (gbm + GBN) * 64 : gbm * GTP * 4; }
 constexpr int glds(int gbm) { return glds_main(gbm) + 32 * 4; }          // 49280 (64 pixels: three workgroups per CU) / 67712 (128: two)
 
 // GBM = pixels per workgroup: 64 (4 wavefronts as 2 x 2) or 128 (8 wavefronts as 4 x 2).  The weight tile of a chunk (16 KB) is
 // fetched once per workgroup: with three products per fp32 product the 64-pixel form is bound by that L2 -> LDS traffic
 // (24 KB per chunk for 1.6 MF), the 128-pixel form moves 32 KB for twice the work.
-template <int GBM>
+// MS = rows of the MFMA shape (see conv_f16x3_kernel): 32, or 16 = v_mfma_f32_16x16x32_f16 with the permuted accumulator layout
+template <int GBM, int MS>
 __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Args a)
 {
+    static_assert(MS == 32 || MS == 16, "MFMA shape");
     constexpr int GNT = GBM * 4, GA_PLANE = GBM * 64, GA_BUF = NPL * GA_PLANE;
     constexpr int PL = NPL, BPC = NPL * GBN * 4 / GNT;         // planes; 16-byte weight pieces per thread and chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -720,6 +725,12 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
     const int sw = (lr >> 2) & 3;
     const int rdA = (wm0 + lr) * 64, rdB = (wn0 + lr) * 64;
     const int pk0 = ((0 + lh) ^ sw) << 4, pk1 = ((2 + lh) ^ sw) << 4;
+    // MS == 16: lane l holds channels 16 nj + cm and pixel rows 16 mi + rq + i of the wavefront's 32 x 64 tile
+    const int l16 = lane & 15, lq = lane >> 4;
+    const int cm = 4 * pi4(l16 >> 2) + (l16 & 3), rq = 4 * pi4(lq);
+    const int rdA16 = (wm0 + cm) * 64 + ((lq ^ pi4(l16 >> 2)) << 4), rdB16 = (wn0 + cm) * 64 + ((lq ^ pi4(l16 >> 2)) << 4);
+    auto ROWL = [&](int r) { return MS == 32 ? wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh : wm0 + ((r >> 2) & 1) * 16 + rq + (r & 3); };
+    auto COLL = [&](int j, int r) { return MS == 32 ? wn0 + j * 32 + lr : wn0 + j * 32 + (r >> 3) * 16 + cm; };
     f32x16 acc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -753,6 +764,40 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
             else
                 gload(t, to, kc, q, ra, rb);
         }
+        if (pf_q < q_last) TAP_WALK_NEXT();
+    };
+    // MS == 16: a chunk is one k-step of the 16x16x32 instruction; 2 x 4 accumulators of four registers, the eight independent
+    // accumulators of a product back to back
+    f32x4 a16[2][4];
+    if constexpr (MS == 16) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj) a16[mi][nj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto step16 = [&](int cur, f32x4 (&ra)[PL], f32x4 (&rb)[BPC]) {
+        const unsigned char *Ab = As + cur * GA_BUF + rdA16, *Bb = Bs + cur * GB_BUF + rdB16;
+        const int t = __builtin_amdgcn_readfirstlane(pf_t), kc = __builtin_amdgcn_readfirstlane(pf_kc), q = __builtin_amdgcn_readfirstlane(pf_q);
+        const int to = __builtin_amdgcn_readfirstlane(pf_to);
+        h16x8 A[2][PL], B[4][PL];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) A[mi][pl] = *reinterpret_cast<const h16x8 *>(Ab + mi * 16 * 64 + pl * GA_PLANE);
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl) B[nj][pl] = *reinterpret_cast<const h16x8 *>(Bb + nj * 16 * 64 + pl * GB_PLANE);
+#pragma unroll
+        for (int prod = 0; prod < 3; ++prod) {          // smallest terms first
+#pragma unroll
+            for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    a16[mi][nj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[mi][prod == 0 ? 1 : 0], B[nj][prod == 1 ? 1 : 0], a16[mi][nj], 0, 0, 0);
+            if (prod == 0) sstore(cur ^ 1, ra, rb);
+        }
+        gload(t, to, kc, q, ra, rb);
         if (pf_q < q_last) TAP_WALK_NEXT();
     };
     // A wavefront whose 64 columns lie entirely beyond N (the second column pair of the last tile of a 320-channel layer: a
@@ -801,7 +846,23 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.yq[1] = q_pow2(-oe);
     }
     __syncthreads();
-    if (!dead) {
+    if (!dead && MS == 16) {
+        int q = q_begin;
+        for (; q + 1 < q_end; q += 2) {
+            step16(0, raA, rbA);
+            __syncthreads();
+            step16(1, raB, rbB);
+            __syncthreads();
+        }
+        if (q < q_end) {
+            step16(0, raA, rbA);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = a16[(r >> 2) & 1][2 * j + (r >> 3)][r & 3];
+    } else if (!dead) {
         int q = q_begin;
         for (; q + 1 < q_end; q += 2) {
             step(0, raA, rbA);
@@ -834,10 +895,9 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
         float *wsp = a.ws + (size_t)zsplit * Mtot * Npad;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int n = bn0 + wn0 + j * 32 + lr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = bm0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = bm0 + ROWL(r), n = bn0 + COLL(j, r);
                 if (m < Mtot) __hip_atomic_store(&wsp[(size_t)m * Npad + n], acc[j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -879,7 +939,7 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) T[(wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * GTP + wn0 + j * 32 + lr] = acc[j][r];
+            for (int r = 0; r < 16; ++r) T[ROWL(r) * GTP + COLL(j, r)] = acc[j][r];
     }
     __syncthreads();
     float omax = 0.f;
@@ -1583,15 +1643,23 @@ STEM_EXPORT int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int x
     }
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void *)conv_f16x3_gen_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, glds(64));
-        (void)hipFuncSetAttribute((const void *)conv_f16x3_gen_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, glds(128));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_gen_kernel<64, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, glds(64));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_gen_kernel<128, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, glds(128));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_gen_kernel<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, glds(64));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_gen_kernel<128, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, glds(128));
         attr_done = true;
     }
     const dim3 grid(cdiv(M, bm), ntn, a.nsplit);
-    if (bm == 128)
-        hipLaunchKernelGGL(conv_f16x3_gen_kernel<128>, grid, dim3(512), glds(128), (hipStream_t)stream, a);
+    const int gmsel = stem_tuning(STEM_TUNE_FX3_GEN_MFMA);         // MFMA shape: stem_tuning_set("fx3_gen_mfma", 16 | 32); 0 = default
+    const bool g16 = gmsel ? gmsel == 16 : GEN_DEFAULT_MFMA16;
+    if (bm == 128 && g16)
+        hipLaunchKernelGGL((conv_f16x3_gen_kernel<128, 16>), grid, dim3(512), glds(128), (hipStream_t)stream, a);
+    else if (bm == 128)
+        hipLaunchKernelGGL((conv_f16x3_gen_kernel<128, 32>), grid, dim3(512), glds(128), (hipStream_t)stream, a);
+    else if (g16)
+        hipLaunchKernelGGL((conv_f16x3_gen_kernel<64, 16>), grid, dim3(256), glds(64), (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(conv_f16x3_gen_kernel<64>, grid, dim3(256), glds(64), (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv_f16x3_gen_kernel<64, 32>), grid, dim3(256), glds(64), (hipStream_t)stream, a);
     STEM_LAUNCH_CHECK("stem_conv2d_f16x3_gen_fwd");
     return 0;
 }

@@ -25,7 +25,7 @@ STEM_EXPORT int stem_built_with_experiments(void)
 }
 
 static int g_tuning[STEM_TUNE_COUNT] = {0};
-static const char *const kTuningNames[STEM_TUNE_COUNT] = {"fx3_tile", "fx3_split", "wg3_split", "arp_workers", "fx3_depth", "fx3_gen_tile", "fx3_mfma"};
+static const char *const kTuningNames[STEM_TUNE_COUNT] = {"fx3_tile", "fx3_split", "wg3_split", "arp_workers", "fx3_depth", "fx3_gen_tile", "fx3_mfma", "fx3_gen_mfma"};
 int stem_tuning(int id) { return g_tuning[id]; }
 STEM_EXPORT int stem_tuning_set(const char *name, int value)
 {
@@ -35,11 +35,12 @@ STEM_EXPORT int stem_tuning_set(const char *name, int value)
             STEM_CHECK_ARG(i != STEM_TUNE_FX3_TILE || value == 0 || value == 64 || value == 128, "stem_tuning_set: fx3_tile is 0 (automatic), 64 or 128");
             STEM_CHECK_ARG(i != STEM_TUNE_FX3_GEN_TILE || value == 0 || value == 64 || value == 128, "stem_tuning_set: fx3_gen_tile is 0 (automatic), 64 or 128");
             STEM_CHECK_ARG(i != STEM_TUNE_FX3_DEPTH || value == 0 || value == 2 || value == 3, "stem_tuning_set: fx3_depth is 0 (automatic), 2 or 3 (LDS stages of the split-operand main loops)");
+            STEM_CHECK_ARG(i != STEM_TUNE_FX3_GEN_MFMA || value == 0 || value == 16 || value == 32, "stem_tuning_set: fx3_gen_mfma is 0 (automatic), 16 or 32 (rows of the general kernel's MFMA shape)");
             STEM_CHECK_ARG(i != STEM_TUNE_FX3_MFMA || value == 0 || value == 16 || value == 32, "stem_tuning_set: fx3_mfma is 0 (automatic), 16 or 32 (rows of the MFMA shape)");
             g_tuning[i] = value;
             return 0;
         }
-    stem_set_error("stem_tuning_set: unknown selector '%s' (fx3_tile, fx3_split, wg3_split, arp_workers, fx3_depth, fx3_gen_tile, fx3_mfma)", name);
+    stem_set_error("stem_tuning_set: unknown selector '%s' (fx3_tile, fx3_split, wg3_split, arp_workers, fx3_depth, fx3_gen_tile, fx3_mfma, fx3_gen_mfma)", name);
     return -1;
 }
 STEM_EXPORT int stem_tuning_get(const char *name)

@@ -39,7 +39,7 @@ static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 // Plan selectors (a tile shape, a split factor: every choice computes the same contraction, differing at most in summation
 // order) are integers set through the exported stem_tuning_set() -- tests and sweep tools use them; nothing reads the
 // environment per launch.
-enum { STEM_TUNE_FX3_TILE = 0, STEM_TUNE_FX3_SPLIT, STEM_TUNE_WG3_SPLIT, STEM_TUNE_ARP_WORKERS, STEM_TUNE_FX3_DEPTH, STEM_TUNE_FX3_GEN_TILE, STEM_TUNE_FX3_MFMA, STEM_TUNE_COUNT };
+enum { STEM_TUNE_FX3_TILE = 0, STEM_TUNE_FX3_SPLIT, STEM_TUNE_WG3_SPLIT, STEM_TUNE_ARP_WORKERS, STEM_TUNE_FX3_DEPTH, STEM_TUNE_FX3_GEN_TILE, STEM_TUNE_FX3_MFMA, STEM_TUNE_FX3_GEN_MFMA, STEM_TUNE_COUNT };
 int stem_tuning(int id);
 // Switches that CHANGE RESULTS (ablated kernel stages, instrumentation) exist only in a library built with
 // -DSTEM_EXPERIMENTS (`make experiments` -> libstem_hip_exper.so, for tools/debug): in the shipped library the macro below is

@@ -231,11 +231,13 @@ GEN_CASES = [  # B, C, H, W, K, R
 @pytest.mark.parametrize("case", GEN_CASES)
 @pytest.mark.parametrize("split", [0, 1, 3])
 @pytest.mark.parametrize("tile", [0, 64, 128])
-def test_gen_forward_and_input_gradient_vs_oracle(F, case, split, tile):
+@pytest.mark.parametrize("mfma", [32, 16])
+def test_gen_forward_and_input_gradient_vs_oracle(F, case, split, tile, mfma):
     """forward + leaky ReLU and input-gradient x leaky-ReLU derivative (what autograd derives for conv(lrelu(u))) against the
-    oracle, with the planner's split-K factor (0), unsplit (1) and a forced 3-way split, and with the library's pixel tile (0),
-    64-pixel (4 wavefronts) and 128-pixel (8 wavefronts) workgroups; planes output = fp32 output."""
-    with F.tuning(fx3_split=split, fx3_gen_tile=tile):
+    oracle, with the planner's split-K factor (0), unsplit (1) and a forced 3-way split, with the library's pixel tile (0),
+    64-pixel (4 wavefronts) and 128-pixel (8 wavefronts) workgroups, and with both MFMA shapes (32x32x16; 16x16x32 with its
+    permuted accumulator layout through the split-K slabs and the epilogue tile); planes output = fp32 output."""
+    with F.tuning(fx3_split=split, fx3_gen_tile=tile, fx3_gen_mfma=mfma):
         _gen_forward_and_input_gradient(F, case, split)
 
 
@@ -336,10 +338,10 @@ def test_masked_convolution_on_the_general_kernel(F, mask_type, R):
     wd = dev(w)
     wp = F.pack_weight_f16x2_gen(wd, taps=taps)
     assert np.array_equal(host(wd), w * mask)                        # zeroed in place, live taps untouched
-    for tile in (64, 128):
-        with F.tuning(fx3_gen_tile=tile):
+    for tile, mfma in ((64, 32), (128, 32), (64, 16), (128, 16)):
+        with F.tuning(fx3_gen_tile=tile, fx3_gen_mfma=mfma):
             y, _ = F.conv2d_f16x3_gen(F.F16Planes.split(dev(x)), wp, dev(b), K, R, R, 1, R // 2, taps=taps)
-        assert_close(host(y), orc.conv2d_fwd(x, w * mask, b, 1, R // 2), what=f"masked {mask_type} {R}x{R} tile {tile}", floor=0.1)
+        assert_close(host(y), orc.conv2d_fwd(x, w * mask, b, 1, R // 2), what=f"masked {mask_type} {R}x{R} tile {tile} mfma {mfma}", floor=0.1)
 
 
 def _gen_forward_and_input_gradient(F, case, split):
@@ -524,7 +526,7 @@ def test_random_shapes_through_all_three_kernels():
     assert worst <= 1e-5, worst
 
 
-@pytest.mark.parametrize("plan", [dict(fx3_tile=128, fx3_depth=3, fx3_mfma=16, fx3_gen_tile=128), dict(fx3_tile=64, fx3_depth=3, fx3_mfma=16),
+@pytest.mark.parametrize("plan", [dict(fx3_tile=128, fx3_depth=3, fx3_mfma=16, fx3_gen_tile=128, fx3_gen_mfma=16), dict(fx3_tile=64, fx3_depth=3, fx3_mfma=16, fx3_gen_tile=64, fx3_gen_mfma=16),
                                   dict(fx3_tile=128, fx3_depth=3, fx3_mfma=32, fx3_gen_tile=64)],
                          ids=["tile128-3stage-mfma16", "tile64-3stage-mfma16", "tile128-3stage-mfma32"])
 def test_random_shapes_under_forced_plans(F, plan):

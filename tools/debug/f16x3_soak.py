@@ -7,8 +7,8 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import f16x3_fuzz
 from spatiotemporalentropymodel_amd import functional as F
 worst = {}
-for name, plan in (("default", {}), ("t128-3-16", dict(fx3_tile=128, fx3_depth=3, fx3_mfma=16, fx3_gen_tile=128)),
-                   ("t64-3-16", dict(fx3_tile=64, fx3_depth=3, fx3_mfma=16, fx3_gen_tile=64)), ("t128-3-32", dict(fx3_tile=128, fx3_depth=3, fx3_mfma=32)),
+for name, plan in (("default", {}), ("t128-3-16", dict(fx3_tile=128, fx3_depth=3, fx3_mfma=16, fx3_gen_tile=128, fx3_gen_mfma=16)),
+                   ("t64-3-16", dict(fx3_tile=64, fx3_depth=3, fx3_mfma=16, fx3_gen_tile=64, fx3_gen_mfma=16)), ("t128-3-32", dict(fx3_tile=128, fx3_depth=3, fx3_mfma=32)),
                    ("t64-3-32", dict(fx3_tile=64, fx3_depth=3, fx3_mfma=32)), ("t128-2", dict(fx3_tile=128, fx3_depth=2))):
     with F.tuning(**plan):
         import io, contextlib
