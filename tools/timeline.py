@@ -2,7 +2,7 @@
 """GPU timeline summary from a rocprofv3 --kernel-trace CSV: busy union vs span (how much of the wall time at least one
 kernel was running), idle gaps, per-queue busy time, and the kernels by total time inside the steady-state window.
 Usage: timeline.py kernel_trace.csv [skip_fraction=0.4] [NAME N]   (the first `skip_fraction` of the kernels = warm-up; with NAME N
-also the mean duration of the LAST N launches whose name contains NAME -- bench.py times its roofline kernel on launches it
+also the mean duration of the LAST N launches whose name contains NAME (NAME@GRID: and whose grid has GRID threads) -- bench.py times its roofline kernel on launches it
 repeats alone after the timed region)."""
 import csv
 import sys
@@ -11,10 +11,15 @@ from collections import defaultdict
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
+        name = r["Kernel_Name"]
+        grid = r.get("Grid_Size_X") or r.get("Grid_Size") or ""
+        if "conv_f16x3_kernel<" in name and grid:          # one instantiation serves several layers (g_a.2: 262144 threads, g_a.4: 65536)
+            name = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0] + f" [grid {grid}]"
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
 rows.sort()
 if len(sys.argv) > 4:
-    sel = [r for r in rows if sys.argv[3] in r[2]][-int(sys.argv[4]):]
+    want = sys.argv[3].split("@")                     # NAME or NAME@GRID
+    sel = [r for r in rows if want[0] in r[2] and (len(want) == 1 or f"[grid {want[1]}]" in r[2])][-int(sys.argv[4]):]
     if sel:
         d = [(e - s) / 1e3 for s, e, *_ in sel]
         print(f"last {len(sel)} launches of '{sys.argv[3]}': mean {sum(d) / len(d):.1f} us (min {min(d):.1f}, max {max(d):.1f})")
