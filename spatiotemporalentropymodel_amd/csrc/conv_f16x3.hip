@@ -1583,7 +1583,11 @@ int gen_bm(int M, int ntn, int nchunks)
 {
     const int forced = stem_tuning(STEM_TUNE_FX3_GEN_TILE);   // stem_tuning_set("fx3_gen_tile", 64 | 128): tests / sweeps
     if (forced) return forced;
-    return cdiv(M, 128) * ntn >= 64 && nchunks > 20 ? 128 : 64;
+    // (the nchunks > 20 clause of the isolated sweep is gone: inside the training step the short 1x1 launches -- EPM.2 / EPM.4 and
+    // the EPM input gradients, 22-26 us on either tile alone -- run 0.07 ms per step faster on the larger workgroups, six
+    // alternating pairs 15.21-15.26 against 15.16-15.20 ms: fewer, larger workgroups share the loaded chip better)
+    (void)nchunks;
+    return cdiv(M, 128) * ntn >= 64 ? 128 : 64;
 }
 }   // namespace
 
