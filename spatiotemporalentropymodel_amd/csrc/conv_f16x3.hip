@@ -23,9 +23,14 @@
 // Tile: 128 pixels x 192 channels per workgroup, 8 wavefronts as 4 (M) x 2 (N), each 32 x 96 = three 32x32 accumulators;
 // K chunk = one tap x 32 input channels = 2 k-steps x 3 tiles x 3 products = 18 MFMAs per wavefront.  LDS rows are 64 B
 // (32 fp16) per plane with the 16-byte piece index XOR-swizzled by (row >> 2) & 3: ds_read_b128 / ds_write_b128 are
-// conflict-free without padding.  Staging is register-based, two chunks ahead, woven between the MFMA groups as in igemm.hip.
-// The GDN that follows every analysis convolution (gdn.py:52-67) is fused exactly as in igemm.hip's FUSE epilogue (second
-// contraction over the squared outputs parked in LDS, fp32 MFMA -- 8 % of the matrix time now).
+// conflict-free without padding.  Staging is register-based, two chunks ahead, woven between the MFMA groups as in igemm.hip;
+// with three LDS stages (DEPTH 3) the next k-step's fragments are read and the stores issued between the MFMAs of the current one.
+// The same products are also instantiated on v_mfma_f32_16x16x32_f16 (MS 16: one k-step per chunk, twice the instructions of
+// half the size, a permuted accumulator layout that keeps ds_read_b128 conflict-free on the same LDS image): equal or slower
+// alone, faster on a loaded, power-limited chip -- which is where these kernels run.
+// The GDN that follows every analysis convolution (gdn.py:52-67) is fused: second contraction over the squared outputs, which
+// are scaled by the tile's own maximum, split and parked in LDS as A-operand images; gamma' streams in as a packed 1x1 weight
+// image; the same fp16 instruction.
 #include <math.h>
 #include <stdlib.h>
 
