@@ -1602,6 +1602,10 @@ STEM_EXPORT size_t stem_conv2d_f16x3_gen_workspace_bytes(int B, int H, int W, in
     if (OH < 1 || OW < 1 || C % 32) return 0;
     const int M = B * OH * OW, nchunks = (C / 32) * (taps > 0 ? taps : R * S), tiles = cdiv(M, gen_bm(M, cdiv(N, GBN), nchunks)) * cdiv(N, GBN);
     int s = gen_split(tiles, nchunks);
+    if (stem_fx3_img_eligible(B, H, W, N, R, S, stride, pad)) {       // the image-tile form plans its own split: room for either
+        const int si = stem_fx3_img_split(stem_fx3_img_tiles(B, H, W, N), nchunks);
+        if (si > s) s = si;
+    }
     while (s > 1 && (size_t)s * M * cdiv(N, GBN) * GBN * sizeof(float) >= 0x7FFFFF00ull) --s;
     return s > 1 ? kGenCntBytes + (size_t)s * M * cdiv(N, GBN) * GBN * sizeof(float) : 0;
 }
@@ -1639,10 +1643,18 @@ STEM_EXPORT int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int x
             a.dy[r * S + s] = (signed char)(r - pad);
             a.dx[r * S + s] = (signed char)(s - pad);
         }
-    int split = gen_split(tiles, nchunks);
+    // stride-1 "same" layers on images of 16x16 blocks: the image-tile form (conv_f16x3_img.hip: halo in LDS, weights by LDS-DMA)
+    const bool img = stem_fx3_img_eligible(B, H, W, N, R, S, stride, pad);
+    const int itiles = img ? stem_fx3_img_tiles(B, H, W, N) : 0;
+    int split = img ? stem_fx3_img_split(itiles, nchunks) : gen_split(tiles, nchunks);
     while (split > 1 && (size_t)split * M * ntn * GBN * sizeof(float) >= 0x7FFFFF00ull) --split;      // the slabs are read through one buffer view
     const size_t need = kGenCntBytes + (size_t)split * M * ntn * GBN * sizeof(float);
     if (split > 1 && (!ws || ws_bytes < need || (size_t)tiles * sizeof(int) > kGenCntBytes)) split = 1;      // no workspace: unsplit, same result up to summation order
+    if (img)
+        return stem_fx3_img_launch(xp, xq, xpix, (int)xb, wp, reinterpret_cast<const float *>(static_cast<const unsigned char *>(wp) + wb), (int)wb,
+                                   bias, epi, slope, z, ldz, y, ldy, yp, yq, B, H, W, C, N, R, T, split,
+                                   split > 1 ? reinterpret_cast<float *>(static_cast<unsigned char *>(ws) + kGenCntBytes) : nullptr,
+                                   split > 1 ? static_cast<int *>(ws) : nullptr, stream);
     a.nsplit = split;
     a.cps = cdiv(nchunks, split);
     a.nsplit = cdiv(nchunks, a.cps);

@@ -25,14 +25,17 @@ def init_from_env(backend=None, single=None):
     """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torch.distributed.run contract).
 
     Backend: STEM_DIST_BACKEND, else RCCL ("nccl") when every rank has a GPU of its own, else gloo -- RCCL refuses two
-    ranks on one device, so WORLD_SIZE > device count (the one-GPU test box, the CPU tests) exchanges through the host
+    ranks on one device, so LOCAL_WORLD_SIZE > device count (the one-GPU test box, the CPU tests) exchanges through the host
     (`all_reduce_sum_`).  `single` (or STEM_DIST_SINGLE=1) creates the process group at world size 1 as well, so that a
     one-GPU box executes the very RCCL calls, stream ordering and reducer bookkeeping of a multi-rank run."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = torch.cuda.device_count()                   # counting devices does not initialise the GPU
-    shared = ndev > 0 and world > ndev
+    # ranks PER NODE against devices per node: a multi-node job (WORLD_SIZE=16 over two 8-GPU nodes) shares nothing and stays on
+    # RCCL; torch.distributed.run sets LOCAL_WORLD_SIZE, a bare launch (bench.launch_ranks, the tests) is one node = WORLD_SIZE
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    shared = ndev > 0 and local_world > ndev
     if shared:
         local = local % ndev                           # more ranks than GPUs (single-GPU test box): share devices
     if single is None:
@@ -183,7 +186,9 @@ class OverlappedGradReducer:
         if self._stream is None:
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
             return
-        self._stream.wait_stream(torch.cuda.current_stream())      # the slice is final on the stream that reported it
+        # every slice of the run was ordered in front of the reducer's stream when it was REPORTED (reduce_params); the wait below
+        # only covers a caller that exchanges from a stream nobody reported on
+        self._stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._stream):
             all_reduce_sum_(g)
 
@@ -194,6 +199,11 @@ class OverlappedGradReducer:
         spans = sorted(self._off[id(p)] for p in params if id(p) in self._off)
         if not spans:
             return
+        if self.active and self._stream is not None:
+            # a reported slice may wait in `_pending` and leave merged with slices reported later from OTHER streams (a second
+            # weight-gradient lane, a hook caller with its own streams): order it in front of the reducer's stream now, on the
+            # stream that made it final, not on whichever stream happens to be current when the run is exchanged
+            self._stream.wait_stream(torch.cuda.current_stream())
         # merge neighbours (tensors are padded to 4 elements) into maximal runs; never bridge over foreign tensors,
         # whose gradients may not be final yet
         runs = []

@@ -50,13 +50,13 @@ class _Layer:
 
     def fx3_eligible(self):
         return (self.kind == "conv" and self.stride == 1 and not self.masked and self.C % 32 == 0 and self.K % 32 == 0
-                and self.R * self.R <= 25 and self.pad == self.R // 2)
+                and self.R % 2 == 1 and self.R * self.R <= 25 and self.pad == self.R // 2)     # odd windows: 'same' shapes both ways
 
     def fx3_masked_eligible(self):
         """the context model's masked convolution, forward only (its input is data + noise: no input gradient): the general
         kernel runs over the live taps alone -- 12 of 25 for the 5x5 type-A mask (layers.py:21-47)"""
         return (self.kind == "conv" and self.stride == 1 and bool(self.masked) and not self.need_dgrad and self.C % 32 == 0
-                and self.K % 4 == 0 and self.R * self.R <= 25 and self.pad == self.R // 2)
+                and self.K % 4 == 0 and self.R % 2 == 1 and self.R * self.R <= 25 and self.pad == self.R // 2)
 
     def fx3s_eligible(self):
         n_out, n_red = (self.K, self.C) if self.kind == "conv" else (self.C, self.K)       # outputs / contraction channels of that face
@@ -124,8 +124,8 @@ class _Layer:
     def wg3_eligible(self):
         """weight gradient on csrc/wgrad_f16x3.hip: stride-1 convolutions (all taps are produced, as autograd does for the
         masked context convolution too)"""
-        return (self.kind == "conv" and self.stride == 1 and self.C % 32 == 0 and self.K % 32 == 0 and self.R * self.R <= 25
-                and self.pad == self.R // 2)
+        return (self.kind == "conv" and self.stride == 1 and self.C % 32 == 0 and self.K % 32 == 0 and self.R % 2 == 1
+                and self.R * self.R <= 25 and self.pad == self.R // 2)
 
     def wgrad_any(self, x, dy, xp=None, dyp=None):
         """weight + bias gradient from the planes operands when this layer runs its weight gradient on the fp16 kernel and both
@@ -306,7 +306,7 @@ class StemEngine:
             # fp32 kernel when there are none), so they follow the layer's own eligibility
             l.wg3 = self.use_fx3 and self.use_wg3 and l.wg3_eligible()
 
-    #: forward and input-gradient of the stride-1 layers (TPM, HE.0, HD.4, EPM) on the fp16 matrix cores with fp32-exact products
+    #: forward and input-gradient of the stride-1 layers (TPM, HE.0, HD.4, EPM) on the fp16 matrix cores: three fp16 products per fp32 product on operands split into two scaled fp16 planes, ~2^-21 relative per product (tests: 1e-4 gates; measured 0.4-1.6e-6 of max per layer against fp64)
     #: (three fp16 MFMAs per fp32 product, csrc/conv_f16x3.hip); STEM_ENGINE_F16X3=0 keeps every layer on the fp32-MFMA kernels
     use_fx3 = os.environ.get("STEM_ENGINE_F16X3", "1") != "0"
     #: the entropy glue (prologue, Gaussian backward) records the maxima of the fp32 tensors it writes, so that their fp16 splits

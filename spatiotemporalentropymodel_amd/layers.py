@@ -139,7 +139,7 @@ def _on_side_stream(fn, *tensors):
 # ----------------------------------------------------------------------------- autograd functions
 def _layers_f16x3_enabled():
     """stride-1 convolutions of the layer-wise (autograd) models -- the variable-rate family of models/stem_roi.py -- on the fp16
-    matrix cores (six products per fp32 product, csrc/conv_f16x3.hip / wgrad_f16x3.hip); STEM_LAYERS_F16X3=0: fp32 MFMA"""
+    matrix cores (three fp16 products per fp32 product on two-plane operands, ~2^-21 per product: csrc/conv_f16x3.hip / wgrad_f16x3.hip); STEM_LAYERS_F16X3=0: fp32 MFMA"""
     return os.environ.get("STEM_LAYERS_F16X3", "1") != "0"
 
 
@@ -148,7 +148,9 @@ def _conv_f16x3_route(weight, stride, pad, masked, x_shape):
     counts that are multiples of 32, operands within the kernels' 2 GiB buffer views"""
     K, Cc, R, S = weight.shape
     B, _, H, W = x_shape
-    return (stride == 1 and R == S and pad == R // 2 and not masked and Cc % 32 == 0 and K % 32 == 0 and R * S <= 25
+    # odd windows only: with an even R the output is (H + 1) x (W + 1) and the input gradient needs pad R - 1 - pad, which the
+    # planes hand-over between layers ('same' shapes) does not carry
+    return (stride == 1 and R == S and R % 2 == 1 and pad == R // 2 and not masked and Cc % 32 == 0 and K % 32 == 0 and R * S <= 25
             and B * H * W <= _LAYERS_F16X3_MAXPIX
             and _planes_fit(B * H * W, max(Cc, K)) and B * H * W * ((max(K, Cc) + 127) // 128) * 512 < 0x7FFFFF00)
 

@@ -303,6 +303,7 @@ def test_backend_choice_follows_device_count(monkeypatch):
     monkeypatch.setattr(D.dist, "init_process_group", lambda backend, rank, world_size, **kw: seen.update(b=backend, r=rank, w=world_size, kw=kw))
     monkeypatch.setattr(D.torch.cuda, "set_device", lambda d: seen.update(dev=d))
     monkeypatch.delenv("STEM_DIST_BACKEND", raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
     for ndev, world, rank, want, local in ((8, 8, 5, "nccl", 5), (1, 2, 1, "gloo", 0), (0, 2, 1, "gloo", 1), (1, 1, 0, "nccl", 0)):
         monkeypatch.setattr(D.torch.cuda, "device_count", lambda n=ndev: n)
         monkeypatch.setenv("WORLD_SIZE", str(world)); monkeypatch.setenv("RANK", str(rank)); monkeypatch.setenv("LOCAL_RANK", str(rank))
@@ -311,6 +312,16 @@ def test_backend_choice_follows_device_count(monkeypatch):
         assert seen["b"] == want and seen["w"] == world, (ndev, world, seen)
         if want == "nccl" and "pg_options" in seen["kw"]:          # RCCL's own stream at high priority, like the schedule's side streams
             assert seen["kw"]["pg_options"].is_high_priority_stream
+    # two nodes of 8 GPUs under torch.distributed.run (WORLD_SIZE=16, LOCAL_WORLD_SIZE=8): nothing is shared, RCCL it is;
+    # 16 ranks on ONE 8-GPU node share devices and go through the host
+    monkeypatch.setattr(D.torch.cuda, "device_count", lambda: 8)
+    for lws, want, local in ((8, "nccl", 3), (16, "gloo", 3)):
+        monkeypatch.setenv("WORLD_SIZE", "16"); monkeypatch.setenv("RANK", "11"); monkeypatch.setenv("LOCAL_RANK", "3")
+        monkeypatch.setenv("LOCAL_WORLD_SIZE", str(lws))
+        seen.clear()
+        assert D.init_from_env() == (11, 16, local)
+        assert seen["b"] == want and seen["w"] == 16, (lws, seen)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
     # world size 1 without `single`: no process group at all
     seen.clear()
     monkeypatch.setenv("WORLD_SIZE", "1"); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("LOCAL_RANK", "0")
