@@ -116,30 +116,9 @@ def _median_time(fn, repeats=3, warmup=1, budget_s=None):
     return float(np.median(ts)), ts
 
 
-def cpu_baseline(budget_s=75.0):
-    """The reference's CPU path as it can be represented on this box: the fp32 port of
-    the path on the host BLAS (oracle/stem_port_blas.py: im2col + SGEMM per convolution, what torch-CPU / MKL-DNN does for the
-    reference; elementwise entropy-model pieces from oracle/stem_oracle.c), BLAS threads = the box's PHYSICAL cores:
-
-      (i)  config 2: one P-frame optimisation step at B = 16 (g_a of the frame, STEM forward, EMLoss, backward, global-norm
-           clip + Adam): 2 warm-ups, then the median of up to 10 runs -- fewer (never under 3) when 10 would take more than
-           `budget_s` seconds, because the default bench run has to finish within minutes; the record says how many;
-      (ii) config 1: forward of one 7x256x256 septuplet through the small model (7 g_a, 6 STEM forwards, 6 g_s).
-
-    value = frames/s of (i) over a septuplet schedule (7 g_a + 6 P-steps per 7 frames), like the GPU number."""
-    sys.path.insert(0, os.path.join(REPO, "oracle"))
-    import stem_oracle as orc
-    import stem_port_blas as port
+def _baseline_weights(rng):
+    """random-init weights of the config-2 / config-1 models in the reference's state-dict layout (numpy)"""
     from spatiotemporalentropymodel_amd.weights import closed_form_tensor
-    cores = _physical_cores()
-    limiter = None
-    try:
-        from threadpoolctl import threadpool_info, threadpool_limits
-        limiter = threadpool_limits(limits=cores, user_api="blas")
-        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
-    except Exception:
-        blas_threads = os.cpu_count() or 1
-    rng = np.random.default_rng(0)
 
     def W(*s):
         return (rng.standard_normal(s) * math.sqrt(2.0 / np.prod(s[1:]))).astype(np.float32)
@@ -170,8 +149,62 @@ def cpu_baseline(budget_s=75.0):
         sd["entropy_bottleneck.quantiles"] = closed_form_tensor("entropy_bottleneck.quantiles", (ebc, 1, 3)).numpy()
         return sd
 
+    return transforms, stem_weights
+
+
+def _cpu_baseline_torch(budget_s):
+    """(i) of cpu_baseline on torch CPU operators: what the reference itself executes on a CPU (oracle/stem_torch_cpu.py, pinned
+    against the C oracle by tests/test_oracle_vs_golden.py::test_torch_cpu_leg_matches_oracle)."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import stem_torch_cpu as tc
+    cores = _physical_cores()
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        rng = np.random.default_rng(0)
+        transforms, stem_weights = _baseline_weights(rng)
+        tr = tc.PFrameTrainer(transforms(192, 192), stem_weights(256, 192))
+        B = BATCH
+        ga_times = []
+
+        def p_step():
+            x = torch.from_numpy(rng.random((B, 3, SIZE, SIZE), dtype=np.float32))
+            lat = (B, 192, SIZE // 16, SIZE // 16)
+            noise = {"z": torch.from_numpy(rng.uniform(-0.5, 0.5, (B, 256, SIZE // 64, SIZE // 64)).astype(np.float32)),
+                     "q": torch.from_numpy(rng.uniform(-0.5, 0.5, lat).astype(np.float32)),
+                     "lik": torch.from_numpy(rng.uniform(-0.5, 0.5, lat).astype(np.float32))}
+            y_noise = torch.from_numpy(rng.uniform(-0.5, 0.5, lat).astype(np.float32))
+            ga_times.append(tr.step(x, noise, y_noise)[1])
+
+        t_step, step_times = _median_time(p_step, repeats=10, warmup=2, budget_s=budget_s)
+        t_ga = float(np.median(ga_times[2:]))
+        threads = torch.get_num_threads()
+    finally:
+        torch.set_num_threads(old_threads)
+    t_sept = FRAMES * t_ga + (FRAMES - 1) * (t_step - t_ga)
+    return {"frames_per_s": FRAMES * B / t_sept, "threads": int(threads), "p_step_s": t_step, "g_a_s": t_ga, "batch": B,
+            "warmup_runs": 2, "timed_runs": len(step_times), "p_step_runs_s": [round(t, 4) for t in step_times]}
+
+
+def _cpu_baseline_port(budget_s):
+    """the same step on the numpy im2col + SGEMM port of the path (oracle/stem_port_blas.py on the host BLAS, elementwise
+    entropy-model pieces from oracle/stem_oracle.c): the round-1..3 baseline, kept beside the torch-CPU leg; plus config 1
+    (forward of one 7x256x256 septuplet through the small model: 7 g_a, 6 STEM forwards, 6 g_s)."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import stem_oracle as orc
+    import stem_port_blas as port
+    cores = _physical_cores()
+    limiter = None
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+        limiter = threadpool_limits(limits=cores, user_api="blas")
+        blas_threads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
+    except Exception:
+        blas_threads = os.cpu_count() or 1
+    rng = np.random.default_rng(0)
+    transforms, stem_weights = _baseline_weights(rng)
+
     with port.installed():
-        # ---- (i) config 2
         isd, ssd = transforms(192, 192), stem_weights(256, 192)
         names = sorted(k for k in ssd if not k.endswith("quantiles"))
         adam = {k: (np.zeros_like(ssd[k]), np.zeros_like(ssd[k])) for k in names}
@@ -202,10 +235,9 @@ def cpu_baseline(budget_s=75.0):
 
         B = BATCH
         ga_times = []
-        t_step, step_times = _median_time(lambda: ga_times.append(p_step(B)), repeats=10, warmup=2, budget_s=budget_s)
-        t_ga = float(np.median(ga_times[2:]))
-        t_stem = t_step - t_ga
-        # ---- (ii) config 1: small model, one septuplet forward (eval)
+        t_step, step_times = _median_time(lambda: ga_times.append(p_step(B)), repeats=3, warmup=1, budget_s=budget_s)
+        t_ga = float(np.median(ga_times[1:]))
+        # config 1: small model, one septuplet forward (eval)
         isd1, ssd1 = transforms(64, 96), stem_weights(64, 96)
         frames = [rng.random((1, 3, SIZE, SIZE), dtype=np.float32) for _ in range(FRAMES)]
 
@@ -218,19 +250,37 @@ def cpu_baseline(budget_s=75.0):
                 y_cond = out["y_hat"]
 
         t_sept1, _ = _median_time(septuplet_forward)
-    t_sept = FRAMES * t_ga + (FRAMES - 1) * t_stem
-    if limiter is not None:
-        limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
-    return {"value": FRAMES * B / t_sept, "unit": "frames/s", "cores": int(blas_threads), "kind": "port",
-            "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(), "host_physical_cores": cores, "blas_threads_requested": cores, "batch": B,
-            "warmup_runs": 2, "timed_runs": len(step_times),
-            "p_step_s": t_step, "p_step_runs_s": [round(t, 4) for t in step_times], "g_a_s": t_ga,
-            "config1_septuplet_forward_s": t_sept1,
-            "sample": f"oracle/stem_port_blas.py (fp32 im2col + SGEMM on the host BLAS, {blas_threads} threads) on {_cpu_model()}: "
-                      f"config-2 P-frame step at B={B} (g_a {t_ga:.2f} s + STEM fwd/bwd/clip/Adam {t_stem:.2f} s; 2 warm-ups, median of "
-                      f"{len(step_times)} runs{'' if len(step_times) == 10 else ' (10 would exceed the %d s budget of a default bench run)' % int(budget_s)}), "
-                      f"septuplet = 7 g_a + 6 P-steps -> {FRAMES * B / t_sept:.2f} frames/s; config-1 septuplet forward (small model) "
-                      f"{t_sept1:.2f} s = {FRAMES / t_sept1:.2f} frames/s"}
+    if limiter is not None and hasattr(limiter, "restore_original_limits"):
+        limiter.restore_original_limits()
+    t_sept = FRAMES * t_ga + (FRAMES - 1) * (t_step - t_ga)
+    return {"frames_per_s": FRAMES * B / t_sept, "blas_threads": int(blas_threads), "p_step_s": t_step, "g_a_s": t_ga, "batch": B,
+            "warmup_runs": 1, "timed_runs": len(step_times), "config1_septuplet_forward_s": t_sept1}
+
+
+def cpu_baseline(budget_s=45.0):
+    """The reference's CPU path on this box's host cores, config 2: one P-frame
+    optimisation step at B = 16 (g_a of the frame, STEM forward, EMLoss, backward, global-norm clip + Adam, auxiliary loss +
+    Adam on the quantiles), 2 warm-ups, then the median of up to 10 runs -- fewer (never under 3) when 10 would take more than
+    `budget_s` seconds, because the default bench run has to finish within minutes; the record says how many.
+
+    `value` = the torch-CPU leg (kind "torch-cpu": torch.nn.functional convolutions through MKL-DNN, autograd,
+    clip_grad_norm_, torch.optim.Adam with torch.set_num_threads(physical cores) -- what spatiotemporalpriors.py:807-868 +
+    stem/trainSTEM.py:203-218 execute on a CPU), frames/s over a septuplet schedule (7 g_a + 6 P-steps per 7 frames) like the GPU
+    number.  `port` = the numpy im2col + SGEMM port of rounds 1-3 beside it (one warm-up, 3 runs)."""
+    tl = _cpu_baseline_torch(budget_s)
+    pl = _cpu_baseline_port(30.0)
+    cores = _physical_cores()
+    return {"value": tl["frames_per_s"], "unit": "frames/s", "cores": tl["threads"], "kind": "torch-cpu",
+            "cpu_model": _cpu_model(), "host_logical_cpus": os.cpu_count(), "host_physical_cores": cores, "batch": tl["batch"],
+            "warmup_runs": tl["warmup_runs"], "timed_runs": tl["timed_runs"], "p_step_s": tl["p_step_s"], "p_step_runs_s": tl["p_step_runs_s"],
+            "g_a_s": tl["g_a_s"],
+            "port": {"value": pl["frames_per_s"], "kind": "port", "cores": pl["blas_threads"], "p_step_s": pl["p_step_s"], "g_a_s": pl["g_a_s"],
+                     "warmup_runs": pl["warmup_runs"], "timed_runs": pl["timed_runs"], "config1_septuplet_forward_s": pl["config1_septuplet_forward_s"]},
+            "sample": f"oracle/stem_torch_cpu.py (torch {torch.__version__} CPU operators, {tl['threads']} threads) on {_cpu_model()}: config-2 P-frame "
+                      f"step at B={tl['batch']} (g_a {tl['g_a_s']:.2f} s + STEM fwd / bwd / clip / Adam / aux {tl['p_step_s'] - tl['g_a_s']:.2f} s; "
+                      f"2 warm-ups, median of {tl['timed_runs']} runs), septuplet = 7 g_a + 6 P-steps -> {tl['frames_per_s']:.2f} frames/s; "
+                      f"beside it the numpy im2col + SGEMM port ({pl['blas_threads']} BLAS threads): P-step {pl['p_step_s']:.2f} s -> "
+                      f"{pl['frames_per_s']:.2f} frames/s; config-1 septuplet forward (small model, port) {pl['config1_septuplet_forward_s']:.2f} s"}
 
 
 def bench_roi(args):

@@ -11,7 +11,8 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # STEM_HIP_LIBRARY names another build of the same ABI (tools/debug use `make EXPERIMENTS=1` -> libstem_hip_exper.so)
 HIP_SO = os.environ.get("STEM_HIP_LIBRARY") or os.path.join(_PKG, "libstem_hip.so")
-RANS_SO = os.path.join(_PKG, "libstem_rans.so")
+# STEM_RANS_LIBRARY names another build of the host codec (`make sanitize` -> libstem_rans_asan.so, the sanitizer test)
+RANS_SO = os.environ.get("STEM_RANS_LIBRARY") or os.path.join(_PKG, "libstem_rans.so")
 
 _hip = None
 _rans = None

@@ -418,34 +418,35 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
     // every pass below gives a thread the same pieces: column group ec4 = tid & 31 (4 floats), tile rows (tid >> 5) + 16 k
     constexpr int ER = TPX / (NTHR / 32);                          // 16 pieces per thread
     const int ec4 = tid & 31, er0 = tid >> 5;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int pix = PIXL(mi, r);
-#pragma unroll
-            for (int nj = 0; nj < 2; ++nj) Tt[pix * ITP + wn * 64 + nj * 32 + lr] = acc[mi][nj][r];
-        }
-    __syncthreads();
     f32x4 ev[ER];
     int em[ER];                                                    // global output row of each piece, -1 outside the image
 #pragma unroll
     for (int k = 0; k < ER; ++k) em[k] = MOF(er0 + 16 * k);
     if (a.nsplit > 1) {
-        // partial tile -> workspace as whole 16-byte sc1 stores (rows of 512 contiguous bytes: a scalar sc1 store is one fabric
-        // write per dword, six times the time per byte); then the arrival protocol of igemm.hip: stores acknowledged, one ticket
-        // per workgroup, the last arriver owns the tile and re-zeroes the counter
+        // partial tile -> workspace, one 4-byte agent-scope store per accumulator element (each register: two 128-byte row
+        // segments), then the arrival protocol of igemm.hip: stores acknowledged, one ticket per workgroup, the last arriver owns
+        // the tile and re-zeroes the counter.  NOT 16-byte `buffer_store ... sc1` stores of the tile staged through LDS: with
+        // those the ticket overtook the data on the first launch after the workspace was (re)allocated -- the last arriver
+        // summed the allocation's zeros for a few pieces (tools/debug/repro_fwd.py: 40 of 40 fresh runs; this form and a
+        // plain-store + agent-release form: 0 of 40)
         constexpr int SC1 = 16;
         const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)((size_t)a.nsplit * Mtot * Npad * 4), 0x00020000);
         const int sstep = Mtot * Npad * 4;
         int eoff[ER];
 #pragma unroll
         for (int k = 0; k < ER; ++k) eoff[k] = em[k] >= 0 ? (em[k] * Npad + bn0 + ec4 * 4) * 4 : OOR;
+        float *wsp = a.ws + (size_t)zsplit * Mtot * Npad;
 #pragma unroll
-        for (int k = 0; k < ER; ++k) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(&Tt[(er0 + 16 * k) * ITP + ec4 * 4]);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rws, eoff[k], zsplit * sstep, SC1);
-        }
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = MOF(PIXL(mi, r));
+                if (m >= 0) {
+#pragma unroll
+                    for (int nj = 0; nj < 2; ++nj)
+                        __hip_atomic_store(&wsp[(size_t)m * Npad + bn0 + wn * 64 + nj * 32 + lr], acc[mi][nj][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -481,6 +482,15 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
         }
         IMG_STAMP(5);
     } else {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pix = PIXL(mi, r);
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj) Tt[pix * ITP + wn * 64 + nj * 32 + lr] = acc[mi][nj][r];
+            }
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < ER; ++k) ev[k] = *reinterpret_cast<const f32x4 *>(&Tt[(er0 + 16 * k) * ITP + ec4 * 4]);
     }

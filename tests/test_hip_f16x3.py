@@ -414,35 +414,45 @@ def test_engine_schedule_with_and_without_bf16_layers(monkeypatch):
     from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel_Res
     from spatiotemporalentropymodel_amd.weights import closed_form_fill_, closed_form_input
     d = torch.device("cuda:0")
-    y_cur = closed_form_input("eng:y", (2, 192, 16, 16), -6, 6).to(d)
-    y_cond = closed_form_input("eng:c", (2, 192, 16, 16), -6, 6).to(d)
-    runs = {}
-    for tag, on in (("fp16", True), ("fp32", False)):
-        monkeypatch.setattr(E.StemEngine, "use_fx3", on)
-        m = closed_form_fill_(SpatioTemporalPriorModel_Res()).to(d).train()
-        assert any(l.fx3 for l in m.engine().layers) == on
-        runs[tag] = OP.hip_train_pass(m, y_cur, y_cond, "eng")
-    ref, rgrads, racts = OP.oracle_train_pass(m, y_cur, y_cond, runs["fp32"][4], residual=True)
-    assert abs(runs["fp16"][1] - runs["fp32"][1]) <= 1e-5 * abs(runs["fp32"][1])
-    assert runs["fp16"][2].keys() == runs["fp32"][2].keys() and len(rgrads) > 30
-    dist = {tag: {n: OP.grad_distance(runs[tag][2][n], g) for n, g in rgrads.items() if n in runs[tag][2]} for tag in runs}
-    flips = {tag: OP.decisions_flipped(runs[tag][3], racts, OP.host(runs[tag][0]["likelihoods"]["y"]), ref["lik_y"]) for tag in runs}
-    flips["fp16 vs fp32"] = OP.decisions_flipped(runs["fp16"][3], runs["fp32"][3])
-    for tag in runs:
-        worst = sorted(((v, n) for n, v in dist[tag].items()), reverse=True)[:4]
-        print(f"{tag} route vs oracle: decisions flipped {flips[tag] or 'none'}; worst gradients " + ", ".join(f"{n} {v:.1e}" for v, n in worst))
-    assert sum(sum(f.values()) for f in flips.values()) <= 4, flips
-    flipped = any(flips.values())
-    for n in rgrads:
-        if n not in dist["fp16"]:
+    # A flipped decision moves a pixel's back-propagated gradient outright and says nothing about rounding: the per-tensor gates
+    # need a draw of the inputs on which neither route flips one against the oracle.  Up to four draws; the first clean one is
+    # gated in full -- none of the four clean is a failure (a flip used to silence every gate of the run).
+    seen = []
+    for attempt in range(4):
+        sfx = "" if attempt == 0 else str(attempt)
+        y_cur = closed_form_input("eng:y" + sfx, (2, 192, 16, 16), -6, 6).to(d)
+        y_cond = closed_form_input("eng:c" + sfx, (2, 192, 16, 16), -6, 6).to(d)
+        runs = {}
+        for tag, on in (("fp16", True), ("fp32", False)):
+            monkeypatch.setattr(E.StemEngine, "use_fx3", on)
+            m = closed_form_fill_(SpatioTemporalPriorModel_Res()).to(d).train()
+            assert any(l.fx3 for l in m.engine().layers) == on
+            runs[tag] = OP.hip_train_pass(m, y_cur, y_cond, "eng" + sfx)
+        ref, rgrads, racts = OP.oracle_train_pass(m, y_cur, y_cond, runs["fp32"][4], residual=True)
+        assert abs(runs["fp16"][1] - runs["fp32"][1]) <= 1e-5 * abs(runs["fp32"][1])
+        assert runs["fp16"][2].keys() == runs["fp32"][2].keys() and len(rgrads) > 30
+        dist = {tag: {n: OP.grad_distance(runs[tag][2][n], g) for n, g in rgrads.items() if n in runs[tag][2]} for tag in runs}
+        flips = {tag: OP.decisions_flipped(runs[tag][3], racts, OP.host(runs[tag][0]["likelihoods"]["y"]), ref["lik_y"]) for tag in runs}
+        flips["fp16 vs fp32"] = OP.decisions_flipped(runs["fp16"][3], runs["fp32"][3])
+        for tag in runs:
+            worst = sorted(((v, n) for n, v in dist[tag].items()), reverse=True)[:4]
+            print(f"draw {attempt}, {tag} route vs oracle: decisions flipped {flips[tag] or 'none'}; worst gradients " + ", ".join(f"{n} {v:.1e}" for v, n in worst))
+        assert sum(sum(f.values()) for f in flips.values()) <= 4, flips          # a handful of near-zero pre-activations, not a broken layer
+        seen.append(flips)
+        if any(flips.values()):
             continue
-        db, df = dist["fp16"][n], dist["fp32"][n]
-        if not flipped:
+        ngated = 0
+        for n in rgrads:
+            if n not in dist["fp16"]:
+                continue
+            db, df = dist["fp16"][n], dist["fp32"][n]
             assert db <= 1.5 * df + 1e-4, f"{n}: fp16 route {db:.2e} from the oracle, fp32-MFMA route {df:.2e}"
             assert max(db, df) <= 1e-3, (n, db, df)
             assert_close(runs["fp16"][2][n], runs["fp32"][2][n], rtol=2e-4, what=f"grad {n}, route vs route", floor=1.0)
-    if flipped:
-        print("decisions flipped: per-tensor gates skipped for this run", flips)
+            ngated += 1
+        assert ngated > 30
+        return
+    pytest.fail(f"no draw of the inputs without a flipped decision in four attempts: {seen}")
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

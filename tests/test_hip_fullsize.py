@@ -419,6 +419,42 @@ def test_variable_rate_workload_config5_properties():
 
     oi, op, loss16, _, g16 = run(0, B)
     assert tuple(op["x_hat"].shape) == (B, 3, 256, 256) and np.isfinite(loss16)
+    # ---- the B=16 run against the CPU oracle (this workload was tied to the goldens through properties only): one
+    # sample per quality level through oracle/stem_oracle.py:stem_roi_forward -- I frame, then the P frame conditioned on the
+    # ORACLE's own reconstruction -- with the very noise rows the batch run drew; x_hat, both likelihoods and the sample's loss
+    isd = {k: v.detach().cpu().numpy() for k, v in imodel.state_dict().items()}
+    psd = {k: v.detach().cpu().numpy() for k, v in pmodel.state_dict().items()}
+    from spatiotemporalentropymodel_amd.weights import closed_form_input
+
+    def noise_rows(tag, b, zc, zhw):
+        zfull = closed_form_input(f"noise:cfg5_{tag}_eb:0", (zc, 1, zhw * zhw * B), -0.5, 0.5).reshape(zc, zhw * zhw, B)
+        yfull = closed_form_input(f"noise:cfg5_{tag}_gc:0", (B, 192, 16, 16), -0.5, 0.5)
+        return {"z": zfull[:, :, b].reshape(1, zc, zhw, zhw).numpy().copy(), "y": yfull[b:b + 1].numpy().copy()}
+
+    def sample_loss(o, target, lam_b):
+        bpp = orc.rate_bpp(o["lik_y"], 256 * 256) + orc.rate_bpp(o["lik_z"], 256 * 256)
+        mse = float(np.mean(lam_b.astype(np.float64) * (o["x_hat"].astype(np.float64) - target) ** 2))
+        return bpp + 255 ** 2 * mse
+
+    zc_i, zc_p = oi["likelihoods"]["z"].shape[1], op["likelihoods"]["z"].shape[1]
+    zhw = oi["likelihoods"]["z"].shape[2]
+    for b in (0, 4, 8, 12):
+        f0, f1 = frames[0][b:b + 1].cpu().numpy(), frames[1][b:b + 1].cpu().numpy()
+        qb, lb = qmap[b:b + 1].cpu().numpy(), lam[b:b + 1].cpu().numpy()
+        ro_i = orc.stem_roi_forward(isd, f0, None, qb, noise_rows("i", b, zc_i, zhw), temporal=False)
+        ro_p = orc.stem_roi_forward(psd, f1, ro_i["x_hat"], qb, noise_rows("p", b, zc_p, zhw), temporal=True)
+        for tag, ro, go in (("I", ro_i, oi), ("P", ro_p, op)):
+            assert_close(go["x_hat"][b:b + 1].detach().cpu().numpy(), ro["x_hat"], 1e-4, what=f"sample {b} {tag} x_hat vs oracle", floor=0.1)
+            assert_close(go["likelihoods"]["y"][b:b + 1].detach().cpu().contiguous().numpy(), ro["lik_y"], 1e-4, atol=1e-9,
+                         what=f"sample {b} {tag} lik_y vs oracle", floor=0.1)
+            assert_close(go["likelihoods"]["z"][b:b + 1].detach().cpu().contiguous().numpy(), ro["lik_z"], 1e-4, atol=1e-9,
+                         what=f"sample {b} {tag} lik_z vs oracle", floor=0.1)
+        # the batch criterion is the mean over samples: a sample's loss from the GPU tensors against the oracle's
+        for tag, ro, go, tgt in (("I", ro_i, oi, f0), ("P", ro_p, op, f1)):
+            g_one = {"x_hat": go["x_hat"][b:b + 1].detach().cpu().numpy(), "lik_y": go["likelihoods"]["y"][b:b + 1].detach().cpu().contiguous().numpy(),
+                     "lik_z": go["likelihoods"]["z"][b:b + 1].detach().cpu().contiguous().numpy()}
+            lg, lo_ = sample_loss(g_one, tgt, lb), sample_loss(ro, tgt, lb)
+            assert abs(lg - lo_) <= 1e-4 * abs(lo_), (b, tag, lg, lo_)
     acc, losses, bpps = None, [], []
     for gi in range(4):
         gi_i, gi_p, lg, bpp, gg = run(4 * gi, 4 * gi + 4)
@@ -447,4 +483,6 @@ def test_variable_rate_workload_config5_properties():
           f"{['%.3f' % b for b in bpps]}")
     # measured on MI355X: median 2e-5, 169 of 540 tensors above 1e-4, worst 7.7e-3 (hyper-path SFT MLPs, whose inputs are
     # CONSTANT over space for these uniform quality maps: their gradients are sums over all pixels of terms that cancel)
-    assert errs[len(errs) // 2][0] <= 1e-4 and errs[0][0] < 2e-2 and len(loose) <= 0.4 * len(errs), errs[:8]
+    # the property bound was 2e-2; with the forward tied to the oracle above, the gradient identity is held to 1e-2
+    # on the worst tensor (measured 7.7e-3 on the spatially constant SFT MLPs) and to 5e-3 on all but eight tensors
+    assert errs[len(errs) // 2][0] <= 1e-4 and errs[0][0] < 1e-2 and errs[8][0] < 5e-3 and len(loose) <= 0.4 * len(errs), errs[:10]

@@ -514,3 +514,35 @@ def test_tuned_schedule_defaults_and_cu_mask_words(monkeypatch):
     import contextlib
     assert isinstance(trainer.tuned_schedule(torch.device("cpu")), contextlib.nullcontext)
     assert os.environ["STEM_STREAM_CUMASK"] == "" and os.environ["STEM_STREAM_PRIO"] == ""
+
+
+def test_host_codec_under_sanitizers(tmp_path):
+    """`make sanitize` builds csrc/rans_host.cpp with -fsanitize=address,undefined (the reference's DEBUG_BUILD,
+    setup.py:56-60); the rANS / pmf->CDF / table / container tests of this file -- including the corrupt-stream decoder test --
+    then run against that library in a child process with the sanitizer runtime preloaded.  Any report fails the child
+    (-fno-sanitize-recover, ASan's default abort)."""
+    import shutil
+    import subprocess
+    import sys
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(REPO, "spatiotemporalentropymodel_amd", "csrc")
+    cxx = shutil.which(os.environ.get("CXX", "g++"))
+    if cxx is None:
+        pytest.skip("no host C++ compiler")
+    asan = subprocess.run([cxx, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("the compiler ships no AddressSanitizer runtime")
+    subprocess.check_call(["make", "-C", csrc, "sanitize"], stdout=subprocess.DEVNULL)
+    lib = os.path.join(REPO, "spatiotemporalentropymodel_amd", "libstem_rans_asan.so")
+    assert os.path.exists(lib)
+    env = dict(os.environ, STEM_RANS_LIBRARY=lib, LD_PRELOAD=os.path.realpath(asan),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    cmd = [sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-p", "no:cacheprovider",
+           "-k", "rans or pmf_to_quantized or update_tables or bitstream_container"]
+    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+    out = r.stdout + r.stderr
+    assert "AddressSanitizer" not in out and "runtime error" not in out, out[-4000:]
+    assert r.returncode == 0, out[-4000:]
+    import re
+    m = re.search(r"(\d+) passed", out)
+    assert m and int(m.group(1)) >= 6, out[-2000:]            # the child really ran the codec tests on the sanitized library

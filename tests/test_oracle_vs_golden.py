@@ -500,3 +500,89 @@ def test_blas_port_matches_oracle():
     close(o_blas["lik_z"], o_ref["lik_z"], "lik_z")
     for k in g_ref:
         close(g_blas[k], g_ref[k], "grad " + k)
+
+
+def test_torch_cpu_leg_matches_oracle():
+    """oracle/stem_torch_cpu.py (the torch-CPU restatement of the reference's CPU path that bench.py times as `cpu_baseline`:
+    torch conv2d / conv_transpose2d, autograd, clip_grad_norm_, Adam) against the C oracle: the frozen analysis transform, a whole
+    STEM training forward (every output tensor) and every parameter gradient of the rate loss, then one optimisation step
+    (clip + Adam on the main parameters, auxiliary loss + Adam on the quantiles) against the same step taken in numpy."""
+    import math
+
+    import torch
+
+    import stem_torch_cpu as tc
+    from spatiotemporalentropymodel_amd.weights import closed_form_input, closed_form_tensor
+
+    def dist(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.abs(a - b).max() / max(float(np.abs(b).max()), 1e-30))
+
+    torch.manual_seed(0)
+    rng = np.random.default_rng(3)
+    # ---- g_a on a small image
+    N, M = 32, 48
+    isd, ch = {}, [3, N, N, N, M]
+    for i in range(4):
+        isd[f"g_a.{2 * i}.weight"] = (rng.standard_normal((ch[i + 1], ch[i], 5, 5)) * (2.0 / (ch[i] * 25)) ** 0.5).astype(np.float32)
+        isd[f"g_a.{2 * i}.bias"] = (0.1 * rng.standard_normal(ch[i + 1])).astype(np.float32)
+        if i < 3:
+            isd[f"g_a.{2 * i + 1}.beta"] = np.sqrt(1 + 0.2 * rng.random(N)).astype(np.float32)
+            isd[f"g_a.{2 * i + 1}.gamma"] = np.sqrt(0.1 * np.eye(N) + 0.02 * rng.random((N, N)) + 2.0 ** -36).astype(np.float32)
+    x = rng.random((2, 3, 48, 64), dtype=np.float32)
+    with torch.no_grad():
+        y_t = tc.g_a({k: torch.as_tensor(v) for k, v in isd.items()}, torch.as_tensor(x)).numpy()
+    assert dist(y_t, orc.g_a(isd, x)) < 2e-5
+    # ---- STEM training forward + backward (small config, 4x4 latents, both residual forms)
+    ssd = {k: closed_form_tensor(k, s).numpy() for k, s in _stem_keys(64, 96).items()}
+    B, ls = 2, 4
+    y_cur, y_cond = closed_form_input("tc:y", (B, 96, ls, ls), -4, 4).numpy(), closed_form_input("tc:c", (B, 96, ls, ls), -4, 4).numpy()
+    noise = {"z": closed_form_input("tc:nz", (B, 64, 1, 1), -.5, .5).numpy(), "q": closed_form_input("tc:nq", (B, 96, ls, ls), -.5, .5).numpy(),
+             "lik": closed_form_input("tc:nl", (B, 96, ls, ls), -.5, .5).numpy()}
+    npix = B * 64 * 64
+    for residual in (True, False):
+        keep = {}
+        o_ref = orc.stem_forward(ssd, y_cur, y_cond, residual=residual, training=True, noise=noise, keep=keep)
+        g_ref = orc.stem_backward(ssd, keep, o_ref["lik_y"], o_ref["lik_z"], npix)
+        tsd = {k: torch.as_tensor(v).clone().requires_grad_(True) for k, v in ssd.items()}
+        o = tc.stem_forward(tsd, torch.as_tensor(y_cur), torch.as_tensor(y_cond), residual=residual, training=True,
+                            noise={k: torch.as_tensor(v) for k, v in noise.items()})
+        for k in ("y_hat", "lik_y", "lik_z", "scales", "means"):
+            assert dist(o[k].detach().numpy(), o_ref[k]) < 1e-4, (k, residual, dist(o[k].detach().numpy(), o_ref[k]))
+        tc.em_loss(o["lik_y"], o["lik_z"], npix).backward()
+        worst = 0.0
+        for k, ref in g_ref.items():
+            got = tsd[k].grad.numpy().reshape(ref.shape)
+            worst = max(worst, dist(got, ref))
+            assert dist(got, ref) < 1e-4, ("grad " + k, residual, dist(got, ref))
+        assert tsd["entropy_bottleneck.quantiles"].grad is None          # the training forward does not read the quantiles
+        # the masked taps were zeroed in place (layers.py:44-47) and still received gradient
+        w = tsd["context_prediction.weight"]
+        assert float(w.detach()[:, :, 2, 2:].abs().max()) == 0.0 and float(w.grad[:, :, 3:].abs().max()) > 0.0
+    # ---- one optimisation step: clip_grad_norm_(1.0) + Adam(1e-4); auxiliary loss + Adam(1e-3) on the quantiles
+    img = rng.random((1, 3, 64, 64), dtype=np.float32)
+    isd2 = {k: v for k, v in isd.items()}
+    ssd2 = {k: closed_form_tensor(k, s).numpy() for k, s in _stem_keys(64, M).items()}
+    tr = tc.PFrameTrainer(isd2, ssd2)
+    y = orc.g_a(isd2, img)
+    y_noise = rng.uniform(-0.5, 0.5, y.shape).astype(np.float32)
+    nz = {"z": rng.uniform(-.5, .5, (1, 64, 1, 1)).astype(np.float32), "q": rng.uniform(-.5, .5, y.shape).astype(np.float32),
+          "lik": rng.uniform(-.5, .5, y.shape).astype(np.float32)}
+    loss, _ = tr.step(torch.as_tensor(img), {k: torch.as_tensor(v) for k, v in nz.items()}, torch.as_tensor(y_noise))
+    keep = {}
+    o_ref = orc.stem_forward(ssd2, y, y + y_noise, residual=True, training=True, noise=nz, keep=keep)
+    assert abs(loss - (orc.rate_bpp(o_ref["lik_y"], 64 * 64) + orc.rate_bpp(o_ref["lik_z"], 64 * 64))) < 1e-4 * abs(loss)
+    g_ref = orc.stem_backward(ssd2, keep, o_ref["lik_y"], o_ref["lik_z"], 64 * 64)
+    norm = math.sqrt(sum(float(np.vdot(g, g)) for g in g_ref.values()))
+    clip = min(1.0, 1.0 / (norm + 1e-6))
+    for k, g in g_ref.items():          # first Adam step: p -= lr * g / (|g| + eps) elementwise (bias-corrected m / sqrt(v))
+        gk = g.reshape(ssd2[k].shape).astype(np.float64) * clip
+        base = orc.masked_weight(ssd2[k]) if k == "context_prediction.weight" else ssd2[k]      # masked taps were zeroed in place
+        want = base - 1e-4 * gk / (np.abs(gk) + 1e-8)
+        got = tr.ssd[k].detach().numpy()
+        big = np.abs(gk) > 1e-2 * np.abs(gk).max()            # where the gradient (known to ~1e-5 of its maximum) is known to 1e-3
+        assert np.abs(got - want)[big].max() < 2e-6, k
+    # the quantiles moved by the auxiliary step only: first Adam step = -lr * sign(d aux / d q)
+    q0, q1 = ssd2["entropy_bottleneck.quantiles"], tr.ssd["entropy_bottleneck.quantiles"].detach().numpy()
+    moved = np.abs(q1 - q0)
+    assert float(moved.max()) <= 1e-3 * (1 + 1e-3) and float(moved.max()) > 0.5e-3          # fp32 rounding of q - 1e-3 at |q| ~ 10
