@@ -79,6 +79,7 @@ struct ImgArgs {
 
 #ifdef STEM_EXPERIMENTS
 unsigned long long *g_img_stamps = nullptr;
+__device__ unsigned long long g_img_waits[4];      // sums over wavefronts: cycles waiting for vmcnt, at the barrier, in the loop
 #define IMG_STAMP(i)                                                                                                              \
     do {                                                                                                                          \
         if (a.stamps && threadIdx.x == 0)                                                                                         \
@@ -290,6 +291,10 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
     auto run = [&](auto live_tag) {
         constexpr bool LIVE = decltype(live_tag)::value;
         int c = c0_, slab = slab0_, t = t0_, ts = ts0_, toff = toff0_, pend = pend0_;      // loop state private to this instance
+#ifdef STEM_EXPERIMENTS
+        unsigned long long t_vm_ = 0, t_bar_ = 0;
+        const unsigned long long t_loop0_ = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+#endif
         int ab = 0, slot = 0;
         h16x8 fa0[2][NPL], fb0[2][NPL], fa1[2][NPL], fb1[2][NPL];
         int a0 = 0, a1 = 0, b0 = 0;
@@ -355,7 +360,19 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0)
             __builtin_amdgcn_sched_barrier(0);
+#ifdef STEM_EXPERIMENTS
+            const unsigned long long ts0_ = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            const unsigned long long ts1_ = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+            asm volatile("s_barrier" ::: "memory");
+            if (a.stamps) {
+                const unsigned long long ts2_ = __builtin_amdgcn_s_memtime();
+                t_vm_ += ts1_ - ts0_;
+                t_bar_ += ts2_ - ts1_;
+            }
+#else
             asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+#endif
             if (pend >= 0 && pend - 2 <= (last ? slab : slab - 1)) {
                 storeA((pend - s0) & 1);
                 if (pend + 1 <= s_last) {
@@ -393,6 +410,15 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
             slot = nslot; t = nt; ts = nts; toff = ntoff; slab = nslab; ab = nab;
             a0 = na0; a1 = na1; b0 = nb0;
         }
+#ifdef STEM_EXPERIMENTS
+        if (a.stamps && lane == 0) {        // per wavefront: shader cycles in the loop, waiting for the weight DMA, waiting at the barrier
+            unsigned long long *w = a.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+            if (wave == 0) { w[7] = __builtin_amdgcn_s_memtime() - t_loop0_; }
+            atomicAdd(&g_img_waits[0], t_vm_);
+            atomicAdd(&g_img_waits[1], t_bar_);
+            atomicAdd(&g_img_waits[2], __builtin_amdgcn_s_memtime() - t_loop0_);
+        }
+#endif
     };
     if (dead)
         run(std::false_type{});
@@ -563,6 +589,12 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
 #ifdef STEM_EXPERIMENTS
 // tools/debug/f16x3_img_phases.py: a device buffer of 8 x uint64 per workgroup receives s_memrealtime (100 MHz) at the phase borders
 STEM_EXPORT void stem_exper_img_stamps(void *p) { g_img_stamps = static_cast<unsigned long long *>(p); }
+STEM_EXPORT void stem_exper_img_waits(unsigned long long *out4, int reset)
+{
+    unsigned long long z[4] = {0, 0, 0, 0};
+    if (out4) (void)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_img_waits), sizeof(z));
+    if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_img_waits), z, sizeof(z));
+}
 #endif
 
 // ---- host side: called from stem_conv2d_f16x3_gen_fwd (conv_f16x3.hip) -------------------------------------------------------------

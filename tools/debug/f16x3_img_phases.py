@@ -34,9 +34,16 @@ with F.tuning(**tune):
         F.conv2d_f16x3_gen(xp, wp, b, K, R, R, 1, R // 2, epi=F.GEN_EPI_LRELU, slope=0.01, want_planes=True)
     torch.cuda.synchronize()
     lib.stem_exper_img_stamps(stamps.data_ptr())
+    lib.stem_exper_img_waits.argtypes = [C.c_void_p, C.c_int]
+    lib.stem_exper_img_waits.restype = None
+    lib.stem_exper_img_waits(None, 1)
     F.conv2d_f16x3_gen(xp, wp, b, K, R, R, 1, R // 2, epi=F.GEN_EPI_LRELU, slope=0.01, want_planes=True)
     torch.cuda.synchronize()
     lib.stem_exper_img_stamps(None)
+    wbuf = (C.c_uint64 * 4)()
+    lib.stem_exper_img_waits(wbuf, 0)
+    if wbuf[2]:
+        print(f"  wavefront cycles in the main loop: {100.0 * wbuf[0] / wbuf[2]:.1f} % waiting for the weight DMA (vmcnt), {100.0 * wbuf[1] / wbuf[2]:.1f} % at the barrier")
 s = stamps.view(NW, 8).cpu()
 s = s[s[:, 0] > 0].double() / 100.0          # microseconds
 t0 = float(s[:, 0].min())
