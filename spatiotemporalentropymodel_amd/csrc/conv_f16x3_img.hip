@@ -118,8 +118,8 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
     constexpr int HP = TS + KS - 1, NH = HP * HP, PAD = KS / 2;
     constexpr int NAI = (NH * 4 + NTHR - 1) / NTHR;              // 16-byte pieces of one halo plane per thread: 2 / 3 / 4
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *red = reinterpret_cast<float *>(smem + ILDS_MAIN);      // 16 floats
-    int *flag = reinterpret_cast<int *>(smem + ILDS_MAIN + 64);
+    float *red = reinterpret_cast<float *>(smem + ILDS_MAIN);      // 24 floats
+    int *flag = reinterpret_cast<int *>(smem + ILDS_MAIN + 96);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     IMG_STAMP(0);
@@ -244,11 +244,27 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
     }
     float oscale = 1.f;
     if (a.yp) {
-        const float xmax = q_amax512(a.xq, red), wmax = q_amax512(a.wq, red);
-        float bm = 0.f;
+        // max |x| and max |w| over the slots of the operands' records and max |bias|: the loads of all three go out together,
+        // ONE workgroup reduction carries the three maxima (three back-to-back reductions cost 3 us of every launch's start)
+        int nsx = q_nslots(a.xq), nsw = q_nslots(a.wq);
+        nsx = nsx < 0 ? 0 : (nsx > (1 << 20) ? (1 << 20) : nsx);
+        nsw = nsw < 0 ? 0 : (nsw > (1 << 20) ? (1 << 20) : nsw);
+        float xmax = 0.f, wmax = 0.f, bm = 0.f;
+        for (int i = tid; i < nsx; i += NTHR) xmax = fmaxf(xmax, a.xq[QREC_HDR + i]);
+        for (int i = tid; i < nsw; i += NTHR) wmax = fmaxf(wmax, a.wq[QREC_HDR + i]);
         if (a.bias)
             for (int n = tid; n < a.N; n += NTHR) bm = fmaxf(bm, fabsf(a.bias[n]));
-        bm = block_max512(bm, red);
+        xmax = wave_max(xmax); wmax = wave_max(wmax); bm = wave_max(bm);
+        __syncthreads();
+        if (lane == 0) {
+            red[wave] = xmax; red[8 + wave] = wmax; red[16 + wave] = bm;
+        }
+        __syncthreads();
+        xmax = red[0]; wmax = red[8]; bm = red[16];
+#pragma unroll
+        for (int w8 = 1; w8 < NTHR / 64; ++w8) {
+            xmax = fmaxf(xmax, red[w8]); wmax = fmaxf(wmax, red[8 + w8]); bm = fmaxf(bm, red[16 + w8]);
+        }
         const int oe = q_exp((float)(a.C * a.ntaps) * xmax * wmax + bm);
         oscale = q_pow2(oe);
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.yq[1] = q_pow2(-oe);
@@ -322,21 +338,10 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
             // ---- X ----
             // tap walk to chunk c + 1 (scalar)
             const int nslot = slot == 2 ? 0 : slot + 1;
-            int nt, nts, ntoff, nslab = slab, nab = ab;
-            if (last) {
-                nt = 0; nts = 0; ntoff = 0;
-                ++nslab;
-                nab ^= 1;
-            } else {
-                nt = t + 1;
-                if (ts + 1 == KS) {
-                    nts = 0;
-                    ntoff = toff + HP - (KS - 1);
-                } else {
-                    nts = ts + 1;
-                    ntoff = toff + 1;
-                }
-            }
+            const bool rowend = ts + 1 == KS;                      // selects, not branches: the walk sits between two MFMA blocks
+            const int nt = last ? 0 : t + 1, nts = (last || rowend) ? 0 : ts + 1;
+            const int ntoff = last ? 0 : toff + (rowend ? HP - (KS - 1) : 1);
+            const int nslab = slab + (last ? 1 : 0), nab = ab ^ (last ? 1 : 0);
             int na0 = 0, na1 = 0, nb0 = 0;
             if constexpr (LIVE) {
                 rdfrag(a0 ^ 32, a1 ^ 32, b0 ^ 32, fa1, fb1);
