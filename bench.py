@@ -43,6 +43,7 @@ GA0_FLOP_PER_FRAME = 2 * 192 * 3 * 25 * 128 * 128 + 2 * 192 * 192 * 128 * 128   
 USEFUL_FLOP_PER_STEP = 187.1e9 * BATCH
 PEAK_F16_MFMA_TFLOPS = 2516.6        # same guide: v_mfma_f32_32x32x16_f16 / 16x16x32 (equal flop per cycle), 1024 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz (dense)
 F16_PRODUCTS = 3                     # fp16 MFMA products per fp32 product in the split-operand kernels (csrc/stem_common.h)
+PINNED_CPUS = None                   # host cores this rank pinned itself to (multi-GPU runs: distributed.pin_rank_to_gpu_cores)
 
 
 def _apply_bench_tuning(_lib):
@@ -451,6 +452,11 @@ def main():
         args.warmup = 2 if args.config == "roi" else 3
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    # a rank of a multi-GPU run pins itself to the cores of its GPU's NUMA node before anything touches the GPU (sysfs only)
+    global PINNED_CPUS
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        from spatiotemporalentropymodel_amd.distributed import pin_rank_to_gpu_cores
+        PINNED_CPUS = pin_rank_to_gpu_cores(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"])))
     if args.rendezvous_only:
         return rendezvous_only(args)
     if args.config == "roi":
@@ -654,6 +660,7 @@ def main():
                    "stream_priorities": os.environ.get("STEM_STREAM_PRIO", ""),
                    "stream_cu_masks": os.environ.get("STEM_STREAM_CUMASK", "") or "none",
                    "plan_selectors": os.environ.get("STEM_BENCH_TUNING", "") or "library defaults",
+                   "rank0_host_cores": (f"{len(PINNED_CPUS)} cores of the GPU's NUMA node ({PINNED_CPUS[0]}..{PINNED_CPUS[-1]})" if PINNED_CPUS else "not pinned"),
                    "launch": "hipGraph replay per P-frame step" if use_graph else
                              ("explicit fused schedule (trainer.FusedPFrameStep)" if fused_step is not None else "generic nn.Module / autograd route")},
         "roofline": roof,

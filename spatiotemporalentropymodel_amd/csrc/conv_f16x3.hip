@@ -896,6 +896,10 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
     // ---- sums of this workgroup -> the epilogue tile T (directly, or through the split-K workspace) -----------------------
     float *T = reinterpret_cast<float *>(smem);                     // [GBM][GTP]
     const int Npad = gridDim.y * GBN;
+    // every pass of the epilogue gives a thread the same pieces: column group ec4 (4 floats), tile rows er0 + ERS k
+    constexpr int ERS = GNT / 32, ER = GBM / ERS;                   // 8 pieces per thread
+    const int ec4 = tid & 31, er0 = tid >> 5;
+    f32x4 ev[ER];
     if (a.nsplit > 1) {
         float *wsp = a.ws + (size_t)zsplit * Mtot * Npad;
 #pragma unroll
@@ -922,53 +926,76 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
         constexpr int SC1 = 16;               // sc1: read at the device-coherent level, not this XCD's L2
         const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)((size_t)a.nsplit * Mtot * Npad * 4), 0x00020000);
         const int sstep = Mtot * Npad * 4;
-        for (int e = tid; e < GBM * (GBN / 4); e += GNT) {
-            const int row = e / (GBN / 4), c4 = e - row * (GBN / 4);
-            const int m = bm0 + row;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < Mtot) {
-                const int off0 = (m * Npad + bn0 + c4 * 4) * 4;
-                int sp = 0;
-                for (; sp + 4 <= a.nsplit; sp += 4) {
-                    f32x4 t[4];
+        // the last arriver sums the slabs in split order, 4 pieces x 4 splits in flight (the read is latency-bound: ~1 us
+        // per dependent round of cross-XCD sc1 loads; it used to keep 4 loads in flight per thread)
+        int eoff[ER];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) t[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, off0 + (sp + u) * sstep, 0, SC1));
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) v += t[u];
-                }
-                for (; sp < a.nsplit; ++sp) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, off0 + sp * sstep, 0, SC1));
-            }
-            *reinterpret_cast<f32x4 *>(&T[row * GTP + c4 * 4]) = v;
+        for (int k = 0; k < ER; ++k) {
+            const int m = bm0 + er0 + ERS * k;
+            eoff[k] = m < Mtot ? (m * Npad + bn0 + ec4 * 4) * 4 : OOR;
         }
+#pragma unroll
+        for (int k = 0; k < ER; ++k) ev[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (4 pieces x 4 splits = 16 loads = 64 registers per round: the kernel keeps its two workgroups per CU -- 128 registers)
+#pragma unroll
+        for (int kb = 0; kb < ER; kb += 4)
+            for (int sp = 0; sp < a.nsplit; sp += 4) {
+                f32x4 tt[4][4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        tt[k][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, sp + u < a.nsplit ? eoff[kb + k] : OOR,
+                                                                                                      (sp + u < a.nsplit ? sp + u : 0) * sstep, SC1));
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ev[kb + k] += tt[k][u];          // beyond nsplit: zeros (out-of-range loads)
+            }
     } else {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) T[ROWL(r) * GTP + COLL(j, r)] = acc[j][r];
-    }
-    __syncthreads();
-    float omax = 0.f;
-    // ---- bias / activation, fp32 rows (16 bytes per thread), activated values back into T for the planes pass -----------------
-    for (int e = tid; e < GBM * (GBN / 4); e += GNT) {
-        const int row = e / (GBN / 4), c4 = e - row * (GBN / 4);
-        const int m = bm0 + row, n = bn0 + c4 * 4;
-        if (m >= Mtot || n >= a.N) continue;                // N % 4 == 0 (host check)
-        f32x4 v = *reinterpret_cast<const f32x4 *>(&T[row * GTP + c4 * 4]) * fac;
-        if (a.bias) {               // parameters may sit at any 4-byte offset of a flat buffer: scalar loads
+        __syncthreads();
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] += a.bias[n + c];
+        for (int k = 0; k < ER; ++k) ev[k] = *reinterpret_cast<const f32x4 *>(&T[(er0 + ERS * k) * GTP + ec4 * 4]);
+    }
+    float omax = 0.f;
+    // ---- bias / activation, fp32 rows (16 bytes per thread), activated values into T for the planes pass.  A thread's four
+    // columns are the same in every pass (GNT % 32 == 0): its bias values are loaded once, the z rows of the DACT epilogue all at
+    // once (per-row dependent loads cost ~0.5 us each: 8 us of a 26 us launch)
+    const int ecol = bn0 + ec4 * 4;
+    const bool colok = ecol < a.N;                      // N % 4 == 0 (host check)
+    f32x4 ebias = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias && colok) {               // parameters may sit at any 4-byte offset of a flat buffer: scalar loads
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ebias[c] = a.bias[ecol + c];
+    }
+    f32x4 ez[ER];
+    if (a.epi == GEN_EPI_DACT) {
+#pragma unroll
+        for (int k = 0; k < ER; ++k) {
+            const int m = bm0 + er0 + ERS * k;
+            ez[k] = (colok && m < Mtot) ? *reinterpret_cast<const f32x4 *>(a.z + (size_t)m * a.ldz + ecol) : f32x4{1.f, 1.f, 1.f, 1.f};
         }
+    }
+#pragma unroll
+    for (int k = 0; k < ER; ++k) {
+        const int row = er0 + ERS * k, m = bm0 + row;
+        f32x4 v = ev[k] * fac + ebias;
         if (a.epi == GEN_EPI_LRELU) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = v[c] > 0.f ? v[c] : v[c] * a.slope;
         } else if (a.epi == GEN_EPI_DACT) {
-            const f32x4 zz = *reinterpret_cast<const f32x4 *>(a.z + (size_t)m * a.ldz + n);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = zz[c] > 0.f ? v[c] : v[c] * a.slope;
+            for (int c = 0; c < 4; ++c) v[c] = ez[k][c] > 0.f ? v[c] : v[c] * a.slope;
         }
-        if (a.y) *reinterpret_cast<f32x4 *>(a.y + (size_t)m * a.ldy + n) = v;
-        *reinterpret_cast<f32x4 *>(&T[row * GTP + c4 * 4]) = v;
-        omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        if (colok && m < Mtot) {
+            if (a.y) *reinterpret_cast<f32x4 *>(a.y + (size_t)m * a.ldy + ecol) = v;
+            omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+        if (a.yp) *reinterpret_cast<f32x4 *>(&T[row * GTP + ec4 * 4]) = v;
     }
     if (a.yq) {
         omax = block_max(omax, qred);

@@ -610,6 +610,7 @@ bool stem_fx3_img_eligible(int B, int H, int W, int N, int R, int S, int stride,
     // 42 / 32 / 29 us against 47 / 36 / 30 alone, training step 15.14 against 15.27 ms on one box)
     const int sel = stem_tuning(STEM_TUNE_FX3_GEN_IMG);
     if (sel == 1) return false;
+    if (stem_tuning(STEM_TUNE_FX3_GEN_TILE)) return false;         // a forced pixel tile of the 128-pixel form asks for that form
     if (R == 1 && sel != 2) return false;
     if (stride != 1 || R != S || (R != 1 && R != 3 && R != 5) || pad != R / 2) return false;
     const long tiles = (long)cdiv(H, TS) * cdiv(W, TS);

@@ -342,3 +342,67 @@ def max_over_ranks(value: float, device) -> float:
 def barrier():
     if dist.is_initialized():
         dist.barrier()
+
+
+# ---- host-side placement of a rank: the cores next to its GPU ----------------------------------------------------------------------
+def _parse_cpulist(text):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_cpu_lists(sysfs_root="/sys"):
+    """[cpus next to HIP device 0, device 1, ...]: the GPU nodes of the KFD topology in node order (= HIP's default device
+    order), each with the `local_cpulist` of its PCI device (the cores of the GPU's NUMA node).  Reads sysfs only -- no HIP
+    call, so a rank can use it before it initialises its GPU.  [] when the topology cannot be read."""
+    nodes_dir = os.path.join(sysfs_root, "class", "kfd", "kfd", "topology", "nodes")
+    out = []
+    try:
+        ids = sorted(int(n) for n in os.listdir(nodes_dir) if n.isdigit())
+    except OSError:
+        return []
+    for nid in ids:
+        try:
+            props = dict(line.split(None, 1) for line in open(os.path.join(nodes_dir, str(nid), "properties")) if " " in line.strip())
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) == 0:           # a CPU node of the topology
+            continue
+        minor = props.get("drm_render_minor", "").strip()
+        try:
+            cpus = _parse_cpulist(open(os.path.join(sysfs_root, "class", "drm", f"renderD{minor}", "device", "local_cpulist")).read())
+        except (OSError, ValueError):
+            cpus = []
+        out.append(cpus)
+    return out
+
+
+def pin_rank_to_gpu_cores(local_rank, local_world=1, sysfs_root="/sys", apply=True):
+    """Restrict this process to the host cores of its GPU's NUMA node, BEFORE it makes any GPU call (the HIP runtime's helper
+    threads inherit the mask): with 8 ranks on one host the enqueueing thread of a rank (10+ ms of Python + ctypes per bench
+    step) otherwise migrates across sockets, away from its GPU's PCIe root.  Ranks whose GPUs share a node split that node's
+    cores evenly (SMT siblings stay together when the list enumerates them pairwise).  Returns the core list, or None when the
+    topology is unknown / STEM_PIN_RANKS=0 -- the run then keeps the inherited mask."""
+    if os.environ.get("STEM_PIN_RANKS", "1") == "0":
+        return None
+    lists = gpu_cpu_lists(sysfs_root)
+    if not lists or local_rank >= len(lists) or not lists[local_rank]:
+        return None
+    mine = lists[local_rank]
+    sharers = [r for r in range(min(local_world, len(lists))) if lists[r] == mine]
+    if local_rank in sharers and len(sharers) > 1 and len(mine) >= len(sharers):
+        per = len(mine) // len(sharers)
+        i = sharers.index(local_rank)
+        mine = mine[i * per:(i + 1) * per]
+    try:
+        allowed = os.sched_getaffinity(0)
+        cpus = sorted(c for c in mine if c in allowed) or None
+        if cpus and apply:
+            os.sched_setaffinity(0, cpus)
+        return cpus
+    except (AttributeError, OSError):
+        return None

@@ -328,3 +328,40 @@ def test_backend_choice_follows_device_count(monkeypatch):
     monkeypatch.delenv("STEM_DIST_SINGLE", raising=False)
     D.init_from_env()
     assert not seen
+
+
+def test_rank_pinning_reads_the_gpu_numa_topology(tmp_path, monkeypatch):
+    """distributed.pin_rank_to_gpu_cores: GPU nodes of a (fake) KFD topology in node order, each with the cores of its PCI
+    device's NUMA node; ranks whose GPUs share a node split its cores; unknown topology / STEM_PIN_RANKS=0 leave the mask alone."""
+    from spatiotemporalentropymodel_amd import distributed as D
+    root = tmp_path / "sys"
+    nodes = root / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    # two CPU nodes, then four GPUs: two on NUMA node 0 (cpus 0-3), two on node 1 (cpus 4-7)
+    layout = [(0, None), (0, None), (64, "0-3"), (64, "0-3"), (64, "4-7"), (64, "4-5,6-7")]
+    for i, (simd, cpus) in enumerate(layout):
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text(f"cpu_cores_count 0\nsimd_count {simd}\ndrm_render_minor {128 + i}\n")
+        if cpus is not None:
+            d = root / "class" / "drm" / f"renderD{128 + i}" / "device"
+            d.mkdir(parents=True)
+            (d / "local_cpulist").write_text(cpus + "\n")
+    assert D.gpu_cpu_lists(str(root)) == [[0, 1, 2, 3], [0, 1, 2, 3], [4, 5, 6, 7], [4, 5, 6, 7]]
+    monkeypatch.delenv("STEM_PIN_RANKS", raising=False)
+    monkeypatch.setattr(D.os, "sched_getaffinity", lambda pid: set(range(8)), raising=False)
+    got = [D.pin_rank_to_gpu_cores(r, 4, str(root), apply=False) for r in range(4)]
+    assert got == [[0, 1], [2, 3], [4, 5], [6, 7]]
+    assert D.pin_rank_to_gpu_cores(2, 1, str(root), apply=False) == [4, 5, 6, 7]      # alone on its node: all of it
+    assert D.pin_rank_to_gpu_cores(5, 8, str(root), apply=False) is None              # no such device
+    assert D.pin_rank_to_gpu_cores(0, 4, str(tmp_path / "nothing"), apply=False) is None
+    monkeypatch.setenv("STEM_PIN_RANKS", "0")
+    assert D.pin_rank_to_gpu_cores(0, 4, str(root), apply=False) is None
+    # applying really narrows the mask (to cores this process is allowed to use)
+    monkeypatch.delenv("STEM_PIN_RANKS", raising=False)
+    monkeypatch.undo()
+    allowed = sorted(os.sched_getaffinity(0))
+    d = root / "class" / "drm" / "renderD130" / "device"
+    (d / "local_cpulist").write_text(f"{allowed[0]}\n")
+    try:
+        assert D.pin_rank_to_gpu_cores(0, 1, str(root)) == [allowed[0]] and sorted(os.sched_getaffinity(0)) == [allowed[0]]
+    finally:
+        os.sched_setaffinity(0, allowed)
