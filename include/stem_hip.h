@@ -80,6 +80,14 @@ typedef struct {
 } stem_unpack_desc;
 int stem_pack_weights_multi(const stem_pack_desc *descs, int n, void *stream);
 int stem_unpack_wgrads_multi(const stem_unpack_desc *descs, int n, void *stream);
+/* Second stage of the bias gradient (the `.bias.grad` autograd leaves for a Conv2d, stem/trainSTEM.py:212) for up to 24 layers
+ * with one launch: db (+)= sum over `parts` rows of part[parts][K] -- the per-split column sums stem_conv2d_wgrad_f16x3 leaves. */
+typedef struct {
+    const float *part;
+    float *db;
+    int K, parts, accumulate, reserved;
+} stem_bias_final_desc;
+int stem_bias_grad_final_multi(const stem_bias_final_desc *descs, int n, void *stream);
 
 /* ---- epilogues --------------------------------------------------------- */
 enum { STEM_ACT_NONE = 0, STEM_ACT_LRELU = 1 };

@@ -25,6 +25,7 @@ _HIP_SIG = {
     "stem_unpack_wgrad": [vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "stem_pack_weights_multi": [vp, ci, vp],
     "stem_unpack_wgrads_multi": [vp, ci, vp],
+    "stem_bias_grad_final_multi": [vp, ci, vp],
     "stem_conv2d_fwd": [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, sz, vp],
     "stem_conv2d_fwd_c4": [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_conv2d_dgrad": [vp, ci, vp, vp, ci, vp, ci, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],
@@ -170,6 +171,10 @@ class F16PackDesc(C.Structure):
 
 class UnpackDesc(C.Structure):
     _fields_ = [("dwp", vp), ("dw", vp), ("K", ci), ("C", ci), ("R", ci), ("S", ci), ("splits", ci), ("flags", ci)]
+
+
+class BiasFinalDesc(C.Structure):
+    _fields_ = [("part", vp), ("db", vp), ("K", ci), ("parts", ci), ("accumulate", ci), ("reserved", ci)]
 
 
 class WaveSeg(C.Structure):

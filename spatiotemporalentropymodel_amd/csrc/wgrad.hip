@@ -587,6 +587,50 @@ STEM_EXPORT int stem_bias_grad_final(const float *part, int K, int parts, float 
     return 0;
 }
 
+// every pending bias gradient of a module group with ONE launch: blockIdx.y = descriptor (the second stage used to be one
+// 5-us launch per layer, 13 per P-frame step, each with its dispatch gap on the weight-gradient stream)
+namespace {
+constexpr int MAXBIASFIN = 24;
+struct BiasFinTable {
+    stem_bias_final_desc d[MAXBIASFIN];
+};
+__global__ __launch_bounds__(1024) void colsum_final_multi_kernel(const BiasFinTable tb)
+{
+    __shared__ float red[16][64];
+    const stem_bias_final_desc d = tb.d[blockIdx.y];
+    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= d.K) return;                 // workgroup-uniform: this tensor has fewer 64-column blocks than the widest
+    float s = 0.f;
+    if (c < d.K)
+        for (int p = r; p < d.parts; p += 16) s += d.part[(size_t)p * d.K + c];
+    red[r][lane] = s;
+    __syncthreads();
+    if (r == 0 && c < d.K) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += red[q][lane];           // the summation order of colsum_final_kernel: same bits
+        d.db[c] = d.accumulate ? d.db[c] + v : v;
+    }
+}
+}   // namespace
+
+STEM_EXPORT int stem_bias_grad_final_multi(const stem_bias_final_desc *descs, int n, void *stream)
+{
+    STEM_CHECK_ARG(descs && n >= 1 && n <= MAXBIASFIN, "stem_bias_grad_final_multi: 1..%d descriptors per call, got %d", MAXBIASFIN, n);
+    BiasFinTable tb;
+    memset(&tb, 0, sizeof(tb));
+    int kmax = 0;
+    for (int i = 0; i < n; ++i) {
+        STEM_CHECK_ARG(descs[i].part && descs[i].db && descs[i].K >= 1 && descs[i].parts >= 1, "stem_bias_grad_final_multi: descriptor %d", i);
+        tb.d[i] = descs[i];
+        if (descs[i].K > kmax) kmax = descs[i].K;
+    }
+    hipLaunchKernelGGL(colsum_final_multi_kernel, dim3(cdiv(kmax, 64), n), dim3(1024), 0, (hipStream_t)stream, tb);
+    STEM_LAUNCH_CHECK("stem_bias_grad_final_multi");
+    return 0;
+}
+
 STEM_EXPORT int stem_bias_grad(const float *dy, int lddy, long npix, int K, float *scratch, float *db, int accumulate, void *stream)
 {
     STEM_CHECK_ARG(dy && scratch && db && npix >= 1 && K >= 1 && lddy >= K, "stem_bias_grad: bad arguments");

@@ -150,7 +150,8 @@ class _Layer:
                                 torch.empty(splits * self.K, device=dy.device, dtype=torch.float32))
         dwp, splits, bpart = self._slabs[key]
         gb = _grad_of(self.mod.bias) if self.mod.bias is not None else None
-        F.conv2d_wgrad_f16x3(xp, dyp, self.K, self.R, self.R, self.pad, dwp, splits, db=gb, bias_part=bpart, accumulate_db=True)
+        self.pending_bias = F.conv2d_wgrad_f16x3(xp, dyp, self.K, self.R, self.R, self.pad, dwp, splits, db=gb, bias_part=bpart,
+                                                 accumulate_db=True, defer_bias=self.eng.defer_bias_final)
         self.pending = (dwp, splits)
 
     def _desc32(self, role):
@@ -422,17 +423,36 @@ class StemEngine:
     #: so a data-parallel reducer can start exchanging that slice while the rest of backward still runs
     grad_ready_hook = None
 
+    #: the slab sums (unpack_multi) and the bias gradients' second stages of a module group run on a stream of their own behind
+    #: the group's weight-gradient kernels: the weight-gradient stream is the longest serial chain of a P-frame step's backward
+    #: (13 launches + 13 bias finals + 5 slab sums, ~1.05 ms of 1.95 in a kernel trace), and these HBM-bound passes overlap the
+    #: next group's matrix kernels; STEM_ENGINE_UNPACK_STREAM=0: on the weight-gradient stream as before
+    unpack_stream = os.environ.get("STEM_ENGINE_UNPACK_STREAM", "0") != "0"
+    #: one launch for a group's bias-gradient second stages (stem_bias_grad_final_multi); STEM_ENGINE_BIAS_MULTI=0: one per layer
+    defer_bias_final = os.environ.get("STEM_ENGINE_BIAS_MULTI", "1") != "0"
+
     def _group_ready(self, layers, extra_params):
         dev = layers[0].mod.weight.device
         side = self.side_stream(dev, layers[0].lane)
         if side is None:
             return self._group_ready_on_stream(layers, extra_params)
         # extra_params (entropy-bottleneck gradients) were produced on the compute stream: order them before the hook
-        F.stream_wait(side, F.cur_stream(dev))
-        with F.on_stream(side):
+        us = side
+        if self.unpack_stream:
+            us = self._side.get("unpack")
+            if us is None or us.device != dev:
+                us = self._side["unpack"] = F.make_stream(dev, "side")
+            F.stream_wait(us, side)
+        F.stream_wait(us, F.cur_stream(dev))
+        with F.on_stream(us):
             self._group_ready_on_stream(layers, extra_params)
 
     def _group_ready_on_stream(self, layers, extra_params):
+        bdescs = [l.pending_bias for l in layers if getattr(l, "pending_bias", None) is not None]
+        for l in layers:
+            l.pending_bias = None
+        if bdescs:
+            F.bias_grad_final_multi(bdescs)
         descs = [l.unpack_desc() for l in layers if l.pending is not None]
         if descs:
             arr = (_lib.UnpackDesc * len(descs))(*descs)

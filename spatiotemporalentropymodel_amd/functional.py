@@ -726,7 +726,14 @@ def conv2d_wgrad_f16x3_into(xp: F16Planes, dyp: F16Planes, K, R, S, pad, dw_out,
     _chk(_lib.hip().stem_unpack_wgrad(dwp.data_ptr(), dw_out.data_ptr(), K, Cc, R, S, splits, UNPACK_ACCUMULATE if accumulate else 0, _stream()))
 
 
-def conv2d_wgrad_f16x3(xp: F16Planes, dyp: F16Planes, K, R, S, pad, dwp, splits, db=None, bias_part=None, accumulate_db=False):
+def bias_grad_final_multi(descs):
+    """descs: list of _lib.BiasFinalDesc -- every pending second stage of a module group's bias gradients with one launch"""
+    for i in range(0, len(descs), 24):
+        chunk = descs[i:i + 24]
+        _chk(_lib.hip().stem_bias_grad_final_multi((_lib.BiasFinalDesc * len(chunk))(*chunk), len(chunk), _stream()))
+
+
+def conv2d_wgrad_f16x3(xp: F16Planes, dyp: F16Planes, K, R, S, pad, dwp, splits, db=None, bias_part=None, accumulate_db=False, defer_bias=False):
     """packed weight-gradient slabs [splits][R*S][K][C] of a stride-1 convolution from planes operands (channel views allowed).
     With `db` (and a `bias_part` scratch of splits * K floats) the bias gradient comes out of the same pass: the kernel leaves
     per-split column sums of dy, a second tiny launch adds them into db."""
@@ -736,8 +743,11 @@ def conv2d_wgrad_f16x3(xp: F16Planes, dyp: F16Planes, K, R, S, pad, dwp, splits,
     _chk(_lib.hip().stem_conv2d_wgrad_f16x3(xp.data_ptr(), xp.q_ptr(), xp.pix_bytes, dyp.data_ptr(), dyp.q_ptr(), dyp.pix_bytes, dwp.data_ptr(),
                                              _ptr(bias_part) if db is not None else None,
                                              B, H, W, Cc, K, R, S, pad, splits, _stream()))
+    if db is not None and defer_bias:           # the caller sums the per-split column sums later (bias_grad_final_multi)
+        return _lib.BiasFinalDesc(bias_part.data_ptr(), db.data_ptr(), K, splits, int(accumulate_db), 0)
     if db is not None:
         _chk(_lib.hip().stem_bias_grad_final(bias_part.data_ptr(), K, splits, db.data_ptr(), int(accumulate_db), _stream()))
+    return None
 
 
 _BIAS_SCRATCH = {}
