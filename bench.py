@@ -443,6 +443,8 @@ def main():
                     "calls (selfcheck.p_frame_step) instead of the explicit fused schedule (trainer.FusedPFrameStep)")
     ap.add_argument("--graph", action="store_true", help="replay the P-frame step from its hipGraph (graphs.GraphedPFrameStep) instead of "
                     "issuing it kernel by kernel: 2 ms instead of 11-22 ms of host time per step, same GPU time (DESIGN.md §7)")
+    ap.add_argument("--tape", type=int, default=int(os.environ.get("STEM_BENCH_TAPE", "1")), help="1: the P-frame step through the launch tape "
+                    "(tape.TapedPFrameStep: recorded once, replayed by csrc/tape.hip; bit-identical, ~3 instead of ~11 ms of host time per step)")
     ap.add_argument("--rendezvous-only", action="store_true", help="set up the ranks, run one all-reduce and the timing reduction, exit "
                     "(launcher / process-group check without the workload; works without a GPU)")
     args = ap.parse_args()
@@ -519,6 +521,9 @@ def main():
     if not args.generic and not use_graph:
         from spatiotemporalentropymodel_amd.trainer import FusedPFrameStep
         fused_step = FusedPFrameStep(stem, opt, aux_opt)
+        if args.tape:               # the native executor: the schedule recorded in the first warm-up step, replayed from C++ afterwards
+            from spatiotemporalentropymodel_amd.tape import TapedPFrameStep
+            fused_step = TapedPFrameStep(fused_step)
     graphed = None
     if use_graph:
         from spatiotemporalentropymodel_amd.graphs import GraphedPFrameStep
@@ -662,7 +667,8 @@ def main():
                    "plan_selectors": os.environ.get("STEM_BENCH_TUNING", "") or "library defaults",
                    "rank0_host_cores": (f"{len(PINNED_CPUS)} cores of the GPU's NUMA node ({PINNED_CPUS[0]}..{PINNED_CPUS[-1]})" if PINNED_CPUS else "not pinned"),
                    "launch": "hipGraph replay per P-frame step" if use_graph else
-                             ("explicit fused schedule (trainer.FusedPFrameStep)" if fused_step is not None else "generic nn.Module / autograd route")},
+                             (("explicit fused schedule (trainer.FusedPFrameStep)" + (" replayed from its launch tape by the native executor (tape.TapedPFrameStep, csrc/tape.hip)"
+                                                                                          if args.tape else "")) if fused_step is not None else "generic nn.Module / autograd route")},
         "roofline": roof,
         "roofline_first_layer": first_line,
         "useful_tflops_per_gpu": USEFUL_FLOP_PER_STEP / (dt / args.steps) / 1e12,

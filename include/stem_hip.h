@@ -40,6 +40,20 @@ int stem_abi_version(void);
  * counterpart (torch picks its kernels internally).  Nothing in the library reads the environment to change results:
  * ablated / instrumented variants exist only in builds with -DSTEM_EXPERIMENTS, which
  * stem_built_with_experiments() reports (0 for the shipped library).                                                  */
+/* ---- launch tape: the native executor of a static launch schedule (csrc/tape.hip; reference loop body stem/trainSTEM.py:194-218,
+ * which the reference walks through the Python interpreter and autograd every step).  A tape holds calls of THIS library's
+ * int-returning entry points (function address + integer-class / float arguments; integer arguments may advance by a fixed
+ * amount per replay: Adam's step count, Philox offsets), stream hand-overs and event records / waits; stem_tape_replay re-issues
+ * a range of it on the streams it was recorded on. */
+void *stem_tape_create(void);
+void stem_tape_destroy(void *tape);
+int stem_tape_length(void *tape);
+int stem_tape_add_call(void *tape, void *fn, int nargs, const unsigned char *kinds, const long long *ivals, const double *fvals,
+                       const long long *ideltas);
+int stem_tape_add_wait(void *tape, void *waiting_stream, void *signalling_stream);
+int stem_tape_add_event(void *tape, void *event, void *stream, int wait);
+int stem_tape_replay(void *tape, int lo, int hi, long long n);
+int stem_copy_d2d(void *dst, const void *src, size_t nbytes, void *stream);
 int stem_tuning_set(const char *name, int value);
 int stem_tuning_get(const char *name);
 int stem_built_with_experiments(void);

@@ -135,11 +135,20 @@ _HIP_SIG = {
     "stem_adam_chunk": [],
     "stem_adam_step_bmax": [vp, vp, vp, vp, sz, vp, cf, cf, cf, cf, cf, cf, ci, ci, vp, vp],
     "stem_built_with_experiments": [],
+    "stem_tape_create": [],
+    "stem_tape_destroy": [vp],
+    "stem_tape_length": [vp],
+    "stem_tape_add_call": [vp, vp, ci, vp, vp, vp, vp],
+    "stem_tape_add_wait": [vp, vp, vp],
+    "stem_tape_add_event": [vp, vp, vp, ci],
+    "stem_tape_replay": [vp, ci, ci, C.c_longlong],
+    "stem_copy_d2d": [vp, vp, sz, vp],
     "stem_tuning_set": [C.c_char_p, ci],
     "stem_tuning_get": [C.c_char_p],
     "stem_last_error": [],
 }
-_RESTYPE = {"stem_c4gdn_stream_bytes": sz, "stem_adam_chunk": sz, "stem_f16x2_planes_qrec_offset": sz, "stem_nhwc4_qrec_floats": sz, "stem_bias_grad_scratch_elems": sz, "stem_f16x2_conv_weight_gen_bytes": sz, "stem_conv2d_f16x3_gen_workspace_bytes": sz, "stem_f16x2_planes_bytes": sz, "stem_f16x2_conv_weight_bytes": sz, "stem_packed_weight_elems": sz, "stem_gdn_bwd_workspace_bytes": sz, "stem_wgrad_workspace_elems": sz, "stem_conv_workspace_bytes": sz, "stem_last_error": C.c_char_p}
+_RESTYPE = {"stem_c4gdn_stream_bytes": sz, "stem_adam_chunk": sz, "stem_f16x2_planes_qrec_offset": sz, "stem_nhwc4_qrec_floats": sz, "stem_bias_grad_scratch_elems": sz, "stem_f16x2_conv_weight_gen_bytes": sz, "stem_conv2d_f16x3_gen_workspace_bytes": sz, "stem_f16x2_planes_bytes": sz, "stem_f16x2_conv_weight_bytes": sz, "stem_packed_weight_elems": sz, "stem_gdn_bwd_workspace_bytes": sz, "stem_wgrad_workspace_elems": sz, "stem_conv_workspace_bytes": sz, "stem_last_error": C.c_char_p,
+             "stem_tape_create": vp, "stem_tape_destroy": None}
 
 _RANS_SIG = {
     "stem_rans_encode": [vp, vp, sz, vp, ci, ci, vp, vp, vp, sz],

@@ -270,6 +270,7 @@ class StemEngine:
         self._checked = False
         self._dgrad_pack_event = None
         self._fwd32_pack_event = None
+        self._events = {}
         # the hyper path's weight gradients (HE, HD) queue on their own stream: the 13 weight-gradient launches of a step would
         # otherwise run one after the other and finish ~0.3 ms after the last input-gradient kernel
         if self.wgrad_lanes > 1:
@@ -402,15 +403,16 @@ class StemEngine:
                     F.stream_wait(bs, F.cur_stream(dev))
                     with F.on_stream(bs):
                         F.pack_weights_multi((_lib.PackDesc * len(descs))(*descs))
-                        self._fwd32_pack_event = torch.cuda.Event()
-                        self._fwd32_pack_event.record(bs)
+                        # one event object for the lifetime of the engine: a launch tape replays the record and the wait on it
+                        self._fwd32_pack_event = self._events.setdefault("fwd32", torch.cuda.Event())
+                        F.event_record(self._fwd32_pack_event, bs)
                 elif descs:
                     F.pack_weights_multi((_lib.PackDesc * len(descs))(*descs))
                     if not on_side:
                         self._fwd32_pack_event = None
                 if on_side:
-                    self._dgrad_pack_event = torch.cuda.Event()
-                    self._dgrad_pack_event.record(side)
+                    self._dgrad_pack_event = self._events.setdefault("dgrad", torch.cuda.Event())
+                    F.event_record(self._dgrad_pack_event, side)
         # masked == 2 zeroed taps of the context weight in place: refresh its version in the key
         self._pack_key = tuple((_layers.weight_epoch(l.mod.weight), l.mod.weight._version, l.mod.weight.data_ptr()) for l in self.layers)
 
@@ -460,7 +462,8 @@ class StemEngine:
         if self.grad_ready_hook is not None:
             params = [p for l in layers for p in (l.mod.weight, l.mod.bias) if p is not None] + list(extra_params)
             if params:
-                self.grad_ready_hook(params)
+                hook = self.grad_ready_hook
+                F.tape_py(lambda: hook(params))          # torch.distributed calls: a launch tape re-runs them at this point
 
     def join_side_stream(self):
         for st in self._side.values():
@@ -470,12 +473,12 @@ class StemEngine:
         """a consumer of a forward-role fp32 weight copy: order it after the packing on the hyper branch's stream (a no-op
         for the hyper branch itself, which runs on that stream)"""
         if self._fwd32_pack_event is not None:
-            F.cur_stream().wait_event(self._fwd32_pack_event)
+            F.event_wait(F.cur_stream(), self._fwd32_pack_event)
 
     def _wait_dgrad_packs(self):
         """backward's first consumer of an input-gradient weight copy: order it after the side-stream packing"""
         if self._dgrad_pack_event is not None:
-            F.cur_stream().wait_event(self._dgrad_pack_event)
+            F.event_wait(F.cur_stream(), self._dgrad_pack_event)
             self._dgrad_pack_event = None
 
     # -------------------------------------------------------------------------------------------

@@ -79,6 +79,44 @@ def stream_wait(dst, src):
         ev = _WAIT_EVENTS[key] = torch.cuda.Event()
     ev.record(src)
     ev.wait(dst)
+    if _TAPE is not None:
+        _TAPE.entries.append(("wait", dst.cuda_stream, src.cuda_stream))
+
+
+#: the launch tape that is recording (tape.recording), or None.  The schedule's synchronisation goes through the helpers below so
+#: that a recording sees it; outside a recording they are the plain torch calls.
+_TAPE = None
+
+
+def event_record(ev, stream):
+    """ev.record(stream) for an event the schedule re-uses every step (a tape replays the record on the same event)"""
+    ev.record(stream)
+    if _TAPE is not None:
+        _TAPE.entries.append(("evrec", ev.cuda_event, stream.cuda_stream))
+        _TAPE.keep.append(ev)
+
+
+def event_wait(stream, ev):
+    """stream.wait_event(ev)"""
+    stream.wait_event(ev)
+    if _TAPE is not None:
+        _TAPE.entries.append(("evwait", stream.cuda_stream, ev.cuda_event))
+        _TAPE.keep.append(ev)
+
+
+def tape_py(fn):
+    """call fn() now; under a recording also log it, so that a replay calls it at this point of the schedule, with the stream
+    that is current now (the data-parallel exchange: torch.distributed calls in the middle of backward)"""
+    if _TAPE is not None:
+        _TAPE.entries.append(("py", fn, cur_stream()))
+    return fn()
+
+
+def copy_d2d(dst, src):
+    """dst <- src (same byte count, both dense) as a library call on the current stream: recordable, unlike Tensor.copy_"""
+    assert dst.numel() * dst.element_size() == src.numel() * src.element_size()
+    _chk(_lib.hip().stem_copy_d2d(dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size(), _stream()))
+    return dst
 
 
 _STREAM_PRIO = None
@@ -467,11 +505,11 @@ def deconv2d_wgrad(x, dy, K, R, S, stride, pad, opad, dw_out=None, db_out=None, 
 
 def pack_weights_multi(descs):
     """descs: ctypes array of _lib.PackDesc"""
-    _chk(_lib.hip().stem_pack_weights_multi(C.addressof(descs), len(descs), _stream()))
+    _chk(_lib.hip().stem_pack_weights_multi(descs, len(descs), _stream()))       # the array object itself: a launch tape keeps it alive
 
 
 def unpack_wgrads_multi(descs):
-    _chk(_lib.hip().stem_unpack_wgrads_multi(C.addressof(descs), len(descs), _stream()))
+    _chk(_lib.hip().stem_unpack_wgrads_multi(descs, len(descs), _stream()))
 
 
 def gdn_fwd(x, beta, gamma, inverse=False, beta_min=1e-6, out=None):
@@ -675,7 +713,8 @@ def pack_weights_f16x2_multi(descs):
     """descs: ctypes array of _lib.F16PackDesc (at most 24 per call: the table is a kernel argument)"""
     for i in range(0, len(descs), 24):
         n = min(24, len(descs) - i)
-        _chk(_lib.hip().stem_f16x2_pack_conv_weights_multi(C.byref(descs, i * C.sizeof(_lib.F16PackDesc)), n, _stream()))
+        part = descs if (i == 0 and n == len(descs)) else (_lib.F16PackDesc * n).from_buffer(descs, i * C.sizeof(_lib.F16PackDesc))
+        _chk(_lib.hip().stem_f16x2_pack_conv_weights_multi(part, n, _stream()))      # (an array object, not byref: a launch tape keeps it alive)
 
 
 def conv2d_f16x3_gen(xp: F16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EPI_BIAS, slope=LRELU_SLOPE, z=None, out=None,

@@ -1,0 +1,269 @@
+"""Launch tapes: the training schedule recorded once and replayed by the native executor (csrc/tape.hip).
+
+`trainer.FusedPFrameStep.step` walks ~85 C-ABI launches per P-frame step through Python + ctypes (~20 us each: 10.9 ms of host
+time per bench step against ~14 ms of GPU time).  The schedule is static per geometry, so `TapedPFrameStep` records it --
+
+  * every int-returning call into libstem_hip.so (function address, arguments by class, the arrays it passes kept alive),
+  * the stream hand-overs (`functional.stream_wait`) and the event records / waits of the schedule (`functional.event_record`,
+    `functional.event_wait`),
+  * Python callables that must run in between (`functional.tape_py`: the data-parallel exchange hook) --
+
+from two consecutive ordinary steps: the first with every tensor it allocates kept alive (no address is reused inside the step:
+a replay has no allocator to arbitrate cross-stream reuse), the second to find the integer arguments that advance from step to
+step (Adam's step count, Philox offsets) and by how much.  From then on a step is: copy the two input latents into the recorded
+input buffers, `stem_tape_replay` per segment, advance the Python-side counters.  Results are bit-identical to the untaped
+schedule (tests/test_hip_trainer.py); stream priorities and CU masks stay in force because the launches go to the recorded
+streams (a hipGraph replay lost them).
+
+What a tape assumes, and checks where it can: the same shapes / reducer / grad_scale every step (anything else falls back to a
+fresh recording), no host-side data dependence inside the step (the fused schedule has none), learning rates unchanged (a float
+argument that differs between the two recordings is an error).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+
+import torch
+
+from . import _lib
+from . import functional as F
+
+_POINTER_MIN = 1 << 32          # integer-class arguments at or above this are addresses (device VA, host arrays, streams)
+
+
+class LaunchTape:
+    """One recorded schedule.  Use through `recording()`; `finalize(other)` compares with a second recording and builds the
+    native tape; `replay(n)` re-issues it."""
+
+    def __init__(self):
+        self.entries = []           # ("call", name, addr, kinds, ivals, fvals, keep) | ("wait", dst, src) | ("evrec", ev, st) | ("evwait", st, ev) | ("py", fn, stream)
+        self.keep = []              # tensors / ctypes arrays the recorded addresses point into
+        self._native = None
+        self._segments = None
+
+    # ---- recording ---------------------------------------------------------------------------------------------------------------
+    def add_call(self, name, fn, args):
+        sig = _lib._HIP_SIG[name]
+        kinds, ivals, fvals, keep = [], [], [], []
+        for a, ty in zip(args, sig):
+            if ty is C.c_float:             # the vector register receives the float's bits in its low half
+                kinds.append(1); ivals.append(0); fvals.append(struct.unpack("<d", struct.pack("<fI", float(a), 0))[0])
+                continue
+            if ty is C.c_double:
+                kinds.append(2); ivals.append(0); fvals.append(float(a))
+                continue
+            kinds.append(0); fvals.append(0.0)
+            if a is None:
+                ivals.append(0)
+            elif isinstance(a, int):
+                ivals.append(a)
+            elif isinstance(a, (C.Array, C.Structure)):
+                ivals.append(C.addressof(a)); keep.append(a)
+            elif isinstance(a, C.c_void_p):
+                ivals.append(a.value or 0)
+            elif isinstance(a, bytes):
+                raise TypeError(f"{name}: string arguments are not recordable")
+            else:
+                raise TypeError(f"{name}: argument of type {type(a).__name__} is not recordable (pass addresses as integers)")
+        self.entries.append(("call", name, C.cast(fn, C.c_void_p).value, kinds, ivals, fvals, keep))
+
+    # ---- native tape -------------------------------------------------------------------------------------------------------------
+    def finalize(self, second: "LaunchTape"):
+        """`second`: the next step recorded the ordinary way.  Same entry sequence required; integer arguments below 2^32 that
+        differ are the per-step counters (their difference = the increment per replay); anything else that differs is an error."""
+        a, b = self.entries, second.entries
+        if len(a) != len(b) or any(x[0] != y[0] or (x[0] == "call" and x[1] != y[1]) for x, y in zip(a, b)):
+            raise RuntimeError("LaunchTape: two consecutive steps issued different launch sequences -- the schedule is not static")
+        lib = _lib.hip()
+        nat = lib.stem_tape_create()
+        segs, lo = [], 0
+        ndyn = 0
+        for x, y in zip(a, b):
+            if x[0] == "py":
+                hi = lib.stem_tape_length(nat)
+                if hi > lo:
+                    segs.append((lo, hi))
+                segs.append(x)
+                lo = hi
+                continue
+            if x[0] == "wait":
+                _lib.check(min(0, lib.stem_tape_add_wait(nat, x[1], x[2])))
+            elif x[0] == "evrec":
+                _lib.check(min(0, lib.stem_tape_add_event(nat, x[1], x[2], 0)))
+            elif x[0] == "evwait":
+                _lib.check(min(0, lib.stem_tape_add_event(nat, x[2], x[1], 1)))
+            else:
+                _, name, addr, kinds, iv, fv, _keep = x
+                deltas = [0] * len(iv)
+                for i, (k, va, vb, fa, fb) in enumerate(zip(kinds, iv, y[4], fv, y[5])):
+                    if k != 0:
+                        if struct.pack('<d', fa) != struct.pack('<d', fb):
+                            raise RuntimeError(f"LaunchTape: float argument {i} of {name} changed between two steps ({fa} -> {fb})")
+                    elif va != vb:
+                        if va >= _POINTER_MIN or vb >= _POINTER_MIN:
+                            continue            # addresses of the second (ordinary) step's tensors: the tape keeps the first step's
+                        deltas[i] = vb - va
+                        ndyn += 1
+                n = len(iv)
+                _lib.check(min(0, lib.stem_tape_add_call(nat, addr, n, (C.c_ubyte * n)(*kinds), (C.c_longlong * n)(*iv), (C.c_double * n)(*fv),
+                                                         (C.c_longlong * n)(*deltas))))
+        hi = lib.stem_tape_length(nat)
+        if hi > lo:
+            segs.append((lo, hi))
+        self._native, self._segments, self.dynamic_args = nat, segs, ndyn
+        return self
+
+    def replay(self, n):
+        lib = _lib.hip()
+        for seg in self._segments:
+            if len(seg) == 2:
+                rc = lib.stem_tape_replay(self._native, seg[0], seg[1], n)
+                if rc != 0:
+                    raise RuntimeError(f"LaunchTape: entry {-rc - 1} ({self.entries[-rc - 1][1]}) failed: {(lib.stem_last_error() or b'').decode()}")
+            else:
+                _, fn, stream = seg
+                with F.on_stream(stream):
+                    fn()
+
+    def __len__(self):
+        return len(self.entries)
+
+    def __del__(self):
+        try:
+            if self._native:
+                _lib.hip().stem_tape_destroy(self._native)
+        except Exception:
+            pass
+
+
+class _RecordingLibrary:
+    """stands in for the CDLL while a tape records: int-returning entry points are called AND logged"""
+
+    def __init__(self, lib, tape):
+        self._lib, self._tape, self._cache = lib, tape, {}
+
+    def __getattr__(self, name):
+        w = self._cache.get(name)
+        if w is not None:
+            return w
+        fn = getattr(self._lib, name)
+        if name not in _lib._HIP_SIG or name in _lib._RESTYPE or name.startswith("stem_tape_") or name.startswith("stem_tuning"):
+            return fn                           # size queries, error strings, the tape API itself: not part of a schedule
+        tape = self._tape
+
+        def recorded(*args, _fn=fn, _name=name):
+            rc = _fn(*args)
+            if rc == 0:                         # a launch (status 0); anything else is a query's answer (stem_rate_partials) or an error the caller raises
+                tape.add_call(_name, _fn, args)
+            return rc
+        self._cache[name] = recorded
+        return recorded
+
+
+class recording:
+    """`with recording(tape, keep_allocations=True): step()` -- logs the step into `tape`.  keep_allocations: every tensor torch
+    allocates inside the block stays alive with the tape (unique addresses, valid for as long as the tape is)."""
+
+    _ALLOC = ("empty", "zeros", "empty_like", "zeros_like", "empty_strided")
+
+    def __init__(self, tape, keep_allocations):
+        self.tape, self.keep_alloc = tape, keep_allocations
+
+    def __enter__(self):
+        if F._TAPE is not None:
+            raise RuntimeError("a launch tape is already recording")
+        self._real = _lib.hip()
+        _lib._hip = _RecordingLibrary(self._real, self.tape)
+        F._TAPE = self.tape
+        self._saved = {}
+        if self.keep_alloc:
+            keep = self.tape.keep
+            for n in self._ALLOC:
+                real = getattr(torch, n)
+                self._saved[n] = real
+
+                def held(*a, _real=real, **kw):
+                    t = _real(*a, **kw)
+                    keep.append(t)
+                    return t
+                setattr(torch, n, held)
+            self._clone = torch.Tensor.clone
+
+            def clone(t, *a, _real=self._clone, **kw):
+                r = _real(t, *a, **kw)
+                keep.append(r)
+                return r
+            torch.Tensor.clone = clone
+        return self.tape
+
+    def __exit__(self, *exc):
+        _lib._hip = self._real
+        F._TAPE = None
+        for n, real in self._saved.items():
+            setattr(torch, n, real)
+        if self.keep_alloc:
+            torch.Tensor.clone = self._clone
+        return False
+
+
+class TapedPFrameStep:
+    """`trainer.FusedPFrameStep` behind a launch tape: same arguments, same results (bit for bit), ~3 ms instead of ~11 ms of host
+    time per bench step.  Steps 1-2 run the ordinary schedule (weights packed, workspaces at their final sizes), step 3 is
+    recorded with its allocations kept, step 4 recorded again to find the per-step counters; from step 5 on the tape replays.
+
+    The tensors a replayed step returns are the recorded step's (static buffers, overwritten by the next step): consume them --
+    as the training loop does, `y_cond = out["y_hat"]` is copied into the tape's input buffer at the start of the next step --
+    or copy them before the next call."""
+
+    WARMUP = 2
+
+    def __init__(self, fused):
+        self.fused = fused
+        self._reset(None)
+
+    def _reset(self, key):
+        self.key, self.calls, self.tape, self.first = key, 0, None, None
+        self.replays = 0
+
+    def _counters(self):
+        f = self.fused
+        objs = [(f.opt, "t"), (f.aux_opt, "t"), (f.stem.entropy_bottleneck, "_noise_offset"), (f.stem.gaussian_conditional, "_noise_offset")]
+        return [(o, a) for o, a in objs if hasattr(o, a)]
+
+    def step(self, y_cur, y_cond, num_pixels, grad_scale=1.0, reducer=None):
+        key = (tuple(y_cur.shape), tuple(y_cond.shape), y_cur.device, int(num_pixels), float(grad_scale), id(reducer))
+        if key != self.key:
+            self._reset(key)
+        f = self.fused
+        self.calls += 1
+        if self.calls <= self.WARMUP:
+            return f.step(y_cur, y_cond, num_pixels, grad_scale, reducer)
+        if self.calls == self.WARMUP + 1:                       # recording A: inputs in static buffers, allocations kept
+            self.in_cur, self.in_cond = torch.empty_like(y_cur), torch.empty_like(y_cond)
+            self.in_cur.copy_(y_cur)
+            self.in_cond.copy_(y_cond)
+            self.first = LaunchTape()
+            before = [getattr(o, a) for o, a in self._counters()]
+            with recording(self.first, keep_allocations=True):
+                self.result = f.step(self.in_cur, self.in_cond, num_pixels, grad_scale, reducer)
+            self.deltas = [getattr(o, a) - b for (o, a), b in zip(self._counters(), before)]
+            return self.result
+        if self.calls == self.WARMUP + 2:                       # recording B: the ordinary step, logged for the comparison
+            second = LaunchTape()
+            with recording(second, keep_allocations=False):
+                res = f.step(y_cur, y_cond, num_pixels, grad_scale, reducer)
+            self.tape = self.first.finalize(second)
+            self.replays = 1                                     # this step was "replay index 1" in the counters' progression
+            return res
+        self.in_cur.copy_(y_cur)
+        self.in_cond.copy_(y_cond)
+        self.replays += 1
+        self.tape.replay(self.replays)
+        for (o, a), d in zip(self._counters(), self.deltas):
+            setattr(o, a, getattr(o, a) + d)
+        f.after_replay()
+        return self.result
+
+    def finish(self):
+        self.fused.finish()

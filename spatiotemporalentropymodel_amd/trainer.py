@@ -142,6 +142,7 @@ class FusedPFrameStep:
         self.adam_block_max = os.environ.get("STEM_ADAM_BLOCK_MAX", "1") != "0"
         self._aux_stream = F.make_stream(eb.quantiles.device, "side")
         self._aux_pending = False
+        self._done_event = torch.cuda.Event()            # re-recorded every step: the LazyScalars of the LATEST step wait on it
 
     def step(self, y_cur, y_cond, num_pixels, grad_scale=1.0, reducer=None):
         """y_cur / y_cond: the frame's and the conditioning latents [B,C,h,w]; num_pixels = N*H*W of the FRAMES (EMLoss
@@ -159,7 +160,7 @@ class FusedPFrameStep:
         y_hat, lik_y, lik_z, k = eng.forward(y_cur, y_cond, True, rate_coef=(coef, -1.0 / num_pixels))
         eng.backward(k, k["dlik_y"], k["dlik_z"])                   # an attached OverlappedGradReducer exchanges slices in here
         if reducer is not None:
-            reducer.finish() if hasattr(reducer, "finish") else reducer.all_reduce()
+            F.tape_py(reducer.finish if hasattr(reducer, "finish") else reducer.all_reduce)
         join_wgrad_stream()
         main = F.cur_stream(y_hat.device)
         if self._aux_pending:                    # the previous step's auxiliary work reads the parameters Adam is about to change
@@ -176,14 +177,15 @@ class FusedPFrameStep:
         # optimiser step (above) or until the caller looks at the returned values (LazyScalar).
         F.stream_wait(self._aux_stream, main)
         with F.on_stream(self._aux_stream):
-            gn_copy = opt._sumsq[:1].clone()     # private copies: the persistent buffers are overwritten by the next step
+            # private copies (the persistent buffers are overwritten by the next step), made by a library call: recordable
+            gn_copy = F.copy_d2d(torch.empty_like(opt._sumsq[:1]), opt._sumsq[:1])
             pack = F.eb_pack(eb._tensors14())
             F.eb_aux_loss_grad(eb.quantiles.detach(), pack, eb.target, eb.quantiles._flat_grad_view, loss_out=self._aux_loss)
             eb.quantiles.grad = eb.quantiles._flat_grad_view
             aux_opt.step()
-            aux_copy = self._aux_loss.clone()
-            done = torch.cuda.Event()
-            done.record(self._aux_stream)
+            aux_copy = F.copy_d2d(torch.empty_like(self._aux_loss), self._aux_loss)
+            done = self._done_event
+            F.event_record(done, self._aux_stream)
         self._aux_pending = True
         # the next forward's weight packing, issued now; the fp16 images take their scales from the maxima the optimiser pass left
         eng.ensure_packed(block_max=(opt.block_maxima, opt.flat.data) if use_bmax else None)
@@ -191,6 +193,13 @@ class FusedPFrameStep:
         out = {"y_hat": y_hat, "likelihoods": {"y": lik_y, "z": lik_z}}
         oc = {"y_bpp_loss": loss3[0], "z_bpp_loss": loss3[1], "loss": loss3[2]}
         return out, oc, LazyScalar(aux_copy, done), LazyScalar(gn_copy, done, scale=grad_scale, sqrt=True)
+
+    def after_replay(self):
+        """host-side state a replayed step (tape.TapedPFrameStep) leaves as the ordinary one does: the weights changed (the packed
+        copies' keys), the auxiliary stream holds work, the gradient buffer was cleared by the optimiser pass"""
+        from .layers import bump_weight_epoch
+        bump_weight_epoch(self.opt.flat.params)
+        self._aux_pending = True
 
     def finish(self):
         """order everything the step left on its auxiliary stream before the current stream (end of training, checkpointing,

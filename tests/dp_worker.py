@@ -7,7 +7,7 @@ backward -- hooks fired from StemEngine.backward on the weight-gradient stream, 
 all-reduced while the rest of backward is still queued -- on the single-GPU test box.  The parent test compares what the
 ranks dump with a single-process run over the concatenated batch.
 
-    python tests/dp_worker.py --case train|train_fused|gop|rccl1_train_fused|rccl1_gop --rank R --world W --port P --out DIR
+    python tests/dp_worker.py --case train|train_fused|gop|rccl1_train_fused|rccl1_gop|rccl1_train_taped --rank R --world W --port P --out DIR
 
 The `rccl1_*` cases are ONE rank in a world-size-1 process group on the RCCL ("nccl") backend: the collectives are
 identities, but every RCCL call of the reducers, their side-stream ordering and the device-tensor reductions of bench.py
@@ -142,6 +142,49 @@ def case_train_fused(rank, world, out_dir, steps=2, tag="train_fused"):
     np.savez(os.path.join(out_dir, f"{tag}_rank{rank}.npz"), **dump)
 
 
+def case_train_taped(rank, world, out_dir, steps=8, tag="train_taped", taped=True):
+    """Eight P-frame steps with the overlapped reducer attached, through the native executor (tape.TapedPFrameStep: two ordinary
+    steps, two recorded, four replayed -- the reducer's torch.distributed calls are re-run from the tape's Python entries) or,
+    taped=False, through the plain explicit schedule.  Philox noise (a tape replays the counters, not injected tensors)."""
+    from spatiotemporalentropymodel_amd import distributed as D
+    from spatiotemporalentropymodel_amd import selfcheck as S
+    from spatiotemporalentropymodel_amd.optim import configure_optimizers
+    from spatiotemporalentropymodel_amd.tape import TapedPFrameStep
+    from spatiotemporalentropymodel_amd.trainer import FusedPFrameStep
+    from spatiotemporalentropymodel_amd.weights import smooth_frames
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    imodel, stem = S.build_models(64, 96, 64, 96, dev, inject_noise=False)
+    stem.train()
+    for i, m in enumerate((imodel, stem)):
+        m.entropy_bottleneck.noise_seed = m.gaussian_conditional.noise_seed = D.shard_seed(77 + 100 * i, rank)
+    D.broadcast_parameters(stem)
+    opt, aux_opt = configure_optimizers(stem, types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3))
+    red = D.OverlappedGradReducer(opt.flat).attach(stem.engine())
+    step = FusedPFrameStep(stem, opt, aux_opt)
+    if taped:
+        step = TapedPFrameStep(step)
+    frames = [f[rank:rank + 1].contiguous().to(dev) for f in smooth_frames("dp2:taped", world, steps + 1, 64)]
+    with torch.no_grad():
+        _, y_cond = imodel.getY(frames[0])
+    dump = {}
+    for t in range(1, steps + 1):
+        with torch.no_grad():
+            y_cur, _ = imodel.getY(frames[t])
+        out, oc, aux, gn = step.step(y_cur, y_cond, 64 * 64, grad_scale=red.grad_scale, reducer=red)
+        y_cond = out["y_hat"].clone()
+        dump[f"s{t}:loss"] = np.array([float(oc["loss"]), float(gn), float(aux)])
+    step.finish()
+    torch.cuda.synchronize()
+    dump["params"] = flat_np(opt.flat.data)
+    dump["quantiles"] = flat_np(aux_opt.flat.data)
+    dump["collectives"] = np.array([red.collectives])
+    dump["replays"] = np.array([step.replays if taped else 0])
+    import torch.distributed as dist
+    dump["backend"] = np.array([dist.get_backend() if dist.is_initialized() else "none"])
+    np.savez(os.path.join(out_dir, f"{tag}_rank{rank}.npz"), **dump)
+
+
 def case_gop(rank, world, out_dir, frames_n=3, tag="gop"):
     """One GOP iteration of the variable-rate loop (selfcheck.roi_gop_step) with GopGradAccumulator, one sample per rank."""
     out_tag = tag
@@ -190,7 +233,7 @@ def main():
     D.init_from_env(single=rccl1)
     if rccl1:
         assert a.world == 1 and torch.distributed.get_backend() == "nccl"
-        {"rccl1_train_fused": case_train_fused, "rccl1_gop": case_gop}[a.case](a.rank, a.world, a.out, tag=a.case)
+        {"rccl1_train_fused": case_train_fused, "rccl1_gop": case_gop, "rccl1_train_taped": case_train_taped}[a.case](a.rank, a.world, a.out, tag=a.case)
     else:
         {"train": case_train, "train_fused": case_train_fused, "gop": case_gop}[a.case](a.rank, a.world, a.out)
     D.barrier()

@@ -194,6 +194,23 @@ def test_rccl_world1_fused_schedule_bit_identical_to_no_process_group(dp2_result
         np.testing.assert_array_equal(r[k], loc[k], err_msg=k)
 
 
+@pytest.mark.dp2("rccl1_train_taped")
+def test_rccl_world1_taped_executor_bit_identical_to_the_plain_schedule(dp2_results, tmp_path):
+    """The native step executor inside a data-parallel run: one rank in a real RCCL group, eight P-frame steps through
+    tape.TapedPFrameStep (four of them replayed from the tape, whose Python entries re-issue the reducer's all-reduces on the
+    recorded streams), against the same eight steps without a tape and without a process group: bit-identical losses, norms,
+    parameters and quantiles; the reducer issued the same number of collectives per step on both routes."""
+    import dp_worker
+    (r,) = dp2_results("rccl1_train_taped")
+    assert str(r["backend"][0]) == "nccl" and int(r["replays"][0]) == 5
+    assert not torch.distributed.is_initialized()
+    dp_worker.case_train_taped(0, 1, str(tmp_path), tag="local_taped", taped=False)
+    loc = dict(np.load(tmp_path / "local_taped_rank0.npz"))
+    assert str(loc["backend"][0]) == "none" and int(r["collectives"][0]) == int(loc["collectives"][0]) > 0
+    for k in ["params", "quantiles"] + [f"s{t}:loss" for t in range(1, 9)]:
+        np.testing.assert_array_equal(r[k], loc[k], err_msg=k)
+
+
 @pytest.mark.dp2("rccl1_gop")
 def test_rccl_world1_gop_accumulator_bit_identical_to_no_process_group(dp2_results, tmp_path):
     import dp_worker

@@ -193,3 +193,53 @@ def test_tuned_schedule_changes_no_result(monkeypatch):
     a, b = results
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     assert a[3] == b[3], (a[3], b[3])
+
+
+@pytest.mark.parametrize("tuned", [False, True])
+def test_taped_step_is_bit_identical_to_the_fused_schedule(monkeypatch, tuned):
+    """tape.TapedPFrameStep (the native executor: the schedule recorded once, re-issued by stem_tape_replay) against
+    trainer.FusedPFrameStep over nine P-frame steps -- two ordinary, two recorded, five replayed -- with the latents prefetched
+    on their own stream: identical losses, gradient norms, auxiliary losses, latents and parameters, bit for bit, with and without
+    the tuned schedule (stream priorities / CU mask).  Also: the counters the replays advance on the host side (Adam's step, the
+    noise offsets) match the ordinary run's."""
+    from spatiotemporalentropymodel_amd import functional as F
+    from spatiotemporalentropymodel_amd import trainer
+    from spatiotemporalentropymodel_amd.tape import TapedPFrameStep
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(7)
+    frames = [torch.rand(2, 3, 128, 128, device=dev, generator=g) for _ in range(10)]
+    results = []
+    for taped in (False, True):
+        for k in trainer.SCHEDULE_DEFAULTS:
+            monkeypatch.delenv(k, raising=False)
+            if not tuned:
+                monkeypatch.setenv(k, "")
+        monkeypatch.setattr(F, "_STREAM_PRIO", None)
+        imodel, stem, opt, aux = _pair(64, 96, 64, 96, False, False)
+        sched = trainer.tuned_schedule(dev)
+        step = trainer.FusedPFrameStep(stem, opt, aux)
+        if taped:
+            step = TapedPFrameStep(step)
+        pf = trainer.LatentPrefetcher(imodel)
+        log = []
+        torch.cuda.synchronize()
+        with sched:
+            pf.start(frames, frames_ready=True)
+            y_cond = pf.get(0)[1]
+            for t in range(1, 10):
+                out, oc, aux_l, gn = step.step(pf.get(t)[0], y_cond, 2 * 128 * 128)
+                log.append((float(oc["loss"]), float(oc["y_bpp_loss"]), float(gn), float(aux_l), out["y_hat"].clone(),
+                            out["likelihoods"]["y"].clone()))
+                y_cond = out["y_hat"]
+            step.finish()
+        torch.cuda.synchronize()
+        eb, gc = stem.entropy_bottleneck, stem.gaussian_conditional
+        results.append((opt.flat.data.clone(), aux.flat.data.clone(), log, (opt.t, aux.t, eb._noise_offset, gc._noise_offset)))
+        if taped:
+            assert step.tape is not None and step.replays == 6 and len(step.tape) > 60 and step.tape.dynamic_args >= 3
+    a, b = results
+    for t, (la, lb) in enumerate(zip(a[2], b[2])):
+        assert la[:4] == lb[:4], (t, la[:4], lb[:4])
+        assert torch.equal(la[4], lb[4]) and torch.equal(la[5], lb[5]), t
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert a[3] == b[3], (a[3], b[3])
