@@ -53,6 +53,7 @@ int stem_tape_add_call(void *tape, void *fn, int nargs, const unsigned char *kin
 int stem_tape_add_wait(void *tape, void *waiting_stream, void *signalling_stream);
 int stem_tape_add_event(void *tape, void *event, void *stream, int wait);
 int stem_tape_replay(void *tape, int lo, int hi, long long n);
+int stem_tape_set_iarg(void *tape, int entry, int arg, long long value);
 int stem_copy_d2d(void *dst, const void *src, size_t nbytes, void *stream);
 int stem_tuning_set(const char *name, int value);
 int stem_tuning_get(const char *name);

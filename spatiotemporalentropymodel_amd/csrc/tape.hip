@@ -187,6 +187,17 @@ STEM_EXPORT int stem_tape_replay(void *tape, int lo, int hi, long long n)
     return 0;
 }
 
+/* overwrite integer-class argument `arg` (position among the entry's integer-class arguments) of call entry `entry`: the
+ * addresses that change from step to step (the latents a prefetcher hands over in a different buffer per frame) */
+STEM_EXPORT int stem_tape_set_iarg(void *tape, int entry, int arg, long long value)
+{
+    Tape *t = static_cast<Tape *>(tape);
+    STEM_CHECK_ARG(t && entry >= 0 && entry < (int)t->e.size() && t->e[entry].kind == TAPE_CALL && arg >= 0 && arg < t->e[entry].ni,
+                   "stem_tape_set_iarg: no integer argument %d in entry %d", arg, entry);
+    t->e[entry].iv[arg] = value;
+    return 0;
+}
+
 /* device-to-device copy on a stream (the private copies a step hands out: recorded like any other launch) */
 STEM_EXPORT int stem_copy_d2d(void *dst, const void *src, size_t nbytes, void *stream)
 {

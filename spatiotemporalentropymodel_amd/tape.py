@@ -29,9 +29,6 @@ import torch
 from . import _lib
 from . import functional as F
 
-_POINTER_MIN = 1 << 32          # integer-class arguments at or above this are addresses (device VA, host arrays, streams)
-
-
 class LaunchTape:
     """One recorded schedule.  Use through `recording()`; `finalize(other)` compares with a second recording and builds the
     native tape; `replay(n)` re-issues it."""
@@ -46,6 +43,7 @@ class LaunchTape:
     def add_call(self, name, fn, args):
         sig = _lib._HIP_SIG[name]
         kinds, ivals, fvals, keep = [], [], [], []
+        isptr = [ty is C.c_void_p for ty in sig]            # by declared type: addresses never count as step counters
         for a, ty in zip(args, sig):
             if ty is C.c_float:             # the vector register receives the float's bits in its low half
                 kinds.append(1); ivals.append(0); fvals.append(struct.unpack("<d", struct.pack("<fI", float(a), 0))[0])
@@ -66,7 +64,7 @@ class LaunchTape:
                 raise TypeError(f"{name}: string arguments are not recordable")
             else:
                 raise TypeError(f"{name}: argument of type {type(a).__name__} is not recordable (pass addresses as integers)")
-        self.entries.append(("call", name, C.cast(fn, C.c_void_p).value, kinds, ivals, fvals, keep))
+        self.entries.append(("call", name, C.cast(fn, C.c_void_p).value, kinds, ivals, fvals, keep, isptr))
 
     # ---- native tape -------------------------------------------------------------------------------------------------------------
     def finalize(self, second: "LaunchTape"):
@@ -79,7 +77,10 @@ class LaunchTape:
         nat = lib.stem_tape_create()
         segs, lo = [], 0
         ndyn = 0
+        self.native_index = []      # per entry of self.entries: its index in the native tape (calls only; -1 otherwise)
         for x, y in zip(a, b):
+            if x[0] != "call":
+                self.native_index.append(-1)
             if x[0] == "py":
                 hi = lib.stem_tape_length(nat)
                 if hi > lo:
@@ -94,14 +95,15 @@ class LaunchTape:
             elif x[0] == "evwait":
                 _lib.check(min(0, lib.stem_tape_add_event(nat, x[2], x[1], 1)))
             else:
-                _, name, addr, kinds, iv, fv, _keep = x
+                _, name, addr, kinds, iv, fv, _keep, isptr = x
+                self.native_index.append(lib.stem_tape_length(nat))
                 deltas = [0] * len(iv)
                 for i, (k, va, vb, fa, fb) in enumerate(zip(kinds, iv, y[4], fv, y[5])):
                     if k != 0:
                         if struct.pack('<d', fa) != struct.pack('<d', fb):
                             raise RuntimeError(f"LaunchTape: float argument {i} of {name} changed between two steps ({fa} -> {fb})")
                     elif va != vb:
-                        if va >= _POINTER_MIN or vb >= _POINTER_MIN:
+                        if isptr[i]:
                             continue            # addresses of the second (ordinary) step's tensors: the tape keeps the first step's
                         deltas[i] = vb - va
                         ndyn += 1
@@ -113,6 +115,26 @@ class LaunchTape:
             segs.append((lo, hi))
         self._native, self._segments, self.dynamic_args = nat, segs, ndyn
         return self
+
+    def pointer_slots(self, address):
+        """[(native entry, integer-argument position)] of every recorded pointer argument equal to `address`"""
+        out = []
+        for x, ni in zip(self.entries, self.native_index):
+            if x[0] != "call":
+                continue
+            pos = 0
+            for k, v, isp in zip(x[3], x[4], x[7]):
+                if k != 0:
+                    continue
+                if isp and v == address:
+                    out.append((ni, pos))
+                pos += 1
+        return out
+
+    def set_pointer(self, slots, address):
+        lib = _lib.hip()
+        for ni, pos in slots:
+            _lib.check(lib.stem_tape_set_iarg(self._native, ni, pos, address))
 
     def replay(self, n):
         lib = _lib.hip()
@@ -255,8 +277,16 @@ class TapedPFrameStep:
                 res = f.step(y_cur, y_cond, num_pixels, grad_scale, reducer)
             self.tape = self.first.finalize(second)
             self.replays = 1                                     # this step was "replay index 1" in the counters' progression
+            # the frame's latents arrive in a different buffer every step (the prefetcher's): where the schedule reads the recorded
+            # input buffer, the tape is pointed at the caller's tensor instead of copying it (same shape / strides required)
+            self.cur_slots = self.tape.pointer_slots(self.in_cur.data_ptr())
             return res
-        self.in_cur.copy_(y_cur)
+        if self.cur_slots and y_cur.stride() == self.in_cur.stride() and y_cur.dtype == self.in_cur.dtype:
+            self.tape.set_pointer(self.cur_slots, y_cur.data_ptr())
+        else:
+            if self.cur_slots:
+                self.tape.set_pointer(self.cur_slots, self.in_cur.data_ptr())
+            self.in_cur.copy_(y_cur)
         self.in_cond.copy_(y_cond)
         self.replays += 1
         self.tape.replay(self.replays)

@@ -24,6 +24,9 @@ stem = SpatioTemporalPriorModel_Res().to(dev).train()
 opt, aux_opt = configure_optimizers(stem, types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3))
 frames = bench.synthetic_septuplet(bench.BATCH, bench.SIZE, 1234, dev)
 fused = FusedPFrameStep(stem, opt, aux_opt)
+if os.environ.get("STEM_HOST_TAPE", "1") != "0":           # the native executor (bench.py's default); STEM_HOST_TAPE=0: the Python schedule
+    from spatiotemporalentropymodel_amd.tape import TapedPFrameStep  # noqa: E402
+    fused = TapedPFrameStep(fused)
 prefetch = LatentPrefetcher(imodel, ahead=1)
 npix = bench.BATCH * bench.SIZE * bench.SIZE
 marks = []
