@@ -31,6 +31,12 @@ sys.path.insert(0, REPO)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+
+def RUNTIME():
+    """the package's configuration object (routes, schedule, data parallel; config.StemRuntimeConfig)"""
+    from spatiotemporalentropymodel_amd import config
+    return config.runtime()
+
 PEAK_FP32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 BATCH, SIZE, FRAMES = 16, 256, 7
 # SURVEY.md §8(a)/(d): the 192-ch 5x5 stride-2 analysis conv g_a.2 (7.550 GF/frame) + the GDN contraction fused
@@ -333,7 +339,7 @@ def bench_roi(args):
         return
     kern_ms = float(np.mean([x.elapsed_time(y) for x, y in probe]))
     flop = 2.0 * 192 * 160 * 9 * SIZE * SIZE * B
-    f16_layers = os.environ.get("STEM_LAYERS_F16X3", "1") != "0"
+    f16_layers = RUNTIME().layers_f16x3
     # the probed layer runs on the 192-column split-operand kernel (three fp16 MFMAs per fp32 product: executed = 3 x algorithmic,
     # against the fp16 peak); with STEM_LAYERS_F16X3=0 on the fp32-MFMA kernel against its own peak
     work, peak = (F16_PRODUCTS * flop, PEAK_F16_MFMA_TFLOPS) if f16_layers else (flop, PEAK_FP32_MFMA_TFLOPS)
@@ -511,7 +517,7 @@ def main():
     probe, probe0 = [], []
     if os.environ.get("STEM_BENCH_NOPROBE", "0") != "1":
         imodel.g_a.probe = {2: probe, 0: probe0}
-    f16_chain = os.environ.get("STEM_F16X3", "1") != "0"
+    f16_chain = RUNTIME().analysis_f16x3
 
     # --graph (single device): the P-frame step (zero_grad .. aux Adam, ~160 launches) is replayed from ONE hipGraph per
     # step (graphs.GraphedPFrameStep); getY stays eager so that the HIP-event probe can bracket its dominant kernel.  Data
@@ -601,7 +607,7 @@ def main():
     # g_a.0 + GDN g_a.1 (csrc/c4gdn_f16x3.hip since round 3; igemm.hip's fp32-MFMA kernel with STEM_C4GDN_F16X3=0), measured the same
     # way; the probe brackets the NCHW -> NHWC4 layout kernel (~20 us) and the convolution kernel
     flop0 = GA0_FLOP_PER_FRAME * BATCH
-    c4_f16 = os.environ.get("STEM_C4GDN_F16X3", "1") != "0" and f16_chain
+    c4_f16 = RUNTIME().first_layer_f16x3 and f16_chain
     exec0 = F16_PRODUCTS * (2 * 192 * 128 * 128 * 128 + 2 * 192 * 192 * 128 * 128) * BATCH      # conv K padded 75 -> 128 slots, GDN K = 192; x3 products
     peak0 = PEAK_F16_MFMA_TFLOPS if c4_f16 else PEAK_FP32_MFMA_TFLOPS
     work0 = exec0 if c4_f16 else flop0
@@ -662,8 +668,8 @@ def main():
                    "latents": "getY of frame t + 1 on a second stream during P-frame step t (trainer.LatentPrefetcher)" if prefetch is not None
                               else "getY of all 7 frames before the P-frame steps",
                    "analysis_transform": "fp16 matrix cores, two fp16 planes per operand, 3 products per fp32 product (conv_f16x3.hip)" if f16_chain else "fp32 MFMA",
-                   "stream_priorities": os.environ.get("STEM_STREAM_PRIO", ""),
-                   "stream_cu_masks": os.environ.get("STEM_STREAM_CUMASK", "") or "none",
+                   "stream_priorities": RUNTIME().stream_prio,
+                   "stream_cu_masks": RUNTIME().stream_cumask or "none",
                    "plan_selectors": os.environ.get("STEM_BENCH_TUNING", "") or "library defaults",
                    "rank0_host_cores": (f"{len(PINNED_CPUS)} cores of the GPU's NUMA node ({PINNED_CPUS[0]}..{PINNED_CPUS[-1]})" if PINNED_CPUS else "not pinned"),
                    "launch": "hipGraph replay per P-frame step" if use_graph else

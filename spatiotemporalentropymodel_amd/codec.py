@@ -13,12 +13,11 @@ C function pointer -- through a pinned mailbox.  (A cooperative single-launch va
 """
 from __future__ import annotations
 
-import os
-
 import numpy as np
 import torch
 
 from . import _lib
+from . import config as _config
 from . import functional as F
 from .entropy_models import BufferedRansEncoder, RansDecoder
 
@@ -97,7 +96,7 @@ class _ARContext:
             self._wh2 = torch.empty((npmax, self.w1.shape[0]), device=dev)
             self._wgp = torch.empty((npmax, P), device=dev)
             self._wave_np = npmax
-        if not os.environ.get("STEM_AR_STEPWISE"):
+        if not _config.runtime().ar_stepwise:
             # all W + 3(H-1) steps queued by one library call (no interpreter between the 5 launches of a step)
             F._chk(lib.stem_ar_encode_image(
                 self.w_ctx.data_ptr(), 12 * M, self.b_ctx.data_ptr(), self.w0.data_ptr(), self.w0.shape[1], self.b0.data_ptr(), self.w0.shape[0],
@@ -243,8 +242,9 @@ def stem_decompress(model, strings, shape, y_cond):
     sym_host = torch.empty(M, dtype=torch.int32).pin_memory()
     import ctypes as C
     decode_fn = C.cast(_lib.rans().stem_rans_decoder_decode, C.c_void_p).value      # host symbol decoder, injected as a C pointer
-    stepwise = bool(os.environ.get("STEM_AR_STEPWISE"))
-    lockstep = (B > 1 or bool(os.environ.get("STEM_AR_FORCE_BATCH"))) and not stepwise and not os.environ.get("STEM_AR_NO_BATCH")
+    cfg = _config.runtime()
+    stepwise = cfg.ar_stepwise
+    lockstep = (B > 1 or cfg.ar_force_batch) and not stepwise and not cfg.ar_no_batch
     if lockstep:
         # Independent images advance together (csrc/ar.hip: stem_ar_decode_batch): the loop is bound by the latency of one
         # position (4 dependent launches + a host round trip), which G images share; each image's arithmetic is unchanged.
@@ -267,7 +267,7 @@ def stem_decompress(model, strings, shape, y_cond):
                       ar.w1.data_ptr(), ar.w1.shape[1], ar.b1.data_ptr(), ar.w1.shape[0], ar.w2.data_ptr(), ar.w2.shape[1], ar.b2.data_ptr(),
                       buf.data_ptr(), G, H, W, M, _P, tp_b, hp_b, *[t.data_ptr() for t in scratch],
                       ar.table.data_ptr(), ar.table.numel(), ar.bound, F.LRELU_SLOPE)
-            if os.environ.get("STEM_AR_PIPELINE", "0") == "1":
+            if cfg.ar_pipeline:
                 # flags in pinned memory instead of a stream synchronisation per position, two alternating image groups.
                 # Measured equal for one sequence and slower for 8: the dependent dispatch chain, not the
                 # synchronisation call, is what a position costs.  Kept as a checked alternative, off by default.
@@ -291,7 +291,7 @@ def stem_decompress(model, strings, shape, y_cond):
         # SLOWER than the per-position loop on MI355X (0.49 s against 0.30 s per 1080p P frame: 2 us per L2-local grid barrier
         # and 6-11 us per 64-workgroup matrix-vector product against ~6 us per dependent dispatch), so it is
         # opt-in; should it give up (a bounded wait timed out) the image is decoded again by the per-position loop.
-        if os.environ.get("STEM_AR_PERSISTENT", "0") == "1":
+        if cfg.ar_persistent:
             rc = lib.stem_ar_decode_image_persistent(
                 ar.w_ctx.data_ptr(), 12 * M, ar.b_ctx.data_ptr(), ar.w0.data_ptr(), ar.w0.shape[1], ar.b0.data_ptr(), ar.w0.shape[0],
                 ar.w1.data_ptr(), ar.w1.shape[1], ar.b1.data_ptr(), ar.w1.shape[0], ar.w2.data_ptr(), ar.w2.shape[1], ar.b2.data_ptr(),

@@ -20,6 +20,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import config as _config
+
 
 def init_from_env(backend=None, single=None):
     """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torch.distributed.run contract).
@@ -38,11 +40,12 @@ def init_from_env(backend=None, single=None):
     shared = ndev > 0 and local_world > ndev
     if shared:
         local = local % ndev                           # more ranks than GPUs (single-GPU test box): share devices
+    cfg = _config.runtime()
     if single is None:
-        single = os.environ.get("STEM_DIST_SINGLE", "0") == "1"
+        single = cfg.dist_single
     if (world > 1 or single) and not dist.is_initialized():
         if backend is None:
-            backend = os.environ.get("STEM_DIST_BACKEND") or ("nccl" if ndev > 0 and not shared else "gloo")
+            backend = cfg.dist_backend or ("nccl" if ndev > 0 and not shared else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
@@ -168,7 +171,7 @@ class OverlappedGradReducer:
         #: +4 ms for 6 calls per P-frame step before), so the threshold only keeps tiny groups (the bottleneck's 60 KB) from
         #: travelling alone: 8 MB leaves the last group (the hyper encoder, ~10 MB) for finish() instead of a 39 MB run.
         #: STEM_DP_MIN_BYTES=0 exchanges every group as soon as it is final
-        self.min_bytes = int(os.environ.get("STEM_DP_MIN_BYTES", str(8 << 20))) if min_bytes is None else int(min_bytes)
+        self.min_bytes = _config.runtime().dp_min_bytes if min_bytes is None else int(min_bytes)
 
     @property
     def grad_scale(self):
@@ -387,7 +390,7 @@ def pin_rank_to_gpu_cores(local_rank, local_world=1, sysfs_root="/sys", apply=Tr
     step) otherwise migrates across sockets, away from its GPU's PCIe root.  Ranks whose GPUs share a node split that node's
     cores evenly (SMT siblings stay together when the list enumerates them pairwise).  Returns the core list, or None when the
     topology is unknown / STEM_PIN_RANKS=0 -- the run then keeps the inherited mask."""
-    if os.environ.get("STEM_PIN_RANKS", "1") == "0":
+    if not _config.runtime().pin_ranks:
         return None
     lists = gpu_cpu_lists(sysfs_root)
     if not lists or local_rank >= len(lists) or not lists[local_rank]:

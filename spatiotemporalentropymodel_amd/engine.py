@@ -13,13 +13,15 @@ producing convolution (forward) and into the consuming dgrad's epilogue (backwar
 """
 from __future__ import annotations
 
-import os
-
 import torch
 
 from . import _lib
+from . import config as _config
 from . import functional as F
 from . import layers as _layers
+
+#: the switches below are fields of config.StemRuntimeConfig (read when the module is imported; `StemEngine.<attr>` can be set after that)
+_CFG = _config.runtime()
 
 
 class _Layer:
@@ -310,33 +312,33 @@ class StemEngine:
 
     #: forward and input-gradient of the stride-1 layers (TPM, HE.0, HD.4, EPM) on the fp16 matrix cores: three fp16 products per fp32 product on operands split into two scaled fp16 planes, ~2^-21 relative per product (tests: 1e-4 gates; measured 0.4-1.6e-6 of max per layer against fp64)
     #: (three fp16 MFMAs per fp32 product, csrc/conv_f16x3.hip); STEM_ENGINE_F16X3=0 keeps every layer on the fp32-MFMA kernels
-    use_fx3 = os.environ.get("STEM_ENGINE_F16X3", "1") != "0"
+    use_fx3 = _CFG.engine_f16x3
     #: the entropy glue (prologue, Gaussian backward) records the maxima of the fp32 tensors it writes, so that their fp16 splits
     #: skip the maximum pass (four launches per P-frame step); STEM_ENGINE_RECORDS=0: every split measures its input itself
-    use_records = os.environ.get("STEM_ENGINE_RECORDS", "1") != "0"
+    use_records = _CFG.engine_records
     #: the strided-convolution faces of the hyper path's stride-2 layers (HE.2 / HE.4 forward, HD.2 / HD.0 input gradient) on the
     #: general fp16 kernel; STEM_ENGINE_STRIDED_F16X3=0: igemm.hip
-    use_fx3s = os.environ.get("STEM_ENGINE_STRIDED_F16X3", "1") != "0"
+    use_fx3s = _CFG.engine_strided_f16x3
     #: the masked context convolution's forward on the same kernel over its live taps; STEM_ENGINE_CTX_F16X3=0: igemm.hip
-    use_ctx3 = os.environ.get("STEM_ENGINE_CTX_F16X3", "1") != "0"
+    use_ctx3 = _CFG.engine_ctx_f16x3
     #: ... and their weight gradients (csrc/wgrad_f16x3.hip); STEM_ENGINE_WGRAD_F16X3=0 keeps those on wgrad.hip
-    use_wg3 = os.environ.get("STEM_ENGINE_WGRAD_F16X3", "1") != "0"
+    use_wg3 = _CFG.engine_wgrad_f16x3
 
     #: weight gradients (wgrad + bias column sums + unpack + the data-parallel exchange hook) run on their own stream
     #: and overlap the latency-bound parts of the dgrad chain; set False to keep everything on the compute stream
-    overlap_wgrad = os.environ.get("STEM_ENGINE_OVERLAP", "1") != "0"
+    overlap_wgrad = _CFG.engine_overlap
 
     #: number of weight-gradient streams; 2 puts the hyper path's weight gradients on a stream of their own (measured on the
     #: bench step, same box: 22.65-22.94 ms against 22.67-22.82 ms with one -- no gain, the step is throughput-bound; default 1)
-    wgrad_lanes = int(os.environ.get("STEM_ENGINE_WGRAD_LANES", "1"))
+    wgrad_lanes = _CFG.engine_wgrad_lanes
     #: the next forward's weight packing is split: forward-role copies on the compute stream (the forward waits for them), the
     #: input-gradient copies on a weight-gradient stream (only backward waits): 22.48-22.62 ms against 22.67-22.82 ms per bench
     #: step; STEM_ENGINE_SPLIT_PACK=0: one launch each as before
-    split_pack = os.environ.get("STEM_ENGINE_SPLIT_PACK", "1") != "0"
+    split_pack = _CFG.engine_split_pack
     #: the context model's convolution on a third forward stream (it depends on neither the TPM nor the hyper chain): measured
     #: 24.3 ms against 22.7 ms per bench step -- three concurrent chains slow each other down more than the overlap gains;
     #: off by default, kept as a switch
-    ctx_branch = os.environ.get("STEM_ENGINE_CTX_BRANCH", "0") != "0"
+    ctx_branch = _CFG.engine_ctx_branch
 
     def side_stream(self, device, lane=0):
         if not self.overlap_wgrad or device.type != "cuda":
@@ -349,7 +351,7 @@ class StemEngine:
     #: the hyper path (HE -> bottleneck -> HD) and the temporal / spatial priors are independent until the entropy-parameter
     #: network joins them: the hyper path runs on its own stream in forward and backward so that the ramp-up / drain of its
     #: small launches overlaps the other branch's kernels (30.90 -> 30.75 ms per bench step; STEM_ENGINE_BRANCH=0 disables)
-    branch_streams = os.environ.get("STEM_ENGINE_BRANCH", "1") != "0"
+    branch_streams = _CFG.engine_branch
 
     def _branch(self, device, which=0):
         if not self.branch_streams or device.type != "cuda":
@@ -429,9 +431,9 @@ class StemEngine:
     #: the group's weight-gradient kernels: the weight-gradient stream is the longest serial chain of a P-frame step's backward
     #: (13 launches + 13 bias finals + 5 slab sums, ~1.05 ms of 1.95 in a kernel trace), and these HBM-bound passes overlap the
     #: next group's matrix kernels; STEM_ENGINE_UNPACK_STREAM=0: on the weight-gradient stream as before
-    unpack_stream = os.environ.get("STEM_ENGINE_UNPACK_STREAM", "0") != "0"
+    unpack_stream = _CFG.engine_unpack_stream
     #: one launch for a group's bias-gradient second stages (stem_bias_grad_final_multi); STEM_ENGINE_BIAS_MULTI=0: one per layer
-    defer_bias_final = os.environ.get("STEM_ENGINE_BIAS_MULTI", "1") != "0"
+    defer_bias_final = _CFG.engine_bias_multi
 
     def _group_ready(self, layers, extra_params):
         dev = layers[0].mod.weight.device

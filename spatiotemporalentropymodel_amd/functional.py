@@ -13,6 +13,7 @@ import os
 import torch
 
 from . import _lib
+from . import config as _config
 
 PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_DECONV_FWD, PACK_DECONV_DGRAD, PACK_CONV_FWD_C4 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_LRELU = 0, 1
@@ -130,7 +131,7 @@ def make_stream(device, role):
     global _STREAM_PRIO
     if _STREAM_PRIO is None:
         _STREAM_PRIO = {}
-        for kv in os.environ.get("STEM_STREAM_PRIO", "").split(","):
+        for kv in _config.runtime().stream_prio.split(","):
             if "=" in kv:
                 k, v = kv.split("=")
                 _STREAM_PRIO[k.strip()] = int(v)
@@ -149,7 +150,7 @@ def _cu_mask(role):
     first n CU bits, or the bits i with i % 8 < k (whole XCDs if the mask enumerates CUs XCD-interleaved).  Keeps the long
     analysis-transform kernels of the prefetch stream off part of the chip so that the P-frame step's short kernels always find
     free CUs (bench.py's default: latents=block:192).  A masked stream is created at the default priority."""
-    for kv in os.environ.get("STEM_STREAM_CUMASK", "").split(","):
+    for kv in _config.runtime().stream_cumask.split(","):
         if "=" in kv:
             k, v = kv.split("=")
             if k.strip() == role:
@@ -810,7 +811,7 @@ def _aligned16(*ts):
 def c4gdn_supported(K, R, S, inverse=False):
     """first layer + GDN on the fp16 kernel of csrc/c4gdn_f16x3.hip: N = 64 / 128 / 192 output channels, filters up to 25 taps;
     STEM_C4GDN_F16X3=0 keeps the fp32-MFMA kernel of igemm.hip (routing switch: both meet the 1e-4 gates; the fp16 form carries ~2^-21 relative per product, the fp32 instruction 2^-24)"""
-    return (not inverse and os.environ.get("STEM_C4GDN_F16X3", "1") != "0" and bool(_lib.hip().stem_c4gdn_supported(K, R, S)))
+    return (not inverse and _config.runtime().first_layer_f16x3 and bool(_lib.hip().stem_c4gdn_supported(K, R, S)))
 
 
 def _c4gdn_fits(x4, K, R, S, stride, pad, ld=None, planes=False):

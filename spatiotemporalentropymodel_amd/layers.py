@@ -9,11 +9,11 @@ forward/backward run the HIP kernels through the C ABI.
 from __future__ import annotations
 
 import math
-import os
 
 import torch
 import torch.nn as nn
 
+from . import config as _config
 from . import functional as F
 from .ops import NonNegativeParametrizer
 
@@ -140,7 +140,7 @@ def _on_side_stream(fn, *tensors):
 def _layers_f16x3_enabled():
     """stride-1 convolutions of the layer-wise (autograd) models -- the variable-rate family of models/stem_roi.py -- on the fp16
     matrix cores (three fp16 products per fp32 product on two-plane operands, ~2^-21 per product: csrc/conv_f16x3.hip / wgrad_f16x3.hip); STEM_LAYERS_F16X3=0: fp32 MFMA"""
-    return os.environ.get("STEM_LAYERS_F16X3", "1") != "0"
+    return _config.runtime().layers_f16x3
 
 
 def _conv_f16x3_route(weight, stride, pad, masked, x_shape):
@@ -151,24 +151,21 @@ def _conv_f16x3_route(weight, stride, pad, masked, x_shape):
     # odd windows only: with an even R the output is (H + 1) x (W + 1) and the input gradient needs pad R - 1 - pad, which the
     # planes hand-over between layers ('same' shapes) does not carry
     return (stride == 1 and R == S and R % 2 == 1 and pad == R // 2 and not masked and Cc % 32 == 0 and K % 32 == 0 and R * S <= 25
-            and B * H * W <= _LAYERS_F16X3_MAXPIX
+            and B * H * W <= _config.runtime().layers_f16x3_maxpix
             and _planes_fit(B * H * W, max(Cc, K)) and B * H * W * ((max(K, Cc) + 127) // 128) * 512 < 0x7FFFFF00)
 
 
 #: The general fp16 kernel streams its weight tile once per 64-pixel workgroup and the fp16 weight-gradient kernel re-reads both
 #: operands once per tap: at full-resolution feature maps (a million pixels per batch) both are bound by L2 -> LDS traffic and
-#: lose to the 128x128-tile fp32-MFMA kernels; below this pixel count the fp16 route wins (sweep: DESIGN.md section 9)
-_LAYERS_F16X3_MAXPIX = int(os.environ.get("STEM_LAYERS_F16X3_MAXPIX", str(1 << 30)))
+#: lose to the 128x128-tile fp32-MFMA kernels; `config.layers_f16x3_maxpix` caps the fp16 route's pixel count (sweep: DESIGN.md section 9)
 
 
 def _wide_kernel(n_out, x_shape):
     """large pixel counts with at most 192 output channels: the 192-column kernel (128-pixel workgroups, one weight stream per
     128 pixels) instead of the general one (64-pixel workgroups x 128-column tiles, built for the 16x16 latents)"""
     B, _, H, W = x_shape
-    return n_out <= 192 and B * H * W >= _WIDE_MINPIX
+    return n_out <= 192 and B * H * W >= _config.runtime().layers_wide_minpix
 
-
-_WIDE_MINPIX = int(os.environ.get("STEM_LAYERS_WIDE_MINPIX", "32768"))
 
 
 def planes_of(t):
@@ -561,7 +558,7 @@ def _conv_gdn_fused(conv_mod, gdn, x):
 def _f16x3_enabled():
     """fp32-accurate convolutions on the fp16 matrix cores for inference-only chains (csrc/conv_f16x3.hip).  STEM_F16X3=0
     selects the fp32-MFMA kernels everywhere."""
-    return os.environ.get("STEM_F16X3", "1") != "0"
+    return _config.runtime().analysis_f16x3
 
 
 #: fewest output pixels for which the fp16 kernel beats the fp32-MFMA one (64-pixel tiles, no split-K: below ~3/4 of the CUs

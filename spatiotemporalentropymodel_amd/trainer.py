@@ -20,6 +20,7 @@ import os
 
 import torch
 
+from . import config as _config
 from . import functional as F
 from .layers import join_wgrad_stream
 
@@ -42,7 +43,7 @@ def tuned_schedule(device):
     so that the step's short kernels never queue behind running workgroups of the long analysis-transform kernels.  Scheduling
     only: no result depends on it."""
     for k, v in SCHEDULE_DEFAULTS.items():
-        os.environ.setdefault(k, v)
+        os.environ.setdefault(k, v)                    # config.runtime() parses them (fields stream_prio / stream_cumask)
     F.make_stream(device, "side")                      # parses STEM_STREAM_PRIO once
     if "compute" in (F._STREAM_PRIO or {}):
         return torch.cuda.stream(F.make_stream(device, "compute"))
@@ -118,7 +119,9 @@ class LazyScalar:
         self._v, self._e, self._scale, self._sqrt = value, event, scale, sqrt
 
     def tensor(self):
-        F.cur_stream(self._v.device).wait_event(self._e)
+        cur = F.cur_stream(self._v.device)
+        cur.wait_event(self._e)
+        self._v.record_stream(cur)          # allocated on the auxiliary stream, read here: the allocator must not recycle it under this reader
         v = self._v.reshape(())
         return (v.sqrt() if self._sqrt else v) * self._scale if (self._sqrt or self._scale != 1.0) else v
 
@@ -139,7 +142,7 @@ class FusedPFrameStep:
         #: gradients in place after step() for inspection -- they are then zeroed at the start of the next step instead
         self.clear_grad_in_adam = True
         #: the optimiser pass leaves per-chunk maxima of the updated parameters for the fp16 weight packing (no maximum launches)
-        self.adam_block_max = os.environ.get("STEM_ADAM_BLOCK_MAX", "1") != "0"
+        self.adam_block_max = _config.runtime().adam_block_max
         self._aux_stream = F.make_stream(eb.quantiles.device, "side")
         self._aux_pending = False
         self._done_event = torch.cuda.Event()            # re-recorded every step: the LazyScalars of the LATEST step wait on it

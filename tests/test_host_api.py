@@ -546,3 +546,41 @@ def test_host_codec_under_sanitizers(tmp_path):
     import re
     m = re.search(r"(\d+) passed", out)
     assert m and int(m.group(1)) >= 6, out[-2000:]            # the child really ran the codec tests on the sanitized library
+
+
+def test_runtime_config_is_the_one_reader_of_the_stem_switches(monkeypatch):
+    """config.StemRuntimeConfig: defaults, the environment's overrides (historical STEM_* spellings), override() blocks on top;
+    no module of the package reads a STEM_* switch from os.environ on its own (the two library paths of _lib.py aside)"""
+    import dataclasses
+    import re
+    from spatiotemporalentropymodel_amd import config
+    for v in config._ENV.values():
+        monkeypatch.delenv(v, raising=False)
+    d = config.runtime()
+    assert d == config.StemRuntimeConfig() and d.engine_f16x3 and d.dp_min_bytes == 8 << 20 and not d.ar_persistent
+    assert {f.name for f in dataclasses.fields(d)} == set(config._ENV)
+    monkeypatch.setenv("STEM_ENGINE_F16X3", "0")
+    monkeypatch.setenv("STEM_DP_MIN_BYTES", "4096")
+    monkeypatch.setenv("STEM_STREAM_PRIO", "side=-1")
+    c = config.runtime()
+    assert not c.engine_f16x3 and c.dp_min_bytes == 4096 and c.stream_prio == "side=-1" and c.engine_wgrad_f16x3
+    with config.override(engine_f16x3=True, ar_pipeline=True):
+        assert config.runtime().engine_f16x3 and config.runtime().ar_pipeline
+        monkeypatch.setenv("STEM_AR_STEPWISE", "1")                  # an environment change inside the block keeps the block's fields
+        assert config.runtime().engine_f16x3 and config.runtime().ar_stepwise
+        with config.override(engine_f16x3=False):
+            assert not config.runtime().engine_f16x3
+        assert config.runtime().engine_f16x3
+    assert not config.runtime().engine_f16x3 and not config.runtime().ar_pipeline
+    with pytest.raises(AttributeError):
+        with config.override(no_such_field=1):
+            pass
+    assert config.from_env({"STEM_PIN_RANKS": "0", "STEM_ENGINE_WGRAD_LANES": "2"}).pin_ranks is False
+    assert config.from_env({"STEM_ENGINE_WGRAD_LANES": "2"}).engine_wgrad_lanes == 2
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spatiotemporalentropymodel_amd")
+    for root, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(".py") and fn not in ("config.py", "_lib.py"):
+                text = open(os.path.join(root, fn)).read()
+                reads = re.findall(r'environ(?:\.get\(|\[)\s*"(STEM_[A-Z0-9_]+)"', text)
+                assert not reads, (fn, reads)
