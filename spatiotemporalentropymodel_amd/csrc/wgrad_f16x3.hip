@@ -43,6 +43,24 @@ struct Wg3Args {
     signed char dy[MAXTAP], dx[MAXTAP];
 };
 
+// ---- filter-row form ---------------------------------------------------------------------------------------------------------
+// The per-tap kernel below fetches 16 KiB of operands per 48 MFMAs and workgroup and re-reads dy once per tap.  For 'same'
+// convolutions whose output rows are multiples of 16 pixels a pixel chunk is a run of 16 pixels of ONE image row, and the S taps
+// of a filter row read the same x row shifted by one pixel each: this form's workgroup owns 128 (k) x 64 (c) outputs of ALL S taps
+// of one filter row.  Per chunk it stages the dy rows once and the x row once with its halo (16 + S - 1 pixels, zeros outside
+// the image; LDS-DMA into a four-stage ring, three chunks ahead), reads the dy fragments once and the x fragments of tap s from
+// LDS rows s .. s + 15 -- S times the flop per staged byte and per dy read.
+// 4 wavefronts x (64 k x 32 c) x S taps: 32 S accumulator registers per lane (160 for a 5-tap row), two workgroups per CU.
+// LDS image of x: [row][plane][128 B] in 256-byte rows with the same XOR swizzle (the plane is bit 3 of the 16-byte chunk index:
+// plane 1's address is plane 0's ^ 128); any four consecutive rows hit distinct bank groups, so the shifted reads stay
+// conflict-free.
+constexpr int RT_K = 128, RT_C = 64, RNT = 256;
+constexpr int R_DY = NPL * PLANE;                          // 8192: dy [plane][16 px][256 B]
+constexpr int R_XROWS = 32;                                // 16 + S - 1 <= 20 used; the copy engine fills whole 1 KiB blocks
+constexpr int R_BUF = R_DY + R_XROWS * 256;                // 16384
+constexpr int R_LDS = 4 * R_BUF;                           // four stages: chunk q is multiplied while q + 1 .. q + 3 are in flight
+constexpr int R_MINCHUNKS = 32;                            // pixel chunks per workgroup the planner keeps (slab traffic)
+
 __device__ inline int lds_off(int row, int chunk) { return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
 __device__ inline h16x8 tr_frag(const unsigned char *base, int a0, int a1)
@@ -237,9 +255,212 @@ __global__ __launch_bounds__(NT, 2) void wgrad_f16x3_kernel(const Wg3Args a)
         }
 }
 
-int plan_splits(int B, int OH, int OW, int C, int K, int T)
+template <int S>
+__global__ __launch_bounds__(RNT, 2) void wgrad_f16x3_row_kernel(const Wg3Args a)
+{
+    constexpr int XR = 16 + S - 1, PADX = S / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_c = (a.C + RT_C - 1) / RT_C;
+    // Workgroups are dealt to the 8 XCDs round-robin by their linear id.  The launch is one-dimensional and XCD x takes the
+    // x-th eighth of the list ordered (split, filter row, tile): the workgroups that stream the same pixel range -- the same dy and
+    // x rows -- run on one XCD at about the same time and share them through its L2.
+    const int ntile = ((a.K + RT_K - 1) / RT_K) * tiles_c, nper = gridDim.x >> 3;
+    const int vid = (blockIdx.x & 7) * nper + (blockIdx.x >> 3);
+    if (vid >= ntile * S * a.nsplit) return;
+    const int split = vid / (ntile * S), vrem = vid - split * ntile * S, frow = vrem / ntile, tile = vrem - frow * ntile;
+    const int tk = tile / tiles_c, tc = tile - tk * tiles_c;
+    const int k0 = tk * RT_K, c0 = tc * RT_C;
+    const int ohw = a.OH * a.OW, nchunks = (a.B * ohw) / PX;                 // OW % 16 == 0: a chunk never leaves its image row
+    const int q_begin = split * a.cps, q_end = q_begin + a.cps < nchunks ? q_begin + a.cps : nchunks;
+    const int tdy = frow - PADX;
+
+    // ---- operand stream: LDS-DMA, four instructions per wavefront and chunk (1 KiB each, lane l -> byte 16 l of the destination).
+    //      The LDS images are XOR-swizzled inside their 256-byte rows, so the lane at row r, position c' fetches piece c' ^ f(r) of
+    //      that row.  dy: planes 0 / 1, rows 4 w .. 4 w + 3.  x: rows 4 j .. 4 j + 3 for j = w and w + 4; rows >= XR, pixels outside
+    //      the image and slabs outside the channel range take the offset every buffer view rejects (they read as zeros).
+    //      Issued as inline assembly: the compiler orders every LDS read after ALL pending LDS-DMA it knows of (vmcnt(0) in front
+    //      of the first fragment read of a chunk), which would collapse the three-chunk look-ahead to one; the ring is kept
+    //      consistent by the counted s_waitcnt + barrier at the top of a chunk instead. ----
+    typedef int rsrc4 __attribute__((ext_vector_type(4)));
+    const unsigned long long xa = reinterpret_cast<unsigned long long>(a.xp), da = reinterpret_cast<unsigned long long>(a.dyp);
+    const rsrc4 rx = {(int)(unsigned)xa, (int)(unsigned)(xa >> 32), a.xbytes, 0x00020000};
+    const rsrc4 rdy = {(int)(unsigned)da, (int)(unsigned)(da >> 32), a.dybytes, 0x00020000};
+    auto dma16 = [](const rsrc4 r, unsigned lds_base, int voff) {        // lane l: 16 bytes at voff -> LDS lds_base + 16 l
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(r) : "memory");
+    };
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)smem;
+    const int drow = 4 * wave + (lane >> 4);
+    const int dch = (lane & 15) ^ (((drow & 3) << 2) | ((drow >> 2) & 3));
+    const bool dok = k0 / 32 + (dch >> 2) < a.K / 32;
+    const int dyv = drow * a.dypix + (k0 / 32 + (dch >> 2)) * SLAB + (dch & 3) * 16;
+    int xv[2], xr[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 4 * (wave + 4 * i) + (lane >> 4);
+        const int ch = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        const int sl = (ch >> 2) & 1;
+        xr[i] = (row < XR && c0 / 32 + sl < a.C / 32) ? row - PADX : -0x100000;      // the pixel's distance from the chunk's first (never valid)
+        xv[i] = (row - PADX) * a.xpix + (c0 / 32 + sl) * SLAB + (ch >> 3) * 64 + (ch & 3) * 16;
+    }
+    // position of the next chunk to fetch (image, row, first column), walked chunk by chunk; past the last chunk it stays where
+    // it is (the look-ahead then re-fetches the last chunk into a stage nobody reads)
+    int nq = q_begin, nb, noy, nox;
+    {
+        const int m0 = q_begin * PX;
+        nb = m0 / ohw;
+        const int rem = m0 - nb * ohw;
+        noy = rem / a.OW;
+        nox = rem - noy * a.OW;
+    }
+    auto dma = [&](int stage) {
+        const int iy = noy + tdy;
+        const bool rowok = iy >= 0 && iy < a.H;
+        const unsigned st = __builtin_amdgcn_readfirstlane(lds0 + stage * R_BUF + wave * 1024);
+        const int va = dok ? dyv + nq * PX * a.dypix : OOR;
+        dma16(rdy, st, va);
+        dma16(rdy, st + PLANE, va + 64);
+        const int sbase = ((nb * a.H + iy) * a.W + nox) * a.xpix;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ix = nox + xr[i];
+            const int vx = (rowok && ix >= 0 && ix < a.W) ? sbase + xv[i] : OOR;
+            dma16(rx, st + R_DY + i * 4096, vx);
+        }
+        const bool adv = nq + 1 < q_end, wrapx = nox + PX == a.OW, wrapy = wrapx && noy + 1 == a.OH;       // branch-free: the
+        nq += adv ? 1 : 0;                                                                                   // multiply block stays one
+        nox = adv ? (wrapx ? 0 : nox + PX) : nox;                                                            // basic block
+        noy = (adv && wrapx) ? (wrapy ? 0 : noy + 1) : noy;
+        nb += (adv && wrapy) ? 1 : 0;
+    };
+
+    // ---- fragments: as in the per-tap kernel; the x fragment of tap s starts s rows further down, plane 1 at address ^ 128 ----
+    const int wk0 = (wave >> 1) * 64, wc0 = (wave & 1) * 32;
+    const int g = lane >> 4, cg = g & 1, hh = g >> 1, qq = (lane >> 2) & 3, pp = lane & 3;
+    int adrA[2][2], adrX[S][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int row = 8 * hh + 4 * u + qq;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) adrA[t][u] = lds_off(row, (wk0 + t * 32) / 8 + 2 * cg + (pp >> 1)) + 8 * (pp & 1);
+#pragma unroll
+        for (int s = 0; s < S; ++s) adrX[s][u] = R_DY + lds_off(row + s, wc0 / 8 + 2 * cg + (pp >> 1)) + 8 * (pp & 1);
+    }
+    f32x16 acc[S][2];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[s][i][r] = 0.f;
+
+    // bias gradient: the workgroups of filter row 0 / channel tile 0 see every dy row of their k tile and pixel range exactly once;
+    // each thread re-reads one 16-byte piece per plane from the LDS image (every piece of the 16 x 128 tile is covered once)
+    const bool do_bias = a.bias_part != nullptr && frow == 0 && tc == 0;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int srow = tid >> 4, sslab = (tid >> 2) & 3, spc = tid & 3;
+    const int st0 = lds_off(srow, sslab * 4 + spc);
+
+    const bool dead = k0 + wk0 >= a.K || c0 + wc0 >= a.C;
+    if (q_begin < q_end) {
+        dma(0);
+        dma(1);
+        dma(2);
+    }
+    for (int q = q_begin; q < q_end; ++q) {
+        const int stage = (q - q_begin) & 3;
+        // chunk q has landed (this wavefront's part: all but the 8 instructions of chunks q + 1, q + 2), then everybody's; the
+        // barrier also says that nobody still reads stage (q + 3) & 3, chunk q - 1's
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (dead) dma((stage + 3) & 3);
+        const unsigned char *Ab = smem + stage * R_BUF;
+        if (do_bias) {
+            const hp8 p0 = *reinterpret_cast<const hp8 *>(Ab + st0), p1 = *reinterpret_cast<const hp8 *>(Ab + PLANE + st0);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) bsum[c] += (float)p0[c] + (float)p1[c];
+        }
+        if (!dead) {
+            h16x8 af[2][NPL], bf[2][NPL];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) af[t][pl] = tr_frag(Ab + pl * PLANE, adrA[t][0], adrA[t][1]);
+            bf[0][0] = tr_frag(Ab, adrX[0][0], adrX[0][1]);
+            bf[0][1] = tr_frag(Ab, adrX[0][0] ^ 128, adrX[0][1] ^ 128);
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                if (s + 1 < S) {           // the next tap's fragments are on their way while this tap multiplies
+                    bf[(s + 1) & 1][0] = tr_frag(Ab, adrX[s + 1][0], adrX[s + 1][1]);
+                    bf[(s + 1) & 1][1] = tr_frag(Ab, adrX[s + 1][0] ^ 128, adrX[s + 1][1] ^ 128);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    acc[s][i] = STEM_MFMA16(af[i][1], bf[s & 1][0], acc[s][i]);
+                    acc[s][i] = STEM_MFMA16(af[i][0], bf[s & 1][1], acc[s][i]);
+                    acc[s][i] = STEM_MFMA16(af[i][0], bf[s & 1][0], acc[s][i]);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                if (s == 0) dma((stage + 3) & 3);          // chunk q + 3, issued in the shadow of the first tap's products
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the re-fetches of the last chunk are still landing in LDS
+    __syncthreads();
+
+    if (do_bias) {
+        float *red = reinterpret_cast<float *>(smem);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) red[srow * 128 + sslab * 32 + spc * 8 + c] = bsum[c];
+        __syncthreads();
+        if (tid < 128 && k0 + tid < a.K) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v += red[r * 128 + tid];
+            a.bias_part[(size_t)split * a.K + k0 + tid] = v * q_inv(a.dyq);
+        }
+    }
+    if (dead) return;
+    const float fac = q_inv(a.xq) * q_inv(a.dyq);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int c = c0 + wc0 + lr;
+    if (c >= a.C) return;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        float *out = a.dwp + ((size_t)split * a.T + frow * S + s) * a.K * a.C;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wk0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (k < a.K) out[(size_t)k * a.C + c] = acc[s][i][r] * fac;
+            }
+    }
+}
+
+// the filter-row form applies: 3 x 3 / 5 x 5 window with 'same' padding, output rows in whole 16-pixel chunks.  In the bench step
+// (same box, ms per step): per-tap form everywhere 14.33-14.36, 5 x 5 layers here 14.08-14.13, 3 x 3 layers too 13.96-14.07
+// (isolated the 3 x 3 layers are equal, 31.7 against 31.5 us: fewer, longer workgroups next to the step's other streams).
+// stem_tuning_set("wg3_row", 1): per-tap form everywhere; 3: 5 x 5 only.
+bool row_form(int OH, int OW, int H, int W, int R, int S, int pad)
+{
+    const int sel = stem_tuning(STEM_TUNE_WG3_ROW);
+    return sel != 1 && R == S && (R == 5 || (R == 3 && sel != 3)) && pad == R / 2 && OH == H && OW == W && OW % PX == 0;
+}
+
+int plan_splits(int B, int OH, int OW, int C, int K, int T, bool rows = false, int R = 0)
 {
     const int forced = stem_tuning(STEM_TUNE_WG3_SPLIT);      // stem_tuning_set("wg3_split", n): tests / sweeps
+    if (rows) {       // workgroups = tiles x filter rows x splits: at most 512 (two per CU), at least R_MINCHUNKS pixel chunks each
+        const int nchunks = B * OH * OW / PX, wgs = cdiv(K, RT_K) * cdiv(C, RT_C) * R;
+        int s = forced > 0 ? forced : 512 / wgs;
+        if (forced <= 0 && s > nchunks / R_MINCHUNKS) s = nchunks / R_MINCHUNKS;
+        if (s > nchunks) s = nchunks;
+        if (s < 1) s = 1;
+        return cdiv(nchunks, cdiv(nchunks, s));
+    }
     const int nchunks = cdiv(B * OH * OW, PX), tiles = cdiv(K, TK) * cdiv(C, TC) * T;
     int s = forced > 0 ? forced : (512 + tiles / 2) / tiles;       // two workgroups per CU: aim at ~512 workgroups
     if (s < 1) s = 1;
@@ -257,7 +478,7 @@ STEM_EXPORT int stem_wgrad_f16x3_splits(int B, int H, int W, int C, int K, int R
 {
     const int OH = H + 2 * pad - R + 1, OW = W + 2 * pad - S + 1;
     if (OH < 1 || OW < 1) return 0;
-    return plan_splits(B, OH, OW, C, K, R * S);
+    return plan_splits(B, OH, OW, C, K, R * S, row_form(OH, OW, H, W, R, S, pad), R);
 }
 
 STEM_EXPORT int stem_conv2d_wgrad_f16x3(const void *xp, const float *xq, int xpix, const void *dyp, const float *dyq, int dypix, float *dwp,
@@ -274,7 +495,8 @@ STEM_EXPORT int stem_conv2d_wgrad_f16x3(const void *xp, const float *xq, int xpi
                    "stem_conv2d_wgrad_f16x3: pixel pitches must be multiples of %d bytes covering the channels", SLAB);
     const size_t xb = (size_t)B * H * W * xpix, db = (size_t)B * OH * OW * dypix;
     STEM_CHECK_ARG(xb < 0x7FFFFF00ull && db < 0x7FFFFF00ull, "stem_conv2d_wgrad_f16x3: operand views must stay below 2 GiB");
-    STEM_CHECK_ARG(splits == plan_splits(B, OH, OW, C, K, R * S), "stem_conv2d_wgrad_f16x3: splits must come from stem_wgrad_f16x3_splits");
+    const bool rows = row_form(OH, OW, H, W, R, S, pad);
+    STEM_CHECK_ARG(splits == plan_splits(B, OH, OW, C, K, R * S, rows, R), "stem_conv2d_wgrad_f16x3: splits must come from stem_wgrad_f16x3_splits");
     Wg3Args a;
     memset(&a, 0, sizeof(a));
     a.xp = xp; a.dyp = dyp; a.xq = xq; a.dyq = dyq; a.dwp = dwp; a.bias_part = bias_part; a.xpix = xpix; a.dypix = dypix;
@@ -288,6 +510,21 @@ STEM_EXPORT int stem_conv2d_wgrad_f16x3(const void *xp, const float *xq, int xpi
             a.dy[r * S + s] = (signed char)(r - pad);
             a.dx[r * S + s] = (signed char)(s - pad);
         }
+    if (rows) {
+        static bool attr_rows = false;
+        if (!attr_rows) {
+            (void)hipFuncSetAttribute((const void *)wgrad_f16x3_row_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
+            (void)hipFuncSetAttribute((const void *)wgrad_f16x3_row_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
+            attr_rows = true;
+        }
+        const dim3 grid(cdiv(cdiv(K, RT_K) * cdiv(C, RT_C) * R * splits, 8) * 8);
+        if (R == 3)
+            hipLaunchKernelGGL(wgrad_f16x3_row_kernel<3>, grid, dim3(RNT), R_LDS, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(wgrad_f16x3_row_kernel<5>, grid, dim3(RNT), R_LDS, (hipStream_t)stream, a);
+        STEM_LAUNCH_CHECK("stem_conv2d_wgrad_f16x3");
+        return 0;
+    }
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void *)wgrad_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

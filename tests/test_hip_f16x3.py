@@ -461,7 +461,10 @@ WG_CASES = [  # B, C, H, W, K, R
     (2, 64, 9, 11, 96, 3),           # ragged pixel count (198 = 12 chunks of 16 + 6), one tile
     (1, 160, 13, 7, 96, 5),          # C = 160: second channel tile half empty
     (3, 32, 16, 16, 288, 1),         # 1x1, three k tiles
-    (4, 192, 16, 16, 256, 5),        # TPM.0 geometry at a quarter of the batch
+    (4, 192, 16, 16, 256, 5),        # TPM.0 geometry at a quarter of the batch (filter-row form: rows of 16 pixels)
+    (2, 96, 8, 32, 160, 5),          # filter-row form, two chunks per image row; K = 160 / C = 96: half-empty k and c tiles
+    (1, 96, 3, 48, 64, 5),           # ... three chunks per row, fewer image rows than filter rows
+    (3, 64, 5, 16, 96, 3),           # ... 3 x 3 window
 ]
 
 
@@ -497,6 +500,28 @@ def _weight_gradient_vs_oracle(F, case, split):
     assert_close(host(db), 2 * db_ref, what="bias gradient, accumulated", floor=0.1)
 
 
+@pytest.mark.parametrize("case", [c for c in WG_CASES if c[3] % 16 == 0 and c[5] > 1])
+def test_weight_gradient_filter_row_form_vs_per_tap_form(F, case):
+    """the two forms of csrc/wgrad_f16x3.hip on the geometries the filter-row form takes: each against the oracle (above, the
+    row form by default) and against each other -- same products, sums over pixels in a different order"""
+    B, C, H, W, K, R = case
+    pad = R // 2
+    xp, dyp = F.F16Planes.split(dev(rnd((B, C, H, W), 53, -2, 2))), F.F16Planes.split(dev(rnd((B, K, H, W), 54)))
+    out = {}
+    for form in (0, 1):
+        with F.tuning(wg3_row=form):
+            splits, elems = F.wgrad_f16x3_plan((B, C, H, W), K, R, R, pad)
+            dwp, db = torch.empty(elems, device="cuda"), torch.zeros(K, device="cuda")
+            F.conv2d_wgrad_f16x3(xp, dyp, K, R, R, pad, dwp, splits, db=db)
+            out[form] = (host(dwp.view(splits, R * R, K, C).sum(0)), host(db))
+    assert_close(out[0][0], out[1][0], what=f"filter-row form against per-tap form {case}", floor=0.1)
+    assert_close(out[0][1], out[1][1], what="bias gradient of the two forms", floor=0.1)
+    with F.tuning(wg3_row=1):
+        per_tap_splits = F.wgrad_f16x3_plan((B, C, H, W), K, R, R, pad)[0]
+    with F.tuning(wg3_row=0, wg3_split=2):      # a forced split is honoured by the row form's planner too
+        assert F.wgrad_f16x3_plan((B, C, H, W), K, R, R, pad)[0] <= 2 and per_tap_splits >= 1
+
+
 def test_weight_gradient_from_channel_views(F):
     """x and dy as 32-aligned channel views of wider planes tensors (how the engine feeds the prior branches' slices)"""
     B, H, W = 2, 8, 8
@@ -509,6 +534,17 @@ def test_weight_gradient_from_channel_views(F):
     ref = orc.conv2d_bwd(np.ascontiguousarray(xb[:, 32:96]), np.zeros((96, 64, 3, 3), np.float32), np.ascontiguousarray(dyb[:, 64:160]), 1, 1,
                          need_dx=False)[1]
     assert_close(host(dw), ref, what="wgrad from views", floor=0.1)
+    # the same through the filter-row form (rows of 16 pixels): the views' pixel pitches are those of the wider tensors
+    B, H, W = 2, 4, 16
+    xb, dyb = rnd((B, 160, H, W), 63, -2, 2), rnd((B, 224, H, W), 64)
+    xp, dyp = F.F16Planes.split(dev(xb)).channels(32, 96), F.F16Planes.split(dev(dyb)).channels(64, 160)
+    splits, elems = F.wgrad_f16x3_plan(xp.shape, 96, 5, 5, 2)
+    dwp = torch.empty(elems, device="cuda")
+    F.conv2d_wgrad_f16x3(xp, dyp, 96, 5, 5, 2, dwp, splits)
+    dw = dwp.view(splits, 25, 96, 64).sum(0).permute(1, 2, 0).reshape(96, 64, 5, 5)
+    ref = orc.conv2d_bwd(np.ascontiguousarray(xb[:, 32:96]), np.zeros((96, 64, 5, 5), np.float32), np.ascontiguousarray(dyb[:, 64:160]), 1, 2,
+                         need_dx=False)[1]
+    assert_close(host(dw), ref, what="wgrad from views, filter-row form", floor=0.1)
 
 
 def test_gen_kernel_at_eight_full_hd_sequences(F):

@@ -41,6 +41,21 @@ def case(name, B, C, H, W, K, R, timing=True):
     sc = float(ref.abs().max())
     e6, e32 = float((dw6.double().cpu() - ref).abs().max()) / sc, float((dw32.double().cpu() - ref).abs().max()) / sc
     line = f"{name:8s} splits {splits:2d}  err f16x3 {e6:.2e}  fp32 {e32:.2e}"
+    # full path (slab sums + bias gradient) against fp64, and the per-tap kernel (wg3_row=1) next to the filter-row form
+    dwf, dbf = torch.zeros(K, C, R, R, device=dev), torch.zeros(K, device=dev)
+    F.conv2d_wgrad_f16x3_into(xp, dyp, K, R, R, pad, dwf, dbf)
+    eb = float((dbf.double().cpu() - dy.double().cpu().sum((0, 2, 3))).abs().max()) / float(dy.double().sum((0, 2, 3)).abs().max())
+    ef = float((dwf.double().cpu() - ref).abs().max()) / sc
+    line += f"  into {ef:.2e} bias {eb:.2e}"
+    with F.tuning(wg3_row=1):
+        s1, el1 = F.wgrad_f16x3_plan(x.shape, K, R, R, pad)
+        dwp1 = torch.empty(el1, device=dev)
+        F.conv2d_wgrad_f16x3(xp, dyp, K, R, R, pad, dwp1, s1)
+        d1 = dwp1.view(s1, R * R, K, C).sum(0).permute(1, 2, 0).reshape(K, C, R, R)
+        line += f"  vs per-tap {float((d1 - dw6).abs().max()) / sc:.1e}"
+        if timing:
+            t1 = timeit(lambda: F.conv2d_wgrad_f16x3(xp, dyp, K, R, R, pad, dwp1, s1))
+            line += f" ({s1} splits {t1:6.1f} us)"
     if timing:
         t6 = timeit(lambda: F.conv2d_wgrad_f16x3(xp, dyp, K, R, R, pad, dwp, splits))
         t32 = timeit(lambda: F.conv2d_wgrad(xn, dyn, K, R, R, 1, pad, unpack=False, need_db=False))
@@ -54,6 +69,10 @@ _case = case
 case = lambda name, *a, **k: _case(name, *a, **k) if only is None or name in only else None
 case("small", 2, 64, 9, 11, 96, 3, timing=False)
 case("odd", 1, 96, 13, 7, 160, 5, timing=False)
+case("w32", 2, 96, 8, 32, 160, 5, timing=False)
+case("w16r3", 3, 64, 5, 16, 96, 3, timing=False)
+case("w48", 1, 96, 3, 48, 64, 5, timing=False)
+case("w16one", 1, 32, 1, 16, 32, 3, timing=False)
 case("TPM.0", 16, 192, 16, 16, 256, 5)
 case("TPM.2", 16, 256, 16, 16, 320, 5)
 case("TPM.4", 16, 320, 16, 16, 384, 5)
