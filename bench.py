@@ -565,7 +565,15 @@ def main():
                                                 grad_scale=1.0 / world, reducer=reducer, y_cur=y_cur)
             y_cond = out["y_hat"]                # graph mode: static output buffer, copied into the y_cond input by the next step()
             last = oc
+            if TIMELINE is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                TIMELINE.append(ev)
         return last
+
+    # STEM_BENCH_TIMELINE=1 (dev): where the analysis-transform launches of the prefetch stream fall between the P-frame steps'
+    # ends -- HIP events only, no profiler in the way
+    TIMELINE = [] if os.environ.get("STEM_BENCH_TIMELINE") else None
 
     with compute:
         for _ in range(args.warmup):
@@ -575,9 +583,17 @@ def main():
         D.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        if TIMELINE is not None:
+            TIMELINE.clear()
+            tl0 = torch.cuda.Event(enable_timing=True)
+            tl0.record()
         for _ in range(args.steps):
             last = one_step()
         torch.cuda.synchronize()
+        if TIMELINE is not None and rank == 0:
+            marks = [("P-step end", tl0.elapsed_time(e)) for e in TIMELINE] + [(f"g_a.2 [{tl0.elapsed_time(a):8.3f} .. ", tl0.elapsed_time(b)) for a, b in probe]
+            for name, t in sorted(marks, key=lambda m: m[1])[:60]:
+                print(f"timeline {name} {t:8.3f} ms", file=sys.stderr)
         D.barrier()
         dt = D.max_over_ranks(time.perf_counter() - t0, dev)
 

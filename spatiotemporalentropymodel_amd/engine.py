@@ -352,6 +352,9 @@ class StemEngine:
     #: network joins them: the hyper path runs on its own stream in forward and backward so that the ramp-up / drain of its
     #: small launches overlaps the other branch's kernels (30.90 -> 30.75 ms per bench step; STEM_ENGINE_BRANCH=0 disables)
     branch_streams = _CFG.engine_branch
+    #: the temporal-prior chain is enqueued before the hyper branch (scheduling only)
+    tpm_first = _CFG.engine_tpm_first
+    tpm_first_bwd = _CFG.engine_tpm_first_bwd
 
     def _branch(self, device, which=0):
         if not self.branch_streams or device.type != "cuda":
@@ -535,6 +538,23 @@ class StemEngine:
             t_hat.record_stream(cs)
             epm_in.record_stream(cs)
         split = F.F16Planes.split
+        tp0 = tp2 = None
+
+        def tpm_chain():
+            nonlocal tp0, tp2
+            if self.has_tpm and self.TPM[0].fx3:
+                # planes travel from layer to layer (written by the producing epilogue next to the fp32 copy backward needs)
+                pl["yd"] = split(yd, src_q=_qp(rec.get("in")))       # max(|y_cur|, |y_cond|) bounds y_cond
+                tp0, pl["tp0"] = self.TPM[0].fwd6(pl["yd"], F.ACT_LRELU, planes=True)
+                tp2, pl["tp2"] = self.TPM[1].fwd6(pl["tp0"], F.ACT_LRELU, planes=True)
+                self.TPM[2].fwd6(pl["tp2"], out=epm_in[:, o_tp:o_tp + P])
+            elif self.has_tpm:
+                tp0 = self.TPM[0].fwd(yd, F.ACT_LRELU)
+                tp2 = self.TPM[1].fwd(tp0, F.ACT_LRELU)
+                self.TPM[2].fwd(tp2, out=epm_in[:, o_tp:o_tp + P])
+
+        if self.tpm_first:           # enqueued ahead of the hyper branch's ~14 launches: the TPM chain is the forward's critical path
+            tpm_chain()
         with F.on_stream(bs):
             if self.HE[0].fx3:
                 pl["he_in"] = split(he_in, src_q=_qp(rec.get("in")))
@@ -562,17 +582,8 @@ class StemEngine:
                 self.HD[2].fwd6(pl["hd2"], out=epm_in[:, o_hp:o_hp + P])
             else:
                 self.HD[2].fwd(hd2, out=epm_in[:, o_hp:o_hp + P])
-        tp0 = tp2 = None
-        if self.has_tpm and self.TPM[0].fx3:
-            # planes travel from layer to layer (written by the producing epilogue next to the fp32 copy backward needs)
-            pl["yd"] = split(yd, src_q=_qp(rec.get("in")))       # max(|y_cur|, |y_cond|) bounds y_cond
-            tp0, pl["tp0"] = self.TPM[0].fwd6(pl["yd"], F.ACT_LRELU, planes=True)
-            tp2, pl["tp2"] = self.TPM[1].fwd6(pl["tp0"], F.ACT_LRELU, planes=True)
-            self.TPM[2].fwd6(pl["tp2"], out=epm_in[:, o_tp:o_tp + P])
-        elif self.has_tpm:
-            tp0 = self.TPM[0].fwd(yd, F.ACT_LRELU)
-            tp2 = self.TPM[1].fwd(tp0, F.ACT_LRELU)
-            self.TPM[2].fwd(tp2, out=epm_in[:, o_tp:o_tp + P])
+        if not self.tpm_first:
+            tpm_chain()
         if not fused:
             target = F.sub(yc, yd) if self.residual else (yc if F.nhwc_ld(yc) == Cin else F.copy_channels(yc, F.empty_nhwc(B, Cin, H, W, dev)))
         if self.has_spm:
@@ -648,11 +659,19 @@ class StemEngine:
             dpri = self.EPM[0].dgrad(de0, k["epm_in"].shape)
         self._group_ready(self.EPM, [])
         bs = self._branch(gp.device)
-        if bs is not None:                # hyper chain (HD -> bottleneck -> HE) on its own stream, next to the TPM chain
-            main = F.cur_stream(gp.device)
-            F.stream_wait(bs, main)
+        main = F.cur_stream(gp.device)
+
+        if bs is not None:                 # the hyper chain depends on the EPM input gradient only: its point on the compute stream
+            epm_done = self._events.setdefault("bwd_epm", torch.cuda.Event())
+            F.event_record(epm_done, main)
+
+        def hyper_branch():                # hyper chain (HD -> bottleneck -> HE) on its own stream, next to the TPM chain
+            F.event_wait(bs, epm_done)
             with F.on_stream(bs):
                 self._backward_hyper(k, dpri, dlik_z, dprip)
+
+        if bs is not None and not self.tpm_first_bwd:
+            hyper_branch()
         # spatial prior: weight gradient of all 25 taps, no input gradient (its input is data + noise)
         if self.has_spm:
             if self.CTX.wg3 and dprip is not None:
@@ -677,6 +696,8 @@ class StemEngine:
                 d = self.TPM[1].dgrad(d, k["tp0"].shape, xact=k["tp0"])
                 self.TPM[0].wgrad(k["yd"], d)
             self._group_ready(self.TPM, [])
+        if bs is not None and self.tpm_first_bwd:
+            hyper_branch()
         if bs is None:
             self._backward_hyper(k, dpri, dlik_z, dprip)
         else:
