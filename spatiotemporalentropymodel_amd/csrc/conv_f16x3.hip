@@ -34,6 +34,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "stem_common.h"
 
 namespace {
@@ -1082,10 +1084,10 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
     // version handled one row per unit: 100-byte runs in flip mode and two barriers per 800 values.)
     __shared__ float tile[PKR * 32 * MAXTAP];         // [row][channel in slab][tap]
     const stem_f16x2_pack_desc &d = tab.d[blockIdx.y];
-    const int RS = d.R * d.S, T = d.taps > 0 ? d.taps : RS, nslab = d.C / 32, nchunks = nslab * T, ntile = cdiv_dev(d.N, GBN);
+    const int nslab = d.C / 32, ntile = cdiv_dev(d.N, GBN);
     const float *w = static_cast<const float *>(d.w);
     unsigned char *wp = static_cast<unsigned char *>(d.wp);
-    float *wq = reinterpret_cast<float *>(wp + (size_t)ntile * nslab * RS * GB_BUF);    // the scale record sits behind the FULL image's size
+    float *wq = reinterpret_cast<float *>(wp + (size_t)ntile * nslab * d.R * d.S * GB_BUF);    // the scale record sits behind the FULL image's size
     __shared__ float qred[16];
     float wmax;
     if (d.bmax) {       // maxima of the optimiser pass's chunks that cover this tensor (an upper bound: neighbours may share a chunk)
@@ -1102,49 +1104,65 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
     const int we = q_exp(wmax);
     const float wscale = q_pow2(we);
     if (blockIdx.x == 0 && threadIdx.x == 0) wq[1] = q_pow2(-we);
-    float *wz = (d.bmax && T < RS) ? static_cast<float *>(const_cast<void *>(d.w)) : nullptr;      // masked taps zeroed here (no maximum pass did it)
+    float *wz = (d.bmax && d.taps > 0 && d.taps < d.R * d.S) ? static_cast<float *>(const_cast<void *>(d.w)) : nullptr;      // masked taps zeroed here (no maximum pass did it)
     const int units = ntile * (GBN / PKR) * nslab;
-    for (int u = blockIdx.x; u < units; u += gridDim.x) {
-        const int slab = u % nslab, n0 = (u / nslab) * PKR;   // n runs over the padded rows of all N tiles
-        __syncthreads();
-        if (d.flip) {
-            // element (row r, channel c, tap): w[((slab * 32 + c) * N + n0 + r) * RS + (RS - 1 - tap)]: for fixed c, PKR * RS contiguous floats
-            for (int e = threadIdx.x; e < 32 * PKR * RS; e += 256) {
-                const int c = e / (PKR * RS), rem = e - c * (PKR * RS), r = rem / RS, tp = rem - r * RS;
-                const int n = n0 + r;
-                tile[(r * 32 + c) * MAXTAP + (RS - 1 - tp)] = n < d.N ? w[((size_t)(slab * 32 + c) * d.N + n) * RS + tp] : 0.f;
-            }
-        } else {
-            // element (row r, channel c, tap): w[((n0 + r) * C + slab * 32 + c) * RS + tap]: for fixed r, 32 * RS contiguous floats
-            for (int e = threadIdx.x; e < PKR * 32 * RS; e += 256) {
-                const int r = e / (32 * RS), rem = e - r * (32 * RS), c = rem / RS, tp = rem - c * RS;
-                const int n = n0 + r;
-                const size_t wi = ((size_t)n * d.C + slab * 32 + c) * RS + tp;
-                float wv = n < d.N ? w[wi] : 0.f;
-                if (wz && tp >= T && n < d.N) {
-                    wz[wi] = 0.f;
-                    wv = 0.f;
+    // the element loops divide by RS and 32 RS / PKR RS per element: with the window size a compile-time constant (1, 9, 25: every
+    // layer of the model) those are multiplications -- the pass is bound by its index arithmetic, not by HBM, otherwise
+    auto run = [&](auto rs_const) {
+        constexpr int CRS = decltype(rs_const)::value;
+        const int RS = CRS > 0 ? CRS : d.R * d.S;
+        const int T = d.taps > 0 ? d.taps : RS, nchunks = nslab * T;
+        for (int u = blockIdx.x; u < units; u += gridDim.x) {
+            const int slab = u % nslab, n0 = (u / nslab) * PKR;   // n runs over the padded rows of all N tiles
+            __syncthreads();
+            if (d.flip) {
+                // element (row r, channel c, tap): w[((slab * 32 + c) * N + n0 + r) * RS + (RS - 1 - tap)]: for fixed c, PKR * RS contiguous floats
+                for (int e = threadIdx.x; e < 32 * PKR * RS; e += 256) {
+                    const int c = e / (PKR * RS), rem = e - c * (PKR * RS), r = rem / RS, tp = rem - r * RS;
+                    const int n = n0 + r;
+                    tile[(r * 32 + c) * MAXTAP + (RS - 1 - tp)] = n < d.N ? w[((size_t)(slab * 32 + c) * d.N + n) * RS + tp] : 0.f;
                 }
-                tile[(r * 32 + c) * MAXTAP + tp] = wv;
+            } else {
+                // element (row r, channel c, tap): w[((n0 + r) * C + slab * 32 + c) * RS + tap]: for fixed r, 32 * RS contiguous floats
+                for (int e = threadIdx.x; e < PKR * 32 * RS; e += 256) {
+                    const int r = e / (32 * RS), rem = e - r * (32 * RS), c = rem / RS, tp = rem - c * RS;
+                    const int n = n0 + r;
+                    const size_t wi = ((size_t)n * d.C + slab * 32 + c) * RS + tp;
+                    float wv = n < d.N ? w[wi] : 0.f;
+                    if (wz && tp >= T && n < d.N) {
+                        wz[wi] = 0.f;
+                        wv = 0.f;
+                    }
+                    tile[(r * 32 + c) * MAXTAP + tp] = wv;
+                }
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < PKR * T * 4; e += 256) {
+                const int p = e & 3, r = (e >> 2) % PKR, tap = (e >> 2) / PKR;
+                const int n = n0 + r, nt = n / GBN, nl = n - nt * GBN;
+                h16x8 h[NPL];
+    #pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    hp_t x0, x1;
+                    q_split(tile[(r * 32 + p * 8 + c) * MAXTAP + tap], wscale, x0, x1);
+                    h[0][c] = x0; h[1][c] = x1;
+                }
+                const long qq = (long)nt * nchunks + slab * T + tap;
+                unsigned char *dst = wp + qq * GB_BUF + nl * 64 + ((p ^ ((nl >> 2) & 3)) << 4);
+    #pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<h16x8 *>(dst + pl * GB_PLANE) = h[pl];
             }
         }
-        __syncthreads();
-        for (int e = threadIdx.x; e < PKR * T * 4; e += 256) {
-            const int p = e & 3, r = (e >> 2) % PKR, tap = (e >> 2) / PKR;
-            const int n = n0 + r, nt = n / GBN, nl = n - nt * GBN;
-            h16x8 h[NPL];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                hp_t x0, x1;
-                q_split(tile[(r * 32 + p * 8 + c) * MAXTAP + tap], wscale, x0, x1);
-                h[0][c] = x0; h[1][c] = x1;
-            }
-            const long qq = (long)nt * nchunks + slab * T + tap;
-            unsigned char *dst = wp + qq * GB_BUF + nl * 64 + ((p ^ ((nl >> 2) & 3)) << 4);
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<h16x8 *>(dst + pl * GB_PLANE) = h[pl];
-        }
-    }
+    };
+    const int rs_rt = d.R * d.S;
+    if (rs_rt == 25)
+        run(std::integral_constant<int, 25>{});
+    else if (rs_rt == 9)
+        run(std::integral_constant<int, 9>{});
+    else if (rs_rt == 1)
+        run(std::integral_constant<int, 1>{});
+    else
+        run(std::integral_constant<int, 0>{});
 }
 
 // fp32 NHWC -> planes: one thread per (pixel, slab, 8-channel piece)

@@ -456,7 +456,8 @@ int plan_splits(int B, int OH, int OW, int C, int K, int T, bool rows = false, i
     if (rows) {       // workgroups = tiles x filter rows x splits: at most 512 (two per CU), at least R_MINCHUNKS pixel chunks each
         const int nchunks = B * OH * OW / PX, wgs = cdiv(K, RT_K) * cdiv(C, RT_C) * R;
         int s = forced > 0 ? forced : 512 / wgs;
-        if (forced <= 0 && s > nchunks / R_MINCHUNKS) s = nchunks / R_MINCHUNKS;
+        const int minch = stem_tuning(STEM_TUNE_WG3_MINCH) > 0 ? stem_tuning(STEM_TUNE_WG3_MINCH) : R_MINCHUNKS;      // stem_tuning_set("wg3_minch", n): sweeps
+        if (forced <= 0 && s > nchunks / minch) s = nchunks / minch;
         if (s > nchunks) s = nchunks;
         if (s < 1) s = 1;
         return cdiv(nchunks, cdiv(nchunks, s));
