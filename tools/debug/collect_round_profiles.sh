@@ -26,4 +26,12 @@ if [ -f spatiotemporalentropymodel_amd/libstem_hip_exper.so ]; then
   STEM_AR_PERSISTENT=1 STEM_HIP_LIBRARY=$R/spatiotemporalentropymodel_amd/libstem_hip_exper.so python3 tools/eval_pframe_bench.py --frames 2 > $out/eval_1080p_persistent_kernel.log 2>&1
 fi
 python3 tools/debug/host_lag.py > $out/host_lag.log 2>&1
+python3 tools/host_overhead.py > $out/host_overhead.log 2>&1
+# round 4: image-tile form of the general kernel, filter-row form of the weight gradient, event timeline of the default run
+bash tools/debug/prof_pmc.sh $tag/pmc_img_tpm4 tools/debug/f16x3_img_prof.py TPM.4 img > $out/pmc_img_tpm4.log 2>&1
+bash tools/debug/prof_pmc.sh $tag/pmc_img_tpm4_split5 tools/debug/f16x3_img_prof.py TPM.4 img 5 > $out/pmc_img_tpm4_split5.log 2>&1
+bash tools/debug/prof_pmc.sh $tag/pmc_wgrad_row_tpm4 tools/debug/wgrad3_check.py TPM.4 > $out/pmc_wgrad_row_tpm4.log 2>&1
+python3 tools/debug/wgrad3_check.py 2>&1 | grep -v "amdgpu.ids" > $out/wgrad_row_vs_per_tap.log
+python3 tools/debug/f16x3_img_check.py 2>&1 | grep -v "amdgpu.ids" > $out/img_check.log
+STEM_BENCH_TIMELINE=1 python3 bench.py --steps 4 --warmup 3 --no-cpu-baseline 2> $out/event_timeline.log > /dev/null
 ls -la $out
