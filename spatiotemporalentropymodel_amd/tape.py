@@ -234,9 +234,9 @@ class TapedPFrameStep:
     time per bench step.  Steps 1-2 run the ordinary schedule (weights packed, workspaces at their final sizes), step 3 is
     recorded with its allocations kept, step 4 recorded again to find the per-step counters; from step 5 on the tape replays.
 
-    The tensors a replayed step returns are the recorded step's (static buffers, overwritten by the next step): consume them --
-    as the training loop does, `y_cond = out["y_hat"]` is copied into the tape's input buffer at the start of the next step --
-    or copy them before the next call."""
+    The tensors a replayed step returns are the recorded step's (static buffers, overwritten by the next step; `y_hat` alternates
+    between two buffers so that the next step can read it as its `y_cond` in place): consume them as the training loop does, or
+    copy them before the next call."""
 
     WARMUP = 2
 
@@ -280,6 +280,13 @@ class TapedPFrameStep:
             # the frame's latents arrive in a different buffer every step (the prefetcher's): where the schedule reads the recorded
             # input buffer, the tape is pointed at the caller's tensor instead of copying it (same shape / strides required)
             self.cur_slots = self.tape.pointer_slots(self.in_cur.data_ptr())
+            # the conditioning latents are the previous step's y_hat (stem/trainSTEM.py:179): instead of copying them into the
+            # recorded input buffer, the tape reads them where they are and writes this step's y_hat into the OTHER of two
+            # output buffers (the schedule reads y_cond after it has written y_hat, so the two must not alias)
+            self.cond_slots = self.tape.pointer_slots(self.in_cond.data_ptr())
+            y_hat = self.result[0]["y_hat"]
+            self.yhat_slots = self.tape.pointer_slots(y_hat.data_ptr())
+            self.yhat_bufs = [y_hat, torch.empty_like(y_hat)] if (self.cond_slots and self.yhat_slots) else None
             return res
         if self.cur_slots and y_cur.stride() == self.in_cur.stride() and y_cur.dtype == self.in_cur.dtype:
             self.tape.set_pointer(self.cur_slots, y_cur.data_ptr())
@@ -287,13 +294,24 @@ class TapedPFrameStep:
             if self.cur_slots:
                 self.tape.set_pointer(self.cur_slots, self.in_cur.data_ptr())
             self.in_cur.copy_(y_cur)
-        self.in_cond.copy_(y_cond)
+        result = self.result
+        if self.yhat_bufs is not None and y_cond.stride() == self.in_cond.stride() and y_cond.dtype == self.in_cond.dtype:
+            out = self.yhat_bufs[1] if y_cond.data_ptr() == self.yhat_bufs[0].data_ptr() else self.yhat_bufs[0]
+            self.tape.set_pointer(self.cond_slots, y_cond.data_ptr())
+            self.tape.set_pointer(self.yhat_slots, out.data_ptr())
+            if out is not self.yhat_bufs[0]:
+                result = (dict(self.result[0], y_hat=out),) + tuple(self.result[1:])
+        else:
+            if self.yhat_bufs is not None:
+                self.tape.set_pointer(self.cond_slots, self.in_cond.data_ptr())
+                self.tape.set_pointer(self.yhat_slots, self.yhat_bufs[0].data_ptr())
+            self.in_cond.copy_(y_cond)
         self.replays += 1
         self.tape.replay(self.replays)
         for (o, a), d in zip(self._counters(), self.deltas):
             setattr(o, a, getattr(o, a) + d)
         f.after_replay()
-        return self.result
+        return result
 
     def finish(self):
         self.fused.finish()

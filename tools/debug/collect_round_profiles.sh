@@ -27,6 +27,7 @@ if [ -f spatiotemporalentropymodel_amd/libstem_hip_exper.so ]; then
 fi
 python3 tools/debug/host_lag.py > $out/host_lag.log 2>&1
 python3 tools/host_overhead.py > $out/host_overhead.log 2>&1
+STEM_HOST_TAPE=0 python3 tools/host_overhead.py > $out/host_overhead_python_enqueue.log 2>&1
 # round 4: image-tile form of the general kernel, filter-row form of the weight gradient, event timeline of the default run
 bash tools/debug/prof_pmc.sh $tag/pmc_img_tpm4 tools/debug/f16x3_img_prof.py TPM.4 img > $out/pmc_img_tpm4.log 2>&1
 bash tools/debug/prof_pmc.sh $tag/pmc_img_tpm4_split5 tools/debug/f16x3_img_prof.py TPM.4 img 5 > $out/pmc_img_tpm4_split5.log 2>&1

@@ -31,7 +31,7 @@ generic = bool(os.environ.get("STEM_HOST_GENERIC"))
 if not generic:
     from spatiotemporalentropymodel_amd.trainer import FusedPFrameStep  # noqa: E402
     fused = FusedPFrameStep(stem, opt, aux_opt)
-    if os.environ.get("STEM_HOST_TAPE"):                 # the native executor (tape.TapedPFrameStep)
+    if os.environ.get("STEM_HOST_TAPE", "1") != "0":    # the native executor (tape.TapedPFrameStep), bench.py's default; 0: plain Python enqueue
         from spatiotemporalentropymodel_amd.tape import TapedPFrameStep
         fused = TapedPFrameStep(fused)
 npix = frames[0].shape[0] * frames[0].shape[2] * frames[0].shape[3]
