@@ -36,13 +36,10 @@ class StemRuntimeConfig:
     adam_block_max: bool = True          #: the optimiser pass leaves per-chunk parameter maxima for the fp16 weight packing
     # ---- schedule of the training step (none of these changes a result)
     engine_overlap: bool = True          #: weight gradients on a side stream
-    engine_wgrad_lanes: int = 1
     engine_split_pack: bool = True       #: input-gradient weight images packed on the side stream
-    engine_ctx_branch: bool = False      #: context model on a third forward stream (measured slower)
     engine_branch: bool = True           #: hyper path on its own stream
     engine_tpm_first: bool = True        #: temporal-prior chain enqueued ahead of the hyper branch (forward)
     engine_tpm_first_bwd: bool = True    #: ... in backward (the hyper chain waits for the EPM input gradient through an event)
-    engine_unpack_stream: bool = False   #: slab sums on a stream of their own (measured slower)
     engine_bias_multi: bool = True       #: one launch for a module group's bias-gradient second stages
     stream_prio: str = ""                #: "latents=0,side=-1,compute=-1" (trainer.tuned_schedule installs it)
     stream_cumask: str = ""              #: "latents=block:192"
@@ -65,9 +62,9 @@ _ENV = {
     "engine_strided_f16x3": "STEM_ENGINE_STRIDED_F16X3", "engine_ctx_f16x3": "STEM_ENGINE_CTX_F16X3",
     "engine_wgrad_f16x3": "STEM_ENGINE_WGRAD_F16X3", "engine_records": "STEM_ENGINE_RECORDS", "layers_f16x3": "STEM_LAYERS_F16X3",
     "layers_f16x3_maxpix": "STEM_LAYERS_F16X3_MAXPIX", "layers_wide_minpix": "STEM_LAYERS_WIDE_MINPIX",
-    "adam_block_max": "STEM_ADAM_BLOCK_MAX", "engine_overlap": "STEM_ENGINE_OVERLAP", "engine_wgrad_lanes": "STEM_ENGINE_WGRAD_LANES",
-    "engine_split_pack": "STEM_ENGINE_SPLIT_PACK", "engine_ctx_branch": "STEM_ENGINE_CTX_BRANCH", "engine_branch": "STEM_ENGINE_BRANCH", "engine_tpm_first": "STEM_ENGINE_TPM_FIRST", "engine_tpm_first_bwd": "STEM_ENGINE_TPM_FIRST_BWD",
-    "engine_unpack_stream": "STEM_ENGINE_UNPACK_STREAM", "engine_bias_multi": "STEM_ENGINE_BIAS_MULTI",
+    "adam_block_max": "STEM_ADAM_BLOCK_MAX", "engine_overlap": "STEM_ENGINE_OVERLAP",
+    "engine_split_pack": "STEM_ENGINE_SPLIT_PACK", "engine_branch": "STEM_ENGINE_BRANCH", "engine_tpm_first": "STEM_ENGINE_TPM_FIRST", "engine_tpm_first_bwd": "STEM_ENGINE_TPM_FIRST_BWD",
+    "engine_bias_multi": "STEM_ENGINE_BIAS_MULTI",
     "stream_prio": "STEM_STREAM_PRIO", "stream_cumask": "STEM_STREAM_CUMASK", "dp_min_bytes": "STEM_DP_MIN_BYTES",
     "dist_backend": "STEM_DIST_BACKEND", "dist_single": "STEM_DIST_SINGLE", "pin_ranks": "STEM_PIN_RANKS",
     "ar_persistent": "STEM_AR_PERSISTENT", "ar_pipeline": "STEM_AR_PIPELINE", "ar_stepwise": "STEM_AR_STEPWISE",

@@ -273,11 +273,6 @@ class StemEngine:
         self._dgrad_pack_event = None
         self._fwd32_pack_event = None
         self._events = {}
-        # the hyper path's weight gradients (HE, HD) queue on their own stream: the 13 weight-gradient launches of a step would
-        # otherwise run one after the other and finish ~0.3 ms after the last input-gradient kernel
-        if self.wgrad_lanes > 1:
-            for l in self.HE + self.HD:
-                l.lane = 1
         self._select_fx3()
 
     def _select_fx3(self):
@@ -328,17 +323,12 @@ class StemEngine:
     #: and overlap the latency-bound parts of the dgrad chain; set False to keep everything on the compute stream
     overlap_wgrad = _CFG.engine_overlap
 
-    #: number of weight-gradient streams; 2 puts the hyper path's weight gradients on a stream of their own (measured on the
-    #: bench step, same box: 22.65-22.94 ms against 22.67-22.82 ms with one -- no gain, the step is throughput-bound; default 1)
-    wgrad_lanes = _CFG.engine_wgrad_lanes
+    #: (a second weight-gradient stream for the hyper path, the slab sums on a stream of their own and the context model on a third
+    #: forward stream were switches until round 4: +0.8, +0.6 and +1.6 ms per bench step -- removed)
     #: the next forward's weight packing is split: forward-role copies on the compute stream (the forward waits for them), the
     #: input-gradient copies on a weight-gradient stream (only backward waits): 22.48-22.62 ms against 22.67-22.82 ms per bench
     #: step; STEM_ENGINE_SPLIT_PACK=0: one launch each as before
     split_pack = _CFG.engine_split_pack
-    #: the context model's convolution on a third forward stream (it depends on neither the TPM nor the hyper chain): measured
-    #: 24.3 ms against 22.7 ms per bench step -- three concurrent chains slow each other down more than the overlap gains;
-    #: off by default, kept as a switch
-    ctx_branch = _CFG.engine_ctx_branch
 
     def side_stream(self, device, lane=0):
         if not self.overlap_wgrad or device.type != "cuda":
@@ -430,11 +420,6 @@ class StemEngine:
     #: so a data-parallel reducer can start exchanging that slice while the rest of backward still runs
     grad_ready_hook = None
 
-    #: the slab sums (unpack_multi) and the bias gradients' second stages of a module group run on a stream of their own behind
-    #: the group's weight-gradient kernels: the weight-gradient stream is the longest serial chain of a P-frame step's backward
-    #: (13 launches + 13 bias finals + 5 slab sums, ~1.05 ms of 1.95 in a kernel trace), and these HBM-bound passes overlap the
-    #: next group's matrix kernels; STEM_ENGINE_UNPACK_STREAM=0: on the weight-gradient stream as before
-    unpack_stream = _CFG.engine_unpack_stream
     #: one launch for a group's bias-gradient second stages (stem_bias_grad_final_multi); STEM_ENGINE_BIAS_MULTI=0: one per layer
     defer_bias_final = _CFG.engine_bias_multi
 
@@ -444,14 +429,8 @@ class StemEngine:
         if side is None:
             return self._group_ready_on_stream(layers, extra_params)
         # extra_params (entropy-bottleneck gradients) were produced on the compute stream: order them before the hook
-        us = side
-        if self.unpack_stream:
-            us = self._side.get("unpack")
-            if us is None or us.device != dev:
-                us = self._side["unpack"] = F.make_stream(dev, "side")
-            F.stream_wait(us, side)
-        F.stream_wait(us, F.cur_stream(dev))
-        with F.on_stream(us):
+        F.stream_wait(side, F.cur_stream(dev))
+        with F.on_stream(side):
             self._group_ready_on_stream(layers, extra_params)
 
     def _group_ready_on_stream(self, layers, extra_params):
@@ -527,16 +506,7 @@ class StemEngine:
         main = F.cur_stream(dev) if bs is not None else None
         if bs is not None:
             F.stream_wait(bs, main)
-        # the context model's convolution needs only t_hat (the prologue's output): on a stream of its own, enqueued first so
-        # that it runs next to the hyper and TPM chains instead of after them
         pl = {}             # planes copies of activations, kept for the weight gradients
-        cs = self._branch(dev, 1) if (bs is not None and self.ctx_branch and fused and self.has_spm and self.has_tpm) else None
-        if cs is not None:
-            F.stream_wait(cs, main)
-            with F.on_stream(cs):
-                self._ctx_forward(t_hat, epm_in[:, o_ctx:o_ctx + P], pl)
-            t_hat.record_stream(cs)
-            epm_in.record_stream(cs)
         split = F.F16Planes.split
         tp0 = tp2 = None
 
@@ -590,10 +560,7 @@ class StemEngine:
             # gaussian_conditional.quantize(target, "noise" | "dequantize") with no means (:570-572, :853-855)
             if not fused:
                 t_hat = F.add(target, gc._noise_like(target)) if training else F.round_(target)
-            if cs is not None:
-                F.stream_wait(main, cs)
-            else:
-                self._ctx_forward(t_hat, epm_in[:, o_ctx:o_ctx + P], pl)
+            self._ctx_forward(t_hat, epm_in[:, o_ctx:o_ctx + P], pl)
         if bs is not None:
             F.stream_wait(main, bs)
         if self.EPM[0].fx3:

@@ -243,3 +243,60 @@ def test_taped_step_is_bit_identical_to_the_fused_schedule(monkeypatch, tuned):
         assert torch.equal(la[4], lb[4]) and torch.equal(la[5], lb[5]), t
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert a[3] == b[3], (a[3], b[3])
+
+
+# the switches of config.StemRuntimeConfig that stay supported next to the defaults (round 4: the others were deleted)
+_SCHEDULE_SWITCHES = [("overlap_wgrad", False), ("branch_streams", False), ("split_pack", False), ("defer_bias_final", False),
+                      ("tpm_first", False), ("tpm_first_bwd", False)]
+_ROUTE_SWITCHES = [("use_wg3", False), ("use_fx3s", False), ("use_ctx3", False), ("use_records", False), ("use_fx3", False)]
+
+
+def _two_steps(monkeypatch, switch):
+    """two P-frame steps of the fused schedule at 16x16 latents (the image-tile kernel and the filter-row weight gradient are the
+    forms that run there) with one engine switch away from its default -> (parameters, aux parameters, y_hat, losses, norms)"""
+    from spatiotemporalentropymodel_amd import engine as E
+    from spatiotemporalentropymodel_amd import trainer
+    dev = torch.device("cuda:0")
+    if switch is not None:
+        monkeypatch.setattr(E.StemEngine, switch[0], switch[1])
+    g = torch.Generator(device=dev).manual_seed(9)
+    frames = [torch.rand(2, 3, 256, 256, device=dev, generator=g) for _ in range(3)]
+    imodel, stem, opt, aux = _pair(64, 96, 64, 96, False, False)
+    fused = trainer.FusedPFrameStep(stem, opt, aux)
+    with torch.no_grad():
+        ys = [imodel.getY(f) for f in frames]
+    y_cond, losses, norms = ys[0][1], [], []
+    for t in (1, 2):
+        out, oc, aux_l, gn = fused.step(ys[t][0], y_cond, 2 * 256 * 256)
+        losses.append(float(oc["loss"]))
+        norms.append(float(gn))
+        y_cond = out["y_hat"]
+    fused.finish()
+    torch.cuda.synchronize()
+    if switch is not None:
+        monkeypatch.undo()
+    return opt.flat.data.clone(), aux.flat.data.clone(), y_cond.clone(), losses, norms
+
+
+def test_schedule_switches_change_no_bit(monkeypatch):
+    """every scheduling switch that is still supported (weight gradients on the compute stream, no hyper branch, one packing
+    launch per role, bias second stages per layer, hyper branch enqueued first) gives the default's bits"""
+    ref = _two_steps(monkeypatch, None)
+    for sw in _SCHEDULE_SWITCHES:
+        got = _two_steps(monkeypatch, sw)
+        assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]) and torch.equal(ref[2], got[2]), sw
+        assert ref[3] == got[3] and ref[4] == got[4], (sw, ref[3:], got[3:])
+
+
+@pytest.mark.parametrize("switch", _ROUTE_SWITCHES, ids=[s[0] for s in _ROUTE_SWITCHES])
+def test_route_switches_stay_within_the_gates(monkeypatch, switch):
+    """each arithmetic route that is still selectable (fp32-MFMA weight gradients / strided faces / context convolution, maxima
+    measured instead of recorded, all STEM layers on fp32 MFMA) against the default fp16 route: losses to 1e-5, gradient norms to
+    1e-3 (single flipped leaky-ReLU decisions move individual gradients, tests/test_hip_f16x3.py; the norm absorbs them)"""
+    ref = _two_steps(monkeypatch, None)
+    got = _two_steps(monkeypatch, switch)
+    for a, b in zip(ref[3], got[3]):
+        assert abs(a - b) <= 1e-5 * abs(a), (switch, ref[3], got[3])
+    for a, b in zip(ref[4], got[4]):
+        assert abs(a - b) <= 1e-3 * abs(a), (switch, ref[4], got[4])
+    assert float((ref[2] - got[2]).abs().max()) <= 1e-4 * float(ref[2].abs().max())

@@ -575,8 +575,8 @@ def test_runtime_config_is_the_one_reader_of_the_stem_switches(monkeypatch):
     with pytest.raises(AttributeError):
         with config.override(no_such_field=1):
             pass
-    assert config.from_env({"STEM_PIN_RANKS": "0", "STEM_ENGINE_WGRAD_LANES": "2"}).pin_ranks is False
-    assert config.from_env({"STEM_ENGINE_WGRAD_LANES": "2"}).engine_wgrad_lanes == 2
+    assert config.from_env({"STEM_PIN_RANKS": "0", "STEM_DP_MIN_BYTES": "2"}).pin_ranks is False
+    assert config.from_env({"STEM_DP_MIN_BYTES": "2"}).dp_min_bytes == 2
     pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "spatiotemporalentropymodel_amd")
     for root, _, files in os.walk(pkg):
         for fn in files:
