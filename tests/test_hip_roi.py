@@ -116,7 +116,6 @@ def _check_grads(g, tag, module, rtol=1e-4):
     """Raw (unclipped) gradients of every parameter: checksums and 64-element strided slices at 1e-4 of the
     tensor's own scale (north_star tolerance)."""
     seen = 0
-    flips = []
     for n, p in module.named_parameters():
         key = f"{tag}:gsum:{n}"
         if key not in g:
@@ -132,20 +131,7 @@ def _check_grads(g, tag, module, rtol=1e-4):
         sl = host(p.grad.reshape(-1)[:: max(1, p.numel() // 64)][:64])
         rms = float(np.sqrt(ref[2] / p.numel()))              # whole-tensor RMS: the slice's own max underestimates the scale
         rs = g[f"{tag}:gslice:{n}"]
-        try:
-            assert_close(sl, rs, rtol, atol=rtol * rms, what=f"{tag} grad slice {n}", floor=0.1)
-        except AssertionError:
-            # ONE flipped leaky-ReLU decision (a pre-activation of +-4e-8 next to values of order 1: which side it falls on
-            # depends on the summation order of the kernel plan, in the reference's run as much as in ours) moves the bias
-            # gradient and the filter gradient of one channel by that pixel's contribution -- tools/debug/roi_tile_diff.py shows
-            # exactly this between the 64- and 128-pixel plans of the general kernel (1 of 524288 outputs flipped, every other
-            # difference <= 2e-6).  Signature accepted here: the three whole-tensor checksums above hold at 1e-4, a single slice
-            # element misses, by less than 1e-3 of the slice's maximum; at most two tensors per model.
-            err = np.abs(sl.astype(np.float64) - rs)
-            tol = rtol * rms + rtol * np.maximum(np.abs(rs), 0.1 * np.abs(rs).max())
-            bad = err > tol
-            flips.append(n)
-            assert bad.sum() == 1 and err.max() <= 1e-3 * np.abs(rs).max() and len(flips) <= 2, (n, int(bad.sum()), float(err.max()), flips)
+        assert_close(sl, rs, rtol, atol=rtol * rms, what=f"{tag} grad slice {n}", floor=0.1)
         seen += 1
     return seen
 
@@ -351,10 +337,32 @@ def test_roi_batch_and_nonsquare_consistency():
         assert n == out["x_hat"].shape[0]
         return {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}, xr.grad.detach().clone()
 
+    # post-activation outputs of the quality-map branch's convolutions in the three passes: a pre-activation within fp32 noise of 0
+    # may land on the other side of a leaky-ReLU kink when the batch size changes the tile / split-K plan; its factor (1 vs slope)
+    # then shifts the gradients of that layer and of every layer BELOW it in the chain.  Such a flip is not assumed but shown:
+    from spatiotemporalentropymodel_amd.layers import Conv2d, ConvTranspose2d
+    chain = [(n, mod) for n, mod in m.named_modules() if n.startswith("qmap_feature_ga") and isinstance(mod, (Conv2d, ConvTranspose2d))]
+    acts = {n: [] for n, _ in chain}
+    hooks = [mod.register_forward_hook(lambda mod, inp, out, n=n: acts[n].append((out[0] if isinstance(out, tuple) else out).detach().float()))
+             for n, mod in chain]
     g01, gx01 = grads(slice(0, 2))
     g0, gx0 = grads(slice(0, 1))
     g1, gx1 = grads(slice(1, 2))
+    for h in hooks:
+        h.remove()
     assert len(g01) > 250
+    flips = {}                                # chain position -> number of flipped elements
+    for pos, (n, _) in enumerate(chain):
+        both_out, singles = acts[n][0], acts[n][1:]
+        assert len(acts[n]) == 3
+        for b, one in enumerate(singles):
+            a = both_out[b:b + 1]
+            mism = (a > 0) != (one > 0)
+            if bool(mism.any()):
+                near = torch.maximum(a.abs(), one.abs())[mism].max()
+                # a genuine kink crossing: both values sit within fp32 accumulation noise of zero
+                assert float(near) <= 1e-5 * float(one.abs().max()), (n, float(near), float(one.abs().max()))
+                flips[pos] = flips.get(pos, 0) + int(mism.sum())
     loose = []
     for k in g01:
         ref = 0.5 * (g0[k] + g1[k])
@@ -362,11 +370,12 @@ def test_roi_batch_and_nonsquare_consistency():
         err = float((g01[k] - ref).abs().max())
         if err > 2e-5 * scale + 1e-12:
             loose.append((k, err / scale))
-    # A pre-activation within fp32 noise of 0 may land on the other side of a leaky-ReLU kink when the batch size changes
-    # the tile / split-K configuration (measured: 1 element of 2.6 M in qmap_feature_ga1.2); that element's factor
-    # (1 vs slope) then shifts the gradients of the layers below it by up to ~1e-3 of their (cancelling) sums.
-    # (a flip in layer L of the quality-map branch touches weight and bias of L and of every layer below it: up to 2 x 7 tensors)
-    assert len(loose) <= 14 and all(e < 3e-3 for _, e in loose), loose
+    if loose:
+        # every tensor beyond the strict gate belongs to a layer at or below a SHOWN flip, and stays small
+        assert flips and sum(flips.values()) <= 4, (flips, loose)
+        top = max(flips)
+        allowed = {f"{n}.{w}" for n, _ in chain[:top + 1] for w in ("weight", "bias")}
+        assert all(k in allowed for k, _ in loose) and all(e < 3e-3 for _, e in loose), (flips, [n for n, _ in chain[:top + 1]], loose)
     assert_close(host(gx01[0:1]), host(0.5 * gx0), 1e-4, what="dL/dx_conditioned, sample 0", floor=0.1)
     assert_close(host(gx01[1:2]), host(0.5 * gx1), 1e-4, what="dL/dx_conditioned, sample 1", floor=0.1)
 
