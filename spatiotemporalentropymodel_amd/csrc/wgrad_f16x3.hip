@@ -443,11 +443,13 @@ __global__ __launch_bounds__(RNT, 2) void wgrad_f16x3_row_kernel(const Wg3Args a
 // the filter-row form applies: 3 x 3 / 5 x 5 window with 'same' padding, output rows in whole 16-pixel chunks.  In the bench step
 // (same box, ms per step): per-tap form everywhere 14.33-14.36, 5 x 5 layers here 14.08-14.13, 3 x 3 layers too 13.96-14.07
 // (isolated the 3 x 3 layers are equal, 31.7 against 31.5 us: fewer, longer workgroups next to the step's other streams).
-// stem_tuning_set("wg3_row", 1): per-tap form everywhere; 3: 5 x 5 only.
+// 1 x 1 layers take the same kernel with S = 1 (no tap reuse, but the four-stage operand ring instead of a one-chunk look-ahead):
+// EPM.2 / EPM.4 25.1 / 21.8 -> 20.9 / 16.0 us alone at equal splits (bit-identical sums), EPM.0 equal.
+// stem_tuning_set("wg3_row", 1): per-tap form everywhere; 3: 5 x 5 only; 6: not the 1 x 1 layers.
 bool row_form(int OH, int OW, int H, int W, int R, int S, int pad)
 {
     const int sel = stem_tuning(STEM_TUNE_WG3_ROW);
-    return sel != 1 && R == S && (R == 5 || (R == 3 && sel != 3)) && pad == R / 2 && OH == H && OW == W && OW % PX == 0;
+    return sel != 1 && R == S && (R == 5 || (R == 3 && sel != 3) || (R == 1 && sel != 3 && sel != 6)) && pad == R / 2 && OH == H && OW == W && OW % PX == 0;
 }
 
 int plan_splits(int B, int OH, int OW, int C, int K, int T, bool rows = false, int R = 0)
@@ -456,7 +458,7 @@ int plan_splits(int B, int OH, int OW, int C, int K, int T, bool rows = false, i
     if (rows) {       // workgroups = tiles x filter rows x splits: at most 512 (two per CU), at least R_MINCHUNKS pixel chunks each
         const int nchunks = B * OH * OW / PX, wgs = cdiv(K, RT_K) * cdiv(C, RT_C) * R;
         int s = forced > 0 ? forced : 512 / wgs;
-        const int minch = stem_tuning(STEM_TUNE_WG3_MINCH) > 0 ? stem_tuning(STEM_TUNE_WG3_MINCH) : R_MINCHUNKS;      // stem_tuning_set("wg3_minch", n): sweeps
+        const int minch = stem_tuning(STEM_TUNE_WG3_MINCH) > 0 ? stem_tuning(STEM_TUNE_WG3_MINCH) : (R == 1 ? R_MINCHUNKS / 2 : R_MINCHUNKS);   // one tap: small slabs      // stem_tuning_set("wg3_minch", n): sweeps
         if (forced <= 0 && s > nchunks / minch) s = nchunks / minch;
         if (s > nchunks) s = nchunks;
         if (s < 1) s = 1;
@@ -516,10 +518,13 @@ STEM_EXPORT int stem_conv2d_wgrad_f16x3(const void *xp, const float *xq, int xpi
         if (!attr_rows) {
             (void)hipFuncSetAttribute((const void *)wgrad_f16x3_row_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
             (void)hipFuncSetAttribute((const void *)wgrad_f16x3_row_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
+            (void)hipFuncSetAttribute((const void *)wgrad_f16x3_row_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS);
             attr_rows = true;
         }
         const dim3 grid(cdiv(cdiv(K, RT_K) * cdiv(C, RT_C) * R * splits, 8) * 8);
-        if (R == 3)
+        if (R == 1)
+            hipLaunchKernelGGL(wgrad_f16x3_row_kernel<1>, grid, dim3(RNT), R_LDS, (hipStream_t)stream, a);
+        else if (R == 3)
             hipLaunchKernelGGL(wgrad_f16x3_row_kernel<3>, grid, dim3(RNT), R_LDS, (hipStream_t)stream, a);
         else
             hipLaunchKernelGGL(wgrad_f16x3_row_kernel<5>, grid, dim3(RNT), R_LDS, (hipStream_t)stream, a);

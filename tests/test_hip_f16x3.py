@@ -500,7 +500,7 @@ def _weight_gradient_vs_oracle(F, case, split):
     assert_close(host(db), 2 * db_ref, what="bias gradient, accumulated", floor=0.1)
 
 
-@pytest.mark.parametrize("case", [c for c in WG_CASES if c[3] % 16 == 0 and c[5] > 1])
+@pytest.mark.parametrize("case", [c for c in WG_CASES if c[3] % 16 == 0])
 def test_weight_gradient_filter_row_form_vs_per_tap_form(F, case):
     """the two forms of csrc/wgrad_f16x3.hip on the geometries the filter-row form takes: each against the oracle (above, the
     row form by default) and against each other -- same products, sums over pixels in a different order"""
