@@ -287,7 +287,7 @@ __global__ __launch_bounds__(RNT, 2) void wgrad_f16x3_row_kernel(const Wg3Args a
     const rsrc4 rx = {(int)(unsigned)xa, (int)(unsigned)(xa >> 32), a.xbytes, 0x00020000};
     const rsrc4 rdy = {(int)(unsigned)da, (int)(unsigned)(da >> 32), a.dybytes, 0x00020000};
     auto dma16 = [](const rsrc4 r, unsigned lds_base, int voff) {        // lane l: 16 bytes at voff -> LDS lds_base + 16 l
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(r) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(r) : "memory");      // M0 is reserved (not allocatable, not declarable as a clobber); this kernel has no other user of it
     };
     const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char *)smem;
     const int drow = 4 * wave + (lane >> 4);
