@@ -303,6 +303,12 @@ int stem_gc_forward_train(const float *y, const float *scales, const float *mean
                           uint64_t seed, uint64_t offset, const long long *epoch_dev, uint64_t epoch_stride, float *out,
                           float *lik, float *dlik, double *partials, size_t npix, int C, float scale_bound, float lik_bound,
                           float coef, void *stream);
+/* the same with the backward of stem_gc_backward folded in (EMLoss: d loss / d likelihood = coef / lik is known in the forward,
+ * utils.py:18-27): dscales / dmeans [npix][lddsm] and, optionally, their scale record q -- one launch less per P-frame step */
+int stem_gc_forward_backward_train(const float *y, const float *scales, const float *means, int ldsm, const float *noise,
+                                   uint64_t seed, uint64_t offset, const long long *epoch_dev, uint64_t epoch_stride, float *out,
+                                   float *lik, float *dlik, double *partials, size_t npix, int C, float scale_bound,
+                                   float lik_bound, float coef, float *dscales, float *dmeans, int lddsm, float *q, void *stream);
 int stem_em_loss_finalize(const double *partials_y, int ny, const double *partials_z, int nz, double scale, double *out3,
                           void *stream);
 int stem_eb_aux_loss_grad(const float *quantiles, const float *pack, const float *target3, float *loss, float *dquantiles,

@@ -77,6 +77,7 @@ _HIP_SIG = {
     "stem_rate_partials": [sz],
     "stem_eb_forward_train": [vp, ci, vp, vp, u64, u64, vp, u64, vp, vp, vp, vp, sz, ci, cf, cf, vp],
     "stem_gc_forward_train": [vp, vp, vp, ci, vp, u64, u64, vp, u64, vp, vp, vp, vp, sz, ci, cf, cf, cf, vp],
+    "stem_gc_forward_backward_train": [vp, vp, vp, ci, vp, u64, u64, vp, u64, vp, vp, vp, vp, sz, ci, cf, cf, cf, vp, vp, ci, vp, vp],
     "stem_em_loss_finalize": [vp, ci, vp, ci, C.c_double, vp, vp],
     "stem_eb_aux_loss_grad": [vp, vp, vp, vp, vp, ci, ci, vp],
     "stem_build_indexes": [vp, ci, vp, ci, vp, sz, ci, cf, vp],

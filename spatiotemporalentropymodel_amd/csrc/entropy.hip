@@ -788,12 +788,16 @@ __global__ __launch_bounds__(256) void eb_forward_train_cm_kernel(const float *z
 }
 
 // GaussianConditional.forward in training mode (+noise; means are ignored by the noise quantiser, entropy_models.py:128-135)
+// dsc / dmu (optional, both or none): the backward of the same element in the same pass -- gc_backward_kernel's expressions on the
+// values this thread already holds (d loss / d likelihood is known here: coef / lik) -- and the scale record q of (dscales | dmeans)
 __global__ __launch_bounds__(256) void gc_forward_train_kernel(const float *y, NoiseSrc nl, const float *scales, const float *means,
                                                                int ldsm, float *out, float *lik, float *dlik, double *part,
-                                                               size_t npix, int C, float sb, float lb, float coef)
+                                                               size_t npix, int C, float sb, float lb, float coef, float *dsc, float *dmu,
+                                                               int ldd, float *q)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     double lg = 0.0;
+    float gm = 0.f;
     if (i < npix * C) {
         const size_t pix = i / C;
         const int c = (int)(i - pix * C);
@@ -813,8 +817,25 @@ __global__ __launch_bounds__(256) void gc_forward_train_kernel(const float *y, N
         lik[i] = l;
         dlik[i] = coef / l;
         lg = (double)log2f(l);
+        if (dsc) {
+            const float d = o - mu;
+            const float a = (0.5f - v) / s, b = (-0.5f - v) / s;
+            const float lraw = std_cum(a) - std_cum(b);
+            float g = coef / l;
+            if (!(lraw >= lb || g < 0.f)) g = 0.f;
+            const float k = 0.39894228040143267794f;
+            const float pa = k * expf(-0.5f * a * a), pb = k * expf(-0.5f * b * b);
+            const float dv = g * (-(pa - pb) / s);
+            float ds = g * (-(pa * a - pb * b) / s);
+            const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            if (!(sc >= sb || ds < 0.f)) ds = 0.f;
+            dsc[pix * ldd + c] = ds;
+            dmu[pix * ldd + c] = -dv * sgn;
+            gm = fmaxf(fabsf(ds), fabsf(dv));
+        }
     }
     block_log2_partial(lg, part);
+    if (q) record_block_max(q, gm);
 }
 
 // out[0] = y_bpp, out[1] = z_bpp, out[2] = loss   (EMLoss, utils.py:18-27): sums of the per-block partials in index order
@@ -925,8 +946,22 @@ STEM_EXPORT int stem_gc_forward_train(const float *y, const float *scales, const
     if (npix == 0) return 0;
     hipLaunchKernelGGL(gc_forward_train_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, y,
                        make_noise(noise, seed, offset, epoch_dev, epoch_stride), scales, means, ldsm, out, lik, dlik, partials, npix, C,
-                       scale_bound, lik_bound, coef);
+                       scale_bound, lik_bound, coef, nullptr, nullptr, 0, nullptr);
     STEM_LAUNCH_CHECK("gc_forward_train");
+    return 0;
+}
+
+STEM_EXPORT int stem_gc_forward_backward_train(const float *y, const float *scales, const float *means, int ldsm, const float *noise,
+                                               uint64_t seed, uint64_t offset, const long long *epoch_dev, uint64_t epoch_stride, float *out,
+                                               float *lik, float *dlik, double *partials, size_t npix, int C, float scale_bound,
+                                               float lik_bound, float coef, float *dscales, float *dmeans, int lddsm, float *q, void *stream)
+{
+    STEM_CHECK_ARG(y && scales && means && out && lik && dlik && partials && dscales && dmeans, "stem_gc_forward_backward_train: null pointer");
+    if (npix == 0) return 0;
+    hipLaunchKernelGGL(gc_forward_train_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, y,
+                       make_noise(noise, seed, offset, epoch_dev, epoch_stride), scales, means, ldsm, out, lik, dlik, partials, npix, C,
+                       scale_bound, lik_bound, coef, dscales, dmeans, lddsm, q);
+    STEM_LAUNCH_CHECK("gc_forward_backward_train");
     return 0;
 }
 

@@ -345,6 +345,8 @@ class StemEngine:
     #: the temporal-prior chain is enqueued before the hyper branch (scheduling only)
     tpm_first = _CFG.engine_tpm_first
     tpm_first_bwd = _CFG.engine_tpm_first_bwd
+    #: the GaussianConditional's backward computed by the fused forward glue (one launch less per P-frame step)
+    fuse_gc_backward = _CFG.engine_fuse_gc_backward
 
     def _branch(self, device, which=0):
         if not self.branch_streams or device.type != "cuda":
@@ -574,8 +576,17 @@ class StemEngine:
             gp = self.EPM[2].fwd(e2)                               # [B, 2*Cin, H, W] = scales | means
         scales, means = gp[:, :Cin], gp[:, Cin:]
         if fused:
-            gc_out, lik_y, k["dlik_y"], part_y = F.gc_forward_train(target, scales, means, rate_coef[0], scale_bound=gc._scale_bound,
-                                                                    lik_bound=gc._lik_bound, **gc._noise_slot(target))
+            # the GaussianConditional's backward in the same launch (d loss / d likelihood = coef / lik is known here): backward()
+            # uses it when it is handed this very dlik_y
+            if self.fuse_gc_backward:
+                dgp = F.empty_nhwc(B, 2 * Cin, H, W, dev)
+                gc_out, lik_y, k["dlik_y"], part_y, k["qg"] = F.gc_forward_train(
+                    target, scales, means, rate_coef[0], scale_bound=gc._scale_bound, lik_bound=gc._lik_bound,
+                    backward=(dgp[:, :Cin], dgp[:, Cin:]), record=self.EPM[0].fx3 and self.use_records, **gc._noise_slot(target))
+                k["dgp"] = dgp
+            else:
+                gc_out, lik_y, k["dlik_y"], part_y = F.gc_forward_train(target, scales, means, rate_coef[0], scale_bound=gc._scale_bound,
+                                                                        lik_bound=gc._lik_bound, **gc._noise_slot(target))
             k["loss3"] = F.em_loss_finalize(part_y, part_z, rate_coef[1])
             if not self.has_spm:
                 y_hat = gc_out
@@ -603,9 +614,12 @@ class StemEngine:
         gp = k["gp"]
         B, _, H, W = gp.shape
         self._wait_dgrad_packs()
-        dgp = F.empty_nhwc(B, 2 * Cin, H, W, gp.device)
-        qg = F.gc_backward(k["gc_out"], gp[:, :Cin], gp[:, Cin:], dlik_y, dgp[:, :Cin], dgp[:, Cin:], dy=None,
-                           scale_bound=gc._scale_bound, lik_bound=gc._lik_bound, record=self.EPM[0].fx3 and self.use_records)
+        if k.get("dgp") is not None and dlik_y is k.get("dlik_y"):          # computed by the fused forward glue
+            dgp, qg = k["dgp"], k["qg"]
+        else:
+            dgp = F.empty_nhwc(B, 2 * Cin, H, W, gp.device)
+            qg = F.gc_backward(k["gc_out"], gp[:, :Cin], gp[:, Cin:], dlik_y, dgp[:, :Cin], dgp[:, Cin:], dy=None,
+                               scale_bound=gc._scale_bound, lik_bound=gc._lik_bound, record=self.EPM[0].fx3 and self.use_records)
         # EPM (1x1 chain)
         dprip = None
         pl = k.get("planes", {})

@@ -1211,8 +1211,11 @@ def eb_forward_train(z, pack, coef, noise=None, seed=0, offset=0, epoch=None, bo
     return z_hat, lik, dlik, part
 
 
-def gc_forward_train(y, scales, means, coef, noise=None, seed=0, offset=0, epoch=None, scale_bound=0.11, lik_bound=1e-9):
-    """-> (out, lik, dlik, partials): training-mode GaussianConditional forward (y + noise; dense y) + dlik + log2 partials"""
+def gc_forward_train(y, scales, means, coef, noise=None, seed=0, offset=0, epoch=None, scale_bound=0.11, lik_bound=1e-9, backward=None,
+                     record=False):
+    """-> (out, lik, dlik, partials): training-mode GaussianConditional forward (y + noise; dense y) + dlik + log2 partials.
+    backward=(dscales, dmeans): the gradients gc_backward would compute from dlik, in the same launch -> (..., partials, q) with q
+    their scale record (record=True) or None"""
     B, Cc, H, W = y.shape
     assert nhwc_ld(y) == Cc and nhwc_ld(scales) == nhwc_ld(means)
     out, lik, dlik = (empty_nhwc(B, Cc, H, W, y.device) for _ in range(3))
@@ -1220,6 +1223,15 @@ def gc_forward_train(y, scales, means, coef, noise=None, seed=0, offset=0, epoch
     if noise is not None:
         assert nhwc_ld(noise) == Cc
     nptr, sd, off, ep, stride = _noise_args(noise, seed, offset, epoch)
+    if backward is not None:
+        dsc, dmu = backward
+        assert nhwc_ld(dsc) == nhwc_ld(dmu)
+        q = qrec_for(B * H * W * Cc, y.device) if record else None
+        _chk(_lib.hip().stem_gc_forward_backward_train(y.data_ptr(), scales.data_ptr(), means.data_ptr(), nhwc_ld(scales), nptr, sd, off, ep,
+                                                       stride, out.data_ptr(), lik.data_ptr(), dlik.data_ptr(), part.data_ptr(), B * H * W, Cc,
+                                                       scale_bound, lik_bound, coef, dsc.data_ptr(), dmu.data_ptr(), nhwc_ld(dsc), _ptr(q),
+                                                       _stream()))
+        return out, lik, dlik, part, q
     _chk(_lib.hip().stem_gc_forward_train(y.data_ptr(), scales.data_ptr(), means.data_ptr(), nhwc_ld(scales), nptr, sd, off, ep, stride,
                                           out.data_ptr(), lik.data_ptr(), dlik.data_ptr(), part.data_ptr(), B * H * W, Cc, scale_bound,
                                           lik_bound, coef, _stream()))
