@@ -178,7 +178,7 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
     const int hb0 = (4 * wm + (lr >> 4)) * HP + xl;                   // halo pixel of tap (0, 0) for MFMA tile mi = 0; mi = 1: + 2 HP
     const int swB = (lr >> 2) & 3;
     const int rdB = 2 * IA_BUF + (wn * 64 + lr) * 64;
-    const int pkB0 = ((0 + lh) ^ swB) << 4, pkB1 = ((2 + lh) ^ swB) << 4;
+    const int pkB0 = ((0 + lh) ^ swB) << 4;                             // k-step 1: this address ^ 32
     f32x16 acc[2][2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
