@@ -19,6 +19,8 @@ def run(n=40, seed=0, verbose=True):
     worst = 0.0
     for it in range(n):
         B = int(rng.integers(1, 4)); H = int(rng.integers(3, 24)); W = int(rng.integers(3, 24))
+        if rng.random() < 0.3:          # rows of whole 16-pixel chunks: the filter-row weight gradient and full image tiles
+            W = int(rng.choice([16, 32]))
         C = 32 * int(rng.integers(1, 7)); K = 32 * int(rng.integers(1, 9)); R = int(rng.choice([1, 3, 5])); st = int(rng.choice([1, 1, 2]))
         pad = R // 2
         if (H + 2 * pad - R) // st + 1 < 1 or (W + 2 * pad - R) // st + 1 < 1:
