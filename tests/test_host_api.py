@@ -584,3 +584,77 @@ def test_runtime_config_is_the_one_reader_of_the_stem_switches(monkeypatch):
                 text = open(os.path.join(root, fn)).read()
                 reads = re.findall(r'environ(?:\.get\(|\[)\s*"(STEM_[A-Z0-9_]+)"', text)
                 assert not reads, (fn, reads)
+
+
+def test_launch_tape_trampolines_on_host():
+    """csrc/tape.hip re-issues recorded C calls through x86-64 SysV trampolines (integer-class arguments in registers / on the stack,
+    floats and doubles as SSE patterns).  No GPU needed for that part: the recorded functions here are ctypes callbacks -- 1, 6, 7
+    and 19 integer arguments with 0..6 SSE arguments in between, per-replay deltas, a patched pointer-sized argument, a failing call."""
+    import ctypes as C
+    import struct
+    from spatiotemporalentropymodel_amd import _lib
+    lib = _lib.hip()
+    seen = []
+
+    def make(nint, kinds):
+        """callback taking the argument classes of `kinds` (0 int64, 1 float, 2 double), logging what it received"""
+        ctys = [C.c_longlong if k == 0 else (C.c_float if k == 1 else C.c_double) for k in kinds]
+        proto = C.CFUNCTYPE(C.c_int, *ctys)
+
+        def body(*a):
+            seen.append(tuple(a))
+            return 0
+        cb = proto(body)
+        return cb, C.cast(cb, C.c_void_p).value
+
+    def add(tape, addr, kinds, vals, deltas=None):
+        n = len(kinds)
+        k = (C.c_ubyte * n)(*[1 if x else 0 for x in kinds])
+        iv = (C.c_longlong * n)(*[int(v) if kk == 0 else 0 for kk, v in zip(kinds, vals)])
+        fbits = []
+        for kk, v in zip(kinds, vals):
+            if kk == 1:
+                fbits.append(struct.unpack("<d", struct.pack("<fI", float(v), 0))[0])      # float bits in the low half of the register
+            elif kk == 2:
+                fbits.append(float(v))
+            else:
+                fbits.append(0.0)
+        fv = (C.c_double * n)(*fbits)
+        dl = (C.c_longlong * n)(*(deltas or [0] * n))
+        idx = lib.stem_tape_add_call(tape, addr, n, k, iv, fv, dl)
+        assert idx >= 0, lib.stem_last_error()
+        return idx
+
+    tape = lib.stem_tape_create()
+    keep = []
+    cases = [
+        ([0], [41]),
+        ([0, 0, 0, 0, 0, 0], [1, -2, 3, -4, 5, 1 << 40]),
+        ([0, 1, 0, 2, 0, 0, 0, 0, 0], [7, 1.5, 8, -2.25, 9, 10, 11, 12, 13]),                      # seven integers: one on the stack
+        ([0] * 10 + [2, 1, 1, 2, 1, 2] + [0] * 9, list(range(100, 110)) + [0.5, 1.25, -3.0, 4.75, 8.0, -0.125] + list(range(200, 209))),
+    ]
+    for kinds, vals in cases:
+        cb, addr = make(sum(1 for k in kinds if k == 0), kinds)
+        keep.append(cb)
+        add(tape, addr, kinds, vals)
+    # per-replay deltas and a patched argument
+    cb, addr = make(3, [0, 0, 0])
+    keep.append(cb)
+    e_dyn = add(tape, addr, [0, 0, 0], [1000, 5, 77], deltas=[0, 3, 0])
+    assert lib.stem_tape_length(tape) == 5
+    assert lib.stem_tape_set_iarg(tape, e_dyn, 2, 0x7F0000001234) == 0
+    assert lib.stem_tape_set_iarg(tape, e_dyn, 3, 1) != 0                                         # no such argument
+    assert lib.stem_tape_replay(tape, 0, 5, 4) == 0
+    assert seen[0] == (41,) and seen[1] == (1, -2, 3, -4, 5, 1 << 40)
+    assert seen[2] == (7, 1.5, 8, -2.25, 9, 10, 11, 12, 13)
+    assert seen[3] == tuple(list(range(100, 110)) + [0.5, 1.25, -3.0, 4.75, 8.0, -0.125] + list(range(200, 209)))
+    assert seen[4] == (1000, 5 + 4 * 3, 0x7F0000001234)
+    # a failing call stops the replay and reports its entry
+    proto = C.CFUNCTYPE(C.c_int, C.c_longlong)
+    bad = proto(lambda a: -7)
+    keep.append(bad)
+    e_bad = add(tape, C.cast(bad, C.c_void_p).value, [0], [1])
+    n_before = len(seen)
+    assert lib.stem_tape_replay(tape, 4, e_bad + 1, 1) == -(e_bad + 1)
+    assert len(seen) == n_before + 1 and seen[-1] == (1000, 8, 0x7F0000001234)
+    lib.stem_tape_destroy(tape)
