@@ -147,6 +147,10 @@ int stem_conv2d_dgrad(const float *dy, int lddy, const float *wp, float *dx, int
 #define STEM_WGRAD_SQUARE_G 2     /* flags: use x^2 instead of x (GDN gamma gradient) */
 #define STEM_WGRAD_TABLE_VALID 1   /* flags: `dwp` still holds the gather table of an earlier call with the same geometry */
 #define STEM_WGRAD_ACCUMULATE_DB 4 /* flags: db += column sums instead of db = (gradient accumulation over several backward passes) */
+#define STEM_WGRAD_DEFER_DB 8      /* flags: leave the bias gradient's per-part column sums behind the slabs (dwp + splits * R * S * K * C) and skip
+                                    * the second stage: the caller adds them into db later (stem_bias_grad_final / stem_bias_grad_final_multi
+                                    * with stem_wgrad_bias_parts parts) -- one launch per module group instead of one per layer */
+int stem_wgrad_bias_parts(const float *x, int ldx, const float *dy, int lddy, long npix_dy, int C, int K, int splits, int flags, int deconv);
 int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
                       int B, int H, int W, int C, int K, int R, int S, int stride, int pad,
                       int splits, int flags, void *stream);

@@ -36,6 +36,7 @@ _HIP_SIG = {
     "stem_deconv2d_fwd": [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, cf, vp, sz, vp],
     "stem_deconv2d_dgrad": [vp, ci, vp, vp, ci, vp, ci, cf, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],
     "stem_deconv2d_wgrad": [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
+    "stem_wgrad_bias_parts": [vp, ci, vp, ci, C.c_long, ci, ci, ci, ci, ci],
     "stem_gdn_fwd": [vp, ci, vp, vp, vp, ci, ci, ci, ci, ci, ci, cf, vp],
     "stem_conv2d_gdn_fwd": [vp, ci, vp, vp, vp, vp, vp, ci] + [ci] * 10 + [cf, vp],
     "stem_conv2d_fwd_c4_gdn": [vp, vp, vp, vp, vp, vp, ci] + [ci] * 9 + [cf, vp],

@@ -559,7 +559,8 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float *part, i
     }
 }
 
-int colsum(const float *dy, int ld, size_t npix, int K, float *scratch, float *db, int accumulate, hipStream_t st)
+// final = false: only the first stage (the caller sums the parts later: stem_bias_grad_final / _final_multi)
+int colsum(const float *dy, int ld, size_t npix, int K, float *scratch, float *db, int accumulate, hipStream_t st, bool final = true)
 {
     const int parts = colsum_parts(npix, K);
     const bool vec = (K % 4 == 0) && (ld % 4 == 0) && ((((uintptr_t)dy) & 15) == 0);
@@ -568,6 +569,7 @@ int colsum(const float *dy, int ld, size_t npix, int K, float *scratch, float *d
     else
         hipLaunchKernelGGL((colsum_partial_kernel<false>), dim3(cdiv(K, 64), parts), dim3(256), 0, st, dy, ld, npix, K, parts, scratch);
     STEM_LAUNCH_CHECK("colsum_partial");
+    if (!final) return 0;
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(K, 64)), dim3(1024), 0, st, scratch, K, parts, db, accumulate);
     STEM_LAUNCH_CHECK("colsum_final");
     return 0;
@@ -650,6 +652,15 @@ STEM_EXPORT int stem_wgrad_splits(int B, int Ho, int Wo, int C, int K, int R, in
     return splits;
 }
 
+// number of per-part column sums a STEM_WGRAD_DEFER_DB call leaves at dwp + splits * R * S * K * C (each K floats): the splits of the
+// weight-gradient kernel when it sums dy on its way (convolutions on the vector path), else the column-sum pass's own parts
+STEM_EXPORT int stem_wgrad_bias_parts(const float *x, int ldx, const float *dy, int lddy, long npix_dy, int C, int K, int splits, int flags,
+                                      int deconv)
+{
+    const bool fused_db = !deconv && splits <= CS_MAX_PARTS && wgrad_vec_ok(dy, lddy, K, x, ldx, C) && !(flags & STEM_WGRAD_SQUARE_G);
+    return fused_db ? splits : colsum_parts((size_t)npix_dy, K);
+}
+
 STEM_EXPORT int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int lddy, float *dwp, float *db,
                                   int B, int H, int W, int C, int K, int R, int S, int stride, int pad,
                                   int splits, int flags, void *stream)
@@ -663,12 +674,13 @@ STEM_EXPORT int stem_conv2d_wgrad(const float *x, int ldx, const float *dy, int 
     // The bias gradient is the column sum of dY, the operand the weight-gradient kernel stages on its loop grid: on the vector
     // path its tap-0 workgroups sum the rows they load (one partial per split) and only the tiny second stage is launched.
     const bool fused_db = db && splits <= CS_MAX_PARTS && wgrad_vec_ok(dy, lddy, K, x, ldx, C) && !(flags & STEM_WGRAD_SQUARE_G);
-    if (db && !fused_db && colsum(dy, lddy, (size_t)B * Ho * Wo, K, scratch, db, acc_db, st)) return -2;
+    const bool defer = (flags & STEM_WGRAD_DEFER_DB) != 0;      // the parts stay in the scratch behind the slabs: stem_wgrad_bias_parts of them
+    if (db && !fused_db && colsum(dy, lddy, (size_t)B * Ho * Wo, K, scratch, db, acc_db, st, !defer)) return -2;
     // P = dY on the output grid (K channels), G = x gathered at oy*stride - pad + r  ->  [t][K][C]
     int *ptab = reinterpret_cast<int *>(scratch + (size_t)CS_MAX_PARTS * K);
     if (int rc = run(dy, lddy, K, x, ldx, C, dwp, ptab, B, Ho, Wo, H, W, R, S, stride, pad, splits, flags, st, fused_db ? scratch : nullptr))
         return rc;
-    if (fused_db) {
+    if (fused_db && !defer) {
         hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(K, 64)), dim3(1024), 0, st, scratch, K, splits, db, acc_db);
         STEM_LAUNCH_CHECK("colsum_final");
     }
@@ -683,7 +695,8 @@ STEM_EXPORT int stem_deconv2d_wgrad(const float *x, int ldx, const float *dy, in
     STEM_CHECK_ARG(splits >= 1, "stem_deconv2d_wgrad: splits must be >= 1");
     const int Ho = (H - 1) * stride - 2 * pad + R + opad, Wo = (W - 1) * stride - 2 * pad + S + opad;
     hipStream_t st = (hipStream_t)stream;
-    if (db && colsum(dy, lddy, (size_t)B * Ho * Wo, K, dwp + (size_t)splits * R * S * K * C, db, (flags & STEM_WGRAD_ACCUMULATE_DB) ? 1 : 0, st))
+    if (db && colsum(dy, lddy, (size_t)B * Ho * Wo, K, dwp + (size_t)splits * R * S * K * C, db, (flags & STEM_WGRAD_ACCUMULATE_DB) ? 1 : 0, st,
+                     !(flags & STEM_WGRAD_DEFER_DB)))
         return -2;
     // P = x on the input grid (C channels), G = dY gathered at iy*stride - pad + r  ->  [t][C][K]
     int *ptab = reinterpret_cast<int *>(dwp + (size_t)splits * R * S * K * C + (size_t)CS_MAX_PARTS * K);

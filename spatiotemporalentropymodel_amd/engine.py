@@ -210,12 +210,14 @@ class _Layer:
             splits, elems = F.wgrad_plan(x.shape, self.K, self.R, self.R, self.stride, self.pad, deconv=deconv)
             self._slabs[key] = (torch.empty(elems, device=x.device, dtype=torch.float32), splits)
         dwp, splits = self._slabs[key]
+        defer = self.eng.defer_bias_final and gb is not None
         if deconv:
-            F.deconv2d_wgrad(x, dy, self.K, self.R, self.R, self.stride, self.pad, self.opad, db_out=gb, dwp=dwp, unpack=False,
-                             table_valid=not fresh, accumulate_db=True)
+            _, b = F.deconv2d_wgrad(x, dy, self.K, self.R, self.R, self.stride, self.pad, self.opad, db_out=gb, dwp=dwp, unpack=False,
+                                    table_valid=not fresh, accumulate_db=True, defer_bias=defer)
         else:
-            F.conv2d_wgrad(x, dy, self.K, self.R, self.R, self.stride, self.pad, db_out=gb, dwp=dwp, unpack=False,
-                           table_valid=not fresh, accumulate_db=True)
+            _, b = F.conv2d_wgrad(x, dy, self.K, self.R, self.R, self.stride, self.pad, db_out=gb, dwp=dwp, unpack=False,
+                                  table_valid=not fresh, accumulate_db=True, defer_bias=defer)
+        self.pending_bias = b if defer else None          # the second stage joins the module group's launch (_group_ready_on_stream)
         self.pending = (dwp, splits)
 
     def unpack_desc(self):

@@ -421,7 +421,7 @@ def wgrad_plan(x_shape, K, R, S, stride, pad, deconv=False):
 
 
 _WGRAD_WS = {}
-WGRAD_TABLE_VALID, WGRAD_ACCUMULATE_DB = 1, 4
+WGRAD_TABLE_VALID, WGRAD_ACCUMULATE_DB, WGRAD_DEFER_DB = 1, 4, 8
 UNPACK_DECONV, UNPACK_ACCUMULATE = 1, 2
 
 
@@ -436,8 +436,15 @@ def _wgrad_workspace(key, elems, device):
     return buf, False
 
 
+def _deferred_bias(lib, x, dy, dwp, db, K, Cc, R, S, splits, flags, acc, deconv):
+    """descriptor of the bias gradient's pending second stage after a WGRAD_DEFER_DB call (parts behind the slabs)"""
+    B, _, Ho, Wo = dy.shape
+    parts = int(lib.stem_wgrad_bias_parts(x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), B * Ho * Wo, Cc, K, splits, flags, int(deconv)))
+    return _lib.BiasFinalDesc(dwp.data_ptr() + 4 * splits * R * S * K * Cc, db.data_ptr(), K, parts, int(acc), 0)
+
+
 def conv2d_wgrad(x, dy, K, R, S, stride, pad, dw_out=None, db_out=None, need_db=True, dwp=None, unpack=True, table_valid=False,
-                 accumulate=False, accumulate_db=False):
+                 accumulate=False, accumulate_db=False, defer_bias=False):
     """-> (dW [K,C,R,S], db [K]) in the reference's layouts.  With unpack=False only the packed slabs in `dwp`
     are produced (the caller sums/transposes all layers at once with unpack_wgrads_multi).  accumulate=True adds into
     dw_out / db_out (gradient accumulation over several backward passes)."""
@@ -450,8 +457,13 @@ def conv2d_wgrad(x, dy, K, R, S, stride, pad, dw_out=None, db_out=None, need_db=
     db = (db_out if db_out is not None else torch.empty(K, device=x.device, dtype=torch.float32)) if need_db else None
     assert not accumulate_db or db_out is not None
     flags = (WGRAD_TABLE_VALID if table_valid else 0) | (WGRAD_ACCUMULATE_DB if (accumulate or accumulate_db) else 0)
+    defer_bias = defer_bias and db is not None and not unpack
+    if defer_bias:
+        flags |= WGRAD_DEFER_DB
     _chk(lib.stem_conv2d_wgrad(x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), dwp.data_ptr(), _ptr(db),
                                B, H, W, Cc, K, R, S, stride, pad, splits, flags, _stream()))
+    if defer_bias:          # -> (None, descriptor): the caller runs the second stage (bias_grad_final_multi)
+        return None, _deferred_bias(lib, x, dy, dwp, db, K, Cc, R, S, splits, flags, accumulate or accumulate_db, False)
     if not unpack:
         return None, db
     dw = dw_out if dw_out is not None else torch.empty((K, Cc, R, S), device=x.device, dtype=torch.float32)
@@ -483,7 +495,7 @@ def deconv2d_dgrad(dy, wp_dgrad, x_shape, K, R, S, stride, pad, opad, xact=None,
 
 
 def deconv2d_wgrad(x, dy, K, R, S, stride, pad, opad, dw_out=None, db_out=None, need_db=True, dwp=None, unpack=True, table_valid=False,
-                   accumulate=False, accumulate_db=False):
+                   accumulate=False, accumulate_db=False, defer_bias=False):
     """-> (dW [C,K,R,S], db [K]) in nn.ConvTranspose2d's layout."""
     B, Cc, H, W = x.shape
     lib = _lib.hip()
@@ -494,8 +506,13 @@ def deconv2d_wgrad(x, dy, K, R, S, stride, pad, opad, dw_out=None, db_out=None, 
     db = (db_out if db_out is not None else torch.empty(K, device=x.device, dtype=torch.float32)) if need_db else None
     assert not accumulate_db or db_out is not None
     flags = (WGRAD_TABLE_VALID if table_valid else 0) | (WGRAD_ACCUMULATE_DB if (accumulate or accumulate_db) else 0)
+    defer_bias = defer_bias and db is not None and not unpack
+    if defer_bias:
+        flags |= WGRAD_DEFER_DB
     _chk(lib.stem_deconv2d_wgrad(x.data_ptr(), nhwc_ld(x), dy.data_ptr(), nhwc_ld(dy), dwp.data_ptr(), _ptr(db),
                                  B, H, W, Cc, K, R, S, stride, pad, opad, splits, flags, _stream()))
+    if defer_bias:
+        return None, _deferred_bias(lib, x, dy, dwp, db, K, Cc, R, S, splits, flags, accumulate or accumulate_db, True)
     if not unpack:
         return None, db
     dw = dw_out if dw_out is not None else torch.empty((Cc, K, R, S), device=x.device, dtype=torch.float32)
