@@ -54,7 +54,14 @@ int stem_tape_add_wait(void *tape, void *waiting_stream, void *signalling_stream
 int stem_tape_add_event(void *tape, void *event, void *stream, int wait);
 int stem_tape_replay(void *tape, int lo, int hi, long long n);
 int stem_tape_set_iarg(void *tape, int entry, int arg, long long value);
+/* SSE-class argument `arg` of call `entry` <- the 64-bit register pattern (a double, or a float's bits in the low half): the
+ * hyper-parameters a scheduler edits between steps (stem/trainSTEM.py:123,290) */
+int stem_tape_set_farg(void *tape, int entry, int arg, double pattern);
+/* 1 if fn is an int-returning entry point of this library whose prototype passed the trampolines' compile-time contract check */
+int stem_tape_entry_recordable(void *fn);
 int stem_copy_d2d(void *dst, const void *src, size_t nbytes, void *stream);
+/* optimizer.zero_grad() (stem/trainSTEM.py:203) as a recordable library call */
+int stem_zero_bytes(void *dst, size_t nbytes, void *stream);
 int stem_tuning_set(const char *name, int value);
 int stem_tuning_get(const char *name);
 int stem_built_with_experiments(void);

@@ -145,6 +145,9 @@ _HIP_SIG = {
     "stem_tape_add_event": [vp, vp, vp, ci],
     "stem_tape_replay": [vp, ci, ci, C.c_longlong],
     "stem_tape_set_iarg": [vp, ci, ci, C.c_longlong],
+    "stem_tape_set_farg": [vp, ci, ci, C.c_double],
+    "stem_tape_entry_recordable": [vp],
+    "stem_zero_bytes": [vp, sz, vp],
     "stem_copy_d2d": [vp, vp, sz, vp],
     "stem_tuning_set": [C.c_char_p, ci],
     "stem_tuning_get": [C.c_char_p],

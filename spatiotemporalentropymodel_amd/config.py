@@ -10,7 +10,11 @@ or by setting the variable -- no module reads `os.environ` for these on its own 
     from spatiotemporalentropymodel_amd import config
     cfg = config.runtime()                       # defaults + environment overrides
     with config.override(engine_f16x3=False):    # e.g. the fp32-MFMA route for the training layers
-        ...
+        ...                                      # (build the model's engine INSIDE the block: routes are chosen per engine)
+
+`engine.StemEngine`'s switches (`use_fx3`, `overlap_wgrad`, ...) are descriptors that read these fields at look-up time, so an
+override block or a changed variable reaches them; assigning `StemEngine.<attr> = value` pins a switch regardless of the
+configuration.  Booleans parse "", "0", "false", "no", "off" as False (until round 4 an EMPTY `STEM_ENGINE_*=` counted as enabled).
 """
 from __future__ import annotations
 

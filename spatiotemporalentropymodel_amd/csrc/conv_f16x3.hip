@@ -918,10 +918,7 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
         __syncthreads();
         if (tid == 0) {
             int *c = a.cnt + blockIdx.y * gridDim.x + blockIdx.x;
-            const int ticket = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = ticket == a.nsplit - 1;
-            if (last) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tapi[0] = last;
+            tapi[0] = splitk_last_arriver(c, a.nsplit);
         }
         __syncthreads();
         if (!tapi[0]) return;

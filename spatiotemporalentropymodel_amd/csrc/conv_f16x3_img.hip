@@ -482,10 +482,7 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
         __syncthreads();
         if (tid == 0) {
             int *cn = a.cnt + blockIdx.y * gridDim.x + blockIdx.x;
-            const int ticket = __hip_atomic_fetch_add(cn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int lastw = ticket == a.nsplit - 1;
-            if (lastw) __hip_atomic_store(cn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            flag[0] = lastw;
+            flag[0] = splitk_last_arriver(cn, a.nsplit);
         }
         __syncthreads();
         IMG_STAMP(4);

@@ -488,10 +488,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void igemm_kernel(const
         int *flag = tapi;                     // LDS scratch, free after the main loop
         if (tid == 0) {
             int *c = a.cnt + ((size_t)zphase * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-            const int ticket = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = ticket == a.nsplit - 1;
-            if (last) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            flag[0] = last;
+            flag[0] = splitk_last_arriver(c, a.nsplit);
         }
         __syncthreads();
         if (!flag[0]) return;

@@ -137,6 +137,32 @@ __device__ inline void record_block_max(float *q, float m)
         }
     }
 }
+// Split-K arrival: ONE thread of a workgroup calls this after the workgroup's partial tile went to the workspace (agent-scope
+// 4-byte stores = sc1 write-through, every thread's s_waitcnt vmcnt(0), workgroup barrier); true for the workgroup that arrives
+// last, which then owns the tile (after another barrier it reads the nsplit partials with sc1 loads, which are served at the
+// device-coherent level, not from this XCD's L2) and has re-armed the counter for the next launch.
+//
+// Memory order of the ticket.  In the terms of the HIP memory model the protocol wants a RELEASE before and an ACQUIRE after the
+// ticket; -DSTEM_SPLITK_ORDER=__ATOMIC_ACQ_REL builds exactly that (`buffer_wbl2 sc1` + atomic + `buffer_inv sc1` by the one
+// thread).  Measured in the training step (round 5, profiles/r05_ab_splitk_order.log, alternating passes on one box):
+// 14.36 / 14.44 ms per bench step against 13.83 / 13.85 ms with the relaxed ticket -- +4 %: the write-back / invalidate act on the
+// XCD's whole L2, i.e. on the working sets of the kernels running next to this one.  The shipped form therefore stays RELAXED and
+// rests on what the ISA guarantees for the accesses involved rather than on a fence: an sc1 store is acknowledged (vmcnt) only
+// once it is visible at agent scope, so "all stores acknowledged -> barrier -> ticket" orders data before ticket; the reader's
+// loads are issued after a barrier that follows the ticket's return value (control dependence through LDS) and carry sc1, so they
+// cannot be served from a stale line of the local L2.  What guards it: tests/test_hip_fullsize.py::
+// test_first_launch_on_fresh_workspaces_is_reproducible (the case a wider store form failed in round 4) and the bit-reproducibility
+// tests of the training step.
+#ifndef STEM_SPLITK_ORDER
+#define STEM_SPLITK_ORDER __ATOMIC_RELAXED
+#endif
+__device__ inline bool splitk_last_arriver(int *counter, int nsplit)
+{
+    const int ticket = __hip_atomic_fetch_add(counter, 1, STEM_SPLITK_ORDER, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = ticket == nsplit - 1;
+    if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return last;
+}
 // the two fp16 numbers whose sum is x * s (s a power of two)
 __device__ inline void q_split(const float x, const float s, hp_t &h0, hp_t &h1)
 {

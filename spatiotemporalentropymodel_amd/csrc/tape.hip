@@ -15,7 +15,9 @@
 // order within their class, so calling f(a0, f0, a1) through the prototype (long long a0, long long a1, double f0) places every
 // argument where the callee looks for it (int arguments read the low half of their 8-byte slot; a float argument reads the low
 // 32 bits of its vector register, where the recorded pattern carries the float's bits).
+#include <algorithm>
 #include <array>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -70,7 +72,43 @@ constexpr auto make_callers(std::index_sequence<N...>) -> std::array<Caller, siz
 }
 const auto kCallers = make_callers(std::make_index_sequence<TAPE_MAXI + 1>{});
 
+// ---- the trampolines' contract, checked per entry point at COMPILE time -----------------------------------------------------------
+// call_seq() calls f(a0, f0, a1, ...) through int(long long..., double...): that lands every argument where the callee reads it
+// only if (1) each parameter is a scalar of the INTEGER class (integers, enums, pointers; <= 8 bytes) or of the SSE class (float,
+// double) -- no struct / union / long double / vector by value, whose classification interleaves the two files --, (2) at most
+// TAPE_MAXF <= 8 SSE arguments (all in xmm0-7: none on the stack, where they would interleave with the integer overflow), and
+// (3) at most TAPE_MAXI integer ones (the trampoline table's size).  tape_entries.inc (tools/gen_tape_table.py) lists every
+// int-returning declaration of include/stem_hip.h; a new entry point that breaks the contract fails the build here.
+static_assert(TAPE_MAXF <= 8, "SSE arguments beyond xmm7 go to the stack and would interleave with the integer overflow area");
+template <class T>
+constexpr bool tape_int_class = (std::is_integral<T>::value || std::is_enum<T>::value || std::is_pointer<T>::value) && sizeof(T) <= 8;
+template <class T>
+constexpr bool tape_sse_class = std::is_same<T, float>::value || std::is_same<T, double>::value;
+template <class... A>
+constexpr bool tape_recordable(int (*)(A...))
+{
+    constexpr int ni = (0 + ... + (tape_int_class<A> ? 1 : 0)), nf = (0 + ... + (tape_sse_class<A> ? 1 : 0));
+    return ni + nf == (int)sizeof...(A) && ni <= TAPE_MAXI && nf <= TAPE_MAXF;
+}
+#define STEM_TAPE_ENTRY(name) \
+    static_assert(tape_recordable(&name), #name ": prototype outside the launch tape's calling contract (csrc/tape.hip)");
+#include "tape_entries.inc"
+#undef STEM_TAPE_ENTRY
+
+#define STEM_TAPE_ENTRY(name) reinterpret_cast<const void *>(&name),
+const void *const kRecordable[] = {
+#include "tape_entries.inc"
+};
+#undef STEM_TAPE_ENTRY
+
 }   // namespace
+
+/* 1 if `fn` is the address of an int-returning entry point of this library whose prototype passed the compile-time check of the
+ * trampolines' calling contract (tape.LaunchTape.add_call refuses anything else), 0 otherwise */
+STEM_EXPORT int stem_tape_entry_recordable(void *fn)
+{
+    return std::find(std::begin(kRecordable), std::end(kRecordable), (const void *)fn) != std::end(kRecordable) ? 1 : 0;
+}
 
 STEM_EXPORT void *stem_tape_create(void) { return new Tape(); }
 
@@ -195,6 +233,30 @@ STEM_EXPORT int stem_tape_set_iarg(void *tape, int entry, int arg, long long val
     STEM_CHECK_ARG(t && entry >= 0 && entry < (int)t->e.size() && t->e[entry].kind == TAPE_CALL && arg >= 0 && arg < t->e[entry].ni,
                    "stem_tape_set_iarg: no integer argument %d in entry %d", arg, entry);
     t->e[entry].iv[arg] = value;
+    return 0;
+}
+
+/* overwrite SSE-class argument `arg` (position among the entry's float / double arguments) of call entry `entry` with the 64-bit
+ * pattern `pattern` (as in stem_tape_add_call): the optimiser hyper-parameters a scheduler edits between steps
+ * (stem/trainSTEM.py:123,290: ReduceLROnPlateau rewrites param_groups[0]["lr"]) */
+STEM_EXPORT int stem_tape_set_farg(void *tape, int entry, int arg, double pattern)
+{
+    Tape *t = static_cast<Tape *>(tape);
+    STEM_CHECK_ARG(t && entry >= 0 && entry < (int)t->e.size() && t->e[entry].kind == TAPE_CALL && arg >= 0 && arg < t->e[entry].nf,
+                   "stem_tape_set_farg: no float argument %d in entry %d", arg, entry);
+    t->e[entry].fv[arg] = pattern;
+    return 0;
+}
+
+/* clear `nbytes` of device memory on a stream (optimizer.zero_grad(), stem/trainSTEM.py:203, as a library call: recordable,
+ * unlike Tensor.zero_()) */
+STEM_EXPORT int stem_zero_bytes(void *dst, size_t nbytes, void *stream)
+{
+    STEM_CHECK_ARG(dst || !nbytes, "stem_zero_bytes: null pointer");
+    if (nbytes && hipMemsetAsync(dst, 0, nbytes, (hipStream_t)stream) != hipSuccess) {
+        stem_set_error("stem_zero_bytes: hipMemsetAsync failed");
+        return -2;
+    }
     return 0;
 }
 

@@ -20,8 +20,18 @@ from . import config as _config
 from . import functional as F
 from . import layers as _layers
 
-#: the switches below are fields of config.StemRuntimeConfig (read when the module is imported; `StemEngine.<attr>` can be set after that)
-_CFG = _config.runtime()
+class _Switch:
+    """A StemEngine switch backed by a field of config.StemRuntimeConfig, read when it is LOOKED UP: `config.override(...)` takes
+    effect at once, a changed `STEM_*` variable when the next engine is built (StemEngine.__init__ parses the environment again;
+    a look-up itself reads the parsed object -- 0.1 us instead of 15 -- because the schedule asks ~50 times per step).  The route
+    switches are looked up when an engine is built, the scheduling ones at every step.  A plain value assigned on the class or on
+    an instance (`StemEngine.use_fx3 = False`, tests' monkeypatch) wins."""
+
+    def __init__(self, field):
+        self.field = field
+
+    def __get__(self, obj, owner=None):
+        return getattr(_config._RUNTIME or _config.runtime(), self.field)
 
 
 class _Layer:
@@ -254,6 +264,7 @@ def _grad_of(p):
 
 class StemEngine:
     def __init__(self, model, has_tpm: bool, has_spm: bool, residual: bool):
+        _config.runtime()                   # parse the environment now if a STEM_* variable changed (the switches read the parsed object)
         self.m = model
         self.has_tpm, self.has_spm, self.residual = has_tpm, has_spm, residual
         L = lambda mod: _Layer(mod, "conv", self)
@@ -309,28 +320,28 @@ class StemEngine:
 
     #: forward and input-gradient of the stride-1 layers (TPM, HE.0, HD.4, EPM) on the fp16 matrix cores: three fp16 products per fp32 product on operands split into two scaled fp16 planes, ~2^-21 relative per product (tests: 1e-4 gates; measured 0.4-1.6e-6 of max per layer against fp64)
     #: (three fp16 MFMAs per fp32 product, csrc/conv_f16x3.hip); STEM_ENGINE_F16X3=0 keeps every layer on the fp32-MFMA kernels
-    use_fx3 = _CFG.engine_f16x3
+    use_fx3 = _Switch("engine_f16x3")
     #: the entropy glue (prologue, Gaussian backward) records the maxima of the fp32 tensors it writes, so that their fp16 splits
     #: skip the maximum pass (four launches per P-frame step); STEM_ENGINE_RECORDS=0: every split measures its input itself
-    use_records = _CFG.engine_records
+    use_records = _Switch("engine_records")
     #: the strided-convolution faces of the hyper path's stride-2 layers (HE.2 / HE.4 forward, HD.2 / HD.0 input gradient) on the
     #: general fp16 kernel; STEM_ENGINE_STRIDED_F16X3=0: igemm.hip
-    use_fx3s = _CFG.engine_strided_f16x3
+    use_fx3s = _Switch("engine_strided_f16x3")
     #: the masked context convolution's forward on the same kernel over its live taps; STEM_ENGINE_CTX_F16X3=0: igemm.hip
-    use_ctx3 = _CFG.engine_ctx_f16x3
+    use_ctx3 = _Switch("engine_ctx_f16x3")
     #: ... and their weight gradients (csrc/wgrad_f16x3.hip); STEM_ENGINE_WGRAD_F16X3=0 keeps those on wgrad.hip
-    use_wg3 = _CFG.engine_wgrad_f16x3
+    use_wg3 = _Switch("engine_wgrad_f16x3")
 
     #: weight gradients (wgrad + bias column sums + unpack + the data-parallel exchange hook) run on their own stream
     #: and overlap the latency-bound parts of the dgrad chain; set False to keep everything on the compute stream
-    overlap_wgrad = _CFG.engine_overlap
+    overlap_wgrad = _Switch("engine_overlap")
 
     #: (a second weight-gradient stream for the hyper path, the slab sums on a stream of their own and the context model on a third
     #: forward stream were switches until round 4: +0.8, +0.6 and +1.6 ms per bench step -- removed)
     #: the next forward's weight packing is split: forward-role copies on the compute stream (the forward waits for them), the
     #: input-gradient copies on a weight-gradient stream (only backward waits): 22.48-22.62 ms against 22.67-22.82 ms per bench
     #: step; STEM_ENGINE_SPLIT_PACK=0: one launch each as before
-    split_pack = _CFG.engine_split_pack
+    split_pack = _Switch("engine_split_pack")
 
     def side_stream(self, device, lane=0):
         if not self.overlap_wgrad or device.type != "cuda":
@@ -343,12 +354,12 @@ class StemEngine:
     #: the hyper path (HE -> bottleneck -> HD) and the temporal / spatial priors are independent until the entropy-parameter
     #: network joins them: the hyper path runs on its own stream in forward and backward so that the ramp-up / drain of its
     #: small launches overlaps the other branch's kernels (30.90 -> 30.75 ms per bench step; STEM_ENGINE_BRANCH=0 disables)
-    branch_streams = _CFG.engine_branch
+    branch_streams = _Switch("engine_branch")
     #: the temporal-prior chain is enqueued before the hyper branch (scheduling only)
-    tpm_first = _CFG.engine_tpm_first
-    tpm_first_bwd = _CFG.engine_tpm_first_bwd
+    tpm_first = _Switch("engine_tpm_first")
+    tpm_first_bwd = _Switch("engine_tpm_first_bwd")
     #: the GaussianConditional's backward computed by the fused forward glue (one launch less per P-frame step)
-    fuse_gc_backward = _CFG.engine_fuse_gc_backward
+    fuse_gc_backward = _Switch("engine_fuse_gc_backward")
 
     def _branch(self, device, which=0):
         if not self.branch_streams or device.type != "cuda":
@@ -425,7 +436,7 @@ class StemEngine:
     grad_ready_hook = None
 
     #: one launch for a group's bias-gradient second stages (stem_bias_grad_final_multi); STEM_ENGINE_BIAS_MULTI=0: one per layer
-    defer_bias_final = _CFG.engine_bias_multi
+    defer_bias_final = _Switch("engine_bias_multi")
 
     def _group_ready(self, layers, extra_params):
         dev = layers[0].mod.weight.device

@@ -107,10 +107,30 @@ def event_wait(stream, ev):
 
 def tape_py(fn):
     """call fn() now; under a recording also log it, so that a replay calls it at this point of the schedule, with the stream
-    that is current now (the data-parallel exchange: torch.distributed calls in the middle of backward)"""
+    that is current now (the data-parallel exchange: torch.distributed calls in the middle of backward).  Whatever torch ops fn
+    issues are fn's own business -- a replay re-runs them -- so the recording's foreign-op guard looks away meanwhile."""
+    if _TAPE is None:
+        return fn()
+    _TAPE.entries.append(("py", fn, cur_stream()))
+    _TAPE.in_py += 1
+    try:
+        return fn()
+    finally:
+        _TAPE.in_py -= 1
+
+
+def tape_bind_floats(provider):
+    """Under a recording: the launch just recorded takes its float arguments from `provider()` (a tuple, in the order of the
+    entry point's float / double parameters) on every replay -- values a caller may edit between steps (the optimiser's
+    param_groups: stem/trainSTEM.py:123,290).  No-op otherwise."""
     if _TAPE is not None:
-        _TAPE.entries.append(("py", fn, cur_stream()))
-    return fn()
+        _TAPE.bind_floats(provider)
+
+
+def zero_bytes(t):
+    """t.zero_() for a dense tensor as a library call on the current stream: recordable (tape.LaunchTape), unlike Tensor.zero_()"""
+    _chk(_lib.hip().stem_zero_bytes(t.data_ptr(), t.numel() * t.element_size(), _stream()))
+    return t
 
 
 def copy_d2d(dst, src):

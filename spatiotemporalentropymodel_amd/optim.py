@@ -38,7 +38,10 @@ class FlatParameters:
 
     def zero_grad(self):
         join_wgrad_stream()
-        self.grad.zero_()
+        if self.grad.is_cuda:
+            F.zero_bytes(self.grad)          # a library call: a launch tape records it (Tensor.zero_() would be dropped on replay)
+        else:
+            self.grad.zero_()
         for p in self.params:
             p.grad = p._flat_grad_view
 
@@ -142,6 +145,12 @@ class FusedClipAdam(torch.optim.Optimizer):
             F.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self._sumsq if use_clip else None,
                         float(self.max_norm) if use_clip else 0.0, float(grad_scale), float(g["lr"]), g["betas"][0], g["betas"][1],
                         float(g["eps"]), self.t, zero_grad=zero_grad)
+        if self._dev is None:
+            # a launch tape replays the call above: it must read these values again on every replay, not keep the recorded ones
+            # (whether there is clipping at all decides a pointer argument: that is part of the tape's key, tape.TapedPFrameStep)
+            gs = float(grad_scale)
+            F.tape_bind_floats(lambda: (float(self.max_norm) if use_clip else 0.0, gs, float(g["lr"]), float(g["betas"][0]),
+                                        float(g["betas"][1]), float(g["eps"])))
         bump_weight_epoch(self.flat.params)
         return loss
 

@@ -15,19 +15,45 @@ input buffers, `stem_tape_replay` per segment, advance the Python-side counters.
 schedule (tests/test_hip_trainer.py); stream priorities and CU masks stay in force because the launches go to the recorded
 streams (a hipGraph replay lost them).
 
-What a tape assumes, and checks where it can: the same shapes / reducer / grad_scale every step (anything else falls back to a
-fresh recording), no host-side data dependence inside the step (the fused schedule has none), learning rates unchanged (a float
-argument that differs between the two recordings is an error).
+What a tape assumes, and how each assumption is enforced:
+
+  * the same shapes / strides / reducer / grad_scale / current stream / clipping on-off every step: they form the replay key,
+    anything else starts a fresh recording;
+  * optimiser hyper-parameters may CHANGE between steps (stem/trainSTEM.py:123,290: ReduceLROnPlateau edits
+    param_groups[0]["lr"]): the optimiser binds its launch's float arguments to a provider (`functional.tape_bind_floats`),
+    every replay reads the provider and patches the recorded slots that moved (`stem_tape_set_farg`); any OTHER float argument
+    that differs between the two recordings is an error;
+  * every device operation of the step is a call into libstem_hip.so: a recording runs under `_ForeignOpGuard`, a
+    TorchDispatchMode that notes every torch operator touching device memory other than allocations and views (Tensor.zero_(),
+    copy_(), .contiguous() of a strided input, .item() ...) -- a replay would silently drop them.  Such a recording is refused
+    (TapeRefused) and the step stays on the ordinary schedule;
+  * no host-side data dependence inside the step (the fused schedule has none; .item() is caught by the guard);
+  * every recorded function is an entry point whose prototype passed the trampolines' compile-time contract check
+    (`stem_tape_entry_recordable`: csrc/tape.hip, tape_entries.inc).
 """
 from __future__ import annotations
 
 import ctypes as C
 import struct
+import warnings
 
 import torch
+from torch.utils._python_dispatch import TorchDispatchMode
 
 from . import _lib
 from . import functional as F
+
+
+class TapeRefused(RuntimeError):
+    """the schedule cannot be replayed faithfully (it is not static, or it contains device work a tape does not hold)"""
+
+
+def _pattern(ty, value):
+    """the 64-bit pattern an SSE register receives for an argument of ctypes type `ty`"""
+    if ty is C.c_float:             # the callee reads the low 32 bits
+        return struct.unpack("<d", struct.pack("<fI", float(value), 0))[0]
+    return float(value)
+
 
 class LaunchTape:
     """One recorded schedule.  Use through `recording()`; `finalize(other)` compares with a second recording and builds the
@@ -36,20 +62,31 @@ class LaunchTape:
     def __init__(self):
         self.entries = []           # ("call", name, addr, kinds, ivals, fvals, keep) | ("wait", dst, src) | ("evrec", ev, st) | ("evwait", st, ev) | ("py", fn, stream)
         self.keep = []              # tensors / ctypes arrays the recorded addresses point into
+        self.in_py = 0              # > 0 while a tape_py callable runs (its torch ops are replayed with it)
+        self.foreign = []           # torch operators on device memory seen by the recording's guard (a replay would drop them)
+        self.problems = []          # calls that could not be recorded
+        self.float_bindings = {}    # entry index -> provider() of that call's float arguments (functional.tape_bind_floats)
+        self._bound_now = {}        # entry index -> the patterns the native tape holds now
         self._native = None
         self._segments = None
 
     # ---- recording ---------------------------------------------------------------------------------------------------------------
     def add_call(self, name, fn, args):
         sig = _lib._HIP_SIG[name]
+        addr = C.cast(fn, C.c_void_p).value
+        # the call itself has already run (the step goes on whatever happens here): what cannot be recorded is noted and makes
+        # finalize() refuse the tape
+        if not _lib.hip().stem_tape_entry_recordable(addr):
+            self.problems.append(f"{name} is not in the library's table of recordable entry points (csrc/tape_entries.inc)")
+            return
+        if len(args) != len(sig):
+            self.problems.append(f"{name}: {len(args)} arguments for a prototype of {len(sig)}")
+            return
         kinds, ivals, fvals, keep = [], [], [], []
         isptr = [ty is C.c_void_p for ty in sig]            # by declared type: addresses never count as step counters
         for a, ty in zip(args, sig):
-            if ty is C.c_float:             # the vector register receives the float's bits in its low half
-                kinds.append(1); ivals.append(0); fvals.append(struct.unpack("<d", struct.pack("<fI", float(a), 0))[0])
-                continue
-            if ty is C.c_double:
-                kinds.append(2); ivals.append(0); fvals.append(float(a))
+            if ty is C.c_float or ty is C.c_double:
+                kinds.append(1 if ty is C.c_float else 2); ivals.append(0); fvals.append(_pattern(ty, a))
                 continue
             kinds.append(0); fvals.append(0.0)
             if a is None:
@@ -60,11 +97,40 @@ class LaunchTape:
                 ivals.append(C.addressof(a)); keep.append(a)
             elif isinstance(a, C.c_void_p):
                 ivals.append(a.value or 0)
-            elif isinstance(a, bytes):
-                raise TypeError(f"{name}: string arguments are not recordable")
             else:
-                raise TypeError(f"{name}: argument of type {type(a).__name__} is not recordable (pass addresses as integers)")
-        self.entries.append(("call", name, C.cast(fn, C.c_void_p).value, kinds, ivals, fvals, keep, isptr))
+                self.problems.append(f"{name}: argument of type {type(a).__name__} is not recordable (pass addresses as integers)")
+                return
+        self.entries.append(("call", name, addr, kinds, ivals, fvals, keep, isptr))
+
+    def bind_floats(self, provider):
+        """the call recorded last reads its float arguments from provider() at every replay"""
+        i = len(self.entries) - 1
+        if i < 0 or self.entries[i][0] != "call":
+            raise RuntimeError("tape_bind_floats: no recorded call to bind to")
+        nf = sum(1 for k in self.entries[i][3] if k != 0)
+        if len(provider()) != nf:
+            raise RuntimeError(f"tape_bind_floats: {self.entries[i][1]} has {nf} float arguments, the provider returns {len(provider())}")
+        self.float_bindings[i] = provider
+
+    def _float_patterns(self, i):
+        x = self.entries[i]
+        sig = _lib._HIP_SIG[x[1]]
+        ftys = [ty for ty in sig if ty is C.c_float or ty is C.c_double]
+        return [_pattern(ty, v) for ty, v in zip(ftys, self.float_bindings[i]())]
+
+    def refresh_floats(self):
+        """bound float arguments whose provider moved since the last replay -> patched into the native tape; returns how many"""
+        lib, n = _lib.hip(), 0
+        for i in self.float_bindings:
+            now = self._float_patterns(i)
+            old = self._bound_now[i]
+            if now != old and [struct.pack("<d", v) for v in now] != [struct.pack("<d", v) for v in old]:
+                for pos, (a, b) in enumerate(zip(now, old)):
+                    if struct.pack("<d", a) != struct.pack("<d", b):
+                        _lib.check(lib.stem_tape_set_farg(self._native, self.native_index[i], pos, a))
+                        n += 1
+                self._bound_now[i] = now
+        return n
 
     # ---- native tape -------------------------------------------------------------------------------------------------------------
     def finalize(self, second: "LaunchTape"):
@@ -72,13 +138,20 @@ class LaunchTape:
         differ are the per-step counters (their difference = the increment per replay); anything else that differs is an error."""
         a, b = self.entries, second.entries
         if len(a) != len(b) or any(x[0] != y[0] or (x[0] == "call" and x[1] != y[1]) for x, y in zip(a, b)):
-            raise RuntimeError("LaunchTape: two consecutive steps issued different launch sequences -- the schedule is not static")
+            raise TapeRefused("LaunchTape: two consecutive steps issued different launch sequences -- the schedule is not static")
+        if self.problems or second.problems:
+            raise TapeRefused("LaunchTape: " + "; ".join(sorted(set(self.problems + second.problems))))
+        if self.foreign or second.foreign:
+            ops = sorted(set(self.foreign + second.foreign))
+            raise TapeRefused("LaunchTape: the step runs torch operators on device memory that a replay would drop: " + ", ".join(ops))
+        if set(self.float_bindings) != set(second.float_bindings):
+            raise TapeRefused("LaunchTape: the two recordings bound different launches to float providers")
         lib = _lib.hip()
         nat = lib.stem_tape_create()
         segs, lo = [], 0
         ndyn = 0
         self.native_index = []      # per entry of self.entries: its index in the native tape (calls only; -1 otherwise)
-        for x, y in zip(a, b):
+        for ei, (x, y) in enumerate(zip(a, b)):
             if x[0] != "call":
                 self.native_index.append(-1)
             if x[0] == "py":
@@ -98,10 +171,17 @@ class LaunchTape:
                 _, name, addr, kinds, iv, fv, _keep, isptr = x
                 self.native_index.append(lib.stem_tape_length(nat))
                 deltas = [0] * len(iv)
+                bound = ei in self.float_bindings
+                if bound:                       # the provider is the source of truth from here on (it may have moved since step A)
+                    cur = self._float_patterns(ei)
+                    self._bound_now[ei] = cur
+                    it = iter(cur)
+                    fv = [next(it) if k != 0 else 0.0 for k in kinds]
                 for i, (k, va, vb, fa, fb) in enumerate(zip(kinds, iv, y[4], fv, y[5])):
                     if k != 0:
-                        if struct.pack('<d', fa) != struct.pack('<d', fb):
-                            raise RuntimeError(f"LaunchTape: float argument {i} of {name} changed between two steps ({fa} -> {fb})")
+                        if not bound and struct.pack('<d', fa) != struct.pack('<d', fb):
+                            raise TapeRefused(f"LaunchTape: float argument {i} of {name} changed between two steps ({fa} -> {fb}) and no "
+                                              "provider is bound to it (functional.tape_bind_floats)")
                     elif va != vb:
                         if isptr[i]:
                             continue            # addresses of the second (ordinary) step's tensors: the tape keeps the first step's
@@ -183,9 +263,40 @@ class _RecordingLibrary:
         return recorded
 
 
+class _ForeignOpGuard(TorchDispatchMode):
+    """Notes every torch operator that reads or writes DEVICE memory while a tape records, other than allocations, views and
+    allocator bookkeeping: such work is not a library call, so a replay would skip it (a cleared buffer that is never cleared
+    again, a .contiguous() copy whose temporary the tape reads after it was freed, an .item() the host waits for).  Operators
+    issued inside a functional.tape_py callable are that callable's own: it runs again at every replay."""
+
+    #: operator names (aten::<name>) that move no data
+    BENIGN = frozenset("""empty empty_like empty_strided new_empty new_empty_strided view _unsafe_view reshape _reshape_alias
+        as_strided slice select narrow permute transpose t unsqueeze squeeze expand expand_as detach alias unbind split
+        split_with_sizes chunk view_as flatten unflatten movedim diagonal record_stream is_pinned size stride numel dim
+        is_contiguous storage_offset sym_size sym_stride sym_numel sym_storage_offset is_same_size _has_compatible_shallow_copy_type
+        set_ resize_ lift_fresh _to_copy_meta is_nonzero_meta""".split())
+
+    def __init__(self, tape, is_device=None):
+        super().__init__()
+        self.tape = tape
+        self.is_device = is_device or (lambda t: t.is_cuda)
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        if self.tape.in_py == 0:
+            name = getattr(getattr(func, "overloadpacket", func), "__name__", str(func))
+            if name not in self.BENIGN:
+                import torch.utils._pytree as pytree
+                leaves = pytree.tree_leaves((args, kwargs or {}, out))
+                if any(isinstance(t, torch.Tensor) and self.is_device(t) for t in leaves):
+                    self.tape.foreign.append(f"aten::{name}")
+        return out
+
+
 class recording:
     """`with recording(tape, keep_allocations=True): step()` -- logs the step into `tape`.  keep_allocations: every tensor torch
-    allocates inside the block stays alive with the tape (unique addresses, valid for as long as the tape is)."""
+    allocates inside the block stays alive with the tape (unique addresses, valid for as long as the tape is).  The block runs
+    under `_ForeignOpGuard`: torch operators on device memory end up in `tape.foreign`."""
 
     _ALLOC = ("empty", "zeros", "empty_like", "zeros_like", "empty_strided")
 
@@ -198,6 +309,8 @@ class recording:
         self._real = _lib.hip()
         _lib._hip = _RecordingLibrary(self._real, self.tape)
         F._TAPE = self.tape
+        self._guard = _ForeignOpGuard(self.tape)
+        self._guard.__enter__()
         self._saved = {}
         if self.keep_alloc:
             keep = self.tape.keep
@@ -220,6 +333,7 @@ class recording:
         return self.tape
 
     def __exit__(self, *exc):
+        self._guard.__exit__(*exc)
         _lib._hip = self._real
         F._TAPE = None
         for n, real in self._saved.items():
@@ -236,28 +350,59 @@ class TapedPFrameStep:
 
     The tensors a replayed step returns are the recorded step's (static buffers, overwritten by the next step; `y_hat` alternates
     between two buffers so that the next step can read it as its `y_cond` in place): consume them as the training loop does, or
-    copy them before the next call."""
+    copy them before the next call.
+
+    Optimiser hyper-parameters (lr, betas, eps, max_norm of both optimisers) are read again at every replay: a scheduler that
+    edits `param_groups[0]["lr"]` between steps (stem/trainSTEM.py:123,290) is honoured.  A schedule the tape cannot hold
+    (TapeRefused: device-resident optimiser state, torch operators on device memory inside the step, a launch sequence that
+    differs between two steps) keeps running on the ordinary `FusedPFrameStep.step`, with one warning; `taped` tells which."""
 
     WARMUP = 2
 
     def __init__(self, fused):
         self.fused = fused
+        self.refused = None             # the reason a recording was given up for the current key (the step then runs untaped)
         self._reset(None)
 
     def _reset(self, key):
         self.key, self.calls, self.tape, self.first = key, 0, None, None
         self.replays = 0
+        self.refused = None
+
+    taped = property(lambda self: self.tape is not None)
 
     def _counters(self):
         f = self.fused
         objs = [(f.opt, "t"), (f.aux_opt, "t"), (f.stem.entropy_bottleneck, "_noise_offset"), (f.stem.gaussian_conditional, "_noise_offset")]
         return [(o, a) for o, a in objs if hasattr(o, a)]
 
+    def _refuse(self, why):
+        self.refused, self.tape, self.first = str(why), None, None
+        warnings.warn(f"TapedPFrameStep: running the ordinary schedule instead of a launch tape -- {why}", RuntimeWarning, stacklevel=3)
+
+    def _key(self, y_cur, y_cond, num_pixels, grad_scale, reducer):
+        f = self.fused
+        clip = tuple(bool(o.max_norm is not None and o.max_norm > 0) for o in (f.opt, f.aux_opt))
+        return (tuple(y_cur.shape), tuple(y_cond.shape), tuple(y_cur.stride()), tuple(y_cond.stride()), y_cur.dtype, y_cond.dtype, y_cur.device,
+                int(num_pixels), float(grad_scale), id(reducer), F.cur_stream(y_cur.device).cuda_stream, clip, bool(f.clear_grad_in_adam),
+                bool(f.adam_block_max))
+
     def step(self, y_cur, y_cond, num_pixels, grad_scale=1.0, reducer=None):
-        key = (tuple(y_cur.shape), tuple(y_cond.shape), y_cur.device, int(num_pixels), float(grad_scale), id(reducer))
+        key = self._key(y_cur, y_cond, num_pixels, grad_scale, reducer)
         if key != self.key:
             self._reset(key)
         f = self.fused
+        if self.refused is not None:
+            return f.step(y_cur, y_cond, num_pixels, grad_scale, reducer)
+        if self.calls == 0:
+            # device-resident optimiser state is mirrored from the host by torch fill_ calls a tape does not hold
+            if f.opt._dev is not None or f.aux_opt._dev is not None:
+                self._refuse("the optimiser keeps its step count / learning rate in device memory (enable_device_state)")
+                return f.step(y_cur, y_cond, num_pixels, grad_scale, reducer)
+            for name, t in (("y_cur", y_cur), ("y_cond", y_cond)):
+                if F.nhwc_ld(t) is None and not t.is_contiguous():
+                    self._refuse(f"{name} is neither NHWC nor contiguous: the schedule would convert it with a torch copy")
+                    return f.step(y_cur, y_cond, num_pixels, grad_scale, reducer)
         self.calls += 1
         if self.calls <= self.WARMUP:
             return f.step(y_cur, y_cond, num_pixels, grad_scale, reducer)
@@ -267,18 +412,31 @@ class TapedPFrameStep:
             self.in_cond.copy_(y_cond)
             self.first = LaunchTape()
             before = [getattr(o, a) for o, a in self._counters()]
-            with recording(self.first, keep_allocations=True):
-                self.result = f.step(self.in_cur, self.in_cond, num_pixels, grad_scale, reducer)
+            try:
+                with recording(self.first, keep_allocations=True):
+                    self.result = f.step(self.in_cur, self.in_cond, num_pixels, grad_scale, reducer)
+            except BaseException:
+                self._reset(None)                                # the step itself failed: nothing of this recording survives
+                raise
             self.deltas = [getattr(o, a) - b for (o, a), b in zip(self._counters(), before)]
             return self.result
         if self.calls == self.WARMUP + 2:                       # recording B: the ordinary step, logged for the comparison
             second = LaunchTape()
-            with recording(second, keep_allocations=False):
-                res = f.step(y_cur, y_cond, num_pixels, grad_scale, reducer)
-            self.tape = self.first.finalize(second)
+            try:
+                with recording(second, keep_allocations=False):
+                    res = f.step(y_cur, y_cond, num_pixels, grad_scale, reducer)
+            except BaseException:
+                self._reset(None)
+                raise
+            # the step above has run and its result stands whatever happens to the tape
+            try:
+                self.tape = self.first.finalize(second)
+            except TapeRefused as e:
+                self._refuse(e)
+                return res
             self.replays = 1                                     # this step was "replay index 1" in the counters' progression
             # the frame's latents arrive in a different buffer every step (the prefetcher's): where the schedule reads the recorded
-            # input buffer, the tape is pointed at the caller's tensor instead of copying it (same shape / strides required)
+            # input buffer, the tape is pointed at the caller's tensor instead of copying it (same shape / strides: the key)
             self.cur_slots = self.tape.pointer_slots(self.in_cur.data_ptr())
             # the conditioning latents are the previous step's y_hat (stem/trainSTEM.py:179): instead of copying them into the
             # recorded input buffer, the tape reads them where they are and writes this step's y_hat into the OTHER of two
@@ -288,24 +446,20 @@ class TapedPFrameStep:
             self.yhat_slots = self.tape.pointer_slots(y_hat.data_ptr())
             self.yhat_bufs = [y_hat, torch.empty_like(y_hat)] if (self.cond_slots and self.yhat_slots) else None
             return res
-        if self.cur_slots and y_cur.stride() == self.in_cur.stride() and y_cur.dtype == self.in_cur.dtype:
+        if self.cur_slots:
             self.tape.set_pointer(self.cur_slots, y_cur.data_ptr())
         else:
-            if self.cur_slots:
-                self.tape.set_pointer(self.cur_slots, self.in_cur.data_ptr())
-            self.in_cur.copy_(y_cur)
+            self.in_cur.copy_(y_cur)                             # on the key's stream, which the replay's first launches are ordered after
         result = self.result
-        if self.yhat_bufs is not None and y_cond.stride() == self.in_cond.stride() and y_cond.dtype == self.in_cond.dtype:
+        if self.yhat_bufs is not None:
             out = self.yhat_bufs[1] if y_cond.data_ptr() == self.yhat_bufs[0].data_ptr() else self.yhat_bufs[0]
             self.tape.set_pointer(self.cond_slots, y_cond.data_ptr())
             self.tape.set_pointer(self.yhat_slots, out.data_ptr())
             if out is not self.yhat_bufs[0]:
                 result = (dict(self.result[0], y_hat=out),) + tuple(self.result[1:])
         else:
-            if self.yhat_bufs is not None:
-                self.tape.set_pointer(self.cond_slots, self.in_cond.data_ptr())
-                self.tape.set_pointer(self.yhat_slots, self.yhat_bufs[0].data_ptr())
             self.in_cond.copy_(y_cond)
+        self.tape.refresh_floats()                               # lr / betas / eps / max_norm as the optimisers hold them NOW
         self.replays += 1
         self.tape.replay(self.replays)
         for (o, a), d in zip(self._counters(), self.deltas):

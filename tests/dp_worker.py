@@ -7,7 +7,7 @@ backward -- hooks fired from StemEngine.backward on the weight-gradient stream, 
 all-reduced while the rest of backward is still queued -- on the single-GPU test box.  The parent test compares what the
 ranks dump with a single-process run over the concatenated batch.
 
-    python tests/dp_worker.py --case train|train_fused|gop|rccl1_train_fused|rccl1_gop|rccl1_train_taped --rank R --world W --port P --out DIR
+    python tests/dp_worker.py --case train|train_fused|train_taped|train_untaped|gop|rccl1_train_fused|rccl1_gop|rccl1_train_taped --rank R --world W --port P --out DIR
 
 The `rccl1_*` cases are ONE rank in a world-size-1 process group on the RCCL ("nccl") backend: the collectives are
 identities, but every RCCL call of the reducers, their side-stream ordering and the device-tensor reductions of bench.py
@@ -174,12 +174,15 @@ def case_train_taped(rank, world, out_dir, steps=8, tag="train_taped", taped=Tru
         out, oc, aux, gn = step.step(y_cur, y_cond, 64 * 64, grad_scale=red.grad_scale, reducer=red)
         y_cond = out["y_hat"].clone()
         dump[f"s{t}:loss"] = np.array([float(oc["loss"]), float(gn), float(aux)])
+        if t == 6:                                  # a scheduler's edit between two replayed steps (stem/trainSTEM.py:123,290)
+            opt.param_groups[0]["lr"] *= 0.5
     step.finish()
     torch.cuda.synchronize()
     dump["params"] = flat_np(opt.flat.data)
     dump["quantiles"] = flat_np(aux_opt.flat.data)
     dump["collectives"] = np.array([red.collectives])
     dump["replays"] = np.array([step.replays if taped else 0])
+    dump["taped"] = np.array([bool(taped and step.taped)])
     import torch.distributed as dist
     dump["backend"] = np.array([dist.get_backend() if dist.is_initialized() else "none"])
     np.savez(os.path.join(out_dir, f"{tag}_rank{rank}.npz"), **dump)
@@ -235,7 +238,8 @@ def main():
         assert a.world == 1 and torch.distributed.get_backend() == "nccl"
         {"rccl1_train_fused": case_train_fused, "rccl1_gop": case_gop, "rccl1_train_taped": case_train_taped}[a.case](a.rank, a.world, a.out, tag=a.case)
     else:
-        {"train": case_train, "train_fused": case_train_fused, "gop": case_gop}[a.case](a.rank, a.world, a.out)
+        {"train": case_train, "train_fused": case_train_fused, "gop": case_gop, "train_taped": case_train_taped,
+         "train_untaped": lambda r, w, o: case_train_taped(r, w, o, tag="train_untaped", taped=False)}[a.case](a.rank, a.world, a.out)
     D.barrier()
     torch.distributed.destroy_process_group()
 

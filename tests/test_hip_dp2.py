@@ -202,13 +202,35 @@ def test_rccl_world1_taped_executor_bit_identical_to_the_plain_schedule(dp2_resu
     parameters and quantiles; the reducer issued the same number of collectives per step on both routes."""
     import dp_worker
     (r,) = dp2_results("rccl1_train_taped")
-    assert str(r["backend"][0]) == "nccl" and int(r["replays"][0]) == 5
+    assert str(r["backend"][0]) == "nccl" and int(r["replays"][0]) == 5 and bool(r["taped"][0])
     assert not torch.distributed.is_initialized()
     dp_worker.case_train_taped(0, 1, str(tmp_path), tag="local_taped", taped=False)
     loc = dict(np.load(tmp_path / "local_taped_rank0.npz"))
     assert str(loc["backend"][0]) == "none" and int(r["collectives"][0]) == int(loc["collectives"][0]) > 0
     for k in ["params", "quantiles"] + [f"s{t}:loss" for t in range(1, 9)]:
         np.testing.assert_array_equal(r[k], loc[k], err_msg=k)
+
+
+@pytest.mark.dp2("train_taped")
+@pytest.mark.dp2("train_untaped")
+def test_two_ranks_taped_executor_bit_identical_to_the_plain_two_rank_run(dp2_results):
+    """configs[2] at world size 2 through the native executor: TWO ranks (gloo, sharing cuda:0), eight P-frame steps each through
+    tape.TapedPFrameStep -- two ordinary, two recorded, four replayed; the overlapped reducer's all-reduces are re-issued by the
+    tape's Python entries in the middle of the replayed backward; the learning rate is halved after step 6, between two replays --
+    against the same two ranks on the plain schedule: the replicas stay bit-identical through the replays and equal the untaped
+    run's, step by step (losses, clipped norms, auxiliary losses) and in every parameter."""
+    t0, t1 = dp2_results("train_taped")
+    u0, u1 = dp2_results("train_untaped")
+    assert bool(t0["taped"][0]) and bool(t1["taped"][0]) and int(t0["replays"][0]) == int(t1["replays"][0]) == 5
+    assert str(t0["backend"][0]) == "gloo" and int(t0["collectives"][0]) == int(u0["collectives"][0]) > 0
+    np.testing.assert_array_equal(t0["params"], t1["params"])                # replicas
+    np.testing.assert_array_equal(t0["quantiles"], t1["quantiles"])
+    for k in range(1, 9):                                                    # the norm of the exchanged gradient is global
+        assert t0[f"s{k}:loss"][1] == t1[f"s{k}:loss"][1], k
+    for t, u in ((t0, u0), (t1, u1)):                                        # taped == untaped, rank by rank
+        for k in ["params", "quantiles"] + [f"s{i}:loss" for i in range(1, 9)]:
+            np.testing.assert_array_equal(t[k], u[k], err_msg=k)
+    assert not np.array_equal(t0["s1:loss"], t1["s1:loss"])                  # different samples per rank
 
 
 @pytest.mark.dp2("rccl1_gop")

@@ -486,3 +486,39 @@ def test_variable_rate_workload_config5_properties():
     # the property bound was 2e-2; with the forward tied to the oracle above, the gradient identity is held to 1e-2
     # on the worst tensor (measured 7.7e-3 on the spatially constant SFT MLPs) and to 5e-3 on all but eight tensors
     assert errs[len(errs) // 2][0] <= 1e-4 and errs[0][0] < 1e-2 and errs[8][0] < 5e-3 and len(loose) <= 0.4 * len(errs), errs[:10]
+
+
+def test_first_launch_on_fresh_workspaces_is_reproducible():
+    """The split-K arrival protocol (partials of a tile written by workgroups on different XCDs, a ticket per workgroup, the last
+    arriver sums them: csrc/stem_common.h `splitk_last_arriver`) on its hardest case: the FIRST launches after the workspaces
+    were (re)allocated -- round 4's 16-byte-store form let the ticket overtake the data exactly there and the last arriver
+    summed the allocation's zeros.  Eight fresh big models (fresh engines, workspaces, counters) at the bench geometry: every
+    run's training forward gives the same TPM.0 output as a recomputation afterwards, and all runs give the same tensors."""
+    import types
+    from spatiotemporalentropymodel_amd import functional as F
+    from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel_Res
+    from spatiotemporalentropymodel_amd.optim import configure_optimizers
+    dev = torch.device("cuda:0")
+    runs = []
+    for r in range(8):
+        torch.manual_seed(7)
+        torch.cuda.empty_cache()                                   # the next run's workspaces come from fresh allocations
+        stem = SpatioTemporalPriorModel_Res().to(dev).train()
+        configure_optimizers(stem, types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3))
+        for m in (stem.entropy_bottleneck, stem.gaussian_conditional):
+            m.noise_seed = 99
+        g = torch.Generator(device=dev).manual_seed(11)
+        y_cur = torch.randn(16, 192, 16, 16, device=dev, generator=g) * 3
+        y_cond = y_cur + torch.rand(16, 192, 16, 16, device=dev, generator=g) - 0.5
+        eng = stem.engine()
+        y_hat, lik_y, lik_z, k = eng.forward(y_cur, y_cond, True)
+        torch.cuda.synchronize()
+        again, _ = eng.TPM[0].fwd6(k["planes"]["yd"], F.ACT_LRELU, planes=True)
+        torch.cuda.synchronize()
+        assert torch.equal(again, k["tp0"]), f"run {r}: TPM.0 inside the forward differs from its recomputation"
+        runs.append({n: k[n].clone() for n in ("he0", "he2", "hd0", "hd2", "tp0", "tp2", "e0", "e2", "gp") if isinstance(k.get(n), torch.Tensor)}
+                    | {"lik_y": lik_y.clone(), "y_hat": y_hat.clone()})
+        del stem, eng, k
+    for r in range(1, len(runs)):
+        diff = [n for n in runs[0] if not torch.equal(runs[0][n], runs[r][n])]
+        assert not diff, (r, diff)

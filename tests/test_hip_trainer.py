@@ -245,6 +245,197 @@ def test_taped_step_is_bit_identical_to_the_fused_schedule(monkeypatch, tuned):
     assert a[3] == b[3], (a[3], b[3])
 
 
+def _taped_run(taped, steps, make, frames, npix, edit=None, tuned=True, monkeypatch=None, mutate=None):
+    """`steps` P-frame steps with the latents prefetched, through trainer.FusedPFrameStep (taped=False) or tape.TapedPFrameStep;
+    edit(t, opt, aux) runs after step t (a scheduler's hook); mutate(step_object) before the first step.
+    -> (parameters, aux parameters, per-step log, counters, the step object)"""
+    from spatiotemporalentropymodel_amd import functional as F
+    from spatiotemporalentropymodel_amd import trainer
+    from spatiotemporalentropymodel_amd.tape import TapedPFrameStep
+    dev = frames[0].device
+    if monkeypatch is not None:
+        for k in trainer.SCHEDULE_DEFAULTS:
+            monkeypatch.delenv(k, raising=False)
+            if not tuned:
+                monkeypatch.setenv(k, "")
+        monkeypatch.setattr(F, "_STREAM_PRIO", None)
+    imodel, stem, opt, aux = make()
+    sched = trainer.tuned_schedule(dev)
+    step = trainer.FusedPFrameStep(stem, opt, aux)
+    if mutate is not None:
+        mutate(step, opt, aux)
+    if taped:
+        step = TapedPFrameStep(step)
+    pf = trainer.LatentPrefetcher(imodel)
+    log = []
+    torch.cuda.synchronize()
+    with sched:
+        t = 0
+        while t < steps:
+            pf.start(frames, frames_ready=True)
+            y_cond = pf.get(0)[1]
+            for f in range(1, len(frames)):
+                if t == steps:
+                    break
+                out, oc, aux_l, gn = step.step(pf.get(f)[0], y_cond, npix)
+                t += 1
+                log.append((float(oc["loss"]), float(oc["y_bpp_loss"]), float(gn), float(aux_l), out["y_hat"].clone(),
+                            out["likelihoods"]["y"].clone()))
+                y_cond = out["y_hat"]
+                if edit is not None:
+                    edit(t, opt, aux)
+        step.finish()
+    torch.cuda.synchronize()
+    eb, gc = stem.entropy_bottleneck, stem.gaussian_conditional
+    return opt.flat.data.clone(), aux.flat.data.clone(), log, (opt.t, aux.t, eb._noise_offset, gc._noise_offset), step
+
+
+def _assert_same_run(a, b):
+    for t, (la, lb) in enumerate(zip(a[2], b[2])):
+        assert la[:4] == lb[:4], (t, la[:4], lb[:4])
+        assert torch.equal(la[4], lb[4]) and torch.equal(la[5], lb[5]), t
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert a[3] == b[3], (a[3], b[3])
+
+
+def test_taped_step_follows_the_scheduler(monkeypatch):
+    """stem/trainSTEM.py:123,290: ReduceLROnPlateau rewrites param_groups[0]["lr"] while training runs.  Nine P-frame steps --
+    two ordinary, two recorded, five replayed -- with the main learning rate cut to a tenth after step 6 (by a real
+    ReduceLROnPlateau attached to the fused optimiser), the aux learning rate halved after step 7 and max_norm tightened after
+    step 8: the taped run equals the untaped one bit for bit, and differs from a taped run nobody edited (so the replays did
+    read the new values)."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(17)
+    frames = [torch.rand(2, 3, 128, 128, device=dev, generator=g) for _ in range(10)]
+    scheds = {}
+
+    def edit(t, opt, aux):
+        if t == 1:
+            scheds[id(opt)] = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, "min", patience=0)
+            scheds[id(opt)].step(1.0)
+        if t == 6:
+            scheds[id(opt)].step(2.0)               # no improvement with patience 0: lr x 0.1
+            assert abs(opt.param_groups[0]["lr"] - 1e-5) < 1e-12
+        if t == 7:
+            aux.param_groups[0]["lr"] *= 0.5
+        if t == 8:
+            opt.max_norm = 0.05
+
+    make = lambda: _pair(64, 96, 64, 96, False, False)
+    plain = _taped_run(False, 9, make, frames, 2 * 128 * 128, edit, monkeypatch=monkeypatch)
+    taped = _taped_run(True, 9, make, frames, 2 * 128 * 128, edit, monkeypatch=monkeypatch)
+    still = _taped_run(True, 9, make, frames, 2 * 128 * 128, None, monkeypatch=monkeypatch)
+    assert taped[4].taped and taped[4].replays == 6 and taped[4].refused is None
+    assert len(taped[4].tape.float_bindings) == 2            # the two optimiser launches
+    _assert_same_run(plain, taped)
+    assert not torch.equal(still[0], taped[0]) and not torch.equal(still[1], taped[1])
+    for t in range(6):                                       # ... and identical up to the first edit
+        assert still[2][t][:4] == taped[2][t][:4]
+
+
+def test_taped_step_holds_the_memset_when_adam_does_not_clear(monkeypatch):
+    """`clear_grad_in_adam = False` (gradients left in place for inspection, cleared at the start of the next step): the clearing is
+    a library call (stem_zero_bytes), so the tape holds it -- the bias gradients, which ACCUMULATE into the flat buffer, would
+    otherwise grow from replay to replay."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(19)
+    frames = [torch.rand(2, 3, 128, 128, device=dev, generator=g) for _ in range(9)]
+
+    def keep_grads(step, opt, aux):
+        step.clear_grad_in_adam = False
+    make = lambda: _pair(64, 96, 64, 96, False, False)
+    plain = _taped_run(False, 8, make, frames, 2 * 128 * 128, monkeypatch=monkeypatch, mutate=keep_grads)
+    taped = _taped_run(True, 8, make, frames, 2 * 128 * 128, monkeypatch=monkeypatch, mutate=keep_grads)
+    assert taped[4].taped and taped[4].replays == 5
+    assert any(e[0] == "call" and e[1] == "stem_zero_bytes" for e in taped[4].tape.entries)
+    _assert_same_run(plain, taped)
+
+
+def test_taped_step_refuses_what_it_cannot_replay(monkeypatch):
+    """Schedules a tape cannot hold keep running on the ordinary route, loudly, with the ordinary route's results: (1) torch
+    operators on device memory inside the step (here: a reducer that is NOT announced through functional.tape_py scales the
+    gradient buffer with Tensor.mul_) are seen by the recording's guard; (2) device-resident optimiser state; (3) latents that are
+    neither NHWC nor contiguous."""
+    import warnings
+    from spatiotemporalentropymodel_amd import trainer
+    from spatiotemporalentropymodel_amd.tape import TapedPFrameStep
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(23)
+    frames = [torch.rand(2, 3, 128, 128, device=dev, generator=g) for _ in range(7)]
+    make = lambda: _pair(64, 96, 64, 96, False, False)
+
+    def sneaky(step, opt, aux):                     # a torch op in the middle of the step, outside the library and outside tape_py
+        real = step.eng.backward
+
+        def backward(*a, **kw):
+            r = real(*a, **kw)
+            from spatiotemporalentropymodel_amd.layers import join_wgrad_stream
+            join_wgrad_stream()
+            opt.flat.grad.mul_(0.5)
+            return r
+        step.eng.backward = backward
+    plain = _taped_run(False, 6, make, frames, 2 * 128 * 128, monkeypatch=monkeypatch, mutate=sneaky)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        taped = _taped_run(True, 6, make, frames, 2 * 128 * 128, monkeypatch=monkeypatch, mutate=sneaky)
+    assert not taped[4].taped and "aten::mul_" in taped[4].refused, taped[4].refused
+    assert any("ordinary schedule" in str(x.message) for x in w)
+    _assert_same_run(plain, taped)
+
+    def dev_state(step, opt, aux):
+        opt.enable_device_state()
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        taped = _taped_run(True, 5, make, frames, 2 * 128 * 128, monkeypatch=monkeypatch, mutate=dev_state)
+    assert not taped[4].taped and "device memory" in taped[4].refused
+    plain = _taped_run(False, 5, make, frames, 2 * 128 * 128, monkeypatch=monkeypatch, mutate=dev_state)
+    _assert_same_run(plain, taped)
+
+    imodel, stem, opt, aux = make()
+    step = TapedPFrameStep(trainer.FusedPFrameStep(stem, opt, aux))
+    with torch.no_grad():
+        y0, y1 = imodel.getY(frames[0])[1], imodel.getY(frames[1])[0]
+    odd = torch.empty(y1.shape[0], y1.shape[1], y1.shape[2], 2 * y1.shape[3], device=dev)[:, :, :, ::2]
+    odd.copy_(y1)
+    assert not odd.is_contiguous()
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        for _ in range(5):
+            step.step(odd, y0, 2 * 128 * 128)
+    step.finish()
+    torch.cuda.synchronize()
+    assert not step.taped and "neither NHWC nor contiguous" in step.refused
+
+
+def test_taped_step_at_the_bench_geometry_is_bit_identical(monkeypatch):
+    """The route bench.py times, at ITS geometry: SpatioTemporalPriorModel_Res() (N = M = 192, 256-channel hyper path) on B = 16
+    septuplets of 256 x 256 with the latent prefetcher and the tuned schedule -- where the planner picks the image-tile / ring
+    kernels, split-K workspaces and the multi-tensor tables the tape keeps pointers into.  Twelve P-frame steps = two septuplets
+    (two ordinary, two recorded, eight replayed, the prefetcher restarting in between) taped against untaped: losses, norms,
+    y_hat, likelihoods and every parameter bit for bit."""
+    import types
+    from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel_Res
+    from spatiotemporalentropymodel_amd.optim import configure_optimizers
+    from spatiotemporalentropymodel_amd.zoo import models
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(29)
+    frames = [torch.rand(16, 3, 256, 256, device=dev, generator=g) for _ in range(7)]
+
+    def make():
+        torch.manual_seed(1234)
+        imodel = models["mbt2018"](quality=4).to(dev).eval()
+        stem = SpatioTemporalPriorModel_Res().to(dev).train()
+        for m in (imodel.gaussian_conditional, stem.entropy_bottleneck, stem.gaussian_conditional):
+            m.noise_seed = 4242
+        opt, aux = configure_optimizers(stem, types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3))
+        return imodel, stem, opt, aux
+    plain = _taped_run(False, 12, make, frames, 16 * 256 * 256, monkeypatch=monkeypatch)
+    taped = _taped_run(True, 12, make, frames, 16 * 256 * 256, monkeypatch=monkeypatch)
+    assert taped[4].taped and taped[4].replays == 9 and taped[4].refused is None and len(taped[4].tape) > 60
+    _assert_same_run(plain, taped)
+    assert plain[3][0] == 12
+
+
 # the switches of config.StemRuntimeConfig that stay supported next to the defaults (round 4: the others were deleted)
 _SCHEDULE_SWITCHES = [("overlap_wgrad", False), ("branch_streams", False), ("split_pack", False), ("defer_bias_final", False),
                       ("tpm_first", False), ("tpm_first_bwd", False)]

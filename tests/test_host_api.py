@@ -657,4 +657,73 @@ def test_launch_tape_trampolines_on_host():
     n_before = len(seen)
     assert lib.stem_tape_replay(tape, 4, e_bad + 1, 1) == -(e_bad + 1)
     assert len(seen) == n_before + 1 and seen[-1] == (1000, 8, 0x7F0000001234)
+    # float slots are patchable (the optimiser hyper-parameters a scheduler edits between replays): float and double patterns
+    e_f = 2                                                                                       # kinds [0, 1, 0, 2, 0, ...]
+    assert lib.stem_tape_set_farg(tape, e_f, 0, struct.unpack("<d", struct.pack("<fI", 0.375, 0))[0]) == 0
+    assert lib.stem_tape_set_farg(tape, e_f, 1, 1e-5) == 0
+    assert lib.stem_tape_set_farg(tape, e_f, 2, 0.0) != 0 and b"no float argument" in lib.stem_last_error()
+    assert lib.stem_tape_set_farg(tape, 0, 0, 0.0) != 0                                           # entry 0 has no float argument
+    assert lib.stem_tape_replay(tape, e_f, e_f + 1, 1) == 0
+    assert seen[-1] == (7, 0.375, 8, 1e-5, 9, 10, 11, 12, 13)
     lib.stem_tape_destroy(tape)
+
+
+def test_launch_tape_contract_is_checked_for_every_entry_point():
+    """The trampolines' calling contract (scalar / pointer arguments only, <= 6 SSE-class, <= 40 integer-class) is a static_assert
+    per int-returning entry point in csrc/tape.hip, driven by csrc/tape_entries.inc: the list must be what the header declares
+    (tools/gen_tape_table.py), the library must know every listed function as recordable and nothing else, and the ctypes
+    prototypes the recorder classifies arguments by must agree with the header on which arguments are float / double."""
+    import ctypes as C
+    import re
+    import subprocess
+    import sys
+    from spatiotemporalentropymodel_amd import _lib
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.call([sys.executable, os.path.join(repo, "tools", "gen_tape_table.py"), "--check"]) == 0, \
+        "csrc/tape_entries.inc is stale: run python tools/gen_tape_table.py"
+    listed = re.findall(r"STEM_TAPE_ENTRY\((\w+)\)", open(os.path.join(repo, "spatiotemporalentropymodel_amd", "csrc", "tape_entries.inc")).read())
+    lib, raw = _lib.hip(), C.CDLL(_lib.HIP_SO)
+    assert len(listed) > 100
+    for name in listed:
+        assert lib.stem_tape_entry_recordable(C.cast(getattr(raw, name), C.c_void_p).value) == 1, name
+    for name in ("stem_last_error", "stem_tape_create", "stem_tape_destroy", "stem_adam_chunk"):          # not int-returning
+        assert lib.stem_tape_entry_recordable(C.cast(getattr(raw, name), C.c_void_p).value) == 0, name
+    cb = C.CFUNCTYPE(C.c_int)(lambda: 0)
+    assert lib.stem_tape_entry_recordable(C.cast(cb, C.c_void_p).value) == 0
+    # header vs ctypes prototypes: same argument count, float / double exactly where the header says
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(repo, "include", "stem_hip.h")).read(), flags=re.S)
+    protos = dict(re.findall(r"\bint\s+(stem_[a-z0-9_]+)\s*\(([^)]*)\)", src))
+    for name in listed:
+        params = [p.strip() for p in protos[name].split(",")] if protos[name].strip() not in ("", "void") else []
+        sig = _lib._HIP_SIG[name]
+        assert len(params) == len(sig), (name, params, sig)
+        for p, ty in zip(params, sig):
+            want = C.c_float if re.match(r"(const\s+)?float\s+\w+$", p) else (C.c_double if re.match(r"(const\s+)?double\s+\w+$", p) else None)
+            if want is not None or ty in (C.c_float, C.c_double):
+                assert ty is want, (name, p, ty)
+            assert "[" not in p and not re.match(r"(const\s+)?struct\s+\w+\s+\w+$", p), (name, p)   # no aggregates by value
+
+
+def test_engine_switches_follow_the_runtime_configuration(monkeypatch):
+    """config.override(...) and changed STEM_* variables reach StemEngine's switches (they are descriptors over
+    config.StemRuntimeConfig, not import-time copies); a value assigned on the class pins a switch."""
+    from spatiotemporalentropymodel_amd import config
+    from spatiotemporalentropymodel_amd.engine import StemEngine
+    from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel_Res
+    config.runtime()                                              # an earlier test may have changed and restored the environment
+    assert StemEngine.use_fx3 is True and StemEngine.overlap_wgrad is True
+    with config.override(engine_f16x3=False, engine_overlap=False):
+        assert StemEngine.use_fx3 is False and StemEngine.overlap_wgrad is False
+        eng = SpatioTemporalPriorModel_Res(64, 96).engine()
+        assert not any(l.fx3 for l in eng.layers)                 # routes chosen inside the block: fp32 MFMA everywhere
+    assert StemEngine.use_fx3 is True
+    eng = SpatioTemporalPriorModel_Res(64, 96).engine()
+    assert any(l.fx3 for l in eng.layers) and eng.overlap_wgrad is True
+    monkeypatch.setenv("STEM_ENGINE_F16X3", "0")
+    eng2 = SpatioTemporalPriorModel_Res(64, 96).engine()          # building an engine parses the environment again
+    assert eng2.use_fx3 is False and not any(l.fx3 for l in eng2.layers)
+    monkeypatch.delenv("STEM_ENGINE_F16X3")
+    config.runtime()
+    monkeypatch.setattr(StemEngine, "use_wg3", False)             # pinned on the class
+    with config.override(engine_wgrad_f16x3=True):
+        assert StemEngine.use_wg3 is False
