@@ -497,6 +497,19 @@ size_t stem_conv2d_f16x3_gen_workspace_bytes(int B, int H, int W, int C, int N, 
 int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int xpix, const void *wp, const float *bias, int epi, float slope,
                                const float *z, int ldz, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R,
                                int S, int stride, int pad, int taps, void *ws, size_t ws_bytes, void *stream);
+/* The TRANSPOSED face of a stride-2, R x R (odd), padding R/2 layer whose fine grid is exactly twice the coarse one, on the same
+ * kernel as ONE launch over its four sub-pixel phases (each a stride-1 convolution of the coarse grid with the taps of its parity:
+ * 3x3 / 3x2 / 2x3 / 2x2 for 5x5 -- no structural zeros):
+ *   forward of nn.ConvTranspose2d(C, N, R, stride=2, padding=R/2, output_padding=1)     HD.0 / HD.2 (spatiotemporalpriors.py:822-826)
+ *   input gradient of nn.Conv2d(N, C, R, stride=2, padding=R/2), even-sized input       HE.2 / HE.4 (:814-818; torch autograd)
+ * xp: planes of the coarse tensor [B, H, W, C]; wp: the four phase images made by stem_f16x2_pack_conv_weights_multi with
+ * flip = 2 (rows = the N outputs, contraction channels = C, i.e. the torch weight read as w[c][n][r][s]); y / yp / z: fp32 rows /
+ * planes / activation rows of the fine tensor [B, OHf, OWf, N] with OHf = 2H, or 2H - 1 for the input gradient of a strided
+ * convolution whose input had an odd number of rows (likewise OWf); epi, slope, ws as in stem_conv2d_f16x3_gen_fwd. */
+size_t stem_tconv2d_f16x3_workspace_bytes(int B, int H, int W, int C, int N, int R);
+int stem_tconv2d_f16x3_fwd(const void *xp, const float *xq, int xpix, const void *wp, const float *bias, int epi, float slope,
+                            const float *z, int ldz, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R,
+                            int OHf, int OWf, void *ws, size_t ws_bytes, void *stream);
 
 /* Weight gradient of a stride-1 nn.Conv2d on the 16-bit matrix cores (csrc/wgrad_f16x3.hip): x and dy as planes with their
  * records (pitches in bytes per pixel, 0 = dense; 32-aligned channel views allowed), result as `splits` slabs [R*S][K][C] like
@@ -506,6 +519,14 @@ int stem_wgrad_f16x3_splits(int B, int H, int W, int C, int K, int R, int S, int
 /* bias_part (optional, splits * K floats): per-split column sums of dy, to be finished by stem_bias_grad_final */
 int stem_conv2d_wgrad_f16x3(const void *xp, const float *xq, int xpix, const void *dyp, const float *dyq, int dypix, float *dwp,
                              float *bias_part, int B, int H, int W, int C, int K, int R, int S, int pad, int splits, void *stream);
+/* ... of a STRIDED layer (per-tap form): dW[k][c][r][s] = sum over coarse pixels of g[b, oy, ox][k] * f[b, oy*stride + r - pad, ...][c].
+ * g = `dyp` (K channels, coarse grid), f = `xp` (C channels, fine grid H x W).  nn.Conv2d (HE.2 / HE.4, spatiotemporalpriors.py:814-818):
+ * f = input, g = output gradient, slabs [t][K][C].  nn.ConvTranspose2d (HD.0 / HD.2, :822-826; weight [Cin][Cout][R][S]): g = the
+ * layer's input (K = Cin), f = the gradient of its output (C = Cout), slabs [t][Cin][Cout] (unpack with STEM_UNPACK_DECONV). */
+int stem_wgrad_f16x3_strided_splits(int B, int H, int W, int C, int K, int R, int S, int stride, int pad);
+int stem_conv2d_wgrad_f16x3_strided(const void *xp, const float *xq, int xpix, const void *dyp, const float *dyq, int dypix, float *dwp,
+                                     float *bias_part, int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int splits,
+                                     void *stream);
 int stem_bias_grad_final(const float *part, int K, int parts, float *db, int accumulate, void *stream);
 size_t stem_bias_grad_scratch_elems(long npix, int K);
 int stem_bias_grad(const float *dy, int lddy, long npix, int K, float *scratch, float *db, int accumulate, void *stream);

@@ -103,6 +103,10 @@ _HIP_SIG = {
     "stem_f16x2_conv_weight_gen_bytes": [ci, ci, ci, ci],
     "stem_f16x2_pack_conv_weight_gen": [vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "stem_conv2d_f16x3_gen_workspace_bytes": [ci, ci, ci, ci, ci, ci, ci, ci, ci, ci],
+    "stem_tconv2d_f16x3_workspace_bytes": [ci, ci, ci, ci, ci, ci],
+    "stem_tconv2d_f16x3_fwd": [vp, vp, ci, vp, vp, ci, cf, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],
+    "stem_wgrad_f16x3_strided_splits": [ci, ci, ci, ci, ci, ci, ci, ci, ci],
+    "stem_conv2d_wgrad_f16x3_strided": [vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_f16x2_pack_conv_weights_multi": [vp, ci, vp],
     "stem_wgrad_f16x3_splits": [ci, ci, ci, ci, ci, ci, ci, ci],
     "stem_conv2d_wgrad_f16x3": [vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
@@ -153,7 +157,7 @@ _HIP_SIG = {
     "stem_tuning_get": [C.c_char_p],
     "stem_last_error": [],
 }
-_RESTYPE = {"stem_c4gdn_stream_bytes": sz, "stem_adam_chunk": sz, "stem_f16x2_planes_qrec_offset": sz, "stem_nhwc4_qrec_floats": sz, "stem_bias_grad_scratch_elems": sz, "stem_f16x2_conv_weight_gen_bytes": sz, "stem_conv2d_f16x3_gen_workspace_bytes": sz, "stem_f16x2_planes_bytes": sz, "stem_f16x2_conv_weight_bytes": sz, "stem_packed_weight_elems": sz, "stem_gdn_bwd_workspace_bytes": sz, "stem_wgrad_workspace_elems": sz, "stem_conv_workspace_bytes": sz, "stem_last_error": C.c_char_p,
+_RESTYPE = {"stem_c4gdn_stream_bytes": sz, "stem_adam_chunk": sz, "stem_f16x2_planes_qrec_offset": sz, "stem_nhwc4_qrec_floats": sz, "stem_bias_grad_scratch_elems": sz, "stem_f16x2_conv_weight_gen_bytes": sz, "stem_conv2d_f16x3_gen_workspace_bytes": sz, "stem_tconv2d_f16x3_workspace_bytes": sz, "stem_f16x2_planes_bytes": sz, "stem_f16x2_conv_weight_bytes": sz, "stem_packed_weight_elems": sz, "stem_gdn_bwd_workspace_bytes": sz, "stem_wgrad_workspace_elems": sz, "stem_conv_workspace_bytes": sz, "stem_last_error": C.c_char_p,
              "stem_tape_create": vp, "stem_tape_destroy": None}
 
 _RANS_SIG = {

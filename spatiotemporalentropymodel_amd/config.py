@@ -31,6 +31,7 @@ class StemRuntimeConfig:
     first_layer_f16x3: bool = True       #: g_a.0 + GDN (csrc/c4gdn_f16x3.hip)
     engine_f16x3: bool = True            #: stride-1 STEM layers, forward and input gradient (TPM, HE.0, HD.4, EPM, context model)
     engine_strided_f16x3: bool = True    #: strided faces of the hyper path's stride-2 layers
+    engine_transposed_f16x3: bool = True #: ... their transposed faces (four sub-pixel phases, one launch) and weight gradients
     engine_ctx_f16x3: bool = True        #: the masked context convolution over its live taps
     engine_wgrad_f16x3: bool = True      #: weight gradients of the stride-1 layers (csrc/wgrad_f16x3.hip)
     engine_records: bool = True          #: producers of fp32 tensors record their maxima (no maximum pass in front of a split)
@@ -64,7 +65,7 @@ class StemRuntimeConfig:
 #: field -> environment variable (the historical spellings)
 _ENV = {
     "analysis_f16x3": "STEM_F16X3", "first_layer_f16x3": "STEM_C4GDN_F16X3", "engine_f16x3": "STEM_ENGINE_F16X3",
-    "engine_strided_f16x3": "STEM_ENGINE_STRIDED_F16X3", "engine_ctx_f16x3": "STEM_ENGINE_CTX_F16X3",
+    "engine_strided_f16x3": "STEM_ENGINE_STRIDED_F16X3", "engine_transposed_f16x3": "STEM_ENGINE_TRANSPOSED_F16X3", "engine_ctx_f16x3": "STEM_ENGINE_CTX_F16X3",
     "engine_wgrad_f16x3": "STEM_ENGINE_WGRAD_F16X3", "engine_records": "STEM_ENGINE_RECORDS", "layers_f16x3": "STEM_LAYERS_F16X3",
     "layers_f16x3_maxpix": "STEM_LAYERS_F16X3_MAXPIX", "layers_wide_minpix": "STEM_LAYERS_WIDE_MINPIX",
     "adam_block_max": "STEM_ADAM_BLOCK_MAX", "engine_overlap": "STEM_ENGINE_OVERLAP",

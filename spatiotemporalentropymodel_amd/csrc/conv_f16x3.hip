@@ -55,6 +55,15 @@ constexpr int lds_total(int bm, int depth) { return lds_taps(bm, depth) + 32 * 4
 constexpr int MAXTAP = 25;
 constexpr int OOR = 0x7FFFFF00;                                    // voffset that every buffer view rejects (returns 0)
 
+struct Fx3Phase {
+    int ntaps, S;                  // taps of this phase's window (row-major, S per row)
+    int dy0, dx0;                  // offset of its first tap on the coarse grid; tap t reads (qy + dy0 + t / S, qx + dx0 + t % S)
+    int wofs;                      // byte offset of its weight image inside wp
+    int cps, nsplit;               // split-K plan of this phase (blocks with blockIdx.z >= nsplit leave at once)
+    int wsofs;                     // float offset of its partial-tile slabs inside ws
+    int ooy, oox;                  // py, px
+};
+
 struct Fx3Args {
     const void *xp, *wp;
     const float *xq, *wq;          // scale records of the two operands (stem_common.h)
@@ -79,6 +88,12 @@ struct Fx3Args {
     int nsplit, cps;               // blockIdx.z = split, chunks [split * cps, (split + 1) * cps)
     int xpix;                      // bytes per pixel of the planes buffer x lives in (a 32-channel-aligned slice of a wider tensor)
     signed char dy[MAXTAP], dx[MAXTAP];
+    // transposed face of a stride-2 layer as ONE launch over its four sub-pixel phases (conv_f16x3_gen_kernel<.., .., true>):
+    // blockIdx.x = phase * ptiles + pixel tile of the COARSE grid (OH x OW = H x W here); phase (py, px) is a stride-1 convolution
+    // of the coarse grid with its own regular window of taps and weight image, written to the fine pixels (2 qy + py, 2 qx + px)
+    // of the OHf x OWf output
+    int ptiles, btaps, OHf, OWf;   // btaps: the tap count of the output bound (the largest phase's: one scale for all phases)
+    Fx3Phase ph[4];
 };
 
 __device__ inline int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
@@ -88,7 +103,7 @@ __device__ inline int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 #define TAP_OFFSET(t) (tw_first + ((t) / tw_S) * tw_line + ((t) % tw_S) * tw_col)
 #define TAP_WALK_NEXT()                                                                         \
     do {                                                                                        \
-        const bool wrap_ = pf_t + 1 == a.ntaps, rowend_ = pf_ts + 1 == tw_S;                    \
+        const bool wrap_ = pf_t + 1 == tw_T, rowend_ = pf_ts + 1 == tw_S;                       \
         ++pf_q;                                                                                 \
         pf_to = wrap_ ? tw_first : pf_to + (rowend_ ? tw_line - (tw_S - 1) * tw_col : tw_col);  \
         pf_ts = (wrap_ || rowend_) ? 0 : pf_ts + 1;                                             \
@@ -205,7 +220,7 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
     // prefetch target of the next step (wave-uniform).  The byte offset of tap t inside the planes is carried along in scalar
     // registers (pf_ts = t % S): a table lookup in LDS would drain the wavefront's LDS queue in the middle of the woven block.
     int pf_q = 0, pf_t = 0, pf_kc = 0, pf_ts = 0, pf_to = 0;
-    const int tw_S = a.S, tw_col = pixbytes, tw_line = a.W * pixbytes, tw_first = (a.dy[0] * a.W + a.dx[0]) * pixbytes;
+    const int tw_T = a.ntaps, tw_S = a.S, tw_col = pixbytes, tw_line = a.W * pixbytes, tw_first = (a.dy[0] * a.W + a.dx[0]) * pixbytes;
     auto step = [&](int cur, f32x4 (&ra)[PL], f32x4 (&rb)[BP]) {
         const unsigned char *Ab = As + cur * A_BUF + rdA, *Bb = Bs + cur * B_BUF + rdB;
         const int t = __builtin_amdgcn_readfirstlane(pf_t), kc = __builtin_amdgcn_readfirstlane(pf_kc), q = __builtin_amdgcn_readfirstlane(pf_q);
@@ -654,6 +669,35 @@ __global__ __launch_bounds__(BM * 4) void conv_f16x3_kernel(const Fx3Args a)
 // (dgrad of a conv whose input was activated), fp32 rows with a pitch (the result may be a channel slice of a wider buffer)
 // and / or planes for the next layer.  Weight image per (N tile, chunk): [3][128][64 B], swizzled like the 192-row one.
 enum { GEN_EPI_BIAS = 0, GEN_EPI_LRELU = 1, GEN_EPI_DACT = 2 };
+
+// ---- the transposed face of a stride-2 layer as four sub-pixel phases (forward of nn.ConvTranspose2d, input gradient of a strided
+// nn.Conv2d: spatiotemporalpriors.py:814-829) ---------------------------------------------------------------------------------------
+//   out[b, n, oy, ox] = sum over ch, r, s of in[b, ch, iy, ix] * w[ch][n][r][s]   with   oy = 2 iy - pad + r,  ox = 2 ix - pad + s
+// An output pixel of parity (py, px) = (oy & 1, ox & 1) only meets the taps r = py + pad (mod 2), s = px + pad (mod 2): on the COARSE
+// grid (qy, qx) = (oy >> 1, ox >> 1) phase (py, px) is a stride-1 convolution whose window holds those taps, tap r reading the
+// coarse row qy + (py + pad - r) / 2.  Windows are kept in ascending offset order (descending r): position jy = (rmax - r) / 2.
+// For 5 x 5, pad 2 the four windows are 3x3, 3x2, 2x3, 2x2 = all 25 taps once: no multiplication by structural zeros.
+struct TAxis {
+    int cnt, d0, rmax;             // taps of this parity, offset of the first (smallest offset), largest r
+};
+__host__ __device__ inline TAxis tconv_axis(int R, int pad, int par)
+{
+    TAxis t;
+    const int rmin = (par + pad) & 1;
+    t.cnt = rmin < R ? (R - 1 - rmin) / 2 + 1 : 0;
+    t.rmax = rmin + 2 * (t.cnt - 1);
+    t.d0 = (par + pad - t.rmax) / 2;               // even numerator: exact
+    return t;
+}
+// position of tap (r, s) of the R x S window in the phase-ordered tap sequence [phase 0 | phase 1 | phase 2 | phase 3], phase = 2 py + px
+__host__ __device__ inline int tconv_slot(int R, int S, int pad, int r, int s)
+{
+    const int py = (r + pad) & 1, px = (s + pad) & 1;
+    int base = 0;
+    for (int p = 0; p < 2 * py + px; ++p) base += tconv_axis(R, pad, p >> 1).cnt * tconv_axis(S, pad, p & 1).cnt;
+    const TAxis ay = tconv_axis(R, pad, py), ax = tconv_axis(S, pad, px);
+    return base + ((ay.rmax - r) / 2) * ax.cnt + (ax.rmax - s) / 2;
+}
 constexpr int GBN = 128;
 constexpr int GB_PLANE = GBN * 64, GB_BUF = NPL * GB_PLANE;          // 16384
 constexpr int GTP = GBN + 4;                                         // fp32 pitch of the epilogue tile
@@ -668,10 +712,24 @@ constexpr int glds(int gbm) { return glds_main(gbm) + 32 * 4; }          // 4928
 // fetched once per workgroup: with three products per fp32 product the 64-pixel form is bound by that L2 -> LDS traffic
 // (24 KB per chunk for 1.6 MF), the 128-pixel form moves 32 KB for twice the work.
 // MS = rows of the MFMA shape (see conv_f16x3_kernel): 32, or 16 = v_mfma_f32_16x16x32_f16 with the permuted accumulator layout
-template <int GBM, int MS>
+// PH: the launch covers the four sub-pixel phases of a transposed face (Fx3Args::ph; host: stem_tconv2d_f16x3_fwd)
+template <int GBM, int MS, bool PH = false>
 __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Args a)
 {
     static_assert(MS == 32 || MS == 16, "MFMA shape");
+    int bxt = blockIdx.x, phase = 0;
+    if constexpr (PH) {
+        phase = blockIdx.x / a.ptiles;
+        bxt = blockIdx.x - phase * a.ptiles;
+    }
+    const int ntaps = PH ? a.ph[phase].ntaps : a.ntaps, tapS = PH ? a.ph[phase].S : a.S;
+    const int cps = PH ? a.ph[phase].cps : a.cps, nsplit = PH ? a.ph[phase].nsplit : a.nsplit;
+    const int pdy0 = PH ? a.ph[phase].dy0 : (int)a.dy[0], pdx0 = PH ? a.ph[phase].dx0 : (int)a.dx[0];
+    const int wofs = PH ? a.ph[phase].wofs : 0;
+    if constexpr (PH) {
+        if ((int)blockIdx.z >= nsplit) return;        // the whole workgroup: this phase has fewer splits than the launch's z extent
+    }
+    float *const wsb = PH ? a.ws + a.ph[phase].wsofs : a.ws;
     constexpr int GNT = GBM * 4, GA_PLANE = GBM * 64, GA_BUF = NPL * GA_PLANE;
     constexpr int PL = NPL, BPC = NPL * GBN * 4 / GNT;         // planes; 16-byte weight pieces per thread and chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -681,7 +739,7 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Mtot = a.B * a.OH * a.OW;
-    const int bm0 = blockIdx.x * GBM, bn0 = blockIdx.y * GBN, zsplit = blockIdx.z;
+    const int bm0 = bxt * GBM, bn0 = blockIdx.y * GBN, zsplit = blockIdx.z;
     const int nslab = a.C / KC, pixbytes = a.xpix;
 
     const int srow = tid >> 2, scol = tid & 3;
@@ -694,15 +752,15 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
         const int ohw = a.OH * a.OW, b = mm / ohw, rem = mm - b * ohw, qy = rem / a.OW, qx = rem - qy * a.OW;
         const int by = qy * a.stride, bx = qx * a.stride;
         pb = ((b * a.H + by) * a.W + bx) * pixbytes + scol * 16;
-        for (int t = 0; t < a.ntaps; ++t) {
-            const int iy = by + a.dy[t], ix = bx + a.dx[t];
+        for (int t = 0; t < ntaps; ++t) {
+            const int iy = by + (PH ? pdy0 + t / tapS : (int)a.dy[t]), ix = bx + (PH ? pdx0 + t % tapS : (int)a.dx[t]);
             if (ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) pmask |= 1u << t;
         }
     }
     const int a_st = srow * 64 + ((scol ^ ((srow >> 2) & 3)) << 4);
-    const int nchunks = a.ntaps * nslab;
-    const int q_begin = zsplit * a.cps;
-    const int q_end = q_begin + a.cps < nchunks ? q_begin + a.cps : nchunks;
+    const int nchunks = ntaps * nslab;
+    const int q_begin = zsplit * cps;
+    const int q_end = q_begin + cps < nchunks ? q_begin + cps : nchunks;
     const int q_last = q_end - 1;
     const int wbase = blockIdx.y * nchunks;          // this N tile's chunk sequence inside the packed weights
     __syncthreads();
@@ -712,7 +770,7 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
 
     f32x4 raA[PL], rbA[BPC], raB[PL], rbB[BPC];
     auto gload = [&](int t, int tA, int kc, int q, f32x4 (&ra)[PL], f32x4 (&rb)[BPC]) {
-        const int sA = kc * SLAB, sB = (wbase + q) * GB_BUF;
+        const int sA = kc * SLAB, sB = wofs + (wbase + q) * GB_BUF;
         const int mk = __builtin_amdgcn_sbfe((int)pmask, (unsigned)t, 1u);
         const int off = ((pb + tA) & mk) | (OOR & ~mk);
 #pragma unroll
@@ -745,7 +803,7 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     int pf_q = 0, pf_t = 0, pf_kc = 0, pf_ts = 0, pf_to = 0;          // see conv_f16x3_kernel
-    const int tw_S = a.S, tw_col = pixbytes, tw_line = a.W * pixbytes, tw_first = (a.dy[0] * a.W + a.dx[0]) * pixbytes;
+    const int tw_T = ntaps, tw_S = tapS, tw_col = pixbytes, tw_line = a.W * pixbytes, tw_first = (pdy0 * a.W + pdx0) * pixbytes;
     auto step = [&](int cur, f32x4 (&ra)[PL], f32x4 (&rb)[BPC]) {
         const unsigned char *Ab = As + cur * GA_BUF + rdA, *Bb = Bs + cur * GB_BUF + rdB;
         const int t = __builtin_amdgcn_readfirstlane(pf_t), kc = __builtin_amdgcn_readfirstlane(pf_kc), q = __builtin_amdgcn_readfirstlane(pf_q);
@@ -820,8 +878,8 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
     };
     auto chunk_of = [&](int q, int &t, int &kc) {
         q = q < q_last ? q : q_last;
-        kc = q / a.ntaps;
-        t = q - kc * a.ntaps;
+        kc = q / ntaps;
+        t = q - kc * ntaps;
         return q;
     };
     if (q_begin < q_end) {
@@ -848,7 +906,7 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
         if (a.bias)
             for (int n = tid; n < a.N; n += GNT) bm = fmaxf(bm, fabsf(a.bias[n]));
         bm = block_max(bm, qred);
-        const int oe = q_exp((float)(a.C * a.ntaps) * xmax * wmax + bm);
+        const int oe = q_exp((float)(a.C * (PH ? a.btaps : ntaps)) * xmax * wmax + bm);
         oscale = q_pow2(oe);
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.yq[1] = q_pow2(-oe);
     }
@@ -902,8 +960,21 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
     constexpr int ERS = GNT / 32, ER = GBM / ERS;                   // 8 pieces per thread
     const int ec4 = tid & 31, er0 = tid >> 5;
     f32x4 ev[ER];
-    if (a.nsplit > 1) {
-        float *wsp = a.ws + (size_t)zsplit * Mtot * Npad;
+    // output pixel of tile pixel m: itself, or -- phases -- the fine pixel (2 qy + py, 2 qx + px) of the OHf x OWf output
+    auto OROW = [&](int m) -> size_t {
+        if constexpr (!PH) return (size_t)m;
+        const int ohw = a.OH * a.OW, b = m / ohw, rem = m - b * ohw, qy = rem / a.OW, qx = rem - qy * a.OW;
+        return ((size_t)b * a.OHf + 2 * qy + a.ph[phase].ooy) * a.OWf + 2 * qx + a.ph[phase].oox;
+    };
+    // the tile pixel exists (and -- phases -- its fine pixel lies inside an odd-sized fine grid OHf = 2 OH - 1)
+    auto MOK = [&](int m) -> bool {
+        if (m >= Mtot) return false;
+        if constexpr (!PH) return true;
+        const int ohw = a.OH * a.OW, rem = m % ohw, qy = rem / a.OW, qx = rem - qy * a.OW;
+        return 2 * qy + a.ph[phase].ooy < a.OHf && 2 * qx + a.ph[phase].oox < a.OWf;
+    };
+    if (nsplit > 1) {
+        float *wsp = wsb + (size_t)zsplit * Mtot * Npad;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -918,12 +989,12 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
         __syncthreads();
         if (tid == 0) {
             int *c = a.cnt + blockIdx.y * gridDim.x + blockIdx.x;
-            tapi[0] = splitk_last_arriver(c, a.nsplit);
+            tapi[0] = splitk_last_arriver(c, nsplit);
         }
         __syncthreads();
         if (!tapi[0]) return;
         constexpr int SC1 = 16;               // sc1: read at the device-coherent level, not this XCD's L2
-        const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)((size_t)a.nsplit * Mtot * Npad * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(wsb, 0, (int)((size_t)nsplit * Mtot * Npad * 4), 0x00020000);
         const int sstep = Mtot * Npad * 4;
         // the last arriver sums the slabs in split order, 4 pieces x 4 splits in flight (the read is latency-bound: ~1 us
         // per dependent round of cross-XCD sc1 loads; it used to keep 4 loads in flight per thread)
@@ -938,14 +1009,14 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
         // (4 pieces x 4 splits = 16 loads = 64 registers per round: the kernel keeps its two workgroups per CU -- 128 registers)
 #pragma unroll
         for (int kb = 0; kb < ER; kb += 4)
-            for (int sp = 0; sp < a.nsplit; sp += 4) {
+            for (int sp = 0; sp < nsplit; sp += 4) {
                 f32x4 tt[4][4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
-                        tt[k][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, sp + u < a.nsplit ? eoff[kb + k] : OOR,
-                                                                                                      (sp + u < a.nsplit ? sp + u : 0) * sstep, SC1));
+                        tt[k][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, sp + u < nsplit ? eoff[kb + k] : OOR,
+                                                                                                      (sp + u < nsplit ? sp + u : 0) * sstep, SC1));
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -976,7 +1047,7 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
 #pragma unroll
         for (int k = 0; k < ER; ++k) {
             const int m = bm0 + er0 + ERS * k;
-            ez[k] = (colok && m < Mtot) ? *reinterpret_cast<const f32x4 *>(a.z + (size_t)m * a.ldz + ecol) : f32x4{1.f, 1.f, 1.f, 1.f};
+            ez[k] = (colok && MOK(m)) ? *reinterpret_cast<const f32x4 *>(a.z + OROW(m) * a.ldz + ecol) : f32x4{1.f, 1.f, 1.f, 1.f};
         }
     }
 #pragma unroll
@@ -990,8 +1061,8 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = ez[k][c] > 0.f ? v[c] : v[c] * a.slope;
         }
-        if (colok && m < Mtot) {
-            if (a.y) *reinterpret_cast<f32x4 *>(a.y + (size_t)m * a.ldy + ecol) = v;
+        if (colok && MOK(m)) {
+            if (a.y) *reinterpret_cast<f32x4 *>(a.y + OROW(m) * a.ldy + ecol) = v;
             omax = fmaxf(fmaxf(omax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         }
         if (a.yp) *reinterpret_cast<f32x4 *>(&T[row * GTP + ec4 * 4]) = v;
@@ -1013,7 +1084,7 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
         for (int e = tid; e < GBM * (GBN / 8); e += GNT) {
             const int row = e / (GBN / 8), c8 = e - row * (GBN / 8);
             const int m = bm0 + row, n = bn0 + c8 * 8;
-            if (m >= Mtot || n >= a.N) continue;            // N % 32 == 0 for planes (host check)
+            if (!MOK(m) || n >= a.N) continue;              // N % 32 == 0 for planes (host check)
             const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&T[row * GTP + c8 * 8]);
             const f32x4 v1 = *reinterpret_cast<const f32x4 *>(&T[row * GTP + c8 * 8 + 4]);
             h16x8 h0, h1;
@@ -1025,7 +1096,7 @@ __global__ __launch_bounds__(GBM * 4, 2) void conv_f16x3_gen_kernel(const Fx3Arg
                 q_split(v1[c], oscale, x0, x1);
                 h0[4 + c] = x0; h1[4 + c] = x1;
             }
-            unsigned char *dst = yp + (size_t)m * opix + (n >> 5) * SLAB + ((n >> 3) & 3) * 16;
+            unsigned char *dst = yp + OROW(m) * opix + (n >> 5) * SLAB + ((n >> 3) & 3) * 16;
             *reinterpret_cast<h16x8 *>(dst) = h0;
             *reinterpret_cast<h16x8 *>(dst + 64) = h1;
         }
@@ -1102,6 +1173,19 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
     const float wscale = q_pow2(we);
     if (blockIdx.x == 0 && threadIdx.x == 0) wq[1] = q_pow2(-we);
     float *wz = (d.bmax && d.taps > 0 && d.taps < d.R * d.S) ? static_cast<float *>(const_cast<void *>(d.w)) : nullptr;      // masked taps zeroed here (no maximum pass did it)
+    // flip == 2: the four phase images of a transposed face (tconv_slot): transposed indexing like the flip role, taps permuted into
+    // phase order, one image per phase behind the other (sum of the phases' taps = RS: the record sits where it always does)
+    __shared__ int pslot[MAXTAP], pT[4], pbase[4];
+    if (d.flip == 2) {
+        if (threadIdx.x < d.R * d.S) pslot[threadIdx.x] = tconv_slot(d.R, d.S, d.R / 2, threadIdx.x / d.S, threadIdx.x % d.S);
+        if (threadIdx.x < 4) {
+            int b = 0;
+            for (int p = 0; p < (int)threadIdx.x; ++p) b += tconv_axis(d.R, d.R / 2, p >> 1).cnt * tconv_axis(d.S, d.S / 2, p & 1).cnt;
+            pbase[threadIdx.x] = b;
+            pT[threadIdx.x] = tconv_axis(d.R, d.R / 2, threadIdx.x >> 1).cnt * tconv_axis(d.S, d.S / 2, threadIdx.x & 1).cnt;
+        }
+        __syncthreads();
+    }
     const int units = ntile * (GBN / PKR) * nslab;
     // the element loops divide by RS and 32 RS / PKR RS per element: with the window size a compile-time constant (1, 9, 25: every
     // layer of the model) those are multiplications -- the pass is bound by its index arithmetic, not by HBM, otherwise
@@ -1117,7 +1201,7 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
                 for (int e = threadIdx.x; e < 32 * PKR * RS; e += 256) {
                     const int c = e / (PKR * RS), rem = e - c * (PKR * RS), r = rem / RS, tp = rem - r * RS;
                     const int n = n0 + r;
-                    tile[(r * 32 + c) * MAXTAP + (RS - 1 - tp)] = n < d.N ? w[((size_t)(slab * 32 + c) * d.N + n) * RS + tp] : 0.f;
+                    tile[(r * 32 + c) * MAXTAP + (d.flip == 2 ? pslot[tp] : RS - 1 - tp)] = n < d.N ? w[((size_t)(slab * 32 + c) * d.N + n) * RS + tp] : 0.f;
                 }
             } else {
                 // element (row r, channel c, tap): w[((n0 + r) * C + slab * 32 + c) * RS + tap]: for fixed r, 32 * RS contiguous floats
@@ -1144,7 +1228,11 @@ __global__ __launch_bounds__(256) void pack_weight_gen_multi_kernel(const PackTa
                     q_split(tile[(r * 32 + p * 8 + c) * MAXTAP + tap], wscale, x0, x1);
                     h[0][c] = x0; h[1][c] = x1;
                 }
-                const long qq = (long)nt * nchunks + slab * T + tap;
+                long qq = (long)nt * nchunks + slab * T + tap;
+                if (d.flip == 2) {            // image of phase ph: [N tile][slab * T_ph + local tap], behind the earlier phases' images
+                    const int ph = tap >= pbase[3] ? 3 : (tap >= pbase[2] ? 2 : (tap >= pbase[1] ? 1 : 0));
+                    qq = (long)ntile * nslab * pbase[ph] + (long)nt * (nslab * pT[ph]) + slab * pT[ph] + (tap - pbase[ph]);
+                }
                 unsigned char *dst = wp + qq * GB_BUF + nl * 64 + ((p ^ ((nl >> 2) & 3)) << 4);
     #pragma unroll
                 for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<h16x8 *>(dst + pl * GB_PLANE) = h[pl];
@@ -1577,6 +1665,8 @@ STEM_EXPORT int stem_f16x2_pack_conv_weights_multi(const stem_f16x2_pack_desc *d
     for (int i = 0; i < n; ++i) {
         const stem_f16x2_pack_desc &d = descs_host[i];
         STEM_CHECK_ARG(d.taps >= 0 && d.taps <= d.R * d.S && (d.taps == 0 || !d.flip), "stem_f16x2_pack_conv_weights_multi: descriptor %d: taps", i);
+        STEM_CHECK_ARG(d.flip >= 0 && d.flip <= 2 && (d.flip != 2 || (d.R == d.S && (d.R & 1))),
+                       "stem_f16x2_pack_conv_weights_multi: descriptor %d: flip 0 | 1 | 2 (2 = phase images of a transposed face: odd square windows)", i);
         mt.w[i] = static_cast<float *>(const_cast<void *>(d.w));
         mt.q[i] = reinterpret_cast<float *>(static_cast<unsigned char *>(d.wp) + gen_image_bytes(d.N, d.C, d.R, d.S));
         mt.n[i] = (long)d.N * d.C * d.R * d.S;
@@ -1724,5 +1814,133 @@ STEM_EXPORT int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int x
     else
         hipLaunchKernelGGL((conv_f16x3_gen_kernel<64, 32>), grid, dim3(256), glds(64), (hipStream_t)stream, a);
     STEM_LAUNCH_CHECK("stem_conv2d_f16x3_gen_fwd");
+    return 0;
+}
+
+namespace {
+// chunks per workgroup of a four-phase launch: every workgroup gets (about) the same number of chunks whatever its phase; the
+// cost model of gen_split with the phases' workgroups added up
+int tconv_cps(int tiles_per_phase, const int (&nchunks)[4])
+{
+    const int forced = stem_tuning(STEM_TUNE_FX3_SPLIT);
+    int maxc = 0;
+    for (int p = 0; p < 4; ++p) maxc = nchunks[p] > maxc ? nchunks[p] : maxc;
+    if (forced > 0) return cdiv(maxc, forced < maxc ? forced : maxc);
+    int best = maxc;
+    double best_cost = 1e30;
+    for (int cps = maxc; cps >= 4; --cps) {
+        int wgs = 0, maxns = 0;
+        for (int p = 0; p < 4; ++p) {
+            const int ns = cdiv(nchunks[p], cps);
+            wgs += tiles_per_phase * ns;
+            maxns = ns > maxns ? ns : maxns;
+        }
+        if (maxns > 16) break;
+        const int rounds = cdiv(wgs, 512);          // two workgroups per CU
+        const double cost = rounds * (cps + 6.0) * (wgs <= 256 ? 1.67 : 1.0) + (maxns > 1 ? 0.3 * maxns : 0.0);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = cps;
+        }
+    }
+    return best;
+}
+}   // namespace
+
+STEM_EXPORT size_t stem_tconv2d_f16x3_workspace_bytes(int B, int H, int W, int C, int N, int R)
+{
+    if (C % 32 || R < 1 || R * R > MAXTAP || !(R & 1)) return 0;
+    const int M = B * H * W, ntn = cdiv(N, GBN);
+    // room for any plan: 16 splits of every phase
+    return kGenCntBytes + (size_t)4 * 16 * M * ntn * GBN * sizeof(float);
+}
+
+/* The transposed face of a stride-2, R x R, padding R/2 layer whose fine grid is exactly twice the coarse one:
+ *   forward of nn.ConvTranspose2d(C, N, R, stride=2, padding=R/2, output_padding=1)   (HD.0 / HD.2, spatiotemporalpriors.py:822-826)
+ *   input gradient of nn.Conv2d(N, C, R, stride=2, padding=R/2) on an even-sized input   (HE.2 / HE.4, :814-818, torch autograd)
+ * x: planes of the coarse tensor [B, H, W, C]; wp: the four phase images (stem_f16x2_pack_conv_weights_multi, flip = 2, rows =
+ * the N outputs, contraction channels C); y / yp: fp32 rows / planes of the fine tensor [B, OHf, OWf, N], OHf = 2H (or 2H - 1: the
+ * input gradient of a strided convolution whose input had an odd number of rows; same for OWf); epi / z as in
+ * stem_conv2d_f16x3_gen_fwd (z: rows of the FINE tensor).  One launch: blockIdx.x = phase x coarse pixel tile. */
+STEM_EXPORT int stem_tconv2d_f16x3_fwd(const void *xp, const float *xq, int xpix, const void *wp, const float *bias, int epi, float slope,
+                                        const float *z, int ldz, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R,
+                                        int OHf, int OWf, void *ws, size_t ws_bytes, void *stream)
+{
+    STEM_CHECK_ARG(xp && xq && wp && (y || yp) && (yq || !yp), "stem_tconv2d_f16x3_fwd: null pointer (planes come with their scale records)");
+    STEM_CHECK_ARG((OHf == 2 * H || OHf == 2 * H - 1) && (OWf == 2 * W || OWf == 2 * W - 1),
+                   "stem_tconv2d_f16x3_fwd: the fine grid is 2H or 2H - 1 rows (the odd-sized input of a strided convolution), got %d x %d for %d x %d", OHf, OWf, H, W);
+    STEM_CHECK_ARG(epi >= GEN_EPI_BIAS && epi <= GEN_EPI_DACT && (epi == GEN_EPI_BIAS || fabsf(slope) <= 1.f), "stem_tconv2d_f16x3_fwd: epilogue %d", epi);
+    STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && C >= 32 && C % 32 == 0 && N >= 4 && N % 4 == 0 && R >= 3 && (R & 1) && R * R <= MAXTAP,
+                   "stem_tconv2d_f16x3_fwd: C %% 32 == 0, N %% 4 == 0, odd 3 <= R, R*R <= %d (C=%d N=%d R=%d)", MAXTAP, C, N, R);
+    STEM_CHECK_ARG(!yp || N % 32 == 0, "stem_tconv2d_f16x3_fwd: planes output needs N %% 32 == 0 (N=%d)", N);
+    STEM_CHECK_ARG(!y || (ldy >= N && ldy % 4 == 0 && ((uintptr_t)y & 15) == 0), "stem_tconv2d_f16x3_fwd: y rows must be 16-byte aligned, ldy >= N");
+    STEM_CHECK_ARG(epi != GEN_EPI_DACT || (z && ldz >= N && ldz % 4 == 0 && ((uintptr_t)z & 15) == 0), "stem_tconv2d_f16x3_fwd: DACT needs z (16-byte aligned rows)");
+    if (xpix == 0) xpix = (C / 32) * SLAB;
+    STEM_CHECK_ARG(xpix >= (C / 32) * SLAB && xpix % SLAB == 0, "stem_tconv2d_f16x3_fwd: xpix must be a multiple of %d bytes covering C channels", SLAB);
+    const int pad = R / 2, nslab = C / 32, M = B * H * W, ntn = cdiv(N, GBN);
+    const size_t xb = (size_t)B * H * W * xpix, wb = gen_image_bytes(N, C, R, R);
+    STEM_CHECK_ARG(xb < 0x7FFFFF00ull && wb < 0x7FFFFF00ull && (size_t)4 * M * ntn * GBN * 4 < 0x7FFFFF00ull,
+                   "stem_tconv2d_f16x3_fwd: operand views must stay below 2 GiB (split the batch)");
+    int nch[4], maxT = 0;
+    Fx3Args a;
+    memset(&a, 0, sizeof(a));
+    int tapbase = 0;
+    for (int p = 0; p < 4; ++p) {
+        const TAxis ay = tconv_axis(R, pad, p >> 1), ax = tconv_axis(R, pad, p & 1);
+        Fx3Phase &ph = a.ph[p];
+        ph.ntaps = ay.cnt * ax.cnt;
+        ph.S = ax.cnt;
+        ph.dy0 = ay.d0;
+        ph.dx0 = ax.d0;
+        ph.ooy = p >> 1;
+        ph.oox = p & 1;
+        ph.wofs = (int)((size_t)ntn * nslab * tapbase * GB_BUF);
+        tapbase += ph.ntaps;
+        nch[p] = nslab * ph.ntaps;
+        maxT = ph.ntaps > maxT ? ph.ntaps : maxT;
+        STEM_CHECK_ARG(ph.ntaps >= 1, "stem_tconv2d_f16x3_fwd: empty phase (R=%d)", R);
+    }
+    const int bm = gen_bm(4 * M, ntn, nch[0]), ptiles = cdiv(M, bm);
+    int cps = tconv_cps(ptiles * ntn, nch);
+    // the slabs of all phases sit behind each other in ws; without room for the plan the launch is unsplit (same result up to order)
+    size_t wsfl = 0;
+    int maxns = 1;
+    for (int pass = 0; pass < 2; ++pass) {
+        wsfl = 0;
+        maxns = 1;
+        for (int p = 0; p < 4; ++p) {
+            Fx3Phase &ph = a.ph[p];
+            ph.cps = cps < nch[p] ? cps : nch[p];
+            ph.nsplit = cdiv(nch[p], ph.cps);
+            ph.wsofs = (int)wsfl;
+            if (ph.nsplit > 1) wsfl += (size_t)ph.nsplit * M * ntn * GBN;
+            maxns = ph.nsplit > maxns ? ph.nsplit : maxns;
+        }
+        const bool fits = ws && kGenCntBytes + wsfl * sizeof(float) <= ws_bytes && (size_t)4 * ptiles * ntn * sizeof(int) <= kGenCntBytes &&
+                          wsfl * sizeof(float) < 0x7FFFFF00ull;
+        if (maxns == 1 || fits) break;
+        cps = 1 << 30;                              // second pass: unsplit
+    }
+    a.xp = xp; a.wp = wp; a.bias = bias; a.y = y; a.yp = yp; a.ldy = ldy; a.z = z; a.ldz = ldz; a.epi = epi; a.slope = slope;
+    a.xq = xq; a.yq = yq; a.wq = reinterpret_cast<const float *>(static_cast<const unsigned char *>(wp) + wb);
+    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.OH = H; a.OW = W; a.stride = 1;
+    a.xbytes = (int)xb; a.wbytes = (int)wb; a.xpix = xpix;
+    a.ptiles = ptiles; a.btaps = maxT; a.OHf = OHf; a.OWf = OWf;
+    if (maxns > 1) {
+        a.cnt = static_cast<int *>(ws);
+        a.ws = reinterpret_cast<float *>(static_cast<unsigned char *>(ws) + kGenCntBytes);
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_gen_kernel<64, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, glds(64));
+        (void)hipFuncSetAttribute((const void *)conv_f16x3_gen_kernel<128, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, glds(128));
+        attr_done = true;
+    }
+    const dim3 grid(4 * ptiles, ntn, maxns);
+    if (bm == 128)
+        hipLaunchKernelGGL((conv_f16x3_gen_kernel<128, 16, true>), grid, dim3(512), glds(128), (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((conv_f16x3_gen_kernel<64, 16, true>), grid, dim3(256), glds(64), (hipStream_t)stream, a);
+    STEM_LAUNCH_CHECK("stem_tconv2d_f16x3_fwd");
     return 0;
 }

@@ -614,6 +614,12 @@ bool stem_fx3_img_eligible(int B, int H, int W, int N, int R, int S, int stride,
     // at least half of every tile's pixels exist on average (also what keeps the scale record's slots within planes_slots())
     if ((long)H * W * 2 < tiles * TPX) return false;
     if ((long)B * tiles * cdiv(N, IBN) > 16384) return false;       // arrival counters
+    // This form exists for launches that cannot fill the chip by pixels (the 16 x 16 latents of the training step: 32 pixel tiles
+    // of 128): one workgroup per CU, the halo staged once per channel slab, deep split-K.  A launch whose 128-pixel form already
+    // has two workgroups for every CU gains nothing from it and loses the second workgroup per CU: the variable-rate models' 3 x 3
+    // layers at 64 x 64 .. 256 x 256 (configs[4], B = 16) ran 1.45 s per GOP iteration through this form against 1.00 s through the
+    // 128-pixel form (profiles/r05_roi_bisect.log; round 4 shipped without this rule: VERDICT r4 weak #4).  sel == 2 (sweeps) skips it.
+    if (sel != 2 && (long)cdiv(B * H * W, 128) * cdiv(N, 128) >= 2 * 256) return false;
     return true;
 }
 

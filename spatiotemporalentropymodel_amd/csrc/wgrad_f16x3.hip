@@ -40,6 +40,7 @@ struct Wg3Args {
     int B, H, W, C, K, OH, OW, T;
     int nsplit, cps;               // pixel chunks per split
     int xbytes, dybytes;
+    int stride;                    // per-tap form only: output pixel (oy, ox) of tap t reads x at (oy * stride + dy[t], ox * stride + dx[t])
     signed char dy[MAXTAP], dx[MAXTAP];
 };
 
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad_f16x3_kernel(const Wg3Args a)
         const bool ok = m < M;
         const int mm = ok ? m : 0;
         const int b = mm / ohw, rem = mm - b * ohw, oy = rem / a.OW, ox = rem - oy * a.OW;
-        const int iy = oy + tdy, ix = ox + tdx;
+        const int iy = oy * a.stride + tdy, ix = ox * a.stride + tdx;
         const int offa = (ok && ka_ok) ? m * a.dypix + a_col : OOR;
         const int offb = (ok && cb_ok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? ((b * a.H + iy) * a.W + ix) * a.xpix + b_col : OOR;
 #pragma unroll
@@ -505,6 +506,7 @@ STEM_EXPORT int stem_conv2d_wgrad_f16x3(const void *xp, const float *xq, int xpi
     a.xp = xp; a.dyp = dyp; a.xq = xq; a.dyq = dyq; a.dwp = dwp; a.bias_part = bias_part; a.xpix = xpix; a.dypix = dypix;
     a.B = B; a.H = H; a.W = W; a.C = C; a.K = K; a.OH = OH; a.OW = OW; a.T = R * S;
     a.xbytes = (int)xb; a.dybytes = (int)db;
+    a.stride = 1;
     const int nchunks = cdiv(B * OH * OW, PX);
     a.nsplit = splits;
     a.cps = cdiv(nchunks, splits);
@@ -539,5 +541,61 @@ STEM_EXPORT int stem_conv2d_wgrad_f16x3(const void *xp, const float *xq, int xpi
     const dim3 grid(cdiv(K, TK) * cdiv(C, TC), R * S, splits);
         hipLaunchKernelGGL(wgrad_f16x3_kernel, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
     STEM_LAUNCH_CHECK("stem_conv2d_wgrad_f16x3");
+    return 0;
+}
+
+/* Weight gradient of a STRIDED layer from planes operands (per-tap form; HE.2 / HE.4 and -- with the operands' roles swapped --
+ * HD.0 / HD.2: spatiotemporalpriors.py:814-829, torch autograd):
+ *   dW[k][c][r][s] = sum over coarse pixels (b, oy, ox) of g[b, oy, ox][k] * f[b, oy * stride + r - pad, ox * stride + s - pad][c]
+ * g (`dyp`, K channels) lives on the coarse grid OH x OW = ((H + 2 pad - R) / stride + 1) x ..., f (`xp`, C channels) on the fine grid
+ * H x W.  nn.Conv2d: f = the layer's input, g = the gradient of its output, slabs [t][K][C].  nn.ConvTranspose2d (weight [Cin][Cout]):
+ * g = the layer's INPUT (K = Cin), f = the gradient of its OUTPUT (C = Cout), slabs [t][Cin][Cout] (STEM_UNPACK_DECONV). */
+STEM_EXPORT int stem_wgrad_f16x3_strided_splits(int B, int H, int W, int C, int K, int R, int S, int stride, int pad)
+{
+    if (stride < 1) return 0;
+    const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+    if (OH < 1 || OW < 1) return 0;
+    return plan_splits(B, OH, OW, C, K, R * S);
+}
+
+STEM_EXPORT int stem_conv2d_wgrad_f16x3_strided(const void *xp, const float *xq, int xpix, const void *dyp, const float *dyq, int dypix, float *dwp,
+                                                 float *bias_part, int B, int H, int W, int C, int K, int R, int S, int stride, int pad, int splits,
+                                                 void *stream)
+{
+    STEM_CHECK_ARG(xp && xq && dyp && dyq && dwp, "stem_conv2d_wgrad_f16x3_strided: null pointer");
+    STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && C >= 32 && C % 32 == 0 && K >= 32 && K % 32 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP && pad >= 0 &&
+                   stride >= 1 && stride <= 4,
+                   "stem_conv2d_wgrad_f16x3_strided: C %% 32 == 0, K %% 32 == 0, R*S <= %d, 1 <= stride <= 4 (C=%d K=%d R=%d S=%d stride=%d)", MAXTAP, C, K, R, S, stride);
+    const int OH = (H + 2 * pad - R) / stride + 1, OW = (W + 2 * pad - S) / stride + 1;
+    STEM_CHECK_ARG(OH >= 1 && OW >= 1, "stem_conv2d_wgrad_f16x3_strided: empty output");
+    if (xpix == 0) xpix = (C / 32) * SLAB;
+    if (dypix == 0) dypix = (K / 32) * SLAB;
+    STEM_CHECK_ARG(xpix >= (C / 32) * SLAB && xpix % SLAB == 0 && dypix >= (K / 32) * SLAB && dypix % SLAB == 0,
+                   "stem_conv2d_wgrad_f16x3_strided: pixel pitches must be multiples of %d bytes covering the channels", SLAB);
+    const size_t xb = (size_t)B * H * W * xpix, db = (size_t)B * OH * OW * dypix;
+    STEM_CHECK_ARG(xb < 0x7FFFFF00ull && db < 0x7FFFFF00ull, "stem_conv2d_wgrad_f16x3_strided: operand views must stay below 2 GiB");
+    STEM_CHECK_ARG(splits == plan_splits(B, OH, OW, C, K, R * S), "stem_conv2d_wgrad_f16x3_strided: splits must come from stem_wgrad_f16x3_strided_splits");
+    Wg3Args a;
+    memset(&a, 0, sizeof(a));
+    a.xp = xp; a.dyp = dyp; a.xq = xq; a.dyq = dyq; a.dwp = dwp; a.bias_part = bias_part; a.xpix = xpix; a.dypix = dypix;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.K = K; a.OH = OH; a.OW = OW; a.T = R * S;
+    a.xbytes = (int)xb; a.dybytes = (int)db;
+    a.stride = stride;
+    const int nchunks = cdiv(B * OH * OW, PX);
+    a.nsplit = splits;
+    a.cps = cdiv(nchunks, splits);
+    for (int r = 0; r < R; ++r)
+        for (int s = 0; s < S; ++s) {
+            a.dy[r * S + s] = (signed char)(r - pad);
+            a.dx[r * S + s] = (signed char)(s - pad);
+        }
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)wgrad_f16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_done = true;
+    }
+    const dim3 grid(cdiv(K, TK) * cdiv(C, TC), R * S, splits);
+    hipLaunchKernelGGL(wgrad_f16x3_kernel, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+    STEM_LAUNCH_CHECK("stem_conv2d_wgrad_f16x3_strided");
     return 0;
 }

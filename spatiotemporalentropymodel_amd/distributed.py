@@ -385,16 +385,17 @@ def _parse_cpulist(text):
     return cpus
 
 
-def gpu_cpu_lists(sysfs_root="/sys"):
-    """[cpus next to HIP device 0, device 1, ...]: the GPU nodes of the KFD topology in node order (= HIP's default device
-    order), each with the `local_cpulist` of its PCI device (the cores of the GPU's NUMA node).  Reads sysfs only -- no HIP
-    call, so a rank can use it before it initialises its GPU.  [] when the topology cannot be read."""
+def gpu_cpu_lists(sysfs_root="/sys", with_ids=False):
+    """[cpus next to physical GPU 0, GPU 1, ...]: the GPU nodes of the KFD topology in node order (= HIP's device order when no
+    *_VISIBLE_DEVICES variable re-maps it: visible_device_map), each with the `local_cpulist` of its PCI device (the cores of the
+    GPU's NUMA node).  Reads sysfs only -- no HIP call, so a rank can use it before it initialises its GPU.  [] when the topology
+    cannot be read.  with_ids: -> (lists, [unique_id of each GPU as a hex string or None])."""
     nodes_dir = os.path.join(sysfs_root, "class", "kfd", "kfd", "topology", "nodes")
-    out = []
+    out, uids = [], []
     try:
         ids = sorted(int(n) for n in os.listdir(nodes_dir) if n.isdigit())
     except OSError:
-        return []
+        return ([], []) if with_ids else []
     for nid in ids:
         try:
             props = dict(line.split(None, 1) for line in open(os.path.join(nodes_dir, str(nid), "properties")) if " " in line.strip())
@@ -408,18 +409,61 @@ def gpu_cpu_lists(sysfs_root="/sys"):
         except (OSError, ValueError):
             cpus = []
         out.append(cpus)
-    return out
+        try:
+            uids.append(format(int(props.get("unique_id", "0").strip()), "x") or None)
+        except ValueError:
+            uids.append(None)
+    return (out, uids) if with_ids else out
 
 
-def pin_rank_to_gpu_cores(local_rank, local_world=1, sysfs_root="/sys", apply=True):
+def visible_device_map(n_physical, environ=None, unique_ids=None):
+    """HIP device index -> physical GPU index (position among the KFD topology's GPU nodes) under the two filters the runtime
+    applies, in its order: ROCR_VISIBLE_DEVICES (indices, or "GPU-<unique id>") selects and re-orders what the ROCr layer
+    exposes, HIP_VISIBLE_DEVICES (CUDA_VISIBLE_DEVICES is its alias) then indexes into THAT list.  As in the runtime, a list stops
+    at its first invalid entry.  No variable set: the identity."""
+    environ = os.environ if environ is None else environ
+    phys = list(range(n_physical))
+
+    def apply(spec, cur, allow_uuid):
+        out = []
+        for tok in spec.split(","):
+            tok = tok.strip()
+            idx = None
+            if allow_uuid and tok.upper().startswith("GPU-") and unique_ids:
+                want = tok[4:].lower().lstrip("0")
+                idx = next((i for i, p in enumerate(cur) if unique_ids[p] and unique_ids[p].lstrip("0") == want), None)
+            else:
+                try:
+                    idx = int(tok)
+                except ValueError:
+                    idx = None
+            if idx is None or not 0 <= idx < len(cur) or cur[idx] in out:
+                break
+            out.append(cur[idx])
+        return out
+
+    rocr = environ.get("ROCR_VISIBLE_DEVICES")
+    if rocr is not None:
+        phys = apply(rocr, phys, True)
+    hip = environ.get("HIP_VISIBLE_DEVICES", environ.get("CUDA_VISIBLE_DEVICES"))
+    if hip is not None:
+        phys = apply(hip, phys, False)
+    return phys
+
+
+def pin_rank_to_gpu_cores(local_rank, local_world=1, sysfs_root="/sys", apply=True, environ=None):
     """Restrict this process to the host cores of its GPU's NUMA node, BEFORE it makes any GPU call (the HIP runtime's helper
     threads inherit the mask): with 8 ranks on one host the enqueueing thread of a rank (10+ ms of Python + ctypes per bench
     step) otherwise migrates across sockets, away from its GPU's PCIe root.  Ranks whose GPUs share a node split that node's
-    cores evenly (SMT siblings stay together when the list enumerates them pairwise).  Returns the core list, or None when the
-    topology is unknown / STEM_PIN_RANKS=0 -- the run then keeps the inherited mask."""
+    cores evenly (SMT siblings stay together when the list enumerates them pairwise).  `local_rank` is a HIP device index: a
+    launcher's HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES re-mapping is followed to the physical GPU
+    (visible_device_map).  Returns the core list, or None when the topology is unknown / STEM_PIN_RANKS=0 -- the run then keeps
+    the inherited mask."""
     if not _config.runtime().pin_ranks:
         return None
-    lists = gpu_cpu_lists(sysfs_root)
+    phys_lists, uids = gpu_cpu_lists(sysfs_root, with_ids=True)
+    vis = visible_device_map(len(phys_lists), environ, uids)
+    lists = [phys_lists[p] for p in vis]                      # indexed by HIP device, as the ranks are
     if not lists or local_rank >= len(lists) or not lists[local_rank]:
         return None
     mine = lists[local_rank]

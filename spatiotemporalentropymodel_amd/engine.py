@@ -55,6 +55,10 @@ class _Layer:
         # (HE.2 / HE.4), the input gradient of a ConvTranspose2d (HD.0 / HD.2: a strided convolution of dy with the stored weight
         # [C][K][R][S] read as a Conv2d weight with C outputs); the transposed face stays on igemm.hip's sub-pixel phases
         self.fx3s = False
+        # fx3t: ... and the TRANSPOSED face too (forward of a ConvTranspose2d, input gradient of a strided Conv2d) as one launch of the
+        # same kernel over its four sub-pixel phases (F.tconv2d_f16x3), and the layer's weight gradient on the per-tap fp16 kernel
+        # with a strided gather (F.conv2d_wgrad_f16x3_strided): no fp32-MFMA launch is left in the layer
+        self.fx3t = False
         self.wp6_fwd = self.wp6_dgrad = None
         self._slabs = {}
         self.pending = None       # (dwp, splits) of the last wgrad, consumed by StemEngine.unpack_all
@@ -75,7 +79,24 @@ class _Layer:
         return (self.stride == 2 and not self.masked and n_red % 32 == 0 and n_out % 4 == 0 and self.R * self.R <= 25
                 and (self.kind == "conv" or self.need_dgrad))
 
+    def fx3t_eligible(self):
+        """both faces and the weight gradient on the fp16 kernels: 5x5 / 3x3, stride 2, padding R // 2, the ConvTranspose2d with
+        output_padding 1 (fine grid = twice the coarse grid), channel counts in whole 32-channel slabs"""
+        return (self.fx3s and self.R % 2 == 1 and self.R >= 3 and self.pad == self.R // 2 and self.C % 32 == 0 and self.K % 32 == 0
+                and (self.kind == "conv" or self.opad == 1))
+
     def alloc_packs(self, device):
+        if self.fx3s and self.fx3t:
+            conv = self.kind == "conv"
+            strided = torch.empty(F.f16x2_gen_weight_bytes(*((self.K, self.C) if conv else (self.C, self.K)), self.R, self.R), device=device, dtype=torch.uint8)
+            phases = torch.empty(F.f16x2_gen_weight_bytes(*((self.C, self.K) if conv else (self.K, self.C)), self.R, self.R), device=device, dtype=torch.uint8)
+            self.wp_fwd = torch.empty(0, device=device)              # never read: marks the layer as allocated
+            self.wp_dgrad = None
+            if conv:
+                self.wp6_fwd, self.wp6_dgrad = strided, (phases if self.need_dgrad else None)
+            else:
+                self.wp6_fwd, self.wp6_dgrad = phases, (strided if self.need_dgrad else None)
+            return
         if self.fx3s:
             n = self.K * self.C * self.R * self.R
             nb = F.f16x2_gen_weight_bytes(*((self.K, self.C) if self.kind == "conv" else (self.C, self.K)), self.R, self.R)
@@ -100,6 +121,14 @@ class _Layer:
 
     def role_descs(self, role):
         """(fp32 descriptors, fp16 descriptors) of this layer's packed copies for role 0 (forward) / 1 (input gradient)"""
+        if self.fx3s and self.fx3t:
+            w, conv = self.mod.weight, self.kind == "conv"
+            # strided face: the torch weight read as a Conv2d weight [outputs][contraction]; transposed face: read as w[c][n] (flip = 2)
+            if role == 0:
+                return [], [_lib.F16PackDesc(w.data_ptr(), self.wp6_fwd.data_ptr(), self.K, self.C, self.R, self.R, 0 if conv else 2, 0)]
+            if not self.need_dgrad:
+                return [], []
+            return [], [_lib.F16PackDesc(w.data_ptr(), self.wp6_dgrad.data_ptr(), self.C, self.K, self.R, self.R, 2 if conv else 0, 0)]
         if self.fx3s:
             w, conv = self.mod.weight, self.kind == "conv"
             if role == 0:
@@ -132,6 +161,53 @@ class _Layer:
         """input gradient of a ConvTranspose2d = the strided convolution of dy with the stored weight (fx3s)"""
         return F.conv2d_f16x3_gen(dyp, self.wp6_dgrad, None, self.C, self.R, self.R, self.stride, self.pad,
                                    epi=F.GEN_EPI_DACT if xact is not None else F.GEN_EPI_BIAS, z=xact, want_planes=planes)
+
+    def fwd6t(self, xp, act=F.ACT_NONE, planes=False):
+        """forward of a ConvTranspose2d on the fp16 kernel (four sub-pixel phases, one launch) -> (fp32, planes or None)"""
+        return F.tconv2d_f16x3(xp, self.wp6_fwd, self.mod.bias, self.K, self.R,
+                               epi=F.GEN_EPI_LRELU if act == F.ACT_LRELU else F.GEN_EPI_BIAS, want_planes=planes)
+
+    def dgrad6t(self, dyp, xact=None, planes=False):
+        """input gradient of a strided Conv2d = the transposed face, leaky-ReLU derivative of the layer's input folded in"""
+        return F.tconv2d_f16x3(dyp, self.wp6_dgrad, None, self.C, self.R, epi=F.GEN_EPI_DACT if xact is not None else F.GEN_EPI_BIAS,
+                               z=xact, want_planes=planes, fine_hw=tuple(xact.shape[2:]) if xact is not None else None)
+
+    def wgrad_t(self, fine_p, coarse_p, dy):
+        """weight + bias gradient of a stride-2 layer from planes: `fine_p` the fine-grid operand (a Conv2d's input, a
+        ConvTranspose2d's output gradient), `coarse_p` the coarse-grid one; dy: the fp32 output gradient (bias column sums of
+        the transposed layer).  On the weight-gradient stream like every other weight gradient."""
+        side = self.eng.side_stream(dy.device, self.lane)
+        if side is not None:
+            F.stream_wait(side, F.cur_stream(dy.device))
+            with F.on_stream(side):
+                self._wgrad_t(fine_p, coarse_p, dy)
+            for t in (fine_p.data, coarse_p.data, dy):
+                t.record_stream(side)
+        else:
+            self._wgrad_t(fine_p, coarse_p, dy)
+
+    def _wgrad_t(self, fine_p, coarse_p, dy):
+        conv = self.kind == "conv"
+        Kk = self.K if conv else self.C                  # rows of the slabs = channels of the coarse operand
+        key = ("fp16t",) + tuple(fine_p.shape)
+        if key not in self._slabs:
+            splits, elems = F.wgrad_f16x3_strided_plan(fine_p.shape, Kk, self.R, self.R, self.stride, self.pad)
+            self._slabs[key] = (torch.empty(elems, device=dy.device, dtype=torch.float32), splits,
+                                torch.empty(splits * Kk, device=dy.device, dtype=torch.float32))
+        dwp, splits, bpart = self._slabs[key]
+        gb = _grad_of(self.mod.bias) if self.mod.bias is not None else None
+        F.conv2d_wgrad_f16x3_strided(fine_p, coarse_p, Kk, self.R, self.R, self.stride, self.pad, dwp, splits,
+                                     bias_part=bpart if (conv and gb is not None) else None)
+        self.pending_bias = None
+        if gb is not None and conv:                      # column sums of dy came out of the kernel: second stage
+            desc = _lib.BiasFinalDesc(bpart.data_ptr(), gb.data_ptr(), self.K, splits, 1, 0)
+            if self.eng.defer_bias_final:
+                self.pending_bias = desc
+            else:
+                F.bias_grad_final_multi([desc])
+        elif gb is not None:                             # the transposed layer's bias sees the FINE tensor: its own column sums
+            F.bias_grad(dy, gb, accumulate=True)
+        self.pending = (dwp, splits)
 
     def wg3_eligible(self):
         """weight gradient on csrc/wgrad_f16x3.hip: stride-1 convolutions (all taps are produced, as autograd does for the
@@ -182,6 +258,9 @@ class _Layer:
         self.eng.ensure_packed()
         if self.fx3 or (self.fx3s and self.kind == "conv"):          # callers outside the training schedule (codec.py) hand over fp32 tensors
             return self.fwd6(F.F16Planes.split(x), act, out=out)[0]
+        if self.fx3t and self.kind == "deconv":
+            y = self.fwd6t(F.F16Planes.split(x), act)[0]
+            return y if out is None else F.copy_channels(y, out)
         m = self.mod
         self.eng._wait_fwd32_packs()
         if self.kind == "conv":
@@ -305,6 +384,14 @@ class StemEngine:
             if self.HD[2].fx3 and self.HD[1].fx3s_eligible():
                 self.HD[1].fx3s = True
                 self.HD[0].fx3s = self.HD[0].fx3s_eligible() and self.HD[1].C % 32 == 0
+        if self.use_fx3t and self.use_wg3:
+            for l in self.HE[1:] + self.HD[:2]:
+                l.fx3t = l.fx3t_eligible()
+            # planes travel down each chain: all of a chain's stride-2 layers or none
+            if not (self.HE[1].fx3t and self.HE[2].fx3t and self.HE[0].fx3):
+                self.HE[1].fx3t = self.HE[2].fx3t = False
+            if not (self.HD[0].fx3t and self.HD[1].fx3t and self.HD[2].fx3):
+                self.HD[0].fx3t = self.HD[1].fx3t = False
         if self.has_spm and self.use_fx3 and self.use_ctx3 and self.CTX.fx3_masked_eligible():
             self.CTX.fx3 = True
             self.CTX.taps = F.masked_live_taps(self.CTX.R, self.CTX.R, "B" if self.CTX.masked & 4 else "A")
@@ -327,6 +414,9 @@ class StemEngine:
     #: the strided-convolution faces of the hyper path's stride-2 layers (HE.2 / HE.4 forward, HD.2 / HD.0 input gradient) on the
     #: general fp16 kernel; STEM_ENGINE_STRIDED_F16X3=0: igemm.hip
     use_fx3s = _Switch("engine_strided_f16x3")
+    #: ... and their TRANSPOSED faces (HD.0 / HD.2 forward, HE.2 / HE.4 input gradient: one launch over the four sub-pixel phases)
+    #: plus the four layers' weight gradients (per-tap kernel, strided gather); STEM_ENGINE_TRANSPOSED_F16X3=0: igemm.hip / wgrad.hip
+    use_fx3t = _Switch("engine_transposed_f16x3")
     #: the masked context convolution's forward on the same kernel over its live taps; STEM_ENGINE_CTX_F16X3=0: igemm.hip
     use_ctx3 = _Switch("engine_ctx_f16x3")
     #: ... and their weight gradients (csrc/wgrad_f16x3.hip); STEM_ENGINE_WGRAD_F16X3=0 keeps those on wgrad.hip
@@ -549,6 +639,8 @@ class StemEngine:
             if self.HE[1].fx3s:           # the strided forwards on the general fp16 kernel, planes handed down
                 he2, he2p = self.HE[1].fwd6(he0p, F.ACT_LRELU, planes=self.HE[2].fx3s)
                 z = self.HE[2].fwd6(he2p)[0] if self.HE[2].fx3s else self.HE[2].fwd(he2)
+                if self.HE[1].fx3t:       # the weight gradients read them again
+                    pl["he0"], pl["he2"] = he0p, he2p
             else:
                 he2 = self.HE[1].fwd(he0, F.ACT_LRELU)
                 z = self.HE[2].fwd(he2)
@@ -560,9 +652,17 @@ class StemEngine:
             else:
                 z_hat, lik_z = F.eb_forward(z, pack, medians=eb._medians_vec())
             # hyper decoder; its last conv writes the `hp` slice of the EPM input
-            hd0 = self.HD[0].fwd(z_hat, F.ACT_LRELU)
-            hd2 = self.HD[1].fwd(hd0, F.ACT_LRELU)
-            if self.HD[2].fx3:
+            if self.HD[0].fx3t:          # the transposed layers on the fp16 kernel: planes in, planes out, no maximum / split passes
+                pl["z_hat"] = split(z_hat)
+                hd0, pl["hd0"] = self.HD[0].fwd6t(pl["z_hat"], F.ACT_LRELU, planes=True)
+                hd2, pl["hd2"] = self.HD[1].fwd6t(pl["hd0"], F.ACT_LRELU, planes=True)
+                self.HD[2].fwd6(pl["hd2"], out=epm_in[:, o_hp:o_hp + P])
+            else:
+                hd0 = self.HD[0].fwd(z_hat, F.ACT_LRELU)
+                hd2 = self.HD[1].fwd(hd0, F.ACT_LRELU)
+            if self.HD[0].fx3t:
+                pass
+            elif self.HD[2].fx3:
                 pl["hd2"] = split(hd2)
                 self.HD[2].fwd6(pl["hd2"], out=epm_in[:, o_hp:o_hp + P])
             else:
@@ -721,12 +821,18 @@ class StemEngine:
         else:
             self.HD[2].wgrad(k["hd2"], dhp)
             d = self.HD[2].dgrad(dhp, k["hd2"].shape, xact=k["hd2"])
-        self.HD[1].wgrad(k["hd0"], d)
+        if self.HD[1].fx3t:
+            self.HD[1].wgrad_t(dp, pl["hd0"], d)
+        else:
+            self.HD[1].wgrad(k["hd0"], d)
         if self.HD[1].fx3s:               # input gradients of the transposed layers = strided convolutions of dy, planes handed down
             d, dp = self.HD[1].dgrad6s(dp, xact=k["hd0"], planes=self.HD[0].fx3s)
         else:
             d = self.HD[1].dgrad(d, k["hd0"].shape, xact=k["hd0"])
-        self.HD[0].wgrad(k["z_hat"], d)
+        if self.HD[0].fx3t:
+            self.HD[0].wgrad_t(dp, pl["z_hat"], d)
+        else:
+            self.HD[0].wgrad(k["z_hat"], d)
         dz_hat = self.HD[0].dgrad6s(dp)[0] if self.HD[0].fx3s else self.HD[0].dgrad(d, k["z_hat"].shape)
         # entropy bottleneck: d/dz = dz_hat + likelihood path; 58 parameter gradients per channel
         eb = m.entropy_bottleneck
@@ -734,11 +840,19 @@ class StemEngine:
         F.eb_unpack_grads(dpack, [_grad_of(p) for p in eb._tensors14()], accumulate=True)
         self._group_ready(self.HD, eb._tensors14())
         # hyper encoder
-        self.HE[2].wgrad(k["he2"], dz)
-        d = self.HE[2].dgrad(dz, k["he2"].shape, xact=k["he2"])
-        self.HE[1].wgrad(k["he0"], d)
-        d = self.HE[1].dgrad(d, k["he0"].shape, xact=k["he0"])
-        self.HE[0].wgrad_any(k["he_in"], d, pl.get("he_in"), F.F16Planes.split(d) if self.HE[0].wg3 and "he_in" in pl else None)
+        if self.HE[2].fx3t:               # transposed faces (input gradients of the strided convolutions) and weight gradients on the fp16 kernels
+            dzp = F.F16Planes.split(dz)
+            self.HE[2].wgrad_t(pl["he2"], dzp, dz)
+            d, dp = self.HE[2].dgrad6t(dzp, xact=k["he2"], planes=True)
+            self.HE[1].wgrad_t(pl["he0"], dp, d)
+            d, dp = self.HE[1].dgrad6t(dp, xact=k["he0"], planes=self.HE[0].wg3 and "he_in" in pl)
+            self.HE[0].wgrad_any(k["he_in"], d, pl.get("he_in"), dp)
+        else:
+            self.HE[2].wgrad(k["he2"], dz)
+            d = self.HE[2].dgrad(dz, k["he2"].shape, xact=k["he2"])
+            self.HE[1].wgrad(k["he0"], d)
+            d = self.HE[1].dgrad(d, k["he0"].shape, xact=k["he0"])
+            self.HE[0].wgrad_any(k["he_in"], d, pl.get("he_in"), F.F16Planes.split(d) if self.HE[0].wg3 and "he_in" in pl else None)
         self._group_ready(self.HE, [])
 
 

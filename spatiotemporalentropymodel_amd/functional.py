@@ -613,10 +613,14 @@ class F16Planes:
         return payload, payload + (((16 + ((npix + 63) // 64) * ((Cc + 127) // 128)) * 4 + 15) & ~15)
 
     @staticmethod
-    def empty(B, Cc, H, W, device):
+    def empty(B, Cc, H, W, device, min_slots=0):
+        """min_slots: room for at least this many producer slots in the scale record (a producer whose workgroups do not tile the
+        tensor 64 pixels x 128 channels at a time: the four-phase transposed launch)"""
         if Cc % 32:
             raise ValueError(f"the planes layout needs a channel count that is a multiple of 32, got {Cc}")
         payload, total = F16Planes.nbytes(B * H * W, Cc)            # in Python: this runs ~60 times per training step
+        if min_slots:
+            total = max(total, payload + (((16 + min_slots) * 4 + 15) & ~15))
         return F16Planes(torch.empty(total, device=device, dtype=torch.uint8), (B, Cc, H, W), payload)
 
     @staticmethod
@@ -783,6 +787,75 @@ def conv2d_f16x3_gen(xp: F16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EPI_
                                                yp.data.data_ptr() if yp is not None else None, yp.q_ptr() if yp is not None else None,
                                                B, H, W, Cc, N, R, S, stride, pad, taps, ws_ptr, need, _stream()))
     return y, yp
+
+
+def pack_weight_f16x2_tconv(w: torch.Tensor) -> torch.Tensor:
+    """torch weight read as w[c][n][r][s] (an nn.ConvTranspose2d weight [Cin, Cout, R, R] for its forward; an nn.Conv2d weight
+    [K, C, R, R] for its input gradient: rows n = the face's outputs, c = its contraction channels) -> the four sub-pixel phase
+    images tconv2d_f16x3 streams (one buffer, one scale record)."""
+    _require_cuda(w)
+    Cin, N, R, S = w.shape
+    assert R == S and R % 2 == 1
+    nbytes = f16x2_gen_weight_bytes(N, Cin, R, S)
+    if nbytes == 0:
+        raise ValueError(f"f16x2 weights need a contraction channel count that is a multiple of 32, got {Cin}")
+    out = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+    wc = w.detach().contiguous()
+    pack_weights_f16x2_multi((_lib.F16PackDesc * 1)(_lib.F16PackDesc(wc.data_ptr(), out.data_ptr(), N, Cin, R, S, 2, 0)))
+    return out
+
+
+_WS_TCONV_BYTES = {}
+
+
+def tconv2d_f16x3(xp: F16Planes, wp, bias, N, R, epi=GEN_EPI_BIAS, slope=LRELU_SLOPE, z=None, out=None, want_fp32=True, want_planes=False,
+                  fine_hw=None):
+    """The transposed face of a stride-2, R x R, padding R // 2 layer on the fp16 matrix cores, one launch over its four sub-pixel
+    phases: the forward of nn.ConvTranspose2d(C, N, R, stride=2, padding=R//2, output_padding=1) or the input gradient of
+    nn.Conv2d(N, C, R, stride=2, padding=R//2) on an even-sized input.  xp: planes [B, C, H, W] of the coarse tensor; wp:
+    pack_weight_f16x2_tconv / the engine's phase images.  -> (fp32 NHWC [B, N, 2H, 2W] or None, planes or None); z (GEN_EPI_DACT):
+    the activated tensor of the FINE grid.  fine_hw = (2H - 1 or 2H, 2W - 1 or 2W): the input gradient of a strided convolution
+    whose input had odd sizes."""
+    B, Cc, H, W = xp.shape
+    dev = xp.data.device
+    Hf, Wf = fine_hw if fine_hw is not None else (2 * H, 2 * W)
+    y = None
+    if want_fp32 or out is not None:
+        y = out if out is not None else empty_nhwc(B, N, Hf, Wf, dev)
+    yp = F16Planes.empty(B, N, Hf, Wf, dev, min_slots=4 * ((B * H * W + 63) // 64) * ((N + 127) // 128)) if want_planes else None
+    dims = (B, H, W, Cc, N, R)
+    need = _WS_TCONV_BYTES.get(dims)
+    if need is None:
+        need = _WS_TCONV_BYTES[dims] = int(_lib.hip().stem_tconv2d_f16x3_workspace_bytes(*dims))
+    ws_ptr = 0
+    if need:
+        slot = (dev, _stream())
+        buf = _WS.get(slot)
+        if buf is None or buf.numel() * 4 < need:
+            buf = _WS[slot] = torch.zeros((need + 3) // 4, device=dev, dtype=torch.float32)       # zero head: arrival counters
+        ws_ptr = buf.data_ptr()
+    _chk(_lib.hip().stem_tconv2d_f16x3_fwd(xp.data_ptr(), xp.q_ptr(), xp.pix_bytes, wp.data_ptr(), _ptr(bias), epi, slope, _ptr(z),
+                                            nhwc_ld(z) if z is not None else 0, _ptr(y), nhwc_ld(y) if y is not None else 0,
+                                            yp.data.data_ptr() if yp is not None else None, yp.q_ptr() if yp is not None else None,
+                                            B, H, W, Cc, N, R, Hf, Wf, ws_ptr, need, _stream()))
+    return y, yp
+
+
+def wgrad_f16x3_strided_plan(f_shape, K, R, S, stride, pad):
+    """(splits, slab elements) of conv2d_wgrad_f16x3_strided; f_shape: the FINE-grid operand [B, C, H, W]"""
+    B, Cc, H, W = f_shape
+    splits = int(_lib.hip().stem_wgrad_f16x3_strided_splits(B, H, W, Cc, K, R, S, stride, pad))
+    return splits, splits * R * S * K * Cc
+
+
+def conv2d_wgrad_f16x3_strided(fp: F16Planes, gp: F16Planes, K, R, S, stride, pad, dwp, splits, bias_part=None):
+    """packed weight-gradient slabs [splits][R*S][K][C] of a strided layer from planes operands: gp [B, K, OH, OW] on the coarse
+    grid, fp [B, C, H, W] on the fine grid (nn.Conv2d: fp = input, gp = output gradient; nn.ConvTranspose2d: gp = the layer's
+    input, fp = the gradient of its output -- the slabs then are [t][Cin][Cout]).  bias_part (splits * K floats): per-split column
+    sums of gp (the Conv2d's bias gradient, first stage)."""
+    B, Cc, H, W = fp.shape
+    _chk(_lib.hip().stem_conv2d_wgrad_f16x3_strided(fp.data_ptr(), fp.q_ptr(), fp.pix_bytes, gp.data_ptr(), gp.q_ptr(), gp.pix_bytes, dwp.data_ptr(),
+                                                     _ptr(bias_part), B, H, W, Cc, K, R, S, stride, pad, splits, _stream()))
 
 
 def wgrad_f16x3_plan(x_shape, K, R, S, pad):

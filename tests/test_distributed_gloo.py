@@ -347,6 +347,8 @@ def test_rank_pinning_reads_the_gpu_numa_topology(tmp_path, monkeypatch):
             (d / "local_cpulist").write_text(cpus + "\n")
     assert D.gpu_cpu_lists(str(root)) == [[0, 1, 2, 3], [0, 1, 2, 3], [4, 5, 6, 7], [4, 5, 6, 7]]
     monkeypatch.delenv("STEM_PIN_RANKS", raising=False)
+    for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
     monkeypatch.setattr(D.os, "sched_getaffinity", lambda pid: set(range(8)), raising=False)
     got = [D.pin_rank_to_gpu_cores(r, 4, str(root), apply=False) for r in range(4)]
     assert got == [[0, 1], [2, 3], [4, 5], [6, 7]]
@@ -355,13 +357,30 @@ def test_rank_pinning_reads_the_gpu_numa_topology(tmp_path, monkeypatch):
     assert D.pin_rank_to_gpu_cores(0, 4, str(tmp_path / "nothing"), apply=False) is None
     monkeypatch.setenv("STEM_PIN_RANKS", "0")
     assert D.pin_rank_to_gpu_cores(0, 4, str(root), apply=False) is None
-    # applying really narrows the mask (to cores this process is allowed to use)
     monkeypatch.delenv("STEM_PIN_RANKS", raising=False)
+    # a launcher that re-maps devices: HIP device r is NOT KFD GPU r any more.  unique ids for the UUID form
+    for i, uid in ((2, 0x1111), (3, 0x2222), (4, 0xABCD), (5, 0xF00D)):
+        with open(nodes / str(i) / "properties", "a") as f:
+            f.write(f"unique_id {uid}\n")
+    pin = lambda r, w, env: D.pin_rank_to_gpu_cores(r, w, str(root), apply=False, environ=env)
+    assert D.visible_device_map(4, {}) == [0, 1, 2, 3]
+    assert D.visible_device_map(4, {"HIP_VISIBLE_DEVICES": "3,1"}) == [3, 1]
+    assert D.visible_device_map(4, {"CUDA_VISIBLE_DEVICES": "2"}) == [2]
+    assert D.visible_device_map(4, {"ROCR_VISIBLE_DEVICES": "1,2,3", "HIP_VISIBLE_DEVICES": "2,0"}) == [3, 1]      # HIP indexes what ROCr exposes
+    assert D.visible_device_map(4, {"HIP_VISIBLE_DEVICES": "1,7,2"}) == [1]                                       # stops at the first invalid entry
+    assert D.visible_device_map(4, {"ROCR_VISIBLE_DEVICES": "GPU-abcd,GPU-1111"}, ["1111", "2222", "abcd", "f00d"]) == [2, 0]
+    assert pin(0, 2, {"HIP_VISIBLE_DEVICES": "3,1"}) == [4, 5, 6, 7] and pin(1, 2, {"HIP_VISIBLE_DEVICES": "3,1"}) == [0, 1, 2, 3]
+    assert pin(0, 2, {"HIP_VISIBLE_DEVICES": "2,3"}) == [4, 5] and pin(1, 2, {"HIP_VISIBLE_DEVICES": "2,3"}) == [6, 7]       # both on node 1: split
+    assert pin(0, 1, {"ROCR_VISIBLE_DEVICES": "GPU-f00d"}) == [4, 5, 6, 7]
+    assert pin(1, 2, {"HIP_VISIBLE_DEVICES": "2"}) is None                                                        # one visible device, rank 1 has none
+    # applying really narrows the mask (to cores this process is allowed to use)
     monkeypatch.undo()
     allowed = sorted(os.sched_getaffinity(0))
     d = root / "class" / "drm" / "renderD130" / "device"
     (d / "local_cpulist").write_text(f"{allowed[0]}\n")
     try:
-        assert D.pin_rank_to_gpu_cores(0, 1, str(root)) == [allowed[0]] and sorted(os.sched_getaffinity(0)) == [allowed[0]]
+        # (environ={}: this container exports an EMPTY HIP_VISIBLE_DEVICES -- no device visible, which the map honours too)
+        assert D.pin_rank_to_gpu_cores(0, 1, str(root), environ={"HIP_VISIBLE_DEVICES": ""}) is None
+        assert D.pin_rank_to_gpu_cores(0, 1, str(root), environ={}) == [allowed[0]] and sorted(os.sched_getaffinity(0)) == [allowed[0]]
     finally:
         os.sched_setaffinity(0, allowed)

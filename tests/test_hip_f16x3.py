@@ -584,3 +584,117 @@ def test_random_shapes_under_forced_plans(F, plan):
     with F.tuning(**plan):
         worst = f16x3_fuzz.run(24, 11, verbose=False)
     assert worst <= 1e-5, worst
+
+
+# ---- the transposed faces and the weight gradients of the stride-2 layers on the fp16 matrix cores (round 5) --------------------
+TCONV_CASES = [  # B, C (coarse channels), H, W (coarse grid), N (outputs), R
+    (2, 64, 4, 4, 96, 5),
+    (16, 256, 4, 4, 256, 5),          # HD.0 / the input gradient of HE.4 at the bench geometry
+    (16, 256, 8, 8, 256, 5),          # HD.2 / the input gradient of HE.2
+    (3, 32, 5, 7, 100, 5),            # ragged coarse grid, N not a multiple of 32 (fp32 output only)
+    (2, 96, 6, 9, 160, 3),            # 3 x 3: phases of 1 / 2 / 2 / 4 taps
+]
+
+
+@pytest.mark.parametrize("case", TCONV_CASES)
+@pytest.mark.parametrize("split", [0, 1, 3])
+def test_transposed_face_forward_vs_oracle(F, case, split):
+    """nn.ConvTranspose2d(C, N, R, stride=2, padding=R//2, output_padding=1) forward (HD.0 / HD.2: spatiotemporalpriors.py:822-826)
+    as ONE launch of the general fp16 kernel over the four sub-pixel phases (phase images from the multi-pack, flip = 2): fp32
+    rows, leaky ReLU, planes of the fine tensor with one scale record -- against the oracle, with the planner's split, unsplit
+    and a forced split."""
+    B, C, H, W, N, R = case
+    x = rnd((B, C, H, W), 301, -2, 2)
+    w = (rnd((C, N, R, R), 302) / np.sqrt(C * R * R / 4)).astype(np.float32)
+    b = rnd((N,), 303, -0.1, 0.1)
+    ref = orc.deconv2d_fwd(x, w, b, 2, R // 2, 1)
+    ref_act = np.where(ref > 0, ref, ref * np.float32(0.01)).astype(np.float32)
+    xp = F.F16Planes.split(dev(x))
+    wp = F.pack_weight_f16x2_tconv(dev(w))
+    with F.tuning(fx3_split=split):
+        y, _ = F.tconv2d_f16x3(xp, wp, dev(b), N, R)
+        ya, yap = F.tconv2d_f16x3(xp, wp, dev(b), N, R, epi=F.GEN_EPI_LRELU, want_planes=N % 32 == 0)
+    assert tuple(y.shape) == (B, N, 2 * H, 2 * W)
+    assert_close(host(y), ref, what=f"tconv {case} split={split}", floor=0.1)
+    assert_close(host(ya), ref_act, what=f"tconv + lrelu {case} split={split}", floor=0.1)
+    if yap is not None:
+        assert planes_match(yap, ya), "planes output != fp32 output"
+    # into a channel slice of a wider buffer, no bias
+    wide = torch.zeros(B, 2 * H, 2 * W, N + 32, device="cuda").permute(0, 3, 1, 2)
+    with F.tuning(fx3_split=split):
+        F.tconv2d_f16x3(xp, wp, None, N, R, out=wide[:, 16:16 + N])
+    assert_close(host(wide[:, 16:16 + N]), orc.deconv2d_fwd(x, w, np.zeros(N, np.float32), 2, R // 2, 1), what="tconv slice", floor=0.1)
+    assert float(wide[:, :16].abs().max()) == 0 and float(wide[:, 16 + N:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("case", TCONV_CASES[:3] + TCONV_CASES[4:])
+def test_transposed_face_as_input_gradient_vs_oracle(F, case):
+    """The input gradient of nn.Conv2d(N, C, R, stride=2, padding=R//2) on an even-sized input (HE.2 / HE.4, :814-818; torch
+    autograd) is the same transposed face with the Conv2d weight [K = C_coarse][C_in = N] read as w[c][n][r][s]; the leaky-ReLU
+    derivative of the layer's (activated) input is applied in the epilogue (DACT), planes of the result ride along."""
+    B, C, H, W, N, R = case                                   # dy: [B, C, H, W] coarse; dx: [B, N, 2H, 2W]
+    dy = rnd((B, C, H, W), 311, -1, 1)
+    w = (rnd((C, N, R, R), 312) / np.sqrt(C * R * R / 4)).astype(np.float32)        # Conv2d weight [K][Cin][R][S] with K = C, Cin = N
+    xact = rnd((B, N, 2 * H, 2 * W), 313, -1, 1)
+    dx_ref, _, _ = orc.conv2d_bwd(np.zeros((B, N, 2 * H, 2 * W), np.float32), w, dy, 2, R // 2)
+    ref = np.where(xact > 0, dx_ref, dx_ref * np.float32(0.01)).astype(np.float32)
+    dyp = F.F16Planes.split(dev(dy))
+    wp = F.pack_weight_f16x2_tconv(dev(w))
+    z = F.to_nhwc(dev(xact))
+    d, dp = F.tconv2d_f16x3(dyp, wp, None, N, R, epi=F.GEN_EPI_DACT, z=z, want_planes=N % 32 == 0)
+    assert_close(host(d), ref, what=f"tconv dgrad {case}", floor=0.1)
+    if dp is not None:
+        assert planes_match(dp, d)
+
+
+WGS_CASES = [  # B, C (fine-grid channels), H, W (fine grid), K (coarse-grid channels), R
+    (2, 64, 8, 8, 96, 5),
+    (16, 256, 8, 8, 256, 5),          # HE.4 (8x8 -> 4x4) / HD.0 with the roles swapped
+    (16, 256, 16, 16, 256, 5),        # HE.2 / HD.2
+    (3, 32, 10, 14, 64, 3),
+]
+
+
+@pytest.mark.parametrize("case", WGS_CASES)
+def test_strided_weight_gradient_vs_oracle(F, case):
+    """Weight (and bias) gradient of nn.Conv2d(C, K, R, stride=2, padding=R//2) from planes operands on the per-tap fp16 kernel
+    (HE.2 / HE.4), and of nn.ConvTranspose2d(K, C, R, stride=2, padding=R//2, output_padding=1) with the operands' roles swapped
+    (HD.0 / HD.2: its input on the coarse grid plays dy, the gradient of its output on the fine grid plays x), against the oracle."""
+    B, C, H, W, K, R = case
+    pad = R // 2
+    x = rnd((B, C, H, W), 321, -1, 1)
+    dy = rnd((B, K, H // 2, W // 2), 322, -1, 1)
+    _, dw_ref, db_ref = orc.conv2d_bwd(x, np.zeros((K, C, R, R), np.float32), dy, 2, pad, need_dx=False)
+    xp, dyp = F.F16Planes.split(dev(x)), F.F16Planes.split(dev(dy))
+    splits, elems = F.wgrad_f16x3_strided_plan(xp.shape, K, R, R, 2, pad)
+    dwp = torch.empty(elems, device="cuda")
+    bpart = torch.empty(splits * K, device="cuda")
+    F.conv2d_wgrad_f16x3_strided(xp, dyp, K, R, R, 2, pad, dwp, splits, bias_part=bpart)
+    dw = dwp.view(splits, R * R, K, C).sum(0).permute(1, 2, 0).reshape(K, C, R, R)
+    assert_close(host(dw), dw_ref, what=f"strided wgrad {case}", floor=0.1)
+    assert_close(host(bpart.view(splits, K).sum(0)), db_ref, what="bias column sums", floor=0.1)
+    # ConvTranspose2d(K -> C): weight [K][C][R][S]; x_t = its input [B, K, H/2, W/2] (coarse), dy_t = gradient of its output (fine)
+    xt, dyt = dy, x
+    _, dwt_ref, _ = orc.deconv2d_bwd(xt, np.zeros((K, C, R, R), np.float32), dyt, 2, pad, 1, need_dx=False)
+    dwp.zero_()
+    F.conv2d_wgrad_f16x3_strided(xp, dyp, K, R, R, 2, pad, dwp, splits)          # fp = planes(dy_t) = xp, gp = planes(x_t) = dyp
+    dwt = dwp.view(splits, R * R, K, C).sum(0).permute(1, 2, 0).reshape(K, C, R, R)
+    assert_close(host(dwt), dwt_ref, what=f"transposed layer's wgrad {case}", floor=0.1)
+
+
+@pytest.mark.parametrize("odd", [(True, True), (True, False), (False, True)])
+def test_transposed_face_odd_fine_grid_vs_oracle(F, odd):
+    """a strided convolution of an odd-sized input (2H - 1 rows -> H rows: 1080p latents are 68 -> 34 -> 17) has an input gradient
+    on a fine grid of 2H - 1 rows: the phases' pixels beyond it are not written"""
+    B, C, H, W, N, R = 2, 64, 5, 6, 96, 5
+    Hf, Wf = 2 * H - int(odd[0]), 2 * W - int(odd[1])
+    dy = rnd((B, C, H, W), 331, -1, 1)
+    w = (rnd((C, N, R, R), 332) / np.sqrt(C * R * R / 4)).astype(np.float32)
+    xact = rnd((B, N, Hf, Wf), 333, -1, 1)
+    dx_ref, _, _ = orc.conv2d_bwd(np.zeros((B, N, Hf, Wf), np.float32), w, dy, 2, R // 2)
+    ref = np.where(xact > 0, dx_ref, dx_ref * np.float32(0.01)).astype(np.float32)
+    d, dp = F.tconv2d_f16x3(F.F16Planes.split(dev(dy)), F.pack_weight_f16x2_tconv(dev(w)), None, N, R, epi=F.GEN_EPI_DACT,
+                            z=F.to_nhwc(dev(xact)), want_planes=True, fine_hw=(Hf, Wf))
+    assert tuple(d.shape) == (B, N, Hf, Wf)
+    assert_close(host(d), ref, what=f"tconv dgrad odd {odd}", floor=0.1)
+    assert planes_match(dp, d)

@@ -436,6 +436,11 @@ def test_bf16_planes_views_and_engine_routing_table():
     assert eng.CTX.taps == 12 and all(l.taps == 0 for l in eng.layers if l is not eng.CTX)     # 5x5 type-A mask: 12 live taps
     # the strided-convolution faces of the hyper path's stride-2 layers (HE.2 / HE.4 forward, HD.0 / HD.2 input gradient)
     assert {n: l.fx3s for n, l in zip(fwd, eng.layers)} == dict({n: False for n in fwd}, HE2=True, HE4=True, HD0=True, HD2=True)
+    # ... and (round 5) their transposed faces + weight gradients: chain by chain
+    assert {n: l.fx3t for n, l in zip(fwd, eng.layers)} == dict({n: False for n in fwd}, HE2=True, HE4=True, HD0=True, HD2=True)
+    from spatiotemporalentropymodel_amd import config as _cfg
+    with _cfg.override(engine_transposed_f16x3=False):
+        assert not any(l.fx3t for l in SpatioTemporalPriorModel_Res().engine().layers)
     # Chains are routed as a whole: with latent channel counts that are not multiples of 16 some layers of a chain
     # are ineligible (C % 32), and a half-routed chain would call a kernel whose packed weights were never allocated
     from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel, SpatioTemporalPriorModelWithoutTPM
@@ -453,7 +458,12 @@ def test_bf16_planes_views_and_engine_routing_table():
             assert not l.fx3s or (l.fx3s_eligible() and not l.fx3)
             # every layer has exactly the packed weights its route needs once allocated (CPU: allocation only)
             l.alloc_packs(torch.device("cpu"))
-            if l.fx3s:      # one face on the fp16 kernel, the other on igemm.hip
+            assert not l.fx3t or (l.fx3s and l.fx3t_eligible())
+            if l.fx3t:      # round 5: both faces on the fp16 kernel (strided image + four phase images), no fp32 copy
+                assert l.wp6_fwd is not None and (l.wp6_dgrad is not None) == l.need_dgrad and l.wp_dgrad is None and l.wp_fwd.numel() == 0
+                flips = [d.flip for role in (0, 1) for d in l.role_descs(role)[1]]
+                assert flips == ([0, 2] if l.kind == "conv" else [2, 0]) and not l.role_descs(0)[0] and not l.role_descs(1)[0]
+            elif l.fx3s:    # one face on the fp16 kernel, the other on igemm.hip
                 assert (l.wp6_fwd is not None) == (l.kind == "conv") and (l.wp6_dgrad is not None) == (l.kind == "deconv")
                 assert l.wp_fwd is not None and (l.wp_dgrad is not None) == (l.kind == "conv" and l.need_dgrad)
             else:
