@@ -45,6 +45,7 @@ class StemRuntimeConfig:
     engine_branch: bool = True           #: hyper path on its own stream
     engine_tpm_first: bool = True        #: temporal-prior chain enqueued ahead of the hyper branch (forward)
     engine_tpm_first_bwd: bool = True    #: ... in backward (the hyper chain waits for the EPM input gradient through an event)
+    engine_tpm_wgrad_inline: bool = True #: the TPM chain's weight gradients on the compute stream (behind its input gradients)
     engine_fuse_gc_backward: bool = True #: GaussianConditional backward inside the fused forward glue kernel
     engine_bias_multi: bool = True       #: one launch for a module group's bias-gradient second stages
     stream_prio: str = ""                #: "latents=0,side=-1,compute=-1" (trainer.tuned_schedule installs it)
@@ -69,7 +70,7 @@ _ENV = {
     "engine_wgrad_f16x3": "STEM_ENGINE_WGRAD_F16X3", "engine_records": "STEM_ENGINE_RECORDS", "layers_f16x3": "STEM_LAYERS_F16X3",
     "layers_f16x3_maxpix": "STEM_LAYERS_F16X3_MAXPIX", "layers_wide_minpix": "STEM_LAYERS_WIDE_MINPIX",
     "adam_block_max": "STEM_ADAM_BLOCK_MAX", "engine_overlap": "STEM_ENGINE_OVERLAP",
-    "engine_split_pack": "STEM_ENGINE_SPLIT_PACK", "engine_branch": "STEM_ENGINE_BRANCH", "engine_tpm_first": "STEM_ENGINE_TPM_FIRST", "engine_tpm_first_bwd": "STEM_ENGINE_TPM_FIRST_BWD",
+    "engine_split_pack": "STEM_ENGINE_SPLIT_PACK", "engine_branch": "STEM_ENGINE_BRANCH", "engine_tpm_first": "STEM_ENGINE_TPM_FIRST", "engine_tpm_first_bwd": "STEM_ENGINE_TPM_FIRST_BWD", "engine_tpm_wgrad_inline": "STEM_ENGINE_TPM_WGRAD_INLINE",
     "engine_bias_multi": "STEM_ENGINE_BIAS_MULTI", "engine_fuse_gc_backward": "STEM_ENGINE_FUSE_GC_BACKWARD",
     "stream_prio": "STEM_STREAM_PRIO", "stream_cumask": "STEM_STREAM_CUMASK", "dp_min_bytes": "STEM_DP_MIN_BYTES",
     "dist_backend": "STEM_DIST_BACKEND", "dist_single": "STEM_DIST_SINGLE", "pin_ranks": "STEM_PIN_RANKS",

@@ -1826,24 +1826,20 @@ int tconv_cps(int tiles_per_phase, const int (&nchunks)[4])
     int maxc = 0;
     for (int p = 0; p < 4; ++p) maxc = nchunks[p] > maxc ? nchunks[p] : maxc;
     if (forced > 0) return cdiv(maxc, forced < maxc ? forced : maxc);
-    int best = maxc;
-    double best_cost = 1e30;
-    for (int cps = maxc; cps >= 4; --cps) {
+    if (stem_tuning(STEM_TUNE_TCONV_CPS) > 0) return stem_tuning(STEM_TUNE_TCONV_CPS);       // stem_tuning_set("tconv_cps", n): sweeps
+    // These launches are latency-bound (tools/debug/tconv_sweep.py, round 5: HD.0 24-29 us and HD.2 38-40 us for 12-24 chunks per
+    // workgroup, 49-64 us at 4-8, 45-62 us at 36-72): the shortest loop that keeps the launch within one round of 512 workgroups
+    // (two per CU) and the reduction within 16 slabs, but not below 12 chunks -- under that the slab round trip outweighs the loop
+    for (int cps = 12; cps < maxc; ++cps) {
         int wgs = 0, maxns = 0;
         for (int p = 0; p < 4; ++p) {
             const int ns = cdiv(nchunks[p], cps);
             wgs += tiles_per_phase * ns;
             maxns = ns > maxns ? ns : maxns;
         }
-        if (maxns > 16) break;
-        const int rounds = cdiv(wgs, 512);          // two workgroups per CU
-        const double cost = rounds * (cps + 6.0) * (wgs <= 256 ? 1.67 : 1.0) + (maxns > 1 ? 0.3 * maxns : 0.0);
-        if (cost < best_cost - 1e-9) {
-            best_cost = cost;
-            best = cps;
-        }
+        if (wgs <= 512 && maxns <= 16) return cps;
     }
-    return best;
+    return maxc;
 }
 }   // namespace
 
@@ -1900,7 +1896,9 @@ STEM_EXPORT int stem_tconv2d_f16x3_fwd(const void *xp, const float *xq, int xpix
         maxT = ph.ntaps > maxT ? ph.ntaps : maxT;
         STEM_CHECK_ARG(ph.ntaps >= 1, "stem_tconv2d_f16x3_fwd: empty phase (R=%d)", R);
     }
-    const int bm = gen_bm(4 * M, ntn, nch[0]), ptiles = cdiv(M, bm);
+    // 64-pixel workgroups unless the coarse grid alone fills the chip (HD.2 at B = 16: 34 against 49 us)
+    const int forced_bm = stem_tuning(STEM_TUNE_FX3_GEN_TILE);
+    const int bm = forced_bm ? forced_bm : (4 * cdiv(M, 128) * ntn >= 256 ? 128 : 64), ptiles = cdiv(M, bm);
     int cps = tconv_cps(ptiles * ntn, nch);
     // the slabs of all phases sit behind each other in ws; without room for the plan the launch is unsplit (same result up to order)
     size_t wsfl = 0;

@@ -433,8 +433,15 @@ class StemEngine:
     #: step; STEM_ENGINE_SPLIT_PACK=0: one launch each as before
     split_pack = _Switch("engine_split_pack")
 
+    #: the temporal-prior chain's weight gradients (three filter-row launches + slab sums, ~300 us of the ~900 us the
+    #: weight-gradient stream carries per P-frame step) are issued on the COMPUTE stream, behind the chain's own input gradients:
+    #: that stream has nothing else to do once the TPM input gradients are out (the hyper chain runs on its branch stream), while the
+    #: weight-gradient stream was the last to finish by ~250 us (profiles/r05_gantt_palone.txt).  Scheduling only: lane -1 = "the
+    #: stream the backward runs on".  STEM_ENGINE_TPM_WGRAD_INLINE=0: every weight gradient on the side stream, as in round 4
+    tpm_wgrad_inline = _Switch("engine_tpm_wgrad_inline")
+
     def side_stream(self, device, lane=0):
-        if not self.overlap_wgrad or device.type != "cuda":
+        if not self.overlap_wgrad or device.type != "cuda" or lane < 0:
             return None
         st = self._side.get(lane)
         if st is None or st.device != device:
@@ -775,6 +782,8 @@ class StemEngine:
                 self.CTX.wgrad(k["t_hat"], dpri[:, o_ctx:o_ctx + P])
             self._group_ready([self.CTX], [])
         if self.has_tpm:
+            for l in self.TPM:
+                l.lane = -1 if (self.tpm_wgrad_inline and bs is not None) else 0
             dtp = dpri[:, o_tp:o_tp + P]
             if self.TPM[2].fx3:
                 dtpp = dprip.channels(o_tp, o_tp + P) if dprip is not None else F.F16Planes.split(dtp)
