@@ -256,6 +256,7 @@ class _Layer:
 
     def fwd(self, x, act=F.ACT_NONE, out=None):
         self.eng.ensure_packed()
+        self.eng._wait_fwd_rest()
         if self.fx3 or (self.fx3s and self.kind == "conv"):          # callers outside the training schedule (codec.py) hand over fp32 tensors
             return self.fwd6(F.F16Planes.split(x), act, out=out)[0]
         if self.fx3t and self.kind == "deconv":
@@ -364,6 +365,7 @@ class StemEngine:
         self._checked = False
         self._dgrad_pack_event = None
         self._fwd32_pack_event = None
+        self._fwd_rest_event = None
         self._events = {}
         self._select_fx3()
 
@@ -432,6 +434,11 @@ class StemEngine:
     #: input-gradient copies on a weight-gradient stream (only backward waits): 22.48-22.62 ms against 22.67-22.82 ms per bench
     #: step; STEM_ENGINE_SPLIT_PACK=0: one launch each as before
     split_pack = _Switch("engine_split_pack")
+    #: ... and of the forward-role images only those of the layers that open the forward are packed on the compute stream, the others
+    #: on the weight-gradient stream under the opening kernels.  Shortens the P-frame step's critical path by ~60 us when the step
+    #: runs alone; inside the bench step (chip shared with the latent prefetch) it measured 12.39 against 12.32 ms
+    #: (profiles/r05_ab_pack_first.log): off by default, STEM_ENGINE_PACK_FIRST=1 enables it
+    pack_first = _Switch("engine_pack_first")
 
     #: the temporal-prior chain's weight gradients (three filter-row launches + slab sums, ~300 us of the ~900 us the
     #: weight-gradient stream carries per P-frame step) are issued on the COMPUTE stream, behind the chain's own input gradients:
@@ -501,7 +508,30 @@ class StemEngine:
                 descs6 = [d for _, b in both for d in b]
                 if descs6 and block_max is not None:
                     _attach_block_maxima(descs6, *block_max)
-                if descs6:          # first: the forward's first kernels (HE.0, TPM.0, the context model) wait for these
+                first6 = []
+                if descs6 and side is not None and not on_side and self.pack_first:
+                    # The forward cannot start before its first kernels' images exist, and the optimiser pass cannot overlap anything:
+                    # only the images of the layers that OPEN the forward (TPM.0, HE.0, the context model: 3.9 of 17 M weights) are
+                    # packed on the compute stream; the others follow on the weight-gradient stream, in front of its input-gradient
+                    # images, while the opening kernels run.  Their consumers wait for `fwd_rest` (_wait_fwd_rest).
+                    opening = {id(l) for l in ([self.HE[0]] + ([self.TPM[0]] if self.has_tpm else []) + ([self.CTX] if self.has_spm else []))}
+                    fwd_pairs = [(l, d) for l in self.layers for d in l.role_descs(0)[1]]
+                    first6 = [d for l, d in fwd_pairs if id(l) in opening]
+                    rest6 = [d for l, d in fwd_pairs if id(l) not in opening]
+                    if first6 and rest6:
+                        if block_max is not None:
+                            _attach_block_maxima(first6 + rest6, *block_max)
+                        F.pack_weights_f16x2_multi((_lib.F16PackDesc * len(first6))(*first6))
+                        F.stream_wait(side, F.cur_stream(dev))
+                        with F.on_stream(side):
+                            F.pack_weights_f16x2_multi((_lib.F16PackDesc * len(rest6))(*rest6))
+                            self._fwd_rest_event = self._events.setdefault("fwd_rest", torch.cuda.Event())
+                            F.event_record(self._fwd_rest_event, side)
+                    else:
+                        first6 = []
+                if descs6 and not first6:          # the forward's first kernels (HE.0, TPM.0, the context model) wait for these
+                    if not on_side:
+                        self._fwd_rest_event = None
                     F.pack_weights_f16x2_multi((_lib.F16PackDesc * len(descs6))(*descs6))
                 # the fp32 copies of the forward role (the transposed hyper-decoder layers: consumed on the hyper branch, half a
                 # forward later) are packed on that branch's stream, off the compute stream's optimiser -> forward chain
@@ -571,6 +601,12 @@ class StemEngine:
         if self._fwd32_pack_event is not None:
             F.event_wait(F.cur_stream(), self._fwd32_pack_event)
 
+    def _wait_fwd_rest(self):
+        """a consumer of a forward-role image that was packed on the weight-gradient stream (every layer but the ones that open
+        the forward): order the current stream behind that packing"""
+        if self._fwd_rest_event is not None:
+            F.event_wait(F.cur_stream(), self._fwd_rest_event)
+
     def _wait_dgrad_packs(self):
         """backward's first consumer of an input-gradient weight copy: order it after the side-stream packing"""
         if self._dgrad_pack_event is not None:
@@ -628,9 +664,11 @@ class StemEngine:
                 # planes travel from layer to layer (written by the producing epilogue next to the fp32 copy backward needs)
                 pl["yd"] = split(yd, src_q=_qp(rec.get("in")))       # max(|y_cur|, |y_cond|) bounds y_cond
                 tp0, pl["tp0"] = self.TPM[0].fwd6(pl["yd"], F.ACT_LRELU, planes=True)
+                self._wait_fwd_rest()
                 tp2, pl["tp2"] = self.TPM[1].fwd6(pl["tp0"], F.ACT_LRELU, planes=True)
                 self.TPM[2].fwd6(pl["tp2"], out=epm_in[:, o_tp:o_tp + P])
             elif self.has_tpm:
+                self._wait_fwd_rest()
                 tp0 = self.TPM[0].fwd(yd, F.ACT_LRELU)
                 tp2 = self.TPM[1].fwd(tp0, F.ACT_LRELU)
                 self.TPM[2].fwd(tp2, out=epm_in[:, o_tp:o_tp + P])
@@ -643,6 +681,7 @@ class StemEngine:
                 he0, he0p = self.HE[0].fwd6(pl["he_in"], F.ACT_LRELU, planes=self.HE[1].fx3s)
             else:
                 he0 = self.HE[0].fwd(he_in, F.ACT_LRELU)
+            self._wait_fwd_rest()
             if self.HE[1].fx3s:           # the strided forwards on the general fp16 kernel, planes handed down
                 he2, he2p = self.HE[1].fwd6(he0p, F.ACT_LRELU, planes=self.HE[2].fx3s)
                 z = self.HE[2].fwd6(he2p)[0] if self.HE[2].fx3s else self.HE[2].fwd(he2)
@@ -685,6 +724,7 @@ class StemEngine:
             self._ctx_forward(t_hat, epm_in[:, o_ctx:o_ctx + P], pl)
         if bs is not None:
             F.stream_wait(main, bs)
+        self._wait_fwd_rest()
         if self.EPM[0].fx3:
             pl["epm_in"] = split(epm_in)
             e0, pl["e0"] = self.EPM[0].fwd6(pl["epm_in"], F.ACT_LRELU, planes=True)
