@@ -706,6 +706,49 @@ def gen_f64(ref):
             print(f"  {k}: {d[k]}")
 
 
+def gen_roi_f64(ref, batch=1, size=128, vsize=64):
+    """float64 runs of the variable-rate models' training forward (the cases of gen_stem_roi / gen_stem_variants, same closed-form
+    weights / inputs / noise): the exact likelihoods the fp32 implementations approximate, and how far the reference's own fp32
+    run is from them (`ref32:*`) -- the ROI tests gate lik_y at north_star's 1e-4 of the EXACT value with these."""
+    import compressai.models.stem_roi as ref_roi
+    from compressai.models.stem_roi import stem_roi, stem_roi_i
+    d = {}
+    runs = {}
+    for dtype in (torch.float32, torch.float64):
+        log = []
+        imodel, pmodel = stem_roi_i().train(), stem_roi().train()
+        for tag, m in (("roi_i", imodel), ("roi_p", pmodel)):
+            closed_form_fill_scaled_(m, tag, ROI_CONV_SCALE)
+            m.to(dtype)
+            m.entropy_bottleneck._get_noise_cached = NoiseFeed(tag + "_eb", log)
+            m.gaussian_conditional._get_noise_cached = NoiseFeed(tag + "_gc", log)
+        frames = [f.to(dtype) for f in smooth_frames("roi", batch, 2, size)]
+        qmap = closed_form_input("roi:qmap", (batch, 1, size, size), 0.0, 1.0).to(dtype)
+        with torch.no_grad():
+            out_i = imodel(frames[0], qmap)
+            out_p = pmodel(frames[1], out_i["x_hat"], qmap)
+        r = {"i:lik_y": t2n(out_i["likelihoods"]["y"]), "p:lik_y": t2n(out_p["likelihoods"]["y"])}
+        vframes = [f.to(dtype) for f in smooth_frames("variants", batch, 2, vsize)]
+        vq = closed_form_input("variants:qmap", (batch, 1, vsize, vsize), 0.0, 1.0).to(dtype)
+        for cls in ("stem_baseline", "stem_baselinev2", "stem_roi_wo_gsc"):
+            m = getattr(ref_roi, cls)().train()
+            closed_form_fill_scaled_(m, cls, ROI_CONV_SCALE)
+            m.to(dtype)
+            m.entropy_bottleneck._get_noise_cached = NoiseFeed(cls + "_eb", log)
+            m.gaussian_conditional._get_noise_cached = NoiseFeed(cls + "_gc", log)
+            with torch.no_grad():
+                out = m(vframes[1], vframes[0], vq) if cls == "stem_roi_wo_gsc" else m(vframes[1], vframes[0])
+            r[f"{cls}:lik_y"] = t2n(out["likelihoods"]["y"])
+        runs[dtype] = r
+    for k, v in runs[torch.float64].items():
+        d[k] = v
+        d["ref32:" + k] = np.array([_close_ratio(runs[torch.float32][k], v, atol=1e-9)])
+    save("stem_roi_f64.npz", d)
+    for k in sorted(d):
+        if k.startswith("ref32"):
+            print(f"  {k}: {d[k]}")
+
+
 def gen_container(ref):
     """Byte layout of compressai_examples/codec.py's container (:63-119,178-187) from the reference's own writers."""
     import io
@@ -837,5 +880,7 @@ if __name__ == "__main__":
             gen_roi_dataset(ref_utils)
         if "f64" in which:
             gen_f64(ref_utils)
+        if "roif64" in which:
+            gen_roi_f64(ref_utils)
     finally:
         shutil.rmtree(scratch, ignore_errors=True)
