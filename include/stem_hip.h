@@ -491,6 +491,24 @@ typedef struct {
     int b0, nb, rsv0, rsv1; /* ... chunks b0 .. b0 + nb - 1 cover the tensor: no maximum pass is launched when EVERY descriptor has them */
 } stem_f16x2_pack_desc;
 int stem_f16x2_pack_conv_weights_multi(const stem_f16x2_pack_desc *descs, int n, void *stream);
+/* BOTH images of a layer (forward role + input-gradient role: two transposes of the same numbers) from ONE read of its weights;
+ * replaces two stem_f16x2_pack_conv_weights_multi calls per optimiser step (stem/trainSTEM.py:213: every weight changed).
+ * Tensor w[A][B][R][S]; image r (wp0 / wp1, null = none): mode bit 0: 0 = rows are a (contraction over b: a Conv2d's forward
+ * image, a ConvTranspose2d's input-gradient image), 1 = rows are b (contraction over a); mode >> 1: tap order 0 identity,
+ * 1 mirrored (flip = 1 above), 2 sub-pixel phases (flip = 2); taps0 > 0: masked convolution, the image holds the first taps0
+ * taps and the others are zeroed in w.  bmax / b0 / nb: the optimiser pass's chunk maxima covering the tensor (mandatory).
+ * Padding rows (row count not a multiple of 128) are not written: zero-fill the images once. */
+typedef struct {
+    const void *w;
+    int A, B, R, S;
+    void *wp0;
+    int mode0, taps0;
+    void *wp1;
+    int mode1, taps1;
+    const float *bmax;
+    int b0, nb;
+} stem_f16x2_pair_desc;
+int stem_f16x2_pack_conv_weights_pair_multi(const stem_f16x2_pair_desc *descs, int n, void *stream);
 size_t stem_conv2d_f16x3_gen_workspace_bytes(int B, int H, int W, int C, int N, int R, int S, int stride, int pad, int taps);
 /* xpix: bytes per pixel of the planes buffer xp points into (0 = dense, (C/32) * 128); xp may point at a 32-channel-aligned
  * slab of a wider planes tensor (xq: the record of that whole tensor) */

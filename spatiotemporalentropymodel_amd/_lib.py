@@ -108,6 +108,7 @@ _HIP_SIG = {
     "stem_wgrad_f16x3_strided_splits": [ci, ci, ci, ci, ci, ci, ci, ci, ci],
     "stem_conv2d_wgrad_f16x3_strided": [vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_f16x2_pack_conv_weights_multi": [vp, ci, vp],
+    "stem_f16x2_pack_conv_weights_pair_multi": [vp, ci, vp],
     "stem_wgrad_f16x3_splits": [ci, ci, ci, ci, ci, ci, ci, ci],
     "stem_conv2d_wgrad_f16x3": [vp, vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_bias_grad_final": [vp, ci, ci, vp, ci, vp],
@@ -186,6 +187,11 @@ class PackDesc(C.Structure):
 
 class F16PackDesc(C.Structure):
     _fields_ = [("w", vp), ("wp", vp), ("N", ci), ("C", ci), ("R", ci), ("S", ci), ("flip", ci), ("taps", ci), ("bmax", vp), ("b0", ci), ("nb", ci), ("rsv0", ci), ("rsv1", ci)]
+
+
+class F16PairDesc(C.Structure):
+    _fields_ = [("w", vp), ("A", ci), ("B", ci), ("R", ci), ("S", ci), ("wp0", vp), ("mode0", ci), ("taps0", ci), ("wp1", vp), ("mode1", ci),
+                ("taps1", ci), ("bmax", vp), ("b0", ci), ("nb", ci)]
 
 
 class UnpackDesc(C.Structure):

@@ -42,6 +42,7 @@ class StemRuntimeConfig:
     # ---- schedule of the training step (none of these changes a result)
     engine_overlap: bool = True          #: weight gradients on a side stream
     engine_split_pack: bool = True       #: input-gradient weight images packed on the side stream
+    engine_pack_pair: bool = True        #: both images of a layer from one read of its weights (after an optimiser pass with maxima)
     engine_pack_first: bool = False      #: of the forward-role images only the opening layers' on the compute stream (measured: +0.07 ms)
     engine_branch: bool = True           #: hyper path on its own stream
     engine_tpm_first: bool = True        #: temporal-prior chain enqueued ahead of the hyper branch (forward)
@@ -71,7 +72,7 @@ _ENV = {
     "engine_wgrad_f16x3": "STEM_ENGINE_WGRAD_F16X3", "engine_records": "STEM_ENGINE_RECORDS", "layers_f16x3": "STEM_LAYERS_F16X3",
     "layers_f16x3_maxpix": "STEM_LAYERS_F16X3_MAXPIX", "layers_wide_minpix": "STEM_LAYERS_WIDE_MINPIX",
     "adam_block_max": "STEM_ADAM_BLOCK_MAX", "engine_overlap": "STEM_ENGINE_OVERLAP",
-    "engine_split_pack": "STEM_ENGINE_SPLIT_PACK", "engine_pack_first": "STEM_ENGINE_PACK_FIRST", "engine_branch": "STEM_ENGINE_BRANCH", "engine_tpm_first": "STEM_ENGINE_TPM_FIRST", "engine_tpm_first_bwd": "STEM_ENGINE_TPM_FIRST_BWD", "engine_tpm_wgrad_inline": "STEM_ENGINE_TPM_WGRAD_INLINE",
+    "engine_split_pack": "STEM_ENGINE_SPLIT_PACK", "engine_pack_first": "STEM_ENGINE_PACK_FIRST", "engine_pack_pair": "STEM_ENGINE_PACK_PAIR", "engine_branch": "STEM_ENGINE_BRANCH", "engine_tpm_first": "STEM_ENGINE_TPM_FIRST", "engine_tpm_first_bwd": "STEM_ENGINE_TPM_FIRST_BWD", "engine_tpm_wgrad_inline": "STEM_ENGINE_TPM_WGRAD_INLINE",
     "engine_bias_multi": "STEM_ENGINE_BIAS_MULTI", "engine_fuse_gc_backward": "STEM_ENGINE_FUSE_GC_BACKWARD",
     "stream_prio": "STEM_STREAM_PRIO", "stream_cumask": "STEM_STREAM_CUMASK", "dp_min_bytes": "STEM_DP_MIN_BYTES",
     "dist_backend": "STEM_DIST_BACKEND", "dist_single": "STEM_DIST_SINGLE", "pin_ranks": "STEM_PIN_RANKS",

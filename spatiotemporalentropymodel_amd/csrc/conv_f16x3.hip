@@ -1686,6 +1686,197 @@ STEM_EXPORT int stem_f16x2_pack_conv_weights_multi(const stem_f16x2_pack_desc *d
 }
 
 namespace {
+// ---- both weight images of a layer from ONE read of its weights (round 5) ---------------------------------------------------------
+// The training step re-packs every weight after every optimiser step (stem/trainSTEM.py:213: the weights changed), once per ROLE:
+// the forward image and the input-gradient image of a layer are two transposes of the same numbers.  pack_weight_gen_multi_kernel
+// makes one image per descriptor: 72 MB read + 72 MB written per role, 82 + 108 us per P-frame step, the second on the
+// weight-gradient stream where it competes with the forward's kernels for HBM.  Here a workgroup takes a 32 x 32 x RS tile
+// [a][b][tap] of the torch tensor [A][B][R][S] into LDS once and emits the pieces of BOTH images from it: rows = the tile's a
+// index with 8 consecutive b per 16-byte piece (a Conv2d's forward image, a ConvTranspose2d's input-gradient image), or rows = b
+// with 8 consecutive a (transposed indexing: flip / phases), taps in identity, mirrored or phase order.
+constexpr int PAIR_T = 32;                              // tile edge (channels)
+constexpr int PAIR_NT = 512;
+struct PairRole {
+    void *wp;                 // null: the layer has no image of this role
+    int rows_b;               // 0: image rows = the tensor's leading index a (contraction over b); 1: rows = b (contraction over a)
+    int tapmode;              // 0 identity, 1 mirrored (input gradient of a stride-1 convolution), 2 sub-pixel phase order (tconv_slot)
+    int taps;                 // identity only: > 0 = the image holds the first `taps` taps, the others are ZEROED in w (masked convolution)
+};
+struct PairDesc {
+    float *w;
+    int A, B, R, S;
+    PairRole role[2];
+    const float *bmax;        // per-chunk maxima of the optimiser pass (stem_adam_step_bmax) covering the tensor: chunks b0 .. b0 + nb - 1
+    int b0, nb;
+    int tile0;                // first workgroup of this tensor in the launch
+};
+constexpr int MAXPAIR = 20;
+struct PairTable {
+    PairDesc d[MAXPAIR];
+    int n;
+};
+
+template <int CRS>
+__device__ inline void pair_pack_tile(const PairDesc &d, int tile, float *lds, int *ptap, float wscale)
+{
+    const int RS = CRS > 0 ? CRS : d.R * d.S;
+    const int tb = cdiv_dev(d.B, PAIR_T);
+    const int a0 = (tile / tb) * PAIR_T, b0 = (tile % tb) * PAIR_T;
+    const int na = d.A - a0 < PAIR_T ? d.A - a0 : PAIR_T, nb = d.B - b0 < PAIR_T ? d.B - b0 : PAIR_T;
+    const int row = PAIR_T * RS;                       // floats of one a-row of the tile (b-major, taps innermost): the tensor's own order
+    // masked convolution: the taps beyond the live prefix are zeroed IN PLACE (layers.py:44 `weight.data *= mask` at every forward)
+    const int live = (d.role[0].wp && d.role[0].tapmode == 0 && d.role[0].taps > 0 && d.role[0].taps < RS) ? d.role[0].taps : RS;
+    for (int idx = threadIdx.x; idx < PAIR_T * row; idx += PAIR_NT) {
+        const int a = idx / row, rem = idx - a * row;
+        float v = 0.f;
+        if (a < na && rem < nb * RS) {
+            float *src = d.w + ((size_t)(a0 + a) * d.B + b0) * RS + rem;
+            v = *src;
+            if (live < RS && rem % RS >= live) {
+                *src = 0.f;
+                v = 0.f;
+            }
+        }
+        lds[idx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ri = 0; ri < 2; ++ri) {
+        const PairRole &r = d.role[ri];
+        if (!r.wp) continue;
+        unsigned char *wp = static_cast<unsigned char *>(r.wp);
+        const int N = r.rows_b ? d.B : d.A, C = r.rows_b ? d.A : d.B;           // image rows / contraction channels
+        const int n0 = r.rows_b ? b0 : a0, nrows = r.rows_b ? nb : na, slab = (r.rows_b ? a0 : b0) / 32;
+        const int nslab = C / 32, ntile = cdiv_dev(N, GBN);
+        const int T = (r.tapmode == 0 && r.taps > 0) ? r.taps : RS;
+        const int nchunks = nslab * T;
+        int pT[4] = {0, 0, 0, 0}, pbase[4] = {0, 0, 0, 0};
+        if (r.tapmode == 2) {
+            int acc = 0;
+            for (int p = 0; p < 4; ++p) {
+                pbase[p] = acc;
+                pT[p] = tconv_axis(d.R, d.R / 2, p >> 1).cnt * tconv_axis(d.S, d.S / 2, p & 1).cnt;
+                acc += pT[p];
+            }
+        }
+        for (int e = threadIdx.x; e < PAIR_T * 4 * T; e += PAIR_NT) {
+            const int p = e & 3, rr = (e >> 2) & (PAIR_T - 1), tap = e >> 7;     // piece, row of the tile, image tap
+            if (rr >= nrows) continue;
+            // source tap of image tap `tap`: identity, mirrored, or the tap that sits at phase-ordered position `tap`
+            const int st = r.tapmode == 0 ? tap : (r.tapmode == 1 ? RS - 1 - tap : ptap[tap]);
+            h16x8 h[NPL];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int ch = p * 8 + c;                                      // contraction channel inside the slab
+                const float v = r.rows_b ? lds[(ch * PAIR_T + rr) * RS + st] : lds[(rr * PAIR_T + ch) * RS + st];
+                hp_t x0, x1;
+                q_split(v, wscale, x0, x1);
+                h[0][c] = x0; h[1][c] = x1;
+            }
+            const int n = n0 + rr, nt = n / GBN, nl = n - nt * GBN;
+            long qq = (long)nt * nchunks + slab * T + tap;
+            if (r.tapmode == 2) {
+                const int ph = tap >= pbase[3] ? 3 : (tap >= pbase[2] ? 2 : (tap >= pbase[1] ? 1 : 0));
+                qq = (long)ntile * nslab * pbase[ph] + (long)nt * (nslab * pT[ph]) + slab * pT[ph] + (tap - pbase[ph]);
+            }
+            unsigned char *dst = wp + qq * GB_BUF + nl * 64 + ((p ^ ((nl >> 2) & 3)) << 4);
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) *reinterpret_cast<h16x8 *>(dst + pl * GB_PLANE) = h[pl];
+        }
+    }
+}
+
+__global__ __launch_bounds__(PAIR_NT) void pack_weight_pair_multi_kernel(const PairTable tab)
+{
+    extern __shared__ __attribute__((aligned(16))) float pair_lds[];            // [32][32][RS] floats, then the phase tap table
+    __shared__ float qred[16];
+    int i = 0;
+    while (i + 1 < tab.n && (int)blockIdx.x >= tab.d[i + 1].tile0) ++i;
+    const PairDesc &d = tab.d[i];
+    const int tile = blockIdx.x - d.tile0, RS = d.R * d.S;
+    int *ptap = reinterpret_cast<int *>(pair_lds + PAIR_T * PAIR_T * RS);
+    if ((int)threadIdx.x < RS) ptap[tconv_slot(d.R, d.S, d.R / 2, threadIdx.x / d.S, threadIdx.x % d.S)] = threadIdx.x;
+    // one scale for both images: the maximum of the optimiser pass's chunks that cover the tensor (an upper bound: neighbours may
+    // share a chunk), as in pack_weight_gen_multi_kernel
+    float mm = 0.f;
+    for (int k = threadIdx.x; k < 4 * d.nb; k += PAIR_NT) mm = fmaxf(mm, d.bmax[4 * d.b0 + k]);
+    const float wmax = block_max(mm, qred);
+    const int we = q_exp(wmax);
+    if (tile == 0 && threadIdx.x == 0) {
+#pragma unroll
+        for (int ri = 0; ri < 2; ++ri) {
+            const PairRole &r = d.role[ri];
+            if (!r.wp) continue;
+            const int N = r.rows_b ? d.B : d.A, C = r.rows_b ? d.A : d.B;
+            float *wq = reinterpret_cast<float *>(static_cast<unsigned char *>(r.wp) + (size_t)cdiv_dev(N, GBN) * (C / 32) * RS * GB_BUF);
+            q_header(wq, 1);
+            wq[1] = q_pow2(-we);
+            wq[QREC_HDR] = wmax;
+        }
+    }
+    __syncthreads();
+    const float wscale = q_pow2(we);
+    if (RS == 25)
+        pair_pack_tile<25>(d, tile, pair_lds, ptap, wscale);
+    else if (RS == 9)
+        pair_pack_tile<9>(d, tile, pair_lds, ptap, wscale);
+    else if (RS == 1)
+        pair_pack_tile<1>(d, tile, pair_lds, ptap, wscale);
+    else
+        pair_pack_tile<0>(d, tile, pair_lds, ptap, wscale);
+}
+
+}   // namespace
+
+/* Both images of every layer from one read of its weights (csrc: pack_weight_pair_multi_kernel): descs[i] names the torch tensor
+ * [A][B][R][S], up to two images (role 0 / 1: destination, rows = a or b, tap order, live-tap prefix) and the optimiser pass's
+ * chunk maxima that cover it (mandatory here: the launch has no maximum pass of its own).  Images of a layer whose row count is
+ * not a multiple of 128 must have been zero-filled once (the padding rows are never written).  What it replaces:
+ * stem_f16x2_pack_conv_weights_multi called once per role after every optimiser step (stem/trainSTEM.py:213). */
+STEM_EXPORT int stem_f16x2_pack_conv_weights_pair_multi(const stem_f16x2_pair_desc *descs, int n, void *stream)
+{
+    STEM_CHECK_ARG(descs && n >= 1 && n <= MAXPAIR, "stem_f16x2_pack_conv_weights_pair_multi: 1..%d descriptors per call, got %d", MAXPAIR, n);
+    PairTable tab;
+    memset(&tab, 0, sizeof(tab));
+    int tiles = 0, maxrs = 1;
+    for (int i = 0; i < n; ++i) {
+        const stem_f16x2_pair_desc &h = descs[i];
+        STEM_CHECK_ARG(h.w && h.A >= 1 && h.B >= 1 && h.R >= 1 && h.S >= 1 && h.R * h.S <= MAXTAP && h.bmax && h.nb >= 1,
+                       "stem_f16x2_pack_conv_weights_pair_multi: descriptor %d: tensor, window (<= %d taps) and chunk maxima are mandatory", i, MAXTAP);
+        PairDesc &d = tab.d[i];
+        d.w = static_cast<float *>(const_cast<void *>(h.w));
+        d.A = h.A; d.B = h.B; d.R = h.R; d.S = h.S; d.bmax = h.bmax; d.b0 = h.b0; d.nb = h.nb;
+        const void *wps[2] = {h.wp0, h.wp1};
+        const int modes[2] = {h.mode0, h.mode1}, taps[2] = {h.taps0, h.taps1};
+        for (int r = 0; r < 2; ++r) {
+            d.role[r].wp = const_cast<void *>(wps[r]);
+            if (!wps[r]) continue;
+            d.role[r].rows_b = modes[r] & 1;
+            d.role[r].tapmode = modes[r] >> 1;
+            d.role[r].taps = taps[r];
+            const int C = d.role[r].rows_b ? h.A : h.B;
+            STEM_CHECK_ARG(d.role[r].tapmode >= 0 && d.role[r].tapmode <= 2 && C % 32 == 0 && taps[r] >= 0 && taps[r] <= h.R * h.S &&
+                           (taps[r] == 0 || (d.role[r].tapmode == 0 && r == 0)) && (d.role[r].tapmode != 2 || (h.R == h.S && (h.R & 1))),
+                           "stem_f16x2_pack_conv_weights_pair_multi: descriptor %d role %d: contraction channels %% 32, tap order 0..2, a live-tap "
+                           "prefix only for role 0 in identity order, phase order for odd square windows", i, r);
+        }
+        d.tile0 = tiles;
+        tiles += cdiv(h.A, PAIR_T) * cdiv(h.B, PAIR_T);
+        if (h.R * h.S > maxrs) maxrs = h.R * h.S;
+    }
+    tab.n = n;
+    const size_t lds = (size_t)PAIR_T * PAIR_T * maxrs * sizeof(float) + 32 * sizeof(int);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute((const void *)pack_weight_pair_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(pack_weight_pair_multi_kernel, dim3(tiles), dim3(PAIR_NT), lds, (hipStream_t)stream, tab);
+    STEM_LAUNCH_CHECK("stem_f16x2_pack_conv_weights_pair_multi");
+    return 0;
+}
+
+namespace {
 constexpr size_t kGenCntBytes = 64 * 1024;          // arrival counters in front of the split-K slabs: the layout of igemm.hip's
                                                     // workspace, so that one zero-headed buffer per stream serves both kernels
 

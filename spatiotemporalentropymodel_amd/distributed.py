@@ -168,9 +168,10 @@ class OverlappedGradReducer:
         self._direct = self.active and flat.grad.is_cuda and dist.get_backend() == "nccl"
         self._stream = _side_stream(flat.grad.device) if (flat.grad.is_cuda and not self._direct) else None
         self._works = []           # asynchronous collectives of this step (direct mode)
-        self._reported = []        # (stream, event) of every report since the last finish() (direct mode)
         self._done = []            # [lo, hi) slices reported since the last finish()
-        self._pending = []         # reported, final, not yet exchanged: merged contiguous runs [lo, hi]
+        self._pending = []         # reported, final, not yet exchanged: merged contiguous runs [lo, hi, {stream: event}] -- the events
+                                   # after which the run's slices are final on the streams that reported them (direct mode)
+        self._events = {}          # stream handle -> its event, re-used from step to step
         self.calls = 0             # slices reported (schedule bookkeeping)
         self.collectives = 0       # all-reduce calls issued
         #: a run of final gradients is exchanged once it holds this many bytes (and whatever is left at finish()).  What is
@@ -189,14 +190,14 @@ class OverlappedGradReducer:
         engine.grad_ready_hook = self.reduce_params
         return self
 
-    def _exchange(self, lo, hi):
+    def _exchange(self, lo, hi, deps=None):
         self.collectives += 1
         if not self.active:
             return
         g = self.flat.grad[lo:hi]
         if self._direct:
             cur = torch.cuda.current_stream()
-            for st, ev in self._reported:          # slices of the run that became final on another stream
+            for st, ev in (deps or {}).items():    # slices of THIS run that became final on another stream (nothing else is waited for)
                 if st != cur:
                     cur.wait_event(ev)
             self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
@@ -217,14 +218,19 @@ class OverlappedGradReducer:
         spans = sorted(self._off[id(p)] for p in params if id(p) in self._off)
         if not spans:
             return
+        dep = {}
         if self._direct:
+            # one event per report: "these slices are final on this stream from here on".  A run that is exchanged from the very
+            # stream that reported all of its slices needs none of them (stream order); the events are recorded anyway because a
+            # pending run may leave later, merged with slices of another stream
+            # (one event per stream, recorded again at every report: a wait refers to the latest record before it, which on the
+            # same stream covers the earlier ones)
             cur = torch.cuda.current_stream()
-            if not self._reported or self._reported[-1][0] != cur:
-                ev = torch.cuda.Event()
-                ev.record(cur)
-                self._reported.append((cur, ev))
-            else:                                   # same stream as the last report: one event at its latest point is enough
-                self._reported[-1][1].record(cur)
+            ev = self._events.get(cur.cuda_stream)
+            if ev is None:
+                ev = self._events[cur.cuda_stream] = torch.cuda.Event()
+            ev.record(cur)
+            dep = {cur: ev}
         if self.active and self._stream is not None:
             # a reported slice may wait in `_pending` and leave merged with slices reported later from OTHER streams (a second
             # weight-gradient lane, a hook caller with its own streams): order it in front of the reducer's stream now, on the
@@ -243,20 +249,21 @@ class OverlappedGradReducer:
             hi = min(hi, self.flat.grad.numel())
             self._done.append((lo, hi))
             self.calls += 1
-            self._pending.append([lo, hi])
-        self._pending.sort()
+            self._pending.append([lo, hi, dict(dep)])
+        self._pending.sort(key=lambda r: (r[0], r[1]))
         merged = []
-        for lo, hi in self._pending:
+        for lo, hi, d in self._pending:
             if merged and lo <= merged[-1][1]:
                 merged[-1][1] = max(merged[-1][1], hi)
+                merged[-1][2].update(d)             # the LATEST event of a stream covers its earlier reports
             else:
-                merged.append([lo, hi])
+                merged.append([lo, hi, dict(d)])
         keep = []
-        for lo, hi in merged:
+        for lo, hi, d in merged:
             if (hi - lo) * self.flat.grad.element_size() >= self.min_bytes:
-                self._exchange(lo, hi)
+                self._exchange(lo, hi, d)
             else:
-                keep.append([lo, hi])
+                keep.append([lo, hi, d])
         self._pending = keep
 
     def finish(self):
@@ -279,12 +286,12 @@ class OverlappedGradReducer:
         if pos < n:
             raise RuntimeError(f"OverlappedGradReducer: gradient elements [{pos}, {n}) were never reported by the "
                                f"backward schedule ({self._names(pos, n)}): they would stay rank-local")
-        for lo, hi in pending:                     # what never reached min_bytes on its own
-            self._exchange(lo, hi)
+        for lo, hi, d in pending:                  # what never reached min_bytes on its own
+            self._exchange(lo, hi, d)
         if self._direct:
-            for w in self._works:                  # the current stream waits for the process group's stream
-                w.wait()
-            self._works, self._reported = [], []
+            if self._works:                        # the process group runs its collectives on ONE stream, in issue order: the last
+                self._works[-1].wait()             # one's completion covers them all -- one cross-queue wait instead of one per call
+            self._works = []
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
 

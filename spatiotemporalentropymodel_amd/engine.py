@@ -88,8 +88,9 @@ class _Layer:
     def alloc_packs(self, device):
         if self.fx3s and self.fx3t:
             conv = self.kind == "conv"
-            strided = torch.empty(F.f16x2_gen_weight_bytes(*((self.K, self.C) if conv else (self.C, self.K)), self.R, self.R), device=device, dtype=torch.uint8)
-            phases = torch.empty(F.f16x2_gen_weight_bytes(*((self.C, self.K) if conv else (self.K, self.C)), self.R, self.R), device=device, dtype=torch.uint8)
+            # (zeros: the pair pack never writes the padding rows of a 128-row tile)
+            strided = torch.zeros(F.f16x2_gen_weight_bytes(*((self.K, self.C) if conv else (self.C, self.K)), self.R, self.R), device=device, dtype=torch.uint8)
+            phases = torch.zeros(F.f16x2_gen_weight_bytes(*((self.C, self.K) if conv else (self.K, self.C)), self.R, self.R), device=device, dtype=torch.uint8)
             self.wp_fwd = torch.empty(0, device=device)              # never read: marks the layer as allocated
             self.wp_dgrad = None
             if conv:
@@ -111,8 +112,8 @@ class _Layer:
                 self.wp_dgrad = None
             return
         if self.fx3:
-            self.wp6_fwd = torch.empty(F.f16x2_gen_weight_bytes(self.K, self.C, self.R, self.R), device=device, dtype=torch.uint8)
-            self.wp6_dgrad = torch.empty(F.f16x2_gen_weight_bytes(self.C, self.K, self.R, self.R), device=device,
+            self.wp6_fwd = torch.zeros(F.f16x2_gen_weight_bytes(self.K, self.C, self.R, self.R), device=device, dtype=torch.uint8)
+            self.wp6_dgrad = torch.zeros(F.f16x2_gen_weight_bytes(self.C, self.K, self.R, self.R), device=device,
                                          dtype=torch.uint8) if self.need_dgrad else None
             return
         n = self.K * self.C * self.R * self.R
@@ -139,6 +140,24 @@ class _Layer:
             return ([self._desc32(1)], []) if conv \
                 else ([], [_lib.F16PackDesc(w.data_ptr(), self.wp6_dgrad.data_ptr(), self.C, self.K, self.R, self.R, 0, 0)])
         return ([], self.pack_descs6()[role:role + 1]) if self.fx3 else (self.pack_descs()[role:role + 1], [])
+
+    def pair_desc(self):
+        """both fp16 images of this layer as ONE descriptor of the pair pack (F.pack_weights_f16x2_pair_multi), or None when the
+        layer keeps an fp32 copy of a role"""
+        a, b = self.role_descs(0), self.role_descs(1)
+        if a[0] or b[0] or not a[1]:
+            return None
+        w = self.mod.weight
+        A, Bd = int(w.shape[0]), int(w.shape[1])
+        roles = []
+        for d in (a[1][0], b[1][0] if b[1] else None):
+            if d is None:
+                roles += [None, 0, 0]
+                continue
+            rows_b = int(d.flip != 0)
+            assert (d.N, d.C) == ((Bd, A) if rows_b else (A, Bd)), "pair pack: a role image must be a transpose of the tensor itself"
+            roles += [d.wp, rows_b | (int(d.flip) << 1), int(d.taps)]
+        return _lib.F16PairDesc(w.data_ptr(), A, Bd, self.R, self.R, roles[0], roles[1], roles[2], roles[3], roles[4], roles[5], None, 0, 0)
 
     def pack_descs6(self):
         w = self.mod.weight
@@ -496,6 +515,9 @@ class StemEngine:
                 l.alloc_packs(l.mod.weight.device)
             self._pack_descs = None
         dev = self.layers[0].mod.weight.device
+        if block_max is not None and self.pack_pair and self._pack_pairs(*block_max):
+            self._pack_key = tuple((_layers.weight_epoch(l.mod.weight), l.mod.weight._version, l.mod.weight.data_ptr()) for l in self.layers)
+            return
         side = self.side_stream(dev) if self.split_pack and not torch.cuda.is_current_stream_capturing() else None
         roles = ((0, 1), (1, 2)) if side is not None else ((0, 2),)
         for lo, hi in roles:                     # descriptor 0 of a layer = forward role, descriptor 1 = input-gradient role
@@ -552,6 +574,30 @@ class StemEngine:
                     F.event_record(self._dgrad_pack_event, side)
         # masked == 2 zeroed taps of the context weight in place: refresh its version in the key
         self._pack_key = tuple((_layers.weight_epoch(l.mod.weight), l.mod.weight._version, l.mod.weight.data_ptr()) for l in self.layers)
+
+    #: after an optimiser pass that left chunk maxima, both images of every layer come from ONE launch that reads each weight once
+    #: (F.pack_weights_f16x2_pair_multi) on the compute stream, instead of one launch per role (the input-gradient role on the
+    #: weight-gradient stream, under the forward).  STEM_ENGINE_PACK_PAIR=0: one launch per role as in round 4
+    pack_pair = _Switch("engine_pack_pair")
+
+    def _pack_pairs(self, maxima, flat):
+        """the pair pack of every layer, if every layer's images are fp16 transposes of its tensor and every tensor lies inside the
+        flat buffer the optimiser pass measured; else False (the per-role path runs)"""
+        descs = [l.pair_desc() for l in self.layers]
+        if any(d is None for d in descs):
+            return False
+        ch = F.adam_chunk()
+        base, n = flat.data_ptr(), flat.numel()
+        for d in descs:
+            off = (d.w - base) // 4
+            numel = d.A * d.B * d.R * d.S
+            if (d.w - base) % 4 or off < 0 or off + numel > n:
+                return False
+            d.bmax, d.b0 = maxima.data_ptr(), off // ch
+            d.nb = (off + numel - 1) // ch - d.b0 + 1
+        F.pack_weights_f16x2_pair_multi((_lib.F16PairDesc * len(descs))(*descs))
+        self._dgrad_pack_event = self._fwd_rest_event = None
+        return True
 
     def unpack_all(self):
         for lane in sorted({l.lane for l in self.layers}):

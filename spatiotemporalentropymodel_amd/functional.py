@@ -759,6 +759,14 @@ def pack_weights_f16x2_multi(descs):
         _chk(_lib.hip().stem_f16x2_pack_conv_weights_multi(part, n, _stream()))      # (an array object, not byref: a launch tape keeps it alive)
 
 
+def pack_weights_f16x2_pair_multi(descs):
+    """descs: ctypes array of _lib.F16PairDesc (at most 20 per call): both images of every layer from one read of its weights"""
+    for i in range(0, len(descs), 20):
+        n = min(20, len(descs) - i)
+        part = descs if (i == 0 and n == len(descs)) else (_lib.F16PairDesc * n).from_buffer(descs, i * C.sizeof(_lib.F16PairDesc))
+        _chk(_lib.hip().stem_f16x2_pack_conv_weights_pair_multi(part, n, _stream()))
+
+
 def conv2d_f16x3_gen(xp: F16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EPI_BIAS, slope=LRELU_SLOPE, z=None, out=None,
                       want_fp32=True, want_planes=False, taps=0):
     """General f16x3 convolution (training-time STEM layers): returns (fp32 NHWC tensor or None, F16Planes or None).

@@ -146,7 +146,29 @@ def _worker_overlap(rank, world, port, q):
     eng.grad_ready_hook(groups[4])
     red2.finish()
     ok_b = bool(torch.equal(flat.grad, expect)) and untouched and red2.collectives == 1 and n_a == 6 and red2.calls == 6
-    q.put((rank, {"ok": ok_a and ok_b, "runs": bool(ok_runs), "calls": red.calls, "scale": red.grad_scale}))
+    # the layout configure_optimizers uses (optim.backward_layout_key): groups sit in backward-completion order, so HD and the
+    # bottleneck are ONE run, nothing small is left over for finish(), and the parameter ORDER (names / params / state dicts) is
+    # still the name-sorted one
+    from spatiotemporalentropymodel_amd.optim import backward_layout_key
+    m3 = SpatioTemporalPriorModel_Res(64, 96)
+    main3 = sorted([(n, p) for n, p in m3.named_parameters() if not n.endswith(".quantiles")], key=lambda t: t[0])
+    flat3 = FlatParameters(main3, layout_key=backward_layout_key)
+    eng3 = m3.engine()
+    red3 = D.OverlappedGradReducer(flat3, min_bytes=0).attach(eng3)
+    flat3.grad.copy_(torch.arange(flat3.numel, dtype=torch.float32) % 1000 * (rank + 1))
+    eb3 = m3.entropy_bottleneck
+    groups3 = [[p for l in eng3.EPM for p in (l.mod.weight, l.mod.bias)], [eng3.CTX.mod.weight, eng3.CTX.mod.bias],
+               [p for l in eng3.TPM for p in (l.mod.weight, l.mod.bias)],
+               [p for l in eng3.HD for p in (l.mod.weight, l.mod.bias)] + eb3._tensors14(),
+               [p for l in eng3.HE for p in (l.mod.weight, l.mod.bias)]]
+    lows = []
+    for grp in groups3:
+        eng3.grad_ready_hook(grp)
+        lows.append(min(flat3.offsets[flat3.params.index(p)] if False else next(o for q_, o in zip(flat3.params, flat3.offsets) if q_ is p) for p in grp))
+    red3.finish()
+    ok_c = (bool(torch.equal(flat3.grad, torch.arange(flat3.numel, dtype=torch.float32) % 1000 * 3)) and red3.calls == 5 and red3.collectives == 5
+            and lows == sorted(lows) and lows[0] == 0 and flat3.names == [n for n, _ in main3])
+    q.put((rank, {"ok": ok_a and ok_b and ok_c, "runs": bool(ok_runs), "calls": red.calls, "scale": red.grad_scale}))
     dist.barrier()
     dist.destroy_process_group()
 

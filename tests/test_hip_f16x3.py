@@ -698,3 +698,63 @@ def test_transposed_face_odd_fine_grid_vs_oracle(F, odd):
     assert tuple(d.shape) == (B, N, Hf, Wf)
     assert_close(host(d), ref, what=f"tconv dgrad odd {odd}", floor=0.1)
     assert planes_match(dp, d)
+
+
+def test_pair_pack_writes_the_same_images_as_the_per_role_pack(F):
+    """stem_f16x2_pack_conv_weights_pair_multi (both images of a layer from one read of its weights: 32 x 32 x RS tiles through
+    LDS) against stem_f16x2_pack_conv_weights_multi called per role, byte for byte, with the scales taken from the optimiser
+    pass's chunk maxima in both: stride-1 convolution (forward + mirrored input-gradient image), the masked context convolution
+    (12 live taps, the others zeroed in place), a strided convolution (strided face + four phase images), a transposed
+    convolution (phase images + strided face), 1x1 layers, row counts that are not multiples of 32 / 128."""
+    from spatiotemporalentropymodel_amd import _lib
+    ch = F.adam_chunk()
+    # (A, B, R, role-0 (flip, taps) or None, role-1 flip or None)
+    layers = [(96, 64, 3, (0, 0), 1), (384, 192, 5, (0, 12), None), (128, 160, 5, (0, 0), 2), (64, 96, 5, (2, 0), 0), (576, 384, 1, (0, 0), 1),
+              (100, 64, 1, (0, 0), None), (320, 256, 5, (0, 0), 1)]
+    sizes = [A * B * R * R for A, B, R, _, _ in layers]
+    offs = np.concatenate([[0], np.cumsum([s + 37 for s in sizes])])[:-1]          # odd gaps: tensors share chunks with their neighbours
+    offs = (offs + 3) // 4 * 4
+    n = int(offs[-1] + sizes[-1])
+    rng = np.random.default_rng(9)
+    p0 = rng.standard_normal(n).astype(np.float32) * 0.05
+    bufs = []
+    for _ in range(2):
+        p = dev(p0)
+        g, m, v = dev(rng.standard_normal(n).astype(np.float32)), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        rng = np.random.default_rng(10)                      # the same gradient for both copies
+        bmax = torch.empty(4 * ((n + ch - 1) // ch), device="cuda")
+        bufs.append((p, g, m, v, bmax))
+    bufs[1][1].copy_(bufs[0][1])
+    for p, g, m, v, bmax in bufs:
+        F.adam_step_bmax(p, g, m, v, None, 0.0, 1.0, 1e-3, 0.9, 0.999, 1e-8, 1, bmax, zero_grad=True)
+    assert torch.equal(bufs[0][0], bufs[1][0])
+
+    def chunks(off, numel):
+        b0 = int(off) // ch
+        return b0, (int(off) + numel - 1) // ch - b0 + 1
+
+    single, pair, imgs_s, imgs_p = [], [], [], []
+    for (A, B, R, r0, r1), off, numel in zip(layers, offs, sizes):
+        b0, nb = chunks(off, numel)
+        roles_p = []
+        for which, spec in ((0, r0), (1, (r1, 0) if r1 is not None else None)):
+            if spec is None:
+                roles_p += [None, 0, 0]
+                continue
+            flip, taps = spec
+            N, Cc = (B, A) if flip else (A, B)
+            nbytes = F.f16x2_gen_weight_bytes(N, Cc, R, R)
+            a, b = torch.zeros(nbytes, device="cuda", dtype=torch.uint8), torch.zeros(nbytes, device="cuda", dtype=torch.uint8)
+            imgs_s.append(a)
+            imgs_p.append(b)
+            single.append(_lib.F16PackDesc(bufs[0][0].data_ptr() + 4 * int(off), a.data_ptr(), N, Cc, R, R, flip, taps, bufs[0][4].data_ptr(), b0, nb, 0, 0))
+            roles_p += [b.data_ptr(), int(flip != 0) | (flip << 1), taps]
+        pair.append(_lib.F16PairDesc(bufs[1][0].data_ptr() + 4 * int(off), A, B, R, R, *roles_p, bufs[1][4].data_ptr(), b0, nb))
+    F.pack_weights_f16x2_multi((_lib.F16PackDesc * len(single))(*single))
+    F.pack_weights_f16x2_pair_multi((_lib.F16PairDesc * len(pair))(*pair))
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(imgs_s, imgs_p)):
+        assert torch.equal(a, b), f"image {i}: {int((a != b).sum())} of {a.numel()} bytes differ"
+    assert torch.equal(bufs[0][0], bufs[1][0])                  # the masked taps were zeroed in place by both
+    wctx = bufs[1][0][int(offs[1]):int(offs[1]) + sizes[1]].view(384, 192, 25)
+    assert float(wctx[:, :, 12:].abs().max()) == 0.0 and float(wctx[:, :, :12].abs().max()) > 0.0
