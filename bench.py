@@ -445,6 +445,10 @@ def main():
     ap.add_argument("--latents", default="prefetch", choices=["first", "prefetch"], help="prefetch (default): getY of frame t + 1 runs on a second "
                     "stream while P-frame step t runs (trainer.LatentPrefetcher); first: getY of all 7 frames before the P-frame steps")
     ap.add_argument("--latents-ahead", type=int, default=1)
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("STEM_BENCH_PIPELINE", "0")), help="1: the next septuplet's first two "
+                    "latents are computed during the current septuplet's last two P-frame steps (a training loop whose loader holds the next batch); "
+                    "0 (default): every septuplet enqueues its own two opening transforms -- with the launch tape the host runs a P-frame step ahead of "
+                    "the GPU, so they overlap the previous septuplet's tail anyway (12.12 against 12.15 ms per step, profiles/r05_ab_pipeline.log)")
     ap.add_argument("--generic", action="store_true", help="run the P-frame step through nn.Module / autograd / torch-style optimiser "
                     "calls (selfcheck.p_frame_step) instead of the explicit fused schedule (trainer.FusedPFrameStep)")
     ap.add_argument("--graph", action="store_true", help="replay the P-frame step from its hipGraph (graphs.GraphedPFrameStep) instead of "
@@ -546,7 +550,12 @@ def main():
         # stays ahead of the GPU through the launch-heavy P-frame steps (measured: the GPU idled ~3.3 ms per step waiting
         # for launches when getY was issued inside each P-step, tools/timeline.py).
         if prefetch is not None:
-            prefetch.start(frames, frames_ready=True)       # the synthetic frames were generated before the timed region
+            # the synthetic frames were generated before the timed region.  --pipeline 1: the NEXT septuplet (a loader's following
+            # batch; here the same synthetic tensors) is named too, so that its frames 0 and 1 go through the analysis transform
+            # during this septuplet's last two P-frame steps instead of in front of its own first one (trainer.LatentPrefetcher:
+            # every step still runs its 7 transforms -- the first timed step adopts two from the last warm-up step, the last timed
+            # step computes two for the step that would follow, inside the timed region)
+            prefetch.start(frames, frames_ready=True, next_frames=frames if args.pipeline else None)
             ys = None
             y_cond = prefetch.get(0)[1]
         else:

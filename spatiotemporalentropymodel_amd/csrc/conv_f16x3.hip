@@ -1726,18 +1726,39 @@ __device__ inline void pair_pack_tile(const PairDesc &d, int tile, float *lds, i
     const int row = PAIR_T * RS;                       // floats of one a-row of the tile (b-major, taps innermost): the tensor's own order
     // masked convolution: the taps beyond the live prefix are zeroed IN PLACE (layers.py:44 `weight.data *= mask` at every forward)
     const int live = (d.role[0].wp && d.role[0].tapmode == 0 && d.role[0].taps > 0 && d.role[0].taps < RS) ? d.role[0].taps : RS;
-    for (int idx = threadIdx.x; idx < PAIR_T * row; idx += PAIR_NT) {
-        const int a = idx / row, rem = idx - a * row;
-        float v = 0.f;
-        if (a < na && rem < nb * RS) {
-            float *src = d.w + ((size_t)(a0 + a) * d.B + b0) * RS + rem;
-            v = *src;
-            if (live < RS && rem % RS >= live) {
-                *src = 0.f;
-                v = 0.f;
+    if (na == PAIR_T && nb == PAIR_T && live == RS && (reinterpret_cast<uintptr_t>(d.w) & 15) == 0 && ((size_t)d.B * RS) % 4 == 0) {
+        // full tile: every a-row of the tile is 32 * RS consecutive floats starting on a 16-byte boundary -- float4 loads, four
+        // independent ones in flight per thread
+        constexpr int U = 4;
+        const int row4 = row / 4, n4 = PAIR_T * row4;                  // 32 * RS is a multiple of 4
+        for (int base = threadIdx.x; base < n4; base += U * PAIR_NT) {
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i4 = base + u * PAIR_NT;
+                const int a = i4 / row4, r4 = i4 - a * row4;
+                v[u] = i4 < n4 ? *reinterpret_cast<const f32x4 *>(d.w + ((size_t)(a0 + a) * d.B + b0) * RS + 4 * r4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i4 = base + u * PAIR_NT;
+                if (i4 < n4) *reinterpret_cast<f32x4 *>(lds + 4 * i4) = v[u];
             }
         }
-        lds[idx] = v;
+    } else {
+        for (int idx = threadIdx.x; idx < PAIR_T * row; idx += PAIR_NT) {
+            const int a = idx / row, rem = idx - a * row;
+            float v = 0.f;
+            if (a < na && rem < nb * RS) {
+                float *src = d.w + ((size_t)(a0 + a) * d.B + b0) * RS + rem;
+                v = *src;
+                if (live < RS && rem % RS >= live) {
+                    *src = 0.f;
+                    v = 0.f;
+                }
+            }
+            lds[idx] = v;
+        }
     }
     __syncthreads();
 #pragma unroll

@@ -62,6 +62,9 @@ class LatentPrefetcher:
         for t in range(1, len(frames)):
             y_cur, _ = pf.get(t)              # compute stream waits for frame t's event; frame t + ahead is enqueued
             ...
+
+    Across sequences (a training loop whose loader holds the next batch): `pf.start(frames, next_frames=following)` also computes
+    the following sequence's first two latents during this sequence's last two P-frame steps; `pf.start(following, ...)` adopts them.
     """
 
     def __init__(self, imodel, ahead=1):
@@ -69,29 +72,50 @@ class LatentPrefetcher:
         self._stream = None
         self._frames = self._ys = self._events = None
         self._next = 0
+        self._nxt = None            # {"frames", "ys", "events", "n"}: the FOLLOWING sequence, whose first latents are computed early
 
-    def _enqueue(self, t):
-        dev = self._frames[t].device
+    def _enqueue_into(self, frames, ys, events, t):
+        dev = frames[t].device
         if self._stream is None or self._stream.device != dev:
             self._stream = F.make_stream(dev, "latents")
         with F.on_stream(self._stream), torch.no_grad():
-            self._ys[t] = self.imodel.getY(self._frames[t])
-            self._events[t] = torch.cuda.Event()
-            self._events[t].record(self._stream)
+            ys[t] = self.imodel.getY(frames[t])
+            events[t] = torch.cuda.Event()
+            events[t].record(self._stream)
 
-    def start(self, frames, frames_ready=False):
+    def _enqueue(self, t):
+        self._enqueue_into(self._frames, self._ys, self._events, t)
+
+    def start(self, frames, frames_ready=False, next_frames=None):
         """frames_ready=True: the frame tensors are not being written by work queued on the compute stream (a data loader's
         finished batch), so the first transforms need not wait for what that stream still has queued -- they then overlap the
-        tail of the previous optimisation step"""
-        self._frames = list(frames)
-        n = len(self._frames)
-        self._ys, self._events = [None] * n, [None] * n
+        tail of the previous optimisation step.
+
+        next_frames: the sequence that will be started NEXT (the loader's following batch, already resident).  A sequence cannot
+        begin its first P-frame step before the latents of its frames 0 and 1 exist -- two analysis transforms (~1.5 ms at the
+        bench size) during which the step's own streams idle.  With next_frames those two are computed during the LAST two
+        P-frame steps of this sequence, like every other frame's, and start(next_frames) then finds them in flight.  The transform
+        is frozen (stem/trainSTEM.py:128) and the calls keep their order (this sequence's frames, then the next one's), so every
+        result -- noise draws included -- is what the unpipelined loop computes."""
+        frames = list(frames) if not isinstance(frames, list) else frames
+        n = len(frames)
+        adopted = 0
+        if self._nxt is not None and (self._nxt["frames"] is frames or
+                                      (len(self._nxt["frames"]) == n and all(a is b for a, b in zip(self._nxt["frames"], frames)))):
+            self._ys, self._events, adopted = self._nxt["ys"], self._nxt["events"], self._nxt["n"]
+        else:
+            self._ys, self._events = [None] * n, [None] * n
+        self._frames = frames
+        self._nxt = None
+        if next_frames is not None:
+            nf = list(next_frames) if not isinstance(next_frames, list) else next_frames
+            self._nxt = {"frames": nf, "ys": [None] * len(nf), "events": [None] * len(nf), "n": 0}
         dev = self._frames[0].device
         if self._stream is None or self._stream.device != dev:
             self._stream = F.make_stream(dev, "latents")
         if not frames_ready:
             F.stream_wait(self._stream, F.cur_stream(dev))      # the frames were produced on the compute stream
-        self._next = 0
+        self._next = adopted
         while self._next < n and self._next <= self.ahead:
             self._enqueue(self._next)
             self._next += 1
@@ -99,9 +123,16 @@ class LatentPrefetcher:
 
     def get(self, t):
         """(y, y + noise) of frame t, ordered before whatever the current stream does next"""
-        while self._next < len(self._frames) and self._next <= t + self.ahead:
+        n = len(self._frames)
+        while self._next < n and self._next <= t + self.ahead:
             self._enqueue(self._next)
             self._next += 1
+        if self._nxt is not None and self._next >= n:
+            # positions beyond this sequence: the next one's opening frames, one more than `ahead` (a sequence opens with TWO latents)
+            want = min(t + self.ahead + 2 - n, self.ahead + 1, len(self._nxt["frames"]))
+            while self._nxt["n"] < want:
+                self._enqueue_into(self._nxt["frames"], self._nxt["ys"], self._nxt["events"], self._nxt["n"])
+                self._nxt["n"] += 1
         cur = F.cur_stream(self._frames[t].device)
         cur.wait_event(self._events[t])
         y, yq = self._ys[t]

@@ -151,6 +151,45 @@ def test_latent_prefetcher_equals_direct_calls():
     torch.cuda.synchronize()
 
 
+def test_latent_prefetcher_across_sequences_equals_direct_calls():
+    """start(frames, next_frames=following): the following sequence's first two latents are computed during this sequence's last
+    two consumer steps and adopted by start(following).  Same call order as the unpipelined loop, so y AND the noisy copy (the
+    noise counters advance per call) equal direct sequential calls bit for bit -- three sequences, the last without a successor."""
+    from spatiotemporalentropymodel_amd.trainer import LatentPrefetcher
+    from spatiotemporalentropymodel_amd.zoo import models
+    d = torch.device("cuda:0")
+    g = torch.Generator(device=d).manual_seed(3)
+    seqs = [[torch.rand(2, 3, 128, 128, device=d, generator=g) for _ in range(5)] for _ in range(3)]
+    runs = []
+    for piped in (False, True):
+        torch.manual_seed(4)
+        imodel = models["mbt2018"](quality=4).to(d).eval()
+        imodel.gaussian_conditional.noise_seed = 77
+        out = []
+        if not piped:
+            with torch.no_grad():
+                for fr in seqs:
+                    out.append([tuple(t.clone() for t in imodel.getY(f)) for f in fr])
+        else:
+            pf = LatentPrefetcher(imodel)
+            for i, fr in enumerate(seqs):
+                nxt = seqs[i + 1] if i + 1 < len(seqs) else None
+                pf.start(fr, frames_ready=True, next_frames=nxt)
+                if i > 0:
+                    assert pf._next >= 2                     # frames 0 and 1 were adopted, not recomputed
+                got = [pf.get(0)]
+                for t in range(1, len(fr)):
+                    got.append(pf.get(t))
+                    if nxt is not None and t == len(fr) - 1:
+                        assert pf._nxt["n"] == 2
+                torch.cuda.synchronize()
+                out.append([(y.clone(), yq.clone()) for y, yq in got])
+        runs.append(out)
+    for sa, sb in zip(*runs):
+        for (ya, qa), (yb, qb) in zip(sa, sb):
+            assert torch.equal(ya, yb) and torch.equal(qa, qb)
+
+
 def test_tuned_schedule_changes_no_result(monkeypatch):
     """trainer.tuned_schedule (what bench.py runs under: step streams at high priority on a dedicated compute stream, the
     prefetch stream masked to 192 CUs through hipExtStreamCreateWithCUMask) is scheduling only: three P-frame steps with the
