@@ -487,7 +487,7 @@ def main():
     #    weight-gradient / branch / auxiliary streams -- at HIP's high priority, the latent-prefetch stream at normal priority: the
     #    command processor then dispatches the step's small kernels ahead of the long analysis-transform kernels (22.4 against
     #    22.7 ms per step on the same box).  STEM_STREAM_PRIO="" runs everything at one priority;
-    #  * the latent-prefetch stream is confined to 192 of the 256 CUs (hipExtStreamCreateWithCUMask): a running workgroup of the
+    #  * the latent-prefetch stream is confined to 160 of the 256 CUs (192 until round 4; hipExtStreamCreateWithCUMask): a running workgroup of the
     #    long analysis-transform kernels cannot be pre-empted, so without the mask the step's short, high-priority launches wait for
     #    CUs to drain (HE.2's 25 us launch took 200 us next to g_a.2).  Same box: 15.74 -> 15.39-15.43 ms per step (208 CUs 15.73,
     #    160 CUs 15.58, 144 CUs 16.4); with the round's earlier, slower kernels the same mask cost time.  STEM_STREAM_CUMASK="" removes it.

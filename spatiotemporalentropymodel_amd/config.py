@@ -51,7 +51,7 @@ class StemRuntimeConfig:
     engine_fuse_gc_backward: bool = True #: GaussianConditional backward inside the fused forward glue kernel
     engine_bias_multi: bool = True       #: one launch for a module group's bias-gradient second stages
     stream_prio: str = ""                #: "latents=0,side=-1,compute=-1" (trainer.tuned_schedule installs it)
-    stream_cumask: str = ""              #: "latents=block:192"
+    stream_cumask: str = ""              #: "latents=block:160"
     # ---- data parallel
     dp_min_bytes: int = 8 << 20          #: a run of final gradients is exchanged once it holds this many bytes
     dist_backend: str = ""               #: "" = RCCL when every rank has its own GPU, else gloo

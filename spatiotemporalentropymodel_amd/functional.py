@@ -169,7 +169,7 @@ def _cu_mask(role):
     """STEM_STREAM_CUMASK="latents=block:96" / "latents=mod8:3": restrict a role's stream to a subset of the 256 CUs -- the
     first n CU bits, or the bits i with i % 8 < k (whole XCDs if the mask enumerates CUs XCD-interleaved).  Keeps the long
     analysis-transform kernels of the prefetch stream off part of the chip so that the P-frame step's short kernels always find
-    free CUs (bench.py's default: latents=block:192).  A masked stream is created at the default priority."""
+    free CUs (bench.py's default: latents=block:160).  A masked stream is created at the default priority."""
     for kv in _config.runtime().stream_cumask.split(","):
         if "=" in kv:
             k, v = kv.split("=")

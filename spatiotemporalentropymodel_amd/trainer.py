@@ -25,8 +25,11 @@ from . import functional as F
 from .layers import join_wgrad_stream
 
 
-#: the stream set-up bench.py measures; the environment variables of the same names override them ("" disables)
-SCHEDULE_DEFAULTS = {"STEM_STREAM_PRIO": "latents=0,side=-1,compute=-1", "STEM_STREAM_CUMASK": "latents=block:192"}
+#: the stream set-up bench.py measures; the environment variables of the same names override them ("" disables).
+#: Round 5: 160 of the 256 CUs for the latent prefetch (192 until round 4): the P-frame step got shorter and its three streams now
+#: keep the chip busier, 11.75 against 11.99 ms per bench step (128: 12.15, 144: 12.07, 176: 11.83, 224: 12.10, no mask: 12.08;
+#: profiles/r05_ab_cumask*.log)
+SCHEDULE_DEFAULTS = {"STEM_STREAM_PRIO": "latents=0,side=-1,compute=-1", "STEM_STREAM_CUMASK": "latents=block:160"}
 
 
 def tuned_schedule(device):

@@ -509,10 +509,10 @@ def test_tuned_schedule_defaults_and_cu_mask_words(monkeypatch):
     words handed to hipExtStreamCreateWithCUMask cover exactly the requested CUs (CPU: parsing only, no stream is created)."""
     from spatiotemporalentropymodel_amd import functional as F
     from spatiotemporalentropymodel_amd import trainer
-    assert trainer.SCHEDULE_DEFAULTS == {"STEM_STREAM_PRIO": "latents=0,side=-1,compute=-1", "STEM_STREAM_CUMASK": "latents=block:192"}
-    monkeypatch.setenv("STEM_STREAM_CUMASK", "latents=block:192")
+    assert trainer.SCHEDULE_DEFAULTS == {"STEM_STREAM_PRIO": "latents=0,side=-1,compute=-1", "STEM_STREAM_CUMASK": "latents=block:160"}
+    monkeypatch.setenv("STEM_STREAM_CUMASK", "latents=block:160")
     words = F._cu_mask("latents")
-    assert len(words) == 8 and sum(bin(w).count("1") for w in words) == 192 and words[:6] == [0xFFFFFFFF] * 6 and words[6:] == [0, 0]
+    assert len(words) == 8 and sum(bin(w).count("1") for w in words) == 160 and words[:5] == [0xFFFFFFFF] * 5 and words[5:] == [0, 0, 0]
     assert F._cu_mask("side") is None
     monkeypatch.setenv("STEM_STREAM_CUMASK", "latents=mod8:3,side=block:32")
     assert all(w == 0x07070707 for w in F._cu_mask("latents")) and F._cu_mask("side") == [0xFFFFFFFF] + [0] * 7
