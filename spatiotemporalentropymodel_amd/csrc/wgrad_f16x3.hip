@@ -60,7 +60,10 @@ constexpr int R_DY = NPL * PLANE;                          // 8192: dy [plane][1
 constexpr int R_XROWS = 32;                                // 16 + S - 1 <= 20 used; the copy engine fills whole 1 KiB blocks
 constexpr int R_BUF = R_DY + R_XROWS * 256;                // 16384
 constexpr int R_LDS = 4 * R_BUF;                           // four stages: chunk q is multiplied while q + 1 .. q + 3 are in flight
-constexpr int R_MINCHUNKS = 32;                            // pixel chunks per workgroup the planner keeps (slab traffic)
+constexpr int R_MINCHUNKS = 64;                            // pixel chunks per workgroup the planner keeps (slab traffic).  Round 5: 64 for every
+                                                           // window (32, 16 for 1x1 until round 4): at most four splits at the 4096-pixel
+                                                           // training size -- fewer slabs to write and sum.  In the bench step 11.54 ms against
+                                                           // 11.77 (48: 11.59, 86: 12.09, 128: 12.09, unsplit: 13.99; profiles/r05_ab_wg3_minch.log)
 
 __device__ inline int lds_off(int row, int chunk) { return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
@@ -459,7 +462,7 @@ int plan_splits(int B, int OH, int OW, int C, int K, int T, bool rows = false, i
     if (rows) {       // workgroups = tiles x filter rows x splits: at most 512 (two per CU), at least R_MINCHUNKS pixel chunks each
         const int nchunks = B * OH * OW / PX, wgs = cdiv(K, RT_K) * cdiv(C, RT_C) * R;
         int s = forced > 0 ? forced : 512 / wgs;
-        const int minch = stem_tuning(STEM_TUNE_WG3_MINCH) > 0 ? stem_tuning(STEM_TUNE_WG3_MINCH) : (R == 1 ? R_MINCHUNKS / 2 : R_MINCHUNKS);   // one tap: small slabs      // stem_tuning_set("wg3_minch", n): sweeps
+        const int minch = stem_tuning(STEM_TUNE_WG3_MINCH) > 0 ? stem_tuning(STEM_TUNE_WG3_MINCH) : R_MINCHUNKS;      // stem_tuning_set("wg3_minch", n): sweeps
         if (forced <= 0 && s > nchunks / minch) s = nchunks / minch;
         if (s > nchunks) s = nchunks;
         if (s < 1) s = 1;
