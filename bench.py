@@ -28,6 +28,15 @@ import types
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+# A rank of a data-parallel run has FIVE active streams (compute, weight gradients, hyper branch, latent prefetch + the process
+# group's): with the runtime's default of four hardware queues per priority every high-priority stream gets a queue of its own, and
+# the fifth active queue costs 2.2 ms per step on one MI355X (a stream that only waits for events and records one reproduces it:
+# the queues outnumber what the command processor keeps resident).  With two hardware queues per priority the streams share
+# queues and the same one-rank RCCL run takes 12.84 instead of 13.85 ms (11.54 without a group; profiles/r05_ab_hwq2.log).  Must be
+# in the environment before the HIP runtime starts, i.e. before torch is imported; single-GPU runs keep the default (12.6 vs 11.5 ms).
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("STEM_DIST_SINGLE", "").strip() not in ("", "0", "false", "no", "off"):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

@@ -16,6 +16,7 @@ compute stream still has queued.
 from __future__ import annotations
 
 import os
+import sys
 
 import torch
 import torch.distributed as dist

@@ -481,6 +481,8 @@ class StemEngine:
     #: the temporal-prior chain is enqueued before the hyper branch (scheduling only)
     tpm_first = _Switch("engine_tpm_first")
     tpm_first_bwd = _Switch("engine_tpm_first_bwd")
+    #: the context model's forward on the weight-gradient stream (opt-in experiment, STEM_ENGINE_CTX_ON_SIDE=1)
+    ctx_on_side = _Switch("engine_ctx_on_side")
     #: the GaussianConditional's backward computed by the fused forward glue (one launch less per P-frame step)
     fuse_gc_backward = _Switch("engine_fuse_gc_backward")
 
@@ -681,12 +683,16 @@ class StemEngine:
         assert not fused or training, "the fused glue is the TRAINING forward"
         k = {}
         target = t_hat = y_hat = None
+        ctx_go = None
         rec = self._rec = {}    # scale records left by the producers of fp32 tensors that are split for the fp16 kernels below
         if fused:
             # one kernel: he_in = [y_cur | y_cond], target, t_hat = target + noise, y_hat = t_hat (+ y_cond); it also records
             # max |y_cur|, |y_cond| and max |t_hat| per workgroup: the splits of he_in, y_cond and t_hat need no maximum pass
             slot = gc._noise_slot(yc) if self.has_spm else {}
             he_in, target, t_hat, y_hat = F.prior_prologue(yc, yd, self.residual, True, self.has_spm, records=rec if self.use_fx3 and self.use_records else None, **slot)
+            if self.has_spm and self.ctx_on_side and self.side_stream(dev) is not None and self._branch(dev) is not None:
+                ctx_go = self._events.setdefault("ctx_go", torch.cuda.Event())       # t_hat exists from here on
+                F.event_record(ctx_go, F.cur_stream(dev))
         else:
             # hyper encoder on cat(y_cur, y_cond): the two halves are written into one buffer
             he_in = F.empty_nhwc(B, 2 * Cin, H, W, dev)
@@ -767,7 +773,18 @@ class StemEngine:
             # gaussian_conditional.quantize(target, "noise" | "dequantize") with no means (:570-572, :853-855)
             if not fused:
                 t_hat = F.add(target, gc._noise_like(target)) if training else F.round_(target)
-            self._ctx_forward(t_hat, epm_in[:, o_ctx:o_ctx + P], pl)
+            if ctx_go is not None:
+                # the context model only needs t_hat: on the weight-gradient stream (idle during the forward) next to the TPM chain
+                # and the hyper branch, instead of behind the TPM chain
+                side = self.side_stream(dev)
+                F.event_wait(side, ctx_go)
+                with F.on_stream(side):
+                    self._ctx_forward(t_hat, epm_in[:, o_ctx:o_ctx + P], pl)
+                t_hat.record_stream(side)
+                epm_in.record_stream(side)
+                F.stream_wait(main, side)
+            else:
+                self._ctx_forward(t_hat, epm_in[:, o_ctx:o_ctx + P], pl)
         if bs is not None:
             F.stream_wait(main, bs)
         self._wait_fwd_rest()

@@ -20,7 +20,7 @@ def test_hip_library_exports_header_symbols():
     for n in names:
         assert hasattr(lib, n), f"libstem_hip.so does not export {n}"
     assert set(names) == set(_lib.declared_hip_symbols()), set(names) ^ set(_lib.declared_hip_symbols())
-    assert _lib.hip().stem_abi_version() == 4
+    assert _lib.hip().stem_abi_version() == 5
 
 
 def test_rans_library_exports_header_symbols():

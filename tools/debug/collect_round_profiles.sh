@@ -6,8 +6,8 @@ python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 python3 bench.py --gpus 2 --steps 2 --warmup 1 > $out/bench_gpus2_one_device.json 2> $out/bench_gpus2.err
 STEM_DIST_SINGLE=1 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_rccl_world1.json 2> $out/bench_rccl_world1.err
 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_no_group.json 2>/dev/null
-python3 bench.py --config roi --steps 2 --warmup 1 > $out/bench_roi_b16.json 2> $out/bench_roi.err
-STEM_LAYERS_F16X3=0 python3 bench.py --config roi --steps 2 --warmup 1 > $out/bench_roi_b16_fp32_layers.json 2>/dev/null
+python3 bench.py --config roi > $out/bench_roi_b16.json 2> $out/bench_roi.err
+STEM_LAYERS_F16X3=0 python3 bench.py --config roi > $out/bench_roi_b16_fp32_layers.json 2>/dev/null
 bash tools/debug/prof_bench.sh $tag/bench_trace > /dev/null 2>&1
 bash tools/debug/prof_pmc.sh $tag/pmc_ga2 tools/debug/f16x3_prof.py planes 5 > $out/pmc_ga2.log 2>&1
 bash tools/debug/prof_tcc.sh $tag/tcc_ga2 tools/debug/f16x3_prof.py planes 5 > $out/tcc_ga2.log 2>&1
@@ -35,4 +35,12 @@ bash tools/debug/prof_pmc.sh $tag/pmc_wgrad_row_tpm4 tools/debug/wgrad3_check.py
 python3 tools/debug/wgrad3_check.py 2>&1 | grep -v "amdgpu.ids" > $out/wgrad_row_vs_per_tap.log
 python3 tools/debug/f16x3_img_check.py 2>&1 | grep -v "amdgpu.ids" > $out/img_check.log
 STEM_BENCH_TIMELINE=1 python3 bench.py --steps 4 --warmup 3 --no-cpu-baseline 2> $out/event_timeline.log > /dev/null
+ls -la $out
+# round 5: the transposed faces on the fp16 kernel (one launch over four sub-pixel phases), the pair pack, a P-frame step alone
+python3 tools/debug/tconv_sweep.py 2>&1 | grep -v "amdgpu.ids" > $out/tconv_sweep.log
+python3 tools/debug/pack_time.py 2>&1 | grep -v "amdgpu.ids" > $out/pack_time.log
+bash tools/debug/gantt2.sh $tag/gantt_palone --latents first > /dev/null 2>&1
+bash tools/debug/gantt2.sh $tag/gantt_default > /dev/null 2>&1
+python3 -m pytest tests/test_hip_dynrange.py -m gpu -q -s 2>&1 | grep -E "per channel|passed|failed" > $out/dynrange_per_channel.log
+python3 -m pytest tests/test_hip_roi.py -m gpu -q -s 2>&1 | grep -E "f64 gate|passed|failed" > $out/roi_f64_gates.log
 ls -la $out

@@ -23,6 +23,13 @@ imodel = models["mbt2018"](quality=4).to(dev).eval()
 stem = SpatioTemporalPriorModel_Res().to(dev).train()
 opt, aux_opt = configure_optimizers(stem, types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3))
 frames = bench.synthetic_septuplet(bench.BATCH, bench.SIZE, 1234, dev)
+reducer = None
+if os.environ.get("STEM_DIST_SINGLE"):                       # one rank in a real RCCL group: the data-parallel path's host cost
+    from spatiotemporalentropymodel_amd import distributed as D  # noqa: E402
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    D.init_from_env(single=True)
+    reducer = D.OverlappedGradReducer(opt.flat).attach(stem.engine())
 fused = FusedPFrameStep(stem, opt, aux_opt)
 if os.environ.get("STEM_HOST_TAPE", "1") != "0":           # the native executor (bench.py's default); STEM_HOST_TAPE=0: the Python schedule
     from spatiotemporalentropymodel_amd.tape import TapedPFrameStep  # noqa: E402
@@ -41,7 +48,7 @@ def one_step(record):
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             marks.append((time.perf_counter(), e))
-        out, oc, aux, gn = fused.step(y_cur, y_cond, npix)
+        out, oc, aux, gn = fused.step(y_cur, y_cond, npix, reducer=reducer)
         y_cond = out["y_hat"]
 
 
