@@ -576,7 +576,9 @@ class GaussianConditional(EntropyModel):
 
     def forward(self, inputs, scales, means=None):
         if means is None:
-            raise NotImplementedError("the HIP Gaussian kernel takes explicit means (every STEM call site passes them)")
+            # entropy_models.py:570-596 with means=None: quantize(inputs) without an offset, likelihood of the values themselves --
+            # exactly what a zero mean computes (x - 0 and round(x - 0) + 0 are x and round(x) in fp32); the kernel takes the tensor
+            means = torch.zeros_like(inputs, memory_format=torch.preserve_format).detach()
         noise = self._noise_like(_dense(inputs.detach())) if self.training else None
         return _GCFunction.apply(inputs, scales, means, noise, self._scale_bound, self._lik_bound if self.use_likelihood_bound else 0.0)
 

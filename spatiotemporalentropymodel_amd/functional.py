@@ -166,8 +166,8 @@ def make_stream(device, role):
 
 
 def _cu_mask(role):
-    """STEM_STREAM_CUMASK="latents=block:96" / "latents=mod8:3": restrict a role's stream to a subset of the 256 CUs -- the
-    first n CU bits, or the bits i with i % 8 < k (whole XCDs if the mask enumerates CUs XCD-interleaved).  Keeps the long
+    """STEM_STREAM_CUMASK="latents=block:96" / "side=tail:96" / "latents=mod8:3": restrict a role's stream to a subset of the 256 CUs
+    -- the first n CU bits, the last n, or the bits i with i % 8 < k (whole XCDs if the mask enumerates CUs XCD-interleaved).  Keeps the long
     analysis-transform kernels of the prefetch stream off part of the chip so that the P-frame step's short kernels always find
     free CUs (bench.py's default: latents=block:160).  A masked stream is created at the default priority."""
     for kv in _config.runtime().stream_cumask.split(","):
@@ -176,7 +176,12 @@ def _cu_mask(role):
             if k.strip() == role:
                 kind, n = v.split(":")
                 n = int(n)
-                bits = [i < n for i in range(256)] if kind == "block" else [(i % 8) < n for i in range(256)]
+                if kind == "block":
+                    bits = [i < n for i in range(256)]
+                elif kind == "tail":                      # the LAST n CU bits: the complement of block:(256 - n)
+                    bits = [i >= 256 - n for i in range(256)]
+                else:
+                    bits = [(i % 8) < n for i in range(256)]
                 words = [sum(1 << b for b in range(32) if bits[32 * w + b]) for w in range(8)]
                 return words
     return None
