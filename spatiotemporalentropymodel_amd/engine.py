@@ -494,7 +494,7 @@ class StemEngine:
             bs = self._bstreams = {}
         st = bs.get(which)
         if st is None or st.device != device:
-            st = bs[which] = F.make_stream(device, "side")
+            st = bs[which] = F.make_stream(device, "branch")
         return st
 
     def ensure_packed(self, block_max=None):

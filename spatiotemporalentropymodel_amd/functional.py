@@ -162,7 +162,8 @@ def make_stream(device, role):
         except (RuntimeError, OSError, AttributeError) as e:      # a scheduling hint, not a result: run unmasked rather than not at all
             import warnings
             warnings.warn(f"CU mask for the '{role}' stream not applied ({e}); using an unmasked stream")
-    return torch.cuda.Stream(device=device, priority=_STREAM_PRIO.get(role, 0))
+    prio = _STREAM_PRIO.get(role, _STREAM_PRIO.get("side", 0) if role == "branch" else 0)      # "branch" (the hyper path's stream) defaults to side's
+    return torch.cuda.Stream(device=device, priority=prio)
 
 
 def _cu_mask(role):
