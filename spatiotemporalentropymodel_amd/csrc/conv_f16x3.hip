@@ -1696,6 +1696,7 @@ namespace {
 // with 8 consecutive a (transposed indexing: flip / phases), taps in identity, mirrored or phase order.
 constexpr int PAIR_T = 32;                              // tile edge (channels)
 constexpr int PAIR_NT = 512;
+constexpr int PAIR_PAD = 4;                             // floats added to the LDS pitch of a tile row (bank spread, see pair_pack_tile)
 struct PairRole {
     void *wp;                 // null: the layer has no image of this role
     int rows_b;               // 0: image rows = the tensor's leading index a (contraction over b); 1: rows = b (contraction over a)
@@ -1716,21 +1717,28 @@ struct PairTable {
     int n;
 };
 
-template <int CRS>
+// TA = rows a of the tile: 32, or 16 for 5 x 5 windows (51 KB of LDS instead of 102: three workgroups per CU instead of one --
+// the pass is HBM-bound and a lone workgroup per CU alternates between loading and storing)
+__host__ __device__ inline int pair_ta(int RS) { return RS > 16 ? 16 : PAIR_T; }      // (8 for 5x5 and 16 for 3x3 measured 66.0 against 64.6 us)
+template <int CRS, int TA>
 __device__ inline void pair_pack_tile(const PairDesc &d, int tile, float *lds, int *ptap, float wscale)
 {
     const int RS = CRS > 0 ? CRS : d.R * d.S;
     const int tb = cdiv_dev(d.B, PAIR_T);
-    const int a0 = (tile / tb) * PAIR_T, b0 = (tile % tb) * PAIR_T;
-    const int na = d.A - a0 < PAIR_T ? d.A - a0 : PAIR_T, nb = d.B - b0 < PAIR_T ? d.B - b0 : PAIR_T;
+    const int a0 = (tile / tb) * TA, b0 = (tile % tb) * PAIR_T;
+    const int na = d.A - a0 < TA ? d.A - a0 : TA, nb = d.B - b0 < PAIR_T ? d.B - b0 : PAIR_T;
     const int row = PAIR_T * RS;                       // floats of one a-row of the tile (b-major, taps innermost): the tensor's own order
+    // LDS pitch of an a-row: 32 * RS floats are a multiple of 32 banks for every window (25, 9, 1), so the emission's readers --
+    // lanes = (piece p, row rr) -- all hit the banks of ONE row: 16-way conflicts.  Four more floats per row keep the float4
+    // stores aligned and spread the 16 rows of a wavefront over eight bank groups
+    const int lrow = row + PAIR_PAD;
     // masked convolution: the taps beyond the live prefix are zeroed IN PLACE (layers.py:44 `weight.data *= mask` at every forward)
     const int live = (d.role[0].wp && d.role[0].tapmode == 0 && d.role[0].taps > 0 && d.role[0].taps < RS) ? d.role[0].taps : RS;
-    if (na == PAIR_T && nb == PAIR_T && live == RS && (reinterpret_cast<uintptr_t>(d.w) & 15) == 0 && ((size_t)d.B * RS) % 4 == 0) {
+    if (na == TA && nb == PAIR_T && live == RS && (reinterpret_cast<uintptr_t>(d.w) & 15) == 0 && ((size_t)d.B * RS) % 4 == 0) {
         // full tile: every a-row of the tile is 32 * RS consecutive floats starting on a 16-byte boundary -- float4 loads, four
         // independent ones in flight per thread
         constexpr int U = 4;
-        const int row4 = row / 4, n4 = PAIR_T * row4;                  // 32 * RS is a multiple of 4
+        const int row4 = row / 4, n4 = TA * row4;                      // 32 * RS is a multiple of 4
         for (int base = threadIdx.x; base < n4; base += U * PAIR_NT) {
             f32x4 v[U];
 #pragma unroll
@@ -1742,11 +1750,14 @@ __device__ inline void pair_pack_tile(const PairDesc &d, int tile, float *lds, i
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int i4 = base + u * PAIR_NT;
-                if (i4 < n4) *reinterpret_cast<f32x4 *>(lds + 4 * i4) = v[u];
+                if (i4 < n4) {
+                    const int a = i4 / row4, r4 = i4 - a * row4;
+                    *reinterpret_cast<f32x4 *>(lds + a * lrow + 4 * r4) = v[u];
+                }
             }
         }
     } else {
-        for (int idx = threadIdx.x; idx < PAIR_T * row; idx += PAIR_NT) {
+        for (int idx = threadIdx.x; idx < TA * row; idx += PAIR_NT) {
             const int a = idx / row, rem = idx - a * row;
             float v = 0.f;
             if (a < na && rem < nb * RS) {
@@ -1757,7 +1768,7 @@ __device__ inline void pair_pack_tile(const PairDesc &d, int tile, float *lds, i
                     v = 0.f;
                 }
             }
-            lds[idx] = v;
+            lds[a * lrow + rem] = v;
         }
     }
     __syncthreads();
@@ -1780,16 +1791,21 @@ __device__ inline void pair_pack_tile(const PairDesc &d, int tile, float *lds, i
                 acc += pT[p];
             }
         }
-        for (int e = threadIdx.x; e < PAIR_T * 4 * T; e += PAIR_NT) {
-            const int p = e & 3, rr = (e >> 2) & (PAIR_T - 1), tap = e >> 7;     // piece, row of the tile, image tap
+        // pieces of this tile in the image: rows = a: TA rows x 4 pieces (the tile's 32 b are one contraction slab); rows = b: 32 rows x
+        // TA / 8 pieces (the tile's TA a are pieces pofs .. of their slab)
+        const int ppr = r.rows_b ? TA / 8 : 4, prow = r.rows_b ? PAIR_T : TA;
+        const int pofs = r.rows_b ? (a0 & 31) >> 3 : 0;
+        for (int e = threadIdx.x; e < prow * ppr * T; e += PAIR_NT) {
+            const int pp = e % ppr, rr = (e / ppr) % prow, tap = e / (ppr * prow);      // piece, row of the tile, image tap
             if (rr >= nrows) continue;
+            const int p = pofs + pp;
             // source tap of image tap `tap`: identity, mirrored, or the tap that sits at phase-ordered position `tap`
             const int st = r.tapmode == 0 ? tap : (r.tapmode == 1 ? RS - 1 - tap : ptap[tap]);
             h16x8 h[NPL];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const int ch = p * 8 + c;                                      // contraction channel inside the slab
-                const float v = r.rows_b ? lds[(ch * PAIR_T + rr) * RS + st] : lds[(rr * PAIR_T + ch) * RS + st];
+                const int ch = pp * 8 + c;                                     // contraction channel inside the tile
+                const float v = r.rows_b ? lds[ch * lrow + rr * RS + st] : lds[rr * lrow + ch * RS + st];
                 hp_t x0, x1;
                 q_split(v, wscale, x0, x1);
                 h[0][c] = x0; h[1][c] = x1;
@@ -1815,7 +1831,7 @@ __global__ __launch_bounds__(PAIR_NT) void pack_weight_pair_multi_kernel(const P
     while (i + 1 < tab.n && (int)blockIdx.x >= tab.d[i + 1].tile0) ++i;
     const PairDesc &d = tab.d[i];
     const int tile = blockIdx.x - d.tile0, RS = d.R * d.S;
-    int *ptap = reinterpret_cast<int *>(pair_lds + PAIR_T * PAIR_T * RS);
+    int *ptap = reinterpret_cast<int *>(pair_lds + pair_ta(RS) * (PAIR_T * RS + PAIR_PAD));
     if ((int)threadIdx.x < RS) ptap[tconv_slot(d.R, d.S, d.R / 2, threadIdx.x / d.S, threadIdx.x % d.S)] = threadIdx.x;
     // one scale for both images: the maximum of the optimiser pass's chunks that cover the tensor (an upper bound: neighbours may
     // share a chunk), as in pack_weight_gen_multi_kernel
@@ -1838,13 +1854,15 @@ __global__ __launch_bounds__(PAIR_NT) void pack_weight_pair_multi_kernel(const P
     __syncthreads();
     const float wscale = q_pow2(we);
     if (RS == 25)
-        pair_pack_tile<25>(d, tile, pair_lds, ptap, wscale);
+        pair_pack_tile<25, 16>(d, tile, pair_lds, ptap, wscale);
     else if (RS == 9)
-        pair_pack_tile<9>(d, tile, pair_lds, ptap, wscale);
+        pair_pack_tile<9, PAIR_T>(d, tile, pair_lds, ptap, wscale);
     else if (RS == 1)
-        pair_pack_tile<1>(d, tile, pair_lds, ptap, wscale);
+        pair_pack_tile<1, PAIR_T>(d, tile, pair_lds, ptap, wscale);
+    else if (RS > 16)
+        pair_pack_tile<0, 16>(d, tile, pair_lds, ptap, wscale);
     else
-        pair_pack_tile<0>(d, tile, pair_lds, ptap, wscale);
+        pair_pack_tile<0, PAIR_T>(d, tile, pair_lds, ptap, wscale);
 }
 
 }   // namespace
@@ -1859,7 +1877,8 @@ STEM_EXPORT int stem_f16x2_pack_conv_weights_pair_multi(const stem_f16x2_pair_de
     STEM_CHECK_ARG(descs && n >= 1 && n <= MAXPAIR, "stem_f16x2_pack_conv_weights_pair_multi: 1..%d descriptors per call, got %d", MAXPAIR, n);
     PairTable tab;
     memset(&tab, 0, sizeof(tab));
-    int tiles = 0, maxrs = 1;
+    int tiles = 0;
+    size_t lds = 0;
     for (int i = 0; i < n; ++i) {
         const stem_f16x2_pair_desc &h = descs[i];
         STEM_CHECK_ARG(h.w && h.A >= 1 && h.B >= 1 && h.R >= 1 && h.S >= 1 && h.R * h.S <= MAXTAP && h.bmax && h.nb >= 1,
@@ -1882,11 +1901,11 @@ STEM_EXPORT int stem_f16x2_pack_conv_weights_pair_multi(const stem_f16x2_pair_de
                            "prefix only for role 0 in identity order, phase order for odd square windows", i, r);
         }
         d.tile0 = tiles;
-        tiles += cdiv(h.A, PAIR_T) * cdiv(h.B, PAIR_T);
-        if (h.R * h.S > maxrs) maxrs = h.R * h.S;
+        tiles += cdiv(h.A, pair_ta(h.R * h.S)) * cdiv(h.B, PAIR_T);
+        const size_t need = (size_t)pair_ta(h.R * h.S) * (PAIR_T * h.R * h.S + PAIR_PAD) * sizeof(float) + 32 * sizeof(int);
+        if (need > lds) lds = need;
     }
     tab.n = n;
-    const size_t lds = (size_t)PAIR_T * PAIR_T * maxrs * sizeof(float) + 32 * sizeof(int);
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         (void)hipFuncSetAttribute((const void *)pack_weight_pair_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
