@@ -515,6 +515,11 @@ size_t stem_conv2d_f16x3_gen_workspace_bytes(int B, int H, int W, int C, int N, 
 int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int xpix, const void *wp, const float *bias, int epi, float slope,
                                const float *z, int ldz, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R,
                                int S, int stride, int pad, int taps, void *ws, size_t ws_bytes, void *stream);
+/* ... for rows [n0, n0 + N) of a weight image of N_image rows (whole 128-row tiles): a layer's outputs range by range, so that the
+ * consumer of one range need not wait for the others (the input gradient of EPM.0 feeds three independent chains) */
+int stem_conv2d_f16x3_gen_fwd_rows(const void *xp, const float *xq, int xpix, const void *wp_image, int N_image, int n0, const float *bias,
+                                    int epi, float slope, const float *z, int ldz, float *y, int ldy, void *yp, float *yq, int B, int H, int W,
+                                    int C, int N, int R, int S, int stride, int pad, int taps, void *ws, size_t ws_bytes, void *stream);
 /* The TRANSPOSED face of a stride-2, R x R (odd), padding R/2 layer whose fine grid is exactly twice the coarse one, on the same
  * kernel as ONE launch over its four sub-pixel phases (each a stride-1 convolution of the coarse grid with the taps of its parity:
  * 3x3 / 3x2 / 2x3 / 2x2 for 5x5 -- no structural zeros):

@@ -103,6 +103,7 @@ _HIP_SIG = {
     "stem_f16x2_conv_weight_gen_bytes": [ci, ci, ci, ci],
     "stem_f16x2_pack_conv_weight_gen": [vp, vp, ci, ci, ci, ci, ci, ci, vp],
     "stem_conv2d_f16x3_gen_workspace_bytes": [ci, ci, ci, ci, ci, ci, ci, ci, ci, ci],
+    "stem_conv2d_f16x3_gen_fwd_rows": [vp, vp, ci, vp, ci, ci, vp, ci, cf, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],
     "stem_tconv2d_f16x3_workspace_bytes": [ci, ci, ci, ci, ci, ci],
     "stem_tconv2d_f16x3_fwd": [vp, vp, ci, vp, vp, ci, cf, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, sz, vp],
     "stem_wgrad_f16x3_strided_splits": [ci, ci, ci, ci, ci, ci, ci, ci, ci],

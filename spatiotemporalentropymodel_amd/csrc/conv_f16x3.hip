@@ -1973,12 +1973,18 @@ STEM_EXPORT size_t stem_conv2d_f16x3_gen_workspace_bytes(int B, int H, int W, in
     return s > 1 ? kGenCntBytes + (size_t)s * M * cdiv(N, GBN) * GBN * sizeof(float) : 0;
 }
 
-STEM_EXPORT int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int xpix, const void *wp, const float *bias, int epi, float slope,
-                                           const float *z, int ldz, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R,
-                                           int S, int stride, int pad, int taps, void *ws, size_t ws_bytes, void *stream)
+namespace {
+// N_image / n0: the weight image holds N_image rows and this launch computes its rows [n0, n0 + N) -- n0 a multiple of the 128-row
+// N tile, so the sub-image is a contiguous range of the image's N tiles; the scale record is the whole image's
+int gen_fwd_impl(const void *wp_image, int N_image, int n0, const void *xp, const float *xq, int xpix, const float *bias, int epi, float slope,
+                 const float *z, int ldz, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R,
+                 int S, int stride, int pad, int taps, void *ws, size_t ws_bytes, void *stream)
 {
     STEM_CHECK_ARG(taps >= 0 && taps <= R * S, "stem_conv2d_f16x3_gen_fwd: 0 <= taps <= R*S (taps=%d)", taps);
     const int T = taps > 0 ? taps : R * S;
+    STEM_CHECK_ARG(wp_image && n0 >= 0 && n0 % GBN == 0 && n0 + N <= N_image && (n0 + N == N_image || N % GBN == 0),
+                   "stem_conv2d_f16x3_gen_fwd: rows [%d, %d) of an image of %d rows must be whole 128-row tiles", n0, n0 + N, N_image);
+    const void *wp = static_cast<const unsigned char *>(wp_image) + (size_t)(n0 / GBN) * (C / 32) * T * GB_BUF;
     STEM_CHECK_ARG(xp && xq && wp && (y || yp) && (yq || !yp), "stem_conv2d_f16x3_gen_fwd: null pointer (planes come with their scale records)");
     STEM_CHECK_ARG(epi == GEN_EPI_BIAS || fabsf(slope) <= 1.f, "stem_conv2d_f16x3_gen_fwd: |slope| <= 1");
     STEM_CHECK_ARG(B >= 1 && H >= 1 && W >= 1 && C >= 32 && C % 32 == 0 && N >= 4 && N % 4 == 0 && R >= 1 && S >= 1 && R * S <= MAXTAP &&
@@ -1998,7 +2004,8 @@ STEM_EXPORT int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int x
     Fx3Args a;
     memset(&a, 0, sizeof(a));
     a.xp = xp; a.wp = wp; a.bias = bias; a.y = y; a.yp = yp; a.ldy = ldy; a.z = z; a.ldz = ldz; a.epi = epi; a.slope = slope;
-    a.xq = xq; a.yq = yq; a.wq = reinterpret_cast<const float *>(static_cast<const unsigned char *>(wp) + wb);
+    const float *wq_image = reinterpret_cast<const float *>(static_cast<const unsigned char *>(wp_image) + gen_image_bytes(N_image, C, R, S));
+    a.xq = xq; a.yq = yq; a.wq = wq_image;
     a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.OH = OH; a.OW = OW; a.stride = stride; a.ntaps = T; a.S = S;
     a.xbytes = (int)xb; a.wbytes = (int)wb; a.xpix = xpix;
     for (int r = 0; r < R; ++r)
@@ -2007,14 +2014,14 @@ STEM_EXPORT int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int x
             a.dx[r * S + s] = (signed char)(s - pad);
         }
     // stride-1 "same" layers on images of 16x16 blocks: the image-tile form (conv_f16x3_img.hip: halo in LDS, weights by LDS-DMA)
-    const bool img = stem_fx3_img_eligible(B, H, W, N, R, S, stride, pad);
+    const bool img = N == N_image && stem_fx3_img_eligible(B, H, W, N, R, S, stride, pad);
     const int itiles = img ? stem_fx3_img_tiles(B, H, W, N) : 0;
     int split = img ? stem_fx3_img_split(itiles, nchunks) : gen_split(tiles, nchunks);
     while (split > 1 && (size_t)split * M * ntn * GBN * sizeof(float) >= 0x7FFFFF00ull) --split;      // the slabs are read through one buffer view
     const size_t need = kGenCntBytes + (size_t)split * M * ntn * GBN * sizeof(float);
     if (split > 1 && (!ws || ws_bytes < need || (size_t)tiles * sizeof(int) > kGenCntBytes)) split = 1;      // no workspace: unsplit, same result up to summation order
     if (img)
-        return stem_fx3_img_launch(xp, xq, xpix, (int)xb, wp, reinterpret_cast<const float *>(static_cast<const unsigned char *>(wp) + wb), (int)wb,
+        return stem_fx3_img_launch(xp, xq, xpix, (int)xb, wp, wq_image, (int)wb,
                                    bias, epi, slope, z, ldz, y, ldy, yp, yq, B, H, W, C, N, R, T, split,
                                    split > 1 ? reinterpret_cast<float *>(static_cast<unsigned char *>(ws) + kGenCntBytes) : nullptr,
                                    split > 1 ? static_cast<int *>(ws) : nullptr, stream);
@@ -2046,6 +2053,26 @@ STEM_EXPORT int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int x
         hipLaunchKernelGGL((conv_f16x3_gen_kernel<64, 32>), grid, dim3(256), glds(64), (hipStream_t)stream, a);
     STEM_LAUNCH_CHECK("stem_conv2d_f16x3_gen_fwd");
     return 0;
+}
+}   // namespace
+
+STEM_EXPORT int stem_conv2d_f16x3_gen_fwd(const void *xp, const float *xq, int xpix, const void *wp, const float *bias, int epi, float slope,
+                                           const float *z, int ldz, float *y, int ldy, void *yp, float *yq, int B, int H, int W, int C, int N, int R,
+                                           int S, int stride, int pad, int taps, void *ws, size_t ws_bytes, void *stream)
+{
+    return gen_fwd_impl(wp, N, 0, xp, xq, xpix, bias, epi, slope, z, ldz, y, ldy, yp, yq, B, H, W, C, N, R, S, stride, pad, taps, ws, ws_bytes, stream);
+}
+
+/* the same for rows [n0, n0 + N) of a weight image of N_image rows (n0 and, unless the range ends the image, N multiples of 128):
+ * a layer's outputs computed range by range, so that the consumer of one range need not wait for the others (the input gradient
+ * of EPM.0 -- spatiotemporalpriors.py:832-838 in backward -- feeds three independent chains) */
+STEM_EXPORT int stem_conv2d_f16x3_gen_fwd_rows(const void *xp, const float *xq, int xpix, const void *wp_image, int N_image, int n0,
+                                                const float *bias, int epi, float slope, const float *z, int ldz, float *y, int ldy, void *yp,
+                                                float *yq, int B, int H, int W, int C, int N, int R, int S, int stride, int pad, int taps, void *ws,
+                                                size_t ws_bytes, void *stream)
+{
+    return gen_fwd_impl(wp_image, N_image, n0, xp, xq, xpix, bias, epi, slope, z, ldz, y, ldy, yp, yq, B, H, W, C, N, R, S, stride, pad, taps, ws,
+                        ws_bytes, stream);
 }
 
 namespace {

@@ -34,6 +34,17 @@ class _Switch:
         return getattr(_config._RUNTIME or _config.runtime(), self.field)
 
 
+class _RangePlanes:
+    """the planes of a tensor that was produced range by range (one F16Planes per channel range, each with its own scale record):
+    `channels(c0, c1)` hands out the part that covers exactly that range"""
+
+    def __init__(self, parts):
+        self.parts = dict(parts)            # (c0, c1) -> F16Planes
+
+    def channels(self, c0, c1):
+        return self.parts[(c0, c1)]
+
+
 class _Layer:
     """One convolution of the schedule: parameters, persistent packed-weight buffers and wgrad slabs."""
 
@@ -483,6 +494,10 @@ class StemEngine:
     tpm_first_bwd = _Switch("engine_tpm_first_bwd")
     #: the context model's forward on the weight-gradient stream (opt-in experiment, STEM_ENGINE_CTX_ON_SIDE=1)
     ctx_on_side = _Switch("engine_ctx_on_side")
+    #: EPM.0's input gradient as one launch per prior range, the hyper chain's range first, so that the chain that ends the backward
+    #: starts a third of the launch earlier.  Three 128-row-tile launches instead of one: 11.80 against 11.61 ms per bench step
+    #: (profiles/r05_ab_epm_by_prior.log) -- three smaller launches cost more than the earlier start returns.  Off; STEM_ENGINE_EPM_DGRAD_BY_PRIOR=1
+    epm_dgrad_by_prior = _Switch("engine_epm_dgrad_by_prior")
     #: the GaussianConditional's backward computed by the fused forward glue (one launch less per P-frame step)
     fuse_gc_backward = _Switch("engine_fuse_gc_backward")
 
@@ -853,7 +868,23 @@ class StemEngine:
             self.EPM[1].wgrad_any(k["e0"], de2, pl.get("e0"), de2p)
             de0, de0p = self.EPM[1].dgrad6(de2p, xact=k["e0"], planes=True)
             self.EPM[0].wgrad_any(k["epm_in"], de0, pl.get("epm_in"), de0p)
-            dpri, dprip = self.EPM[0].dgrad6(de0p, planes=True)    # the prior branches read 32-aligned channel views of the planes
+            if self.epm_dgrad_by_prior and P % 128 == 0 and self.branch_streams and self._branch(gp.device) is not None:
+                # EPM.0's input gradient feeds three independent consumers (hyper chain, TPM chain, context weight gradient): computed
+                # range by range, the hyper chain's first -- the chain that ends the backward -- which then starts a third of the
+                # launch earlier (rows [n0, n0 + P) of the flipped weight image = whole 128-row tiles)
+                l0 = self.EPM[0]
+                dpri = F.empty_nhwc(B, self.nprior * P, H, W, gp.device)
+                order = [o_hp] + ([o_tp] if self.has_tpm else []) + ([o_ctx] if self.has_spm else [])
+                parts = {}
+                for j, o in enumerate(order):
+                    _, parts[(o, o + P)] = F.conv2d_f16x3_gen(de0p, l0.wp6_dgrad, None, P, l0.R, l0.R, 1, l0.pad, out=dpri[:, o:o + P],
+                                                              want_planes=True, rows=(self.nprior * P, o))
+                    if j == 0:
+                        hp_done = self._events.setdefault("bwd_epm", torch.cuda.Event())
+                        F.event_record(hp_done, F.cur_stream(gp.device))
+                dprip = _RangePlanes(parts)
+            else:
+                dpri, dprip = self.EPM[0].dgrad6(de0p, planes=True)    # the prior branches read 32-aligned channel views of the planes
         else:
             self.EPM[2].wgrad(k["e2"], dgp)
             de2 = self.EPM[2].dgrad(dgp, k["e2"].shape, xact=k["e2"])
@@ -867,7 +898,8 @@ class StemEngine:
 
         if bs is not None:                 # the hyper chain depends on the EPM input gradient only: its point on the compute stream
             epm_done = self._events.setdefault("bwd_epm", torch.cuda.Event())
-            F.event_record(epm_done, main)
+            if not isinstance(dprip, _RangePlanes):          # (range by range: recorded right behind the hyper chain's range)
+                F.event_record(epm_done, main)
 
         def hyper_branch():                # hyper chain (HD -> bottleneck -> HE) on its own stream, next to the TPM chain
             F.event_wait(bs, epm_done)

@@ -774,10 +774,11 @@ def pack_weights_f16x2_pair_multi(descs):
 
 
 def conv2d_f16x3_gen(xp: F16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EPI_BIAS, slope=LRELU_SLOPE, z=None, out=None,
-                      want_fp32=True, want_planes=False, taps=0):
+                      want_fp32=True, want_planes=False, taps=0, rows=None):
     """General f16x3 convolution (training-time STEM layers): returns (fp32 NHWC tensor or None, F16Planes or None).
     `out` may be a channel slice of a wider NHWC buffer; epi = GEN_EPI_DACT multiplies by the leaky-ReLU derivative at z;
-    taps > 0: a masked convolution whose weight image holds only its first `taps` taps (pack_weight_f16x2_gen(..., taps=))."""
+    taps > 0: a masked convolution whose weight image holds only its first `taps` taps (pack_weight_f16x2_gen(..., taps=)).
+    rows = (N_image, n0): `wp` holds N_image rows and this call computes its rows [n0, n0 + N) (whole 128-row tiles)."""
     B, Cc, H, W = xp.shape
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
     dev = xp.data.device
@@ -796,6 +797,13 @@ def conv2d_f16x3_gen(xp: F16Planes, wp, bias, N, R, S, stride, pad, epi=GEN_EPI_
         if buf is None or buf.numel() * 4 < need:
             buf = _WS[slot] = torch.zeros((need + 3) // 4, device=dev, dtype=torch.float32)       # zero head: arrival counters
         ws_ptr = buf.data_ptr()
+    if rows is not None:
+        _chk(_lib.hip().stem_conv2d_f16x3_gen_fwd_rows(xp.data_ptr(), xp.q_ptr(), xp.pix_bytes, wp.data_ptr(), int(rows[0]), int(rows[1]), _ptr(bias),
+                                                        epi, slope, _ptr(z), nhwc_ld(z) if z is not None else 0, _ptr(y),
+                                                        nhwc_ld(y) if y is not None else 0, yp.data.data_ptr() if yp is not None else None,
+                                                        yp.q_ptr() if yp is not None else None, B, H, W, Cc, N, R, S, stride, pad, taps, ws_ptr, need,
+                                                        _stream()))
+        return y, yp
     _chk(_lib.hip().stem_conv2d_f16x3_gen_fwd(xp.data_ptr(), xp.q_ptr(), xp.pix_bytes, wp.data_ptr(), _ptr(bias), epi, slope, _ptr(z),
                                                nhwc_ld(z) if z is not None else 0, _ptr(y), nhwc_ld(y) if y is not None else 0,
                                                yp.data.data_ptr() if yp is not None else None, yp.q_ptr() if yp is not None else None,
