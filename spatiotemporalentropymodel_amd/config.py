@@ -38,6 +38,7 @@ class StemRuntimeConfig:
     layers_f16x3: bool = True            #: stride-1 convolutions of the layer-wise (variable-rate) models
     layers_f16x3_maxpix: int = 1 << 30   #: ... up to this many pixels per batch
     layers_wide_minpix: int = 32768      #: from this many pixels on (<= 192 outputs) the 192-column kernel
+    trainer_overwrite_grads: bool = True #: the explicit P-frame step's backward overwrites the gradient buffer (no clearing pass, no accumulate read)
     adam_block_max: bool = True          #: the optimiser pass leaves per-chunk parameter maxima for the fp16 weight packing
     # ---- schedule of the training step (none of these changes a result)
     engine_overlap: bool = True          #: weight gradients on a side stream
@@ -73,7 +74,7 @@ _ENV = {
     "engine_strided_f16x3": "STEM_ENGINE_STRIDED_F16X3", "engine_transposed_f16x3": "STEM_ENGINE_TRANSPOSED_F16X3", "engine_ctx_f16x3": "STEM_ENGINE_CTX_F16X3",
     "engine_wgrad_f16x3": "STEM_ENGINE_WGRAD_F16X3", "engine_records": "STEM_ENGINE_RECORDS", "layers_f16x3": "STEM_LAYERS_F16X3",
     "layers_f16x3_maxpix": "STEM_LAYERS_F16X3_MAXPIX", "layers_wide_minpix": "STEM_LAYERS_WIDE_MINPIX",
-    "adam_block_max": "STEM_ADAM_BLOCK_MAX", "engine_overlap": "STEM_ENGINE_OVERLAP",
+    "adam_block_max": "STEM_ADAM_BLOCK_MAX", "trainer_overwrite_grads": "STEM_TRAINER_OVERWRITE_GRADS", "engine_overlap": "STEM_ENGINE_OVERLAP",
     "engine_split_pack": "STEM_ENGINE_SPLIT_PACK", "engine_pack_first": "STEM_ENGINE_PACK_FIRST", "engine_pack_pair": "STEM_ENGINE_PACK_PAIR", "engine_branch": "STEM_ENGINE_BRANCH", "engine_tpm_first": "STEM_ENGINE_TPM_FIRST", "engine_tpm_first_bwd": "STEM_ENGINE_TPM_FIRST_BWD", "engine_tpm_wgrad_inline": "STEM_ENGINE_TPM_WGRAD_INLINE",
     "engine_bias_multi": "STEM_ENGINE_BIAS_MULTI", "engine_fuse_gc_backward": "STEM_ENGINE_FUSE_GC_BACKWARD", "engine_ctx_on_side": "STEM_ENGINE_CTX_ON_SIDE", "engine_epm_dgrad_by_prior": "STEM_ENGINE_EPM_DGRAD_BY_PRIOR",
     "stream_prio": "STEM_STREAM_PRIO", "stream_cumask": "STEM_STREAM_CUMASK", "dp_min_bytes": "STEM_DP_MIN_BYTES",

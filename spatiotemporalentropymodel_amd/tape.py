@@ -385,7 +385,7 @@ class TapedPFrameStep:
         clip = tuple(bool(o.max_norm is not None and o.max_norm > 0) for o in (f.opt, f.aux_opt))
         return (tuple(y_cur.shape), tuple(y_cond.shape), tuple(y_cur.stride()), tuple(y_cond.stride()), y_cur.dtype, y_cond.dtype, y_cur.device,
                 int(num_pixels), float(grad_scale), id(reducer), F.cur_stream(y_cur.device).cuda_stream, clip, bool(f.clear_grad_in_adam),
-                bool(f.adam_block_max))
+                bool(f.adam_block_max), bool(f.overwrite_grads))
 
     def step(self, y_cur, y_cond, num_pixels, grad_scale=1.0, reducer=None):
         key = self._key(y_cur, y_cond, num_pixels, grad_scale, reducer)

@@ -175,6 +175,11 @@ class FusedPFrameStep:
         #: clear the gradient buffer inside the Adam pass (saves the 72 MB memset of the next step); set False to leave the
         #: gradients in place after step() for inspection -- they are then zeroed at the start of the next step instead
         self.clear_grad_in_adam = True
+        #: this schedule produces every gradient exactly once per step, so its backward OVERWRITES the flat gradient buffer instead
+        #: of adding into a cleared one (engine.accumulate_grads = False for the backward): no clearing inside the Adam pass (72 MB
+        #: written) and no read of the old values by the slab sums (72 MB read) -- and the gradients stay in place after step() for
+        #: inspection.  False restores the clear-then-accumulate form (`clear_grad_in_adam` then decides where the clearing happens)
+        self.overwrite_grads = _config.runtime().trainer_overwrite_grads
         #: the optimiser pass leaves per-chunk maxima of the updated parameters for the fp16 weight packing (no maximum launches)
         self.adam_block_max = _config.runtime().adam_block_max
         # the auxiliary work (one workgroup of latency-bound launches after the optimiser pass) shares the weight-gradient stream, which
@@ -191,14 +196,19 @@ class FusedPFrameStep:
         Call finish() before reading `entropy_bottleneck.quantiles` / the aux optimiser outside of step()."""
         stem, opt, aux_opt, eng = self.stem, self.opt, self.aux_opt, self.eng
         eb = stem.entropy_bottleneck
-        if self._grad_clean and opt._dev is None:                   # cleared by the previous step's Adam pass
+        overwrite = bool(self.overwrite_grads)                      # (the data-parallel reducers sum in place: unaffected)
+        if overwrite or (self._grad_clean and opt._dev is None):    # nothing to clear / cleared by the previous step's Adam pass
             for p in opt.flat.params:
                 p.grad = p._flat_grad_view
         else:
             opt.flat.zero_grad()                                    # one memset; the aux gradient is overwritten below
         coef = -1.0 / (math.log(2.0) * num_pixels)
         y_hat, lik_y, lik_z, k = eng.forward(y_cur, y_cond, True, rate_coef=(coef, -1.0 / num_pixels))
-        eng.backward(k, k["dlik_y"], k["dlik_z"])                   # an attached OverlappedGradReducer exchanges slices in here
+        eng.accumulate_grads = not overwrite
+        try:
+            eng.backward(k, k["dlik_y"], k["dlik_z"])               # an attached OverlappedGradReducer exchanges slices in here
+        finally:
+            eng.accumulate_grads = True
         if reducer is not None:
             F.tape_py(reducer.finish if hasattr(reducer, "finish") else reducer.all_reduce)
         join_wgrad_stream()
@@ -207,7 +217,7 @@ class FusedPFrameStep:
             F.stream_wait(main, self._aux_stream)
             self._aux_pending = False
         F.sumsq(opt.flat.grad, opt._sumsq, overwrite=True)
-        clean = opt._dev is None and self.clear_grad_in_adam
+        clean = opt._dev is None and self.clear_grad_in_adam and not overwrite
         use_bmax = opt._dev is None and eng.use_fx3 and self.adam_block_max
         opt.step(grad_scale=grad_scale, norm_is_current=True, zero_grad=clean, block_max=use_bmax)
         self._grad_clean = clean

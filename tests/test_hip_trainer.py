@@ -37,7 +37,8 @@ def test_fused_step_tracks_generic_step_philox_noise():
     im_b, stem_b, opt_b, aux_b = _pair(64, 96, 64, 96, False, False)
     assert torch.equal(opt_a.flat.data, opt_b.flat.data)
     fused = FusedPFrameStep(stem_b, opt_b, aux_b)
-    fused.clear_grad_in_adam = False                      # step 1's gradients are inspected below
+    assert fused.overwrite_grads                          # the gradients stay in place after a step: step 1's are inspected below
+    fused.clear_grad_in_adam = False
     crit = EMLoss()
     with torch.no_grad():
         _, y_cond_a = im_a.getY(frames[0])
@@ -69,7 +70,7 @@ def test_fused_step_tracks_generic_step_philox_noise():
     assert float(err.max()) <= 6.3e-4 and float((err <= 2e-6).float().mean()) >= 0.97, (float(err.max()), float((err <= 2e-6).float().mean()))
     assert float((aux_a.flat.data - aux_b.flat.data).abs().max()) <= 1e-4
     assert opt_b.t == 3 and aux_b.t == 3
-    assert float(opt_b.flat.grad.abs().max()) == 0.0      # cleared in the Adam pass
+    assert float(opt_b.flat.grad.abs().max()) > 0.0       # overwrite mode (the default): nothing clears the buffer, the last step's gradients stay
 
 
 @pytest.mark.parametrize("tag", ["small", "big"])
@@ -381,6 +382,7 @@ def test_taped_step_holds_the_memset_when_adam_does_not_clear(monkeypatch):
     frames = [torch.rand(2, 3, 128, 128, device=dev, generator=g) for _ in range(9)]
 
     def keep_grads(step, opt, aux):
+        step.overwrite_grads = False                    # the clear-then-accumulate form, clearing at the start of the next step
         step.clear_grad_in_adam = False
     make = lambda: _pair(64, 96, 64, 96, False, False)
     plain = _taped_run(False, 8, make, frames, 2 * 128 * 128, monkeypatch=monkeypatch, mutate=keep_grads)
@@ -388,6 +390,28 @@ def test_taped_step_holds_the_memset_when_adam_does_not_clear(monkeypatch):
     assert taped[4].taped and taped[4].replays == 5
     assert any(e[0] == "call" and e[1] == "stem_zero_bytes" for e in taped[4].tape.entries)
     _assert_same_run(plain, taped)
+
+
+def test_overwriting_backward_equals_clear_then_accumulate(monkeypatch):
+    """FusedPFrameStep's default backward OVERWRITES the flat gradient buffer (every gradient is produced exactly once per step:
+    no clearing pass, no read of the old value); `overwrite_grads = False` clears (inside the Adam pass, or with a memset) and
+    accumulates as autograd does.  Same losses, norms, latents and parameters bit for bit over five steps -- untaped and taped."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(31)
+    frames = [torch.rand(2, 3, 128, 128, device=dev, generator=g) for _ in range(7)]
+    make = lambda: _pair(64, 96, 64, 96, False, False)
+
+    def accumulate(step, opt, aux):
+        step.overwrite_grads = False
+
+    def accumulate_memset(step, opt, aux):
+        step.overwrite_grads = False
+        step.clear_grad_in_adam = False
+    ref = _taped_run(False, 6, make, frames, 2 * 128 * 128, monkeypatch=monkeypatch)
+    for taped, mutate in ((False, accumulate), (False, accumulate_memset), (True, None), (True, accumulate)):
+        got = _taped_run(taped, 6, make, frames, 2 * 128 * 128, monkeypatch=monkeypatch, mutate=mutate)
+        _assert_same_run(ref, got)
+        assert not taped or got[4].taped
 
 
 def test_taped_step_refuses_what_it_cannot_replay(monkeypatch):
