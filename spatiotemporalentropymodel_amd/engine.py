@@ -498,6 +498,8 @@ class StemEngine:
     tpm_first_bwd = _Switch("engine_tpm_first_bwd")
     #: the context model's forward on the weight-gradient stream (opt-in experiment, STEM_ENGINE_CTX_ON_SIDE=1)
     ctx_on_side = _Switch("engine_ctx_on_side")
+    #: one planes tensor for he_in = [y_cur | y_cond] and the TPM chain's input (its second half): a split launch less per step
+    share_in_planes = _Switch("engine_share_in_planes")
     #: EPM.0's input gradient as one launch per prior range, the hyper chain's range first, so that the chain that ends the backward
     #: starts a third of the launch earlier.  Three 128-row-tile launches instead of one: 11.80 against 11.61 ms per bench step
     #: (profiles/r05_ab_epm_by_prior.log) -- three smaller launches cost more than the earlier start returns.  Off; STEM_ENGINE_EPM_DGRAD_BY_PRIOR=1
@@ -729,11 +731,21 @@ class StemEngine:
         split = F.F16Planes.split
         tp0 = tp2 = None
 
+        if self.share_in_planes and fused and self.HE[0].fx3 and self.has_tpm and self.TPM[0].fx3 and Cin % 32 == 0 and rec.get("in") is not None:
+            # he_in = [y_cur | y_cond] and the TPM chain's input y_cond share ONE planes tensor (same record: max(|y_cur|, |y_cond|)):
+            # one split on the compute stream, the TPM chain reads its second half as a channel view, the hyper branch (which waits
+            # for this stream anyway) the whole -- a launch less, the same values
+            pl["he_in"] = split(he_in, src_q=_qp(rec.get("in")))
+            pl["yd"] = pl["he_in"].channels(Cin, 2 * Cin)
+            if bs is not None:
+                F.stream_wait(bs, main)
+
         def tpm_chain():
             nonlocal tp0, tp2
             if self.has_tpm and self.TPM[0].fx3:
                 # planes travel from layer to layer (written by the producing epilogue next to the fp32 copy backward needs)
-                pl["yd"] = split(yd, src_q=_qp(rec.get("in")))       # max(|y_cur|, |y_cond|) bounds y_cond
+                if "yd" not in pl:
+                    pl["yd"] = split(yd, src_q=_qp(rec.get("in")))       # max(|y_cur|, |y_cond|) bounds y_cond
                 tp0, pl["tp0"] = self.TPM[0].fwd6(pl["yd"], F.ACT_LRELU, planes=True)
                 self._wait_fwd_rest()
                 tp2, pl["tp2"] = self.TPM[1].fwd6(pl["tp0"], F.ACT_LRELU, planes=True)
@@ -748,7 +760,8 @@ class StemEngine:
             tpm_chain()
         with F.on_stream(bs):
             if self.HE[0].fx3:
-                pl["he_in"] = split(he_in, src_q=_qp(rec.get("in")))
+                if "he_in" not in pl:
+                    pl["he_in"] = split(he_in, src_q=_qp(rec.get("in")))
                 he0, he0p = self.HE[0].fwd6(pl["he_in"], F.ACT_LRELU, planes=self.HE[1].fx3s)
             else:
                 he0 = self.HE[0].fwd(he_in, F.ACT_LRELU)
