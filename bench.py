@@ -31,11 +31,13 @@ sys.path.insert(0, REPO)
 # A rank of a data-parallel run has FIVE active streams (compute, weight gradients, hyper branch, latent prefetch + the process
 # group's): with the runtime's default of four hardware queues per priority every high-priority stream gets a queue of its own, and
 # the fifth active queue costs 2.2 ms per step on one MI355X (a stream that only waits for events and records one reproduces it:
-# the queues outnumber what the command processor keeps resident).  With two hardware queues per priority the streams share
-# queues and the same one-rank RCCL run takes 12.84 instead of 13.85 ms (11.54 without a group; profiles/r05_ab_hwq2.log).  Must be
-# in the environment before the HIP runtime starts, i.e. before torch is imported; single-GPU runs keep the default (12.6 vs 11.5 ms).
-if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("STEM_DIST_SINGLE", "").strip() not in ("", "0", "false", "no", "off"):
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+# DESIGN.md 8).  With GPU_MAX_HW_QUEUES=2 the streams share queues and a ONE-rank RCCL run takes 12.84 instead of 13.85 ms (11.54
+# without a group; profiles/r05_ab_hwq2.log) -- but a one-rank collective is a no-op, whereas a real one is a kernel that waits for
+# its peers and would then sit in a queue it shares with one of the step's streams.  That cannot be measured on a one-GPU box, so
+# multi-rank runs keep the runtime's default; STEM_BENCH_HW_QUEUES=<n> sets GPU_MAX_HW_QUEUES for an experiment (it has to be in the
+# environment before the HIP runtime starts, i.e. before torch is imported).
+if os.environ.get("STEM_BENCH_HW_QUEUES", "").strip():
+    os.environ["GPU_MAX_HW_QUEUES"] = os.environ["STEM_BENCH_HW_QUEUES"].strip()
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
