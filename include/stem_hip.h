@@ -62,6 +62,14 @@ int stem_tape_entry_recordable(void *fn);
 int stem_copy_d2d(void *dst, const void *src, size_t nbytes, void *stream);
 /* optimizer.zero_grad() (stem/trainSTEM.py:203) as a recordable library call */
 int stem_zero_bytes(void *dst, size_t nbytes, void *stream);
+/* stream flags (8 bytes of signal memory): a stream waits for work the host has not issued yet -- the compute stream of a
+ * data-parallel rank behind the gradient all-reduces its helper thread issues (torch.distributed / DistributedDataParallel in
+ * stem_roi/train_stem_roi.py; here distributed.OverlappedGradReducer).  wait_ge: proceed once *flag >= value (a step counter: monotonic);
+ * write: *flag <- value when the stream gets there, or at once from the host with stream == (void*)-1 */
+int stem_stream_flag_create(void **flag);
+int stem_stream_flag_destroy(void *flag);
+int stem_stream_flag_wait_ge(void *flag, unsigned value, void *stream);
+int stem_stream_flag_write(void *flag, unsigned value, void *stream);
 int stem_tuning_set(const char *name, int value);
 int stem_tuning_get(const char *name);
 int stem_built_with_experiments(void);

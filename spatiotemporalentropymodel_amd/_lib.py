@@ -155,6 +155,10 @@ _HIP_SIG = {
     "stem_tape_entry_recordable": [vp],
     "stem_zero_bytes": [vp, sz, vp],
     "stem_copy_d2d": [vp, vp, sz, vp],
+    "stem_stream_flag_create": [vp],
+    "stem_stream_flag_destroy": [vp],
+    "stem_stream_flag_wait_ge": [vp, C.c_uint, vp],
+    "stem_stream_flag_write": [vp, C.c_uint, vp],
     "stem_tuning_set": [C.c_char_p, ci],
     "stem_tuning_get": [C.c_char_p],
     "stem_last_error": [],

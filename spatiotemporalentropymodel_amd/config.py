@@ -57,6 +57,7 @@ class StemRuntimeConfig:
     stream_prio: str = ""                #: "latents=0,side=-1,compute=-1" (trainer.tuned_schedule installs it)
     stream_cumask: str = ""              #: "latents=block:160"
     # ---- data parallel
+    dp_threaded: int = 2                 #: RCCL collectives issued by a helper thread once their producers' events completed (no pending wait in the group's queue): 2 + stream flag for the way back, 1 host-blocking finish(), 0 off
     dp_min_bytes: int = 8 << 20          #: a run of final gradients is exchanged once it holds this many bytes
     dist_backend: str = ""               #: "" = RCCL when every rank has its own GPU, else gloo
     dist_single: bool = False            #: a process group at world size 1 (one-GPU boxes execute the RCCL calls)
@@ -78,7 +79,7 @@ _ENV = {
     "adam_block_max": "STEM_ADAM_BLOCK_MAX", "trainer_overwrite_grads": "STEM_TRAINER_OVERWRITE_GRADS", "engine_overlap": "STEM_ENGINE_OVERLAP",
     "engine_split_pack": "STEM_ENGINE_SPLIT_PACK", "engine_pack_first": "STEM_ENGINE_PACK_FIRST", "engine_pack_pair": "STEM_ENGINE_PACK_PAIR", "engine_branch": "STEM_ENGINE_BRANCH", "engine_tpm_first": "STEM_ENGINE_TPM_FIRST", "engine_tpm_first_bwd": "STEM_ENGINE_TPM_FIRST_BWD", "engine_tpm_wgrad_inline": "STEM_ENGINE_TPM_WGRAD_INLINE",
     "engine_bias_multi": "STEM_ENGINE_BIAS_MULTI", "engine_fuse_gc_backward": "STEM_ENGINE_FUSE_GC_BACKWARD", "engine_ctx_on_side": "STEM_ENGINE_CTX_ON_SIDE", "engine_share_in_planes": "STEM_ENGINE_SHARE_IN_PLANES", "engine_epm_dgrad_by_prior": "STEM_ENGINE_EPM_DGRAD_BY_PRIOR",
-    "stream_prio": "STEM_STREAM_PRIO", "stream_cumask": "STEM_STREAM_CUMASK", "dp_min_bytes": "STEM_DP_MIN_BYTES",
+    "stream_prio": "STEM_STREAM_PRIO", "stream_cumask": "STEM_STREAM_CUMASK", "dp_min_bytes": "STEM_DP_MIN_BYTES", "dp_threaded": "STEM_DP_THREADED",
     "dist_backend": "STEM_DIST_BACKEND", "dist_single": "STEM_DIST_SINGLE", "pin_ranks": "STEM_PIN_RANKS",
     "ar_persistent": "STEM_AR_PERSISTENT", "ar_pipeline": "STEM_AR_PIPELINE", "ar_stepwise": "STEM_AR_STEPWISE",
     "ar_force_batch": "STEM_AR_FORCE_BATCH", "ar_no_batch": "STEM_AR_NO_BATCH",

@@ -14,7 +14,7 @@ void stem_set_error(const char *fmt, ...)
     va_end(ap);
 }
 STEM_EXPORT const char *stem_last_error(void) { return g_err; }
-STEM_EXPORT int stem_abi_version(void) { return 5; }      // 5 (round 5): + stem_tconv2d_f16x3_*, stem_conv2d_wgrad_f16x3_strided, stem_f16x2_pack_conv_weights_pair_multi, stem_tape_set_farg, stem_tape_entry_recordable, stem_zero_bytes; stem_f16x2_pack_desc.flip = 2
+STEM_EXPORT int stem_abi_version(void) { return 5; }      // 5 (round 5): + stem_tconv2d_f16x3_*, stem_conv2d_wgrad_f16x3_strided, stem_f16x2_pack_conv_weights_pair_multi, stem_tape_set_farg, stem_tape_entry_recordable, stem_zero_bytes, stem_stream_flag_*; stem_f16x2_pack_desc.flip = 2
 STEM_EXPORT int stem_built_with_experiments(void)
 {
 #ifdef STEM_EXPERIMENTS

@@ -260,6 +260,65 @@ STEM_EXPORT int stem_zero_bytes(void *dst, size_t nbytes, void *stream)
     return 0;
 }
 
+/* ---- stream flags: order a stream behind work that the HOST has not issued yet --------------------------------------------------
+ * A data-parallel rank's helper thread issues the gradient all-reduces (torch.distributed: stem_roi/train_stem_roi.py wraps the
+ * models in DistributedDataParallel) only once their inputs are final, so that the communication queue never holds a pending wait
+ * (DESIGN.md 8); the compute stream, whose optimiser launches the host enqueues long before, waits for "flag >= step" instead of for
+ * an event that does not exist yet.  The flag is 8 bytes of signal memory (hipMallocSignalMemory: what hipStreamWaitValue32 takes). */
+STEM_EXPORT int stem_stream_flag_create(void **flag)
+{
+    STEM_CHECK_ARG(flag, "stem_stream_flag_create: null pointer");
+    int dev = 0, ok = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ok, hipDeviceAttributeCanUseStreamWaitValue, dev) != hipSuccess || !ok) {
+        stem_set_error("stem_stream_flag_create: this device / runtime has no stream wait-value operation");
+        return -3;
+    }
+    void *p = nullptr;
+    if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) != hipSuccess || !p) {
+        stem_set_error("stem_stream_flag_create: hipExtMallocWithFlags(hipMallocSignalMemory) failed");
+        return -2;
+    }
+    *static_cast<volatile uint64_t *>(p) = 0;           /* signal memory is host-visible */
+    *flag = p;
+    return 0;
+}
+
+STEM_EXPORT int stem_stream_flag_destroy(void *flag)
+{
+    if (flag && hipFree(flag) != hipSuccess) {
+        stem_set_error("stem_stream_flag_destroy: hipFree failed");
+        return -2;
+    }
+    return 0;
+}
+
+/* stream proceeds once *flag >= value (the caller counts steps: monotonic) */
+STEM_EXPORT int stem_stream_flag_wait_ge(void *flag, unsigned value, void *stream)
+{
+    STEM_CHECK_ARG(flag, "stem_stream_flag_wait_ge: null flag");
+    if (hipStreamWaitValue32((hipStream_t)stream, flag, value, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) {
+        stem_set_error("stem_stream_flag_wait_ge: hipStreamWaitValue32 failed");
+        return -2;
+    }
+    return 0;
+}
+
+/* *flag <- value once the stream reaches this point; stream == (void*)-1: from the host, now (the error path of the helper thread:
+ * nothing may be left waiting) */
+STEM_EXPORT int stem_stream_flag_write(void *flag, unsigned value, void *stream)
+{
+    STEM_CHECK_ARG(flag, "stem_stream_flag_write: null flag");
+    if (stream == (void *)-1) {
+        __atomic_store_n(static_cast<uint32_t *>(flag), value, __ATOMIC_RELEASE);
+        return 0;
+    }
+    if (hipStreamWriteValue32((hipStream_t)stream, flag, value, 0) != hipSuccess) {
+        stem_set_error("stem_stream_flag_write: hipStreamWriteValue32 failed");
+        return -2;
+    }
+    return 0;
+}
+
 /* device-to-device copy on a stream (the private copies a step hands out: recorded like any other launch) */
 STEM_EXPORT int stem_copy_d2d(void *dst, const void *src, size_t nbytes, void *stream)
 {

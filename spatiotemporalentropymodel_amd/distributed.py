@@ -15,6 +15,7 @@ compute stream still has queued.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 import sys
 
@@ -147,6 +148,126 @@ class FlatGradReducer:
         cur.wait_stream(self._stream)
 
 
+class _CollectiveIssuer:
+    """Issues RCCL all-reduces from a helper thread, each one only AFTER the events its slice depends on have completed.
+
+    Why.  torch's process group makes ITS stream wait for an event recorded on the caller's stream.  The host runs several P-frame
+    steps ahead of the GPU, so that wait sits unsatisfied in the process group's hardware queue for milliseconds -- and on this chip a
+    PENDING wait in a fifth queue is what a data-parallel rank pays for (round 5, profiles/r05_ab_fifth_queue.log: a fifth stream
+    that records events, or waits for events that are already complete, costs nothing; the same stream with a pending wait costs
+    +2.4 ms per bench step, with or without RCCL behind it).  Here the helper thread synchronises with the producer's event on the
+    HOST and then calls all_reduce from an otherwise idle stream: the event the process group records is complete when it is
+    recorded, its stream never holds a pending wait, and the collective starts at once.  All ranks issue the same collectives in the
+    same order (the order of submit()), as before.
+
+    The other direction -- the compute stream has to wait for collectives that do not exist yet when the host enqueues the optimiser
+    step -- goes through a stream flag (stem_stream_flag_*: hipStreamWaitValue32 on signal memory): fence() enqueues "wait until
+    flag >= n" on the caller's stream and tells the helper, which orders a flag write behind the step's last collective.  Without
+    the wait-value operation (`use_flag=False`, or the runtime lacks it) fence() blocks the host until the helper has issued
+    everything and waits for the last Work handle instead: correct, but the host loses its run-ahead."""
+
+    def __init__(self, device, use_flag=True):
+        import queue
+        import threading
+        self.device = device
+        self.q = queue.SimpleQueue()
+        self.free = queue.SimpleQueue()                        # events the helper is done with
+        self.cv = threading.Condition()
+        self.submitted = self.issued = 0
+        self.works, self.err = [], None
+        self.idle = torch.cuda.Stream(device=device)          # never runs kernels: what is recorded on it completes at once
+        self.flag, self.seq = None, 0
+        if use_flag:
+            from . import _lib
+            f = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                if _lib.hip().stem_stream_flag_create(ctypes.byref(f)) == 0:
+                    self.flag = f
+        self.thread = threading.Thread(target=self._run, name="stem-collectives", daemon=True)
+        self.thread.start()
+
+    def event(self):
+        try:
+            return self.free.get_nowait()
+        except Exception:
+            return torch.cuda.Event()
+
+    def submit(self, events, tensor):
+        if self.err is not None:
+            self._raise()
+        self.submitted += 1
+        self.q.put((events, tensor))
+
+    def _raise(self):
+        with self.cv:
+            err, self.err = self.err, None
+        raise RuntimeError("data-parallel helper thread: a collective failed") from err
+
+    def _run(self):
+        from . import _lib
+        torch.cuda.set_device(self.device)
+        last = None
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if item[0] == "fence":                             # everything submitted before it has been issued (one thread, in order)
+                rc = -1
+                try:
+                    if last is not None:
+                        with torch.cuda.stream(self.idle):
+                            last.wait()                        # idle stream behind the process group's stream: for the collective's own duration
+                    rc = _lib.hip().stem_stream_flag_write(self.flag, item[1], self.idle.cuda_stream)
+                except BaseException as e:
+                    with self.cv:
+                        self.err = self.err or e
+                if rc != 0:                                    # nothing may be left waiting for a flag nobody writes
+                    _lib.hip().stem_stream_flag_write(self.flag, item[1], ctypes.c_void_p(-1))
+                last = None
+                continue
+            events, g = item
+            w, err = None, None
+            try:
+                for ev in events:
+                    ev.synchronize()                           # host-side: the slice is final
+                with torch.cuda.stream(self.idle):
+                    w = dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
+            except BaseException as e:                         # handed to the thread that submits / fences
+                err = e
+            for ev in events:
+                self.free.put(ev)
+            last = w if w is not None else last
+            with self.cv:
+                if w is not None and self.flag is None:
+                    self.works.append(w)
+                self.err = self.err or err
+                self.issued += 1
+                self.cv.notify_all()
+
+    def fence(self):
+        """order the caller's current stream behind every collective submitted so far"""
+        from . import functional as F_
+        from . import _lib
+        if self.err is not None:
+            self._raise()
+        if self.flag is not None:
+            self.seq += 1
+            self.q.put(("fence", self.seq))
+            F_._chk(_lib.hip().stem_stream_flag_wait_ge(self.flag, self.seq, F_._stream()))
+            return
+        with self.cv:
+            while self.issued < self.submitted:
+                self.cv.wait()
+            works, self.works = self.works, []
+        if self.err is not None:
+            self._raise()
+        if works:
+            works[-1].wait()                                   # one stream, in order: the last one's completion covers them all
+
+    def close(self):
+        self.q.put(None)
+
+
 class OverlappedGradReducer:
     """Sum all-reduce of a FlatParameters gradient buffer, one contiguous slice per module group, started from
     StemEngine.grad_ready_hook while the rest of backward is still running (RCCL on a side stream).
@@ -173,6 +294,11 @@ class OverlappedGradReducer:
         self._pending = []         # reported, final, not yet exchanged: merged contiguous runs [lo, hi, {stream: event}] -- the events
                                    # after which the run's slices are final on the streams that reported them (direct mode)
         self._events = {}          # stream handle -> its event, re-used from step to step
+        # RCCL: collectives are issued by a helper thread once their producers' events have completed (_CollectiveIssuer): the
+        # process group's queue never holds a pending wait.  STEM_DP_THREADED=0: issued here, from the reporting stream (round 4)
+        # STEM_DP_THREADED: 2 (default) helper thread + stream flag; 1 helper thread, finish() blocks the host; 0 off
+        mode = int(_config.runtime().dp_threaded)
+        self._issuer = _CollectiveIssuer(flat.grad.device, use_flag=mode >= 2) if (self._direct and mode > 0) else None
         self.calls = 0             # slices reported (schedule bookkeeping)
         self.collectives = 0       # all-reduce calls issued
         #: a run of final gradients is exchanged once it holds this many bytes (and whatever is left at finish()).  What is
@@ -196,6 +322,15 @@ class OverlappedGradReducer:
         if not self.active:
             return
         g = self.flat.grad[lo:hi]
+        if self._direct and self._issuer is not None:
+            # one fresh event per stream that reported a slice of this run, recorded NOW (its stream's tail covers the reports)
+            evs = []
+            for st in (deps or {torch.cuda.current_stream(): None}):
+                ev = self._issuer.event()          # not the per-stream events of reduce_params: the host is steps ahead of the helper
+                ev.record(st)
+                evs.append(ev)
+            self._issuer.submit(evs, g)
+            return
         if self._direct:
             cur = torch.cuda.current_stream()
             for st, ev in (deps or {}).items():    # slices of THIS run that became final on another stream (nothing else is waited for)
@@ -289,7 +424,9 @@ class OverlappedGradReducer:
                                f"backward schedule ({self._names(pos, n)}): they would stay rank-local")
         for lo, hi, d in pending:                  # what never reached min_bytes on its own
             self._exchange(lo, hi, d)
-        if self._direct:
+        if self._direct and self._issuer is not None:
+            self._issuer.fence()
+        elif self._direct:
             if self._works:                        # the process group runs its collectives on ONE stream, in issue order: the last
                 self._works[-1].wait()             # one's completion covers them all -- one cross-queue wait instead of one per call
             self._works = []

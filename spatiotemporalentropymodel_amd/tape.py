@@ -250,8 +250,12 @@ class _RecordingLibrary:
         if w is not None:
             return w
         fn = getattr(self._lib, name)
-        if name not in _lib._HIP_SIG or name in _lib._RESTYPE or name.startswith("stem_tape_") or name.startswith("stem_tuning"):
-            return fn                           # size queries, error strings, the tape API itself: not part of a schedule
+        if (name not in _lib._HIP_SIG or name in _lib._RESTYPE or name.startswith("stem_tape_") or name.startswith("stem_tuning")
+                or name.startswith("stem_stream_flag_")):
+            # size queries, error strings, the tape API itself: not part of a schedule.  Stream flags carry a step counter and are
+            # written by the data-parallel helper THREAD (distributed._CollectiveIssuer): they belong to the reducer's Python
+            # entries, which a replay calls again
+            return fn
         tape = self._tape
 
         def recorded(*args, _fn=fn, _name=name):

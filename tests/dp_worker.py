@@ -230,13 +230,17 @@ def main():
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     rccl1 = a.case.startswith("rccl1_")
+    base = a.case
+    if "@" in a.case:                               # rccl1_<case>@<n>: the reducer's issue mode (STEM_DP_THREADED=n)
+        base, mode = a.case.split("@")
+        os.environ["STEM_DP_THREADED"] = mode
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.port), RANK=str(a.rank), WORLD_SIZE=str(a.world),
                       LOCAL_RANK="0", STEM_DIST_BACKEND="nccl" if rccl1 else "gloo")
     from spatiotemporalentropymodel_amd import distributed as D
     D.init_from_env(single=rccl1)
     if rccl1:
         assert a.world == 1 and torch.distributed.get_backend() == "nccl"
-        {"rccl1_train_fused": case_train_fused, "rccl1_gop": case_gop, "rccl1_train_taped": case_train_taped}[a.case](a.rank, a.world, a.out, tag=a.case)
+        {"rccl1_train_fused": case_train_fused, "rccl1_gop": case_gop, "rccl1_train_taped": case_train_taped}[base](a.rank, a.world, a.out, tag=a.case)
     else:
         {"train": case_train, "train_fused": case_train_fused, "gop": case_gop, "train_taped": case_train_taped,
          "train_untaped": lambda r, w, o: case_train_taped(r, w, o, tag="train_untaped", taped=False)}[a.case](a.rank, a.world, a.out)

@@ -463,3 +463,35 @@ def test_gaussian_conditional_without_means(F):
         out, lik = gc(dev(y), dev(sc))
     np.testing.assert_array_equal(host(out), np.rint(y))
     assert_close(host(lik), orc.gc_likelihood_fwd(np.rint(y), sc, None), atol=1e-9, what="gc lik without means (eval)", floor=0.1)
+
+
+@pytest.mark.gpu
+def test_stream_flag_orders_a_stream_behind_a_later_write(F):
+    """stem_stream_flag_*: a stream waits for `flag >= n` although nobody has issued the write yet (the data-parallel reducer's way
+    back from its helper thread: distributed._CollectiveIssuer); writes come from another stream or, on the error path, the host."""
+    import ctypes
+    import time
+    from spatiotemporalentropymodel_amd import _lib
+    lib = _lib.hip()
+    flag = ctypes.c_void_p()
+    assert lib.stem_stream_flag_create(ctypes.byref(flag)) == 0 and flag.value
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    t = torch.ones(1 << 16, device="cuda")
+    torch.cuda.synchronize()
+    try:
+        for n, host in ((1, False), (2, True)):
+            t.fill_(1.0)
+            torch.cuda.synchronize()
+            assert lib.stem_stream_flag_wait_ge(flag, n, a.cuda_stream) == 0
+            assert lib.stem_zero_bytes(t.data_ptr(), t.numel() * 4, a.cuda_stream) == 0
+            time.sleep(0.05)
+            assert not a.query()                                   # parked in front of the memset
+            assert lib.stem_stream_flag_write(flag, n, ctypes.c_void_p(-1) if host else b.cuda_stream) == 0
+            a.synchronize()
+            assert float(t.abs().max()) == 0.0
+        assert lib.stem_stream_flag_wait_ge(flag, 1, a.cuda_stream) == 0       # already past: no wait
+        a.synchronize()
+    finally:
+        lib.stem_stream_flag_write(flag, 0xffffffff, ctypes.c_void_p(-1))     # whatever happened, nothing stays parked
+        torch.cuda.synchronize()
+        assert lib.stem_stream_flag_destroy(flag) == 0
