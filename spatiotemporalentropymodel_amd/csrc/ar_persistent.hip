@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int NWG_DEFAULT = 64;         // resident workers (256 threads each): 256 wavefronts, up to 3 output rows per wavefront
+constexpr int NWG_DEFAULT = 32;         // resident workers (512 threads each, one per CU of an XCD): 256 wavefronts, up to 3 output rows per wavefront
 constexpr int GRID = 1024;              // candidates: 128 per XCD
 constexpr int XMAX = 2304;              // longest input vector (the 12-tap context window at M = 192)
 constexpr long SPIN_LIMIT = 4000000;    // ~1-2 s of polling
@@ -43,6 +43,7 @@ struct ArpArgs {
     float bound, slope;
     int *mail;                          // pinned: [0] flag_idx, [16] flag_sym, [32 + slot * 2M ..] idx, [32 + 2 * 2M + slot * 2M ..] sym
     int nwg;                            // workers
+    float *dbg;                         // experiments build: [position][2M + n0 + n1 + 2M] copies of ctx | h1 | h2 | gp (null: off)
     int *dev;                           // device, one 128-byte line per word group: [0] worker tickets, [1] chosen XCC (-1) -- agent scope;
                                         // [64] barrier counter, [96] abort, [128] committed positions, [192..] CDF indexes -- L2-local
 };
@@ -91,79 +92,57 @@ __device__ inline bool grid_barrier(int *bar, int target, int *abort_w, int tid)
     return ok != 0;
 }
 
-// rows [first, N) in steps of `stride`: y[n] = act(bias[n] + W[n] . x), x in LDS, one wavefront per row.  The weight loads of a
-// row (up to 9 x 16 bytes per lane) are issued back to back -- the products are latency-bound, what counts is loads in flight --
-// and then accumulated in the order of gemv3_decode_kernel: segments in order, columns lane * 4 + 256 t ascending.
-constexpr int MAXT = 12;                // 256-column steps of the longest product: 4 + 4 + 2 for the 12-tap window at M = 192
-__device__ inline void rows(const float *Wm, int ldw, const float *bias, const float *xs, const int *seg_len, const int *seg_woff, const int *seg_xoff,
-                            float *y, int N, int first, int stride, bool lrelu, float slope, const ArpArgs &a, int *idx_out)
-{
-    const int lane = threadIdx.x & 63;
-    // flatten the (segment, step) pairs of this product: the same list for every row
-    int woffs[MAXT], xoffs[MAXT], nt = 0;
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-        for (int k = 0; k < seg_len[q]; k += 256)
-            if (nt < MAXT) {
-                woffs[nt] = seg_woff[q] + k;
-                xoffs[nt] = seg_xoff[q] + k;
-                // the last step of a segment may be partial: lanes beyond its end do not contribute
-                if (k + lane * 4 >= seg_len[q]) woffs[nt] = -1;
-                ++nt;
-            }
-    for (int n = first; n < N; n += stride) {
-        const float *wr = Wm + (size_t)n * ldw + lane * 4;
-        f32x4 wv[MAXT];
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-            if (t < nt) wv[t] = *reinterpret_cast<const f32x4 *>(wr + (woffs[t] >= 0 ? woffs[t] : 0));
-        float acc = 0.f;
-#pragma unroll
-        for (int t = 0; t < MAXT; ++t)
-            if (t < nt && woffs[t] >= 0) {
-                const f32x4 xv = *reinterpret_cast<const f32x4 *>(xs + xoffs[t] + lane * 4);
-                acc += xv[0] * wv[t][0] + xv[1] * wv[t][1] + xv[2] * wv[t][2] + xv[3] * wv[t][3];
-            }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-        if (lane == 0) {
-            float v = acc + (bias ? bias[n] : 0.f);
-            if (lrelu) v = v > 0.f ? v : v * slope;
-            st_agent(y + n, v);
-            if (idx_out && n < a.M) {
-                const float sc = fmaxf(v, a.bound);
-                int k = a.T - 1;
-                for (int t = 0; t < a.T - 1; ++t) k -= (sc <= a.table[t]) ? 1 : 0;
-                *reinterpret_cast<volatile int *>(idx_out + n) = k;
-            }
-        }
-    }
-}
+// ---- what a position costs, and what this kernel keeps off that path ---------------------------------------------------------------
+// The first version (round 3) streamed all 9.7 MB of fp32 weights from the memory side for every position: 7-11 us per product,
+// 0.49 s per 1080p frame.  Of the four products only a part depends on the symbol that has just been decoded:
+//   ctx  = b_c + W_c . (row h-2: 5 pixels | row h-1: 5 pixels | row h: pixels w-2, w-1)      only the LAST segment is new
+//   h1   = lrelu(b_0 + W_0 . (tp | hp | ctx))                                                  only the ctx segment is new
+//   h2, gp                                                                                     entirely
+// and a wavefront's dot product accumulates its segments IN ORDER (lane partial sums over columns lane * 4 + 256 t, then the
+// xor-shuffle reduction): the lane partials after the leading segments are a well-defined intermediate state.  So
+//   * while the host decodes the symbols of position p, every wavefront computes the lane partials of position p + 1 over the
+//     segments that are already known (rows above: complete since the previous image row; tp, hp: inputs);
+//   * once the symbols are in, it CONTINUES those sums with the new segment -- same additions in the same order, hence the same
+//     floats as gemv3_decode_kernel (ar.hip) and as the encoder, bit for bit;
+//   * each global wavefront g owns output rows g, g + 256, ... of every product for the whole image and keeps the weights it needs
+//     on the dependent path in REGISTERS (148 VGPRs at M = 192: the last segment of its ctx rows, its EPM.0 / EPM.2 / EPM.4 rows)
+//     and the weights of the rows-above part of its ctx rows in LDS (16 KB per wavefront): nothing but the 384..768-float
+//     vectors handed from product to product moves on the dependent path.
+// 32 workgroups of 512 threads (one per CU of one XCD, 256 wavefronts), four L2-local grid barriers per position.
+constexpr int NT = 512, NWAVES = 256;
+constexpr int RC = 2, R0 = 3, R1 = 3, R2 = 2;           // rows per wavefront: ctx / gp (<= 512 rows), EPM.0 and EPM.2 (<= 768 rows)
+constexpr int TCA = 8, TCL = 2, T0A = 4, T0C = 2, T1 = 3, T2 = 3;      // 256-column steps: ctx rows-above (2 x 4), ctx left, EPM.0 tp|hp, EPM.0 ctx, EPM.2, EPM.4
+constexpr int WL_FLOATS = (NT / 64) * RC * TCA * 64 * 4;               // LDS image of the rows-above ctx weights: 32768 floats
+constexpr int XA_FLOATS = 2048, XP_FLOATS = 1024, XV_FLOATS = 768;     // staging: rows-above window (10 M), tp | hp, the vector of the current product
+constexpr int ARP_LDS = (WL_FLOATS + XA_FLOATS + XP_FLOATS + XV_FLOATS) * 4;
 
-// a vector other workgroups have just written (the L1 was invalidated after the barrier; 16 bytes per lane, all of a thread's loads in
-// flight together), or read-only data (plain loads), into LDS.  n is a multiple of 4 and at most 3 x 1024 floats.
-__device__ inline void stage(float *dst, const float *src, int n, bool coherent)
+__device__ inline float dot4(const f32x4 xv, const f32x4 wv) { return xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3]; }
+
+// global -> LDS.  COHERENT: data other workgroups write during the launch (the latent buffer, the vectors handed from product to
+// product) -- `sc1` loads, which are served by the L2 whatever this CU's L1 holds.  Round 3's kernel read them with plain loads after
+// `buffer_inv sc0` and was right only because the 150 KB of weights it streamed per position had evicted every line by then: with the
+// weights resident the L1 keeps last position's lines and `buffer_inv sc0` does not drop them (tools/debug/arp_probe.py).
+template <bool COHERENT>
+__device__ inline void stage512(float *dst, const float *src, int n)
 {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, n * 4, 0x00020000);
-    const int o = threadIdx.x * 16;
-    f32x4 v[3];
-    if (coherent) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, o + j * 4096, 0, 0));
-    } else {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) v[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, o + j * 4096, 0, 0));
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-        if (threadIdx.x * 4 + j * 1024 < n) *reinterpret_cast<f32x4 *>(dst + threadIdx.x * 4 + j * 1024) = v[j];
+    for (int i = threadIdx.x * 4; i < n; i += NT * 4)
+        *reinterpret_cast<f32x4 *>(dst + i) = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, i * 4, 0, COHERENT ? 16 : 0));
 }
 
-__global__ __launch_bounds__(256) void ar_decode_persistent_kernel(const ArpArgs a)
+__device__ inline float wave_sum_xor(float acc)
 {
-    __shared__ __attribute__((aligned(16))) float xs[XMAX];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    return acc;
+}
+
+__global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *wl = lds, *xa = lds + WL_FLOATS, *xp = xa + XA_FLOATS, *xv = xp + XP_FLOATS;
     __shared__ int role;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int *bar = a.dev + 64, *abort_w = a.dev + 96, *commit = a.dev + 128;
     if (tid == 0) {
         // worker selection: the first workgroup to arrive fixes the XCD, the first NWG workgroups of that XCD are the workers
@@ -182,10 +161,99 @@ __global__ __launch_bounds__(256) void ar_decode_persistent_kernel(const ArpArgs
     const int wg = role;
     if (wg < 0) return;
 
-    const int M = a.M, P = 2 * M, Wp = a.W + 2 * a.pad, N = a.H * a.W;
-    const int wave = tid >> 6, first = wg * 4 + wave, stride = a.nwg * 4, NWG = a.nwg;
+    const int M = a.M, P = 2 * M, Wp = a.W + 2 * a.pad, N = a.H * a.W, NWG = a.nwg;
+    const int g = wg * (NT / 64) + wave;                    // global wavefront: rows g, g + 256, ... of every product
+    const int l4 = lane * 4;
     volatile int *flag_sym = a.mail + 16;
     int nbar = 0;
+
+    // ---- 256-column steps of the products' segments (the same for every row; step t of a segment covers its columns
+    // [256 t, 256 t + 256): `left` columns remain from there, a lane takes part while lane * 4 < left).  Index arithmetic only, so
+    // that the weight arrays below are indexed by compile-time constants and stay in registers.
+    const int tpP = a.tp ? P : 0;
+    auto ca_woff = [&](int t) { return (t >> 2) * 5 * M + (t & 3) * 256; };        // ctx, rows above: 2 segments x <= 4 steps; x offset = weight offset
+    auto ca_left = [&](int t) { return 5 * M - (t & 3) * 256; };
+    auto cl_left = [&](int t) { return 2 * M - t * 256; };                           // ctx, this row: weight offset 10 M + 256 t, x offset 256 t
+    auto ea_woff = [&](int t) { return (t >> 1) * tpP + (t & 1) * 256; };            // EPM.0 over tp | hp: 2 segments x <= 2 steps (tp may be absent)
+    auto ea_left = [&](int t) { return (t >> 1) == 0 && !a.tp ? 0 : P - (t & 1) * 256; };
+    auto ec_left = [&](int t) { return P - t * 256; };                               // EPM.0 over ctx: weight offset tpP + P + 256 t
+    auto e1_left = [&](int t) { return a.n0 - t * 256; };
+    auto e2_left = [&](int t) { return a.n1 - t * 256; };
+
+    // ---- this wavefront's weights: registers for everything behind the new symbol, LDS for the rows-above part of ctx ---------------
+    auto wload = [&](const float *Wm, int ldw, int n, int N_, int woff, int left) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < N_ && l4 < left) v = *reinterpret_cast<const f32x4 *>(Wm + (size_t)n * ldw + woff + l4);
+        return v;
+    };
+    f32x4 wcl[RC][TCL], w0a[R0][T0A], w0c[R0][T0C], w1[R1][T1], w2[R2][T2];
+#pragma unroll
+    for (int r = 0; r < RC; ++r) {
+#pragma unroll
+        for (int t = 0; t < TCL; ++t) wcl[r][t] = wload(a.w_ctx, a.ld_ctx, g + NWAVES * r, P, 10 * M + t * 256, cl_left(t));
+#pragma unroll
+        for (int t = 0; t < TCA; ++t)
+            *reinterpret_cast<f32x4 *>(wl + (((wave * RC + r) * TCA + t) * 64 + lane) * 4) = wload(a.w_ctx, a.ld_ctx, g + NWAVES * r, P, ca_woff(t), ca_left(t));
+    }
+#pragma unroll
+    for (int r = 0; r < R0; ++r) {
+#pragma unroll
+        for (int t = 0; t < T0A; ++t) w0a[r][t] = wload(a.w0, a.ld0, g + NWAVES * r, a.n0, ea_woff(t), ea_left(t));
+#pragma unroll
+        for (int t = 0; t < T0C; ++t) w0c[r][t] = wload(a.w0, a.ld0, g + NWAVES * r, a.n0, tpP + P + t * 256, ec_left(t));
+    }
+#pragma unroll
+    for (int r = 0; r < R1; ++r)
+#pragma unroll
+        for (int t = 0; t < T1; ++t) w1[r][t] = wload(a.w1, a.ld1, g + NWAVES * r, a.n1, t * 256, e1_left(t));
+#pragma unroll
+    for (int r = 0; r < R2; ++r)
+#pragma unroll
+        for (int t = 0; t < T2; ++t) w2[r][t] = wload(a.w2, a.ld2, g + NWAVES * r, P, t * 256, e2_left(t));
+    // biases of this wavefront's rows (lane 0 finishes a row)
+    float bc[RC], b0v[R0], b1v[R1], b2v[R2];
+#pragma unroll
+    for (int r = 0; r < RC; ++r) bc[r] = g + NWAVES * r < P ? a.b_ctx[g + NWAVES * r] : 0.f;
+#pragma unroll
+    for (int r = 0; r < R0; ++r) b0v[r] = g + NWAVES * r < a.n0 ? a.b0[g + NWAVES * r] : 0.f;
+#pragma unroll
+    for (int r = 0; r < R1; ++r) b1v[r] = g + NWAVES * r < a.n1 ? a.b1[g + NWAVES * r] : 0.f;
+#pragma unroll
+    for (int r = 0; r < R2; ++r) b2v[r] = g + NWAVES * r < P ? a.b2[g + NWAVES * r] : 0.f;
+
+    // lane partials of position q over the segments that do not depend on the symbols still to come: ctx over the two rows above,
+    // EPM.0 over tp | hp.  Everything it reads was final at least one grid barrier ago (the rows above: an image row ago).
+    float cpart[RC], epart[R0];
+    auto lookahead = [&](int q) {
+        const int qh = q / a.W, qw = q - qh * a.W;
+        const float *r0 = a.buf + ((size_t)qh * Wp + qw) * M;
+        __syncthreads();                                     // the previous users of xa / xp are done
+        stage512<true>(xa, r0, 5 * M);
+        stage512<true>(xa + 5 * M, r0 + (size_t)Wp * M, 5 * M);
+        if (a.tp) stage512<false>(xp, a.tp + (size_t)q * P, P);
+        stage512<false>(xp + tpP, a.hp + (size_t)q * P, P);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < TCA; ++t)
+                if (l4 < ca_left(t))
+                    acc += dot4(*reinterpret_cast<const f32x4 *>(xa + ca_woff(t) + l4), *reinterpret_cast<const f32x4 *>(wl + (((wave * RC + r) * TCA + t) * 64 + lane) * 4));
+            cpart[r] = acc;
+        }
+#pragma unroll
+        for (int r = 0; r < R0; ++r) {
+            float acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < T0A; ++t)
+                if (l4 < ea_left(t)) acc += dot4(*reinterpret_cast<const f32x4 *>(xp + ea_woff(t) + l4), w0a[r][t]);
+            epart[r] = acc;
+        }
+    };
+    __syncthreads();                                         // the LDS weight image is complete
+    lookahead(0);
+
 #ifdef STEM_EXPERIMENTS
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
     const long long cyc0 = __builtin_readcyclecounter(), wall0 = tlast;
@@ -226,7 +294,7 @@ __global__ __launch_bounds__(256) void ar_decode_persistent_kernel(const ArpArgs
                     const int pp = p - 1, ph = pp / a.W, pw = pp - ph * a.W;
                     const int *sym = a.mail + 32 + 2 * P + (pp & 1) * P;
                     float *pix = a.buf + ((size_t)(ph + a.pad) * Wp + (pw + a.pad)) * M;
-                    for (int c = tid; c < M; c += 256) {
+                    for (int c = tid; c < M; c += NT) {
                         const int sv = __hip_atomic_load(sym + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         st_agent(pix + c, (float)sv + ld_agent(a.gp + M + c));
                     }
@@ -247,56 +315,91 @@ __global__ __launch_bounds__(256) void ar_decode_persistent_kernel(const ArpArgs
             if (role) return;
         }
         ARP_MARK(0);
-        // ---- ctx = b_c + W_c . window: rows h, h + 1 (5 pixels each) and h + 2 (2 pixels) of the padded buffer from column w
+        // ---- ctx: the partials of the rows above, continued over pixels (h, w-2), (h, w-1) of the padded buffer's row h + 2
         {
-            const float *r0 = a.buf + ((size_t)h * Wp + w) * M;
-            stage(xs, r0, 5 * M, true);
-            stage(xs + 5 * M, r0 + (size_t)Wp * M, 5 * M, true);
-            stage(xs + 10 * M, r0 + 2 * (size_t)Wp * M, 2 * M, true);
+            stage512<true>(xv, a.buf + ((size_t)(h + 2) * Wp + w) * M, 2 * M);
             __syncthreads();
-            const int len[3] = {5 * M, 5 * M, 2 * M}, woff[3] = {0, 5 * M, 10 * M}, xoff[3] = {0, 5 * M, 10 * M};
-            rows(a.w_ctx, a.ld_ctx, a.b_ctx, xs, len, woff, xoff, a.ctx, P, first, stride, false, 0.f, a, nullptr);
+#pragma unroll
+            for (int r = 0; r < RC; ++r) {
+                const int n = g + NWAVES * r;
+                float acc = cpart[r];
+#pragma unroll
+                for (int t = 0; t < TCL; ++t)
+                    if (l4 < cl_left(t)) acc += dot4(*reinterpret_cast<const f32x4 *>(xv + t * 256 + l4), wcl[r][t]);
+                acc = wave_sum_xor(acc);
+                if (lane == 0 && n < P) st_agent(a.ctx + n, acc + bc[r]);
+            }
         }
         ARP_MARK(1);
         if (!grid_barrier(bar, ++nbar * NWG, abort_w, tid)) return;
         ARP_MARK(2);
-        // ---- h1 = lrelu(b_0 + W_0 . (tp | hp | ctx))
+        // ---- h1 = lrelu(b_0 + W_0 . (tp | hp | ctx)): the partials over tp | hp, continued over ctx
         {
-            int len[3], woff[3], xoff[3];
-            int o = 0;
-            if (a.tp) {
-                stage(xs, a.tp + (size_t)p * P, P, false);
-                o = P;
-            }
-            stage(xs + o, a.hp + (size_t)p * P, P, false);
-            stage(xs + o + P, a.ctx, P, true);
+            stage512<true>(xv, a.ctx, P);
             __syncthreads();
-            if (a.tp) {
-                len[0] = P; len[1] = P; len[2] = P; woff[0] = 0; woff[1] = P; woff[2] = 2 * P; xoff[0] = 0; xoff[1] = P; xoff[2] = 2 * P;
-            } else {
-                len[0] = P; len[1] = P; len[2] = 0; woff[0] = 0; woff[1] = P; woff[2] = 0; xoff[0] = 0; xoff[1] = P; xoff[2] = 0;
+#pragma unroll
+            for (int r = 0; r < R0; ++r) {
+                const int n = g + NWAVES * r;
+                float acc = epart[r];
+#pragma unroll
+                for (int t = 0; t < T0C; ++t)
+                    if (l4 < ec_left(t)) acc += dot4(*reinterpret_cast<const f32x4 *>(xv + t * 256 + l4), w0c[r][t]);
+                acc = wave_sum_xor(acc);
+                if (lane == 0 && n < a.n0) {
+                    float v = acc + b0v[r];
+                    v = v > 0.f ? v : v * a.slope;
+                    st_agent(a.h1 + n, v);
+                }
             }
-            rows(a.w0, a.ld0, a.b0, xs, len, woff, xoff, a.h1, a.n0, first, stride, true, a.slope, a, nullptr);
         }
         ARP_MARK(3);
         if (!grid_barrier(bar, ++nbar * NWG, abort_w, tid)) return;
         ARP_MARK(4);
         // ---- h2 = lrelu(b_1 + W_1 . h1)
         {
-            stage(xs, a.h1, a.n0, true);
+            stage512<true>(xv, a.h1, a.n0);
             __syncthreads();
-            const int len[3] = {a.n0, 0, 0}, woff[3] = {0, 0, 0}, xoff[3] = {0, 0, 0};
-            rows(a.w1, a.ld1, a.b1, xs, len, woff, xoff, a.h2, a.n1, first, stride, true, a.slope, a, nullptr);
+#pragma unroll
+            for (int r = 0; r < R1; ++r) {
+                const int n = g + NWAVES * r;
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < T1; ++t)
+                    if (l4 < e1_left(t)) acc += dot4(*reinterpret_cast<const f32x4 *>(xv + t * 256 + l4), w1[r][t]);
+                acc = wave_sum_xor(acc);
+                if (lane == 0 && n < a.n1) {
+                    float v = acc + b1v[r];
+                    v = v > 0.f ? v : v * a.slope;
+                    st_agent(a.h2 + n, v);
+                }
+            }
         }
         ARP_MARK(5);
         if (!grid_barrier(bar, ++nbar * NWG, abort_w, tid)) return;
         ARP_MARK(4);
         // ---- gp = b_2 + W_2 . h2 (scales | means); the scales' CDF indexes go to the host mailbox of this position's parity
         {
-            stage(xs, a.h2, a.n1, true);
+            stage512<true>(xv, a.h2, a.n1);
             __syncthreads();
-            const int len[3] = {a.n1, 0, 0}, woff[3] = {0, 0, 0}, xoff[3] = {0, 0, 0};
-            rows(a.w2, a.ld2, a.b2, xs, len, woff, xoff, a.gp, P, first, stride, false, 0.f, a, a.dev + 192);
+#pragma unroll
+            for (int r = 0; r < R2; ++r) {
+                const int n = g + NWAVES * r;
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < T2; ++t)
+                    if (l4 < e2_left(t)) acc += dot4(*reinterpret_cast<const f32x4 *>(xv + t * 256 + l4), w2[r][t]);
+                acc = wave_sum_xor(acc);
+                if (lane == 0 && n < P) {
+                    const float v = acc + b2v[r];
+                    st_agent(a.gp + n, v);
+                    if (n < M) {
+                        const float sc = fmaxf(v, a.bound);
+                        int k = a.T - 1;
+                        for (int t = 0; t < a.T - 1; ++t) k -= (sc <= a.table[t]) ? 1 : 0;
+                        *reinterpret_cast<volatile int *>(a.dev + 192 + n) = k;
+                    }
+                }
+            }
         }
         ARP_MARK(6);
         if (!grid_barrier(bar, ++nbar * NWG, abort_w, tid)) return;
@@ -304,14 +407,25 @@ __global__ __launch_bounds__(256) void ar_decode_persistent_kernel(const ArpArgs
         // indexes of position p are complete in device memory: workgroup 0 copies them to the host mailbox as ONE contiguous
         // store (M x 4 bytes; written lane by lane from the products they were 4-byte PCIe writes, ~20 us per position), waits
         // for it and raises the flag (relaxed: a system-scope release would write back the whole L2 first)
+#ifdef STEM_EXPERIMENTS
+        if (a.dbg && wg == 1) {
+            float *d = a.dbg + (size_t)p * (2 * P + a.n0 + a.n1);
+            for (int c = tid; c < P; c += NT) d[c] = ld_agent(a.ctx + c);
+            for (int c = tid; c < a.n0; c += NT) d[P + c] = ld_agent(a.h1 + c);
+            for (int c = tid; c < a.n1; c += NT) d[P + a.n0 + c] = ld_agent(a.h2 + c);
+            for (int c = tid; c < P; c += NT) d[P + a.n0 + a.n1 + c] = ld_agent(a.gp + c);
+        }
+#endif
         if (wg == 0) {
             int *dst = a.mail + 32 + (p & 1) * P;
-            for (int c = tid; c < M; c += 256)
+            for (int c = tid; c < M; c += NT)
                 __hip_atomic_store(dst + c, *reinterpret_cast<const volatile int *>(a.dev + 192 + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) __hip_atomic_store(a.mail, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        // while the host decodes: the known part of the next position
+        if (p + 1 < N) lookahead(p + 1);
     }
 #ifdef STEM_EXPERIMENTS
     if (wg == 0 && tid == 0)
@@ -344,7 +458,7 @@ __global__ __launch_bounds__(256) void ar_decode_persistent_kernel(const ArpArgs
             const int pp = N - 1, ph = pp / a.W, pw = pp - ph * a.W;
             const int *sym = a.mail + 32 + 2 * P + (pp & 1) * P;
             float *pix = a.buf + ((size_t)(ph + a.pad) * Wp + (pw + a.pad)) * M;
-            for (int c = tid; c < M; c += 256) {
+            for (int c = tid; c < M; c += NT) {
                 const int sv = __hip_atomic_load(sym + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 st_agent(pix + c, (float)sv + ld_agent(a.gp + M + c));
             }
@@ -352,6 +466,9 @@ __global__ __launch_bounds__(256) void ar_decode_persistent_kernel(const ArpArgs
     }
 }
 
+#ifdef STEM_EXPERIMENTS
+float *g_arp_dbg = nullptr;
+#endif
 struct ArpState {
     int *pinned = nullptr, *dev = nullptr;
     size_t pinned_ints = 0;
@@ -372,10 +489,9 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
                    "stem_ar_decode_image_persistent: null pointer");
     STEM_CHECK_ARG(H > 0 && W > 0 && M > 0 && M % 4 == 0 && n0 % 4 == 0 && n1 % 4 == 0 && ld_ctx % 4 == 0 && ld0 % 4 == 0 && ld1 % 4 == 0 &&
                    ld2 % 4 == 0 && T >= 1 && pad == 2, "stem_ar_decode_image_persistent: bad sizes");
-    STEM_CHECK_ARG(12 * M <= XMAX && n0 <= XMAX && n1 <= XMAX && 6 * M <= XMAX, "stem_ar_decode_image_persistent: vectors longer than %d floats (M=%d n0=%d n1=%d)",
-                   XMAX, M, n0, n1);
-    STEM_CHECK_ARG(2 * cdiv(5 * M, 256) + cdiv(2 * M, 256) <= MAXT && 3 * cdiv(2 * M, 256) <= MAXT && cdiv(n0, 256) <= MAXT && cdiv(n1, 256) <= MAXT,
-                   "stem_ar_decode_image_persistent: a product needs more than %d 256-column steps (M=%d n0=%d n1=%d)", MAXT, M, n0, n1);
+    STEM_CHECK_ARG(5 * M <= 1024 && 10 * M <= XA_FLOATS && 4 * M <= XP_FLOATS && 2 * M <= NWAVES * RC && n0 <= NWAVES * R0 && n1 <= NWAVES * R1 &&
+                   n0 <= XV_FLOATS && n1 <= XV_FLOATS && 2 * M <= XV_FLOATS,
+                   "stem_ar_decode_image_persistent: built for M <= 204 and EPM widths <= 768 (M=%d n0=%d n1=%d)", M, n0, n1);
     hipStream_t st = (hipStream_t)stream;
     const int P = 2 * M, N = H * W;
     const size_t need = 32 + 4 * (size_t)P;
@@ -406,9 +522,16 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
     a.ld_ctx = ld_ctx; a.ld0 = ld0; a.n0 = n0; a.ld1 = ld1; a.n1 = n1; a.ld2 = ld2;
     a.buf = buf; a.H = H; a.W = W; a.M = M; a.pad = pad; a.tp = tp; a.hp = hp; a.ctx = ctx; a.h1 = h1; a.h2 = h2; a.gp = gp;
     a.table = table; a.T = T; a.bound = scale_bound; a.slope = slope; a.mail = pin; a.dev = g_arp.dev;
-    a.nwg = stem_tuning(STEM_TUNE_ARP_WORKERS) > 0 ? stem_tuning(STEM_TUNE_ARP_WORKERS) : NWG_DEFAULT;
-    if (a.nwg > GRID / 8) a.nwg = GRID / 8;
-    hipLaunchKernelGGL(ar_decode_persistent_kernel, dim3(GRID), dim3(256), 0, st, a);
+#ifdef STEM_EXPERIMENTS
+    a.dbg = g_arp_dbg;
+#endif
+    a.nwg = NWG_DEFAULT;             // the row -> wavefront map is fixed: 32 workgroups x 8 wavefronts (the "arp_workers" selector of round 3 is ignored)
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void *)ar_decode_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ARP_LDS);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(ar_decode_persistent_kernel, dim3(GRID), dim3(NT), ARP_LDS, st, a);
     if (hipGetLastError() != hipSuccess) {
         stem_set_error("stem_ar_decode_image_persistent: launch failed");
         return -2;
@@ -463,3 +586,8 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
     }
     return 0;
 }
+
+#ifdef STEM_EXPERIMENTS
+// tools/debug/arp_probe.py: per-position copies of the four products' outputs
+STEM_EXPORT void stem_exper_arp_debug(float *p) { g_arp_dbg = p; }
+#endif

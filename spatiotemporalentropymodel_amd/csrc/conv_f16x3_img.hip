@@ -77,6 +77,9 @@ struct ImgArgs {
     unsigned long long *stamps;     // phase stamps of every workgroup (libstem_hip_exper.so only; null otherwise)
 };
 
+#ifndef STEM_IMG_ZFLIP
+#define STEM_IMG_ZFLIP 0        // experiments: the K splits dealt to the workgroups in reverse order
+#endif
 #ifdef STEM_EXPERIMENTS
 unsigned long long *g_img_stamps = nullptr;
 __device__ unsigned long long g_img_waits[4];      // sums over wavefronts: cycles waiting for vmcnt, at the barrier, in the loop
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
     const int tpi = a.tiles_x * a.tiles_y;
     const int bimg = blockIdx.x / tpi, trem = blockIdx.x - bimg * tpi, tyi = trem / a.tiles_x, txi = trem - tyi * a.tiles_x;
     const int y0 = tyi * TS, x0 = txi * TS;
-    const int bn0 = blockIdx.y * IBN, zsplit = blockIdx.z;
+    const int bn0 = blockIdx.y * IBN, zsplit = STEM_IMG_ZFLIP ? gridDim.z - 1 - blockIdx.z : blockIdx.z;
     const int nslab = a.C / KC, T = a.ntaps, nchunks = T * nslab;
     const int q_begin = zsplit * a.cps;
     const int q_end = q_begin + a.cps < nchunks ? q_begin + a.cps : nchunks;
@@ -418,7 +421,12 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
 #ifdef STEM_EXPERIMENTS
         if (a.stamps && lane == 0) {        // per wavefront: shader cycles in the loop, waiting for the weight DMA, waiting at the barrier
             unsigned long long *w = a.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
-            if (wave == 0) { w[7] = __builtin_amdgcn_s_memtime() - t_loop0_; }
+            if (wave == 0) {                  // where the workgroup ran: XCC_ID [63:60], HW_ID (se / sh / cu) [59:44], shader cycles in the loop [43:0]
+                unsigned hw, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                w[7] = ((unsigned long long)(xcc & 0xF) << 60) | ((unsigned long long)(hw & 0xFFFF) << 44) | ((__builtin_amdgcn_s_memtime() - t_loop0_) & 0xFFFFFFFFFFFull);
+            }
             atomicAdd(&g_img_waits[0], t_vm_);
             atomicAdd(&g_img_waits[1], t_bar_);
             atomicAdd(&g_img_waits[2], __builtin_amdgcn_s_memtime() - t_loop0_);
