@@ -19,6 +19,7 @@
 // lane * 4 + 256 t ascending, xor-shuffle reduction, bias, leaky ReLU), compiled without FMA contraction like ar.hip -- the
 // entropy parameters, hence symbols and bytes, are those of the per-position loop and of the encoder.
 #include <chrono>
+#include <vector>
 
 #include "stem_common.h"
 
@@ -41,7 +42,7 @@ struct ArpArgs {
     const float *table;
     int T;
     float bound, slope;
-    int *mail;                          // pinned: [0] flag_idx, [16] flag_sym, [32 + slot * 2M ..] idx, [32 + 2 * 2M + slot * 2M ..] sym
+    int *mail;                          // pinned: [16] host abort (-1); 8-byte words {value, position + 1}: [32 + slot * 2M ..] idx, [32 + 2 * 2M + slot * 2M ..] sym (slot = position parity)
     int nwg;                            // workers
     float *dbg;                         // experiments build: [position][2M + n0 + n1 + 2M] copies of ctx | h1 | h2 | gp (null: off)
     int *dev;                           // device, one 128-byte line per word group: [0] worker tickets, [1] chosen XCC (-1) -- agent scope;
@@ -113,8 +114,8 @@ constexpr int NT = 512, NWAVES = 256;
 constexpr int RC = 2, R0 = 3, R1 = 3, R2 = 2;           // rows per wavefront: ctx / gp (<= 512 rows), EPM.0 and EPM.2 (<= 768 rows)
 constexpr int TCA = 8, TCL = 2, T0A = 4, T0C = 2, T1 = 3, T2 = 3;      // 256-column steps: ctx rows-above (2 x 4), ctx left, EPM.0 tp|hp, EPM.0 ctx, EPM.2, EPM.4
 constexpr int WL_FLOATS = (NT / 64) * RC * TCA * 64 * 4;               // LDS image of the rows-above ctx weights: 32768 floats
-constexpr int XA_FLOATS = 2048, XP_FLOATS = 1024, XV_FLOATS = 768;     // staging: rows-above window (10 M), tp | hp, the vector of the current product
-constexpr int ARP_LDS = (WL_FLOATS + XA_FLOATS + XP_FLOATS + XV_FLOATS) * 4;
+constexpr int XA_FLOATS = 2048, XP_FLOATS = 1024, XV_FLOATS = 768;     // staging (look-ahead only): rows-above window (10 M), tp | hp; longest vector of a product
+constexpr int ARP_LDS = (WL_FLOATS + XA_FLOATS + XP_FLOATS) * 4;
 
 __device__ inline float dot4(const f32x4 xv, const f32x4 wv) { return xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3]; }
 
@@ -140,7 +141,7 @@ __device__ inline float wave_sum_xor(float acc)
 __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *wl = lds, *xa = lds + WL_FLOATS, *xp = xa + XA_FLOATS, *xv = xp + XP_FLOATS;
+    float *wl = lds, *xa = lds + WL_FLOATS, *xp = xa + XA_FLOATS;
     __shared__ int role;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int *bar = a.dev + 64, *abort_w = a.dev + 96, *commit = a.dev + 128;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
     const int M = a.M, P = 2 * M, Wp = a.W + 2 * a.pad, N = a.H * a.W, NWG = a.nwg;
     const int g = wg * (NT / 64) + wave;                    // global wavefront: rows g, g + 256, ... of every product
     const int l4 = lane * 4;
-    volatile int *flag_sym = a.mail + 16;
+    volatile int *host_abort = a.mail + 16;             // the host's only flag: -1 = give up
     int nbar = 0;
 
     // ---- 256-column steps of the products' segments (the same for every row; step t of a segment covers its columns
@@ -221,6 +222,14 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
 #pragma unroll
     for (int r = 0; r < R2; ++r) b2v[r] = g + NWAVES * r < P ? a.b2[g + NWAVES * r] : 0.f;
 
+    const float tb = lane < a.T - 1 ? a.table[lane] : 0.f;          // this lane's entry of the scale table
+    // a vector other workgroups have just written, straight into registers: lane l takes columns 256 t + 4 l (sc1: served by the L2)
+    auto xload = [&](f32x4 *x, const float *src, int n, int nt) {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, n * 4, 0x00020000);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (t < nt) x[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (t * 256 + l4) * 4, 0, 16));
+    };
     // lane partials of position q over the segments that do not depend on the symbols still to come: ctx over the two rows above,
     // EPM.0 over tp | hp.  Everything it reads was final at least one grid barrier ago (the rows above: an image row ago).
     float cpart[RC], epart[R0];
@@ -268,64 +277,61 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
 #endif
     for (int p = 0; p < N; ++p) {
         const int h = p / a.W, w = p - h * a.W;
-        // ---- previous position: y_hat = symbol + mean, once the host has posted the symbols (workgroup 0), then everybody goes on
+        // ---- previous position: y_hat = symbol + mean, once the host has posted the symbols (workgroup 0), then everybody goes on.
+        // Mailbox words are 8 bytes, {value, position + 1}: one naturally aligned load or store each, so a word is never seen half
+        // written and no separate flag (a second PCIe round trip) is needed.
         if (p > 0) {
+            __shared__ int bad;
+            if (tid == 0) bad = 0;
+            __syncthreads();
             if (wg == 0) {
-                __shared__ int got;
-                if (tid == 0) {
+                const int pp = p - 1, ph = pp / a.W, pw = pp - ph * a.W;
+                const long long *symw = reinterpret_cast<const long long *>(a.mail + 32 + 2 * P) + (size_t)(pp & 1) * M;
+                float *pix = a.buf + ((size_t)(ph + a.pad) * Wp + (pw + a.pad)) * M;
+                for (int c = tid; c < M; c += NT) {
                     long spins = 0;
-                    int good = 1;
+                    long long v;
                     for (;;) {
-                        // relaxed: an acquire at system scope would invalidate the L2 on every poll; the symbol loads below are
-                        // system-scope loads issued after this one has returned
-                        const int v = __hip_atomic_load((int *)flag_sym, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        if (v >= p) break;
-                        if (v < 0 || ++spins > SPIN_LIMIT || ((spins & 255) == 0 && poll_l2(abort_w))) {
-                            good = 0;
+                        v = __hip_atomic_load(symw + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if ((int)(v >> 32) == p) break;
+                        if ((++spins & 63) == 0 && (spins > SPIN_LIMIT / 16 || __hip_atomic_load((int *)host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < 0)) {
+                            bad = 1;
                             break;
                         }
                         __builtin_amdgcn_s_sleep(1);
                     }
-                    if (!good) __hip_atomic_fetch_add(abort_w, 1, __ATOMIC_RELAXED, ARP_SCOPE);
-                    got = good;
-                }
-                __syncthreads();
-                if (got) {
-                    const int pp = p - 1, ph = pp / a.W, pw = pp - ph * a.W;
-                    const int *sym = a.mail + 32 + 2 * P + (pp & 1) * P;
-                    float *pix = a.buf + ((size_t)(ph + a.pad) * Wp + (pw + a.pad)) * M;
-                    for (int c = tid; c < M; c += NT) {
-                        const int sv = __hip_atomic_load(sym + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        st_agent(pix + c, (float)sv + ld_agent(a.gp + M + c));
-                    }
+                    st_agent(pix + c, (float)(int)v + ld_agent(a.gp + M + c));
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (tid == 0) __hip_atomic_fetch_add(commit, 1, __ATOMIC_RELAXED, ARP_SCOPE);          // commit counts committed positions
+                if (tid == 0) {
+                    if (bad) __hip_atomic_fetch_add(abort_w, 1, __ATOMIC_RELAXED, ARP_SCOPE);
+                    __hip_atomic_fetch_add(commit, 1, __ATOMIC_RELAXED, ARP_SCOPE);          // commit counts committed positions
+                }
             } else if (tid == 0) {
                 long spins = 0;
                 while (poll_l2(commit) < p) {
-                    if ((++spins & 1023) == 0 && (spins > SPIN_LIMIT || poll_l2(abort_w))) break;
+                    if ((++spins & 1023) == 0 && (spins > SPIN_LIMIT || poll_l2(abort_w))) {
+                        bad = 1;
+                        break;
+                    }
                 }
             }
             __syncthreads();
-            l1_invalidate();
-            if (tid == 0) role = poll_l2(abort_w);
-            __syncthreads();
-            if (role) return;
+            if (bad) return;
         }
         ARP_MARK(0);
         // ---- ctx: the partials of the rows above, continued over pixels (h, w-2), (h, w-1) of the padded buffer's row h + 2
         {
-            stage512<true>(xv, a.buf + ((size_t)(h + 2) * Wp + w) * M, 2 * M);
-            __syncthreads();
+            f32x4 x[TCL];
+            xload(x, a.buf + ((size_t)(h + 2) * Wp + w) * M, 2 * M, TCL);
 #pragma unroll
             for (int r = 0; r < RC; ++r) {
                 const int n = g + NWAVES * r;
                 float acc = cpart[r];
 #pragma unroll
                 for (int t = 0; t < TCL; ++t)
-                    if (l4 < cl_left(t)) acc += dot4(*reinterpret_cast<const f32x4 *>(xv + t * 256 + l4), wcl[r][t]);
+                    if (l4 < cl_left(t)) acc += dot4(x[t], wcl[r][t]);
                 acc = wave_sum_xor(acc);
                 if (lane == 0 && n < P) st_agent(a.ctx + n, acc + bc[r]);
             }
@@ -335,15 +341,15 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
         ARP_MARK(2);
         // ---- h1 = lrelu(b_0 + W_0 . (tp | hp | ctx)): the partials over tp | hp, continued over ctx
         {
-            stage512<true>(xv, a.ctx, P);
-            __syncthreads();
+            f32x4 x[T0C];
+            xload(x, a.ctx, P, T0C);
 #pragma unroll
             for (int r = 0; r < R0; ++r) {
                 const int n = g + NWAVES * r;
                 float acc = epart[r];
 #pragma unroll
                 for (int t = 0; t < T0C; ++t)
-                    if (l4 < ec_left(t)) acc += dot4(*reinterpret_cast<const f32x4 *>(xv + t * 256 + l4), w0c[r][t]);
+                    if (l4 < ec_left(t)) acc += dot4(x[t], w0c[r][t]);
                 acc = wave_sum_xor(acc);
                 if (lane == 0 && n < a.n0) {
                     float v = acc + b0v[r];
@@ -357,15 +363,15 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
         ARP_MARK(4);
         // ---- h2 = lrelu(b_1 + W_1 . h1)
         {
-            stage512<true>(xv, a.h1, a.n0);
-            __syncthreads();
+            f32x4 x[T1];
+            xload(x, a.h1, a.n0, T1);
 #pragma unroll
             for (int r = 0; r < R1; ++r) {
                 const int n = g + NWAVES * r;
                 float acc = 0.f;
 #pragma unroll
                 for (int t = 0; t < T1; ++t)
-                    if (l4 < e1_left(t)) acc += dot4(*reinterpret_cast<const f32x4 *>(xv + t * 256 + l4), w1[r][t]);
+                    if (l4 < e1_left(t)) acc += dot4(x[t], w1[r][t]);
                 acc = wave_sum_xor(acc);
                 if (lane == 0 && n < a.n1) {
                     float v = acc + b1v[r];
@@ -379,34 +385,32 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
         ARP_MARK(4);
         // ---- gp = b_2 + W_2 . h2 (scales | means); the scales' CDF indexes go to the host mailbox of this position's parity
         {
-            stage512<true>(xv, a.h2, a.n1);
-            __syncthreads();
+            f32x4 x[T2];
+            xload(x, a.h2, a.n1, T2);
 #pragma unroll
             for (int r = 0; r < R2; ++r) {
                 const int n = g + NWAVES * r;
                 float acc = 0.f;
 #pragma unroll
                 for (int t = 0; t < T2; ++t)
-                    if (l4 < e2_left(t)) acc += dot4(*reinterpret_cast<const f32x4 *>(xv + t * 256 + l4), w2[r][t]);
-                acc = wave_sum_xor(acc);
+                    if (l4 < e2_left(t)) acc += dot4(x[t], w2[r][t]);
+                acc = wave_sum_xor(acc);                 // every lane holds the sum
+                const float v = acc + b2v[r];
+                // index = #(table[:-1] < scale) (entropy_models.py:598-604): every lane compares the scale with ITS table entry
+                const float sc = fmaxf(v, a.bound);
+                int k = a.T - 1 - __builtin_popcountll(__ballot(lane < a.T - 1 && sc <= tb));
+                for (int t = 64; t < a.T - 1; ++t) k -= (sc <= a.table[t]) ? 1 : 0;            // tables beyond 65 levels
                 if (lane == 0 && n < P) {
-                    const float v = acc + b2v[r];
                     st_agent(a.gp + n, v);
-                    if (n < M) {
-                        const float sc = fmaxf(v, a.bound);
-                        int k = a.T - 1;
-                        for (int t = 0; t < a.T - 1; ++t) k -= (sc <= a.table[t]) ? 1 : 0;
-                        *reinterpret_cast<volatile int *>(a.dev + 192 + n) = k;
-                    }
+                    if (n < M) *reinterpret_cast<volatile int *>(a.dev + 192 + n) = k;
                 }
             }
         }
         ARP_MARK(6);
         if (!grid_barrier(bar, ++nbar * NWG, abort_w, tid)) return;
         ARP_MARK(7);
-        // indexes of position p are complete in device memory: workgroup 0 copies them to the host mailbox as ONE contiguous
-        // store (M x 4 bytes; written lane by lane from the products they were 4-byte PCIe writes, ~20 us per position), waits
-        // for it and raises the flag (relaxed: a system-scope release would write back the whole L2 first)
+        // indexes of position p are complete in device memory: workgroup 0 copies them to the host mailbox as 8-byte words
+        // {index, p + 1} (written lane by lane from the products they were separate small PCIe writes from 24 CUs: ~20 us per position)
 #ifdef STEM_EXPERIMENTS
         if (a.dbg && wg == 1) {
             float *d = a.dbg + (size_t)p * (2 * P + a.n0 + a.n1);
@@ -417,12 +421,11 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
         }
 #endif
         if (wg == 0) {
-            int *dst = a.mail + 32 + (p & 1) * P;
-            for (int c = tid; c < M; c += NT)
-                __hip_atomic_store(dst + c, *reinterpret_cast<const volatile int *>(a.dev + 192 + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(a.mail, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            long long *dst = reinterpret_cast<long long *>(a.mail + 32) + (size_t)(p & 1) * M;
+            for (int c = tid; c < M; c += NT) {
+                const long long word = ((long long)(p + 1) << 32) | (unsigned)*reinterpret_cast<const volatile int *>(a.dev + 192 + c);
+                __hip_atomic_store(dst + c, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         // while the host decodes: the known part of the next position
         if (p + 1 < N) lookahead(p + 1);
@@ -437,31 +440,24 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
 #endif
     // ---- last position's symbols
     if (wg == 0) {
-        __shared__ int got2;
-        if (tid == 0) {
+        const int pp = N - 1, ph = pp / a.W, pw = pp - ph * a.W;
+        const long long *symw = reinterpret_cast<const long long *>(a.mail + 32 + 2 * P) + (size_t)(pp & 1) * M;
+        float *pix = a.buf + ((size_t)(ph + a.pad) * Wp + (pw + a.pad)) * M;
+        for (int c = tid; c < M; c += NT) {
             long spins = 0;
-            int good = 1;
+            long long v;
+            bool good = true;
             for (;;) {
-                const int v = __hip_atomic_load((int *)flag_sym, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (v >= N) break;
-                if (v < 0 || ++spins > SPIN_LIMIT) {
-                    good = 0;
+                v = __hip_atomic_load(symw + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((int)(v >> 32) == N) break;
+                if ((++spins & 63) == 0 && (spins > SPIN_LIMIT / 16 || __hip_atomic_load((int *)host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < 0)) {
+                    good = false;
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (!good) __hip_atomic_fetch_add(abort_w, 1, __ATOMIC_RELAXED, ARP_SCOPE);
-            got2 = good;
-        }
-        __syncthreads();
-        if (got2) {
-            const int pp = N - 1, ph = pp / a.W, pw = pp - ph * a.W;
-            const int *sym = a.mail + 32 + 2 * P + (pp & 1) * P;
-            float *pix = a.buf + ((size_t)(ph + a.pad) * Wp + (pw + a.pad)) * M;
-            for (int c = tid; c < M; c += NT) {
-                const int sv = __hip_atomic_load(sym + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                st_agent(pix + c, (float)sv + ld_agent(a.gp + M + c));
-            }
+            if (good) st_agent(pix + c, (float)(int)v + ld_agent(a.gp + M + c));
+            else __hip_atomic_fetch_add(abort_w, 1, __ATOMIC_RELAXED, ARP_SCOPE);
         }
     }
 }
@@ -509,8 +505,7 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
         return -2;
     }
     int *pin = g_arp.pinned;
-    pin[0] = 0;
-    pin[16] = 0;
+    memset(pin, 0, need * sizeof(int));            // sequence numbers of the previous image must not match this one's
     static int init[192];
     memset(init, 0, sizeof(init));
     init[1] = -1;
@@ -537,11 +532,21 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
         return -2;
     }
     int rc_out = 0;
+    std::vector<int32_t> idx_v((size_t)M), sym_v((size_t)M);
     for (int p = 0; p < N; ++p) {
         const auto t0 = std::chrono::steady_clock::now();
         long spins = 0;
         bool lost = false;
-        while (__atomic_load_n(pin, __ATOMIC_ACQUIRE) < p + 1) {
+        const long long *idxw = reinterpret_cast<const long long *>(pin + 32) + (size_t)(p & 1) * M;
+        long long *symw = reinterpret_cast<long long *>(pin + 32 + 2 * P) + (size_t)(p & 1) * M;
+        // all M words carry this position's sequence number (they arrive in any order)
+        for (int c = M - 1; c >= 0;) {
+            const long long v = __atomic_load_n(idxw + c, __ATOMIC_ACQUIRE);
+            if ((int)(v >> 32) == p + 1) {
+                idx_v[(size_t)c] = (int32_t)v;
+                --c;
+                continue;
+            }
             if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
                 lost = true;
                 break;
@@ -553,14 +558,13 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
             rc_out = -2;
             break;
         }
-        const int32_t *idx = pin + 32 + (p & 1) * P;
-        int32_t *sym = pin + 32 + 2 * P + (p & 1) * P;
-        if (int rc = decode(dec, idx, (size_t)M, cdfs, ncdf, cdf_stride, sizes, offsets, sym)) {
+        if (int rc = decode(dec, idx_v.data(), (size_t)M, cdfs, ncdf, cdf_stride, sizes, offsets, sym_v.data())) {
             stem_set_error("stem_ar_decode_image_persistent: host symbol decoder failed (%d) at position %d", rc, p);
             rc_out = -3;
             break;
         }
-        __atomic_store_n(pin + 16, p + 1, __ATOMIC_RELEASE);
+        for (int c = 0; c < M; ++c)
+            __atomic_store_n(symw + c, ((long long)(p + 1) << 32) | (unsigned)sym_v[(size_t)c], __ATOMIC_RELEASE);
     }
     if (rc_out) __atomic_store_n(pin + 16, -1, __ATOMIC_RELEASE);           // the kernel's polls stop
     if (hipStreamSynchronize(st) != hipSuccess) {
