@@ -27,6 +27,8 @@
 
 namespace {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int NWG_DEFAULT = 32;         // resident workers (512 threads each, one per CU of an XCD): 256 wavefronts, up to 3 output rows per wavefront
 constexpr int GRID = 1024;              // candidates: 128 per XCD
 constexpr int XMAX = 2304;              // longest input vector (the 12-tap context window at M = 192)
@@ -44,6 +46,7 @@ struct ArpArgs {
     float bound, slope;
     int *mail;                          // pinned: [16] host abort (-1); 8-byte words {value, position + 1}: [32 + slot * 2M ..] idx, [32 + 2 * 2M + slot * 2M ..] sym (slot = position parity)
     int nwg;                            // workers
+    long long *words;                   // device: tagged 8-byte words {value, position + 1}: ctx [2M] | h1 [n0] | h2 [n1] | gp [2M] | idx [M] | pixel ring [2][M]
     float *dbg;                         // experiments build: [position][2M + n0 + n1 + 2M] copies of ctx | h1 | h2 | gp (null: off)
     int *dev;                           // device, one 128-byte line per word group: [0] worker tickets, [1] chosen XCC (-1) -- agent scope;
                                         // [64] barrier counter, [96] abort, [128] committed positions, [192..] CDF indexes -- L2-local
@@ -114,10 +117,17 @@ constexpr int NT = 512, NWAVES = 256;
 constexpr int RC = 2, R0 = 3, R1 = 3, R2 = 2;           // rows per wavefront: ctx / gp (<= 512 rows), EPM.0 and EPM.2 (<= 768 rows)
 constexpr int TCA = 8, TCL = 2, T0A = 4, T0C = 2, T1 = 3, T2 = 3;      // 256-column steps: ctx rows-above (2 x 4), ctx left, EPM.0 tp|hp, EPM.0 ctx, EPM.2, EPM.4
 constexpr int WL_FLOATS = (NT / 64) * RC * TCA * 64 * 4;               // LDS image of the rows-above ctx weights: 32768 floats
-constexpr int XA_FLOATS = 2048, XP_FLOATS = 1024, XV_FLOATS = 768;     // staging (look-ahead only): rows-above window (10 M), tp | hp; longest vector of a product
-constexpr int ARP_LDS = (WL_FLOATS + XA_FLOATS + XP_FLOATS) * 4;
+constexpr int XA_FLOATS = 2048, XP_FLOATS = 1024, XV_FLOATS = 768;     // staging: rows-above window (10 M) and tp | hp for the look-ahead; the vector of the current product
+constexpr int ARP_LDS = (WL_FLOATS + XA_FLOATS + XP_FLOATS + XV_FLOATS) * 4;
 
 __device__ inline float dot4(const f32x4 xv, const f32x4 wv) { return xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3]; }
+// the values of four tagged words.  A plain struct: hipcc (ROCm 7.2) compiled f32x4{lo[0], lo[2], hi[0], hi[2]} of two 16-byte loads
+// to {lo[0], lo[0], hi[0], hi[0]} (tools/debug/arp_probe.py showed every second column twice)
+struct X4 {
+    float a, b, c, d;
+};
+__device__ inline float dot4(const X4 xv, const f32x4 wv) { return xv.a * wv[0] + xv.b * wv[1] + xv.c * wv[2] + xv.d * wv[3]; }
+__device__ inline float as_f(unsigned u) { return __builtin_bit_cast(float, u); }
 
 // global -> LDS.  COHERENT: data other workgroups write during the launch (the latent buffer, the vectors handed from product to
 // product) -- `sc1` loads, which are served by the L2 whatever this CU's L1 holds.  Round 3's kernel read them with plain loads after
@@ -141,10 +151,10 @@ __device__ inline float wave_sum_xor(float acc)
 __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *wl = lds, *xa = lds + WL_FLOATS, *xp = xa + XA_FLOATS;
+    float *wl = lds, *xa = lds + WL_FLOATS, *xp = xa + XA_FLOATS, *xv = xp + XP_FLOATS;
     __shared__ int role;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int *bar = a.dev + 64, *abort_w = a.dev + 96, *commit = a.dev + 128;
+    int *abort_w = a.dev + 96;
     if (tid == 0) {
         // worker selection: the first workgroup to arrive fixes the XCD, the first NWG workgroups of that XCD are the workers
         const int me = xcc_id();
@@ -162,11 +172,10 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
     const int wg = role;
     if (wg < 0) return;
 
-    const int M = a.M, P = 2 * M, Wp = a.W + 2 * a.pad, N = a.H * a.W, NWG = a.nwg;
+    const int M = a.M, P = 2 * M, Wp = a.W + 2 * a.pad, N = a.H * a.W;
     const int g = wg * (NT / 64) + wave;                    // global wavefront: rows g, g + 256, ... of every product
     const int l4 = lane * 4;
     volatile int *host_abort = a.mail + 16;             // the host's only flag: -1 = give up
-    int nbar = 0;
 
     // ---- 256-column steps of the products' segments (the same for every row; step t of a segment covers its columns
     // [256 t, 256 t + 256): `left` columns remain from there, a lane takes part while lane * 4 < left).  Index arithmetic only, so
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
         if (n < N_ && l4 < left) v = *reinterpret_cast<const f32x4 *>(Wm + (size_t)n * ldw + woff + l4);
         return v;
     };
-    f32x4 wcl[RC][TCL], w0a[R0][T0A], w0c[R0][T0C], w1[R1][T1], w2[R2][T2];
+    f32x4 wcl[RC][TCL], w0c[R0][T0C], w1[R1][T1], w2[R2][T2];
 #pragma unroll
     for (int r = 0; r < RC; ++r) {
 #pragma unroll
@@ -198,8 +207,6 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
     }
 #pragma unroll
     for (int r = 0; r < R0; ++r) {
-#pragma unroll
-        for (int t = 0; t < T0A; ++t) w0a[r][t] = wload(a.w0, a.ld0, g + NWAVES * r, a.n0, ea_woff(t), ea_left(t));
 #pragma unroll
         for (int t = 0; t < T0C; ++t) w0c[r][t] = wload(a.w0, a.ld0, g + NWAVES * r, a.n0, tpP + P + t * 256, ec_left(t));
     }
@@ -223,13 +230,6 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
     for (int r = 0; r < R2; ++r) b2v[r] = g + NWAVES * r < P ? a.b2[g + NWAVES * r] : 0.f;
 
     const float tb = lane < a.T - 1 ? a.table[lane] : 0.f;          // this lane's entry of the scale table
-    // a vector other workgroups have just written, straight into registers: lane l takes columns 256 t + 4 l (sc1: served by the L2)
-    auto xload = [&](f32x4 *x, const float *src, int n, int nt) {
-        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, n * 4, 0x00020000);
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-            if (t < nt) x[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (t * 256 + l4) * 4, 0, 16));
-    };
     // lane partials of position q over the segments that do not depend on the symbols still to come: ctx over the two rows above,
     // EPM.0 over tp | hp.  Everything it reads was final at least one grid barrier ago (the rows above: an image row ago).
     float cpart[RC], epart[R0];
@@ -250,19 +250,71 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
                 if (l4 < ca_left(t))
                     acc += dot4(*reinterpret_cast<const f32x4 *>(xa + ca_woff(t) + l4), *reinterpret_cast<const f32x4 *>(wl + (((wave * RC + r) * TCA + t) * 64 + lane) * 4));
             cpart[r] = acc;
+            __builtin_amdgcn_sched_barrier(0);               // one row's operands at a time: the registers belong to the resident weights
         }
 #pragma unroll
         for (int r = 0; r < R0; ++r) {
+            // these weights (2.4 MB for all rows at M = 192) are not on the dependent path: they stay in the XCD's L2 and are read
+            // again for every position, which leaves the registers to the weights that are
+            f32x4 w0a[T0A];
+            const float *w0p = a.w0;
+            asm volatile("" ::: "memory");           // the loads below must not be hoisted out of the position loop
+#pragma unroll
+            for (int t = 0; t < T0A; ++t) w0a[t] = wload(w0p, a.ld0, g + NWAVES * r, a.n0, ea_woff(t), ea_left(t));
             float acc = 0.f;
 #pragma unroll
             for (int t = 0; t < T0A; ++t)
-                if (l4 < ea_left(t)) acc += dot4(*reinterpret_cast<const f32x4 *>(xp + ea_woff(t) + l4), w0a[r][t]);
+                if (l4 < ea_left(t)) acc += dot4(*reinterpret_cast<const f32x4 *>(xp + ea_woff(t) + l4), w0a[t]);
             epart[r] = acc;
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     __syncthreads();                                         // the LDS weight image is complete
     lookahead(0);
 
+    // ---- tagged words: everything the workgroups hand to each other (and the host mailbox) is an 8-byte word {value, position + 1},
+    // written by ONE 8-byte store.  A consumer loads the words it needs and spins until they carry its position's tag: the data is
+    // its own flag -- one L2 round trip from producer to consumer, where a grid barrier (stores acknowledged, atomic arrival, polls,
+    // then the loads) took four.  Overwriting is safe without a second buffer: nobody starts position p + 1 before the pixel of
+    // position p is committed, which needs the host's symbols, which need ALL indexes of position p -- every product of p is done.
+    long long *ctxw = a.words, *h1w = ctxw + P, *h2w = h1w + a.n0, *gpw = h2w + a.n1, *idxw = gpw + P, *pixw = idxw + M;      // pixw: [2][M] by position parity
+    auto pack = [](float v, int tag) { return ((long long)tag << 32) | (unsigned)__builtin_bit_cast(int, v); };
+    auto packi = [](int v, int tag) { return ((long long)tag << 32) | (unsigned)v; };
+    auto put = [&](long long *dst, long long word) { __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    bool dead = false;                                        // a bounded wait ran out (or somebody else's did): leave
+    auto give_up = [&](long &spins) {
+        if ((++spins & 255) != 0) return false;
+        if (spins > SPIN_LIMIT || __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_fetch_add(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return true;
+        }
+        return false;
+    };
+    // a tagged vector into LDS, the workgroup's 512 threads one word each (and again 512 further on): every thread spins on ITS
+    // words until they carry `tag`.  (All 256 wavefronts polling whole vectors -- 1.5 MB per round through one L2 -- took 3.4-4 us
+    // per hand-over; one copy per workgroup is 32 x 6 KB.)
+    auto xwait = [&](const long long *src, int n, int tag) {
+        __syncthreads();                                     // the previous readers of xv are done
+        for (int c = tid; c < n; c += NT) {
+            long spins = 0;
+            long long v;
+            for (;;) {
+                v = __hip_atomic_load(src + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(v >> 32) == tag) break;
+                if (give_up(spins)) {
+                    dead = true;
+                    break;
+                }
+            }
+            xv[c] = __builtin_bit_cast(float, (int)v);
+        }
+        dead = __syncthreads_or(dead);                       // a workgroup leaves as one
+    };
+    auto xget = [&](int t, int n) {                          // columns 256 t + 4 lane .. + 3 (zeros beyond the vector)
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t * 256 + l4 < n) v = *reinterpret_cast<const f32x4 *>(xv + t * 256 + l4);
+        return v;
+    };
 #ifdef STEM_EXPERIMENTS
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
     const long long cyc0 = __builtin_readcyclecounter(), wall0 = tlast;
@@ -275,125 +327,155 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
 #else
 #define ARP_MARK(i)
 #endif
-    for (int p = 0; p < N; ++p) {
-        const int h = p / a.W, w = p - h * a.W;
-        // ---- previous position: y_hat = symbol + mean, once the host has posted the symbols (workgroup 0), then everybody goes on.
-        // Mailbox words are 8 bytes, {value, position + 1}: one naturally aligned load or store each, so a word is never seen half
-        // written and no separate flag (a second PCIe round trip) is needed.
-        if (p > 0) {
-            __shared__ int bad;
-            if (tid == 0) bad = 0;
-            __syncthreads();
-            if (wg == 0) {
-                const int pp = p - 1, ph = pp / a.W, pw = pp - ph * a.W;
-                const long long *symw = reinterpret_cast<const long long *>(a.mail + 32 + 2 * P) + (size_t)(pp & 1) * M;
-                float *pix = a.buf + ((size_t)(ph + a.pad) * Wp + (pw + a.pad)) * M;
-                for (int c = tid; c < M; c += NT) {
-                    long spins = 0;
-                    long long v;
-                    for (;;) {
-                        v = __hip_atomic_load(symw + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                        if ((int)(v >> 32) == p) break;
-                        if ((++spins & 63) == 0 && (spins > SPIN_LIMIT / 16 || __hip_atomic_load((int *)host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < 0)) {
-                            bad = 1;
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    st_agent(pix + c, (float)(int)v + ld_agent(a.gp + M + c));
+    // workgroup 0, one thread per channel: the pixel of position pp = symbol + mean, once the host has posted the symbol
+    auto commit_pixel = [&](int pp) {
+        const int ph = pp / a.W, pw = pp - ph * a.W;
+        const long long *symw = reinterpret_cast<const long long *>(a.mail + 32 + 2 * P) + (size_t)(pp & 1) * M;
+        float *pix = a.buf + ((size_t)(ph + a.pad) * Wp + (pw + a.pad)) * M;
+        for (int c = tid; c < M; c += NT) {
+            long spins = 0;
+            long long sv, mv;
+            for (;;) {
+                sv = __hip_atomic_load(symw + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((int)(sv >> 32) == pp + 1) break;
+                if ((++spins & 63) == 0 && (spins > SPIN_LIMIT / 16 || __hip_atomic_load((int *)host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < 0 ||
+                                            __hip_atomic_load(abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                    __hip_atomic_fetch_add(abort_w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dead = true;
+                    return;
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0) {
-                    if (bad) __hip_atomic_fetch_add(abort_w, 1, __ATOMIC_RELAXED, ARP_SCOPE);
-                    __hip_atomic_fetch_add(commit, 1, __ATOMIC_RELAXED, ARP_SCOPE);          // commit counts committed positions
-                }
-            } else if (tid == 0) {
-                long spins = 0;
-                while (poll_l2(commit) < p) {
-                    if ((++spins & 1023) == 0 && (spins > SPIN_LIMIT || poll_l2(abort_w))) {
-                        bad = 1;
-                        break;
-                    }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            spins = 0;
+            for (;;) {                                        // the mean: complete long ago (its index has been to the host and back)
+                mv = __hip_atomic_load(gpw + M + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(mv >> 32) == pp + 1) break;
+                if (give_up(spins)) {
+                    dead = true;
+                    return;
                 }
             }
-            __syncthreads();
-            if (bad) return;
+            const float y = (float)(int)sv + __builtin_bit_cast(float, (int)mv);
+            st_agent(pix + c, y);
+            put(pixw + (size_t)(pp & 1) * M + c, pack(y, pp + 1));
         }
-        ARP_MARK(0);
-        // ---- ctx: the partials of the rows above, continued over pixels (h, w-2), (h, w-1) of the padded buffer's row h + 2
+    };
+    for (int p = 0; p < N; ++p) {
+        const int h = p / a.W, w = p - h * a.W, tag = p + 1;
+        if (p > 0 && wg == 0) commit_pixel(p - 1);
+        if (dead) return;
+        // ---- ctx: the partials of the rows above, continued over pixels (h, w-2), (h, w-1) -- positions p - 2 and p - 1 of the pixel
+        // ring (zeros at the left border).  Every wavefront waits for position p - 1's pixel here whether or not the window holds it:
+        // that wait is what keeps the workgroups within one position of each other.
         {
+            __syncthreads();
+            for (int c = tid; c < 2 * M; c += NT) {
+                float v = 0.f;
+                if (p > 0) {
+                    const int newer = c >= M ? 1 : 0, cc = c - newer * M, pp = p - 2 + newer;               // position of that pixel
+                    if (newer || w >= 2) {                                                                    // p - 2 exists whenever w >= 2
+                        long spins = 0;
+                        long long wv;
+                        for (;;) {
+                            wv = __hip_atomic_load(pixw + (size_t)(pp & 1) * M + cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((int)(wv >> 32) == pp + 1) break;
+                            if (give_up(spins)) {
+                                dead = true;
+                                break;
+                            }
+                        }
+                        if (newer ? w >= 1 : w >= 2) v = __builtin_bit_cast(float, (int)wv);
+                    }
+                }
+                xv[c] = v;
+            }
+            if (__syncthreads_or(dead)) return;
             f32x4 x[TCL];
-            xload(x, a.buf + ((size_t)(h + 2) * Wp + w) * M, 2 * M, TCL);
+#pragma unroll
+            for (int t = 0; t < TCL; ++t) x[t] = xget(t, 2 * M);
+            ARP_MARK(0);
 #pragma unroll
             for (int r = 0; r < RC; ++r) {
                 const int n = g + NWAVES * r;
                 float acc = cpart[r];
 #pragma unroll
                 for (int t = 0; t < TCL; ++t)
-                    if (l4 < cl_left(t)) acc += dot4(x[t], wcl[r][t]);
+                    acc += dot4(x[t], wcl[r][t]);
                 acc = wave_sum_xor(acc);
-                if (lane == 0 && n < P) st_agent(a.ctx + n, acc + bc[r]);
+                if (lane == 0 && n < P) put(ctxw + n, pack(acc + bc[r], tag));
             }
         }
         ARP_MARK(1);
-        if (!grid_barrier(bar, ++nbar * NWG, abort_w, tid)) return;
-        ARP_MARK(2);
         // ---- h1 = lrelu(b_0 + W_0 . (tp | hp | ctx)): the partials over tp | hp, continued over ctx
         {
+            xwait(ctxw, P, tag);
+            if (dead) return;
             f32x4 x[T0C];
-            xload(x, a.ctx, P, T0C);
+#pragma unroll
+            for (int t = 0; t < T0C; ++t) x[t] = xget(t, P);
+            ARP_MARK(2);
+#ifdef STEM_EXPERIMENTS
+            if (a.dbg && p == 0) {           // what this wavefront multiplies at position 0: its ctx columns and its look-ahead partials
+                float *e = a.dbg + (size_t)N * (2 * P + a.n0 + a.n1) + (size_t)g * (256 + 64 * R0);
+                for (int c = 0; c < 4; ++c) e[l4 + c] = x[0][c];
+                for (int r = 0; r < R0; ++r) e[256 + 64 * r + lane] = epart[r];
+            }
+#endif
 #pragma unroll
             for (int r = 0; r < R0; ++r) {
                 const int n = g + NWAVES * r;
                 float acc = epart[r];
 #pragma unroll
                 for (int t = 0; t < T0C; ++t)
-                    if (l4 < ec_left(t)) acc += dot4(x[t], w0c[r][t]);
+                    acc += dot4(x[t], w0c[r][t]);
                 acc = wave_sum_xor(acc);
                 if (lane == 0 && n < a.n0) {
                     float v = acc + b0v[r];
                     v = v > 0.f ? v : v * a.slope;
-                    st_agent(a.h1 + n, v);
+                    put(h1w + n, pack(v, tag));
                 }
             }
         }
         ARP_MARK(3);
-        if (!grid_barrier(bar, ++nbar * NWG, abort_w, tid)) return;
-        ARP_MARK(4);
         // ---- h2 = lrelu(b_1 + W_1 . h1)
         {
+            xwait(h1w, a.n0, tag);
+            if (dead) return;
             f32x4 x[T1];
-            xload(x, a.h1, a.n0, T1);
+#pragma unroll
+            for (int t = 0; t < T1; ++t) x[t] = xget(t, a.n0);
+            ARP_MARK(4);
 #pragma unroll
             for (int r = 0; r < R1; ++r) {
                 const int n = g + NWAVES * r;
                 float acc = 0.f;
 #pragma unroll
                 for (int t = 0; t < T1; ++t)
-                    if (l4 < e1_left(t)) acc += dot4(x[t], w1[r][t]);
+                    acc += dot4(x[t], w1[r][t]);
                 acc = wave_sum_xor(acc);
                 if (lane == 0 && n < a.n1) {
                     float v = acc + b1v[r];
                     v = v > 0.f ? v : v * a.slope;
-                    st_agent(a.h2 + n, v);
+                    put(h2w + n, pack(v, tag));
                 }
             }
         }
         ARP_MARK(5);
-        if (!grid_barrier(bar, ++nbar * NWG, abort_w, tid)) return;
-        ARP_MARK(4);
-        // ---- gp = b_2 + W_2 . h2 (scales | means); the scales' CDF indexes go to the host mailbox of this position's parity
+        // ---- gp = b_2 + W_2 . h2 (scales | means) and the scales' CDF indexes
         {
+            xwait(h2w, a.n1, tag);
+            if (dead) return;
             f32x4 x[T2];
-            xload(x, a.h2, a.n1, T2);
+#pragma unroll
+            for (int t = 0; t < T2; ++t) x[t] = xget(t, a.n1);
+            ARP_MARK(4);
 #pragma unroll
             for (int r = 0; r < R2; ++r) {
                 const int n = g + NWAVES * r;
                 float acc = 0.f;
 #pragma unroll
                 for (int t = 0; t < T2; ++t)
-                    if (l4 < e2_left(t)) acc += dot4(x[t], w2[r][t]);
+                    acc += dot4(x[t], w2[r][t]);
                 acc = wave_sum_xor(acc);                 // every lane holds the sum
                 const float v = acc + b2v[r];
                 // index = #(table[:-1] < scale) (entropy_models.py:598-604): every lane compares the scale with ITS table entry
@@ -401,32 +483,44 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
                 int k = a.T - 1 - __builtin_popcountll(__ballot(lane < a.T - 1 && sc <= tb));
                 for (int t = 64; t < a.T - 1; ++t) k -= (sc <= a.table[t]) ? 1 : 0;            // tables beyond 65 levels
                 if (lane == 0 && n < P) {
-                    st_agent(a.gp + n, v);
-                    if (n < M) *reinterpret_cast<volatile int *>(a.dev + 192 + n) = k;
+                    put(gpw + n, pack(v, tag));
+                    if (n < M) put(idxw + n, packi(k, tag));
                 }
             }
         }
         ARP_MARK(6);
-        if (!grid_barrier(bar, ++nbar * NWG, abort_w, tid)) return;
-        ARP_MARK(7);
-        // indexes of position p are complete in device memory: workgroup 0 copies them to the host mailbox as 8-byte words
-        // {index, p + 1} (written lane by lane from the products they were separate small PCIe writes from 24 CUs: ~20 us per position)
-#ifdef STEM_EXPERIMENTS
-        if (a.dbg && wg == 1) {
-            float *d = a.dbg + (size_t)p * (2 * P + a.n0 + a.n1);
-            for (int c = tid; c < P; c += NT) d[c] = ld_agent(a.ctx + c);
-            for (int c = tid; c < a.n0; c += NT) d[P + c] = ld_agent(a.h1 + c);
-            for (int c = tid; c < a.n1; c += NT) d[P + a.n0 + c] = ld_agent(a.h2 + c);
-            for (int c = tid; c < P; c += NT) d[P + a.n0 + a.n1 + c] = ld_agent(a.gp + c);
-        }
-#endif
+        // ---- workgroup 0 forwards the indexes to the host mailbox (written lane by lane from the products they were separate small
+        // PCIe writes from 24 CUs: ~20 us per position)
         if (wg == 0) {
             long long *dst = reinterpret_cast<long long *>(a.mail + 32) + (size_t)(p & 1) * M;
             for (int c = tid; c < M; c += NT) {
-                const long long word = ((long long)(p + 1) << 32) | (unsigned)*reinterpret_cast<const volatile int *>(a.dev + 192 + c);
-                __hip_atomic_store(dst + c, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                long spins = 0;
+                long long v;
+                for (;;) {
+                    v = __hip_atomic_load(idxw + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((int)(v >> 32) == tag) break;
+                    if (give_up(spins)) return;
+                }
+                __hip_atomic_store(dst + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
+        ARP_MARK(7);
+#ifdef STEM_EXPERIMENTS
+        if (a.dbg && wg == 1) {
+            // (after the look-ahead's first barrier below nobody of this workgroup is still multiplying; the other workgroups cannot
+            // start the next position before the host has answered)
+            float *d = a.dbg + (size_t)p * (2 * P + a.n0 + a.n1);
+            for (int c = tid; c < 2 * P + a.n0 + a.n1; c += NT) {
+                long spins = 0;
+                long long v;
+                for (;;) {
+                    v = __hip_atomic_load(ctxw + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((int)(v >> 32) == tag || give_up(spins)) break;
+                }
+                d[c] = __builtin_bit_cast(float, (int)v);
+            }
+        }
+#endif
         // while the host decodes: the known part of the next position
         if (p + 1 < N) lookahead(p + 1);
     }
@@ -438,28 +532,7 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
         reinterpret_cast<long long *>(a.dev + 32)[9] = wall_clock64() - wall0;
     }
 #endif
-    // ---- last position's symbols
-    if (wg == 0) {
-        const int pp = N - 1, ph = pp / a.W, pw = pp - ph * a.W;
-        const long long *symw = reinterpret_cast<const long long *>(a.mail + 32 + 2 * P) + (size_t)(pp & 1) * M;
-        float *pix = a.buf + ((size_t)(ph + a.pad) * Wp + (pw + a.pad)) * M;
-        for (int c = tid; c < M; c += NT) {
-            long spins = 0;
-            long long v;
-            bool good = true;
-            for (;;) {
-                v = __hip_atomic_load(symw + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((int)(v >> 32) == N) break;
-                if ((++spins & 63) == 0 && (spins > SPIN_LIMIT / 16 || __hip_atomic_load((int *)host_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < 0)) {
-                    good = false;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (good) st_agent(pix + c, (float)(int)v + ld_agent(a.gp + M + c));
-            else __hip_atomic_fetch_add(abort_w, 1, __ATOMIC_RELAXED, ARP_SCOPE);
-        }
-    }
+    if (wg == 0) commit_pixel(N - 1);                         // the last position's symbols
 }
 
 #ifdef STEM_EXPERIMENTS
@@ -467,7 +540,8 @@ float *g_arp_dbg = nullptr;
 #endif
 struct ArpState {
     int *pinned = nullptr, *dev = nullptr;
-    size_t pinned_ints = 0;
+    long long *words = nullptr;
+    size_t pinned_ints = 0, nwords = 0;
 };
 thread_local ArpState g_arp;
 
@@ -504,6 +578,18 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
         stem_set_error("stem_ar_decode_image_persistent: cannot allocate the device flags");
         return -2;
     }
+    const size_t nwords = 2 * (size_t)P + n0 + n1 + 3 * (size_t)M;
+    if (g_arp.nwords < nwords) {
+        if (g_arp.words) (void)hipFree(g_arp.words);
+        g_arp.words = nullptr;
+        g_arp.nwords = 0;
+        if (hipMalloc((void **)&g_arp.words, nwords * sizeof(long long)) != hipSuccess) {
+            stem_set_error("stem_ar_decode_image_persistent: cannot allocate the tagged vectors");
+            return -2;
+        }
+        g_arp.nwords = nwords;
+    }
+    if (hipMemsetAsync(g_arp.words, 0, nwords * sizeof(long long), st) != hipSuccess) return -2;       // tag 0: nothing written yet
     int *pin = g_arp.pinned;
     memset(pin, 0, need * sizeof(int));            // sequence numbers of the previous image must not match this one's
     static int init[192];
@@ -516,7 +602,7 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
     a.w_ctx = w_ctx; a.b_ctx = b_ctx; a.w0 = w0; a.b0 = b0; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.ld_ctx = ld_ctx; a.ld0 = ld0; a.n0 = n0; a.ld1 = ld1; a.n1 = n1; a.ld2 = ld2;
     a.buf = buf; a.H = H; a.W = W; a.M = M; a.pad = pad; a.tp = tp; a.hp = hp; a.ctx = ctx; a.h1 = h1; a.h2 = h2; a.gp = gp;
-    a.table = table; a.T = T; a.bound = scale_bound; a.slope = slope; a.mail = pin; a.dev = g_arp.dev;
+    a.table = table; a.T = T; a.bound = scale_bound; a.slope = slope; a.mail = pin; a.dev = g_arp.dev; a.words = g_arp.words;
 #ifdef STEM_EXPERIMENTS
     a.dbg = g_arp_dbg;
 #endif
