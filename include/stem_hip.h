@@ -387,6 +387,9 @@ int stem_ar_decode_image(const float *w_ctx, int ld_ctx, const float *b_ctx, con
  * stream synchronisation.  Same arguments and results as stem_ar_decode_image (bit for bit: same dot-product order) without
  * the caller's mailboxes; every wait is bounded, a non-zero return leaves `buf` and the decoder state undefined (decode the
  * image again with stem_ar_decode_image from a fresh decoder).  Replaces the loop body of spatiotemporalpriors.py:1015-1054. */
+/* 1 if stem_ar_decode_image_persistent handles these widths (M latent channels; n0 / n1 outputs of EPM.0 / EPM.2): its workgroups
+ * keep the weights of fixed output rows resident (M <= 204, n0, n1 <= 768: every model of spatiotemporalpriors.py) */
+int stem_ar_decode_image_persistent_supported(int M, int n0, int n1);
 int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, const float *b_ctx, const float *w0, int ld0, const float *b0, int n0,
                                     const float *w1, int ld1, const float *b1, int n1, const float *w2, int ld2, const float *b2,
                                     float *buf, int H, int W, int M, int pad, const float *tp, const float *hp,

@@ -9,7 +9,7 @@ asynchronously (wavefront-parallel, t = w + 3h) and calls the host coder once; t
 inside the library (stem_ar_decode_image): per position four launches (the first also writes back the previous pixel,
 the last also emits the CDF indexes), one stream synchronisation and one call of the host rANS decoder -- injected as a
 C function pointer -- through a pinned mailbox.  (A cooperative single-launch variant was measured slower on ROCm 7.2:
-0.74 s vs 0.44 s per 1080p frame; a persistent device loop remains the "next" row, DESIGN.md.)
+0.74 s vs 0.44 s per 1080p frame.  One image: a persistent kernel, csrc/ar_persistent.hip.)
 """
 from __future__ import annotations
 
@@ -286,12 +286,11 @@ def stem_decompress(model, strings, shape, y_cond):
             decode_image_stepwise(ar, buf, H, W, tp_b, hp_b, dec, tables, idx_host, sym_host)
             out[b:b + 1].copy_(buf[_P:_P + H, _P:_P + W].permute(2, 0, 1).unsqueeze(0))
             continue
-        # The whole raster-order loop of this image runs inside the library.  STEM_AR_PERSISTENT=1 runs it as ONE persistent kernel
-        # (csrc/ar_persistent.hip: resident workgroups of one XCD, grid barriers, pinned mailboxes) -- bit-identical, and measured
-        # SLOWER than the per-position loop on MI355X (0.49 s against 0.30 s per 1080p P frame: 2 us per L2-local grid barrier
-        # and 6-11 us per 64-workgroup matrix-vector product against ~6 us per dependent dispatch), so it is
-        # opt-in; should it give up (a bounded wait timed out) the image is decoded again by the per-position loop.
-        if cfg.ar_persistent:
+        # The whole raster-order loop of this image runs inside the library: as ONE persistent kernel (csrc/ar_persistent.hip: 32 resident
+        # workgroups of one XCD with the weights of their output rows in registers, tagged 8-byte words instead of barriers, the known
+        # part of the next position accumulated while the host decodes; 0.12-0.13 s per 1080p P frame) or, STEM_AR_PERSISTENT=0 /
+        # unsupported widths / a bounded wait that ran out, as four launches + one synchronisation per position (0.29 s).  Bit-identical.
+        if cfg.ar_persistent and lib.stem_ar_decode_image_persistent_supported(M, ar.w0.shape[0], ar.w1.shape[0]):
             rc = lib.stem_ar_decode_image_persistent(
                 ar.w_ctx.data_ptr(), 12 * M, ar.b_ctx.data_ptr(), ar.w0.data_ptr(), ar.w0.shape[1], ar.b0.data_ptr(), ar.w0.shape[0],
                 ar.w1.data_ptr(), ar.w1.shape[1], ar.b1.data_ptr(), ar.w1.shape[0], ar.w2.data_ptr(), ar.w2.shape[1], ar.b2.data_ptr(),

@@ -63,7 +63,7 @@ class StemRuntimeConfig:
     dist_single: bool = False            #: a process group at world size 1 (one-GPU boxes execute the RCCL calls)
     pin_ranks: bool = True               #: ranks pin themselves to their GPU's NUMA cores
     # ---- decoder loop (all forms are bit-identical)
-    ar_persistent: bool = False
+    ar_persistent: bool = True
     ar_pipeline: bool = False
     ar_stepwise: bool = False
     ar_force_batch: bool = False

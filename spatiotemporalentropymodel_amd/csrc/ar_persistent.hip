@@ -2,18 +2,19 @@
 //
 // stem_ar_decode_image (ar.hip) pays, per latent position, four DEPENDENT dispatches (~6 us each on the queue), a stream
 // synchronisation and the host coder: ~35 us x 8160 positions = 0.29 s per 1080p P frame, whatever the arithmetic costs.
-// Here the whole loop is one launch:
-//   * NW workgroups stay resident and walk through the positions together; the four matrix-vector products of a position
-//     (context window -> ctx, EPM.0, EPM.2, EPM.4) are separated by grid barriers (one atomic counter, monotonic targets)
-//     instead of kernel boundaries;
-//   * the workers are taken from ONE XCD (every workgroup reads its XCC id; the first arrival picks the XCD, the first NW
-//     workgroups of that XCD stay, all others exit): the barrier counter and the vectors handed from product to product then
-//     live in one L2.  All cross-workgroup accesses are agent-scope (sc1) loads / stores / atomics, so the kernel is correct
-//     wherever the workgroups land -- the XCD choice only decides how fast the barriers are;
-//   * the host takes part through two pinned-memory mailboxes per position parity: the last product writes the CDF indexes and
-//     a sequence flag, the host thread (spinning inside stem_ar_decode_image_persistent) runs the rANS symbol decoder and
-//     posts the symbols with its own flag, workgroup 0 polls that flag, commits y_hat = symbol + mean to the latent buffer
-//     and releases the other workers.  Every wait is bounded; a timeout raises an abort word that ends the kernel.
+// Here the whole loop is one launch (0.12-0.13 s per 1080p P frame, bit-identical):
+//   * 32 workgroups of 512 threads stay resident -- one per CU of ONE XCD (every candidate reads its XCC id; the first arrival
+//     picks the XCD, the first 32 workgroups of that XCD stay, all others exit), so that everything they exchange lives in one L2
+//     -- and walk through the positions together; global wavefront g owns output rows g, g + 256, ... of all four products
+//     (context window -> ctx, EPM.0, EPM.2, EPM.4) for the whole image and keeps their weights in registers / LDS;
+//   * values travel between workgroups, and between device and host, as 8-byte words {value, position + 1} written by ONE store
+//     each: the consumer spins on the words it needs until they carry its position's tag.  No barriers, no separate flags;
+//   * only the part of a position's arithmetic that depends on the symbol just decoded is on the dependent path: the rest is
+//     accumulated ahead, as lane partials, while the host decodes (see below);
+//   * the host takes part through a pinned mailbox: workgroup 0 forwards the CDF indexes, the host thread (spinning inside
+//     stem_ar_decode_image_persistent) runs the rANS symbol decoder and posts the symbols, workgroup 0 commits
+//     y_hat = symbol + mean to the latent buffer and to a two-pixel ring of tagged words, which releases the other workers.
+//     Every wait is bounded; a timeout raises an abort word that ends the kernel (the caller then decodes with the loop).
 //
 // Arithmetic: every output row is one wavefront's dot product in the order of gemv3_decode_kernel (segments in order, columns
 // lane * 4 + 256 t ascending, xor-shuffle reduction, bias, leaky ReLU), compiled without FMA contraction like ar.hip -- the
@@ -48,53 +49,14 @@ struct ArpArgs {
     int nwg;                            // workers
     long long *words;                   // device: tagged 8-byte words {value, position + 1}: ctx [2M] | h1 [n0] | h2 [n1] | gp [2M] | idx [M] | pixel ring [2][M]
     float *dbg;                         // experiments build: [position][2M + n0 + n1 + 2M] copies of ctx | h1 | h2 | gp (null: off)
-    int *dev;                           // device, one 128-byte line per word group: [0] worker tickets, [1] chosen XCC (-1) -- agent scope;
-                                        // [64] barrier counter, [96] abort, [128] committed positions, [192..] CDF indexes -- L2-local
+    int *dev;                           // device, one 128-byte line per word group: [0] worker tickets, [1] chosen XCC (-1), [96] abort;
+                                        // [32..] the experiments build's timers
 };
 
 __device__ inline int xcc_id() { return __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15; }      // HW_REG_XCC_ID[3:0]
 
-// The workers share ONE XCD by construction (same HW_REG_XCC_ID), i.e. one L2, and everything they exchange -- barrier counter,
-// flags, the vectors handed from product to product -- is kept coherent AT that L2: stores are written through the CU's L1
-// (it is a write-through cache) and waited for; the counter / flags are read with an atomic RMW (fetch_add 0), which executes in
-// the L2; before data written by other CUs is loaded, the CU's L1 is invalidated (`buffer_inv sc0`).  Agent-scope (sc1)
-// accesses would be correct wherever the workgroups run but go to the memory side: measured 2.7-3.3 us per barrier.
-#define ARP_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
-__device__ inline int poll_l2(int *p)
-{
-    // written in assembly: the compiler turns an idempotent fetch_add(p, 0) into a plain load, which the L1 may serve forever
-    int v;
-    const int zero = 0;
-    asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p), "v"(zero) : "memory");
-    return v;
-}
-__device__ inline void l1_invalidate() { asm volatile("buffer_inv sc0" ::: "memory"); }
-__device__ inline float ld_agent(const float *p) { return *reinterpret_cast<const volatile float *>(p); }       // after l1_invalidate()
+// plain-memory accesses that must not be served from this CU's L1 (the latent buffer other workgroups read next image row)
 __device__ inline void st_agent(float *p, float v) { *reinterpret_cast<volatile float *>(p) = v; }
-
-// all workers arrive (their stores have been waited for), then every worker sees the counter reach `target`
-__device__ inline bool grid_barrier(int *bar, int target, int *abort_w, int tid)
-{
-    __shared__ int ok;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, ARP_SCOPE);
-        long spins = 0;
-        int good = 1;
-        while (poll_l2(bar) < target) {
-            if ((++spins & 1023) == 0 && (spins > SPIN_LIMIT || poll_l2(abort_w))) {
-                __hip_atomic_fetch_add(abort_w, 1, __ATOMIC_RELAXED, ARP_SCOPE);
-                good = 0;
-                break;
-            }
-        }
-        ok = good;
-    }
-    __syncthreads();
-    l1_invalidate();
-    return ok != 0;
-}
 
 // ---- what a position costs, and what this kernel keeps off that path ---------------------------------------------------------------
 // The first version (round 3) streamed all 9.7 MB of fp32 weights from the memory side for every position: 7-11 us per product,
@@ -112,7 +74,7 @@ __device__ inline bool grid_barrier(int *bar, int target, int *abort_w, int tid)
 //     on the dependent path in REGISTERS (148 VGPRs at M = 192: the last segment of its ctx rows, its EPM.0 / EPM.2 / EPM.4 rows)
 //     and the weights of the rows-above part of its ctx rows in LDS (16 KB per wavefront): nothing but the 384..768-float
 //     vectors handed from product to product moves on the dependent path.
-// 32 workgroups of 512 threads (one per CU of one XCD, 256 wavefronts), four L2-local grid barriers per position.
+// 32 workgroups of 512 threads (one per CU of one XCD, 256 wavefronts); hand-overs by tagged words (further down).
 constexpr int NT = 512, NWAVES = 256;
 constexpr int RC = 2, R0 = 3, R1 = 3, R2 = 2;           // rows per wavefront: ctx / gp (<= 512 rows), EPM.0 and EPM.2 (<= 768 rows)
 constexpr int TCA = 8, TCL = 2, T0A = 4, T0C = 2, T1 = 3, T2 = 3;      // 256-column steps: ctx rows-above (2 x 4), ctx left, EPM.0 tp|hp, EPM.0 ctx, EPM.2, EPM.4
@@ -231,7 +193,7 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
 
     const float tb = lane < a.T - 1 ? a.table[lane] : 0.f;          // this lane's entry of the scale table
     // lane partials of position q over the segments that do not depend on the symbols still to come: ctx over the two rows above,
-    // EPM.0 over tp | hp.  Everything it reads was final at least one grid barrier ago (the rows above: an image row ago).
+    // EPM.0 over tp | hp.  Everything it reads has been final for at least a position (the rows above: for an image row).
     float cpart[RC], epart[R0];
     auto lookahead = [&](int q) {
         const int qh = q / a.W, qw = q - qh * a.W;
@@ -547,6 +509,13 @@ thread_local ArpState g_arp;
 
 }   // namespace
 
+// 1 if the persistent kernel's fixed row -> wavefront map holds a model of these widths (M latent channels, n0 / n1 = EPM.0 / EPM.2 outputs)
+STEM_EXPORT int stem_ar_decode_image_persistent_supported(int M, int n0, int n1)
+{
+    return M > 0 && M % 4 == 0 && n0 % 4 == 0 && n1 % 4 == 0 && 5 * M <= 1024 && 10 * M <= XA_FLOATS && 4 * M <= XP_FLOATS && 2 * M <= NWAVES * RC &&
+           n0 <= NWAVES * R0 && n1 <= NWAVES * R1 && n0 <= XV_FLOATS && n1 <= XV_FLOATS && 2 * M <= XV_FLOATS;
+}
+
 // C ABI: same contract as stem_ar_decode_image (ar.hip) minus the caller's mailboxes (kept here, pinned, per host thread).
 STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, const float *b_ctx, const float *w0, int ld0, const float *b0, int n0,
                                                 const float *w1, int ld1, const float *b1, int n1, const float *w2, int ld2, const float *b2,
@@ -559,8 +528,7 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
                    "stem_ar_decode_image_persistent: null pointer");
     STEM_CHECK_ARG(H > 0 && W > 0 && M > 0 && M % 4 == 0 && n0 % 4 == 0 && n1 % 4 == 0 && ld_ctx % 4 == 0 && ld0 % 4 == 0 && ld1 % 4 == 0 &&
                    ld2 % 4 == 0 && T >= 1 && pad == 2, "stem_ar_decode_image_persistent: bad sizes");
-    STEM_CHECK_ARG(5 * M <= 1024 && 10 * M <= XA_FLOATS && 4 * M <= XP_FLOATS && 2 * M <= NWAVES * RC && n0 <= NWAVES * R0 && n1 <= NWAVES * R1 &&
-                   n0 <= XV_FLOATS && n1 <= XV_FLOATS && 2 * M <= XV_FLOATS,
+    STEM_CHECK_ARG(stem_ar_decode_image_persistent_supported(M, n0, n1),
                    "stem_ar_decode_image_persistent: built for M <= 204 and EPM widths <= 768 (M=%d n0=%d n1=%d)", M, n0, n1);
     hipStream_t st = (hipStream_t)stream;
     const int P = 2 * M, N = H * W;

@@ -150,27 +150,33 @@ def test_lockstep_batch_decode_equals_per_image_decode(monkeypatch):
     assert float((a - y_cur).abs().max()) <= 0.5 + 1e-4
 
 
-@pytest.mark.parametrize("cls_name", ["SpatioTemporalPriorModelWithoutTPM", "SpatioTemporalPriorModel_Res"])
-def test_persistent_decoder_equals_per_position_loop(cls_name, monkeypatch):
-    """csrc/ar_persistent.hip (one launch per image: resident workgroups, grid barriers between the four products of a position,
-    host symbol decoder behind pinned mailboxes; opt-in, STEM_AR_PERSISTENT=1) against stem_ar_decode_image (four launches + a
-    synchronisation per position) and the Python-driven single-step loop: identical reconstructions, bit for bit, no fallback
-    taken, and the stream decodes to within half a quantisation step of the input.  spatiotemporalpriors.py:1015-1054."""
+@pytest.mark.parametrize("cls_name,widths,hw", [("SpatioTemporalPriorModelWithoutTPM", (64, 96), (8, 20)), ("SpatioTemporalPriorModel_Res", (64, 96), (8, 20)),
+                                                ("SpatioTemporalPriorModel_Res", (256, 192), (4, 12)), ("SpatioTemporalPriorModel_Res", (64, 96), (12, 4))])
+def test_persistent_decoder_equals_per_position_loop(cls_name, widths, hw, monkeypatch):
+    """csrc/ar_persistent.hip, the default single-image decoder (one launch per image: 32 resident workgroups with the weights of
+    their output rows in registers, tagged 8-byte words from product to product, the next position's known part accumulated
+    while the host decodes, host symbol decoder behind a pinned mailbox) against stem_ar_decode_image (four launches + a
+    synchronisation per position, STEM_AR_PERSISTENT=0) and the Python-driven single-step loop: identical reconstructions, bit for
+    bit, no fallback taken, and the stream decodes to within half a quantisation step of the input.  Small and full-width model
+    (M = 96: two 256-column steps per window row; M = 192: four, the last one partial), with and without the temporal prior, and the
+    narrowest image the hyper path admits (4 columns: the window hangs over both borders at once).  spatiotemporalpriors.py:1015-1054."""
     import warnings
     import spatiotemporalentropymodel_amd.models as M
+    from spatiotemporalentropymodel_amd import config
     from spatiotemporalentropymodel_amd.weights import closed_form_fill_, closed_form_input
     dev = torch.device("cuda:0")
-    m = closed_form_fill_(getattr(M, cls_name)(64, 96)).to(dev).eval()
+    m = closed_form_fill_(getattr(M, cls_name)(*widths)).to(dev).eval()
     m.update(force=True)
-    y_cur = closed_form_input("pd:y", (1, 96, 8, 20), -6, 6).to(dev)
-    y_cond = closed_form_input("pd:c", (1, 96, 8, 20), -6, 6).to(dev)
+    y_cur = closed_form_input("pd:y", (1, widths[1], *hw), -6, 6).to(dev)
+    y_cond = closed_form_input("pd:c", (1, widths[1], *hw), -6, 6).to(dev)
 
     def y_hat(res):
         return (res["y_hat"] if isinstance(res, dict) else res).clone()
 
     with torch.no_grad():
         enc = m.compress(y_cur, y_cond)
-        monkeypatch.setenv("STEM_AR_PERSISTENT", "1")
+        monkeypatch.delenv("STEM_AR_PERSISTENT", raising=False)
+        assert config.runtime().ar_persistent                                   # the default route
         with warnings.catch_warnings():
             warnings.simplefilter("error")                                      # the fallback announces itself with a warning
             a = y_hat(m.decompress(enc["strings"], enc["shape"], y_cond))

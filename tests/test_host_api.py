@@ -567,7 +567,7 @@ def test_runtime_config_is_the_one_reader_of_the_stem_switches(monkeypatch):
     for v in config._ENV.values():
         monkeypatch.delenv(v, raising=False)
     d = config.runtime()
-    assert d == config.StemRuntimeConfig() and d.engine_f16x3 and d.dp_min_bytes == 8 << 20 and not d.ar_persistent
+    assert d == config.StemRuntimeConfig() and d.engine_f16x3 and d.dp_min_bytes == 8 << 20 and d.ar_persistent
     assert {f.name for f in dataclasses.fields(d)} == set(config._ENV)
     monkeypatch.setenv("STEM_ENGINE_F16X3", "0")
     monkeypatch.setenv("STEM_DP_MIN_BYTES", "4096")
