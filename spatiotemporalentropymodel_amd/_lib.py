@@ -14,8 +14,10 @@ HIP_SO = os.environ.get("STEM_HIP_LIBRARY") or os.path.join(_PKG, "libstem_hip.s
 # STEM_RANS_LIBRARY names another build of the host codec (`make sanitize` -> libstem_rans_asan.so, the sanitizer test)
 RANS_SO = os.environ.get("STEM_RANS_LIBRARY") or os.path.join(_PKG, "libstem_rans.so")
 
+DP_SO = os.environ.get("STEM_DP_LIBRARY") or os.path.join(_PKG, "libstem_dp.so")
 _hip = None
 _rans = None
+_dp = None
 
 vp, ci, cf, sz, u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 
@@ -252,6 +254,31 @@ def check(rc: int):
 
 def declared_hip_symbols():
     return sorted(_HIP_SIG)
+
+
+_DP_SIG = {
+    "stem_dp_unique_id": [C.c_void_p],
+    "stem_dp_create": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int],
+    "stem_dp_submit": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t],
+    "stem_dp_fence": [C.c_void_p, C.c_void_p],
+    "stem_dp_status": [C.c_void_p],
+    "stem_dp_destroy": [C.c_void_p],
+    "stem_dp_last_error": [],
+}
+
+
+def dp():
+    """libstem_dp.so (include/stem_dp.h): the native RCCL issue path of a data-parallel rank; links librccl"""
+    global _dp
+    if _dp is None:
+        if not os.path.exists(DP_SO):
+            raise StemLibraryError(f"{DP_SO} is missing: run `make -C {os.path.join(_PKG, 'csrc')}`")
+        _dp = _bind(C.CDLL(DP_SO), _DP_SIG, {"stem_dp_last_error": C.c_char_p})
+    return _dp
+
+
+def declared_dp_symbols():
+    return sorted(_DP_SIG)
 
 
 def declared_rans_symbols():

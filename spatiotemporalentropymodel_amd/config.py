@@ -57,7 +57,7 @@ class StemRuntimeConfig:
     stream_prio: str = ""                #: "latents=0,side=-1,compute=-1" (trainer.tuned_schedule installs it)
     stream_cumask: str = ""              #: "latents=block:160"
     # ---- data parallel
-    dp_threaded: int = 2                 #: RCCL collectives issued by a helper thread once their producers' events completed (no pending wait in the group's queue): 2 + stream flag for the way back, 1 host-blocking finish(), 0 off
+    dp_threaded: int = 3                 #: RCCL collectives issued by a helper thread once their producers' events completed (no pending wait in the communication queue): 3 native thread + own communicator (libstem_dp.so), 2 Python thread through torch.distributed, both with a stream flag for the way back; 1 host-blocking finish(); 0 off
     dp_min_bytes: int = 8 << 20          #: a run of final gradients is exchanged once it holds this many bytes
     dist_backend: str = ""               #: "" = RCCL when every rank has its own GPU, else gloo
     dist_single: bool = False            #: a process group at world size 1 (one-GPU boxes execute the RCCL calls)

@@ -268,6 +268,45 @@ class _CollectiveIssuer:
         self.q.put(None)
 
 
+class _NativeIssuer:
+    """The same job as _CollectiveIssuer without Python on the path: libstem_dp.so (include/stem_dp.h, csrc/dp_rccl.cpp) owns an RCCL
+    communicator of its own, a C++ helper thread that polls the producers' events and then enqueues ncclAllReduce, and the stream
+    flag the compute stream waits for.  The communicator id travels through torch.distributed once, at construction (collective:
+    every rank builds its reducers in the same order)."""
+
+    def __init__(self, device):
+        from . import _lib
+        self.lib = _lib.dp()
+        dev = torch.device(device)
+        ident = (ctypes.c_ubyte * 128)()
+        if dist.get_rank() == 0:
+            self._chk(self.lib.stem_dp_unique_id(ident))
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0)
+        ident = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
+        self.h = ctypes.c_void_p()
+        self._chk(self.lib.stem_dp_create(ctypes.byref(self.h), ident, dist.get_world_size(), dist.get_rank(), dev.index or 0))
+        import atexit
+        atexit.register(self.close)                          # the helper thread and the communicator go before the runtime does
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError("libstem_dp: " + (self.lib.stem_dp_last_error() or b"").decode())
+
+    def submit_streams(self, streams, tensor):
+        arr = (ctypes.c_void_p * len(streams))(*[s.cuda_stream for s in streams])
+        self._chk(self.lib.stem_dp_submit(self.h, arr, len(streams), tensor.data_ptr(), tensor.numel()))
+
+    def fence(self):
+        from . import functional as F_
+        self._chk(self.lib.stem_dp_fence(self.h, F_._stream()))
+
+    def close(self):
+        if self.h:
+            self.lib.stem_dp_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+
 class OverlappedGradReducer:
     """Sum all-reduce of a FlatParameters gradient buffer, one contiguous slice per module group, started from
     StemEngine.grad_ready_hook while the rest of backward is still running (RCCL on a side stream).
@@ -296,9 +335,18 @@ class OverlappedGradReducer:
         self._events = {}          # stream handle -> its event, re-used from step to step
         # RCCL: collectives are issued by a helper thread once their producers' events have completed (_CollectiveIssuer): the
         # process group's queue never holds a pending wait.  STEM_DP_THREADED=0: issued here, from the reporting stream (round 4)
-        # STEM_DP_THREADED: 2 (default) helper thread + stream flag; 1 helper thread, finish() blocks the host; 0 off
+        # STEM_DP_THREADED: 3 (default) native helper thread with its own RCCL communicator (libstem_dp.so) + stream flag; 2 Python
+        # helper thread issuing through torch.distributed + stream flag; 1 that thread, finish() blocking the host; 0 off
         mode = int(_config.runtime().dp_threaded)
-        self._issuer = _CollectiveIssuer(flat.grad.device, use_flag=mode >= 2) if (self._direct and mode > 0) else None
+        self._issuer = None
+        if self._direct and mode >= 3 and flat.grad.dtype == torch.float32:
+            try:
+                self._issuer = _NativeIssuer(flat.grad.device)
+            except Exception as e:                           # no librccl / no wait-value operation: the Python helper does the same job
+                import warnings
+                warnings.warn(f"native RCCL issue path unavailable ({e}); issuing through torch.distributed")
+        if self._issuer is None and self._direct and mode > 0:
+            self._issuer = _CollectiveIssuer(flat.grad.device, use_flag=mode >= 2)
         self.calls = 0             # slices reported (schedule bookkeeping)
         self.collectives = 0       # all-reduce calls issued
         #: a run of final gradients is exchanged once it holds this many bytes (and whatever is left at finish()).  What is
@@ -322,6 +370,9 @@ class OverlappedGradReducer:
         if not self.active:
             return
         g = self.flat.grad[lo:hi]
+        if self._direct and isinstance(self._issuer, _NativeIssuer):
+            self._issuer.submit_streams(list(deps or {torch.cuda.current_stream(): None}), g)
+            return
         if self._direct and self._issuer is not None:
             # one fresh event per stream that reported a slice of this run, recorded NOW (its stream's tail covers the reports)
             evs = []

@@ -97,6 +97,7 @@ def case_train(rank, world, out_dir, steps=2):
     dump["params"] = flat_np(opt.flat.data)
     dump["quantiles"] = flat_np(aux_opt.flat.data)
     dump["reducer_calls"] = np.array([red.calls])
+    dump["issuer"] = np.array([type(getattr(red, "_issuer", None)).__name__])
     np.savez(os.path.join(out_dir, f"train_rank{rank}.npz"), **dump)
 
 
@@ -136,6 +137,7 @@ def case_train_fused(rank, world, out_dir, steps=2, tag="train_fused"):
     dump["params"] = flat_np(opt.flat.data)
     dump["quantiles"] = flat_np(aux_opt.flat.data)
     dump["reducer_calls"] = np.array([red.calls])
+    dump["issuer"] = np.array([type(getattr(red, "_issuer", None)).__name__])
     import torch.distributed as dist
     dump["backend"] = np.array([dist.get_backend() if dist.is_initialized() else "none"])
     dump["max_over_ranks"] = np.array([D.max_over_ranks(3.25, dev)])

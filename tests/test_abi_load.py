@@ -32,6 +32,19 @@ def test_rans_library_exports_header_symbols():
     assert set(names) == set(_lib.declared_rans_symbols())
 
 
+def test_dp_library_exports_header_symbols():
+    """libstem_dp.so (native RCCL issue path of a data-parallel rank) loads without a GPU and exports what include/stem_dp.h declares"""
+    from spatiotemporalentropymodel_amd import _lib
+    names = _declared("stem_dp.h")
+    assert len(names) == 7
+    lib = ctypes.CDLL(_lib.DP_SO)
+    for n in names:
+        assert hasattr(lib, n), f"libstem_dp.so does not export {n}"
+    assert set(names) == set(_lib.declared_dp_symbols())
+    d = _lib.dp()
+    assert d.stem_dp_submit(None, None, 0, None, 0) != 0 and b"stem_dp_submit" in d.stem_dp_last_error()      # argument checks need no device
+
+
 def test_ops_fail_loudly_without_gpu():
     """The product path must not fall back to CPU: CPU tensors are rejected."""
     import pytest

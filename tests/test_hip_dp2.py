@@ -214,17 +214,21 @@ def test_rccl_world1_taped_executor_bit_identical_to_the_plain_schedule(dp2_resu
 
 @pytest.mark.dp2("rccl1_train_fused")
 @pytest.mark.dp2("rccl1_train_fused@0")
+@pytest.mark.dp2("rccl1_train_fused@2")
 @pytest.mark.dp2("rccl1_train_taped")
 @pytest.mark.dp2("rccl1_train_taped@1")
 def test_rccl_world1_issue_modes_agree(dp2_results):
-    """The reducer's three ways of issuing RCCL collectives (STEM_DP_THREADED): 2, the default -- a helper thread issues each
-    all-reduce once its producers' events have completed and the compute stream waits for a stream flag
-    (distributed._CollectiveIssuer, stem_stream_flag_*); 1 -- the helper thread, finish() blocking the host; 0 -- round 4's route,
-    asynchronous collectives from the reporting stream.  Same schedule, same bits (plain and through the launch tape)."""
-    (d,), (m0,) = dp2_results("rccl1_train_fused"), dp2_results("rccl1_train_fused@0")
-    assert int(d["reducer_calls"][0]) == int(m0["reducer_calls"][0]) == 10
+    """The reducer's ways of issuing RCCL collectives (STEM_DP_THREADED): 3, the default -- libstem_dp.so: a native helper thread
+    with its own communicator enqueues each ncclAllReduce once its producers' events have completed, the compute stream waits for
+    a stream flag (distributed._NativeIssuer, include/stem_dp.h); 2 -- the same from a Python thread through torch.distributed
+    (_CollectiveIssuer, stem_stream_flag_*); 1 -- that thread, finish() blocking the host; 0 -- round 4's route, asynchronous
+    collectives from the reporting stream.  Same schedule, same bits (plain and through the launch tape)."""
+    (d,), (m0,), (m2,) = dp2_results("rccl1_train_fused"), dp2_results("rccl1_train_fused@0"), dp2_results("rccl1_train_fused@2")
+    assert str(d["issuer"][0]) == "_NativeIssuer" and str(m2["issuer"][0]) == "_CollectiveIssuer" and str(m0["issuer"][0]) == "NoneType"
+    assert int(d["reducer_calls"][0]) == int(m0["reducer_calls"][0]) == int(m2["reducer_calls"][0]) == 10
     for k in ("grad_avg", "params", "quantiles", "s1:loss", "s2:loss"):
         np.testing.assert_array_equal(d[k], m0[k], err_msg=k)
+        np.testing.assert_array_equal(d[k], m2[k], err_msg=k)
     (t,), (t1,) = dp2_results("rccl1_train_taped"), dp2_results("rccl1_train_taped@1")
     assert int(t1["replays"][0]) == 5 and bool(t1["taped"][0]) and int(t["collectives"][0]) == int(t1["collectives"][0])
     for k in ["params", "quantiles"] + [f"s{i}:loss" for i in range(1, 9)]:
