@@ -390,6 +390,9 @@ int stem_ar_decode_image(const float *w_ctx, int ld_ctx, const float *b_ctx, con
 /* 1 if stem_ar_decode_image_persistent handles these widths (M latent channels; n0 / n1 outputs of EPM.0 / EPM.2): its workgroups
  * keep the weights of fixed output rows resident (M <= 204, n0, n1 <= 768: every model of spatiotemporalpriors.py) */
 int stem_ar_decode_image_persistent_supported(int M, int n0, int n1);
+/* calling thread: its next persistent decodes run on XCD `xcc` (0..7; -1 = first come): several images at once, one XCD + one stream +
+ * one host thread each (per-thread mailboxes inside the library) */
+int stem_ar_decode_image_persistent_prefer_xcc(int xcc);
 int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, const float *b_ctx, const float *w0, int ld0, const float *b0, int n0,
                                     const float *w1, int ld1, const float *b1, int n1, const float *w2, int ld2, const float *b2,
                                     float *buf, int H, int W, int M, int pad, const float *tp, const float *hp,

@@ -126,6 +126,7 @@ _HIP_SIG = {
     "stem_f16x2_pack_conv_weight_flip": [vp, vp, ci, ci, ci, ci, vp],
     "stem_conv2d_f16x3_fwd": [vp, vp, vp, vp, vp, vp, cf, vp, ci, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp],
     "stem_ar_decode_image_persistent_supported": [ci, ci, ci],
+    "stem_ar_decode_image_persistent_prefer_xcc": [ci],
     "stem_ar_decode_image_persistent": [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf,
                                         vp, vp, vp, ci, ci, vp, vp, vp],
     "stem_ar_decode_batch_pipelined": [vp, ci, vp, vp, ci, vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf,

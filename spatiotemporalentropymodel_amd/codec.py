@@ -245,6 +245,14 @@ def stem_decompress(model, strings, shape, y_cond):
     cfg = _config.runtime()
     stepwise = cfg.ar_stepwise
     lockstep = (B > 1 or cfg.ar_force_batch) and not stepwise and not cfg.ar_no_batch
+    decoded = set()
+    if (B > 1 and cfg.ar_persistent and cfg.ar_concurrent and not stepwise and not cfg.ar_force_batch and not cfg.ar_no_batch
+            and lib.stem_ar_decode_image_persistent_supported(M, ar.w0.shape[0], ar.w1.shape[0])):
+        # Several images: one persistent decoder each, eight at a time -- every kernel takes one XCD (32 CUs), its own stream and its own
+        # host thread for the rANS side (the library keeps its mailboxes per thread); the images do not wait for each other as they
+        # do in the lockstep loop below.  An image whose kernel gives up is decoded by the per-position loop further down.
+        decoded = _decode_concurrently(lib, ar, strings[0], out, H, W, M, tp, hp, tables, decode_fn, dev)
+        lockstep = False
     if lockstep:
         # Independent images advance together (csrc/ar.hip: stem_ar_decode_batch): the loop is bound by the latency of one
         # position (4 dependent launches + a host round trip), which G images share; each image's arithmetic is unchanged.
@@ -277,6 +285,8 @@ def stem_decompress(model, strings, shape, y_cond):
                                                 *tables.args(), F._stream()))
             out[b0:b0 + G].copy_(buf[:, _P:_P + H, _P:_P + W].permute(0, 3, 1, 2))
     for b, s in enumerate(strings[0] if not lockstep else []):
+        if b in decoded:
+            continue
         buf = _padded(None, H, W, M, dev)
         dec = RansDecoder()
         dec.set_stream(s)
@@ -314,6 +324,53 @@ def stem_decompress(model, strings, shape, y_cond):
     if model.RESIDUAL:
         out = F.add(out, _dense(yd))
     return out
+
+
+_POOL = None
+_SIDE = {}
+
+
+def _decode_concurrently(lib, ar, strings_y, out, H, W, M, tp, hp, tables, decode_fn, dev):
+    """stem_ar_decode_image_persistent for images 0 .. B-1, up to eight at once (XCD i % 8 for image i) -> the set of images done"""
+    global _POOL
+    import warnings
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=8, thread_name_prefix="stem-decode")     # kept: the library's per-thread state is allocated once
+    streams = _SIDE.setdefault(dev, [torch.cuda.Stream(device=dev) for _ in range(8)])
+    B = len(strings_y)
+    bufs = [_padded(None, H, W, M, dev) for _ in range(B)]
+    cur = torch.cuda.current_stream(dev)
+    for st in streams:
+        st.wait_stream(cur)                                  # the cleared buffers, tp / hp and the weights are this stream's work
+
+    def job(b):
+        torch.cuda.set_device(dev)
+        lib.stem_ar_decode_image_persistent_prefer_xcc(b % 8)
+        dec = RansDecoder()
+        dec.set_stream(strings_y[b])
+        hp_b = hp.data_ptr() + 4 * (b * H * W * 2 * M)
+        tp_b = tp.data_ptr() + 4 * (b * H * W * 2 * M) if tp is not None else 0
+        rc = lib.stem_ar_decode_image_persistent(
+            ar.w_ctx.data_ptr(), 12 * M, ar.b_ctx.data_ptr(), ar.w0.data_ptr(), ar.w0.shape[1], ar.b0.data_ptr(), ar.w0.shape[0],
+            ar.w1.data_ptr(), ar.w1.shape[1], ar.b1.data_ptr(), ar.w1.shape[0], ar.w2.data_ptr(), ar.w2.shape[1], ar.b2.data_ptr(),
+            bufs[b].data_ptr(), H, W, M, _P, tp_b, hp_b, ar.ctx.data_ptr(), ar.h1.data_ptr(), ar.h2.data_ptr(), ar.gp.data_ptr(),
+            ar.table.data_ptr(), ar.table.numel(), ar.bound, F.LRELU_SLOPE, decode_fn, dec._h, *tables.args(), streams[b % 8].cuda_stream)
+        err = (lib.stem_last_error() or b"").decode() if rc else ""
+        lib.stem_ar_decode_image_persistent_prefer_xcc(-1)
+        return rc, err
+
+    done = set()
+    for b0 in range(0, B, 8):                                # eight XCDs: eight images at a time
+        futs = [(b, _POOL.submit(job, b)) for b in range(b0, min(b0 + 8, B))]
+        for b, f in futs:
+            rc, err = f.result()                             # the call returns after its stream has been synchronised
+            if rc == 0:
+                out[b:b + 1].copy_(bufs[b][_P:_P + H, _P:_P + W].permute(2, 0, 1).unsqueeze(0))
+                done.add(b)
+            else:
+                warnings.warn(f"persistent decoder gave up on image {b} ({err}); decoding it with the per-position loop")
+    return done
 
 
 def _dense(t):

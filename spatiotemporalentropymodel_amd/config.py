@@ -67,6 +67,7 @@ class StemRuntimeConfig:
     ar_pipeline: bool = False
     ar_stepwise: bool = False
     ar_force_batch: bool = False
+    ar_concurrent: bool = True           #: several images: one persistent decoder per image, up to 8 at once (one XCD, one stream, one host thread each); off: the lockstep batch loop
     ar_no_batch: bool = False
 
 
@@ -82,7 +83,7 @@ _ENV = {
     "stream_prio": "STEM_STREAM_PRIO", "stream_cumask": "STEM_STREAM_CUMASK", "dp_min_bytes": "STEM_DP_MIN_BYTES", "dp_threaded": "STEM_DP_THREADED",
     "dist_backend": "STEM_DIST_BACKEND", "dist_single": "STEM_DIST_SINGLE", "pin_ranks": "STEM_PIN_RANKS",
     "ar_persistent": "STEM_AR_PERSISTENT", "ar_pipeline": "STEM_AR_PIPELINE", "ar_stepwise": "STEM_AR_STEPWISE",
-    "ar_force_batch": "STEM_AR_FORCE_BATCH", "ar_no_batch": "STEM_AR_NO_BATCH",
+    "ar_force_batch": "STEM_AR_FORCE_BATCH", "ar_concurrent": "STEM_AR_CONCURRENT", "ar_no_batch": "STEM_AR_NO_BATCH",
 }
 
 

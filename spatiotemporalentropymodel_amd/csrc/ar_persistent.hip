@@ -47,6 +47,7 @@ struct ArpArgs {
     float bound, slope;
     int *mail;                          // pinned: [16] host abort (-1); 8-byte words {value, position + 1}: [32 + slot * 2M ..] idx, [32 + 2 * 2M + slot * 2M ..] sym (slot = position parity)
     int nwg;                            // workers
+    int want_xcc;                       // -1: the first candidate to arrive picks the XCD; 0..7: this one (several images at once: one XCD each)
     long long *words;                   // device: tagged 8-byte words {value, position + 1}: ctx [2M] | h1 [n0] | h2 [n1] | gp [2M] | idx [M] | pixel ring [2][M]
     float *dbg;                         // experiments build: [position][2M + n0 + n1 + 2M] copies of ctx | h1 | h2 | gp (null: off)
     int *dev;                           // device, one 128-byte line per word group: [0] worker tickets, [1] chosen XCC (-1), [96] abort;
@@ -120,9 +121,12 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
     if (tid == 0) {
         // worker selection: the first workgroup to arrive fixes the XCD, the first NWG workgroups of that XCD are the workers
         const int me = xcc_id();
-        int expected = -1;
-        __hip_atomic_compare_exchange_strong(a.dev + 1, &expected, me, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int chosen = __hip_atomic_load(a.dev + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int chosen = a.want_xcc;
+        if (chosen < 0) {
+            int expected = -1;
+            __hip_atomic_compare_exchange_strong(a.dev + 1, &expected, me, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            chosen = __hip_atomic_load(a.dev + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         int r = -1;
         if (chosen == me) {
             r = __hip_atomic_fetch_add(a.dev, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -506,8 +510,18 @@ struct ArpState {
     size_t pinned_ints = 0, nwords = 0;
 };
 thread_local ArpState g_arp;
+thread_local int g_arp_want_xcc = -1;
 
 }   // namespace
+
+// Calling thread: its next images run on XCD `xcc` (0..7; -1: whichever candidate arrives first picks).  For decoding several images
+// at once from several host threads -- one XCD, one stream, one host thread each: the kernel needs an XCD to itself.
+STEM_EXPORT int stem_ar_decode_image_persistent_prefer_xcc(int xcc)
+{
+    STEM_CHECK_ARG(xcc >= -1 && xcc < 8, "stem_ar_decode_image_persistent_prefer_xcc: XCD %d (0..7, or -1)", xcc);
+    g_arp_want_xcc = xcc;
+    return 0;
+}
 
 // 1 if the persistent kernel's fixed row -> wavefront map holds a model of these widths (M latent channels, n0 / n1 = EPM.0 / EPM.2 outputs)
 STEM_EXPORT int stem_ar_decode_image_persistent_supported(int M, int n0, int n1)
@@ -574,6 +588,7 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
 #ifdef STEM_EXPERIMENTS
     a.dbg = g_arp_dbg;
 #endif
+    a.want_xcc = g_arp_want_xcc;
     a.nwg = NWG_DEFAULT;             // the row -> wavefront map is fixed: 32 workgroups x 8 wavefronts (the "arp_workers" selector of round 3 is ignored)
     static bool attr_done = false;
     if (!attr_done) {

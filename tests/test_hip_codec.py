@@ -118,8 +118,10 @@ def test_fused_decode_loop_equals_stepwise_entry_points(cls_name, monkeypatch):
 
 
 def test_lockstep_batch_decode_equals_per_image_decode(monkeypatch):
-    """decompress() of a batch advances the images in lockstep (stem_ar_decode_batch); per image it must reproduce what the
-    one-image-at-a-time loop (stem_ar_decode_image, the reference's order) decodes, bit for bit -- 5 images, non-square."""
+    """decompress() of a batch: by default one persistent decoder per image, all five at once on an XCD each
+    (codec._decode_concurrently); STEM_AR_CONCURRENT=0 / STEM_AR_FORCE_BATCH=1: the images advance in lockstep
+    (stem_ar_decode_batch); STEM_AR_NO_BATCH=1: one image after the other.  Per image every route must reproduce what the
+    per-position loop (stem_ar_decode_image, the reference's order) decodes, bit for bit -- 5 images, non-square."""
     import spatiotemporalentropymodel_amd.models as M
     from spatiotemporalentropymodel_amd.weights import closed_form_fill_, closed_form_input
     dev = torch.device("cuda:0")
@@ -129,7 +131,19 @@ def test_lockstep_batch_decode_equals_per_image_decode(monkeypatch):
     y_cond = closed_form_input("lb:c", (5, 96, 8, 12), -6, 6).to(dev)
     with torch.no_grad():
         enc = m.compress(y_cur, y_cond)
-        a = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                 # a kernel that gives up announces its fallback with a warning
+            a = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()
+        monkeypatch.setenv("STEM_AR_CONCURRENT", "0")
+        a0 = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()        # lockstep
+        monkeypatch.delenv("STEM_AR_CONCURRENT")
+        monkeypatch.setenv("STEM_AR_PERSISTENT", "0")
+        monkeypatch.setenv("STEM_AR_NO_BATCH", "1")
+        ref = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()       # the per-position loop, image by image
+        monkeypatch.delenv("STEM_AR_PERSISTENT")
+        monkeypatch.delenv("STEM_AR_NO_BATCH")
+        assert torch.equal(a, ref) and torch.equal(a0, ref)
         monkeypatch.setenv("STEM_AR_FORCE_BATCH", "1")     # the lockstep loop also for one image
         monkeypatch.setenv("STEM_AR_PIPELINE", "1")        # flag-polling variant: no stream synchronisation per position
         c = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()
