@@ -276,8 +276,17 @@ class _NativeIssuer:
 
     def __init__(self, device):
         from . import _lib
-        self.lib = _lib.dp()
         dev = torch.device(device)
+        # the choice of route is collective: a rank that cannot load the library must take the others with it to the fallback, or
+        # they would wait for it in ncclCommInitRank
+        try:
+            self.lib, mine = _lib.dp(), 1
+        except Exception:
+            self.lib, mine = None, 0
+        ok = torch.tensor([mine], device=dev, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            raise RuntimeError("libstem_dp.so is not loadable on every rank")
         ident = (ctypes.c_ubyte * 128)()
         if dist.get_rank() == 0:
             self._chk(self.lib.stem_dp_unique_id(ident))
