@@ -5,6 +5,7 @@ cd $R
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 python3 bench.py --gpus 2 --steps 2 --warmup 1 > $out/bench_gpus2_one_device.json 2> $out/bench_gpus2.err
 STEM_DIST_SINGLE=1 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_rccl_world1.json 2> $out/bench_rccl_world1.err
+STEM_DIST_SINGLE=1 bash tools/debug/ab_env.sh "-" "STEM_DP_THREADED=2" "STEM_DP_THREADED=0" > $out/ab_rccl_world1_issue_modes.log 2>&1
 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_no_group.json 2>/dev/null
 python3 bench.py --config roi > $out/bench_roi_b16.json 2> $out/bench_roi.err
 STEM_LAYERS_F16X3=0 python3 bench.py --config roi > $out/bench_roi_b16_fp32_layers.json 2>/dev/null
@@ -20,10 +21,12 @@ for t in f16x3_check f16x3_chain wgrad3_check f16x3_gen_check; do python3 tools/
 python3 tools/debug/f16x3_split_sweep.py gen 2>&1 | grep -v amdgpu > $out/split_sweep_gen.log
 python3 tools/debug/f16x3_split_sweep.py wgrad 2>&1 | grep -v amdgpu > $out/split_sweep_wgrad.log
 python3 tools/debug/f16x3_depth_sweep.py 2>&1 | grep -v amdgpu > $out/depth_sweep.log
-python3 tools/eval_pframe_bench.py --frames 3 > $out/eval_1080p_per_position_loop.log 2>&1
-python3 tools/eval_pframe_bench.py --frames 3 --sequences 8 > $out/eval_1080p_8_sequences_lockstep.log 2>&1
-if [ -f spatiotemporalentropymodel_amd/libstem_hip_exper.so ]; then
-  STEM_AR_PERSISTENT=1 STEM_HIP_LIBRARY=$R/spatiotemporalentropymodel_amd/libstem_hip_exper.so python3 tools/eval_pframe_bench.py --frames 2 > $out/eval_1080p_persistent_kernel.log 2>&1
+python3 tools/eval_pframe_bench.py --frames 8 > $out/eval_1080p_persistent_default.log 2>&1
+STEM_AR_PERSISTENT=0 python3 tools/eval_pframe_bench.py --frames 3 > $out/eval_1080p_per_position_loop.log 2>&1
+python3 tools/eval_pframe_bench.py --frames 3 --sequences 8 > $out/eval_1080p_8_sequences_concurrent.log 2>&1
+STEM_AR_CONCURRENT=0 python3 tools/eval_pframe_bench.py --frames 3 --sequences 8 > $out/eval_1080p_8_sequences_lockstep.log 2>&1
+if [ -f spatiotemporalentropymodel_amd/libstem_hip_exper.so ]; then       # per-position phase timers of the persistent decoder
+  STEM_HIP_LIBRARY=$R/spatiotemporalentropymodel_amd/libstem_hip_exper.so python3 tools/eval_pframe_bench.py --frames 2 > $out/eval_1080p_persistent_phases.log 2>&1
 fi
 python3 tools/debug/host_lag.py > $out/host_lag.log 2>&1
 python3 tools/host_overhead.py > $out/host_overhead.log 2>&1
