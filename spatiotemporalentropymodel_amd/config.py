@@ -52,6 +52,7 @@ class StemRuntimeConfig:
     engine_epm_dgrad_by_prior: bool = False #: EPM.0's input gradient range by range, the hyper chain's range first (measured: +0.19 ms)
     engine_share_in_planes: bool = True  #: he_in's planes double as the TPM chain's input (channel view)
     engine_ctx_on_side: bool = False     #: the context model's forward on the weight-gradient stream (experiment)
+    engine_ctx_split_on_side: bool = True #: the planes of t_hat (the context model's input) are made on the weight-gradient stream, idle during the forward, instead of between TPM.4 and the context model
     engine_fuse_gc_backward: bool = True #: GaussianConditional backward inside the fused forward glue kernel
     engine_bias_multi: bool = True       #: one launch for a module group's bias-gradient second stages
     stream_prio: str = ""                #: "latents=0,side=-1,compute=-1" (trainer.tuned_schedule installs it)
@@ -79,7 +80,7 @@ _ENV = {
     "layers_f16x3_maxpix": "STEM_LAYERS_F16X3_MAXPIX", "layers_wide_minpix": "STEM_LAYERS_WIDE_MINPIX",
     "adam_block_max": "STEM_ADAM_BLOCK_MAX", "trainer_overwrite_grads": "STEM_TRAINER_OVERWRITE_GRADS", "engine_overlap": "STEM_ENGINE_OVERLAP",
     "engine_split_pack": "STEM_ENGINE_SPLIT_PACK", "engine_pack_first": "STEM_ENGINE_PACK_FIRST", "engine_pack_pair": "STEM_ENGINE_PACK_PAIR", "engine_branch": "STEM_ENGINE_BRANCH", "engine_tpm_first": "STEM_ENGINE_TPM_FIRST", "engine_tpm_first_bwd": "STEM_ENGINE_TPM_FIRST_BWD", "engine_tpm_wgrad_inline": "STEM_ENGINE_TPM_WGRAD_INLINE",
-    "engine_bias_multi": "STEM_ENGINE_BIAS_MULTI", "engine_fuse_gc_backward": "STEM_ENGINE_FUSE_GC_BACKWARD", "engine_ctx_on_side": "STEM_ENGINE_CTX_ON_SIDE", "engine_share_in_planes": "STEM_ENGINE_SHARE_IN_PLANES", "engine_epm_dgrad_by_prior": "STEM_ENGINE_EPM_DGRAD_BY_PRIOR",
+    "engine_bias_multi": "STEM_ENGINE_BIAS_MULTI", "engine_fuse_gc_backward": "STEM_ENGINE_FUSE_GC_BACKWARD", "engine_ctx_on_side": "STEM_ENGINE_CTX_ON_SIDE", "engine_ctx_split_on_side": "STEM_ENGINE_CTX_SPLIT_ON_SIDE", "engine_share_in_planes": "STEM_ENGINE_SHARE_IN_PLANES", "engine_epm_dgrad_by_prior": "STEM_ENGINE_EPM_DGRAD_BY_PRIOR",
     "stream_prio": "STEM_STREAM_PRIO", "stream_cumask": "STEM_STREAM_CUMASK", "dp_min_bytes": "STEM_DP_MIN_BYTES", "dp_threaded": "STEM_DP_THREADED",
     "dist_backend": "STEM_DIST_BACKEND", "dist_single": "STEM_DIST_SINGLE", "pin_ranks": "STEM_PIN_RANKS",
     "ar_persistent": "STEM_AR_PERSISTENT", "ar_pipeline": "STEM_AR_PIPELINE", "ar_stepwise": "STEM_AR_STEPWISE",

@@ -498,6 +498,7 @@ class StemEngine:
     tpm_first_bwd = _Switch("engine_tpm_first_bwd")
     #: the context model's forward on the weight-gradient stream (opt-in experiment, STEM_ENGINE_CTX_ON_SIDE=1)
     ctx_on_side = _Switch("engine_ctx_on_side")
+    ctx_split_on_side = _Switch("engine_ctx_split_on_side")
     #: one planes tensor for he_in = [y_cur | y_cond] and the TPM chain's input (its second half): a split launch less per step
     share_in_planes = _Switch("engine_share_in_planes")
     #: EPM.0's input gradient as one launch per prior range, the hyper chain's range first, so that the chain that ends the backward
@@ -730,6 +731,18 @@ class StemEngine:
         pl = {}             # planes copies of activations, kept for the weight gradients
         split = F.F16Planes.split
         tp0 = tp2 = None
+        ctx_split_done = None
+        if (fused and self.has_spm and self.CTX.fx3 and self.ctx_split_on_side and ctx_go is None and rec.get("t_hat") is not None
+                and self.side_stream(dev) is not None):
+            # t_hat exists since the prologue and the context model runs behind the TPM chain: its planes are made meanwhile on the
+            # weight-gradient stream, which has nothing to do during the forward (one launch less between TPM.4 and the context model)
+            side = self.side_stream(dev)
+            F.stream_wait(side, F.cur_stream(dev))
+            with F.on_stream(side):
+                pl["t_hat"] = split(t_hat, src_q=_qp(rec.get("t_hat")))
+                ctx_split_done = self._events.setdefault("ctx_split", torch.cuda.Event())
+                F.event_record(ctx_split_done, side)
+            t_hat.record_stream(side)
 
         if self.share_in_planes and fused and self.HE[0].fx3 and self.has_tpm and self.TPM[0].fx3 and Cin % 32 == 0 and rec.get("in") is not None:
             # he_in = [y_cur | y_cond] and the TPM chain's input y_cond share ONE planes tensor (same record: max(|y_cur|, |y_cond|)):
@@ -816,6 +829,8 @@ class StemEngine:
                 epm_in.record_stream(side)
                 F.stream_wait(main, side)
             else:
+                if ctx_split_done is not None:
+                    F.event_wait(F.cur_stream(dev), ctx_split_done)
                 self._ctx_forward(t_hat, epm_in[:, o_ctx:o_ctx + P], pl)
         if bs is not None:
             F.stream_wait(main, bs)
@@ -963,7 +978,8 @@ class StemEngine:
         """context_prediction(t_hat) -> its channel slice of the EPM input (spatiotemporalpriors.py:857): on the fp16 kernel over
         the live taps of the mask (the planes of t_hat stay for the weight gradient), else on igemm.hip's masked form"""
         if self.CTX.fx3:
-            pl["t_hat"] = F.F16Planes.split(t_hat, src_q=_qp(self._rec.get("t_hat")))
+            if "t_hat" not in pl:
+                pl["t_hat"] = F.F16Planes.split(t_hat, src_q=_qp(self._rec.get("t_hat")))
             self.CTX.fwd6(pl["t_hat"], out=out)
         else:
             self.CTX.fwd(t_hat, out=out)

@@ -501,7 +501,7 @@ def test_taped_step_at_the_bench_geometry_is_bit_identical(monkeypatch):
 
 # the switches of config.StemRuntimeConfig that stay supported next to the defaults (round 4: the others were deleted)
 _SCHEDULE_SWITCHES = [("overlap_wgrad", False), ("branch_streams", False), ("split_pack", False), ("defer_bias_final", False),
-                      ("tpm_first", False), ("tpm_first_bwd", False), ("tpm_wgrad_inline", False), ("pack_first", True), ("pack_pair", False), ("share_in_planes", False)]
+                      ("tpm_first", False), ("tpm_first_bwd", False), ("tpm_wgrad_inline", False), ("pack_first", True), ("pack_pair", False), ("share_in_planes", False), ("ctx_split_on_side", False)]
 _ROUTE_SWITCHES = [("epm_dgrad_by_prior", True), ("fuse_gc_backward", False), ("use_wg3", False), ("use_fx3t", False), ("use_fx3s", False), ("use_ctx3", False), ("use_records", False), ("use_fx3", False)]
 
 
