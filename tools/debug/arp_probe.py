@@ -97,15 +97,18 @@ if bad:
 print("buffers equal:", bool(torch.equal(buf1, buf2)), " max |diff|", float((buf1 - buf2).abs().max()))
 
 if dbg is not None:
+    # experiments build: the four products' outputs per position (dumped by workgroup 1) against torch on the loop's final buffer,
+    # and what every wavefront multiplied in EPM.0 at position 0 (its ctx columns, its look-ahead lane partials)
     lib.stem_exper_arp_debug(None)
     Wp = W + 4
     b1 = buf1.view(H + 4, Wp, M)
     hpv = hp[0].permute(1, 2, 0).reshape(H * W, 2 * M)
-    for p in (0, 1, 2, W, W + 1):
+    tpv = None if tp is None else tp[0].permute(1, 2, 0).reshape(H * W, 2 * M)
+    for p in (0, 1, 2, W, W + 1, H * W - 1):
         h, w = divmod(p, W)
         win = torch.cat([b1[h, w:w + 5].reshape(-1), b1[h + 1, w:w + 5].reshape(-1), b1[h + 2, w:w + 2].reshape(-1)])
         ctx = ar.b_ctx + ar.w_ctx @ win
-        parts = ([] if tp is None else [tp[0].permute(1, 2, 0).reshape(H * W, 2 * M)[p]]) + [hpv[p], ctx]
+        parts = ([] if tpv is None else [tpv[p]]) + [hpv[p], ctx]
         h1 = torch.nn.functional.leaky_relu(ar.b0 + ar.w0 @ torch.cat(parts), F.LRELU_SLOPE)
         h2 = torch.nn.functional.leaky_relu(ar.b1 + ar.w1 @ h1, F.LRELU_SLOPE)
         gp = ar.b2 + ar.w2 @ h2
@@ -113,51 +116,11 @@ if dbg is not None:
         e = [float((d[:2 * M] - ctx).abs().max()), float((d[2 * M:2 * M + n0] - h1).abs().max()), float((d[2 * M + n0:2 * M + n0 + n1] - h2).abs().max()),
              float((d[2 * M + n0 + n1:] - gp).abs().max())]
         print(f" position {p}: max |kernel - torch| ctx {e[0]:.3e} h1 {e[1]:.3e} h2 {e[2]:.3e} gp {e[3]:.3e}   (|ctx| max {float(ctx.abs().max()):.2f})")
-        if p == 0:
-            hk = d[2 * M:2 * M + n0]
-            pre = lambda hpx, cx, b: torch.nn.functional.leaky_relu(b + ar.w0 @ torch.cat(([] if tp is None else [tp[0].permute(1, 2, 0).reshape(H * W, 2 * M)[p]]) + [hpx, cx]), F.LRELU_SLOPE)
-            for name, alt in (("bias = 0", pre(hpv[p], ctx, 0 * ar.b0)), ("hp = 0", pre(0 * hpv[p], ctx, ar.b0)), ("ctx = 0", pre(hpv[p], 0 * ctx, ar.b0)),
-                              ("ctx = 2 ctx", pre(hpv[p], 2 * ctx, ar.b0)), ("hp of p+1", pre(hpv[p + 1], ctx, ar.b0))):
-                print(f"   h1(0) if {name}: max |kernel - alt| {float((hk - alt).abs().max()):.3e}")
-            inv = torch.where(hk > 0, hk, hk / F.LRELU_SLOPE)
-            o = 0 if tp is None else 2 * M
-            comps = [ar.b0, ar.w0[:, o:o + 2 * M] @ hpv[p], ar.w0[:, o + 2 * M:o + 4 * M] @ ctx] + ([] if tp is None else [ar.w0[:, :2 * M] @ tp[0].permute(1, 2, 0).reshape(H * W, 2 * M)[p]])
-            kc = inv - comps[0] - comps[1] - (comps[3] if len(comps) > 3 else 0)
-            print("   kernel's ctx part (rows 0..7):", [round(float(v), 4) for v in kc[:8]], " true:", [round(float(v), 4) for v in comps[2][:8]])
-            kh = inv - comps[0] - comps[2] - (comps[3] if len(comps) > 3 else 0)
-            print("   kernel's hp part (rows 0..7):", [round(float(v), 4) for v in kh[:8]], " true:", [round(float(v), 4) for v in comps[1][:8]])
-            for lanes in (8, 16, 24, 32, 40, 48):
-                part = ar.w0[:, o + 2 * M:o + 2 * M + 4 * lanes] @ ctx[:4 * lanes]
-                print(f"   W_ctx ctx over the first {lanes} lanes' columns: max |kernel ctx part - it| {float((kc - part).abs().max()):.3e}")
-            A = torch.stack(comps, 1).double().cpu()
-            sol = torch.linalg.lstsq(A, inv.double().cpu().unsqueeze(1)).solution.flatten()
-            print("   least-squares coefficients of [bias, W_hp hp, W_ctx ctx, (W_tp tp)] in the kernel's pre-activation:", [round(float(v), 4) for v in sol],
-                  " residual", float((A @ sol.unsqueeze(1) - inv.double().cpu().unsqueeze(1)).abs().max()))
-            for nm, a_, b_ in (("h1", d[2 * M:2 * M + n0], h1), ("h2", d[2 * M + n0:2 * M + n0 + n1], h2), ("gp", d[2 * M + n0 + n1:], gp)):
-                bad = ((a_ - b_).abs() > 1e-4).nonzero().flatten()
-                print(f"   {nm}: {bad.numel()} wrong rows: {bad[:32].tolist()}")
-                good = ((a_ - b_).abs() <= 1e-4).nonzero().flatten()
-                print(f"   {nm}: right rows: {good.tolist()[:120]}")
-                print(f"   {nm}: errors of rows 0..15: {[round(float(v), 4) for v in (a_ - b_)[:16]]}")
-        if p >= 1:
-            hk = d[2 * M:2 * M + n0]
-            for name, hpx, cx in (("hp of p-1", hpv[p - 1], ctx), ("ctx of p-1", hpv[p], dbg[p - 1][:2 * M]), ("both of p-1", hpv[p - 1], dbg[p - 1][:2 * M]),
-                                  ("hp = 0", torch.zeros_like(hpv[p]), ctx), ("ctx = 0", hpv[p], torch.zeros_like(ctx))):
-                pr = ([] if tp is None else [tp[0].permute(1, 2, 0).reshape(H * W, 2 * M)[p]]) + [hpx, cx]
-                alt = torch.nn.functional.leaky_relu(ar.b0 + ar.w0 @ torch.cat(pr), F.LRELU_SLOPE)
-                print(f"   h1 if {name}: max |kernel - alt| {float((hk - alt).abs().max()):.3e}")
-        if p == 1:
-            bad = (d[:2 * M] - ctx).abs() > 1e-3
-            print("   wrong ctx rows:", bad.nonzero().flatten()[:24].tolist(), "of", int(bad.sum()))
-
-if dbg is not None:
     ex = dbg_all[H * W * (4 * M + n0 + n1):].view(256, 256 + 64 * 3)
     ctx0 = dbg[0][:2 * M]
     seen = ex[:, :2 * M]
-    print("E0 at position 0: waves whose ctx columns differ from ctx:", int(((seen - ctx0.unsqueeze(0)).abs().max(1).values > 0).sum()), "of 256; max diff",
-          float((seen - ctx0.unsqueeze(0)).abs().max()))
-    # lane partials over tp | hp: lane l sums columns 4 l + 256 t of each segment, in order
-    segs = ([] if tp is None else [tp[0].permute(1, 2, 0).reshape(H * W, 2 * M)[0]]) + [hp[0].permute(1, 2, 0).reshape(H * W, 2 * M)[0]]
+    print("EPM.0 at position 0: wavefronts whose ctx columns differ from ctx:", int(((seen - ctx0.unsqueeze(0)).abs().max(1).values > 0).sum()), "of 256")
+    segs = ([] if tpv is None else [tpv[0]]) + [hpv[0]]
     xcat = torch.cat(segs)
     worst = 0.0
     for gw in (0, 1, 100, 255):
@@ -175,12 +138,4 @@ if dbg is not None:
                             o = si * 2 * M + c
                             ref[l] += (xcat[o:o + 4] * wrow[o:o + 4]).sum()
             worst = max(worst, float((ex[gw, 256 + 64 * r:256 + 64 * r + 64] - ref).abs().max()))
-    print("look-ahead partials of EPM.0 (4 waves x 3 rows): max |kernel - reference|", worst)
-if dbg is not None:
-    print("ctx[:12]      ", [round(float(v), 4) for v in ctx0[:12]])
-    print("wave 0 sees   ", [round(float(v), 4) for v in seen[0][:12]])
-    print("wave 7 sees   ", [round(float(v), 4) for v in seen[7][:12]])
-    print("b_ctx[:12]    ", [round(float(v), 4) for v in ar.b_ctx[:12]])
-    # is what they see a permutation of ctx?
-    a_, b_ = torch.sort(seen[0])[0], torch.sort(ctx0)[0]
-    print("sorted equal:", bool(torch.equal(a_, b_)), " max |sorted diff|", float((a_ - b_).abs().max()))
+    print("look-ahead lane partials of EPM.0 (4 wavefronts x 3 rows): max |kernel - reference|", worst)

@@ -25,8 +25,9 @@ python3 tools/eval_pframe_bench.py --frames 8 > $out/eval_1080p_persistent_defau
 STEM_AR_PERSISTENT=0 python3 tools/eval_pframe_bench.py --frames 3 > $out/eval_1080p_per_position_loop.log 2>&1
 python3 tools/eval_pframe_bench.py --frames 3 --sequences 8 > $out/eval_1080p_8_sequences_concurrent.log 2>&1
 STEM_AR_CONCURRENT=0 python3 tools/eval_pframe_bench.py --frames 3 --sequences 8 > $out/eval_1080p_8_sequences_lockstep.log 2>&1
-if [ -f spatiotemporalentropymodel_amd/libstem_hip_exper.so ]; then       # per-position phase timers of the persistent decoder
-  STEM_HIP_LIBRARY=$R/spatiotemporalentropymodel_amd/libstem_hip_exper.so python3 tools/eval_pframe_bench.py --frames 2 > $out/eval_1080p_persistent_phases.log 2>&1
+X=spatiotemporalentropymodel_amd/libstem_hip_exper.so; [ -f $X ] || X=spatiotemporalentropymodel_amd/libstem_hip_xtmp.so
+if [ -f $X ]; then       # per-position phase timers of the persistent decoder
+  STEM_HIP_LIBRARY=$R/$X python3 tools/eval_pframe_bench.py --frames 2 > $out/eval_1080p_persistent_phases.log 2>&1
 fi
 python3 tools/debug/host_lag.py > $out/host_lag.log 2>&1
 python3 tools/host_overhead.py > $out/host_overhead.log 2>&1
