@@ -203,20 +203,29 @@ def stem_compress(model, y_cur, y_cond):
         indexes = gc.build_indexes(scales)
         y_strings = gc.compress(target, indexes, means=means)
         return {"strings": [y_strings, z_strings], "shape": zshape}
-    ar = _ARContext(model, yc.device)
+    return {"strings": [_encode_latents(model, target, hp, tp), z_strings], "shape": zshape}
+
+
+def _encode_latents(model, target, hp, tp):
+    """the raster-order coding of `target` (dense NHWC [B, M, H, W]) given the hyper prior `hp` and the temporal prior `tp` (or
+    None): spatiotemporalpriors.py:916-961 / priors.py:586-631 -> one string per image"""
+    gc = model.gaussian_conditional
+    B, M, H, W = target.shape
+    dev = target.device
+    ar = _ARContext(model, dev)
     tables = gc.host_tables()
     y_strings = []
     for b in range(B):
-        buf = _padded(target[b:b + 1], H, W, M, yc.device)
-        sym = torch.empty((H * W, M), device=yc.device, dtype=torch.int32)
-        idx = torch.empty((H * W, M), device=yc.device, dtype=torch.int32)
+        buf = _padded(target[b:b + 1], H, W, M, dev)
+        sym = torch.empty((H * W, M), device=dev, dtype=torch.int32)
+        idx = torch.empty((H * W, M), device=dev, dtype=torch.int32)
         hp_b = hp.data_ptr() + 4 * (b * H * W * 2 * M)
         tp_b = tp.data_ptr() + 4 * (b * H * W * 2 * M) if tp is not None else 0
         ar.encode_wavefront(buf, H, W, tp_b, hp_b, sym, idx)
         enc = BufferedRansEncoder()
         enc.encode_with_indexes(sym.cpu().numpy(), idx.cpu().numpy(), tables)      # one host call per image (:955-959)
         y_strings.append(enc.flush())
-    return {"strings": [y_strings, z_strings], "shape": zshape}
+    return y_strings
 
 
 def stem_decompress(model, strings, shape, y_cond):
@@ -225,12 +234,25 @@ def stem_decompress(model, strings, shape, y_cond):
     yd = F.to_nhwc(y_cond.detach())
     B, P, H, W = hp.shape
     M = P // 2
-    dev = hp.device
     if not model.HAS_SPM:
         gp = _gaussian_params(model, [p for p in (tp, hp) if p is not None])
         scales, means = gp[:, :M], gp[:, M:]
         indexes = gc.build_indexes(scales)
         return gc.decompress(strings[0], indexes, means=means)
+    out = _decode_latents(model, strings[0], hp, tp)
+    if model.RESIDUAL:
+        out = F.add(out, _dense(yd))
+    return out
+
+
+def _decode_latents(model, strings_y, hp, tp):
+    """the raster-order decoding of spatiotemporalpriors.py:1015-1054 / priors.py:676-716 for every image of the batch, given the
+    hyper prior `hp` (dense NHWC [B, 2M, H, W]) and the temporal prior `tp` (or None) -> the decoded latents, dense NHWC"""
+    gc = model.gaussian_conditional
+    strings = [strings_y]
+    B, P, H, W = hp.shape
+    M = P // 2
+    dev = hp.device
     ar = _ARContext(model, dev)
     tables = gc.host_tables()
     lib = _lib.hip()
@@ -321,9 +343,35 @@ def stem_decompress(model, strings, shape, y_cond):
             ar.table.data_ptr(), ar.table.numel(), ar.bound, F.LRELU_SLOPE, idx_host.data_ptr(), sym_host.data_ptr(),
             decode_fn, dec._h, *tables.args(), F._stream()))
         out[b:b + 1].copy_(buf[_P:_P + H, _P:_P + W].permute(2, 0, 1).unsqueeze(0))
-    if model.RESIDUAL:
-        out = F.add(out, _dense(yd))
     return out
+
+
+# ---- the I-frame codec: JointAutoregressiveHierarchicalPriors ("mbt2018") --------------------------------------------------------
+def iframe_compress(model, x):
+    """compressai/models/priors.py:544-584: y = g_a(x), z = h_a(y) through the bottleneck's coder, params = h_s(z_hat), then the
+    raster-order coding of y itself given params -- the same loop as a STEM model without temporal prior and without residual"""
+    eb = model.entropy_bottleneck
+    y = model.g_a(x)
+    z = model.h_a(y)
+    z_strings = eb.compress(z)
+    z_hat = eb.decompress(z_strings, z.shape[-2:]).to(y.device).float()
+    params = _dense(F.to_nhwc(model.h_s(z_hat)))
+    yn = _dense(F.to_nhwc(y.detach()))
+    if tuple(params.shape[-2:]) != tuple(yn.shape[-2:]):
+        raise ValueError(f"latent size {tuple(yn.shape[-2:])} does not survive the two stride-2 hyper stages (hyper-prior is "
+                         f"{tuple(params.shape[-2:])}): pad images to multiples of 64 pixels, as stem/evalSTEM.py:95-108 does")
+    return {"strings": [_encode_latents(model, yn, params, None), z_strings], "shape": z.shape[-2:]}
+
+
+def iframe_decompress(model, strings, shape):
+    """compressai/models/priors.py:633-674 -> {"x_hat", "y_hat"}"""
+    assert isinstance(strings, list) and len(strings) == 2
+    z_hat = model.entropy_bottleneck.decompress(strings[1], shape)
+    dev = next(model.parameters()).device
+    params = _dense(F.to_nhwc(model.h_s(z_hat.to(dev).float())))
+    y_hat = _decode_latents(model, strings[0], params, None)
+    x_hat = F.to_nchw(model.g_s(y_hat), clamp01=True)
+    return {"x_hat": x_hat, "y_hat": y_hat}
 
 
 _POOL = None

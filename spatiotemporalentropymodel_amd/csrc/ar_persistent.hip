@@ -48,7 +48,6 @@ struct ArpArgs {
     int *mail;                          // pinned: [16] host abort (-1); 8-byte words {value, position + 1}: [32 + slot * 2M ..] idx, [32 + 2 * 2M + slot * 2M ..] sym (slot = position parity)
     int nwg;                            // workers
     int want_xcc;                       // -1: the first candidate to arrive picks the XCD; 0..7: this one (several images at once: one XCD each)
-    const long long *symw;              // the host's symbol words [2][M] by position parity: in DEVICE memory when the host can store there (large BAR), else in the pinned mailbox
     long long *words;                   // device: tagged 8-byte words {value, position + 1}: ctx [2M] | h1 [n0] | h2 [n1] | gp [2M] | idx [M] | pixel ring [2][M]
     float *dbg;                         // experiments build: [position][2M + n0 + n1 + 2M] copies of ctx | h1 | h2 | gp (null: off)
     int *dev;                           // device, one 128-byte line per word group: [0] worker tickets, [1] chosen XCC (-1), [96] abort;
@@ -297,7 +296,7 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
     // workgroup 0, one thread per channel: the pixel of position pp = symbol + mean, once the host has posted the symbol
     auto commit_pixel = [&](int pp) {
         const int ph = pp / a.W, pw = pp - ph * a.W;
-        const long long *symw = a.symw + (size_t)(pp & 1) * M;
+        const long long *symw = reinterpret_cast<const long long *>(a.mail + 32 + 2 * P) + (size_t)(pp & 1) * M;
         float *pix = a.buf + ((size_t)(ph + a.pad) * Wp + (pw + a.pad)) * M;
         for (int c = tid; c < M; c += NT) {
             long spins = 0;
@@ -508,9 +507,7 @@ float *g_arp_dbg = nullptr;
 struct ArpState {
     int *pinned = nullptr, *dev = nullptr;
     long long *words = nullptr;
-    long long *symdev = nullptr;        // symbol words in uncached device memory, written by the host through the BAR (null: not possible here)
-    size_t pinned_ints = 0, nwords = 0, nsym = 0;
-    int large_bar = -1;
+    size_t pinned_ints = 0, nwords = 0;
 };
 thread_local ArpState g_arp;
 thread_local int g_arp_want_xcc = -1;
@@ -575,26 +572,6 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
         g_arp.nwords = nwords;
     }
     if (hipMemsetAsync(g_arp.words, 0, nwords * sizeof(long long), st) != hipSuccess) return -2;       // tag 0: nothing written yet
-    // The symbols' way back.  With a large BAR the host stores them straight into device memory (posted writes) and workgroup 0 polls
-    // its own memory; otherwise they stay in the pinned mailbox and every poll is a PCIe read round trip (~2 us).
-    if (g_arp.large_bar < 0) {
-        int dev_id = 0, lb = 0;
-        g_arp.large_bar = (hipGetDevice(&dev_id) == hipSuccess && hipDeviceGetAttribute(&lb, hipDeviceAttributeIsLargeBar, dev_id) == hipSuccess && lb &&
-                           stem_tuning(STEM_TUNE_ARP_WORKERS) != 1) ? 1 : 0;          // tuning "arp_workers" = 1: keep the symbols in host memory (A/B)
-    }
-    if (g_arp.large_bar && g_arp.nsym < 2 * (size_t)M) {
-        if (g_arp.symdev) (void)hipFree(g_arp.symdev);
-        g_arp.symdev = nullptr;
-        g_arp.nsym = 0;
-        void *sp = nullptr;
-        if (hipExtMallocWithFlags(&sp, 2 * (size_t)M * sizeof(long long), hipDeviceMallocUncached) == hipSuccess && sp) {
-            g_arp.symdev = static_cast<long long *>(sp);
-            g_arp.nsym = 2 * (size_t)M;
-        } else {
-            g_arp.large_bar = 0;
-        }
-    }
-    if (g_arp.symdev && hipMemsetAsync(g_arp.symdev, 0, 2 * (size_t)M * sizeof(long long), st) != hipSuccess) return -2;
     int *pin = g_arp.pinned;
     memset(pin, 0, need * sizeof(int));            // sequence numbers of the previous image must not match this one's
     static int init[192];
@@ -608,7 +585,6 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
     a.ld_ctx = ld_ctx; a.ld0 = ld0; a.n0 = n0; a.ld1 = ld1; a.n1 = n1; a.ld2 = ld2;
     a.buf = buf; a.H = H; a.W = W; a.M = M; a.pad = pad; a.tp = tp; a.hp = hp; a.ctx = ctx; a.h1 = h1; a.h2 = h2; a.gp = gp;
     a.table = table; a.T = T; a.bound = scale_bound; a.slope = slope; a.mail = pin; a.dev = g_arp.dev; a.words = g_arp.words;
-    a.symw = g_arp.symdev ? g_arp.symdev : reinterpret_cast<const long long *>(pin + 32 + 2 * P);
 #ifdef STEM_EXPERIMENTS
     a.dbg = g_arp_dbg;
 #endif
@@ -631,7 +607,7 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
         long spins = 0;
         bool lost = false;
         const long long *idxw = reinterpret_cast<const long long *>(pin + 32) + (size_t)(p & 1) * M;
-        long long *symw = (g_arp.symdev ? g_arp.symdev : reinterpret_cast<long long *>(pin + 32 + 2 * P)) + (size_t)(p & 1) * M;
+        long long *symw = reinterpret_cast<long long *>(pin + 32 + 2 * P) + (size_t)(p & 1) * M;
         // all M words carry this position's sequence number (they arrive in any order)
         for (int c = M - 1; c >= 0;) {
             const long long v = __atomic_load_n(idxw + c, __ATOMIC_ACQUIRE);
@@ -658,7 +634,6 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
         }
         for (int c = 0; c < M; ++c)
             __atomic_store_n(symw + c, ((long long)(p + 1) << 32) | (unsigned)sym_v[(size_t)c], __ATOMIC_RELEASE);
-        if (g_arp.symdev) __builtin_ia32_sfence();           // device memory is mapped write-combining: the words leave now, not when the buffers fill
     }
     if (rc_out) __atomic_store_n(pin + 16, -1, __ATOMIC_RELEASE);           // the kernel's polls stop
     if (hipStreamSynchronize(st) != hipSuccess) {

@@ -1,16 +1,17 @@
 """CompressionModel base class and the I-frame transforms of JointAutoregressiveHierarchicalPriors
 ("mbt2018": compressai/models/priors.py:42-106, 406-694).
 
-On the STEM path only g_a / g_s (getY / getX) are executed; the I-frame codec's own hyper-prior
-modules are constructed so that reference checkpoints load key-for-key, but its
-forward / compress / decompress are out of scope and raise.
+On the STEM training path only g_a / g_s (getY / getX) are executed.  The evaluation loop also codes its I frames with this
+model (stem/evalSTEM.py:54-59: compress / decompress; priors.py:476-716): forward (inference), compress and decompress run the
+hyper-prior modules and the same raster-order coder as the STEM models (codec.py: the entropy-parameter network sees
+cat(params, ctx) exactly like a STEM model without temporal prior).
 """
 import torch
 import torch.nn as nn
 
 from .. import functional as F
 from ..entropy_models import EntropyBottleneck, GaussianConditional
-from ..layers import GDN, Conv2d, ConvTranspose2d, FusedSequential, LeakyReLU, MaskedConv2d, conv, deconv
+from ..layers import GDN, Conv2d, ConvTranspose2d, FusedSequential, LeakyReLU, MaskedConv2d, cat, conv, deconv
 from .utils import update_registered_buffers
 
 __all__ = ["CompressionModel", "JointAutoregressiveHierarchicalPriors"]
@@ -83,14 +84,53 @@ class JointAutoregressiveHierarchicalPriors(CompressionModel):
         """g_s + clamp(0,1); returns a contiguous NCHW image batch (layout change and clamp fused)."""
         return F.to_nchw(self.g_s(y_hat), clamp01=True)
 
+    # ---- the I-frame codec (priors.py:476-716; stem/evalSTEM.py:54-59) ---------------------------------------------------------
+    #: what codec.py's raster-order coder asks a model: a spatial prior, no temporal prior, the latents themselves are coded
+    HAS_SPM, HAS_TPM, RESIDUAL = True, False, False
+
+    @property
+    def in_channels(self):
+        return self.M
+
+    @property
+    def EPM(self):
+        return self.entropy_parameters
+
     def forward(self, x):
-        raise NotImplementedError("I-frame coding (mbt2018.forward) is outside the STEM hot path; use getY/getX")
+        """priors.py:476-508 -> {"y", "y_hat", "x_hat", "likelihoods": {"y", "z"}, "entropy_params": {"scales_hat", "means_hat"}}"""
+        y = self.g_a(x)
+        z = self.h_a(y)
+        z_hat, z_likelihoods = self.entropy_bottleneck(z)
+        params = self.h_s(z_hat)
+        y_hat = self.gaussian_conditional.quantize(y, "noise" if self.training else "dequantize")
+        ctx_params = self.context_prediction(y_hat)
+        gaussian_params = self.entropy_parameters(cat([params, ctx_params]))
+        scales_hat, means_hat = gaussian_params.chunk(2, 1)
+        _, y_likelihoods = self.gaussian_conditional(y, scales_hat, means=means_hat)
+        x_hat = self.g_s(y_hat)
+        return {"y": y, "y_hat": y_hat, "x_hat": x_hat, "likelihoods": {"y": y_likelihoods, "z": z_likelihoods},
+                "entropy_params": {"scales_hat": scales_hat, "means_hat": means_hat}}
 
     def compress(self, x):
-        raise NotImplementedError("I-frame coding (mbt2018.compress) is outside the STEM hot path")
+        """priors.py:544-584 -> {"strings": [y_strings, z_strings], "shape": z.shape[-2:]}"""
+        from ..codec import iframe_compress
+        with torch.no_grad():
+            return iframe_compress(self, x)
 
     def decompress(self, strings, shape):
-        raise NotImplementedError("I-frame coding (mbt2018.decompress) is outside the STEM hot path")
+        """priors.py:633-674 -> {"x_hat", "y_hat"}"""
+        from ..codec import iframe_decompress
+        with torch.no_grad():
+            return iframe_decompress(self, strings, shape)
+
+    def update(self, scale_table=None, force=False):
+        """the Gaussian tables next to the bottleneck's (priors.py's MeanScaleHyperprior.update, which mbt2018 inherits)"""
+        from .spatiotemporalpriors import get_scale_table
+        if scale_table is None:
+            scale_table = get_scale_table()
+        updated = self.gaussian_conditional.update_scale_table(scale_table, force=force)
+        updated |= super().update(force=force)
+        return updated
 
     def load_state_dict(self, state_dict, strict=True):
         update_registered_buffers(self.gaussian_conditional, "gaussian_conditional",

@@ -430,6 +430,46 @@ def gen_stem_codec(ref):
     save("stem_codec_small.npz", d)
 
 
+def gen_iframe_codec(ref):
+    """mbt2018 = JointAutoregressiveHierarchicalPriors as the I-frame codec of the evaluation loop (stem/evalSTEM.py:54-59 calls
+    its compress / decompress; compressai/models/priors.py:476-676): forward (eval), compress, decompress of one 128 x 128 image
+    through the small model; the last analysis layer is scaled x4 after the closed-form fill so that the symbols are not all zero,
+    and the first synthesis layer's weight by 1/4 so that the inverse-GDN chain sees the magnitudes it was filled for."""
+    from compressai.models.priors import JointAutoregressiveHierarchicalPriors
+
+    imodel = JointAutoregressiveHierarchicalPriors(64, 96).eval()
+    closed_form_fill_(imodel)
+    with torch.no_grad():
+        imodel.g_a[6].weight.mul_(4.0)
+        imodel.g_a[6].bias.mul_(4.0)
+        imodel.g_s[0].weight.mul_(0.25)
+    imodel.update(force=True)
+    x = smooth_frames("icodec", 1, 1, 128)[0]
+    d = {"x": t2n(x)}
+    with torch.no_grad():
+        enc = imodel.compress(x)
+        dec = imodel.decompress(enc["strings"], enc["shape"])
+        fwd = imodel(x)
+    d["y_string"] = np.frombuffer(enc["strings"][0][0], dtype=np.uint8)
+    d["z_string"] = np.frombuffer(enc["strings"][1][0], dtype=np.uint8)
+    d["shape"] = np.array(enc["shape"])
+    d["x_hat"], d["y_hat"] = t2n(dec["x_hat"]), t2n(dec["y_hat"])
+    for k in ("y", "y_hat", "x_hat"):
+        d[f"fwd:{k}"] = t2n(fwd[k])
+    d["fwd:lik_y"], d["fwd:lik_z"] = t2n(fwd["likelihoods"]["y"]), t2n(fwd["likelihoods"]["z"])
+    d["fwd:scales"], d["fwd:means"] = t2n(fwd["entropy_params"]["scales_hat"]), t2n(fwd["entropy_params"]["means_hat"])
+    d["eb_cdf"], d["eb_offset"] = t2n(imodel.entropy_bottleneck._quantized_cdf), t2n(imodel.entropy_bottleneck._offset)
+    d["eb_cdf_length"] = t2n(imodel.entropy_bottleneck._cdf_length)
+    d["gc_cdf"] = t2n(imodel.gaussian_conditional._quantized_cdf).astype(np.int32)
+    d["gc_offset"], d["gc_cdf_length"] = t2n(imodel.gaussian_conditional._offset), t2n(imodel.gaussian_conditional._cdf_length)
+    d["gc_scale_table"] = t2n(imodel.gaussian_conditional.scale_table)
+    nz = int((np.frombuffer(enc["strings"][0][0], dtype=np.uint8) != 0).sum())
+    print(f"iframe codec: y string {len(enc['strings'][0][0])} bytes ({nz} non-zero), z string {len(enc['strings'][1][0])} bytes, "
+          f"|y| max {float(fwd['y'].abs().max()):.2f}, |x_hat| max before the clamp {float(fwd['x_hat'].abs().max()):.2f}, "
+          f"decoded pixels strictly inside (0, 1): {float(((dec['x_hat'] > 0) & (dec['x_hat'] < 1)).float().mean()):.2f}, y_hat non-zero {float((dec['y_hat'] != 0).float().mean()):.2f}")
+    save("iframe_codec_small.npz", d)
+
+
 ROI_CONV_SCALE = 0.7
 
 
@@ -851,7 +891,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     scratch, ref_utils = import_reference()
     try:
-        which = sys.argv[1:] or ["ops", "codec", "fwd", "train_small", "train_big", "stemcodec", "roi", "roiops", "roigop", "container", "dataset", "variants", "ablations", "f64"]
+        which = sys.argv[1:] or ["ops", "codec", "fwd", "train_small", "train_big", "stemcodec", "iframecodec", "roi", "roiops", "roigop", "container", "dataset", "variants", "ablations", "f64"]
         if "ops" in which:
             gen_ops(ref_utils)
         if "codec" in which:
@@ -864,6 +904,8 @@ if __name__ == "__main__":
             _train_case(ref_utils, 256, 192, 192, 192, batch=2, size=64, tag="big")
         if "stemcodec" in which:
             gen_stem_codec(ref_utils)
+        if "iframecodec" in which:
+            gen_iframe_codec(ref_utils)
         if "roi" in which:
             gen_stem_roi(ref_utils)
         if "roiops" in which:

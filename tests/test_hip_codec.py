@@ -201,3 +201,64 @@ def test_persistent_decoder_equals_per_position_loop(cls_name, widths, hw, monke
         c = y_hat(m.decompress(enc["strings"], enc["shape"], y_cond))
     assert torch.equal(a, b) and torch.equal(a, a2) and torch.equal(b, c)
     assert float((a - y_cur).abs().max()) <= 0.5 + 1e-4
+
+
+def test_iframe_codec_matches_reference(golden):
+    """JointAutoregressiveHierarchicalPriors ("mbt2018") as the evaluation loop's I-frame codec (stem/evalSTEM.py:54-59;
+    compressai/models/priors.py:476-716): compress() reproduces the reference's two bitstreams byte for byte, decompress() of the
+    reference's strings its latents and image, forward() its inference outputs -- small model, closed-form weights with the last
+    analysis layer scaled x4 and the first synthesis layer x1/4 as in tests/golden/make_golden.py:gen_iframe_codec.  Both decoder routes (persistent kernel, loop)."""
+    import os
+    from spatiotemporalentropymodel_amd import config
+    from spatiotemporalentropymodel_amd.models.priors import JointAutoregressiveHierarchicalPriors
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_
+    g = golden("iframe_codec_small.npz")
+    dev = torch.device("cuda:0")
+    m = closed_form_fill_(JointAutoregressiveHierarchicalPriors(64, 96))
+    with torch.no_grad():
+        m.g_a[6].weight.mul_(4.0)
+        m.g_a[6].bias.mul_(4.0)
+        m.g_s[0].weight.mul_(0.25)
+    m = m.to(dev).eval()
+    assert m.update(force=True) is True
+    # as with any checkpoint, the coder uses the tables stored in the state_dict (update() runs host transcendental kernels whose
+    # last ulp depends on the CPU: test_bitstreams_match_reference)
+    for ours, ref in ((host(m.entropy_bottleneck._quantized_cdf), g["eb_cdf"]), (host(m.gaussian_conditional._quantized_cdf), g["gc_cdf"])):
+        diff = np.abs(ours.astype(np.int64) - ref)
+        assert diff.max() <= 1 and (diff != 0).mean() < 5e-3
+    sd = m.state_dict()
+    for k, v in (("entropy_bottleneck._quantized_cdf", g["eb_cdf"]), ("entropy_bottleneck._offset", g["eb_offset"]),
+                 ("entropy_bottleneck._cdf_length", g["eb_cdf_length"]), ("gaussian_conditional._quantized_cdf", g["gc_cdf"]),
+                 ("gaussian_conditional._offset", g["gc_offset"]), ("gaussian_conditional._cdf_length", g["gc_cdf_length"])):
+        sd[k] = torch.from_numpy(v).to(dev)
+    m.load_state_dict(sd)
+    x = torch.from_numpy(g["x"]).to(dev)
+    with torch.no_grad():
+        enc = m.compress(x)
+        assert tuple(enc["shape"]) == tuple(g["shape"])
+        assert enc["strings"][1][0] == g["z_string"].tobytes(), "hyper-latent bitstream differs"
+        assert enc["strings"][0][0] == g["y_string"].tobytes(), "latent bitstream differs from the reference's"
+        ref_strings = [[g["y_string"].tobytes()], [g["z_string"].tobytes()]]
+        outs = []
+        for persistent in ("1", "0"):
+            os.environ["STEM_AR_PERSISTENT"] = persistent
+            try:
+                assert config.runtime().ar_persistent == (persistent == "1")
+                outs.append(m.decompress(ref_strings, enc["shape"]))
+            finally:
+                os.environ.pop("STEM_AR_PERSISTENT")
+        assert torch.equal(outs[0]["y_hat"], outs[1]["y_hat"]) and torch.equal(outs[0]["x_hat"], outs[1]["x_hat"])
+        dec = outs[0]
+        assert_close(host(dec["y_hat"]), g["y_hat"], what="decoded y_hat vs reference", floor=0.1)
+        # the image is the synthesis transform's output clamped to [0, 1]: with these weights it spans +-|x|max before the clamp, and a
+        # pixel next to a clamp edge carries the UNclamped tensor's rounding error -- 1e-4 of that tensor's scale
+        pre = float(np.abs(g["fwd:x_hat"]).max())
+        assert_close(host(dec["x_hat"]), g["x_hat"], atol=1e-4 * max(pre, 1.0), what="decoded image vs reference", floor=0.1)
+        fwd = m(x)
+    assert_close(host(fwd["y"]), g["fwd:y"], what="forward y", floor=0.1)
+    assert_close(host(fwd["y_hat"]), g["fwd:y_hat"], what="forward y_hat", floor=0.1)
+    assert_close(host(fwd["x_hat"]), g["fwd:x_hat"], what="forward x_hat", floor=0.1)
+    assert_close(host(fwd["entropy_params"]["scales_hat"]), g["fwd:scales"], what="scales", floor=0.1)
+    assert_close(host(fwd["entropy_params"]["means_hat"]), g["fwd:means"], what="means", floor=0.1)
+    assert_close(host(fwd["likelihoods"]["z"]), g["fwd:lik_z"], what="lik_z", floor=0.1, atol=1e-9)
+    assert_close(host(fwd["likelihoods"]["y"]), g["fwd:lik_y"], rtol=2e-4, what="lik_y", floor=0.1, atol=1e-9)

@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--sequences", type=int, default=1)
-    ap.add_argument("--workers", type=int, default=0, help="persistent decoder: 1 keeps the host-written symbol words in pinned host memory instead of device memory (A/B of the large-BAR route); other values are ignored since round 5 (the row map fixes 32 workgroups)")
+    ap.add_argument("--workers", type=int, default=0, help="ignored since round 5 (the persistent decoder's row map fixes 32 workgroups)")
     a = ap.parse_args()
     if a.workers:
         from spatiotemporalentropymodel_amd import _lib
