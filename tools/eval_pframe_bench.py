@@ -38,6 +38,7 @@ def main():
     G = a.sequences
     dev = torch.device("cuda:0")
     imodel = closed_form_fill_(models["mbt2018"](quality=4)).to(dev).eval()
+    imodel.update(force=True)
     stem = closed_form_fill_(SpatioTemporalPriorModel_Res()).to(dev).eval()
     stem.update(force=True)
     yy, xx = torch.meshgrid(torch.arange(a.height, device=dev), torch.arange(a.width, device=dev), indexing="ij")
@@ -52,8 +53,19 @@ def main():
         return torch.cat([imodel.getX(y[i:i + 4].contiguous(memory_format=torch.channels_last)) for i in range(0, y.shape[0], 4)])
 
     with torch.no_grad():
-        y_cond = getY(bitstream.pad(frames[0], 64))        # stands in for the decoded I frame's latent
-        y_cond = torch.round(y_cond)
+        # the I frame through mbt2018's own codec, as inferenceI_DVR does (stem/evalSTEM.py:54-59); its decoded latent conditions frame 1
+        x0 = bitstream.pad(frames[0], 64)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        enc_i = [imodel.compress(x0[i:i + 1]) for i in range(G)]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        dec_i = [imodel.decompress(e["strings"], e["shape"]) for e in enc_i]
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        y_cond = torch.cat([d["y_hat"] for d in dec_i])
+        bpp_i = sum(len(b) for e in enc_i for s_ in e["strings"] for b in s_) * 8.0 / (a.height * a.width * G)
+        print(f"I frame x {G} sequences: encode {(t1 - t0) / G:.3f} s, decode {(t2 - t1) / G:.3f} s per frame, bpp {bpp_i:.4f} (mbt2018.compress / decompress)")
         for t in range(1, a.frames + 1):
             x = frames[t]
             xp = bitstream.pad(x, 64)
