@@ -646,8 +646,8 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
         long long t[10];
         if (hipMemcpy(t, g_arp.dev + 32, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) {
             fprintf(stderr, "[ar persistent] shader clock %.0f MHz (s_memtime cycles per 100 MHz tick x 100)\n", 100.0 * (double)t[8] / (double)t[9]);
-            fprintf(stderr, "[ar persistent] 100 MHz ticks per position (workgroup 0): wait host + commit %.1f, ctx %.1f + barrier %.1f, h1 %.1f, h2 %.1f, "
-                            "barriers after h1 / h2 %.1f, gp %.1f + barrier %.1f\n", (double)t[0] / N, (double)t[1] / N, (double)t[2] / N, (double)t[3] / N,
+            fprintf(stderr, "[ar persistent] 100 MHz ticks per position (workgroup 0): mail + look-ahead + host + commit %.1f, ctx %.1f + hand-over %.1f, h1 %.1f, h2 %.1f, "
+                            "hand-overs of h1 and h2 %.1f, gp %.1f + mail %.1f\n", (double)t[0] / N, (double)t[1] / N, (double)t[2] / N, (double)t[3] / N,
                     (double)t[5] / N, (double)t[4] / N, (double)t[6] / N, (double)t[7] / N);
         }
     }
