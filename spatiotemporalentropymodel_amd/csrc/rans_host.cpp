@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/stem_rans.h"
@@ -85,9 +86,47 @@ int push_events(std::vector<Event> &ev, const int32_t *symbols, const int32_t *i
     return 0;
 }
 
+// x / freq without a division instruction on the coder's serial path: floor(x * m / 2^(63 + s)) with s = ceil(log2 freq),
+// m = ceil(2^(63 + s) / freq) < 2^64.  Exact for every 0 <= x < 2^63 (Granlund & Montgomery, "Division by invariant integers using
+// multiplication", theorem 4.2 with N = 63: 2^(N+s) <= m * freq <= 2^(N+s) + 2^s) -- and the state in front of a table symbol is
+// below ((L >> 16) << 32) * freq <= 2^63.  One table for all frequencies 1 .. 2^16, built (and checked against `/`) on first use.
+struct Rcp {
+    uint64_t m;
+    uint32_t sh;        // q = mulhi64(x, m) >> sh   (sh = s - 1; freq == 1: m = 0 marks "q = x")
+};
+const Rcp *rcp_table()
+{
+    static const std::vector<Rcp> table = [] {
+        std::vector<Rcp> t((size_t)(1u << kPrec) + 1);
+        t[0] = {0, 0};
+        t[1] = {0, 0};
+        for (uint32_t d = 2; d <= (1u << kPrec); ++d) {
+            uint32_t s = 0;
+            while ((1u << s) < d) ++s;
+            const unsigned __int128 num = (unsigned __int128)1 << (63 + s);
+            const uint64_t m = (uint64_t)((num + d - 1) / d);
+            t[d] = {m, s - 1};
+            // spot checks on both sides of multiples of d, at the top of the range and at the renormalisation bound
+            const uint64_t top = (((uint64_t)kLower >> kPrec) << 32) * d - 1;
+            const uint64_t probes[] = {0, 1, d - 1, d, d + 1, (uint64_t)d * d - 1, (uint64_t)d * d, top, top - d, top / 2 + 1, 0x7FFFFFFFFFFFFFFFull,
+                                       0x7FFFFFFFFFFFFFFFull / d * d - 1, 0x7FFFFFFFFFFFFFFFull / d * d, 0x123456789ABCDEFull};
+            for (uint64_t x : probes) {
+                const uint64_t q = (uint64_t)(((unsigned __int128)x * m) >> 64) >> (s - 1);
+                if (q != x / d) {
+                    fprintf(stderr, "rans_host: reciprocal table wrong for d=%u x=%llu\n", d, (unsigned long long)x);
+                    abort();
+                }
+            }
+        }
+        return t;
+    }();
+    return table.data();
+}
+
 // Encode events last-to-first; words are emitted back-to-front into a scratch vector.
 long flush_events(std::vector<Event> &ev, uint8_t *out, size_t cap)
 {
+    const Rcp *rcp = rcp_table();
     std::vector<uint32_t> words(ev.size() + 2);
     size_t pos = words.size();
     uint64_t x = kLower;
@@ -99,7 +138,9 @@ long flush_events(std::vector<Event> &ev, uint8_t *out, size_t cap)
                 words[--pos] = (uint32_t)x;
                 x >>= 32;
             }
-            x = ((x / e.freq) << kPrec) + (x % e.freq) + e.start;
+            const Rcp r = rcp[e.freq];
+            const uint64_t q = r.m ? (uint64_t)(((unsigned __int128)x * r.m) >> 64) >> r.sh : x;
+            x = (q << kPrec) + (x - q * e.freq) + e.start;
         } else {
             const uint64_t limit = ((kLower >> 16) << 32) * (uint64_t)(1u << (16 - kEscBits));
             if (x >= limit) {

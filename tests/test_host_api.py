@@ -737,3 +737,38 @@ def test_engine_switches_follow_the_runtime_configuration(monkeypatch):
     monkeypatch.setattr(StemEngine, "use_wg3", False)             # pinned on the class
     with config.override(engine_wgrad_f16x3=True):
         assert StemEngine.use_wg3 is False
+
+
+def test_rans_encoder_divides_like_the_oracle():
+    """The host encoder replaces `x / freq` on its serial path by a multiplication with a tabulated reciprocal (csrc/rans_host.cpp:
+    exact for every state below 2^63).  Random tables -- including frequencies of 1 and of almost 2^16 next to each other --, ragged
+    lengths, escapes: the bytes equal those of the oracle's encoder, which divides (oracle/stem_oracle.c), and decode back."""
+    import sys
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import stem_oracle as orc
+    rng = np.random.default_rng(11)
+    for trial in range(40):
+        ncdf, stride = int(rng.integers(1, 6)), int(rng.integers(4, 48))
+        cdfs = np.zeros((ncdf, stride), dtype=np.int32)
+        sizes = np.zeros(ncdf, dtype=np.int32)
+        offsets = rng.integers(-5, 3, ncdf).astype(np.int32)
+        for c in range(ncdf):
+            ln = int(rng.integers(3, stride + 1))
+            sizes[c] = ln
+            if trial % 3 == 0:
+                w = np.ones(ln - 1)
+                w[int(rng.integers(0, ln - 1))] = 1e9
+            else:
+                w = rng.random(ln - 1) ** int(rng.integers(1, 6)) + 1e-12
+            f = np.maximum(1, np.floor(w / w.sum() * (65536 - (ln - 1)))).astype(np.int64)
+            f[np.argmax(f)] += 65536 - f.sum()
+            cdfs[c, 1:ln] = np.cumsum(f)
+        n = int(rng.integers(1, 3000))
+        idx = rng.integers(0, ncdf, n).astype(np.int32)
+        sym = np.array([int(rng.integers(-3, sizes[i] + 2)) + int(offsets[i]) for i in idx], dtype=np.int32)
+        if trial % 5 == 0:
+            sym[rng.integers(0, n, 3)] = rng.integers(-70000, 70000, 3)
+        ours = em.RansEncoder().encode_with_indexes(sym, idx, cdfs, sizes, offsets)
+        assert ours == orc.rans_encode(sym, idx, cdfs, sizes, offsets), trial
+        np.testing.assert_array_equal(np.asarray(em.RansDecoder().decode_with_indexes(ours, idx, cdfs, sizes, offsets)), sym)
