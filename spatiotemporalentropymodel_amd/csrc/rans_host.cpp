@@ -159,11 +159,45 @@ long flush_events(std::vector<Event> &ev, uint8_t *out, size_t cap)
     return (long)nbytes;
 }
 
+// Symbol search of the decoder: lut[row][cum >> kLutShift] = the symbol whose interval holds the bucket's first value; from there a
+// short walk forward finds the symbol of `cum` (a binary search over up to 3133 entries mispredicts a dozen branches per symbol, and
+// the decoder's symbols sit on the dependent path of the raster-order loop: csrc/ar_persistent.hip).  Built per decoder object once it
+// has seen kLutAfter symbols with the same tables; a row that is not a strictly increasing 0 .. 2^16 sequence keeps the binary search.
+constexpr int kLutShift = 6, kLutBuckets = 1 << (kPrec - kLutShift);
+constexpr size_t kLutAfter = 2048;
+
 struct Decoder {
     std::vector<uint32_t> words;
     size_t pos = 0;
     uint64_t x = 0;
     bool ready = false;
+    std::vector<uint16_t> lut;
+    std::vector<uint8_t> lut_row_ok;
+    const int32_t *lut_cdfs = nullptr, *lut_sizes = nullptr;
+    int lut_ncdf = 0, lut_stride = 0;
+    size_t seen = 0;
+
+    void build_lut(const Tables &t)
+    {
+        lut.assign((size_t)t.ncdf * kLutBuckets, 0);
+        lut_row_ok.assign((size_t)t.ncdf, 0);
+        for (int ci = 0; ci < t.ncdf; ++ci) {
+            const int32_t len = t.sizes[ci];
+            if (len < 2 || len > t.stride || len > 65535) continue;
+            const int32_t *cdf = t.cdfs + (size_t)ci * t.stride;
+            bool ok = cdf[0] == 0 && cdf[len - 1] == (1 << kPrec);
+            for (int s = 1; ok && s < len; ++s) ok = cdf[s] > cdf[s - 1];
+            if (!ok) continue;
+            int s = 0;
+            for (int b = 0; b < kLutBuckets; ++b) {
+                const uint32_t first = (uint32_t)b << kLutShift;
+                while ((uint32_t)cdf[s + 1] <= first) ++s;          // cdf[len - 1] = 2^16 > first: s stays below len - 1
+                lut[(size_t)ci * kLutBuckets + b] = (uint16_t)s;
+            }
+            lut_row_ok[(size_t)ci] = 1;
+        }
+        lut_cdfs = t.cdfs; lut_sizes = t.sizes; lut_ncdf = t.ncdf; lut_stride = t.stride;
+    }
 
     inline bool refill()
     {
@@ -189,6 +223,8 @@ int set_stream(Decoder &d, const uint8_t *stream, size_t nbytes)
     d.x = (uint64_t)d.words[0] | ((uint64_t)d.words[1] << 32);
     d.pos = 2;
     d.ready = true;
+    d.lut_cdfs = nullptr;           // a new stream may come with new tables behind the same pointers
+    d.seen = 0;
     return 0;
 }
 
@@ -196,6 +232,10 @@ int decode(Decoder &d, const int32_t *indexes, size_t n, const Tables &t, int32_
 {
     if (!d.ready) return fail(-1, "rans decode: set_stream was not called");
     if (!t.ok() || (n && (!indexes || !out))) return fail(-1, "rans decode: null table or input");
+    const bool same = d.lut_cdfs == t.cdfs && d.lut_sizes == t.sizes && d.lut_ncdf == t.ncdf && d.lut_stride == t.stride;
+    d.seen += n;
+    if (!same && d.seen > kLutAfter) d.build_lut(t);
+    const bool fast = d.lut_cdfs == t.cdfs && d.lut_sizes == t.sizes && d.lut_ncdf == t.ncdf && d.lut_stride == t.stride;
     for (size_t i = 0; i < n; ++i) {
         const int32_t ci = indexes[i];
         if (ci < 0 || ci >= t.ncdf) return fail(-1, "rans decode: index %d out of range at %zu", ci, i);
@@ -204,13 +244,19 @@ int decode(Decoder &d, const int32_t *indexes, size_t n, const Tables &t, int32_
         const int32_t *cdf = t.cdfs + (size_t)ci * t.stride;
         const uint32_t cum = (uint32_t)(d.x & ((1u << kPrec) - 1));
         // largest s with cdf[s] <= cum (cdf is strictly increasing, cdf[0] = 0, cdf[len-1] = 2^16)
-        int lo = 0, hi = len - 1;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if ((uint32_t)cdf[mid] <= cum)
-                lo = mid;
-            else
-                hi = mid;
+        int lo = 0;
+        if (fast && d.lut_row_ok[(size_t)ci]) {
+            lo = d.lut[(size_t)ci * kLutBuckets + (cum >> kLutShift)];
+            while ((uint32_t)cdf[lo + 1] <= cum) ++lo;               // checked at build time: ends below len - 1
+        } else {
+            int hi = len - 1;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if ((uint32_t)cdf[mid] <= cum)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
         }
         const uint32_t start = (uint32_t)cdf[lo], freq = (uint32_t)(cdf[lo + 1] - cdf[lo]);
         d.x = (uint64_t)freq * (d.x >> kPrec) + cum - start;

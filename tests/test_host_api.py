@@ -772,3 +772,38 @@ def test_rans_encoder_divides_like_the_oracle():
         ours = em.RansEncoder().encode_with_indexes(sym, idx, cdfs, sizes, offsets)
         assert ours == orc.rans_encode(sym, idx, cdfs, sizes, offsets), trial
         np.testing.assert_array_equal(np.asarray(em.RansDecoder().decode_with_indexes(ours, idx, cdfs, sizes, offsets)), sym)
+
+
+def test_rans_decoder_lookup_search_equals_binary_search():
+    """The host decoder finds a symbol through a per-row lookup table + a short walk once it has seen 2048 symbols of a stream
+    (csrc/rans_host.cpp), with a binary search before that and for rows that are not strictly increasing 0 .. 2^16 sequences.  Long
+    random streams (the switch happens in the middle of a stream decoded in pieces of 192 symbols, as the raster-order loop does),
+    narrow and wide rows, escapes: the symbols equal the encoder's input and the oracle's decoder output."""
+    import sys
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import stem_oracle as orc
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        ncdf, stride = int(rng.integers(2, 9)), int(rng.choice([8, 64, 700, 3133]))
+        cdfs = np.zeros((ncdf, stride), dtype=np.int32)
+        sizes = np.zeros(ncdf, dtype=np.int32)
+        offsets = rng.integers(-40, 3, ncdf).astype(np.int32)
+        for c in range(ncdf):
+            ln = int(rng.integers(3, stride + 1))
+            sizes[c] = ln
+            w = np.exp(-0.5 * ((np.arange(ln - 1) - (ln - 1) / 2) / max(1.0, (ln - 1) / rng.uniform(3, 30))) ** 2) + 1e-9
+            f = np.maximum(1, np.floor(w / w.sum() * (65536 - (ln - 1)))).astype(np.int64)
+            f[np.argmax(f)] += 65536 - f.sum()
+            cdfs[c, 1:ln] = np.cumsum(f)
+        n = 192 * int(rng.integers(20, 60))
+        idx = rng.integers(0, ncdf, n).astype(np.int32)
+        sym = np.array([int(rng.integers(-2, sizes[i])) + int(offsets[i]) for i in idx], dtype=np.int32)
+        stream = em.RansEncoder().encode_with_indexes(sym, idx, cdfs, sizes, offsets)
+        np.testing.assert_array_equal(np.asarray(orc.rans_decode(stream, idx, cdfs, sizes, offsets)), sym)
+        np.testing.assert_array_equal(em.RansDecoder().decode_with_indexes_np(stream, idx, cdfs, sizes, offsets), sym)
+        dec = em.RansDecoder()
+        dec.set_stream(stream)
+        t = em._as_tables(cdfs, sizes, offsets)
+        got = np.concatenate([np.asarray(dec.decode_stream(idx[i:i + 192], t)) for i in range(0, n, 192)])
+        np.testing.assert_array_equal(got, sym)
