@@ -301,6 +301,15 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
         for (int c = tid; c < M; c += NT) {
             long spins = 0;
             long long sv, mv;
+            for (;;) {                                        // the mean first: it has been there since EPM.4, the symbol is what takes time
+                mv = __hip_atomic_load(gpw + M + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((int)(mv >> 32) == pp + 1) break;
+                if (give_up(spins)) {
+                    dead = true;
+                    return;
+                }
+            }
+            spins = 0;
             for (;;) {
                 sv = __hip_atomic_load(symw + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if ((int)(sv >> 32) == pp + 1) break;
@@ -311,15 +320,6 @@ __global__ __launch_bounds__(NT, 1) void ar_decode_persistent_kernel(const ArpAr
                     return;
                 }
                 __builtin_amdgcn_s_sleep(1);
-            }
-            spins = 0;
-            for (;;) {                                        // the mean: complete long ago (its index has been to the host and back)
-                mv = __hip_atomic_load(gpw + M + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((int)(mv >> 32) == pp + 1) break;
-                if (give_up(spins)) {
-                    dead = true;
-                    return;
-                }
             }
             const float y = (float)(int)sv + __builtin_bit_cast(float, (int)mv);
             st_agent(pix + c, y);
