@@ -265,6 +265,9 @@ int stem_eb_forward(const float *z, int ldz, const float *noise, const float *pa
 /* backward: dlik -> dz (+= dzhat_in if non-NULL) and dpack[C][58].                                */
 int stem_eb_backward(const float *z_hat, const float *pack, const float *dlik, const float *dzhat_in,
                      float *dz, float *dpack, int B, int H, int W, int C, float bound, void *stream);
+/* ... also leaving the scale record of dz (16 + C floats; NULL: none) for the split in front of the hyper encoder's backward */
+int stem_eb_backward_rec(const float *z_hat, const float *pack, const float *dlik, const float *dzhat_in,
+                         float *dz, float *dpack, int B, int H, int W, int C, float bound, float *dz_rec, void *stream);
 /* EntropyBottleneck.loss (entropy_models.py:383-386): loss[1], dquantiles[C][3]                   */
 int stem_eb_aux_loss(const float *quantiles, const float *pack, const float *target3, float *loss,
                      float *dquantiles, int C, void *stream);
@@ -318,6 +321,11 @@ int stem_rate_partials(size_t n);
 int stem_eb_forward_train(const float *z, int ldz, const float *pack, const float *noise, uint64_t seed, uint64_t offset,
                           const long long *epoch_dev, uint64_t epoch_stride, float *z_hat, float *lik, float *dlik,
                           double *partials, size_t npix, int C, float bound, float coef, void *stream);
+/* ... also leaving the scale record of z_hat (16 + ceil(npix * C / 256) floats; NULL: none) for the split in front of the hyper
+ * decoder's fp16 layers: no separate maximum pass over z_hat */
+int stem_eb_forward_train_rec(const float *z, int ldz, const float *pack, const float *noise, uint64_t seed, uint64_t offset,
+                              const long long *epoch_dev, uint64_t epoch_stride, float *z_hat, float *lik, float *dlik,
+                              double *partials, size_t npix, int C, float bound, float coef, float *zhat_rec, void *stream);
 int stem_gc_forward_train(const float *y, const float *scales, const float *means, int ldsm, const float *noise,
                           uint64_t seed, uint64_t offset, const long long *epoch_dev, uint64_t epoch_stride, float *out,
                           float *lik, float *dlik, double *partials, size_t npix, int C, float scale_bound, float lik_bound,

@@ -65,6 +65,7 @@ _HIP_SIG = {
     "stem_eb_unpack_grads": [vp, vp, ci, ci, vp],
     "stem_eb_forward": [vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cf, vp],
     "stem_eb_backward": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp],
+    "stem_eb_backward_rec": [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp],
     "stem_eb_aux_loss": [vp, vp, vp, vp, vp, ci, vp],
     "stem_gc_forward": [vp, vp, vp, vp, ci, vp, vp, sz, ci, ci, cf, cf, vp],
     "stem_gc_backward": [vp, vp, vp, ci, vp, vp, vp, ci, vp, sz, ci, cf, cf, vp, vp],
@@ -79,6 +80,7 @@ _HIP_SIG = {
     "stem_prior_prologue": [vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, u64, u64, vp, u64, sz, ci, ci, ci, vp, vp, vp],
     "stem_rate_partials": [sz],
     "stem_eb_forward_train": [vp, ci, vp, vp, u64, u64, vp, u64, vp, vp, vp, vp, sz, ci, cf, cf, vp],
+    "stem_eb_forward_train_rec": [vp, ci, vp, vp, u64, u64, vp, u64, vp, vp, vp, vp, sz, ci, cf, cf, vp, vp],
     "stem_gc_forward_train": [vp, vp, vp, ci, vp, u64, u64, vp, u64, vp, vp, vp, vp, sz, ci, cf, cf, cf, vp],
     "stem_gc_forward_backward_train": [vp, vp, vp, ci, vp, u64, u64, vp, u64, vp, vp, vp, vp, sz, ci, cf, cf, cf, vp, vp, ci, vp, vp],
     "stem_em_loss_finalize": [vp, ci, vp, ci, C.c_double, vp, vp],

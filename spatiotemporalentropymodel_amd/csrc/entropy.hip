@@ -216,9 +216,10 @@ __global__ __launch_bounds__(256) void eb_forward_cm_kernel(const float *z, int 
 constexpr int EB_BWD_NT = 256;
 __global__ __launch_bounds__(EB_BWD_NT) void eb_backward_kernel(const float *zhat, const float *pack, const float *dlik,
                                                                 const float *dzin, float *dz, float *dpack, size_t npix, int C,
-                                                                float bound)
+                                                                float bound, float *q)
 {
     __shared__ float red[EB_BWD_NT / 64][NP];
+    float dzmax = 0.f;
     const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *p = pack + (size_t)c * NP;
     __shared__ float prep[NP];
@@ -244,8 +245,13 @@ __global__ __launch_bounds__(EB_BWD_NT) void eb_backward_kernel(const float *zha
         const float glo = -gd * sl * (1.f - sl) * sg;
         float gv = eb_logits_bwd(p, e, v + 0.5f, pre_up, in_up, gup, dp);
         gv += eb_logits_bwd(p, e, v - 0.5f, pre_lo, in_lo, glo, dp);
-        if (dz) dz[i] = gv + (dzin ? dzin[i] : 0.f);
+        if (dz) {
+            const float o = gv + (dzin ? dzin[i] : 0.f);
+            dz[i] = o;
+            dzmax = fmaxf(dzmax, fabsf(o));
+        }
     }
+    if (q) record_block_max(q, dzmax);         // max |dz| of this channel: the split in front of the hyper encoder's backward needs no maximum pass
     if (dpack) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -491,14 +497,20 @@ STEM_EXPORT int stem_eb_forward(const float *z, int ldz, const float *noise, con
     return 0;
 }
 
+STEM_EXPORT int stem_eb_backward_rec(const float *z_hat, const float *pack, const float *dlik, const float *dzhat_in,
+                                     float *dz, float *dpack, int B, int H, int W, int C, float bound, float *dz_rec, void *stream)
+{
+    STEM_CHECK_ARG(z_hat && pack && dlik && (dz || !dz_rec), "stem_eb_backward: null pointer");
+    hipLaunchKernelGGL(eb_backward_kernel, dim3(C), dim3(EB_BWD_NT), 0, (hipStream_t)stream, z_hat, pack, dlik, dzhat_in, dz, dpack,
+                       (size_t)B * H * W, C, bound, dz_rec);
+    STEM_LAUNCH_CHECK("eb_backward");
+    return 0;
+}
+
 STEM_EXPORT int stem_eb_backward(const float *z_hat, const float *pack, const float *dlik, const float *dzhat_in,
                                  float *dz, float *dpack, int B, int H, int W, int C, float bound, void *stream)
 {
-    STEM_CHECK_ARG(z_hat && pack && dlik, "stem_eb_backward: null pointer");
-    hipLaunchKernelGGL(eb_backward_kernel, dim3(C), dim3(EB_BWD_NT), 0, (hipStream_t)stream, z_hat, pack, dlik, dzhat_in, dz, dpack,
-                       (size_t)B * H * W, C, bound);
-    STEM_LAUNCH_CHECK("eb_backward");
-    return 0;
+    return stem_eb_backward_rec(z_hat, pack, dlik, dzhat_in, dz, dpack, B, H, W, C, bound, nullptr, stream);
 }
 
 STEM_EXPORT int stem_eb_aux_loss(const float *quantiles, const float *pack, const float *target3, float *loss,
@@ -720,10 +732,11 @@ __device__ __forceinline__ void block_log2_partial(double s, double *part)
 // EntropyBottleneck.forward in training mode (+noise) with its rate term and d rate / d likelihood
 __global__ __launch_bounds__(256) void eb_forward_train_kernel(const float *z, int ldz, NoiseSrc nz, const float *pack, float *zhat,
                                                                float *lik, float *dlik, double *part, size_t npix, int C,
-                                                               float bound, float coef)
+                                                               float bound, float coef, float *q)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     double lg = 0.0;
+    float zm = 0.f;
     if (i < npix * C) {
         const size_t pix = i / C;
         const int c = (int)(i - pix * C);
@@ -738,6 +751,7 @@ __global__ __launch_bounds__(256) void eb_forward_train_kernel(const float *z, i
             v += r[i & 3];
         }
         zhat[i] = v;
+        zm = fmaxf(zm, fabsf(v));
         const float lo = eb_logits<false>(e, v - 0.5f, nullptr, nullptr);
         const float up = eb_logits<false>(e, v + 0.5f, nullptr, nullptr);
         const float s = lo + up;
@@ -748,6 +762,7 @@ __global__ __launch_bounds__(256) void eb_forward_train_kernel(const float *z, i
         lg = (double)log2f(l);
     }
     block_log2_partial(lg, part);
+    if (q) record_block_max(q, zm);
 }
 
 // The same with one workgroup per CHANNEL (threads over pixels): the 48 softplus / tanh values of a channel's parameters
@@ -756,10 +771,11 @@ __global__ __launch_bounds__(256) void eb_forward_train_kernel(const float *z, i
 // channel are strided, which only matters for large tensors.  Same arithmetic per element, same Philox counters.
 __global__ __launch_bounds__(256) void eb_forward_train_cm_kernel(const float *z, int ldz, NoiseSrc nz, const float *pack, float *zhat,
                                                                   float *lik, float *dlik, double *part, size_t npix, int C,
-                                                                  float bound, float coef)
+                                                                  float bound, float coef, float *q)
 {
     __shared__ float prep[NP];
     double lg = 0.0;
+    float zm = 0.f;
     for (int c = blockIdx.x; c < C; c += gridDim.x) {
         EbPrep e;
         eb_prepare_shared(pack + (size_t)c * NP, prep, e);
@@ -774,6 +790,7 @@ __global__ __launch_bounds__(256) void eb_forward_train_cm_kernel(const float *z
                 v += r[i & 3];
             }
             zhat[i] = v;
+            zm = fmaxf(zm, fabsf(v));
             const float lo = eb_logits<false>(e, v - 0.5f, nullptr, nullptr);
             const float up = eb_logits<false>(e, v + 0.5f, nullptr, nullptr);
             const float s = lo + up;
@@ -785,6 +802,7 @@ __global__ __launch_bounds__(256) void eb_forward_train_cm_kernel(const float *z
         }
     }
     block_log2_partial(lg, part);
+    if (q) record_block_max(q, zm);
 }
 
 // GaussianConditional.forward in training mode (+noise; means are ignored by the noise quantiser, entropy_models.py:128-135)
@@ -921,20 +939,28 @@ STEM_EXPORT int stem_prior_prologue(const float *y_cur, int ldc, const float *y_
 
 STEM_EXPORT int stem_rate_partials(size_t n) { return (int)nblk(n); }
 
-STEM_EXPORT int stem_eb_forward_train(const float *z, int ldz, const float *pack, const float *noise, uint64_t seed, uint64_t offset,
-                                      const long long *epoch_dev, uint64_t epoch_stride, float *z_hat, float *lik, float *dlik,
-                                      double *partials, size_t npix, int C, float bound, float coef, void *stream)
+STEM_EXPORT int stem_eb_forward_train_rec(const float *z, int ldz, const float *pack, const float *noise, uint64_t seed, uint64_t offset,
+                                          const long long *epoch_dev, uint64_t epoch_stride, float *z_hat, float *lik, float *dlik,
+                                          double *partials, size_t npix, int C, float bound, float coef, float *zhat_rec, void *stream)
 {
     STEM_CHECK_ARG(z && pack && z_hat && lik && dlik && partials, "stem_eb_forward_train: null pointer");
     if (npix == 0) return 0;
     if (npix <= 4096)        // few pixels per channel (hyper-latents): one workgroup per channel shares the prepared parameters
         hipLaunchKernelGGL(eb_forward_train_cm_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, z, ldz,
-                           make_noise(noise, seed, offset, epoch_dev, epoch_stride), pack, z_hat, lik, dlik, partials, npix, C, bound, coef);
+                           make_noise(noise, seed, offset, epoch_dev, epoch_stride), pack, z_hat, lik, dlik, partials, npix, C, bound, coef, zhat_rec);
     else
         hipLaunchKernelGGL(eb_forward_train_kernel, dim3(nblk(npix * C)), dim3(256), 0, (hipStream_t)stream, z, ldz,
-                           make_noise(noise, seed, offset, epoch_dev, epoch_stride), pack, z_hat, lik, dlik, partials, npix, C, bound, coef);
+                           make_noise(noise, seed, offset, epoch_dev, epoch_stride), pack, z_hat, lik, dlik, partials, npix, C, bound, coef, zhat_rec);
     STEM_LAUNCH_CHECK("eb_forward_train");
     return 0;
+}
+
+STEM_EXPORT int stem_eb_forward_train(const float *z, int ldz, const float *pack, const float *noise, uint64_t seed, uint64_t offset,
+                                      const long long *epoch_dev, uint64_t epoch_stride, float *z_hat, float *lik, float *dlik,
+                                      double *partials, size_t npix, int C, float bound, float coef, void *stream)
+{
+    return stem_eb_forward_train_rec(z, ldz, pack, noise, seed, offset, epoch_dev, epoch_stride, z_hat, lik, dlik, partials, npix, C, bound, coef,
+                                     nullptr, stream);
 }
 
 STEM_EXPORT int stem_gc_forward_train(const float *y, const float *scales, const float *means, int ldsm, const float *noise,

@@ -789,14 +789,18 @@ class StemEngine:
                 z = self.HE[2].fwd(he2)
             pack = F.eb_pack(eb._tensors14())
             if fused:
-                z_hat, lik_z, k["dlik_z"], part_z = F.eb_forward_train(z, pack, rate_coef[0], bound=eb._lik_bound, **eb._noise_slot(z))
+                if self.HD[0].fx3t and self.use_records:         # the kernel leaves max |z_hat| for the split below: no maximum pass
+                    z_hat, lik_z, k["dlik_z"], part_z, rec["z_hat"] = F.eb_forward_train(z, pack, rate_coef[0], bound=eb._lik_bound, record=True,
+                                                                                         **eb._noise_slot(z))
+                else:
+                    z_hat, lik_z, k["dlik_z"], part_z = F.eb_forward_train(z, pack, rate_coef[0], bound=eb._lik_bound, **eb._noise_slot(z))
             elif training:
                 z_hat, lik_z = F.eb_forward(z, pack, noise=eb._noise_like(z))
             else:
                 z_hat, lik_z = F.eb_forward(z, pack, medians=eb._medians_vec())
             # hyper decoder; its last conv writes the `hp` slice of the EPM input
             if self.HD[0].fx3t:          # the transposed layers on the fp16 kernel: planes in, planes out, no maximum / split passes
-                pl["z_hat"] = split(z_hat)
+                pl["z_hat"] = split(z_hat, src_q=_qp(rec.get("z_hat")))
                 hd0, pl["hd0"] = self.HD[0].fwd6t(pl["z_hat"], F.ACT_LRELU, planes=True)
                 hd2, pl["hd2"] = self.HD[1].fwd6t(pl["hd0"], F.ACT_LRELU, planes=True)
                 self.HD[2].fwd6(pl["hd2"], out=epm_in[:, o_hp:o_hp + P])
@@ -1013,12 +1017,16 @@ class StemEngine:
         dz_hat = self.HD[0].dgrad6s(dp)[0] if self.HD[0].fx3s else self.HD[0].dgrad(d, k["z_hat"].shape)
         # entropy bottleneck: d/dz = dz_hat + likelihood path; 58 parameter gradients per channel
         eb = m.entropy_bottleneck
-        dz, dpack = F.eb_backward(k["z_hat"], k["pack"], dlik_z, dzhat_in=dz_hat, bound=eb._lik_bound)
+        qdz = None
+        if self.HE[2].fx3t and self.use_records:
+            dz, dpack, qdz = F.eb_backward(k["z_hat"], k["pack"], dlik_z, dzhat_in=dz_hat, bound=eb._lik_bound, record=True)
+        else:
+            dz, dpack = F.eb_backward(k["z_hat"], k["pack"], dlik_z, dzhat_in=dz_hat, bound=eb._lik_bound)
         F.eb_unpack_grads(dpack, [_grad_of(p) for p in eb._tensors14()], accumulate=self.accumulate_grads)
         self._group_ready(self.HD, eb._tensors14())
         # hyper encoder
         if self.HE[2].fx3t:               # transposed faces (input gradients of the strided convolutions) and weight gradients on the fp16 kernels
-            dzp = F.F16Planes.split(dz)
+            dzp = F.F16Planes.split(dz, src_q=_qp(qdz))
             self.HE[2].wgrad_t(pl["he2"], dzp, dz)
             d, dp = self.HE[2].dgrad6t(dzp, xact=k["he2"], planes=True)
             self.HE[1].wgrad_t(pl["he0"], dp, d)

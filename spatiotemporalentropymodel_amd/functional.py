@@ -1128,10 +1128,16 @@ def eb_forward(z, pack, medians=None, noise=None, bound=1e-9):
     return z_hat, lik
 
 
-def eb_backward(z_hat, pack, dlik, dzhat_in=None, bound=1e-9):
+def eb_backward(z_hat, pack, dlik, dzhat_in=None, bound=1e-9, record=False):
+    """record=True: -> (dz, dpack, q) with q the scale record of dz (one slot per channel) for F16Planes.split(dz, src_q=)"""
     B, Cc, H, W = z_hat.shape
     dz = empty_nhwc(B, Cc, H, W, z_hat.device)
     dpack = torch.empty_like(pack)
+    if record:
+        q = torch.empty(16 + Cc, device=z_hat.device, dtype=torch.float32)
+        _chk(_lib.hip().stem_eb_backward_rec(z_hat.data_ptr(), pack.data_ptr(), dlik.data_ptr(), _ptr(dzhat_in), dz.data_ptr(),
+                                             dpack.data_ptr(), B, H, W, Cc, bound, q.data_ptr(), _stream()))
+        return dz, dpack, q
     _chk(_lib.hip().stem_eb_backward(z_hat.data_ptr(), pack.data_ptr(), dlik.data_ptr(), _ptr(dzhat_in), dz.data_ptr(),
                                      dpack.data_ptr(), B, H, W, Cc, bound, _stream()))
     return dz, dpack
@@ -1330,14 +1336,21 @@ def rate_partials(n):
     return int(_lib.hip().stem_rate_partials(n))
 
 
-def eb_forward_train(z, pack, coef, noise=None, seed=0, offset=0, epoch=None, bound=1e-9):
-    """-> (z_hat, lik, dlik, partials): training-mode EntropyBottleneck forward + dlik = coef / lik + log2 partial sums"""
+def eb_forward_train(z, pack, coef, noise=None, seed=0, offset=0, epoch=None, bound=1e-9, record=False):
+    """-> (z_hat, lik, dlik, partials): training-mode EntropyBottleneck forward + dlik = coef / lik + log2 partial sums;
+    record=True: -> (..., partials, q) with q the scale record of z_hat for F16Planes.split(z_hat, src_q=)"""
     B, Cc, H, W = z.shape
     z_hat, lik, dlik = (empty_nhwc(B, Cc, H, W, z.device) for _ in range(3))
     part = torch.empty(rate_partials(z.numel()), dtype=torch.float64, device=z.device)
     if noise is not None:
         assert nhwc_ld(noise) == Cc
     nptr, sd, off, ep, stride = _noise_args(noise, seed, offset, epoch)
+    if record:
+        q = qrec_for(z.numel(), z.device)
+        _chk(_lib.hip().stem_eb_forward_train_rec(z.data_ptr(), nhwc_ld(z), pack.data_ptr(), nptr, sd, off, ep, stride, z_hat.data_ptr(),
+                                                  lik.data_ptr(), dlik.data_ptr(), part.data_ptr(), B * H * W, Cc, bound, coef, q.data_ptr(),
+                                                  _stream()))
+        return z_hat, lik, dlik, part, q
     _chk(_lib.hip().stem_eb_forward_train(z.data_ptr(), nhwc_ld(z), pack.data_ptr(), nptr, sd, off, ep, stride, z_hat.data_ptr(),
                                           lik.data_ptr(), dlik.data_ptr(), part.data_ptr(), B * H * W, Cc, bound, coef, _stream()))
     return z_hat, lik, dlik, part
