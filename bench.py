@@ -458,7 +458,7 @@ def main():
                     "roi = configs[4], the variable-rate GOP iteration")
     ap.add_argument("--roi-batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 10; 2 for --config roi)")
-    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 2 for --config roi: as the first GPU program on a fresh box one warm-up iteration left 0.3 s per iteration of first-use cost in the timed ones)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 6 for --config roi: the first process that runs the variable-rate models on a box needs about that many iterations before an iteration takes what it takes in every later process -- 1.40 s after two, 0.95-1.0 s after six)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latents", default="prefetch", choices=["first", "prefetch"], help="prefetch (default): getY of frame t + 1 runs on a second "
                     "stream while P-frame step t runs (trainer.LatentPrefetcher); first: getY of all 7 frames before the P-frame steps")
@@ -479,7 +479,7 @@ def main():
     if args.steps is None:
         args.steps = 2 if args.config == "roi" else 10
     if args.warmup is None:
-        args.warmup = 2 if args.config == "roi" else 3
+        args.warmup = 6 if args.config == "roi" else 3
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     # a rank of a multi-GPU run pins itself to the cores of its GPU's NUMA node before anything touches the GPU (sysfs only)
