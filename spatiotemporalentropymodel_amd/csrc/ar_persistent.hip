@@ -608,7 +608,9 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
         bool lost = false;
         const long long *idxw = reinterpret_cast<const long long *>(pin + 32) + (size_t)(p & 1) * M;
         long long *symw = reinterpret_cast<long long *>(pin + 32 + 2 * P) + (size_t)(p & 1) * M;
-        // all M words carry this position's sequence number (they arrive in any order)
+        // all M words carry this position's sequence number (they arrive in any order).  The first position also waits for the launch
+        // itself: behind whatever the stream still holds, and -- several images at once -- behind another image's kernel that shares
+        // its hardware queue
         for (int c = M - 1; c >= 0;) {
             const long long v = __atomic_load_n(idxw + c, __ATOMIC_ACQUIRE);
             if ((int)(v >> 32) == p + 1) {
@@ -616,7 +618,7 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
                 --c;
                 continue;
             }
-            if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+            if ((++spins & 0xFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(p == 0 ? 120 : 5)) {
                 lost = true;
                 break;
             }
