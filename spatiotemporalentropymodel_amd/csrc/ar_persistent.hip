@@ -84,13 +84,8 @@ constexpr int XA_FLOATS = 2048, XP_FLOATS = 1024, XV_FLOATS = 768;     // stagin
 constexpr int ARP_LDS = (WL_FLOATS + XA_FLOATS + XP_FLOATS + XV_FLOATS) * 4;
 
 __device__ inline float dot4(const f32x4 xv, const f32x4 wv) { return xv[0] * wv[0] + xv[1] * wv[1] + xv[2] * wv[2] + xv[3] * wv[3]; }
-// the values of four tagged words.  A plain struct: hipcc (ROCm 7.2) compiled f32x4{lo[0], lo[2], hi[0], hi[2]} of two 16-byte loads
-// to {lo[0], lo[0], hi[0], hi[0]} (tools/debug/arp_probe.py showed every second column twice)
-struct X4 {
-    float a, b, c, d;
-};
-__device__ inline float dot4(const X4 xv, const f32x4 wv) { return xv.a * wv[0] + xv.b * wv[1] + xv.c * wv[2] + xv.d * wv[3]; }
-__device__ inline float as_f(unsigned u) { return __builtin_bit_cast(float, u); }
+// (a tagged word's value goes through a scalar before it is reinterpreted: hipcc of ROCm 7.2 reads the wrong element when
+// __builtin_bit_cast is applied directly to an element of an ext-vector -- tools/debug/probe/vec_even_elements.hip)
 
 // global -> LDS.  COHERENT: data other workgroups write during the launch (the latent buffer, the vectors handed from product to
 // product) -- `sc1` loads, which are served by the L2 whatever this CU's L1 holds.  Round 3's kernel read them with plain loads after
