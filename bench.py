@@ -525,8 +525,8 @@ def main():
     D.broadcast_parameters(stem)
     D.broadcast_parameters(imodel)
     seed = D.shard_seed(1234, rank)
-    for m in (imodel.gaussian_conditional, stem.entropy_bottleneck, stem.gaussian_conditional):
-        m.noise_seed = seed * 7919 + id(m) % 1000
+    for i, m in enumerate((imodel.gaussian_conditional, stem.entropy_bottleneck, stem.gaussian_conditional)):
+        m.noise_seed = seed * 7919 + 131 * i          # one Philox stream per noise source, the same in every run of this rank
     opt, aux_opt = configure_optimizers(stem, types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3))
     # gradient slices are all-reduced (RCCL, side stream) as backward finishes each module group
     # (also at world size 1 when STEM_DIST_SINGLE=1 created a one-rank RCCL group: same calls, same stream ordering)
