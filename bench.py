@@ -353,6 +353,12 @@ def bench_roi(args):
     torch.cuda.synchronize()
     D.barrier()
     dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    dp_report = None
+    if acc is not None:                              # the replicas' own evidence (see main(): config.data_parallel)
+        torch.cuda.synchronize()
+        same = [D.replicas_identical(o.flat.data) for o in opts]
+        dp_report = {"rccl_nranks": D.dist.get_world_size(), "exchange_route": f"torch.distributed {D.dist.get_backend()} (GopGradAccumulator)",
+                     "replicas_identical": all(ok for ok, _ in same), "replica_checksums_rank0": [f"{c & (2 ** 64 - 1):016x}" for _, c in same]}
     if rank != 0:
         return
     kern_ms = float(np.mean([x.elapsed_time(y) for x, y in probe]))
@@ -370,7 +376,7 @@ def bench_roi(args):
                                "GOP, clip after every frame, one step of 4 Adam optimisers), 4 lambda points (quality 0.30/0.45/0.55/0.70) in one batch",
                    "per_gpu_batch": B, "global_batch": B * world, "frames_per_step": FRAMES * B * world, "parallelism": f"dp{world}",
                    "stride1_convolutions": "fp16 matrix cores, two fp16 planes per operand, 3 products per fp32 product (layers.Conv2dFunction)" if f16_layers else "fp32 MFMA",
-                   "final_loss": float(log[-1][0]["loss"].detach())},
+                   "final_loss": float(log[-1][0]["loss"].detach()), **({"data_parallel": dp_report} if dp_report else {})},
         "roofline": {"bound": "mfma",
                      "kernel": ("conv_f16x3_kernel<128> with activation epilogue" if f16_layers else "igemm") +
                                " = conv3x3 192->160 at 256x256 (stem_roi.qmap_feature_ga1.2, forward), B=%d" % B,
@@ -641,6 +647,34 @@ def main():
                     imodel.getY(f)
         torch.cuda.synchronize()
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in probe])) if probe else float("nan")
+    # ---- what a data-parallel run says about ITSELF (every rank takes part; outside the timed region) -------------------------------
+    # rccl_nranks: the rank count the communicator that carried the gradients reports (ncclCommCount of libstem_dp's own
+    # communicator; the torch group's size on the other routes) -- n_gpus alone is only WORLD_SIZE read back from the environment;
+    # replicas_identical: MIN == MAX over ranks of a 64-bit checksum of the parameters' bits after the timed region;
+    # STEM_BENCH_VERIFY=1: one P-frame step through the reducer on every shard against the same step over the global batch on rank 0.
+    dp_report = None
+    if reducer is not None:
+        if fused_step is not None:
+            fused_step.finish()
+        torch.cuda.synchronize()
+        reducer.check()                       # a failed exchange aborts this rank (non-zero exit; the launcher stops the peers)
+        same, csum = D.replicas_identical(opt.flat.data)
+        dp_report = {"rccl_nranks": reducer.rccl_nranks, "exchange_route": reducer.route, "collectives_per_step": None,
+                     "replicas_identical": same, "replica_checksum_rank0": f"{csum & (2 ** 64 - 1):016x}", "loss_vs_single_rank": None}
+        dp_report["collectives_per_step"] = reducer.collectives / max(1, (args.steps + args.warmup) * (FRAMES - 1))
+        if os.environ.get("STEM_BENCH_VERIFY", "0") == "1":
+            from spatiotemporalentropymodel_amd.selfcheck import dp_step_vs_full_batch
+
+            def make_models():
+                torch.manual_seed(1234)
+                return models["mbt2018"](quality=4).to(dev).eval(), SpatioTemporalPriorModel_Res().to(dev)
+
+            v = dp_step_vs_full_batch(make_models, lambda r: synthetic_septuplet(BATCH, SIZE, D.shard_seed(1234, r), dev)[:2], rank, world, dev, SIZE)
+            dp_report["loss_vs_single_rank"] = {"loss_dp_mean_over_ranks": v["loss_dp"], "loss_full_batch_rank0_alone": v["loss_full"],
+                                                "rel_diff": v["loss_rel"], "averaged_gradient_max_rel_diff": v["grad_rel"],
+                                                "global_batch": BATCH * world, "rccl_nranks": v["rccl_nranks"],
+                                                "what": "one P-frame step (stem/trainSTEM.py:194-218) from identical initial weights, "
+                                                        "frames of every rank's seed, closed-form noise sliced per rank"}
     if rank != 0:
         return
     kern0_ms = float(np.mean([a.elapsed_time(b) for a, b in probe0])) if probe0 else float("nan")
@@ -726,9 +760,16 @@ def main():
         "roofline_first_layer": first_line,
         "useful_tflops_per_gpu": USEFUL_FLOP_PER_STEP / (dt / args.steps) / 1e12,
     }
+    if dp_report is not None:
+        res["config"]["data_parallel"] = dp_report
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline()
     _emit(res)
+    if dp_report is not None:
+        lv = dp_report["loss_vs_single_rank"]
+        if not dp_report["replicas_identical"] or dp_report["rccl_nranks"] != world or (lv is not None and not (lv["rel_diff"] < 1e-5 and lv["averaged_gradient_max_rel_diff"] < 1e-4)):
+            print("bench.py: the data-parallel run failed its own check (config.data_parallel)", file=sys.stderr)
+            sys.exit(3)
 
 
 if __name__ == "__main__":

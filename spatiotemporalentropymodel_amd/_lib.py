@@ -262,6 +262,10 @@ def declared_hip_symbols():
 _DP_SIG = {
     "stem_dp_unique_id": [C.c_void_p],
     "stem_dp_create": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int],
+    "stem_dp_prepare": [C.c_void_p, C.c_int],
+    "stem_dp_connect": [C.c_void_p, C.c_void_p, C.c_int, C.c_int],
+    "stem_dp_nranks": [C.c_void_p],
+    "stem_dp_abort": [C.c_void_p, C.c_int, C.c_char_p],
     "stem_dp_submit": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t],
     "stem_dp_fence": [C.c_void_p, C.c_void_p],
     "stem_dp_status": [C.c_void_p],

@@ -20,6 +20,7 @@
 // lane * 4 + 256 t ascending, xor-shuffle reduction, bias, leaky ReLU), compiled without FMA contraction like ar.hip -- the
 // entropy parameters, hence symbols and bytes, are those of the per-position loop and of the encoder.
 #include <chrono>
+#include <mutex>
 #include <vector>
 
 #include "stem_common.h"
@@ -503,7 +504,11 @@ struct ArpState {
     int *pinned = nullptr, *dev = nullptr;
     long long *words = nullptr;
     size_t pinned_ints = 0, nwords = 0;
+    int device = -1;               // the HIP device `dev` / `words` were allocated on
 };
+// start values of the device flags: word 1 = -1 ("no XCD claimed yet"), everything else 0.  Constant: eight host threads copy from it at once
+const int kArpInit[192] = {0, -1};
+std::once_flag g_arp_attr_once;
 thread_local ArpState g_arp;
 thread_local int g_arp_want_xcc = -1;
 
@@ -542,6 +547,19 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
     hipStream_t st = (hipStream_t)stream;
     const int P = 2 * M, N = H * W;
     const size_t need = 32 + 4 * (size_t)P;
+    int device = -1;
+    if (hipGetDevice(&device) != hipSuccess) {
+        stem_set_error("stem_ar_decode_image_persistent: no current device");
+        return -2;
+    }
+    if (g_arp.device != device) {                  // this host thread last decoded on another GPU: its device buffers live there
+        if (g_arp.dev) (void)hipFree(g_arp.dev);
+        if (g_arp.words) (void)hipFree(g_arp.words);
+        g_arp.dev = nullptr;
+        g_arp.words = nullptr;
+        g_arp.nwords = 0;
+        g_arp.device = device;
+    }
     if (g_arp.pinned_ints < need) {
         if (g_arp.pinned) (void)hipHostFree(g_arp.pinned);
         g_arp.pinned = nullptr;
@@ -569,10 +587,7 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
     if (hipMemsetAsync(g_arp.words, 0, nwords * sizeof(long long), st) != hipSuccess) return -2;       // tag 0: nothing written yet
     int *pin = g_arp.pinned;
     memset(pin, 0, need * sizeof(int));            // sequence numbers of the previous image must not match this one's
-    static int init[192];
-    memset(init, 0, sizeof(init));
-    init[1] = -1;
-    if (hipMemcpyAsync(g_arp.dev, init, sizeof(init), hipMemcpyHostToDevice, st) != hipSuccess) return -2;
+    if (hipMemcpyAsync(g_arp.dev, kArpInit, sizeof(kArpInit), hipMemcpyHostToDevice, st) != hipSuccess) return -2;
 
     ArpArgs a;
     memset(&a, 0, sizeof(a));
@@ -585,11 +600,9 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
 #endif
     a.want_xcc = g_arp_want_xcc;
     a.nwg = NWG_DEFAULT;             // the row -> wavefront map is fixed: 32 workgroups x 8 wavefronts (the "arp_workers" selector of round 3 is ignored)
-    static bool attr_done = false;
-    if (!attr_done) {
+    std::call_once(g_arp_attr_once, [] {
         (void)hipFuncSetAttribute((const void *)ar_decode_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ARP_LDS);
-        attr_done = true;
-    }
+    });
     hipLaunchKernelGGL(ar_decode_persistent_kernel, dim3(GRID), dim3(NT), ARP_LDS, st, a);
     if (hipGetLastError() != hipSuccess) {
         stem_set_error("stem_ar_decode_image_persistent: launch failed");
@@ -597,16 +610,19 @@ STEM_EXPORT int stem_ar_decode_image_persistent(const float *w_ctx, int ld_ctx, 
     }
     int rc_out = 0;
     std::vector<int32_t> idx_v((size_t)M), sym_v((size_t)M);
+    // stem_tuning_set("arp_giveup_at", k): the host gives up at position k - 1 exactly as a wait that ran out does (abort word, error
+    // return, a half-written latent buffer behind it) -- the test of the caller's fall-back to the per-position loop; 0 = never
+    const int giveup_at = stem_tuning(STEM_TUNE_ARP_GIVEUP_AT);
     for (int p = 0; p < N; ++p) {
         const auto t0 = std::chrono::steady_clock::now();
         long spins = 0;
-        bool lost = false;
+        bool lost = giveup_at > 0 && p == giveup_at - 1;
         const long long *idxw = reinterpret_cast<const long long *>(pin + 32) + (size_t)(p & 1) * M;
         long long *symw = reinterpret_cast<long long *>(pin + 32 + 2 * P) + (size_t)(p & 1) * M;
         // all M words carry this position's sequence number (they arrive in any order).  The first position also waits for the launch
         // itself: behind whatever the stream still holds, and -- several images at once -- behind another image's kernel that shares
         // its hardware queue
-        for (int c = M - 1; c >= 0;) {
+        for (int c = M - 1; c >= 0 && !lost;) {
             const long long v = __atomic_load_n(idxw + c, __ATOMIC_ACQUIRE);
             if ((int)(v >> 32) == p + 1) {
                 idx_v[(size_t)c] = (int32_t)v;

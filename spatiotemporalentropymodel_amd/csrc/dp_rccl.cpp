@@ -6,6 +6,7 @@
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -39,17 +40,23 @@ struct Task {
 };
 
 struct Dp {
-    ncclComm_t comm = nullptr;
+    std::atomic<ncclComm_t> comm{nullptr};
     hipStream_t cs = nullptr;      // the communicator's stream: collectives and flag writes, nothing that waits
     unsigned *flag = nullptr;      // signal memory: "fences completed"
     unsigned seq = 0;
     int device = 0;
+    int world = 0;
+    bool connected = false;
+    long fault_at = -1;            // STEM_DP_FAULT=<n>: the n-th exchange (0-based) fails in the helper as a refused collective would
+    long exchanges = 0;
     std::thread helper;
     std::mutex mu;
+    std::mutex comm_mu;            // a collective is enqueued, or the communicator aborted / destroyed, by one thread at a time
     std::condition_variable cv;
     std::deque<Task> q;
     std::vector<hipEvent_t> pool;
     std::atomic<int> status{0};
+    std::atomic<int> claimed{0};   // the one thread that fills err[]
     char err[256] = "";
 
     hipEvent_t event()
@@ -66,6 +73,12 @@ struct Dp {
         (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
         return e;
     }
+    void recycle(const hipEvent_t *ev, int n)
+    {
+        std::lock_guard<std::mutex> l(mu);
+        for (int i = 0; i < n; ++i)
+            if (ev[i]) pool.push_back(ev[i]);
+    }
     void push(const Task &t)
     {
         {
@@ -74,10 +87,25 @@ struct Dp {
         }
         cv.notify_one();
     }
-    void note(int rc, const char *what)
+    // First failure wins: the message is complete BEFORE the status becomes visible (readers look at err once status != 0).
+    // Abort-all: this rank's communicator is aborted, so that its own queued collectives end and every later submit / fence of this
+    // rank returns the status -- the rank leaves with a non-zero exit code and its launcher stops the peers (bench.launch_ranks,
+    // torch.distributed.run), which would otherwise sit inside a collective this rank never joins.
+    void fail_all(int rc, const char *what)
     {
         int zero = 0;
-        if (status.compare_exchange_strong(zero, rc)) snprintf(err, sizeof(err), "%s", what);
+        if (!claimed.compare_exchange_strong(zero, 1)) return;
+        snprintf(err, sizeof(err), "%s", what);
+        status.store(rc, std::memory_order_release);
+        std::lock_guard<std::mutex> l(comm_mu);
+        ncclComm_t c = comm.exchange(nullptr);
+        if (c) (void)ncclCommAbort(c);
+    }
+    void release_flag(unsigned seq_)
+    {
+        // nothing may be left waiting for a value nobody writes: after a failure the flag is stored from the host
+        (void)hipStreamSynchronize(cs);
+        __atomic_store_n(flag, seq_, __ATOMIC_RELEASE);
     }
     void run()
     {
@@ -92,12 +120,12 @@ struct Dp {
             }
             if (t.kind == 2) return;
             if (t.kind == 1) {
-                // behind the collectives on the same stream; should the enqueue fail the flag is written from here: nothing may be
-                // left waiting for a value nobody writes
-                if (hipStreamWriteValue32(cs, flag, t.seq, 0) != hipSuccess) {
-                    note(-2, "hipStreamWriteValue32 failed");
-                    (void)hipStreamSynchronize(cs);
-                    __atomic_store_n(flag, t.seq, __ATOMIC_RELEASE);
+                // behind the collectives on the same stream
+                if (status.load(std::memory_order_acquire) != 0) {
+                    release_flag(t.seq);
+                } else if (hipStreamWriteValue32(cs, flag, t.seq, 0) != hipSuccess) {
+                    fail_all(-2, "hipStreamWriteValue32 failed");
+                    release_flag(t.seq);
                 }
                 continue;
             }
@@ -106,17 +134,43 @@ struct Dp {
             for (int i = 0; i < t.nev; ++i) {
                 hipError_t e;
                 while ((e = hipEventQuery(t.ev[i])) == hipErrorNotReady) __builtin_ia32_pause();
-                if (e != hipSuccess) note(-2, "hipEventQuery failed");
+                if (e != hipSuccess) fail_all(-2, "hipEventQuery failed");
             }
+            recycle(t.ev, t.nev);
+            const long index = exchanges++;
+            if (status.load(std::memory_order_acquire) != 0) continue;
+            if (index == fault_at) {
+                fail_all(-3, "injected fault (STEM_DP_FAULT): collective refused");
+                continue;
+            }
+            ncclResult_t r = ncclSuccess;
             {
-                std::lock_guard<std::mutex> l(mu);
-                for (int i = 0; i < t.nev; ++i) pool.push_back(t.ev[i]);
+                std::lock_guard<std::mutex> l(comm_mu);
+                ncclComm_t c = comm.load();
+                if (!c) continue;
+                r = ncclAllReduce(t.buf, t.buf, t.count, ncclFloat, ncclSum, c, cs);
             }
-            if (status.load() == 0) {
-                const ncclResult_t r = ncclAllReduce(t.buf, t.buf, t.count, ncclFloat, ncclSum, comm, cs);
-                if (r != ncclSuccess) note(-3, ncclGetErrorString(r));
-            }
+            if (r != ncclSuccess) fail_all(-3, ncclGetErrorString(r));
         }
+    }
+    void teardown()
+    {
+        if (helper.joinable()) {
+            Task t;
+            t.kind = 2;
+            push(t);
+            helper.join();
+        }
+        (void)hipSetDevice(device);
+        if (cs) (void)hipStreamSynchronize(cs);
+        {
+            std::lock_guard<std::mutex> l(comm_mu);
+            ncclComm_t c = comm.exchange(nullptr);
+            if (c) (void)ncclCommDestroy(c);
+        }
+        for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+        if (cs) (void)hipStreamDestroy(cs);
+        if (flag) (void)hipFree(flag);
     }
 };
 
@@ -135,48 +189,94 @@ STEM_EXPORT int stem_dp_unique_id(unsigned char *id128)
     return 0;
 }
 
-STEM_EXPORT int stem_dp_create(void **handle, const unsigned char *id128, int world, int rank, int device)
+STEM_EXPORT int stem_dp_prepare(void **handle, int device)
 {
-    if (!handle || !id128 || world < 1 || rank < 0 || rank >= world) return fail(-1, "stem_dp_create: bad arguments (world %d, rank %d)", world, rank);
-    if (hipSetDevice(device) != hipSuccess) return fail(-2, "stem_dp_create: hipSetDevice(%d) failed", device);
+    if (!handle) return fail(-1, "stem_dp_prepare: null pointer");
+    *handle = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return fail(-2, "stem_dp_prepare: hipSetDevice(%d) failed", device);
     int ok = 0;
     if (hipDeviceGetAttribute(&ok, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess || !ok)
-        return fail(-4, "stem_dp_create: this device / runtime has no stream wait-value operation");
+        return fail(-4, "stem_dp_prepare: this device / runtime has no stream wait-value operation");
     Dp *d = new Dp;
     d->device = device;
+    if (const char *f = getenv("STEM_DP_FAULT"))
+        if (*f) d->fault_at = atol(f);
     void *f = nullptr;
     if (hipExtMallocWithFlags(&f, 8, hipMallocSignalMemory) != hipSuccess || !f) {
         delete d;
-        return fail(-2, "stem_dp_create: hipExtMallocWithFlags(hipMallocSignalMemory) failed");
+        return fail(-2, "stem_dp_prepare: hipExtMallocWithFlags(hipMallocSignalMemory) failed");
     }
     d->flag = static_cast<unsigned *>(f);
     *reinterpret_cast<volatile unsigned long long *>(f) = 0;
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (hipStreamCreateWithPriority(&d->cs, hipStreamNonBlocking, hi) != hipSuccess) {
-        (void)hipFree(f);
+        d->cs = nullptr;
+        d->teardown();
         delete d;
-        return fail(-2, "stem_dp_create: cannot create the communication stream");
+        return fail(-2, "stem_dp_prepare: cannot create the communication stream");
     }
-    ncclUniqueId id;
-    memcpy(&id, id128, sizeof(id));
-    const ncclResult_t r = ncclCommInitRank(&d->comm, world, id, rank);
-    if (r != ncclSuccess) {
-        (void)hipStreamDestroy(d->cs);
-        (void)hipFree(f);
-        delete d;
-        return fail(-3, "stem_dp_create: ncclCommInitRank: %s", ncclGetErrorString(r));
-    }
-    d->helper = std::thread([d] { d->run(); });
     *handle = d;
     return 0;
+}
+
+STEM_EXPORT int stem_dp_connect(void *handle, const unsigned char *id128, int world, int rank)
+{
+    Dp *d = static_cast<Dp *>(handle);
+    if (!d || !id128 || world < 1 || rank < 0 || rank >= world) return fail(-1, "stem_dp_connect: bad arguments (world %d, rank %d)", world, rank);
+    if (d->connected) return fail(-1, "stem_dp_connect: this handle is connected already");
+    if (hipSetDevice(d->device) != hipSuccess) return fail(-2, "stem_dp_connect: hipSetDevice(%d) failed", d->device);
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    const ncclResult_t r = ncclCommInitRank(&c, world, id, rank);
+    if (r != ncclSuccess) return fail(-3, "stem_dp_connect: ncclCommInitRank: %s", ncclGetErrorString(r));
+    int n = 0;
+    if (ncclCommCount(c, &n) != ncclSuccess || n != world) {
+        (void)ncclCommAbort(c);
+        return fail(-3, "stem_dp_connect: the communicator reports %d ranks, %d expected", n, world);
+    }
+    d->comm.store(c);
+    d->world = world;
+    d->connected = true;
+    d->helper = std::thread([d] { d->run(); });
+    return 0;
+}
+
+STEM_EXPORT int stem_dp_create(void **handle, const unsigned char *id128, int world, int rank, int device)
+{
+    if (!handle || !id128 || world < 1 || rank < 0 || rank >= world) return fail(-1, "stem_dp_create: bad arguments (world %d, rank %d)", world, rank);
+    void *h = nullptr;
+    int rc = stem_dp_prepare(&h, device);
+    if (rc != 0) return rc;
+    rc = stem_dp_connect(h, id128, world, rank);
+    if (rc != 0) {
+        (void)stem_dp_destroy(h);
+        return rc;
+    }
+    *handle = h;
+    return 0;
+}
+
+STEM_EXPORT int stem_dp_nranks(void *handle)
+{
+    Dp *d = static_cast<Dp *>(handle);
+    if (!d) return fail(-1, "stem_dp_nranks: null handle");
+    std::lock_guard<std::mutex> l(d->comm_mu);
+    ncclComm_t c = d->comm.load();
+    if (!c) return fail(d->status.load() ? d->status.load() : -1, "stem_dp_nranks: no communicator (%s)", d->connected ? d->err : "not connected");
+    int n = 0;
+    const ncclResult_t r = ncclCommCount(c, &n);
+    if (r != ncclSuccess) return fail(-3, "stem_dp_nranks: %s", ncclGetErrorString(r));
+    return n;
 }
 
 STEM_EXPORT int stem_dp_submit(void *handle, void *const *streams, int n, float *buf, size_t count)
 {
     Dp *d = static_cast<Dp *>(handle);
     if (!d || !buf || n < 0 || n > MAXEV || (n && !streams)) return fail(-1, "stem_dp_submit: bad arguments (%d streams)", n);
-    if (int s = d->status.load()) return fail(s, "stem_dp_submit: the helper thread failed earlier: %s", d->err);
+    if (!d->connected) return fail(-1, "stem_dp_submit: not connected");
+    if (int s = d->status.load(std::memory_order_acquire)) return fail(s, "stem_dp_submit: this rank's exchange failed earlier: %s", d->err);
     if (!count) return 0;
     Task t;
     t.buf = buf;
@@ -184,7 +284,12 @@ STEM_EXPORT int stem_dp_submit(void *handle, void *const *streams, int n, float 
     t.nev = n;
     for (int i = 0; i < n; ++i) {
         t.ev[i] = d->event();
-        if (!t.ev[i] || hipEventRecord(t.ev[i], (hipStream_t)streams[i]) != hipSuccess) return fail(-2, "stem_dp_submit: hipEventRecord failed");
+        if (!t.ev[i] || hipEventRecord(t.ev[i], (hipStream_t)streams[i]) != hipSuccess) {
+            // the collective cannot be issued on this rank: its peers would wait for it -- abort-all, and the events go back
+            d->recycle(t.ev, i + 1);
+            d->fail_all(-2, "stem_dp_submit: hipEventRecord failed");
+            return fail(-2, "stem_dp_submit: hipEventRecord failed");
+        }
     }
     d->push(t);
     return 0;
@@ -194,13 +299,18 @@ STEM_EXPORT int stem_dp_fence(void *handle, void *stream)
 {
     Dp *d = static_cast<Dp *>(handle);
     if (!d) return fail(-1, "stem_dp_fence: null handle");
-    if (int s = d->status.load()) return fail(s, "stem_dp_fence: the helper thread failed earlier: %s", d->err);
+    if (!d->connected) return fail(-1, "stem_dp_fence: not connected");
+    if (int s = d->status.load(std::memory_order_acquire)) return fail(s, "stem_dp_fence: this rank's exchange failed earlier: %s", d->err);
     Task t;
     t.kind = 1;
+    // 32-bit sequence compared with >=: it would wrap after 2^32 fences (one per optimiser step: ~1e8 septuplets of 6 steps at
+    // 10 ms each = 8 years of training); a run that long re-creates its reducer
     t.seq = ++d->seq;
     d->push(t);
-    if (hipStreamWaitValue32((hipStream_t)stream, d->flag, t.seq, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess)
+    if (hipStreamWaitValue32((hipStream_t)stream, d->flag, t.seq, hipStreamWaitValueGte, 0xffffffffu) != hipSuccess) {
+        d->fail_all(-2, "stem_dp_fence: hipStreamWaitValue32 failed");
         return fail(-2, "stem_dp_fence: hipStreamWaitValue32 failed");
+    }
     return 0;
 }
 
@@ -208,25 +318,24 @@ STEM_EXPORT int stem_dp_status(void *handle)
 {
     Dp *d = static_cast<Dp *>(handle);
     if (!d) return fail(-1, "stem_dp_status: null handle");
-    const int s = d->status.load();
+    const int s = d->status.load(std::memory_order_acquire);
     if (s) (void)fail(s, "%s", d->err);
     return s;
+}
+
+STEM_EXPORT int stem_dp_abort(void *handle, int code, const char *why)
+{
+    Dp *d = static_cast<Dp *>(handle);
+    if (!d) return fail(-1, "stem_dp_abort: null handle");
+    d->fail_all(code < 0 ? code : -5, why && *why ? why : "aborted by the host");
+    return 0;
 }
 
 STEM_EXPORT int stem_dp_destroy(void *handle)
 {
     Dp *d = static_cast<Dp *>(handle);
     if (!d) return 0;
-    Task t;
-    t.kind = 2;
-    d->push(t);
-    if (d->helper.joinable()) d->helper.join();
-    (void)hipSetDevice(d->device);
-    (void)hipStreamSynchronize(d->cs);
-    if (d->comm) (void)ncclCommDestroy(d->comm);
-    for (hipEvent_t e : d->pool) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(d->cs);
-    (void)hipFree(d->flag);
+    d->teardown();
     delete d;
     return 0;
 }

@@ -25,7 +25,7 @@ STEM_EXPORT int stem_built_with_experiments(void)
 }
 
 static int g_tuning[STEM_TUNE_COUNT] = {0};
-static const char *const kTuningNames[STEM_TUNE_COUNT] = {"fx3_tile", "fx3_split", "wg3_split", "arp_workers", "fx3_depth", "fx3_gen_tile", "fx3_mfma", "fx3_gen_mfma", "fx3_gen_img", "fx3_img_w", "wg3_row", "wg3_minch", "tconv_cps"};
+static const char *const kTuningNames[STEM_TUNE_COUNT] = {"fx3_tile", "fx3_split", "wg3_split", "arp_workers", "fx3_depth", "fx3_gen_tile", "fx3_mfma", "fx3_gen_mfma", "fx3_gen_img", "fx3_img_w", "wg3_row", "wg3_minch", "tconv_cps", "arp_giveup_at"};
 int stem_tuning(int id) { return g_tuning[id]; }
 STEM_EXPORT int stem_tuning_set(const char *name, int value)
 {
@@ -40,7 +40,7 @@ STEM_EXPORT int stem_tuning_set(const char *name, int value)
             g_tuning[i] = value;
             return 0;
         }
-    stem_set_error("stem_tuning_set: unknown selector '%s' (fx3_tile, fx3_split, wg3_split, arp_workers, fx3_depth, fx3_gen_tile, fx3_mfma, fx3_gen_mfma, fx3_gen_img, fx3_img_w)", name);
+    stem_set_error("stem_tuning_set: unknown selector '%s' (fx3_tile, fx3_split, wg3_split, arp_workers, fx3_depth, fx3_gen_tile, fx3_mfma, fx3_gen_mfma, fx3_gen_img, fx3_img_w, wg3_row, wg3_minch, tconv_cps, arp_giveup_at)", name);
     return -1;
 }
 STEM_EXPORT int stem_tuning_get(const char *name)

@@ -245,10 +245,21 @@ int decode(Decoder &d, const int32_t *indexes, size_t n, const Tables &t, int32_
         const uint32_t cum = (uint32_t)(d.x & ((1u << kPrec) - 1));
         // largest s with cdf[s] <= cum (cdf is strictly increasing, cdf[0] = 0, cdf[len-1] = 2^16)
         int lo = 0;
+        bool found = false;
         if (fast && d.lut_row_ok[(size_t)ci]) {
+            // The lookup table is keyed on the tables' ADDRESSES: should their contents have been rewritten in place since it was
+            // built, the start may be wrong and the walk must neither leave the row nor return a wrong symbol -- it is bounded by the
+            // row, its answer is checked (cdf[lo] <= cum < cdf[lo + 1]), and anything else goes to the binary search below.
             lo = d.lut[(size_t)ci * kLutBuckets + (cum >> kLutShift)];
-            while ((uint32_t)cdf[lo + 1] <= cum) ++lo;               // checked at build time: ends below len - 1
-        } else {
+            if (lo > len - 2) lo = len - 2;
+            while (lo < len - 2 && (uint32_t)cdf[lo + 1] <= cum) ++lo;
+            found = (uint32_t)cdf[lo] <= cum && cum < (uint32_t)cdf[lo + 1];
+            if (!found) {
+                d.lut_cdfs = nullptr;                                 // stale: rebuilt from the current contents at the next call
+                lo = 0;
+            }
+        }
+        if (!found) {
             int hi = len - 1;
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;

@@ -268,39 +268,70 @@ class _CollectiveIssuer:
         self.q.put(None)
 
 
+class NativeRouteUnavailable(RuntimeError):
+    """AGREED by every rank (one MIN all-reduce): some rank cannot prepare the native RCCL issue path, none of them uses it"""
+
+
+def _agree_all(ok: bool, device) -> bool:
+    """True only if `ok` on every rank: one MIN all-reduce on the torch process group (host tensor under gloo)"""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if dist.get_backend() == "gloo" else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 class _NativeIssuer:
     """The same job as _CollectiveIssuer without Python on the path: libstem_dp.so (include/stem_dp.h, csrc/dp_rccl.cpp) owns an RCCL
     communicator of its own, a C++ helper thread that polls the producers' events and then enqueues ncclAllReduce, and the stream
     flag the compute stream waits for.  The communicator id travels through torch.distributed once, at construction (collective:
-    every rank builds its reducers in the same order)."""
+    every rank builds its reducers in the same order).
 
-    def __init__(self, device):
+    Construction never leaves a peer behind.  Step 1 is LOCAL on every rank (library load, stem_dp_prepare: device, wait-value
+    capability, flag, stream; rank 0 also draws the id); then the ranks agree (MIN) -- if any of them failed, ALL raise
+    NativeRouteUnavailable and the caller may choose another route, collectively.  Step 2 is the collective stem_dp_connect
+    (ncclCommInitRank), followed by a second agreement: past this point there is no fallback, a failure raises RuntimeError on
+    every rank.  `lib` injects a stand-in for libstem_dp.so (CPU tests of this protocol)."""
+
+    def __init__(self, device, lib=None):
         from . import _lib
         dev = torch.device(device)
-        # the choice of route is collective: a rank that cannot load the library must take the others with it to the fallback, or
-        # they would wait for it in ncclCommInitRank
-        try:
-            self.lib, mine = _lib.dp(), 1
-        except Exception:
-            self.lib, mine = None, 0
-        ok = torch.tensor([mine], device=dev, dtype=torch.int32)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            raise RuntimeError("libstem_dp.so is not loadable on every rank")
+        self.h, self.lib, why = ctypes.c_void_p(), None, ""
         ident = (ctypes.c_ubyte * 128)()
-        if dist.get_rank() == 0:
-            self._chk(self.lib.stem_dp_unique_id(ident))
+        try:
+            self.lib = lib if lib is not None else _lib.dp()
+            rc = self.lib.stem_dp_prepare(ctypes.byref(self.h), dev.index or 0)
+            if rc == 0 and dist.get_rank() == 0:
+                rc = self.lib.stem_dp_unique_id(ident)
+            if rc != 0:
+                why = self._last_error()
+        except Exception as e:                               # library not loadable on this rank
+            rc, why = -1, str(e)
+        if not _agree_all(rc == 0, dev):
+            self.close()
+            raise NativeRouteUnavailable("the native RCCL issue path cannot be prepared on every rank"
+                                         + (f" (this rank: {why})" if rc != 0 else " (this rank is fine)"))
         box = [bytes(ident)]
         dist.broadcast_object_list(box, src=0)
         ident = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
-        self.h = ctypes.c_void_p()
-        self._chk(self.lib.stem_dp_create(ctypes.byref(self.h), ident, dist.get_world_size(), dist.get_rank(), dev.index or 0))
+        rc = self.lib.stem_dp_connect(self.h, ident, dist.get_world_size(), dist.get_rank())
+        why = self._last_error() if rc != 0 else ""
+        n = self.lib.stem_dp_nranks(self.h) if rc == 0 else -1
+        if not _agree_all(rc == 0 and n == dist.get_world_size(), dev):
+            self.close()
+            raise RuntimeError("libstem_dp: the RCCL communicator could not be built on every rank"
+                               + (f" (this rank: {why or f'{n} ranks reported, {dist.get_world_size()} expected'})" if rc != 0 or n != dist.get_world_size() else ""))
+        self.nranks = int(n)
         import atexit
         atexit.register(self.close)                          # the helper thread and the communicator go before the runtime does
 
+    def _last_error(self):
+        try:
+            return (self.lib.stem_dp_last_error() or b"").decode()
+        except Exception:
+            return ""
+
     def _chk(self, rc):
         if rc != 0:
-            raise RuntimeError("libstem_dp: " + (self.lib.stem_dp_last_error() or b"").decode())
+            raise RuntimeError("libstem_dp: " + self._last_error())
 
     def submit_streams(self, streams, tensor):
         arr = (ctypes.c_void_p * len(streams))(*[s.cuda_stream for s in streams])
@@ -310,10 +341,19 @@ class _NativeIssuer:
         from . import functional as F_
         self._chk(self.lib.stem_dp_fence(self.h, F_._stream()))
 
-    def close(self):
+    def check(self):
+        """raises if this rank's exchange has failed (the helper thread works behind the host: call after the step's fence, and
+        after a synchronise before trusting the replicas)"""
+        self._chk(self.lib.stem_dp_status(self.h))
+
+    def abort(self, why="aborted by the host"):
         if self.h:
+            self.lib.stem_dp_abort(self.h, -5, str(why).encode()[:200])
+
+    def close(self):
+        if self.h and self.lib is not None:
             self.lib.stem_dp_destroy(self.h)
-            self.h = ctypes.c_void_p()
+        self.h = ctypes.c_void_p()
 
 
 class OverlappedGradReducer:
@@ -351,8 +391,8 @@ class OverlappedGradReducer:
         if self._direct and mode >= 3 and flat.grad.dtype == torch.float32:
             try:
                 self._issuer = _NativeIssuer(flat.grad.device)
-            except Exception as e:                           # no librccl / no wait-value operation: the Python helper does the same job
-                import warnings
+            except NativeRouteUnavailable as e:              # agreed by ALL ranks (no librccl / no wait-value operation somewhere):
+                import warnings                              # every rank takes the Python helper; any later failure raises everywhere
                 warnings.warn(f"native RCCL issue path unavailable ({e}); issuing through torch.distributed")
         if self._issuer is None and self._direct and mode > 0:
             self._issuer = _CollectiveIssuer(flat.grad.device, use_flag=mode >= 2)
@@ -486,12 +526,37 @@ class OverlappedGradReducer:
             self._exchange(lo, hi, d)
         if self._direct and self._issuer is not None:
             self._issuer.fence()
+            if isinstance(self._issuer, _NativeIssuer):
+                self._issuer.check()               # a failure the helper thread met since the last step: abort-all, this rank raises
         elif self._direct:
             if self._works:                        # the process group runs its collectives on ONE stream, in issue order: the last
                 self._works[-1].wait()             # one's completion covers them all -- one cross-queue wait instead of one per call
             self._works = []
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
+
+    def check(self):
+        """raises if the native exchange of this rank has failed (call after a device synchronise, before trusting the replicas)"""
+        if isinstance(self._issuer, _NativeIssuer):
+            self._issuer.check()
+
+    @property
+    def rccl_nranks(self):
+        """ranks as the communicator that carries the gradients reports them: ncclCommCount of libstem_dp's communicator on the native
+        route, the torch process group's size otherwise; None without a process group"""
+        if isinstance(self._issuer, _NativeIssuer):
+            return self._issuer.nranks
+        return dist.get_world_size() if self.active else None
+
+    @property
+    def route(self):
+        if not self.active:
+            return "none"
+        if isinstance(self._issuer, _NativeIssuer):
+            return "libstem_dp (native helper thread, own RCCL communicator)"
+        if self._issuer is not None:
+            return f"torch.distributed {dist.get_backend()} from a Python helper thread"
+        return f"torch.distributed {dist.get_backend()}"
 
     def _names(self, lo, hi):
         hit = [n for n, p, o in zip(self.flat.names, self.flat.params, self.flat.offsets) if o < hi and o + p.numel() > lo]
@@ -559,6 +624,28 @@ class GopGradAccumulator:
     def finish(self):
         for f in self.exchanged + self.local:
             f.grad.copy_(self.sums[id(f)])
+
+
+def replica_checksum(t: torch.Tensor) -> int:
+    """a 64-bit position-weighted checksum of the BITS of an fp32 tensor (wrapping int64 arithmetic): equal on two replicas only if
+    they are bit-identical (up to the 2^-64 collision odds of a checksum)"""
+    bits = t.detach().reshape(-1).view(torch.int32).to(torch.int64)
+    w = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64) % 65521 + 1
+    return int((bits * w).sum().item())
+
+
+def replicas_identical(t: torch.Tensor):
+    """-> (identical, checksum of this rank): MIN and MAX all-reduce of replica_checksum(t) must agree.  Weights of a
+    data-parallel job stay replicated only if every rank applied the same reduced gradient: this is the check of that."""
+    c = replica_checksum(t)
+    if not dist.is_initialized():
+        return True, c
+    dev = "cpu" if dist.get_backend() == "gloo" else t.device
+    lo = torch.tensor([c], dtype=torch.int64, device=dev)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(int(lo.item()) == int(hi.item())), c
 
 
 def shard_seed(base_seed: int, rank: int) -> int:

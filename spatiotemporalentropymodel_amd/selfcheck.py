@@ -27,6 +27,81 @@ class NoiseFeed:
         return closed_form_input(name, tuple(shape), -0.5, 0.5).to(device)
 
 
+class SlicedNoise:
+    """noise_source for rank `rank` of `world`: the rows this rank's `per_rank` samples own in the noise tensor ONE process would
+    draw for the concatenated batch (same closed-form stream as NoiseFeed) -- what makes a data-parallel step comparable, number
+    for number, with the single-process step over the global batch (tests/dp_worker.py, dp_step_vs_full_batch)."""
+
+    def __init__(self, role, rank, world, per_rank, batch_last=False):
+        self.role, self.rank, self.world, self.per, self.k, self.batch_last = role, rank, world, per_rank, 0, batch_last
+
+    def __call__(self, shape, device):
+        name = f"noise:{self.role}:{self.k}"
+        self.k += 1
+        lo, hi = self.rank * self.per, (self.rank + 1) * self.per
+        if self.batch_last:                       # EntropyBottleneck asks for [C, 1, H*W*B] with B innermost
+            Cc, one, n = shape
+            hw = n // self.per
+            full = closed_form_input(name, (Cc, 1, hw * self.per * self.world), -0.5, 0.5)
+            return full.reshape(Cc, hw, self.per * self.world)[:, :, lo:hi].reshape(Cc, 1, n).contiguous().to(device)
+        full = closed_form_input(name, (shape[0] * self.world,) + tuple(shape[1:]), -0.5, 0.5)
+        return full[lo:hi].contiguous().to(device)
+
+
+def dp_step_vs_full_batch(make_models, frames_of_rank, rank, world, device, size):
+    """The self-check of a data-parallel run (bench.py STEM_BENCH_VERIFY=1, tests): ONE P-frame optimisation step of the explicit
+    schedule (trainer.FusedPFrameStep) through the overlapped reducer on every rank's shard, against the same step over the
+    GLOBAL batch computed by rank 0 alone from the same initial weights -- same frames, the same noise numbers (SlicedNoise).
+    The loop body is stem/trainSTEM.py:194-218; the reference has no parallel form to compare with.
+
+    make_models() -> (imodel, stem) with identical weights on every call and rank; frames_of_rank(r) -> [frame0, frame1] of
+    rank r's shard ([B,3,size,size] on `device`).  Collective (every rank calls it).  Returns on every rank
+    {"loss_dp", "loss_full", "loss_rel", "grad_rel", "rccl_nranks", "route"}; loss_full / *_rel are None off rank 0."""
+    import torch.distributed as dist
+    from . import distributed as D
+    from .optim import configure_optimizers
+    from .trainer import FusedPFrameStep
+
+    def one(rank_, world_, frames, reducer_on):
+        imodel, stem = make_models()
+        stem.train()
+        B = frames[0].shape[0]
+        imodel.gaussian_conditional.noise_source = SlicedNoise("iframe_gc", rank_, world_, B)
+        stem.entropy_bottleneck.noise_source = SlicedNoise("stem_eb", rank_, world_, B, batch_last=True)
+        stem.gaussian_conditional.noise_source = SlicedNoise("stem_gc", rank_, world_, B)
+        opt, aux_opt = configure_optimizers(stem, types.SimpleNamespace(learning_rate=1e-4, aux_learning_rate=1e-3))
+        red = D.OverlappedGradReducer(opt.flat).attach(stem.engine()) if reducer_on else None
+        fused = FusedPFrameStep(stem, opt, aux_opt)
+        fused.clear_grad_in_adam = False
+        with torch.no_grad():
+            _, y_cond = imodel.getY(frames[0])
+            y_cur, _ = imodel.getY(frames[1])
+        out, oc, aux, gn = fused.step(y_cur, y_cond, B * size * size, grad_scale=1.0 / world_ if reducer_on else 1.0, reducer=red)
+        fused.finish()
+        torch.cuda.synchronize(device)
+        if red is not None:
+            red.check()
+        g = opt.flat.grad.detach().clone() * (1.0 / world_ if reducer_on else 1.0)
+        info = (red.rccl_nranks, red.route) if red is not None else (None, "none")
+        stem.engine().grad_ready_hook = None
+        return float(oc["loss"]), g, info
+
+    loss_r, g_dp, (nranks, route) = one(rank, world, frames_of_rank(rank), dist.is_initialized())
+    t = torch.tensor([loss_r], dtype=torch.float64, device="cpu" if (dist.is_initialized() and dist.get_backend() == "gloo") else device)
+    if dist.is_initialized():
+        dist.all_reduce(t)
+    res = {"loss_dp": float(t.item()) / world, "loss_full": None, "loss_rel": None, "grad_rel": None, "rccl_nranks": nranks, "route": route}
+    if rank == 0:
+        full = [torch.cat([frames_of_rank(r)[i] for r in range(world)]) for i in range(2)]
+        loss_f, g_full, _ = one(0, 1, full, False)
+        res["loss_full"] = loss_f
+        res["loss_rel"] = abs(res["loss_dp"] - loss_f) / max(abs(loss_f), 1e-30)
+        res["grad_rel"] = float((g_dp - g_full).abs().max() / g_full.abs().max().clamp_min(1e-30))
+    if dist.is_initialized():
+        dist.barrier()
+    return res
+
+
 def build_models(ebc, cin, N, M, device, cls=None, closed_form=True, inject_noise=True):
     from .models import JointAutoregressiveHierarchicalPriors, SpatioTemporalPriorModel_Res
     cls = cls or SpatioTemporalPriorModel_Res

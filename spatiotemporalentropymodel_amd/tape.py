@@ -185,6 +185,10 @@ class LaunchTape:
                     elif va != vb:
                         if isptr[i]:
                             continue            # addresses of the second (ordinary) step's tensors: the tape keeps the first step's
+                        # what advances from step to step is a counter (Adam's step count, a Philox offset): it grows.  A leading
+                        # dimension or a shape that differs between two recordings of the same key is a bug the tape must not paper over
+                        if vb < va:
+                            raise TapeRefused(f"LaunchTape: integer argument {i} of {name} went from {va} to {vb} between two steps: not a step counter")
                         deltas[i] = vb - va
                         ndyn += 1
                 n = len(iv)
@@ -411,7 +415,14 @@ class TapedPFrameStep:
         if self.calls <= self.WARMUP:
             return f.step(y_cur, y_cond, num_pixels, grad_scale, reducer)
         if self.calls == self.WARMUP + 1:                       # recording A: inputs in static buffers, allocations kept
-            self.in_cur, self.in_cond = torch.empty_like(y_cur), torch.empty_like(y_cond)
+            # the recorded input buffers carry the CALLER's strides (empty_like of a non-dense view -- a channel slice of an NHWC
+            # tensor -- would be dense: the recording would bake ld = C into the launches' integer arguments and set_pointer would
+            # then aim them at a tensor with another ld)
+            self.in_cur = torch.empty_strided(y_cur.size(), y_cur.stride(), dtype=y_cur.dtype, device=y_cur.device)
+            self.in_cond = torch.empty_strided(y_cond.size(), y_cond.stride(), dtype=y_cond.dtype, device=y_cond.device)
+            if self.in_cur.stride() != y_cur.stride() or self.in_cond.stride() != y_cond.stride():
+                self._refuse("the input latents' strides cannot be reproduced in a recorded buffer")
+                return f.step(y_cur, y_cond, num_pixels, grad_scale, reducer)
             self.in_cur.copy_(y_cur)
             self.in_cond.copy_(y_cond)
             self.first = LaunchTape()

@@ -7,7 +7,7 @@ backward -- hooks fired from StemEngine.backward on the weight-gradient stream, 
 all-reduced while the rest of backward is still queued -- on the single-GPU test box.  The parent test compares what the
 ranks dump with a single-process run over the concatenated batch.
 
-    python tests/dp_worker.py --case train|train_fused|train_taped|train_untaped|gop|rccl1_train_fused|rccl1_gop|rccl1_train_taped --rank R --world W --port P --out DIR
+    python tests/dp_worker.py --case train|train_fused|train_taped|train_untaped|gop|rccl1_train_fused|rccl1_gop|rccl1_train_taped|rccl2_verify|rccl2_train_taped --rank R --world W --port P --out DIR
 
 The `rccl1_*` cases are ONE rank in a world-size-1 process group on the RCCL ("nccl") backend: the collectives are
 identities, but every RCCL call of the reducers, their side-stream ordering and the device-tensor reductions of bench.py
@@ -25,25 +25,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-class SlicedNoise:
-    """noise_source for rank `r` of `world`: the rows this rank's samples own in the noise tensor a single process
-    would draw for the concatenated batch (same closed-form stream as selfcheck.NoiseFeed)."""
+from spatiotemporalentropymodel_amd.selfcheck import SlicedNoise  # noqa: E402,F401  (the rows a rank owns in the global batch's noise)
 
-    def __init__(self, role, rank, world, per_rank, batch_last=False):
-        self.role, self.rank, self.world, self.per, self.k, self.batch_last = role, rank, world, per_rank, 0, batch_last
 
-    def __call__(self, shape, device):
-        from spatiotemporalentropymodel_amd.weights import closed_form_input
-        name = f"noise:{self.role}:{self.k}"
-        self.k += 1
-        lo, hi = self.rank * self.per, (self.rank + 1) * self.per
-        if self.batch_last:                       # EntropyBottleneck asks for [C, 1, H*W*B] with B innermost
-            Cc, one, n = shape
-            hw = n // self.per
-            full = closed_form_input(name, (Cc, 1, hw * self.per * self.world), -0.5, 0.5)
-            return full.reshape(Cc, hw, self.per * self.world)[:, :, lo:hi].reshape(Cc, 1, n).contiguous().to(device)
-        full = closed_form_input(name, (shape[0] * self.world,) + tuple(shape[1:]), -0.5, 0.5)
-        return full[lo:hi].contiguous().to(device)
+DEVICE_INDEX = 0          # rccl2_* cases: the rank's own device
 
 
 def flat_np(t):
@@ -59,7 +44,7 @@ def case_train(rank, world, out_dir, steps=2):
     from spatiotemporalentropymodel_amd.losses import EMLoss
     from spatiotemporalentropymodel_amd.optim import configure_optimizers
     from spatiotemporalentropymodel_amd.weights import smooth_frames
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda", DEVICE_INDEX)
     imodel, stem = S.build_models(64, 96, 64, 96, dev, inject_noise=False)
     stem.train()
     imodel.gaussian_conditional.noise_source = SlicedNoise("iframe_gc", rank, world, 1)
@@ -109,7 +94,7 @@ def case_train_fused(rank, world, out_dir, steps=2, tag="train_fused"):
     from spatiotemporalentropymodel_amd.optim import configure_optimizers
     from spatiotemporalentropymodel_amd.trainer import FusedPFrameStep
     from spatiotemporalentropymodel_amd.weights import smooth_frames
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda", DEVICE_INDEX)
     imodel, stem = S.build_models(64, 96, 64, 96, dev, inject_noise=False)
     stem.train()
     imodel.gaussian_conditional.noise_source = SlicedNoise("iframe_gc", rank, world, 1)
@@ -154,7 +139,7 @@ def case_train_taped(rank, world, out_dir, steps=8, tag="train_taped", taped=Tru
     from spatiotemporalentropymodel_amd.tape import TapedPFrameStep
     from spatiotemporalentropymodel_amd.trainer import FusedPFrameStep
     from spatiotemporalentropymodel_amd.weights import smooth_frames
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda", DEVICE_INDEX)
     torch.manual_seed(5)
     imodel, stem = S.build_models(64, 96, 64, 96, dev, inject_noise=False)
     stem.train()
@@ -185,6 +170,9 @@ def case_train_taped(rank, world, out_dir, steps=8, tag="train_taped", taped=Tru
     dump["collectives"] = np.array([red.collectives])
     dump["replays"] = np.array([step.replays if taped else 0])
     dump["taped"] = np.array([bool(taped and step.taped)])
+    dump["issuer"] = np.array([type(getattr(red, "_issuer", None)).__name__])
+    dump["nranks"] = np.array([red.rccl_nranks or 0])
+    dump["replicas_identical"] = np.array([D.replicas_identical(opt.flat.data)[0]])
     import torch.distributed as dist
     dump["backend"] = np.array([dist.get_backend() if dist.is_initialized() else "none"])
     np.savez(os.path.join(out_dir, f"{tag}_rank{rank}.npz"), **dump)
@@ -199,7 +187,7 @@ def case_gop(rank, world, out_dir, frames_n=3, tag="gop"):
     from spatiotemporalentropymodel_amd.models import stem_roi, stem_roi_i
     from spatiotemporalentropymodel_amd.optim import configure_optimizers
     from spatiotemporalentropymodel_amd.weights import closed_form_fill_scaled_, closed_form_input, smooth_frames
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda", DEVICE_INDEX)
     imodel, pmodel = stem_roi_i(), stem_roi()
     closed_form_fill_scaled_(imodel, "stem_roi_i", 0.7)
     closed_form_fill_scaled_(pmodel, "stem_roi", 0.7)
@@ -223,6 +211,26 @@ def case_gop(rank, world, out_dir, frames_n=3, tag="gop"):
     np.savez(os.path.join(out_dir, f"{out_tag}_rank{rank}.npz"), **dump)
 
 
+def case_rccl2_verify(rank, world, out_dir, tag="rccl2_verify"):
+    """TWO real RCCL ranks, one device each (needs >= 2 visible GPUs): (a) one P-frame step through the overlapped reducer against
+    the same step over the global batch on rank 0 alone (selfcheck.dp_step_vs_full_batch -- bench.py's STEM_BENCH_VERIFY check);
+    (b) replicas_identical on parameters that went through it."""
+    from spatiotemporalentropymodel_amd import distributed as D
+    from spatiotemporalentropymodel_amd import selfcheck as S
+    from spatiotemporalentropymodel_amd.weights import smooth_frames
+    dev = torch.device("cuda", DEVICE_INDEX)
+    torch.cuda.set_device(dev)
+    allf = smooth_frames("dp2:verify", world, 2, 64)
+    v = S.dp_step_vs_full_batch(lambda: S.build_models(64, 96, 64, 96, dev, inject_noise=False),
+                                lambda r: [f[r:r + 1].contiguous().to(dev) for f in allf], rank, world, dev, 64)
+    same, csum = D.replicas_identical(torch.full((1000,), 1.5, device=dev))
+    diff, _ = D.replicas_identical(torch.full((1000,), 1.5 + rank, device=dev))
+    np.savez(os.path.join(out_dir, f"{tag}_rank{rank}.npz"), loss_dp=np.array([v["loss_dp"]]),
+             loss_rel=np.array([v["loss_rel"] if v["loss_rel"] is not None else -1.0]),
+             grad_rel=np.array([v["grad_rel"] if v["grad_rel"] is not None else -1.0]),
+             nranks=np.array([v["rccl_nranks"] or 0]), route=np.array([v["route"]]), same=np.array([same]), diff=np.array([diff]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--case", required=True)
@@ -232,15 +240,22 @@ def main():
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     rccl1 = a.case.startswith("rccl1_")
+    rccl2 = a.case.startswith("rccl2_")
+    global DEVICE_INDEX
     base = a.case
     if "@" in a.case:                               # rccl1_<case>@<n>: the reducer's issue mode (STEM_DP_THREADED=n)
         base, mode = a.case.split("@")
         os.environ["STEM_DP_THREADED"] = mode
+    if rccl2:                                       # one device per rank, RCCL between them
+        DEVICE_INDEX = a.rank
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.port), RANK=str(a.rank), WORLD_SIZE=str(a.world),
-                      LOCAL_RANK="0", STEM_DIST_BACKEND="nccl" if rccl1 else "gloo")
+                      LOCAL_RANK=str(DEVICE_INDEX), STEM_DIST_BACKEND="nccl" if (rccl1 or rccl2) else "gloo")
     from spatiotemporalentropymodel_amd import distributed as D
     D.init_from_env(single=rccl1)
-    if rccl1:
+    if rccl2:
+        assert a.world == 2 and torch.distributed.get_backend() == "nccl" and torch.cuda.device_count() >= 2
+        {"rccl2_verify": case_rccl2_verify, "rccl2_train_taped": case_train_taped}[base](a.rank, a.world, a.out, tag=a.case)
+    elif rccl1:
         assert a.world == 1 and torch.distributed.get_backend() == "nccl"
         {"rccl1_train_fused": case_train_fused, "rccl1_gop": case_gop, "rccl1_train_taped": case_train_taped}[base](a.rank, a.world, a.out, tag=a.case)
     else:

@@ -36,13 +36,28 @@ def test_dp_library_exports_header_symbols():
     """libstem_dp.so (native RCCL issue path of a data-parallel rank) loads without a GPU and exports what include/stem_dp.h declares"""
     from spatiotemporalentropymodel_amd import _lib
     names = _declared("stem_dp.h")
-    assert len(names) == 7
+    assert len(names) == 11
     lib = ctypes.CDLL(_lib.DP_SO)
     for n in names:
         assert hasattr(lib, n), f"libstem_dp.so does not export {n}"
     assert set(names) == set(_lib.declared_dp_symbols())
     d = _lib.dp()
     assert d.stem_dp_submit(None, None, 0, None, 0) != 0 and b"stem_dp_submit" in d.stem_dp_last_error()      # argument checks need no device
+    assert d.stem_dp_connect(None, None, 1, 0) != 0 and d.stem_dp_nranks(None) < 0 and d.stem_dp_abort(None, -1, None) != 0
+
+
+def test_dp_prepare_fails_cleanly_without_a_device():
+    """stem_dp_prepare is the LOCAL half of the construction: on a box without a GPU it returns an error with a message and leaves
+    the handle NULL -- which is what lets the ranks agree (distributed._NativeIssuer) before any of them enters ncclCommInitRank"""
+    import pytest
+    import torch
+    from spatiotemporalentropymodel_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    d = _lib.dp()
+    h = ctypes.c_void_p(1234)
+    assert d.stem_dp_prepare(ctypes.byref(h), 0) != 0
+    assert not h.value and b"stem_dp_prepare" in d.stem_dp_last_error()
 
 
 def test_ops_fail_loudly_without_gpu():

@@ -406,3 +406,124 @@ def test_rank_pinning_reads_the_gpu_numa_topology(tmp_path, monkeypatch):
         assert D.pin_rank_to_gpu_cores(0, 1, str(root), environ={}) == [allowed[0]] and sorted(os.sched_getaffinity(0)) == [allowed[0]]
     finally:
         os.sched_setaffinity(0, allowed)
+
+
+# ---- the native issue path's construction protocol (distributed._NativeIssuer) with a stand-in for libstem_dp.so -------------------
+class _FakeDp:
+    """what _NativeIssuer calls on libstem_dp.so, recording the calls; `fail` names the entry point that fails on this rank"""
+
+    def __init__(self, fail=None, nranks=2):
+        self.fail, self.n, self.calls, self.status = fail, nranks, [], 0
+
+    def _rc(self, name):
+        self.calls.append(name)
+        return -2 if self.fail == name else 0
+
+    def stem_dp_prepare(self, href, device):
+        rc = self._rc("prepare")
+        if rc == 0:
+            import ctypes
+            ctypes.cast(href, ctypes.POINTER(ctypes.c_void_p))[0] = 0x1000
+        return rc
+
+    def stem_dp_unique_id(self, ident):
+        ident[0] = 42
+        return self._rc("unique_id")
+
+    def stem_dp_connect(self, h, ident, world, rank):
+        self.ident0 = ident[0]
+        return self._rc("connect")
+
+    def stem_dp_nranks(self, h):
+        self.calls.append("nranks")
+        return self.n
+
+    def stem_dp_status(self, h):
+        return self.status
+
+    def stem_dp_destroy(self, h):
+        self.calls.append("destroy")
+        return 0
+
+    def stem_dp_last_error(self):
+        return f"fake: {self.fail} failed".encode()
+
+
+def _worker_native_protocol(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, REPO)
+    torch.set_num_threads(1)
+    from spatiotemporalentropymodel_amd import distributed as D
+    D.init_from_env(backend="gloo")
+    out = {}
+
+    def attempt(fake):
+        try:
+            iss = D._NativeIssuer("cpu", lib=fake)
+            return "ok", iss
+        except D.NativeRouteUnavailable as e:
+            return "unavailable", str(e)
+        except RuntimeError as e:
+            return "error", str(e)
+
+    # (a) rank 1 cannot prepare: BOTH ranks learn it before anybody connects; the prepared rank's handle is destroyed
+    fake = _FakeDp(fail="prepare" if rank == 1 else None)
+    out["a"] = (attempt(fake)[0], list(fake.calls))
+    # (b) rank 0 cannot draw the id
+    fake = _FakeDp(fail="unique_id" if rank == 0 else None)
+    out["b"] = (attempt(fake)[0], list(fake.calls))
+    # (c) connect fails on rank 0 only: past the agreement there is no fallback -- RuntimeError on both
+    fake = _FakeDp(fail="connect" if rank == 0 else None)
+    kind, msg = attempt(fake)
+    out["c"] = (kind, list(fake.calls))
+    # (d) RCCL reports another rank count than the process group's
+    fake = _FakeDp(nranks=2 if rank == 0 else 1)
+    out["d"] = (attempt(fake)[0], list(fake.calls))
+    # (e) everything fine: the id drawn on rank 0 reached rank 1, nranks is what the communicator says
+    fake = _FakeDp()
+    kind, iss = attempt(fake)
+    out["e"] = (kind, list(fake.calls), fake.ident0, iss.nranks if kind == "ok" else None)
+    if kind == "ok":
+        iss.check()
+        fake.status = -3
+        fake.fail = "collective"
+        try:
+            iss.check()
+            out["check"] = "silent"
+        except RuntimeError as e:
+            out["check"] = str(e)
+        iss.h = None                                   # nothing real to destroy at exit
+    # replica checksums: equal tensors agree, one flipped low bit is seen by every rank
+    t = torch.arange(10000, dtype=torch.float32) * 0.37
+    out["same"] = D.replicas_identical(t)[0]
+    if rank == 1:
+        t.view(torch.int32)[7777] ^= 1
+    out["diff"] = D.replicas_identical(t)[0]
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, out))
+
+
+@pytest.mark.timeout(300)
+def test_native_issuer_construction_is_agreed_by_all_ranks_gloo():
+    """ADVICE r5 (distributed.py:297): a rank-local failure while the native RCCL path is set up must never leave the peers inside
+    ncclCommInitRank or reducing on different communicators.  Two gloo ranks, libstem_dp.so replaced by a recording stand-in."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_native_protocol, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        assert res[r]["a"][0] == "unavailable" and "connect" not in res[r]["a"][1]
+        assert res[r]["b"][0] == "unavailable" and "connect" not in res[r]["b"][1]
+        assert res[r]["c"][0] == "error" and "connect" in res[r]["c"][1] and "destroy" in res[r]["c"][1]
+        assert res[r]["d"][0] == "error"
+        assert res[r]["e"][0] == "ok" and res[r]["e"][2] == 42 and res[r]["e"][3] == 2
+        assert "collective failed" in res[r]["check"]
+        assert res[r]["same"] is True and res[r]["diff"] is False
+    assert "destroy" in res[0]["a"][1] and "prepare" in res[1]["a"][1]          # rank 0 had prepared fine: its handle is released

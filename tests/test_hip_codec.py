@@ -262,3 +262,47 @@ def test_iframe_codec_matches_reference(golden):
     assert_close(host(fwd["entropy_params"]["means_hat"]), g["fwd:means"], what="means", floor=0.1)
     assert_close(host(fwd["likelihoods"]["z"]), g["fwd:lik_z"], what="lik_z", floor=0.1, atol=1e-9)
     assert_close(host(fwd["likelihoods"]["y"]), g["fwd:lik_y"], rtol=2e-4, what="lik_y", floor=0.1, atol=1e-9)
+
+
+@pytest.mark.parametrize("batch,giveup_at", [(1, 1), (1, 57), (1, 160), (3, 40)])
+def test_persistent_decoder_give_up_falls_back_to_the_loop(batch, giveup_at, monkeypatch):
+    """The persistent decoder's bounded waits may run out (codec.py: "persistent decoder gave up"): the host raises the abort word,
+    the kernel's workgroups leave their polls, the call returns an error with the latent buffer half written -- and the image is
+    then decoded again by the per-position loop from a FRESH buffer and a FRESH rANS decoder.  Forced here at the first position,
+    in the middle of the image and at its last position (stem_tuning_set("arp_giveup_at", k): the host gives up at position k - 1
+    exactly as a timed-out wait does), for a single image and for a batch decoded concurrently (each image's own kernel gives up):
+    the warning fires, the reconstruction equals the loop's bit for bit, and the next call -- knob cleared -- runs persistently
+    again without a warning (the library's per-thread flags and mailboxes survive an aborted image).
+    spatiotemporalpriors.py:1015-1054."""
+    import warnings
+    import spatiotemporalentropymodel_amd.models as M
+    from spatiotemporalentropymodel_amd import _lib
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_, closed_form_input
+    dev = torch.device("cuda:0")
+    m = closed_form_fill_(M.SpatioTemporalPriorModel_Res(64, 96)).to(dev).eval()
+    m.update(force=True)
+    y_cur = closed_form_input("gu:y", (batch, 96, 8, 20), -6, 6).to(dev)
+    y_cond = closed_form_input("gu:c", (batch, 96, 8, 20), -6, 6).to(dev)
+    lib = _lib.hip()
+    with torch.no_grad():
+        enc = m.compress(y_cur, y_cond)
+        monkeypatch.setenv("STEM_AR_PERSISTENT", "0")
+        monkeypatch.setenv("STEM_AR_NO_BATCH", "1")
+        ref = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()          # the loop
+        monkeypatch.delenv("STEM_AR_PERSISTENT")
+        monkeypatch.delenv("STEM_AR_NO_BATCH")
+        assert lib.stem_tuning_set(b"arp_giveup_at", giveup_at) == 0
+        try:
+            with warnings.catch_warnings(record=True) as seen:
+                warnings.simplefilter("always")
+                got = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()
+        finally:
+            assert lib.stem_tuning_set(b"arp_giveup_at", 0) == 0
+        gave_up = [w for w in seen if "persistent decoder gave up" in str(w.message)]
+        assert len(gave_up) >= batch, [str(w.message) for w in seen]      # a batch retries each image alone before it takes the loop
+        assert f"position {giveup_at - 1}" in str(gave_up[0].message)
+        assert torch.equal(got, ref)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            again = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()
+        assert torch.equal(again, ref)

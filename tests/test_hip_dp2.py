@@ -273,6 +273,40 @@ def test_rccl_world1_gop_accumulator_bit_identical_to_no_process_group(dp2_resul
         np.testing.assert_array_equal(r[k], loc[k], err_msg=k)
 
 
+# ---- two REAL RCCL ranks: runs wherever two devices are visible, skips on the one-GPU test box -------------------------------------
+_TWO = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="two RCCL ranks need a device each (RCCL refuses two ranks on one device)")
+
+
+@_TWO
+@pytest.mark.dp2("rccl2_verify")
+def test_rccl_two_devices_equals_full_batch(dp2_results):
+    """configs[2] at world size 2 over RCCL/xGMI: one P-frame step (stem/trainSTEM.py:194-218) through the overlapped reducer and
+    libstem_dp's own communicator on two devices, against the same step over the global batch computed by rank 0 alone --
+    the check `STEM_BENCH_VERIFY=1 bench.py --gpus N` prints as config.data_parallel.loss_vs_single_rank."""
+    r0, r1 = dp2_results("rccl2_verify")
+    assert int(r0["nranks"][0]) == int(r1["nranks"][0]) == 2 and "libstem_dp" in str(r0["route"][0])
+    assert r0["loss_dp"][0] == r1["loss_dp"][0]
+    assert 0 <= float(r0["loss_rel"][0]) < 1e-5 and 0 <= float(r0["grad_rel"][0]) < 1e-4, (r0["loss_rel"], r0["grad_rel"])
+    assert bool(r0["same"][0]) and bool(r1["same"][0]) and not bool(r0["diff"][0]) and not bool(r1["diff"][0])
+
+
+@_TWO
+@pytest.mark.dp2("rccl2_train_taped")
+@pytest.mark.dp2("train_untaped")
+def test_rccl_two_devices_taped_equals_the_gloo_pair(dp2_results):
+    """Eight P-frame steps on two devices through the launch tape with the native RCCL issue path, against the same two ranks
+    sharing one device over gloo on the plain schedule: a two-term sum does not depend on its order, so losses, norms and every
+    parameter must be bit-identical, and the replicas identical to each other."""
+    t0, t1 = dp2_results("rccl2_train_taped")
+    u0, u1 = dp2_results("train_untaped")
+    assert str(t0["backend"][0]) == "nccl" and str(t0["issuer"][0]) == "_NativeIssuer" and int(t0["nranks"][0]) == 2
+    assert bool(t0["taped"][0]) and bool(t0["replicas_identical"][0]) and bool(t1["replicas_identical"][0])
+    np.testing.assert_array_equal(t0["params"], t1["params"])
+    for t, u in ((t0, u0), (t1, u1)):
+        for k in ["params", "quantiles"] + [f"s{i}:loss" for i in range(1, 9)]:
+            np.testing.assert_array_equal(t[k], u[k], err_msg=k)
+
+
 @pytest.mark.bench_gpus2
 def test_bench_gpus2_typed_bare_runs_two_ranks_on_one_device():
     """`python bench.py --gpus 2 --steps 2 --warmup 1` without any launcher (the driver's command form with N = 2): the parent
@@ -296,3 +330,9 @@ def test_bench_gpus2_typed_bare_runs_two_ranks_on_one_device():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["config"]["global_batch"] == 32 and rec["config"]["parallelism"] == "dp2"
     assert rec["value"] > 0 and rec["scaling"] == "weak" and "roofline" in rec and "cpu_baseline" not in rec
+    # the run's own evidence that it was data parallel: the ranks the exchanging group reports, bit-identical replicas after the
+    # timed region, and (STEM_BENCH_VERIFY=1, set by conftest) the first step against rank 0 alone over the global batch
+    dp = rec["config"]["data_parallel"]
+    assert dp["rccl_nranks"] == 2 and dp["replicas_identical"] is True and "gloo" in dp["exchange_route"]
+    lv = dp["loss_vs_single_rank"]
+    assert lv["global_batch"] == 32 and lv["rel_diff"] < 1e-5 and lv["averaged_gradient_max_rel_diff"] < 1e-4, lv

@@ -70,4 +70,108 @@ def test_native_exchange_rejects_bad_arguments():
     ident = (C.c_ubyte * 128)()
     h = C.c_void_p()
     assert lib.stem_dp_create(C.byref(h), ident, 2, 5, 0) != 0 and b"bad arguments" in lib.stem_dp_last_error()
+    assert lib.stem_dp_connect(None, ident, 1, 0) != 0 and lib.stem_dp_nranks(None) < 0 and lib.stem_dp_abort(None, -1, None) != 0
     assert lib.stem_dp_destroy(None) == 0
+
+
+def _prepared(lib, connect=True):
+    ident = (C.c_ubyte * 128)()
+    assert lib.stem_dp_unique_id(ident) == 0
+    h = C.c_void_p()
+    assert lib.stem_dp_prepare(C.byref(h), 0) == 0, lib.stem_dp_last_error()
+    assert h.value
+    if connect:
+        assert lib.stem_dp_connect(h, ident, 1, 0) == 0, lib.stem_dp_last_error()
+    return h, ident
+
+
+def test_prepare_is_local_and_connect_reports_the_communicators_rank_count():
+    """The two construction steps (include/stem_dp.h): stem_dp_prepare touches no communicator (nranks / submit / fence refuse the
+    handle), stem_dp_connect builds it and stem_dp_nranks reads the rank count back from RCCL (ncclCommCount), a second connect
+    is refused."""
+    lib = _lib()
+    torch.cuda.set_device(0)
+    h, ident = _prepared(lib, connect=False)
+    try:
+        assert lib.stem_dp_nranks(h) < 0 and b"not connected" in lib.stem_dp_last_error()
+        buf = torch.zeros(16, device="cuda:0")
+        assert lib.stem_dp_submit(h, None, 0, buf.data_ptr(), 16) != 0 and b"not connected" in lib.stem_dp_last_error()
+        assert lib.stem_dp_fence(h, None) != 0
+        assert lib.stem_dp_connect(h, ident, 1, 0) == 0, lib.stem_dp_last_error()
+        assert lib.stem_dp_nranks(h) == 1
+        assert lib.stem_dp_connect(h, ident, 1, 0) != 0 and b"connected already" in lib.stem_dp_last_error()
+        assert lib.stem_dp_status(h) == 0
+    finally:
+        assert lib.stem_dp_destroy(h) == 0
+
+
+def test_helper_failure_is_abort_all_and_nothing_is_left_waiting(monkeypatch):
+    """A collective the helper thread cannot issue (fault injected at exchange 1 by STEM_DP_FAULT, read at prepare): the status
+    carries the first failure and its message, the communicator is gone (stem_dp_nranks refuses), a fence that was already queued
+    is released from the host -- the consumer stream finishes instead of waiting for a flag nobody writes -- and every later
+    submit / fence returns the status, so that the rank leaves with an error instead of stepping on unreduced gradients."""
+    lib = _lib()
+    torch.cuda.set_device(0)
+    monkeypatch.setenv("STEM_DP_FAULT", "1")
+    h, _ = _prepared(lib)
+    monkeypatch.delenv("STEM_DP_FAULT")
+    try:
+        cons = torch.cuda.Stream()
+        buf = torch.ones(1 << 20, device="cuda:0")
+        torch.cuda.synchronize()
+        st = (C.c_void_p * 1)(torch.cuda.current_stream().cuda_stream)
+        assert lib.stem_dp_submit(h, st, 1, buf.data_ptr(), buf.numel()) == 0            # exchange 0: fine
+        assert lib.stem_dp_fence(h, cons.cuda_stream) == 0
+        cons.synchronize()
+        assert lib.stem_dp_status(h) == 0
+        assert lib.stem_dp_submit(h, st, 1, buf.data_ptr(), buf.numel()) == 0            # exchange 1: refused inside the helper
+        rc_fence = lib.stem_dp_fence(h, cons.cuda_stream)                                 # queued before or after the helper noticed
+        with torch.cuda.stream(cons):
+            snap = buf.clone()
+        cons.synchronize()                                                                # must return either way
+        import time
+        t0 = time.time()
+        while lib.stem_dp_status(h) == 0 and time.time() - t0 < 10:
+            time.sleep(0.01)
+        assert lib.stem_dp_status(h) == -3 and b"injected fault" in lib.stem_dp_last_error()
+        assert rc_fence in (0, -3)
+        assert lib.stem_dp_nranks(h) < 0
+        assert lib.stem_dp_submit(h, st, 1, buf.data_ptr(), buf.numel()) == -3 and b"failed earlier" in lib.stem_dp_last_error()
+        assert lib.stem_dp_fence(h, cons.cuda_stream) == -3
+        assert float(snap.sum()) == float(buf.numel())
+    finally:
+        assert lib.stem_dp_destroy(h) == 0
+
+
+def test_host_abort_has_the_same_effect():
+    lib = _lib()
+    torch.cuda.set_device(0)
+    h, _ = _prepared(lib)
+    try:
+        assert lib.stem_dp_abort(h, -7, b"rank 3 lost its loader") == 0
+        assert lib.stem_dp_status(h) == -7 and b"rank 3 lost its loader" in lib.stem_dp_last_error()
+        assert lib.stem_dp_abort(h, -8, b"second") == 0 and lib.stem_dp_status(h) == -7          # the first failure stands
+        assert lib.stem_dp_fence(h, torch.cuda.current_stream().cuda_stream) == -7
+        torch.cuda.synchronize()
+    finally:
+        assert lib.stem_dp_destroy(h) == 0
+
+
+def test_reducer_raises_after_a_failed_exchange(monkeypatch):
+    """through the Python binding: distributed._NativeIssuer.check() (called by OverlappedGradReducer.finish() after the step's
+    fence, and by bench.py after its synchronise) turns the status into an exception"""
+    from spatiotemporalentropymodel_amd import distributed as D
+    lib = _lib()
+    torch.cuda.set_device(0)
+    h, _ = _prepared(lib)
+    iss = D._NativeIssuer.__new__(D._NativeIssuer)
+    iss.lib, iss.h = lib, h
+    try:
+        iss.check()
+        iss.abort("peer died")
+        with pytest.raises(RuntimeError, match="peer died"):
+            iss.check()
+        with pytest.raises(RuntimeError, match="failed earlier"):
+            iss.fence()
+    finally:
+        iss.close()

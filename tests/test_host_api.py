@@ -807,3 +807,47 @@ def test_rans_decoder_lookup_search_equals_binary_search():
         t = em._as_tables(cdfs, sizes, offsets)
         got = np.concatenate([np.asarray(dec.decode_stream(idx[i:i + 192], t)) for i in range(0, n, 192)])
         np.testing.assert_array_equal(got, sym)
+
+
+def test_rans_decoder_survives_tables_rewritten_behind_the_same_pointers():
+    """ADVICE r5 (rans_host.cpp:250): the decoder's lookup table is keyed on the ADDRESSES of the CDF tables.  Tables updated in
+    place inside one stream (an entropy model's `update()` writing into the same buffers) leave it stale: the walk from a stale
+    start must stay inside the row (it runs under AddressSanitizer in test_host_codec_under_sanitizers: name contains "rans") and
+    the symbols must still be the ones the CURRENT tables define -- the stale table is dropped and the binary search answers."""
+    rng = np.random.default_rng(11)
+    ncdf, stride = 4, 600
+
+    def tables(spread):
+        cdfs = np.zeros((ncdf, stride), dtype=np.int32)
+        sizes = np.zeros(ncdf, dtype=np.int32)
+        for c in range(ncdf):
+            ln = int(rng.integers(40, stride + 1))
+            sizes[c] = ln
+            w = np.exp(-0.5 * ((np.arange(ln - 1) - (ln - 1) * rng.uniform(0.2, 0.8)) / spread) ** 2) + 1e-9
+            f = np.maximum(1, np.floor(w / w.sum() * (65536 - (ln - 1)))).astype(np.int64)
+            f[np.argmax(f)] += 65536 - f.sum()
+            cdfs[c, 1:ln] = np.cumsum(f)
+        return cdfs, sizes
+
+    offsets = np.zeros(ncdf, dtype=np.int32)
+    cdfs_a, sizes_a = tables(4.0)
+    cdfs_b, sizes_b = tables(60.0)
+    n = 192 * 30
+    idx = rng.integers(0, ncdf, n).astype(np.int32)
+    half = n // 2
+    sym = np.empty(n, dtype=np.int32)
+    sym[:half] = [int(rng.integers(0, sizes_a[i] - 1)) for i in idx[:half]]
+    sym[half:] = [int(rng.integers(0, sizes_b[i] - 1)) for i in idx[half:]]
+    enc = em.BufferedRansEncoder()                                   # one stream, two table sets
+    enc.encode_with_indexes(sym[:half], idx[:half], cdfs_a, sizes_a, offsets)
+    enc.encode_with_indexes(sym[half:], idx[half:], cdfs_b, sizes_b, offsets)
+    stream = enc.flush()
+    live_c, live_s = cdfs_a.copy(), sizes_a.copy()                   # the buffers the decoder sees: same addresses throughout
+    t = em._as_tables(live_c, live_s, offsets)
+    dec = em.RansDecoder()
+    dec.set_stream(stream)
+    got = [np.asarray(dec.decode_stream(idx[i:i + 192], t)) for i in range(0, half, 192)]            # builds the lookup table (> 2048 symbols)
+    live_c[...] = cdfs_b                                             # rewritten IN PLACE
+    live_s[...] = sizes_b
+    got += [np.asarray(dec.decode_stream(idx[i:i + 192], t)) for i in range(half, n, 192)]
+    np.testing.assert_array_equal(np.concatenate(got), sym)
