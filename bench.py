@@ -385,6 +385,118 @@ def bench_roi(args):
                      "avg_launch_ms": kern_ms, "launches_timed": len(probe), "traffic": None}})
 
 
+def _cpu_baseline_eval(stem, enc, y_cond, y_hat_gpu, budget_s=15.0):
+    """cpu_baseline of --config eval: the raster-order decoding loop as the reference executes it on a CPU
+    (oracle/stem_torch_cpu.decode_positions: torch CPU conv2d per position + the reference's own RansDecoder from oracle/_ref) on
+    the FIRST positions of the very P frame the GPU just decoded (its strings, its tables, its hyper / temporal prior tensors),
+    for `budget_s` seconds; the positions it decodes are compared with the GPU's."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import stem_oracle as orc
+    import stem_torch_cpu as tc
+    dec = orc.reference_rans_decoder()
+    if dec is None:
+        return None
+    cores = _physical_cores()
+    old = torch.get_num_threads()
+    torch.set_num_threads(cores)
+    try:
+        with torch.no_grad():
+            dev = y_cond.device
+            z_hat = stem.entropy_bottleneck.decompress(enc["strings"][1], enc["shape"]).to(dev).float()
+            hp = stem.HD(z_hat).float().cpu().contiguous()
+            tp = stem.TPM(y_cond).float().cpu().contiguous()
+        gc = stem.gaussian_conditional
+        tables = {"gc_cdf": gc._quantized_cdf.cpu().numpy(), "gc_cdf_length": gc._cdf_length.cpu().numpy(), "gc_offset": gc._offset.cpu().numpy(),
+                  "gc_scale_table": gc.scale_table.cpu().numpy()}
+        ssd = {k: v.detach().float().cpu().numpy() for k, v in stem.state_dict().items() if k.startswith(("context_prediction.", "EPM."))}
+        H, W = hp.shape[-2:]
+        yc = y_cond.float().cpu().contiguous()
+        # a first short run sizes the sample (and warms the operators up), the second is the measurement
+        _, n0, t0 = tc.decode_positions(ssd, yc, hp, tp, enc["strings"][0][0], tables, dec, max_positions=24)
+        per = t0 / max(n0, 1)
+        npos = int(max(64, min(H * W, budget_s / per)))
+        res, n, dt = tc.decode_positions(ssd, yc, hp, tp, enc["strings"][0][0], tables, orc.reference_rans_decoder(), max_positions=npos)
+        rows = n // W                                        # complete rows decoded by the sample
+        got = (res[:, :, :rows] + yc[:, :, :rows]).numpy()
+        ref = y_hat_gpu[:, :, :rows].float().cpu().numpy()
+        err = float(np.abs(got - ref).max() / max(float(np.abs(ref).max()), 1e-30)) if rows else None
+    finally:
+        torch.set_num_threads(old)
+    per = dt / n
+    return {"value": 1.0 / (per * H * W), "unit": "frames/s", "cores": cores, "kind": "torch-cpu", "cpu_model": _cpu_model(),
+            "positions_timed": n, "seconds": dt, "us_per_position": per * 1e6, "positions_per_frame": H * W,
+            "decode_loop_s_per_frame_extrapolated": per * H * W, "sample_rows_vs_gpu_max_rel_diff": err,
+            "sample": f"the first {n} of {H * W} positions of one 1080p P frame's raster-order decoding loop (spatiotemporalpriors.py:1015-1054) on torch "
+                      f"{torch.__version__} CPU operators, {cores} threads, with the reference's own RansDecoder (oracle/_ref): {per * 1e6:.0f} us per position "
+                      f"-> {per * H * W:.1f} s for the loop of one frame; value = 1 / that (decode loop ONLY: the reference's encoder walks the same loop, "
+                      f"SURVEY.md 3.2: 13 s encode + 39 s decode per frame), i.e. an upper bound of the reference's CPU frames/s"}
+
+
+def bench_eval(args):
+    """--config eval: BASELINE.json configs[3] -- the evaluation loop of stem/evalSTEM.py (evaluation.eval_gop) on ONE synthetic
+    1920x1080 sequence, GOP 12: a step = one GOP = the I frame through mbt2018's compress / decompress + 11 P frames through
+    getY -> forward -> compress -> decompress -> getX with host rANS.  value = frames/s of the whole loop (encode AND decode of
+    every frame, as the script runs them back to back).  The path is bound by the LATENCY of one raster position (four dependent
+    matrix-vector products + a host round trip for the symbols), not by HBM or the matrix pipe: `roofline.bound` says so."""
+    from spatiotemporalentropymodel_amd import _lib, evaluation
+    from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel_Res
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_
+    from spatiotemporalentropymodel_amd.zoo import models
+    _lib.hip()
+    assert args.gpus == 1, "the evaluation loop is sequential in the frames of a sequence: one GPU (replicas only)"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    Hh, Ww, GOP = args.eval_height, args.eval_width, args.eval_gop
+    imodel = closed_form_fill_(models["mbt2018"](quality=4)).to(dev).eval()
+    imodel.update(force=True)
+    stem = closed_form_fill_(SpatioTemporalPriorModel_Res()).to(dev).eval()
+    stem.update(force=True)
+    yy, xx = torch.meshgrid(torch.arange(Hh, device=dev), torch.arange(Ww, device=dev), indexing="ij")
+    frames = [torch.stack([0.5 + 0.4 * torch.sin((xx + 3 * t) / (40.0 + 10 * c)) * torch.cos((yy + t) / (55.0 - 5 * c)) for c in range(3)])
+              for t in range(GOP)]
+    for _ in range(args.warmup):
+        evaluation.eval_gop(imodel, stem, frames, gop=GOP)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    runs = [evaluation.eval_gop(imodel, stem, frames, gop=GOP) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = [f for r in runs for f in r["frames"]]
+    P = [f for f in per if f["type"] == "P"]
+    I = [f for f in per if f["type"] == "I"]
+    mean = lambda xs: float(np.mean(xs)) if xs else None        # noqa: E731
+    npos = ((Hh + 63) // 64 * 4) * ((Ww + 63) // 64 * 4)
+    dec_p = mean([f["decoding_time"] for f in P])
+    last = runs[-1]["frames"]
+    res = {
+        "metric": "frames/s", "value": GOP * args.steps / dt, "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[3]: evaluation loop of stem/evalSTEM.py (evaluation.eval_gop), one {Ww}x{Hh} sequence, GOP {GOP}: I frame by mbt2018(192,192) "
+                               "compress / decompress, P frames by SpatioTemporalPriorModel_Res(256,192) getY / forward / compress / decompress / getX, host rANS; "
+                               "closed-form (untrained) weights: every one of the 192 symbols of a position is non-trivial (5.7 bpp), nothing like a trained model's 0.08 bpp",
+                   "frames_per_step": GOP, "p_frames_per_step": GOP - 1, "latent_positions_per_frame": npos,
+                   "decoder": "persistent kernel (csrc/ar_persistent.hip)" if RUNTIME().ar_persistent else "per-position loop (csrc/ar.hip)",
+                   "i_frame": {"encode_s": mean([f["encoding_time"] for f in I]), "decode_s": mean([f["decoding_time"] for f in I]), "bpp": mean([f["bpp"] for f in I])},
+                   "p_frame": {"encode_s": mean([f["encoding_time"] for f in P]), "decode_s": dec_p, "bpp": mean([f["bpp"] for f in P]),
+                               "estimate_bpp": mean([f["estimate_bpp"] for f in P]), "psnr_db": mean([f["psnr"] for f in P])},
+                   "psnr_ave": runs[-1]["psnr_ave"], "bpp_ave": runs[-1]["bpp_ave"]},
+        "roofline": {"bound": "latency", "kernel": "ar_decode_persistent_kernel: the raster-order loop of one P frame (context 5x5 product, EPM.0, EPM.2, EPM.4 per position, "
+                                                   "symbols from the host decoder through a pinned mailbox); the frame's decode time also holds HD / TPM / g_s (a few ms)",
+                     "achieved": npos / dec_p, "peak": 1e6 / 2.6, "unit": "positions/s", "frac": (npos / dec_p) / (1e6 / 2.6),
+                     "us_per_position": dec_p / npos * 1e6,
+                     "peak_definition": "one position's ARITHMETIC alone, 2.6 us: the four dependent products on 32 resident workgroups with the weights in registers "
+                                        "(phase stamps of the instrumented library, profiles/r05f_eval_1080p_persistent_phases.log: ctx 0.42 + h1 0.83 + h2 0.74 + gp 0.62 us); "
+                                        "the rest of a position is hand-overs between the products (4.9 us) and the host's symbol decoding + mailbox round trip (6.5 us)",
+                     "traffic": None}}
+    if not args.no_cpu_baseline:
+        pf = [f for f in last if f["type"] == "P"][0]
+        k = last.index(pf)
+        enc = {"strings": pf["strings"], "shape": pf["shape"]}
+        res["cpu_baseline"] = _cpu_baseline_eval(stem, enc, last[k - 1]["y_conditioned"], pf["y_conditioned"])
+    _emit(res)
+
+
 def _emit(res):
     """the ONE JSON line, as the LAST line of stdout: RCCL prints its version banner through C stdio, which (not a terminal) is
     flushed at exit, i.e. after a Python print -- flush it first"""
@@ -460,8 +572,11 @@ def rendezvous_only(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--config", default="stem", choices=["stem", "roi"], help="stem = BASELINE configs[1] (the metric's workload, default); "
-                    "roi = configs[4], the variable-rate GOP iteration")
+    ap.add_argument("--config", default="stem", choices=["stem", "roi", "eval"], help="stem = BASELINE configs[1] (the metric's workload, default); "
+                    "roi = configs[4], the variable-rate GOP iteration; eval = configs[3], the evaluation loop (compress / decompress with host rANS) on one 1080p GOP")
+    ap.add_argument("--eval-height", type=int, default=1080)
+    ap.add_argument("--eval-width", type=int, default=1920)
+    ap.add_argument("--eval-gop", type=int, default=12)
     ap.add_argument("--roi-batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 10; 2 for --config roi)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 6 for --config roi: the first process that runs the variable-rate models on a box needs about that many iterations before an iteration takes what it takes in every later process -- 1.40 s after two, 0.95-1.0 s after six)")
@@ -483,9 +598,9 @@ def main():
                     "(launcher / process-group check without the workload; works without a GPU)")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 2 if args.config == "roi" else 10
+        args.steps = {"roi": 2, "eval": 2}.get(args.config, 10)
     if args.warmup is None:
-        args.warmup = 6 if args.config == "roi" else 3
+        args.warmup = {"roi": 6, "eval": 1}.get(args.config, 3)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     # a rank of a multi-GPU run pins itself to the cores of its GPU's NUMA node before anything touches the GPU (sysfs only)
@@ -497,6 +612,8 @@ def main():
         return rendezvous_only(args)
     if args.config == "roi":
         return bench_roi(args)
+    if args.config == "eval":
+        return bench_eval(args)
 
     from spatiotemporalentropymodel_amd import _lib
     from spatiotemporalentropymodel_amd import distributed as D
@@ -547,38 +664,39 @@ def main():
         imodel.g_a.probe = {2: probe, 0: probe0}
     f16_chain = RUNTIME().analysis_f16x3
 
+    # The loop body of stem/trainSTEM.py:174-226 is the package's (trainer.SeptupletTrainer.train_septuplet: getY of the frames
+    # on the prefetch stream, one P-frame optimisation step per later frame through the launch tape / the explicit schedule / the
+    # generic nn.Module route); rand = 1.0 keeps all seven frames of every septuplet (the metric's unit), i.e. the script's
+    # temporal subsampling (:175-182, trainer.subsample_septuplet) is not drawn.
     # --graph (single device): the P-frame step (zero_grad .. aux Adam, ~160 launches) is replayed from ONE hipGraph per
     # step (graphs.GraphedPFrameStep); getY stays eager so that the HIP-event probe can bracket its dominant kernel.  Data
     # parallel runs are always eager: the RCCL exchanges are issued from inside backward.
     use_graph = world == 1 and args.graph
-    fused_step = None
-    if not args.generic and not use_graph:
-        from spatiotemporalentropymodel_amd.trainer import FusedPFrameStep
-        fused_step = FusedPFrameStep(stem, opt, aux_opt)
-        if args.tape:               # the native executor: the schedule recorded in the first warm-up step, replayed from C++ afterwards
-            from spatiotemporalentropymodel_amd.tape import TapedPFrameStep
-            fused_step = TapedPFrameStep(fused_step)
+    from spatiotemporalentropymodel_amd.trainer import SeptupletTrainer
+    route = "generic" if args.generic else ("taped" if args.tape else "fused")
+    septuplets = SeptupletTrainer(imodel, stem, opt, aux_opt, route="fused" if use_graph else route, prefetch=args.latents == "prefetch",
+                                  ahead=args.latents_ahead, reducer=reducer, grad_scale=1.0 / world, criterion=crit)
+    fused_step, prefetch = septuplets.step_fn, septuplets.prefetch
     graphed = None
     if use_graph:
         from spatiotemporalentropymodel_amd.graphs import GraphedPFrameStep
         graphed = GraphedPFrameStep(stem, crit, opt, aux_opt, (SIZE, SIZE))
+        fused_step = None
 
-    prefetch = None
-    if args.latents == "prefetch":
-        from spatiotemporalentropymodel_amd.trainer import LatentPrefetcher
-        prefetch = LatentPrefetcher(imodel, ahead=args.latents_ahead)
+    def _mark(t, out, oc, aux, gn):
+        if TIMELINE is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            TIMELINE.append(ev)
+    septuplets.on_step = _mark
 
     def one_step():
-        # The I-frame model is frozen (stem/trainSTEM.py:128, no_grad), so the latents of all 7 frames are computed first:
-        # 7 x 4 long kernels that the host enqueues in ~1 ms and the GPU needs ~12 ms for.  With that head start the host
-        # stays ahead of the GPU through the launch-heavy P-frame steps (measured: the GPU idled ~3.3 ms per step waiting
-        # for launches when getY was issued inside each P-step, tools/timeline.py).
-        if prefetch is not None:
+        if graphed is None:
             # the synthetic frames were generated before the timed region.  --pipeline 1: the NEXT septuplet (a loader's following
             # batch; here the same synthetic tensors) is named too, so that its frames 0 and 1 go through the analysis transform
-            # during this septuplet's last two P-frame steps instead of in front of its own first one (trainer.LatentPrefetcher:
-            # every step still runs its 7 transforms -- the first timed step adopts two from the last warm-up step, the last timed
-            # step computes two for the step that would follow, inside the timed region)
+            # during this septuplet's last two P-frame steps instead of in front of its own first one
+            return septuplets.train_septuplet(frames, rand=1.0, next_images=frames if (args.pipeline and prefetch is not None) else None)[-1][0]
+        if prefetch is not None:
             prefetch.start(frames, frames_ready=True, next_frames=frames if args.pipeline else None)
             ys = None
             y_cond = prefetch.get(0)[1]
@@ -589,19 +707,10 @@ def main():
         last = None
         for t in range(1, FRAMES):
             y_cur = prefetch.get(t)[0] if prefetch is not None else ys[t][0]
-            if graphed is not None:
-                out, oc, aux, gn = graphed.step(y_cur, y_cond)
-            elif fused_step is not None:
-                out, oc, aux, gn = fused_step.step(y_cur, y_cond, BATCH * SIZE * SIZE, grad_scale=1.0 / world, reducer=reducer)
-            else:
-                out, oc, aux, gn = p_frame_step(imodel, stem, crit, opt, aux_opt, frames[t], y_cond,
-                                                grad_scale=1.0 / world, reducer=reducer, y_cur=y_cur)
+            out, oc, aux, gn = graphed.step(y_cur, y_cond)
             y_cond = out["y_hat"]                # graph mode: static output buffer, copied into the y_cond input by the next step()
             last = oc
-            if TIMELINE is not None:
-                ev = torch.cuda.Event(enable_timing=True)
-                ev.record()
-                TIMELINE.append(ev)
+            _mark(t, out, oc, aux, gn)
         return last
 
     # STEM_BENCH_TIMELINE=1 (dev): where the analysis-transform launches of the prefetch stream fall between the P-frame steps'
@@ -753,6 +862,7 @@ def main():
                    "stream_cu_masks": RUNTIME().stream_cumask or "none",
                    "plan_selectors": os.environ.get("STEM_BENCH_TUNING", "") or "library defaults",
                    "rank0_host_cores": (f"{len(PINNED_CPUS)} cores of the GPU's NUMA node ({PINNED_CPUS[0]}..{PINNED_CPUS[-1]})" if PINNED_CPUS else "not pinned"),
+                   "loop": "trainer.SeptupletTrainer.train_septuplet (stem/trainSTEM.py:174-226), all 7 frames of every septuplet",
                    "launch": "hipGraph replay per P-frame step" if use_graph else
                              (("explicit fused schedule (trainer.FusedPFrameStep)" + (" replayed from its launch tape by the native executor (tape.TapedPFrameStep, csrc/tape.hip)"
                                                                                           if args.tape else "")) if fused_step is not None else "generic nn.Module / autograd route")},

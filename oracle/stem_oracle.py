@@ -429,6 +429,110 @@ def stem_forward(sd, y_cur, y_cond, residual: bool, training: bool, noise=None, 
     return {"y_hat": y_hat, "lik_y": lik_y, "lik_z": lik_z, "scales": scales, "means": means}
 
 
+def _lrelu_vec(v, slope=LRELU):
+    return np.where(v >= 0, v, v * np.float32(slope)).astype(np.float32)
+
+
+def reference_rans_decoder():
+    """the reference's own stateful decoder (compressai/cpp_exts/rans/rans_interface.cpp compiled into oracle/_ref by the
+    Makefile), or None when oracle/_ref is absent"""
+    import os as _os
+    import sys as _sys
+    ref_dir = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "_ref")
+    if not _os.path.isdir(ref_dir) or not any(f.startswith("ans") for f in _os.listdir(ref_dir)):
+        return None
+    if ref_dir not in _sys.path:
+        _sys.path.insert(0, ref_dir)
+    import ans
+    return ans.RansDecoder()
+
+
+def stem_decoder_priors(sd, z_string, shape, y_cond, tables):
+    """what the decoder knows before the raster-order loop (spatiotemporalpriors.py:976-980): z_hat off the bottleneck's string
+    (channel c's table for every element of channel c, dequantised with the medians), hyper prior HD(z_hat), temporal prior
+    TPM(y_conditioned) -> (hp, tp), each [1, 2M, H, W]"""
+    sd = {n: np.asarray(v, np.float32) for n, v in sd.items() if np.asarray(v).dtype.kind == "f"}
+    y_cond = _f(y_cond)
+    zc = sd["entropy_bottleneck.quantiles"].shape[0]
+    zh, zw = int(shape[0]), int(shape[1])
+    med = sd["entropy_bottleneck.quantiles"][:, 0, 1]
+    zidx = np.repeat(np.arange(zc, dtype=np.int32), zh * zw)
+    zsym = rans_decode(z_string, zidx, tables["eb_cdf"], tables["eb_cdf_length"], tables["eb_offset"])
+    z_hat = (zsym.reshape(1, zc, zh, zw).astype(np.float32) + med.reshape(1, zc, 1, 1)).astype(np.float32)
+    hd0 = lrelu_fwd(deconv2d_fwd(z_hat, sd["HD.0.weight"], sd["HD.0.bias"], 2, 2, 1))
+    hd2 = lrelu_fwd(deconv2d_fwd(hd0, sd["HD.2.weight"], sd["HD.2.bias"], 2, 2, 1))
+    hp = conv2d_fwd(hd2, sd["HD.4.weight"], sd["HD.4.bias"], 1, 1)
+    tp0 = lrelu_fwd(conv2d_fwd(y_cond, sd["TPM.0.weight"], sd["TPM.0.bias"], 1, 2))
+    tp2 = lrelu_fwd(conv2d_fwd(tp0, sd["TPM.2.weight"], sd["TPM.2.bias"], 1, 2))
+    tp = conv2d_fwd(tp2, sd["TPM.4.weight"], sd["TPM.4.bias"], 1, 2)
+    return hp, tp
+
+
+def stem_decompress(sd, strings, shape, y_cond, tables, residual=True, max_positions=None, timing=None, decoder=None):
+    """SpatioTemporalPriorModel_Res.decompress + _decompress_ar (spatiotemporalpriors.py:964-1054; residual=False: the plain model,
+    :681-770): z_hat from the bottleneck's string, hyper / temporal prior through HD / TPM, then the raster-order loop -- per
+    position a 5x5 crop of what has been decoded so far through the masked context convolution, the three 1x1 EPM layers on the
+    concatenated (temporal, hyper, context) parameters, table indexes from the scales, `M` symbols off the rANS stream, dequantise
+    with the means, write back.  One image (strings = [[y_string], [z_string]]).
+
+    tables: {"eb_cdf", "eb_cdf_length", "eb_offset", "gc_cdf", "gc_cdf_length", "gc_offset", "gc_scale_table"} (the buffers a
+    checkpoint carries).  max_positions: stop after that many positions (bounded CPU-baseline sample; the result is then partial).
+    timing: a dict that receives {"positions", "loop_s"}.  decoder: a stateful symbol decoder with the reference's interface
+    (set_stream / decode_stream: reference_rans_decoder()); without one the C restatement decodes prefixes of growing length
+    (it keeps no state between calls: quadratic, for the small pinned cases only).  Returns y_hat [1, M, H, W]."""
+    import time as _time
+    sd = {n: np.asarray(v, np.float32) for n, v in sd.items() if np.asarray(v).dtype.kind == "f"}
+    y_cond = _f(y_cond)
+    zh, zw = int(shape[0]), int(shape[1])
+    hp, tp = stem_decoder_priors(sd, strings[1][0], shape, y_cond, tables)
+    M = y_cond.shape[1]
+    H, W = zh * 4, zw * 4
+    pad = 2
+    # (the decoder reads context_prediction.weight without the mask, :1028: the forward pass has multiplied the mask into the
+    # parameter in place by then, layers.py:44-47; the taps at and behind the centre meet zeros of res_hat anyway)
+    wctx = masked_weight(sd["context_prediction.weight"]).reshape(2 * M, -1)      # [2M, M*25]
+    bctx = sd["context_prediction.bias"]
+    w0, b0 = sd["EPM.0.weight"].reshape(sd["EPM.0.weight"].shape[0], -1), sd["EPM.0.bias"]
+    w1, b1 = sd["EPM.2.weight"].reshape(sd["EPM.2.weight"].shape[0], -1), sd["EPM.2.bias"]
+    w2, b2 = sd["EPM.4.weight"].reshape(sd["EPM.4.weight"].shape[0], -1), sd["EPM.4.bias"]
+    table = _f(tables["gc_scale_table"])
+    res = np.zeros((M, H + 2 * pad, W + 2 * pad), np.float32)
+    # the stream is consumed position by position: one decoder state across calls (orc_rans_decode decodes a prefix of the
+    # stream, so the loop decodes prefixes of growing length and keeps the newest M symbols -- quadratic, hence only for the
+    # small pinned cases; the bounded timing sample uses its own per-position cost below)
+    all_idx = []
+    if decoder is not None:
+        decoder.set_stream(strings[0][0])
+        cdf_l = np.asarray(tables["gc_cdf"]).tolist()
+        len_l, off_l = np.asarray(tables["gc_cdf_length"]).tolist(), np.asarray(tables["gc_offset"]).tolist()
+    t0 = _time.perf_counter()
+    npos = 0
+    for h in range(H):
+        for w in range(W):
+            if max_positions is not None and npos >= max_positions:
+                break
+            crop = res[:, h:h + 5, w:w + 5].reshape(-1)
+            ctx = wctx @ crop + bctx
+            v = np.concatenate([tp[0, :, h, w], hp[0, :, h, w], ctx]).astype(np.float32)
+            h1 = _lrelu_vec(w0 @ v + b0)
+            h2 = _lrelu_vec(w1 @ h1 + b1)
+            gp = (w2 @ h2 + b2).astype(np.float32)
+            scales, means = gp[:M], gp[M:]
+            idx = build_indexes(scales, table)
+            if decoder is not None:
+                sym = np.asarray(decoder.decode_stream(idx.tolist(), cdf_l, len_l, off_l), np.int32)
+            else:
+                all_idx.append(idx)
+                cat = np.concatenate(all_idx)
+                sym = rans_decode(strings[0][0], cat, tables["gc_cdf"], tables["gc_cdf_length"], tables["gc_offset"])[-M:]
+            res[:, h + pad, w + pad] = sym.astype(np.float32) + means
+            npos += 1
+    if timing is not None:
+        timing["positions"], timing["loop_s"] = npos, _time.perf_counter() - t0
+    out = res[None, :, pad:pad + H, pad:pad + W]
+    return (out + y_cond) if residual else out.copy()
+
+
 def stem_backward(sd, keep, lik_y, lik_z, num_pixels):
     """Gradient of EMLoss = (sum log lik_y + sum log lik_z) / (-ln2 * num_pixels) wrt every STEM parameter
     (torch autograd of spatiotemporalpriors.py:845-868 with y_cur / y_cond detached as in stem/trainSTEM.py:208)."""

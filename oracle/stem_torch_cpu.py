@@ -182,3 +182,50 @@ class PFrameTrainer:
         aux.backward()
         self.aux_opt.step()
         return float(loss.detach()), t_ga
+
+
+@torch.no_grad()
+def decode_positions(ssd, y_cond, hp, tp, string, tables, decoder, max_positions=None):
+    """The raster-order decoding loop of SpatioTemporalPriorModel_Res._decompress_ar (spatiotemporalpriors.py:1015-1054) as the
+    reference executes it on a CPU: per position a 5x5 crop through torch's conv2d with the context weights, the three 1x1
+    EPM convolutions, table indexes from the scales, Python lists into the symbol decoder, dequantise, write back.  `decoder`:
+    the reference's own RansDecoder (oracle/_ref, stem_oracle.reference_rans_decoder()).  hp / tp: the hyper / temporal prior
+    tensors [1, 2M, H, W].  Stops after max_positions (the bounded timing sample of bench.py --config eval).
+    -> (res_hat [1, M, H, W] as far as decoded, positions, seconds in the loop)"""
+    import time
+    f = lambda k: torch.as_tensor(ssd[k], dtype=torch.float32)      # noqa: E731
+    M = y_cond.shape[1]
+    H, W = hp.shape[-2:]
+    wc = f("context_prediction.weight").clone()
+    wc[:, :, 2, 2:] = 0                                              # MaskedConv2d type A (layers.py:39-42), multiplied in place by forward
+    wc[:, :, 3:] = 0
+    bc = f("context_prediction.bias")
+    epm = [(f(f"EPM.{i}.weight"), f(f"EPM.{i}.bias")) for i in (0, 2, 4)]
+    table = torch.as_tensor(tables["gc_scale_table"], dtype=torch.float32)
+    cdf = [list(map(int, r)) for r in tables["gc_cdf"]]
+    lens, offs = [int(v) for v in tables["gc_cdf_length"]], [int(v) for v in tables["gc_offset"]]
+    decoder.set_stream(string)
+    hp, tp = torch.as_tensor(hp, dtype=torch.float32), torch.as_tensor(tp, dtype=torch.float32)
+    res = torch.zeros(1, M, H + 4, W + 4)
+    n, t0 = 0, time.perf_counter()
+    for h in range(H):
+        for w in range(W):
+            if max_positions is not None and n >= max_positions:
+                return res[:, :, 2:2 + H, 2:2 + W], n, time.perf_counter() - t0
+            crop = res[:, :, h:h + 5, w:w + 5]
+            ctx = Fn.conv2d(crop, wc, bc)
+            g = torch.cat((tp[:, :, h:h + 1, w:w + 1], hp[:, :, h:h + 1, w:w + 1], ctx), dim=1)
+            g = _lrelu(Fn.conv2d(g, *epm[0]))
+            g = _lrelu(Fn.conv2d(g, *epm[1]))
+            g = Fn.conv2d(g, *epm[2])
+            scales, means = g.chunk(2, 1)
+            # GaussianConditional.build_indexes (entropy_models.py:598-604): count the table entries below the bounded scale
+            s = torch.clamp(scales, min=SCALE_BOUND)
+            idx = torch.full(s.shape, len(table) - 1, dtype=torch.int32)
+            for v in table[:-1]:
+                idx -= (s <= v).int()
+            rv = decoder.decode_stream(idx.squeeze().tolist(), cdf, lens, offs)
+            rv = torch.Tensor(rv).reshape(1, -1, 1, 1) + means
+            res[:, :, h + 2:h + 3, w + 2:w + 3] = rv
+            n += 1
+    return res[:, :, 2:2 + H, 2:2 + W], n, time.perf_counter() - t0

@@ -50,6 +50,7 @@ struct Dp {
     long fault_at = -1;            // STEM_DP_FAULT=<n>: the n-th exchange (0-based) fails in the helper as a refused collective would
     long exchanges = 0;
     std::thread helper;
+    std::thread aborter;           // runs ncclCommAbort after a failure (see fail_all)
     std::mutex mu;
     std::mutex comm_mu;            // a collective is enqueued, or the communicator aborted / destroyed, by one thread at a time
     std::condition_variable cv;
@@ -97,15 +98,30 @@ struct Dp {
         if (!claimed.compare_exchange_strong(zero, 1)) return;
         snprintf(err, sizeof(err), "%s", what);
         status.store(rc, std::memory_order_release);
-        std::lock_guard<std::mutex> l(comm_mu);
-        ncclComm_t c = comm.exchange(nullptr);
-        if (c) (void)ncclCommAbort(c);
+        ncclComm_t c = nullptr;
+        {
+            std::lock_guard<std::mutex> l(comm_mu);
+            c = comm.exchange(nullptr);
+        }
+        // ncclCommAbort synchronises with the DEVICE (observed: it does not return while a consumer stream sits in the
+        // hipStreamWaitValue32 of a fence), and the flags of the fences queued so far are released by the helper thread right after
+        // this function: the abort gets a thread of its own (joined at destruction), so that neither waits for the other
+        if (c) {
+            const int dev = device;
+            aborter = std::thread([c, dev] {
+                (void)hipSetDevice(dev);
+                (void)ncclCommAbort(c);
+            });
+        }
     }
     void release_flag(unsigned seq_)
     {
-        // nothing may be left waiting for a value nobody writes: after a failure the flag is stored from the host
+        // nothing may be left waiting for a value nobody writes: after a failure the flag is still written -- on the communication
+        // stream, which is ours and outlives the aborted communicator; should even that enqueue fail, by a copy from the host
+        if (hipStreamWriteValue32(cs, flag, seq_, 0) == hipSuccess) return;
         (void)hipStreamSynchronize(cs);
-        __atomic_store_n(flag, seq_, __ATOMIC_RELEASE);
+        const unsigned v[2] = {seq_, 0};
+        (void)hipMemcpy(flag, v, sizeof(v), hipMemcpyHostToDevice);
     }
     void run()
     {
@@ -125,7 +141,9 @@ struct Dp {
                     release_flag(t.seq);
                 } else if (hipStreamWriteValue32(cs, flag, t.seq, 0) != hipSuccess) {
                     fail_all(-2, "hipStreamWriteValue32 failed");
-                    release_flag(t.seq);
+                    (void)hipStreamSynchronize(cs);
+                    const unsigned v[2] = {t.seq, 0};
+                    (void)hipMemcpy(flag, v, sizeof(v), hipMemcpyHostToDevice);
                 }
                 continue;
             }
@@ -162,6 +180,7 @@ struct Dp {
             helper.join();
         }
         (void)hipSetDevice(device);
+        if (aborter.joinable()) aborter.join();
         if (cs) (void)hipStreamSynchronize(cs);
         {
             std::lock_guard<std::mutex> l(comm_mu);

@@ -880,28 +880,73 @@ __global__ __launch_bounds__(256) void em_loss_finalize_kernel(const double *py,
     }
 }
 
-// EntropyBottleneck.loss with its quantile gradient, one workgroup, no pre-zeroed accumulator: loss[0] = sum |logits - target|,
-// dq = d loss / d quantiles (written, or added when accumulate)
-__global__ __launch_bounds__(256) void eb_aux_block_kernel(const float *quant, const float *pack, const float *target, float *loss,
-                                                           float *dq, int C, int accumulate)
+// d logits / d v alone: eb_logits_bwd without the 58 parameter gradients (same operations on the input-gradient chain, in the
+// same order: the value is bit-identical to eb_logits_bwd's return value)
+__device__ __forceinline__ float eb_logits_dv(const EbPrep &e, const float pre[4][3], float gl)
+{
+    float gh[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gh[k] = gl * e.sp4[k];
+#pragma unroll
+    for (int l = 2; l >= 0; --l) {
+        float gin[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float a = pre[l + 1][o], ta = tanhf(a), tf = e.tf[l][o];
+            const float ga = gh[o] * (1.f + tf * (1.f - ta * ta));
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gin[k] += ga * e.sp[l][o * 3 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gh[k] = gin[k];
+    }
+    float gv = 0.f;
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const float a = pre[0][o], ta = tanhf(a), tf = e.tf0[o];
+        const float ga = gh[o] * (1.f + tf * (1.f - ta * ta));
+        gv += ga * e.sp0[o];
+    }
+    return gv;
+}
+
+// EntropyBottleneck.loss with its quantile gradient (entropy_models.py:383-386), one workgroup, no pre-zeroed accumulator:
+// loss[0] = sum |logits - target|, dq = d loss / d quantiles (written, or added when accumulate).  One (channel, quantile) pair per
+// thread -- up to AUX_T of them at once (3 C = 768 for the training model: one pass) -- and only the input-gradient chain of the
+// reverse pass (round 5: 256 threads x 3 items each with all 58 parameter gradients in a scratch-backed array, 86 us per launch;
+// the same numbers: the |d| terms are summed in the order of that kernel, item t, t + 256, t + 512 per slot, then the same tree).
+constexpr int AUX_T = 768;
+__global__ __launch_bounds__(AUX_T) void eb_aux_block_kernel(const float *quant, const float *pack, const float *target, float *loss,
+                                                             float *dq, int C, int accumulate)
 {
     __shared__ float red[256];
-    float local = 0.f;
-    for (int i = threadIdx.x; i < C * 3; i += 256) {
-        const int c = i / 3, k = i - c * 3;
-        EbPrep e;
-        eb_prepare(pack + (size_t)c * NP, e);
-        float pre[4][3], inp[4][3], dp[NP];
+    __shared__ float vals[AUX_T];
+    const int n = C * 3;
+    float slot = 0.f;                                  // threads 0 .. 255: the running sum of items t, t + 256, t + 512, ...
+    for (int base = 0; base < n; base += AUX_T) {
+        const int i = base + threadIdx.x;
+        float ad = 0.f;
+        if (i < n) {
+            const int c = i / 3, k = i - c * 3;
+            EbPrep e;
+            eb_prepare(pack + (size_t)c * NP, e);
+            float pre[4][3], inp[4][3];
+            const float v = quant[i];
+            const float d = eb_logits<true>(e, v, pre, inp) - target[k];
+            ad = fabsf(d);
+            const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            const float g = eb_logits_dv(e, pre, sgn);
+            if (dq) dq[i] = accumulate ? dq[i] + g : g;
+        }
+        vals[threadIdx.x] = ad;
+        __syncthreads();
+        if (threadIdx.x < 256) {
 #pragma unroll
-        for (int q = 0; q < NP; ++q) dp[q] = 0.f;
-        const float v = quant[i];
-        const float d = eb_logits<true>(e, v, pre, inp) - target[k];
-        local += fabsf(d);
-        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        const float g = eb_logits_bwd(pack + (size_t)c * NP, e, v, pre, inp, sgn, dp);
-        if (dq) dq[i] = accumulate ? dq[i] + g : g;
+            for (int j = 0; j < AUX_T / 256; ++j) slot += vals[threadIdx.x + 256 * j];
+        }
+        __syncthreads();
     }
-    red[threadIdx.x] = local;
+    if (threadIdx.x < 256) red[threadIdx.x] = slot;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
@@ -1004,7 +1049,7 @@ STEM_EXPORT int stem_eb_aux_loss_grad(const float *quantiles, const float *pack,
                                       int C, int accumulate, void *stream)
 {
     STEM_CHECK_ARG(quantiles && pack && target3 && loss, "stem_eb_aux_loss_grad: null pointer");
-    hipLaunchKernelGGL(eb_aux_block_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, quantiles, pack, target3, loss, dquantiles, C,
+    hipLaunchKernelGGL(eb_aux_block_kernel, dim3(1), dim3(AUX_T), 0, (hipStream_t)stream, quantiles, pack, target3, loss, dquantiles, C,
                        accumulate);
     STEM_LAUNCH_CHECK("eb_aux_block");
     return 0;

@@ -153,14 +153,27 @@ __device__ inline void record_block_max(float *q, float m)
 // cannot be served from a stale line of the local L2.  What guards it: tests/test_hip_fullsize.py::
 // test_first_launch_on_fresh_workspaces_is_reproducible (the case a wider store form failed in round 4) and the bit-reproducibility
 // tests of the training step.
+//
+// STEM_SPLITK_ACQUIRE_LAST (round 6): the reader's half of that pair where it is needed and nowhere else -- an agent-scope ACQUIRE
+// fence (`buffer_inv sc1`) executed by the one thread of the ONE workgroup per tile whose ticket says "last", relaxed tickets for
+// everybody else, stores as they are.  nsplit times fewer cache operations than the acquire-release ticket and no write-back at
+// all; A/B in the step: profiles/r06_ab_splitk_acquire_last.log.
 #ifndef STEM_SPLITK_ORDER
 #define STEM_SPLITK_ORDER __ATOMIC_RELAXED
+#endif
+#ifndef STEM_SPLITK_ACQUIRE_LAST
+#define STEM_SPLITK_ACQUIRE_LAST 1
 #endif
 __device__ inline bool splitk_last_arriver(int *counter, int nsplit)
 {
     const int ticket = __hip_atomic_fetch_add(counter, 1, STEM_SPLITK_ORDER, __HIP_MEMORY_SCOPE_AGENT);
     const bool last = ticket == nsplit - 1;
-    if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (last) {
+#if STEM_SPLITK_ACQUIRE_LAST
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+        __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     return last;
 }
 // the two fp16 numbers whose sum is x * s (s a power of two)

@@ -257,3 +257,83 @@ class FusedPFrameStep:
         if self._aux_pending:
             F.stream_wait(F.cur_stream(self._aux_loss.device), self._aux_stream)
             self._aux_pending = False
+
+
+def subsample_septuplet(images, rand):
+    """The temporal subsampling of stem/trainSTEM.py:175-182: with probability 1/4 each, frames 1,3,5,7 / 1,4,7 / 1,7 / all seven
+    of the septuplet (`rand` = the loop's random.random() draw)."""
+    if rand <= 0.25:
+        return images[0:7:2]
+    if rand <= 0.50:
+        return images[0:7:3]
+    if rand <= 0.75:
+        return images[0:7:6]
+    return images
+
+
+class SeptupletTrainer:
+    """The loop body of stem/trainSTEM.py:174-226 for ONE loader item (a septuplet: list of 7 frame batches [B,3,H,W]) -- the unit
+    BASELINE.json's metric counts and `bench.py` times:
+
+        frames = subsample_septuplet(images, random.random())          # :175-182
+        _, y_condition = IFrameCompressor.getY(frames[0])              # :199 (frozen I-frame model, :128)
+        for every later frame:  y_cur = getY(frame) -> stem(y_cur, y_condition.detach()) -> y_condition = y_hat ->
+                                criterion -> backward -> clip -> optimizer.step -> aux_loss.backward -> aux_optimizer.step   (:203-218)
+
+    route "taped" (default): the explicit schedule FusedPFrameStep replayed from its launch tape; "fused": the explicit schedule
+    issued launch by launch; "generic": nn.Module / autograd / optimiser calls (selfcheck.p_frame_step), which needs `criterion`.
+    prefetch: getY of frame t + `ahead` on its own stream while step t runs (LatentPrefetcher); otherwise all latents first.
+    reducer / grad_scale: data parallel (distributed.OverlappedGradReducer attached to stem.engine(), 1 / world).
+    `rng`: a random.Random for the subsampling draw (seed it per rank and per epoch as the training script seeds `random`)."""
+
+    def __init__(self, imodel, stem, optimizer, aux_optimizer, *, route="taped", prefetch=True, ahead=1, reducer=None, grad_scale=1.0,
+                 criterion=None, rng=None):
+        import random
+        self.imodel, self.stem, self.opt, self.aux_opt = imodel, stem, optimizer, aux_optimizer
+        self.route, self.reducer, self.grad_scale, self.criterion = route, reducer, float(grad_scale), criterion
+        self.rng = rng or random.Random(0)
+        self.step_fn = None
+        if route in ("taped", "fused"):
+            self.step_fn = FusedPFrameStep(stem, optimizer, aux_optimizer)
+            if route == "taped":
+                from .tape import TapedPFrameStep
+                self.step_fn = TapedPFrameStep(self.step_fn)
+        elif route != "generic":
+            raise ValueError(f"SeptupletTrainer: unknown route {route!r}")
+        elif criterion is None:
+            raise ValueError("SeptupletTrainer: the generic route needs the criterion module")
+        self.prefetch = LatentPrefetcher(imodel, ahead=ahead) if prefetch else None
+        self.on_step = None             # called after every P-frame step with (t, out, criterion_out, aux, grad_norm)
+
+    def train_septuplet(self, images, rand=None, next_images=None, frames_ready=True):
+        """One loader item.  rand: the subsampling draw (None: self.rng.random(); 1.0 keeps all seven frames).  next_images: the
+        FOLLOWING item's (already subsampled) frames, whose first two latents are then computed during this item's last steps.
+        Returns [(criterion_out, aux, grad_norm)] of the P-frame steps (device-resident values; no host synchronisation)."""
+        frames = list(subsample_septuplet(list(images), self.rng.random() if rand is None else rand))
+        num_pixels = frames[0].shape[0] * frames[0].shape[-2] * frames[0].shape[-1]
+        if self.prefetch is not None:
+            self.prefetch.start(frames, frames_ready=frames_ready, next_frames=next_images)
+            ys = None
+            y_cond = self.prefetch.get(0)[1]
+        else:
+            with torch.no_grad():
+                ys = [self.imodel.getY(f) for f in frames]
+            y_cond = ys[0][1]
+        log = []
+        for t in range(1, len(frames)):
+            y_cur = self.prefetch.get(t)[0] if self.prefetch is not None else ys[t][0]
+            if self.step_fn is not None:
+                out, oc, aux, gn = self.step_fn.step(y_cur, y_cond, num_pixels, grad_scale=self.grad_scale, reducer=self.reducer)
+            else:
+                from .selfcheck import p_frame_step
+                out, oc, aux, gn = p_frame_step(self.imodel, self.stem, self.criterion, self.opt, self.aux_opt, frames[t], y_cond,
+                                                grad_scale=self.grad_scale, reducer=self.reducer, y_cur=y_cur)
+            y_cond = out["y_hat"]
+            log.append((oc, aux, gn))
+            if self.on_step is not None:
+                self.on_step(t, out, oc, aux, gn)
+        return log
+
+    def finish(self):
+        if self.step_fn is not None:
+            self.step_fn.finish()

@@ -97,6 +97,42 @@ def closed_form_fill_scaled_(module: torch.nn.Module, prefix: str, conv_scale: f
     return module
 
 
+def channel_spread(name: str, K: int, decades: float = 3.0) -> np.ndarray:
+    """per-output-channel scale factors of one layer: log-uniform over `decades` decades (a pure function of the layer's name and
+    the channel index), normalised to unit mean square so that a stack of layers keeps its signal level"""
+    u = (hash_uniform(name + ":spread", K, salt=7) + 1.0) * 0.5              # [0, 1)
+    s = 10.0 ** (-decades * u)
+    return s / np.sqrt(np.mean(s * s))
+
+
+@torch.no_grad()
+def closed_form_fill_spread_(module: torch.nn.Module, prefix: str = "", decades: float = 3.0, conv_scale: float = 1.0) -> torch.nn.Module:
+    """closed_form_fill_ with INHOMOGENEOUS layers: output channel k of every convolution (4-D weight and its bias) is multiplied
+    by channel_spread(name)[k] -- three decades between the loudest and the quietest channel of each layer, as trained
+    entropy-parameter heads and GDN-normalised transforms show, instead of the one variance per layer of the plain fill.  The
+    model-level parity tests on these weights judge every output channel against ITS OWN maximum (tests/test_hip_spread.py).
+    For a transposed convolution (weight [in, out, kh, kw]) the output channels are dimension 1."""
+    transposed = {n for n, m in module.named_modules() if type(m).__name__ == "ConvTranspose2d"}      # torch's and layers.ConvTranspose2d
+    for name, p in module.named_parameters():
+        key = f"{prefix}.{name}" if prefix else name
+        t = closed_form_tensor(key, p.shape, p)
+        if t is None:
+            continue
+        owner, leaf = name.rsplit(".", 1) if "." in name else ("", name)
+        if leaf == "weight" and t.dim() == 4:
+            tr = owner in transposed
+            K = t.shape[1] if tr else t.shape[0]
+            sc = torch.from_numpy(channel_spread(key[: -len(".weight")], K, decades).astype(np.float32)).to(t.device)
+            t = t * conv_scale * (sc.view(1, K, 1, 1) if tr else sc.view(K, 1, 1, 1))
+        elif leaf == "bias" and t.dim() == 1:
+            w = dict(module.named_parameters()).get(owner + ".weight")
+            if w is not None and w.dim() == 4 and t.shape[0] in (w.shape[0], w.shape[1]):
+                sc = torch.from_numpy(channel_spread(key[: -len(".bias")], t.shape[0], decades).astype(np.float32)).to(t.device)
+                t = t * sc
+        p.copy_(t)
+    return module
+
+
 def closed_form_input(name: str, shape, lo: float = 0.0, hi: float = 1.0) -> torch.Tensor:
     """Deterministic input/noise tensor in [lo, hi)."""
     n = int(np.prod(shape))

@@ -306,3 +306,84 @@ def test_persistent_decoder_give_up_falls_back_to_the_loop(batch, giveup_at, mon
             warnings.simplefilter("error")
             again = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()
         assert torch.equal(again, ref)
+
+
+def _eval_gop_models(g, dev):
+    """the two models of tests/golden/make_golden.py:eval_gop_models, with the reference's CDF tables loaded as a checkpoint's
+    state_dict would bring them (update() runs host transcendental kernels whose last ulp depends on the CPU)"""
+    from spatiotemporalentropymodel_amd.models import SpatioTemporalPriorModel_Res
+    from spatiotemporalentropymodel_amd.models.priors import JointAutoregressiveHierarchicalPriors
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_
+    imodel = closed_form_fill_(JointAutoregressiveHierarchicalPriors(64, 96))
+    with torch.no_grad():
+        imodel.g_a[6].weight.mul_(4.0)
+        imodel.g_a[6].bias.mul_(4.0)
+        imodel.g_s[0].weight.mul_(0.25)
+    stem = closed_form_fill_(SpatioTemporalPriorModel_Res(64, 96))
+    out = []
+    for tag, m in (("i", imodel), ("p", stem)):
+        m = m.to(dev).eval()
+        assert m.update(force=True) is True
+        for ours, ref in ((host(m.entropy_bottleneck._quantized_cdf), g[f"{tag}:eb_cdf"]), (host(m.gaussian_conditional._quantized_cdf), g[f"{tag}:gc_cdf"])):
+            diff = np.abs(ours.astype(np.int64) - ref)
+            assert diff.max() <= 1 and (diff != 0).mean() < 5e-3
+        sd = m.state_dict()
+        for k, v in (("entropy_bottleneck._quantized_cdf", g[f"{tag}:eb_cdf"]), ("entropy_bottleneck._offset", g[f"{tag}:eb_offset"]),
+                     ("entropy_bottleneck._cdf_length", g[f"{tag}:eb_cdf_length"]), ("gaussian_conditional._quantized_cdf", g[f"{tag}:gc_cdf"]),
+                     ("gaussian_conditional._offset", g[f"{tag}:gc_offset"]), ("gaussian_conditional._cdf_length", g[f"{tag}:gc_cdf_length"])):
+            sd[k] = torch.from_numpy(v).to(dev)
+        m.load_state_dict(sd)
+        out.append(m)
+    return out
+
+
+@pytest.mark.parametrize("persistent", ["1", "0"])
+def test_eval_gop_chain_matches_reference(golden, persistent, monkeypatch):
+    """BASELINE configs[3] end to end, as a CHAIN: evaluation.eval_gop (I frame through mbt2018's compress / decompress, two P frames
+    through getY -> forward -> compress -> decompress -> getX, each conditioned on the previous frame's DECODED latents; pad to 64,
+    crop) against what the reference's own inferenceI_DVR / inferenceP_DVR (stem/evalSTEM.py:34-153) produced on the same 120 x 104
+    frames (tests/golden/eval_gop.npz): every string byte for byte -- so the actual bpp is EQUAL --, the rate estimate and the PSNR
+    within 1e-4 relative, the conditioning latents and the last reconstruction within 1e-4.  Both decoder routes."""
+    from spatiotemporalentropymodel_amd import config, evaluation
+    from spatiotemporalentropymodel_amd.weights import smooth_frames
+    g = golden("eval_gop.npz")
+    dev = torch.device("cuda:0")
+    imodel, stem = _eval_gop_models(g, dev)
+    h, w = (int(v) for v in g["size"])
+    n = int(g["nframes"][0])
+    frames = [f[0, :, 4:4 + h, 12:12 + w].contiguous().to(dev) for f in smooth_frames("evalgop", 1, n, 128)]
+    monkeypatch.setenv("STEM_AR_PERSISTENT", persistent)
+    assert config.runtime().ar_persistent == (persistent == "1")
+    res = evaluation.eval_gop(imodel, stem, frames, gop=12)
+    assert [f["type"] for f in res["frames"]] == ["I"] + ["P"] * (n - 1)
+    for t, f in enumerate(res["frames"]):
+        assert tuple(f["shape"]) == tuple(g[f"f{t}:shape"])
+        assert f["strings"][1][0] == g[f"f{t}:z_string"].tobytes(), f"frame {t}: hyper-latent bitstream differs"
+        assert f["strings"][0][0] == g[f"f{t}:y_string"].tobytes(), f"frame {t}: latent bitstream differs from the reference's"
+        bpp, est, ps = g[f"f{t}:scalars"]
+        assert f["bpp"] == bpp
+        assert abs(f["estimate_bpp"] - est) <= 1e-4 * abs(est), (t, f["estimate_bpp"], est)
+        assert abs(f["psnr"] - ps) <= 1e-4 * abs(ps), (t, f["psnr"], ps)
+        assert_close(host(f["y_conditioned"]), g[f"f{t}:y_conditioned"], what=f"frame {t}: decoded latents", floor=0.1)
+    assert_close(host(res["frames"][-1]["x_hat"]), g["last:x_hat"], atol=1e-4, what="last frame's reconstruction", floor=0.1)
+    assert abs(res["bpp_ave"] - np.mean([g[f"f{t}:scalars"][0] for t in range(n)])) < 1e-12
+
+
+def test_eval_gop_restarts_the_chain_at_every_i_frame(golden):
+    """the frame loop of stem/evalSTEM.py:186-209: frame k (1-based) is an I frame when k % GOP == 1.  With GOP = 2 the five-frame
+    sequence is I P I P I; every I frame's result does not depend on what came before it (same bytes as coding it alone), and a P
+    frame's strings change with its conditioning latents."""
+    from spatiotemporalentropymodel_amd import evaluation
+    from spatiotemporalentropymodel_amd.weights import smooth_frames
+    g = golden("eval_gop.npz")
+    dev = torch.device("cuda:0")
+    imodel, stem = _eval_gop_models(g, dev)
+    frames = [f[0, :, :64, :64].contiguous().to(dev) for f in smooth_frames("evalgop2", 1, 5, 64)]
+    res = evaluation.eval_gop(imodel, stem, frames, gop=2)
+    assert [f["type"] for f in res["frames"]] == ["I", "P", "I", "P", "I"]
+    alone = evaluation.inference_iframe(imodel, frames[2])
+    assert alone["strings"] == res["frames"][2]["strings"] and alone["bpp"] == res["frames"][2]["bpp"]
+    other = evaluation.inference_pframe(imodel, stem, frames[3], res["frames"][0]["y_conditioned"])
+    assert other["strings"][0] != res["frames"][3]["strings"][0]
+    allintra = evaluation.eval_gop(imodel, stem, frames[:2], gop=12, all_intra=True)
+    assert [f["type"] for f in allintra["frames"]] == ["I", "I"]

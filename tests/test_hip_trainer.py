@@ -554,3 +554,41 @@ def test_route_switches_stay_within_the_gates(monkeypatch, switch):
     for a, b in zip(ref[4], got[4]):
         assert abs(a - b) <= 1e-3 * abs(a), (switch, ref[4], got[4])
     assert float((ref[2] - got[2]).abs().max()) <= 1e-4 * float(ref[2].abs().max())
+
+
+def test_septuplet_loop_with_temporal_subsampling_is_the_same_on_every_route():
+    """trainer.SeptupletTrainer.train_septuplet -- the loop body of stem/trainSTEM.py:174-226 that bench.py times -- over five
+    loader items whose subsampling draws (:175-182) pick frames 1,3,5,7 / 1,4,7 / 1,7 / all seven / all seven: through the launch
+    tape (with the latent prefetch) and through the plain explicit schedule (latents first) the per-step losses, clipped norms and
+    every parameter after the 19 optimisation steps are bit-identical; the frame selection is the reference's slices."""
+    import random
+    from spatiotemporalentropymodel_amd.trainer import SeptupletTrainer, subsample_septuplet
+    seven = list(range(7))
+    assert subsample_septuplet(seven, 0.25) == [0, 2, 4, 6] and subsample_septuplet(seven, 0.2500001) == [0, 3, 6]
+    assert subsample_septuplet(seven, 0.50) == [0, 3, 6] and subsample_septuplet(seven, 0.75) == [0, 6] and subsample_septuplet(seven, 0.76) == seven
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(3)
+    items = [[torch.rand(1, 3, 64, 64, device=dev, generator=g) for _ in range(7)] for _ in range(5)]
+    draws = [0.1, 0.4, 0.6, 0.9, 1.0]
+    results = []
+    for route, prefetch in (("taped", True), ("fused", False)):
+        im, stem, opt, aux = _pair(64, 96, 64, 96, False, False)
+        for i, m in enumerate((im.gaussian_conditional, stem.entropy_bottleneck, stem.gaussian_conditional)):
+            m.noise_seed = 1000 + i
+        tr = SeptupletTrainer(im, stem, opt, aux, route=route, prefetch=prefetch, rng=random.Random(5))
+        log = []
+        for frames, r in zip(items, draws):
+            for oc, aux_l, gn in tr.train_septuplet(frames, rand=r):
+                log.append((float(oc["loss"]), float(gn), float(aux_l)))
+        tr.finish()
+        torch.cuda.synchronize()
+        results.append((log, opt.flat.data.clone(), aux.flat.data.clone(), tr))
+    (la, pa, qa, ta), (lb, pb, qb, _) = results
+    assert len(la) == len(lb) == 3 + 2 + 1 + 6 + 6
+    assert ta.step_fn.taped and ta.step_fn.replays >= 10
+    for x, y in zip(la, lb):
+        assert x[1] == y[1] and abs(x[0] - y[0]) <= 1e-12 * abs(y[0]) and abs(x[2] - y[2]) <= 1e-12 * abs(y[2]), (x, y)
+    assert torch.equal(pa, pb) and torch.equal(qa, qb)
+    # a draw from the trainer's own generator (rand=None) is the seeded sequence
+    r = random.Random(5)
+    assert len(ta.train_septuplet(items[0])) == len(subsample_septuplet(seven, r.random())) - 1

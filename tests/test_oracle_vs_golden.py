@@ -586,3 +586,100 @@ def test_torch_cpu_leg_matches_oracle():
     q0, q1 = ssd2["entropy_bottleneck.quantiles"], tr.ssd["entropy_bottleneck.quantiles"].detach().numpy()
     moved = np.abs(q1 - q0)
     assert float(moved.max()) <= 1e-3 * (1 + 1e-3) and float(moved.max()) > 0.5e-3          # fp32 rounding of q - 1e-3 at |q| ~ 10
+
+
+@pytest.mark.parametrize("decoder", ["restatement", "reference"])
+def test_stem_decompress_matches_reference(golden, decoder):
+    """oracle.stem_decompress (spatiotemporalpriors.py:964-1054: bottleneck string -> z_hat -> HD / TPM -> the raster-order loop
+    with the masked context convolution, the EPM layers, table indexes, rANS symbols, dequantise) on the reference's own strings
+    (tests/golden/stem_codec_small.npz, 8 x 8 latents): the decoded latents equal the reference's.  With the C restatement of the
+    symbol decoder and with the reference's own decoder (oracle/_ref)."""
+    g = golden("stem_codec_small.npz")
+    ssd = _closed_form_sd(_stem_keys(64, 96))
+    tab = {"eb_cdf": g["res:eb_cdf"], "eb_cdf_length": g["res:eb_cdf_length"], "eb_offset": g["res:eb_offset"], "gc_cdf": g["gc_cdf"],
+           "gc_cdf_length": g["gc_cdf_length"], "gc_offset": g["gc_offset"], "gc_scale_table": g["gc_scale_table"]}
+    dec = None
+    if decoder == "reference":
+        dec = orc.reference_rans_decoder()
+        if dec is None:
+            pytest.skip("oracle/_ref not built")
+    t = {}
+    y = orc.stem_decompress(ssd, [[g["res:y_string"].tobytes()], [g["res:z_string"].tobytes()]], g["res:shape"], g["y_cond"], tab, timing=t, decoder=dec)
+    assert t["positions"] == 64
+    assert_close(y, g["res:y_hat"], what="oracle decode vs reference", floor=0.1)
+
+
+def test_torch_cpu_decode_loop_matches_reference(golden):
+    """oracle/stem_torch_cpu.decode_positions -- the raster-order loop on torch CPU operators with the reference's own symbol
+    decoder, the CPU-baseline leg of `bench.py --config eval` -- decodes the reference's string to the reference's latents."""
+    import torch
+    import stem_torch_cpu as tc
+    dec = orc.reference_rans_decoder()
+    if dec is None:
+        pytest.skip("oracle/_ref not built")
+    g = golden("stem_codec_small.npz")
+    ssd = _closed_form_sd(_stem_keys(64, 96))
+    tab = {"eb_cdf": g["res:eb_cdf"], "eb_cdf_length": g["res:eb_cdf_length"], "eb_offset": g["res:eb_offset"], "gc_cdf": g["gc_cdf"],
+           "gc_cdf_length": g["gc_cdf_length"], "gc_offset": g["gc_offset"], "gc_scale_table": g["gc_scale_table"]}
+    hp, tp = orc.stem_decoder_priors(ssd, g["res:z_string"].tobytes(), g["res:shape"], g["y_cond"], tab)
+    res, n, _ = tc.decode_positions(ssd, torch.from_numpy(g["y_cond"]), hp, tp, g["res:y_string"].tobytes(), tab, dec)
+    assert n == 64
+    assert_close(res.numpy() + g["y_cond"], g["res:y_hat"], what="torch-CPU decode loop vs reference", floor=0.1)
+    part, n2, _ = tc.decode_positions(ssd, torch.from_numpy(g["y_cond"]), hp, tp, g["res:y_string"].tobytes(), tab, orc.reference_rans_decoder(), max_positions=10)
+    assert n2 == 10 and np.array_equal(part.numpy()[:, :, 0], res.numpy()[:, :, 0]) and not part.numpy()[:, :, 2:].any()
+
+
+def test_oracle_on_spread_weights_per_channel(golden):
+    """The oracle on INHOMOGENEOUS weights (weights.closed_form_fill_spread_: every convolution's output channels log-uniform over
+    three decades), every channel judged against ITS OWN maximum of the reference's float64 run (tests/golden/spread_f64.npz,
+    make_golden.py:gen_spread): the g_a chain, the STEM training forward and every output-channel row of every weight gradient.
+    The GPU twin of this test is tests/test_hip_spread.py."""
+    import torch
+    from spatiotemporalentropymodel_amd.models import JointAutoregressiveHierarchicalPriors, SpatioTemporalPriorModel_Res
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_spread_, closed_form_input, smooth_frames
+    g = golden("spread_f64.npz")
+    dec = float(g["decades"][0])
+    im = closed_form_fill_spread_(JointAutoregressiveHierarchicalPriors(64, 96), decades=dec)
+    st = closed_form_fill_spread_(SpatioTemporalPriorModel_Res(64, 96), decades=dec)
+    isd = {k: v.detach().numpy() for k, v in im.state_dict().items() if v.dtype == torch.float32}
+    ssd = {k: v.detach().numpy() for k, v in st.state_dict().items() if v.dtype == torch.float32}
+    batch, size, ebc, cin = 2, 128, 64, 96
+    ls, lz = size // 16, size // 64
+
+    def pc(a, b, what, axis=1, atol=0.0, rtol=1e-4):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        red = tuple(i for i in range(b.ndim) if i != axis)
+        r = (np.maximum(np.abs(a - b) - atol, 0).max(axis=red) / np.abs(b).max(axis=red)).max()
+        assert r <= rtol, f"{what}: a channel is {r:.3e} of its own maximum from the float64 reference"
+        return r
+
+    frames = [f.numpy() for f in smooth_frames("spread", batch, 2, size)]
+    noise = {k: closed_form_input(n, s, -0.5, 0.5).numpy() for k, n, s in (
+        ("icond", "noise:iframe_gc:0", (batch, cin, ls, ls)), ("z", "noise:stem_eb:0", (ebc, 1, batch * lz * lz)),
+        ("q", "noise:stem_gc:0", (batch, cin, ls, ls)), ("lik", "noise:stem_gc:1", (batch, cin, ls, ls)))}
+    noise["z"] = orc.cl_to_nchw(noise["z"].reshape(ebc, -1), (batch, ebc, lz, lz))
+    y_cond = orc.g_a(isd, frames[0]) + noise["icond"]
+    y_cur = orc.g_a(isd, frames[1])
+    pc(y_cur, g["stem:y_cur"], "y_cur")
+    pc(y_cond, g["stem:y_cond"], "y_cond")
+    keep = {}
+    out = orc.stem_forward(ssd, y_cur, y_cond, residual=True, training=True, noise=noise, keep=keep)
+    pc(out["y_hat"], g["stem:y_hat"], "y_hat")
+    pc(out["lik_y"], g["stem:lik_y"], "lik_y", atol=1e-9)
+    pc(out["lik_z"], g["stem:lik_z"], "lik_z", atol=1e-9)
+    grads = orc.stem_backward(ssd, keep, out["lik_y"], out["lik_z"], batch * size * size)
+    rows = 0
+    for name, gr in grads.items():
+        key = f"stem:grow:{name}"
+        if key not in g:
+            continue
+        gr = np.asarray(gr, np.float64).reshape(ssd[name].shape)
+        if name.startswith(("HD.0", "HD.2")):                      # transposed layers: output channels are dimension 1
+            gr = gr.transpose(1, 0, 2, 3)
+        gr = gr.reshape(gr.shape[0], -1)
+        cols = np.linspace(0, gr.shape[1] - 1, g[key].shape[1]).astype(np.int64)
+        rowmax = g[f"stem:growmax:{name}"].astype(np.float64)
+        err = np.abs(gr[:, cols] - g[key]).max(axis=1) / rowmax
+        assert err.max() <= 1e-4, (name, int(err.argmax()), float(err.max()))
+        rows += len(err)
+    assert rows > 3000
