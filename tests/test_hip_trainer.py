@@ -577,9 +577,11 @@ def test_septuplet_loop_with_temporal_subsampling_is_the_same_on_every_route():
             m.noise_seed = 1000 + i
         tr = SeptupletTrainer(im, stem, opt, aux, route=route, prefetch=prefetch, rng=random.Random(5))
         log = []
+        # a replayed step returns the recorded step's static buffers (tape.TapedPFrameStep): values are read step by step, as a
+        # training loop's logging does (stem/trainSTEM.py:220-224), not after the item
+        tr.on_step = lambda t, out, oc, aux_l, gn: log.append((float(oc["loss"]), float(gn), float(aux_l)))
         for frames, r in zip(items, draws):
-            for oc, aux_l, gn in tr.train_septuplet(frames, rand=r):
-                log.append((float(oc["loss"]), float(gn), float(aux_l)))
+            assert len(tr.train_septuplet(frames, rand=r)) == len(subsample_septuplet(seven, r)) - 1
         tr.finish()
         torch.cuda.synchronize()
         results.append((log, opt.flat.data.clone(), aux.flat.data.clone(), tr))
