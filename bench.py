@@ -427,17 +427,25 @@ def _cpu_baseline_eval(stem, enc, y_cond, y_hat_gpu, budget_s=15.0):
         per = tried[best]
         npos = int(max(64, min(H * W, budget_s / per)))
         res, n, dt = tc.decode_positions(ssd, yc, hp, tp, enc["strings"][0][0], tables, orc.reference_rans_decoder(), max_positions=npos)
+        # The sample against the GPU's decode of the same string, row by row.  The two evaluate the scales in different fp32 orders: a
+        # scale within fp32 noise of a table threshold picks another CDF on one side, after which the two rANS decoders read different
+        # symbols for the rest of the image (the reference warns about exactly this between its own CPU and GPU runs,
+        # spatiotemporalpriors.py:966-970).  Reported: how many leading rows agree to 1e-4, and the worst difference inside them.
         rows = n // W                                        # complete rows decoded by the sample
         got = (res[:, :, :rows] + yc[:, :, :rows]).numpy()
         ref = y_hat_gpu[:, :, :rows].float().cpu().numpy()
-        err = float(np.abs(got - ref).max() / max(float(np.abs(ref).max()), 1e-30)) if rows else None
+        scale = max(float(np.abs(ref).max()), 1e-30) if rows else 1.0
+        row_err = np.abs(got - ref).max(axis=(0, 1, 3)) / scale if rows else np.zeros(0)
+        agree = int(np.argmax(row_err > 1e-4)) if (row_err > 1e-4).any() else rows
+        err = float(row_err[:agree].max()) if agree else None
     finally:
         torch.set_num_threads(old)
     per = dt / n
     return {"value": 1.0 / (per * H * W), "unit": "frames/s", "cores": best, "kind": "torch-cpu", "cpu_model": _cpu_model(), "host_physical_cores": cores,
             "us_per_position_by_threads": {str(k): v * 1e6 for k, v in tried.items()},
             "positions_timed": n, "seconds": dt, "us_per_position": per * 1e6, "positions_per_frame": H * W,
-            "decode_loop_s_per_frame_extrapolated": per * H * W, "sample_rows_vs_gpu_max_rel_diff": err,
+            "decode_loop_s_per_frame_extrapolated": per * H * W, "sample_rows": rows, "sample_rows_agreeing_with_gpu": agree,
+            "agreeing_rows_max_rel_diff": err,
             "sample": f"the first {n} of {H * W} positions of one 1080p P frame's raster-order decoding loop (spatiotemporalpriors.py:1015-1054) on torch "
                       f"{torch.__version__} CPU operators, {best} threads (the fastest of {sorted(tried)} on this {cores}-core host), with the reference's own RansDecoder (oracle/_ref): {per * 1e6:.0f} us per position "
                       f"-> {per * H * W:.1f} s for the loop of one frame; value = 1 / that (decode loop ONLY: the reference's encoder walks the same loop, "
@@ -461,6 +469,13 @@ def bench_eval(args):
     torch.cuda.set_device(dev)
     Hh, Ww, GOP = args.eval_height, args.eval_width, args.eval_gop
     imodel = closed_form_fill_(models["mbt2018"](quality=4)).to(dev).eval()
+    if args.eval_latent_scale != 1.0:
+        # a lower operating point without trained weights: the last analysis layer scaled down (and the first synthesis layer up), so
+        # that most of a position's 192 symbols are zero as at a trained model's rates; the arithmetic per position is unchanged
+        with torch.no_grad():
+            imodel.g_a[6].weight.mul_(args.eval_latent_scale)
+            imodel.g_a[6].bias.mul_(args.eval_latent_scale)
+            imodel.g_s[0].weight.mul_(1.0 / args.eval_latent_scale)
     imodel.update(force=True)
     stem = closed_form_fill_(SpatioTemporalPriorModel_Res()).to(dev).eval()
     stem.update(force=True)
@@ -468,10 +483,10 @@ def bench_eval(args):
     frames = [torch.stack([0.5 + 0.4 * torch.sin((xx + 3 * t) / (40.0 + 10 * c)) * torch.cos((yy + t) / (55.0 - 5 * c)) for c in range(3)])
               for t in range(GOP)]
     for _ in range(args.warmup):
-        evaluation.eval_gop(imodel, stem, frames, gop=GOP)
+        evaluation.eval_gop(imodel, stem, frames, gop=GOP, with_msssim=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    runs = [evaluation.eval_gop(imodel, stem, frames, gop=GOP) for _ in range(args.steps)]
+    runs = [evaluation.eval_gop(imodel, stem, frames, gop=GOP, with_msssim=False) for _ in range(args.steps)]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     per = [f for r in runs for f in r["frames"]]
@@ -487,7 +502,8 @@ def bench_eval(args):
         "config": {"workload": f"configs[3]: evaluation loop of stem/evalSTEM.py (evaluation.eval_gop), one {Ww}x{Hh} sequence, GOP {GOP}: I frame by mbt2018(192,192) "
                                "compress / decompress, P frames by SpatioTemporalPriorModel_Res(256,192) getY / forward / compress / decompress / getX, host rANS; "
                                "closed-form (untrained) weights: every one of the 192 symbols of a position is non-trivial (5.7 bpp), nothing like a trained model's 0.08 bpp",
-                   "frames_per_step": GOP, "p_frames_per_step": GOP - 1, "latent_positions_per_frame": npos,
+                   "frames_per_step": GOP, "p_frames_per_step": GOP - 1, "latent_positions_per_frame": npos, "latent_scale": args.eval_latent_scale,
+                   "not_in_the_timed_loop": "MS-SSIM (evaluation.ms_ssim: a host-side reporting metric of the script, next to the codec path; PSNR is computed)",
                    "decoder": "persistent kernel (csrc/ar_persistent.hip)" if RUNTIME().ar_persistent else "per-position loop (csrc/ar.hip)",
                    "i_frame": {"encode_s": mean([f["encoding_time"] for f in I]), "decode_s": mean([f["decoding_time"] for f in I]), "bpp": mean([f["bpp"] for f in I])},
                    "p_frame": {"encode_s": mean([f["encoding_time"] for f in P]), "decode_s": dec_p, "bpp": mean([f["bpp"] for f in P]),
@@ -589,6 +605,8 @@ def main():
     ap.add_argument("--eval-height", type=int, default=1080)
     ap.add_argument("--eval-width", type=int, default=1920)
     ap.add_argument("--eval-gop", type=int, default=12)
+    ap.add_argument("--eval-latent-scale", type=float, default=1.0, help="--config eval: scale of the I-frame model's last analysis layer (1.0: the closed-form "
+                    "weights as they are, ~5.7 bpp; 0.02: most symbols zero, a trained model's operating range)")
     ap.add_argument("--roi-batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default 10; 2 for --config roi)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 6 for --config roi: the first process that runs the variable-rate models on a box needs about that many iterations before an iteration takes what it takes in every later process -- 1.40 s after two, 0.95-1.0 s after six)")

@@ -880,47 +880,30 @@ __global__ __launch_bounds__(256) void em_loss_finalize_kernel(const double *py,
     }
 }
 
-// d logits / d v alone: eb_logits_bwd without the 58 parameter gradients (same operations on the input-gradient chain, in the
-// same order: the value is bit-identical to eb_logits_bwd's return value)
-__device__ __forceinline__ float eb_logits_dv(const EbPrep &e, const float pre[4][3], float gl)
-{
-    float gh[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) gh[k] = gl * e.sp4[k];
-#pragma unroll
-    for (int l = 2; l >= 0; --l) {
-        float gin[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int o = 0; o < 3; ++o) {
-            const float a = pre[l + 1][o], ta = tanhf(a), tf = e.tf[l][o];
-            const float ga = gh[o] * (1.f + tf * (1.f - ta * ta));
-#pragma unroll
-            for (int k = 0; k < 3; ++k) gin[k] += ga * e.sp[l][o * 3 + k];
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) gh[k] = gin[k];
-    }
-    float gv = 0.f;
-#pragma unroll
-    for (int o = 0; o < 3; ++o) {
-        const float a = pre[0][o], ta = tanhf(a), tf = e.tf0[o];
-        const float ga = gh[o] * (1.f + tf * (1.f - ta * ta));
-        gv += ga * e.sp0[o];
-    }
-    return gv;
-}
-
 // EntropyBottleneck.loss with its quantile gradient (entropy_models.py:383-386), one workgroup, no pre-zeroed accumulator:
-// loss[0] = sum |logits - target|, dq = d loss / d quantiles (written, or added when accumulate).  One (channel, quantile) pair per
-// thread -- up to AUX_T of them at once (3 C = 768 for the training model: one pass) -- and only the input-gradient chain of the
-// reverse pass (round 5: 256 threads x 3 items each with all 58 parameter gradients in a scratch-backed array, 86 us per launch;
-// the same numbers: the |d| terms are summed in the order of that kernel, item t, t + 256, t + 512 per slot, then the same tree).
+// loss[0] = sum |logits - target|, dq = d loss / d quantiles (written, or added when accumulate).
+//   phase 1: the C x 58 parameter transforms (softplus / identity / tanh: most of the arithmetic) once each, spread over the
+//            workgroup, into LDS -- round 5's kernel repeated a channel's 58 transforms for each of its three quantiles;
+//   phase 2: one (channel, quantile) pair per thread, AUX_T pairs per pass (3 C = 768 for the training model: one pass): the
+//            forward keeps the gates' tanh values, the reverse pass walks only the input-gradient chain (no parameter gradients)
+//            and re-uses them.
+// Same numbers as before: the transforms, the forward and the d/dv chain are the operations of eb_prepare / eb_logits /
+// eb_logits_bwd in their order, and the |d| terms are summed in the order of the 256-thread kernel (item t, t + 256, t + 512 per
+// slot, then the same tree).  86 -> ~15 us per launch.
 constexpr int AUX_T = 768;
 __global__ __launch_bounds__(AUX_T) void eb_aux_block_kernel(const float *quant, const float *pack, const float *target, float *loss,
                                                              float *dq, int C, int accumulate)
 {
+    extern __shared__ float prep[];                    // [C][NP] transformed parameters
     __shared__ float red[256];
     __shared__ float vals[AUX_T];
+    for (int i = threadIdx.x; i < C * NP; i += AUX_T) {
+        const int k = i % NP;
+        const float pv = pack[i];
+        const int r = k < 9 ? k / 3 : (k < 54 ? ((k - 9) % 15 < 9 ? 0 : ((k - 9) % 15 < 12 ? 1 : 2)) : (k < 57 ? 0 : 1));
+        prep[i] = r == 0 ? softplus_f(pv) : (r == 1 ? pv : tanhf(pv));
+    }
+    __syncthreads();
     const int n = C * 3;
     float slot = 0.f;                                  // threads 0 .. 255: the running sum of items t, t + 256, t + 512, ...
     for (int base = 0; base < n; base += AUX_T) {
@@ -928,14 +911,55 @@ __global__ __launch_bounds__(AUX_T) void eb_aux_block_kernel(const float *quant,
         float ad = 0.f;
         if (i < n) {
             const int c = i / 3, k = i - c * 3;
-            EbPrep e;
-            eb_prepare(pack + (size_t)c * NP, e);
-            float pre[4][3], inp[4][3];
+            const float *e = prep + (size_t)c * NP;    // sp0[3] b0[3] tf0[3] | 3 x (sp[9] b[3] tf[3]) | sp4[3] b4
             const float v = quant[i];
-            const float d = eb_logits<true>(e, v, pre, inp) - target[k];
+            float h[3], ta[4][3];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float a = e[o] * v + e[3 + o];
+                ta[0][o] = tanhf(a);
+                h[o] = a + e[6 + o] * ta[0][o];
+            }
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const float *q = e + 9 + 15 * l;
+                float gg[3];
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const float a = q[o * 3 + 0] * h[0] + q[o * 3 + 1] * h[1] + q[o * 3 + 2] * h[2] + q[9 + o];
+                    ta[l + 1][o] = tanhf(a);
+                    gg[o] = a + q[12 + o] * ta[l + 1][o];
+                }
+#pragma unroll
+                for (int o = 0; o < 3; ++o) h[o] = gg[o];
+            }
+            const float d = (e[54] * h[0] + e[55] * h[1] + e[56] * h[2] + e[57]) - target[k];
             ad = fabsf(d);
-            const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-            const float g = eb_logits_dv(e, pre, sgn);
+            const float gl = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            float gh[3];
+#pragma unroll
+            for (int kk = 0; kk < 3; ++kk) gh[kk] = gl * e[54 + kk];
+#pragma unroll
+            for (int l = 2; l >= 0; --l) {
+                const float *q = e + 9 + 15 * l;
+                float gin[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const float t = ta[l + 1][o], tf = q[12 + o];
+                    const float ga = gh[o] * (1.f + tf * (1.f - t * t));
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) gin[kk] += ga * q[o * 3 + kk];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 3; ++kk) gh[kk] = gin[kk];
+            }
+            float g = 0.f;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float t = ta[0][o], tf = e[6 + o];
+                const float ga = gh[o] * (1.f + tf * (1.f - t * t));
+                g += ga * e[o];
+            }
             if (dq) dq[i] = accumulate ? dq[i] + g : g;
         }
         vals[threadIdx.x] = ad;
@@ -1049,7 +1073,14 @@ STEM_EXPORT int stem_eb_aux_loss_grad(const float *quantiles, const float *pack,
                                       int C, int accumulate, void *stream)
 {
     STEM_CHECK_ARG(quantiles && pack && target3 && loss, "stem_eb_aux_loss_grad: null pointer");
-    hipLaunchKernelGGL(eb_aux_block_kernel, dim3(1), dim3(AUX_T), 0, (hipStream_t)stream, quantiles, pack, target3, loss, dquantiles, C,
+    const size_t lds = (size_t)C * NP * sizeof(float);
+    STEM_CHECK_ARG(C >= 1 && lds + (256 + AUX_T) * sizeof(float) <= 160 * 1024, "stem_eb_aux_loss_grad: C = %d channels do not fit one workgroup's LDS", C);
+    static int lds_set = 0;
+    if (lds > (size_t)lds_set) {
+        (void)hipFuncSetAttribute((const void *)eb_aux_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = (int)lds;
+    }
+    hipLaunchKernelGGL(eb_aux_block_kernel, dim3(1), dim3(AUX_T), lds, (hipStream_t)stream, quantiles, pack, target3, loss, dquantiles, C,
                        accumulate);
     STEM_LAUNCH_CHECK("eb_aux_block");
     return 0;

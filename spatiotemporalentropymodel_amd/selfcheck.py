@@ -247,9 +247,14 @@ def smoke_check(verbose=False):
     with torch.no_grad():
         y_hip, _ = imodel.getY(frames[1])
     checks["g_a_vs_oracle"] = float(np.max(np.abs(y_hip.cpu().contiguous().numpy() - y_ref)) / np.abs(y_ref).max())
+    # the yardstick beside each float64 gate: how far the REFERENCE'S OWN fp32 run is from the exact value in the same metric
+    # (make_golden.py:gen_f64) -- lik_y at 7.6e-5 reads differently next to the reference's 5.0e-5 than next to nothing
+    r32 = x["small:ref32:s1:scalars"]
+    yard = {"loss": float(r32[0]), "y_bpp": float(r32[1]), "z_bpp": float(r32[2]), "aux_loss": float(r32[3]), "grad_norm": float(r32[4]),
+            "lik_y_vs_f64": float(x["small:ref32:lik_y"][0])}
     if verbose:
         for k, v in checks.items():
-            print(f"smoke: {k:18s} rel err {v:.3e}")
+            print(f"smoke: {k:18s} rel err {v:.3e}" + (f"   (reference-fp32 vs float64: {yard[k]:.3e})" if k in yard else ""))
     bad = {k: v for k, v in checks.items() if not v < 1e-4}
     if bad:
         raise AssertionError(f"smoke(): HIP path disagrees with the reference/oracle: {bad}")

@@ -291,6 +291,7 @@ def test_persistent_decoder_give_up_falls_back_to_the_loop(batch, giveup_at, mon
         ref = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()          # the loop
         monkeypatch.delenv("STEM_AR_PERSISTENT")
         monkeypatch.delenv("STEM_AR_NO_BATCH")
+        m.decompress(enc["strings"], enc["shape"], y_cond)             # (the process's one-time self-check of the persistent route runs undisturbed)
         assert lib.stem_tuning_set(b"arp_giveup_at", giveup_at) == 0
         try:
             with warnings.catch_warnings(record=True) as seen:
@@ -387,3 +388,47 @@ def test_eval_gop_restarts_the_chain_at_every_i_frame(golden):
     assert other["strings"][0] != res["frames"][3]["strings"][0]
     allintra = evaluation.eval_gop(imodel, stem, frames[:2], gop=12, all_intra=True)
     assert [f["type"] for f in allintra["frames"]] == ["I", "I"]
+
+
+def test_persistent_route_is_self_checked_once_per_process(monkeypatch):
+    """codec._persistent_trusted: the first decode of a model geometry in a process encodes a 4 x 6 synthetic image with the model's
+    own weights and decodes it by the persistent kernel AND by the per-position loop; the persistent kernel is used from then on
+    only if the two agree bit for bit.  Here: a fresh geometry passes its check (and is not checked again); a check that sees the
+    kernel give up (forced with the give-up knob) switches that geometry to the loop for the rest of the process, with a warning,
+    and decoding stays correct."""
+    import warnings
+    import spatiotemporalentropymodel_amd.models as M
+    from spatiotemporalentropymodel_amd import _lib, codec
+    from spatiotemporalentropymodel_amd.weights import closed_form_fill_, closed_form_input
+    dev = torch.device("cuda:0")
+    lib = _lib.hip()
+    saved = dict(codec._ARP_TRUSTED)
+    try:
+        codec._ARP_TRUSTED.clear()
+        m = closed_form_fill_(M.SpatioTemporalPriorModel_Res(64, 96)).to(dev).eval()
+        m.update(force=True)
+        y_cur = closed_form_input("sc:y", (1, 96, 4, 8), -6, 6).to(dev)
+        y_cond = closed_form_input("sc:c", (1, 96, 4, 8), -6, 6).to(dev)
+        with torch.no_grad():
+            enc = m.compress(y_cur, y_cond)
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                a = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()
+            assert list(codec._ARP_TRUSTED.values()) == [True]
+            codec._ARP_TRUSTED.clear()
+            assert lib.stem_tuning_set(b"arp_giveup_at", 3) == 0
+            try:
+                with warnings.catch_warnings(record=True) as seen:
+                    warnings.simplefilter("always")
+                    b = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()
+            finally:
+                assert lib.stem_tuning_set(b"arp_giveup_at", 0) == 0
+            assert list(codec._ARP_TRUSTED.values()) == [False]
+            assert any("did not reproduce the per-position loop" in str(w.message) for w in seen)
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")                  # the loop from here on: no persistent launch, nothing to give up
+                c = m.decompress(enc["strings"], enc["shape"], y_cond)["y_hat"].clone()
+        assert torch.equal(a, b) and torch.equal(a, c)
+    finally:
+        codec._ARP_TRUSTED.clear()
+        codec._ARP_TRUSTED.update(saved)

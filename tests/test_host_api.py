@@ -851,3 +851,57 @@ def test_rans_decoder_survives_tables_rewritten_behind_the_same_pointers():
     live_s[...] = sizes_b
     got += [np.asarray(dec.decode_stream(idx[i:i + 192], t)) for i in range(half, n, 192)]
     np.testing.assert_array_equal(np.concatenate(got), sym)
+
+
+def test_ms_ssim_against_an_independent_formulation():
+    """evaluation.ms_ssim (the "ms-ssim" entry of stem/evalSTEM.py:81,147; the script takes it from the third-party pytorch_msssim,
+    absent from the reference tree and from this image: no golden vector, see the module's header) against the same published
+    algorithm written independently with scipy's 1-D correlations in float64, plus its defining properties."""
+    import torch
+    from scipy.ndimage import correlate1d
+    from spatiotemporalentropymodel_amd.evaluation import ms_ssim
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:200, 0:232]
+    img = np.stack([0.5 + 0.4 * np.sin(xx / (9.0 + c)) * np.cos(yy / (13.0 - c)) for c in range(3)])[None]
+    noisy = np.clip(img + 0.05 * rng.standard_normal(img.shape), 0, 1)
+    blurred = np.clip(0.5 * img + 0.5 * np.roll(img, 3, axis=3), 0, 1)
+
+    def reference(a, b):
+        c = np.arange(11) - 5
+        g = np.exp(-(c ** 2) / (2 * 1.5 ** 2))
+        g /= g.sum()
+
+        def filt(v):                                    # 'valid' separable correlation along H and W
+            v = correlate1d(correlate1d(v, g, axis=2, mode="constant"), g, axis=3, mode="constant")
+            return v[:, :, 5:-5, 5:-5]
+
+        def pool(v):
+            ph, pw = v.shape[2] % 2, v.shape[3] % 2
+            v = np.pad(v, ((0, 0), (0, 0), (ph, ph), (pw, pw)))            # avg_pool2d(padding=p) pads both sides with zeros, counted
+            H2, W2 = v.shape[2] // 2, v.shape[3] // 2
+            return v[:, :, :2 * H2, :2 * W2].reshape(v.shape[0], v.shape[1], H2, 2, W2, 2).mean(axis=(3, 5))
+
+        C1, C2 = 0.01 ** 2, 0.03 ** 2
+        w = [0.0448, 0.2856, 0.3001, 0.2363, 0.1333]
+        out = np.ones(a.shape[:2])
+        for lv in range(5):
+            m1, m2 = filt(a), filt(b)
+            s11, s22, s12 = filt(a * a) - m1 * m1, filt(b * b) - m2 * m2, filt(a * b) - m1 * m2
+            cs = (2 * s12 + C2) / (s11 + s22 + C2)
+            ss = (2 * m1 * m2 + C1) / (m1 * m1 + m2 * m2 + C1) * cs
+            t = cs.mean(axis=(2, 3)) if lv < 4 else ss.mean(axis=(2, 3))
+            out *= np.maximum(t, 0) ** w[lv]
+            if lv < 4:
+                a, b = pool(a), pool(b)
+        return float(out.mean())
+
+    for other in (noisy, blurred):
+        got = ms_ssim(torch.from_numpy(img).float(), torch.from_numpy(other).float())
+        assert abs(got - reference(img.astype(np.float64), other.astype(np.float64))) < 2e-5, (got, reference(img, other))
+    t = torch.from_numpy(img).float()
+    assert abs(ms_ssim(t, t) - 1.0) < 1e-6
+    a, b = ms_ssim(t, torch.from_numpy(noisy).float()), ms_ssim(torch.from_numpy(noisy).float(), t)
+    assert abs(a - b) < 1e-6 and 0 < a < 1
+    worse = np.clip(img + 0.15 * rng.standard_normal(img.shape), 0, 1)
+    assert ms_ssim(t, torch.from_numpy(worse).float()) < a
+    assert ms_ssim(t[:, :, :160, :160], t[:, :, :160, :160]) is None          # no fifth scale: reported as absent, not as a number
