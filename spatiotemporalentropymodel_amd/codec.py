@@ -260,6 +260,21 @@ def _persistent_trusted(model, M, n0, n1, dev):
     if key in _ARP_TRUSTED:
         return _ARP_TRUSTED[key]
     _ARP_TRUSTED[key] = True                               # the check's own decode below takes the persistent route
+    try:
+        ok = _persistent_selfcheck(model, M, dev)
+    except BaseException:
+        _ARP_TRUSTED.pop(key, None)                        # nothing was established: the next decode checks again
+        raise
+    if not ok:
+        import warnings
+        warnings.warn("the persistent decoder did not reproduce the per-position loop on this process's self-check (toolchain / driver change?): "
+                      "decoding with the loop from here on", RuntimeWarning)
+    _ARP_TRUSTED[key] = ok
+    return ok
+
+
+def _persistent_selfcheck(model, M, dev):
+    global _FORCE_LOOP
     from .weights import closed_form_input
     H, W = 4, 6
     with torch.no_grad():
@@ -276,13 +291,7 @@ def _persistent_trusted(model, M, n0, n1, dev):
             b = _decode_latents(model, strings, hp, tp)
         finally:
             _FORCE_LOOP = False
-        ok = bool(torch.equal(a, b)) and not any("persistent decoder gave up" in str(w.message) for w in seen)
-    if not ok:
-        import warnings
-        warnings.warn("the persistent decoder did not reproduce the per-position loop on this process's self-check (toolchain / driver change?): "
-                      "decoding with the loop from here on", RuntimeWarning)
-    _ARP_TRUSTED[key] = ok
-    return ok
+        return bool(torch.equal(a, b)) and not any("persistent decoder gave up" in str(w.message) for w in seen)
 
 
 def _decode_latents(model, strings_y, hp, tp):
