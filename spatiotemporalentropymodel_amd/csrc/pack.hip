@@ -25,7 +25,7 @@ STEM_EXPORT int stem_built_with_experiments(void)
 }
 
 static int g_tuning[STEM_TUNE_COUNT] = {0};
-static const char *const kTuningNames[STEM_TUNE_COUNT] = {"fx3_tile", "fx3_split", "wg3_split", "arp_workers", "fx3_depth", "fx3_gen_tile", "fx3_mfma", "fx3_gen_mfma", "fx3_gen_img", "fx3_img_w", "wg3_row", "wg3_minch", "tconv_cps", "arp_giveup_at"};
+static const char *const kTuningNames[STEM_TUNE_COUNT] = {"fx3_tile", "fx3_split", "wg3_split", "arp_workers", "fx3_depth", "fx3_gen_tile", "fx3_mfma", "fx3_gen_mfma", "fx3_gen_img", "fx3_img_w", "wg3_row", "wg3_minch", "tconv_cps", "arp_giveup_at", "unpack_mb"};
 int stem_tuning(int id) { return g_tuning[id]; }
 STEM_EXPORT int stem_tuning_set(const char *name, int value)
 {
@@ -36,11 +36,12 @@ STEM_EXPORT int stem_tuning_set(const char *name, int value)
             STEM_CHECK_ARG(i != STEM_TUNE_FX3_GEN_TILE || value == 0 || value == 64 || value == 128, "stem_tuning_set: fx3_gen_tile is 0 (automatic), 64 or 128");
             STEM_CHECK_ARG(i != STEM_TUNE_FX3_DEPTH || value == 0 || value == 2 || value == 3, "stem_tuning_set: fx3_depth is 0 (automatic), 2 or 3 (LDS stages of the split-operand main loops)");
             STEM_CHECK_ARG(i != STEM_TUNE_FX3_GEN_MFMA || value == 0 || value == 16 || value == 32, "stem_tuning_set: fx3_gen_mfma is 0 (automatic), 16 or 32 (rows of the general kernel's MFMA shape)");
+            STEM_CHECK_ARG(i != STEM_TUNE_UNPACK_MB || value == 0 || (value % 32 == 0 && value >= 32 && value <= 192), "stem_tuning_set: unpack_mb is 0 (automatic) or a multiple of 32 up to 192");
             STEM_CHECK_ARG(i != STEM_TUNE_FX3_MFMA || value == 0 || value == 16 || value == 32, "stem_tuning_set: fx3_mfma is 0 (automatic), 16 or 32 (rows of the MFMA shape)");
             g_tuning[i] = value;
             return 0;
         }
-    stem_set_error("stem_tuning_set: unknown selector '%s' (fx3_tile, fx3_split, wg3_split, arp_workers, fx3_depth, fx3_gen_tile, fx3_mfma, fx3_gen_mfma, fx3_gen_img, fx3_img_w, wg3_row, wg3_minch, tconv_cps, arp_giveup_at)", name);
+    stem_set_error("stem_tuning_set: unknown selector '%s' (fx3_tile, fx3_split, wg3_split, arp_workers, fx3_depth, fx3_gen_tile, fx3_mfma, fx3_gen_mfma, fx3_gen_img, fx3_img_w, wg3_row, wg3_minch, tconv_cps, arp_giveup_at, unpack_mb)", name);
     return -1;
 }
 STEM_EXPORT int stem_tuning_get(const char *name)
@@ -122,37 +123,40 @@ __global__ __launch_bounds__(256) void pack_multi_kernel(const PackTable tb)
 struct UnpackD {
     const float *dwp;
     float *dw;
-    int A, Bd, T, splits, block0, accumulate;
+    int A, Bd, T, splits, block0, accumulate, mb;
 };
 struct UnpackTable {
     UnpackD d[MAXD];
     int n;
 };
-// one workgroup per (row a, 64-wide range of b): reads T coalesced 256-byte runs per split, transposes the [t][b] tile
-// through LDS and writes one contiguous 64*T run.  (The first version used one workgroup per row a with a serial loop
-// over all Bd*T elements x splits: ~1000 workgroups of dependent loads ran at 0.5 TB/s, 2 ms per bench step.)
-constexpr int UNPACK_MB = 64;
+// one workgroup per (row a, mb-wide range of b; mb = 64 .. 192 in steps of 32): reads T coalesced runs of mb floats per split, transposes the [t][b]
+// tile through LDS and writes one contiguous mb*T run.  (The first version used one workgroup per row a with a serial loop
+// over all Bd*T elements x splits: ~1000 workgroups of dependent loads ran at 0.5 TB/s, 2 ms per bench step.)  Round 6: ranges of up
+// to 192 floats (768-byte runs) where they divide the row -- the pass gathers its input in runs, and longer runs are what
+// HBM delivers faster; the sums and their order are unchanged.
+constexpr int UNPACK_MB = 64, UNPACK_MB_MAX = 192;
 __global__ __launch_bounds__(256) void unpack_multi_kernel(const UnpackTable tb)
 {
-    extern __shared__ float tile[];   // [UNPACK_MB][T+1]
+    extern __shared__ float tile[];   // [mb][T+1]
     int i = 0;
     while (i + 1 < tb.n && (int)blockIdx.x >= tb.d[i + 1].block0) ++i;
     const UnpackD d = tb.d[i];
-    const int chunks = (d.Bd + UNPACK_MB - 1) / UNPACK_MB;
+    const int mb = d.mb;
+    const int chunks = (d.Bd + mb - 1) / mb;
     const int blk = blockIdx.x - d.block0;
-    const int a = blk / chunks, b0 = (blk - a * chunks) * UNPACK_MB;
-    const int nb = d.Bd - b0 < UNPACK_MB ? d.Bd - b0 : UNPACK_MB;
+    const int a = blk / chunks, b0 = (blk - a * chunks) * mb;
+    const int nb = d.Bd - b0 < mb ? d.Bd - b0 : mb;
     const int n = nb * d.T;
     const size_t slab = (size_t)d.T * d.A * d.Bd;
-    // Round 5: a full 64-wide range whose rows start on 16-byte boundaries is read as float4 (four consecutive b per thread) with
+    // Round 5: a full range whose rows start on 16-byte boundaries is read as float4 (four consecutive b per thread) with
     // the slabs of a piece in flight together, and written back as float4: the same sums in the same order (even slabs into one
     // accumulator, odd into the other), a third fewer instructions per byte -- the pass is HBM-bound and sits at the tail of backward
-    const bool vec = nb == UNPACK_MB && (d.Bd & 3) == 0 && ((reinterpret_cast<uintptr_t>(d.dwp) | reinterpret_cast<uintptr_t>(d.dw)) & 15) == 0 &&
+    const bool vec = nb == mb && (d.Bd & 3) == 0 && ((reinterpret_cast<uintptr_t>(d.dwp) | reinterpret_cast<uintptr_t>(d.dw)) & 15) == 0 &&
                      ((size_t)d.Bd * d.T) % 4 == 0 && (slab & 3) == 0;
     if (vec) {
-        const int n4 = d.T * (UNPACK_MB / 4);
+        const int q = mb / 4, n4 = d.T * q;                      // q = 16 or 32 float4 pieces per run
         for (int k = threadIdx.x; k < n4; k += 256) {
-            const int t = k >> 4, b4 = k & 15;
+            const int t = k / q, b4 = k - t * q;
             const f32x4 *src = reinterpret_cast<const f32x4 *>(d.dwp + ((size_t)t * d.A + a) * d.Bd + b0) + b4;
             f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
             int sp = 0;
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(256) void unpack_multi_kernel(const UnpackTable tb)
             for (int j = 0; j < 4; ++j) tile[(b4 * 4 + j) * (d.T + 1) + t] = v[j];
         }
         __syncthreads();
-        float *dst = d.dw + ((size_t)a * d.Bd + b0) * d.T;        // 64 * T consecutive floats, 16-byte aligned (Bd * T % 4 == 0, b0 % 64 == 0)
+        float *dst = d.dw + ((size_t)a * d.Bd + b0) * d.T;        // mb * T consecutive floats, 16-byte aligned (Bd * T % 4 == 0, b0 % 64 == 0)
         for (int k4 = threadIdx.x; k4 < n / 4; k4 += 256) {
             f32x4 v;
 #pragma unroll
@@ -422,8 +426,20 @@ STEM_EXPORT int stem_unpack_wgrads_multi(const stem_unpack_desc *descs, int n, v
             d.Bd = deconv ? q.K : q.C;
             d.splits = q.splits;
             d.block0 = blocks;
-            blocks += d.A * cdiv(d.Bd, UNPACK_MB);
-            const size_t need = (size_t)UNPACK_MB * (d.T + 1) * sizeof(float);
+            // 128-wide ranges where they divide the row and leave enough workgroups to fill the chip (sweeps: stem_tuning_set("unpack_mb", 64 | 128))
+            const int forced_mb = stem_tuning(STEM_TUNE_UNPACK_MB);
+            d.mb = UNPACK_MB;
+            if (forced_mb) {
+                d.mb = forced_mb;
+            } else {
+                for (int mb = UNPACK_MB_MAX; mb > UNPACK_MB; mb -= 32)           // the longest run that divides the row and still fills the chip twice
+                    if (d.Bd % mb == 0 && (long)d.A * (d.Bd / mb) >= 512) {
+                        d.mb = mb;
+                        break;
+                    }
+            }
+            blocks += d.A * cdiv(d.Bd, d.mb);
+            const size_t need = (size_t)d.mb * (d.T + 1) * sizeof(float);
             if (need > lds) lds = need;
         }
         if (blocks) hipLaunchKernelGGL(unpack_multi_kernel, dim3(blocks), dim3(256), lds, st, tb);

@@ -39,7 +39,7 @@ static inline size_t cdivz(size_t a, size_t b) { return (a + b - 1) / b; }
 // Plan selectors (a tile shape, a split factor: every choice computes the same contraction, differing at most in summation
 // order) are integers set through the exported stem_tuning_set() -- tests and sweep tools use them; nothing reads the
 // environment per launch.
-enum { STEM_TUNE_FX3_TILE = 0, STEM_TUNE_FX3_SPLIT, STEM_TUNE_WG3_SPLIT, STEM_TUNE_ARP_WORKERS, STEM_TUNE_FX3_DEPTH, STEM_TUNE_FX3_GEN_TILE, STEM_TUNE_FX3_MFMA, STEM_TUNE_FX3_GEN_MFMA, STEM_TUNE_FX3_GEN_IMG, STEM_TUNE_FX3_IMG_W, STEM_TUNE_WG3_ROW, STEM_TUNE_WG3_MINCH, STEM_TUNE_TCONV_CPS, STEM_TUNE_ARP_GIVEUP_AT, STEM_TUNE_COUNT };
+enum { STEM_TUNE_FX3_TILE = 0, STEM_TUNE_FX3_SPLIT, STEM_TUNE_WG3_SPLIT, STEM_TUNE_ARP_WORKERS, STEM_TUNE_FX3_DEPTH, STEM_TUNE_FX3_GEN_TILE, STEM_TUNE_FX3_MFMA, STEM_TUNE_FX3_GEN_MFMA, STEM_TUNE_FX3_GEN_IMG, STEM_TUNE_FX3_IMG_W, STEM_TUNE_WG3_ROW, STEM_TUNE_WG3_MINCH, STEM_TUNE_TCONV_CPS, STEM_TUNE_ARP_GIVEUP_AT, STEM_TUNE_UNPACK_MB, STEM_TUNE_COUNT };
 int stem_tuning(int id);
 // image-tile form of the general split-operand convolution (conv_f16x3_img.hip), dispatched from stem_conv2d_f16x3_gen_fwd
 bool stem_fx3_img_eligible(int B, int H, int W, int N, int R, int S, int stride, int pad);
