@@ -75,6 +75,7 @@ struct ImgArgs {
     int xpix;
     int tiles_x, tiles_y;
     unsigned long long *stamps;     // phase stamps of every workgroup (libstem_hip_exper.so only; null otherwise)
+    int ablate;                     // libstem_hip_exper.so only: 1 = every second chunk's barrier left out (WRONG results: timing ablation)
 };
 
 #ifndef STEM_IMG_ZFLIP
@@ -82,6 +83,7 @@ struct ImgArgs {
 #endif
 #ifdef STEM_EXPERIMENTS
 unsigned long long *g_img_stamps = nullptr;
+int g_img_ablate = 0;
 __device__ unsigned long long g_img_waits[4];      // sums over wavefronts: cycles waiting for vmcnt, at the barrier, in the loop
 #define IMG_STAMP(i)                                                                                                              \
     do {                                                                                                                          \
@@ -372,7 +374,9 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
             const unsigned long long ts0_ = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
             asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             const unsigned long long ts1_ = a.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-            asm volatile("s_barrier" ::: "memory");
+            // ablation (round 6): what a barrier every TWO chunks could buy at most -- every second barrier left out (the weight ring
+            // is then read while it is overwritten: results are wrong, the instruction stream and its timing are the loop's)
+            if (!(a.ablate == 1 && (c & 1))) asm volatile("s_barrier" ::: "memory");
             if (a.stamps) {
                 const unsigned long long ts2_ = __builtin_amdgcn_s_memtime();
                 t_vm_ += ts1_ - ts0_;
@@ -599,6 +603,7 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
 #ifdef STEM_EXPERIMENTS
 // tools/debug/f16x3_img_phases.py: a device buffer of 8 x uint64 per workgroup receives s_memrealtime (100 MHz) at the phase borders
 STEM_EXPORT void stem_exper_img_stamps(void *p) { g_img_stamps = static_cast<unsigned long long *>(p); }
+STEM_EXPORT void stem_exper_img_ablate(int mode) { g_img_ablate = mode; }
 STEM_EXPORT void stem_exper_img_waits(unsigned long long *out4, int reset)
 {
     unsigned long long z[4] = {0, 0, 0, 0};
@@ -666,6 +671,7 @@ int stem_fx3_img_launch(const void *xp, const float *xq, int xpix, int xbytes, c
     a.xpix = xpix;
 #ifdef STEM_EXPERIMENTS
     a.stamps = g_img_stamps;
+    a.ablate = g_img_ablate;
 #endif
     a.tiles_x = cdiv(W, TS); a.tiles_y = cdiv(H, TS);
     const int nchunks = (C / 32) * T;

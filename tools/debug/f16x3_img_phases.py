@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Where a workgroup of the image-tile kernel spends its time: phase stamps (s_memrealtime, 100 MHz) of every workgroup of one
 launch.  Needs the experiments build: `make -C spatiotemporalentropymodel_amd/csrc experiments`, then
-    STEM_HIP_LIBRARY=spatiotemporalentropymodel_amd/libstem_hip_exper.so python3 tools/debug/f16x3_img_phases.py [layer] [split]
+    STEM_HIP_LIBRARY=spatiotemporalentropymodel_amd/libstem_hip_exper.so python3 tools/debug/f16x3_img_phases.py [layer] [split] [ablate]
+ablate = 1: every second chunk's barrier left out (wrong results; the upper bound of what one barrier per two chunks could buy).
 """
 import ctypes as C
 import os
@@ -15,6 +16,7 @@ from spatiotemporalentropymodel_amd import _lib, functional as F  # noqa: E402
 LAYERS = {"TPM.0": (192, 256, 5), "TPM.2": (256, 320, 5), "TPM.4": (320, 384, 5), "HE.0": (384, 256, 3), "EPM.0": (1152, 768, 1), "EPM.4": (576, 384, 1)}
 name = sys.argv[1] if len(sys.argv) > 1 else "TPM.4"
 split = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+ablate = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 C_, K, R = LAYERS[name]
 dev = torch.device("cuda:0")
 x = torch.randn(16, C_, 16, 16, device=dev)
@@ -24,6 +26,11 @@ xp, wp = F.F16Planes.split(x), F.pack_weight_f16x2_gen(w)
 lib = _lib.hip()
 lib.stem_exper_img_stamps.argtypes = [C.c_void_p]
 lib.stem_exper_img_stamps.restype = None
+if ablate:
+    lib.stem_exper_img_ablate.argtypes = [C.c_int]
+    lib.stem_exper_img_ablate.restype = None
+    lib.stem_exper_img_ablate(ablate)
+    print(f"ABLATION {ablate}: every second chunk's barrier left out (results are wrong, timing only)")
 NW = 4096
 stamps = torch.zeros(NW * 8, dtype=torch.int64, device=dev)
 tune = dict(fx3_gen_img=2)
