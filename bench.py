@@ -827,7 +827,7 @@ def main():
     # way; the probe brackets the NCHW -> NHWC4 layout kernel (~20 us) and the convolution kernel
     flop0 = GA0_FLOP_PER_FRAME * BATCH
     c4_f16 = RUNTIME().first_layer_f16x3 and f16_chain
-    exec0 = F16_PRODUCTS * (2 * 192 * 128 * 128 * 128 + 2 * 192 * 192 * 128 * 128) * BATCH      # conv K padded 75 -> 128 slots, GDN K = 192; x3 products
+    exec0 = F16_PRODUCTS * (2 * 192 * 80 * 128 * 128 + 2 * 192 * 192 * 128 * 128) * BATCH       # conv K: 75 real products in 80 slots (128 until round 5), GDN K = 192; x3 products
     peak0 = PEAK_F16_MFMA_TFLOPS if c4_f16 else PEAK_FP32_MFMA_TFLOPS
     work0 = exec0 if c4_f16 else flop0
     first_line = {"bound": "mfma",

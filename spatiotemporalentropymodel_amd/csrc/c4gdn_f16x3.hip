@@ -17,8 +17,11 @@
 //   * three fp16 MFMAs per fp32 product as in conv_f16x3.hip (operands as two fp16 numbers of a power-of-two-scaled copy,
 //     the products a0.b0, a0.b1, a1.b0): fp32-class accuracy, fp32 accumulation; the image is scaled by its measured maximum,
 //     the squared conv outputs and the result by upper bounds derived from it (scale records, stem_common.h);
-//   * the image patch of a pixel is read straight from the NHWC4 image (two 16-byte loads per lane and k-step: taps s, s + 1
-//     of one filter row x 4 channels = the 8 consecutive k of the lane's fragment), zero-filled outside the image.
+//   * the image patch of a pixel is read straight from the NHWC4 image: a conv k-step is FIVE taps of one filter row x 3 image
+//     channels = 15 K slots + one zero slot (round 6: the 75 real products of the 5x5 filter in 80 slots / 5 k-steps; until round 5
+//     tap pairs x 4 channels = 128 slots / 8 k-steps, a quarter of them multiplying the NHWC4 padding channel).  Lane half h reads
+//     the three pixels at columns 5 u + 2 h + {0, 1, 2} of the row (three 16-byte loads, zero-filled outside the image) and picks
+//     its eight slots from them.
 //
 // Channel order inside a 32-row MFMA tile: row r of the A operand holds channel 16 ((r >> 2) & 1) + 4 (r >> 3) + (r & 3), which
 // makes the 16 accumulator registers of lane (pixel p, half h) the CONTIGUOUS channels 16 h .. 16 h + 15 of the tile: k-step s
@@ -52,21 +55,26 @@ struct C4gArgs {
     void *yp;
     int ldy;
     int B, H, W, N, OH, OW, R, S, stride, pad;
-    int ksc;                       // conv k-steps: ceil(R * ceil(S / 2) / 2)
+    int ksc;                       // conv k-steps: R * ceil(S / 5)
     int xbytes;
     float beta_bound;
+    int ablate;                    // libstem_hip_exper.so only (WRONG results, timing ablations): bit 1 = the ring's wait + barrier only at every second
+                                   // step (bit 0 was "5 instead of 8 conv k-steps" before the kernel did that itself: profiles/r06_c4gdn_ablation.log)
 };
+#ifdef STEM_EXPERIMENTS
+int g_c4g_ablate = 0;
+#endif
 
 // ---- A-operand stream -------------------------------------------------------------------------------------------------------
-// chunk t < ksc (conv k-step t): fragment (nb, plane) at ((nb * 2 + plane) * 64 + lane) * 16; lane (r, h) element j is the
-//   weight of channel nb * 32 + rho(r) for K slot (pair q = 2 t + h, tap j >> 2 of the pair, image channel j & 3), where pair q
-//   = (filter row q / PR, taps 2 (q % PR) and 2 (q % PR) + 1), PR = ceil(S / 2); slots beyond the filter hold 0;
+// chunk t < ksc (conv k-step t = filter row t / SPR, column group u = t % SPR, SPR = ceil(S / 5)): fragment (nb, plane) at
+//   ((nb * 2 + plane) * 64 + lane) * 16; lane (r, h) element j is the weight of channel nb * 32 + rho(r) for K slot 8 h + j of the
+//   step: slot q < 15 = (tap column 5 u + q / 3, image channel q % 3), slot 15 = 0; columns beyond the filter hold 0;
 // chunk ksc + 2 kb + s (GDN k-step s of k-block kb): fragment (nb, plane) at the same place; lane (r, h) element j =
 //   gamma'[nb * 32 + rho(r)][kb * 32 + 16 h + 8 s + j], gamma' = max(gamma, 2^-18)^2 - 2^-36 (parametrizers.py:42-45).
 __global__ __launch_bounds__(256) void c4gdn_pack_kernel(const float *wp_c4, const float *gamma, unsigned char *out, int N, int R, int S, int ksc,
                                                          float *wq, float *gq)
 {
-    const int NB = N / 32, PR = (S + 1) / 2;
+    const int NB = N / 32, SPR = (S + 4) / 5;
     const int nchunks = ksc + 2 * NB;
     // scales: the weights by their maximum, gamma' = max(gamma, 2^-18)^2 - 2^-36 by the bound max(|gamma|max, 2^-18)^2
     __shared__ float qred[16];
@@ -85,10 +93,10 @@ __global__ __launch_bounds__(256) void c4gdn_pack_kernel(const float *wp_c4, con
     const int nb = fp;
     const bool used = nb < NB;
     if (c < ksc) {
-        const int ch = nb * 32 + rho(r), q = 2 * c + h, prow = q / PR, s0 = 2 * (q % PR);
+        const int ch = nb * 32 + rho(r), prow = c / SPR, u = c - prow * SPR;
         for (int j = 0; j < 8; ++j) {
-            const int s = s0 + (j >> 2), cc = j & 3;
-            v[j] = (used && prow < R && s < S) ? wp_c4[(ch * 32 + prow * S + s) * 4 + cc] : 0.f;      // channel 3 of the C4 pack is zero
+            const int q = 8 * h + j, s = 5 * u + q / 3, cc = q % 3;
+            v[j] = (used && q < 15 && prow < R && s < S) ? wp_c4[(ch * 32 + prow * S + s) * 4 + cc] : 0.f;
         }
     } else {
         const int gi = c - ksc, kb = gi >> 1, s = gi & 1;
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_f16x3_kernel(const C4gArgs 
         pix0 = (b * a.H + by) * a.W + bx;              // pixel index of tap (0, 0); may be negative at the border (masked below)
     }
     const int nchunks = a.ksc + 2 * NB;
-    const int PR = (a.S + 1) / 2, npairs = a.R * PR;
+    const int SPR = (a.S + 4) / 5;
 
     // ---- A-operand ring: chunk c -> buffer c & 1, 3 KiB per wavefront as three 1 KiB pieces (wavefront w copies bytes
     // [3072 w, 3072 w + 3072); buffer form: one VGPR of lane offset, the chunk offset in an SGPR, the piece offsets as immediates)
@@ -169,17 +177,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_f16x3_kernel(const C4gArgs 
         __syncthreads();
     };
 
-    // ---- image patch of this lane's pixel for conv k-step t: pair q = 2 t + h = (filter row, taps s0 and s0 + 1) ---------------
+    // ---- image patch of this lane's pixel for conv k-step t: filter row t / SPR, tap columns 5 u + 2 h + {0, 1, 2} -------------------
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.x4), 0, a.xbytes, 0x00020000);
-    auto patch_load = [&](int t, f32x4 &v0, f32x4 &v1) {
-        const int q = 2 * t + h, prow = q / PR, s0 = 2 * (q - prow * PR);
+    auto patch_load = [&](int t, f32x4 (&v)[3]) {
+        const int prow = t / SPR, s0 = 5 * (t - prow * SPR) + 2 * h;
         const int iy = by + prow, ix = bx + s0;
-        const bool rowok = ok && q < npairs && iy >= 0 && iy < a.H;
+        const bool rowok = ok && t < a.ksc && iy >= 0 && iy < a.H;
         const int off = (pix0 + prow * a.W + s0) * 16;
-        const int o0 = (rowok && ix >= 0 && ix < a.W) ? off : OOR;
-        const int o1 = (rowok && ix + 1 >= 0 && ix + 1 < a.W && s0 + 1 < a.S) ? off + 16 : OOR;
-        v0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o0, 0, 0));
-        v1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o1, 0, 0));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int o = (rowok && ix + i >= 0 && ix + i < a.W && s0 + i < a.S) ? off + 16 * i : OOR;
+            v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, o, 0, 0));
+        }
     };
 
     // ---- scales (stem_common.h): the image by its measured maximum; the squares and the output by upper bounds derived from it --
@@ -227,24 +236,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_f16x3_kernel(const C4gArgs 
     }
 
     ring_issue(0);
-    f32x4 pv0, pv1;
-    patch_load(0, pv0, pv1);
+    f32x4 pv[3];
+    patch_load(0, pv);
 
     // ---- convolution: ksc chunks of one k-step x NB tiles x 3 products -----------------------------------------------------------
+#ifdef STEM_EXPERIMENTS
+    const int ksc_run = a.ksc;            // (ablation bit 0 of round 6 -- 5 instead of 8 conv k-steps -- is what the kernel does now)
+    int step_no = 0;
+#define C4G_RING_WAIT() do { if (!((a.ablate & 2) && (step_no++ & 1))) ring_wait(); } while (0)
+#else
+    const int ksc_run = a.ksc;
+#define C4G_RING_WAIT() ring_wait()
+#endif
 #pragma unroll 1
-    for (int t = 0; t < a.ksc; ++t) {
-        ring_wait();
+    for (int t = 0; t < ksc_run; ++t) {
+        C4G_RING_WAIT();
         ring_issue(t + 1);
         h16x8 b[2];
+        {
+            // the lane's eight K slots out of its three pixels: h = 0: slots 0..7 = p0.xyz p1.xyz p2.xy; h = 1: slots 8..15 = p0.z p1.xyz
+            // p2.xyz 0 (its p0 is the tap column 5 u + 2, whose x and y belong to the other half)
+            const float e[8] = {h ? pv[0][2] : pv[0][0], h ? pv[1][0] : pv[0][1], h ? pv[1][1] : pv[0][2], h ? pv[1][2] : pv[1][0],
+                                h ? pv[2][0] : pv[1][1], h ? pv[2][1] : pv[1][2], h ? pv[2][2] : pv[2][0], h ? 0.f : pv[2][1]};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            hp_t h0, h1;
-            q_split(pv0[j], xscale, h0, h1);
-            b[0][j] = h0; b[1][j] = h1;
-            q_split(pv1[j], xscale, h0, h1);
-            b[0][4 + j] = h0; b[1][4 + j] = h1;
+            for (int j = 0; j < 8; ++j) {
+                hp_t h0, h1;
+                q_split(e[j], xscale, h0, h1);
+                b[0][j] = h0; b[1][j] = h1;
+            }
         }
-        patch_load(t + 1 < a.ksc ? t + 1 : t, pv0, pv1);
+        patch_load(t + 1 < a.ksc ? t + 1 : t, pv);
         const unsigned char *buf = smem + (t & 1) * CHUNK + lane * 16;
         h16x8 af[2][2];
         lda(buf, af[0]);
@@ -275,7 +296,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_f16x3_kernel(const C4gArgs 
     for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
         for (int s = 0; s < 2; ++s, ++c) {
-            ring_wait();
+            C4G_RING_WAIT();
             ring_issue(c + 1);
             const unsigned char *buf = smem + (c & 1) * CHUNK + lane * 16;
             h16x8 b[2];
@@ -347,7 +368,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void c4gdn_f16x3_kernel(const C4gArgs 
     }
 }
 
-int conv_ksteps(int R, int S) { return (R * ((S + 1) / 2) + 1) / 2; }
+int conv_ksteps(int R, int S) { return R * ((S + 4) / 5); }
 constexpr int QSLOTS = 16;
 constexpr size_t QREC_BYTES = (QREC_HDR + QSLOTS) * sizeof(float);
 
@@ -367,6 +388,11 @@ __global__ __launch_bounds__(256) void c4gdn_amax_kernel(const float *w, long nw
 }
 
 }   // namespace
+
+#ifdef STEM_EXPERIMENTS
+// tools/debug/c4gdn_time.py <mask>: timing ablations of the first-layer kernel (results are WRONG under them)
+STEM_EXPORT void stem_exper_c4gdn_ablate(int mask) { g_c4g_ablate = mask; }
+#endif
 
 // ---- C ABI --------------------------------------------------------------------------------------------------------------------
 STEM_EXPORT int stem_c4gdn_supported(int N, int R, int S)
@@ -421,6 +447,9 @@ STEM_EXPORT int stem_conv2d_c4_gdn_f16x3(const float *x4, const float *xq, const
     a.ksc = conv_ksteps(R, S);
     a.xbytes = (int)xb;
     a.beta_bound = (float)sqrt((double)beta_min + 1.4551915228366852e-11);
+#ifdef STEM_EXPERIMENTS
+    a.ablate = g_c4g_ablate;
+#endif
     const int M = B * OH * OW;
     const dim3 grid(cdiv(M, WG_PIX)), block(NTHREADS);
     hipStream_t st = (hipStream_t)stream;
