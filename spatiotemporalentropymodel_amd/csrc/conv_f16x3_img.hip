@@ -75,7 +75,7 @@ struct ImgArgs {
     int xpix;
     int tiles_x, tiles_y;
     unsigned long long *stamps;     // phase stamps of every workgroup (libstem_hip_exper.so only; null otherwise)
-    int ablate;                     // libstem_hip_exper.so only: 1 = every second chunk's barrier left out (WRONG results: timing ablation)
+    int ablate;                     // libstem_hip_exper.so only (WRONG results: timing ablations): 1 = every second chunk's barrier left out, 2 = return after the main loop
 };
 
 #ifndef STEM_IMG_ZFLIP
@@ -444,6 +444,9 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the look-ahead DMA of the last chunks still writes LDS
     __syncthreads();            // every wavefront is done with the operand images: the epilogue tile takes their place
     IMG_STAMP(3);
+#ifdef STEM_EXPERIMENTS
+    if (a.ablate == 2) return;  // ablation: nothing after the main loop (no partial tiles, ticket, slab read, epilogue): what the tail costs at most
+#endif
 
     // ---- sums of this workgroup -> the epilogue tile Tt (directly, or through the split-K workspace) --------------------------
     // accumulator register r of MFMA tile mi: tile row rho = (r & 3) + 8 (r >> 2) + 4 lh -> pixel (4 wm + 2 mi + (rho >> 4), rotated column)

@@ -2,7 +2,9 @@
 """Where a workgroup of the image-tile kernel spends its time: phase stamps (s_memrealtime, 100 MHz) of every workgroup of one
 launch.  Needs the experiments build: `make -C spatiotemporalentropymodel_amd/csrc experiments`, then
     STEM_HIP_LIBRARY=spatiotemporalentropymodel_amd/libstem_hip_exper.so python3 tools/debug/f16x3_img_phases.py [layer] [split] [ablate]
-ablate = 1: every second chunk's barrier left out (wrong results; the upper bound of what one barrier per two chunks could buy).
+ablate = 1: every second chunk's barrier left out (wrong results; the upper bound of what one barrier per two chunks could buy);
+ablate = 2: the workgroups return right after the main loop (what everything behind it costs at most); the launch's duration by HIP
+events is printed in every mode.
 """
 import ctypes as C
 import os
@@ -30,7 +32,7 @@ if ablate:
     lib.stem_exper_img_ablate.argtypes = [C.c_int]
     lib.stem_exper_img_ablate.restype = None
     lib.stem_exper_img_ablate(ablate)
-    print(f"ABLATION {ablate}: every second chunk's barrier left out (results are wrong, timing only)")
+    print(f"ABLATION {ablate} (results are wrong, timing only)")
 NW = 4096
 stamps = torch.zeros(NW * 8, dtype=torch.int64, device=dev)
 tune = dict(fx3_gen_img=2)
@@ -51,6 +53,17 @@ with F.tuning(**tune):
     lib.stem_exper_img_waits(wbuf, 0)
     if wbuf[2]:
         print(f"  wavefront cycles in the main loop: {100.0 * wbuf[0] / wbuf[2]:.1f} % waiting for the weight DMA (vmcnt), {100.0 * wbuf[1] / wbuf[2]:.1f} % at the barrier")
+with F.tuning(**tune):                # the launch by HIP events, without the stamps
+    ts = []
+    for _ in range(20):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        F.conv2d_f16x3_gen(xp, wp, b, K, R, R, 1, R // 2, epi=F.GEN_EPI_LRELU, slope=0.01, want_planes=True)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    print(f"{name}: launch by HIP events: median {ts[10]:.1f} us, min {ts[0]:.1f} us")
 s = stamps.view(NW, 8).cpu()
 s = s[s[:, 0] > 0].double() / 100.0          # microseconds
 t0 = float(s[:, 0].min())
