@@ -81,6 +81,9 @@ struct ImgArgs {
 #ifndef STEM_IMG_ZFLIP
 #define STEM_IMG_ZFLIP 0        // experiments: the K splits dealt to the workgroups in reverse order
 #endif
+#ifndef STEM_IMG_LAZY_LAST
+#define STEM_IMG_LAZY_LAST 0    // 1: the last ARRIVING split keeps its tile in LDS instead of writing and re-reading it (see the split-K hand-over).
+#endif                          // Built, bit-identical, and measured SLOWER in the step (round 6, profiles/r06_ab_img_lazy_last.log): off
 #ifdef STEM_EXPERIMENTS
 unsigned long long *g_img_stamps = nullptr;
 int g_img_ablate = 0;
@@ -475,6 +478,18 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
         // those the ticket overtook the data on the first launch after the workspace was (re)allocated -- the last arriver
         // summed the allocation's zeros for a few pieces (tools/debug/repro_fwd.py: 40 of 40 fresh runs; this form and a
         // plain-store + agent-release form: 0 of 40)
+        //
+        // Round 6 (STEM_IMG_LAZY_LAST): the workgroup that ARRIVES last does not write and re-read its own tile.  The counter holds two
+        // numbers: arrivals (low 16 bits: taken right behind the main loop, before anything is written) and written tiles (high 16
+        // bits: added behind the stores' acknowledgement, as the old ticket was).  The last arriver keeps its tile in LDS, waits
+        // until the nsplit - 1 others -- which arrived earlier, i.e. are already writing -- have all signalled "written", and sums
+        // the tiles IN SPLIT ORDER with its own at its place in that order: the same additions on the same values as before (a
+        // store / load round trip is exact), so results do not depend on who arrived last, nor on this switch.  What it saves is
+        // the 128-KB write-through + its acknowledgement on the one workgroup every tile waits for (17 us of a 107-us TPM.4 launch
+        // lie behind the main loop: profiles/r06_img_tail_ablation.log).  MEASURED (alternating in-step passes, same results bit for
+        // bit): 11.46 / 11.54 / 11.52 ms with it against 11.30 / 11.28 / 11.31 without -- the extra agent-scope atomic + barrier
+        // right behind the loop is paid by EVERY workgroup, and inside the step the splits of a tile arrive closer together than
+        // the 8 us a write takes, so the last arriver waits for the others' writes instead of doing its own.  Default off.
         constexpr int SC1 = 16;
         const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(a.ws, 0, (int)((size_t)a.nsplit * Mtot * Npad * 4), 0x00020000);
         const int sstep = Mtot * Npad * 4;
@@ -482,27 +497,60 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
 #pragma unroll
         for (int k = 0; k < ER; ++k) eoff[k] = em[k] >= 0 ? (em[k] * Npad + bn0 + ec4 * 4) * 4 : OOR;
         float *wsp = a.ws + (size_t)zsplit * Mtot * Npad;
+        int *cn = a.cnt + blockIdx.y * gridDim.x + blockIdx.x;
+#if STEM_IMG_LAZY_LAST
+        if (tid == 0) flag[0] = (__hip_atomic_fetch_add(cn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFF) == a.nsplit - 1;
+        __syncthreads();
+        const bool lazy = flag[0] != 0;
+#else
+        const bool lazy = false;
+#endif
+        if (!lazy) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = MOF(PIXL(mi, r));
-                if (m >= 0) {
+                for (int r = 0; r < 16; ++r) {
+                    const int m = MOF(PIXL(mi, r));
+                    if (m >= 0) {
 #pragma unroll
-                    for (int nj = 0; nj < 2; ++nj)
-                        __hip_atomic_store(&wsp[(size_t)m * Npad + bn0 + wn * 64 + nj * 32 + lr], acc[mi][nj][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int nj = 0; nj < 2; ++nj)
+                            __hip_atomic_store(&wsp[(size_t)m * Npad + bn0 + wn * 64 + nj * 32 + lr], acc[mi][nj][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+#if STEM_IMG_LAZY_LAST
+            if (tid == 0) __hip_atomic_fetch_add(cn, 0x10000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // "written"
+            IMG_STAMP(4);
+            return;
+#else
+            if (tid == 0) flag[0] = splitk_last_arriver(cn, a.nsplit);
+            __syncthreads();
+            IMG_STAMP(4);
+            if (!flag[0]) return;
+#endif
+        } else {
+            // own tile -> LDS (the layout of the unsplit path); the others' tiles are complete once "written" has reached nsplit - 1.
+            // They arrived before this workgroup and need nothing from it: the wait cannot deadlock; it is bounded all the same
+            // (~1 s: a launch is over in 100 us) so that a lost workgroup shows up as a wrong result in a test, not as a hung GPU
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pix = PIXL(mi, r);
+#pragma unroll
+                    for (int nj = 0; nj < 2; ++nj) Tt[pix * ITP + wn * 64 + nj * 32 + lr] = acc[mi][nj][r];
+                }
+            if (tid == 0) {
+                long spins = 0;
+                while ((__hip_atomic_load(cn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 16) != a.nsplit - 1 && ++spins < (1L << 22)) __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(cn, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            int *cn = a.cnt + blockIdx.y * gridDim.x + blockIdx.x;
-            flag[0] = splitk_last_arriver(cn, a.nsplit);
+            __syncthreads();
+            IMG_STAMP(4);
         }
-        __syncthreads();
-        IMG_STAMP(4);
-        if (!flag[0]) return;
-        // the last arriver sums the slabs in split order (own slab included: one fixed order whoever arrives last), 8 rows x 4
+        // the owner sums the slabs in split order (own tile included at its place: one fixed order whoever arrives last), 8 rows x 4
         // splits = 32 sc1 loads in flight per thread: the read is latency-bound (cross-XCD, ~1 us per dependent round)
 #pragma unroll
         for (int k = 0; k < ER; ++k) ev[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -514,13 +562,19 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
                 for (int k = 0; k < 8; ++k)
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int so = (sp + u < a.nsplit ? sp + u : 0) * sstep;
-                        tt[k][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, sp + u < a.nsplit ? eoff[kb + k] : OOR, so, SC1));
+                        const bool other = sp + u < a.nsplit && !(lazy && sp + u == zsplit);
+                        const int so = (other ? sp + u : 0) * sstep;
+                        tt[k][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, other ? eoff[kb + k] : OOR, so, SC1));
                     }
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) ev[kb + k] += tt[k][u];          // beyond nsplit: zeros (out-of-range loads)
+                    for (int u = 0; u < 4; ++u) {
+                        if (lazy && sp + u == zsplit)      // this workgroup's own tile, from LDS, at its place in the order
+                            ev[kb + k] += *reinterpret_cast<const f32x4 *>(&Tt[(er0 + 16 * (kb + k)) * ITP + ec4 * 4]);
+                        else
+                            ev[kb + k] += tt[k][u];          // beyond nsplit: zeros (out-of-range loads)
+                    }
             }
         }
         IMG_STAMP(5);
