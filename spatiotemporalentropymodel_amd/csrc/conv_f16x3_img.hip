@@ -75,7 +75,9 @@ struct ImgArgs {
     int xpix;
     int tiles_x, tiles_y;
     unsigned long long *stamps;     // phase stamps of every workgroup (libstem_hip_exper.so only; null otherwise)
-    int ablate;                     // libstem_hip_exper.so only (WRONG results: timing ablations): 1 = every second chunk's barrier left out, 2 = return after the main loop
+    int ny;                         // N tiles of the launch (cdiv(N, IBN))
+    int ablate;                     // libstem_hip_exper.so only (WRONG results: timing ablations): 1 = every second chunk's barrier left out, 2 = return after the
+                                    // main loop, 3 = one-dimensional launch with the splits of a tile on one XCD and partial tiles without sc1
 };
 
 #ifndef STEM_IMG_ZFLIP
@@ -130,15 +132,28 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
     int *flag = reinterpret_cast<int *>(smem + ILDS_MAIN + 96);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (tile, N tile, K split) of this workgroup: the launch's three grid dimensions
+    int BX = blockIdx.x, BY = blockIdx.y, BZ = blockIdx.z, GX = gridDim.x, GY = gridDim.y, GZ = gridDim.z;
+#ifdef STEM_EXPERIMENTS
+    if (a.ablate == 3) {
+        // ablation (round 6, timing only): a one-dimensional launch in which the splits of one tile run on ONE XCD (workgroup i is
+        // dispatched to XCD i mod 8): linear id L -> XCD L & 7, slot L >> 3 -> tile (slot / nsplit) * 8 + XCD, split slot % nsplit;
+        // the partial tiles are then stored and read WITHOUT sc1 (they stay in that XCD's L2).  Results are not guaranteed.
+        const int L = blockIdx.x, slot = L >> 3, T = (slot / a.nsplit) * 8 + (L & 7);
+        GX = a.B * a.tiles_x * a.tiles_y; GY = a.ny; GZ = a.nsplit;
+        if (T >= GX * GY) return;
+        BX = T % GX; BY = T / GX; BZ = slot % a.nsplit;
+    }
+#endif
     IMG_STAMP(0);
     const int tpi = a.tiles_x * a.tiles_y;
-    const int bimg = blockIdx.x / tpi, trem = blockIdx.x - bimg * tpi, tyi = trem / a.tiles_x, txi = trem - tyi * a.tiles_x;
+    const int bimg = BX / tpi, trem = BX - bimg * tpi, tyi = trem / a.tiles_x, txi = trem - tyi * a.tiles_x;
     const int y0 = tyi * TS, x0 = txi * TS;
-    const int bn0 = blockIdx.y * IBN, zsplit = STEM_IMG_ZFLIP ? gridDim.z - 1 - blockIdx.z : blockIdx.z;
+    const int bn0 = BY * IBN, zsplit = STEM_IMG_ZFLIP ? GZ - 1 - BZ : BZ;
     const int nslab = a.C / KC, T = a.ntaps, nchunks = T * nslab;
     const int q_begin = zsplit * a.cps;
     const int q_end = q_begin + a.cps < nchunks ? q_begin + a.cps : nchunks;
-    const int wbase = blockIdx.y * nchunks;
+    const int wbase = BY * nchunks;
     const int Mtot = a.B * a.H * a.W;
 
     // ---- halo staging: piece idx = tid + i * 512 -> (halo pixel h, 16-byte piece p), both planes -----------------------------
@@ -275,7 +290,7 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
         }
         const int oe = q_exp((float)(a.C * a.ntaps) * xmax * wmax + bm);
         oscale = q_pow2(oe);
-        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.yq[1] = q_pow2(-oe);
+        if (BX == 0 && BY == 0 && tid == 0) a.yq[1] = q_pow2(-oe);
     }
     if (q_begin < q_end) {
         storeA(0);
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
         }
 #ifdef STEM_EXPERIMENTS
         if (a.stamps && lane == 0) {        // per wavefront: shader cycles in the loop, waiting for the weight DMA, waiting at the barrier
-            unsigned long long *w = a.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+            unsigned long long *w = a.stamps + ((size_t)(BZ * GY + BY) * GX + BX) * 8;
             if (wave == 0) {                  // where the workgroup ran: XCC_ID [63:60], HW_ID (se / sh / cu) [59:44], shader cycles in the loop [43:0]
                 unsigned hw, xcc;
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -463,7 +478,7 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
         return (oy < a.H && ox < a.W) ? (bimg * a.H + oy) * a.W + ox : -1;
     };
     float *Tt = reinterpret_cast<float *>(smem);                   // [256][ITP]
-    const int Npad = gridDim.y * IBN;
+    const int Npad = GY * IBN;
     // every pass below gives a thread the same pieces: column group ec4 = tid & 31 (4 floats), tile rows (tid >> 5) + 16 k
     constexpr int ER = TPX / (NTHR / 32);                          // 16 pieces per thread
     const int ec4 = tid & 31, er0 = tid >> 5;
@@ -497,7 +512,7 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
 #pragma unroll
         for (int k = 0; k < ER; ++k) eoff[k] = em[k] >= 0 ? (em[k] * Npad + bn0 + ec4 * 4) * 4 : OOR;
         float *wsp = a.ws + (size_t)zsplit * Mtot * Npad;
-        int *cn = a.cnt + blockIdx.y * gridDim.x + blockIdx.x;
+        int *cn = a.cnt + BY * GX + BX;
 #if STEM_IMG_LAZY_LAST
         if (tid == 0) flag[0] = (__hip_atomic_fetch_add(cn, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFF) == a.nsplit - 1;
         __syncthreads();
@@ -514,7 +529,15 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
                     if (m >= 0) {
 #pragma unroll
                         for (int nj = 0; nj < 2; ++nj)
+                        {
+#ifdef STEM_EXPERIMENTS
+                            if (a.ablate == 3) {
+                                wsp[(size_t)m * Npad + bn0 + wn * 64 + nj * 32 + lr] = acc[mi][nj][r];
+                                continue;
+                            }
+#endif
                             __hip_atomic_store(&wsp[(size_t)m * Npad + bn0 + wn * 64 + nj * 32 + lr], acc[mi][nj][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
                     }
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -564,6 +587,12 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
                     for (int u = 0; u < 4; ++u) {
                         const bool other = sp + u < a.nsplit && !(lazy && sp + u == zsplit);
                         const int so = (other ? sp + u : 0) * sstep;
+#ifdef STEM_EXPERIMENTS
+                        if (a.ablate == 3) {
+                            tt[k][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, other ? eoff[kb + k] : OOR, so, 1));      // sc0: past the L1, from this XCD's L2
+                            continue;
+                        }
+#endif
                         tt[k][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, other ? eoff[kb + k] : OOR, so, SC1));
                     }
 #pragma unroll
@@ -618,9 +647,9 @@ __global__ __launch_bounds__(NTHR) void conv_f16x3_img_kernel(const ImgArgs a)
     if (a.yq) {
         omax = block_max512(omax, red);
         if (tid == 0) {
-            a.yq[QREC_HDR + blockIdx.y * gridDim.x + blockIdx.x] = omax;
-            if (blockIdx.x == 0 && blockIdx.y == 0) {
-                q_header(a.yq, gridDim.x * gridDim.y);
+            a.yq[QREC_HDR + BY * GX + BX] = omax;
+            if (BX == 0 && BY == 0) {
+                q_header(a.yq, GX * GY);
                 if (!a.yp) a.yq[1] = 1.f;
             }
         }
@@ -745,7 +774,12 @@ int stem_fx3_img_launch(const void *xp, const float *xq, int xpix, int xbytes, c
         (void)hipFuncSetAttribute((const void *)conv_f16x3_img_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, ILDS);
         attr_done = true;
     }
-    const dim3 grid(B * a.tiles_x * a.tiles_y, cdiv(N, IBN), a.nsplit);
+    a.ny = cdiv(N, IBN);
+    dim3 grid(B * a.tiles_x * a.tiles_y, cdiv(N, IBN), a.nsplit);
+#ifdef STEM_EXPERIMENTS
+    if (a.ablate == 3 && a.nsplit > 1) grid = dim3(cdiv(B * a.tiles_x * a.tiles_y * a.ny, 8) * 8 * a.nsplit);
+    else if (a.ablate == 3) a.ablate = 0;
+#endif
     hipStream_t st = (hipStream_t)stream;
     if (KS == 1)
         hipLaunchKernelGGL((conv_f16x3_img_kernel<1>), grid, dim3(NTHR), ILDS, st, a);

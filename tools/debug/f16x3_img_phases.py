@@ -3,8 +3,10 @@
 launch.  Needs the experiments build: `make -C spatiotemporalentropymodel_amd/csrc experiments`, then
     STEM_HIP_LIBRARY=spatiotemporalentropymodel_amd/libstem_hip_exper.so python3 tools/debug/f16x3_img_phases.py [layer] [split] [ablate]
 ablate = 1: every second chunk's barrier left out (wrong results; the upper bound of what one barrier per two chunks could buy);
-ablate = 2: the workgroups return right after the main loop (what everything behind it costs at most); the launch's duration by HIP
-events is printed in every mode.
+ablate = 2: the workgroups return right after the main loop (what everything behind it costs at most);
+ablate = 3: one-dimensional launch with the splits of a tile on ONE XCD, partial tiles stored / read without sc1 (they stay in the
+XCD's L2; results not guaranteed); the launch's duration by HIP events and the difference from the normal mode's result are printed
+in every mode.
 """
 import ctypes as C
 import os
@@ -28,6 +30,8 @@ xp, wp = F.F16Planes.split(x), F.pack_weight_f16x2_gen(w)
 lib = _lib.hip()
 lib.stem_exper_img_stamps.argtypes = [C.c_void_p]
 lib.stem_exper_img_stamps.restype = None
+with F.tuning(**dict(fx3_gen_img=2, **({"fx3_split": split} if split else {}))):
+    ref_out = F.conv2d_f16x3_gen(xp, wp, b, K, R, R, 1, R // 2, epi=F.GEN_EPI_LRELU, slope=0.01, want_planes=True)[0].clone()
 if ablate:
     lib.stem_exper_img_ablate.argtypes = [C.c_int]
     lib.stem_exper_img_ablate.restype = None
@@ -64,6 +68,8 @@ with F.tuning(**tune):                # the launch by HIP events, without the st
         ts.append(e0.elapsed_time(e1) * 1e3)
     ts.sort()
     print(f"{name}: launch by HIP events: median {ts[10]:.1f} us, min {ts[0]:.1f} us")
+    out = F.conv2d_f16x3_gen(xp, wp, b, K, R, R, 1, R // 2, epi=F.GEN_EPI_LRELU, slope=0.01, want_planes=True)[0]
+    print(f"{name}: max |this mode - normal mode| / max = {float((out - ref_out).abs().max() / ref_out.abs().max()):.2e}")
 s = stamps.view(NW, 8).cpu()
 s = s[s[:, 0] > 0].double() / 100.0          # microseconds
 t0 = float(s[:, 0].min())
